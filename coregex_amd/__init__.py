@@ -1,0 +1,205 @@
+"""coregex_amd — MI355X-native bulk FindAll for coregex (host-side mirror of the reference API).
+
+Python stands where the reference's Go API would (no Go toolchain in this image): names and argument
+meaning follow ``coregex.Regexp`` on the FindAll path (regex.go:695-1450) and ``meta.Engine``
+(meta/findall.go:155,297,390).  All matching happens in ``libcoregex_hip.so`` on the GPU.
+
+    rx = coregex_amd.compile(r"\\d+\\.\\d+\\.\\d+\\.\\d+")
+    rx.strategy                    # 'UseDigitPrefilter'  (meta/strategy.go)
+    rx.find_all_index(data, -1)    # (M, 2) int64, == Regexp.FindAllIndex
+    rx.count(data, -1)             # == meta.Engine.Count
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Timing  # noqa: F401
+
+STRATEGY_NAMES = [
+    "UseNFA", "UseDFA", "UseBoth", "UseReverseAnchored", "UseReverseSuffix", "UseOnePass",
+    "UseReverseInner", "UseBoundedBacktracker", "UseTeddy", "UseReverseSuffixSet",
+    "UseCharClassSearcher", "UseCompositeSearcher", "UseBranchDispatch", "UseDigitPrefilter",
+    "UseAhoCorasick", "UseAnchoredLiteral", "UseMultilineReverseSuffix",
+]
+
+
+class CoregexError(Exception):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class UnsupportedPattern(CoregexError):
+    """CXG_E_UNSUPPORTED: the caller keeps its CPU loop (mirrors the reference's degrade-don't-fail)."""
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = _lib.lib().cxg_last_error().decode(errors="replace")
+    if rc == _lib.CXG_E_UNSUPPORTED:
+        raise UnsupportedPattern(rc, msg)
+    raise CoregexError(rc, msg)
+
+
+def device_count() -> int:
+    return _lib.lib().cxg_device_count()
+
+
+def set_device(i: int):
+    _check(_lib.lib().cxg_set_device(i))
+
+
+def _host_view(hay):
+    if isinstance(hay, np.ndarray):
+        a = np.ascontiguousarray(hay, dtype=np.uint8)
+    else:
+        b = bytes(hay)
+        a = np.frombuffer(b, dtype=np.uint8) if b else np.zeros(0, dtype=np.uint8)
+    return a
+
+
+class Regex:
+    """Mirror of coregex.Regexp on the FindAll path; every search runs on the GPU."""
+
+    def __init__(self, handle, pattern: bytes):
+        self._h = handle
+        self.pattern = pattern
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib._lib is not None:
+            _lib._lib.cxg_program_destroy(self._h)
+            self._h = None
+
+    # --- introspection (meta.Engine.Strategy(), NumSubexp) ---
+    @property
+    def strategy(self) -> str:
+        return STRATEGY_NAMES[_lib.lib().cxg_program_strategy(self._h)]
+
+    @property
+    def num_groups(self) -> int:
+        return _lib.lib().cxg_program_num_groups(self._h)
+
+    @property
+    def nfa_states(self) -> int:
+        return _lib.lib().cxg_program_nfa_states(self._h)
+
+    @property
+    def dfa_states(self) -> int:
+        return _lib.lib().cxg_program_dfa_states(self._h)
+
+    @property
+    def supported(self) -> bool:
+        return bool(_lib.lib().cxg_program_supported(self._h))
+
+    @property
+    def why_unsupported(self) -> str:
+        if self.supported:
+            return ""
+        return _lib.lib().cxg_last_error().decode(errors="replace")
+
+    def blob(self) -> bytes:
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(_lib.lib().cxg_program_blob(self._h, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value)
+
+    def nfa(self):
+        """Host copy of the NFA as (states ndarray-of-tuples, trans, start_anchored, start_unanchored, captures)."""
+        v = _lib.Nfa()
+        _check(_lib.lib().cxg_program_nfa(self._h, C.byref(v)))
+        return v
+
+    # --- FindAll family over host bytes (what the cgo shim calls) ---
+    def find_all_index(self, hay, n: int = -1) -> np.ndarray:
+        """Regexp.FindAllIndex(b, n) as an (M, 2) int64 array; n == 0 -> empty (regex.go:696)."""
+        if n == 0:
+            return np.zeros((0, 2), dtype=np.int64)
+        return self._rows(_lib.lib().cxg_find_all, hay, n, 2)
+
+    def find_all_submatch_index(self, hay, n: int = -1) -> np.ndarray:
+        w = 2 * self.num_groups
+        if n == 0:
+            return np.zeros((0, w), dtype=np.int64)
+        return self._rows(_lib.lib().cxg_find_all_submatch, hay, n, w)
+
+    def count(self, hay, n: int = -1) -> int:
+        a = _host_view(hay)
+        out = C.c_uint64(0)
+        _check(_lib.lib().cxg_count(self._h, a.ctypes.data, a.size, n, C.byref(out)))
+        return int(out.value)
+
+    def _rows(self, fn, hay, n, width):
+        a = _host_view(hay)
+        cap = max(1024, a.size // 64 + 16)
+        while True:
+            out = np.empty((cap, width), dtype=np.int64)
+            got = C.c_uint64(0)
+            rc = fn(self._h, a.ctypes.data, a.size, n, out.ctypes.data, cap, C.byref(got))
+            if rc == _lib.CXG_E_CAPACITY:
+                cap = int(got.value)
+                continue
+            _check(rc)
+            return out[: got.value].copy()
+
+    # --- device-resident haystacks (bench, shards) ---
+    def find_all_device(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1,
+                        stream: int = 0, timing: Timing | None = None) -> int:
+        got = C.c_uint64(0)
+        rc = _lib.lib().cxg_find_all_device(self._h, d_hay, length, base, n, d_out or None, cap, C.byref(got),
+                                            stream or None, C.byref(timing) if timing is not None else None)
+        _check(rc)
+        return int(got.value)
+
+
+def compile(pattern) -> Regex:  # noqa: A001  (mirrors coregex.Compile)
+    p = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
+    h = C.c_void_p()
+    _check(_lib.lib().cxg_compile(p, len(p), C.byref(h)))
+    return Regex(h, p)
+
+
+def must_compile(pattern) -> Regex:
+    return compile(pattern)
+
+
+class DeviceBuffer:
+    """cxg_buffer: a haystack resident in HBM."""
+
+    def __init__(self, length: int):
+        h = C.c_void_p()
+        _check(_lib.lib().cxg_buffer_alloc(length, C.byref(h)))
+        self._h = h
+        self.length = length
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib._lib is not None:
+            _lib._lib.cxg_buffer_free(self._h)
+            self._h = None
+
+    @property
+    def ptr(self) -> int:
+        return _lib.lib().cxg_buffer_device_ptr(self._h)
+
+    def upload(self, data, off: int = 0):
+        a = _host_view(data)
+        _check(_lib.lib().cxg_buffer_upload(self._h, off, a.ctypes.data, a.size))
+
+    def download(self, off: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint8)
+        _check(_lib.lib().cxg_buffer_download(self._h, off, out.ctypes.data, n))
+        return out
+
+    def fill_synth(self, config: int, seed: int, first_page: int = 0):
+        _check(_lib.lib().cxg_buffer_fill_synth(self._h, config, seed, first_page))
+
+
+def synth_pages(config: int, seed: int, first_page: int, npages: int) -> np.ndarray:
+    """CPU twin of the device corpus generator (synthlog-v1)."""
+    out = np.empty(npages * 4096, dtype=np.uint8)
+    L = _lib.lib()
+    for i in range(npages):
+        L.cxg_synth_page_host(config, seed, first_page + i, out.ctypes.data + i * 4096)
+    return out

@@ -1,0 +1,435 @@
+// capi.hip — the extern "C" surface of libcoregex_hip.so (include/coregex_hip.h).
+// Host glue only: program construction (host/), device copies, per-thread stream + scratch
+// (the SearchState analogue, meta/search_state.go:23-62), launches (device/).  There is no CPU
+// search path in this library: without a gfx950 device every search entry returns CXG_E_NO_GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/coregex_hip.h"
+#include "device/scan_dfa.h"
+#include "device/synth.hpp"
+#include "device/walk.hpp"
+#include "host/frontend.h"
+#include "host/program.h"
+
+namespace cxgdev {
+hipError_t launch_scan_dfa(uint32_t kind, const ScanArgs& a, uint32_t fwd_states, uint32_t rev_states, hipStream_t stream);
+size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
+hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
+hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
+}  // namespace cxgdev
+
+namespace {
+
+thread_local std::string t_err;
+thread_local int t_device = 0;
+
+int fail(int code, const std::string& msg) { t_err = msg; return code; }
+int failHip(hipError_t e, const char* what) {
+  t_err = std::string(what) + ": " + hipGetErrorString(e);
+  return CXG_E_DEVICE;
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) return failHip(_e, #expr);    \
+  } while (0)
+
+int deviceCount() {
+  static int n = -1;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (n >= 0) return n;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  int ok = 0;
+  for (int d = 0; d < c; d++) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  n = (ok == c) ? c : 0;   // only an all-gfx950 box is accepted
+  return n;
+}
+
+// Per-thread scratch for one in-flight call per device.
+struct Scratch {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) -> 32 B
+  uint64_t* status = nullptr;
+  uint64_t statusCap = 0;
+  uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
+  uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
+  int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
+};
+thread_local Scratch t_scratch[16];
+
+int getScratch(Scratch** out) {
+  if (deviceCount() <= 0) return fail(CXG_E_NO_GPU, "no gfx950 device visible (this library has no CPU search path)");
+  if (t_device < 0 || t_device >= deviceCount() || t_device >= 16) return fail(CXG_E_INVALID, "bad device index");
+  HIP_TRY(hipSetDevice(t_device));
+  Scratch& s = t_scratch[t_device];
+  if (s.device < 0) {
+    HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (auto& e : s.ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hostCtl), 64, hipHostMallocDefault));
+    s.device = t_device;
+  }
+  *out = &s;
+  return CXG_OK;
+}
+
+int ensureStatus(Scratch& s, uint64_t ntiles) {
+  if (ntiles <= s.statusCap) return CXG_OK;
+  if (s.status) HIP_TRY(hipFree(s.status));
+  s.status = nullptr; s.statusCap = 0;
+  uint64_t cap = ntiles + ntiles / 4 + 1024;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.status), cap * sizeof(uint64_t)));
+  s.statusCap = cap;
+  return CXG_OK;
+}
+
+int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  cxg_program* mp = const_cast<cxg_program*>(p);   // device copies are a cache, the program stays logically immutable
+  if (!mp->dev[device]) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, p->blob.size()));
+    HIP_TRY(hipMemcpy(d, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
+    mp->dev[device] = d;
+  }
+  *out = static_cast<const uint8_t*>(mp->dev[device]);
+  return CXG_OK;
+}
+
+uint64_t tilesFor(uint32_t kind, uint64_t len);
+
+int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
+               uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+  if (!p) return fail(CXG_E_INVALID, "null program");
+  if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot.empty() ? "unsupported program" : p->whyNot);
+  if (n_out) *n_out = 0;
+  if (timing) std::memset(timing, 0, sizeof *timing);
+  if (limit == 0) return CXG_OK;  // Count(n == 0) == 0, meta/findall.go:298
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  if (len == 0) return CXG_OK;    // non-nullable patterns never match the empty haystack
+  if (reinterpret_cast<uintptr_t>(d_hay) & 15u) return fail(CXG_E_INVALID, "device haystack must be 16-byte aligned");
+  if (d_out && (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail(CXG_E_INVALID, "device output must be 16-byte aligned");
+  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data());
+  hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
+  const uint8_t* d_blob;
+  if (int rc = deviceBlob(p, t_device, &d_blob)) return rc;
+  cxgdev::ScanArgs a;
+  a.hay = static_cast<const uint8_t*>(d_hay);
+  a.len = len;
+  a.base = base;
+  a.blob = d_blob;
+  a.out = static_cast<int64_t*>(d_out);
+  a.cap = d_out ? cap : 0;
+  if (limit > 0 && static_cast<uint64_t>(limit) < a.cap) a.cap = static_cast<uint64_t>(limit);
+  a.ntiles = tilesFor(h->kind, len);
+  if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
+  if (int rc = ensureStatus(s, a.ntiles)) return rc;
+  a.status = s.status;
+  a.ticket = reinterpret_cast<uint32_t*>(s.ctl);
+  a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
+  a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
+  HIP_TRY(hipEventRecord(s.ev[0], stream));
+  HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
+  HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
+  HIP_TRY(hipEventRecord(s.ev[1], stream));
+  hipError_t le;
+  switch (h->kind) {
+    case cxgdev::kKindDigit: case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
+    case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;
+    case cxgdev::kKindTeddy: le = cxgdev::launch_scan_teddy(a, stream); break;
+    default: return fail(CXG_E_INTERNAL, "unknown program kind");
+  }
+  if (le != hipSuccess) return failHip(le, "kernel launch");
+  HIP_TRY(hipEventRecord(s.ev[2], stream));
+  HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  const uint64_t total = s.hostCtl[1];
+  const uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
+  if (timing) {
+    float k = 0, t = 0;
+    (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
+    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
+    timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = 1;
+    timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
+  }
+  if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
+  uint64_t n = total;
+  if (limit > 0 && n > static_cast<uint64_t>(limit)) n = static_cast<uint64_t>(limit);
+  if (n_out) *n_out = n;
+  if (d_out && n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
+  (void)row_width;
+  return CXG_OK;
+}
+
+uint64_t tilesFor(uint32_t kind, uint64_t len) {
+  (void)kind;
+  return (len + cxgdev::kTile - 1) / cxgdev::kTile;
+}
+
+__global__ void k_fill_synth(uint8_t* dst, uint64_t npages, uint32_t config, uint64_t seed, uint64_t first_page) {
+  const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+  if (i >= npages) return;
+  cxgsynth::page(config, seed, first_page + i, dst + i * cxgsynth::kPage);
+}
+
+int hostScan(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
+             uint64_t* n_out, int width) {
+  if (!p) return fail(CXG_E_INVALID, "null program");
+  if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot.empty() ? "unsupported program" : p->whyNot);
+  if (n_out) *n_out = 0;
+  if (limit == 0 || len == 0) return CXG_OK;
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  if (len + 64 > s.hayCap) {
+    if (s.hay) HIP_TRY(hipFree(s.hay));
+    s.hay = nullptr; s.hayCap = 0;
+    uint64_t c = len + len / 8 + 4096;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.hay), c));
+    s.hayCap = c;
+  }
+  HIP_TRY(hipMemcpyAsync(s.hay, hay, len, hipMemcpyHostToDevice, s.stream));
+  uint64_t want = rows ? cap : 0;
+  if (limit > 0 && static_cast<uint64_t>(limit) < want) want = static_cast<uint64_t>(limit);
+  if (want * width * 8 > (64ull << 20)) {   // large cap: count first, then size the staging exactly
+    uint64_t n = 0;
+    if (int rc = scanDevice(p, s.hay, len, 0, limit, nullptr, 0, &n, nullptr, nullptr, width)) return rc;
+    if (n > cap) { if (n_out) *n_out = n; return fail(CXG_E_CAPACITY, "output capacity too small"); }
+    want = n;
+  }
+  if (want * width > s.outCap) {
+    if (s.out) HIP_TRY(hipFree(s.out));
+    s.out = nullptr; s.outCap = 0;
+    uint64_t c = want * width + 1024;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.out), c * sizeof(int64_t)));
+    s.outCap = c;
+  }
+  uint64_t n = 0;
+  int rc = scanDevice(p, s.hay, len, 0, limit, rows ? s.out : nullptr, want, &n, nullptr, nullptr, width);
+  if (n_out) *n_out = n;
+  if (rc) return rc;
+  if (rows && n) HIP_TRY(hipMemcpy(rows, s.out, n * width * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return CXG_OK;
+}
+
+}  // namespace
+
+struct cxg_buffer {
+  int device = 0;
+  uint8_t* d = nullptr;
+  uint64_t len = 0;
+};
+
+extern "C" {
+
+const char* cxg_last_error(void) { return t_err.c_str(); }
+const char* cxg_version(void) { return "coregex_hip 0.1 (gfx950)"; }
+int cxg_device_count(void) { return deviceCount(); }
+int cxg_set_device(int device) {
+  if (device < 0 || device >= 16) return fail(CXG_E_INVALID, "bad device index");
+  t_device = device;
+  return CXG_OK;
+}
+
+const char* cxg_strategy_name(int s) {
+  static const char* n[] = {"UseNFA", "UseDFA", "UseBoth", "UseReverseAnchored", "UseReverseSuffix", "UseOnePass",
+                            "UseReverseInner", "UseBoundedBacktracker", "UseTeddy", "UseReverseSuffixSet",
+                            "UseCharClassSearcher", "UseCompositeSearcher", "UseBranchDispatch", "UseDigitPrefilter",
+                            "UseAhoCorasick", "UseAnchoredLiteral", "UseMultilineReverseSuffix"};
+  return (s >= 0 && s < 17) ? n[s] : "?";
+}
+
+int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
+  if (!pattern || !out) return fail(CXG_E_INVALID, "null argument");
+  *out = nullptr;
+  try {
+    cxg::Ast ast = cxg::parsePattern(std::string(pattern, len));
+    auto* p = new cxg_program();
+    try {
+      p->nfa = cxg::buildNfa(ast);
+    } catch (const cxg::FrontendError& e) {
+      if (e.code != CXG_E_UNSUPPORTED) { delete p; return fail(e.code, e.msg); }
+      p->supported = false; p->whyNot = e.msg; p->strategy = CXG_USE_NFA; p->ngroups = ast.ncap + 1;
+      *out = p;
+      return CXG_OK;
+    }
+    cxg::Plan plan = cxg::selectStrategy(ast, p->nfa);
+    p->ngroups = static_cast<int>(p->nfa.captureCount);
+    p->nfaStates = static_cast<int>(p->nfa.states.size());
+    cxg_nfa view = p->nfa.view();
+    switch (plan.strategy) {
+      case CXG_USE_CHARCLASS_SEARCHER: cxg::buildProgramFromCharClass(p, plan.membership, 1); break;
+      case CXG_USE_TEDDY: {
+        std::vector<std::vector<uint8_t>> lits;
+        for (auto& l : plan.prefixes) lits.push_back(l.bytes);
+        cxg::buildProgramFromLiterals(p, lits);
+        break;
+      }
+      default: cxg::buildProgramFromNfa(p, view, plan.strategy, plan.flags); break;
+    }
+    p->strategy = plan.strategy;
+    p->flags = plan.flags;
+    p->ngroups = static_cast<int>(p->nfa.captureCount);
+    p->nfaStates = static_cast<int>(p->nfa.states.size());
+    if (!plan.confident && p->supported) {
+      p->supported = false;
+      p->whyNot = "the reference may route this pattern to a reverse-search strategy outside the device subset";
+    }
+    if (p->ngroups > 1 && p->supported) {
+      // FindAllIndex ignores groups; FindAllSubmatchIndex needs the capture pass (not built yet)
+    }
+    *out = p;
+    return CXG_OK;
+  } catch (const cxg::FrontendError& e) {
+    return fail(e.code, e.msg);
+  } catch (const std::exception& e) {
+    return fail(CXG_E_INTERNAL, e.what());
+  }
+}
+
+int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_program** out) {
+  if (!nfa || !out || !nfa->states) return fail(CXG_E_INVALID, "null argument");
+  auto* p = new cxg_program();
+  cxg::buildProgramFromNfa(p, *nfa, strategy, flags);
+  *out = p;
+  return CXG_OK;
+}
+
+int cxg_program_from_literals(const uint8_t* const* lits, const uint32_t* lens, uint32_t n, cxg_program** out) {
+  if (!lits || !lens || !out) return fail(CXG_E_INVALID, "null argument");
+  std::vector<std::vector<uint8_t>> v;
+  for (uint32_t i = 0; i < n; i++) v.emplace_back(lits[i], lits[i] + lens[i]);
+  auto* p = new cxg_program();
+  cxg::buildProgramFromLiterals(p, v);
+  *out = p;
+  return CXG_OK;
+}
+
+int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match, cxg_program** out) {
+  if (!membership || !out) return fail(CXG_E_INVALID, "null argument");
+  auto* p = new cxg_program();
+  cxg::buildProgramFromCharClass(p, membership, min_match);
+  *out = p;
+  return CXG_OK;
+}
+
+void cxg_program_destroy(cxg_program* p) {
+  if (!p) return;
+  for (int d = 0; d < 16; d++)
+    if (p->dev[d]) { (void)hipSetDevice(d); (void)hipFree(p->dev[d]); }
+  delete p;
+}
+
+int cxg_program_strategy(const cxg_program* p) { return p ? p->strategy : -1; }
+int cxg_program_num_groups(const cxg_program* p) { return p ? p->ngroups : 0; }
+int cxg_program_nfa_states(const cxg_program* p) { return p ? p->nfaStates : -1; }
+int cxg_program_dfa_states(const cxg_program* p) { return p ? static_cast<int>(p->fwd.nstates) : 0; }
+int cxg_program_supported(const cxg_program* p) {
+  if (p && !p->supported) t_err = p->whyNot;
+  return p && p->supported ? 1 : 0;
+}
+int cxg_program_blob(const cxg_program* p, const void** data, size_t* len) {
+  if (!p || !data || !len) return fail(CXG_E_INVALID, "null argument");
+  if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot);
+  *data = p->blob.data();
+  *len = p->blob.size();
+  return CXG_OK;
+}
+int cxg_program_nfa(const cxg_program* p, cxg_nfa* out) {
+  if (!p || !out) return fail(CXG_E_INVALID, "null argument");
+  if (p->nfa.states.empty()) return fail(CXG_E_INVALID, "program was not built by cxg_compile");
+  *out = p->nfa.view();
+  return CXG_OK;
+}
+
+int cxg_find_all(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* spans, uint64_t cap,
+                 uint64_t* n_out) {
+  return hostScan(p, hay, len, limit, spans, cap, n_out, 2);
+}
+int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, uint64_t* n_out) {
+  return hostScan(p, hay, len, limit, nullptr, 0, n_out, 2);
+}
+int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* slots,
+                          uint64_t cap, uint64_t* n_out) {
+  if (p && p->ngroups == 1) return hostScan(p, hay, len, limit, slots, cap, n_out, 2);
+  (void)hay; (void)len; (void)limit; (void)slots; (void)cap; (void)n_out;
+  return fail(CXG_E_UNSUPPORTED, "capture groups: device capture pass not built yet");
+}
+
+int cxg_buffer_alloc(uint64_t len, cxg_buffer** out) {
+  if (!out) return fail(CXG_E_INVALID, "null argument");
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  auto* b = new cxg_buffer();
+  b->device = t_device;
+  b->len = len;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&b->d), len + 4096);
+  if (e != hipSuccess) { delete b; return failHip(e, "hipMalloc"); }
+  *out = b;
+  return CXG_OK;
+}
+void cxg_buffer_free(cxg_buffer* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  (void)hipFree(b->d);
+  delete b;
+}
+int cxg_buffer_upload(cxg_buffer* b, uint64_t off, const uint8_t* src, uint64_t len) {
+  if (!b || off + len > b->len) return fail(CXG_E_INVALID, "bad range");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpy(b->d + off, src, len, hipMemcpyHostToDevice));
+  return CXG_OK;
+}
+int cxg_buffer_download(const cxg_buffer* b, uint64_t off, uint8_t* dst, uint64_t len) {
+  if (!b || off + len > b->len) return fail(CXG_E_INVALID, "bad range");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpy(dst, b->d + off, len, hipMemcpyDeviceToHost));
+  return CXG_OK;
+}
+uint64_t cxg_buffer_len(const cxg_buffer* b) { return b ? b->len : 0; }
+void* cxg_buffer_device_ptr(const cxg_buffer* b) { return b ? b->d : nullptr; }
+
+int cxg_buffer_fill_synth(cxg_buffer* b, uint32_t config, uint64_t seed, uint64_t first_page) {
+  if (!b || b->len % cxgsynth::kPage) return fail(CXG_E_INVALID, "buffer length must be a multiple of 4096");
+  HIP_TRY(hipSetDevice(b->device));
+  const uint64_t npages = b->len / cxgsynth::kPage;
+  if (npages == 0) return CXG_OK;
+  const unsigned block = 64;
+  const unsigned grid = static_cast<unsigned>((npages + block - 1) / block);
+  hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, b->d, npages, config, seed, first_page);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return CXG_OK;
+}
+int cxg_synth_page_host(uint32_t config, uint64_t seed, uint64_t page, uint8_t out[4096]) {
+  cxgsynth::page(config, seed, page, out);
+  return CXG_OK;
+}
+
+int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
+                        uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
+  return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
+}
+int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
+                                 void* d_out, uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
+  if (p && p->ngroups == 1) return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
+  return fail(CXG_E_UNSUPPORTED, "capture groups: device capture pass not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,29 @@
+// Launch interface of the DFA scan kernels (scan_dfa.hip); shared with capi.hip and tests/emu.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cxgdev {
+
+constexpr int kThreads = 256;                 // 4 waves of 64
+constexpr int kChunk = 64;                    // bytes owned per lane
+constexpr int kTile = kThreads * kChunk;      // 16 KiB per workgroup
+constexpr int kHaloChunks = 4;
+constexpr int kHalo = kHaloChunks * kChunk;   // 256 B staged past the tile for lanes that overrun
+constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
+
+struct ScanArgs {
+  const uint8_t* hay;   // device, 16-byte aligned
+  uint64_t len;
+  int64_t base;         // added to every reported offset (shard origin)
+  const uint8_t* blob;  // device copy of the program image (walk.hpp BlobHeader)
+  int64_t* out;         // [cap][2] or nullptr to count only
+  uint64_t cap;
+  uint64_t* status;     // [ntiles] look-back words, zeroed before launch
+  uint32_t* ticket;     // zeroed before launch
+  uint64_t* total;      // match count (written by the last tile)
+  uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog
+  uint64_t ntiles;
+};
+
+}  // namespace cxgdev

@@ -1,0 +1,179 @@
+// Per-lane FindAll walks — the sequential algorithms of the reference, executed by one GPU lane
+// over the sync-delimited segments that START inside its byte chunk [c0, c1).
+//
+//   lane_digit  = meta.findAllIndicesLoop (meta/findall.go:176-283) over
+//                 findIndicesDigitPrefilterAtWithState (meta/find_indices.go:1050-1088):
+//                 digit scan (simd/memchr_digit_amd64.s:26) -> anchored table walk
+//                 (dfa/lazy/lazy.go:219-324) -> digit-run skip (:1079-1084).
+//   lane_bidir  = the useDFADirect loop (meta/findall.go:216-239): unanchored forward walk
+//                 (dfa/lazy/lazy.go:1102-1315) then SearchReverse (:1769-1920).
+//
+// Why a lane may start in the middle of the haystack: a byte outside the pattern's alphabet
+// ("sync byte") kills every live DFA state and cannot be part of a match, so the reference's
+// sequential state right after it is the same as at position 0 (pos == that index, nothing pending).
+// A lane therefore owns every position p in [c0, c1) with p == 0 or hay[p-1] sync, runs the
+// reference loop from there, and stops at the first owned-by-someone-else segment start.  The
+// concatenation over lanes equals the single-threaded result for non-nullable patterns.
+//
+// The DFA tables use *immediate* acceptance (a state accepts when its NFA set holds Match); the
+// reference's 1-byte match delay (lazy.go:1360,1371) is the same information one transition later:
+// "match-tagged after consuming hay[pos]" == "accepting before consuming hay[pos]".
+//
+// This header is plain C++ so that tests/emu can compile the very same walks for the host and
+// compare them with the oracle lane by lane; the product only ever instantiates them in HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CXG_HD __host__ __device__ __forceinline__
+#else
+#define CXG_HD inline
+#endif
+
+namespace cxgdev {
+
+constexpr uint32_t kBlobMagic = 0x43584731u;  // "CXG1"
+enum BlobKind : uint32_t { kKindDigit = 1, kKindBidir = 2, kKindCharClass = 3, kKindTeddy = 4 };
+constexpr uint32_t kInfoSync = 1u;       // byte is outside the pattern alphabet
+constexpr uint32_t kInfoMember = 2u;     // char-class membership (kKindCharClass)
+constexpr uint32_t kInfoStartIdle = 4u;  // fwd.start --byte--> fwd.start (skippable while idle)
+constexpr uint32_t kFlagRunSkip = 1u;
+
+struct BlobHeader {             // device image of a program; all offsets in bytes from the blob start
+  uint32_t magic, kind, flags, ngroups;
+  uint32_t fwd_states, fwd_start, fwd_first_accept, fwd_off;
+  uint32_t rev_states, rev_start, rev_first_accept, rev_off;
+  uint32_t info_off, total_bytes, aux_off, aux_len;
+};
+
+struct DfaView {
+  const uint8_t* T;   // [states][stride] next-state table; state 0 is dead
+  uint32_t stride;    // 256 in the blob, 260 when staged in LDS (bank skew)
+  uint32_t start;
+  uint32_t first_accept;  // states >= first_accept hold Match
+};
+
+CXG_HD bool is_digit(uint32_t b) { return (b - 0x30u) < 10u; }
+
+// 0x80 in every byte lane of x that holds an ASCII digit.  x ^ 0x30.. maps '0'..'9' to 0..9 and
+// everything else to >= 10; the carry-free add of 0x76 sets bit 7 exactly for low-7 values >= 10.
+CXG_HD uint32_t digit_mask4(uint32_t x) {
+  const uint32_t t = x ^ 0x30303030u;
+  const uint32_t nd = (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
+  return nd ^ 0x80808080u;
+}
+CXG_HD uint32_t ctz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return static_cast<uint32_t>(__builtin_ctz(v));
+#else
+  return static_cast<uint32_t>(__builtin_ctz(v));
+#endif
+}
+
+// Mem concept: uint32_t byte(int32_t r) for r in [-1, rend), r relative to the tile base;
+//              uint32_t dword(int32_t r) little-endian 4 bytes at r (r % 4 == 0, r + 4 <= wide_limit(x));
+//              int32_t wide_limit(int32_t x): largest bound <= x up to which dword() may be used.
+// Sink concept: void emit(int32_t s, int32_t e).
+
+// Finds the first owned segment start in [c0, c1); returns -1 if the lane owns none.
+template <class Mem>
+CXG_HD int32_t first_owned_start(const Mem& m, const uint8_t* info, int32_t c0, int32_t c1, int32_t rend,
+                                 bool chunk_at_origin) {
+  int32_t pos = c0;
+  if (pos >= rend) return -1;
+  if (chunk_at_origin) return pos;
+  if (info[m.byte(pos - 1)] & kInfoSync) return pos;
+  for (;;) {
+    if (pos >= c1 || pos >= rend) return -1;
+    uint32_t b = m.byte(pos);
+    pos++;
+    if (info[b] & kInfoSync) break;
+  }
+  if (pos >= c1 || pos >= rend) return -1;
+  return pos;
+}
+
+template <class Mem, class Sink>
+CXG_HD void lane_digit(const Mem& m, const DfaView& d, const uint8_t* info, bool skip_safe, int32_t c0, int32_t c1,
+                       int32_t rend, bool chunk_at_origin, Sink& sink) {
+  int32_t pos = first_owned_start(m, info, c0, c1, rend, chunk_at_origin);
+  if (pos < 0) return;
+  for (;;) {
+    // prefilter: next digit at >= pos (prefilter/digit.go:72).  Inside the lane's own chunk no
+    // ownership check is needed, so aligned dwords are tested 4 bytes at a time (the GPU twin of
+    // the 32 B/iter AVX2 loop, simd/memchr_digit_amd64.s:26).
+    {
+      const int32_t wide_end = m.wide_limit(c1 < rend ? c1 : rend);
+      while (pos < wide_end) {
+        if ((pos & 3) == 0 && pos + 4 <= wide_end) {
+          const uint32_t dm = digit_mask4(m.dword(pos));
+          if (dm) { pos += static_cast<int32_t>(ctz32(dm) >> 3); break; }
+          pos += 4;
+          continue;
+        }
+        if (is_digit(m.byte(pos))) break;
+        pos++;
+      }
+    }
+    for (;;) {
+      if (pos >= rend) return;
+      if (pos >= c1 && (info[m.byte(pos - 1)] & kInfoSync)) return;  // next owner's segment
+      if (is_digit(m.byte(pos))) break;
+      pos++;
+    }
+    const int32_t dpos = pos;
+    // anchored verify (lazy.go:219-324)
+    uint32_t q = d.start;
+    int32_t last = -1, i = dpos;
+    for (;;) {
+      if (q >= d.first_accept) last = i;
+      if (i >= rend) break;
+      q = d.T[q * d.stride + m.byte(i)];
+      if (q == 0) break;
+      i++;
+    }
+    if (last >= 0) {
+      sink.emit(dpos, last);
+      pos = last > pos ? last : pos + 1;  // findall.go:267-275 (matches are non-empty here)
+    } else {
+      pos = dpos + 1;                      // find_indices.go:1079-1084
+      if (skip_safe)
+        while (pos < rend && is_digit(m.byte(pos))) pos++;
+    }
+  }
+}
+
+template <class Mem, class Sink>
+CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const uint8_t* info, int32_t c0, int32_t c1,
+                       int32_t rend, bool chunk_at_origin, Sink& sink) {
+  int32_t pos = first_owned_start(m, info, c0, c1, rend, chunk_at_origin);
+  if (pos < 0) return;
+  for (;;) {
+    // forward: end of the leftmost-first match at >= pos (lazy.go:1102-1315)
+    uint32_t q = f.start;
+    int32_t last = -1, i = pos;
+    for (;;) {
+      if (q >= f.first_accept) last = i;
+      if (i >= rend) break;
+      if (q == f.start && i >= c1 && last < 0 && i > 0 && (info[m.byte(i - 1)] & kInfoSync)) return;
+      q = f.T[q * f.stride + m.byte(i)];
+      if (q == 0) break;
+      i++;
+    }
+    if (last < 0) return;  // findall.go:228-230
+    // reverse: leftmost start in [pos, last) (lazy.go:1769-1920)
+    uint32_t s = r.start;
+    int32_t st = -1;
+    for (int32_t at = last - 1; at >= pos; at--) {
+      s = r.T[s * r.stride + m.byte(at)];
+      if (s == 0) break;
+      if (s >= r.first_accept) st = at;
+    }
+    if (st < 0) return;    // findall.go:235-237
+    sink.emit(st, last);
+    pos = last > pos ? last : pos + 1;
+  }
+}
+
+}  // namespace cxgdev

@@ -1,0 +1,79 @@
+// Host front-end of the MI355X FindAll path: pattern -> AST -> Thompson NFA -> strategy.
+//
+// This is the C++ stand-in for the part of the reference that `north_star` keeps in Go
+// (coregex.Compile -> meta.CompileRegexp, meta/compile.go:440-654): there is no Go toolchain
+// in this image, so the host side above the C ABI is written here, mirroring the reference's
+// observable outputs for the accelerated subset:
+//   * AST shape of regexp/syntax.Parse(pattern, syntax.Perl) (meta/compile.go:58) — literal-run
+//     merging, alternation factoring, single-rune classes;
+//   * NFA state numbering of nfa.Compiler (nfa/compile.go:99-233,1225-1682) — creation order;
+//   * prefix literal extraction (literal/extractor.go:128-365) and SelectStrategy
+//     (meta/strategy.go:1377-1546) for the strategies the device path serves.
+// Everything outside the subset yields Unsupported so the caller keeps its CPU loop
+// (CXG_E_UNSUPPORTED).  Independent of oracle/ by construction: nothing here includes it.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/coregex_hip.h"
+
+namespace cxg {
+
+enum class Node : uint8_t {
+  NoMatch, Empty, Lit, Class, AnyNotNL, Any, BeginLine, EndLine, BeginText, EndText, WordB, NoWordB,
+  Capture, Star, Plus, Quest, Repeat, Concat, Alt
+};
+
+struct Ast {
+  struct N {
+    Node kind = Node::Empty;
+    bool fold = false;        // FoldCase literal
+    bool lazy = false;        // non-greedy quantifier
+    std::vector<int32_t> r;   // runes, or class range pairs
+    std::vector<int> kids;
+    int min = 0, max = 0, cap = 0;
+  };
+  std::vector<N> nodes;
+  int root = -1;
+  int ncap = 0;
+  int add(Node k) { nodes.emplace_back(); nodes.back().kind = k; return static_cast<int>(nodes.size()) - 1; }
+  N& at(int i) { return nodes[i]; }
+  const N& at(int i) const { return nodes[i]; }
+  std::string repr(int i) const;
+};
+
+struct FrontendError {
+  int code;  // CXG_E_SYNTAX or CXG_E_UNSUPPORTED
+  std::string msg;
+};
+
+Ast parsePattern(const std::string& pattern);  // throws FrontendError
+
+struct HostNfa {
+  std::vector<cxg_nfa_state> states;
+  std::vector<cxg_nfa_trans> trans;
+  uint32_t startAnchored = 0, startUnanchored = 0;
+  uint32_t captureCount = 1;
+  bool alwaysAnchored = false;
+  cxg_nfa view() const {
+    return cxg_nfa{states.data(), static_cast<uint32_t>(states.size()), trans.data(),
+                   static_cast<uint32_t>(trans.size()), startAnchored, startUnanchored, captureCount};
+  }
+};
+
+HostNfa buildNfa(const Ast& ast);  // throws FrontendError(CXG_E_UNSUPPORTED) for look-around / non-ASCII classes
+
+struct PrefixLit { std::vector<uint8_t> bytes; bool exact; };
+
+struct Plan {
+  int strategy = CXG_USE_NFA;
+  uint32_t flags = 0;
+  std::vector<PrefixLit> prefixes;
+  uint8_t membership[256] = {0};   // UseCharClassSearcher
+  bool confident = true;           // false: a strategy outside the subset may apply (reverse searchers etc.)
+};
+
+Plan selectStrategy(const Ast& ast, const HostNfa& nfa);
+
+}  // namespace cxg

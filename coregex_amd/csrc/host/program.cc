@@ -1,0 +1,302 @@
+// See program.h.
+#include "program.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+namespace cxg {
+
+namespace {
+
+struct Closure {
+  const cxg_nfa& n;
+  std::vector<uint32_t> mark;   // generation stamps
+  uint32_t gen = 0;
+  std::vector<uint32_t> stack;
+  explicit Closure(const cxg_nfa& nfa) : n(nfa), mark(nfa.n_states, 0) {}
+  void begin() { gen++; }
+  // epsilonClosureInto, builder.go:245-293
+  void into(std::vector<uint32_t>& out, uint32_t seed) {
+    stack.clear();
+    stack.push_back(seed);
+    while (!stack.empty()) {
+      uint32_t cur = stack.back();
+      stack.pop_back();
+      if (cur == CXG_NFA_INVALID || cur >= n.n_states) continue;
+      if (mark[cur] == gen) continue;
+      mark[cur] = gen;
+      out.push_back(cur);
+      const cxg_nfa_state& s = n.states[cur];
+      switch (s.kind) {
+        case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE:
+          if (s.next != CXG_NFA_INVALID) stack.push_back(s.next);
+          break;
+        case CXG_NFA_SPLIT:
+          if (s.right != CXG_NFA_INVALID) stack.push_back(s.right);
+          if (s.left != CXG_NFA_INVALID) stack.push_back(s.left);
+          break;
+        default: break;
+      }
+    }
+  }
+};
+
+}  // namespace
+
+void alphabetOf(const cxg_nfa& nfa, bool in[256]) {
+  std::memset(in, 0, 256);
+  // the unanchored prefix (compile.go:1633-1650) is Split(pattern, [00-FF] -> self): not pattern alphabet
+  uint32_t prefixAny = CXG_NFA_INVALID;
+  if (nfa.start_unanchored != nfa.start_anchored && nfa.start_unanchored < nfa.n_states) {
+    const cxg_nfa_state& sp = nfa.states[nfa.start_unanchored];
+    if (sp.kind == CXG_NFA_SPLIT && sp.right < nfa.n_states) {
+      const cxg_nfa_state& a = nfa.states[sp.right];
+      if (a.kind == CXG_NFA_BYTE_RANGE && a.lo == 0 && a.hi == 255 && a.next == nfa.start_unanchored) prefixAny = sp.right;
+    }
+  }
+  for (uint32_t i = 0; i < nfa.n_states; i++) {
+    if (i == prefixAny) continue;
+    const cxg_nfa_state& s = nfa.states[i];
+    if (s.kind == CXG_NFA_BYTE_RANGE) for (int b = s.lo; b <= s.hi; b++) in[b] = true;
+    else if (s.kind == CXG_NFA_SPARSE)
+      for (uint32_t k = 0; k < s.trans_len; k++) {
+        const cxg_nfa_trans& t = nfa.trans[s.trans_off + k];
+        for (int b = t.lo; b <= t.hi; b++) in[b] = true;
+      }
+  }
+}
+
+Dfa determinize(const cxg_nfa& nfa, uint32_t startState, bool breakAtMatch, uint32_t maxStates) {
+  for (uint32_t i = 0; i < nfa.n_states; i++)
+    if (nfa.states[i].kind == CXG_NFA_LOOK) throw BuildError{CXG_E_UNSUPPORTED, "look-around assertion in NFA"};
+  // byte classes (nfa/alphabet.go:100-166): determinize once per class representative
+  bool boundary[256] = {false};
+  auto mark = [&](int lo, int hi) { if (lo > 0) boundary[lo - 1] = true; boundary[hi] = true; };
+  for (uint32_t i = 0; i < nfa.n_states; i++) {
+    const cxg_nfa_state& s = nfa.states[i];
+    if (s.kind == CXG_NFA_BYTE_RANGE) mark(s.lo, s.hi);
+    else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) mark(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
+  }
+  std::vector<int> repOf(256);
+  std::vector<int> reps;
+  { int rep = 0; for (int b = 0; b < 256; b++) { if (b == 0 || boundary[b - 1]) { rep = b; reps.push_back(b); } repOf[b] = rep; } }
+
+  Closure cl(nfa);
+  std::map<std::vector<uint32_t>, uint32_t> ids;   // ordered NFA list -> provisional id
+  std::vector<std::vector<uint32_t>> sets;
+  std::vector<std::vector<uint32_t>> next;          // [id][256] provisional
+  auto intern = [&](std::vector<uint32_t>&& set) -> uint32_t {
+    auto it = ids.find(set);
+    if (it != ids.end()) return it->second;
+    uint32_t id = static_cast<uint32_t>(sets.size());
+    if (id >= maxStates) throw BuildError{CXG_E_UNSUPPORTED, "DFA exceeds the LDS state budget"};
+    ids.emplace(set, id);
+    sets.push_back(std::move(set));
+    next.emplace_back(256, 0u);
+    return id;
+  };
+  intern({});  // id 0 = dead (empty set)
+  std::vector<uint32_t> st;
+  cl.begin();
+  cl.into(st, startState);
+  uint32_t start = intern(std::move(st));
+  auto holdsMatch = [&](const std::vector<uint32_t>& s) { for (uint32_t x : s) if (nfa.states[x].kind == CXG_NFA_MATCH) return true; return false; };
+  for (uint32_t cur = 1; cur < sets.size(); cur++) {
+    const bool brk = breakAtMatch && holdsMatch(sets[cur]);
+    for (int rep : reps) {
+      std::vector<uint32_t> out;
+      cl.begin();
+      const std::vector<uint32_t> src = sets[cur];  // copy: sets may grow
+      for (uint32_t sid : src) {  // moveWithWordContextBreak, builder.go:183-242
+        const cxg_nfa_state& s = nfa.states[sid];
+        if (brk && s.kind == CXG_NFA_MATCH) break;
+        if (s.kind == CXG_NFA_BYTE_RANGE) {
+          if (rep >= s.lo && rep <= s.hi) cl.into(out, s.next);
+        } else if (s.kind == CXG_NFA_SPARSE) {
+          for (uint32_t k = 0; k < s.trans_len; k++) {
+            const cxg_nfa_trans& t = nfa.trans[s.trans_off + k];
+            if (rep >= t.lo && rep <= t.hi) cl.into(out, t.next);
+          }
+        }
+      }
+      uint32_t to = out.empty() ? 0u : intern(std::move(out));
+      next[cur][rep] = to;
+    }
+  }
+  // renumber: dead 0, non-accepting, then accepting
+  const uint32_t n = static_cast<uint32_t>(sets.size());
+  std::vector<uint32_t> perm(n, 0);
+  uint32_t k = 1;
+  for (uint32_t i = 1; i < n; i++) if (!holdsMatch(sets[i])) perm[i] = k++;
+  const uint32_t firstAccept = k;
+  for (uint32_t i = 1; i < n; i++) if (holdsMatch(sets[i])) perm[i] = k++;
+  Dfa d;
+  d.nstates = n;
+  d.start = perm[start];
+  d.firstAccept = firstAccept;
+  d.table.assign(static_cast<size_t>(n) * 256, 0);
+  for (uint32_t i = 1; i < n; i++)
+    for (int b = 0; b < 256; b++) d.table[static_cast<size_t>(perm[i]) * 256 + b] = static_cast<uint8_t>(perm[next[i][repOf[b]]]);
+  return d;
+}
+
+HostNfa reverseOf(const cxg_nfa& fwd) {
+  // R(t) == "the forward run is at state t here".  Reading byte b backwards moves R(t) -> R(s) for
+  // every byte state s with s.next == t that accepts b; epsilon edges are reversed.  The reverse
+  // automaton starts at R(Match) and accepts at R(start_anchored).  The reference builds the same
+  // language in nfa/reverse.go; state order is irrelevant because the reverse DFA runs without
+  // break-at-match (meta/compile.go:193-194) and therefore reports the set-theoretic minimum start.
+  const uint32_t N = fwd.n_states;
+  std::vector<std::vector<cxg_nfa_trans>> byteIn(N);
+  std::vector<std::vector<uint32_t>> epsIn(N);
+  std::vector<uint8_t> skip(N, 0);
+  if (fwd.start_unanchored != fwd.start_anchored && fwd.start_unanchored < N) {
+    skip[fwd.start_unanchored] = 1;
+    const cxg_nfa_state& sp = fwd.states[fwd.start_unanchored];
+    if (sp.kind == CXG_NFA_SPLIT && sp.right < N) skip[sp.right] = 1;
+  }
+  uint32_t fwdMatch = CXG_NFA_INVALID;
+  for (uint32_t s = 0; s < N; s++) {
+    const cxg_nfa_state& st = fwd.states[s];
+    if (st.kind == CXG_NFA_MATCH) fwdMatch = s;
+    if (skip[s]) continue;
+    switch (st.kind) {
+      case CXG_NFA_BYTE_RANGE: if (st.next < N) byteIn[st.next].push_back({st.lo, st.hi, 0, s}); break;
+      case CXG_NFA_SPARSE:
+        for (uint32_t k = 0; k < st.trans_len; k++) { const cxg_nfa_trans& t = fwd.trans[st.trans_off + k]; if (t.next < N) byteIn[t.next].push_back({t.lo, t.hi, 0, s}); }
+        break;
+      case CXG_NFA_SPLIT:
+        if (st.left < N) epsIn[st.left].push_back(s);
+        if (st.right < N) epsIn[st.right].push_back(s);
+        break;
+      case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE: if (st.next < N) epsIn[st.next].push_back(s); break;
+      default: break;
+    }
+  }
+  HostNfa r;
+  auto blank = [](uint8_t kind) { cxg_nfa_state s; std::memset(&s, 0, sizeof s); s.kind = kind; s.next = s.left = s.right = CXG_NFA_INVALID; return s; };
+  r.states.assign(N, blank(CXG_NFA_FAIL));
+  auto add = [&](cxg_nfa_state s) { r.states.push_back(s); return static_cast<uint32_t>(r.states.size() - 1); };
+  const uint32_t revMatch = add(blank(CXG_NFA_MATCH));
+  for (uint32_t t = 0; t < N; t++) {
+    if (skip[t]) continue;
+    std::vector<uint32_t> alts;
+    if (t == fwd.start_anchored) alts.push_back(revMatch);
+    if (!byteIn[t].empty()) {
+      cxg_nfa_state sp = blank(CXG_NFA_SPARSE);
+      sp.trans_off = static_cast<uint32_t>(r.trans.size());
+      sp.trans_len = static_cast<uint32_t>(byteIn[t].size());
+      for (auto& tr : byteIn[t]) r.trans.push_back(tr);
+      alts.push_back(add(sp));
+    }
+    for (uint32_t s : epsIn[t]) alts.push_back(s);
+    if (alts.empty()) continue;
+    uint32_t chain = alts.back();
+    for (size_t i = alts.size() - 1; i-- > 0;) { cxg_nfa_state sp = blank(CXG_NFA_SPLIT); sp.left = alts[i]; sp.right = chain; chain = add(sp); }
+    r.states[t] = blank(CXG_NFA_EPSILON);
+    r.states[t].next = chain;
+  }
+  r.startAnchored = r.startUnanchored = fwdMatch;
+  r.captureCount = 1;
+  r.alwaysAnchored = true;
+  return r;
+}
+
+namespace {
+
+constexpr uint32_t kMaxDfaStates = 224;  // u8 ids; 224*260 B = 58 KB of LDS leaves room for the tile
+
+void appendTable(std::vector<uint8_t>& blob, const Dfa& d, uint32_t& off) {
+  off = static_cast<uint32_t>(blob.size());
+  blob.insert(blob.end(), d.table.begin(), d.table.end());
+  while (blob.size() % 16) blob.push_back(0);
+}
+
+}  // namespace
+
+void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
+  p->strategy = strategy;
+  p->flags = flags;
+  p->ngroups = static_cast<int>(nfa.capture_count);
+  p->nfaStates = static_cast<int>(nfa.n_states);
+  p->supported = false;
+  try {
+    if (nfa.n_states == 0 || nfa.start_anchored >= nfa.n_states || nfa.start_unanchored >= nfa.n_states)
+      throw BuildError{CXG_E_INVALID, "malformed NFA"};
+    cxgdev::BlobHeader h;
+    std::memset(&h, 0, sizeof h);
+    h.magic = cxgdev::kBlobMagic;
+    h.ngroups = nfa.capture_count;
+    bool inAlpha[256];
+    alphabetOf(nfa, inAlpha);
+    uint8_t info[256];
+    for (int b = 0; b < 256; b++) info[b] = inAlpha[b] ? 0 : cxgdev::kInfoSync;
+    std::vector<uint8_t> blob(sizeof h, 0);
+    if (strategy == CXG_USE_DIGIT_PREFILTER) {
+      // findIndicesDigitPrefilterAtWithState: anchored DFA at each digit candidate
+      p->fwd = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
+      if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+      h.kind = cxgdev::kKindDigit;
+      if (flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) h.flags |= cxgdev::kFlagRunSkip;
+      for (int b = '0'; b <= '9'; b++) info[b] &= ~cxgdev::kInfoSync;  // digits are candidates, never sync
+    } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
+      // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA
+      if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+      p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
+      if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+      HostNfa rn = reverseOf(nfa);
+      cxg_nfa rv = rn.view();
+      p->rev = determinize(rv, rv.start_anchored, false, kMaxDfaStates);
+      if (p->fwd.nstates + p->rev.nstates > kMaxDfaStates) throw BuildError{CXG_E_UNSUPPORTED, "DFA pair exceeds the LDS state budget"};
+      h.kind = cxgdev::kKindBidir;
+      for (int b = 0; b < 256; b++)
+        if (p->fwd.table[static_cast<size_t>(p->fwd.start) * 256 + b] == p->fwd.start) info[b] |= cxgdev::kInfoStartIdle;
+    } else {
+      throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
+    }
+    h.fwd_states = p->fwd.nstates; h.fwd_start = p->fwd.start; h.fwd_first_accept = p->fwd.firstAccept;
+    appendTable(blob, p->fwd, h.fwd_off);
+    if (h.kind == cxgdev::kKindBidir) {
+      h.rev_states = p->rev.nstates; h.rev_start = p->rev.start; h.rev_first_accept = p->rev.firstAccept;
+      appendTable(blob, p->rev, h.rev_off);
+    }
+    h.info_off = static_cast<uint32_t>(blob.size());
+    blob.insert(blob.end(), info, info + 256);
+    h.total_bytes = static_cast<uint32_t>(blob.size());
+    std::memcpy(blob.data(), &h, sizeof h);
+    p->blob.swap(blob);
+    p->supported = true;
+  } catch (const BuildError& e) {
+    p->whyNot = e.msg;
+  }
+}
+
+void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch) {
+  p->strategy = CXG_USE_CHARCLASS_SEARCHER;
+  p->ngroups = 1;
+  p->supported = false;
+  if (minMatch != 1) { p->whyNot = "minMatch != 1"; return; }
+  cxgdev::BlobHeader h;
+  std::memset(&h, 0, sizeof h);
+  h.magic = cxgdev::kBlobMagic;
+  h.kind = cxgdev::kKindCharClass;
+  h.ngroups = 1;
+  std::vector<uint8_t> blob(sizeof h, 0);
+  h.info_off = static_cast<uint32_t>(blob.size());
+  for (int b = 0; b < 256; b++) blob.push_back(membership[b] ? cxgdev::kInfoMember : cxgdev::kInfoSync);
+  h.total_bytes = static_cast<uint32_t>(blob.size());
+  std::memcpy(blob.data(), &h, sizeof h);
+  p->blob.swap(blob);
+  p->supported = true;
+}
+
+void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits) {
+  p->strategy = CXG_USE_TEDDY;
+  p->ngroups = 1;
+  p->supported = false;
+  p->whyNot = "Teddy device kernel not built yet";
+  (void)lits;
+}
+
+}  // namespace cxg

@@ -1,0 +1,59 @@
+// cxg_program: strategy + eager tables built on the host, shipped to the device as one blob.
+//
+// The reference determinizes lazily (dfa/lazy/lazy.go:1336-1446) because state sets can blow up;
+// for the accelerated subset the whole table is built up front: lazy vs eager is
+// unobservable, the table must fit LDS anyway, and a pattern whose DFA does not fit is refused
+// (CXG_E_UNSUPPORTED) instead of degraded.  Semantics kept from the reference:
+//   * closure insertion order  dfa/lazy/builder.go:245-293 (stack, push right then left)
+//   * break-at-match           dfa/lazy/builder.go:210-213 (forward DFAs only, meta/compile.go:193)
+//   * byte-range / sparse move dfa/lazy/builder.go:215-230
+// Deliberate difference: a DFA state is identified by its *ordered* NFA list (the reference keys on
+// the sorted set, dfa/lazy/state.go:342-346, and keeps whichever order it met first).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/coregex_hip.h"
+#include "../device/walk.hpp"
+#include "frontend.h"
+
+namespace cxg {
+
+struct Dfa {
+  uint32_t nstates = 0;          // including the dead state 0
+  uint32_t start = 0;
+  uint32_t firstAccept = 0;      // states >= firstAccept contain Match
+  std::vector<uint8_t> table;    // [nstates][256]
+};
+
+struct BuildError { int code; std::string msg; };
+
+// Throws BuildError(CXG_E_UNSUPPORTED) when the NFA has look-around or the DFA exceeds maxStates.
+Dfa determinize(const cxg_nfa& nfa, uint32_t startState, bool breakAtMatch, uint32_t maxStates);
+HostNfa reverseOf(const cxg_nfa& fwd);             // language-reversed automaton (nfa/reverse.go:8-300)
+void alphabetOf(const cxg_nfa& nfa, bool inAlphabet[256]);  // bytes some pattern transition accepts
+
+}  // namespace cxg
+
+struct cxg_program {
+  int strategy = CXG_USE_NFA;
+  uint32_t flags = 0;
+  int ngroups = 1;
+  int nfaStates = -1;
+  bool supported = false;
+  std::string whyNot;
+  cxg::HostNfa nfa;              // kept for cxg_program_nfa (cxg_compile only)
+  cxg::Dfa fwd, rev;
+  std::vector<uint8_t> blob;     // cxgdev::BlobHeader + tables
+  // device copies, one per device, created on first use (capi.cc)
+  void* dev[16] = {nullptr};
+};
+
+namespace cxg {
+// Fills p->fwd/rev/blob/supported from (nfa, strategy, flags).  Never throws: unsupported programs
+// get supported=false + whyNot.
+void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags);
+void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch);
+void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits);
+}  // namespace cxg

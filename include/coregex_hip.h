@@ -1,0 +1,157 @@
+/* coregex_hip.h — C ABI of libcoregex_hip.so: the MI355X (gfx950) bulk FindAll path.
+ *
+ * Drop-in boundary.  The reference has no FFI today; the seam these entry
+ * points replace is one call per *haystack*:
+ *
+ *   cxg_find_all           <- (*meta.Engine).FindAllIndicesStreaming   meta/findall.go:155
+ *                              (reached from Regex.FindAll/FindAllIndex/AppendAllIndex, regex.go:395,702,752)
+ *   cxg_count              <- (*meta.Engine).Count                      meta/findall.go:297
+ *   cxg_find_all_submatch  <- (*meta.Engine).FindAllSubmatch            meta/findall.go:390
+ *                              (flattened as Regex.FindAllSubmatchIndex does, regex.go:1423-1450)
+ *   cxg_program_from_nfa   <- what a cgo shim builds once per compiled *meta.Engine from
+ *                              e.nfa (nfa/nfa.go:23-154 State), e.strategy (meta/strategy.go:19-230),
+ *                              e.digitRunSkipSafe (meta/compile.go:176)
+ *   cxg_program_from_literals <- prefilter.Teddy patterns (prefilter/teddy.go:110-130) for UseTeddy
+ *   cxg_program_from_charclass <- nfa.CharClassSearcher.membership (nfa/charclass_searcher.go:21-27)
+ *   cxg_compile            <- meta.Compile (meta/compile.go:40): host stand-in used where no Go
+ *                              toolchain exists (this image); same pattern -> strategy -> tables
+ *                              pipeline, C++ (coregex_amd/csrc/host/).
+ *
+ * Conventions: return 0 on success, a negative CXG_E_* otherwise.  Offsets are absolute int64
+ * indices into the haystack, identical to Go `int`.  The caller owns `hay` and the output
+ * arrays; nothing is retained past return (cgo pointer rule).  A cxg_program is immutable and
+ * may be shared by threads; every call uses its own stream and scratch (the SearchState
+ * analogue, meta/search_state.go:23-62).  No torch types appear in any signature.
+ */
+#ifndef COREGEX_HIP_H_
+#define COREGEX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CXG_OK 0
+#define CXG_E_INVALID (-1)      /* bad argument / malformed program description */
+#define CXG_E_UNSUPPORTED (-2)  /* pattern or strategy outside the accelerated subset: caller keeps its CPU loop */
+#define CXG_E_CAPACITY (-3)     /* output array too small: *n_out holds the required number of rows */
+#define CXG_E_DEVICE (-4)       /* HIP runtime failure (cxg_last_error has the text) */
+#define CXG_E_NO_GPU (-5)       /* no gfx950 device visible: there is no CPU fallback in this library */
+#define CXG_E_SYNTAX (-6)       /* cxg_compile: pattern does not parse */
+#define CXG_E_INTERNAL (-7)     /* device-side invariant violated (watchdog, scratch overflow) */
+
+/* meta.Strategy values (meta/strategy.go:19-230), same numbering. */
+enum cxg_strategy {
+  CXG_USE_NFA = 0, CXG_USE_DFA = 1, CXG_USE_BOTH = 2, CXG_USE_REVERSE_ANCHORED = 3,
+  CXG_USE_REVERSE_SUFFIX = 4, CXG_USE_ONEPASS = 5, CXG_USE_REVERSE_INNER = 6,
+  CXG_USE_BOUNDED_BACKTRACKER = 7, CXG_USE_TEDDY = 8, CXG_USE_REVERSE_SUFFIX_SET = 9,
+  CXG_USE_CHARCLASS_SEARCHER = 10, CXG_USE_COMPOSITE_SEARCHER = 11, CXG_USE_BRANCH_DISPATCH = 12,
+  CXG_USE_DIGIT_PREFILTER = 13, CXG_USE_AHO_CORASICK = 14, CXG_USE_ANCHORED_LITERAL = 15,
+  CXG_USE_MULTILINE_REVERSE_SUFFIX = 16
+};
+
+/* nfa.StateKind (nfa/nfa.go:23-60), same numbering. */
+enum cxg_nfa_kind {
+  CXG_NFA_MATCH = 0, CXG_NFA_BYTE_RANGE = 1, CXG_NFA_SPARSE = 2, CXG_NFA_SPLIT = 3,
+  CXG_NFA_EPSILON = 4, CXG_NFA_CAPTURE = 5, CXG_NFA_FAIL = 6, CXG_NFA_LOOK = 7
+};
+
+#define CXG_NFA_INVALID 0xFFFFFFFFu
+
+typedef struct cxg_nfa_trans {  /* nfa.Transition (nfa/nfa.go:138-142) */
+  uint8_t lo, hi;
+  uint16_t _pad;
+  uint32_t next;
+} cxg_nfa_trans;
+
+typedef struct cxg_nfa_state {  /* nfa.State (nfa/nfa.go:119-154), flattened */
+  uint8_t kind;        /* cxg_nfa_kind */
+  uint8_t lo, hi;      /* BYTE_RANGE */
+  uint8_t cap_start;   /* CAPTURE: 1 = opening */
+  uint32_t next;       /* BYTE_RANGE / EPSILON / CAPTURE / LOOK */
+  uint32_t left, right;/* SPLIT (left is explored first) */
+  uint32_t cap_index;  /* CAPTURE */
+  uint32_t trans_off;  /* SPARSE: first entry in the transition array */
+  uint32_t trans_len;  /* SPARSE */
+} cxg_nfa_state;
+
+typedef struct cxg_nfa {
+  const cxg_nfa_state* states;
+  uint32_t n_states;
+  const cxg_nfa_trans* trans;
+  uint32_t n_trans;
+  uint32_t start_anchored, start_unanchored;  /* NFA.StartAnchored / StartUnanchored */
+  uint32_t capture_count;                      /* NFA.CaptureCount(), includes group 0 */
+} cxg_nfa;
+
+#define CXG_FLAG_DIGIT_RUN_SKIP_SAFE 1u  /* Engine.digitRunSkipSafe (meta/compile.go:176) */
+#define CXG_FLAG_HAS_REVERSE_DFA 2u      /* Engine.reverseDFA != nil (meta/compile.go:184-205) */
+
+typedef struct cxg_program cxg_program;  /* opaque: strategy + tables, host and device copies */
+typedef struct cxg_buffer cxg_buffer;    /* opaque: device-resident haystack */
+
+typedef struct cxg_timing {  /* filled by the *_device entry points when non-NULL */
+  float kernel_ms;           /* HIP-event time of the scan kernel(s) on the call's stream */
+  float total_ms;            /* scan + status reset + count read-back, same stream */
+  uint32_t n_launches;
+  uint32_t grid, block;
+  uint64_t tiles;
+} cxg_timing;
+
+const char* cxg_last_error(void);          /* thread-local text of the last failure */
+const char* cxg_version(void);
+int cxg_device_count(void);                /* gfx950 devices visible; 0 => every search returns CXG_E_NO_GPU */
+int cxg_set_device(int device);            /* per-thread device for subsequent calls (default 0) */
+
+/* ---- program construction ------------------------------------------------------------ */
+int cxg_compile(const char* pattern, size_t len, cxg_program** out);
+int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_program** out);
+int cxg_program_from_literals(const uint8_t* const* lits, const uint32_t* lens, uint32_t n, cxg_program** out);
+int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match, cxg_program** out);
+void cxg_program_destroy(cxg_program* p);
+
+int cxg_program_strategy(const cxg_program* p);         /* cxg_strategy */
+const char* cxg_strategy_name(int strategy);
+int cxg_program_num_groups(const cxg_program* p);       /* NumSubexp()+1 */
+int cxg_program_nfa_states(const cxg_program* p);       /* -1 if built without an NFA */
+int cxg_program_dfa_states(const cxg_program* p);       /* eager forward DFA states incl. dead */
+int cxg_program_supported(const cxg_program* p);        /* 1 if the device path accepts it */
+/* Device image of the program (what every kernel stages into LDS); for tests and the emulator. */
+int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
+/* Host-side copy of the NFA a program was compiled from (cxg_compile only); pointers live as long as p. */
+int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);
+
+/* ---- search over a host haystack (what the cgo shim calls) --------------------------- */
+int cxg_find_all(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit,
+                 int64_t* spans /* [cap][2] */, uint64_t cap, uint64_t* n_out);
+int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, uint64_t* n_out);
+int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit,
+                          int64_t* slots /* [cap][2*groups], -1 unset */, uint64_t cap, uint64_t* n_out);
+
+/* ---- device-resident corpus (benchmarks, multi-GPU shards) --------------------------- */
+int cxg_buffer_alloc(uint64_t len, cxg_buffer** out);               /* on the calling thread's device */
+void cxg_buffer_free(cxg_buffer* b);
+int cxg_buffer_upload(cxg_buffer* b, uint64_t off, const uint8_t* src, uint64_t len);
+int cxg_buffer_download(const cxg_buffer* b, uint64_t off, uint8_t* dst, uint64_t len);
+uint64_t cxg_buffer_len(const cxg_buffer* b);
+void* cxg_buffer_device_ptr(const cxg_buffer* b);
+/* synthlog-v1 (DESIGN.md "Synthetic corpus"): page `first_page + i` of config `config` written at
+ * byte offset i*4096.  Generated on the device; cxg_synth_page_host is the CPU twin used by tests. */
+int cxg_buffer_fill_synth(cxg_buffer* b, uint32_t config, uint64_t seed, uint64_t first_page);
+int cxg_synth_page_host(uint32_t config, uint64_t seed, uint64_t page, uint8_t out[4096]);
+
+/* Raw device pointers (torch tensors' data_ptr(), a HIP stream handle or NULL for the call's own).
+ * d_out holds rows of `row_width` int64 (2 for find_all, 2*groups for submatch); rows are absolute
+ * offsets into d_hay plus `base`.  d_out may be NULL with cap 0 to count only. */
+int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
+                        void* d_out, uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing);
+int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base,
+                                 int64_t limit, void* d_out, uint64_t cap, uint64_t* n_out, void* stream,
+                                 cxg_timing* timing);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COREGEX_HIP_H_ */

@@ -1,0 +1,66 @@
+// TEST INFRASTRUCTURE ONLY — host emulation of the device lane walks.
+//
+// Compiles coregex_amd/csrc/device/walk.hpp (the exact per-lane functions the HIP kernels
+// instantiate) for the CPU and runs them tile by tile, lane by lane, in the order the kernel's rank
+// computation imposes (tile-major, lane-major, emission order).  It lets the CPU-only test tier check
+// chunk ownership, sync-byte logic and the eager tables against the oracle without a GPU.  It is NOT
+// a fallback: nothing in coregex_amd/ links or loads it, and it is built from tests/ only.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../coregex_amd/csrc/device/scan_dfa.h"
+#include "../../coregex_amd/csrc/device/walk.hpp"
+
+using namespace cxgdev;
+
+namespace {
+struct HostMem {
+  const uint8_t* g;   // hay + tile_lo
+  int32_t lim;
+  uint32_t byte(int32_t r) const { return g[r]; }
+  uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
+  int32_t wide_limit(int32_t x) const { return x < lim ? x : lim; }
+};
+struct VecSink {
+  std::vector<int64_t>* out;
+  int64_t origin;
+  void emit(int32_t s, int32_t e) { out->push_back(origin + s); out->push_back(origin + e); }
+};
+}  // namespace
+
+extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_t len, int chunk, int64_t* out,
+                                int64_t cap_vals) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic) return -1;
+  const uint8_t* info = blob + h->info_off;
+  std::vector<int64_t> res;
+  const int lanes = kThreads;
+  const uint64_t tile_bytes = static_cast<uint64_t>(lanes) * chunk;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * tile_bytes;
+    const uint64_t remaining = len - tile_lo;
+    const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+    const int32_t stage = rend < static_cast<int32_t>(tile_bytes) + kHalo ? rend : static_cast<int32_t>(tile_bytes) + kHalo;
+    HostMem m{hay + tile_lo, stage};
+    VecSink sink{&res, static_cast<int64_t>(tile_lo)};
+    for (int lane = 0; lane < lanes; lane++) {
+      const int32_t c0 = lane * chunk, c1 = c0 + chunk;
+      const bool at_origin = tile_lo == 0 && lane == 0;
+      if (h->kind == kKindDigit) {
+        DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
+        lane_digit(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
+      } else if (h->kind == kKindBidir) {
+        DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
+        DfaView r{blob + h->rev_off, 256, h->rev_start, h->rev_first_accept};
+        lane_bidir(m, f, r, info, c0, c1, rend, at_origin, sink);
+      } else {
+        return -2;
+      }
+    }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}

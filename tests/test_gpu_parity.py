@@ -1,0 +1,148 @@
+"""GPU tier (`-m gpu`): parity of the HIP path with the CPU oracle, through the C ABI.
+
+Integer/index work: the bar is bit-exact span arrays.  Sizes the oracle finishes in seconds are
+compared row by row; larger device-resident corpora are checked through size-independent properties
+(count + order-sensitive hash against the oracle run over the same pages, shard concatenation)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from refcorpus import COMPAT_PATTERNS, generate_test_input
+
+pytestmark = pytest.mark.gpu
+
+DEVICE_PATTERNS = {
+    "la_ips": r"\d+\.\d+\.\d+\.\d+", "version": r"\d+\.\d+\.\d+", "la_peak_hours": COMPAT_PATTERNS["la_peak_hours"],
+    "ip": COMPAT_PATTERNS["ip"], "char_class": r"[\w]+", "error_literal": r"error", "alternation_overlap": r"ab|abc",
+    "nested_groups_as_index": r"((a+)(b+))", "non_greedy_has_no_reverse": r"a+?", "digits": r"[0-9]+", "lower": r"[a-z]+",
+}
+
+
+@pytest.fixture(scope="module")
+def need_gpu():
+    assert cx.device_count() >= 1, "GPU tests need an MI355X; the library has no CPU path"
+
+
+def _check(oracle, pat, hay, n=-1):
+    rx = cx.compile(pat)
+    if not rx.supported:
+        pytest.skip(f"{pat}: {rx.why_unsupported}")
+    exp = oracle.Regex(pat).find_all_index(hay, n)
+    got = rx.find_all_index(hay, n)
+    assert got.shape == exp.shape, (pat, got.shape, exp.shape)
+    assert np.array_equal(got, exp), pat
+    return rx, exp
+
+
+@pytest.mark.parametrize("name", sorted(DEVICE_PATTERNS))
+def test_reference_corpus(need_gpu, oracle, name):
+    corpus = generate_test_input()
+    pat = DEVICE_PATTERNS[name]
+    rx, exp = _check(oracle, pat, corpus)
+    assert rx.count(corpus) == len(exp)
+    assert rx.count(corpus, 1000) == min(1000, len(exp))       # meta/stdlib_compat_test.go:139
+    lim = rx.find_all_index(corpus, 7)
+    assert np.array_equal(lim, exp[:7])
+
+
+def test_edge_cases(need_gpu, oracle):
+    pat = r"\d+\.\d+\.\d+\.\d+"
+    for hay in [b"", b"1", b"1.2.3.4", b"x1.2.3.4", b"1.2.3.4\n", b"1.2.3", b"1.2.3.4.5.6.7.8.9", b"11..2.3.4.5 999.1.1.1.",
+                b"a1.2.3.4\n5.6.7.8", b"\n" * 100, b"9" * 5000, b"1.2.3.4" * 3000, b"." * 70000]:
+        _check(oracle, pat, hay)
+    for hay in [b"", b"a", b"hello world", b"  abc123  DEF_456  ", b"!@# $%^", b"x" * 40000, b"ab " * 30000]:
+        _check(oracle, r"[\w]+", hay)
+    for hay in [b"", b"error", b"xerrorx", b"errerror", b"erro", b"error" * 5000, b"e" * 20000]:
+        _check(oracle, r"error", hay)
+
+
+def test_tile_and_chunk_boundaries(need_gpu, oracle):
+    """Matches straddling every 64-byte lane chunk and the 16 KiB tile edge, lengths around the tile size."""
+    pat = r"\d+\.\d+\.\d+\.\d+"
+    base = np.full(3 * 16384 + 300, ord("x"), dtype=np.uint8)
+    ip = np.frombuffer(b"192.168.100.200", dtype=np.uint8)
+    for off in list(range(16384 - 20, 16384 + 5)) + list(range(40, 70)) + [2 * 16384 - 7, 3 * 16384 + 280]:
+        hay = base.copy()
+        hay[off:off + len(ip)] = ip
+        _check(oracle, pat, hay)
+    for n in (16383, 16384, 16385, 16384 + 255, 16384 + 256, 16384 + 257, 32768):
+        hay = np.frombuffer((b"10.0.0.1 - " * 4000)[:n], dtype=np.uint8)
+        _check(oracle, pat, hay)
+        _check(oracle, r"[\w]+", hay)
+        _check(oracle, r"error", np.frombuffer((b"an error; " * 4000)[:n], dtype=np.uint8))
+
+
+def test_random_inputs(need_gpu, oracle):
+    rng = np.random.default_rng(2024)
+    alphabet = np.frombuffer(b"0123456789. ab\ncdxy@_eror:", dtype=np.uint8)
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"\d+\.\d", r"[0-5]+x", r"\d{1,3}\.\d{1,3}", r"ab|abc", r"[1-9][0-9]*|0"]
+    for pat in pats:
+        for n in (1, 17, 63, 64, 65, 1000, 16384, 50000):
+            hay = alphabet[rng.integers(0, len(alphabet), size=n)]
+            _check(oracle, pat, hay)
+
+
+def test_no_sync_bytes(need_gpu, oracle):
+    """Only pattern-alphabet bytes: one lane ends up walking far past its tile (HBM fallback path)."""
+    hay = (b"1.2.3.4.5.6.7.8.9..10.11.12.13" * 2000)
+    _check(oracle, r"\d+\.\d+\.\d+\.\d+", hay)
+    _check(oracle, r"[\w]+", b"a" * 100000)
+
+
+def test_dense_matches_take_the_direct_write_path(need_gpu, oracle):
+    """> 1024 matches per 16 KiB tile overflow the LDS record buffer."""
+    hay = b"1.2 " * 20000
+    _check(oracle, r"\d+\.\d", hay)
+    _check(oracle, r"[\w]+", b"a " * 40000)      # > 3072 runs per tile
+
+
+def test_capacity_and_limit(need_gpu):
+    import ctypes as C
+    from coregex_amd import _lib
+    rx = cx.compile(r"[\w]+")
+    hay = np.frombuffer(b"aa bb cc dd ee ff", dtype=np.uint8)
+    out = np.zeros((2, 2), dtype=np.int64)
+    got = C.c_uint64(0)
+    rc = _lib.lib().cxg_find_all(rx._h, hay.ctypes.data, hay.size, -1, out.ctypes.data, 2, C.byref(got))
+    assert rc == _lib.CXG_E_CAPACITY and got.value == 6
+    rc = _lib.lib().cxg_find_all(rx._h, hay.ctypes.data, hay.size, 2, out.ctypes.data, 2, C.byref(got))
+    assert rc == 0 and got.value == 2 and out.tolist() == [[0, 2], [3, 5]]
+
+
+def test_synth_corpus_device_equals_host_twin(need_gpu):
+    for cfg in (1, 2, 3, 4, 5):
+        buf = cx.DeviceBuffer(64 * 4096)
+        buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 100)
+        assert np.array_equal(buf.download(0, 64 * 4096), cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 100, 64))
+
+
+@pytest.mark.parametrize("cfg,pat", [(2, r"\d+\.\d+\.\d+\.\d+"), (4, r"[\w]+"), (1, r"error")])
+def test_device_resident_corpus_64mib(need_gpu, oracle, cfg, pat):
+    """Full comparison against the oracle on 64 MiB of synthlog-v1 resident in HBM, plus
+    shard concatenation: FindAll(whole) == concat(FindAll(page-aligned shards) + base)."""
+    import torch
+    npages = 16384
+    nbytes = npages * 4096
+    buf = cx.DeviceBuffer(nbytes)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+    host = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 0, npages)
+    exp = oracle.Regex(pat).find_all_index(host)
+    rx = cx.compile(pat)
+    n = rx.find_all_device(buf.ptr, nbytes)
+    assert n == len(exp)
+    out = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    n2 = rx.find_all_device(buf.ptr, nbytes, out.data_ptr(), n + 8, timing=t)
+    assert n2 == n and t.kernel_ms > 0
+    got = out[:n].cpu().numpy()
+    assert np.array_equal(got, exp)
+    # shards at page boundaries, rebased with `base`
+    parts = []
+    cuts = [0, 5000 * 4096, 11111 * 4096, nbytes]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        k = rx.find_all_device(buf.ptr + lo, hi - lo, out.data_ptr(), n + 8, base=lo)
+        parts.append(out[:k].cpu().numpy().copy())
+    assert np.array_equal(np.concatenate(parts), exp)
+    assert zlib.crc32(got.tobytes()) == zlib.crc32(exp.tobytes())

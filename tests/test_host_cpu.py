@@ -1,0 +1,149 @@
+"""CPU tier (`-m "not gpu"`): the C-ABI library loads and exports what the header declares, the host
+front-end agrees with the oracle (strategy, NFA size), and the device lane walks — compiled for the
+host by tests/emu — reproduce the oracle's spans for every chunk geometry.  No GPU compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from coregex_amd import _lib
+from refcorpus import COMPAT_PATTERNS, generate_test_input
+
+import emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "coregex_hip.h")).read()
+    declared = set(re.findall(r"\b(cxg_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"cxg_nfa"}
+    L = _lib.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(declared) == sorted(_lib.SYMBOLS)
+    assert L.cxg_version().startswith(b"coregex_hip")
+
+
+def test_no_gpu_means_loud_failure():
+    if cx.device_count() > 0:
+        pytest.skip("a GPU is present")
+    rx = cx.compile(r"\d+\.\d+\.\d+\.\d+")
+    with pytest.raises(cx.CoregexError) as ei:
+        rx.find_all_index(b"1.2.3.4")
+    assert ei.value.code == _lib.CXG_E_NO_GPU
+
+
+PATTERNS = [
+    r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"error|warning|fatal|critical", r"(\w+)@(\w+)\.(\w+)",
+    r"\d+\.\d+\.\d+", r"\d+:\d+:\d+", r"[a-z]+", r"[0-9a-f]+", r"ab", r"a", r"ab|abc", r"((a+)(b+))", r"a+?",
+    r"[a-zA-Z]+[0-9]+", r"\w+[0-9]+", r"(\w)+", r"25[0-5]|2[0-4][0-9]|1[0-9][0-9]|[1-9][0-9]|[0-9]",
+    r"(?:0[0-9]|1[0-9]|2[0-3]):[0-5][0-9]:[0-5][0-9]", r"[1-9][0-9]*|0", r"foo|bar|baz", r"[a-f0-9]{32,}",
+    r"apple|banana|cherry|date|elderberry|fig|grape|honeydew|kiwi|lemon|mango|orange", r"x[ab]+?y", r"(a|ab)(c|bcd)",
+    r"\d{1,3}\.\d{1,3}", r"[0-5]+x", r"(foo|foobar)\d+", r"ERROR|WARN", r"a{2,4}b", r"(?:ab)*c", r"a||b", r"[a-c]|x|yz",
+]
+
+
+@pytest.mark.parametrize("pat", PATTERNS)
+def test_frontend_agrees_with_oracle(oracle, pat):
+    o = oracle.Regex(pat)
+    p = cx.compile(pat)
+    assert p.nfa_states == o.nfa_states, pat
+    assert p.num_groups == o.num_groups
+    if o.strategy_restated:
+        assert p.strategy == o.strategy, pat
+
+
+def test_nfa_view_matches_oracle_dump(oracle):
+    """State-by-state comparison of the product NFA with the oracle's (creation order is semantic)."""
+    kinds = {0: "Match", 1: "ByteRange", 2: "Sparse", 3: "Split", 4: "Eps", 5: "Cap"}
+    for pat in PATTERNS:
+        p = cx.compile(pat)
+        v = p.nfa()
+        lines = oracle.Regex(pat).dump().strip().split("\n")[2:]
+        assert len(lines) == v.n_states, pat
+        for i, line in enumerate(lines):
+            st = v.states[i]
+            body = line.split(": ", 1)[1]
+            k = kinds[st.kind]
+            if k == "Split":
+                assert body.endswith(f"Split({st.left},{st.right})"), (pat, i, body)
+            elif k == "ByteRange":
+                assert body == f"ByteRange[{st.lo}-{st.hi}]->{st.next}", (pat, i, body)
+            elif k == "Sparse":
+                exp = "Sparse" + "".join(
+                    f" [{v.trans[st.trans_off + j].lo}-{v.trans[st.trans_off + j].hi}]->{v.trans[st.trans_off + j].next}"
+                    for j in range(st.trans_len))
+                assert body == exp, (pat, i, body)
+            elif k == "Match":
+                assert body == "Match"
+            elif k == "Cap":
+                assert body == f"Cap{st.cap_index}{'(' if st.cap_start else ')'}->{st.next}", (pat, i, body)
+            else:
+                nxt = -1 if st.next == 0xFFFFFFFF else st.next
+                assert body == f"Eps->{nxt}", (pat, i, body)
+
+
+EMU_PATTERNS = [p for p in PATTERNS]
+
+
+@pytest.mark.parametrize("chunk", [4, 16, 64])
+def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
+    corpus = generate_test_input()
+    n_checked = 0
+    for name, pat in COMPAT_PATTERNS.items():
+        try:
+            p = cx.compile(pat)
+        except cx.CoregexError:
+            continue
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA"):
+            continue
+        got = emu.find_all(p.blob(), corpus, chunk)
+        exp = oracle.Regex(pat).find_all_index(corpus)
+        assert got.tolist() == exp.tolist(), (name, chunk)
+        n_checked += 1
+    assert n_checked >= 5
+
+
+def test_emulated_lane_walks_random(oracle):
+    rng = np.random.default_rng(7)
+    alphabet = np.frombuffer(b"0123456789. ab\ncdxy@_eror:", dtype=np.uint8)
+    tried = 0
+    for pat in EMU_PATTERNS:
+        p = cx.compile(pat)
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA"):
+            continue
+        o = oracle.Regex(pat)
+        blob = p.blob()
+        tried += 1
+        for it in range(120):
+            n = int(rng.integers(0, 700))
+            hay = alphabet[rng.integers(0, len(alphabet), size=n)].tobytes()
+            exp = o.find_all_index(hay).tolist()
+            for chunk in (4, 8, 64):
+                got = emu.find_all(blob, hay, chunk).tolist()
+                assert got == exp, (pat, chunk, hay)
+    assert tried >= 10
+
+
+def test_emulated_no_sync_bytes_at_all(oracle):
+    """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
+    pat = r"\d+\.\d+\.\d+\.\d+"
+    p = cx.compile(pat)
+    hay = (b"1.2.3.4.5.6.7.8.9..10.11.12.13" * 40)
+    assert emu.find_all(p.blob(), hay, 8).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+
+
+def test_synth_corpus_is_frozen():
+    """synthlog-v1 must not drift: checksum of the first 16 pages of every config."""
+    import zlib
+    sums = {c: zlib.crc32(cx.synth_pages(c, 0xC0FFEE00 + c, 0, 16).tobytes()) for c in (1, 2, 3, 4, 5)}
+    frozen = SYNTH_CRC
+    assert sums == frozen, sums
+    pg = cx.synth_pages(2, 0xC0FFEE02, 5, 2)
+    assert pg[4095] == 10 and pg[8191] == 10 and pg.max() < 128
+
+
+SYNTH_CRC = {1: 1650641072, 2: 4080580921, 3: 4062772577, 4: 2183380067, 5: 32623048}
