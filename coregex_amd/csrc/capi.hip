@@ -21,6 +21,7 @@ namespace cxgdev {
 hipError_t launch_scan_dfa(uint32_t kind, const ScanArgs& a, uint32_t fwd_states, uint32_t rev_states, hipStream_t stream);
 size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
+hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -112,6 +113,12 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
+// CXG_DIGIT_KERNEL=1 selects the first-generation nested-loop kernel (kept for A/B profiling).
+int digitKernelGeneration() {
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 2; }();
+  return g;
+}
+
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
@@ -150,7 +157,11 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   switch (h->kind) {
-    case cxgdev::kKindDigit: case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
+    case cxgdev::kKindDigit:
+      if (digitKernelGeneration() == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
+      else le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
+      break;
+    case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
     case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;
     case cxgdev::kKindTeddy: le = cxgdev::launch_scan_teddy(a, stream); break;
     default: return fail(CXG_E_INTERNAL, "unknown program kind");

@@ -63,6 +63,7 @@ CXG_HD uint32_t digit_mask4(uint32_t x) {
   const uint32_t nd = (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
   return nd ^ 0x80808080u;
 }
+CXG_HD uint32_t ctz64(uint64_t v) { return static_cast<uint32_t>(__builtin_ctzll(v)); }
 CXG_HD uint32_t ctz32(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return static_cast<uint32_t>(__builtin_ctz(v));
@@ -140,6 +141,91 @@ CXG_HD void lane_digit(const Mem& m, const DfaView& d, const uint8_t* info, bool
       pos = dpos + 1;                      // find_indices.go:1079-1084
       if (skip_safe)
         while (pos < rend && is_digit(m.byte(pos))) pos++;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flat form of lane_digit for SIMT execution.  Same algorithm, restructured so that a wave's lanes
+// stay convergent: ONE loop whose every iteration is one DFA transition for every live lane; the
+// prefilter ("next digit at >= pos", "end of this digit run") is answered in O(1) from a bitmap of
+// digit positions that the kernel builds while it stages the tile (the bit-parallel counterpart of
+// memchrDigitAVX2).  Ownership is resolved once up front: the lane's candidates are exactly the
+// digit positions below `stop`, the first segment start at or after c1 (see lane_digit: a verify can
+// never step over a sync byte, so the reference's scan always arrives at `stop` and ends there).
+//
+// Extra Mem concept: uint64_t digits(int32_t w) -> bit k set iff byte 64*w+k is an ASCII digit, valid
+// for bytes below bitmap_limit() (bits at or beyond it read 0); int32_t bitmap_limit().
+
+template <class Mem>
+CXG_HD int32_t next_digit(const Mem& m, int32_t pos, int32_t limit) {
+  const int32_t blim = m.bitmap_limit();
+  while (pos < limit) {
+    if (pos < blim) {
+      const uint64_t w = m.digits(pos >> 6) >> (pos & 63);
+      if (w) return pos + static_cast<int32_t>(ctz64(w));
+      pos = (pos | 63) + 1;
+    } else {
+      if (is_digit(m.byte(pos))) return pos;
+      pos++;
+    }
+  }
+  return limit;
+}
+
+template <class Mem>
+CXG_HD int32_t next_nondigit(const Mem& m, int32_t pos, int32_t rend) {
+  const int32_t blim = m.bitmap_limit();
+  while (pos < rend && pos < blim) {
+    const uint64_t nd = (~m.digits(pos >> 6)) >> (pos & 63);   // logical shift: vacated top bits read "digit"
+    if (nd) {
+      const int32_t p = pos + static_cast<int32_t>(ctz64(nd));
+      if (p < blim) return p;          // blim <= rend
+      pos = blim;                      // bits at/after blim are not real data: continue byte-wise
+      break;
+    }
+    pos = (pos | 63) + 1;
+  }
+  while (pos < rend && is_digit(m.byte(pos))) pos++;
+  return pos < rend ? pos : rend;
+}
+
+template <class Mem, class Sink>
+CXG_HD void lane_digit_flat(const Mem& m, const DfaView& d, const uint8_t* info, bool skip_safe, int32_t c0,
+                            int32_t c1, int32_t rend, bool chunk_at_origin, Sink& sink) {
+  int32_t pos = first_owned_start(m, info, c0, c1, rend, chunk_at_origin);
+  if (pos < 0) return;
+  int32_t stop = c1 - 1;
+  while (stop < rend && !(info[m.byte(stop)] & kInfoSync)) stop++;
+  stop = stop < rend ? stop + 1 : rend;
+  bool need = true;
+  uint32_t q = 0, cur = 0;
+  int32_t last = -1, i = 0, dpos = 0;
+  for (;;) {
+    if (need) {
+      dpos = next_digit(m, pos, stop);
+      if (dpos >= stop) break;
+      q = d.start; last = -1; i = dpos; need = false;
+      cur = m.byte(i);
+    }
+    if (q >= d.first_accept) last = i;
+    bool end = i >= rend;
+    if (!end) {
+      const int32_t ni = i + 1 < rend ? i + 1 : i;     // speculative fetch of the next byte, off the q chain
+      const uint32_t nxt = m.byte(ni);
+      q = d.T[q * d.stride + cur];
+      cur = nxt;
+      if (q == 0) end = true; else i++;
+    }
+    if (end) {
+      if (last >= 0) {
+        sink.emit(dpos, last);
+        pos = last > dpos ? last : dpos + 1;
+      } else {
+        pos = dpos + 1;
+        if (skip_safe) pos = next_nondigit(m, pos, rend);
+      }
+      need = true;
     }
   }
 }

@@ -16,19 +16,19 @@ def lib():
         subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "emu")])
         L = C.CDLL(_PATH)
         L.emu_find_all.restype = C.c_int64
-        L.emu_find_all.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64]
+        L.emu_find_all.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_int]
         _lib = L
     return _lib
 
 
-def find_all(blob: bytes, hay, chunk: int = 64) -> np.ndarray:
+def find_all(blob: bytes, hay, chunk: int = 64, flat: bool = False) -> np.ndarray:
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     # pad so the emulator's dword reads near the end stay inside the allocation
     padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
     cap = 1 << 12
     while True:
         out = np.empty(cap, dtype=np.int64)
-        n = lib().emu_find_all(blob, padded.ctypes.data, a.size, chunk, out.ctypes.data, cap)
+        n = lib().emu_find_all(blob, padded.ctypes.data, a.size, chunk, out.ctypes.data, cap, int(flat))
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
             return out[:n].reshape(-1, 2).copy()

@@ -18,6 +18,9 @@ namespace {
 struct HostMem {
   const uint8_t* g;   // hay + tile_lo
   int32_t lim;
+  const uint64_t* bits = nullptr;   // digit bitmap of the staged bytes (flat walk)
+  uint64_t digits(int32_t w) const { return bits[w]; }
+  int32_t bitmap_limit() const { return lim; }
   uint32_t byte(int32_t r) const { return g[r]; }
   uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
   int32_t wide_limit(int32_t x) const { return x < lim ? x : lim; }
@@ -30,7 +33,7 @@ struct VecSink {
 }  // namespace
 
 extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_t len, int chunk, int64_t* out,
-                                int64_t cap_vals) {
+                                int64_t cap_vals, int flat) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic) return -1;
   const uint8_t* info = blob + h->info_off;
@@ -44,13 +47,18 @@ extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_
     const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
     const int32_t stage = rend < static_cast<int32_t>(tile_bytes) + kHalo ? rend : static_cast<int32_t>(tile_bytes) + kHalo;
     HostMem m{hay + tile_lo, stage};
+    std::vector<uint64_t> bits((static_cast<size_t>(stage) + 63) / 64 + 2, 0);
+    for (int32_t k = 0; k < stage; k++)
+      if (is_digit(hay[tile_lo + k])) bits[k >> 6] |= 1ull << (k & 63);
+    m.bits = bits.data();
     VecSink sink{&res, static_cast<int64_t>(tile_lo)};
     for (int lane = 0; lane < lanes; lane++) {
       const int32_t c0 = lane * chunk, c1 = c0 + chunk;
       const bool at_origin = tile_lo == 0 && lane == 0;
       if (h->kind == kKindDigit) {
         DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
-        lane_digit(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
+        if (flat) lane_digit_flat(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
+        else lane_digit(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
       } else if (h->kind == kKindBidir) {
         DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
         DfaView r{blob + h->rev_off, 256, h->rev_start, h->rev_first_accept};

@@ -103,6 +103,8 @@ def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
         got = emu.find_all(p.blob(), corpus, chunk)
         exp = oracle.Regex(pat).find_all_index(corpus)
         assert got.tolist() == exp.tolist(), (name, chunk)
+        if p.strategy == "UseDigitPrefilter":
+            assert emu.find_all(p.blob(), corpus, chunk, flat=True).tolist() == exp.tolist(), (name, chunk, "flat")
         n_checked += 1
     assert n_checked >= 5
 
@@ -125,6 +127,8 @@ def test_emulated_lane_walks_random(oracle):
             for chunk in (4, 8, 64):
                 got = emu.find_all(blob, hay, chunk).tolist()
                 assert got == exp, (pat, chunk, hay)
+                if p.strategy == "UseDigitPrefilter":
+                    assert emu.find_all(blob, hay, chunk, flat=True).tolist() == exp, (pat, chunk, hay, "flat")
     assert tried >= 10
 
 
@@ -134,6 +138,7 @@ def test_emulated_no_sync_bytes_at_all(oracle):
     p = cx.compile(pat)
     hay = (b"1.2.3.4.5.6.7.8.9..10.11.12.13" * 40)
     assert emu.find_all(p.blob(), hay, 8).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+    assert emu.find_all(p.blob(), hay, 8, flat=True).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
 
 
 def test_synth_corpus_is_frozen():
