@@ -66,6 +66,7 @@ struct Scratch {
   uint64_t* status = nullptr;
   uint64_t statusCap = 0;
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
+  uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
   uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
 };
@@ -151,6 +152,15 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl);
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
+  static const bool profOn = getenv("CXG_PROF") != nullptr;
+  static const uint32_t dbgBits = getenv("CXG_DEBUG") ? static_cast<uint32_t>(atoi(getenv("CXG_DEBUG"))) : 0u;
+  a.prof = nullptr;
+  a.dbg = dbgBits;
+  if (profOn) {
+    if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 64));
+    HIP_TRY(hipMemsetAsync(s.prof, 0, 64, stream));
+    a.prof = s.prof;
+  }
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
@@ -179,7 +189,16 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = 1;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
   }
+  if (profOn) {
+    uint64_t pc[8];
+    HIP_TRY(hipMemcpy(pc, s.prof, 64, hipMemcpyDeviceToHost));
+    if (pc[5])
+      fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
+              (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
+              (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
+  }
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
+  if (dbgBits) { if (n_out) *n_out = total; return CXG_OK; }
   uint64_t n = total;
   if (limit > 0 && n > static_cast<uint64_t>(limit)) n = static_cast<uint64_t>(limit);
   if (n_out) *n_out = n;

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
   __shared__ uint64_t s_base;
 
   const int tid = threadIdx.x;
+  const uint64_t t0 = a.prof ? clock64() : 0;
   if (tid == 0) {
     s_tile_id = atomicAdd(a.ticket, 1u);
     s_rec_count = 0;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
     if (tid < 64) reinterpret_cast<uint32_t*>(s_info)[tid] = reinterpret_cast<const uint32_t*>(a.blob + h->info_off)[tid];
   }
   __syncthreads();
+  const uint64_t t1 = a.prof ? clock64() : 0;
   const uint64_t tile = s_tile_id;
   if (tile >= a.ntiles) return;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
     }
   }
   __syncthreads();
+  const uint64_t t2 = a.prof ? clock64() : 0;
 
   FlatMem m{s_tile, s_bits, g, stage};
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
@@ -146,13 +149,29 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
   const bool at_origin = (tile_lo == 0 && tid == 0);
 
   RecSink2 sink{s_recs, &s_rec_count, static_cast<uint32_t>(tid), 0u};
-  lane_digit_flat(m, fv, s_info, skip_safe, c0, c1, rend, at_origin, sink);
+  if (!(a.dbg & 1u)) lane_digit_flat(m, fv, s_info, skip_safe, c0, c1, rend, at_origin, sink);
   if (sink.n > 0xFFFFu) atomicOr(a.err, 1u);
+  const uint64_t t3 = a.prof ? clock64() : 0;
 
   uint32_t total;
   const uint32_t excl = block_exclusive_scan(sink.n, s_wsum, total);
   s_cnt[tid] = excl;
-  tile_lookback(a.status, a.total, a.err, tile, a.ntiles, total, &s_base);
+  const uint64_t t4 = a.prof ? clock64() : 0;
+  if (a.dbg & 2u) {
+    if (tid == 0) { s_base = atomicAdd(reinterpret_cast<unsigned long long*>(a.total), static_cast<unsigned long long>(total)); }
+    __syncthreads();
+  } else {
+    tile_lookback(a.status, a.total, a.err, tile, a.ntiles, total, &s_base);
+  }
+  const uint64_t t5 = a.prof ? clock64() : 0;
+  if (a.prof && (tid & 63) == 0) {   // per wave: phase cycles (stage tables, stage tile, walk, scan, look-back)
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 0), static_cast<unsigned long long>(t1 - t0));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 1), static_cast<unsigned long long>(t2 - t1));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 2), static_cast<unsigned long long>(t3 - t2));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 3), static_cast<unsigned long long>(t4 - t3));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 4), static_cast<unsigned long long>(t5 - t4));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 5), 1ull);
+  }
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(tile_lo);
   if (a.out == nullptr) return;

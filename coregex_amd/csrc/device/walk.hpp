@@ -230,6 +230,85 @@ CXG_HD void lane_digit_flat(const Mem& m, const DfaView& d, const uint8_t* info,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// UseTeddy: FindAll over an exact literal alternation (meta/find_indices.go:925-951 ->
+// prefilter.Teddy.FindMatch, prefilter/teddy.go:391-444).  The reference finds fingerprint
+// candidates with nibble-mask shuffles (teddy_ssse3_amd64.s:273: a position is a candidate when
+// lo[0][b0&15] & hi[0][b0>>4] & lo[1][b1&15] & hi[1][b1>>4] != 0 for its first two bytes) and then
+// compares the literals of each hit bucket, buckets low to high, ids ascending (verifyBucket
+// teddy.go:532-550).  lo&hi of one byte depend only on that byte, so the device tables hold the
+// products directly: AB[b] = A | B<<8 with A = lo[0]&hi[0], B = lo[1]&hi[1]; the kernel turns them
+// into one candidate bit per haystack byte while staging the tile.
+// Restriction (checked on the host): the literal set is prefix-free, so at most one literal matches at
+// a position and the bucket-major / position-major order difference of the reference's two code
+// paths (teddy.go:400-403,447-458) cannot be observed.
+
+struct TeddyView {
+  const uint16_t* ab;      // [256]
+  const uint8_t* order;    // literal ids, bucket-major then id
+  const uint8_t* lens;     // by id
+  const uint8_t* bucket;   // by id
+  const uint16_t* off;     // by id, into bytes
+  const uint8_t* bytes;
+  uint32_t nlits;
+};
+
+struct TeddyAux {           // layout of the blob's aux section (all offsets relative to aux start)
+  uint32_t nlits, nbuckets, minlen, maxlen;
+  uint32_t ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len, _pad;
+};
+
+template <class Mem>
+CXG_HD uint32_t teddy_mask_at(const Mem& m, const TeddyView& t, int32_t i, int32_t rend) {
+  if (i + 1 >= rend) return 0;
+  return (t.ab[m.byte(i)] & 0xFFu) & (t.ab[m.byte(i + 1)] >> 8);
+}
+
+// Mem concept adds: uint64_t cands(int32_t w), int32_t bitmap_limit().
+template <class Mem>
+CXG_HD int32_t next_cand(const Mem& m, const TeddyView& t, int32_t pos, int32_t limit, int32_t rend) {
+  const int32_t blim = m.bitmap_limit();
+  while (pos < limit) {
+    if (pos < blim) {
+      const uint64_t w = m.cands(pos >> 6) >> (pos & 63);
+      if (w) return pos + static_cast<int32_t>(ctz64(w));
+      pos = (pos | 63) + 1;
+    } else {
+      if (teddy_mask_at(m, t, pos, rend)) return pos;
+      pos++;
+    }
+  }
+  return limit;
+}
+
+template <class Mem, class Sink>
+CXG_HD void lane_teddy(const Mem& m, const TeddyView& t, const uint8_t* info, int32_t c0, int32_t c1, int32_t rend,
+                       bool chunk_at_origin, Sink& sink) {
+  int32_t pos = first_owned_start(m, info, c0, c1, rend, chunk_at_origin);
+  if (pos < 0) return;
+  int32_t stop = c1 - 1;
+  while (stop < rend && !(info[m.byte(stop)] & kInfoSync)) stop++;
+  stop = stop < rend ? stop + 1 : rend;
+  for (;;) {
+    const int32_t c = next_cand(m, t, pos, stop, rend);
+    if (c >= stop) return;
+    const uint32_t mask = teddy_mask_at(m, t, c, rend);
+    int32_t mlen = 0;
+    for (uint32_t k = 0; k < t.nlits && !mlen; k++) {
+      const uint32_t id = t.order[k];
+      if (!((mask >> t.bucket[id]) & 1u)) continue;
+      const int32_t len = t.lens[id];
+      if (c + len > rend) continue;
+      const uint8_t* lit = t.bytes + t.off[id];
+      int32_t j = 0;
+      while (j < len && m.byte(c + j) == lit[j]) j++;
+      if (j == len) mlen = len;
+    }
+    if (mlen) { sink.emit(c, c + mlen); pos = c + mlen; }
+    else pos = c + 1;
+  }
+}
+
 template <class Mem, class Sink>
 CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const uint8_t* info, int32_t c0, int32_t c1,
                        int32_t rend, bool chunk_at_origin, Sink& sink) {

@@ -292,11 +292,73 @@ void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], ui
 }
 
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits) {
+  // NewTeddy / buildMasks (prefilter/teddy.go:189-311): 2..32 literals of >= 3 bytes, bucket = id mod 8,
+  // 2-byte fingerprint.  33..64 literals (Fat Teddy) and > 64 (Aho-Corasick) are outside the device subset.
   p->strategy = CXG_USE_TEDDY;
   p->ngroups = 1;
   p->supported = false;
-  p->whyNot = "Teddy device kernel not built yet";
-  (void)lits;
+  if (lits.size() < 2 || lits.size() > 32) { p->whyNot = "Slim Teddy takes 2..32 literals"; return; }
+  size_t minlen = SIZE_MAX, maxlen = 0;
+  for (auto& l : lits) { minlen = std::min(minlen, l.size()); maxlen = std::max(maxlen, l.size()); }
+  if (minlen < 3) { p->whyNot = "Teddy literal shorter than 3 bytes"; return; }
+  if (maxlen > 255) { p->whyNot = "Teddy literal longer than 255 bytes"; return; }
+  for (size_t i = 0; i < lits.size(); i++)
+    for (size_t j = 0; j < lits.size(); j++)
+      if (i != j && lits[i].size() <= lits[j].size() && std::equal(lits[i].begin(), lits[i].end(), lits[j].begin())) {
+        p->whyNot = "literal set is not prefix-free (the reference's verification order becomes observable)";
+        return;
+      }
+  const uint32_t nb = static_cast<uint32_t>(std::min<size_t>(8, lits.size()));
+  uint16_t ab[256] = {0};
+  {
+    uint8_t lo[2][16] = {{0}}, hi[2][16] = {{0}};
+    for (size_t id = 0; id < lits.size(); id++) {
+      const uint8_t bit = static_cast<uint8_t>(1u << (id % nb));
+      for (int pos = 0; pos < 2; pos++) { lo[pos][lits[id][pos] & 15] |= bit; hi[pos][lits[id][pos] >> 4] |= bit; }
+    }
+    for (int b = 0; b < 256; b++) ab[b] = static_cast<uint16_t>((lo[0][b & 15] & hi[0][b >> 4]) | ((lo[1][b & 15] & hi[1][b >> 4]) << 8));
+  }
+  cxgdev::BlobHeader h;
+  std::memset(&h, 0, sizeof h);
+  h.magic = cxgdev::kBlobMagic;
+  h.kind = cxgdev::kKindTeddy;
+  h.ngroups = 1;
+  std::vector<uint8_t> blob(sizeof h, 0);
+  h.info_off = static_cast<uint32_t>(blob.size());
+  bool inAlpha[256] = {false};
+  for (auto& l : lits) for (uint8_t b : l) inAlpha[b] = true;
+  for (int b = 0; b < 256; b++) blob.push_back(inAlpha[b] ? 0 : cxgdev::kInfoSync);
+  h.aux_off = static_cast<uint32_t>(blob.size());
+  cxgdev::TeddyAux ax;
+  std::memset(&ax, 0, sizeof ax);
+  ax.nlits = static_cast<uint32_t>(lits.size()); ax.nbuckets = nb; ax.minlen = static_cast<uint32_t>(minlen); ax.maxlen = static_cast<uint32_t>(maxlen);
+  std::vector<uint8_t> aux(sizeof ax, 0);
+  auto align = [&](size_t a) { while (aux.size() % a) aux.push_back(0); };
+  ax.ab_off = static_cast<uint32_t>(aux.size());
+  aux.insert(aux.end(), reinterpret_cast<uint8_t*>(ab), reinterpret_cast<uint8_t*>(ab) + sizeof ab);
+  ax.order_off = static_cast<uint32_t>(aux.size());
+  for (uint32_t b = 0; b < nb; b++) for (size_t id = b; id < lits.size(); id += nb) aux.push_back(static_cast<uint8_t>(id));
+  align(4);
+  ax.lens_off = static_cast<uint32_t>(aux.size());
+  for (auto& l : lits) aux.push_back(static_cast<uint8_t>(l.size()));
+  align(4);
+  ax.bucket_off = static_cast<uint32_t>(aux.size());
+  for (size_t id = 0; id < lits.size(); id++) aux.push_back(static_cast<uint8_t>(id % nb));
+  align(4);
+  ax.off_off = static_cast<uint32_t>(aux.size());
+  { uint16_t o = 0; for (auto& l : lits) { aux.push_back(o & 0xFF); aux.push_back(o >> 8); o = static_cast<uint16_t>(o + l.size()); } }
+  align(4);
+  ax.bytes_off = static_cast<uint32_t>(aux.size());
+  for (auto& l : lits) aux.insert(aux.end(), l.begin(), l.end());
+  ax.bytes_len = static_cast<uint32_t>(aux.size()) - ax.bytes_off;
+  align(16);
+  std::memcpy(aux.data(), &ax, sizeof ax);
+  h.aux_len = static_cast<uint32_t>(aux.size());
+  blob.insert(blob.end(), aux.begin(), aux.end());
+  h.total_bytes = static_cast<uint32_t>(blob.size());
+  std::memcpy(blob.data(), &h, sizeof h);
+  p->blob.swap(blob);
+  p->supported = true;
 }
 
 }  // namespace cxg
