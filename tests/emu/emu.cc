@@ -20,6 +20,8 @@ struct HostMem {
   int32_t lim;
   const uint64_t* bits = nullptr;   // digit bitmap of the staged bytes (flat walk)
   uint64_t digits(int32_t w) const { return bits[w]; }
+  const uint64_t* cbits = nullptr;  // Teddy candidate bitmap
+  uint64_t cands(int32_t w) const { return cbits[w]; }
   int32_t bitmap_limit() const { return lim; }
   uint32_t byte(int32_t r) const { return g[r]; }
   uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
@@ -51,6 +53,7 @@ extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_
     for (int32_t k = 0; k < stage; k++)
       if (is_digit(hay[tile_lo + k])) bits[k >> 6] |= 1ull << (k & 63);
     m.bits = bits.data();
+    std::vector<uint64_t> cbits;
     VecSink sink{&res, static_cast<int64_t>(tile_lo)};
     for (int lane = 0; lane < lanes; lane++) {
       const int32_t c0 = lane * chunk, c1 = c0 + chunk;
@@ -63,6 +66,18 @@ extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_
         DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
         DfaView r{blob + h->rev_off, 256, h->rev_start, h->rev_first_accept};
         lane_bidir(m, f, r, info, c0, c1, rend, at_origin, sink);
+      } else if (h->kind == kKindTeddy) {
+        const uint8_t* aux = blob + h->aux_off;
+        const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(aux);
+        TeddyView tv{reinterpret_cast<const uint16_t*>(aux + ax->ab_off), aux + ax->order_off, aux + ax->lens_off,
+                     aux + ax->bucket_off, reinterpret_cast<const uint16_t*>(aux + ax->off_off), aux + ax->bytes_off, ax->nlits};
+        if (lane == 0) {
+          cbits.assign((static_cast<size_t>(stage) + 63) / 64 + 2, 0);
+          for (int32_t k = 0; k < stage; k++)
+            if (teddy_mask_at(m, tv, k, rend)) cbits[k >> 6] |= 1ull << (k & 63);
+          m.cbits = cbits.data();
+        }
+        lane_teddy(m, tv, info, c0, c1, rend, at_origin, sink);
       } else {
         return -2;
       }

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEVICE_PATTERNS = {
     "la_ips": r"\d+\.\d+\.\d+\.\d+", "version": r"\d+\.\d+\.\d+", "la_peak_hours": COMPAT_PATTERNS["la_peak_hours"],
     "ip": COMPAT_PATTERNS["ip"], "char_class": r"[\w]+", "error_literal": r"error", "alternation_overlap": r"ab|abc",
-    "nested_groups_as_index": r"((a+)(b+))", "non_greedy_has_no_reverse": r"a+?", "digits": r"[0-9]+", "lower": r"[a-z]+",
+    "nested_groups_as_index": r"((a+)(b+))", "literal_alt": COMPAT_PATTERNS["literal_alt"], "multi_literal": COMPAT_PATTERNS["multi_literal"], "non_greedy_has_no_reverse": r"a+?", "digits": r"[0-9]+", "lower": r"[a-z]+",
 }
 
 
@@ -56,6 +56,8 @@ def test_edge_cases(need_gpu, oracle):
         _check(oracle, r"[\w]+", hay)
     for hay in [b"", b"error", b"xerrorx", b"errerror", b"erro", b"error" * 5000, b"e" * 20000]:
         _check(oracle, r"error", hay)
+    for hay in [b"", b"fo", b"foo", b"xfoobarbaz", b"bazbazba", b"foo" * 7000, b"ba" * 20000, b"foobarbaz " * 3000]:
+        _check(oracle, r"foo|bar|baz", hay)
 
 
 def test_tile_and_chunk_boundaries(need_gpu, oracle):
@@ -118,7 +120,10 @@ def test_synth_corpus_device_equals_host_twin(need_gpu):
         assert np.array_equal(buf.download(0, 64 * 4096), cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 100, 64))
 
 
-@pytest.mark.parametrize("cfg,pat", [(2, r"\d+\.\d+\.\d+\.\d+"), (4, r"[\w]+"), (1, r"error")])
+LITS16 = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+
+
+@pytest.mark.parametrize("cfg,pat", [(2, r"\d+\.\d+\.\d+\.\d+"), (4, r"[\w]+"), (1, r"error"), (3, LITS16)])
 def test_device_resident_corpus_64mib(need_gpu, oracle, cfg, pat):
     """Full comparison against the oracle on 64 MiB of synthlog-v1 resident in HBM, plus
     shard concatenation: FindAll(whole) == concat(FindAll(page-aligned shards) + base)."""

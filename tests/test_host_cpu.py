@@ -98,7 +98,7 @@ def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
             p = cx.compile(pat)
         except cx.CoregexError:
             continue
-        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA"):
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy"):
             continue
         got = emu.find_all(p.blob(), corpus, chunk)
         exp = oracle.Regex(pat).find_all_index(corpus)
@@ -115,7 +115,7 @@ def test_emulated_lane_walks_random(oracle):
     tried = 0
     for pat in EMU_PATTERNS:
         p = cx.compile(pat)
-        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA"):
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy"):
             continue
         o = oracle.Regex(pat)
         blob = p.blob()
@@ -139,6 +139,24 @@ def test_emulated_no_sync_bytes_at_all(oracle):
     hay = (b"1.2.3.4.5.6.7.8.9..10.11.12.13" * 40)
     assert emu.find_all(p.blob(), hay, 8).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
     assert emu.find_all(p.blob(), hay, 8, flat=True).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+
+
+def test_teddy_programs(oracle):
+    """Teddy: prefix-free sets are accepted and reproduce the oracle; overlapping sets are refused."""
+    lits16 = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+    p = cx.compile(lits16)
+    assert p.strategy == "UseTeddy" and p.supported
+    o = oracle.Regex(lits16)
+    assert o.strategy == "UseTeddy" and o.strategy_restated
+    hay = cx.synth_pages(3, 0xC0FFEE03, 0, 64).tobytes()
+    exp = o.find_all_index(hay).tolist()
+    assert len(exp) > 500
+    for chunk in (4, 64):
+        assert emu.find_all(p.blob(), hay, chunk).tolist() == exp
+    tricky = b"errorerrorwarningwarnin fatalfatalities criticalcritica panicpanic xerrory erro error"
+    assert emu.find_all(p.blob(), tricky, 4).tolist() == o.find_all_index(tricky).tolist()
+    q = cx.compile("foobar|bazz|foo")   # not adjacent: regexp/syntax does not factor it, literals stay exact
+    assert q.strategy == "UseTeddy" and not q.supported and "prefix-free" in q.why_unsupported
 
 
 def test_synth_corpus_is_frozen():
