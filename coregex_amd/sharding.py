@@ -1,0 +1,63 @@
+"""Byte-range sharding of one corpus over the GPUs of a node.
+
+FindAll over a buffer equals the concatenation of FindAll over pieces cut right after a byte outside
+the pattern's alphabet, with offsets rebased — so each rank scans its own shard with the single-GPU
+kernel and there is **no collective on the data path**.  The only communication is optional result
+collection: `gather_rows` moves the (small) index arrays to rank 0 with `torch.distributed`
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PAGE = 4096  # synthlog pages end in '\n'; shards are cut at page boundaries
+
+
+def plan_shards(nbytes: int, world: int, page: int = PAGE):
+    """Contiguous [lo, hi) byte ranges, page aligned, sizes differing by at most one page."""
+    npages = (nbytes + page - 1) // page
+    base, extra = divmod(npages, world)
+    out, lo = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        hi = min(nbytes, lo + n * page)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def cut_is_safe(sync_table: np.ndarray, byte_before_cut: int) -> bool:
+    """A shard may start at `cut` iff hay[cut-1] is a sync byte of the program (info table bit 0)."""
+    return bool(sync_table[byte_before_cut] & 1)
+
+
+def sync_table_of(rx) -> np.ndarray:
+    """The 256-entry byte-info table of a compiled program (bit 0 = outside the pattern alphabet)."""
+    import struct
+    blob = rx.blob()
+    info_off = struct.unpack_from("<I", blob, 12 * 4)[0]
+    return np.frombuffer(blob, dtype=np.uint8, count=256, offset=info_off)
+
+
+def apply_limit(rows: np.ndarray, n: int) -> np.ndarray:
+    """`n > 0` limits are applied after concatenation (global prefix), as FindAllIndex(b, n) would."""
+    return rows if n <= 0 else rows[:n]
+
+
+def gather_rows(local_rows: np.ndarray, dist, device="cpu"):
+    """All ranks call; rank 0 receives the concatenation in rank order (already sorted by start)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    width = local_rows.shape[1]
+    cnt = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts + [1])
+    pad = torch.zeros((mx, width), dtype=torch.int64, device=device)
+    pad[: local_rows.shape[0]] = torch.from_numpy(np.ascontiguousarray(local_rows)).to(device)
+    bufs = [torch.zeros((mx, width), dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if rank != 0:
+        return None
+    return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], axis=0)

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world-size-2 gloo.  Each rank takes its page-aligned shard of one synthlog corpus,
+produces its rows (the device walks compiled for the host stand in for the GPU here), rebases them with
+`base`, and rank 0 gathers the concatenation — which must equal the oracle's FindAll over the whole
+corpus.  Also checks the cut-safety rule that makes shards independent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, pat, cfg, npages, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import coregex_amd as cx
+    from coregex_amd import sharding
+    import emu
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rx = cx.compile(pat)
+        nbytes = npages * 4096
+        lo, hi = sharding.plan_shards(nbytes, world)[rank]
+        shard = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, lo // 4096, (hi - lo) // 4096)
+        if lo > 0:
+            prev = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, lo // 4096 - 1, 1)[-1]
+            assert sharding.cut_is_safe(sharding.sync_table_of(rx), int(prev))
+        rows = emu.find_all(rx.blob(), shard) + lo          # rebase: what `base` does on the device
+        allrows = sharding.gather_rows(rows, dist)
+        if rank == 0:
+            q.put(allrows)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pat,cfg", [(r"\d+\.\d+\.\d+\.\d+", 2), (r"error", 1)])
+def test_two_rank_sharding_equals_whole(oracle, pat, cfg):
+    import torch.multiprocessing as mp
+    import coregex_amd as cx
+    from coregex_amd import sharding
+    npages, world = 37, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, pat, cfg, npages, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 0, npages)
+    exp = oracle.Regex(pat).find_all_index(whole)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(sharding.apply_limit(got, 5), oracle.Regex(pat).find_all_index(whole, 5))
+
+
+def test_plan_shards_is_page_aligned_and_complete():
+    from coregex_amd import sharding
+    for nbytes, world in [(4096 * 10, 3), (4096 * 8, 8), (4096 * 7 + 100, 2), (1 << 30, 8)]:
+        sh = sharding.plan_shards(nbytes, world)
+        assert sh[0][0] == 0 and sh[-1][1] == nbytes
+        for (a, b), (c, d) in zip(sh[:-1], sh[1:]):
+            assert b == c and b % 4096 == 0
+
+
+def test_newline_is_a_sync_byte_for_all_benchmark_patterns():
+    import coregex_amd as cx
+    from coregex_amd import sharding
+    for pat in (r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error",
+                "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"):
+        assert sharding.cut_is_safe(sharding.sync_table_of(cx.compile(pat)), ord("\n")), pat
