@@ -101,6 +101,15 @@ class Regex:
             return ""
         return _lib.lib().cxg_last_error().decode(errors="replace")
 
+    @property
+    def submatch_supported(self) -> bool:
+        return bool(_lib.lib().cxg_program_submatch_supported(self._h))
+
+    def submatch_blobs(self):
+        sp, sn, cp, cn = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        _check(_lib.lib().cxg_program_submatch_blobs(self._h, C.byref(sp), C.byref(sn), C.byref(cp), C.byref(cn)))
+        return C.string_at(sp, sn.value), C.string_at(cp, cn.value)
+
     def blob(self) -> bytes:
         p, n = C.c_void_p(), C.c_size_t()
         _check(_lib.lib().cxg_program_blob(self._h, C.byref(p), C.byref(n)))
@@ -145,6 +154,14 @@ class Regex:
             return out[: got.value].copy()
 
     # --- device-resident haystacks (bench, shards) ---
+    def find_all_submatch_device(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1,
+                                 stream: int = 0, timing: Timing | None = None) -> int:
+        got = C.c_uint64(0)
+        rc = _lib.lib().cxg_find_all_submatch_device(self._h, d_hay, length, base, n, d_out or None, cap, C.byref(got),
+                                                     stream or None, C.byref(timing) if timing is not None else None)
+        _check(rc)
+        return int(got.value)
+
     def find_all_device(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1,
                         stream: int = 0, timing: Timing | None = None) -> int:
         got = C.c_uint64(0)

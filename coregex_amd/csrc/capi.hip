@@ -98,18 +98,20 @@ int ensureStatus(Scratch& s, uint64_t ntiles) {
   return CXG_OK;
 }
 
-int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
+int deviceCopy(const std::vector<uint8_t>& host, void** slot, const uint8_t** out) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  cxg_program* mp = const_cast<cxg_program*>(p);   // device copies are a cache, the program stays logically immutable
-  if (!mp->dev[device]) {
+  if (!*slot) {   // device copies are a cache, the program stays logically immutable
     void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, p->blob.size()));
-    HIP_TRY(hipMemcpy(d, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice));
-    mp->dev[device] = d;
+    HIP_TRY(hipMalloc(&d, host.size()));
+    HIP_TRY(hipMemcpy(d, host.data(), host.size(), hipMemcpyHostToDevice));
+    *slot = d;
   }
-  *out = static_cast<const uint8_t*>(mp->dev[device]);
+  *out = static_cast<const uint8_t*>(*slot);
   return CXG_OK;
+}
+int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
+  return deviceCopy(p->blob, &const_cast<cxg_program*>(p)->dev[device], out);
 }
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
@@ -120,10 +122,24 @@ int digitKernelGeneration() {
   return g;
 }
 
+__global__ void k_captures(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+                           const uint8_t* capblob, uint32_t* err) {
+  const uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+  if (i >= nrows) return;
+  const cxgdev::CapHeader* ch = reinterpret_cast<const cxgdev::CapHeader*>(capblob);
+  cxgdev::CapView cv{capblob + ch->next_off, capblob + ch->maskid_off, capblob + ch->fin_off,
+                     reinterpret_cast<const uint32_t*>(capblob + ch->masks_off), ch->n_entries, ch->start_entry};
+  // rows hold absolute offsets (hay_base added); the walk indexes the device buffer, so shift the pointer
+  if (!cxgdev::capture_walk(cv, hay - hay_base, rows + i * width, width)) atomicOr(err, 4u);
+}
+
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
-  if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot.empty() ? "unsupported program" : p->whyNot);
+  const bool submatch = row_width > 2;
+  if (submatch) {
+    if (!p->subSupported) return fail(CXG_E_UNSUPPORTED, p->subWhyNot.empty() ? "submatch unsupported for this program" : p->subWhyNot);
+  } else if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot.empty() ? "unsupported program" : p->whyNot);
   if (n_out) *n_out = 0;
   if (timing) std::memset(timing, 0, sizeof *timing);
   if (limit == 0) return CXG_OK;  // Count(n == 0) == 0, meta/findall.go:298
@@ -133,10 +149,15 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (len == 0) return CXG_OK;    // non-nullable patterns never match the empty haystack
   if (reinterpret_cast<uintptr_t>(d_hay) & 15u) return fail(CXG_E_INVALID, "device haystack must be 16-byte aligned");
   if (d_out && (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail(CXG_E_INVALID, "device output must be 16-byte aligned");
-  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data());
+  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(submatch ? p->subBlob.data() : p->blob.data());
   hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
   const uint8_t* d_blob;
-  if (int rc = deviceBlob(p, t_device, &d_blob)) return rc;
+  const uint8_t* d_cap = nullptr;
+  if (submatch) {
+    cxg_program* mp = const_cast<cxg_program*>(p);
+    if (int rc = deviceCopy(p->subBlob, &mp->devSub[t_device], &d_blob)) return rc;
+    if (int rc = deviceCopy(p->capBlob, &mp->devCap[t_device], &d_cap)) return rc;
+  } else if (int rc = deviceBlob(p, t_device, &d_blob)) return rc;
   cxgdev::ScanArgs a;
   a.hay = static_cast<const uint8_t*>(d_hay);
   a.len = len;
@@ -145,6 +166,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   a.out = static_cast<int64_t*>(d_out);
   a.cap = d_out ? cap : 0;
   if (limit > 0 && static_cast<uint64_t>(limit) < a.cap) a.cap = static_cast<uint64_t>(limit);
+  a.row_width = static_cast<uint32_t>(row_width);
   a.ntiles = tilesFor(h->kind, len);
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
   if (int rc = ensureStatus(s, a.ntiles)) return rc;
@@ -177,6 +199,21 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
+  uint32_t launches = 1;
+  if (submatch && a.out) {
+    // capture pass: one thread per match row, after the span kernel on the same stream.  The row count is
+    // only known on the device, so read it back first (one 8-byte copy).
+    HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint64_t nrows = s.hostCtl[1];
+    if (nrows > a.cap) nrows = a.cap;
+    if (nrows) {
+      const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
+      hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+      HIP_TRY(hipGetLastError());
+      launches = 2;
+    }
+  }
   HIP_TRY(hipEventRecord(s.ev[2], stream));
   HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
@@ -186,7 +223,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     float k = 0, t = 0;
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
-    timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = 1;
+    timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
   }
   if (profOn) {
@@ -221,7 +258,8 @@ __global__ void k_fill_synth(uint8_t* dst, uint64_t npages, uint32_t config, uin
 int hostScan(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
              uint64_t* n_out, int width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
-  if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot.empty() ? "unsupported program" : p->whyNot);
+  if (width > 2 ? !p->subSupported : !p->supported)
+    return fail(CXG_E_UNSUPPORTED, width > 2 ? p->subWhyNot : (p->whyNot.empty() ? "unsupported program" : p->whyNot));
   if (n_out) *n_out = 0;
   if (limit == 0 || len == 0) return CXG_OK;
   Scratch* sp;
@@ -321,9 +359,7 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
       p->supported = false;
       p->whyNot = "the reference may route this pattern to a reverse-search strategy outside the device subset";
     }
-    if (p->ngroups > 1 && p->supported) {
-      // FindAllIndex ignores groups; FindAllSubmatchIndex needs the capture pass (not built yet)
-    }
+    if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view);   // FindAllSubmatchIndex path (spans + one-pass captures)
     *out = p;
     return CXG_OK;
   } catch (const cxg::FrontendError& e) {
@@ -361,8 +397,12 @@ int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match
 
 void cxg_program_destroy(cxg_program* p) {
   if (!p) return;
-  for (int d = 0; d < 16; d++)
-    if (p->dev[d]) { (void)hipSetDevice(d); (void)hipFree(p->dev[d]); }
+  for (int d = 0; d < 16; d++) {
+    if (p->dev[d] || p->devSub[d] || p->devCap[d]) (void)hipSetDevice(d);
+    if (p->dev[d]) (void)hipFree(p->dev[d]);
+    if (p->devSub[d]) (void)hipFree(p->devSub[d]);
+    if (p->devCap[d]) (void)hipFree(p->devCap[d]);
+  }
   delete p;
 }
 
@@ -381,6 +421,16 @@ int cxg_program_blob(const cxg_program* p, const void** data, size_t* len) {
   *len = p->blob.size();
   return CXG_OK;
 }
+int cxg_program_submatch_blobs(const cxg_program* p, const void** sb, size_t* sl, const void** cb, size_t* cl) {
+  if (!p || !sb || !sl || !cb || !cl) return fail(CXG_E_INVALID, "null argument");
+  if (!p->subSupported) return fail(CXG_E_UNSUPPORTED, p->subWhyNot);
+  *sb = p->subBlob.data(); *sl = p->subBlob.size(); *cb = p->capBlob.data(); *cl = p->capBlob.size();
+  return CXG_OK;
+}
+int cxg_program_submatch_supported(const cxg_program* p) {
+  if (p && !p->subSupported) t_err = p->subWhyNot;
+  return p && p->subSupported ? 1 : 0;
+}
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out) {
   if (!p || !out) return fail(CXG_E_INVALID, "null argument");
   if (p->nfa.states.empty()) return fail(CXG_E_INVALID, "program was not built by cxg_compile");
@@ -398,8 +448,7 @@ int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t li
 int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* slots,
                           uint64_t cap, uint64_t* n_out) {
   if (p && p->ngroups == 1) return hostScan(p, hay, len, limit, slots, cap, n_out, 2);
-  (void)hay; (void)len; (void)limit; (void)slots; (void)cap; (void)n_out;
-  return fail(CXG_E_UNSUPPORTED, "capture groups: device capture pass not built yet");
+  return hostScan(p, hay, len, limit, slots, cap, n_out, p ? 2 * p->ngroups : 2);
 }
 
 int cxg_buffer_alloc(uint64_t len, cxg_buffer** out) {
@@ -458,8 +507,7 @@ int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, i
 }
 int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
                                  void* d_out, uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
-  if (p && p->ngroups == 1) return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
-  return fail(CXG_E_UNSUPPORTED, "capture groups: device capture pass not built yet");
+  return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, p ? 2 * p->ngroups : 2);
 }
 
 }  // extern "C"

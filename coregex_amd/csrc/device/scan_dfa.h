@@ -25,6 +25,7 @@ struct ScanArgs {
   uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog
   uint64_t ntiles;
   uint64_t* prof;       // optional [8] phase cycle counters (CXG_PROF=1), else nullptr
+  uint32_t row_width;   // int64 per output row: 2, or 2*groups when a capture pass follows
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };
 

@@ -66,14 +66,15 @@ struct RecSink {
 struct DirectSink {   // overflow path: ranks are known, write straight to HBM
   int64_t* out;
   uint64_t cap;
+  uint32_t width;
   uint64_t first;       // tile base + this lane's exclusive rank
   int64_t origin;       // absolute offset of relative position 0
   uint32_t n;
   __device__ __forceinline__ void emit(int32_t s, int32_t e) {
     const uint64_t row = first + n++;
     if (out && row < cap) {
-      out[row * 2 + 0] = origin + s;
-      out[row * 2 + 1] = origin + e;
+      out[row * width + 0] = origin + s;
+      out[row * width + 1] = origin + e;
     }
   }
 };
@@ -172,12 +173,12 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
         longlong2 v;
         v.x = origin + static_cast<int32_t>(s_recs[i * 3 + 0]);
         v.y = origin + static_cast<int32_t>(s_recs[i * 3 + 1]);
-        *reinterpret_cast<longlong2*>(a.out + row * 2) = v;
+        *reinterpret_cast<longlong2*>(a.out + row * a.row_width) = v;   // row_width is even: 16-byte aligned
       }
     }
   } else {
     // LDS record buffer overflowed (dense matches): walk again, writing at the now-known ranks
-    DirectSink ds{a.out, a.cap, base + excl, origin, 0u};
+    DirectSink ds{a.out, a.cap, a.row_width, base + excl, origin, 0u};
     run_lane<KIND>(m, fv, rv, s_info, skip_safe, c0, c1, rend, at_origin, ds);
   }
 }

@@ -341,4 +341,48 @@ CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const u
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Capture pass for FindAllSubmatchIndex (meta/findall.go:390-447 -> PikeVM slots, nfa/pikevm.go:2186).
+// The span [s, e) of every match comes from the bidirectional DFA kernel (same leftmost-first result
+// as the PikeVM's group 0).  For one-pass patterns — at every point of the match at most one
+// byte-consuming NFA state accepts the next byte — the path through the NFA is forced, so the slots
+// are recovered by ONE anchored walk over the span: `ent` is the current entry point (an NFA state
+// whose epsilon closure is about to be taken), next[ent][byte] the entry after consuming the byte, and
+// mask[...] the capture slots whose Capture states lie on the (first, in DFS priority order) epsilon
+// path taken — they are stamped with the current position, exactly where addSearchThread stamps them
+// (pikevm.go:1986).  fin[ent] is the slot set on the path to Match.  Unset groups stay -1.
+struct CapView {
+  const uint8_t* next;     // [n_entries][256], 0xFF = no transition
+  const uint8_t* maskid;   // [n_entries][256]
+  const uint8_t* fin;      // [n_entries], 0xFF = Match not reachable
+  const uint32_t* masks;   // [n_masks] slot bitmasks (bit k = slot k, k >= 2)
+  uint32_t n_entries, start_entry;
+};
+
+struct CapHeader {          // device image: header then the arrays, offsets from the header start
+  uint32_t magic, n_entries, start_entry, n_masks, nslots;
+  uint32_t next_off, maskid_off, fin_off, masks_off, total_bytes;
+};
+
+// hay: absolute haystack; row: 2*ngroups int64 with row[0], row[1] already holding s, e.
+// Returns false if the table and the span disagree (must not happen; reported as an internal error).
+CXG_HD bool capture_walk(const CapView& c, const uint8_t* hay, int64_t* row, uint32_t nslots) {
+  const int64_t s = row[0], e = row[1];
+  for (uint32_t k = 2; k < nslots; k++) row[k] = -1;
+  uint32_t ent = c.start_entry;
+  for (int64_t i = s; i < e; i++) {
+    const uint32_t b = hay[i];
+    const uint32_t nx = c.next[ent * 256 + b];
+    if (nx == 0xFFu) return false;
+    uint32_t m = c.masks[c.maskid[ent * 256 + b]];
+    while (m) { const uint32_t k = ctz32(m); m &= m - 1; row[k] = i; }
+    ent = nx;
+  }
+  const uint32_t f = c.fin[ent];
+  if (f == 0xFFu) return false;
+  uint32_t m = c.masks[f];
+  while (m) { const uint32_t k = ctz32(m); m &= m - 1; row[k] = e; }
+  return true;
+}
+
 }  // namespace cxgdev

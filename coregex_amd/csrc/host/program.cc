@@ -272,6 +272,138 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
   }
 }
 
+namespace {
+
+// Ordered epsilon closure with the capture slots met on the way (DFS, left first; first visit wins —
+// the PikeVM's Visited set, nfa/pikevm.go:1925-1928).
+struct CapClosure {
+  const cxg_nfa& n;
+  struct Item { uint32_t state; uint32_t mask; };
+  explicit CapClosure(const cxg_nfa& nfa) : n(nfa) {}
+  void run(uint32_t seed, std::vector<Item>& out) const {
+    std::vector<uint8_t> seen(n.n_states, 0);
+    struct Fr { uint32_t s, m; };
+    std::vector<Fr> st{{seed, 0}};
+    while (!st.empty()) {
+      Fr f = st.back(); st.pop_back();
+      if (f.s == CXG_NFA_INVALID || f.s >= n.n_states || seen[f.s]) continue;
+      seen[f.s] = 1;
+      const cxg_nfa_state& x = n.states[f.s];
+      switch (x.kind) {
+        case CXG_NFA_MATCH: case CXG_NFA_BYTE_RANGE: case CXG_NFA_SPARSE: out.push_back({f.s, f.m}); break;
+        case CXG_NFA_EPSILON: st.push_back({x.next, f.m}); break;
+        case CXG_NFA_SPLIT: st.push_back({x.right, f.m}); st.push_back({x.left, f.m}); break;
+        case CXG_NFA_CAPTURE: {
+          const uint32_t slot = x.cap_index * 2 + (x.cap_start ? 0u : 1u);
+          st.push_back({x.next, slot < 32 ? (f.m | (1u << slot)) : f.m});
+          break;
+        }
+        default: break;
+      }
+    }
+  }
+};
+
+}  // namespace
+
+void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
+  p->subSupported = false;
+  try {
+    if (nfa.capture_count > 16) throw BuildError{CXG_E_UNSUPPORTED, "more than 15 capture groups"};
+    if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+    // ---- spans: unanchored forward + reverse DFA (the bidirectional image of buildProgramFromNfa)
+    Dfa fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
+    if (fwd.start >= fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+    HostNfa rn = reverseOf(nfa);
+    cxg_nfa rv = rn.view();
+    Dfa rev = determinize(rv, rv.start_anchored, false, kMaxDfaStates);
+    if (fwd.nstates + rev.nstates > kMaxDfaStates) throw BuildError{CXG_E_UNSUPPORTED, "DFA pair exceeds the LDS state budget"};
+    {
+      cxgdev::BlobHeader h;
+      std::memset(&h, 0, sizeof h);
+      h.magic = cxgdev::kBlobMagic; h.kind = cxgdev::kKindBidir; h.ngroups = nfa.capture_count;
+      bool inAlpha[256]; alphabetOf(nfa, inAlpha);
+      uint8_t info[256];
+      for (int b = 0; b < 256; b++) {
+        info[b] = inAlpha[b] ? 0 : cxgdev::kInfoSync;
+        if (fwd.table[static_cast<size_t>(fwd.start) * 256 + b] == fwd.start) info[b] |= cxgdev::kInfoStartIdle;
+      }
+      std::vector<uint8_t> blob(sizeof h, 0);
+      h.fwd_states = fwd.nstates; h.fwd_start = fwd.start; h.fwd_first_accept = fwd.firstAccept;
+      appendTable(blob, fwd, h.fwd_off);
+      h.rev_states = rev.nstates; h.rev_start = rev.start; h.rev_first_accept = rev.firstAccept;
+      appendTable(blob, rev, h.rev_off);
+      h.info_off = static_cast<uint32_t>(blob.size());
+      blob.insert(blob.end(), info, info + 256);
+      h.total_bytes = static_cast<uint32_t>(blob.size());
+      std::memcpy(blob.data(), &h, sizeof h);
+      p->subBlob.swap(blob);
+    }
+    // ---- one-pass capture table
+    CapClosure cc(nfa);
+    std::vector<uint32_t> entryState;             // entry id -> NFA state whose closure is taken
+    std::map<uint32_t, uint32_t> entryOf;
+    auto entry = [&](uint32_t st) -> uint32_t {
+      auto it = entryOf.find(st);
+      if (it != entryOf.end()) return it->second;
+      if (entryState.size() >= 254) throw BuildError{CXG_E_UNSUPPORTED, "capture table too large"};
+      uint32_t id = static_cast<uint32_t>(entryState.size());
+      entryOf[st] = id; entryState.push_back(st);
+      return id;
+    };
+    std::vector<uint32_t> masks;                  // distinct slot masks
+    auto maskId = [&](uint32_t m) -> uint8_t {
+      for (size_t i = 0; i < masks.size(); i++) if (masks[i] == m) return static_cast<uint8_t>(i);
+      if (masks.size() >= 254) throw BuildError{CXG_E_UNSUPPORTED, "too many distinct capture actions"};
+      masks.push_back(m);
+      return static_cast<uint8_t>(masks.size() - 1);
+    };
+    std::vector<uint8_t> next, mid, fin;
+    entry(nfa.start_anchored);
+    for (uint32_t e = 0; e < entryState.size(); e++) {
+      next.resize((e + 1) * 256, 0xFF); mid.resize((e + 1) * 256, 0); fin.resize(e + 1, 0xFF);
+      std::vector<CapClosure::Item> items;
+      cc.run(entryState[e], items);
+      std::vector<int> owner(256, -1);           // which consuming state claimed the byte
+      for (auto& it : items) {
+        const cxg_nfa_state& x = nfa.states[it.state];
+        if (x.kind == CXG_NFA_MATCH) { if (fin[e] == 0xFF) fin[e] = maskId(it.mask); continue; }
+        auto claim = [&](int lo, int hi, uint32_t to) {
+          for (int b = lo; b <= hi; b++) {
+            if (owner[b] >= 0 && owner[b] != static_cast<int>(it.state))
+              throw BuildError{CXG_E_UNSUPPORTED, "pattern is not one-pass (two NFA paths accept the same byte); captures need the general PikeVM pass"};
+            if (owner[b] < 0) {
+              owner[b] = static_cast<int>(it.state);
+              const uint32_t ne = entry(to);       // may grow entryState (vectors resized at loop top)
+              next[e * 256 + b] = static_cast<uint8_t>(ne);
+              mid[e * 256 + b] = maskId(it.mask);
+            }
+          }
+        };
+        if (x.kind == CXG_NFA_BYTE_RANGE) claim(x.lo, x.hi, x.next);
+        else for (uint32_t k = 0; k < x.trans_len; k++) { const cxg_nfa_trans& t = nfa.trans[x.trans_off + k]; claim(t.lo, t.hi, t.next); }
+      }
+    }
+    cxgdev::CapHeader ch;
+    std::memset(&ch, 0, sizeof ch);
+    ch.magic = cxgdev::kBlobMagic; ch.n_entries = static_cast<uint32_t>(entryState.size()); ch.start_entry = 0;
+    ch.n_masks = static_cast<uint32_t>(masks.size()); ch.nslots = nfa.capture_count * 2;
+    std::vector<uint8_t> cb(sizeof ch, 0);
+    auto put = [&](const void* d, size_t n, uint32_t& off) { while (cb.size() % 16) cb.push_back(0); off = static_cast<uint32_t>(cb.size()); const uint8_t* q = static_cast<const uint8_t*>(d); cb.insert(cb.end(), q, q + n); };
+    put(next.data(), next.size(), ch.next_off);
+    put(mid.data(), mid.size(), ch.maskid_off);
+    put(fin.data(), fin.size(), ch.fin_off);
+    if (masks.empty()) masks.push_back(0);
+    put(masks.data(), masks.size() * 4, ch.masks_off);
+    ch.total_bytes = static_cast<uint32_t>(cb.size());
+    std::memcpy(cb.data(), &ch, sizeof ch);
+    p->capBlob.swap(cb);
+    p->subSupported = true;
+  } catch (const BuildError& e) {
+    p->subWhyNot = e.msg;
+  }
+}
+
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch) {
   p->strategy = CXG_USE_CHARCLASS_SEARCHER;
   p->ngroups = 1;

@@ -46,14 +46,24 @@ struct cxg_program {
   cxg::HostNfa nfa;              // kept for cxg_program_nfa (cxg_compile only)
   cxg::Dfa fwd, rev;
   std::vector<uint8_t> blob;     // cxgdev::BlobHeader + tables
-  // device copies, one per device, created on first use (capi.cc)
+  // FindAllSubmatchIndex: spans from a bidirectional DFA image + one-pass capture table (any strategy:
+  // the reference sends FindAllSubmatch of DFA/Both/NFA/DigitPrefilter engines to the PikeVM, whose
+  // result is plain leftmost-first, meta/findall.go:89-98)
+  bool subSupported = false;
+  std::string subWhyNot;
+  std::vector<uint8_t> subBlob;  // kKindBidir image
+  std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
+  // device copies, one per device, created on first use (capi.hip)
   void* dev[16] = {nullptr};
+  void* devSub[16] = {nullptr};
+  void* devCap[16] = {nullptr};
 };
 
 namespace cxg {
 // Fills p->fwd/rev/blob/supported from (nfa, strategy, flags).  Never throws: unsupported programs
 // get supported=false + whyNot.
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags);
+void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa);   // fills subBlob/capBlob/subSupported
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch);
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits);
 }  // namespace cxg

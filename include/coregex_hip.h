@@ -120,6 +120,10 @@ int cxg_program_dfa_states(const cxg_program* p);       /* eager forward DFA sta
 int cxg_program_supported(const cxg_program* p);        /* 1 if the device path accepts it */
 /* Device image of the program (what every kernel stages into LDS); for tests and the emulator. */
 int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
+/* Images used by the FindAllSubmatch path: bidirectional-DFA span program + one-pass capture table. */
+int cxg_program_submatch_blobs(const cxg_program* p, const void** span_blob, size_t* span_len,
+                               const void** cap_blob, size_t* cap_len);
+int cxg_program_submatch_supported(const cxg_program* p);
 /* Host-side copy of the NFA a program was compiled from (cxg_compile only); pointers live as long as p. */
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);
 

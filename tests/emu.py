@@ -17,6 +17,8 @@ def lib():
         L = C.CDLL(_PATH)
         L.emu_find_all.restype = C.c_int64
         L.emu_find_all.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_int]
+        L.emu_find_all_submatch.restype = C.c_int64
+        L.emu_find_all_submatch.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -32,4 +34,17 @@ def find_all(blob: bytes, hay, chunk: int = 64, flat: bool = False) -> np.ndarra
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
             return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
+
+
+def find_all_submatch(span_blob: bytes, cap_blob: bytes, hay, width: int, chunk: int = 64) -> np.ndarray:
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_submatch(span_blob, cap_blob, padded.ctypes.data, a.size, chunk, out.ctypes.data, cap)
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
+            return out[:n].reshape(-1, width).copy()
         cap = int(n)

@@ -87,3 +87,27 @@ extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+// FindAllSubmatch: spans from the bidirectional image, then the one-pass capture walk per row.
+extern "C" int64_t emu_find_all_submatch(const uint8_t* span_blob, const uint8_t* cap_blob, const uint8_t* hay,
+                                         uint64_t len, int chunk, int64_t* out, int64_t cap_vals) {
+  std::vector<int64_t> spans(1024);
+  int64_t n = emu_find_all(span_blob, hay, len, chunk, spans.data(), static_cast<int64_t>(spans.size()), 0);
+  if (n < 0) return n;
+  if (n > static_cast<int64_t>(spans.size())) {
+    spans.resize(n);
+    n = emu_find_all(span_blob, hay, len, chunk, spans.data(), n, 0);
+  }
+  const CapHeader* ch = reinterpret_cast<const CapHeader*>(cap_blob);
+  CapView cv{cap_blob + ch->next_off, cap_blob + ch->maskid_off, cap_blob + ch->fin_off,
+             reinterpret_cast<const uint32_t*>(cap_blob + ch->masks_off), ch->n_entries, ch->start_entry};
+  const uint32_t w = ch->nslots;
+  const int64_t rows = n / 2;
+  if (!out || rows * w > cap_vals) return rows * w;
+  for (int64_t i = 0; i < rows; i++) {
+    int64_t* row = out + i * w;
+    row[0] = spans[2 * i]; row[1] = spans[2 * i + 1];
+    if (!capture_walk(cv, hay, row, w)) return -3;
+  }
+  return rows * w;
+}

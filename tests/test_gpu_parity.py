@@ -151,3 +151,34 @@ def test_device_resident_corpus_64mib(need_gpu, oracle, cfg, pat):
         parts.append(out[:k].cpu().numpy().copy())
     assert np.array_equal(np.concatenate(parts), exp)
     assert zlib.crc32(got.tobytes()) == zlib.crc32(exp.tobytes())
+
+
+def test_find_all_submatch_index(need_gpu, oracle):
+    """BASELINE config 5: `(\\w+)@(\\w+)\\.(\\w+)` FindAllSubmatchIndex, rows of 2*groups int64, -1 unset."""
+    import torch
+    pats = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a)(b)?c", r"(\w+)=(\d+)", r"((a+)(b+))"]
+    corpus = generate_test_input()
+    for pat in pats:
+        rx = cx.compile(pat)
+        assert rx.submatch_supported, pat
+        o = oracle.Regex(pat)
+        for hay in (corpus, b"", b"a@b.c x@y.z", b"abc ac bc abcabc", b"k=1 kk=22;zz=x"):
+            exp = o.find_all_submatch_index(hay)
+            got = rx.find_all_submatch_index(hay)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:40])
+        assert np.array_equal(rx.find_all_submatch_index(corpus, 3), o.find_all_submatch_index(corpus, 3))
+    # device-resident 32 MiB of synthlog config 5
+    pat = r"(\w+)@(\w+)\.(\w+)"
+    rx = cx.compile(pat)
+    npages = 8192
+    buf = cx.DeviceBuffer(npages * 4096)
+    buf.fill_synth(5, 0xC0FFEE05, 0)
+    host = cx.synth_pages(5, 0xC0FFEE05, 0, npages)
+    exp = oracle.Regex(pat).find_all_submatch_index(host)
+    n = rx.find_all_submatch_device(buf.ptr, npages * 4096)
+    assert n == len(exp)
+    out = torch.empty((n + 4, 8), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    n2 = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), n + 4, timing=t)
+    assert n2 == n and t.n_launches == 2
+    assert np.array_equal(out[:n].cpu().numpy(), exp)

@@ -141,6 +141,38 @@ def test_emulated_no_sync_bytes_at_all(oracle):
     assert emu.find_all(p.blob(), hay, 8, flat=True).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
 
 
+SUBMATCH_PATTERNS = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a+)(b+)", r"([a-z]+)([0-9]+)", r"(\d{4})-(\d{2})-(\d{2})",
+                     r"(\w+)", r"(foo|bar)baz", r"(a)(b)?c", r"x(ab)+y", r"(\w+)=(\d+)", r"((a+)(b+))"]
+
+
+def test_submatch_programs_emulated(oracle):
+    """FindAllSubmatchIndex: bidirectional spans + one-pass capture table vs the oracle's PikeVM slots."""
+    corpus = generate_test_input()
+    synth = cx.synth_pages(5, 0xC0FFEE05, 0, 32).tobytes()
+    rng = np.random.default_rng(99)
+    alphabet = np.frombuffer(b"0123456789.-= ab\ncxy@_fo", dtype=np.uint8)
+    checked = 0
+    for pat in SUBMATCH_PATTERNS:
+        p = cx.compile(pat)
+        if not p.submatch_supported:
+            continue
+        o = oracle.Regex(pat)
+        sb, cb = p.submatch_blobs()
+        w = 2 * p.num_groups
+        for hay in (corpus, synth):
+            exp = o.find_all_submatch_index(hay)
+            got = emu.find_all_submatch(sb, cb, hay, w, 64)
+            assert got.tolist() == exp.tolist(), pat
+        for _ in range(60):
+            hay = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 300)))].tobytes()
+            assert emu.find_all_submatch(sb, cb, hay, w, 4).tolist() == o.find_all_submatch_index(hay).tolist(), (pat, hay)
+        checked += 1
+    assert checked >= 8
+    assert cx.compile(r"(\w+)@(\w+)\.(\w+)").submatch_supported
+    amb = cx.compile(r"(a|ab)(c|bcd)")       # two NFA paths accept 'a': not one-pass
+    assert not amb.submatch_supported and "one-pass" in cx._lib.lib().cxg_last_error().decode()
+
+
 def test_teddy_programs(oracle):
     """Teddy: prefix-free sets are accepted and reproduce the oracle; overlapping sets are refused."""
     lits16 = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
