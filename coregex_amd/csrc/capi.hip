@@ -22,6 +22,7 @@ hipError_t launch_scan_dfa(uint32_t kind, const ScanArgs& a, uint32_t fwd_states
 size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
+hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -116,9 +117,10 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
-// CXG_DIGIT_KERNEL=1 selects the first-generation nested-loop kernel (kept for A/B profiling).
+// CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) generation (A/B profiling);
+// default 3 = candidate-list kernel when the program allows it, falling back to 2 on digit-dense tiles.
 int digitKernelGeneration() {
-  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 2; }();
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 3; }();
   return g;
 }
 
@@ -171,7 +173,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
   if (int rc = ensureStatus(s, a.ntiles)) return rc;
   a.status = s.status;
-  a.ticket = reinterpret_cast<uint32_t*>(s.ctl);
+  a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
   static const bool profOn = getenv("CXG_PROF") != nullptr;
@@ -183,6 +185,9 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     HIP_TRY(hipMemsetAsync(s.prof, 0, 64, stream));
     a.prof = s.prof;
   }
+  int gen = digitKernelGeneration();
+  if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
+relaunch:
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
@@ -190,8 +195,9 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   hipError_t le;
   switch (h->kind) {
     case cxgdev::kKindDigit:
-      if (digitKernelGeneration() == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
-      else le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
+      if (gen == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
+      else if (gen == 2) le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
+      else le = cxgdev::launch_scan_digit_list(a, h->fwd_states, stream);
       break;
     case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
     case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;
@@ -234,6 +240,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
   }
+  if ((err & 8u) && h->kind == cxgdev::kKindDigit && gen >= 3) { gen = 2; goto relaunch; }   // digit-dense tile: candidate list overflowed
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
   if (dbgBits) { if (n_out) *n_out = total; return CXG_OK; }
   uint64_t n = total;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
 
   const int tid = threadIdx.x;
   if (tid == 0) {
-    s_tile_id = atomicAdd(a.ticket, 1u);
+    s_tile_id = static_cast<uint32_t>(claim_tile(a.ticket, a.ntiles));
     s_rec_count = 0;
   }
   // ---- stage the program: tables with skewed rows, then the info bytes

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
   const int tid = threadIdx.x;
   const uint64_t t0 = a.prof ? clock64() : 0;
   if (tid == 0) {
-    s_tile_id = atomicAdd(a.ticket, 1u);
+    s_tile_id = static_cast<uint32_t>(claim_tile(a.ticket, a.ntiles));
     s_rec_count = 0;
   }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);

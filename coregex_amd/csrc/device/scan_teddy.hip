@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_teddy(ScanArgs a) {
   __shared__ uint64_t s_base;
 
   const int tid = threadIdx.x;
-  if (tid == 0) { s_tile_id = atomicAdd(a.ticket, 1u); s_rec_count = 0; }
+  if (tid == 0) { s_tile_id = static_cast<uint32_t>(claim_tile(a.ticket, a.ntiles)); s_rec_count = 0; }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   if (tid < 64) reinterpret_cast<uint32_t*>(s_info)[tid] = reinterpret_cast<const uint32_t*>(a.blob + h->info_off)[tid];
   for (uint32_t i = tid; i < h->aux_len / 4; i += kThreads)

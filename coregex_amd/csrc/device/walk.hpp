@@ -39,6 +39,7 @@ constexpr uint32_t kInfoSync = 1u;       // byte is outside the pattern alphabet
 constexpr uint32_t kInfoMember = 2u;     // char-class membership (kKindCharClass)
 constexpr uint32_t kInfoStartIdle = 4u;  // fwd.start --byte--> fwd.start (skippable while idle)
 constexpr uint32_t kFlagRunSkip = 1u;
+constexpr uint32_t kFlagFastDigit = 2u;   // run-skip safe and tail closed: candidate-list kernel allowed; aux = sflags[256]
 
 struct BlobHeader {             // device image of a program; all offsets in bytes from the blob start
   uint32_t magic, kind, flags, ngroups;
@@ -306,6 +307,79 @@ CXG_HD void lane_teddy(const Mem& m, const TeddyView& t, const uint8_t* info, in
     }
     if (mlen) { sink.emit(c, c + mlen); pos = c + mlen; }
     else pos = c + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Third form of the UseDigitPrefilter walk: candidates first, owners second.
+//
+// Preconditions, established on the host (program.cc) and recorded as kFlagFastDigit:
+//   (a) digitRunSkipSafe (meta/compile.go:176): a failed candidate skips the rest of its digit run;
+//   (b) "tail closed": from every accepting DFA state every digit leads to an accepting state, so a
+//       match never ends in front of a digit.
+// Under (a)+(b) the positions the reference's loop can ever try are exactly the digit-RUN STARTS
+// (find_indices.go:1059 lands on a run start after a failure because of the skip, and after a match
+// because of (b); the first candidate of a segment follows a sync byte).  Whether a candidate succeeds
+// is a function of the bytes alone (SearchAtAnchored has no history), so all run starts of a tile can be
+// verified independently — by any lane, perfectly balanced — and the sequential semantics reduce to:
+// walk the owned segment's successful candidates in order and emit those with start >= previous end.
+//
+// verify_jump also skips digit runs in O(1): in a state that maps every digit to itself the walk
+// cannot change state until the run ends, so it jumps to the run end with the digit bitmap.
+constexpr uint32_t kStateDigitLoop = 1u;   // sflags[q]: every digit maps q -> q
+
+template <class Mem>
+CXG_HD int32_t verify_jump(const Mem& m, const DfaView& d, const uint8_t* sflags, int32_t c, int32_t rend) {
+  uint32_t q = d.start;
+  int32_t last = -1, i = c;
+  for (;;) {
+    if (q >= d.first_accept) last = i;
+    if (i >= rend) break;
+    const uint32_t b = m.byte(i);
+    if ((sflags[q] & kStateDigitLoop) && is_digit(b)) { i = next_nondigit(m, i + 1, rend); continue; }
+    q = d.T[q * d.stride + b];
+    if (q == 0) break;
+    i++;
+  }
+  return last;
+}
+
+// Greedy selection over the candidate list for the segments this lane owns.
+// cand_pos[k] ascending; cand_len[k] = match length at that candidate, 0 = no match.
+// first_idx = number of candidates below c0.  Candidates at or beyond list_limit (the staged range) are
+// not in the list: that tail, if the lane's range reaches it, is walked directly.
+template <class Mem, class Sink>
+CXG_HD void lane_select(const Mem& m, const DfaView& d, const uint8_t* info, const uint8_t* sflags,
+                        const uint16_t* cand_pos, const uint8_t* cand_len, uint32_t ncand, uint32_t first_idx,
+                        int32_t list_limit, int32_t c0, int32_t c1, int32_t rend, bool chunk_at_origin, Sink& sink) {
+  int32_t pos = first_owned_start(m, info, c0, c1, rend, chunk_at_origin);
+  if (pos < 0) return;
+  int32_t stop = c1 - 1;
+  while (stop < rend && !(info[m.byte(stop)] & kInfoSync)) stop++;
+  stop = stop < rend ? stop + 1 : rend;
+  uint32_t k = first_idx;
+  while (k < ncand) {
+    const int32_t c = cand_pos[k];
+    if (c >= stop) return;
+    int32_t len = cand_len[k];
+    k++;
+    if (c < pos || len == 0) continue;
+    if (len == 255) len = verify_jump(m, d, sflags, c, rend) - c;   // stored saturated: recompute the long match
+    sink.emit(c, c + len);
+    pos = c + len;
+  }
+  // the owned range runs past the candidate list (lane at the tile edge with no sync byte in the halo)
+  if (stop > list_limit) {
+    if (pos < list_limit) pos = list_limit;
+    // a digit run straddling list_limit started inside the list; it is not a new candidate
+    if (pos == list_limit && pos > 0 && pos < rend && is_digit(m.byte(pos - 1))) pos = next_nondigit(m, pos, rend);
+    for (;;) {
+      const int32_t c = next_digit(m, pos, stop);
+      if (c >= stop) return;
+      const int32_t e = verify_jump(m, d, sflags, c, rend);
+      if (e >= 0) { sink.emit(c, e); pos = e > c ? e : c + 1; }
+      else pos = next_nondigit(m, c + 1, rend);
+    }
   }
 }
 

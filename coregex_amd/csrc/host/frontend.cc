@@ -973,6 +973,80 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
       default: return false;
     }
   }
+  Lits suffixes(int n, int depth) {  // extractSuffixes extractor.go:575-700
+    if (depth > 100) return {};
+    const auto& x = a.at(n);
+    switch (x.kind) {
+      case Node::Lit: {
+        if (x.fold) { sawFold = true; return {}; }
+        auto b = utf8(x.r);
+        if (b.size() > kMaxLitLen) b.erase(b.begin(), b.end() - kMaxLitLen);
+        Lits o; o.v.push_back({b, true}); return o;
+      }
+      case Node::Concat: {
+        int last = static_cast<int>(x.kids.size()) - 1;
+        while (last >= 0) {
+          Node k = a.at(x.kids[last]).kind;
+          if (k != Node::EndLine && k != Node::EndText && k != Node::WordB && k != Node::NoWordB) break;
+          last--;
+        }
+        if (last < 0) return {};
+        Lits suf = suffixes(x.kids[last], depth + 1);
+        if (suf.v.empty()) return {};
+        for (int i = last - 1; i >= 0; i--) {
+          const auto& y = a.at(x.kids[i]);
+          if (y.kind == Node::WordB || y.kind == Node::NoWordB) continue;
+          if (y.kind != Node::Lit) { inexact(suf); return suf; }
+          auto pre = utf8(y.r);
+          for (auto& l : suf.v) {
+            std::vector<uint8_t> nb = pre;
+            nb.insert(nb.end(), l.bytes.begin(), l.bytes.end());
+            if (nb.size() > kMaxLitLen) nb.erase(nb.begin(), nb.end() - kMaxLitLen);
+            l.bytes.swap(nb);
+          }
+          if (suf.v.size() > kMaxLits) return suf;
+        }
+        return suf;
+      }
+      case Node::Alt: {
+        Lits all;
+        for (int k : x.kids) {
+          Lits s2 = suffixes(k, depth + 1);
+          if (s2.v.empty()) return {};
+          for (auto& l : s2.v) { all.v.push_back(l); if (all.v.size() >= kMaxLits) return all; }
+        }
+        return all;
+      }
+      case Node::Class: return expandClass(x);
+      case Node::Capture: return x.kids.empty() ? Lits{} : suffixes(x.kids[0], depth + 1);
+      default: return {};
+    }
+  }
+  Lits inner(int n, int depth) {  // extractInner extractor.go:744-810
+    if (depth > 100) return {};
+    const auto& x = a.at(n);
+    switch (x.kind) {
+      case Node::Lit: {
+        if (x.fold) { sawFold = true; return {}; }
+        auto b = utf8(x.r);
+        if (b.size() > kMaxLitLen) b.resize(kMaxLitLen);
+        Lits o; o.v.push_back({b, false}); return o;
+      }
+      case Node::Concat: for (int k : x.kids) { Lits s2 = inner(k, depth + 1); if (!s2.v.empty()) return s2; } return {};
+      case Node::Alt: {
+        Lits all;
+        for (int k : x.kids) {
+          Lits s2 = inner(k, depth + 1);
+          if (s2.v.empty()) return {};
+          for (auto& l : s2.v) { all.v.push_back(l); if (all.v.size() >= kMaxLits) return all; }
+        }
+        return all;
+      }
+      case Node::Class: return expandClass(x);
+      case Node::Capture: return x.kids.empty() ? Lits{} : inner(x.kids[0], depth + 1);
+      default: return {};
+    }
+  }
   Lits concat(const Ast::N& x, int depth) {  // extractPrefixesConcat extractor.go:302-363
     size_t st = 0;
     while (st < x.kids.size() && (a.at(x.kids[st]).kind == Node::BeginLine || a.at(x.kids[st]).kind == Node::BeginText)) st++;
@@ -1133,38 +1207,75 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   bool teddyLits = pre.v.size() >= 2 && pre.v.size() <= 64 && minLen >= 3;
   bool acLits = pre.v.size() > 64 && minLen >= 1;
 
-  // selectReverseStrategy (strategy.go:974-1093).  The reverse searchers are outside the device
-  // subset; the gate only needs to know whether one *would* be chosen, so it is conservative:
-  // whenever no fast prefix prefilter exists and a suffix or inner literal is extractable under the
-  // whitelisted shapes, the plan is marked not confident and the caller keeps its CPU path.
-  bool fastPrefix = !pre.v.empty() && (good || pre.v.size() == 1 || minLen >= 3);
+  // selectReverseStrategy (strategy.go:974-1093), restated for look-around-free patterns (the NFA builder
+  // has already refused ^ $ \b).  The reverse searchers themselves are outside the device subset: when
+  // one would be chosen the plan carries that strategy and the program is refused.
+  bool fastPrefix = !pre.v.empty() && (good || pre.v.size() == 1 || minLen >= 3);   // hasFastPrefixPrefilter :948-967
   const auto& r = ast.at(root);
-  if (!fastPrefix && r.kind == Node::Concat && r.kids.size() >= 2) {
-    bool wcBeforeLast = false;
-    for (size_t k = 0; k + 1 < r.kids.size(); k++) {
-      int c = r.kids[k];
+  auto lcSuffixLen = [](const Lits& l) {
+    if (l.v.empty()) return size_t{0};
+    size_t n = l.v[0].bytes.size();
+    for (auto& x : l.v) { size_t k = 0; const auto& b0 = l.v[0].bytes; const auto& b = x.bytes; while (k < n && k < b.size() && b0[b0.size() - 1 - k] == b[b.size() - 1 - k]) k++; n = k; }
+    return n;
+  };
+  auto lcPrefixLen = [](const Lits& l) {
+    if (l.v.empty()) return size_t{0};
+    size_t n = l.v[0].bytes.size();
+    for (auto& x : l.v) { size_t k = 0; while (k < n && k < x.bytes.size() && x.bytes[k] == l.v[0].bytes[k]) k++; n = k; }
+    return n;
+  };
+  auto safeSuffix = [&](int n0) {   // isSafeForReverseSuffix :605-634
+    int n = n0;
+    while (ast.at(n).kind == Node::Capture && !ast.at(n).kids.empty()) n = ast.at(n).kids[0];
+    const auto& x = ast.at(n);
+    if (x.kind != Node::Concat || x.kids.size() < 2) return false;
+    int wc = 0;
+    for (size_t k = 0; k + 1 < x.kids.size(); k++) {
+      int c = x.kids[k];
       while (ast.at(c).kind == Node::Capture && !ast.at(c).kids.empty()) c = ast.at(c).kids[0];
       const auto& y = ast.at(c);
-      if ((y.kind == Node::Plus && ast.at(y.kids[0]).kind == Node::Class) || (y.kind == Node::Repeat && y.min >= 1)) wcBeforeLast = true;
+      if ((y.kind == Node::Plus && ast.at(y.kids[0]).kind == Node::Class) || (y.kind == Node::Repeat && y.min >= 1)) wc++;
     }
-    bool suffixLit = sh.yieldsLiteral(r.kids.back());
-    if (wcBeforeLast && suffixLit) p.confident = false;  // UseReverseSuffix / UseReverseSuffixSet territory
-    const auto& f = ast.at(r.kids[0]);
-    bool innerSafe = f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class;  // isSafeForReverseInner :874-907
-    if (innerSafe && r.kids.size() >= 3) {
+    return wc > 0;
+  };
+  auto safeInner = [&](int n0) {    // isSafeForReverseInner :874-907
+    int n = n0;
+    while (ast.at(n).kind == Node::Capture && !ast.at(n).kids.empty()) n = ast.at(n).kids[0];
+    const auto& x = ast.at(n);
+    if (x.kind != Node::Concat || x.kids.size() < 2) return false;
+    const auto& f = ast.at(x.kids[0]);
+    return f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class;
+  };
+  if (!fastPrefix) {
+    int reverse = 0;
+    bool decided = false;
+    Lits suf = lx.suffixes(root, 0);
+    if (!suf.v.empty() && lcSuffixLen(suf) >= 1) {
+      decided = true;                                         // strategy.go:1041-1051: either way the search for a
+      if (safeSuffix(root)) reverse = CXG_USE_REVERSE_SUFFIX; // reverse strategy ends here
+    }
+    if (!decided && safeSuffix(root) && !suf.v.empty()) {     // shouldUseReverseSuffixSet :909-935
+      bool exactAlt = !pre.v.empty() && allExact && pre.v.size() == suf.v.size();
+      size_t ms = SIZE_MAX;
+      for (auto& l : suf.v) ms = std::min(ms, l.bytes.size());
+      if (!exactAlt && suf.v.size() >= 2 && suf.v.size() <= 32 && ms >= 2) { reverse = CXG_USE_REVERSE_SUFFIX_SET; decided = true; }
+    }
+    if (!decided && r.kind == Node::Concat && r.kids.size() >= 3) {   // ExtractInnerForReverseSearch extractor.go:1061-1100
       for (size_t k = 1; k + 1 < r.kids.size(); k++) {
-        if (!sh.yieldsLiteral(r.kids[k])) continue;
+        Lits in = lx.inner(r.kids[k], 0);
+        if (in.v.empty()) continue;
         bool before = false, after = false;
         for (size_t j = 0; j < k; j++) before = before || sh.wildcardOrRep(r.kids[j]);
         for (size_t j = k + 1; j < r.kids.size(); j++) after = after || sh.wildcardOrRep(r.kids[j]);
         if (before && after) {
-          const auto& y = ast.at(r.kids[k]);
-          bool oneByte = y.kind == Node::Lit && y.r.size() == 1;
-          if (!(oneByte && sh.digitLead(root))) p.confident = false;  // UseReverseInner territory (Issue #75 exception)
+          const size_t l = lcPrefixLen(in);
+          if (l == 1 && sh.digitLead(root)) break;            // Issue #75: DigitPrefilter wins
+          if (l >= 1 && safeInner(root)) reverse = CXG_USE_REVERSE_INNER;
           break;
         }
       }
     }
+    if (reverse) { p.strategy = reverse; return p; }
   }
 
   int nfaSize = static_cast<int>(nfa.states.size());

@@ -233,6 +233,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     uint8_t info[256];
     for (int b = 0; b < 256; b++) info[b] = inAlpha[b] ? 0 : cxgdev::kInfoSync;
     std::vector<uint8_t> blob(sizeof h, 0);
+    std::vector<uint8_t> sflags;
     if (strategy == CXG_USE_DIGIT_PREFILTER) {
       // findIndicesDigitPrefilterAtWithState: anchored DFA at each digit candidate
       p->fwd = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
@@ -240,6 +241,19 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       h.kind = cxgdev::kKindDigit;
       if (flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) h.flags |= cxgdev::kFlagRunSkip;
       for (int b = '0'; b <= '9'; b++) info[b] &= ~cxgdev::kInfoSync;  // digits are candidates, never sync
+      // per-state flags + the "tail closed" property for the candidate-list kernel (walk.hpp lane_select)
+      sflags.assign(256, 0);
+      bool tailClosed = true;
+      for (uint32_t q = 1; q < p->fwd.nstates; q++) {
+        bool loop = true;
+        for (int b = '0'; b <= '9'; b++) {
+          const uint8_t t = p->fwd.table[static_cast<size_t>(q) * 256 + b];
+          if (t != q) loop = false;
+          if (q >= p->fwd.firstAccept && t < p->fwd.firstAccept) tailClosed = false;
+        }
+        if (loop) sflags[q] |= cxgdev::kStateDigitLoop;
+      }
+      if ((flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) && tailClosed) h.flags |= cxgdev::kFlagFastDigit;
     } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
       // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
@@ -263,6 +277,11 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     }
     h.info_off = static_cast<uint32_t>(blob.size());
     blob.insert(blob.end(), info, info + 256);
+    if (!sflags.empty()) {
+      h.aux_off = static_cast<uint32_t>(blob.size());
+      h.aux_len = 256;
+      blob.insert(blob.end(), sflags.begin(), sflags.end());
+    }
     h.total_bytes = static_cast<uint32_t>(blob.size());
     std::memcpy(blob.data(), &h, sizeof h);
     p->blob.swap(blob);

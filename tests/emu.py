@@ -23,7 +23,7 @@ def lib():
     return _lib
 
 
-def find_all(blob: bytes, hay, chunk: int = 64, flat: bool = False) -> np.ndarray:
+def find_all(blob: bytes, hay, chunk: int = 64, flat: int = 0) -> np.ndarray:
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     # pad so the emulator's dword reads near the end stay inside the allocation
     padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])

@@ -54,13 +54,37 @@ extern "C" int64_t emu_find_all(const uint8_t* blob, const uint8_t* hay, uint64_
       if (is_digit(hay[tile_lo + k])) bits[k >> 6] |= 1ull << (k & 63);
     m.bits = bits.data();
     std::vector<uint64_t> cbits;
+    std::vector<uint16_t> cpos; std::vector<uint8_t> clen; std::vector<uint32_t> cexcl;
     VecSink sink{&res, static_cast<int64_t>(tile_lo)};
     for (int lane = 0; lane < lanes; lane++) {
       const int32_t c0 = lane * chunk, c1 = c0 + chunk;
       const bool at_origin = tile_lo == 0 && lane == 0;
       if (h->kind == kKindDigit) {
         DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
-        if (flat) lane_digit_flat(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
+        if (flat == 2) {
+          // candidate-list kernel (scan_digit_list.hip): phases B and C once per tile, D per lane
+          if (!(h->flags & kFlagFastDigit)) return -4;
+          const uint8_t* sfl = blob + h->aux_off;
+          if (lane == 0) {
+            cpos.clear(); clen.clear(); cexcl.assign(lanes + 1, 0);
+            for (int32_t pos = 0; pos < stage; pos++) {
+              const bool dg = is_digit(m.byte(pos));
+              const bool prev = (pos > 0 || tile_lo > 0) ? is_digit(m.byte(pos - 1)) : false;
+              if (dg && !prev) cpos.push_back(static_cast<uint16_t>(pos));
+            }
+            for (int l = 0; l <= lanes; l++) {          // candidates below lane l's chunk start
+              uint32_t n = 0;
+              while (n < cpos.size() && static_cast<int32_t>(cpos[n]) < l * chunk) n++;
+              cexcl[l] = n;
+            }
+            for (uint16_t c : cpos) {
+              const int32_t e = verify_jump(m, f, sfl, c, rend);
+              clen.push_back(static_cast<uint8_t>(e < 0 ? 0 : (e - c > 255 ? 255 : e - c)));
+            }
+          }
+          lane_select(m, f, info, sfl, cpos.data(), clen.data(), static_cast<uint32_t>(cpos.size()), cexcl[lane], stage, c0,
+                      c1, rend, at_origin, sink);
+        } else if (flat) lane_digit_flat(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
         else lane_digit(m, f, info, (h->flags & kFlagRunSkip) != 0, c0, c1, rend, at_origin, sink);
       } else if (h->kind == kKindBidir) {
         DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};

@@ -42,7 +42,7 @@ PATTERNS = [
     r"[a-zA-Z]+[0-9]+", r"\w+[0-9]+", r"(\w)+", r"25[0-5]|2[0-4][0-9]|1[0-9][0-9]|[1-9][0-9]|[0-9]",
     r"(?:0[0-9]|1[0-9]|2[0-3]):[0-5][0-9]:[0-5][0-9]", r"[1-9][0-9]*|0", r"foo|bar|baz", r"[a-f0-9]{32,}",
     r"apple|banana|cherry|date|elderberry|fig|grape|honeydew|kiwi|lemon|mango|orange", r"x[ab]+?y", r"(a|ab)(c|bcd)",
-    r"\d{1,3}\.\d{1,3}", r"[0-5]+x", r"(foo|foobar)\d+", r"ERROR|WARN", r"a{2,4}b", r"(?:ab)*c", r"a||b", r"[a-c]|x|yz",
+    r"\d{1,3}\.\d{1,3}", r"[0-5]+x", r"(foo|foobar)\d+", r"\d+[a-z]", r"\d+\.\d", r"\d+\.\d+x?", r"\w+\.txt", r"[a-z]+@[a-z]+", r"ERROR|WARN", r"a{2,4}b", r"(?:ab)*c", r"a||b", r"[a-c]|x|yz",
 ]
 
 
@@ -89,6 +89,11 @@ def test_nfa_view_matches_oracle_dump(oracle):
 EMU_PATTERNS = [p for p in PATTERNS]
 
 
+def _fast_digit(p) -> bool:
+    import struct
+    return bool(struct.unpack_from("<I", p.blob(), 8)[0] & 2)
+
+
 @pytest.mark.parametrize("chunk", [4, 16, 64])
 def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
     corpus = generate_test_input()
@@ -104,7 +109,9 @@ def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
         exp = oracle.Regex(pat).find_all_index(corpus)
         assert got.tolist() == exp.tolist(), (name, chunk)
         if p.strategy == "UseDigitPrefilter":
-            assert emu.find_all(p.blob(), corpus, chunk, flat=True).tolist() == exp.tolist(), (name, chunk, "flat")
+            assert emu.find_all(p.blob(), corpus, chunk, flat=1).tolist() == exp.tolist(), (name, chunk, "flat")
+            if _fast_digit(p):
+                assert emu.find_all(p.blob(), corpus, chunk, flat=2).tolist() == exp.tolist(), (name, chunk, "list")
         n_checked += 1
     assert n_checked >= 5
 
@@ -128,7 +135,9 @@ def test_emulated_lane_walks_random(oracle):
                 got = emu.find_all(blob, hay, chunk).tolist()
                 assert got == exp, (pat, chunk, hay)
                 if p.strategy == "UseDigitPrefilter":
-                    assert emu.find_all(blob, hay, chunk, flat=True).tolist() == exp, (pat, chunk, hay, "flat")
+                    assert emu.find_all(blob, hay, chunk, flat=1).tolist() == exp, (pat, chunk, hay, "flat")
+                    if _fast_digit(p):
+                        assert emu.find_all(blob, hay, chunk, flat=2).tolist() == exp, (pat, chunk, hay, "list")
     assert tried >= 10
 
 
@@ -138,7 +147,13 @@ def test_emulated_no_sync_bytes_at_all(oracle):
     p = cx.compile(pat)
     hay = (b"1.2.3.4.5.6.7.8.9..10.11.12.13" * 40)
     assert emu.find_all(p.blob(), hay, 8).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
-    assert emu.find_all(p.blob(), hay, 8, flat=True).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+    assert emu.find_all(p.blob(), hay, 8, flat=1).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+    assert _fast_digit(p)
+    assert emu.find_all(p.blob(), hay, 8, flat=2).tolist() == oracle.Regex(pat).find_all_index(hay).tolist()
+    # fast-digit preconditions: run-skip safe AND tail closed
+    assert not _fast_digit(cx.compile(r"\d+\.\d+x?"))       # a match (ending in x) can end in front of a digit
+    assert not _fast_digit(cx.compile(r"\d{1,3}\.\d{1,3}"))   # leading class is bounded: no run skip
+    assert _fast_digit(cx.compile(r"\d+\.\d+\.\d+")) and _fast_digit(cx.compile(r"\d+:\d+:\d+"))
 
 
 SUBMATCH_PATTERNS = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a+)(b+)", r"([a-z]+)([0-9]+)", r"(\d{4})-(\d{2})-(\d{2})",
