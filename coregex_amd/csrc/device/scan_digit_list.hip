@@ -126,6 +126,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
   }
   __syncthreads();
 
+  if (a.dbg & 1u) {   // timing experiment: staging only
+    if (tid == 0 && tile == a.ntiles - 1) *a.total = 0;
+    return;
+  }
   // ---- B: run starts -> candidate list (positions ascending)
   const uint64_t M = s_bits[tid];
   uint64_t carry;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   for (uint32_t k = tid; k < ncand; k += kThreads) {
     const int32_t c = s_cpos[k];
-    const int32_t e = verify_jump(m, fv, s_sfl, c, rend);
+    const int32_t e = (a.dbg & 4u) ? -1 : verify_jump(m, fv, s_sfl, c, rend);
     const int32_t len = e < 0 ? 0 : (e - c > 255 ? 255 : e - c);
     s_clen[k] = static_cast<uint8_t>(len);
   }
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
   const int32_t c0 = tid * kChunk, c1 = c0 + kChunk;
   const bool at_origin = (tile_lo == 0 && tid == 0);
   CountSink cs{0u};
-  lane_select(m, fv, s_info, s_sfl, s_cpos, s_clen, ncand, cexcl, stage, c0, c1, rend, at_origin, cs);
+  if (!(a.dbg & 8u)) lane_select(m, fv, s_info, s_sfl, s_cpos, s_clen, ncand, cexcl, stage, c0, c1, rend, at_origin, cs);
   uint32_t total;
   const uint32_t excl = block_exclusive_scan(cs.n, s_wsum, total);
   tile_lookback(a.status, a.total, a.err, tile, a.ntiles, total, &s_base);
