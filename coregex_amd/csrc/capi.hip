@@ -23,6 +23,7 @@ size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
+hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -118,9 +119,10 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) generation (A/B profiling);
-// default 3 = candidate-list kernel when the program allows it, falling back to 2 on digit-dense tiles.
+// default 4 = chain-prefilter kernel, 3 = candidate-list kernel, each only when the program allows it;
+// both hand the scan to generation 2 when a tile raises the fallback flag.
 int digitKernelGeneration() {
-  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 3; }();
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 4; }();
   return g;
 }
 
@@ -186,6 +188,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     a.prof = s.prof;
   }
   int gen = digitKernelGeneration();
+  if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
   if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
 relaunch:
   HIP_TRY(hipEventRecord(s.ev[0], stream));
@@ -197,7 +200,8 @@ relaunch:
     case cxgdev::kKindDigit:
       if (gen == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
       else if (gen == 2) le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
-      else le = cxgdev::launch_scan_digit_list(a, h->fwd_states, stream);
+      else if (gen == 3) le = cxgdev::launch_scan_digit_list(a, h->fwd_states, stream);
+      else le = cxgdev::launch_scan_digit_chain(a, h->fwd_states, stream);
       break;
     case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
     case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;

@@ -383,6 +383,79 @@ CXG_HD void lane_select(const Mem& m, const DfaView& d, const uint8_t* info, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bit-parallel candidate pruning for the candidate-list kernels ("chain prefilter").
+//
+// When the anchored DFA is a chain — start -C1-> q1 (loops on C1) -F1-> q2 -C2-> q3 (loops on C2) ... —
+// the leading elements of the pattern are known as a sequence of RUN(class+) / BYTE(class) steps.  A
+// run start can only succeed if those steps can be taken from it, and that test is evaluated for all
+// positions of a tile at once on per-class bitmaps (one bit per haystack byte), right to left:
+//     BYTE(F):  G_k = F & (G_{k+1} >> 1)
+//     RUN(C):   G_k = all bits of the C-runs whose end position is in G_{k+1}
+// The run step is one multi-word addition: in bit-REVERSED space the marker just below a run, shifted
+// onto it and added to C, ripples through exactly that run (Parabix-style ScanThru).  Surviving run
+// starts (a superset of the successful candidates — the chain may be a prefix of the pattern, and
+// class tests may be widened) are then verified with the DFA as before, so the result stays exact.
+// All bitmaps of this scheme are stored reversed: bit i of word w describes byte N-1-(64w+i), N = 64*words.
+enum ChainOpKind : uint8_t { kChainByte = 0, kChainRun = 1 };
+enum ChainClassKind : uint8_t { kClsDigit = 0, kClsByte = 1, kClsRange = 2 };
+constexpr int kChainMaxOps = 16, kChainMaxCls = 4;
+
+struct ChainAux {             // aux section of a kKindDigit blob when kFlagChain is set (follows sflags[256])
+  uint32_t nops, ncls;
+  uint8_t op_kind[kChainMaxOps];
+  uint8_t op_cls[kChainMaxOps];
+  uint8_t cls_kind[kChainMaxCls];
+  uint8_t cls_lo[kChainMaxCls];
+  uint8_t cls_hi[kChainMaxCls];
+  uint8_t _pad[4];
+};
+constexpr uint32_t kFlagChain = 4u;
+
+CXG_HD bool chain_class_has(const ChainAux& c, int k, uint32_t b) {
+  if (c.cls_kind[k] == kClsDigit) return is_digit(b);
+  return b >= c.cls_lo[k] && b <= c.cls_hi[k];
+}
+
+// Sequential reference form (host emulator and tests): words[] arrays are reversed bitmaps of `nw` words.
+// cls[k] = class bitmaps; out = G_1 (positions from which ops[0..nops) can all be taken).
+inline void chain_eval_seq(const ChainAux& c, const uint64_t* const* cls, int nw, uint64_t* out, uint64_t* tmp) {
+  for (int w = 0; w < nw; w++) out[w] = ~0ull;                      // G_{n+1}: nothing required after the chain
+  for (int k = static_cast<int>(c.nops) - 1; k >= 0; k--) {
+    const uint64_t* C = cls[c.op_cls[k]];
+    if (c.op_kind[k] == kChainByte) {                                 // G_k = F & (G_{k+1} "next byte")
+      uint64_t lowbit = 1;                                            // beyond the highest original position: G_{n+1}=1
+      // next byte in original order = next LOWER reversed index: shift left, taking bit 63 of word w-1
+      uint64_t carry = 0;
+      for (int w = 0; w < nw; w++) {
+        const uint64_t g = out[w];
+        tmp[w] = C[w] & ((g << 1) | (w == 0 ? lowbit : carry));
+        carry = g >> 63;
+      }
+      for (int w = 0; w < nw; w++) out[w] = tmp[w];
+    } else {                                                          // run step
+      // K = positions just below a reversed run (orig: first byte after the run) that are in G_{k+1}
+      uint64_t carry = 0;                                             // multiword add carry
+      uint64_t kprev_hi = 0;                                          // bit 63 of K in word w-1
+      for (int w = 0; w < nw; w++) {
+        const uint64_t cup = (C[w] >> 1) | ((w + 1 < nw ? C[w + 1] : 0ull) << 63);
+        const uint64_t K = out[w] & ~C[w] & cup;
+        const uint64_t M = (K << 1) | kprev_hi;
+        kprev_hi = K >> 63;
+        const uint64_t s1 = C[w] + M;
+        const uint64_t c1 = s1 < M ? 1u : 0u;
+        const uint64_t s2 = s1 + carry;
+        const uint64_t c2 = s2 < s1 ? 1u : 0u;
+        tmp[w] = C[w] & ~s2;
+        carry = c1 | c2;
+      }
+      // a run whose end lies below reversed bit 0 (beyond the last original position): G_{n+1}=1 there only
+      // matters at true end of input, handled by the caller through the virtual position below bit 0
+      for (int w = 0; w < nw; w++) out[w] = tmp[w];
+    }
+  }
+}
+
 template <class Mem, class Sink>
 CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const uint8_t* info, int32_t c0, int32_t c1,
                        int32_t rend, bool chunk_at_origin, Sink& sink) {

@@ -234,6 +234,8 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     for (int b = 0; b < 256; b++) info[b] = inAlpha[b] ? 0 : cxgdev::kInfoSync;
     std::vector<uint8_t> blob(sizeof h, 0);
     std::vector<uint8_t> sflags;
+    cxgdev::ChainAux chain;
+    std::memset(&chain, 0, sizeof chain);
     if (strategy == CXG_USE_DIGIT_PREFILTER) {
       // findIndicesDigitPrefilterAtWithState: anchored DFA at each digit candidate
       p->fwd = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
@@ -254,6 +256,50 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         if (loop) sflags[q] |= cxgdev::kStateDigitLoop;
       }
       if ((flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) && tailClosed) h.flags |= cxgdev::kFlagFastDigit;
+      // chain prefilter (walk.hpp "chain prefilter"): follow the DFA while it is a chain of
+      // run(class+) / byte(class) steps whose classes have a SWAR-friendly form.
+      if (h.flags & cxgdev::kFlagFastDigit) {
+        std::memset(&chain, 0, sizeof chain);
+        const Dfa& d = p->fwd;
+        auto classOf = [&](const bool in[256], uint8_t& kind, uint8_t& lo, uint8_t& hi) {
+          int first = -1, last = -1, cnt = 0;
+          for (int b = 0; b < 256; b++) if (in[b]) { if (first < 0) first = b; last = b; cnt++; }
+          if (cnt == 0 || last - first + 1 != cnt || last > 127) return false;     // contiguous ASCII range only
+          lo = static_cast<uint8_t>(first); hi = static_cast<uint8_t>(last);
+          kind = (first == '0' && last == '9') ? cxgdev::kClsDigit : (cnt == 1 ? cxgdev::kClsByte : cxgdev::kClsRange);
+          return true;
+        };
+        uint32_t q = d.start;
+        for (int step = 0; step < cxgdev::kChainMaxOps; step++) {
+          if (q >= d.firstAccept) break;                       // a match may end here: later steps are not necessary
+          int target = -1; bool branching = false;
+          bool F[256] = {false};
+          for (int b = 0; b < 256; b++) {
+            const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+            if (t == 0 || t == q) continue;
+            if (target < 0) target = static_cast<int>(t);
+            if (static_cast<int>(t) != target) { branching = true; break; }
+            F[b] = true;
+          }
+          if (branching || target < 0) break;
+          bool loopT[256] = {false}; bool anyLoop = false, same = true;
+          for (int b = 0; b < 256; b++) { loopT[b] = d.table[static_cast<size_t>(target) * 256 + b] == static_cast<uint32_t>(target); anyLoop = anyLoop || loopT[b]; }
+          for (int b = 0; b < 256; b++) if (loopT[b] != F[b]) same = false;
+          uint8_t kind, lo, hi;
+          if (!classOf(F, kind, lo, hi)) break;
+          if (anyLoop && !same) break;                         // loops on a different class: not a plain run
+          int ci = -1;
+          for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == kind && chain.cls_lo[k] == lo && chain.cls_hi[k] == hi) ci = static_cast<int>(k);
+          if (ci < 0) { if (chain.ncls >= cxgdev::kChainMaxCls) break; ci = static_cast<int>(chain.ncls++); chain.cls_kind[ci] = kind; chain.cls_lo[ci] = lo; chain.cls_hi[ci] = hi; }
+          chain.op_kind[chain.nops] = anyLoop ? cxgdev::kChainRun : cxgdev::kChainByte;
+          chain.op_cls[chain.nops] = static_cast<uint8_t>(ci);
+          chain.nops++;
+          q = static_cast<uint32_t>(target);
+        }
+        // the candidates are digit-run starts: the chain is only usable if it begins with run(digit)
+        if (chain.nops >= 2 && chain.op_kind[0] == cxgdev::kChainRun && chain.cls_kind[chain.op_cls[0]] == cxgdev::kClsDigit && chain.op_cls[0] == 0)
+          h.flags |= cxgdev::kFlagChain;
+      }
     } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
       // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
@@ -279,8 +325,11 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     blob.insert(blob.end(), info, info + 256);
     if (!sflags.empty()) {
       h.aux_off = static_cast<uint32_t>(blob.size());
-      h.aux_len = 256;
       blob.insert(blob.end(), sflags.begin(), sflags.end());
+      const uint8_t* cb = reinterpret_cast<const uint8_t*>(&chain);
+      blob.insert(blob.end(), cb, cb + sizeof chain);           // ChainAux follows sflags[256]
+      while (blob.size() % 16) blob.push_back(0);
+      h.aux_len = static_cast<uint32_t>(blob.size()) - h.aux_off;
     }
     h.total_bytes = static_cast<uint32_t>(blob.size());
     std::memcpy(blob.data(), &h, sizeof h);

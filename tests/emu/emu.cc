@@ -135,3 +135,66 @@ extern "C" int64_t emu_find_all_submatch(const uint8_t* span_blob, const uint8_t
   }
   return rows * w;
 }
+
+// Fourth-generation digit kernel (scan_digit_chain.hip), tile by tile: reversed class bitmaps, the chain
+// evaluated with chain_eval_seq, survivors verified with verify_jump, ownership by segment start, greedy
+// FindAll order.  Returns -5 when a tile would raise the "rerun with the flat kernel" flag.
+namespace {
+struct PlainMem {
+  const uint8_t* g;
+  uint32_t byte(int32_t r) const { return g[r]; }
+  uint64_t digits(int32_t) const { return 0; }
+  int32_t bitmap_limit() const { return 0; }
+};
+}  // namespace
+
+extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || h->kind != kKindDigit) return -1;
+  if ((h->flags & (kFlagFastDigit | kFlagChain)) != (kFlagFastDigit | kFlagChain)) return -4;
+  const uint8_t* info = blob + h->info_off;
+  const uint8_t* sfl = blob + h->aux_off;
+  const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
+  DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
+  const int nwd = kThreads + kHaloChunks, NW = nwd + 1;
+  const int64_t N = 64LL * NW;
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + kTile - 1) / kTile;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(kTile);
+    const uint64_t remaining = len - tile_lo;
+    const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+    const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
+    const uint8_t* g = hay + tile_lo;
+    std::vector<std::vector<uint64_t>> cls(ch.ncls, std::vector<uint64_t>(NW, 0));
+    for (int32_t p = 0; p < stage; p++)
+      for (uint32_t c = 0; c < ch.ncls; c++)
+        if (chain_class_has(ch, static_cast<int>(c), g[p])) { const int64_t i = N - 1 - p; cls[c][i >> 6] |= 1ull << (i & 63); }
+    std::vector<const uint64_t*> cp;
+    for (auto& v : cls) cp.push_back(v.data());
+    std::vector<uint64_t> G(NW), tmp(NW);
+    chain_eval_seq(ch, cp.data(), NW, G.data(), tmp.data());
+    bool halo_sync = stage == rend;
+    for (int32_t p = kTile - 1; p < stage && !halo_sync; p++) halo_sync = (info[g[p]] & kInfoSync) != 0;
+    if (!halo_sync) return -5;
+    PlainMem m{g};
+    int32_t cur_end = -1;
+    for (int32_t c = 0; c < stage; c++) {                          // ascending position
+      const int64_t i = N - 1 - c;
+      const bool dg = is_digit(g[c]);
+      const bool prev = (c > 0 || tile_lo > 0) ? is_digit(g[c - 1]) : false;
+      if (!(dg && !prev)) continue;
+      if (!((G[i >> 6] >> (i & 63)) & 1)) continue;               // pruned by the chain
+      const int32_t e = verify_jump(m, f, sfl, c, rend);
+      if (e < 0) continue;
+      int32_t p = c - 1;
+      while (p >= 0 && !(info[g[p]] & kInfoSync)) p--;
+      int32_t seg = p >= 0 ? p + 1 : ((tile_lo == 0 || (info[g[-1]] & kInfoSync)) ? 0 : -1);
+      if (!(seg >= 0 && seg < kTile)) continue;
+      if (c >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + c); res.push_back(static_cast<int64_t>(tile_lo) + e); cur_end = e; }
+    }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}

@@ -141,6 +141,37 @@ def test_emulated_lane_walks_random(oracle):
     assert tried >= 10
 
 
+def test_chain_prefilter_emulated(oracle):
+    """Bit-parallel chain prefilter + DFA verify (4th-generation digit kernel) vs the oracle."""
+    import struct
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"0123456789..:: ab\nxy-", dtype=np.uint8)
+    corpus = generate_test_input()
+    synth = cx.synth_pages(2, 0xC0FFEE02, 3, 40).tobytes()
+    n_ok = 0
+    for pat in [r"\d+\.\d+\.\d+\.\d+", r"\d+\.\d+\.\d+", r"\d+:\d+:\d+", r"\d+[a-f]+;\d+", r"\d+\.\d+"]:
+        p = cx.compile(pat)
+        if not p.supported or p.strategy != "UseDigitPrefilter":
+            continue
+        if (struct.unpack_from("<I", p.blob(), 8)[0] & 6) != 6:
+            continue
+        o = oracle.Regex(pat)
+        n_ok += 1
+        for hay in (corpus, synth, b"", b"1.2.3.4", b"9" * 300 + b" 1.2.3.4 " + b"7." * 200):
+            got = emu.find_all_chain(p.blob(), hay)
+            assert got is not None and got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay))
+        for _ in range(150):
+            n = int(rng.integers(0, 40000))
+            hay = alphabet[rng.integers(0, len(alphabet), size=n)].tobytes()
+            got = emu.find_all_chain(p.blob(), hay)
+            if got is None:
+                continue          # no sync byte in a halo: the kernel would hand the scan to the flat kernel
+            assert got.tolist() == o.find_all_index(hay).tolist(), (pat, n)
+    assert n_ok >= 3
+    # a halo without any synchronising byte must raise the fallback flag, never a wrong answer
+    assert emu.find_all_chain(cx.compile(r"\d+\.\d+\.\d+\.\d+").blob(), b"1.2.3.4." * 4000) is None
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
