@@ -191,6 +191,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
   if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
 relaunch:
+  a.ngroups = (h->kind == cxgdev::kKindDigit && gen >= 4) ? (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles : a.ntiles;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));

@@ -10,6 +10,7 @@ constexpr int kChunk = 64;                    // bytes owned per lane
 constexpr int kTile = kThreads * kChunk;      // 16 KiB per workgroup
 constexpr int kHaloChunks = 4;
 constexpr int kHalo = kHaloChunks * kChunk;   // 256 B staged past the tile for lanes that overrun
+constexpr int kGroupTiles = 8;                // tiles per workgroup in the grouped kernels (one ticket / look-back per 128 KiB)
 constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
 
 struct ScanArgs {
@@ -24,6 +25,7 @@ struct ScanArgs {
   uint64_t* total;      // match count (written by the last tile)
   uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog
   uint64_t ntiles;
+  uint64_t ngroups;     // look-back units: == ntiles, except for kernels that process kGroupTiles tiles per workgroup
   uint64_t* prof;       // optional [8] phase cycle counters (CXG_PROF=1), else nullptr
   uint32_t row_width;   // int64 per output row: 2, or 2*groups when a capture pass follows
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)

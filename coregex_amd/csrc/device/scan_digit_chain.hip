@@ -15,6 +15,10 @@
 //      (bytes from L2) — this is what makes the result exact — and finds its segment start for ownership.
 //   D  one lane applies the reference's FindAll order (start >= previous end) to the owned successes;
 //      block scan, look-back, 16-byte row stores.
+// A workgroup processes a GROUP of 8 consecutive tiles: one ticket atomic, one table staging, one
+// look-back and one row write-out per 128 KiB.  (A ticket per 16 KiB tile costs ~0.6 ms per GiB on its
+// own — scripts/microbench/stream.hip: 6.6 TB/s plain tile reads vs 1.4 TB/s with a per-tile ticket.)
+// Rows of the group are collected in LDS in FindAll order and written with coalesced 16-byte stores.
 // If the halo holds no synchronising byte, or a tile has more survivors than the LDS list, the tile
 // raises a flag and the host reruns the scan with the flat kernel (exact, slower).
 #include <hip/hip_runtime.h>
@@ -33,6 +37,7 @@ constexpr int kWords = kThreads + kHaloChunks;   // 260 data words
 constexpr int kNW = kWords + 1;                  // + one all-zero word beyond the staged window (reversed word 0)
 constexpr int kNP = kNW * 4;                     // 16-bit pieces per bitmap
 constexpr int kSurvCap = 512;
+constexpr int kRowCap = 2048;                    // rows buffered per group
 
 struct GlobalMem {       // verification reads the haystack straight from L2/HBM (rare)
   const uint8_t* g;
@@ -67,14 +72,16 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
   __shared__ uint16_t s_spos[kSurvCap];
   __shared__ uint16_t s_slen[kSurvCap];
   __shared__ uint8_t s_sown[kSurvCap];
-  __shared__ uint8_t s_semit[kSurvCap];
+  __shared__ uint32_t s_rowpos[kRowCap];
+  __shared__ uint16_t s_rowlen[kRowCap];
+  __shared__ uint32_t s_nrows;
   __shared__ uint32_t s_wsum[4];
   __shared__ uint32_t s_halo[8];
   __shared__ uint64_t s_tile_id;
   __shared__ uint64_t s_base;
 
   const int tid = threadIdx.x;
-  if (tid == 0) s_tile_id = claim_tile(a.ticket, a.ntiles);
+  if (tid == 0) { s_tile_id = claim_tile(a.ticket, a.ngroups); s_nrows = 0; }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   const uint32_t fwd_states = h->fwd_states;
   uint8_t* s_fwd = s_dyn;
@@ -91,14 +98,22 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
       reinterpret_cast<uint32_t*>(s_chain)[tid - 128] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off + 256)[tid - 128];
   }
   __syncthreads();
-  const uint64_t tile = s_tile_id;
-  if (tile >= a.ntiles) return;
+  const uint64_t group = s_tile_id;
+  if (group >= a.ngroups) return;
+  const uint32_t ncls = s_chain->ncls, nops = s_chain->nops;
+  DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
+  const int wa = kNW - 1 - tid;
+  const bool has_b = tid < 5;
+  const int wb = tid;
+
+  for (int gj = 0; gj < kGroupTiles; gj++) {
+  const uint64_t tile = group * kGroupTiles + gj;
+  if (tile >= a.ntiles) break;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
   const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
-  const uint32_t ncls = s_chain->ncls, nops = s_chain->nops;
 
   // ---- A: class bitmaps, reversed
   {
@@ -131,9 +146,6 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
     }
   }
   // lanes and words: lane t owns reversed word wa = kNW-1-t (its own 64-byte chunk); lanes 0..4 also own word t
-  const int wa = kNW - 1 - tid;
-  const bool has_b = tid < 5;
-  const int wb = tid;
   s_g[0][wa] = ~0ull;
   if (has_b) s_g[0][wb] = ~0ull;
   __syncthreads();
@@ -222,7 +234,6 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
 
   // ---- C: verify survivors with the DFA; ownership = where their segment starts
   GlobalMem m{g};
-  DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   for (uint32_t k = tid; k < nsurv; k += kThreads) {
     const int32_t c = s_spos[k];
     const int32_t e = verify_jump(m, fv, s_sfl, c, rend);
@@ -242,43 +253,42 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
   }
   __syncthreads();
 
-  // ---- D: FindAll order among the owned successes (sequential by nature, a few dozen items)
+  // ---- D: FindAll order among the owned successes (sequential by nature, a few dozen items): the lane
+  // appends the emitted rows to the group's row list, which therefore is in FindAll order.
   if (tid == 0) {
     int32_t cur_end = -1;
+    uint32_t n = s_nrows;
     for (uint32_t k = 0; k < nsurv; k++) {
-      uint8_t em = 0;
-      if (s_sown[k]) {
-        const int32_t c = s_spos[k];
-        if (c >= cur_end) { em = 1; cur_end = c + s_slen[k]; }
-      }
-      s_semit[k] = em;
+      if (!s_sown[k]) continue;
+      const int32_t c = s_spos[k];
+      if (c < cur_end) continue;
+      cur_end = c + s_slen[k];
+      if (n < static_cast<uint32_t>(kRowCap)) { s_rowpos[n] = static_cast<uint32_t>(gj) * kTile + static_cast<uint32_t>(c); s_rowlen[n] = s_slen[k]; }
+      n++;
     }
+    s_nrows = n;
   }
-  __syncthreads();
-  const uint32_t e0 = (static_cast<uint32_t>(tid) < nsurv) ? s_semit[tid] : 0u;
-  const uint32_t e1 = (static_cast<uint32_t>(tid) + kThreads < nsurv) ? s_semit[tid + kThreads] : 0u;
-  uint32_t tot0, tot1;
-  const uint32_t x0 = block_exclusive_scan(e0, s_wsum, tot0);
-  __syncthreads();
-  const uint32_t x1 = block_exclusive_scan(e1, s_wsum, tot1);
-  const uint32_t total = tot0 + tot1;
-  tile_lookback(a.status, a.total, a.err, tile, a.ntiles, total, &s_base);
+  __syncthreads();                                                    // LDS is reused by the next tile
+  }  // tiles of the group
+
+  uint32_t total = s_nrows;
+  if (total > static_cast<uint32_t>(kRowCap)) { if (tid == 0) atomicOr(a.err, 8u); total = kRowCap; }
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
-  const int64_t origin = a.base + static_cast<int64_t>(tile_lo);
-  if (e0) {
-    const uint64_t row = base + x0;
-    if (row < a.cap) { longlong2 v; v.x = origin + s_spos[tid]; v.y = v.x + s_slen[tid]; *reinterpret_cast<longlong2*>(a.out + row * 2) = v; }
-  }
-  if (e1) {
-    const uint64_t row = base + tot0 + x1;
-    if (row < a.cap) { longlong2 v; v.x = origin + s_spos[tid + kThreads]; v.y = v.x + s_slen[tid + kThreads]; *reinterpret_cast<longlong2*>(a.out + row * 2) = v; }
+  const int64_t origin = a.base + static_cast<int64_t>(group * kGroupTiles * static_cast<uint64_t>(kTile));
+  for (uint32_t i = tid; i < total; i += kThreads) {
+    const uint64_t row = base + i;
+    if (row < a.cap) {
+      longlong2 v; v.x = origin + s_rowpos[i]; v.y = v.x + s_rowlen[i];
+      *reinterpret_cast<longlong2*>(a.out + row * 2) = v;
+    }
   }
 }
 
 hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream) {
   const size_t dyn = static_cast<size_t>(fwd_states) * kRowStride + 512 + sizeof(ChainAux) + 16;
-  hipLaunchKernelGGL(k_scan_digit_chain, dim3(static_cast<unsigned>(a.ntiles)), dim3(kThreads), dyn, stream, a);
+  hipLaunchKernelGGL(k_scan_digit_chain, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), dyn, stream, a);
   return hipGetLastError();
 }
 
