@@ -24,6 +24,7 @@ hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
+hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -119,10 +120,11 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) generation (A/B profiling);
-// default 4 = chain-prefilter kernel, 3 = candidate-list kernel, each only when the program allows it;
+// default 5 = wave-local chain-prefilter kernel, 4 = workgroup chain kernel, 3 = candidate-list kernel, each
+// only when the program allows it;
 // both hand the scan to generation 2 when a tile raises the fallback flag.
 int digitKernelGeneration() {
-  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 4; }();
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 5; }();
   return g;
 }
 
@@ -189,9 +191,12 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   }
   int gen = digitKernelGeneration();
   if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
+  if (gen > 5) gen = 5;
   if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
 relaunch:
-  a.ngroups = (h->kind == cxgdev::kKindDigit && gen >= 4) ? (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles : a.ntiles;
+  a.ngroups = a.ntiles;
+  if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
+  if (h->kind == cxgdev::kKindDigit && gen == 5) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
@@ -202,7 +207,8 @@ relaunch:
       if (gen == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
       else if (gen == 2) le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
       else if (gen == 3) le = cxgdev::launch_scan_digit_list(a, h->fwd_states, stream);
-      else le = cxgdev::launch_scan_digit_chain(a, h->fwd_states, stream);
+      else if (gen == 4) le = cxgdev::launch_scan_digit_chain(a, h->fwd_states, stream);
+      else le = cxgdev::launch_scan_digit_wave(a, h->fwd_states, stream);
       break;
     case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
     case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;

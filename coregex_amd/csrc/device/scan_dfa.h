@@ -11,6 +11,12 @@ constexpr int kTile = kThreads * kChunk;      // 16 KiB per workgroup
 constexpr int kHaloChunks = 4;
 constexpr int kHalo = kHaloChunks * kChunk;   // 256 B staged past the tile for lanes that overrun
 constexpr int kGroupTiles = 8;                // tiles per workgroup in the grouped kernels (one ticket / look-back per 128 KiB)
+// wave-tile geometry of scan_digit_wave.hip: one wave64 per 3840 B (+256 B halo = 64 bitmap words)
+constexpr int kWaveTile = 3840;
+constexpr int kWaveHalo = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int kTilesPerWave = 8;
+constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
 constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
 
 struct ScanArgs {

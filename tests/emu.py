@@ -18,7 +18,7 @@ def lib():
         L.emu_find_all.restype = C.c_int64
         L.emu_find_all.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_int]
         L.emu_find_all_chain.restype = C.c_int64
-        L.emu_find_all_chain.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64]
+        L.emu_find_all_chain.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
         L.emu_find_all_submatch.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64]
         _lib = L
@@ -52,14 +52,14 @@ def find_all_submatch(span_blob: bytes, cap_blob: bytes, hay, width: int, chunk:
         cap = int(n)
 
 
-def find_all_chain(blob: bytes, hay):
+def find_all_chain(blob: bytes, hay, tile: int = 16384, halo: int = 256):
     """Fourth-generation digit kernel, emulated.  Returns None when the tile-level fallback flag would be raised."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
     cap = 1 << 12
     while True:
         out = np.empty(cap, dtype=np.int64)
-        n = lib().emu_find_all_chain(blob, padded.ctypes.data + 8, a.size, out.ctypes.data, cap)
+        n = lib().emu_find_all_chain(blob, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, halo)
         if n == -5:
             return None
         assert n >= 0, f"emulator error {n}"

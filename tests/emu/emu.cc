@@ -148,7 +148,8 @@ struct PlainMem {
 };
 }  // namespace
 
-extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals) {
+extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                      int tile_bytes, int halo_bytes) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic || h->kind != kKindDigit) return -1;
   if ((h->flags & (kFlagFastDigit | kFlagChain)) != (kFlagFastDigit | kFlagChain)) return -4;
@@ -156,15 +157,15 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
   const uint8_t* sfl = blob + h->aux_off;
   const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
   DfaView f{blob + h->fwd_off, 256, h->fwd_start, h->fwd_first_accept};
-  const int nwd = kThreads + kHaloChunks, NW = nwd + 1;
+  const int nwd = (tile_bytes + halo_bytes) / 64, NW = nwd + 1;
   const int64_t N = 64LL * NW;
   std::vector<int64_t> res;
-  const uint64_t ntiles = (len + kTile - 1) / kTile;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
   for (uint64_t t = 0; t < ntiles; t++) {
-    const uint64_t tile_lo = t * static_cast<uint64_t>(kTile);
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
     const uint64_t remaining = len - tile_lo;
     const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
-    const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
+    const int32_t stage = rend < tile_bytes + halo_bytes ? rend : tile_bytes + halo_bytes;
     const uint8_t* g = hay + tile_lo;
     std::vector<std::vector<uint64_t>> cls(ch.ncls, std::vector<uint64_t>(NW, 0));
     for (int32_t p = 0; p < stage; p++)
@@ -175,7 +176,7 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
     std::vector<uint64_t> G(NW), tmp(NW);
     chain_eval_seq(ch, cp.data(), NW, G.data(), tmp.data());
     bool halo_sync = stage == rend;
-    for (int32_t p = kTile - 1; p < stage && !halo_sync; p++) halo_sync = (info[g[p]] & kInfoSync) != 0;
+    for (int32_t p = tile_bytes - 1; p < stage && !halo_sync; p++) halo_sync = (info[g[p]] & kInfoSync) != 0;
     if (!halo_sync) return -5;
     PlainMem m{g};
     int32_t cur_end = -1;
@@ -190,7 +191,7 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
       int32_t p = c - 1;
       while (p >= 0 && !(info[g[p]] & kInfoSync)) p--;
       int32_t seg = p >= 0 ? p + 1 : ((tile_lo == 0 || (info[g[-1]] & kInfoSync)) ? 0 : -1);
-      if (!(seg >= 0 && seg < kTile)) continue;
+      if (!(seg >= 0 && seg < tile_bytes)) continue;
       if (c >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + c); res.push_back(static_cast<int64_t>(tile_lo) + e); cur_end = e; }
     }
   }

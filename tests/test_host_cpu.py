@@ -160,13 +160,16 @@ def test_chain_prefilter_emulated(oracle):
         for hay in (corpus, synth, b"", b"1.2.3.4", b"9" * 300 + b" 1.2.3.4 " + b"7." * 200):
             got = emu.find_all_chain(p.blob(), hay)
             assert got is not None and got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay))
+            got = emu.find_all_chain(p.blob(), hay, 3840, 256)      # wave-tile geometry (scan_digit_wave.hip)
+            assert got is not None and got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), "wave")
         for _ in range(150):
             n = int(rng.integers(0, 40000))
             hay = alphabet[rng.integers(0, len(alphabet), size=n)].tobytes()
-            got = emu.find_all_chain(p.blob(), hay)
-            if got is None:
-                continue          # no sync byte in a halo: the kernel would hand the scan to the flat kernel
-            assert got.tolist() == o.find_all_index(hay).tolist(), (pat, n)
+            for geom in ((16384, 256), (3840, 256)):
+                got = emu.find_all_chain(p.blob(), hay, *geom)
+                if got is None:
+                    continue      # no sync byte in a halo: the kernel would hand the scan to the flat kernel
+                assert got.tolist() == o.find_all_index(hay).tolist(), (pat, n, geom)
     assert n_ok >= 3
     # a halo without any synchronising byte must raise the fallback flag, never a wrong answer
     assert emu.find_all_chain(cx.compile(r"\d+\.\d+\.\d+\.\d+").blob(), b"1.2.3.4." * 4000) is None
