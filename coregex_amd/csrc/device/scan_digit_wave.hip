@@ -32,9 +32,14 @@ namespace {
 constexpr int kRowStride = 260;
 constexpr int kWRows = 512;                       // rows buffered per wave per group
 
-struct GMem {
+struct GMem {            // bytes of the wave-tile window come from the wave's LDS copy, anything outside from L2/HBM
   const uint8_t* g;
-  __device__ __forceinline__ uint32_t byte(int32_t r) const { return g[r]; }
+  const uint8_t* lds;
+  int32_t lim;
+  __device__ __forceinline__ uint32_t byte(int32_t r) const {
+    if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[r];
+    return g[r];
+  }
   __device__ __forceinline__ uint64_t digits(int32_t) const { return 0; }
   __device__ __forceinline__ int32_t bitmap_limit() const { return 0; }
 };
@@ -72,6 +77,7 @@ __device__ __forceinline__ void wave_lds_sync() {                // same-wave LD
 __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   // DFA table, info, sflags, ChainAux
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][kChainMaxCls][64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_bytes[kWavesPerBlock][kWaveTile + kWaveHalo];
   __shared__ uint32_t s_rowpos[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_rowlen[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_spos[kWavesPerBlock][64];
@@ -124,6 +130,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       for (int k = 0; k < 4; k++) {
         const int v = lane + 64 * k;
         x[k] = (v < nfull) ? *reinterpret_cast<const uint4*>(g + (v << 4)) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {                                 // keep the window's bytes for the verify walks
+        const int v = lane + 64 * k;
+        if (v < nfull) *reinterpret_cast<uint4*>(&s_bytes[wave][v << 4]) = x[k];
       }
       uint64_t C0 = 0, C1 = 0, C2 = 0, C3 = 0;                      // class words (wave-uniform selects, no indexed registers)
       for (uint32_t c = 0; c < ncls; c++) {
@@ -214,13 +225,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       uint32_t owned = 0;
       if (static_cast<uint32_t>(lane) < nsurv) {
         c = s_spos[wave][lane];
-        GMem m{g};
+        GMem m{g, s_bytes[wave], nfull << 4};
         const int32_t e = verify_jump(m, fv, s_sfl, c, rend);
         len = e < 0 ? 0 : e - c;
         if (len > 0xFFFF) { fallback = 1; len = 0; }
         if (len) {
           int32_t p = c - 1;
-          while (p >= 0 && !(s_info[g[p]] & kInfoSync)) p--;
+          while (p >= 0 && !(s_info[m.byte(p)] & kInfoSync)) p--;
           int32_t seg;
           if (p >= 0) seg = p + 1;
           else seg = (tile_lo == 0 || (s_info[g[-1]] & kInfoSync)) ? 0 : -1;
