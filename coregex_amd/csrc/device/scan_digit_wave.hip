@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];   // DFA table, info, sflags, ChainAux
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][kChainMaxCls][64];
   __shared__ __attribute__((aligned(16))) uint8_t s_bytes[kWavesPerBlock][kWaveTile + kWaveHalo];
+  __shared__ __attribute__((aligned(16))) uint64_t s_u[kWavesPerBlock][64];   // union of the class bitmaps (complete chains)
   __shared__ uint32_t s_rowpos[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_rowlen[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_spos[kWavesPerBlock][64];
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
+  const bool complete = (h->flags & kFlagChainComplete) != 0;
 
   for (int j = 0; j < kTilesPerWave; j++) {
     const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
@@ -131,10 +133,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
         const int v = lane + 64 * k;
         x[k] = (v < nfull) ? *reinterpret_cast<const uint4*>(g + (v << 4)) : make_uint4(0, 0, 0, 0);
       }
+      if (!complete) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {                                 // keep the window's bytes for the verify walks
-        const int v = lane + 64 * k;
-        if (v < nfull) *reinterpret_cast<uint4*>(&s_bytes[wave][v << 4]) = x[k];
+        for (int k = 0; k < 4; k++) {                               // keep the window's bytes for the verify walks
+          const int v = lane + 64 * k;
+          if (v < nfull) *reinterpret_cast<uint4*>(&s_bytes[wave][v << 4]) = x[k];
+        }
       }
       uint64_t C0 = 0, C1 = 0, C2 = 0, C3 = 0;                      // class words (wave-uniform selects, no indexed registers)
       for (uint32_t c = 0; c < ncls; c++) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       }
       // halo check: is there a synchronising byte in [kWaveTile-1, stage)?  (vectors 239..255 live in load slot 3)
       uint32_t sync_here = 0;
-      {
+      if (!complete) {
         const int v = lane + 192;
         if (v >= 239 && (v << 4) < stage) {
           const uint32_t w[4] = {x[3].x, x[3].y, x[3].z, x[3].w};
@@ -164,12 +168,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
             if (b >= first && (v << 4) + b < stage) sync_here |= s_info[(w[b >> 2] >> ((b & 3) * 8)) & 0xFFu] & kInfoSync;
         }
       }
-      const bool halo_ok = (stage == rend) || (__ballot(sync_here != 0) != 0ull);
       wave_lds_sync();
       C0 = s_cls[wave][0][lane];                                    // lane l holds reversed word l (chunk 63-l)
       if (ncls > 1) C1 = s_cls[wave][1][lane];
       if (ncls > 2) C2 = s_cls[wave][2][lane];
       if (ncls > 3) C3 = s_cls[wave][3][lane];
+      if (complete) {
+        // sync bytes = complement of the class union; the halo is reversed words 0..3 plus bit 0 of word 4
+        const uint64_t U = C0 | C1 | C2 | C3;
+        s_u[wave][lane] = U;
+        const int32_t lo_idx = (kWaveTile + kWaveHalo) - stage;     // reversed indices below this are past the data
+        uint64_t valid = 0;
+        if (lane < 4) { const int32_t sh = lo_idx - 64 * lane; valid = sh <= 0 ? ~0ull : (sh >= 64 ? 0ull : (~0ull << sh)); }
+        else if (lane == 4) valid = (lo_idx <= 256) ? 1ull : 0ull;
+        sync_here = (~U & valid) != 0ull ? 1u : 0u;
+      }
+      const bool halo_ok = (stage == rend) || (__ballot(sync_here != 0) != 0ull);
 
       // ---- B: chain, right to left, in registers
       uint64_t G = ~0ull;
@@ -225,16 +239,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       uint32_t owned = 0;
       if (static_cast<uint32_t>(lane) < nsurv) {
         c = s_spos[wave][lane];
-        GMem m{g, s_bytes[wave], nfull << 4};
-        const int32_t e = verify_jump(m, fv, s_sfl, c, rend);
+        GMem m{g, s_bytes[wave], complete ? 0 : (nfull << 4)};
+        int32_t e = -1;
+        bool walked = false;
+        if (complete) {
+          const uint64_t* cw[kChainMaxCls] = {s_cls[wave][0], s_cls[wave][1], s_cls[wave][2], s_cls[wave][3]};
+          const int32_t ie = chain_walk_end(*s_chain, cw, 4095 - c);
+          if (ie >= 0 && (4095 - ie < stage || (4095 - ie == stage && stage == rend))) { e = 4095 - ie; walked = true; }   // an end AT a cut window edge is unknown
+        }
+        if (!walked) e = verify_jump(m, fv, s_sfl, c, rend);
         len = e < 0 ? 0 : e - c;
         if (len > 0xFFFF) { fallback = 1; len = 0; }
         if (len) {
-          int32_t p = c - 1;
-          while (p >= 0 && !(s_info[m.byte(p)] & kInfoSync)) p--;
           int32_t seg;
-          if (p >= 0) seg = p + 1;
-          else seg = (tile_lo == 0 || (s_info[g[-1]] & kInfoSync)) ? 0 : -1;
+          if (complete) {
+            const int32_t jz = rev_scan_up_zero(s_u[wave], 4096 - c, 4096);   // nearest sync byte before c
+            if (jz < 4096) seg = 4096 - jz;
+            else seg = (tile_lo == 0 || (s_info[g[-1]] & kInfoSync)) ? 0 : -1;
+          } else {
+            int32_t p = c - 1;
+            while (p >= 0 && !(s_info[m.byte(p)] & kInfoSync)) p--;
+            if (p >= 0) seg = p + 1;
+            else seg = (tile_lo == 0 || (s_info[g[-1]] & kInfoSync)) ? 0 : -1;
+          }
           owned = (seg >= 0 && seg < kWaveTile) ? 1u : 0u;
         }
       }

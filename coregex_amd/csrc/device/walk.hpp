@@ -411,6 +411,7 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t _pad[4];
 };
 constexpr uint32_t kFlagChain = 4u;
+constexpr uint32_t kFlagChainComplete = 8u;   // the chain is the whole DFA: survivors are matches, classes = alphabet
 
 CXG_HD bool chain_class_has(const ChainAux& c, int k, uint32_t b) {
   if (c.cls_kind[k] == kClsDigit) return is_digit(b);
@@ -454,6 +455,42 @@ inline void chain_eval_seq(const ChainAux& c, const uint64_t* const* cls, int nw
       for (int w = 0; w < nw; w++) out[w] = tmp[w];
     }
   }
+}
+
+// ---- complete chains: end of match, ownership and halo test straight from the reversed bitmaps -------------
+// W: reversed bitmap of `nw` words (bit i of word w <-> byte N-1-(64w+i), N = 64*nw).
+CXG_HD int32_t rev_scan_down_zero(const uint64_t* W, int32_t i) {       // highest j <= i with bit j clear, or -1
+  while (i >= 0) {
+    const int32_t w = i >> 6, b = i & 63;
+    const uint64_t m = ~W[w] & (b == 63 ? ~0ull : ((2ull << b) - 1ull));
+    if (m) return (w << 6) + 63 - static_cast<int32_t>(__builtin_clzll(m));
+    i = (w << 6) - 1;
+  }
+  return -1;
+}
+CXG_HD int32_t rev_scan_up_zero(const uint64_t* W, int32_t i, int32_t nbits) {   // lowest j >= i with bit j clear, or nbits
+  while (i < nbits) {
+    const int32_t w = i >> 6, b = i & 63;
+    const uint64_t m = ~W[w] & (~0ull << b);
+    if (m) return (w << 6) + static_cast<int32_t>(ctz64(m));
+    i = (w + 1) << 6;
+  }
+  return nbits;
+}
+// Walks the chain forward from reversed index i (a surviving digit-run start).  Returns the reversed index of
+// the first byte after the match, or -2 when the walk leaves the window (caller falls back to the DFA walk).
+CXG_HD int32_t chain_walk_end(const ChainAux& c, const uint64_t* const* cls, int32_t i) {
+  for (uint32_t k = 0; k < c.nops; k++) {
+    const uint64_t* W = cls[c.op_cls[k]];
+    if (i < 0) return -2;
+    if (c.op_kind[k] == kChainRun) {
+      i = rev_scan_down_zero(W, i);
+      if (i < 0) return -2;
+    } else {
+      i -= 1;
+    }
+  }
+  return i < 0 ? -2 : i;
 }
 
 template <class Mem, class Sink>

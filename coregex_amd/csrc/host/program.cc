@@ -297,8 +297,29 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           q = static_cast<uint32_t>(target);
         }
         // the candidates are digit-run starts: the chain is only usable if it begins with run(digit)
-        if (chain.nops >= 2 && chain.op_kind[0] == cxgdev::kChainRun && chain.cls_kind[chain.op_cls[0]] == cxgdev::kClsDigit && chain.op_cls[0] == 0)
+        if (chain.nops >= 2 && chain.op_kind[0] == cxgdev::kChainRun && chain.cls_kind[chain.op_cls[0]] == cxgdev::kClsDigit && chain.op_cls[0] == 0) {
           h.flags |= cxgdev::kFlagChain;
+          // "complete": the chain IS the DFA.  It ended in the only accepting state, that state either loops
+          // (last op is a run) or is terminal, and nothing else leaves it; every byte any state accepts is in
+          // one of the chain classes.  Then a survivor is a match and its end follows from the same steps.
+          bool complete = q >= d.firstAccept && d.firstAccept == d.nstates - 1;
+          if (complete) {
+            for (int b = 0; b < 256 && complete; b++) {
+              const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+              if (t != 0 && t != q) complete = false;
+              const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;
+              if (t == q && !(lastRun && cxgdev::chain_class_has(chain, chain.op_cls[chain.nops - 1], static_cast<uint32_t>(b)))) complete = false;
+            }
+            // the pattern alphabet (non-sync bytes) must equal the union of the chain classes
+            for (int b = 0; b < 256 && complete; b++) {
+              bool inChain = false;
+              for (uint32_t k = 0; k < chain.ncls; k++) inChain = inChain || cxgdev::chain_class_has(chain, static_cast<int>(k), static_cast<uint32_t>(b));
+              const bool inAlphabet = !(info[b] & cxgdev::kInfoSync);
+              if (inChain != inAlphabet) complete = false;
+            }
+          }
+          if (complete) h.flags |= cxgdev::kFlagChainComplete;
+        }
       }
     } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
       // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA

@@ -175,8 +175,14 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
     for (auto& v : cls) cp.push_back(v.data());
     std::vector<uint64_t> G(NW), tmp(NW);
     chain_eval_seq(ch, cp.data(), NW, G.data(), tmp.data());
+    const bool complete = (h->flags & kFlagChainComplete) != 0;
+    std::vector<uint64_t> U(NW, 0);
+    for (auto& v : cls) for (int w = 0; w < NW; w++) U[w] |= v[w];
     bool halo_sync = stage == rend;
-    for (int32_t p = tile_bytes - 1; p < stage && !halo_sync; p++) halo_sync = (info[g[p]] & kInfoSync) != 0;
+    for (int32_t p = tile_bytes - 1; p < stage && !halo_sync; p++) {
+      const int64_t i = N - 1 - p;
+      halo_sync = complete ? !((U[i >> 6] >> (i & 63)) & 1) : (info[g[p]] & kInfoSync) != 0;
+    }
     if (!halo_sync) return -5;
     PlainMem m{g};
     int32_t cur_end = -1;
@@ -186,11 +192,25 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
       const bool prev = (c > 0 || tile_lo > 0) ? is_digit(g[c - 1]) : false;
       if (!(dg && !prev)) continue;
       if (!((G[i >> 6] >> (i & 63)) & 1)) continue;               // pruned by the chain
-      const int32_t e = verify_jump(m, f, sfl, c, rend);
+      int32_t e = -1;
+      bool walked = false;
+      if (complete) {
+        const int32_t ie = chain_walk_end(ch, cp.data(), static_cast<int32_t>(i));
+        if (ie >= 0 && (N - 1 - ie < stage || (N - 1 - ie == stage && stage == rend))) { e = static_cast<int32_t>(N - 1 - ie); walked = true; }
+      }
+      if (!walked) e = verify_jump(m, f, sfl, c, rend);
+      if (complete && e != verify_jump(m, f, sfl, c, rend)) return -6;      // the chain must agree with the DFA
       if (e < 0) continue;
-      int32_t p = c - 1;
-      while (p >= 0 && !(info[g[p]] & kInfoSync)) p--;
-      int32_t seg = p >= 0 ? p + 1 : ((tile_lo == 0 || (info[g[-1]] & kInfoSync)) ? 0 : -1);
+      int32_t seg;
+      if (complete) {
+        const int32_t jz = rev_scan_up_zero(U.data(), static_cast<int32_t>(N - c), static_cast<int32_t>(N));
+        // positions at or beyond `stage` read as zero bits but lie BELOW index N-stage, never above i: safe
+        seg = jz < static_cast<int32_t>(N) ? static_cast<int32_t>(N - jz) : ((tile_lo == 0 || (info[g[-1]] & kInfoSync)) ? 0 : -1);
+      } else {
+        int32_t p = c - 1;
+        while (p >= 0 && !(info[g[p]] & kInfoSync)) p--;
+        seg = p >= 0 ? p + 1 : ((tile_lo == 0 || (info[g[-1]] & kInfoSync)) ? 0 : -1);
+      }
       if (!(seg >= 0 && seg < tile_bytes)) continue;
       if (c >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + c); res.push_back(static_cast<int64_t>(tile_lo) + e); cur_end = e; }
     }
