@@ -115,6 +115,27 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
   uint32_t fallback = 0;
   const bool complete = (h->flags & kFlagChainComplete) != 0;
 
+  // Software pipeline: the 4 loads of wave-tile j+1 are issued as soon as tile j's class masks have been
+  // taken from the registers, so their HBM latency overlaps phases B-D of tile j.
+  uint4 x[4];
+  auto issue_loads = [&](int jj) {
+    const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nf = 0;
+    if (jj < kTilesPerWave && lo < a.len) {
+      const uint64_t rem = a.len - lo;
+      const int32_t st = rem > static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int32_t>(rem);
+      nf = st >> 4;
+    }
+    const uint8_t* gp = a.hay + lo;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int v = lane + 64 * k;
+      x[k] = (v < nf) ? *reinterpret_cast<const uint4*>(gp + (v << 4)) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  issue_loads(0);
+
   for (int j = 0; j < kTilesPerWave; j++) {
     const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
@@ -125,14 +146,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       const int32_t stage = rend < kWaveTile + kWaveHalo ? rend : kWaveTile + kWaveHalo;
       const uint8_t* g = a.hay + tile_lo;
 
-      // ---- A: loads, class masks, transpose through the wave's LDS scratch
-      uint4 x[4];
+      // ---- A: class masks of the vectors loaded one iteration ago, transpose through the wave's LDS scratch
       const int nfull = stage >> 4;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int v = lane + 64 * k;
-        x[k] = (v < nfull) ? *reinterpret_cast<const uint4*>(g + (v << 4)) : make_uint4(0, 0, 0, 0);
-      }
       if (!complete) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {                               // keep the window's bytes for the verify walks
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
             if (b >= first && (v << 4) + b < stage) sync_here |= s_info[(w[b >> 2] >> ((b & 3) * 8)) & 0xFFu] & kInfoSync;
         }
       }
+      issue_loads(j + 1);                                           // x[] is free from here on
       wave_lds_sync();
       C0 = s_cls[wave][0][lane];                                    // lane l holds reversed word l (chunk 63-l)
       if (ncls > 1) C1 = s_cls[wave][1][lane];
