@@ -59,11 +59,18 @@ __device__ __forceinline__ uint32_t cls4(uint32_t x, uint32_t kind, uint32_t lo,
 __device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t kind, uint32_t lo, uint32_t hi) {
   return cls4(x.x, kind, lo, hi) | (cls4(x.y, kind, lo, hi) << 4) | (cls4(x.z, kind, lo, hi) << 8) | (cls4(x.w, kind, lo, hi) << 12);
 }
+// Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
+__device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t dpp_from_upper(uint32_t v) {  // lane i <- lane i+1 (lane 63 keeps its own)
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
 __device__ __forceinline__ uint64_t shfl_up64(uint64_t v) {      // value of lane-1 (lane 0 gets its own)
-  return (static_cast<uint64_t>(__shfl_up(static_cast<unsigned>(v >> 32), 1, 64)) << 32) | __shfl_up(static_cast<unsigned>(v), 1, 64);
+  return (static_cast<uint64_t>(dpp_from_lower(static_cast<uint32_t>(v >> 32))) << 32) | dpp_from_lower(static_cast<uint32_t>(v));
 }
 __device__ __forceinline__ uint64_t shfl_down64(uint64_t v) {    // value of lane+1 (lane 63 gets its own)
-  return (static_cast<uint64_t>(__shfl_down(static_cast<unsigned>(v >> 32), 1, 64)) << 32) | __shfl_down(static_cast<unsigned>(v), 1, 64);
+  return (static_cast<uint64_t>(dpp_from_upper(static_cast<uint32_t>(v >> 32))) << 32) | dpp_from_upper(static_cast<uint32_t>(v));
 }
 __device__ __forceinline__ void wave_lds_sync() {                // same-wave LDS hand-off: drain, no barrier
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
         const int32_t o = __shfl_up(pmax, d, 64);
         if (lane >= d && o > pmax) pmax = o;
       }
-      const int32_t prev_end = __shfl_up(pmax, 1, 64);
+      const int32_t prev_end = static_cast<int32_t>(dpp_from_lower(static_cast<uint32_t>(pmax)));
       const bool overlap = owned && lane > 0 && c < prev_end;
       uint32_t emit = owned;
       if (__ballot(overlap) != 0ull) {
