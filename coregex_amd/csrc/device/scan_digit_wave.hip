@@ -44,20 +44,30 @@ struct GMem {            // bytes of the wave-tile window come from the wave's L
   __device__ __forceinline__ int32_t bitmap_limit() const { return 0; }
 };
 
-__device__ __forceinline__ uint32_t gather4w(uint32_t m80) { return (((m80 >> 7) * 0x00204081u) >> 21) & 0xFu; }
-__device__ __forceinline__ uint32_t cls4(uint32_t x, uint32_t kind, uint32_t lo, uint32_t hi) {
-  if (kind == kClsDigit) return gather4w(digit_mask4(x));
+// 0x80-per-byte flags -> the four flags in bits 28..31 (byte 0 lowest); two shift-or steps, no multiply
+// (v_mul_lo_u32 is quarter rate).  Bits below 28 are junk.
+__device__ __forceinline__ uint32_t gather_top(uint32_t m80) {
+  const uint32_t t = m80 | (m80 << 7);
+  return t | (t << 14);
+}
+// 0x80 flag in every byte of x that is NOT in the class (inverted once per 16 bytes by the caller)
+__device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t kind, uint32_t lo, uint32_t hi) {
+  if (kind == kClsDigit) {
+    const uint32_t t = x ^ 0x30303030u;
+    return (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
+  }
   if (kind == kClsByte) {
     const uint32_t v = x ^ (lo * 0x01010101u);
-    const uint32_t nz = (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
-    return gather4w(nz ^ 0x80808080u);
+    return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
   }
   const uint32_t ge = ((x | 0x80808080u) - lo * 0x01010101u) & 0x80808080u;
   const uint32_t gt = ((x & 0x7F7F7F7Fu) + (0x7Fu - hi) * 0x01010101u) & 0x80808080u;
-  return gather4w(ge & ~gt & ~x & 0x80808080u);
+  return ~(ge & ~gt & ~x) & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t kind, uint32_t lo, uint32_t hi) {
-  return cls4(x.x, kind, lo, hi) | (cls4(x.y, kind, lo, hi) << 4) | (cls4(x.z, kind, lo, hi) << 8) | (cls4(x.w, kind, lo, hi) << 12);
+  const uint32_t n = (gather_top(notcls4(x.x, kind, lo, hi)) >> 28) | ((gather_top(notcls4(x.y, kind, lo, hi)) >> 24) & 0xF0u) |
+                     ((gather_top(notcls4(x.z, kind, lo, hi)) >> 20) & 0xF00u) | ((gather_top(notcls4(x.w, kind, lo, hi)) >> 16) & 0xF000u);
+  return n ^ 0xFFFFu;
 }
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)

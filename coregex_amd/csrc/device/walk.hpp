@@ -56,6 +56,14 @@ struct DfaView {
 };
 
 CXG_HD bool is_digit(uint32_t b) { return (b - 0x30u) < 10u; }
+// state * stride: both < 2^24, so the full-rate 24-bit multiply serves (v_mul_lo_u32 is quarter rate)
+CXG_HD uint32_t rowmul(uint32_t q, uint32_t stride) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(q, stride);
+#else
+  return q * stride;
+#endif
+}
 
 // 0x80 in every byte lane of x that holds an ASCII digit.  x ^ 0x30.. maps '0'..'9' to 0..9 and
 // everything else to >= 10; the carry-free add of 0x76 sets bit 7 exactly for low-7 values >= 10.
@@ -131,7 +139,7 @@ CXG_HD void lane_digit(const Mem& m, const DfaView& d, const uint8_t* info, bool
     for (;;) {
       if (q >= d.first_accept) last = i;
       if (i >= rend) break;
-      q = d.T[q * d.stride + m.byte(i)];
+      q = d.T[rowmul(q, d.stride) + m.byte(i)];
       if (q == 0) break;
       i++;
     }
@@ -214,7 +222,7 @@ CXG_HD void lane_digit_flat(const Mem& m, const DfaView& d, const uint8_t* info,
     if (!end) {
       const int32_t ni = i + 1 < rend ? i + 1 : i;     // speculative fetch of the next byte, off the q chain
       const uint32_t nxt = m.byte(ni);
-      q = d.T[q * d.stride + cur];
+      q = d.T[rowmul(q, d.stride) + cur];
       cur = nxt;
       if (q == 0) end = true; else i++;
     }
@@ -337,7 +345,7 @@ CXG_HD int32_t verify_jump(const Mem& m, const DfaView& d, const uint8_t* sflags
     if (i >= rend) break;
     const uint32_t b = m.byte(i);
     if ((sflags[q] & kStateDigitLoop) && is_digit(b)) { i = next_nondigit(m, i + 1, rend); continue; }
-    q = d.T[q * d.stride + b];
+    q = d.T[rowmul(q, d.stride) + b];
     if (q == 0) break;
     i++;
   }
@@ -506,7 +514,7 @@ CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const u
       if (q >= f.first_accept) last = i;
       if (i >= rend) break;
       if (q == f.start && i >= c1 && last < 0 && i > 0 && (info[m.byte(i - 1)] & kInfoSync)) return;
-      q = f.T[q * f.stride + m.byte(i)];
+      q = f.T[rowmul(q, f.stride) + m.byte(i)];
       if (q == 0) break;
       i++;
     }
@@ -515,7 +523,7 @@ CXG_HD void lane_bidir(const Mem& m, const DfaView& f, const DfaView& r, const u
     uint32_t s = r.start;
     int32_t st = -1;
     for (int32_t at = last - 1; at >= pos; at--) {
-      s = r.T[s * r.stride + m.byte(at)];
+      s = r.T[rowmul(s, r.stride) + m.byte(at)];
       if (s == 0) break;
       if (s >= r.first_accept) st = at;
     }
