@@ -70,7 +70,7 @@ class Regex:
         self.pattern = pattern
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib._lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and _lib._lib is not None:
             _lib._lib.cxg_program_destroy(self._h)
             self._h = None
 
@@ -192,7 +192,7 @@ class DeviceBuffer:
         self.length = length
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib._lib is not None:
+        if getattr(self, "_h", None) and _lib is not None and _lib._lib is not None:
             _lib._lib.cxg_buffer_free(self._h)
             self._h = None
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
         for (int k = 0; k < 4; k++) {
           const int v = lane + 64 * k;
           uint32_t mask = 0;
-          if (v < nfull) mask = cls16(x[k], kind, lo, hi);
+          if (v < nfull) mask = (a.dbg & 0x40000u) ? (x[k].x & 1u) : cls16(x[k], kind, lo, hi);
           else if (v == nfull) {
             const int base = v << 4;
             for (int b = 0; base + b < stage; b++) mask |= (chain_class_has(*s_chain, static_cast<int>(c), g[base + b]) ? 1u : 0u) << b;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
         }
       }
       issue_loads(j + 1);                                           // x[] is free from here on
-      wave_lds_sync();
+      if (!(a.dbg & 0x400000u)) wave_lds_sync();
       C0 = s_cls[wave][0][lane];                                    // lane l holds reversed word l (chunk 63-l)
       if (ncls > 1) C1 = s_cls[wave][1][lane];
       if (ncls > 2) C2 = s_cls[wave][2][lane];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       // ---- B: chain, right to left, in registers
       uint64_t G = ~0ull;
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
-      for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
+      for (int k = (a.dbg & 0x10000u) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) {
         const uint32_t ci = s_chain->op_cls[k];
         const uint64_t Ck = ci == 0 ? C0 : ci == 1 ? C1 : ci == 2 ? C2 : C3;
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
@@ -247,6 +247,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       uint64_t dup = shfl_down64(D);
       if (lane == 63) dup = (tile_lo > 0 && is_digit(g[-1])) ? 1ull : 0ull;
       uint64_t surv = D & ~((D >> 1) | (dup << 63)) & G;
+      if (a.dbg & 0x30000u) surv = (a.dbg & 0x80000u) ? (surv & 1ull) : 0ull;   // timing experiments: no / few survivors
+      if (a.dbg & 0x200000u) { if (surv == 0x123456789ull) emitted_here = 1; }
+      else {
       // ---- C: compaction in ascending position (= descending lane, descending bit)
       const uint32_t mine = static_cast<uint32_t>(__popcll(surv));
       uint32_t suffix = mine;                                       // inclusive suffix sum over lanes >= lane
@@ -335,10 +338,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
           s_rowlen[wave][r] = static_cast<uint16_t>(len);
         }
       }
+      }
     }
     if (lane == 0) s_cnt[wave][j] = emitted_here;
     nrows_w += emitted_here;
   }
+  if (a.dbg & 0x100000u) return;
   if (nrows_w > static_cast<uint32_t>(kWRows)) fallback = 1;
   if (__ballot(fallback != 0) != 0ull && lane == 0) atomicOr(a.err, 8u);
   __syncthreads();

@@ -1,0 +1,18 @@
+# timing ablations of the gen5 kernel (results are WRONG under CXG_DEBUG; time only)
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+cat > /tmp/abl.py <<'PY'
+import os, sys, torch, coregex_amd as cx
+from coregex_amd import Timing
+pat = sys.argv[1] if len(sys.argv) > 1 else r"\d+\.\d+\.\d+\.\d+"
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+n = 1 << 30
+buf = cx.DeviceBuffer(n); buf.fill_synth(cfg, 1, 0)
+re_ = cx.compile(pat)
+out = torch.empty((24_000_000 if cfg != 4 else 200_000_000, 2), dtype=torch.int64, device="cuda")
+t = Timing(); best = 1e9; cnt = 0
+for i in range(6):
+    cnt = re_.find_all_device(buf.ptr, n, out.data_ptr(), out.shape[0], timing=t)
+    if i: best = min(best, t.kernel_ms)
+print(os.environ.get("CXG_DEBUG", "0"), pat, "count", cnt, "kernel_ms", round(best, 4))
+PY
+for d in 0 458752 1507328 2555904 3604480 7798784; do CXG_DEBUG=$d PYTHONPATH=$GRAFT_REPO_ROOT timeout 120 python /tmp/abl.py 2>/dev/null | tail -1; done
