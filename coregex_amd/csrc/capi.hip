@@ -25,6 +25,7 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -120,11 +121,12 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) generation (A/B profiling);
-// default 5 = wave-local chain-prefilter kernel, 4 = workgroup chain kernel, 3 = candidate-list kernel, each
-// only when the program allows it;
-// both hand the scan to generation 2 when a tile raises the fallback flag.
+// default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain),
+// 5 = wave-local chain-prefilter kernel, 4 = workgroup chain kernel, 3 = candidate-list kernel, each only when
+// the program allows it; all hand the scan to generation 2 (UseDFA: the bidirectional table kernel) when a
+// tile raises the fallback flag.
 int digitKernelGeneration() {
-  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 5; }();
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 6; }();
   return g;
 }
 
@@ -190,19 +192,27 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     a.prof = s.prof;
   }
   int gen = digitKernelGeneration();
-  if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
-  if (gen > 5) gen = 5;
-  if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
+  uint32_t relaunches = 0;
+  if (gen > 6) gen = 6;
+  if (gen == 6 && !(h->flags & cxgdev::kFlagChainOrdered)) gen = 5;
+  if (h->kind == cxgdev::kKindDigit) {
+    if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
+    if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
+  } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
 relaunch:
   a.ngroups = a.ntiles;
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
-  if (h->kind == cxgdev::kKindDigit && gen == 5) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  if (gen == 5 || gen == 6) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
-  switch (h->kind) {
+  if (gen == 6) {
+    const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
+    le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls, stream);
+  }
+  else switch (h->kind) {
     case cxgdev::kKindDigit:
       if (gen == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
       else if (gen == 2) le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
@@ -235,23 +245,32 @@ relaunch:
   HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   const uint64_t total = s.hostCtl[1];
-  const uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
+  uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
   if (timing) {
     float k = 0, t = 0;
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
-    timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches;
+    timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
   }
   if (profOn) {
     uint64_t pc[8];
     HIP_TRY(hipMemcpy(pc, s.prof, 64, hipMemcpyDeviceToHost));
-    if (pc[5])
+    if (gen == 6 && pc[7])
+      fprintf(stderr, "[CXG_PROF] gen6 pairing mismatch: tile_lo=%llu n=%llu n_ends=%llu cout=%llu zA=%lld zB=%lld stage=%llu (count %llu)\n",
+              (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3],
+              (long long)pc[4], (long long)pc[5], (unsigned long long)pc[6], (unsigned long long)pc[7]);
+    else if (pc[5])
       fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
   }
-  if ((err & 8u) && h->kind == cxgdev::kKindDigit && gen >= 3) { gen = 2; goto relaunch; }   // digit-dense tile: candidate list overflowed
+  if ((err & 8u) && gen >= 3) {
+    static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
+    relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // dense tile / no sync byte in a halo: table kernels
+  }
+  err &= 0xFFu;
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
   if (dbgBits) { if (n_out) *n_out = total; return CXG_OK; }
   uint64_t n = total;

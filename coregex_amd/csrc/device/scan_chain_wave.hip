@@ -1,0 +1,409 @@
+// scan_chain_wave.hip — FindAll for programs whose anchored DFA is ONE complete, ordered chain of
+// run(class+) / byte(class) steps (walk.hpp ChainAux, program.cc extractChain): `\d+\.\d+\.\d+\.\d+`
+// (UseDigitPrefilter), a literal such as `error`, `[a-z]+=\d+` (UseDFA).  Sixth kernel generation: the whole
+// search — candidates, match ends, segment ownership — is bit-parallel on class bitmaps; no DFA table,
+// no per-match walk, no workgroup barrier on the data path.
+//
+// Reference semantics kept (meta/findall.go:176-283 over the DFA searches of dfa/lazy/lazy.go): leftmost-first
+// match at or after `pos`, non-empty, next search from its end.  For a complete chain "a match starts at p" is
+// "the chain can be taken from p" and its end is where the (greedy, deterministic) steps lead.
+//
+// One wave64 owns a wave-tile of 60 x 64 B = 3840 B and reads 256 B of halo behind it: 4096 B = 64 bitmap
+// words, one per lane.
+//   A  4 coalesced 16-byte loads per lane (software-pipelined one tile ahead); per class a 16-bit mask per
+//      vector (SWAR compare + shift-or gather) into the wave's LDS scratch; lane l reads forward word l and,
+//      bit-reversed, word 63-l (the reversed bitmap: bit i <-> byte 4095-i).
+//   B  chain right to left on the REVERSED words: a run step is one multiword addition (carries move towards
+//      earlier bytes), resolved across lanes with two ballots: recv = (P + (G<<1)) ^ P.  Result: the starts S.
+//   O  ownership, wave-uniform: with zA = first synchronising byte at >= -1 and zB = first one at >= 3839, the
+//      tile owns exactly the starts in (zA, zB] (a match never crosses a synchronising byte).
+//   F  chain left to right on the FORWARD words from the owned starts: run step M = (M + C) & ~C, byte step
+//      M <<= 1.  Result: the ends E; the k-th start pairs with the k-th end ("ordered" chains).
+//   P  ranks of starts and ends by one packed DPP prefix sum; (start, end) meet again in LDS; FindAll drops a
+//      match that begins inside the previous emitted one (adjacent compare; rare serial path when it happens).
+// A workgroup (4 waves) takes ONE ticket per 32 wave-tiles (120 KiB); after a single barrier the group's
+// rows are ordered, looked back (block_common.hpp) and written as coalesced 16-byte stores.
+// Fallback flag (err bit 8: the host reruns the scan with the table-walking kernels): no synchronising byte
+// in a halo, > 64 owned starts in a wave-tile, row buffer overflow, or a violated pairing invariant.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_common.hpp"
+#include "scan_dfa.h"
+#include "walk.hpp"
+
+#ifndef CXG_CHAIN_WAVES
+#define CXG_CHAIN_WAVES 5
+#endif
+#ifndef CXG_CHAIN_PREFETCH
+#define CXG_CHAIN_PREFETCH 1
+#endif
+
+namespace cxgdev {
+
+namespace {
+
+constexpr int kWRows = 512;                       // rows buffered per wave per group
+constexpr int32_t kFar = 1 << 20;                 // "no such byte" position
+
+// 0x80-per-byte flags -> the four flags in bits 28..31 (byte 0 lowest); two shift-or steps, no multiply
+// (v_mul_lo_u32 is quarter rate).  Bits below 28 are junk.
+__device__ __forceinline__ uint32_t gather_top(uint32_t m80) {
+  const uint32_t t = m80 | (m80 << 7);
+  return t | (t << 14);
+}
+// 0x80 flag in every byte of x that is NOT in the class (inverted once per 16 bytes by the caller)
+__device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t kind, uint32_t lo, uint32_t hi) {
+  if (kind == kClsDigit) {
+    const uint32_t t = x ^ 0x30303030u;
+    return (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
+  }
+  if (kind == kClsByte) {
+    const uint32_t v = x ^ (lo * 0x01010101u);
+    return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+  }
+  const uint32_t ge = ((x | 0x80808080u) - lo * 0x01010101u) & 0x80808080u;
+  const uint32_t gt = ((x & 0x7F7F7F7Fu) + (0x7Fu - hi) * 0x01010101u) & 0x80808080u;
+  return ~(ge & ~gt & ~x) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t kind, uint32_t lo, uint32_t hi) {
+  const uint32_t n = (gather_top(notcls4(x.x, kind, lo, hi)) >> 28) | ((gather_top(notcls4(x.y, kind, lo, hi)) >> 24) & 0xF0u) |
+                     ((gather_top(notcls4(x.z, kind, lo, hi)) >> 20) & 0xF00u) | ((gather_top(notcls4(x.w, kind, lo, hi)) >> 16) & 0xF000u);
+  return n ^ 0xFFFFu;
+}
+// Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
+__device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint32_t dpp_from_upper(uint32_t v) {  // lane i <- lane i+1 (lane 63 keeps its own)
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
+__device__ __forceinline__ uint64_t from_lower64(uint64_t v) {
+  return (static_cast<uint64_t>(dpp_from_lower(static_cast<uint32_t>(v >> 32))) << 32) | dpp_from_lower(static_cast<uint32_t>(v));
+}
+__device__ __forceinline__ uint64_t from_upper64(uint64_t v) {
+  return (static_cast<uint64_t>(dpp_from_upper(static_cast<uint32_t>(v >> 32))) << 32) | dpp_from_upper(static_cast<uint32_t>(v));
+}
+__device__ __forceinline__ uint64_t brev64(uint64_t v) {
+  return (static_cast<uint64_t>(__brev(static_cast<uint32_t>(v))) << 32) | __brev(static_cast<uint32_t>(v >> 32));
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l))) << 32) |
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+}
+__device__ __forceinline__ void wave_lds_sync() {                // same-wave LDS hand-off: drain, no barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Inclusive prefix sum over the 64 lanes, all DPP (row shifts, then row broadcasts).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111 /*row_shr:1*/, 0xF, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112 /*row_shr:2*/, 0xF, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114 /*row_shr:4*/, 0xF, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142 /*row_bcast:15*/, 0xA, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143 /*row_bcast:31*/, 0xC, 0xF, false));
+  return v;
+}
+// bits [lo, hi] (inclusive, window bit indices) that fall into lane's word [64*lane, 64*lane+63]
+__device__ __forceinline__ uint64_t word_range(int lane, int32_t lo, int32_t hi) {
+  const int32_t a = lo - 64 * lane, b = hi - 64 * lane;
+  if (b < 0 || a > 63) return 0ull;
+  const uint64_t ge = a <= 0 ? ~0ull : (~0ull << a);
+  const uint64_t le = b >= 63 ? ~0ull : ((2ull << b) - 1ull);
+  return ge & le;
+}
+
+}  // namespace
+
+template <int NCLS>
+__device__ __forceinline__ uint64_t pick(const uint64_t (&w)[NCLS], uint32_t ci) {   // wave-uniform select, no indexed registers
+  uint64_t v = w[0];
+#pragma unroll
+  for (int c = 1; c < NCLS; c++) v = (ci == static_cast<uint32_t>(c)) ? w[c] : v;
+  return v;
+}
+
+template <int NCLS>
+__global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
+  __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];                   // starts, reversed -> forward
+  __shared__ uint32_t s_rowpos[kWavesPerBlock][kWRows];
+  __shared__ uint16_t s_rowlen[kWavesPerBlock][kWRows];
+  __shared__ uint16_t s_spos[kWavesPerBlock][64];
+  __shared__ uint16_t s_epos[kWavesPerBlock][66];
+  __shared__ uint8_t s_em[kWavesPerBlock][64];
+  __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
+  __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
+  __shared__ ChainAux s_chain_mem;
+  __shared__ uint64_t s_group;
+  __shared__ uint64_t s_base;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
+  if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(ChainAux) / 4))
+    reinterpret_cast<uint32_t*>(&s_chain_mem)[tid - 64] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off + 256)[tid - 64];
+  __syncthreads();
+  const ChainAux* s_chain = &s_chain_mem;
+  const uint64_t group = s_group;
+  if (group >= a.ngroups) return;
+  const uint32_t nops = s_chain->nops;
+  const bool lead_run = s_chain->op_kind[0] == kChainRun;
+  const uint32_t lead_cls = s_chain->op_cls[0];
+  uint32_t nrows_w = 0;                                            // wave-uniform
+  uint32_t fallback = 0;
+
+  uint4 x[4];
+  auto issue_loads = [&](int jj) {
+    const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nf = 0;
+    if (jj < kTilesPerWave && lo < a.len) {
+      const uint64_t rem = a.len - lo;
+      const int32_t st = rem > static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int32_t>(rem);
+      nf = st >> 4;
+    }
+    const uint8_t* gp = a.hay + lo;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int v = lane + 64 * k;
+      x[k] = (v < nf) ? *reinterpret_cast<const uint4*>(gp + (v << 4)) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (CXG_CHAIN_PREFETCH) issue_loads(0);
+
+  for (int j = 0; j < kTilesPerWave; j++) {
+    if (!CXG_CHAIN_PREFETCH) issue_loads(j);
+    const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
+    const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
+    uint32_t emitted_here = 0;
+    if (tile_lo < a.len) {
+      const uint64_t remaining = a.len - tile_lo;
+      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      const int32_t stage = rend < kWaveTile + kWaveHalo ? rend : kWaveTile + kWaveHalo;
+      const uint8_t* g = a.hay + tile_lo;
+
+      // ---- A: class masks of the vectors loaded one iteration ago, transposed through the wave's LDS scratch
+      const int nfull = stage >> 4;
+#pragma unroll
+      for (int c = 0; c < NCLS; c++) {
+        const uint32_t kind = s_chain->cls_kind[c], lo = s_chain->cls_lo[c], hi = s_chain->cls_hi[c];
+        uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int v = lane + 64 * k;
+          uint32_t mask = 0;
+          if (v < nfull) mask = cls16(x[k], kind, lo, hi);
+          else if (v == nfull) {
+            const int base = v << 4;
+            for (int b = 0; base + b < stage; b++) mask |= (chain_class_has(*s_chain, static_cast<int>(c), g[base + b]) ? 1u : 0u) << b;
+          }
+          pieces[v] = static_cast<uint16_t>(mask);
+        }
+      }
+      if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on
+      wave_lds_sync();
+      uint64_t F[NCLS], R[NCLS], U = 0;                             // forward / reversed words, class union
+#pragma unroll
+      for (int c = 0; c < NCLS; c++) { F[c] = s_cls[wave][c][lane]; R[c] = brev64(s_cls[wave][c][63 - lane]); U |= F[c]; }
+
+      // ---- O: ownership bounds from the synchronising bytes (complement of the class union, inside the data)
+      int32_t zA = -1, zB = kFar;
+      {
+        const int32_t nv = stage - 64 * lane;
+        const uint64_t valid = nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+        const uint64_t Z = ~U & valid;
+        if (tile_lo > 0) {
+          const uint32_t pb = g[-1];
+          bool in_alpha = false;
+#pragma unroll
+          for (int c = 0; c < NCLS; c++) in_alpha = in_alpha || chain_class_has(*s_chain, c, pb);
+          if (in_alpha) {                                           // the segment at the tile's first byte began earlier
+            const unsigned long long bz = __ballot(Z != 0ull);
+            if (bz) { const int L = __builtin_ctzll(bz); zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L))); }
+            else zA = kFar;
+          }
+        }
+        const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kWaveTile + kWaveHalo - 1);
+        const unsigned long long bzb = __ballot(Zb != 0ull);
+        if (bzb) { const int L = __builtin_ctzll(bzb); zB = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, L))); }
+        else if (stage != rend) { zB = -2; fallback |= 1; }         // no synchronising byte in the halo: ownership unknown
+      }
+
+      // ---- B: chain, right to left, on the reversed words
+      uint64_t G = ~0ull;
+      const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
+      for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
+        const uint32_t ci = s_chain->op_cls[k];
+        const uint64_t Ck = pick<NCLS>(R, ci);
+        const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
+        if (s_chain->op_kind[k] == kChainByte) {
+          uint64_t low = from_lower64(G) >> 63;                     // DPP outside any lane-dependent branch: a
+          if (lane == 0) low = inject;                              // disabled source lane would not be read
+          G = Ck & ((G << 1) | low);
+        } else {
+          uint64_t cup = from_upper64(Ck);
+          if (lane == 63) cup = 0;
+          const uint64_t K = G & ~Ck & ((Ck >> 1) | (cup << 63));
+          uint64_t klow = from_lower64(K) >> 63;
+          if (lane == 0) klow = inject & Ck;                        // virtual marker just beyond the last byte
+          const uint64_t M = (K << 1) | klow;
+          const uint64_t s1 = Ck + M;
+          const unsigned long long GG = __ballot(s1 < M);
+          const unsigned long long PP = __ballot(s1 == ~0ull);
+          const unsigned long long recv = (PP + (GG << 1)) ^ PP;    // lanes that receive a carry
+          G = Ck & ~(s1 + ((recv >> lane) & 1ull));
+        }
+      }
+      // starts, reversed orientation: with a leading run only the first byte of the run is a candidate
+      uint64_t surv = G;
+      if (lead_run) {
+        const uint64_t D = pick<NCLS>(R, lead_cls);
+        uint64_t dup = from_upper64(D);
+        if (lane == 63) dup = (tile_lo > 0 && chain_class_has(*s_chain, static_cast<int>(lead_cls), g[-1])) ? 1ull : 0ull;
+        surv = D & ~((D >> 1) | (dup << 63)) & G;
+      }
+      if (__ballot(surv != 0ull) != 0ull) {
+        // ---- to forward orientation, restricted to the owned range (zA, zB]
+        s_x[wave][lane] = surv;
+        wave_lds_sync();
+        const uint64_t S = brev64(s_x[wave][63 - lane]) & word_range(lane, zA + 1, zB);
+        // ---- F: chain left to right on the forward words
+        uint64_t M = S;
+        uint32_t cout = 0;                                          // an end exactly at byte 4096 (end of input)
+        for (uint32_t k = 0; k < nops; k++) {
+          const uint32_t ci = s_chain->op_cls[k];
+          const uint64_t Ck = pick<NCLS>(F, ci);
+          uint32_t co;
+          if (s_chain->op_kind[k] == kChainByte) {
+            co = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(M >> 32), 63)) >> 31;
+            uint64_t low = from_lower64(M) >> 63;
+            if (lane == 0) low = 0ull;
+            M = (M << 1) | low;
+          } else {
+            const uint64_t s1 = Ck + M;
+            const unsigned long long GG = __ballot(s1 < M);
+            const unsigned long long PP = __ballot(s1 == ~0ull);
+            const unsigned long long recv = (PP + (GG << 1)) ^ PP;
+            co = static_cast<uint32_t>(((GG >> 63) | ((PP >> 63) & (recv >> 63))) & 1ull);
+            M = (s1 + ((recv >> lane) & 1ull)) & ~Ck;
+          }
+          if (k + 1 == nops) cout = co;
+          else if (co) fallback |= 2;                                // a match left the window mid-chain: cannot happen for owned starts
+        }
+        // ---- P: ranks of starts and ends, (start, end) pairs
+        const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(M));
+        const uint32_t packed = ns | (ne << 16);
+        const uint32_t incl = wave_inclusive_sum(packed);
+        const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        uint32_t n = tot & 0xFFFFu;
+        const uint32_t n_ends = (tot >> 16) + cout;
+        if (n != n_ends) {                                          // pairing invariant violated
+          if (a.prof && lane == 0 && atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 7), 1ull) == 0ull) {
+            a.prof[0] = tile_lo; a.prof[1] = n; a.prof[2] = n_ends; a.prof[3] = cout; a.prof[4] = static_cast<uint64_t>(static_cast<int64_t>(zA));
+            a.prof[5] = static_cast<uint64_t>(static_cast<int64_t>(zB)); a.prof[6] = static_cast<uint64_t>(stage);
+          }
+          fallback |= 4; n = 0;
+        }
+        if (n > 64u) { fallback |= 8; n = 64u; }
+        {
+          uint32_t is = (incl & 0xFFFFu) - ns, ie = (incl >> 16) - ne;
+          uint64_t sb = S, eb = M;
+          while (sb) {
+            const int bit = __builtin_ctzll(sb);
+            sb &= sb - 1;
+            if (is < 64u) s_spos[wave][is] = static_cast<uint16_t>(64 * lane + bit);
+            is++;
+          }
+          while (eb) {
+            const int bit = __builtin_ctzll(eb);
+            eb &= eb - 1;
+            if (ie < 64u) s_epos[wave][ie] = static_cast<uint16_t>(64 * lane + bit);
+            ie++;
+          }
+          if (cout && lane == 0 && (tot >> 16) < 64u) s_epos[wave][tot >> 16] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
+        }
+        wave_lds_sync();
+        int32_t c = 0, e = 0;
+        uint32_t emit = 0;
+        if (static_cast<uint32_t>(lane) < n) { c = s_spos[wave][lane]; e = s_epos[wave][lane]; emit = 1; }
+        // FindAll order: a match starting inside the previous emitted match is skipped (findall.go:267-275).
+        // Ends ascend with starts, so an overlap shows between neighbours.
+        const int32_t next_c = static_cast<int32_t>(dpp_from_upper(static_cast<uint32_t>(c)));
+        const bool overlap = (static_cast<uint32_t>(lane) + 1u < n) && next_c < e;
+        if (__ballot(overlap) != 0ull) {
+          if (lane == 0) {
+            int32_t cur_end = -1;
+            for (uint32_t k = 0; k < n; k++) {
+              uint8_t em = 0;
+              const int32_t ck = s_spos[wave][k];
+              if (ck >= cur_end) { em = 1; cur_end = s_epos[wave][k]; }
+              s_em[wave][k] = em;
+            }
+          }
+          wave_lds_sync();
+          emit = (static_cast<uint32_t>(lane) < n) ? s_em[wave][lane] : 0u;
+        }
+        const unsigned long long em_mask = __ballot(emit != 0);
+        emitted_here = static_cast<uint32_t>(__popcll(em_mask));
+        if (emit) {
+          const uint32_t r = nrows_w + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
+          if (r < static_cast<uint32_t>(kWRows)) {
+            s_rowpos[wave][r] = static_cast<uint32_t>(j * kWavesPerBlock + wave) * kWaveTile + static_cast<uint32_t>(c);
+            s_rowlen[wave][r] = static_cast<uint16_t>(e - c);
+          }
+        }
+      }
+    }
+    if (lane == 0) s_cnt[wave][j] = emitted_here;
+    nrows_w += emitted_here;
+  }
+  if (nrows_w > static_cast<uint32_t>(kWRows)) fallback |= 16;
+  if (fallback != 0 && lane == 0) atomicOr(a.err, 8u | (fallback << 8));   // bits 8.. = reason (diagnostics, CXG_VERBOSE)
+  __syncthreads();
+
+  // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
+  if (tid < 64) {
+    const int q = tid;
+    const uint32_t v = (q < kWavesPerBlock * kTilesPerWave) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t incl = wave_inclusive_sum(v);
+    if (q < kWavesPerBlock * kTilesPerWave) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * kTilesPerWave - 1) s_qbase[kWavesPerBlock * kTilesPerWave] = incl;
+  }
+  __syncthreads();
+  const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  if (a.out == nullptr) return;
+  const uint64_t base = s_base;
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);
+  uint32_t start = 0;
+  for (int j = 0; j < kTilesPerWave; j++) {
+    const uint32_t n = s_cnt[wave][j];
+    const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
+    for (uint32_t i = lane; i < n; i += 64) {
+      const uint32_t r = start + i;
+      if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
+        longlong2 v; v.x = origin + s_rowpos[wave][r]; v.y = v.x + s_rowlen[wave][r];
+        *reinterpret_cast<longlong2*>(a.out + (dst + i) * 2) = v;
+      }
+    }
+    start += n;
+  }
+}
+
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, hipStream_t stream) {
+  const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  switch (ncls) {
+    case 1: hipLaunchKernelGGL(k_scan_chain_wave<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(k_scan_chain_wave<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(k_scan_chain_wave<3>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(k_scan_chain_wave<4>, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace cxgdev

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
         const uint64_t Ck = ci == 0 ? C0 : ci == 1 ? C1 : ci == 2 ? C2 : C3;
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
         if (s_chain->op_kind[k] == kChainByte) {
-          const uint64_t low = (lane == 0) ? inject : (shfl_up64(G) >> 63);
+          uint64_t low = shfl_up64(G) >> 63;                        // DPP outside any lane-dependent branch: a
+          if (lane == 0) low = inject;                              // disabled source lane would not be read
           G = Ck & ((G << 1) | low);
         } else {
           uint64_t cup = shfl_down64(Ck);

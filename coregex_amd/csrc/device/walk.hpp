@@ -419,6 +419,7 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t _pad[4];
 };
 constexpr uint32_t kFlagChain = 4u;
+constexpr uint32_t kFlagChainOrdered = 16u;    // complete, and the k-th match start pairs with the k-th match end (program.cc extractChain)
 constexpr uint32_t kFlagChainComplete = 8u;   // the chain is the whole DFA: survivors are matches, classes = alphabet
 
 CXG_HD bool chain_class_has(const ChainAux& c, int k, uint32_t b) {

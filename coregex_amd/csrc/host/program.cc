@@ -213,6 +213,75 @@ void appendTable(std::vector<uint8_t>& blob, const Dfa& d, uint32_t& off) {
   while (blob.size() % 16) blob.push_back(0);
 }
 
+// Follows the anchored DFA `d` from its start while it is a chain of run(class+) / byte(class) steps whose
+// classes have a SWAR-friendly form (contiguous ASCII range).  `complete`: the chain IS the DFA — it ended in
+// the only accepting state, that state either loops on the last run's class or is terminal, nothing else
+// leaves it, and the pattern alphabet (non-sync bytes of `info`) equals the union of the chain classes; then
+// a position satisfying the chain is a match and its end follows from the same steps.  `ordered`: no run's
+// class meets the class of the step before it, so two matches starting at different candidates never reach
+// the same step at the same byte: the k-th start pairs with the k-th end (scan_chain_wave.hip).
+void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain, bool& complete, bool& ordered) {
+  std::memset(&chain, 0, sizeof chain);
+  complete = ordered = false;
+  auto classOf = [&](const bool in[256], uint8_t& kind, uint8_t& lo, uint8_t& hi) {
+    int first = -1, last = -1, cnt = 0;
+    for (int b = 0; b < 256; b++) if (in[b]) { if (first < 0) first = b; last = b; cnt++; }
+    if (cnt == 0 || last - first + 1 != cnt || last > 127) return false;     // contiguous ASCII range only
+    lo = static_cast<uint8_t>(first); hi = static_cast<uint8_t>(last);
+    kind = (first == '0' && last == '9') ? cxgdev::kClsDigit : (cnt == 1 ? cxgdev::kClsByte : cxgdev::kClsRange);
+    return true;
+  };
+  uint32_t q = d.start;
+  for (int step = 0; step < cxgdev::kChainMaxOps; step++) {
+    if (q >= d.firstAccept) break;                       // a match may end here: later steps are not necessary
+    int target = -1; bool branching = false;
+    bool F[256] = {false};
+    for (int b = 0; b < 256; b++) {
+      const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+      if (t == 0 || t == q) continue;
+      if (target < 0) target = static_cast<int>(t);
+      if (static_cast<int>(t) != target) { branching = true; break; }
+      F[b] = true;
+    }
+    if (branching || target < 0) break;
+    bool loopT[256] = {false}; bool anyLoop = false, same = true;
+    for (int b = 0; b < 256; b++) { loopT[b] = d.table[static_cast<size_t>(target) * 256 + b] == static_cast<uint32_t>(target); anyLoop = anyLoop || loopT[b]; }
+    for (int b = 0; b < 256; b++) if (loopT[b] != F[b]) same = false;
+    uint8_t kind, lo, hi;
+    if (!classOf(F, kind, lo, hi)) break;
+    if (anyLoop && !same) break;                         // loops on a different class: not a plain run
+    int ci = -1;
+    for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == kind && chain.cls_lo[k] == lo && chain.cls_hi[k] == hi) ci = static_cast<int>(k);
+    if (ci < 0) { if (chain.ncls >= cxgdev::kChainMaxCls) break; ci = static_cast<int>(chain.ncls++); chain.cls_kind[ci] = kind; chain.cls_lo[ci] = lo; chain.cls_hi[ci] = hi; }
+    chain.op_kind[chain.nops] = anyLoop ? cxgdev::kChainRun : cxgdev::kChainByte;
+    chain.op_cls[chain.nops] = static_cast<uint8_t>(ci);
+    chain.nops++;
+    q = static_cast<uint32_t>(target);
+  }
+  if (chain.nops == 0) return;
+  complete = q >= d.firstAccept && d.firstAccept == d.nstates - 1;
+  if (complete) {
+    const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;
+    for (int b = 0; b < 256 && complete; b++) {
+      const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+      if (t != 0 && t != q) complete = false;
+      if (t == q && !(lastRun && cxgdev::chain_class_has(chain, chain.op_cls[chain.nops - 1], static_cast<uint32_t>(b)))) complete = false;
+    }
+    for (int b = 0; b < 256 && complete; b++) {
+      bool inChain = false;
+      for (uint32_t k = 0; k < chain.ncls; k++) inChain = inChain || cxgdev::chain_class_has(chain, static_cast<int>(k), static_cast<uint32_t>(b));
+      const bool inAlphabet = !(info[b] & cxgdev::kInfoSync);
+      if (inChain != inAlphabet) complete = false;
+    }
+  }
+  ordered = true;
+  for (uint32_t k = 1; k < chain.nops; k++) {
+    if (chain.op_kind[k] != cxgdev::kChainRun) continue;
+    for (int b = 0; b < 256; b++)
+      if (cxgdev::chain_class_has(chain, chain.op_cls[k], static_cast<uint32_t>(b)) && cxgdev::chain_class_has(chain, chain.op_cls[k - 1], static_cast<uint32_t>(b))) ordered = false;
+  }
+}
+
 }  // namespace
 
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
@@ -256,69 +325,17 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         if (loop) sflags[q] |= cxgdev::kStateDigitLoop;
       }
       if ((flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) && tailClosed) h.flags |= cxgdev::kFlagFastDigit;
-      // chain prefilter (walk.hpp "chain prefilter"): follow the DFA while it is a chain of
-      // run(class+) / byte(class) steps whose classes have a SWAR-friendly form.
+      // chain prefilter (walk.hpp "chain prefilter"); the candidates are digit-run starts, so the chain is
+      // only usable if it begins with run(digit)
       if (h.flags & cxgdev::kFlagFastDigit) {
-        std::memset(&chain, 0, sizeof chain);
-        const Dfa& d = p->fwd;
-        auto classOf = [&](const bool in[256], uint8_t& kind, uint8_t& lo, uint8_t& hi) {
-          int first = -1, last = -1, cnt = 0;
-          for (int b = 0; b < 256; b++) if (in[b]) { if (first < 0) first = b; last = b; cnt++; }
-          if (cnt == 0 || last - first + 1 != cnt || last > 127) return false;     // contiguous ASCII range only
-          lo = static_cast<uint8_t>(first); hi = static_cast<uint8_t>(last);
-          kind = (first == '0' && last == '9') ? cxgdev::kClsDigit : (cnt == 1 ? cxgdev::kClsByte : cxgdev::kClsRange);
-          return true;
-        };
-        uint32_t q = d.start;
-        for (int step = 0; step < cxgdev::kChainMaxOps; step++) {
-          if (q >= d.firstAccept) break;                       // a match may end here: later steps are not necessary
-          int target = -1; bool branching = false;
-          bool F[256] = {false};
-          for (int b = 0; b < 256; b++) {
-            const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
-            if (t == 0 || t == q) continue;
-            if (target < 0) target = static_cast<int>(t);
-            if (static_cast<int>(t) != target) { branching = true; break; }
-            F[b] = true;
-          }
-          if (branching || target < 0) break;
-          bool loopT[256] = {false}; bool anyLoop = false, same = true;
-          for (int b = 0; b < 256; b++) { loopT[b] = d.table[static_cast<size_t>(target) * 256 + b] == static_cast<uint32_t>(target); anyLoop = anyLoop || loopT[b]; }
-          for (int b = 0; b < 256; b++) if (loopT[b] != F[b]) same = false;
-          uint8_t kind, lo, hi;
-          if (!classOf(F, kind, lo, hi)) break;
-          if (anyLoop && !same) break;                         // loops on a different class: not a plain run
-          int ci = -1;
-          for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == kind && chain.cls_lo[k] == lo && chain.cls_hi[k] == hi) ci = static_cast<int>(k);
-          if (ci < 0) { if (chain.ncls >= cxgdev::kChainMaxCls) break; ci = static_cast<int>(chain.ncls++); chain.cls_kind[ci] = kind; chain.cls_lo[ci] = lo; chain.cls_hi[ci] = hi; }
-          chain.op_kind[chain.nops] = anyLoop ? cxgdev::kChainRun : cxgdev::kChainByte;
-          chain.op_cls[chain.nops] = static_cast<uint8_t>(ci);
-          chain.nops++;
-          q = static_cast<uint32_t>(target);
-        }
-        // the candidates are digit-run starts: the chain is only usable if it begins with run(digit)
+        bool complete = false, ordered = false;
+        extractChain(p->fwd, info, chain, complete, ordered);
         if (chain.nops >= 2 && chain.op_kind[0] == cxgdev::kChainRun && chain.cls_kind[chain.op_cls[0]] == cxgdev::kClsDigit && chain.op_cls[0] == 0) {
           h.flags |= cxgdev::kFlagChain;
-          // "complete": the chain IS the DFA.  It ended in the only accepting state, that state either loops
-          // (last op is a run) or is terminal, and nothing else leaves it; every byte any state accepts is in
-          // one of the chain classes.  Then a survivor is a match and its end follows from the same steps.
-          bool complete = q >= d.firstAccept && d.firstAccept == d.nstates - 1;
-          if (complete) {
-            for (int b = 0; b < 256 && complete; b++) {
-              const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
-              if (t != 0 && t != q) complete = false;
-              const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;
-              if (t == q && !(lastRun && cxgdev::chain_class_has(chain, chain.op_cls[chain.nops - 1], static_cast<uint32_t>(b)))) complete = false;
-            }
-            // the pattern alphabet (non-sync bytes) must equal the union of the chain classes
-            for (int b = 0; b < 256 && complete; b++) {
-              bool inChain = false;
-              for (uint32_t k = 0; k < chain.ncls; k++) inChain = inChain || cxgdev::chain_class_has(chain, static_cast<int>(k), static_cast<uint32_t>(b));
-              const bool inAlphabet = !(info[b] & cxgdev::kInfoSync);
-              if (inChain != inAlphabet) complete = false;
-            }
-          }
           if (complete) h.flags |= cxgdev::kFlagChainComplete;
+          if (complete && ordered) h.flags |= cxgdev::kFlagChainOrdered;
+        } else {
+          std::memset(&chain, 0, sizeof chain);
         }
       }
     } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
@@ -333,6 +350,19 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       h.kind = cxgdev::kKindBidir;
       for (int b = 0; b < 256; b++)
         if (p->fwd.table[static_cast<size_t>(p->fwd.start) * 256 + b] == p->fwd.start) info[b] |= cxgdev::kInfoStartIdle;
+      // When the anchored DFA is one complete, ordered chain (a literal, `[a-z]+=\d+`, ...) the leftmost-first
+      // FindAll result is a pure bit-parallel function of the class bitmaps: scan_chain_wave.hip.
+      try {
+        const Dfa anch = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
+        bool complete = false, ordered = false;
+        extractChain(anch, info, chain, complete, ordered);
+        if (chain.nops >= 1 && complete && ordered) {
+          h.flags |= cxgdev::kFlagChain | cxgdev::kFlagChainComplete | cxgdev::kFlagChainOrdered;
+          sflags.assign(256, 0);                                    // keeps the aux layout of the digit image
+        } else {
+          std::memset(&chain, 0, sizeof chain);
+        }
+      } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
     }

@@ -15,4 +15,5 @@ for i in range(6):
     if i: best = min(best, t.kernel_ms)
 print(os.environ.get("CXG_DEBUG", "0"), pat, "count", cnt, "kernel_ms", round(best, 4), "launches", t.n_launches)
 PY
-for d in 0 458752 1507328 2555904 3604480 7798784; do CXG_DEBUG=$d PYTHONPATH=$GRAFT_REPO_ROOT timeout 120 python /tmp/abl.py 2>/dev/null | tail -1; done
+for d in 0; do CXG_PROF=1 CXG_VERBOSE=1 CXG_DEBUG=$d PYTHONPATH=$GRAFT_REPO_ROOT timeout 120 python /tmp/abl.py 2>&1 | grep -v "^$" | grep -v "^\[cxg\]" | sort | uniq -c | tail -8; done
+

@@ -219,3 +219,108 @@ extern "C" int64_t emu_find_all_chain(const uint8_t* blob, const uint8_t* hay, u
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Sequential twin of scan_chain_wave.hip (sixth generation): everything from the class bitmaps — starts by
+// the right-to-left chain on the reversed bitmap, ownership from the synchronising bytes (zA, zB], ends by
+// the left-to-right chain on the forward bitmap, k-th start paired with k-th end.  Window = tile + halo
+// bytes (a multiple of 64).  Returns the number of int64 values, or -(16 + reason) when a tile would raise
+// the fallback flag (reason bits as in the kernel).
+namespace {
+struct MW {                       // little multiword helpers on forward or reversed bitmaps of nw words
+  static bool get(const std::vector<uint64_t>& w, int64_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
+  static void set(std::vector<uint64_t>& w, int64_t i) { w[i >> 6] |= 1ull << (i & 63); }
+};
+}  // namespace
+
+extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                       int tile_bytes, int halo_bytes) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic) return -1;
+  if (!(h->flags & kFlagChainOrdered)) return -4;
+  const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
+  const int NW = (tile_bytes + halo_bytes) / 64;
+  const int64_t N = 64LL * NW;
+  if (N != tile_bytes + halo_bytes) return -2;
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  auto in_alpha = [&](uint32_t b) { for (uint32_t c = 0; c < ch.ncls; c++) if (chain_class_has(ch, static_cast<int>(c), b)) return true; return false; };
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
+    const uint64_t remaining = len - tile_lo;
+    const int64_t rend = static_cast<int64_t>(remaining);
+    const int64_t stage = rend < N ? rend : N;
+    const uint8_t* g = hay + tile_lo;
+    // reversed bitmaps get one spare word below the window (index < 64 <-> bytes past the window: no class, any G),
+    // which is what the kernel's `inject` amounts to at the end of input and harmless elsewhere (not owned)
+    const int64_t Nr = N + 64;
+    std::vector<std::vector<uint64_t>> F(ch.ncls, std::vector<uint64_t>(NW, 0)), R(ch.ncls, std::vector<uint64_t>(NW + 1, 0));
+    for (int64_t p = 0; p < stage; p++)
+      for (uint32_t c = 0; c < ch.ncls; c++)
+        if (chain_class_has(ch, static_cast<int>(c), g[p])) { MW::set(F[c], p); MW::set(R[c], Nr - 1 - p); }
+    // ---- ownership bounds
+    int64_t zA = -1, zB = 1 << 20;
+    uint32_t reason = 0;
+    if (tile_lo > 0 && in_alpha(g[-1])) {
+      zA = 1 << 20;
+      for (int64_t p = 0; p < stage; p++) if (!in_alpha(g[p])) { zA = p; break; }
+    }
+    {
+      bool found = false;
+      for (int64_t p = tile_bytes - 1; p < stage; p++) if (!in_alpha(g[p])) { zB = p; found = true; break; }
+      if (!found && stage != rend) { zB = -2; reason |= 1; }
+    }
+    // ---- starts: chain right to left on the reversed bitmap (walk.hpp chain_eval_seq)
+    std::vector<const uint64_t*> rp;
+    for (auto& v : R) rp.push_back(v.data());
+    std::vector<uint64_t> G(NW + 1), tmp(NW + 1);
+    // chain_eval_seq assumes "nothing required after the chain" beyond the window; at the end of input exactly
+    // at the window edge that is what the kernel injects, and inside the window class bits are zero past `stage`.
+    chain_eval_seq(ch, rp.data(), NW + 1, G.data(), tmp.data());
+    std::vector<uint64_t> S(NW, 0);
+    const bool lead_run = ch.op_kind[0] == kChainRun;
+    const int lc = ch.op_cls[0];
+    for (int64_t p = 0; p < stage; p++) {
+      if (!MW::get(G, Nr - 1 - p)) continue;
+      if (lead_run) {
+        const bool prev = (p > 0 || tile_lo > 0) ? chain_class_has(ch, lc, g[p - 1]) : false;
+        if (!chain_class_has(ch, lc, g[p]) || prev) continue;
+      }
+      if (p > zA && p <= zB) MW::set(S, p);
+    }
+    // ---- ends: chain left to right on the forward bitmap
+    std::vector<uint64_t> M = S;
+    bool cout = false;
+    for (uint32_t k = 0; k < ch.nops; k++) {
+      const std::vector<uint64_t>& C = F[ch.op_cls[k]];
+      bool co = false;
+      if (ch.op_kind[k] == kChainByte) {
+        uint64_t carry = 0;
+        for (int w = 0; w < NW; w++) { const uint64_t nx = M[w] >> 63; M[w] = (M[w] << 1) | carry; carry = nx; }
+        co = carry != 0;
+      } else {
+        uint64_t carry = 0;
+        for (int w = 0; w < NW; w++) {
+          const uint64_t a = M[w], b = C[w];
+          uint64_t s = a + b; uint64_t c1 = s < a;
+          const uint64_t s2 = s + carry; c1 |= (s2 < s);
+          M[w] = s2 & ~b; carry = c1;
+        }
+        co = carry != 0;
+      }
+      if (k + 1 == ch.nops) cout = co; else if (co) reason |= 2;
+    }
+    std::vector<int64_t> sp, ep;
+    for (int64_t p = 0; p < N; p++) { if (MW::get(S, p)) sp.push_back(p); if (MW::get(M, p)) ep.push_back(p); }
+    if (cout) ep.push_back(N);
+    if (sp.size() != ep.size()) reason |= 4;
+    if (sp.size() > 64) reason |= 8;
+    if (reason) return -(16 + static_cast<int64_t>(reason));
+    int64_t cur_end = -1;
+    for (size_t i = 0; i < sp.size(); i++)
+      if (sp[i] >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + sp[i]); res.push_back(static_cast<int64_t>(tile_lo) + ep[i]); cur_end = ep[i]; }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}

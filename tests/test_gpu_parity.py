@@ -76,10 +76,52 @@ def test_tile_and_chunk_boundaries(need_gpu, oracle):
         _check(oracle, r"error", np.frombuffer((b"an error; " * 4000)[:n], dtype=np.uint8))
 
 
+def test_wave_tile_boundaries(need_gpu, oracle):
+    """The chain kernels work on 3840-byte wave-tiles with a 256-byte halo: matches straddling every lane word,
+    the tile edge, the halo edge and the 120 KiB group edge; inputs ending exactly on those edges."""
+    group = 3840 * 32
+    for pat, lit in ((r"\d+\.\d+\.\d+\.\d+", b"192.168.100.200"), (r"error", b"error"), (r"ab+c", b"abbbbc")):
+        base = np.full(2 * group + 5000, ord(" "), dtype=np.uint8)
+        ip = np.frombuffer(lit, dtype=np.uint8)
+        offs = list(range(3840 - 20, 3840 + 5)) + list(range(4096 - 20, 4096 + 3)) + list(range(50, 70)) + \
+            list(range(group - 18, group + 3)) + [2 * 3840 - 1, 7 * 3840 - 3, group + 3840 - 6]
+        for off in offs:
+            hay = base.copy()
+            hay[off:off + len(ip)] = ip
+            _check(oracle, pat, hay)
+        rep = lit + b" - "
+        for n in (3839, 3840, 3841, 4095, 4096, 4097, 2 * 3840, group - 1, group, group + 1, group + 4096):
+            _check(oracle, pat, np.frombuffer((rep * (n // len(rep) + 2))[:n], dtype=np.uint8))
+            tail = np.full(n, ord(" "), dtype=np.uint8)
+            tail[n - len(ip):] = ip                              # the match ends exactly at the end of input
+            _check(oracle, pat, tail)
+    # overlapping candidates: FindAll keeps the first, the next search starts at its end
+    _check(oracle, r"\d+\.\d+\.\d+\.\d+", b"1.2.3.4.5.6.7.8.9 " * 500)
+    _check(oracle, r"aba", b"abababababa ababa " * 700)
+    # more than 64 starts in a wave-tile / no sync byte in a halo: the scan is handed to the table kernels
+    _check(oracle, r"aba", b"aba" * 5000)
+    _check(oracle, r"error", b"error " * 3000)
+
+
+def test_chain_kernel_is_the_one_that_runs(need_gpu):
+    """No silent fallback on the benchmark corpora: one launch (the bit-parallel chain kernel), no rerun."""
+    import torch
+    for cfg, pat in ((2, r"\d+\.\d+\.\d+\.\d+"), (1, r"error")):
+        nbytes = 4096 * 4096
+        buf = cx.DeviceBuffer(nbytes)
+        buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+        rx = cx.compile(pat)
+        n = rx.find_all_device(buf.ptr, nbytes)
+        out = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
+        t = cx.Timing()
+        assert rx.find_all_device(buf.ptr, nbytes, out.data_ptr(), n + 8, timing=t) == n
+        assert t.n_launches == 1, (pat, t.n_launches)
+
+
 def test_random_inputs(need_gpu, oracle):
     rng = np.random.default_rng(2024)
     alphabet = np.frombuffer(b"0123456789. ab\ncdxy@_eror:", dtype=np.uint8)
-    pats = [r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"\d+\.\d", r"[0-5]+x", r"\d{1,3}\.\d{1,3}", r"ab|abc", r"[1-9][0-9]*|0"]
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"\d+\.\d", r"[0-5]+x", r"\d{1,3}\.\d{1,3}", r"ab|abc", r"[1-9][0-9]*|0", r"ab+c", r"\d+:\d+:\d+"]
     for pat in pats:
         for n in (1, 17, 63, 64, 65, 1000, 16384, 50000):
             hay = alphabet[rng.integers(0, len(alphabet), size=n)]

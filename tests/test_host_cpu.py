@@ -175,6 +175,58 @@ def test_chain_prefilter_emulated(oracle):
     assert emu.find_all_chain(cx.compile(r"\d+\.\d+\.\d+\.\d+").blob(), b"1.2.3.4." * 4000) is None
 
 
+def test_bitparallel_chain_emulated(oracle):
+    """Sixth generation (scan_chain_wave.hip): starts, ownership and ends all from class bitmaps — digit-prefilter
+    chains and UseDFA chains (literals, run/byte sequences) vs the oracle, several window geometries."""
+    import struct
+    rng = np.random.default_rng(23)
+    corpus = generate_test_input()
+    n_ok = 0
+    cases = [(r"\d+\.\d+\.\d+\.\d+", b"0123456789..:: ab\nxy-", 2), (r"\d+:\d+:\d+", b"0123456789..:: ab\nxy-", 2),
+             (r"error", b"eror rre\nxE", 1), (r"[a-z]+=\d+", b"abz=09 =\n-", 2), (r"ab+c", b"abc abbc\n", 1), (r"aba", b"ab \n", 1),
+             (r"GET", b"GET \nEG", 1)]
+    for pat, alpha, cfg in cases:
+        p = cx.compile(pat)
+        flags = struct.unpack_from("<I", p.blob(), 8)[0] if p.supported else 0
+        if not (flags & 16):
+            continue
+        n_ok += 1
+        o = oracle.Regex(pat)
+        alphabet = np.frombuffer(alpha, dtype=np.uint8)
+        synth = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 7, 24).tobytes()
+        for hay in (corpus, synth, b"", b"1.2.3.4", b"error", b"xerror", b"a=1", b"ababa abbbc"):
+            for geom in ((3840, 256), (192, 64), (64, 64)):
+                got = emu.find_all_chain6(p.blob(), hay, *geom)
+                if isinstance(got, int):
+                    assert got in (-17, -24), (pat, geom, got)     # only "no sync byte in a halo" / "> 64 starts" may fall back
+                    continue
+                assert got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), geom)
+        for _ in range(120):
+            n = int(rng.integers(0, 20000))
+            hay = alphabet[rng.integers(0, len(alphabet), size=n)].tobytes()
+            exp = o.find_all_index(hay).tolist()
+            for geom in ((3840, 256), (192, 64), (128, 128)):
+                got = emu.find_all_chain6(p.blob(), hay, *geom)
+                if isinstance(got, int):
+                    assert got in (-17, -24, -25), (pat, geom, got)
+                    continue
+                assert got.tolist() == exp, (pat, n, geom)
+        # exact window edge at the end of input: the last run touches the last byte of a full window
+        for total in (4096, 4096 + 3840, 256, 128):
+            tail = {"error": b"error", "GET": b"GET"}.get(pat, None)
+            if tail is None:
+                tail = b"1.2.3.4" if "." in pat else (b"1:2:3" if ":" in pat else (b"ab=12" if "=" in pat else (b"abbc" if "+" in pat else b"aba")))
+            hay = b" " * (total - len(tail)) + tail
+            got = emu.find_all_chain6(p.blob(), hay, 3840, 256)
+            assert not isinstance(got, int) and got.tolist() == o.find_all_index(hay).tolist(), (pat, total)
+    assert n_ok >= 5, n_ok
+    # unordered chains (a run whose class meets the class of the step before) must not get the flag
+    for pat in (r"a[ab]+", r"\d\d+x"):
+        p = cx.compile(pat)
+        if p.supported:
+            assert not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
