@@ -139,8 +139,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "kernel": {"1": "k_scan_dfa<digit>", "2": "k_scan_digit_flat", "3": "k_scan_digit_list", "4": "k_scan_digit_chain"}.get(os.environ.get("CXG_DIGIT_KERNEL", "5"), "k_scan_digit_wave") if rx.strategy == "UseDigitPrefilter" else rx.strategy,
+            "traffic": _pmc_traffic(args, nbytes),
+            "kernel": {"1": "k_scan_dfa<digit>", "2": "k_scan_digit_flat", "3": "k_scan_digit_list", "4": "k_scan_digit_chain", "5": "k_scan_digit_wave"}.get(os.environ.get("CXG_DIGIT_KERNEL", "6"), "k_scan_chain_wave<2>") if rx.strategy == "UseDigitPrefilter" else rx.strategy,
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
             "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),
@@ -182,6 +182,23 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _pmc_traffic(args, nbytes):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this very command
+    (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled
+    per MI355X_MICROARCH.md "HBM" for wide coalesced reads on gfx950).  None when no profile matches the workload:
+    counters cannot be read from inside the timed process."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("pattern") == args.pattern and d.get("synth_config") == args.synth_config and d.get("bytes_per_gpu") == nbytes \
+                and d.get("digit_kernel", "6") == os.environ.get("CXG_DIGIT_KERNEL", "6"):
+            return d.get("traffic_bytes_per_launch")
+    return None
 
 
 def _cpu_model():

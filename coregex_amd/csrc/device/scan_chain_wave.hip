@@ -35,6 +35,9 @@
 #ifndef CXG_CHAIN_WAVES
 #define CXG_CHAIN_WAVES 5
 #endif
+#ifndef CXG_CHAIN_SCHED_BARRIER
+#define CXG_CHAIN_SCHED_BARRIER 1
+#endif
 #ifndef CXG_CHAIN_PREFETCH
 #define CXG_CHAIN_PREFETCH 1
 #endif
@@ -202,6 +205,9 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
             for (int b = 0; base + b < stage; b++) mask |= (chain_class_has(*s_chain, static_cast<int>(c), g[base + b]) ? 1u : 0u) << b;
           }
           pieces[v] = static_cast<uint16_t>(mask);
+#if CXG_CHAIN_SCHED_BARRIER
+          __builtin_amdgcn_sched_barrier(0);                        // one vector at a time: fewer live temporaries
+#endif
         }
       }
       if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on

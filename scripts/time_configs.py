@@ -1,0 +1,34 @@
+"""Kernel time of the five BASELINE configs on 1 GiB of synthlog-v1 resident in HBM (GPU box only)."""
+import sys
+import torch
+import coregex_amd as cx
+
+LITS16 = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+CASES = [(1, "error"), (2, r"\d+\.\d+\.\d+\.\d+"), (3, LITS16), (4, r"[\w]+"), (5, r"(\w+)@(\w+)\.(\w+)")]
+only = [int(a) for a in sys.argv[1:]]
+n = 1 << 30
+for cfg, pat in CASES:
+    if only and cfg not in only:
+        continue
+    buf = cx.DeviceBuffer(n)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+    rx = cx.compile(pat)
+    t = cx.Timing()
+    if cfg == 5:
+        w = 2 * rx.num_groups
+        cnt = rx.find_all_submatch_device(buf.ptr, n)
+        out = torch.empty((cnt + 8, w), dtype=torch.int64, device="cuda")
+        f = lambda: rx.find_all_submatch_device(buf.ptr, n, out.data_ptr(), cnt + 8, timing=t)
+    else:
+        cnt = rx.find_all_device(buf.ptr, n)
+        out = torch.empty((cnt + 8, 2), dtype=torch.int64, device="cuda")
+        f = lambda: rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 8, timing=t)
+    best = 1e9
+    for i in range(5):
+        f()
+        if i:
+            best = min(best, t.kernel_ms)
+    width = 16 if cfg != 5 else 8 * 2 * rx.num_groups
+    print(f"cfg {cfg} {rx.strategy:22s} matches {cnt:10d} kernel_ms {best:8.4f} launches {t.n_launches} "
+          f"N/t {n / best / 1e6:8.1f} GB/s  (N+W*M)/t {(n + width * cnt) / best / 1e6:8.1f} GB/s", flush=True)
+    del buf, out
