@@ -33,7 +33,7 @@
 #include "walk.hpp"
 
 #ifndef CXG_CHAIN_WAVES
-#define CXG_CHAIN_WAVES 5
+#define CXG_CHAIN_WAVES 8
 #endif
 #ifndef CXG_CHAIN_SCHED_BARRIER
 #define CXG_CHAIN_SCHED_BARRIER 1
@@ -55,24 +55,55 @@ __device__ __forceinline__ uint32_t gather_top(uint32_t m80) {
   const uint32_t t = m80 | (m80 << 7);
   return t | (t << 14);
 }
-// 0x80 flag in every byte of x that is NOT in the class (inverted once per 16 bytes by the caller)
-__device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t kind, uint32_t lo, uint32_t hi) {
-  if (kind == kClsDigit) {
+// 0x80 flag in every byte of x that is NOT in the class (inverted once per 16 bytes by the caller).
+// KIND is a template parameter so that the per-class switch is taken once per wave-tile, not once per dword.
+template <int KIND>
+__device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t lo4, uint32_t hi4) {   // lo4/hi4: class bounds splat over the bytes
+  if (KIND == kClsDigit) {
     const uint32_t t = x ^ 0x30303030u;
     return (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
   }
-  if (kind == kClsByte) {
-    const uint32_t v = x ^ (lo * 0x01010101u);
+  if (KIND == kClsByte) {
+    const uint32_t v = x ^ lo4;
     return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
   }
-  const uint32_t ge = ((x | 0x80808080u) - lo * 0x01010101u) & 0x80808080u;
-  const uint32_t gt = ((x & 0x7F7F7F7Fu) + (0x7Fu - hi) * 0x01010101u) & 0x80808080u;
+  const uint32_t ge = ((x | 0x80808080u) - lo4) & 0x80808080u;
+  const uint32_t gt = ((x & 0x7F7F7F7Fu) + hi4) & 0x80808080u;     // hi4 = (0x7F - hi) splat
   return ~(ge & ~gt & ~x) & 0x80808080u;
 }
-__device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t kind, uint32_t lo, uint32_t hi) {
-  const uint32_t n = (gather_top(notcls4(x.x, kind, lo, hi)) >> 28) | ((gather_top(notcls4(x.y, kind, lo, hi)) >> 24) & 0xF0u) |
-                     ((gather_top(notcls4(x.z, kind, lo, hi)) >> 20) & 0xF00u) | ((gather_top(notcls4(x.w, kind, lo, hi)) >> 16) & 0xF000u);
-  return n ^ 0xFFFFu;
+// 16 class bits of a 16-byte vector.  The four 0x80 flags of a dword are gathered by one v_dot4_u32_u8 against
+// the weights (1,2,4,8) resp. (16,32,64,128): 128 x the byte of flags accumulates over a dword pair.
+template <int KIND>
+__device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t lo4, uint32_t hi4) {
+  const uint32_t lo = __builtin_amdgcn_udot4(notcls4<KIND>(x.y, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(notcls4<KIND>(x.x, lo4, hi4), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(notcls4<KIND>(x.w, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(notcls4<KIND>(x.z, lo4, hi4), 0x08040201u, 0u, false), false);
+  return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
+}
+// One class of one FULL wave-tile window (4096 bytes present): 4 vectors per lane -> 4 16-bit pieces of the
+// forward bitmap in LDS.
+template <int KIND>
+__device__ __forceinline__ void classify_tile(const uint4 (&x)[4], uint32_t lo, uint32_t hi, int lane, uint16_t* pieces) {
+  const uint32_t lo4 = lo * 0x01010101u, hi4 = (0x7Fu - hi) * 0x01010101u;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    pieces[lane + 64 * k] = static_cast<uint16_t>(cls16<KIND>(x[k], lo4, hi4));
+#if CXG_CHAIN_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);                              // one vector at a time: fewer live temporaries
+#endif
+  }
+}
+// The last window(s) of the haystack, cut short by the end of input: byte by byte from memory (cold path).
+__device__ __forceinline__ void classify_tail(uint32_t kind, uint32_t lo, uint32_t hi, const uint8_t* g, int32_t stage, int lane, uint16_t* pieces) {
+  for (int k = 0; k < 4; k++) {
+    const int v = lane + 64 * k, base = v << 4;
+    uint32_t mask = 0;
+    for (int b = 0; b < 16 && base + b < stage; b++) {
+      const uint32_t y = g[base + b];
+      const bool in = kind == kClsDigit ? (y - 0x30u) < 10u : (y >= lo && y <= hi);
+      mask |= (in ? 1u : 0u) << b;
+    }
+    pieces[v] = static_cast<uint16_t>(mask);
+  }
 }
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
@@ -121,6 +152,31 @@ __device__ __forceinline__ uint64_t word_range(int lane, int32_t lo, int32_t hi)
 
 }  // namespace
 
+// The chain description held in scalar registers for the whole kernel (no LDS/VGPR traffic in the op loops).
+template <int NCLS>
+struct ChainRegs {
+  uint32_t nops;
+  uint32_t op_is_run;      // bit k: step k is a run
+  uint32_t op_cls2;        // 2 bits per step: its class
+  uint32_t kind[NCLS], lo[NCLS], hi[NCLS];
+  __device__ __forceinline__ bool has(int c, uint32_t b) const {
+    return kind[c] == kClsDigit ? (b - 0x30u) < 10u : (b >= lo[c] && b <= hi[c]);
+  }
+  __device__ __forceinline__ bool in_alphabet(uint32_t b) const {
+    bool r = false;
+#pragma unroll
+    for (int c = 0; c < NCLS; c++) r = r || has(c, b);
+    return r;
+  }
+};
+// One byte of the haystack through the scalar data cache (s_load: lgkmcnt, never the vmcnt of the prefetch).
+__device__ __forceinline__ uint32_t scalar_byte(const uint8_t* base, uint64_t off) {
+  typedef const uint32_t __attribute__((address_space(4))) * cptr_t;
+  const uint64_t a = reinterpret_cast<uint64_t>(base) + off;
+  const uint32_t w = *reinterpret_cast<cptr_t>(a & ~3ull);
+  return (w >> ((a & 3ull) * 8)) & 0xFFu;
+}
+
 template <int NCLS>
 __device__ __forceinline__ uint64_t pick(const uint64_t (&w)[NCLS], uint32_t ci) {   // wave-uniform select, no indexed registers
   uint64_t v = w[0];
@@ -140,22 +196,32 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
   __shared__ uint8_t s_em[kWavesPerBlock][64];
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
-  __shared__ ChainAux s_chain_mem;
   __shared__ uint64_t s_group;
   __shared__ uint64_t s_base;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: per-wave LDS bases live in SGPRs
+  int lane = lane0;
   if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
-  if (tid >= 64 && tid < 64 + static_cast<int>(sizeof(ChainAux) / 4))
-    reinterpret_cast<uint32_t*>(&s_chain_mem)[tid - 64] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off + 256)[tid - 64];
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.blob + h->aux_off + 256);   // uniform address: scalar loads
+  ChainRegs<NCLS> ch;
+  ch.nops = gch->nops;
+  ch.op_is_run = 0; ch.op_cls2 = 0;
+#pragma unroll
+  for (int k = 0; k < kChainMaxOps; k++) {
+    ch.op_is_run |= (gch->op_kind[k] == kChainRun ? 1u : 0u) << k;
+    ch.op_cls2 |= static_cast<uint32_t>(gch->op_cls[k] & 3u) << (2 * k);
+  }
+#pragma unroll
+  for (int c = 0; c < NCLS; c++) { ch.kind[c] = gch->cls_kind[c]; ch.lo[c] = gch->cls_lo[c]; ch.hi[c] = gch->cls_hi[c]; }
   __syncthreads();
-  const ChainAux* s_chain = &s_chain_mem;
-  const uint64_t group = s_group;
+  const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
   if (group >= a.ngroups) return;
-  const uint32_t nops = s_chain->nops;
-  const bool lead_run = s_chain->op_kind[0] == kChainRun;
-  const uint32_t lead_cls = s_chain->op_cls[0];
+  const uint32_t nops = ch.nops;
+  const bool lead_run = (ch.op_is_run & 1u) != 0;
+  const uint32_t lead_cls = ch.op_cls2 & 3u;
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
 
@@ -170,15 +236,25 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       nf = st >> 4;
     }
     const uint8_t* gp = a.hay + lo;
+    if (nf == (kWaveTile + kWaveHalo) / 16) {                       // full window: four unconditional loads
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int v = lane + 64 * k;
-      x[k] = (v < nf) ? *reinterpret_cast<const uint4*>(gp + (v << 4)) : make_uint4(0, 0, 0, 0);
+      for (int k = 0; k < 4; k++) x[k] = *reinterpret_cast<const uint4*>(gp + ((lane + 64 * k) << 4));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int v = lane + 64 * k;
+        x[k] = (v < nf) ? *reinterpret_cast<const uint4*>(gp + (v << 4)) : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   if (CXG_CHAIN_PREFETCH) issue_loads(0);
 
   for (int j = 0; j < kTilesPerWave; j++) {
+    // Opaque copy of the lane id per wave-tile: lane-derived masks and LDS addresses are recomputed (a few ALU
+    // ops) instead of being hoisted out of the loop and spilled — a scratch reload waits on vmcnt, which would
+    // also drain the prefetched tile.
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
     if (!CXG_CHAIN_PREFETCH) issue_loads(j);
     const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
@@ -190,25 +266,14 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       const uint8_t* g = a.hay + tile_lo;
 
       // ---- A: class masks of the vectors loaded one iteration ago, transposed through the wave's LDS scratch
-      const int nfull = stage >> 4;
 #pragma unroll
       for (int c = 0; c < NCLS; c++) {
-        const uint32_t kind = s_chain->cls_kind[c], lo = s_chain->cls_lo[c], hi = s_chain->cls_hi[c];
+        const uint32_t kind = ch.kind[c], lo = ch.lo[c], hi = ch.hi[c];
         uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int v = lane + 64 * k;
-          uint32_t mask = 0;
-          if (v < nfull) mask = cls16(x[k], kind, lo, hi);
-          else if (v == nfull) {
-            const int base = v << 4;
-            for (int b = 0; base + b < stage; b++) mask |= (chain_class_has(*s_chain, static_cast<int>(c), g[base + b]) ? 1u : 0u) << b;
-          }
-          pieces[v] = static_cast<uint16_t>(mask);
-#if CXG_CHAIN_SCHED_BARRIER
-          __builtin_amdgcn_sched_barrier(0);                        // one vector at a time: fewer live temporaries
-#endif
-        }
+        if (stage != kWaveTile + kWaveHalo) classify_tail(kind, lo, hi, g, stage, lane, pieces);
+        else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
+        else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
+        else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
       if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on
       wave_lds_sync();
@@ -216,18 +281,24 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
 #pragma unroll
       for (int c = 0; c < NCLS; c++) { F[c] = s_cls[wave][c][lane]; R[c] = brev64(s_cls[wave][c][63 - lane]); U |= F[c]; }
 
+      // the byte in front of the tile, once, through the scalar cache
+      bool prev_in_alphabet = false, prev_in_lead = false;
+      if (tile_lo > 0) {
+        const uint32_t pb = scalar_byte(a.hay, tile_lo - 1);
+        prev_in_alphabet = ch.in_alphabet(pb);
+#pragma unroll
+        for (int c = 0; c < NCLS; c++) prev_in_lead = prev_in_lead || (lead_cls == static_cast<uint32_t>(c) && ch.has(c, pb));
+      }
       // ---- O: ownership bounds from the synchronising bytes (complement of the class union, inside the data)
       int32_t zA = -1, zB = kFar;
       {
-        const int32_t nv = stage - 64 * lane;
-        const uint64_t valid = nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
-        const uint64_t Z = ~U & valid;
+        uint64_t Z = ~U;
+        if (stage != kWaveTile + kWaveHalo) {                       // short last window: bytes past the data are not synchronising
+          const int32_t nv = stage - 64 * lane;
+          Z &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+        }
         if (tile_lo > 0) {
-          const uint32_t pb = g[-1];
-          bool in_alpha = false;
-#pragma unroll
-          for (int c = 0; c < NCLS; c++) in_alpha = in_alpha || chain_class_has(*s_chain, c, pb);
-          if (in_alpha) {                                           // the segment at the tile's first byte began earlier
+          if (prev_in_alphabet) {                                           // the segment at the tile's first byte began earlier
             const unsigned long long bz = __ballot(Z != 0ull);
             if (bz) { const int L = __builtin_ctzll(bz); zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L))); }
             else zA = kFar;
@@ -243,20 +314,18 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       uint64_t G = ~0ull;
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
       for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
-        const uint32_t ci = s_chain->op_cls[k];
+        const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
         const uint64_t Ck = pick<NCLS>(R, ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
-        if (s_chain->op_kind[k] == kChainByte) {
+        if (!((ch.op_is_run >> k) & 1u)) {
           uint64_t low = from_lower64(G) >> 63;                     // DPP outside any lane-dependent branch: a
           if (lane == 0) low = inject;                              // disabled source lane would not be read
           G = Ck & ((G << 1) | low);
         } else {
-          uint64_t cup = from_upper64(Ck);
-          if (lane == 63) cup = 0;
-          const uint64_t K = G & ~Ck & ((Ck >> 1) | (cup << 63));
-          uint64_t klow = from_lower64(K) >> 63;
-          if (lane == 0) klow = inject & Ck;                        // virtual marker just beyond the last byte
-          const uint64_t M = (K << 1) | klow;
+          const uint64_t T = G & ~Ck;
+          uint64_t tlow = from_lower64(T) >> 63;
+          if (lane == 0) tlow = inject;
+          const uint64_t M = ((T << 1) | tlow) & Ck;
           const uint64_t s1 = Ck + M;
           const unsigned long long GG = __ballot(s1 < M);
           const unsigned long long PP = __ballot(s1 == ~0ull);
@@ -269,7 +338,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       if (lead_run) {
         const uint64_t D = pick<NCLS>(R, lead_cls);
         uint64_t dup = from_upper64(D);
-        if (lane == 63) dup = (tile_lo > 0 && chain_class_has(*s_chain, static_cast<int>(lead_cls), g[-1])) ? 1ull : 0ull;
+        if (lane == 63) dup = prev_in_lead ? 1ull : 0ull;
         surv = D & ~((D >> 1) | (dup << 63)) & G;
       }
       if (__ballot(surv != 0ull) != 0ull) {
@@ -281,10 +350,10 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         uint64_t M = S;
         uint32_t cout = 0;                                          // an end exactly at byte 4096 (end of input)
         for (uint32_t k = 0; k < nops; k++) {
-          const uint32_t ci = s_chain->op_cls[k];
+          const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
           const uint64_t Ck = pick<NCLS>(F, ci);
           uint32_t co;
-          if (s_chain->op_kind[k] == kChainByte) {
+          if (!((ch.op_is_run >> k) & 1u)) {
             co = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(M >> 32), 63)) >> 31;
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
