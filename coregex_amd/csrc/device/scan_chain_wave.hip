@@ -46,6 +46,7 @@ namespace cxgdev {
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWRows = 512;                       // rows buffered per wave per group
 constexpr int32_t kFar = 1 << 20;                 // "no such byte" position
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t lo4, uint32_t h
 // 16 class bits of a 16-byte vector.  The four 0x80 flags of a dword are gathered by one v_dot4_u32_u8 against
 // the weights (1,2,4,8) resp. (16,32,64,128): 128 x the byte of flags accumulates over a dword pair.
 template <int KIND>
-__device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t lo4, uint32_t hi4) {
+__device__ __forceinline__ uint32_t cls16(const u32x4& x, uint32_t lo4, uint32_t hi4) {
   const uint32_t lo = __builtin_amdgcn_udot4(notcls4<KIND>(x.y, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(notcls4<KIND>(x.x, lo4, hi4), 0x08040201u, 0u, false), false);
   const uint32_t hi = __builtin_amdgcn_udot4(notcls4<KIND>(x.w, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(notcls4<KIND>(x.z, lo4, hi4), 0x08040201u, 0u, false), false);
   return ((lo >> 7) | (hi << 1)) ^ 0xFFFFu;
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t cls16(const uint4& x, uint32_t lo4, uint32_t
 // One class of one FULL wave-tile window (4096 bytes present): 4 vectors per lane -> 4 16-bit pieces of the
 // forward bitmap in LDS.
 template <int KIND>
-__device__ __forceinline__ void classify_tile(const uint4 (&x)[4], uint32_t lo, uint32_t hi, int lane, uint16_t* pieces) {
+__device__ __forceinline__ void classify_tile(const u32x4 (&x)[4], uint32_t lo, uint32_t hi, int lane, uint16_t* pieces) {
   const uint32_t lo4 = lo * 0x01010101u, hi4 = (0x7Fu - hi) * 0x01010101u;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -90,19 +91,6 @@ __device__ __forceinline__ void classify_tile(const uint4 (&x)[4], uint32_t lo, 
 #if CXG_CHAIN_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);                              // one vector at a time: fewer live temporaries
 #endif
-  }
-}
-// The last window(s) of the haystack, cut short by the end of input: byte by byte from memory (cold path).
-__device__ __forceinline__ void classify_tail(uint32_t kind, uint32_t lo, uint32_t hi, const uint8_t* g, int32_t stage, int lane, uint16_t* pieces) {
-  for (int k = 0; k < 4; k++) {
-    const int v = lane + 64 * k, base = v << 4;
-    uint32_t mask = 0;
-    for (int b = 0; b < 16 && base + b < stage; b++) {
-      const uint32_t y = g[base + b];
-      const bool in = kind == kClsDigit ? (y - 0x30u) < 10u : (y >= lo && y <= hi);
-      mask |= (in ? 1u : 0u) << b;
-    }
-    pieces[v] = static_cast<uint16_t>(mask);
   }
 }
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
@@ -225,27 +213,21 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
 
-  uint4 x[4];
+  // Window loads go through a buffer resource sized to the bytes that exist (rounded up to a dword): lanes past
+  // the end of the input read zeros, so there is no tail path and no branch around a load.  The up to 3 bytes
+  // between len and the dword boundary are masked out of the bitmaps below (`stage` test).
+  u32x4 x[4];
   auto issue_loads = [&](int jj) {
     const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
-    int nf = 0;
+    int nrec = 0;
     if (jj < kTilesPerWave && lo < a.len) {
       const uint64_t rem = a.len - lo;
-      const int32_t st = rem > static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int32_t>(rem);
-      nf = st >> 4;
+      nrec = rem >= static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int>((rem + 3) & ~3ull);
     }
-    const uint8_t* gp = a.hay + lo;
-    if (nf == (kWaveTile + kWaveHalo) / 16) {                       // full window: four unconditional loads
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo : 0), 0, nrec, 0x00020000);
 #pragma unroll
-      for (int k = 0; k < 4; k++) x[k] = *reinterpret_cast<const uint4*>(gp + ((lane + 64 * k) << 4));
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int v = lane + 64 * k;
-        x[k] = (v < nf) ? *reinterpret_cast<const uint4*>(gp + (v << 4)) : make_uint4(0, 0, 0, 0);
-      }
-    }
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, 0, 0);
   };
   if (CXG_CHAIN_PREFETCH) issue_loads(0);
 
@@ -263,15 +245,13 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
       const int32_t stage = rend < kWaveTile + kWaveHalo ? rend : kWaveTile + kWaveHalo;
-      const uint8_t* g = a.hay + tile_lo;
 
       // ---- A: class masks of the vectors loaded one iteration ago, transposed through the wave's LDS scratch
 #pragma unroll
       for (int c = 0; c < NCLS; c++) {
         const uint32_t kind = ch.kind[c], lo = ch.lo[c], hi = ch.hi[c];
         uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
-        if (stage != kWaveTile + kWaveHalo) classify_tail(kind, lo, hi, g, stage, lane, pieces);
-        else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
+        if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
         else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
         else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
@@ -279,7 +259,16 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       wave_lds_sync();
       uint64_t F[NCLS], R[NCLS], U = 0;                             // forward / reversed words, class union
 #pragma unroll
-      for (int c = 0; c < NCLS; c++) { F[c] = s_cls[wave][c][lane]; R[c] = brev64(s_cls[wave][c][63 - lane]); U |= F[c]; }
+      for (int c = 0; c < NCLS; c++) { F[c] = s_cls[wave][c][lane]; R[c] = brev64(s_cls[wave][c][63 - lane]); }
+      if (stage != kWaveTile + kWaveHalo) {                         // short last window: nothing past the data is in a class
+        const int32_t nf = stage - 64 * lane, nr = stage - 64 * (63 - lane);
+        const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+        const uint64_t vr = brev64(nr <= 0 ? 0ull : (nr >= 64 ? ~0ull : ((1ull << nr) - 1ull)));
+#pragma unroll
+        for (int c = 0; c < NCLS; c++) { F[c] &= vf; R[c] &= vr; }
+      }
+#pragma unroll
+      for (int c = 0; c < NCLS; c++) U |= F[c];
 
       // the byte in front of the tile, once, through the scalar cache
       bool prev_in_alphabet = false, prev_in_lead = false;
