@@ -109,6 +109,15 @@ __device__ __forceinline__ uint64_t from_upper64(uint64_t v) {
 __device__ __forceinline__ uint64_t brev64(uint64_t v) {
   return (static_cast<uint64_t>(__brev(static_cast<uint32_t>(v))) << 32) | __brev(static_cast<uint32_t>(v >> 32));
 }
+// Value of lane 63-l: DPP row_mirror inside the rows of 16, then v_permlane16_swap / v_permlane32_swap (gfx950)
+// to exchange the rows — registers only, no LDS round trip.
+__device__ __forceinline__ uint32_t lane_reverse32(uint32_t v, int lane) {
+  const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x140 /*row_mirror*/, 0xF, 0xF, false));
+  const auto r16 = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+  const uint32_t s16 = ((lane >> 4) & 1) ? r16[0] : r16[1];
+  const auto r32 = __builtin_amdgcn_permlane32_swap(s16, s16, false, false);
+  return (lane & 32) ? r32[0] : r32[1];
+}
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
   return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l))) << 32) |
          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
@@ -118,6 +127,16 @@ __device__ __forceinline__ void wave_lds_sync() {                // same-wave LD
   __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// s + (bit `lane` of mask): the per-lane carry-in comes straight from the scalar mask (v_addc with an SGPR-pair
+// carry operand), two VALU ops for the 64-bit add instead of shift + and + add.
+__device__ __forceinline__ uint64_t add_carry_mask(uint64_t s, unsigned long long mask) {
+  uint32_t lo, hi;
+  unsigned long long c;
+  asm("v_addc_co_u32_e64 %0, %2, %3, 0, %5\n\tv_addc_co_u32_e64 %1, %2, %4, 0, %2"
+      : "=&v"(lo), "=&v"(hi), "=&s"(c)
+      : "v"(static_cast<uint32_t>(s)), "v"(static_cast<uint32_t>(s >> 32)), "s"(mask));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 // Inclusive prefix sum over the 64 lanes, all DPP (row shifts, then row broadcasts).
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
@@ -157,14 +176,6 @@ struct ChainRegs {
     return r;
   }
 };
-// One byte of the haystack through the scalar data cache (s_load: lgkmcnt, never the vmcnt of the prefetch).
-__device__ __forceinline__ uint32_t scalar_byte(const uint8_t* base, uint64_t off) {
-  typedef const uint32_t __attribute__((address_space(4))) * cptr_t;
-  const uint64_t a = reinterpret_cast<uint64_t>(base) + off;
-  const uint32_t w = *reinterpret_cast<cptr_t>(a & ~3ull);
-  return (w >> ((a & 3ull) * 8)) & 0xFFu;
-}
-
 template <int NCLS>
 __device__ __forceinline__ uint64_t pick(const uint64_t (&w)[NCLS], uint32_t ci) {   // wave-uniform select, no indexed registers
   uint64_t v = w[0];
@@ -176,7 +187,6 @@ __device__ __forceinline__ uint64_t pick(const uint64_t (&w)[NCLS], uint32_t ci)
 template <int NCLS>
 __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
-  __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];                   // starts, reversed -> forward
   __shared__ uint32_t s_rowpos[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_rowlen[kWavesPerBlock][kWRows];
   __shared__ uint16_t s_spos[kWavesPerBlock][64];
@@ -217,6 +227,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
   // the end of the input read zeros, so there is no tail path and no branch around a load.  The up to 3 bytes
   // between len and the dword boundary are masked out of the bitmaps below (`stage` test).
   u32x4 x[4];
+  uint32_t xprev = 0;                                              // the dword that ends with the byte in front of the tile
   auto issue_loads = [&](int jj) {
     const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
@@ -225,9 +236,11 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       const uint64_t rem = a.len - lo;
       nrec = rem >= static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int>((rem + 3) & ~3ull);
     }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo : 0), 0, nrec, 0x00020000);
+    const int pre = (nrec && lo) ? 16 : 0;                          // the resource starts 16 bytes early (keeps alignment)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, 0, 0);
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, pre ? 12 : nrec + pre, 0);   // out of range (zero) at the haystack start
   };
   if (CXG_CHAIN_PREFETCH) issue_loads(0);
 
@@ -251,10 +264,14 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       for (int c = 0; c < NCLS; c++) {
         const uint32_t kind = ch.kind[c], lo = ch.lo[c], hi = ch.hi[c];
         uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
-        if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
+        if (a.dbg & 0x80000u) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) pieces[lane + 64 * q] = static_cast<uint16_t>(x[q].x ^ x[q].y ^ x[q].z ^ x[q].w);
+        } else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
         else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
         else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
+      const uint32_t xprev_cur = xprev;                             // arrived with x[] (same vmcnt)
       if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on
       wave_lds_sync();
       uint64_t F[NCLS], R[NCLS], U = 0;                             // forward / reversed words, class union
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       // the byte in front of the tile, once, through the scalar cache
       bool prev_in_alphabet = false, prev_in_lead = false;
       if (tile_lo > 0) {
-        const uint32_t pb = scalar_byte(a.hay, tile_lo - 1);
+        const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
         prev_in_alphabet = ch.in_alphabet(pb);
 #pragma unroll
         for (int c = 0; c < NCLS; c++) prev_in_lead = prev_in_lead || (lead_cls == static_cast<uint32_t>(c) && ch.has(c, pb));
@@ -301,8 +318,9 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
 
       // ---- B: chain, right to left, on the reversed words
       uint64_t G = ~0ull;
+      if (a.dbg & 0x10000u) G = R[0];
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
-      for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
+      for (int k = (a.dbg & 0x10000u) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) {
         const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
         const uint64_t Ck = pick<NCLS>(R, ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
@@ -316,10 +334,10 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
           if (lane == 0) tlow = inject;
           const uint64_t M = ((T << 1) | tlow) & Ck;
           const uint64_t s1 = Ck + M;
-          const unsigned long long GG = __ballot(s1 < M);
-          const unsigned long long PP = __ballot(s1 == ~0ull);
+          const unsigned long long GG = __builtin_amdgcn_ballot_w64(s1 < M);
+          const unsigned long long PP = __builtin_amdgcn_ballot_w64(s1 == ~0ull);
           const unsigned long long recv = (PP + (GG << 1)) ^ PP;    // lanes that receive a carry
-          G = Ck & ~(s1 + ((recv >> lane) & 1ull));
+          G = Ck & ~add_carry_mask(s1, recv);
         }
       }
       // starts, reversed orientation: with a leading run only the first byte of the run is a candidate
@@ -330,42 +348,42 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         if (lane == 63) dup = prev_in_lead ? 1ull : 0ull;
         surv = D & ~((D >> 1) | (dup << 63)) & G;
       }
+      if (a.dbg & 0x30000u) surv = 0;                               // timing ablations only (results wrong)
       if (__ballot(surv != 0ull) != 0ull) {
         // ---- to forward orientation, restricted to the owned range (zA, zB]
-        s_x[wave][lane] = surv;
-        wave_lds_sync();
-        const uint64_t S = brev64(s_x[wave][63 - lane]) & word_range(lane, zA + 1, zB);
+        const uint64_t S = ((static_cast<uint64_t>(__brev(lane_reverse32(static_cast<uint32_t>(surv), lane))) << 32) |
+                            __brev(lane_reverse32(static_cast<uint32_t>(surv >> 32), lane))) & word_range(lane, zA + 1, zB);
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
-        uint32_t cout = 0;                                          // an end exactly at byte 4096 (end of input)
+        unsigned long long co64 = 0, mid = 0;                       // bit 63: a marker left the window at this / an earlier step
         for (uint32_t k = 0; k < nops; k++) {
           const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
           const uint64_t Ck = pick<NCLS>(F, ci);
-          uint32_t co;
+          mid |= co64;
           if (!((ch.op_is_run >> k) & 1u)) {
-            co = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(M >> 32), 63)) >> 31;
+            co64 = __builtin_amdgcn_ballot_w64(static_cast<int64_t>(M) < 0);
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
             M = (M << 1) | low;
           } else {
             const uint64_t s1 = Ck + M;
-            const unsigned long long GG = __ballot(s1 < M);
-            const unsigned long long PP = __ballot(s1 == ~0ull);
+            const unsigned long long GG = __builtin_amdgcn_ballot_w64(s1 < M);
+            const unsigned long long PP = __builtin_amdgcn_ballot_w64(s1 == ~0ull);
             const unsigned long long recv = (PP + (GG << 1)) ^ PP;
-            co = static_cast<uint32_t>(((GG >> 63) | ((PP >> 63) & (recv >> 63))) & 1ull);
-            M = (s1 + ((recv >> lane) & 1ull)) & ~Ck;
+            co64 = GG | (PP & recv);
+            M = add_carry_mask(s1, recv) & ~Ck;
           }
-          if (k + 1 == nops) cout = co;
-          else if (co) fallback |= 2;                                // a match left the window mid-chain: cannot happen for owned starts
         }
+        const uint32_t cout = static_cast<uint32_t>(co64 >> 63);      // an end exactly at byte 4096 (end of input)
+        if (mid >> 63) fallback |= 2;                               // a match left the window mid-chain: cannot happen for owned starts
         // ---- P: ranks of starts and ends, (start, end) pairs
         const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(M));
         const uint32_t packed = ns | (ne << 16);
         const uint32_t incl = wave_inclusive_sum(packed);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-        uint32_t n = tot & 0xFFFFu;
+        uint32_t n = (a.dbg & 0x40000u) ? 0u : (tot & 0xFFFFu);
         const uint32_t n_ends = (tot >> 16) + cout;
-        if (n != n_ends) {                                          // pairing invariant violated
+        if (n != n_ends && !(a.dbg & 0x40000u)) {                   // pairing invariant violated
           if (a.prof && lane == 0 && atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 7), 1ull) == 0ull) {
             a.prof[0] = tile_lo; a.prof[1] = n; a.prof[2] = n_ends; a.prof[3] = cout; a.prof[4] = static_cast<uint64_t>(static_cast<int64_t>(zA));
             a.prof[5] = static_cast<uint64_t>(static_cast<int64_t>(zB)); a.prof[6] = static_cast<uint64_t>(stage);
