@@ -176,13 +176,21 @@ struct ChainRegs {
     return r;
   }
 };
-template <int NCLS>
-__device__ __forceinline__ uint64_t pick(const uint64_t (&w)[NCLS], uint32_t ci) {   // wave-uniform select, no indexed registers
-  uint64_t v = w[0];
-#pragma unroll
-  for (int c = 1; c < NCLS; c++) v = (ci == static_cast<uint32_t>(c)) ? w[c] : v;
-  return v;
-}
+// Up to four class words as NAMED registers (an array here ends up in scratch memory, indexed by the scalar class
+// id, for NCLS >= 3).  Wave-uniform select by compare chain.
+struct Words4 {
+  uint64_t w0, w1, w2, w3;
+  template <int NCLS>
+  __device__ __forceinline__ uint64_t pick(uint32_t ci) const {
+    uint64_t v = w0;
+    if (NCLS > 1) v = (ci == 1u) ? w1 : v;
+    // the empty asm keeps the compiler from folding a longer select chain into an indexed load from scratch memory
+    if (NCLS > 2) { asm volatile("" : "+v"(v)); v = (ci == 2u) ? w2 : v; }
+    if (NCLS > 3) { asm volatile("" : "+v"(v)); v = (ci == 3u) ? w3 : v; }
+    return v;
+  }
+  __device__ __forceinline__ void and_all(uint64_t m) { w0 &= m; w1 &= m; w2 &= m; w3 &= m; }
+};
 
 template <int NCLS>
 __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(ScanArgs a) {
@@ -264,28 +272,25 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       for (int c = 0; c < NCLS; c++) {
         const uint32_t kind = ch.kind[c], lo = ch.lo[c], hi = ch.hi[c];
         uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
-        if (a.dbg & 0x80000u) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) pieces[lane + 64 * q] = static_cast<uint16_t>(x[q].x ^ x[q].y ^ x[q].z ^ x[q].w);
-        } else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
+        if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
         else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
         else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
       const uint32_t xprev_cur = xprev;                             // arrived with x[] (same vmcnt)
       if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on
       wave_lds_sync();
-      uint64_t F[NCLS], R[NCLS], U = 0;                             // forward / reversed words, class union
-#pragma unroll
-      for (int c = 0; c < NCLS; c++) { F[c] = s_cls[wave][c][lane]; R[c] = brev64(s_cls[wave][c][63 - lane]); }
+      Words4 F{0, 0, 0, 0}, R{0, 0, 0, 0};                          // forward / reversed words
+      F.w0 = s_cls[wave][0][lane]; R.w0 = brev64(s_cls[wave][0][63 - lane]);
+      if (NCLS > 1) { F.w1 = s_cls[wave][NCLS > 1 ? 1 : 0][lane]; R.w1 = brev64(s_cls[wave][NCLS > 1 ? 1 : 0][63 - lane]); }
+      if (NCLS > 2) { F.w2 = s_cls[wave][NCLS > 2 ? 2 : 0][lane]; R.w2 = brev64(s_cls[wave][NCLS > 2 ? 2 : 0][63 - lane]); }
+      if (NCLS > 3) { F.w3 = s_cls[wave][NCLS > 3 ? 3 : 0][lane]; R.w3 = brev64(s_cls[wave][NCLS > 3 ? 3 : 0][63 - lane]); }
       if (stage != kWaveTile + kWaveHalo) {                         // short last window: nothing past the data is in a class
         const int32_t nf = stage - 64 * lane, nr = stage - 64 * (63 - lane);
         const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
         const uint64_t vr = brev64(nr <= 0 ? 0ull : (nr >= 64 ? ~0ull : ((1ull << nr) - 1ull)));
-#pragma unroll
-        for (int c = 0; c < NCLS; c++) { F[c] &= vf; R[c] &= vr; }
+        F.and_all(vf); R.and_all(vr);
       }
-#pragma unroll
-      for (int c = 0; c < NCLS; c++) U |= F[c];
+      const uint64_t U = F.w0 | F.w1 | F.w2 | F.w3;                 // class union
 
       // the byte in front of the tile, once, through the scalar cache
       bool prev_in_alphabet = false, prev_in_lead = false;
@@ -318,11 +323,10 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
 
       // ---- B: chain, right to left, on the reversed words
       uint64_t G = ~0ull;
-      if (a.dbg & 0x10000u) G = R[0];
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
-      for (int k = (a.dbg & 0x10000u) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) {
+      for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
         const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
-        const uint64_t Ck = pick<NCLS>(R, ci);
+        const uint64_t Ck = R.pick<NCLS>(ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
         if (!((ch.op_is_run >> k) & 1u)) {
           uint64_t low = from_lower64(G) >> 63;                     // DPP outside any lane-dependent branch: a
@@ -343,12 +347,11 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       // starts, reversed orientation: with a leading run only the first byte of the run is a candidate
       uint64_t surv = G;
       if (lead_run) {
-        const uint64_t D = pick<NCLS>(R, lead_cls);
+        const uint64_t D = R.pick<NCLS>(lead_cls);
         uint64_t dup = from_upper64(D);
         if (lane == 63) dup = prev_in_lead ? 1ull : 0ull;
         surv = D & ~((D >> 1) | (dup << 63)) & G;
       }
-      if (a.dbg & 0x30000u) surv = 0;                               // timing ablations only (results wrong)
       if (__ballot(surv != 0ull) != 0ull) {
         // ---- to forward orientation, restricted to the owned range (zA, zB]
         const uint64_t S = ((static_cast<uint64_t>(__brev(lane_reverse32(static_cast<uint32_t>(surv), lane))) << 32) |
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         unsigned long long co64 = 0, mid = 0;                       // bit 63: a marker left the window at this / an earlier step
         for (uint32_t k = 0; k < nops; k++) {
           const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
-          const uint64_t Ck = pick<NCLS>(F, ci);
+          const uint64_t Ck = F.pick<NCLS>(ci);
           mid |= co64;
           if (!((ch.op_is_run >> k) & 1u)) {
             co64 = __builtin_amdgcn_ballot_w64(static_cast<int64_t>(M) < 0);
@@ -381,9 +384,9 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         const uint32_t packed = ns | (ne << 16);
         const uint32_t incl = wave_inclusive_sum(packed);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-        uint32_t n = (a.dbg & 0x40000u) ? 0u : (tot & 0xFFFFu);
+        uint32_t n = tot & 0xFFFFu;
         const uint32_t n_ends = (tot >> 16) + cout;
-        if (n != n_ends && !(a.dbg & 0x40000u)) {                   // pairing invariant violated
+        if (n != n_ends) {                                          // pairing invariant violated
           if (a.prof && lane == 0 && atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 7), 1ull) == 0ull) {
             a.prof[0] = tile_lo; a.prof[1] = n; a.prof[2] = n_ends; a.prof[3] = cout; a.prof[4] = static_cast<uint64_t>(static_cast<int64_t>(zA));
             a.prof[5] = static_cast<uint64_t>(static_cast<int64_t>(zB)); a.prof[6] = static_cast<uint64_t>(stage);
