@@ -187,8 +187,8 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   a.prof = nullptr;
   a.dbg = dbgBits;
   if (profOn) {
-    if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 64));
-    HIP_TRY(hipMemsetAsync(s.prof, 0, 64, stream));
+    if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));
+    HIP_TRY(hipMemsetAsync(s.prof, 0, 128, stream));
     a.prof = s.prof;
   }
   int gen = digitKernelGeneration();
@@ -254,8 +254,14 @@ relaunch:
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
   }
   if (profOn) {
-    uint64_t pc[8];
-    HIP_TRY(hipMemcpy(pc, s.prof, 64, hipMemcpyDeviceToHost));
+    uint64_t pc[16];
+    HIP_TRY(hipMemcpy(pc, s.prof, 128, hipMemcpyDeviceToHost));
+    if (gen == 6 && pc[15]) {
+      fprintf(stderr, "[CXG_PROF] gen6 waves=%llu avg cycles per wave and group:", (unsigned long long)pc[15]);
+      static const char* names[7] = {"A", "ldsT", "own", "B", "starts", "F", "rows"};
+      for (int i = 0; i < 7; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)(pc[8 + i] / pc[15]));
+      fprintf(stderr, "\n");
+    }
     if (gen == 6 && pc[7])
       fprintf(stderr, "[CXG_PROF] gen6 pairing mismatch: tile_lo=%llu n=%llu n_ends=%llu cout=%llu zA=%lld zB=%lld stage=%llu (count %llu)\n",
               (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3],

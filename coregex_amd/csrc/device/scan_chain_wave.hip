@@ -19,12 +19,13 @@
 //      tile owns exactly the starts in (zA, zB] (a match never crosses a synchronising byte).
 //   F  chain left to right on the FORWARD words from the owned starts: run step M = (M + C) & ~C, byte step
 //      M <<= 1.  Result: the ends E; the k-th start pairs with the k-th end ("ordered" chains).
-//   P  ranks of starts and ends by one packed DPP prefix sum; (start, end) meet again in LDS; FindAll drops a
-//      match that begins inside the previous emitted one (adjacent compare; rare serial path when it happens).
+//   P  ranks of starts and ends by one packed DPP prefix sum; both compactions keep the order, so start k and
+//      end k land in row k of the wave's row buffer.  FindAll drops a match that begins inside the previous
+//      emitted one: detected as "rank of the start != number of ends at or before it", resolved serially (rare).
 // A workgroup (4 waves) takes ONE ticket per 32 wave-tiles (120 KiB); after a single barrier the group's
 // rows are ordered, looked back (block_common.hpp) and written as coalesced 16-byte stores.
 // Fallback flag (err bit 8: the host reruns the scan with the table-walking kernels): no synchronising byte
-// in a halo, > 64 owned starts in a wave-tile, row buffer overflow, or a violated pairing invariant.
+// in a halo, row buffer overflow (> 512 matches per wave and group), or a violated pairing invariant.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -37,6 +38,20 @@
 #endif
 #ifndef CXG_CHAIN_SCHED_BARRIER
 #define CXG_CHAIN_SCHED_BARRIER 1
+#endif
+// -DCXG_CHAIN_PROF=1 (experiments only): s_memtime at the phase boundaries, cycles summed into ScanArgs::prof[8..15]
+#ifndef CXG_CHAIN_PROF
+#define CXG_CHAIN_PROF 0
+#endif
+#if CXG_CHAIN_PROF
+#define PHASE_MARK(i) do { const uint64_t t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+// -DCXG_ABL=n (experiments only, results WRONG): 1 = no chain passes and no rows, 2 = no forward pass and no rows,
+// 3 = no rows, 4 = no class masks either (with 1).  Used to attribute instruction counts to the phases.
+#ifndef CXG_ABL
+#define CXG_ABL 0
 #endif
 #ifndef CXG_CHAIN_PREFETCH
 #define CXG_CHAIN_PREFETCH 1
@@ -195,11 +210,9 @@ struct Words4 {
 template <int NCLS>
 __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
-  __shared__ uint32_t s_rowpos[kWavesPerBlock][kWRows];
-  __shared__ uint16_t s_rowlen[kWavesPerBlock][kWRows];
-  __shared__ uint16_t s_spos[kWavesPerBlock][64];
-  __shared__ uint16_t s_epos[kWavesPerBlock][66];
-  __shared__ uint8_t s_em[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
+  __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile
+  __shared__ uint16_t s_re[kWavesPerBlock][kWRows];
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
   __shared__ uint64_t s_group;
@@ -252,6 +265,10 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
   };
   if (CXG_CHAIN_PREFETCH) issue_loads(0);
 
+#if CXG_CHAIN_PROF
+  uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tlast = __builtin_readcyclecounter();
+#endif
   for (int j = 0; j < kTilesPerWave; j++) {
     // Opaque copy of the lane id per wave-tile: lane-derived masks and LDS addresses are recomputed (a few ALU
     // ops) instead of being hoisted out of the loop and spilled — a scratch reload waits on vmcnt, which would
@@ -272,10 +289,14 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       for (int c = 0; c < NCLS; c++) {
         const uint32_t kind = ch.kind[c], lo = ch.lo[c], hi = ch.hi[c];
         uint16_t* pieces = reinterpret_cast<uint16_t*>(s_cls[wave][c]);
-        if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
+        if (CXG_ABL == 4) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) pieces[lane + 64 * q] = static_cast<uint16_t>(x[q].x ^ x[q].y ^ x[q].z ^ x[q].w);
+        } else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
         else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
         else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
+      PHASE_MARK(0);                                                // A: wait for the window + class masks
       const uint32_t xprev_cur = xprev;                             // arrived with x[] (same vmcnt)
       if (CXG_CHAIN_PREFETCH) issue_loads(j + 1);                   // x[] is free from here on
       wave_lds_sync();
@@ -292,6 +313,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       }
       const uint64_t U = F.w0 | F.w1 | F.w2 | F.w3;                 // class union
 
+      PHASE_MARK(1);                                                // loads issued, LDS transpose, words read
       // the byte in front of the tile, once, through the scalar cache
       bool prev_in_alphabet = false, prev_in_lead = false;
       if (tile_lo > 0) {
@@ -321,10 +343,11 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         else if (stage != rend) { zB = -2; fallback |= 1; }         // no synchronising byte in the halo: ownership unknown
       }
 
+      PHASE_MARK(2);                                                // previous byte + ownership bounds
       // ---- B: chain, right to left, on the reversed words
       uint64_t G = ~0ull;
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
-      for (int k = static_cast<int>(nops) - 1; k >= 0; k--) {
+      for (int k = (CXG_ABL == 1 || CXG_ABL == 4) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) {
         const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
         const uint64_t Ck = R.pick<NCLS>(ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
@@ -338,12 +361,13 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
           if (lane == 0) tlow = inject;
           const uint64_t M = ((T << 1) | tlow) & Ck;
           const uint64_t s1 = Ck + M;
-          const unsigned long long GG = __builtin_amdgcn_ballot_w64(s1 < M);
-          const unsigned long long PP = __builtin_amdgcn_ballot_w64(s1 == ~0ull);
+          const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, M, 36 /*ult*/);
+          const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
           const unsigned long long recv = (PP + (GG << 1)) ^ PP;    // lanes that receive a carry
           G = Ck & ~add_carry_mask(s1, recv);
         }
       }
+      PHASE_MARK(3);                                                // backward chain
       // starts, reversed orientation: with a leading run only the first byte of the run is a candidate
       uint64_t surv = G;
       if (lead_run) {
@@ -352,100 +376,100 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
         if (lane == 63) dup = prev_in_lead ? 1ull : 0ull;
         surv = D & ~((D >> 1) | (dup << 63)) & G;
       }
+      if (CXG_ABL == 1 || CXG_ABL == 2 || CXG_ABL == 4) surv = 0;
       if (__ballot(surv != 0ull) != 0ull) {
         // ---- to forward orientation, restricted to the owned range (zA, zB]
-        const uint64_t S = ((static_cast<uint64_t>(__brev(lane_reverse32(static_cast<uint32_t>(surv), lane))) << 32) |
-                            __brev(lane_reverse32(static_cast<uint32_t>(surv >> 32), lane))) & word_range(lane, zA + 1, zB);
+        s_x[wave][lane] = surv;                                     // the kernel is VALU-bound: two LDS instructions beat the
+        wave_lds_sync();                                            // ~20 VALU of a register lane reversal (lane_reverse32)
+        const uint64_t S = brev64(s_x[wave][63 - lane]) & word_range(lane, zA + 1, zB);
+        PHASE_MARK(4);                                              // starts, moved to forward orientation
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
-        unsigned long long co64 = 0, mid = 0;                       // bit 63: a marker left the window at this / an earlier step
         for (uint32_t k = 0; k < nops; k++) {
           const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
           const uint64_t Ck = F.pick<NCLS>(ci);
-          mid |= co64;
           if (!((ch.op_is_run >> k) & 1u)) {
-            co64 = __builtin_amdgcn_ballot_w64(static_cast<int64_t>(M) < 0);
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
             M = (M << 1) | low;
           } else {
             const uint64_t s1 = Ck + M;
-            const unsigned long long GG = __builtin_amdgcn_ballot_w64(s1 < M);
-            const unsigned long long PP = __builtin_amdgcn_ballot_w64(s1 == ~0ull);
+            const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, M, 36 /*ult*/);
+            const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
             const unsigned long long recv = (PP + (GG << 1)) ^ PP;
-            co64 = GG | (PP & recv);
             M = add_carry_mask(s1, recv) & ~Ck;
           }
         }
-        const uint32_t cout = static_cast<uint32_t>(co64 >> 63);      // an end exactly at byte 4096 (end of input)
-        if (mid >> 63) fallback |= 2;                               // a match left the window mid-chain: cannot happen for owned starts
+        PHASE_MARK(5);                                              // forward chain
         // ---- P: ranks of starts and ends, (start, end) pairs
         const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(M));
         const uint32_t packed = ns | (ne << 16);
         const uint32_t incl = wave_inclusive_sum(packed);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-        uint32_t n = tot & 0xFFFFu;
+        uint32_t n = CXG_ABL == 3 ? 0u : (tot & 0xFFFFu);
+        // A marker that left the window is a match ending exactly at byte 4096: possible only when that is the
+        // end of the input, and then only for the last match.  Anything else breaks the pairing and falls back.
+        const uint32_t cout = (at_eoi_edge && (tot & 0xFFFFu) == (tot >> 16) + 1u) ? 1u : 0u;
         const uint32_t n_ends = (tot >> 16) + cout;
-        if (n != n_ends) {                                          // pairing invariant violated
+        if (n != n_ends && CXG_ABL != 3) {                          // pairing invariant violated
           if (a.prof && lane == 0 && atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 7), 1ull) == 0ull) {
             a.prof[0] = tile_lo; a.prof[1] = n; a.prof[2] = n_ends; a.prof[3] = cout; a.prof[4] = static_cast<uint64_t>(static_cast<int64_t>(zA));
             a.prof[5] = static_cast<uint64_t>(static_cast<int64_t>(zB)); a.prof[6] = static_cast<uint64_t>(stage);
           }
           fallback |= 4; n = 0;
         }
-        if (n > 64u) { fallback |= 8; n = 64u; }
-        {
+        // Both compactions keep the order, so start k and end k land in the same row without ever meeting in
+        // a register.  FindAll skips a match that begins inside the previous emitted one (findall.go:267-275):
+        // that shows as a start whose rank differs from the number of ends at or before it.
+        uint32_t ov = 0;
+        if (n) {
           uint32_t is = (incl & 0xFFFFu) - ns, ie = (incl >> 16) - ne;
+          const uint32_t ie0 = ie;
           uint64_t sb = S, eb = M;
           while (sb) {
             const int bit = __builtin_ctzll(sb);
             sb &= sb - 1;
-            if (is < 64u) s_spos[wave][is] = static_cast<uint16_t>(64 * lane + bit);
+            const uint32_t r = nrows_w + is;
+            if (r < static_cast<uint32_t>(kWRows)) s_rs[wave][r] = static_cast<uint16_t>(64 * lane + bit);
+            const uint32_t ends_le = ie0 + static_cast<uint32_t>(__popcll(M & ((2ull << bit) - 1ull)));
+            ov |= (ends_le != is) ? 1u : 0u;
             is++;
           }
           while (eb) {
             const int bit = __builtin_ctzll(eb);
             eb &= eb - 1;
-            if (ie < 64u) s_epos[wave][ie] = static_cast<uint16_t>(64 * lane + bit);
+            const uint32_t r = nrows_w + ie;
+            if (r < static_cast<uint32_t>(kWRows)) s_re[wave][r] = static_cast<uint16_t>(64 * lane + bit);
             ie++;
           }
-          if (cout && lane == 0 && (tot >> 16) < 64u) s_epos[wave][tot >> 16] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
+          if (cout && lane == 0 && nrows_w + (tot >> 16) < static_cast<uint32_t>(kWRows)) s_re[wave][nrows_w + (tot >> 16)] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
         }
-        wave_lds_sync();
-        int32_t c = 0, e = 0;
-        uint32_t emit = 0;
-        if (static_cast<uint32_t>(lane) < n) { c = s_spos[wave][lane]; e = s_epos[wave][lane]; emit = 1; }
-        // FindAll order: a match starting inside the previous emitted match is skipped (findall.go:267-275).
-        // Ends ascend with starts, so an overlap shows between neighbours.
-        const int32_t next_c = static_cast<int32_t>(dpp_from_upper(static_cast<uint32_t>(c)));
-        const bool overlap = (static_cast<uint32_t>(lane) + 1u < n) && next_c < e;
-        if (__ballot(overlap) != 0ull) {
+        emitted_here = n;
+        if (__ballot(ov != 0) != 0ull && nrows_w + n <= static_cast<uint32_t>(kWRows)) {   // rare: resolve serially, in place
+          wave_lds_sync();
+          uint32_t kept = 0;
           if (lane == 0) {
             int32_t cur_end = -1;
-            for (uint32_t k = 0; k < n; k++) {
-              uint8_t em = 0;
-              const int32_t ck = s_spos[wave][k];
-              if (ck >= cur_end) { em = 1; cur_end = s_epos[wave][k]; }
-              s_em[wave][k] = em;
+            for (uint32_t q = 0; q < n; q++) {
+              const uint16_t sq = s_rs[wave][nrows_w + q], eq = s_re[wave][nrows_w + q];
+              if (static_cast<int32_t>(sq) >= cur_end) { s_rs[wave][nrows_w + kept] = sq; s_re[wave][nrows_w + kept] = eq; kept++; cur_end = eq; }
             }
           }
+          emitted_here = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(kept)));
           wave_lds_sync();
-          emit = (static_cast<uint32_t>(lane) < n) ? s_em[wave][lane] : 0u;
-        }
-        const unsigned long long em_mask = __ballot(emit != 0);
-        emitted_here = static_cast<uint32_t>(__popcll(em_mask));
-        if (emit) {
-          const uint32_t r = nrows_w + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
-          if (r < static_cast<uint32_t>(kWRows)) {
-            s_rowpos[wave][r] = static_cast<uint32_t>(j * kWavesPerBlock + wave) * kWaveTile + static_cast<uint32_t>(c);
-            s_rowlen[wave][r] = static_cast<uint16_t>(e - c);
-          }
         }
       }
     }
+    PHASE_MARK(6);                                                  // ranks + rows
     if (lane == 0) s_cnt[wave][j] = emitted_here;
     nrows_w += emitted_here;
   }
+#if CXG_CHAIN_PROF
+  if (a.prof && lane == 0) {
+    for (int i = 0; i < 7; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 8 + i), static_cast<unsigned long long>(pacc[i]));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 15), 1ull);
+  }
+#endif
   if (nrows_w > static_cast<uint32_t>(kWRows)) fallback |= 16;
   if (fallback != 0 && lane == 0) atomicOr(a.err, 8u | (fallback << 8));   // bits 8.. = reason (diagnostics, CXG_VERBOSE)
   __syncthreads();
@@ -471,7 +495,8 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
     for (uint32_t i = lane; i < n; i += 64) {
       const uint32_t r = start + i;
       if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
-        longlong2 v; v.x = origin + s_rowpos[wave][r]; v.y = v.x + s_rowlen[wave][r];
+        const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+        longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
         *reinterpret_cast<longlong2*>(a.out + (dst + i) * 2) = v;
       }
     }

@@ -198,7 +198,7 @@ def test_bitparallel_chain_emulated(oracle):
             for geom in ((3840, 256), (192, 64), (64, 64)):
                 got = emu.find_all_chain6(p.blob(), hay, *geom)
                 if isinstance(got, int):
-                    assert got in (-17, -24), (pat, geom, got)     # only "no sync byte in a halo" / "> 64 starts" may fall back
+                    assert got in (-17,), (pat, geom, got)     # only "no sync byte in a halo" / "> 64 starts" may fall back
                     continue
                 assert got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), geom)
         for _ in range(120):
@@ -208,7 +208,7 @@ def test_bitparallel_chain_emulated(oracle):
             for geom in ((3840, 256), (192, 64), (128, 128)):
                 got = emu.find_all_chain6(p.blob(), hay, *geom)
                 if isinstance(got, int):
-                    assert got in (-17, -24, -25), (pat, geom, got)
+                    assert got in (-17,), (pat, geom, got)
                     continue
                 assert got.tolist() == exp, (pat, n, geom)
         # exact window edge at the end of input: the last run touches the last byte of a full window
