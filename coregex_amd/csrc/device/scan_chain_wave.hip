@@ -75,14 +75,10 @@ __device__ __forceinline__ uint32_t gather_top(uint32_t m80) {
 // KIND is a template parameter so that the per-class switch is taken once per wave-tile, not once per dword.
 template <int KIND>
 __device__ __forceinline__ uint32_t notcls4(uint32_t x, uint32_t lo4, uint32_t hi4) {   // lo4/hi4: class bounds splat over the bytes
-  if (KIND == kClsDigit) {
-    const uint32_t t = x ^ 0x30303030u;
-    return (((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u;
-  }
-  if (KIND == kClsByte) {
-    const uint32_t v = x ^ lo4;
-    return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
-  }
+  // (x ^ c) has the top bit of x in every byte (c < 0x80), so the final "| top bit" can take x itself: three
+  // ternary-logic / add ops per dword.
+  if (KIND == kClsDigit) return ((((x ^ 0x30303030u) & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u;
+  if (KIND == kClsByte) return ((((x ^ lo4) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
   const uint32_t ge = ((x | 0x80808080u) - lo4) & 0x80808080u;
   const uint32_t gt = ((x & 0x7F7F7F7Fu) + hi4) & 0x80808080u;     // hi4 = (0x7F - hi) splat
   return ~(ge & ~gt & ~x) & 0x80808080u;
@@ -155,20 +151,22 @@ __device__ __forceinline__ uint64_t add_carry_mask(uint64_t s, unsigned long lon
 }
 // Inclusive prefix sum over the 64 lanes, all DPP (row shifts, then row broadcasts).
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111 /*row_shr:1*/, 0xF, 0xF, false));
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112 /*row_shr:2*/, 0xF, 0xF, false));
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114 /*row_shr:4*/, 0xF, 0xF, false));
-  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111 /*row_shr:1*/, 0xF, 0xF, true));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112 /*row_shr:2*/, 0xF, 0xF, true));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114 /*row_shr:4*/, 0xF, 0xF, true));
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118 /*row_shr:8*/, 0xF, 0xF, true));
   v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142 /*row_bcast:15*/, 0xA, 0xF, false));
   v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143 /*row_bcast:31*/, 0xC, 0xF, false));
   return v;
 }
 // bits [lo, hi] (inclusive, window bit indices) that fall into lane's word [64*lane, 64*lane+63]
 __device__ __forceinline__ uint64_t word_range(int lane, int32_t lo, int32_t hi) {
+  // bits >= a and <= b of the word, a/b relative to the word and clamped so that the shifts stay in range
   const int32_t a = lo - 64 * lane, b = hi - 64 * lane;
-  if (b < 0 || a > 63) return 0ull;
-  const uint64_t ge = a <= 0 ? ~0ull : (~0ull << a);
-  const uint64_t le = b >= 63 ? ~0ull : ((2ull << b) - 1ull);
+  const uint32_t ac = static_cast<uint32_t>(a < 0 ? 0 : (a > 64 ? 64 : a));        // 0..64: number of low bits to drop
+  const uint32_t bc = static_cast<uint32_t>(b < -1 ? 0 : (b > 63 ? 64 : b + 1));   // 0..64: number of low bits to keep
+  const uint64_t ge = ac >= 64u ? 0ull : (~0ull << ac);
+  const uint64_t le = bc >= 64u ? ~0ull : ~(~0ull << bc);
   return ge & le;
 }
 
