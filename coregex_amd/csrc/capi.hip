@@ -25,7 +25,7 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
-hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, hipStream_t stream);
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -196,6 +196,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (gen > 6) gen = 6;
   if (gen == 6 && !(h->flags & cxgdev::kFlagChainOrdered)) gen = 5;
   if (h->kind == cxgdev::kKindDigit) {
+    if ((gen == 4 || gen == 5) && (h->flags & cxgdev::kFlagChainSets)) gen = 3;   // only generation 6 evaluates set classes
     if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
     if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
@@ -210,7 +211,8 @@ relaunch:
   hipError_t le;
   if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
-    le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls, stream);
+    le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
+                                        (h->flags & cxgdev::kFlagChainSets) != 0, stream);
   }
   else switch (h->kind) {
     case cxgdev::kKindDigit:

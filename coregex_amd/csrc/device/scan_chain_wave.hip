@@ -104,6 +104,27 @@ __device__ __forceinline__ void classify_tile(const u32x4 (&x)[4], uint32_t lo, 
 #endif
   }
 }
+// A class that is a union of up to four ASCII ranges (\w = [0-9A-Z_a-z]): range tests share x|0x80 and x&0x7F.
+struct SetRanges { uint32_t n; uint32_t lo4[kChainMaxRanges], hi4[kChainMaxRanges]; };   // splat bounds, hi4 = (0x7F - hi) splat
+__device__ __forceinline__ uint32_t notset4(uint32_t x, const SetRanges& r) {
+  const uint32_t xh = x | 0x80808080u, xl = x & 0x7F7F7F7Fu;
+  uint32_t in = (xh - r.lo4[0]) & ~(xl + r.hi4[0]);
+  if (r.n > 1) in |= (xh - r.lo4[1]) & ~(xl + r.hi4[1]);
+  if (r.n > 2) in |= (xh - r.lo4[2]) & ~(xl + r.hi4[2]);
+  if (r.n > 3) in |= (xh - r.lo4[3]) & ~(xl + r.hi4[3]);
+  return ~(in & ~x) & 0x80808080u;
+}
+__device__ __forceinline__ void classify_tile_set(const u32x4 (&x)[4], const SetRanges& r, int lane, uint16_t* pieces) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t lo = __builtin_amdgcn_udot4(notset4(x[k].y, r), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].x, r), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(notset4(x[k].w, r), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].z, r), 0x08040201u, 0u, false), false);
+    pieces[lane + 64 * k] = static_cast<uint16_t>(((lo >> 7) | (hi << 1)) ^ 0xFFFFu);
+#if CXG_CHAIN_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
   return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
@@ -173,14 +194,27 @@ __device__ __forceinline__ uint64_t word_range(int lane, int32_t lo, int32_t hi)
 }  // namespace
 
 // The chain description held in scalar registers for the whole kernel (no LDS/VGPR traffic in the op loops).
-template <int NCLS>
+template <int NCLS, bool SETS>
 struct ChainRegs {
   uint32_t nops;
   uint32_t op_is_run;      // bit k: step k is a run
   uint32_t op_cls2;        // 2 bits per step: its class
   uint32_t kind[NCLS], lo[NCLS], hi[NCLS];
+  const ChainAux* aux;     // uniform address: the ranges of kClsSet classes are read through the scalar cache at use
   __device__ __forceinline__ bool has(int c, uint32_t b) const {
+    if (SETS && kind[c] == kClsSet) {
+      bool in = false;
+      for (uint32_t r = 0; r < aux->cls_nr[c]; r++) in = in || (b >= aux->cls_rlo[c][r] && b <= aux->cls_rhi[c][r]);
+      return in;
+    }
     return kind[c] == kClsDigit ? (b - 0x30u) < 10u : (b >= lo[c] && b <= hi[c]);
+  }
+  __device__ __forceinline__ SetRanges ranges(int c) const {
+    SetRanges r;
+    r.n = aux->cls_nr[c];
+#pragma unroll
+    for (int q = 0; q < kChainMaxRanges; q++) { r.lo4[q] = aux->cls_rlo[c][q] * 0x01010101u; r.hi4[q] = (0x7Fu - aux->cls_rhi[c][q]) * 0x01010101u; }
+    return r;
   }
   __device__ __forceinline__ bool in_alphabet(uint32_t b) const {
     bool r = false;
@@ -205,8 +239,10 @@ struct Words4 {
   __device__ __forceinline__ void and_all(uint64_t m) { w0 &= m; w1 &= m; w2 &= m; w3 &= m; }
 };
 
-template <int NCLS>
-__global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(ScanArgs a) {
+// SETS: some class is a union of ranges (kClsSet); a separate instantiation keeps that code (and its register
+// pressure) out of the kernels of single-range programs.
+template <int NCLS, bool SETS>
+__global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
   __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile
@@ -222,7 +258,8 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
   if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.blob + h->aux_off + 256);   // uniform address: scalar loads
-  ChainRegs<NCLS> ch;
+  ChainRegs<NCLS, SETS> ch;
+  ch.aux = gch;
   ch.nops = gch->nops;
   ch.op_is_run = 0; ch.op_cls2 = 0;
 #pragma unroll
@@ -292,6 +329,7 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
           for (int q = 0; q < 4; q++) pieces[lane + 64 * q] = static_cast<uint16_t>(x[q].x ^ x[q].y ^ x[q].z ^ x[q].w);
         } else if (kind == kClsDigit) classify_tile<kClsDigit>(x, lo, hi, lane, pieces);
         else if (kind == kClsByte) classify_tile<kClsByte>(x, lo, hi, lane, pieces);
+        else if (SETS && kind == kClsSet) classify_tile_set(x, ch.ranges(c), lane, pieces);
         else classify_tile<kClsRange>(x, lo, hi, lane, pieces);
       }
       PHASE_MARK(0);                                                // A: wait for the window + class masks
@@ -495,20 +533,24 @@ __global__ __launch_bounds__(kThreads, CXG_CHAIN_WAVES) void k_scan_chain_wave(S
       if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
         const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
         longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * 2) = v;
+        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;   // row_width > 2: a capture pass fills the rest
       }
     }
     start += n;
   }
 }
 
-hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, hipStream_t stream) {
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  switch (ncls) {
-    case 1: hipLaunchKernelGGL(k_scan_chain_wave<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(k_scan_chain_wave<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(k_scan_chain_wave<3>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(k_scan_chain_wave<4>, grid, block, 0, stream, a); break;
+  switch (ncls * 2 + (sets ? 1 : 0)) {
+    case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false>), grid, block, 0, stream, a); break;
+    case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true>), grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false>), grid, block, 0, stream, a); break;
+    case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

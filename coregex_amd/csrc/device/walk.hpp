@@ -406,8 +406,8 @@ CXG_HD void lane_select(const Mem& m, const DfaView& d, const uint8_t* info, con
 // class tests may be widened) are then verified with the DFA as before, so the result stays exact.
 // All bitmaps of this scheme are stored reversed: bit i of word w describes byte N-1-(64w+i), N = 64*words.
 enum ChainOpKind : uint8_t { kChainByte = 0, kChainRun = 1 };
-enum ChainClassKind : uint8_t { kClsDigit = 0, kClsByte = 1, kClsRange = 2 };
-constexpr int kChainMaxOps = 16, kChainMaxCls = 4;
+enum ChainClassKind : uint8_t { kClsDigit = 0, kClsByte = 1, kClsRange = 2, kClsSet = 3 };   // set: union of 2..4 ASCII ranges (\w)
+constexpr int kChainMaxOps = 16, kChainMaxCls = 4, kChainMaxRanges = 4;
 
 struct ChainAux {             // aux section of a kKindDigit blob when kFlagChain is set (follows sflags[256])
   uint32_t nops, ncls;
@@ -416,14 +416,22 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t cls_kind[kChainMaxCls];
   uint8_t cls_lo[kChainMaxCls];
   uint8_t cls_hi[kChainMaxCls];
-  uint8_t _pad[4];
+  uint8_t cls_nr[kChainMaxCls];                       // kClsSet: number of ranges, then the ranges
+  uint8_t cls_rlo[kChainMaxCls][kChainMaxRanges];
+  uint8_t cls_rhi[kChainMaxCls][kChainMaxRanges];
 };
+constexpr uint32_t kFlagChainSets = 32u;        // some class is a kClsSet: only scan_chain_wave.hip evaluates those
 constexpr uint32_t kFlagChain = 4u;
 constexpr uint32_t kFlagChainOrdered = 16u;    // complete, and the k-th match start pairs with the k-th match end (program.cc extractChain)
 constexpr uint32_t kFlagChainComplete = 8u;   // the chain is the whole DFA: survivors are matches, classes = alphabet
 
 CXG_HD bool chain_class_has(const ChainAux& c, int k, uint32_t b) {
   if (c.cls_kind[k] == kClsDigit) return is_digit(b);
+  if (c.cls_kind[k] == kClsSet) {
+    bool in = false;
+    for (int r = 0; r < c.cls_nr[k]; r++) in = in || (b >= c.cls_rlo[k][r] && b <= c.cls_rhi[k][r]);
+    return in;
+  }
   return b >= c.cls_lo[k] && b <= c.cls_hi[k];
 }
 

@@ -223,12 +223,21 @@ void appendTable(std::vector<uint8_t>& blob, const Dfa& d, uint32_t& off) {
 void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain, bool& complete, bool& ordered) {
   std::memset(&chain, 0, sizeof chain);
   complete = ordered = false;
-  auto classOf = [&](const bool in[256], uint8_t& kind, uint8_t& lo, uint8_t& hi) {
-    int first = -1, last = -1, cnt = 0;
-    for (int b = 0; b < 256; b++) if (in[b]) { if (first < 0) first = b; last = b; cnt++; }
-    if (cnt == 0 || last - first + 1 != cnt || last > 127) return false;     // contiguous ASCII range only
-    lo = static_cast<uint8_t>(first); hi = static_cast<uint8_t>(last);
-    kind = (first == '0' && last == '9') ? cxgdev::kClsDigit : (cnt == 1 ? cxgdev::kClsByte : cxgdev::kClsRange);
+  struct Cls { uint8_t kind, lo, hi, nr, rlo[cxgdev::kChainMaxRanges], rhi[cxgdev::kChainMaxRanges]; };
+  auto classOf = [&](const bool in[256], Cls& c) {       // a class is a union of at most 4 ASCII ranges
+    std::memset(&c, 0, sizeof c);
+    int nr = 0;
+    for (int b = 0; b < 256; b++) {
+      if (!in[b] || (b > 0 && in[b - 1])) continue;
+      int e = b;
+      while (e + 1 < 256 && in[e + 1]) e++;
+      if (e > 127 || nr >= cxgdev::kChainMaxRanges) return false;
+      c.rlo[nr] = static_cast<uint8_t>(b); c.rhi[nr] = static_cast<uint8_t>(e); nr++;
+    }
+    if (nr == 0) return false;
+    c.nr = static_cast<uint8_t>(nr); c.lo = c.rlo[0]; c.hi = c.rhi[nr - 1];
+    if (nr > 1) c.kind = cxgdev::kClsSet;
+    else c.kind = (c.lo == '0' && c.hi == '9') ? cxgdev::kClsDigit : (c.lo == c.hi ? cxgdev::kClsByte : cxgdev::kClsRange);
     return true;
   };
   uint32_t q = d.start;
@@ -247,12 +256,19 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
     bool loopT[256] = {false}; bool anyLoop = false, same = true;
     for (int b = 0; b < 256; b++) { loopT[b] = d.table[static_cast<size_t>(target) * 256 + b] == static_cast<uint32_t>(target); anyLoop = anyLoop || loopT[b]; }
     for (int b = 0; b < 256; b++) if (loopT[b] != F[b]) same = false;
-    uint8_t kind, lo, hi;
-    if (!classOf(F, kind, lo, hi)) break;
+    Cls cl;
+    if (!classOf(F, cl)) break;
     if (anyLoop && !same) break;                         // loops on a different class: not a plain run
     int ci = -1;
-    for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == kind && chain.cls_lo[k] == lo && chain.cls_hi[k] == hi) ci = static_cast<int>(k);
-    if (ci < 0) { if (chain.ncls >= cxgdev::kChainMaxCls) break; ci = static_cast<int>(chain.ncls++); chain.cls_kind[ci] = kind; chain.cls_lo[ci] = lo; chain.cls_hi[ci] = hi; }
+    for (uint32_t k = 0; k < chain.ncls; k++)
+      if (chain.cls_kind[k] == cl.kind && chain.cls_lo[k] == cl.lo && chain.cls_hi[k] == cl.hi && chain.cls_nr[k] == cl.nr &&
+          std::memcmp(chain.cls_rlo[k], cl.rlo, sizeof cl.rlo) == 0 && std::memcmp(chain.cls_rhi[k], cl.rhi, sizeof cl.rhi) == 0) ci = static_cast<int>(k);
+    if (ci < 0) {
+      if (chain.ncls >= cxgdev::kChainMaxCls) break;
+      ci = static_cast<int>(chain.ncls++);
+      chain.cls_kind[ci] = cl.kind; chain.cls_lo[ci] = cl.lo; chain.cls_hi[ci] = cl.hi; chain.cls_nr[ci] = cl.nr;
+      std::memcpy(chain.cls_rlo[ci], cl.rlo, sizeof cl.rlo); std::memcpy(chain.cls_rhi[ci], cl.rhi, sizeof cl.rhi);
+    }
     chain.op_kind[chain.nops] = anyLoop ? cxgdev::kChainRun : cxgdev::kChainByte;
     chain.op_cls[chain.nops] = static_cast<uint8_t>(ci);
     chain.nops++;
@@ -331,9 +347,16 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         bool complete = false, ordered = false;
         extractChain(p->fwd, info, chain, complete, ordered);
         if (chain.nops >= 2 && chain.op_kind[0] == cxgdev::kChainRun && chain.cls_kind[chain.op_cls[0]] == cxgdev::kClsDigit && chain.op_cls[0] == 0) {
-          h.flags |= cxgdev::kFlagChain;
-          if (complete) h.flags |= cxgdev::kFlagChainComplete;
-          if (complete && ordered) h.flags |= cxgdev::kFlagChainOrdered;
+          bool sets = false;
+          for (uint32_t k = 0; k < chain.ncls; k++) sets = sets || chain.cls_kind[k] == cxgdev::kClsSet;
+          if (!sets || (complete && ordered)) {
+            h.flags |= cxgdev::kFlagChain;
+            if (complete) h.flags |= cxgdev::kFlagChainComplete;
+            if (complete && ordered) h.flags |= cxgdev::kFlagChainOrdered;
+            if (sets) h.flags |= cxgdev::kFlagChainSets;
+          } else {
+            std::memset(&chain, 0, sizeof chain);
+          }
         } else {
           std::memset(&chain, 0, sizeof chain);
         }
@@ -358,6 +381,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         extractChain(anch, info, chain, complete, ordered);
         if (chain.nops >= 1 && complete && ordered) {
           h.flags |= cxgdev::kFlagChain | cxgdev::kFlagChainComplete | cxgdev::kFlagChainOrdered;
+          for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == cxgdev::kClsSet) h.flags |= cxgdev::kFlagChainSets;
           sflags.assign(256, 0);                                    // keeps the aux layout of the digit image
         } else {
           std::memset(&chain, 0, sizeof chain);
@@ -454,6 +478,25 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
       appendTable(blob, rev, h.rev_off);
       h.info_off = static_cast<uint32_t>(blob.size());
       blob.insert(blob.end(), info, info + 256);
+      // spans by the bit-parallel chain kernel when the anchored DFA is one complete, ordered chain
+      try {
+        const Dfa anch = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
+        cxgdev::ChainAux chain;
+        bool complete = false, ordered = false;
+        uint8_t syncInfo[256];
+        for (int b = 0; b < 256; b++) syncInfo[b] = info[b] & cxgdev::kInfoSync;
+        extractChain(anch, syncInfo, chain, complete, ordered);
+        if (chain.nops >= 1 && complete && ordered) {
+          h.flags |= cxgdev::kFlagChain | cxgdev::kFlagChainComplete | cxgdev::kFlagChainOrdered;
+          for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == cxgdev::kClsSet) h.flags |= cxgdev::kFlagChainSets;
+          h.aux_off = static_cast<uint32_t>(blob.size());
+          blob.insert(blob.end(), 256, 0);
+          const uint8_t* cb = reinterpret_cast<const uint8_t*>(&chain);
+          blob.insert(blob.end(), cb, cb + sizeof chain);
+          while (blob.size() % 16) blob.push_back(0);
+          h.aux_len = static_cast<uint32_t>(blob.size()) - h.aux_off;
+        }
+      } catch (const BuildError&) {}
       h.total_bytes = static_cast<uint32_t>(blob.size());
       std::memcpy(blob.data(), &h, sizeof h);
       p->subBlob.swap(blob);
