@@ -141,6 +141,71 @@ __global__ void k_captures(const uint8_t* hay, int64_t hay_base, int64_t* rows, 
   if (!cxgdev::capture_walk(cv, hay - hay_base, rows + i * width, width)) atomicOr(err, 4u);
 }
 
+// Capture pass, fast form: the one-pass table (next | maskid << 8 per entry and byte) staged in LDS, the slots of
+// a row kept in registers as offsets from the match start and written once (one 64-byte row per thread for
+// three groups).  MAXS = slots held in registers; wider rows and bigger tables use k_captures.
+constexpr uint32_t kCapLdsEntries = 48;
+template <int MAXS>
+__global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+                                                      const uint8_t* capblob, uint32_t* err) {
+  __shared__ uint16_t s_tab[kCapLdsEntries * 256];
+  __shared__ uint32_t s_masks[256];
+  __shared__ uint8_t s_fin[kCapLdsEntries];
+  const cxgdev::CapHeader* ch = reinterpret_cast<const cxgdev::CapHeader*>(capblob);
+  const uint32_t ne = ch->n_entries;
+  const uint8_t* gnext = capblob + ch->next_off;
+  const uint8_t* gmid = capblob + ch->maskid_off;
+  for (uint32_t i = threadIdx.x; i < ne * 256u; i += blockDim.x) s_tab[i] = static_cast<uint16_t>(gnext[i] | (gmid[i] << 8));
+  for (uint32_t i = threadIdx.x; i < ch->n_masks && i < 256u; i += blockDim.x) s_masks[i] = reinterpret_cast<const uint32_t*>(capblob + ch->masks_off)[i];
+  for (uint32_t i = threadIdx.x; i < ne; i += blockDim.x) s_fin[i] = capblob[ch->fin_off + i];
+  __syncthreads();
+  const uint8_t* h0 = hay - hay_base;                              // rows hold absolute offsets (hay_base added)
+  bool bad = false;
+  for (uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; r < nrows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    int64_t* row = rows + r * width;
+    const longlong2 se = *reinterpret_cast<const longlong2*>(row);
+    const int64_t s = se.x, e = se.y;
+    int32_t v[MAXS];
+#pragma unroll
+    for (int q = 0; q < MAXS; q++) v[q] = -1;
+    uint32_t ent = ch->start_entry;
+    uint32_t w = 0;
+    for (int64_t i = s; i < e; i++) {
+      const uint64_t addr = reinterpret_cast<uint64_t>(h0) + static_cast<uint64_t>(i);
+      if (i == s || (addr & 3u) == 0) w = *reinterpret_cast<const uint32_t*>(addr & ~3ull);   // one dword load per 4 bytes
+      const uint32_t b = (w >> ((addr & 3u) * 8)) & 0xFFu;
+      const uint32_t t = s_tab[ent * 256u + b];
+      const uint32_t nx = t & 0xFFu;
+      if (nx == 0xFFu) { bad = true; break; }
+      const uint32_t m = s_masks[t >> 8];
+      if (m) {
+        const int32_t rel = static_cast<int32_t>(i - s);
+#pragma unroll
+        for (int q = 2; q < MAXS; q++) if ((m >> q) & 1u) v[q] = rel;
+      }
+      ent = nx;
+    }
+    const uint32_t f = s_fin[ent];
+    if (f == 0xFFu) bad = true;
+    else {
+      const uint32_t m = s_masks[f];
+      const int32_t rel = static_cast<int32_t>(e - s);
+#pragma unroll
+      for (int q = 2; q < MAXS; q++) if ((m >> q) & 1u) v[q] = rel;
+    }
+#pragma unroll
+    for (int q = 2; q + 1 < MAXS; q += 2) {
+      if (static_cast<uint32_t>(q) < width) {
+        longlong2 o;
+        o.x = v[q] < 0 ? -1 : s + v[q];
+        o.y = v[q + 1] < 0 ? -1 : s + v[q + 1];
+        *reinterpret_cast<longlong2*>(row + q) = o;
+      }
+    }
+  }
+  if (bad) atomicOr(err, 4u);
+}
+
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
@@ -237,8 +302,18 @@ relaunch:
     uint64_t nrows = s.hostCtl[1];
     if (nrows > a.cap) nrows = a.cap;
     if (nrows) {
-      const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
-      hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+      const cxgdev::CapHeader* chh = reinterpret_cast<const cxgdev::CapHeader*>(p->capBlob.data());
+      const bool lds_ok = chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
+      if (lds_ok && a.row_width <= 8) {
+        const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
+        hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+      } else if (lds_ok && a.row_width <= 16) {
+        const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
+        hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+      } else {
+        const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
+        hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+      }
       HIP_TRY(hipGetLastError());
       launches = 2;
     }
