@@ -1,0 +1,311 @@
+// scan_teddy_wave.hip — FindAll for UseTeddy (exact literal alternation, Slim Teddy: <= 32 prefix-free literals),
+// second generation: the wave is the unit of work (same skeleton as scan_chain_wave.hip).
+//
+// Reference semantics kept (meta/find_indices.go:925-951 -> prefilter.Teddy.FindMatch, prefilter/teddy.go:391-444,
+// verifyBucket :532-550; FindAll advance meta/findall.go:267-275): the next match is at the first fingerprint
+// candidate at or after `pos` at which a literal of a hit bucket compares equal; the search resumes at its end.
+//
+// One wave64 owns a wave-tile of 60 x 64 B = 3840 B and reads 256 B of halo behind it: 4096 B = 64 bitmap
+// words, one per lane.
+//   A  four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead; the window is also kept
+//      in the wave's LDS scratch for the verifier.  Per byte ONE LDS lookup T[b] = A | B<<8 | sync<<16
+//      (A = lo[0]&hi[0], B = lo[1]&hi[1] of the reference's nibble masks, teddy.go:271-311): candidate bit
+//      i = A(b_i) & B(b_{i+1}) != 0, synchronising bit i = b_i outside the literals' alphabet.  16-bit pieces
+//      go through LDS and come back as one 64-bit word per lane.
+//   O  ownership, wave-uniform, as in the chain kernel: with zA = first synchronising byte at >= -1 and zB =
+//      first one at >= 3839 the tile owns the candidates in (zA, zB].
+//   V  owned candidates are ranked (DPP prefix sum), listed in LDS and verified 64 at a time, one per lane:
+//      buckets of the fingerprint low to high, literals of a bucket in id order, bytes from the LDS window.
+//   D  FindAll order: a verified candidate that starts inside the previous emitted match is dropped
+//      (prefix max of the ends; a rare serial path when a round contains such a candidate).
+// Group structure, tickets, look-back and row write-out: block_common.hpp / scan_chain_wave.hip.
+// Fallback flag (err bit 8: the host reruns the scan with scan_teddy.hip): no synchronising byte in a halo,
+// > 256 owned candidates in a wave-tile, row buffer overflow.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_common.hpp"
+#include "scan_dfa.h"
+#include "walk.hpp"
+#include "wave_common.hpp"
+
+namespace cxgdev {
+
+namespace {
+
+constexpr int kTRows = 384;                       // rows buffered per wave per group
+constexpr int kTCands = 256;                      // owned candidates listed per wave-tile
+constexpr int kTAuxMax = 4096;
+constexpr int32_t kTFar = 1 << 20;
+constexpr int kWin = kWaveTile + kWaveHalo;       // 4096
+
+// 16 flags (bytes of four dwords, each 0 or non-zero) -> 16 bits; NZ: test for non-zero first
+__device__ __forceinline__ uint32_t nz80(uint32_t t) { return (((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u; }
+__device__ __forceinline__ uint32_t gather16_nz(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {
+  const uint32_t lo = __builtin_amdgcn_udot4(nz80(t1), 0x80402010u, __builtin_amdgcn_udot4(nz80(t0), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(nz80(t3), 0x80402010u, __builtin_amdgcn_udot4(nz80(t2), 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1);
+}
+__device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3) {   // bytes are 0 or 1
+  const uint32_t lo = __builtin_amdgcn_udot4(t1, 0x80402010u, __builtin_amdgcn_udot4(t0, 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(t3, 0x80402010u, __builtin_amdgcn_udot4(t2, 0x08040201u, 0u, false), false);
+  return lo | (hi << 8);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
+  __shared__ uint32_t s_T[256];                                    // A | B<<8 | sync<<16 per byte value
+  __shared__ uint8_t s_boff[16];                                   // bucket b: its literals are order[s_boff[b] .. s_boff[b+1])
+  __shared__ __attribute__((aligned(16))) uint8_t s_bytes[kWavesPerBlock][kWin + 16];
+  __shared__ __attribute__((aligned(16))) uint64_t s_cw[kWavesPerBlock][2][64];   // candidate / synchronising bitmaps
+  __shared__ uint16_t s_cpos[kWavesPerBlock][kTCands];
+  __shared__ uint16_t s_rs[kWavesPerBlock][kTRows];
+  __shared__ uint16_t s_re[kWavesPerBlock][kTRows];
+  __shared__ uint8_t s_em[kWavesPerBlock][64];
+  __shared__ uint16_t s_ce[kWavesPerBlock][64];
+  __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
+  __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
+  __shared__ uint64_t s_group;
+  __shared__ uint64_t s_base;
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
+  for (uint32_t i = tid; i < h->aux_len / 4 && i < kTAuxMax / 4; i += kThreads)
+    reinterpret_cast<uint32_t*>(s_aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
+  __syncthreads();
+  const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(s_aux);
+  const uint16_t* t_ab = reinterpret_cast<const uint16_t*>(s_aux + ax->ab_off);
+  const uint8_t* t_order = s_aux + ax->order_off;
+  const uint8_t* t_lens = s_aux + ax->lens_off;
+  const uint8_t* t_bucket = s_aux + ax->bucket_off;
+  const uint16_t* t_off = reinterpret_cast<const uint16_t*>(s_aux + ax->off_off);
+  const uint8_t* t_bytes = s_aux + ax->bytes_off;
+  const uint32_t nlits = ax->nlits;
+  s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x10000u : 0u);
+  if (tid < 16) {                                                  // order[] is bucket-major: first index of every bucket
+    uint32_t first = nlits;
+    for (uint32_t k = nlits; k-- > 0;) if (t_bucket[t_order[k]] >= static_cast<uint32_t>(tid)) first = k;
+    s_boff[tid] = static_cast<uint8_t>(first);
+  }
+  __syncthreads();
+  const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  if (group >= a.ngroups) return;
+  uint32_t nrows_w = 0;                                            // wave-uniform
+  uint32_t fallback = 0;
+
+  u32x4 x[4];
+  uint32_t xprev = 0;
+  auto issue_loads = [&](int jj) {
+    const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nrec = 0;
+    if (jj < kTilesPerWave && lo < a.len) {
+      const uint64_t rem = a.len - lo;
+      nrec = rem >= static_cast<uint64_t>(kWin) ? kWin : static_cast<int>((rem + 3) & ~3ull);
+    }
+    const int pre = (nrec && lo) ? 16 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, pre ? 12 : nrec + pre, 0);
+  };
+  issue_loads(0);
+
+  for (int j = 0; j < kTilesPerWave; j++) {
+    lane = lane0;
+    asm volatile("" : "+v"(lane));                                  // see scan_chain_wave.hip: no hoisted-and-spilled lane constants
+    const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
+    const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
+    uint32_t emitted_here = 0;
+    if (tile_lo < a.len) {
+      const uint64_t remaining = a.len - tile_lo;
+      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      const int32_t stage = rend < kWin ? rend : kWin;
+
+      // ---- A: window to LDS, table lookups, candidate and synchronising bits
+      uint32_t e0[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        *reinterpret_cast<u32x4*>(&s_bytes[wave][(lane + 64 * k) << 4]) = x[k];
+        e0[k] = s_T[x[k].x & 0xFFu];
+      }
+      uint16_t* pc = reinterpret_cast<uint16_t*>(s_cw[wave][0]);
+      uint16_t* ps = reinterpret_cast<uint16_t*>(s_cw[wave][1]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t en = dpp_from_upper(e0[k]);                       // first byte of the next vector: lane+1, same k
+        const uint32_t wrap = (k < 3) ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e0[k < 3 ? k + 1 : 3]), 0)) : 0u;
+        if (lane == 63) en = wrap;
+        const uint32_t w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+        uint32_t tq[4], sq[4];
+        uint32_t ecur = e0[k];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          uint32_t t = 0, s = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const int i = q * 4 + b;
+            const uint32_t enext = (i == 15) ? en : s_T[(w[(i + 1) >> 2] >> (((i + 1) & 3) * 8)) & 0xFFu];
+            t |= ((ecur & (enext >> 8)) & 0xFFu) << (8 * b);
+            s |= ((ecur >> 16) & 1u) << (8 * b);
+            ecur = enext;
+          }
+          tq[q] = t; sq[q] = s;
+        }
+        pc[lane + 64 * k] = static_cast<uint16_t>(gather16_nz(tq[0], tq[1], tq[2], tq[3]));
+        ps[lane + 64 * k] = static_cast<uint16_t>(gather16_01(sq[0], sq[1], sq[2], sq[3]));
+      }
+      const uint32_t xprev_cur = xprev;
+      issue_loads(j + 1);                                           // x[] is free from here on
+      wave_lds_sync();
+      const uint64_t C = s_cw[wave][0][lane];
+      uint64_t Z = s_cw[wave][1][lane];
+      if (stage != kWin) {                                          // short last window: bytes past the data read as 0
+        const int32_t nv = stage - 64 * lane;
+        Z &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+      }
+
+      // ---- O: ownership bounds
+      int32_t zA = -1, zB = kTFar;
+      if (tile_lo > 0) {
+        const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
+        if (!(s_T[pb] & 0x10000u)) {                                // the segment at the tile's first byte began earlier
+          const unsigned long long bz = __ballot(Z != 0ull);
+          if (bz) { const int L = __builtin_ctzll(bz); zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L))); }
+          else zA = kTFar;
+        }
+      }
+      {
+        const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kWin - 1);
+        const unsigned long long bzb = __ballot(Zb != 0ull);
+        if (bzb) { const int L = __builtin_ctzll(bzb); zB = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, L))); }
+        else if (stage != rend) { zB = -2; fallback |= 1; }
+      }
+      const uint64_t Co = C & word_range(lane, zA + 1, zB);
+
+      // ---- V: list the owned candidates, verify 64 at a time
+      const uint32_t nc_lane = static_cast<uint32_t>(__popcll(Co));
+      const uint32_t incl = wave_inclusive_sum(nc_lane);
+      uint32_t ncand = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      if (ncand > static_cast<uint32_t>(kTCands)) { fallback |= 8; ncand = kTCands; }
+      if (ncand) {
+        uint32_t idx = incl - nc_lane;
+        uint64_t cb = Co;
+        while (cb) {
+          const int bit = __builtin_ctzll(cb);
+          cb &= cb - 1;
+          if (idx < static_cast<uint32_t>(kTCands)) s_cpos[wave][idx] = static_cast<uint16_t>(64 * lane + bit);
+          idx++;
+        }
+        wave_lds_sync();
+        int32_t cur_end = -1;                                       // wave-uniform: end of the last emitted match
+        for (uint32_t r0 = 0; r0 < ncand; r0 += 64) {
+          int32_t c = 0, mlen = 0;
+          if (r0 + static_cast<uint32_t>(lane) < ncand) {
+            c = s_cpos[wave][r0 + lane];
+            const uint8_t* wb = s_bytes[wave];
+            uint32_t mask = (s_T[wb[c]] & 0xFFu) & ((s_T[wb[c + 1]] >> 8) & 0xFFu);
+            while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
+              const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
+              mask &= mask - 1;
+              for (uint32_t k = s_boff[bk]; k < s_boff[bk + 1] && !mlen; k++) {
+                const uint32_t id = t_order[k];
+                const int32_t len = t_lens[id];
+                if (c + len > rend) continue;
+                const uint8_t* lit = t_bytes + t_off[id];
+                int32_t q = 0;
+                while (q < len && wb[c + q] == lit[q]) q++;
+                if (q == len) mlen = len;
+              }
+            }
+          }
+          // ---- D: FindAll order inside the round (candidates ascend with the lane)
+          const int32_t e = mlen ? c + mlen : 0;
+          int32_t pmax = e;                                         // inclusive prefix max of the ends
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_up(pmax, d, 64);
+            if (lane >= d && o > pmax) pmax = o;
+          }
+          int32_t before = static_cast<int32_t>(dpp_from_lower(static_cast<uint32_t>(pmax)));
+          if (lane == 0) before = 0;
+          if (cur_end > before) before = cur_end;
+          uint32_t emit = mlen ? 1u : 0u;
+          if (__ballot(mlen && c < before) != 0ull) {               // some verified candidate lies inside an earlier match
+            s_ce[wave][lane] = static_cast<uint16_t>(e);
+            wave_lds_sync();
+            if (lane == 0) {
+              int32_t ce = cur_end;
+              for (uint32_t k = 0; k < 64 && r0 + k < ncand; k++) {
+                const int32_t ek = s_ce[wave][k];
+                uint8_t em = 0;
+                if (ek && static_cast<int32_t>(s_cpos[wave][r0 + k]) >= ce) { em = 1; ce = ek; }
+                s_em[wave][k] = em;
+              }
+            }
+            wave_lds_sync();
+            emit = s_em[wave][lane];
+          }
+          const unsigned long long em_mask = __ballot(emit != 0);
+          if (em_mask) {
+            const int last = 63 - __builtin_clzll(em_mask);
+            cur_end = __builtin_amdgcn_readlane(e, last);
+            const uint32_t n_em = static_cast<uint32_t>(__popcll(em_mask));
+            if (emit) {
+              const uint32_t r = nrows_w + emitted_here + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
+              if (r < static_cast<uint32_t>(kTRows)) { s_rs[wave][r] = static_cast<uint16_t>(c); s_re[wave][r] = static_cast<uint16_t>(e); }
+            }
+            emitted_here += n_em;
+          }
+        }
+      }
+    }
+    if (lane == 0) s_cnt[wave][j] = emitted_here;
+    nrows_w += emitted_here;
+  }
+  if (nrows_w > static_cast<uint32_t>(kTRows)) fallback |= 16;
+  if (fallback != 0 && lane == 0) atomicOr(a.err, 8u | (fallback << 8));
+  __syncthreads();
+
+  // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
+  if (tid < 64) {
+    const int q = tid;
+    const uint32_t v = (q < kWavesPerBlock * kTilesPerWave) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t incl = wave_inclusive_sum(v);
+    if (q < kWavesPerBlock * kTilesPerWave) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * kTilesPerWave - 1) s_qbase[kWavesPerBlock * kTilesPerWave] = incl;
+  }
+  __syncthreads();
+  const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  if (a.out == nullptr) return;
+  const uint64_t base = s_base;
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);
+  uint32_t start = 0;
+  for (int j = 0; j < kTilesPerWave; j++) {
+    const uint32_t n = s_cnt[wave][j];
+    const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
+    for (uint32_t i = lane0; i < n; i += 64) {
+      const uint32_t r = start + i;
+      if (r < static_cast<uint32_t>(kTRows) && dst + i < a.cap) {
+        const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+        longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
+        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;
+      }
+    }
+    start += n;
+  }
+}
+
+hipError_t launch_scan_teddy_wave(const ScanArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_teddy_wave, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace cxgdev
