@@ -8,10 +8,13 @@
 // One wave64 owns a wave-tile of 60 x 64 B = 3840 B and reads 256 B of halo behind it: 4096 B = 64 bitmap
 // words, one per lane.
 //   A  four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead; the window is also kept
-//      in the wave's LDS scratch for the verifier.  Per byte ONE LDS lookup T[b] = A | B<<8 | sync<<16
-//      (A = lo[0]&hi[0], B = lo[1]&hi[1] of the reference's nibble masks, teddy.go:271-311): candidate bit
-//      i = A(b_i) & B(b_{i+1}) != 0, synchronising bit i = b_i outside the literals' alphabet.  16-bit pieces
-//      go through LDS and come back as one 64-bit word per lane.
+//      in the wave's LDS scratch for the verifier.  Per byte ONE LDS lookup T[b] = A | B<<8 | C<<16 | sync<<24
+//      (A = lo[0]&hi[0], B = lo[1]&hi[1] of the reference's nibble masks, teddy.go:271-311; C = buckets with a
+//      literal whose third byte is b — every literal has >= 3 bytes, and any superset of the true match starts
+//      is a valid candidate set because candidates are verified exactly): candidate bit i =
+//      A(b_i) & B(b_{i+1}) & C(b_{i+2}) != 0, synchronising bit i = b_i outside the literals' alphabet.  The
+//      byte extraction, the three-way AND and the packing are SDWA operations (one VALU op each per byte);
+//      16-bit pieces go through LDS and come back as one 64-bit word per lane.
 //   O  ownership, wave-uniform, as in the chain kernel: with zA = first synchronising byte at >= -1 and zB =
 //      first one at >= 3839 the tile owns the candidates in (zA, zB].
 //   V  owned candidates are ranked (DPP prefix sum), listed in LDS and verified 64 at a time, one per lane:
@@ -52,11 +55,23 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
   return lo | (hi << 8);
 }
 
+// SDWA helpers (sub-dword addressing: byte select on the sources, byte placement with preserve on the destination)
+#define CXG_SDWA_ADDR(dst, w, B) \
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #B : "=v"(dst) : "v"(two), "v"(w))
+#define CXG_SDWA_AND01(dst, ea, eb) \
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1" : "=v"(dst) : "v"(ea), "v"(eb))
+#define CXG_SDWA_AND2_PACK(T, d, ec, K) \
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_" #K " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(T) : "v"(d), "v"(ec))
+#define CXG_SDWA_MOV3_PACK(S, e, K) \
+  asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_" #K " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(S) : "v"(e))
+// one byte step: candidate flag of position i (entries ei, ei1, ei2) and its synchronising flag into byte K
+#define CXG_TEDDY_STEP(T, S, ei, ei1, ei2, K) do { uint32_t d_; CXG_SDWA_AND01(d_, ei, ei1); CXG_SDWA_AND2_PACK(T, d_, ei2, K); CXG_SDWA_MOV3_PACK(S, ei, K); } while (0)
+
 }  // namespace
 
 __global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
-  __shared__ uint32_t s_T[256];                                    // A | B<<8 | sync<<16 per byte value
+  __shared__ uint32_t s_T[256];                                    // A | B<<8 | C<<16 | sync<<24 per byte value
   __shared__ uint8_t s_boff[16];                                   // bucket b: its literals are order[s_boff[b] .. s_boff[b+1])
   __shared__ __attribute__((aligned(16))) uint8_t s_bytes[kWavesPerBlock][kWin + 16];
   __shared__ __attribute__((aligned(16))) uint64_t s_cw[kWavesPerBlock][2][64];   // candidate / synchronising bitmaps
@@ -86,7 +101,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(s_aux + ax->off_off);
   const uint8_t* t_bytes = s_aux + ax->bytes_off;
   const uint32_t nlits = ax->nlits;
-  s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x10000u : 0u);
+  s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x1000000u : 0u);
+  __syncthreads();
+  if (static_cast<uint32_t>(tid) < nlits) atomicOr(&s_T[t_bytes[t_off[tid] + 2]], 0x10000u << t_bucket[tid]);   // third-byte masks
   if (tid < 16) {                                                  // order[] is bucket-major: first index of every bucket
     uint32_t first = nlits;
     for (uint32_t k = nlits; k-- > 0;) if (t_bucket[t_order[k]] >= static_cast<uint32_t>(tid)) first = k;
@@ -129,37 +146,53 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
       const int32_t stage = rend < kWin ? rend : kWin;
 
       // ---- A: window to LDS, table lookups, candidate and synchronising bits
-      uint32_t e0[4];
+      const uint32_t two = 2u;
+      uint32_t e0[4], e1[4];                                        // entries of the first two bytes of every vector
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         *reinterpret_cast<u32x4*>(&s_bytes[wave][(lane + 64 * k) << 4]) = x[k];
-        e0[k] = s_T[x[k].x & 0xFFu];
+        uint32_t a0, a1;
+        CXG_SDWA_ADDR(a0, x[k].x, 0); CXG_SDWA_ADDR(a1, x[k].x, 1);
+        e0[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_T) + a0);
+        e1[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_T) + a1);
       }
       uint16_t* pc = reinterpret_cast<uint16_t*>(s_cw[wave][0]);
       uint16_t* ps = reinterpret_cast<uint16_t*>(s_cw[wave][1]);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        uint32_t en = dpp_from_upper(e0[k]);                       // first byte of the next vector: lane+1, same k
-        const uint32_t wrap = (k < 3) ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e0[k < 3 ? k + 1 : 3]), 0)) : 0u;
-        if (lane == 63) en = wrap;
-        const uint32_t w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-        uint32_t tq[4], sq[4];
-        uint32_t ecur = e0[k];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          uint32_t t = 0, s = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const int i = q * 4 + b;
-            const uint32_t enext = (i == 15) ? en : s_T[(w[(i + 1) >> 2] >> (((i + 1) & 3) * 8)) & 0xFFu];
-            t |= ((ecur & (enext >> 8)) & 0xFFu) << (8 * b);
-            s |= ((ecur >> 16) & 1u) << (8 * b);
-            ecur = enext;
-          }
-          tq[q] = t; sq[q] = s;
-        }
-        pc[lane + 64 * k] = static_cast<uint16_t>(gather16_nz(tq[0], tq[1], tq[2], tq[3]));
-        ps[lane + 64 * k] = static_cast<uint16_t>(gather16_01(sq[0], sq[1], sq[2], sq[3]));
+        // entries of the two bytes behind the vector: lane+1 of the same load, or lane 0 of the next load
+        uint32_t n0 = dpp_from_upper(e0[k]), n1 = dpp_from_upper(e1[k]);
+        const uint32_t w0 = (k < 3) ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e0[k < 3 ? k + 1 : 3]), 0)) : 0u;
+        const uint32_t w1 = (k < 3) ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e1[k < 3 ? k + 1 : 3]), 0)) : 0u;
+        if (lane == 63) { n0 = w0; n1 = w1; }
+        const uint8_t* Tb = reinterpret_cast<const uint8_t*>(s_T);
+        uint32_t ad, e[18];
+        e[0] = e0[k]; e[1] = e1[k]; e[16] = n0; e[17] = n1;
+        CXG_SDWA_ADDR(ad, x[k].x, 2); e[2] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].x, 3); e[3] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].y, 0); e[4] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].y, 1); e[5] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].y, 2); e[6] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].y, 3); e[7] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].z, 0); e[8] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].z, 1); e[9] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].z, 2); e[10] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].z, 3); e[11] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].w, 0); e[12] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].w, 1); e[13] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].w, 2); e[14] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        CXG_SDWA_ADDR(ad, x[k].w, 3); e[15] = *reinterpret_cast<const uint32_t*>(Tb + ad);
+        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        CXG_TEDDY_STEP(t0, s0, e[0], e[1], e[2], 0);   CXG_TEDDY_STEP(t0, s0, e[1], e[2], e[3], 1);
+        CXG_TEDDY_STEP(t0, s0, e[2], e[3], e[4], 2);   CXG_TEDDY_STEP(t0, s0, e[3], e[4], e[5], 3);
+        CXG_TEDDY_STEP(t1, s1, e[4], e[5], e[6], 0);   CXG_TEDDY_STEP(t1, s1, e[5], e[6], e[7], 1);
+        CXG_TEDDY_STEP(t1, s1, e[6], e[7], e[8], 2);   CXG_TEDDY_STEP(t1, s1, e[7], e[8], e[9], 3);
+        CXG_TEDDY_STEP(t2, s2, e[8], e[9], e[10], 0);  CXG_TEDDY_STEP(t2, s2, e[9], e[10], e[11], 1);
+        CXG_TEDDY_STEP(t2, s2, e[10], e[11], e[12], 2); CXG_TEDDY_STEP(t2, s2, e[11], e[12], e[13], 3);
+        CXG_TEDDY_STEP(t3, s3, e[12], e[13], e[14], 0); CXG_TEDDY_STEP(t3, s3, e[13], e[14], e[15], 1);
+        CXG_TEDDY_STEP(t3, s3, e[14], e[15], e[16], 2); CXG_TEDDY_STEP(t3, s3, e[15], e[16], e[17], 3);
+        pc[lane + 64 * k] = static_cast<uint16_t>(gather16_nz(t0, t1, t2, t3));
+        ps[lane + 64 * k] = static_cast<uint16_t>(gather16_01(s0, s1, s2, s3));
       }
       const uint32_t xprev_cur = xprev;
       issue_loads(j + 1);                                           // x[] is free from here on
@@ -175,7 +208,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
       int32_t zA = -1, zB = kTFar;
       if (tile_lo > 0) {
         const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
-        if (!(s_T[pb] & 0x10000u)) {                                // the segment at the tile's first byte began earlier
+        if (!(s_T[pb] & 0x1000000u)) {                                // the segment at the tile's first byte began earlier
           const unsigned long long bz = __ballot(Z != 0ull);
           if (bz) { const int L = __builtin_ctzll(bz); zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L))); }
           else zA = kTFar;
@@ -210,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
           if (r0 + static_cast<uint32_t>(lane) < ncand) {
             c = s_cpos[wave][r0 + lane];
             const uint8_t* wb = s_bytes[wave];
-            uint32_t mask = (s_T[wb[c]] & 0xFFu) & ((s_T[wb[c + 1]] >> 8) & 0xFFu);
+            uint32_t mask = (s_T[wb[c]] & 0xFFu) & ((s_T[wb[c + 1]] >> 8) & 0xFFu) & ((s_T[wb[c + 2]] >> 16) & 0xFFu);
             while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
               const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
               mask &= mask - 1;
