@@ -103,10 +103,31 @@ def test_wave_tile_boundaries(need_gpu, oracle):
     _check(oracle, r"error", b"error " * 3000)
 
 
+def test_teddy_wave_paths(need_gpu, oracle):
+    """Wave Teddy kernel: matches at lane/tile/group edges, overlapping literal occurrences (FindAll keeps the
+    first), and the two fallbacks (no synchronising byte in a halo, more rows than the wave's buffer)."""
+    group = 3840 * 32
+    pat = "spider|error|crawler|denied"
+    base = np.full(group + 9000, ord(" "), dtype=np.uint8)
+    for lit in (b"spider", b"error", b"crawler"):
+        ip = np.frombuffer(lit, dtype=np.uint8)
+        for off in list(range(3840 - 8, 3840 + 2)) + list(range(4096 - 8, 4096 + 2)) + list(range(58, 66)) + list(range(group - 8, group + 2)):
+            hay = base.copy()
+            hay[off:off + len(ip)] = ip
+            _check(oracle, pat, hay)
+    _check(oracle, pat, b"spiderror crawlerror deniederror " * 900)        # overlaps: 'error' inside 'spider'+'ror'
+    _check(oracle, pat, b"errorerrorerror" * 2000)                             # no synchronising byte at all
+    _check(oracle, pat, b"error " * 9000)                                      # > 384 rows per wave and group
+    _check(oracle, pat, b"erro spide crawle denie " * 3000)                    # fingerprints hit, no literal matches
+    tail = np.full(4096, ord(" "), dtype=np.uint8)
+    tail[-5:] = np.frombuffer(b"error", dtype=np.uint8)
+    _check(oracle, pat, tail)                                                  # match ends exactly at the end of input
+
+
 def test_chain_kernel_is_the_one_that_runs(need_gpu):
     """No silent fallback on the benchmark corpora: one launch (the bit-parallel chain kernel), no rerun."""
     import torch
-    for cfg, pat in ((2, r"\d+\.\d+\.\d+\.\d+"), (1, r"error")):
+    for cfg, pat in ((2, r"\d+\.\d+\.\d+\.\d+"), (1, r"error"), (3, LITS16)):
         nbytes = 4096 * 4096
         buf = cx.DeviceBuffer(nbytes)
         buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)

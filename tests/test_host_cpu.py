@@ -220,6 +220,20 @@ def test_bitparallel_chain_emulated(oracle):
             got = emu.find_all_chain6(p.blob(), hay, 3840, 256)
             assert not isinstance(got, int) and got.tolist() == o.find_all_index(hay).tolist(), (pat, total)
     assert n_ok >= 5, n_ok
+    # FindAllSubmatch programs: the span image carries the chain too, classes may be unions of ranges (\\w)
+    for pat, cfg in ((r"(\w+)@(\w+)\.(\w+)", 5), (r"(\w+)=(\d+)", 5)):
+        p = cx.compile(pat)
+        span_blob = p.submatch_blobs()[0]
+        assert (struct.unpack_from("<I", span_blob, 8)[0] & 48) == 48, pat        # ordered chain with set classes
+        o = oracle.Regex(pat)
+        synth = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 3, 48).tobytes()
+        for hay in (synth, corpus, b"a@b.c", b"foo@bar.com x@y.z k=1"):
+            for geom in ((3840, 256), (192, 64)):
+                got = emu.find_all_chain6(span_blob, hay, *geom)
+                if isinstance(got, int):
+                    assert got == -17, (pat, geom, got)
+                    continue
+                assert got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), geom)
     # unordered chains (a run whose class meets the class of the step before) must not get the flag
     for pat in (r"a[ab]+", r"\d\d+x"):
         p = cx.compile(pat)
