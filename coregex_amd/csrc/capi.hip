@@ -28,6 +28,7 @@ hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, hipStream_t stream);
+hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
 namespace {
@@ -268,17 +269,22 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   } else if (h->kind == cxgdev::kKindTeddy) {
     static const bool oldTeddy = getenv("CXG_TEDDY_KERNEL") && atoi(getenv("CXG_TEDDY_KERNEL")) == 1;
     gen = oldTeddy ? 0 : 7;                                         // 7 = wave kernel (scan_teddy_wave.hip), 0 = scan_teddy.hip
+  } else if (h->kind == cxgdev::kKindCharClass) {
+    static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
+    gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
 relaunch:
   a.ngroups = a.ntiles;
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
+  if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 5 || gen == 6 || gen == 7) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
   HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
-  if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, stream);
+  if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
+  else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, stream);
   else if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,

@@ -98,16 +98,6 @@ __device__ __forceinline__ void classify_tile(const u32x4 (&x)[4], uint32_t lo, 
 #endif
   }
 }
-// A class that is a union of up to four ASCII ranges (\w = [0-9A-Z_a-z]): range tests share x|0x80 and x&0x7F.
-struct SetRanges { uint32_t n; uint32_t lo4[kChainMaxRanges], hi4[kChainMaxRanges]; };   // splat bounds, hi4 = (0x7F - hi) splat
-__device__ __forceinline__ uint32_t notset4(uint32_t x, const SetRanges& r) {
-  const uint32_t xh = x | 0x80808080u, xl = x & 0x7F7F7F7Fu;
-  uint32_t in = (xh - r.lo4[0]) & ~(xl + r.hi4[0]);
-  if (r.n > 1) in |= (xh - r.lo4[1]) & ~(xl + r.hi4[1]);
-  if (r.n > 2) in |= (xh - r.lo4[2]) & ~(xl + r.hi4[2]);
-  if (r.n > 3) in |= (xh - r.lo4[3]) & ~(xl + r.hi4[3]);
-  return ~(in & ~x) & 0x80808080u;
-}
 __device__ __forceinline__ void classify_tile_set(const u32x4 (&x)[4], const SetRanges& r, int lane, uint16_t* pieces) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {

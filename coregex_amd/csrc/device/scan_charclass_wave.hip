@@ -1,0 +1,219 @@
+// scan_charclass_wave.hip — FindAll for UseCharClassSearcher (`[class]+`) with the wave as the unit of work.
+// GPU form of nfa.CharClassSearcher.FindAllIndices (nfa/charclass_searcher.go:158-211): maximal runs of member
+// bytes, in order, a trailing run closed at the end of input.
+//
+// Output dominates this path (one 16-byte span per ~5.5 bytes of log text: 3 bytes written per byte read), so a
+// group's rows are never buffered as a whole: bitmaps wait in LDS for the group's base, rows are staged one
+// wave-tile at a time.
+//   pass 1  per wave-tile (60 x 64 B = 3840 B + 256 B halo = 64 bitmap words, one per lane): window by four
+//           buffer_load_dwordx4 per lane, membership by SWAR range tests (the class is a union of <= 4 ASCII
+//           ranges) + v_dot4 gather, 16-bit pieces through LDS -> word M per lane;
+//             starts S = M & ~(M << 1 | carry),  ends E = ~M & (M << 1 | carry)   (exclusive ends)
+//           the tile owns the runs that START in its first 3840 bytes; S and E words stay in LDS, counts are
+//           summed per tile;
+//   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, one look-back -> global base of every tile;
+//   pass 2  per wave-tile every lane drops the starts and ends it holds into the wave's LDS staging at their
+//           ranks (both compactions keep the order, so start k and end k meet in row k without ever meeting in a
+//           register), then the wave writes the rows as fully coalesced 16-byte stores (1 KiB per instruction).
+//           The first end of a window that begins inside a run belongs to the previous tile and is skipped.
+// Fallback flag (err bit 8: the host reruns the scan with scan_charclass.hip): a run that starts in the tile and
+// does not end inside the window (longer than the 256-byte halo) unless it ends with the input; more than 1024
+// runs in one wave-tile.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_common.hpp"
+#include "scan_dfa.h"
+#include "walk.hpp"
+#include "wave_common.hpp"
+
+namespace cxgdev {
+
+namespace {
+constexpr int kWin = kWaveTile + kWaveHalo;       // 4096
+constexpr int kCcStage = 1024;                    // rows staged per wave-tile (typical log text: ~700)
+}
+
+__global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_m[kWavesPerBlock][64];                    // membership pieces -> words
+  __shared__ __attribute__((aligned(16))) uint64_t s_S[kWavesPerBlock][kCcTilesPerWave][64];   // owned starts
+  __shared__ __attribute__((aligned(16))) uint64_t s_E[kWavesPerBlock][kCcTilesPerWave][64];   // their ends
+  __shared__ uint16_t s_rs[kWavesPerBlock][kCcStage];              // pass 2 staging: start / end inside the window
+  __shared__ uint16_t s_re[kWavesPerBlock][kCcStage];
+  __shared__ uint32_t s_cnt[kWavesPerBlock][kCcTilesPerWave];
+  __shared__ uint32_t s_qbase[kWavesPerBlock * kCcTilesPerWave + 1];
+  __shared__ uint64_t s_group;
+  __shared__ uint64_t s_base;
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
+  const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
+  SetRanges rg;
+  rg.n = ax->nr;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
+  __syncthreads();
+  const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  if (group >= a.ngroups) return;
+  uint32_t fallback = 0;
+
+  u32x4 x[4];
+  uint32_t xprev = 0;
+  auto issue_loads = [&](int jj) {
+    const uint64_t wtn = group * (kWavesPerBlock * kCcTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nrec = 0;
+    if (jj < kCcTilesPerWave && lo < a.len) {
+      const uint64_t rem = a.len - lo;
+      nrec = rem >= static_cast<uint64_t>(kWin) ? kWin : static_cast<int>((rem + 3) & ~3ull);
+    }
+    const int pre = (nrec && lo) ? 16 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, pre ? 12 : nrec + pre, 0);
+  };
+  issue_loads(0);
+
+  // ---- pass 1: bitmaps and counts
+  for (int j = 0; j < kCcTilesPerWave; j++) {
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const uint64_t wt = group * (kWavesPerBlock * kCcTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
+    const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
+    uint64_t S = 0, E = 0;
+    uint32_t n = 0;
+    if (tile_lo < a.len) {
+      const uint64_t remaining = a.len - tile_lo;
+      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      const int32_t stage = rend < kWin ? rend : kWin;
+      uint16_t* pieces = reinterpret_cast<uint16_t*>(s_m[wave]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t lo = __builtin_amdgcn_udot4(notset4(x[k].y, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].x, rg), 0x08040201u, 0u, false), false);
+        const uint32_t hi = __builtin_amdgcn_udot4(notset4(x[k].w, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].z, rg), 0x08040201u, 0u, false), false);
+        pieces[lane + 64 * k] = static_cast<uint16_t>(((lo >> 7) | (hi << 1)) ^ 0xFFFFu);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const uint32_t xprev_cur = xprev;
+      issue_loads(j + 1);
+      wave_lds_sync();
+      uint64_t M = s_m[wave][lane];
+      if (stage != kWin) {                                          // short last window: nothing past the data is a member
+        const int32_t nv = stage - 64 * lane;
+        M &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+      }
+      // the byte in front of the tile
+      uint32_t prev_member = 0;
+      if (tile_lo > 0) {
+        const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (static_cast<uint32_t>(q) < ax->nr && pb >= ax->lo[q] && pb <= ax->hi[q]) prev_member = 1;
+      }
+      uint64_t carry = from_lower64(M) >> 63;                      // DPP outside lane-dependent branches
+      if (lane == 0) carry = prev_member;
+      const uint64_t P = (M << 1) | carry;                          // "the previous byte is a member"
+      S = M & ~P;
+      E = ~M & P;                                                   // exclusive end: first non-member after a run
+      S &= word_range(lane, 0, kWaveTile - 1);                      // runs that start in the halo belong to the next tile
+      // ends: skip the one that closes a run begun in front of the tile, keep as many as there are owned starts
+      const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
+      const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
+      const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      n = tot & 0xFFFFu;
+      const uint32_t skip = prev_member;                            // (prev member: the window starts inside or right behind a run)
+      const uint32_t have = (tot >> 16) >= skip ? (tot >> 16) - skip : 0u;
+      // a run reaching the last byte of a full window ends at 4096: fine at the end of input, else unknown
+      const bool at_eoi_edge = (stage == rend) && (stage == kWin);
+      if (have < n && !(at_eoi_edge && have + 1 == n)) fallback |= 1;
+      if (n > static_cast<uint32_t>(kCcStage)) fallback |= 8;
+      // keep the ends with rank in [skip, skip + n): mask off the others
+      {
+        const uint32_t ie = (incl >> 16) - ne;                      // ends in lower lanes
+        uint64_t keep = 0, eb = E;
+        uint32_t r = ie;
+        while (eb) {
+          const int bit = __builtin_ctzll(eb);
+          eb &= eb - 1;
+          if (r >= skip && r < skip + n) keep |= 1ull << bit;
+          r++;
+        }
+        E = keep;
+      }
+      // the rank bookkeeping of pass 2 needs the exclusive prefixes again: keep them packed in the words' place
+      s_S[wave][j][lane] = S;
+      s_E[wave][j][lane] = E;
+      if (lane == 0 && at_eoi_edge && have + 1 == n) s_cnt[wave][j] = n | 0x80000000u;   // last end = 4096 (written by pass 2)
+      else if (lane == 0) s_cnt[wave][j] = n;
+    } else {
+      s_S[wave][j][lane] = 0; s_E[wave][j][lane] = 0;
+      if (lane == 0) s_cnt[wave][j] = 0;
+    }
+  }
+  if (fallback != 0 && lane0 == 0) atomicOr(a.err, 8u | (fallback << 8));
+  __syncthreads();
+
+  // ---- group: exclusive prefix over the wave-tiles q = j*4 + wave, look-back
+  if (tid < 64) {
+    const int q = tid;
+    const uint32_t v = (q < kWavesPerBlock * kCcTilesPerWave) ? (s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] & 0x7FFFFFFFu) : 0u;
+    const uint32_t incl = wave_inclusive_sum(v);
+    if (q < kWavesPerBlock * kCcTilesPerWave) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * kCcTilesPerWave - 1) s_qbase[kWavesPerBlock * kCcTilesPerWave] = incl;
+  }
+  __syncthreads();
+  const uint32_t total = s_qbase[kWavesPerBlock * kCcTilesPerWave];
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  if (a.out == nullptr) return;
+
+  // ---- pass 2: starts and ends straight to their rows
+  const uint64_t base = s_base;
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave);
+  for (int j = 0; j < kCcTilesPerWave; j++) {
+    const uint32_t cn = s_cnt[wave][j];
+    const uint32_t n = cn & 0x7FFFFFFFu;
+    if (n == 0) continue;
+    const uint64_t S = s_S[wave][j][lane0], E = s_E[wave][j][lane0];
+    const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
+    const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
+    const uint64_t row0 = base + s_qbase[j * kWavesPerBlock + wave];
+    uint32_t r = (incl & 0xFFFFu) - ns;
+    uint64_t sb = S;
+    while (sb) {
+      const int bit = __builtin_ctzll(sb);
+      sb &= sb - 1;
+      if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
+      r++;
+    }
+    r = (incl >> 16) - ne;
+    uint64_t eb = E;
+    while (eb) {
+      const int bit = __builtin_ctzll(eb);
+      eb &= eb - 1;
+      if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
+      r++;
+    }
+    if ((cn & 0x80000000u) && lane0 == 0 && n - 1 < static_cast<uint32_t>(kCcStage)) s_re[wave][n - 1] = static_cast<uint16_t>(kWin);   // run ending with the input
+    wave_lds_sync();
+    const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+    const uint32_t nst = n < static_cast<uint32_t>(kCcStage) ? n : static_cast<uint32_t>(kCcStage);
+    for (uint32_t i = lane0; i < nst; i += 64) {
+      if (row0 + i < a.cap) {
+        longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i];
+        *reinterpret_cast<longlong2*>(a.out + (row0 + i) * 2) = v;
+      }
+    }
+    wave_lds_sync();                                                // staging is reused by the next tile
+  }
+}
+
+hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_charclass_wave, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace cxgdev

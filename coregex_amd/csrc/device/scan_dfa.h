@@ -17,6 +17,8 @@ constexpr int kWaveHalo = 256;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerWave = 8;
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
+constexpr int kCcTilesPerWave = 4;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup
+constexpr uint64_t kCcGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave;
 constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
 
 struct ScanArgs {

@@ -9,6 +9,17 @@ namespace cxgdev {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// A class that is a union of up to four ASCII ranges (\w = [0-9A-Z_a-z]): range tests share x|0x80 and x&0x7F.
+struct SetRanges { uint32_t n; uint32_t lo4[4], hi4[4]; };   // splat bounds, hi4 = (0x7F - hi) splat
+__device__ __forceinline__ uint32_t notset4(uint32_t x, const SetRanges& r) {
+  const uint32_t xh = x | 0x80808080u, xl = x & 0x7F7F7F7Fu;
+  uint32_t in = (xh - r.lo4[0]) & ~(xl + r.hi4[0]);
+  if (r.n > 1) in |= (xh - r.lo4[1]) & ~(xl + r.hi4[1]);
+  if (r.n > 2) in |= (xh - r.lo4[2]) & ~(xl + r.hi4[2]);
+  if (r.n > 3) in |= (xh - r.lo4[3]) & ~(xl + r.hi4[3]);
+  return ~(in & ~x) & 0x80808080u;
+}
+
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
   return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));

@@ -579,6 +579,25 @@ void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], ui
   std::vector<uint8_t> blob(sizeof h, 0);
   h.info_off = static_cast<uint32_t>(blob.size());
   for (int b = 0; b < 256; b++) blob.push_back(membership[b] ? cxgdev::kInfoMember : cxgdev::kInfoSync);
+  {  // membership as ranges: the wave kernel (scan_charclass_wave.hip) classifies with SWAR range tests
+    cxgdev::CharClassAux ax;
+    std::memset(&ax, 0, sizeof ax);
+    bool ok = true;
+    for (int b = 0; b < 256 && ok; b++) {
+      if (!membership[b] || (b > 0 && membership[b - 1])) continue;
+      int e = b;
+      while (e + 1 < 256 && membership[e + 1]) e++;
+      if (e > 127 || ax.nr >= 4) { ok = false; break; }
+      ax.lo[ax.nr] = static_cast<uint8_t>(b); ax.hi[ax.nr] = static_cast<uint8_t>(e); ax.nr++;
+    }
+    if (ok && ax.nr >= 1) {
+      h.flags |= cxgdev::kFlagCcRanges;
+      h.aux_off = static_cast<uint32_t>(blob.size());
+      const uint8_t* ab = reinterpret_cast<const uint8_t*>(&ax);
+      blob.insert(blob.end(), ab, ab + sizeof ax);
+      h.aux_len = sizeof ax;
+    }
+  }
   h.total_bytes = static_cast<uint32_t>(blob.size());
   std::memcpy(blob.data(), &h, sizeof h);
   p->blob.swap(blob);

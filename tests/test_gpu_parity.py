@@ -124,10 +124,28 @@ def test_teddy_wave_paths(need_gpu, oracle):
     _check(oracle, pat, tail)                                                  # match ends exactly at the end of input
 
 
+def test_charclass_wave_paths(need_gpu, oracle):
+    """Wave char-class kernel: runs across lane words, the tile edge, the halo edge and the group edge; runs that
+    end with the input; the fallbacks (a run longer than the halo, > 1024 runs in a wave-tile)."""
+    group = 3840 * 16
+    for n in (1, 63, 64, 65, 3839, 3840, 3841, 4095, 4096, 4097, group - 1, group, group + 1, group + 4097):
+        _check(oracle, r"[\w]+", np.frombuffer((b"ab cde_f 12 " * (n // 12 + 2))[:n], dtype=np.uint8))
+        _check(oracle, r"[\w]+", np.frombuffer((b"x" * n), dtype=np.uint8))                      # one run, ends with the input
+    base = np.full(group + 9000, ord(" "), dtype=np.uint8)
+    for off in (3830, 3839, 3840, 4090, 4095, 4096, group - 3, group):
+        for ln in (1, 5, 100, 255, 256, 257, 300):
+            hay = base.copy()
+            hay[off:off + ln] = ord("w")
+            _check(oracle, r"[\w]+", hay)
+    _check(oracle, r"[\w]+", b"a " * 30000)                                                        # 1920 runs per wave-tile
+    _check(oracle, r"[a-c]+", b"abcabc--cab-" * 5000)
+    _check(oracle, r"[0-9a-fA-F]+", b"deadBEEF 0x1f 77zz " * 4000)
+
+
 def test_chain_kernel_is_the_one_that_runs(need_gpu):
     """No silent fallback on the benchmark corpora: one launch (the bit-parallel chain kernel), no rerun."""
     import torch
-    for cfg, pat in ((2, r"\d+\.\d+\.\d+\.\d+"), (1, r"error"), (3, LITS16)):
+    for cfg, pat in ((2, r"\d+\.\d+\.\d+\.\d+"), (1, r"error"), (3, LITS16), (4, r"[\w]+")):
         nbytes = 4096 * 4096
         buf = cx.DeviceBuffer(nbytes)
         buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
