@@ -386,7 +386,9 @@ __global__ void k_fill_synth(uint8_t* dst, uint64_t npages, uint32_t config, uin
   cxgsynth::page(config, seed, first_page + i, dst + i * cxgsynth::kPage);
 }
 
-int hostScan(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
+// Host-memory haystack (what the cgo shim passes): H2D copy into the call's scratch buffer, the device scan,
+// D2H copy of the rows.  No CPU compute path exists in this library.
+int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
              uint64_t* n_out, int width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
   if (width > 2 ? !p->subSupported : !p->supported)
@@ -571,15 +573,15 @@ int cxg_program_nfa(const cxg_program* p, cxg_nfa* out) {
 
 int cxg_find_all(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* spans, uint64_t cap,
                  uint64_t* n_out) {
-  return hostScan(p, hay, len, limit, spans, cap, n_out, 2);
+  return scanHostBuffer(p, hay, len, limit, spans, cap, n_out, 2);
 }
 int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, uint64_t* n_out) {
-  return hostScan(p, hay, len, limit, nullptr, 0, n_out, 2);
+  return scanHostBuffer(p, hay, len, limit, nullptr, 0, n_out, 2);
 }
 int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* slots,
                           uint64_t cap, uint64_t* n_out) {
-  if (p && p->ngroups == 1) return hostScan(p, hay, len, limit, slots, cap, n_out, 2);
-  return hostScan(p, hay, len, limit, slots, cap, n_out, p ? 2 * p->ngroups : 2);
+  if (p && p->ngroups == 1) return scanHostBuffer(p, hay, len, limit, slots, cap, n_out, 2);
+  return scanHostBuffer(p, hay, len, limit, slots, cap, n_out, p ? 2 * p->ngroups : 2);
 }
 
 int cxg_buffer_alloc(uint64_t len, cxg_buffer** out) {

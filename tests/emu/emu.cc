@@ -323,3 +323,112 @@ extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, 
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Sequential twin of scan_teddy_wave.hip: three-byte fingerprint candidates, ownership (zA, zB] from the
+// synchronising bytes, exact verification (buckets low to high, ids ascending), FindAll order inside the tile.
+// Returns -(16 + reason) when a tile would raise the fallback flag.
+extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                           int tile_bytes, int halo_bytes) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || h->kind != kKindTeddy) return -1;
+  const uint8_t* info = blob + h->info_off;
+  const uint8_t* aux = blob + h->aux_off;
+  const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(aux);
+  TeddyView tv{reinterpret_cast<const uint16_t*>(aux + ax->ab_off), aux + ax->order_off, aux + ax->lens_off,
+               aux + ax->bucket_off, reinterpret_cast<const uint16_t*>(aux + ax->off_off), aux + ax->bytes_off, ax->nlits};
+  uint32_t T[256];
+  for (int b = 0; b < 256; b++) T[b] = tv.ab[b] | ((info[b] & kInfoSync) ? 0x1000000u : 0u);
+  for (uint32_t id = 0; id < tv.nlits; id++) T[tv.bytes[tv.off[id] + 2]] |= 0x10000u << tv.bucket[id];
+  const int64_t N = tile_bytes + halo_bytes;
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
+    const int64_t rend = static_cast<int64_t>(len - tile_lo);
+    const int64_t stage = rend < N ? rend : N;
+    const uint8_t* g = hay + tile_lo;
+    auto is_sync = [&](int64_t p) { return (T[g[p]] & 0x1000000u) != 0; };
+    int64_t zA = -1, zB = 1 << 20;
+    uint32_t reason = 0;
+    if (tile_lo > 0 && !is_sync(-1)) {
+      zA = 1 << 20;
+      for (int64_t p = 0; p < stage; p++) if (is_sync(p)) { zA = p; break; }
+    }
+    {
+      bool found = false;
+      for (int64_t p = tile_bytes - 1; p < stage; p++) if (is_sync(p)) { zB = p; found = true; break; }
+      if (!found && stage != rend) { zB = -2; reason |= 1; }
+    }
+    std::vector<int64_t> cand;
+    for (int64_t p = 0; p + 2 < stage || (p + 2 < rend && p < stage); p++) {
+      if (p >= stage) break;
+      const uint32_t b1 = (p + 1 < rend) ? g[p + 1] : 0u, b2 = (p + 2 < rend) ? g[p + 2] : 0u;
+      // the kernel sees zeros past the window/input: entries of byte 0 (no literal contains it in these tests)
+      const uint32_t e1 = (p + 1 < N) ? T[b1] : 0u, e2 = (p + 2 < N) ? T[b2] : 0u;
+      if ((T[g[p]] & 0xFFu) & ((e1 >> 8) & 0xFFu) & ((e2 >> 16) & 0xFFu)) if (p > zA && p <= zB) cand.push_back(p);
+    }
+    if (cand.size() > 256) reason |= 8;
+    if (reason) return -(16 + static_cast<int64_t>(reason));
+    int64_t cur_end = -1;
+    for (int64_t c : cand) {
+      uint32_t mask = (T[g[c]] & 0xFFu) & ((T[g[c + 1]] >> 8) & 0xFFu) & ((T[g[c + 2]] >> 16) & 0xFFu);
+      int64_t mlen = 0;
+      while (mask && !mlen) {
+        const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
+        mask &= mask - 1;
+        for (uint32_t k = 0; k < tv.nlits && !mlen; k++) {
+          const uint32_t id = tv.order[k];
+          if (tv.bucket[id] != bk) continue;
+          const int64_t ln = tv.lens[id];
+          if (c + ln > rend) continue;
+          if (std::memcmp(g + c, tv.bytes + tv.off[id], static_cast<size_t>(ln)) == 0) mlen = ln;
+        }
+      }
+      if (mlen && c >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + c); res.push_back(static_cast<int64_t>(tile_lo) + c + mlen); cur_end = c + mlen; }
+    }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}
+
+// Sequential twin of scan_charclass_wave.hip: starts/ends of member runs per window, the tile owns the runs that
+// start in its first tile_bytes bytes, the end that closes a run begun in front of the tile is skipped.
+extern "C" int64_t emu_find_all_charclass_wave(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                               int tile_bytes, int halo_bytes) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || h->kind != kKindCharClass) return -1;
+  if (!(h->flags & kFlagCcRanges)) return -4;
+  const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(blob + h->aux_off);
+  auto member = [&](uint32_t b) { for (uint32_t q = 0; q < ax->nr; q++) if (b >= ax->lo[q] && b <= ax->hi[q]) return true; return false; };
+  const int64_t N = tile_bytes + halo_bytes;
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
+    const int64_t rend = static_cast<int64_t>(len - tile_lo);
+    const int64_t stage = rend < N ? rend : N;
+    const uint8_t* g = hay + tile_lo;
+    const bool prev_member = tile_lo > 0 && member(g[-1]);
+    std::vector<int64_t> S, E;                      // E: exclusive ends seen inside the window [0, N)
+    for (int64_t p = 0; p < N; p++) {
+      const bool m = p < stage && member(g[p]);
+      const bool pm = p == 0 ? prev_member : (p - 1 < stage && member(g[p - 1]));
+      if (m && !pm && p < tile_bytes) S.push_back(p);
+      if (!m && pm) E.push_back(p);
+    }
+    const size_t skip = prev_member ? 1 : 0;
+    const size_t have = E.size() >= skip ? E.size() - skip : 0;
+    const bool at_eoi_edge = stage == rend && stage == N;
+    if (have < S.size() && !(at_eoi_edge && have + 1 == S.size())) return -(16 + 1);
+    if (S.size() > 1024) return -(16 + 8);
+    for (size_t i = 0; i < S.size(); i++) {
+      const int64_t e = (skip + i < E.size()) ? E[skip + i] : N;
+      res.push_back(static_cast<int64_t>(tile_lo) + S[i]); res.push_back(static_cast<int64_t>(tile_lo) + e);
+    }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}

@@ -241,6 +241,46 @@ def test_bitparallel_chain_emulated(oracle):
             assert not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
 
 
+def test_teddy_and_charclass_wave_twins(oracle):
+    """Sequential twins of scan_teddy_wave.hip (three-byte fingerprint + exact verification + (zA, zB] ownership) and
+    scan_charclass_wave.hip (start/end bitmaps, skipped leading end) vs the oracle, several window geometries."""
+    rng = np.random.default_rng(31)
+    corpus = generate_test_input()
+    lits = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+    for pat, alpha, cfg in ((lits, b"erowanigftlcpmusdbyxv  \n.", 3), ("spider|error|crawler|denied", b"spidercawln  \n", 3)):
+        p = cx.compile(pat)
+        assert p.strategy == "UseTeddy" and p.supported
+        o = oracle.Regex(pat)
+        alphabet = np.frombuffer(alpha, dtype=np.uint8)
+        synth = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 5, 32).tobytes()
+        hays = [corpus, synth, b"", b"error", b"xerror", b"spiderror crawlerror", b"err", b"erro"]
+        hays += [alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 20000)))].tobytes() for _ in range(60)]
+        for hay in hays:
+            exp = o.find_all_index(hay).tolist()
+            for geom in ((3840, 256), (192, 64), (128, 128)):
+                got = emu.find_all_teddy_wave(p.blob(), hay, *geom)
+                if isinstance(got, int):
+                    assert got in (-17, -24, -25), (pat, geom, got)
+                    continue
+                assert got.tolist() == exp, (pat, len(hay), geom)
+    for pat, alpha in ((r"[\w]+", b"ab_9 Z-\n"), (r"[a-c]+", b"abcd \n"), (r"[0-9a-fA-F]+", b"09afAFgz \n")):
+        p = cx.compile(pat)
+        assert p.strategy == "UseCharClassSearcher" and p.supported
+        o = oracle.Regex(pat)
+        alphabet = np.frombuffer(alpha, dtype=np.uint8)
+        synth = cx.synth_pages(4, 0xC0FFEE04, 9, 16).tobytes()
+        hays = [corpus, synth, b"", b"a", b" a", b"a ", b"w" * 4096, b"w" * 3840 + b" ", b" " + b"w" * 200 + b" "]
+        hays += [alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 12000)))].tobytes() for _ in range(60)]
+        for hay in hays:
+            exp = o.find_all_index(hay).tolist()
+            for geom in ((3840, 256), (192, 64), (64, 64)):
+                got = emu.find_all_charclass_wave(p.blob(), hay, *geom)
+                if isinstance(got, int):
+                    assert got in (-17, -24), (pat, geom, got)      # a run longer than the halo / too many runs
+                    continue
+                assert got.tolist() == exp, (pat, len(hay), geom)
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
