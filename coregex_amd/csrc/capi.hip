@@ -268,7 +268,8 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
   } else if (h->kind == cxgdev::kKindTeddy) {
     static const bool oldTeddy = getenv("CXG_TEDDY_KERNEL") && atoi(getenv("CXG_TEDDY_KERNEL")) == 1;
-    gen = oldTeddy ? 0 : 7;                                         // 7 = wave kernel (scan_teddy_wave.hip), 0 = scan_teddy.hip
+    gen = (oldTeddy || h->aux_len > 2048u) ? 0 : 7;                 // the wave kernel stages at most 2 KiB of literal tables
+    // 7 = wave kernel (scan_teddy_wave.hip), 0 = scan_teddy.hip
   } else if (h->kind == cxgdev::kKindCharClass) {
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
     gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip

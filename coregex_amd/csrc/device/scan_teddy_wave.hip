@@ -23,7 +23,7 @@
 //      (prefix max of the ends; a rare serial path when a round contains such a candidate).
 // Group structure, tickets, look-back and row write-out: block_common.hpp / scan_chain_wave.hip.
 // Fallback flag (err bit 8: the host reruns the scan with scan_teddy.hip): no synchronising byte in a halo,
-// > 256 owned candidates in a wave-tile, row buffer overflow.
+// > 192 owned candidates in a wave-tile, row buffer overflow.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,9 +36,9 @@ namespace cxgdev {
 
 namespace {
 
-constexpr int kTRows = 384;                       // rows buffered per wave per group
-constexpr int kTCands = 256;                      // owned candidates listed per wave-tile
-constexpr int kTAuxMax = 4096;
+constexpr int kTRows = 320;                       // rows buffered per wave per group
+constexpr int kTCands = 192;                      // owned candidates listed per wave-tile
+constexpr int kTAuxMax = 2048;
 constexpr int32_t kTFar = 1 << 20;
 constexpr int kWin = kWaveTile + kWaveHalo;       // 4096
 
@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
 
 }  // namespace
 
-__global__ __launch_bounds__(kThreads, 4) void k_scan_teddy_wave(ScanArgs a) {
+__global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
   __shared__ uint32_t s_T[256];                                    // A | B<<8 | C<<16 | sync<<24 per byte value
   __shared__ uint8_t s_boff[16];                                   // bucket b: its literals are order[s_boff[b] .. s_boff[b+1])

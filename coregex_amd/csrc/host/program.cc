@@ -665,6 +665,7 @@ void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint
   for (auto& l : lits) aux.insert(aux.end(), l.begin(), l.end());
   ax.bytes_len = static_cast<uint32_t>(aux.size()) - ax.bytes_off;
   align(16);
+  if (aux.size() > 4096) { p->whyNot = "literal table exceeds the kernels' LDS budget (4 KiB)"; return; }
   std::memcpy(aux.data(), &ax, sizeof ax);
   h.aux_len = static_cast<uint32_t>(aux.size());
   blob.insert(blob.end(), aux.begin(), aux.end());
