@@ -143,14 +143,18 @@ __global__ void k_captures(const uint8_t* hay, int64_t hay_base, int64_t* rows, 
   if (!cxgdev::capture_walk(cv, hay - hay_base, rows + i * width, width)) atomicOr(err, 4u);
 }
 
-// Capture pass, fast form: the one-pass table (next | maskid << 8 per entry and byte) staged in LDS, the slots of
-// a row kept in registers as offsets from the match start and written once (one 64-byte row per thread for
-// three groups).  MAXS = slots held in registers; wider rows and bigger tables use k_captures.
+// Capture pass, fast form: the one-pass table (next | maskid << 8 per entry and byte) staged in LDS (dynamic size),
+// the first 64+ bytes of every match fetched with five 16-byte loads issued together (one memory latency per
+// match instead of one per 4 bytes) and parked in the thread's LDS slot, the slots of a row kept in registers as
+// offsets from the match start and written once (one 64-byte row per thread for three groups).
+// MAXS = slots held in registers; wider rows and bigger tables use k_captures.
 constexpr uint32_t kCapLdsEntries = 48;
+constexpr int kCapSlotDwords = 21;                                  // 80 bytes + 1 dword of bank skew per thread
 template <int MAXS>
-__global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
-                                                      const uint8_t* capblob, uint32_t* err) {
-  __shared__ uint16_t s_tab[kCapLdsEntries * 256];
+__global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_t hay_base, uint64_t hay_len, int64_t* rows, uint64_t nrows,
+                                                      uint32_t width, const uint8_t* capblob, uint32_t* err) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_tab[];  // [n_entries][256]
+  __shared__ uint32_t s_hay[256 * kCapSlotDwords];
   __shared__ uint32_t s_masks[256];
   __shared__ uint8_t s_fin[kCapLdsEntries];
   const cxgdev::CapHeader* ch = reinterpret_cast<const cxgdev::CapHeader*>(capblob);
@@ -162,20 +166,28 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
   for (uint32_t i = threadIdx.x; i < ne; i += blockDim.x) s_fin[i] = capblob[ch->fin_off + i];
   __syncthreads();
   const uint8_t* h0 = hay - hay_base;                              // rows hold absolute offsets (hay_base added)
+  const uint64_t lim16 = (reinterpret_cast<uint64_t>(hay) + hay_len + 15u) & ~15ull;   // 16-byte loads stay below this
+  uint32_t* slot = s_hay + threadIdx.x * kCapSlotDwords;
+  const uint8_t* slotb = reinterpret_cast<const uint8_t*>(slot);
   bool bad = false;
   for (uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; r < nrows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     int64_t* row = rows + r * width;
     const longlong2 se = *reinterpret_cast<const longlong2*>(row);
     const int64_t s = se.x, e = se.y;
+    const uint64_t a0 = (reinterpret_cast<uint64_t>(h0) + static_cast<uint64_t>(s)) & ~15ull;
+    const uint32_t skew = static_cast<uint32_t>((reinterpret_cast<uint64_t>(h0) + static_cast<uint64_t>(s)) & 15u);
+    uint4 q[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) q[k] = (a0 + 16u * k + 16u <= lim16) ? *reinterpret_cast<const uint4*>(a0 + 16u * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 5; k++) { slot[4 * k] = q[k].x; slot[4 * k + 1] = q[k].y; slot[4 * k + 2] = q[k].z; slot[4 * k + 3] = q[k].w; }
+    const int64_t staged = s + (80 - static_cast<int64_t>(skew));   // bytes [s, staged) are in the slot
     int32_t v[MAXS];
 #pragma unroll
-    for (int q = 0; q < MAXS; q++) v[q] = -1;
+    for (int k = 0; k < MAXS; k++) v[k] = -1;
     uint32_t ent = ch->start_entry;
-    uint32_t w = 0;
     for (int64_t i = s; i < e; i++) {
-      const uint64_t addr = reinterpret_cast<uint64_t>(h0) + static_cast<uint64_t>(i);
-      if (i == s || (addr & 3u) == 0) w = *reinterpret_cast<const uint32_t*>(addr & ~3ull);   // one dword load per 4 bytes
-      const uint32_t b = (w >> ((addr & 3u) * 8)) & 0xFFu;
+      const uint32_t b = (i < staged) ? slotb[skew + static_cast<uint32_t>(i - s)] : h0[i];
       const uint32_t t = s_tab[ent * 256u + b];
       const uint32_t nx = t & 0xFFu;
       if (nx == 0xFFu) { bad = true; break; }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
       if (m) {
         const int32_t rel = static_cast<int32_t>(i - s);
 #pragma unroll
-        for (int q = 2; q < MAXS; q++) if ((m >> q) & 1u) v[q] = rel;
+        for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = rel;
       }
       ent = nx;
     }
@@ -193,15 +205,15 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
       const uint32_t m = s_masks[f];
       const int32_t rel = static_cast<int32_t>(e - s);
 #pragma unroll
-      for (int q = 2; q < MAXS; q++) if ((m >> q) & 1u) v[q] = rel;
+      for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = rel;
     }
 #pragma unroll
-    for (int q = 2; q + 1 < MAXS; q += 2) {
-      if (static_cast<uint32_t>(q) < width) {
+    for (int k = 2; k + 1 < MAXS; k += 2) {
+      if (static_cast<uint32_t>(k) < width) {
         longlong2 o;
-        o.x = v[q] < 0 ? -1 : s + v[q];
-        o.y = v[q + 1] < 0 ? -1 : s + v[q + 1];
-        *reinterpret_cast<longlong2*>(row + q) = o;
+        o.x = v[k] < 0 ? -1 : s + v[k];
+        o.y = v[k + 1] < 0 ? -1 : s + v[k + 1];
+        *reinterpret_cast<longlong2*>(row + k) = o;
       }
     }
   }
@@ -318,10 +330,10 @@ relaunch:
       const bool lds_ok = chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
       if (lds_ok && a.row_width <= 8) {
         const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
-        hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+        hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
       } else if (lds_ok && a.row_width <= 16) {
         const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
-        hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+        hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
       } else {
         const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
         hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
