@@ -187,6 +187,17 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   }
 #pragma unroll
   for (int c = 0; c < NCLS; c++) { ch.kind[c] = gch->cls_kind[c]; ch.lo[c] = gch->cls_lo[c]; ch.hi[c] = gch->cls_hi[c]; }
+  // the blob is read with vector loads (its address comes out of a loaded header field): make the description
+  // provably wave-uniform so that everything derived from it stays on the scalar unit
+  ch.nops = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.nops)));
+  ch.op_is_run = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.op_is_run)));
+  ch.op_cls2 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.op_cls2)));
+#pragma unroll
+  for (int c = 0; c < NCLS; c++) {
+    ch.kind[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.kind[c])));
+    ch.lo[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.lo[c])));
+    ch.hi[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.hi[c])));
+  }
   __syncthreads();
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
@@ -310,14 +321,16 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
           if (lane == 0) low = inject;                              // disabled source lane would not be read
           G = Ck & ((G << 1) | low);
         } else {
+          // T: positions outside the class from which the rest of the chain holds (the byte after a run).  Adding T
+          // to (Ck | T) turns every T position into a carry that ripples up through the class run above it and
+          // clears it: one multiword addition, no shift and no neighbour move.  The run of the window's last byte
+          // at the end of input gets its carry from the virtual position behind it (inject).
           const uint64_t T = G & ~Ck;
-          uint64_t tlow = from_lower64(T) >> 63;
-          if (lane == 0) tlow = inject;
-          const uint64_t M = ((T << 1) | tlow) & Ck;
-          const uint64_t s1 = Ck + M;
-          const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, M, 36 /*ult*/);
+          const uint64_t s1 = (Ck | T) + T;
+          const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, T, 36 /*ult*/);
           const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
-          const unsigned long long recv = (PP + (GG << 1)) ^ PP;    // lanes that receive a carry
+          const unsigned long long G1 = (GG << 1) | static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(inject)));
+          const unsigned long long recv = (PP + G1) ^ PP;           // lanes that receive a carry
           G = Ck & ~add_carry_mask(s1, recv);
         }
       }
