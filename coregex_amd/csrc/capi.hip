@@ -300,6 +300,7 @@ relaunch:
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, stream);
   else if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
+    std::memcpy(a.chain, hb + h->aux_off + 256, sizeof(cxgdev::ChainAux));
     le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, stream);
   }

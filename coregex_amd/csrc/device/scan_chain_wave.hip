@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   int lane = lane0;
   if (tid == 0) s_group = claim_tile(a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
-  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.blob + h->aux_off + 256);   // uniform address: scalar loads
+  static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
   ch.aux = gch;
   ch.nops = gch->nops;

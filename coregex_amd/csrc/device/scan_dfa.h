@@ -36,6 +36,8 @@ struct ScanArgs {
   uint64_t ngroups;     // look-back units: == ntiles, except for kernels that process kGroupTiles tiles per workgroup
   uint64_t* prof;       // optional [8] phase cycle counters (CXG_PROF=1), else nullptr
   uint32_t row_width;   // int64 per output row: 2, or 2*groups when a capture pass follows
+  uint8_t chain[96];    // scan_chain_wave.hip: copy of the program's ChainAux (walk.hpp) — kernel arguments are read with
+                        // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };
 
