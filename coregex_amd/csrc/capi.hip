@@ -68,8 +68,8 @@ struct Scratch {
   int device = -1;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) -> 32 B
-  uint64_t* status = nullptr;
+  uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) ... 8 XCD tickets at +32 -> 64 B, in front of `status`
+  uint64_t* status = nullptr;    // ctl + 64: one allocation, one memset per launch
   uint64_t statusCap = 0;
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
   uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
@@ -86,7 +86,6 @@ int getScratch(Scratch** out) {
   if (s.device < 0) {
     HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     for (auto& e : s.ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.hostCtl), 64, hipHostMallocDefault));
     s.device = t_device;
   }
@@ -95,11 +94,12 @@ int getScratch(Scratch** out) {
 }
 
 int ensureStatus(Scratch& s, uint64_t ntiles) {
-  if (ntiles <= s.statusCap) return CXG_OK;
-  if (s.status) HIP_TRY(hipFree(s.status));
-  s.status = nullptr; s.statusCap = 0;
+  if (ntiles <= s.statusCap && s.ctl) return CXG_OK;
+  if (s.ctl) HIP_TRY(hipFree(s.ctl));
+  s.ctl = nullptr; s.status = nullptr; s.statusCap = 0;
   uint64_t cap = ntiles + ntiles / 4 + 1024;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.status), cap * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + cap * sizeof(uint64_t)));
+  s.status = reinterpret_cast<uint64_t*>(s.ctl + 64);
   s.statusCap = cap;
   return CXG_OK;
 }
@@ -292,8 +292,8 @@ relaunch:
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 5 || gen == 6 || gen == 7) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
-  HIP_TRY(hipMemsetAsync(s.ctl, 0, 64, stream));
-  HIP_TRY(hipMemsetAsync(s.status, 0, a.ntiles * sizeof(uint64_t), stream));
+  // control block and the look-back words this launch will use, in one memset
+  HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
