@@ -276,8 +276,8 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (gen == 6 && !(h->flags & cxgdev::kFlagChainOrdered)) gen = 5;
   if (h->kind == cxgdev::kKindDigit) {
     if ((gen == 4 || gen == 5) && (h->flags & cxgdev::kFlagChainSets)) gen = 3;   // only generation 6 evaluates set classes
-    if (gen >= 4 && !(h->flags & cxgdev::kFlagChain)) gen = 3;
-    if (gen >= 3 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
+    if ((gen == 4 || gen == 5) && !(h->flags & cxgdev::kFlagChain)) gen = 3;
+    if (gen >= 3 && gen != 6 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
   } else if (h->kind == cxgdev::kKindTeddy) {
     static const bool oldTeddy = getenv("CXG_TEDDY_KERNEL") && atoi(getenv("CXG_TEDDY_KERNEL")) == 1;
     gen = (oldTeddy || h->aux_len > 2048u) ? 0 : 7;                 // the wave kernel stages at most 2 KiB of literal tables

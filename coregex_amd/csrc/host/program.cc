@@ -360,6 +360,19 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         } else {
           std::memset(&chain, 0, sizeof chain);
         }
+      } else if (!(flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE)) {
+        // No run skip (the pattern does not start with an unbounded digit run, meta/strategy.go:530-560): the
+        // reference tries EVERY digit position in order (find_indices.go:1059-1088), i.e. plain leftmost-first over
+        // matches that start with a digit.  A complete ordered chain (`\d{4}-\d{2}-\d{2}`) can then run on the
+        // bit-parallel kernel; kFlagChain stays clear, generations 4/5 assume digit-run-start candidates.
+        bool complete = false, ordered = false;
+        extractChain(p->fwd, info, chain, complete, ordered);
+        if (chain.nops >= 1 && complete && ordered) {
+          h.flags |= cxgdev::kFlagChainComplete | cxgdev::kFlagChainOrdered;
+          for (uint32_t k = 0; k < chain.ncls; k++) if (chain.cls_kind[k] == cxgdev::kClsSet) h.flags |= cxgdev::kFlagChainSets;
+        } else {
+          std::memset(&chain, 0, sizeof chain);
+        }
       }
     } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
       // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA

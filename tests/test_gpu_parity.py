@@ -159,8 +159,8 @@ def test_chain_kernel_is_the_one_that_runs(need_gpu):
 
 def test_random_inputs(need_gpu, oracle):
     rng = np.random.default_rng(2024)
-    alphabet = np.frombuffer(b"0123456789. ab\ncdxy@_eror:", dtype=np.uint8)
-    pats = [r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"\d+\.\d", r"[0-5]+x", r"\d{1,3}\.\d{1,3}", r"ab|abc", r"[1-9][0-9]*|0", r"ab+c", r"\d+:\d+:\d+"]
+    alphabet = np.frombuffer(b"0123456789. ab\ncdxy@_eror:-", dtype=np.uint8)
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"\d+\.\d", r"[0-5]+x", r"\d{1,3}\.\d{1,3}", r"ab|abc", r"[1-9][0-9]*|0", r"ab+c", r"\d+:\d+:\d+", r"\d{4}-\d{2}-\d{2}", r"\d\d:\d\d"]
     for pat in pats:
         for n in (1, 17, 63, 64, 65, 1000, 16384, 50000):
             hay = alphabet[rng.integers(0, len(alphabet), size=n)]

@@ -184,7 +184,7 @@ def test_bitparallel_chain_emulated(oracle):
     n_ok = 0
     cases = [(r"\d+\.\d+\.\d+\.\d+", b"0123456789..:: ab\nxy-", 2), (r"\d+:\d+:\d+", b"0123456789..:: ab\nxy-", 2),
              (r"error", b"eror rre\nxE", 1), (r"[a-z]+=\d+", b"abz=09 =\n-", 2), (r"ab+c", b"abc abbc\n", 1), (r"aba", b"ab \n", 1),
-             (r"GET", b"GET \nEG", 1)]
+             (r"GET", b"GET \nEG", 1), (r"\d{4}-\d{2}-\d{2}", b"0123456789-- \n", 2), (r"\d\d:\d\d", b"0189:: \n", 2)]
     for pat, alpha, cfg in cases:
         p = cx.compile(pat)
         flags = struct.unpack_from("<I", p.blob(), 8)[0] if p.supported else 0
