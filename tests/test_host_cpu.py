@@ -27,6 +27,16 @@ def test_library_exports_every_header_symbol():
     assert L.cxg_version().startswith(b"coregex_hip")
 
 
+def test_header_is_plain_c_and_example_compiles(tmp_path):
+    """include/coregex_hip.h is C99 (no C++/torch types): the example host program compiles against it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = tmp_path / "find_all.o"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-c", os.path.join(root, "examples", "find_all.c"), "-o", str(obj)])
+    assert obj.stat().st_size > 0
+
+
 def test_no_gpu_means_loud_failure():
     if cx.device_count() > 0:
         pytest.skip("a GPU is present")
