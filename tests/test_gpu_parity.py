@@ -142,6 +142,29 @@ def test_charclass_wave_paths(need_gpu, oracle):
     _check(oracle, r"[0-9a-fA-F]+", b"deadBEEF 0x1f 77zz " * 4000)
 
 
+def test_c_host_program(need_gpu, oracle, tmp_path):
+    """examples/find_all.c: a plain-C host over the C ABI, linked against the /opt/rocm build of the library
+    (what a cgo shim would link), prints the same spans as the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "coregex_amd", "libcoregex_hip_rocm.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "coregex_amd", "csrc"), "rocm"])
+    exe = tmp_path / "find_all"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "find_all.c"),
+                           "-L", os.path.join(root, "coregex_amd"), "-lcoregex_hip_rocm", "-o", str(exe)])
+    hay = cx.synth_pages(2, 0xC0FFEE02, 11, 64).tobytes()
+    f = tmp_path / "hay.log"
+    f.write_bytes(hay)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "coregex_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outp = subprocess.run([str(exe), r"\d+\.\d+\.\d+\.\d+", str(f)], env=env, capture_output=True, text=True, timeout=120)
+    assert outp.returncode == 0, outp.stderr
+    rows = [tuple(map(int, ln.split())) for ln in outp.stdout.splitlines() if ln and not ln.startswith("#")]
+    exp = oracle.Regex(r"\d+\.\d+\.\d+\.\d+").find_all_index(hay)
+    assert rows == [tuple(r) for r in exp.tolist()]
+
+
 def test_chain_kernel_is_the_one_that_runs(need_gpu):
     """No silent fallback on the benchmark corpora: one launch (the bit-parallel chain kernel), no rerun."""
     import torch
