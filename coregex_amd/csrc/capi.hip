@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -286,7 +287,10 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
     gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
+  // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
+  static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
 relaunch:
+  a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
@@ -372,6 +376,12 @@ relaunch:
       fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
+  }
+  if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
+    staticGroupsOk.store(false);
+    fprintf(stderr, "[cxg] look-back watchdog fired with static group assignment: switching to tickets\n");
+    relaunches++;
+    goto relaunch;
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;

@@ -36,6 +36,16 @@ __device__ __forceinline__ uint64_t claim_tile(uint32_t* tickets, uint64_t ntile
   return ntiles;   // cannot happen when grid == ntiles
 }
 
+// Group of a workgroup in the wave kernels.  Static mode: group = blockIdx.x, no atomic — the ~9 000 ticket atomics
+// of a 1 GiB scan queue at the eight L2 counters and cost ~10 % of the kernel.  The look-back only needs "every
+// smaller group is resident or finished"; workgroups are handed to each XCD in index order, so the smallest
+// unfinished group always finds a free slot on its XCD (slots there are only ever held by smaller, i.e. finished
+// or running, groups) and never waits.  Should a device dispatch differently, the look-back's spin watchdog raises
+// error bit 1 and the host reruns the scan with tickets (capi.hip).
+__device__ __forceinline__ uint64_t claim_group(bool static_groups, uint32_t* tickets, uint64_t ngroups) {
+  return static_groups ? static_cast<uint64_t>(blockIdx.x) : claim_tile(tickets, ngroups);
+}
+
 // Exclusive prefix of `mine` over the 256 threads of the block; `total` = block sum.
 // s_wsum: 4 uint32 of LDS.  Contains one __syncthreads().
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t* s_wsum, uint32_t& total) {
