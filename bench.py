@@ -36,10 +36,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # Defaults: the kernel time of this workload drifts for the first ~30 launches after idle (0.31 -> 0.34 -> 0.30 ms,
-    # clock/power management, scripts/time_dist.py), so the default warm-up is long enough to time the steady state.
+    # The kernel time of this workload drifts for the first ~30 launches after idle (0.31 -> 0.34 -> 0.30 ms, clock /
+    # power management, scripts/time_dist.py): --settle passes run before the W warm-up steps.
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle", type=int, default=40, help="untimed passes before the warm-up steps (clock settling)")
     ap.add_argument("--gib-per-gpu", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pattern", default=PATTERN)
@@ -86,6 +87,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock settling: the first ~30 launches after idle drift (scripts/time_dist.py); these untimed passes come
+    # before the W warm-up steps of the contract so that a short --warmup still times the steady state.
+    for _ in range(args.settle):
+        step()
     for _ in range(args.warmup):
         step()
     t = cx.Timing()
