@@ -73,6 +73,8 @@ struct Scratch {
   uint64_t* status = nullptr;    // ctl + 64: one allocation, one memset per launch
   uint64_t statusCap = 0;
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
+  uint32_t epoch = 0;            // last launch epoch used on `status` (block_common.hpp kEpochShift), 1..1023
+  bool needZero = true;          // the next epoch launch must start from a zeroed control block + status array
   uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
   uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
@@ -102,6 +104,7 @@ int ensureStatus(Scratch& s, uint64_t ntiles) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + cap * sizeof(uint64_t)));
   s.status = reinterpret_cast<uint64_t*>(s.ctl + 64);
   s.statusCap = cap;
+  s.needZero = true;
   return CXG_OK;
 }
 
@@ -295,9 +298,27 @@ relaunch:
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 5 || gen == 6 || gen == 7) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  // Wave kernels with static groups tag their look-back words with a launch epoch and clear the next launch's error
+  // word themselves: no memset between launches.  Everything else starts from a zeroed control block + status words.
+  static const bool epochsOk = getenv("CXG_NO_EPOCH") == nullptr;
+  const bool useEpoch = epochsOk && a.static_groups != 0;
+  a.epoch = 0;
+  a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
+  a.err_next = a.err;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
-  // control block and the look-back words this launch will use, in one memset
-  HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
+  if (useEpoch) {
+    if (s.needZero || s.epoch >= 1023u) {
+      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + s.statusCap * sizeof(uint64_t), stream));
+      s.epoch = 0; s.needZero = false;
+    }
+    a.epoch = ++s.epoch;
+    a.err = reinterpret_cast<uint32_t*>(s.ctl + 16) + (a.epoch & 3u);
+    a.err_next = reinterpret_cast<uint32_t*>(s.ctl + 16) + ((a.epoch + 1u) & 3u);
+  } else {
+    // control block and the look-back words this launch will use, in one memset
+    HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
+    s.needZero = true;                                              // legacy words and error bits are left behind
+  }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
@@ -351,7 +372,7 @@ relaunch:
   HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   const uint64_t total = s.hostCtl[1];
-  uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
+  uint32_t err = reinterpret_cast<const uint32_t*>(s.hostCtl)[4 + (a.epoch & 3u)];
   if (timing) {
     float k = 0, t = 0;
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);

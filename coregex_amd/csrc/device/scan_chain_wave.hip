@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: per-wave LDS bases live in SGPRs
   int lane = lane0;
-  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
+  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);

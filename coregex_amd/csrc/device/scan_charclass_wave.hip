@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
+  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
   SetRanges rg;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kCcTilesPerWave];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
   if (a.out == nullptr) return;
 
   // ---- pass 2: starts and ends straight to their rows

@@ -38,6 +38,8 @@ struct ScanArgs {
   uint32_t row_width;   // int64 per output row: 2, or 2*groups when a capture pass follows
   uint8_t chain[96];    // scan_chain_wave.hip: copy of the program's ChainAux (walk.hpp) — kernel arguments are read with
                         // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
+  uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
+  uint32_t* err_next;      // epoch launches: the error word of the NEXT launch, zeroed by group 0 (no memset between launches)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
+  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kTAuxMax / 4; i += kThreads)
     reinterpret_cast<uint32_t*>(s_aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);

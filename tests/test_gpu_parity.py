@@ -142,6 +142,25 @@ def test_charclass_wave_paths(need_gpu, oracle):
     _check(oracle, r"[0-9a-fA-F]+", b"deadBEEF 0x1f 77zz " * 4000)
 
 
+def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
+    """The wave kernels tag their look-back words with a launch epoch (1..1023) instead of zeroing them: more than
+    1023 launches on one scratch (epoch wrap), interleaved with table-walking kernels that do zero it."""
+    hay = cx.synth_pages(2, 0xC0FFEE02, 3, 32).tobytes()
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"error", r"[\w]+"]
+    legacy = r"\d+\.\d+x?"                                         # digit flat kernel (zeroed status, tickets)
+    rxs = [cx.compile(p) for p in pats]
+    exp = [len(oracle.Regex(p).find_all_index(hay)) for p in pats]
+    rl = cx.compile(legacy)
+    el = len(oracle.Regex(legacy).find_all_index(hay))
+    for i in range(1200):
+        j = i % 3
+        assert rxs[j].count(hay) == exp[j], (i, pats[j])
+        if i % 97 == 0:
+            assert rl.count(hay) == el, i
+    got = rxs[0].find_all_index(hay)
+    assert np.array_equal(got, oracle.Regex(pats[0]).find_all_index(hay))
+
+
 def test_c_host_program(need_gpu, oracle, tmp_path):
     """examples/find_all.c: a plain-C host over the C ABI, linked against the /opt/rocm build of the library
     (what a cgo shim would link), prints the same spans as the oracle."""
