@@ -174,7 +174,6 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: per-wave LDS bases live in SGPRs
   int lane = lane0;
   if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
-  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
