@@ -161,6 +161,30 @@ def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
     assert np.array_equal(got, oracle.Regex(pats[0]).find_all_index(hay))
 
 
+@pytest.mark.parametrize("env", [{"CXG_TICKETS": "1"}, {"CXG_NO_EPOCH": "1"}, {"CXG_DIGIT_KERNEL": "5"}, {"CXG_DIGIT_KERNEL": "2"},
+                                 {"CXG_TEDDY_KERNEL": "1", "CXG_CC_KERNEL": "1"}])
+def test_alternative_kernel_modes(need_gpu, env):
+    """The modes behind the defaults (ticket atomics instead of static groups, zeroed status words instead of epochs,
+    older kernel generations, the table-walking Teddy / char-class kernels) give the same spans."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, zlib, numpy as np; sys.path.insert(0, %r); import coregex_amd as cx\n"
+        "out = []\n"
+        "for cfg, pat in ((2, r'\\d+\\.\\d+\\.\\d+\\.\\d+'), (1, 'error'), (3, 'error|warning|fatal|critical'), (4, r'[\\w]+')):\n"
+        "    hay = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 2, 96)\n"
+        "    got = cx.compile(pat).find_all_index(hay)\n"
+        "    out.append('%%d:%%08x' %% (len(got), zlib.crc32(got.tobytes())))\n"
+        "print(' '.join(out))\n" % root)
+    base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    alt = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    assert base.returncode == 0, base.stderr[-2000:]
+    assert alt.returncode == 0, alt.stderr[-2000:]
+    assert base.stdout.strip().splitlines()[-1] == alt.stdout.strip().splitlines()[-1], (env, base.stdout, alt.stdout)
+
+
 def test_c_host_program(need_gpu, oracle, tmp_path):
     """examples/find_all.c: a plain-C host over the C ABI, linked against the /opt/rocm build of the library
     (what a cgo shim would link), prints the same spans as the oracle."""
