@@ -352,7 +352,12 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
         PHASE_MARK(4);                                              // starts, moved to forward orientation
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
-        for (uint32_t k = 0; k < nops; k++) {
+        const bool fixed_len = ch.op_is_run == 0u;                   // a literal: every match is nops bytes long
+        if (fixed_len) {                                            // ends = starts shifted by the length (< 64)
+          const uint64_t lower = from_lower64(S);
+          M = (S << nops) | ((lane == 0) ? 0ull : (lower >> (64u - nops)));
+        }
+        for (uint32_t k = 0; k < (fixed_len ? 0u : nops); k++) {
           const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
           const uint64_t Ck = F.pick<NCLS>(ci);
           if (!((ch.op_is_run >> k) & 1u)) {
@@ -397,19 +402,22 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
             const int bit = __builtin_ctzll(sb);
             sb &= sb - 1;
             const uint32_t r = nrows_w + is;
-            if (r < static_cast<uint32_t>(kWRows)) s_rs[wave][r] = static_cast<uint16_t>(64 * lane + bit);
+            if (r < static_cast<uint32_t>(kWRows)) {
+              s_rs[wave][r] = static_cast<uint16_t>(64 * lane + bit);
+              if (fixed_len) s_re[wave][r] = static_cast<uint16_t>(64 * lane + bit + nops);
+            }
             const uint32_t ends_le = ie0 + static_cast<uint32_t>(__popcll(M & ((2ull << bit) - 1ull)));
             ov |= (ends_le != is) ? 1u : 0u;
             is++;
           }
-          while (eb) {
+          while (eb && !fixed_len) {
             const int bit = __builtin_ctzll(eb);
             eb &= eb - 1;
             const uint32_t r = nrows_w + ie;
             if (r < static_cast<uint32_t>(kWRows)) s_re[wave][r] = static_cast<uint16_t>(64 * lane + bit);
             ie++;
           }
-          if (cout && lane == 0 && nrows_w + (tot >> 16) < static_cast<uint32_t>(kWRows)) s_re[wave][nrows_w + (tot >> 16)] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
+          if (cout && !fixed_len && lane == 0 && nrows_w + (tot >> 16) < static_cast<uint32_t>(kWRows)) s_re[wave][nrows_w + (tot >> 16)] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
         }
         emitted_here = n;
         if (__ballot(ov != 0) != 0ull && nrows_w + n <= static_cast<uint32_t>(kWRows)) {   // rare: resolve serially, in place
