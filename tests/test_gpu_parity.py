@@ -185,6 +185,35 @@ def test_alternative_kernel_modes(need_gpu, env):
     assert base.stdout.strip().splitlines()[-1] == alt.stdout.strip().splitlines()[-1], (env, base.stdout, alt.stdout)
 
 
+def test_random_patterns(need_gpu, oracle):
+    """Fuzz: random concatenations of literal bytes, classes and class+ — whatever the device path accepts (chain kernel,
+    table-walking kernels, Teddy, char-class) must reproduce the oracle; the strategy must match the oracle's too."""
+    rng = np.random.default_rng(78)
+    atoms = ["a", "b", "c", "x", r"\.", ":", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]", "ab|xy", "abc|xyz|a:c"]
+    alphabet = np.frombuffer(b"abcxyz.:0123456789 \n", dtype=np.uint8)
+    hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))] for n in (0, 7, 300, 5000, 40000)]
+    seen, n_ok = set(), 0
+    while len(seen) < 160:
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+        if pat in seen:
+            continue
+        seen.add(pat)
+        try:
+            rx = cx.compile(pat)
+        except cx.CoregexError:
+            continue
+        o = oracle.Regex(pat)
+        assert rx.strategy == o.strategy, pat
+        if not rx.supported:
+            continue
+        n_ok += 1
+        for hay in hays:
+            got = rx.find_all_index(hay)
+            exp = o.find_all_index(hay)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, rx.strategy, len(hay))
+    assert n_ok >= 50, n_ok
+
+
 def test_c_host_program(need_gpu, oracle, tmp_path):
     """examples/find_all.c: a plain-C host over the C ABI, linked against the /opt/rocm build of the library
     (what a cgo shim would link), prints the same spans as the oracle."""

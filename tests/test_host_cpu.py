@@ -251,6 +251,49 @@ def test_bitparallel_chain_emulated(oracle):
             assert not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
 
 
+def _random_chain_patterns(rng, count):
+    """Random concatenations of literal bytes, classes and class+ over a small alphabet (some are chains, some not)."""
+    atoms = ["a", "b", "c", "x", r"\.", ":", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]"]
+    out = []
+    while len(out) < count:
+        n = int(rng.integers(1, 6))
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(n))
+        if pat not in out:
+            out.append(pat)
+    return out
+
+
+def test_random_chain_patterns_emulated(oracle):
+    """Fuzz of the chain extraction (complete / ordered flags) and the bit-parallel evaluation: whatever pattern gets
+    the ordered-chain flag must reproduce the oracle on random haystacks, window geometry 192+64 and 3840+256."""
+    import struct
+    rng = np.random.default_rng(77)
+    alphabet = np.frombuffer(b"abcxyz.:0123456789 \n", dtype=np.uint8)
+    hays = [alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 6000)))].tobytes() for _ in range(12)]
+    n_chain = 0
+    for pat in _random_chain_patterns(rng, 220):
+        try:
+            p = cx.compile(pat)
+        except cx.CoregexError:
+            continue
+        if not p.supported:
+            continue
+        if not (struct.unpack_from("<I", p.blob(), 8)[0] & 16):
+            continue
+        n_chain += 1
+        o = oracle.Regex(pat)
+        assert o.strategy == p.strategy, pat
+        for hay in hays:
+            exp = o.find_all_index(hay).tolist()
+            for geom in ((192, 64), (3840, 256)):
+                got = emu.find_all_chain6(p.blob(), hay, *geom)
+                if isinstance(got, int):
+                    assert got == -17, (pat, geom, got)
+                    continue
+                assert got.tolist() == exp, (pat, len(hay), geom)
+    assert n_chain >= 40, n_chain
+
+
 def test_teddy_and_charclass_wave_twins(oracle):
     """Sequential twins of scan_teddy_wave.hip (three-byte fingerprint + exact verification + (zA, zB] ownership) and
     scan_charclass_wave.hip (start/end bitmaps, skipped leading end) vs the oracle, several window geometries."""
