@@ -358,13 +358,12 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
           M = (S << nops) | ((lane == 0) ? 0ull : (lower >> (64u - nops)));
         }
         for (uint32_t k = 0; k < (fixed_len ? 0u : nops); k++) {
-          const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
-          const uint64_t Ck = F.pick<NCLS>(ci);
           if (!((ch.op_is_run >> k) & 1u)) {
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
             M = (M << 1) | low;
           } else {
+            const uint64_t Ck = F.pick<NCLS>((ch.op_cls2 >> (2 * k)) & 3u);
             const uint64_t s1 = Ck + M;
             const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, M, 36 /*ult*/);
             const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
