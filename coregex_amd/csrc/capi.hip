@@ -14,6 +14,7 @@
 #include "../../include/coregex_hip.h"
 #include "device/scan_dfa.h"
 #include "device/synth.hpp"
+#include "device/block_common.hpp"
 #include "device/walk.hpp"
 #include "host/frontend.h"
 #include "host/program.h"
@@ -144,7 +145,7 @@ __global__ void k_captures(const uint8_t* hay, int64_t hay_base, int64_t* rows, 
   cxgdev::CapView cv{capblob + ch->next_off, capblob + ch->maskid_off, capblob + ch->fin_off,
                      reinterpret_cast<const uint32_t*>(capblob + ch->masks_off), ch->n_entries, ch->start_entry};
   // rows hold absolute offsets (hay_base added); the walk indexes the device buffer, so shift the pointer
-  if (!cxgdev::capture_walk(cv, hay - hay_base, rows + i * width, width)) atomicOr(err, 4u);
+  if (!cxgdev::capture_walk(cv, hay - hay_base, rows + i * width, width)) cxgdev::raise_err(err, 4u);
 }
 
 // Capture pass, fast form: the one-pass table (next | maskid << 8 per entry and byte) staged in LDS (dynamic size),
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
       }
     }
   }
-  if (bad) atomicOr(err, 4u);
+  if (bad) cxgdev::raise_err(err, 4u);
 }
 
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
@@ -303,8 +304,8 @@ relaunch:
   static const bool epochsOk = getenv("CXG_NO_EPOCH") == nullptr;
   const bool useEpoch = epochsOk && a.static_groups != 0;
   a.epoch = 0;
+  a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
-  a.err_next = a.err;
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
@@ -312,8 +313,11 @@ relaunch:
       s.epoch = 0; s.needZero = false;
     }
     a.epoch = ++s.epoch;
-    a.err = reinterpret_cast<uint32_t*>(s.ctl + 16) + (a.epoch & 3u);
-    a.err_next = reinterpret_cast<uint32_t*>(s.ctl + 16) + ((a.epoch + 1u) & 3u);
+    // total and error word in pinned host memory: written by the kernel (one store / a rare system-scope OR),
+    // visible when the stream has drained, read here without a device-to-host copy
+    s.hostCtl[1] = 0; s.hostCtl[2] = 0;
+    a.total = s.hostCtl + 1;
+    a.err = reinterpret_cast<uint32_t*>(s.hostCtl + 2);
   } else {
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
@@ -347,7 +351,7 @@ relaunch:
   if (submatch && a.out) {
     // capture pass: one thread per match row, after the span kernel on the same stream.  The row count is
     // only known on the device, so read it back first (one 8-byte copy).
-    HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
+    if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     uint64_t nrows = s.hostCtl[1];
     if (nrows > a.cap) nrows = a.cap;
@@ -369,10 +373,10 @@ relaunch:
     }
   }
   HIP_TRY(hipEventRecord(s.ev[2], stream));
-  HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
+  if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));   // wave kernels wrote hostCtl themselves
   HIP_TRY(hipStreamSynchronize(stream));
   const uint64_t total = s.hostCtl[1];
-  uint32_t err = reinterpret_cast<const uint32_t*>(s.hostCtl)[4 + (a.epoch & 3u)];
+  uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
   if (timing) {
     float k = 0, t = 0;
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);

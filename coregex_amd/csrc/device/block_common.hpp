@@ -13,6 +13,12 @@
 
 namespace cxgdev {
 
+// Error / fallback bits: the word may live in pinned host memory (wave kernels: the host reads it without a copy),
+// so the OR is a system-scope atomic.  Rare path.
+__device__ __forceinline__ void raise_err(uint32_t* err, uint32_t bits) {
+  __hip_atomic_fetch_or(err, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr uint64_t kFlagAggregate = 1ull << 62;
 constexpr uint64_t kFlagInclusive = 2ull << 62;
 constexpr uint64_t kFlagMask = 3ull << 62;
@@ -95,7 +101,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
         if (idx >= 0) w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
         if (!__all(ready)) {
-          if (++spins > kSpinLimit) { if (lane == 0) atomicOr(err, 2u); break; }
+          if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
           __builtin_amdgcn_s_sleep(2);
           continue;
         }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: per-wave LDS bases live in SGPRs
   int lane = lane0;
-  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
+  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
   static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   }
 #endif
   if (nrows_w > static_cast<uint32_t>(kWRows)) fallback |= 16;
-  if (fallback != 0 && lane == 0) atomicOr(a.err, 8u | (fallback << 8));   // bits 8.. = reason (diagnostics, CXG_VERBOSE)
+  if (fallback != 0 && lane == 0) raise_err(a.err, 8u | (fallback << 8));   // bits 8.. = reason (diagnostics, CXG_VERBOSE)
   __syncthreads();
 
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
+  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
   SetRanges rg;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       if (lane == 0) s_cnt[wave][j] = 0;
     }
   }
-  if (fallback != 0 && lane0 == 0) atomicOr(a.err, 8u | (fallback << 8));
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
   __syncthreads();
 
   // ---- group: exclusive prefix over the wave-tiles q = j*4 + wave, look-back

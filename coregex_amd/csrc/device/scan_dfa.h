@@ -30,8 +30,8 @@ struct ScanArgs {
   uint64_t cap;
   uint64_t* status;     // [ntiles] look-back words, zeroed before launch
   uint32_t* ticket;     // zeroed before launch
-  uint64_t* total;      // match count (written by the last tile)
-  uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog
+  uint64_t* total;      // match count (written by the last tile); wave kernels: pinned host memory, read without a copy
+  uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog, bit2 capture table, bit3 fallback; host memory likewise
   uint64_t ntiles;
   uint64_t ngroups;     // look-back units: == ntiles, except for kernels that process kGroupTiles tiles per workgroup
   uint64_t* prof;       // optional [8] phase cycle counters (CXG_PROF=1), else nullptr
@@ -39,7 +39,6 @@ struct ScanArgs {
   uint8_t chain[96];    // scan_chain_wave.hip: copy of the program's ChainAux (walk.hpp) — kernel arguments are read with
                         // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
   uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
-  uint32_t* err_next;      // epoch launches: the error word of the NEXT launch, zeroed by group 0 (no memset between launches)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };

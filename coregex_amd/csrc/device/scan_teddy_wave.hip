@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); if (a.epoch && blockIdx.x == 0) *a.err_next = 0u; }
+  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kTAuxMax / 4; i += kThreads)
     reinterpret_cast<uint32_t*>(s_aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
     nrows_w += emitted_here;
   }
   if (nrows_w > static_cast<uint32_t>(kTRows)) fallback |= 16;
-  if (fallback != 0 && lane == 0) atomicOr(a.err, 8u | (fallback << 8));
+  if (fallback != 0 && lane == 0) raise_err(a.err, 8u | (fallback << 8));
   __syncthreads();
 
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
