@@ -142,6 +142,45 @@ def test_charclass_wave_paths(need_gpu, oracle):
     _check(oracle, r"[0-9a-fA-F]+", b"deadBEEF 0x1f 77zz " * 4000)
 
 
+LITS16_EARLY = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+
+
+@pytest.mark.parametrize("cfg,pat,gib", [(2, r"\d+\.\d+\.\d+\.\d+", 8), (1, r"error", 8), (3, LITS16_EARLY, 4), (4, r"[\w]+", 2)])
+def test_full_size_shard_property(need_gpu, cfg, pat, gib):
+    """BASELINE-size haystacks (the 64 GiB / 8 north-star shard is 8 GiB): FindAll over the whole buffer equals the
+    concatenation of FindAll over page-aligned shards rebased by `base` — an order-sensitive checksum of all spans and
+    the counts, computed on the device; plus sortedness and non-overlap of the whole result."""
+    import torch
+    nbytes = gib << 30
+    buf = cx.DeviceBuffer(nbytes)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+    rx = cx.compile(pat)
+    n = rx.find_all_device(buf.ptr, nbytes)
+    assert n > 0
+    out = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
+    assert rx.find_all_device(buf.ptr, nbytes, out.data_ptr(), n + 8) == n
+    whole = out[:n]
+    assert bool((whole[:, 1] > whole[:, 0]).all()) and bool((whole[1:, 0] >= whole[:-1, 1]).all())      # sorted, disjoint, non-empty
+    idx = torch.arange(1, n + 1, dtype=torch.int64, device="cuda")
+    def checksum(rows, first):                                        # order-sensitive: row k weighted by its global rank
+        w = idx[first:first + rows.shape[0]]
+        return int((rows[:, 0] * w).sum().item()), int((rows[:, 1] * (w + 7)).sum().item())
+    ref = checksum(whole, 0)
+    shard = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
+    npages = nbytes // 4096
+    cuts = [0, npages // 8 * 4096, npages // 3 * 4096, (npages // 2 + 1) * 4096, nbytes]
+    acc0 = acc1 = 0
+    first = 0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        k_ = rx.find_all_device(buf.ptr + lo, hi - lo, shard.data_ptr(), n + 8, base=lo)
+        c = checksum(shard[:k_], first)
+        acc0 += c[0]; acc1 += c[1]
+        first += k_
+    assert first == n
+    mask = (1 << 64) - 1
+    assert (acc0 & mask, acc1 & mask) == (ref[0] & mask, ref[1] & mask)
+
+
 def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
     """The wave kernels tag their look-back words with a launch epoch (1..1023) instead of zeroing them: more than
     1023 launches on one scratch (epoch wrap), interleaved with table-walking kernels that do zero it."""
