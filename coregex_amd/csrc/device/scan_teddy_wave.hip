@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
             wave_lds_sync();
             if (lane == 0) {
               int32_t ce = cur_end;
-              for (uint32_t k = 0; k < 64 && r0 + k < ncand; k++) {
+              for (uint32_t k = 0; k < 64; k++) {                   // all 64: lanes past ncand hold e = 0 and must read em = 0
                 const int32_t ek = s_ce[wave][k];
                 uint8_t em = 0;
                 if (ek && static_cast<int32_t>(s_cpos[wave][r0 + k]) >= ce) { em = 1; ce = ek; }

@@ -224,6 +224,24 @@ def test_alternative_kernel_modes(need_gpu, env):
     assert base.stdout.strip().splitlines()[-1] == alt.stdout.strip().splitlines()[-1], (env, base.stdout, alt.stdout)
 
 
+def test_teddy_wave_overlap_round_with_idle_lanes(need_gpu, oracle):
+    """A verify round of the Teddy wave kernel that resolves overlapping candidates serially must not emit from lanes
+    past the round's candidates (they once read a stale flag left by an earlier, fuller round of the same wave)."""
+    pat = "[x-z]ab|xya"
+    rx = cx.compile(pat)
+    assert rx.strategy == "UseTeddy"
+    o = oracle.Regex(pat)
+    tile = 3840
+    dense = (b"xyab" + b"." * 60) * (tile // 64)          # 120 candidates per wave-tile, every second one suppressed
+    sparse = (b"." * 1000 + b"xyab" + b"." * (tile - 1004))  # 2 candidates, one suppressed
+    for order in ((dense, sparse), (sparse, dense), (dense, sparse, dense, sparse)):
+        hay = np.frombuffer(b"".join(part * 4 for part in order) * 3, dtype=np.uint8)
+        got = rx.find_all_index(hay)
+        exp = o.find_all_index(hay)
+        assert got.shape == exp.shape, (got.shape, exp.shape)
+        assert np.array_equal(got, exp)
+
+
 def test_random_patterns(need_gpu, oracle):
     """Fuzz: random concatenations of literal bytes, classes and class+ — whatever the device path accepts (chain kernel,
     table-walking kernels, Teddy, char-class) must reproduce the oracle; the strategy must match the oracle's too."""
