@@ -141,6 +141,119 @@ Dfa determinize(const cxg_nfa& nfa, uint32_t startState, bool breakAtMatch, uint
   return d;
 }
 
+// The reference's lazy DFA files a state under its SORTED NFA set plus the from-word and match-delay flags
+// (dfa/lazy/state.go:329-373) but steps through the set in the insertion order of whichever variant was determinized
+// first, breaking at the first match state (builder.go:183-242).  When two different priority orders of one set are
+// reachable AND behave differently (`a?(a|b)`: after "b" and after "a"), what the reference returns depends on what
+// its cache saw earlier — in this call or a previous one on the same Regex.  There is no single answer to reproduce,
+// so such programs are refused.  Explores the reference's states without conflating them — (ordered list, from-word,
+// source-held-a-match) — and minimises that automaton (Moore); orders filed under one key that land in one
+// equivalence class are harmless (`a?c`: the cache may keep either, every continuation reports the same matches),
+// and then the eager DFA above (keyed by the ordered list) is the reference's automaton whatever its history.
+bool priorityOrderConflict(const cxg_nfa& nfa, std::initializer_list<uint32_t> starts) {
+  bool boundary[256] = {false};
+  auto mark = [&](int lo, int hi) { if (lo > 0) boundary[lo - 1] = true; boundary[hi] = true; };
+  for (uint32_t i = 0; i < nfa.n_states; i++) {
+    const cxg_nfa_state& s = nfa.states[i];
+    if (s.kind == CXG_NFA_BYTE_RANGE) mark(s.lo, s.hi);
+    else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) mark(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
+  }
+  mark('0', '9'); mark('A', 'Z'); mark('_', '_'); mark('a', 'z');   // the from-word flag splits classes too
+  std::vector<int> reps;
+  for (int b = 0; b < 256; b++) if (b == 0 || boundary[b - 1]) reps.push_back(b);
+  auto isWord = [](int b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z'); };
+  auto holdsMatch = [&](const std::vector<uint32_t>& v, size_t n) { for (size_t i = 0; i < n; i++) if (nfa.states[v[i]].kind == CXG_NFA_MATCH) return true; return false; };
+
+  constexpr size_t kMaxTuples = 4096;
+  Closure cl(nfa);
+  std::map<std::vector<uint32_t>, uint32_t> ids;                    // ordered list + flags word -> tuple id
+  std::map<std::vector<uint32_t>, std::vector<uint32_t>> filedAs;   // sorted set + flags word -> tuple ids filed there
+  std::vector<std::vector<uint32_t>> tuples;                        // ordered list, then the flags word
+  std::vector<std::vector<int32_t>> next;                           // [tuple][rep index], -1 = dead
+  bool anyConflict = false;
+  auto intern = [&](std::vector<uint32_t>&& list, uint32_t flagsWord) -> int32_t {
+    std::vector<uint32_t> key(list);
+    std::sort(key.begin(), key.end());
+    key.push_back(0x80000000u | flagsWord);
+    list.push_back(0x80000000u | flagsWord);
+    auto it = ids.find(list);
+    if (it != ids.end()) return static_cast<int32_t>(it->second);
+    const uint32_t id = static_cast<uint32_t>(tuples.size());
+    if (id >= kMaxTuples) throw BuildError{CXG_E_UNSUPPORTED, "DFA exceeds the LDS state budget"};
+    std::vector<uint32_t>& filed = filedAs[key];
+    if (!filed.empty()) anyConflict = true;
+    filed.push_back(id);
+    ids.emplace(list, id);
+    tuples.push_back(std::move(list));
+    next.emplace_back(reps.size(), -1);
+    return static_cast<int32_t>(id);
+  };
+  for (uint32_t st : starts)
+    for (uint32_t w = 0; w < 2; w++) {
+      std::vector<uint32_t> set;
+      cl.begin();
+      cl.into(set, st);
+      intern(std::move(set), w);
+    }
+  for (size_t cur = 0; cur < tuples.size(); cur++) {
+    const std::vector<uint32_t> src = tuples[cur];   // copy: tuples grows
+    const size_t n = src.size() - 1;
+    const bool srcMatch = holdsMatch(src, n);
+    for (size_t ri = 0; ri < reps.size(); ri++) {
+      const int rep = reps[ri];
+      std::vector<uint32_t> out;
+      cl.begin();
+      for (size_t i = 0; i < n; i++) {
+        const cxg_nfa_state& s = nfa.states[src[i]];
+        if (srcMatch && s.kind == CXG_NFA_MATCH) break;
+        if (s.kind == CXG_NFA_BYTE_RANGE) {
+          if (rep >= s.lo && rep <= s.hi) cl.into(out, s.next);
+        } else if (s.kind == CXG_NFA_SPARSE) {
+          for (uint32_t k = 0; k < s.trans_len; k++) {
+            const cxg_nfa_trans& t = nfa.trans[s.trans_off + k];
+            if (rep >= t.lo && rep <= t.hi) cl.into(out, t.next);
+          }
+        }
+      }
+      if (out.empty() && !srcMatch) continue;   // dead
+      next[cur][ri] = intern(std::move(out), (isWord(rep) ? 1u : 0u) | (srcMatch ? 2u : 0u));
+    }
+  }
+  if (!anyConflict) return false;
+  // Moore minimisation.  Observable per state: the delayed match flag and "holds a match" (end of input) — both
+  // functions of the filing key, so states filed together start in one class.
+  const size_t nt = tuples.size();
+  std::vector<uint32_t> cls(nt);
+  for (size_t i = 0; i < nt; i++) {
+    const size_t n = tuples[i].size() - 1;
+    cls[i] = ((tuples[i][n] & 2u) ? 1u : 0u) | (holdsMatch(tuples[i], n) ? 2u : 0u);
+  }
+  size_t nclasses = 0;
+  for (;;) {
+    std::map<std::vector<uint32_t>, uint32_t> sig;
+    std::vector<uint32_t> ncls(nt);
+    for (size_t i = 0; i < nt; i++) {
+      std::vector<uint32_t> k;
+      k.reserve(reps.size() + 1);
+      k.push_back(cls[i]);
+      for (size_t ri = 0; ri < reps.size(); ri++) k.push_back(next[i][ri] < 0 ? 0xFFFFFFFFu : cls[static_cast<size_t>(next[i][ri])]);
+      ncls[i] = sig.emplace(std::move(k), static_cast<uint32_t>(sig.size())).first->second;
+    }
+    cls.swap(ncls);
+    if (sig.size() == nclasses) break;
+    nclasses = sig.size();
+  }
+  for (const auto& kv : filedAs)
+    for (uint32_t id : kv.second)
+      if (cls[id] != cls[kv.second[0]]) return true;
+  return false;
+}
+
+void refuseOrderConflict(const cxg_nfa& nfa, std::initializer_list<uint32_t> starts) {
+  if (priorityOrderConflict(nfa, starts))
+    throw BuildError{CXG_E_UNSUPPORTED, "reference DFA cache conflates priority orders of one NFA set (result depends on cache history)"};
+}
+
 HostNfa reverseOf(const cxg_nfa& fwd) {
   // R(t) == "the forward run is at state t here".  Reading byte b backwards moves R(t) -> R(s) for
   // every byte state s with s.next == t that accepts b; epsilon edges are reversed.  The reverse
@@ -296,6 +409,22 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
     for (int b = 0; b < 256; b++)
       if (cxgdev::chain_class_has(chain, chain.op_cls[k], static_cast<uint32_t>(b)) && cxgdev::chain_class_has(chain, chain.op_cls[k - 1], static_cast<uint32_t>(b))) ordered = false;
   }
+  // A chain that begins with a run takes its starts at run starts.  FindAll resumes at the end of the previous
+  // match, so a match may also start INSIDE a run of the first class when the previous match ended there
+  // (`z+\.\w\w` on "z.azz.bc": [0,4] then [4,8]).  That needs the last byte of a match to be in the first class
+  // with another first-class byte behind it: excluded when the last class misses the first class, or when the chain
+  // ends with a run whose class covers the first class (the match then stops at a byte outside both).
+  if (chain.nops >= 1 && chain.op_kind[0] == cxgdev::kChainRun) {
+    const int first = chain.op_cls[0], last = chain.op_cls[chain.nops - 1];
+    bool meet = false, firstOutsideLast = false;
+    for (int b = 0; b < 256; b++) {
+      const bool inF = cxgdev::chain_class_has(chain, first, static_cast<uint32_t>(b)), inL = cxgdev::chain_class_has(chain, last, static_cast<uint32_t>(b));
+      meet = meet || (inF && inL);
+      firstOutsideLast = firstOutsideLast || (inF && !inL);
+    }
+    const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;
+    if (meet && (!lastRun || firstOutsideLast)) ordered = false;
+  }
 }
 
 }  // namespace
@@ -325,6 +454,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       // findIndicesDigitPrefilterAtWithState: anchored DFA at each digit candidate
       p->fwd = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+      refuseOrderConflict(nfa, {nfa.start_anchored});
       h.kind = cxgdev::kKindDigit;
       if (flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) h.flags |= cxgdev::kFlagRunSkip;
       for (int b = '0'; b <= '9'; b++) info[b] &= ~cxgdev::kInfoSync;  // digits are candidates, never sync
@@ -379,6 +509,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+      refuseOrderConflict(nfa, {nfa.start_unanchored});
       HostNfa rn = reverseOf(nfa);
       cxg_nfa rv = rn.view();
       p->rev = determinize(rv, rv.start_anchored, false, kMaxDfaStates);

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Extended GPU fuzz (not part of pytest): random patterns x structured haystacks, device path vs the oracle.
+Usage: python scripts/gpu_fuzz.py [seed] [n_patterns].  Prints one line per mismatch and a summary."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import coregex_amd as cx
+from oracle import oracle
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+npat = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+rng = np.random.default_rng(seed)
+atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
+         "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "[^a]", "x*", "(xy|ab|ca)",
+         "abcx|bcxy|cxyz|xyza", "z+"]
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+T = 3840
+def rnd(n, p=None):
+    return alphabet[rng.integers(0, len(alphabet), size=int(n))] if p is None else alphabet[rng.choice(len(alphabet), size=int(n), p=p)]
+skew = np.ones(len(alphabet)); skew[:6] = 8; skew /= skew.sum()
+sk2 = np.ones(len(alphabet)); sk2[9:19] = 10; sk2 /= sk2.sum()
+hays = [rnd(0), rnd(5), rnd(T - 1), rnd(T + 1), rnd(32 * T), rnd(32 * T + 7, skew), rnd(70000, sk2), rnd(200000, skew),
+        np.frombuffer((b"xyab" + b"." * 28) * 4000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 9000, dtype=np.uint8),
+        np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 3000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
+ORACLE_ONLY = bool(os.environ.get('FUZZ_ORACLE_ONLY'))
+seen, n_dev, n_sub, bad = set(), 0, 0, 0
+by_strategy = {}
+t0 = time.time()
+while len(seen) < npat:
+    pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+    if pat in seen:
+        continue
+    seen.add(pat)
+    try:
+        rx = cx.compile(pat)
+    except cx.CoregexError:
+        continue
+    try:
+        o = oracle.Regex(pat)
+    except oracle.OracleError as ex:
+        if rx.supported:
+            print('ORACLE-REJECTS-BUT-DEVICE-ACCEPTS', repr(pat), ex); bad += 1
+        continue
+    if rx.strategy != o.strategy:
+        print("STRATEGY", repr(pat), rx.strategy, o.strategy); bad += 1
+    if rx.supported:
+        n_dev += 1
+        by_strategy[rx.strategy] = by_strategy.get(rx.strategy, 0) + 1
+        for hi, hay in enumerate(hays):
+            exp = o.find_all_index(hay)
+            if ORACLE_ONLY:
+                continue
+            try:
+                got = rx.find_all_index(hay)
+            except cx.CoregexError as ex:
+                print('ERROR', repr(pat), rx.strategy, 'hay', hi, len(hay), ex); bad += 1
+                continue
+            if got.shape != exp.shape or not np.array_equal(got, exp):
+                print("MISMATCH", repr(pat), rx.strategy, "hay", hi, len(hay), got.shape, exp.shape); bad += 1
+            c = rx.count(hay)
+            if c != len(exp):
+                print("COUNT", repr(pat), rx.strategy, "hay", hi, c, len(exp)); bad += 1
+    if "(" in pat and rx.submatch_supported:
+        n_sub += 1
+        for hi, hay in enumerate(hays[:8]):
+            exp = o.find_all_submatch_index(hay)
+            if ORACLE_ONLY:
+                continue
+            got = rx.find_all_submatch_index(hay)
+            if got.shape != exp.shape or not np.array_equal(got, exp):
+                print("SUBMATCH", repr(pat), "hay", hi, len(hay), got.shape, exp.shape); bad += 1
+print("seed", seed, "patterns", len(seen), "device", n_dev, "submatch", n_sub, "bad", bad, by_strategy, "%.1fs" % (time.time() - t0))

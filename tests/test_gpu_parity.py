@@ -243,14 +243,25 @@ def test_teddy_wave_overlap_round_with_idle_lanes(need_gpu, oracle):
 
 
 def test_random_patterns(need_gpu, oracle):
-    """Fuzz: random concatenations of literal bytes, classes and class+ — whatever the device path accepts (chain kernel,
-    table-walking kernels, Teddy, char-class) must reproduce the oracle; the strategy must match the oracle's too."""
+    """Fuzz: random concatenations of literal bytes, classes, class+, optional and alternation atoms — whatever the device
+    path accepts (chain kernel, table-walking kernels, Teddy, char-class) must reproduce the oracle, spans and counts,
+    and captures where the program has them; the strategy must match the oracle's too.  Haystacks include few-symbol
+    and periodic ones (dense, abutting and overlapping candidates) and one with no synchronising byte for 70 000 bytes.
+    scripts/gpu_fuzz.py is the long-running version of the same loop."""
     rng = np.random.default_rng(78)
-    atoms = ["a", "b", "c", "x", r"\.", ":", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]", "ab|xy", "abc|xyz|a:c"]
-    alphabet = np.frombuffer(b"abcxyz.:0123456789 \n", dtype=np.uint8)
-    hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))] for n in (0, 7, 300, 5000, 40000)]
-    seen, n_ok = set(), 0
-    while len(seen) < 160:
+    atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
+             "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
+             "abcx|bcxy|cxyz|xyza", "z+"]
+    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+    tile = 3840
+    skew = np.ones(len(alphabet)); skew[:6] = 8; skew /= skew.sum()
+    hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))] for n in (0, 7, tile - 1, tile + 1, 40000)]
+    hays += [alphabet[rng.choice(len(alphabet), size=32 * tile + 7, p=skew)],
+             alphabet[rng.choice(len(alphabet), size=30000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))],
+             np.frombuffer((b"xyab" + b"." * 28) * 2000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 5000, dtype=np.uint8),
+             np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 1000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
+    seen, n_ok, n_sub, strategies = set(), 0, 0, set()
+    while len(seen) < 220:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
         if pat in seen:
             continue
@@ -261,14 +272,22 @@ def test_random_patterns(need_gpu, oracle):
             continue
         o = oracle.Regex(pat)
         assert rx.strategy == o.strategy, pat
-        if not rx.supported:
-            continue
-        n_ok += 1
-        for hay in hays:
-            got = rx.find_all_index(hay)
-            exp = o.find_all_index(hay)
-            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, rx.strategy, len(hay))
-    assert n_ok >= 50, n_ok
+        if rx.supported:
+            n_ok += 1
+            strategies.add(rx.strategy)
+            for hay in hays:
+                got = rx.find_all_index(hay)
+                exp = o.find_all_index(hay)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (pat, rx.strategy, len(hay))
+                assert rx.count(hay) == len(exp), (pat, rx.strategy, len(hay))
+        if "(" in pat and rx.submatch_supported:
+            n_sub += 1
+            for hay in hays[:7]:
+                got = rx.find_all_submatch_index(hay)
+                exp = o.find_all_submatch_index(hay)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (pat, "submatch", len(hay))
+    assert n_ok >= 80 and n_sub >= 10, (n_ok, n_sub)
+    assert {"UseDFA", "UseTeddy", "UseDigitPrefilter", "UseCharClassSearcher"} <= strategies, strategies
 
 
 def test_c_host_program(need_gpu, oracle, tmp_path):

@@ -231,10 +231,10 @@ def test_bitparallel_chain_emulated(oracle):
             assert not isinstance(got, int) and got.tolist() == o.find_all_index(hay).tolist(), (pat, total)
     assert n_ok >= 5, n_ok
     # FindAllSubmatch programs: the span image carries the chain too, classes may be unions of ranges (\\w)
-    for pat, cfg in ((r"(\w+)@(\w+)\.(\w+)", 5), (r"(\w+)=(\d+)", 5)):
+    for pat, cfg in ((r"(\w+)@(\w+)\.(\w+)", 5), (r"([a-z]+)=(\d+)", 5)):
         p = cx.compile(pat)
         span_blob = p.submatch_blobs()[0]
-        assert (struct.unpack_from("<I", span_blob, 8)[0] & 48) == 48, pat        # ordered chain with set classes
+        assert (struct.unpack_from("<I", span_blob, 8)[0] & 16) == 16, pat        # ordered chain (\\w: a set class)
         o = oracle.Regex(pat)
         synth = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 3, 48).tobytes()
         for hay in (synth, corpus, b"a@b.c", b"foo@bar.com x@y.z k=1"):
@@ -249,6 +249,15 @@ def test_bitparallel_chain_emulated(oracle):
         p = cx.compile(pat)
         if p.supported:
             assert not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
+    # a chain that begins with a run and can end on a byte of that run's class with more of the class behind it: the
+    # next match may start mid-run ("z.azz.bc" -> [0,4] [4,8]), which run-start candidates cannot express
+    for pat, hay, exp in ((r"z+\.\w\w", b"z.azz.bc", [[0, 4], [4, 8]]), (r"[a-z0-9]+\.+[x-z]", b"ab.xy.z", [[0, 4], [4, 7]])):
+        p = cx.compile(pat)
+        assert p.supported and not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
+        assert oracle.Regex(pat).find_all_index(hay).tolist() == exp
+        assert emu.find_all(p.blob(), hay).tolist() == exp
+    span_blob = cx.compile(r"(\w+)=(\d+)").submatch_blobs()[0]
+    assert not (struct.unpack_from("<I", span_blob, 8)[0] & 16)
 
 
 def _random_chain_patterns(rng, count):
@@ -270,6 +279,8 @@ def test_random_chain_patterns_emulated(oracle):
     rng = np.random.default_rng(77)
     alphabet = np.frombuffer(b"abcxyz.:0123456789 \n", dtype=np.uint8)
     hays = [alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 6000)))].tobytes() for _ in range(12)]
+    # few-symbol haystacks: dense, abutting matches (a match that starts where the previous one ended, inside a run)
+    hays += [alphabet[rng.choice(len(alphabet), size=4000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))].tobytes() for _ in range(10)]
     n_chain = 0
     for pat in _random_chain_patterns(rng, 220):
         try:
@@ -332,6 +343,49 @@ def test_teddy_and_charclass_wave_twins(oracle):
                     assert got in (-17, -24), (pat, geom, got)      # a run longer than the halo / too many runs
                     continue
                 assert got.tolist() == exp, (pat, len(hay), geom)
+
+
+def test_history_dependent_reference_programs_are_refused(oracle):
+    """The reference's lazy DFA files states under their sorted NFA set but walks them in first-built order
+    (dfa/lazy/state.go:329-373): for `a?(a|b)` its answer depends on what the Regex scanned before.  The host refuses
+    exactly those programs (program.cc priorityOrderConflict); for everything it accepts, the oracle's answer must
+    not depend on cache history — a Regex reused across haystacks in either order equals a fresh one."""
+    fresh, used = oracle.Regex("a?(a|b)"), oracle.Regex("a?(a|b)")
+    used.find_all_index(b"b")
+    assert fresh.find_all_index(b"aaaa").tolist() == [[0, 2], [2, 4]]
+    assert used.find_all_index(b"aaaa").tolist() == [[0, 1], [1, 2], [2, 3], [3, 4]]
+    for pat in ("a?(a|b)", r"\wa?[ab]", "a?[ab]", "x*[x-z]"):
+        rx = cx.compile(pat)
+        assert not rx.supported and "cache history" in rx.why_unsupported, pat
+    for pat in ("a?c", r"-?\d+", "x*a", "a?z+", r"https?://\w+", r"\d+\.\d+\.\d+\.\d+"):
+        assert cx.compile(pat).supported, pat
+    rng = np.random.default_rng(5)
+    atoms = ["a", "b", "c", "x", r"\.", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "a+", "ab|xy", r"\w", r"\w+", "[ab]", "(a|b)", "(ab)+",
+             "a?", "b?", r"\d{1,3}", "x*", "(a|ab)", "(ab|a)", "[ab]*"]
+    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+    skew = np.ones(len(alphabet)); skew[:6] = 8; skew /= skew.sum()
+    hays = [alphabet[rng.choice(len(alphabet), size=n, p=skew)] for n in (60, 500, 6000)] + [np.frombuffer(b"a" * 300 + b"b" + b"a" * 300, dtype=np.uint8)]
+    seen, n_checked, n_refused = set(), 0, 0
+    while len(seen) < 250:
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+        if pat in seen:
+            continue
+        seen.add(pat)
+        try:
+            rx = cx.compile(pat)
+        except cx.CoregexError:
+            continue
+        if rx.strategy not in ("UseDFA", "UseDigitPrefilter"):
+            continue
+        if not rx.supported:
+            n_refused += "cache history" in rx.why_unsupported
+            continue
+        shared = oracle.Regex(pat)
+        n_checked += 1
+        for order in (range(len(hays)), reversed(range(len(hays)))):
+            for hi in order:
+                assert np.array_equal(shared.find_all_index(hays[hi]), oracle.Regex(pat).find_all_index(hays[hi])), (pat, hi)
+    assert n_checked >= 60 and n_refused >= 1, (n_checked, n_refused)
 
 
 def test_emulated_no_sync_bytes_at_all(oracle):
