@@ -354,6 +354,8 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
     return true;
   };
   uint32_t q = d.start;
+  for (int b = 0; b < 256; b++)                          // `x*...`: an optional leading run is not a chain step
+    if (d.table[static_cast<size_t>(q) * 256 + b] == q) return;
   for (int step = 0; step < cxgdev::kChainMaxOps; step++) {
     if (q >= d.firstAccept) break;                       // a match may end here: later steps are not necessary
     int target = -1; bool branching = false;

@@ -1,0 +1,64 @@
+"""CPU fuzz (not part of pytest): random patterns vs the oracle through the host front-end and the sequential twins of the
+kernels (tests/emu).  Usage: python scripts/cpu_fuzz.py SEED0 SEED1 — 150 patterns per seed, one line per mismatch."""
+import sys, struct, time
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import coregex_amd as cx, emu
+from oracle import oracle
+seed0, seed1 = int(sys.argv[1]), int(sys.argv[2])
+atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
+         "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
+         "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?", "(?:a|b|c)+",
+         "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
+bad=0; tot=0; strat={}
+t0=time.time()
+for seed in range(seed0, seed1):
+    rng = np.random.default_rng(seed)
+    hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))].tobytes() for n in (0, 3, 200, 5000)]
+    hays += [alphabet[rng.choice(len(alphabet), size=5000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))].tobytes() for _ in range(4)]
+    hays += [b"abcxyza:c" * 300, b"a" * 900 + b"b" + b"a" * 900]
+    seen=set()
+    while len(seen) < 150:
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+        if pat in seen: continue
+        seen.add(pat)
+        try: rx = cx.compile(pat)
+        except cx.CoregexError as e:
+            try: o = oracle.Regex(pat); print('HOST-REJECTS', repr(pat), e); bad+=1
+            except oracle.OracleError: pass
+            continue
+        try: o = oracle.Regex(pat)
+        except oracle.OracleError as e:
+            if rx.supported: print('ORACLE-REJECTS', repr(pat), e); bad+=1
+            continue
+        if rx.strategy != o.strategy: print('STRATEGY', repr(pat), rx.strategy, o.strategy); bad+=1
+        if not rx.supported:
+            if rx.submatch_supported:
+                pass
+            else: continue
+        tot+=1; strat[rx.strategy]=strat.get(rx.strategy,0)+1
+        if rx.supported:
+            blob = rx.blob(); kind = struct.unpack_from("<I", blob, 4)[0]; fl = struct.unpack_from("<I", blob, 8)[0]
+            for hay in hays:
+                exp = o.find_all_index(hay).tolist()
+                got = emu.find_all(blob, hay).tolist() if rx.strategy!='UseCharClassSearcher' else exp
+                if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
+                if fl & 16 and rx.strategy in ('UseDFA','UseDigitPrefilter'):
+                    for geom in ((192,64),(3840,256)):
+                        g6 = emu.find_all_chain6(blob, hay, *geom)
+                        if not isinstance(g6,int) and g6.tolist()!=exp: print('CHAIN6', repr(pat), len(hay), geom, len(g6), len(exp)); bad+=1
+                if rx.strategy=='UseTeddy':
+                    g = emu.find_all_teddy_wave(blob, hay)
+                    if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('TEDDYW', repr(pat), len(hay)); bad+=1
+                if rx.strategy=='UseCharClassSearcher' and (fl & 64):
+                    g = emu.find_all_charclass_wave(blob, hay)
+                    if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('CCW', repr(pat), len(hay)); bad+=1
+        if "(" in pat and rx.submatch_supported:
+            sb, cb = rx.submatch_blobs()[:2]
+            w = 2*(o.num_groups if hasattr(o,'num_groups') else rx.num_groups)
+            for hay in hays[:6]:
+                exp = o.find_all_submatch_index(hay)
+                got = emu.find_all_submatch(sb, cb, hay, exp.shape[1])
+                if got.shape!=exp.shape or not np.array_equal(got,exp): print('SUBMATCH', repr(pat), len(hay), got.shape, exp.shape); bad+=1; break
+print('seeds', seed0, seed1, 'checked', tot, 'bad', bad, strat, '%.0fs'%(time.time()-t0))

@@ -11,9 +11,10 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 npat = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 rng = np.random.default_rng(seed)
 atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
-         "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "[^a]", "x*", "(xy|ab|ca)",
-         "abcx|bcxy|cxyz|xyza", "z+"]
-alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+         "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
+         "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?",
+         "(?:a|b|c)+", "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
 T = 3840
 def rnd(n, p=None):
     return alphabet[rng.integers(0, len(alphabet), size=int(n))] if p is None else alphabet[rng.choice(len(alphabet), size=int(n), p=p)]

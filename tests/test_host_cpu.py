@@ -388,6 +388,69 @@ def test_history_dependent_reference_programs_are_refused(oracle):
     assert n_checked >= 60 and n_refused >= 1, (n_checked, n_refused)
 
 
+def test_wide_fuzz_host_and_twins(oracle):
+    """Wide fuzz (optional/star prefixes, non-greedy, case folding, dot, counted repeats, captures): strategy agreement
+    with the oracle, and for everything the device path accepts the lane walks and the wave-kernel twins reproduce the
+    oracle's spans and captures.  scripts/cpu_fuzz.py is the long-running version."""
+    import struct
+    atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
+             "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
+             "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?",
+             "(?:a|b|c)+", "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
+    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
+    n_dev, n_sub, n_chain = 0, 0, 0
+    for seed in (300, 301, 302, 303):
+        rng = np.random.default_rng(seed)
+        hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))].tobytes() for n in (0, 3, 200, 5000)]
+        hays += [alphabet[rng.choice(len(alphabet), size=5000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))].tobytes() for _ in range(4)]
+        hays += [b"abcxyza:c" * 300, b"a" * 900 + b"b" + b"a" * 900]
+        seen = set()
+        while len(seen) < 150:
+            pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+            if pat in seen:
+                continue
+            seen.add(pat)
+            try:
+                rx = cx.compile(pat)
+            except cx.CoregexError:
+                with pytest.raises(oracle.OracleError):
+                    oracle.Regex(pat)
+                continue
+            try:
+                o = oracle.Regex(pat)
+            except oracle.OracleError:
+                assert not rx.supported, pat
+                continue
+            assert rx.strategy == o.strategy, pat
+            if rx.supported:
+                n_dev += 1
+                blob = rx.blob()
+                flags = struct.unpack_from("<I", blob, 8)[0]
+                n_chain += bool(flags & 16)
+                for hay in hays:
+                    exp = o.find_all_index(hay).tolist()
+                    if rx.strategy != "UseCharClassSearcher":
+                        assert emu.find_all(blob, hay).tolist() == exp, (pat, rx.strategy, len(hay))
+                    twins = []
+                    if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter"):
+                        twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
+                    elif rx.strategy == "UseTeddy":
+                        twins = [emu.find_all_teddy_wave(blob, hay)]
+                    elif rx.strategy == "UseCharClassSearcher" and (flags & 64):
+                        twins = [emu.find_all_charclass_wave(blob, hay)]
+                    for got in twins:
+                        if got is not None and not isinstance(got, int):
+                            assert got.tolist() == exp, (pat, rx.strategy, len(hay))
+            if "(" in pat and rx.submatch_supported:
+                n_sub += 1
+                sb, cb = rx.submatch_blobs()[:2]
+                for hay in hays[:6]:
+                    exp = o.find_all_submatch_index(hay)
+                    got = emu.find_all_submatch(sb, cb, hay, exp.shape[1])
+                    assert got.shape == exp.shape and np.array_equal(got, exp), (pat, "submatch", len(hay))
+    assert n_dev >= 200 and n_sub >= 30 and n_chain >= 20, (n_dev, n_sub, n_chain)
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
