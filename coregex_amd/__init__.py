@@ -36,12 +36,19 @@ class UnsupportedPattern(CoregexError):
     """CXG_E_UNSUPPORTED: the caller keeps its CPU loop (mirrors the reference's degrade-don't-fail)."""
 
 
+class UnsupportedInput(CoregexError):
+    """CXG_E_INPUT: this haystack holds a long stretch without synchronising bytes; the caller keeps its CPU loop for
+    this call (the compiled program stays usable for other haystacks)."""
+
+
 def _check(rc: int):
     if rc == 0:
         return
     msg = _lib.lib().cxg_last_error().decode(errors="replace")
     if rc == _lib.CXG_E_UNSUPPORTED:
         raise UnsupportedPattern(rc, msg)
+    if rc == _lib.CXG_E_INPUT:
+        raise UnsupportedInput(rc, msg)
     raise CoregexError(rc, msg)
 
 

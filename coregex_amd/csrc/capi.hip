@@ -414,6 +414,8 @@ relaunch:
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // dense tile / no sync byte in a halo: table kernels
   }
   err &= 0xFFu;
+  if (err & cxgdev::kErrSerialLimit)
+    return fail(CXG_E_INPUT, "haystack has a stretch without synchronising bytes beyond the serial-walk budget (128 KiB)");
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
   if (dbgBits) { if (n_out) *n_out = total; return CXG_OK; }
   uint64_t n = total;

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_charclass(ScanArgs a) {
   if (tile >= a.ntiles) return;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
 
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_charclass(ScanArgs a) {
     if (e >= stage) {                       // ran off the staged bitmap: finish in HBM
       e = stage;
       while (e < rend && ((s_info[g[e]] >> 1) & 1u)) e++;
+      if (e >= wl.flag_at) raise_err(a.err, kErrSerialLimit);   // the run outlasts the serial-walk budget
     }
     const uint32_t row = excl + j++;
     if (buffered) {

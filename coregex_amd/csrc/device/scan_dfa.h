@@ -20,6 +20,22 @@ constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPe
 constexpr int kCcTilesPerWave = 4;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup
 constexpr uint64_t kCcGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave;
 constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
+// Serial-walk budget.  A lane that owns a stretch without synchronising bytes walks it alone at ~1.6 us per byte
+// (dependent byte loads from L2/HBM; scripts/time_nosync.py): a mebibyte takes seconds.  Every walk is therefore cut
+// kSerialLimit bytes behind its staged window — the cut plays end of input — and a lane that reads the last byte
+// before the cut raises error bit 32: the host returns CXG_E_INPUT and the caller keeps its CPU loop for this
+// haystack.  (The cut also keeps lane-relative offsets inside int32 for haystacks beyond 2 GiB.)
+constexpr int32_t kSerialLimit = 128 * 1024;
+constexpr uint32_t kErrSerialLimit = 32u;
+struct WalkLimit { int32_t rend; int32_t flag_at; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline WalkLimit walk_limit(uint64_t remaining, int32_t window) {
+  const uint64_t cut = static_cast<uint64_t>(window) + static_cast<uint64_t>(kSerialLimit);
+  if (remaining > cut) return WalkLimit{static_cast<int32_t>(cut), static_cast<int32_t>(cut) - 1};
+  return WalkLimit{static_cast<int32_t>(remaining), 0x7FFFFFFF};
+}
 
 struct ScanArgs {
   const uint8_t* hay;   // device, 16-byte aligned

@@ -37,8 +37,11 @@ struct LdsMem {
   const uint8_t* lds;   // staged tile (+halo)
   const uint8_t* g;     // hay + tile_lo
   int32_t lim;          // bytes [0, lim) are staged
+  int32_t flag_at = 0x7FFFFFFF;   // reading this byte or beyond means the walk ran into the serial-walk cut
+  mutable uint32_t over = 0;
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[lds_pad(r)];
+    over |= static_cast<uint32_t>(r >= flag_at);
     return g[r];
   }
   __device__ __forceinline__ uint32_t dword(int32_t r) const {
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
   if (tile >= a.ntiles) return;   // uniform
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
   // ---- stage the tile: coalesced 16-byte loads, 4 ds_write_b32 each
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
   __syncthreads();
 
   LdsMem m{s_tile, g, stage};
+  m.flag_at = wl.flag_at;
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   DfaView rv{s_rev, kRowStride, h->rev_start, h->rev_first_accept};
   const bool skip_safe = (h->flags & kFlagRunSkip) != 0;
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
 
   RecSink sink{s_recs, &s_rec_count, static_cast<uint32_t>(tid), 0u};
   run_lane<KIND>(m, fv, rv, s_info, skip_safe, c0, c1, rend, at_origin, sink);
+  if (m.over) raise_err(a.err, kErrSerialLimit);
   // a lane may emit more than 65 535 matches (no synchronising byte for a long stretch); the 16-bit rank in a
   // buffered record is only read when the whole tile emitted <= the record capacity, so that is not an error
 

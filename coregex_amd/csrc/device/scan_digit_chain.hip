@@ -41,7 +41,9 @@ constexpr int kRowCap = 2048;                    // rows buffered per group
 
 struct GlobalMem {       // verification reads the haystack straight from L2/HBM (rare)
   const uint8_t* g;
-  __device__ __forceinline__ uint32_t byte(int32_t r) const { return g[r]; }
+  int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
+  mutable uint32_t over = 0;
+  __device__ __forceinline__ uint32_t byte(int32_t r) const { over |= static_cast<uint32_t>(r >= flag_at); return g[r]; }
   __device__ __forceinline__ uint64_t digits(int32_t) const { return 0; }
   __device__ __forceinline__ int32_t bitmap_limit() const { return 0; }
 };
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
   if (tile >= a.ntiles) break;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
 
@@ -234,11 +237,13 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_chain(ScanArgs a) {
 
   // ---- C: verify survivors with the DFA; ownership = where their segment starts
   GlobalMem m{g};
+  m.flag_at = wl.flag_at;
   for (uint32_t k = tid; k < nsurv; k += kThreads) {
     const int32_t c = s_spos[k];
     const int32_t e = verify_jump(m, fv, s_sfl, c, rend);
     int32_t len = e < 0 ? 0 : e - c;
     if (len > 0xFFFF) { atomicOr(a.err, 8u); len = 0; }
+    if (m.over) { raise_err(a.err, kErrSerialLimit); m.over = 0; }
     s_slen[k] = static_cast<uint16_t>(len);
     uint8_t owned = 0;
     if (len) {

@@ -35,8 +35,11 @@ struct FlatMem {
   const uint64_t* bits;
   const uint8_t* g;
   int32_t lim;
+  int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
+  mutable uint32_t over = 0;
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[lds_pad2(r)];
+    over |= static_cast<uint32_t>(r >= flag_at);
     return g[r];
   }
   __device__ __forceinline__ uint64_t digits(int32_t w) const { return bits[w]; }
@@ -115,7 +118,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
   if (tile >= a.ntiles) return;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
   {
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
   const uint64_t t2 = a.prof ? clock64() : 0;
 
   FlatMem m{s_tile, s_bits, g, stage};
+  m.flag_at = wl.flag_at;
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   const bool skip_safe = (h->flags & kFlagRunSkip) != 0;
   const int32_t c0 = tid * kChunk, c1 = c0 + kChunk;
@@ -161,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
 
   RecSink2 sink{s_recs, &s_rec_count, static_cast<uint32_t>(tid), 0u};
   if (!(a.dbg & 1u)) lane_digit_flat(m, fv, s_info, skip_safe, c0, c1, rend, at_origin, sink);
+  if (m.over) raise_err(a.err, kErrSerialLimit);
   // a lane may emit more than 65 535 matches (no synchronising byte for a long stretch); the 16-bit rank in a
   // buffered record is only read when the whole tile emitted <= the record capacity, so that is not an error
   const uint64_t t3 = a.prof ? clock64() : 0;

@@ -34,8 +34,11 @@ struct ListMem {
   const uint64_t* bits;
   const uint8_t* g;
   int32_t lim;
+  int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
+  mutable uint32_t over = 0;
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[lds_pad3(r)];
+    over |= static_cast<uint32_t>(r >= flag_at);
     return g[r];
   }
   __device__ __forceinline__ uint64_t digits(int32_t w) const { return bits[w]; }
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
   if (tile >= a.ntiles) return;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
 
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
 
   // ---- C: verify, one candidate per lane per round
   ListMem m{s_tile, s_bits, g, stage};
+  m.flag_at = wl.flag_at;
   DfaView fv{s_fwd, kRowStride, h->fwd_start, h->fwd_first_accept};
   for (uint32_t k = tid; k < ncand; k += kThreads) {
     const int32_t c = s_cpos[k];
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_list(ScanArgs a) {
   const bool at_origin = (tile_lo == 0 && tid == 0);
   CountSink cs{0u};
   if (!(a.dbg & 8u)) lane_select(m, fv, s_info, s_sfl, s_cpos, s_clen, ncand, cexcl, stage, c0, c1, rend, at_origin, cs);
+  if (m.over) raise_err(a.err, kErrSerialLimit);
   uint32_t total;
   const uint32_t excl = block_exclusive_scan(cs.n, s_wsum, total);
   tile_lookback(a.status, a.total, a.err, tile, a.ntiles, total, &s_base);

@@ -36,8 +36,11 @@ struct GMem {            // bytes of the wave-tile window come from the wave's L
   const uint8_t* g;
   const uint8_t* lds;
   int32_t lim;
+  int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
+  mutable uint32_t over = 0;
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[r];
+    over |= static_cast<uint32_t>(r >= flag_at);
     return g[r];
   }
   __device__ __forceinline__ uint64_t digits(int32_t) const { return 0; }
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
     uint32_t emitted_here = 0;
     if (tile_lo < a.len) {
       const uint64_t remaining = a.len - tile_lo;
-      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      const WalkLimit wl = walk_limit(remaining, kWaveTile + kWaveHalo);   // serial-walk budget, scan_dfa.h
+      const int32_t rend = wl.rend;
       const int32_t stage = rend < kWaveTile + kWaveHalo ? rend : kWaveTile + kWaveHalo;
       const uint8_t* g = a.hay + tile_lo;
 
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
       if (static_cast<uint32_t>(lane) < nsurv) {
         c = s_spos[wave][lane];
         GMem m{g, s_bytes[wave], complete ? 0 : (nfull << 4)};
+        m.flag_at = wl.flag_at;
         int32_t e = -1;
         bool walked = false;
         if (complete) {
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_digit_wave(ScanArgs a) {
           if (ie >= 0 && (4095 - ie < stage || (4095 - ie == stage && stage == rend))) { e = 4095 - ie; walked = true; }   // an end AT a cut window edge is unknown
         }
         if (!walked) e = verify_jump(m, fv, s_sfl, c, rend);
+        if (m.over) raise_err(a.err, kErrSerialLimit);
         len = e < 0 ? 0 : e - c;
         if (len > 0xFFFF) { fallback = 1; len = 0; }
         if (len) {

@@ -23,7 +23,9 @@ struct TeddyMem {
   const uint64_t* bits;
   const uint8_t* g;
   int32_t lim;
-  __device__ __forceinline__ uint32_t byte(int32_t r) const { return g[r]; }
+  int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
+  mutable uint32_t over = 0;
+  __device__ __forceinline__ uint32_t byte(int32_t r) const { over |= static_cast<uint32_t>(r >= flag_at); return g[r]; }
   __device__ __forceinline__ uint64_t cands(int32_t w) const { return bits[w]; }
   __device__ __forceinline__ int32_t bitmap_limit() const { return lim; }
 };
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_teddy(ScanArgs a) {
   if (tile >= a.ntiles) return;
   const uint64_t tile_lo = tile * static_cast<uint64_t>(kTile);
   const uint64_t remaining = a.len - tile_lo;
-  const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+  const WalkLimit wl = walk_limit(remaining, kTile + kHalo);   // serial-walk budget, scan_dfa.h
+  const int32_t rend = wl.rend;
   const int32_t stage = rend < kTile + kHalo ? rend : kTile + kHalo;
   const uint8_t* g = a.hay + tile_lo;
 
@@ -111,10 +114,12 @@ __global__ __launch_bounds__(kThreads) void k_scan_teddy(ScanArgs a) {
   __syncthreads();
 
   TeddyMem m{s_bits, g, stage};
+  m.flag_at = wl.flag_at;
   const int32_t c0 = tid * kChunk, c1 = c0 + kChunk;
   const bool at_origin = (tile_lo == 0 && tid == 0);
   RecSinkT sink{s_recs, &s_rec_count, static_cast<uint32_t>(tid), 0u};
   lane_teddy(m, tv, s_info, c0, c1, rend, at_origin, sink);
+  if (m.over) raise_err(a.err, kErrSerialLimit);
   // a lane may emit more than 65 535 matches (no synchronising byte for a long stretch); the 16-bit rank in a
   // buffered record is only read when the whole tile emitted <= the record capacity, so that is not an error
 

@@ -41,6 +41,8 @@ extern "C" {
 #define CXG_E_NO_GPU (-5)       /* no gfx950 device visible: there is no CPU fallback in this library */
 #define CXG_E_SYNTAX (-6)       /* cxg_compile: pattern does not parse */
 #define CXG_E_INTERNAL (-7)     /* device-side invariant violated (watchdog, scratch overflow) */
+#define CXG_E_INPUT (-8)        /* this haystack has a stretch of > 128 KiB without a synchronising byte (one lane would
+                                   walk it alone): the caller keeps its CPU loop for THIS call; the program stays usable */
 
 /* meta.Strategy values (meta/strategy.go:19-230), same numbering. */
 enum cxg_strategy {

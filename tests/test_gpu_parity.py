@@ -242,6 +242,37 @@ def test_teddy_wave_overlap_round_with_idle_lanes(need_gpu, oracle):
         assert np.array_equal(got, exp)
 
 
+def test_long_sync_free_stretch_is_refused_cleanly(need_gpu, oracle):
+    """A stretch without synchronising bytes is walked by ONE lane (~1.6 us per byte).  Up to the serial-walk budget
+    (128 KiB, scan_dfa.h) the result is exact; beyond it the call returns CXG_E_INPUT quickly instead of running for
+    seconds (or tripping the look-back watchdog), and the program stays usable."""
+    import time
+    cases = [(r"\d+\.\d+\.\d+\.\d+", b"1."), (r"error|warning|fatal|critical", b"error"), (r"[\w]+", b"a"), (r"[a-c]+x[a-c]", b"abc")]
+    for pat, unit in cases:
+        rx = cx.compile(pat)
+        if not rx.supported:
+            continue
+        o = oracle.Regex(pat)
+        ok = np.frombuffer(b"  " + (unit * 40000)[:100 * 1024] + b"  1.2.3.4 error abcxa ", dtype=np.uint8)
+        assert np.array_equal(rx.find_all_index(ok), o.find_all_index(ok)), pat
+        for n in (600 * 1024, 3 << 20):
+            bad = np.frombuffer(b" 1.2.3.4 " + (unit * (n // len(unit) + 1))[:n] + b" error ", dtype=np.uint8)
+            t0 = time.time()
+            with pytest.raises(cx.UnsupportedInput):
+                rx.find_all_index(bad)
+            try:                                       # counting char-class runs needs no run ends: exact, no walk
+                assert rx.count(bad) == len(o.find_all_index(bad)) and rx.strategy == "UseCharClassSearcher"
+            except cx.UnsupportedInput:
+                pass
+            assert time.time() - t0 < 5.0, (pat, n, time.time() - t0)
+        assert np.array_equal(rx.find_all_index(ok), o.find_all_index(ok)), pat
+    rx = cx.compile(r"(\w+)@(\w+)\.(\w+)")
+    with pytest.raises(cx.UnsupportedInput):
+        rx.find_all_submatch_index(np.frombuffer(b"ab" * (400 * 1024), dtype=np.uint8))
+    hay = b"x a@b.c y"
+    assert np.array_equal(rx.find_all_submatch_index(hay), oracle.Regex(r"(\w+)@(\w+)\.(\w+)").find_all_submatch_index(hay))
+
+
 def test_random_patterns(need_gpu, oracle):
     """Fuzz: random concatenations of literal bytes, classes, class+, optional and alternation atoms — whatever the device
     path accepts (chain kernel, table-walking kernels, Teddy, char-class) must reproduce the oracle, spans and counts,
