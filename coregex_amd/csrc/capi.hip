@@ -270,6 +270,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const uint32_t dbgBits = getenv("CXG_DEBUG") ? static_cast<uint32_t>(atoi(getenv("CXG_DEBUG"))) : 0u;
   a.prof = nullptr;
   a.dbg = dbgBits;
+  a.max_len = (h->flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u;
   if (profOn) {
     if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));
     HIP_TRY(hipMemsetAsync(s.prof, 0, 128, stream));
@@ -414,6 +415,8 @@ relaunch:
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // dense tile / no sync byte in a halo: table kernels
   }
   err &= 0xFFu;
+  if (err & cxgdev::kErrLongMatch)
+    return fail(CXG_E_INPUT, "UseBoth program met a match longer than 100 bytes (the reference restarts its PikeVM inside such a match)");
   if (err & cxgdev::kErrSerialLimit)
     return fail(CXG_E_INPUT, "haystack has a stretch without synchronising bytes beyond the serial-walk budget (128 KiB)");
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));

@@ -446,6 +446,13 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
 #endif
   if (nrows_w > static_cast<uint32_t>(kWRows)) fallback |= 16;
   if (fallback != 0 && lane == 0) raise_err(a.err, 8u | (fallback << 8));   // bits 8.. = reason (diagnostics, CXG_VERBOSE)
+  if (a.max_len != 0) {                                             // UseBoth programs only (uniform): no match may exceed the restart span
+    wave_lds_sync();
+    bool long_hit = false;
+    for (uint32_t r = lane0; r < nrows_w && r < static_cast<uint32_t>(kWRows); r += 64)
+      long_hit = long_hit || (static_cast<uint32_t>(s_re[wave][r]) - static_cast<uint32_t>(s_rs[wave][r]) > a.max_len);
+    if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+  }
   __syncthreads();
 
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q

@@ -27,6 +27,7 @@ constexpr int kRecCap = 1024;                 // LDS match records per tile befo
 // haystack.  (The cut also keeps lane-relative offsets inside int32 for haystacks beyond 2 GiB.)
 constexpr int32_t kSerialLimit = 128 * 1024;
 constexpr uint32_t kErrSerialLimit = 32u;
+constexpr uint32_t kErrLongMatch = 64u;
 struct WalkLimit { int32_t rend; int32_t flag_at; };
 #if defined(__HIPCC__)
 __host__ __device__
@@ -56,6 +57,7 @@ struct ScanArgs {
                         // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
   uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)
+  uint32_t max_len;     // != 0: a match longer than this raises error bit 64 (UseBoth programs, walk.hpp kFlagBothRestart)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };
 

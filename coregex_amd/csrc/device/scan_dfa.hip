@@ -55,7 +55,9 @@ struct RecSink {
   uint32_t* rec_count;
   uint32_t lane;
   uint32_t n;
+  uint32_t max_len = 0, long_hit = 0;
   __device__ __forceinline__ void emit(int32_t s, int32_t e) {
+    long_hit |= static_cast<uint32_t>(max_len != 0 && static_cast<uint32_t>(e - s) > max_len);
     const uint32_t j = n++;
     const uint32_t slot = atomicAdd(rec_count, 1u);
     if (slot < static_cast<uint32_t>(kRecCap)) {
@@ -156,8 +158,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
   const bool at_origin = (tile_lo == 0 && tid == 0);
 
   RecSink sink{s_recs, &s_rec_count, static_cast<uint32_t>(tid), 0u};
+  sink.max_len = a.max_len;
   run_lane<KIND>(m, fv, rv, s_info, skip_safe, c0, c1, rend, at_origin, sink);
   if (m.over) raise_err(a.err, kErrSerialLimit);
+  if (sink.long_hit) raise_err(a.err, kErrLongMatch);
   // a lane may emit more than 65 535 matches (no synchronising byte for a long stretch); the 16-bit rank in a
   // buffered record is only read when the whole tile emitted <= the record capacity, so that is not an error
 

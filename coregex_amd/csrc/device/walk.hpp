@@ -420,6 +420,9 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t cls_rlo[kChainMaxCls][kChainMaxRanges];
   uint8_t cls_rhi[kChainMaxCls][kChainMaxRanges];
 };
+constexpr uint32_t kFlagBothRestart = 128u;    // UseBoth program: the reference restarts its PikeVM 100 bytes before the DFA's match end
+                                                // (find_indices.go:425-431) — identical to leftmost-first unless a match is longer than that
+constexpr uint32_t kBothRestartSpan = 100u;
 constexpr uint32_t kFlagCcRanges = 64u;         // kKindCharClass: membership is a union of <= 4 ASCII ranges (CharClassAux in aux)
 struct CharClassAux { uint32_t nr; uint8_t lo[4], hi[4]; uint32_t _pad; };
 constexpr uint32_t kFlagChainSets = 32u;        // some class is a kClsSet: only scan_chain_wave.hip evaluates those

@@ -506,8 +506,14 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           std::memset(&chain, 0, sizeof chain);
         }
       }
-    } else if (strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) {
-      // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA
+    } else if ((strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) || strategy == CXG_USE_BOTH) {
+      // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA.
+      // UseBoth (findIndicesAdaptiveAtWithState, find_indices.go:408-441): the DFA's match end only picks where the
+      // PikeVM starts — `at`, or end-100 when end > at+100.  The PikeVM is leftmost-first, and nothing starts between
+      // `at` and the leftmost match, so the answer is the plain leftmost-first match unless that match is longer than
+      // 100 bytes (then the PikeVM starts inside it).  The kernels compute leftmost-first and raise error bit 64 on a
+      // longer match (kFlagBothRestart): CXG_E_INPUT, the caller keeps its CPU loop for that haystack.
+      if (strategy == CXG_USE_BOTH) h.flags |= cxgdev::kFlagBothRestart;
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};

@@ -42,9 +42,13 @@ for seed in range(seed0, seed1):
             blob = rx.blob(); kind = struct.unpack_from("<I", blob, 4)[0]; fl = struct.unpack_from("<I", blob, 8)[0]
             for hay in hays:
                 exp = o.find_all_index(hay).tolist()
+                if rx.strategy == 'UseBoth':     # plain leftmost-first unless a match is longer than 100 bytes (device: CXG_E_INPUT)
+                    plain = o.find_all_submatch_index(hay)[:, :2]
+                    if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100:
+                        exp = plain.tolist()
                 got = emu.find_all(blob, hay).tolist() if rx.strategy!='UseCharClassSearcher' else exp
                 if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
-                if fl & 16 and rx.strategy in ('UseDFA','UseDigitPrefilter'):
+                if fl & 16 and rx.strategy in ('UseDFA','UseDigitPrefilter','UseBoth'):
                     for geom in ((192,64),(3840,256)):
                         g6 = emu.find_all_chain6(blob, hay, *geom)
                         if not isinstance(g6,int) and g6.tolist()!=exp: print('CHAIN6', repr(pat), len(hay), geom, len(g6), len(exp)); bad+=1

@@ -273,6 +273,33 @@ def test_long_sync_free_stretch_is_refused_cleanly(need_gpu, oracle):
     assert np.array_equal(rx.find_all_submatch_index(hay), oracle.Regex(r"(\w+)@(\w+)\.(\w+)").find_all_submatch_index(hay))
 
 
+def test_use_both_programs(need_gpu, oracle):
+    """UseBoth (find_indices.go:408-441): the DFA's end only picks where the PikeVM starts (end-100 for far ends), so
+    FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's answer starts
+    inside the match and the device path refuses the haystack (CXG_E_INPUT) instead of guessing."""
+    pat = r"(\w+)@(\w+)\.(\w+)"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == "UseBoth" and rx.supported
+    corpus = generate_test_input()
+    hay = cx.synth_pages(5, 0xC0FFEE05, 0, 512)
+    for h in (corpus, hay, b"", b"a@b.c", b"x " + b"a" * 60 + b"@b.com y"):
+        got, exp = rx.find_all_index(h), o.find_all_index(h)
+        assert got.shape == exp.shape and np.array_equal(got, exp)
+        assert rx.count(h) == len(exp)
+    exactly = b"u" * 94 + b"@b.com"                          # 100 bytes: still the plain answer
+    assert np.array_equal(rx.find_all_index(exactly), o.find_all_index(exactly)) and len(o.find_all_index(exactly)) == 1
+    longer = b"  " + b"u" * 95 + b"@b.com  k@l.mn "           # 101 bytes: the reference answers [3, 103)
+    assert o.find_all_index(longer).tolist()[0] == [3, 103]
+    with pytest.raises(cx.UnsupportedInput):
+        rx.find_all_index(longer)
+    with pytest.raises(cx.UnsupportedInput):
+        rx.count(longer)
+    big = np.concatenate([hay, np.frombuffer(longer, dtype=np.uint8), hay])      # one long match inside 4 MiB
+    with pytest.raises(cx.UnsupportedInput):
+        rx.find_all_index(big)
+    assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))        # the program stays usable
+
+
 def test_random_patterns(need_gpu, oracle):
     """Fuzz: random concatenations of literal bytes, classes, class+, optional and alternation atoms — whatever the device
     path accepts (chain kernel, table-walking kernels, Teddy, char-class) must reproduce the oracle, spans and counts,
@@ -291,7 +318,7 @@ def test_random_patterns(need_gpu, oracle):
              alphabet[rng.choice(len(alphabet), size=30000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))],
              np.frombuffer((b"xyab" + b"." * 28) * 2000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 5000, dtype=np.uint8),
              np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 1000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
-    seen, n_ok, n_sub, strategies = set(), 0, 0, set()
+    seen, n_ok, n_sub, strategies, n_both_refused = set(), 0, 0, set(), 0
     while len(seen) < 220:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
         if pat in seen:
@@ -307,8 +334,15 @@ def test_random_patterns(need_gpu, oracle):
             n_ok += 1
             strategies.add(rx.strategy)
             for hay in hays:
-                got = rx.find_all_index(hay)
                 exp = o.find_all_index(hay)
+                try:
+                    got = rx.find_all_index(hay)
+                except cx.UnsupportedInput:
+                    # only a UseBoth program on a haystack whose plain leftmost-first result holds a match > 100 bytes
+                    plain = o.find_all_submatch_index(hay)[:, :2]
+                    assert rx.strategy == "UseBoth" and int((plain[:, 1] - plain[:, 0]).max()) > 100, (pat, rx.strategy, len(hay))
+                    n_both_refused += 1
+                    continue
                 assert got.shape == exp.shape and np.array_equal(got, exp), (pat, rx.strategy, len(hay))
                 assert rx.count(hay) == len(exp), (pat, rx.strategy, len(hay))
         if "(" in pat and rx.submatch_supported:
@@ -318,7 +352,7 @@ def test_random_patterns(need_gpu, oracle):
                 exp = o.find_all_submatch_index(hay)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (pat, "submatch", len(hay))
     assert n_ok >= 80 and n_sub >= 10, (n_ok, n_sub)
-    assert {"UseDFA", "UseTeddy", "UseDigitPrefilter", "UseCharClassSearcher"} <= strategies, strategies
+    assert {"UseDFA", "UseTeddy", "UseDigitPrefilter", "UseCharClassSearcher", "UseBoth"} <= strategies, strategies
 
 
 def test_c_host_program(need_gpu, oracle, tmp_path):

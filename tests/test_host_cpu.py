@@ -398,7 +398,7 @@ def test_wide_fuzz_host_and_twins(oracle):
              "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?",
              "(?:a|b|c)+", "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
-    n_dev, n_sub, n_chain = 0, 0, 0
+    n_dev, n_sub, n_chain, n_both, n_both_long = 0, 0, 0, 0, 0
     for seed in (300, 301, 302, 303):
         rng = np.random.default_rng(seed)
         hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))].tobytes() for n in (0, 3, 200, 5000)]
@@ -429,10 +429,20 @@ def test_wide_fuzz_host_and_twins(oracle):
                 n_chain += bool(flags & 16)
                 for hay in hays:
                     exp = o.find_all_index(hay).tolist()
+                    if rx.strategy == "UseBoth":
+                        # the reference restarts its PikeVM 100 bytes before the DFA's end: plain leftmost-first unless a
+                        # match is longer than that — then the kernels raise error bit 64 (CXG_E_INPUT), checked on the GPU
+                        plain = o.find_all_submatch_index(hay)[:, :2]
+                        assert (flags & 128), pat
+                        if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100:
+                            n_both_long += 1
+                            assert emu.find_all(blob, hay).tolist() == plain.tolist(), (pat, len(hay))
+                            continue
+                        n_both += 1
                     if rx.strategy != "UseCharClassSearcher":
                         assert emu.find_all(blob, hay).tolist() == exp, (pat, rx.strategy, len(hay))
                     twins = []
-                    if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter"):
+                    if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter", "UseBoth"):
                         twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
                     elif rx.strategy == "UseTeddy":
                         twins = [emu.find_all_teddy_wave(blob, hay)]
@@ -448,7 +458,7 @@ def test_wide_fuzz_host_and_twins(oracle):
                     exp = o.find_all_submatch_index(hay)
                     got = emu.find_all_submatch(sb, cb, hay, exp.shape[1])
                     assert got.shape == exp.shape and np.array_equal(got, exp), (pat, "submatch", len(hay))
-    assert n_dev >= 200 and n_sub >= 30 and n_chain >= 20, (n_dev, n_sub, n_chain)
+    assert n_dev >= 200 and n_sub >= 30 and n_chain >= 20 and n_both >= 20 and n_both_long >= 1, (n_dev, n_sub, n_chain, n_both, n_both_long)
 
 
 def test_emulated_no_sync_bytes_at_all(oracle):
