@@ -14,7 +14,7 @@ atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?",
          "(?:a|b|c)+", "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
-alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff", dtype=np.uint8)
 T = 3840
 def rnd(n, p=None):
     return alphabet[rng.integers(0, len(alphabet), size=int(n))] if p is None else alphabet[rng.choice(len(alphabet), size=int(n), p=p)]
