@@ -318,6 +318,8 @@ def test_random_patterns(need_gpu, oracle):
              alphabet[rng.choice(len(alphabet), size=30000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))],
              np.frombuffer((b"xyab" + b"." * 28) * 2000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 5000, dtype=np.uint8),
              np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 1000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
+    wide = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff", dtype=np.uint8)      # NUL, DEL, bytes >= 0x80 (SWAR class tests)
+    hays.insert(5, wide[rng.integers(0, len(wide), size=20000)])
     seen, n_ok, n_sub, strategies, n_both_refused = set(), 0, 0, set(), 0
     while len(seen) < 220:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
