@@ -158,7 +158,10 @@ class Regex:
                 cap = int(got.value)
                 continue
             _check(rc)
-            return out[: got.value].copy()
+            n_rows = int(got.value)
+            if n_rows * 2 >= cap:
+                return out[:n_rows]                  # a view: copying 100+ MB would cost more than the scan
+            return out[:n_rows].copy()
 
     # --- device-resident haystacks (bench, shards) ---
     def find_all_submatch_device(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1,
