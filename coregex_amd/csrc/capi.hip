@@ -27,7 +27,7 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
-hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, hipStream_t stream);
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
@@ -186,31 +186,39 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
     for (int k = 0; k < 5; k++) q[k] = (a0 + 16u * k + 16u <= lim16) ? *reinterpret_cast<const uint4*>(a0 + 16u * k) : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 5; k++) { slot[4 * k] = q[k].x; slot[4 * k + 1] = q[k].y; slot[4 * k + 2] = q[k].z; slot[4 * k + 3] = q[k].w; }
-    const int64_t staged = s + (80 - static_cast<int64_t>(skew));   // bytes [s, staged) are in the slot
+    // 32-bit loop state (a match is at most window + serial-walk budget long); the staged part and the rare rest of a
+    // long match are separate loops so that the hot one has no global-memory branch
+    const int32_t len = static_cast<int32_t>(e - s);
+    const int32_t nst = len < 80 - static_cast<int32_t>(skew) ? len : 80 - static_cast<int32_t>(skew);
     int32_t v[MAXS];
 #pragma unroll
     for (int k = 0; k < MAXS; k++) v[k] = -1;
     uint32_t ent = ch->start_entry;
-    for (int64_t i = s; i < e; i++) {
-      const uint32_t b = (i < staged) ? slotb[skew + static_cast<uint32_t>(i - s)] : h0[i];
+    int32_t i = 0;
+    auto step = [&](uint32_t b) -> bool {
       const uint32_t t = s_tab[ent * 256u + b];
       const uint32_t nx = t & 0xFFu;
-      if (nx == 0xFFu) { bad = true; break; }
+      if (nx == 0xFFu) return false;
       const uint32_t m = s_masks[t >> 8];
       if (m) {
-        const int32_t rel = static_cast<int32_t>(i - s);
 #pragma unroll
-        for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = rel;
+        for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = i;
       }
       ent = nx;
+      return true;
+    };
+    const uint8_t* sb = slotb + skew;
+    for (; i < nst; i++) if (!step(sb[i])) { bad = true; break; }
+    if (!bad) {
+      const uint8_t* gb = h0 + s;
+      for (; i < len; i++) if (!step(gb[i])) { bad = true; break; }
     }
     const uint32_t f = s_fin[ent];
     if (f == 0xFFu) bad = true;
     else {
       const uint32_t m = s_masks[f];
-      const int32_t rel = static_cast<int32_t>(e - s);
 #pragma unroll
-      for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = rel;
+      for (int k = 2; k < MAXS; k++) if ((m >> k) & 1u) v[k] = len;
     }
 #pragma unroll
     for (int k = 2; k + 1 < MAXS; k += 2) {
@@ -223,6 +231,18 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
     }
   }
   if (bad) cxgdev::raise_err(err, 4u);
+}
+
+// One resident round of capture workgroups: as many as the LDS footprint lets a CU hold (grid-stride over the rows),
+// so every workgroup stages the table once and all finish together.
+unsigned captureGrid(uint64_t nrows, uint32_t dyn_lds) {
+  const uint32_t lds = 256u * kCapSlotDwords * 4u + 1024u + 64u + dyn_lds;
+  uint32_t per_cu = (160u * 1024u) / lds;
+  if (per_cu > 8u) per_cu = 8u;
+  if (per_cu < 1u) per_cu = 1u;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * per_cu));
 }
 
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
@@ -294,7 +314,11 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
   // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
+  static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
+  bool fusedCaps = false;                                          // captures written by the chain kernel itself
 relaunch:
+  fusedCaps = false;
+  std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
@@ -331,8 +355,12 @@ relaunch:
   else if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     std::memcpy(a.chain, hb + h->aux_off + 256, sizeof(cxgdev::ChainAux));
+    if (submatch && a.out && fuseCapsOk && p->chainCaps[0] && p->chainCaps[1] == a.row_width) {   // ChainCaps.on / .nslots
+      std::memcpy(a.caps, p->chainCaps, sizeof a.caps);
+      fusedCaps = true;
+    }
     le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
-                                        (h->flags & cxgdev::kFlagChainSets) != 0, stream);
+                                        (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
   else switch (h->kind) {
     case cxgdev::kKindDigit:
@@ -349,21 +377,22 @@ relaunch:
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
   uint32_t launches = 1;
-  if (submatch && a.out) {
+  if (submatch && a.out && !fusedCaps) {
     // capture pass: one thread per match row, after the span kernel on the same stream.  The row count is
     // only known on the device, so read it back first (one 8-byte copy).
     if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     uint64_t nrows = s.hostCtl[1];
     if (nrows > a.cap) nrows = a.cap;
+    if (static_cast<uint32_t>(s.hostCtl[2]) & (8u | 2u)) nrows = 0;   // the span kernel asked for a rerun: its rows are not final
     if (nrows) {
       const cxgdev::CapHeader* chh = reinterpret_cast<const cxgdev::CapHeader*>(p->capBlob.data());
       const bool lds_ok = chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
       if (lds_ok && a.row_width <= 8) {
-        const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
+        const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
         hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
       } else if (lds_ok && a.row_width <= 16) {
-        const unsigned grd = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, 256ull * 16));
+        const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
         hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
       } else {
         const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
@@ -613,6 +642,11 @@ int cxg_program_submatch_blobs(const cxg_program* p, const void** sb, size_t* sl
   if (!p->subSupported) return fail(CXG_E_UNSUPPORTED, p->subWhyNot);
   *sb = p->subBlob.data(); *sl = p->subBlob.size(); *cb = p->capBlob.data(); *cl = p->capBlob.size();
   return CXG_OK;
+}
+int cxg_program_chain_captures(const cxg_program* p, uint8_t out[40]) {
+  if (!p || !out || !p->subSupported || !p->chainCaps[0]) return 0;
+  std::memcpy(out, p->chainCaps, 40);
+  return 1;
 }
 int cxg_program_submatch_supported(const cxg_program* p) {
   if (p && !p->subSupported) t_err = p->subWhyNot;

@@ -159,12 +159,15 @@ struct Words4 {
 
 // SETS: some class is a union of ranges (kClsSet); a separate instantiation keeps that code (and its register
 // pressure) out of the kernels of single-range programs.
-template <int NCLS, bool SETS>
-__global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
+// CAP: the rows carry capture slots (ScanArgs::caps, walk.hpp ChainCaps): the ends of up to two runs are compacted
+// next to the starts and ends, and every slot is one of those positions plus a constant.
+template <int NCLS, bool SETS, bool CAP>
+__global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
   __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile
   __shared__ uint16_t s_re[kWavesPerBlock][kWRows];
+  __shared__ uint16_t s_rb[CAP ? 2 : 1][kWavesPerBlock][CAP ? kWRows : 1];   // CAP: ends of the two captured runs
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
   __shared__ uint64_t s_group;
@@ -175,6 +178,9 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
   int lane = lane0;
   if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
   static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
+  static_assert(sizeof(ChainCaps) <= sizeof(a.caps), "ScanArgs::caps too small");
+  const ChainCaps* gcp = reinterpret_cast<const ChainCaps*>(a.caps);   // kernel argument segment: scalar loads
+  const uint32_t cap_op0 = CAP ? gcp->run_op[0] : 0xFFu, cap_op1 = CAP ? gcp->run_op[1] : 0xFFu;
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
   ch.aux = gch;
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
         PHASE_MARK(4);                                              // starts, moved to forward orientation
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
+        uint32_t capcnt0 = 0, capcnt1 = 0;                           // CAP: run ends compacted (wave-uniform)
         const bool fixed_len = ch.op_is_run == 0u;                   // a literal: every match is nops bytes long
         if (fixed_len) {                                            // ends = starts shifted by the length (< 64)
           const uint64_t lower = from_lower64(S);
@@ -369,6 +376,22 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
             const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
             const unsigned long long recv = (PP + (GG << 1)) ^ PP;
             M = add_carry_mask(s1, recv) & ~Ck;
+            if (CAP && (k == cap_op0 || k == cap_op1)) {            // a captured run: its ends, in match order
+              const int x = (k == cap_op0) ? 0 : 1;
+              const uint32_t nm = static_cast<uint32_t>(__popcll(M));
+              const uint32_t incm = wave_inclusive_sum(nm);
+              const uint32_t totm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incm), 63));
+              if (x == 0) capcnt0 = totm; else capcnt1 = totm;
+              uint32_t im = incm - nm;
+              uint64_t mb = M;
+              while (mb) {
+                const int bit = __builtin_ctzll(mb);
+                mb &= mb - 1;
+                const uint32_t r = nrows_w + im;
+                if (r < static_cast<uint32_t>(kWRows)) s_rb[x][wave][r] = static_cast<uint16_t>(64 * lane + bit);
+                im++;
+              }
+            }
           }
         }
         PHASE_MARK(5);                                              // forward chain
@@ -389,6 +412,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
           }
           fallback |= 4; n = 0;
         }
+        if (CAP && n != 0 && ((cap_op0 != 0xFFu && capcnt0 != n) || (cap_op1 != 0xFFu && capcnt1 != n))) { fallback |= 32; n = 0; }   // a marker merged or left the window
         // Both compactions keep the order, so start k and end k land in the same row without ever meeting in
         // a register.  FindAll skips a match that begins inside the previous emitted one (findall.go:267-275):
         // that shows as a start whose rank differs from the number of ends at or before it.
@@ -419,6 +443,7 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
           if (cout && !fixed_len && lane == 0 && nrows_w + (tot >> 16) < static_cast<uint32_t>(kWRows)) s_re[wave][nrows_w + (tot >> 16)] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
         }
         emitted_here = n;
+        if (CAP && __ballot(ov != 0) != 0ull) fallback |= 32;        // dropped rows would have to drop their run ends too: two-kernel path
         if (__ballot(ov != 0) != 0ull && nrows_w + n <= static_cast<uint32_t>(kWRows)) {   // rare: resolve serially, in place
           wave_lds_sync();
           uint32_t kept = 0;
@@ -478,24 +503,49 @@ __global__ __launch_bounds__(kThreads, (SETS ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WA
       if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
         const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
         longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;   // row_width > 2: a capture pass fills the rest
+        int64_t* row = a.out + (dst + i) * a.row_width;
+        *reinterpret_cast<longlong2*>(row) = v;                        // row_width > 2 without CAP: a capture pass fills the rest
+        if (CAP) {
+          const int64_t pos[4] = {v.x, v.y, tb + s_rb[0][wave][r], tb + s_rb[CAP ? 1 : 0][wave][r]};
+          for (uint32_t q = 2; q + 1 < a.row_width && q + 1 < 16u; q += 2) {   // sources and offsets: scalar loads, uniform selects
+            const uint32_t s0 = gcp->src[q], s1 = gcp->src[q + 1];
+            longlong2 o;
+            o.x = s0 == kCapSrcUnset ? -1 : (s0 == 0 ? pos[0] : s0 == 1 ? pos[1] : s0 == 2 ? pos[2] : pos[3]) + gcp->off[q];
+            o.y = s1 == kCapSrcUnset ? -1 : (s1 == 0 ? pos[0] : s1 == 1 ? pos[1] : s1 == 2 ? pos[2] : pos[3]) + gcp->off[q + 1];
+            *reinterpret_cast<longlong2*>(row + q) = o;
+          }
+        }
       }
     }
     start += n;
   }
 }
 
-hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, hipStream_t stream) {
+hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  if (caps) {
+    switch (ncls * 2 + (sets ? 1 : 0)) {
+      case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, true>), grid, block, 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, true>), grid, block, 0, stream, a); break;
+      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, true>), grid, block, 0, stream, a); break;
+      case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, true>), grid, block, 0, stream, a); break;
+      case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, true>), grid, block, 0, stream, a); break;
+      case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, true>), grid, block, 0, stream, a); break;
+      case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, true>), grid, block, 0, stream, a); break;
+      case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, true>), grid, block, 0, stream, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (ncls * 2 + (sets ? 1 : 0)) {
-    case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false>), grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true>), grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false>), grid, block, 0, stream, a); break;
-    case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true>), grid, block, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false>), grid, block, 0, stream, a); break;
-    case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, false>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, false>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, false>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, false>), grid, block, 0, stream, a); break;
+    case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, false>), grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, false>), grid, block, 0, stream, a); break;
+    case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, false>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -57,6 +57,7 @@ struct ScanArgs {
                         // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
   uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)
+  uint8_t caps[40];     // scan_chain_wave.hip CAP instantiations: the program's ChainCaps (walk.hpp); caps[0] == 0: spans only
   uint32_t max_len;     // != 0: a match longer than this raises error bit 64 (UseBoth programs, walk.hpp kFlagBothRestart)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };

@@ -601,11 +601,104 @@ struct CapClosure {
 
 }  // namespace
 
+namespace {
+
+// Captures from chain boundaries.  In a complete ordered chain every step boundary of a match is forced, and the
+// one-pass table stamps a slot on a fixed kind of transition (first byte of a step, a further byte of a run, the
+// end), so a slot is "boundary + constant".  The relation is read off witness matches — every run once with length
+// 1, 2 and several distinct longer lengths — walked through the capture table itself (walk.hpp capture_walk); a slot
+// that is not the same boundary + constant on all of them, or more than two run ends needed, leaves the program on
+// the two-kernel path.
+void deriveChainCaps(const cxgdev::ChainAux& chain, const std::vector<uint8_t>& capBlob, uint32_t nslots, uint8_t out[40]) {
+  std::memset(out, 0, 40);
+  cxgdev::ChainCaps cc;
+  std::memset(&cc, 0, sizeof cc);
+  static_assert(sizeof(cxgdev::ChainCaps) == 40, "ChainCaps layout");
+  if (nslots < 4 || nslots > 16 || chain.nops == 0) return;
+  const cxgdev::CapHeader* ch = reinterpret_cast<const cxgdev::CapHeader*>(capBlob.data());
+  cxgdev::CapView view{capBlob.data() + ch->next_off, capBlob.data() + ch->maskid_off, capBlob.data() + ch->fin_off,
+                       reinterpret_cast<const uint32_t*>(capBlob.data() + ch->masks_off), ch->n_entries, ch->start_entry};
+  const uint32_t nops = chain.nops;
+  auto repByte = [&](int cls) -> int {
+    for (int b = 0; b < 128; b++) if (cxgdev::chain_class_has(chain, cls, static_cast<uint32_t>(b))) return b;
+    return -1;
+  };
+  static const int kLens[6][8] = {{1, 1, 1, 1, 1, 1, 1, 1}, {2, 2, 2, 2, 2, 2, 2, 2}, {2, 3, 4, 5, 6, 7, 8, 9}, {9, 7, 5, 3, 2, 4, 6, 8},
+                                  {1, 4, 1, 3, 1, 5, 1, 2}, {3, 1, 5, 1, 2, 1, 4, 1}};
+  constexpr int kW = 6;
+  std::vector<std::vector<int64_t>> bnd(kW), slots(kW);
+  for (int w = 0; w < kW; w++) {
+    std::vector<uint8_t> hay;
+    bnd[w].push_back(0);
+    for (uint32_t k = 0; k < nops; k++) {
+      const int b = repByte(chain.op_cls[k]);
+      if (b < 0) return;
+      const int len = chain.op_kind[k] == cxgdev::kChainRun ? kLens[w][k % 8] : 1;
+      hay.insert(hay.end(), static_cast<size_t>(len), static_cast<uint8_t>(b));
+      bnd[w].push_back(static_cast<int64_t>(hay.size()));
+    }
+    std::vector<int64_t> row(nslots, -1);
+    row[0] = 0; row[1] = static_cast<int64_t>(hay.size());
+    hay.resize(hay.size() + 8, 0);
+    if (!cxgdev::capture_walk(view, hay.data(), row.data(), nslots)) return;
+    slots[w] = row;
+  }
+  // sources: boundary 0 (start), boundary nops (end), boundary k+1 of every run step k
+  cc.run_op[0] = cc.run_op[1] = 0xFF;
+  auto runSource = [&](uint32_t k) -> int {           // allocate / find the compaction slot of run step k
+    for (int i = 0; i < 2; i++) if (cc.run_op[i] == k) return i;
+    for (int i = 0; i < 2; i++) if (cc.run_op[i] == 0xFF) { cc.run_op[i] = static_cast<uint8_t>(k); return i; }
+    return -1;
+  };
+  for (uint32_t sl = 0; sl < nslots; sl++) {
+    bool allUnset = true, anyUnset = false;
+    for (int w = 0; w < kW; w++) { if (slots[w][sl] < 0) anyUnset = true; else allUnset = false; }
+    if (allUnset) { cc.src[sl] = cxgdev::kCapSrcUnset; cc.off[sl] = 0; continue; }
+    if (anyUnset) return;
+    bool found = false;
+    // candidate boundaries: start, end, then run ends; the consistent one with the smallest constant wins (a literal's
+    // witnesses are all the same string, so several boundaries are consistent there)
+    std::vector<uint32_t> cand = {0u, nops};
+    for (uint32_t k = 0; k + 1 < nops; k++) if (chain.op_kind[k] == cxgdev::kChainRun) cand.push_back(k + 1);
+    int64_t bestAbs = 1000; uint32_t bestB = 0; int64_t bestD = 0;
+    for (uint32_t bi : cand) {
+      const int64_t dlt = slots[0][sl] - bnd[0][bi];
+      bool same = dlt >= -8 && dlt <= 8;
+      for (int w = 1; w < kW && same; w++) same = (slots[w][sl] - bnd[w][bi]) == dlt;
+      if (!same) continue;
+      const int64_t ab = dlt < 0 ? -dlt : dlt;
+      const int64_t cost = ab + ((bi != 0 && bi != nops) ? 100 : 0);   // a run end costs a compaction in the kernel: last resort
+      if (cost < bestAbs) { bestAbs = cost; bestB = bi; bestD = dlt; found = true; }
+    }
+    if (found) {
+      uint8_t src;
+      if (bestB == 0) src = cxgdev::kCapSrcStart;
+      else if (bestB == nops) src = cxgdev::kCapSrcEnd;
+      else {
+        const int r = runSource(bestB - 1);
+        if (r < 0) return;
+        src = static_cast<uint8_t>(cxgdev::kCapSrcRun0 + r);
+      }
+      cc.src[sl] = src; cc.off[sl] = static_cast<int8_t>(bestD);
+    }
+    if (!found) return;
+  }
+  if (cc.src[0] != cxgdev::kCapSrcStart || cc.off[0] != 0 || cc.src[1] != cxgdev::kCapSrcEnd || cc.off[1] != 0) return;
+  cc.on = 1;
+  cc.nslots = static_cast<uint8_t>(nslots);
+  std::memcpy(out, &cc, sizeof cc);
+}
+
+}  // namespace
+
 void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
   p->subSupported = false;
   try {
     if (nfa.capture_count > 16) throw BuildError{CXG_E_UNSUPPORTED, "more than 15 capture groups"};
     if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+    cxgdev::ChainAux spanChain;                   // set when the spans come from the chain kernel
+    std::memset(&spanChain, 0, sizeof spanChain);
+    std::memset(p->chainCaps, 0, sizeof p->chainCaps);
     // ---- spans: unanchored forward + reverse DFA (the bidirectional image of buildProgramFromNfa)
     Dfa fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
     if (fwd.start >= fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
@@ -647,6 +740,7 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
           blob.insert(blob.end(), cb, cb + sizeof chain);
           while (blob.size() % 16) blob.push_back(0);
           h.aux_len = static_cast<uint32_t>(blob.size()) - h.aux_off;
+          spanChain = chain;
         }
       } catch (const BuildError&) {}
       h.total_bytes = static_cast<uint32_t>(blob.size());
@@ -712,6 +806,7 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
     ch.total_bytes = static_cast<uint32_t>(cb.size());
     std::memcpy(cb.data(), &ch, sizeof ch);
     p->capBlob.swap(cb);
+    if (spanChain.nops) deriveChainCaps(spanChain, p->capBlob, nfa.capture_count * 2, p->chainCaps);
     p->subSupported = true;
   } catch (const BuildError& e) {
     p->subWhyNot = e.msg;

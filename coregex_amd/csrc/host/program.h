@@ -53,6 +53,7 @@ struct cxg_program {
   std::string subWhyNot;
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
+  uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
   // device copies, one per device, created on first use (capi.hip)
   void* dev[16] = {nullptr};
   void* devSub[16] = {nullptr};

@@ -125,6 +125,10 @@ int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
 /* Images used by the FindAllSubmatch path: bidirectional-DFA span program + one-pass capture table. */
 int cxg_program_submatch_blobs(const cxg_program* p, const void** span_blob, size_t* span_len,
                                const void** cap_blob, size_t* cap_len);
+/* Diagnostics: the 40-byte ChainCaps record (device/walk.hpp) of a FindAllSubmatch program whose capture slots are
+ * written by the chain kernel itself (slot = match start / match end / end of one of two runs, plus a constant).
+ * Returns 1 and fills out[40] when the program has one, 0 otherwise (captures then come from the one-pass table). */
+int cxg_program_chain_captures(const cxg_program* p, uint8_t out[40]);
 int cxg_program_submatch_supported(const cxg_program* p);
 /* Host-side copy of the NFA a program was compiled from (cxg_compile only); pointers live as long as p. */
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);

@@ -475,13 +475,15 @@ def test_device_resident_corpus_64mib(need_gpu, oracle, cfg, pat):
 def test_find_all_submatch_index(need_gpu, oracle):
     """BASELINE config 5: `(\\w+)@(\\w+)\\.(\\w+)` FindAllSubmatchIndex, rows of 2*groups int64, -1 unset."""
     import torch
-    pats = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a)(b)?c", r"(\w+)=(\d+)", r"((a+)(b+))"]
+    pats = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a)(b)?c", r"(\w+)=(\d+)", r"((a+)(b+))", r"([a-z]+)=(\d+)", r"(ab)c(d)",
+            r"x(\d+)y(\d+)z", r"([a-z])+@", r"(\d+)-(\d+)"]
     corpus = generate_test_input()
     for pat in pats:
         rx = cx.compile(pat)
         assert rx.submatch_supported, pat
         o = oracle.Regex(pat)
-        for hay in (corpus, b"", b"a@b.c x@y.z", b"abc ac bc abcabc", b"k=1 kk=22;zz=x"):
+        for hay in (corpus, b"", b"a@b.c x@y.z", b"abc ac bc abcabc", b"k=1 kk=22;zz=x", b"x1y22z abcd a@ ab@ 10-20 " * 400,
+                    cx.synth_pages(5, 0xC0FFEE05, 7, 96), cx.synth_pages(2, 0xC0FFEE02, 7, 96)):
             exp = o.find_all_submatch_index(hay)
             got = rx.find_all_submatch_index(hay)
             assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:40])
@@ -499,5 +501,5 @@ def test_find_all_submatch_index(need_gpu, oracle):
     out = torch.empty((n + 4, 8), dtype=torch.int64, device="cuda")
     t = cx.Timing()
     n2 = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), n + 4, timing=t)
-    assert n2 == n and t.n_launches == 2
+    assert n2 == n and t.n_launches == 1          # the chain kernel writes the capture slots itself (ChainCaps)
     assert np.array_equal(out[:n].cpu().numpy(), exp)

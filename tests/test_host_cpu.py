@@ -461,6 +461,70 @@ def test_wide_fuzz_host_and_twins(oracle):
     assert n_dev >= 200 and n_sub >= 30 and n_chain >= 20 and n_both >= 20 and n_both_long >= 1, (n_dev, n_sub, n_chain, n_both, n_both_long)
 
 
+def _chain_of(span_blob):
+    """ChainAux (walk.hpp) of a span program: [(is_run, membership[256])]."""
+    import struct
+    aux_off = struct.unpack_from("<I", span_blob, 56)[0]
+    raw = span_blob[aux_off + 256:aux_off + 256 + 88]
+    nops, ncls = struct.unpack_from("<II", raw, 0)
+    op_kind, op_cls = raw[8:24], raw[24:40]
+    cls_kind, cls_lo, cls_hi, cls_nr = raw[40:44], raw[44:48], raw[48:52], raw[52:56]
+    rlo, rhi = raw[56:72], raw[72:88]
+    members = []
+    for c in range(ncls):
+        m = np.zeros(256, dtype=bool)
+        if cls_kind[c] == 0:
+            m[0x30:0x3A] = True
+        elif cls_kind[c] == 3:
+            for r in range(cls_nr[c]):
+                m[rlo[4 * c + r]:rhi[4 * c + r] + 1] = True
+        else:
+            m[cls_lo[c]:cls_hi[c] + 1] = True
+        members.append(m)
+    return [(op_kind[k] == 1, members[op_cls[k]]) for k in range(nops)]      # kChainRun == 1
+
+
+def test_chain_captures_mapping(oracle):
+    """Captures straight from the chain kernel (program.cc deriveChainCaps): every slot of every oracle row equals
+    match start / match end / the end of one of two runs, plus the derived constant — the boundaries recomputed here
+    by walking the chain steps greedily from the match start."""
+    corpus = generate_test_input()
+    n_on = 0
+    cases = [(r"(\w+)@(\w+)\.(\w+)", 5), (r"([a-z]+)=(\d+)", 5), (r"((a+)(b+))", 2), (r"(ab)c(d)", 1), (r"(a)(b)c", 1), (r"x(\d+)y(\d+)z", 2),
+             (r"([a-z])+@", 5), (r"(\d+)-(\d+)", 2), (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", 2), (r"(\w+)=(\d+)", 5), (r"(GET|POST) (\w+)", 2)]
+    for pat, cfg in cases:
+        rx = cx.compile(pat)
+        assert rx.submatch_supported, pat
+        caps = rx.chain_captures()
+        if pat in (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(\w+)=(\d+)", r"(GET|POST) (\w+)"):
+            assert caps is None, pat           # three run ends / chain not restart-safe / not a chain: two-kernel path
+            continue
+        assert caps is not None, pat
+        n_on += 1
+        chain = _chain_of(rx.submatch_blobs()[0])
+        o = oracle.Regex(pat)
+        synth = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 3, 24).tobytes()
+        extra = b"aab abb ab xaab abcd abc x1y22z x12y3z k@l a@ ab@ 10-20 1-2 foo=12 a@b.c aa@bb.cc "
+        for hay in (corpus, synth, extra * 3):
+            h = np.frombuffer(hay, dtype=np.uint8)
+            rows = o.find_all_submatch_index(hay)
+            for row in rows[:4000]:
+                s, e = int(row[0]), int(row[1])
+                pos, run_end = s, {}
+                for k, (is_run, member) in enumerate(chain):
+                    assert pos < len(h) and member[h[pos]], (pat, s, k)
+                    pos += 1
+                    while is_run and pos < len(h) and member[h[pos]]:
+                        pos += 1
+                    run_end[k] = pos
+                assert pos == e, (pat, s, e, pos)
+                src_pos = {0: s, 1: e, 2: run_end.get(caps["run_op"][0]), 3: run_end.get(caps["run_op"][1])}
+                for q, (src, off) in enumerate(caps["slots"]):
+                    exp = -1 if src == 7 else src_pos[src] + off
+                    assert int(row[q]) == exp, (pat, s, q, int(row[q]), exp)
+    assert n_on >= 8
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
