@@ -119,13 +119,13 @@ class Regex:
 
     def chain_captures(self):
         """None, or the ChainCaps record of a program whose capture slots are written by the chain kernel itself:
-        dict(run_op=(a, b), slots=[(source, offset), ...]) with source 0 start, 1 end, 2/3 end of run a/b, 7 unset."""
+        dict(run_op=(a, b, ...), slots=[(source, offset), ...]) with source 0 start, 1 end, 2 + i end of run_op[i], 7 unset."""
         buf = C.create_string_buffer(40)
         if not _lib.lib().cxg_program_chain_captures(self._h, buf):
             return None
         raw = buf.raw
         n = raw[1]
-        return {"run_op": (raw[2], raw[3]), "slots": [(raw[4 + k], int.from_bytes(raw[20 + k:21 + k], "little", signed=True)) for k in range(n)]}
+        return {"run_op": tuple(raw[4:4 + raw[2]]), "slots": [(raw[8 + k], int.from_bytes(raw[24 + k:25 + k], "little", signed=True)) for k in range(n)]}
 
     def blob(self) -> bytes:
         p, n = C.c_void_p(), C.c_size_t()

@@ -159,15 +159,15 @@ struct Words4 {
 
 // SETS: some class is a union of ranges (kClsSet); a separate instantiation keeps that code (and its register
 // pressure) out of the kernels of single-range programs.
-// CAP: the rows carry capture slots (ScanArgs::caps, walk.hpp ChainCaps): the ends of up to two runs are compacted
-// next to the starts and ends, and every slot is one of those positions plus a constant.
+// CAP: the rows carry capture slots (ScanArgs::caps, walk.hpp ChainCaps): the ends of up to four runs are compacted
+// next to the starts and ends (dynamic LDS, 4 KiB per run), and every slot is one of those positions plus a constant.
 template <int NCLS, bool SETS, bool CAP>
 __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
   __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile
   __shared__ uint16_t s_re[kWavesPerBlock][kWRows];
-  __shared__ uint16_t s_rb[CAP ? 2 : 1][kWavesPerBlock][CAP ? kWRows : 1];   // CAP: ends of the two captured runs
+  extern __shared__ __attribute__((aligned(16))) uint16_t s_rb[];   // CAP: [nruns][kWavesPerBlock][kWRows] ends of the captured runs
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
   __shared__ uint64_t s_group;
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   static_assert(sizeof(ChainAux) <= sizeof(a.chain), "ScanArgs::chain too small");
   static_assert(sizeof(ChainCaps) <= sizeof(a.caps), "ScanArgs::caps too small");
   const ChainCaps* gcp = reinterpret_cast<const ChainCaps*>(a.caps);   // kernel argument segment: scalar loads
-  const uint32_t cap_op0 = CAP ? gcp->run_op[0] : 0xFFu, cap_op1 = CAP ? gcp->run_op[1] : 0xFFu;
+  uint32_t cap_op[kCapMaxRuns];
+#pragma unroll
+  for (int x = 0; x < kCapMaxRuns; x++) cap_op[x] = CAP ? gcp->run_op[x] : 0xFFu;
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
   ch.aux = gch;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
         PHASE_MARK(4);                                              // starts, moved to forward orientation
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
-        uint32_t capcnt0 = 0, capcnt1 = 0;                           // CAP: run ends compacted (wave-uniform)
+        uint32_t capcnt[kCapMaxRuns] = {0, 0, 0, 0};                  // CAP: run ends compacted (wave-uniform)
         const bool fixed_len = ch.op_is_run == 0u;                   // a literal: every match is nops bytes long
         if (fixed_len) {                                            // ends = starts shifted by the length (< 64)
           const uint64_t lower = from_lower64(S);
@@ -376,20 +378,22 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
             const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
             const unsigned long long recv = (PP + (GG << 1)) ^ PP;
             M = add_carry_mask(s1, recv) & ~Ck;
-            if (CAP && (k == cap_op0 || k == cap_op1)) {            // a captured run: its ends, in match order
-              const int x = (k == cap_op0) ? 0 : 1;
-              const uint32_t nm = static_cast<uint32_t>(__popcll(M));
-              const uint32_t incm = wave_inclusive_sum(nm);
-              const uint32_t totm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incm), 63));
-              if (x == 0) capcnt0 = totm; else capcnt1 = totm;
-              uint32_t im = incm - nm;
-              uint64_t mb = M;
-              while (mb) {
-                const int bit = __builtin_ctzll(mb);
-                mb &= mb - 1;
-                const uint32_t r = nrows_w + im;
-                if (r < static_cast<uint32_t>(kWRows)) s_rb[x][wave][r] = static_cast<uint16_t>(64 * lane + bit);
-                im++;
+            if (CAP) {
+#pragma unroll
+              for (int x = 0; x < kCapMaxRuns; x++) {
+                if (k != cap_op[x]) continue;                          // a captured run: its ends, in match order
+                const uint32_t nm = static_cast<uint32_t>(__popcll(M));
+                const uint32_t incm = wave_inclusive_sum(nm);
+                capcnt[x] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incm), 63));
+                uint32_t im = incm - nm;
+                uint64_t mb = M;
+                while (mb) {
+                  const int bit = __builtin_ctzll(mb);
+                  mb &= mb - 1;
+                  const uint32_t r = nrows_w + im;
+                  if (r < static_cast<uint32_t>(kWRows)) s_rb[(x * kWavesPerBlock + wave) * kWRows + r] = static_cast<uint16_t>(64 * lane + bit);
+                  im++;
+                }
               }
             }
           }
@@ -412,7 +416,11 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
           }
           fallback |= 4; n = 0;
         }
-        if (CAP && n != 0 && ((cap_op0 != 0xFFu && capcnt0 != n) || (cap_op1 != 0xFFu && capcnt1 != n))) { fallback |= 32; n = 0; }   // a marker merged or left the window
+        if (CAP && n != 0) {
+#pragma unroll
+          for (int x = 0; x < kCapMaxRuns; x++) if (cap_op[x] != 0xFFu && capcnt[x] != n) fallback |= 32;   // a marker merged or left the window
+          if (fallback & 32) n = 0;
+        }
         // Both compactions keep the order, so start k and end k land in the same row without ever meeting in
         // a register.  FindAll skips a match that begins inside the previous emitted one (findall.go:267-275):
         // that shows as a start whose rank differs from the number of ends at or before it.
@@ -506,12 +514,15 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
         int64_t* row = a.out + (dst + i) * a.row_width;
         *reinterpret_cast<longlong2*>(row) = v;                        // row_width > 2 without CAP: a capture pass fills the rest
         if (CAP) {
-          const int64_t pos[4] = {v.x, v.y, tb + s_rb[0][wave][r], tb + s_rb[CAP ? 1 : 0][wave][r]};
-          for (uint32_t q = 2; q + 1 < a.row_width && q + 1 < 16u; q += 2) {   // sources and offsets: scalar loads, uniform selects
-            const uint32_t s0 = gcp->src[q], s1 = gcp->src[q + 1];
+          auto slot = [&](uint32_t sc, int32_t of) -> int64_t {       // source and offset: scalar loads, uniform selects
+            if (sc == kCapSrcUnset) return -1;
+            const int64_t ps = sc == kCapSrcStart ? v.x : sc == kCapSrcEnd ? v.y : tb + s_rb[((sc - kCapSrcRun0) * kWavesPerBlock + wave) * kWRows + r];
+            return ps + of;
+          };
+          for (uint32_t q = 2; q + 1 < a.row_width && q + 1 < 16u; q += 2) {
             longlong2 o;
-            o.x = s0 == kCapSrcUnset ? -1 : (s0 == 0 ? pos[0] : s0 == 1 ? pos[1] : s0 == 2 ? pos[2] : pos[3]) + gcp->off[q];
-            o.y = s1 == kCapSrcUnset ? -1 : (s1 == 0 ? pos[0] : s1 == 1 ? pos[1] : s1 == 2 ? pos[2] : pos[3]) + gcp->off[q + 1];
+            o.x = slot(gcp->src[q], gcp->off[q]);
+            o.y = slot(gcp->src[q + 1], gcp->off[q + 1]);
             *reinterpret_cast<longlong2*>(row + q) = o;
           }
         }
@@ -524,15 +535,16 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   if (caps) {
+    const size_t dyn = static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t);
     switch (ncls * 2 + (sets ? 1 : 0)) {
-      case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, true>), grid, block, 0, stream, a); break;
-      case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, true>), grid, block, 0, stream, a); break;
-      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, true>), grid, block, 0, stream, a); break;
-      case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, true>), grid, block, 0, stream, a); break;
-      case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, true>), grid, block, 0, stream, a); break;
-      case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, true>), grid, block, 0, stream, a); break;
-      case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, true>), grid, block, 0, stream, a); break;
-      case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, true>), grid, block, 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, true>), grid, block, dyn, stream, a); break;
+      case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, true>), grid, block, dyn, stream, a); break;
+      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, true>), grid, block, dyn, stream, a); break;
+      case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, true>), grid, block, dyn, stream, a); break;
+      case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, true>), grid, block, dyn, stream, a); break;
+      case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, true>), grid, block, dyn, stream, a); break;
+      case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, true>), grid, block, dyn, stream, a); break;
+      case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, true>), grid, block, dyn, stream, a); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -567,15 +567,17 @@ struct CapView {
 
 // Captures of a chain program straight from the chain kernel (scan_chain_wave.hip, CAP instantiations): every
 // boundary between chain steps is forced, so slot k of a match is one of the positions the kernel compacts anyway —
-// match start, match end, or the end of one of up to two runs — plus a small constant (program.cc deriveChainCaps).
-constexpr uint8_t kCapSrcStart = 0, kCapSrcEnd = 1, kCapSrcRun0 = 2, kCapSrcRun1 = 3, kCapSrcUnset = 7;
+// match start, match end, or the end of one of up to four runs — plus a small constant (program.cc deriveChainCaps).
+constexpr uint8_t kCapSrcStart = 0, kCapSrcEnd = 1, kCapSrcRun0 = 2, kCapSrcUnset = 7;   // Run0 + i: end of captured run i
+constexpr int kCapMaxRuns = 4;
 struct ChainCaps {            // 40 bytes, travels in ScanArgs
   uint8_t on;                 // 1: valid for this program
   uint8_t nslots;             // 2 * groups (<= 16)
-  uint8_t run_op[2];          // chain step (a run) whose end positions are compacted as Run0 / Run1; 0xFF: unused
+  uint8_t nruns;              // run ends the kernel compacts (0..4): 4 KiB of LDS each
+  uint8_t pad;
+  uint8_t run_op[kCapMaxRuns];  // chain step (a run) whose end positions are compacted as run i; 0xFF: unused
   uint8_t src[16];            // per slot: kCapSrc*
   int8_t off[16];             // per slot: added to the source position
-  uint8_t pad[4];
 };
 
 struct CapHeader {          // device image: header then the arrays, offsets from the header start

@@ -607,7 +607,7 @@ namespace {
 // one-pass table stamps a slot on a fixed kind of transition (first byte of a step, a further byte of a run, the
 // end), so a slot is "boundary + constant".  The relation is read off witness matches — every run once with length
 // 1, 2 and several distinct longer lengths — walked through the capture table itself (walk.hpp capture_walk); a slot
-// that is not the same boundary + constant on all of them, or more than two run ends needed, leaves the program on
+// that is not the same boundary + constant on all of them, or more than four run ends needed, leaves the program on
 // the two-kernel path.
 void deriveChainCaps(const cxgdev::ChainAux& chain, const std::vector<uint8_t>& capBlob, uint32_t nslots, uint8_t out[40]) {
   std::memset(out, 0, 40);
@@ -644,10 +644,10 @@ void deriveChainCaps(const cxgdev::ChainAux& chain, const std::vector<uint8_t>& 
     slots[w] = row;
   }
   // sources: boundary 0 (start), boundary nops (end), boundary k+1 of every run step k
-  cc.run_op[0] = cc.run_op[1] = 0xFF;
+  for (int i = 0; i < cxgdev::kCapMaxRuns; i++) cc.run_op[i] = 0xFF;
   auto runSource = [&](uint32_t k) -> int {           // allocate / find the compaction slot of run step k
-    for (int i = 0; i < 2; i++) if (cc.run_op[i] == k) return i;
-    for (int i = 0; i < 2; i++) if (cc.run_op[i] == 0xFF) { cc.run_op[i] = static_cast<uint8_t>(k); return i; }
+    for (int i = 0; i < cxgdev::kCapMaxRuns; i++) if (cc.run_op[i] == k) return i;
+    for (int i = 0; i < cxgdev::kCapMaxRuns; i++) if (cc.run_op[i] == 0xFF) { cc.run_op[i] = static_cast<uint8_t>(k); cc.nruns = static_cast<uint8_t>(i + 1); return i; }
     return -1;
   };
   for (uint32_t sl = 0; sl < nslots; sl++) {

@@ -496,8 +496,8 @@ def test_chain_captures_mapping(oracle):
         rx = cx.compile(pat)
         assert rx.submatch_supported, pat
         caps = rx.chain_captures()
-        if pat in (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(\w+)=(\d+)", r"(GET|POST) (\w+)"):
-            assert caps is None, pat           # three run ends / chain not restart-safe / not a chain: two-kernel path
+        if pat in (r"(\w+)=(\d+)", r"(GET|POST) (\w+)"):
+            assert caps is None, pat           # chain not restart-safe / not a chain: two-kernel path
             continue
         assert caps is not None, pat
         n_on += 1
@@ -518,7 +518,8 @@ def test_chain_captures_mapping(oracle):
                         pos += 1
                     run_end[k] = pos
                 assert pos == e, (pat, s, e, pos)
-                src_pos = {0: s, 1: e, 2: run_end.get(caps["run_op"][0]), 3: run_end.get(caps["run_op"][1])}
+                src_pos = {0: s, 1: e}
+                src_pos.update({2 + i: run_end[op] for i, op in enumerate(caps["run_op"])})
                 for q, (src, off) in enumerate(caps["slots"]):
                     exp = -1 if src == 7 else src_pos[src] + off
                     assert int(row[q]) == exp, (pat, s, q, int(row[q]), exp)
