@@ -200,7 +200,7 @@ def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
     assert np.array_equal(got, oracle.Regex(pats[0]).find_all_index(hay))
 
 
-@pytest.mark.parametrize("env", [{"CXG_TICKETS": "1"}, {"CXG_NO_EPOCH": "1"}, {"CXG_DIGIT_KERNEL": "5"}, {"CXG_DIGIT_KERNEL": "2"},
+@pytest.mark.parametrize("env", [{"CXG_TICKETS": "1"}, {"CXG_NO_EPOCH": "1"}, {"CXG_DIGIT_KERNEL": "5"}, {"CXG_DIGIT_KERNEL": "2"}, {"CXG_NO_FUSED_CAPTURES": "1"},
                                  {"CXG_TEDDY_KERNEL": "1", "CXG_CC_KERNEL": "1"}])
 def test_alternative_kernel_modes(need_gpu, env):
     """The modes behind the defaults (ticket atomics instead of static groups, zeroed status words instead of epochs,
@@ -216,6 +216,8 @@ def test_alternative_kernel_modes(need_gpu, env):
         "    hay = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 2, 96)\n"
         "    got = cx.compile(pat).find_all_index(hay)\n"
         "    out.append('%%d:%%08x' %% (len(got), zlib.crc32(got.tobytes())))\n"
+        "got = cx.compile(r'(\\w+)@(\\w+)\\.(\\w+)').find_all_submatch_index(cx.synth_pages(5, 0xC0FFEE05, 2, 96))\n"
+        "out.append('%%d:%%08x' %% (len(got), zlib.crc32(got.tobytes())))\n"
         "print(' '.join(out))\n" % root)
     base = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
     alt = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
@@ -482,7 +484,7 @@ def test_find_all_submatch_index(need_gpu, oracle):
         rx = cx.compile(pat)
         assert rx.submatch_supported, pat
         o = oracle.Regex(pat)
-        for hay in (corpus, b"", b"a@b.c x@y.z", b"abc ac bc abcabc", b"k=1 kk=22;zz=x", b"x1y22z abcd a@ ab@ 10-20 " * 400,
+        for hay in (corpus, b"", b"a@b.c x@y.z", b"abc ac bc abcabc", b"k=1 kk=22;zz=x", b"x1y22z abcd a@ ab@ 10-20 " * 400, b"1.2.3.4.5.6.7.8.9 aabbaabb 1.2.3.4 " * 300,   # overlapping candidates: the CAP kernel hands over
                     cx.synth_pages(5, 0xC0FFEE05, 7, 96), cx.synth_pages(2, 0xC0FFEE02, 7, 96)):
             exp = o.find_all_submatch_index(hay)
             got = rx.find_all_submatch_index(hay)
