@@ -79,6 +79,8 @@ struct Scratch {
   uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
   uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
+  uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
+  int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
 };
 thread_local Scratch t_scratch[16];
 
@@ -471,6 +473,9 @@ __global__ void k_fill_synth(uint8_t* dst, uint64_t npages, uint32_t config, uin
 
 // Host-memory haystack (what the cgo shim passes): H2D copy into the call's scratch buffer, the device scan,
 // D2H copy of the rows.  No CPU compute path exists in this library.
+constexpr uint64_t kZeroCopyHay = 256ull << 10;     // bytes of haystack served from pinned host memory
+constexpr uint64_t kZeroCopyVals = 128ull << 10;    // int64 values of rows written to pinned host memory (1 MiB)
+
 int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
              uint64_t* n_out, int width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
@@ -481,6 +486,29 @@ int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64
   Scratch* sp;
   if (int rc = getScratch(&sp)) return rc;
   Scratch& s = *sp;
+  // Small haystacks: two hipMemcpy calls cost more than the scan.  Stage the bytes in pinned host memory with a plain
+  // memcpy, let the kernels read them over PCIe and write the rows into pinned host memory: one launch + one sync.
+  static const bool zeroCopyOk = getenv("CXG_NO_ZERO_COPY") == nullptr;
+  if (zeroCopyOk && len <= kZeroCopyHay) {
+    if (!s.pinHay) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.pinHay), kZeroCopyHay + 4096, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.pinOut), kZeroCopyVals * sizeof(int64_t), hipHostMallocDefault));
+    }
+    std::memcpy(s.pinHay, hay, len);
+    std::memset(s.pinHay + len, 0, 64);
+    uint64_t want = rows ? cap : 0;
+    if (limit > 0 && static_cast<uint64_t>(limit) < want) want = static_cast<uint64_t>(limit);
+    if (want > kZeroCopyVals / static_cast<uint64_t>(width)) want = kZeroCopyVals / static_cast<uint64_t>(width);
+    uint64_t n = 0;
+    const int rc = scanDevice(p, s.pinHay, len, 0, limit, rows ? s.pinOut : nullptr, want, &n, nullptr, nullptr, width);
+    if (rc == CXG_OK) {
+      if (n_out) *n_out = n;
+      if (rows && n) std::memcpy(rows, s.pinOut, n * width * sizeof(int64_t));
+      return CXG_OK;
+    }
+    if (rc != CXG_E_CAPACITY || want >= cap) { if (n_out) *n_out = n; return rc; }
+    // more rows than the pinned array holds and the caller has room for them: the copying path below
+  }
   if (len + 64 > s.hayCap) {
     if (s.hay) HIP_TRY(hipFree(s.hay));
     s.hay = nullptr; s.hayCap = 0;
