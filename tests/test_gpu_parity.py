@@ -434,6 +434,44 @@ def test_capacity_and_limit(need_gpu):
     assert rc == 0 and got.value == 2 and out.tolist() == [[0, 2], [3, 5]]
 
 
+def test_concurrent_callers_share_programs(need_gpu, oracle):
+    """SearchState analogue (meta/search_state.go:23-140): a compiled program is immutable and shareable, every calling
+    thread has its own stream and scratch.  Eight threads hammer five shared programs (all kernel families, host and
+    zero-copy paths, limits) and every answer equals the oracle's."""
+    import threading
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal|critical", r"[\w]+", r"error", r"(\w+)@(\w+)\.(\w+)"]
+    progs = [cx.compile(p) for p in pats]
+    hays = [cx.synth_pages(c, 0xC0FFEE00 + c, 11, n) for c, n in ((2, 16), (3, 300), (4, 40), (1, 700), (5, 100))]
+    exp = [[oracle.Regex(p).find_all_index(h) for h in hays] for p in pats]
+    exp_sub = [oracle.Regex(pats[4]).find_all_submatch_index(h) for h in hays]
+    errors = []
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for _ in range(60):
+                pi, hi = int(rng.integers(0, len(pats))), int(rng.integers(0, len(hays)))
+                mode = int(rng.integers(0, 4))
+                if mode == 0:
+                    assert np.array_equal(progs[pi].find_all_index(hays[hi]), exp[pi][hi]), (pats[pi], hi)
+                elif mode == 1:
+                    assert progs[pi].count(hays[hi]) == len(exp[pi][hi]), (pats[pi], hi)
+                elif mode == 2:
+                    k = 1 + int(rng.integers(0, 50))
+                    assert np.array_equal(progs[pi].find_all_index(hays[hi], k), exp[pi][hi][:k]), (pats[pi], hi, k)
+                else:
+                    assert np.array_equal(progs[4].find_all_submatch_index(hays[hi]), exp_sub[hi]), hi
+        except Exception as ex:                      # noqa: BLE001 - reported from the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(100 + i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_synth_corpus_device_equals_host_twin(need_gpu):
     for cfg in (1, 2, 3, 4, 5):
         buf = cx.DeviceBuffer(64 * 4096)
