@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   ChainRegs<NCLS, SETS> ch;
   ch.aux = gch;
   ch.nops = gch->nops;
+  const bool restart_check = __builtin_amdgcn_readfirstlane(static_cast<int>(gch->restart_check)) != 0;
   ch.op_is_run = 0; ch.op_cls2 = 0;
 #pragma unroll
   for (int k = 0; k < kChainMaxOps; k++) {
@@ -397,6 +398,12 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
               }
             }
           }
+        }
+        if (restart_check && lead_run) {                            // a match that ends inside a run of the first class: FindAll would
+          const uint64_t A = F.pick<NCLS>(lead_cls);                 // resume there, mid-run — not a run start.  Rare; the table kernel takes over.
+          uint64_t lowA = from_lower64(A) >> 63;
+          if (lane == 0) lowA = 0ull;
+          if (__ballot((M & A & ((A << 1) | lowA)) != 0ull) != 0ull) fallback |= 64;
         }
         PHASE_MARK(5);                                              // forward chain
         // ---- P: ranks of starts and ends, (start, end) pairs

@@ -419,6 +419,10 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t cls_nr[kChainMaxCls];                       // kClsSet: number of ranges, then the ranges
   uint8_t cls_rlo[kChainMaxCls][kChainMaxRanges];
   uint8_t cls_rhi[kChainMaxCls][kChainMaxRanges];
+  uint8_t restart_check;        // the chain begins with a run and a match may end INSIDE a run of that class (last class meets the
+                                // first): FindAll would resume there, which run-start candidates cannot express — the kernel hands
+                                // the scan over when it sees such an end (program.cc extractChain)
+  uint8_t pad[7];
 };
 constexpr uint32_t kFlagBothRestart = 128u;    // UseBoth program: the reference restarts its PikeVM 100 bytes before the DFA's match end
                                                 // (find_indices.go:425-431) — identical to leftmost-first unless a match is longer than that

@@ -415,7 +415,9 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
   // match, so a match may also start INSIDE a run of the first class when the previous match ended there
   // (`z+\.\w\w` on "z.azz.bc": [0,4] then [4,8]).  That needs the last byte of a match to be in the first class
   // with another first-class byte behind it: excluded when the last class misses the first class, or when the chain
-  // ends with a run whose class covers the first class (the match then stops at a byte outside both).
+  // ends with a run whose class covers the first class (the match then stops at a byte outside both).  Otherwise the
+  // chain kernel looks for such an end in every tile (rare in real text: `key=12next=3`) and hands the scan to the
+  // table-walking kernel when it finds one.
   if (chain.nops >= 1 && chain.op_kind[0] == cxgdev::kChainRun) {
     const int first = chain.op_cls[0], last = chain.op_cls[chain.nops - 1];
     bool meet = false, firstOutsideLast = false;
@@ -425,7 +427,7 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
       firstOutsideLast = firstOutsideLast || (inF && !inL);
     }
     const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;
-    if (meet && (!lastRun || firstOutsideLast)) ordered = false;
+    if (meet && (!lastRun || firstOutsideLast)) chain.restart_check = 1;   // exact as long as no match ends inside a first-class run: checked per tile
   }
 }
 

@@ -314,6 +314,9 @@ extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, 
     for (int64_t p = 0; p < N; p++) { if (MW::get(S, p)) sp.push_back(p); if (MW::get(M, p)) ep.push_back(p); }
     if (cout) ep.push_back(N);
     if (sp.size() != ep.size()) reason |= 4;
+    if (ch.restart_check && lead_run)          // a match ending inside a run of the first class: the kernel hands the scan over
+      for (int64_t e : ep)
+        if (e > 0 && e < stage && chain_class_has(ch, lc, g[e]) && chain_class_has(ch, lc, g[e - 1])) reason |= 64;
     if (reason) return -(16 + static_cast<int64_t>(reason));
     int64_t cur_end = -1;
     for (size_t i = 0; i < sp.size(); i++)

@@ -543,3 +543,30 @@ def test_find_all_submatch_index(need_gpu, oracle):
     n2 = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), n + 4, timing=t)
     assert n2 == n and t.n_launches == 1          # the chain kernel writes the capture slots itself (ChainCaps)
     assert np.array_equal(out[:n].cpu().numpy(), exp)
+
+
+def test_chain_restart_inside_first_class_run(need_gpu, oracle):
+    """Chains that begin with a run and may end on a byte of that run's class (`z+\\.\\w\\w`, `(\\w+)=(\\d+)`): exact on
+    the chain kernel while no match ends inside a first-class run; when one does (`z.azz.bc`: [0,4] then [4,8]) the
+    kernel raises the fallback flag and the table-walking kernel answers.  Either way the oracle's rows."""
+    calm = ((b"zz.ab  z.cd k=12 next=3;  " + b" " * 120) * 1500)      # sparse enough for the row buffers of the wave kernel
+    tight = ((b"z.azz.bc k=12next=3 " + b" " * 120) * 1500)
+    for pat in (r"z+\.\w\w", r"[a-z0-9]+\.+[x-z]"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        for hay in (calm, tight, calm + tight):
+            assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), pat
+    pat = r"(\w+)=(\d+)"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    for hay in (calm, tight, calm + tight):
+        assert np.array_equal(rx.find_all_submatch_index(hay), o.find_all_submatch_index(hay)), pat
+    # the calm haystack stays on the chain kernel: one launch
+    import torch
+    n = len(calm) // 4096 * 4096
+    buf = cx.DeviceBuffer(n)
+    buf.upload(np.frombuffer(calm[:n], dtype=np.uint8))
+    t = cx.Timing()
+    rx2 = cx.compile(r"z+\.\w\w")
+    cnt = rx2.find_all_device(buf.ptr, n)
+    out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+    assert rx2.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
+    assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"z+\.\w\w").find_all_index(calm[:n]))

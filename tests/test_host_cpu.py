@@ -185,6 +185,21 @@ def test_chain_prefilter_emulated(oracle):
     assert emu.find_all_chain(cx.compile(r"\d+\.\d+\.\d+\.\d+").blob(), b"1.2.3.4." * 4000) is None
 
 
+def _restart_check(blob) -> int:
+    """ChainAux.restart_check of a chain program (walk.hpp): the kernel hands the scan over when a match ends inside a
+    run of the chain's first class."""
+    import struct
+    aux_off = struct.unpack_from("<I", blob, 56)[0]
+    return blob[aux_off + 256 + 88]
+
+
+def _fallback_ok(got: int, blob) -> bool:
+    """Twin returned -(16 + reason): no synchronising byte in a halo (1) is always legitimate, a match ending inside a
+    first-class run (64) only for programs that carry the restart check."""
+    reason = -got - 16
+    return reason > 0 and (reason & ~(1 | (64 if _restart_check(blob) else 0))) == 0
+
+
 def test_bitparallel_chain_emulated(oracle):
     """Sixth generation (scan_chain_wave.hip): starts, ownership and ends all from class bitmaps — digit-prefilter
     chains and UseDFA chains (literals, run/byte sequences) vs the oracle, several window geometries."""
@@ -208,7 +223,7 @@ def test_bitparallel_chain_emulated(oracle):
             for geom in ((3840, 256), (192, 64), (64, 64)):
                 got = emu.find_all_chain6(p.blob(), hay, *geom)
                 if isinstance(got, int):
-                    assert got in (-17,), (pat, geom, got)     # only "no sync byte in a halo" / "> 64 starts" may fall back
+                    assert _fallback_ok(got, p.blob()), (pat, geom, got)
                     continue
                 assert got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), geom)
         for _ in range(120):
@@ -218,7 +233,7 @@ def test_bitparallel_chain_emulated(oracle):
             for geom in ((3840, 256), (192, 64), (128, 128)):
                 got = emu.find_all_chain6(p.blob(), hay, *geom)
                 if isinstance(got, int):
-                    assert got in (-17,), (pat, geom, got)
+                    assert _fallback_ok(got, p.blob()), (pat, geom, got)
                     continue
                 assert got.tolist() == exp, (pat, n, geom)
         # exact window edge at the end of input: the last run touches the last byte of a full window
@@ -241,7 +256,7 @@ def test_bitparallel_chain_emulated(oracle):
             for geom in ((3840, 256), (192, 64)):
                 got = emu.find_all_chain6(span_blob, hay, *geom)
                 if isinstance(got, int):
-                    assert got == -17, (pat, geom, got)
+                    assert _fallback_ok(got, span_blob), (pat, geom, got)
                     continue
                 assert got.tolist() == o.find_all_index(hay).tolist(), (pat, len(hay), geom)
     # unordered chains (a run whose class meets the class of the step before) must not get the flag
@@ -251,13 +266,19 @@ def test_bitparallel_chain_emulated(oracle):
             assert not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
     # a chain that begins with a run and can end on a byte of that run's class with more of the class behind it: the
     # next match may start mid-run ("z.azz.bc" -> [0,4] [4,8]), which run-start candidates cannot express
+    # such chains carry the restart check: the kernel (and its twin) hands the scan over when a match ends inside a
+    # first-class run, and is exact otherwise
     for pat, hay, exp in ((r"z+\.\w\w", b"z.azz.bc", [[0, 4], [4, 8]]), (r"[a-z0-9]+\.+[x-z]", b"ab.xy.z", [[0, 4], [4, 7]])):
         p = cx.compile(pat)
-        assert p.supported and not (struct.unpack_from("<I", p.blob(), 8)[0] & 16), pat
+        assert p.supported and (struct.unpack_from("<I", p.blob(), 8)[0] & 16) and _restart_check(p.blob()) == 1, pat
         assert oracle.Regex(pat).find_all_index(hay).tolist() == exp
         assert emu.find_all(p.blob(), hay).tolist() == exp
+        assert emu.find_all_chain6(p.blob(), hay) == -(16 + 64)
+        calm = hay.replace(b"zz", b"z ").replace(b"xy", b"x ")
+        assert emu.find_all_chain6(p.blob(), calm).tolist() == oracle.Regex(pat).find_all_index(calm).tolist() != []
     span_blob = cx.compile(r"(\w+)=(\d+)").submatch_blobs()[0]
-    assert not (struct.unpack_from("<I", span_blob, 8)[0] & 16)
+    assert (struct.unpack_from("<I", span_blob, 8)[0] & 16) and _restart_check(span_blob) == 1
+    assert _restart_check(cx.compile(r"\d+\.\d+\.\d+\.\d+").blob()) == 0 and _restart_check(cx.compile(r"(\w+)@(\w+)\.(\w+)").submatch_blobs()[0]) == 0
 
 
 def _random_chain_patterns(rng, count):
@@ -299,7 +320,7 @@ def test_random_chain_patterns_emulated(oracle):
             for geom in ((192, 64), (3840, 256)):
                 got = emu.find_all_chain6(p.blob(), hay, *geom)
                 if isinstance(got, int):
-                    assert got == -17, (pat, geom, got)
+                    assert _fallback_ok(got, p.blob()), (pat, geom, got)
                     continue
                 assert got.tolist() == exp, (pat, len(hay), geom)
     assert n_chain >= 40, n_chain
@@ -496,8 +517,8 @@ def test_chain_captures_mapping(oracle):
         rx = cx.compile(pat)
         assert rx.submatch_supported, pat
         caps = rx.chain_captures()
-        if pat in (r"(\w+)=(\d+)", r"(GET|POST) (\w+)"):
-            assert caps is None, pat           # chain not restart-safe / not a chain: two-kernel path
+        if pat == r"(GET|POST) (\w+)":
+            assert caps is None, pat           # not a chain: two-kernel path
             continue
         assert caps is not None, pat
         n_on += 1
