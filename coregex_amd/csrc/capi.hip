@@ -318,6 +318,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
+  bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
 relaunch:
   fusedCaps = false;
   std::memset(a.caps, 0, sizeof a.caps);
@@ -326,6 +327,12 @@ relaunch:
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 5 || gen == 6 || gen == 7) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  a.tiles_per_wave = cxgdev::kTilesPerWave;
+  if (gen == 6 && denseChain) {                                     // four times the row-buffer room per wave-tile
+    a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
+    const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * cxgdev::kDenseTilesPerWave;
+    a.ngroups = (len + gb - 1) / gb;
+  }
   // Wave kernels with static groups tag their look-back words with a launch epoch and clear the next launch's error
   // word themselves: no memset between launches.  Everything else starts from a zeroed control block + status words.
   static const bool epochsOk = getenv("CXG_NO_EPOCH") == nullptr;
@@ -442,6 +449,13 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
+    if (gen == 6 && (err >> 8) == 0x10u && !denseChain) {           // only the row buffers overflowed: same kernel, two tiles per wave
+      if (verbose) fprintf(stderr, "[cxg] chain kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
+      denseChain = true;
+      p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      relaunches++;
+      goto relaunch;
+    }
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // dense tile / no sync byte in a halo: table kernels
   }

@@ -161,7 +161,9 @@ struct Words4 {
 // pressure) out of the kernels of single-range programs.
 // CAP: the rows carry capture slots (ScanArgs::caps, walk.hpp ChainCaps): the ends of up to four runs are compacted
 // next to the starts and ends (dynamic LDS, 4 KiB per run), and every slot is one of those positions plus a constant.
-template <int NCLS, bool SETS, bool CAP>
+// DENSE: two tiles per wave instead of eight (four times the row-buffer room per tile) for match-dense input; the host
+// switches after a row-buffer overflow (capi.hip).  A template parameter: a run-time tile count cost the default 1.2 %.
+template <int NCLS, bool SETS, bool CAP, bool DENSE>
 __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   ch.aux = gch;
   ch.nops = gch->nops;
   const bool restart_check = __builtin_amdgcn_readfirstlane(static_cast<int>(gch->restart_check)) != 0;
+  constexpr int tpw = DENSE ? kDenseTilesPerWave : kTilesPerWave;
   ch.op_is_run = 0; ch.op_cls2 = 0;
 #pragma unroll
   for (int k = 0; k < kChainMaxOps; k++) {
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   u32x4 x[4];
   uint32_t xprev = 0;                                              // the dword that ends with the byte in front of the tile
   auto issue_loads = [&](int jj) {
-    const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
-    if (jj < kTilesPerWave && lo < a.len) {
+    if (jj < tpw && lo < a.len) {
       const uint64_t rem = a.len - lo;
       nrec = rem >= static_cast<uint64_t>(kWaveTile + kWaveHalo) ? kWaveTile + kWaveHalo : static_cast<int>((rem + 3) & ~3ull);
     }
@@ -242,14 +245,14 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tlast = __builtin_readcyclecounter();
 #endif
-  for (int j = 0; j < kTilesPerWave; j++) {
+  for (int j = 0; j < tpw; j++) {
     // Opaque copy of the lane id per wave-tile: lane-derived masks and LDS addresses are recomputed (a few ALU
     // ops) instead of being hoisted out of the loop and spilled — a scratch reload waits on vmcnt, which would
     // also drain the prefetched tile.
     lane = lane0;
     asm volatile("" : "+v"(lane));
     if (!CXG_CHAIN_PREFETCH) issue_loads(j);
-    const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
+    const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
     uint32_t emitted_here = 0;
     if (tile_lo < a.len) {
@@ -498,19 +501,19 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
   if (tid < 64) {
     const int q = tid;
-    const uint32_t v = (q < kWavesPerBlock * kTilesPerWave) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t v = (q < kWavesPerBlock * tpw) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
     const uint32_t incl = wave_inclusive_sum(v);
-    if (q < kWavesPerBlock * kTilesPerWave) s_qbase[q] = incl - v;
-    if (q == kWavesPerBlock * kTilesPerWave - 1) s_qbase[kWavesPerBlock * kTilesPerWave] = incl;
+    if (q < kWavesPerBlock * tpw) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * tpw - 1) s_qbase[kWavesPerBlock * tpw] = incl;
   }
   __syncthreads();
-  const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
+  const uint32_t total = s_qbase[kWavesPerBlock * tpw];
   tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
-  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);
   uint32_t start = 0;
-  for (int j = 0; j < kTilesPerWave; j++) {
+  for (int j = 0; j < tpw; j++) {
     const uint32_t n = s_cnt[wave][j];
     const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
     for (uint32_t i = lane; i < n; i += 64) {
@@ -539,32 +542,32 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   }
 }
 
+namespace {
+template <int NCLS, bool SETS>
+void launch_chain(const ScanArgs& a, bool caps, bool dense, dim3 grid, dim3 block, hipStream_t stream) {
+  const size_t dyn = caps ? static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t) : 0;
+  if (caps) {
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, true>), grid, block, dyn, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, false>), grid, block, dyn, stream, a);
+  } else {
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, false>), grid, block, 0, stream, a);
+  }
+}
+}  // namespace
+
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  if (caps) {
-    const size_t dyn = static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t);
-    switch (ncls * 2 + (sets ? 1 : 0)) {
-      case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, true>), grid, block, dyn, stream, a); break;
-      case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, true>), grid, block, dyn, stream, a); break;
-      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, true>), grid, block, dyn, stream, a); break;
-      case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, true>), grid, block, dyn, stream, a); break;
-      case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, true>), grid, block, dyn, stream, a); break;
-      case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, true>), grid, block, dyn, stream, a); break;
-      case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, true>), grid, block, dyn, stream, a); break;
-      case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, true>), grid, block, dyn, stream, a); break;
-      default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-  }
+  const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
   switch (ncls * 2 + (sets ? 1 : 0)) {
-    case 2: hipLaunchKernelGGL((k_scan_chain_wave<1, false, false>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((k_scan_chain_wave<1, true, false>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false>), grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((k_scan_chain_wave<2, true, false>), grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((k_scan_chain_wave<3, false, false>), grid, block, 0, stream, a); break;
-    case 7: hipLaunchKernelGGL((k_scan_chain_wave<3, true, false>), grid, block, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL((k_scan_chain_wave<4, false, false>), grid, block, 0, stream, a); break;
-    case 9: hipLaunchKernelGGL((k_scan_chain_wave<4, true, false>), grid, block, 0, stream, a); break;
+    case 2: launch_chain<1, false>(a, caps, dense, grid, block, stream); break;
+    case 3: launch_chain<1, true>(a, caps, dense, grid, block, stream); break;
+    case 4: launch_chain<2, false>(a, caps, dense, grid, block, stream); break;
+    case 5: launch_chain<2, true>(a, caps, dense, grid, block, stream); break;
+    case 6: launch_chain<3, false>(a, caps, dense, grid, block, stream); break;
+    case 7: launch_chain<3, true>(a, caps, dense, grid, block, stream); break;
+    case 8: launch_chain<4, false>(a, caps, dense, grid, block, stream); break;
+    case 9: launch_chain<4, true>(a, caps, dense, grid, block, stream); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

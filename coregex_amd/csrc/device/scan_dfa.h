@@ -16,6 +16,7 @@ constexpr int kWaveTile = 3840;
 constexpr int kWaveHalo = 256;
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerWave = 8;
+constexpr int kDenseTilesPerWave = 2;          // chain kernel on match-dense input: 256 rows of buffer per wave-tile instead of 64
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
 constexpr int kCcTilesPerWave = 4;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup
 constexpr uint64_t kCcGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave;
@@ -58,6 +59,7 @@ struct ScanArgs {
   uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)
   uint8_t caps[40];     // scan_chain_wave.hip CAP instantiations: the program's ChainCaps (walk.hpp); caps[0] == 0: spans only
+  uint32_t tiles_per_wave;  // scan_chain_wave.hip: kTilesPerWave, or kDenseTilesPerWave after a row-buffer overflow
   uint32_t max_len;     // != 0: a match longer than this raises error bit 64 (UseBoth programs, walk.hpp kFlagBothRestart)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
 };

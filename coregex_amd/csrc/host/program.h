@@ -10,6 +10,7 @@
 // Deliberate difference: a DFA state is identified by its *ordered* NFA list (the reference keys on
 // the sorted set, dfa/lazy/state.go:342-346, and keeps whichever order it met first).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -53,6 +54,8 @@ struct cxg_program {
   std::string subWhyNot;
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
+  mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: the chain kernel overflowed its row buffers on this
+                                                              // program's input once: later calls start with two tiles per wave (capi.hip)
   uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
   // device copies, one per device, created on first use (capi.hip)
   void* dev[16] = {nullptr};

@@ -570,3 +570,33 @@ def test_chain_restart_inside_first_class_run(need_gpu, oracle):
     out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
     assert rx2.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
     assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"z+\.\w\w").find_all_index(calm[:n]))
+
+
+def test_match_dense_input_switches_to_two_tiles_per_wave(need_gpu, oracle):
+    """More than one match per ~60 bytes overflows the chain kernel's row buffers (512 rows per wave per 8 tiles): the
+    host reruns the SAME kernel with two tiles per wave (256 rows per tile) and remembers it for the program; only
+    input denser than that goes to the table-walking kernel.  Rows equal the oracle's throughout."""
+    import torch
+    dense = np.frombuffer((b"zz.ab z.cd " * 12000)[: 32 * 4096], dtype=np.uint8)          # 2 matches per 11 bytes... per tile ~700: too dense even for 2
+    medium = np.frombuffer(((b"z.ab" + b" " * 26) * 9000)[: 64 * 4096], dtype=np.uint8)   # 1 match per 30 bytes: 128 per tile
+    pat = r"z+\.[a-d][a-d]"
+    o = oracle.Regex(pat)
+    for hay in (medium, dense):
+        rx = cx.compile(pat)
+        buf = cx.DeviceBuffer(hay.size)
+        buf.upload(hay)
+        exp = o.find_all_index(hay)
+        cnt = rx.find_all_device(buf.ptr, hay.size)
+        assert cnt == len(exp)
+        out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+        t = cx.Timing()
+        assert rx.find_all_device(buf.ptr, hay.size, out.data_ptr(), cnt + 4, timing=t) == cnt
+        assert np.array_equal(out[:cnt].cpu().numpy(), exp)
+        if hay is medium:
+            assert t.n_launches == 1, t.n_launches          # the count call above already switched the program to two tiles per wave
+        else:
+            assert t.n_launches >= 2, t.n_launches          # denser than 256 rows per tile: table-walking kernel
+    # captures on dense key=value text
+    pat = r"([a-z]+)=(\d+)"
+    hay = (b"ab=12 c=3 zz=456 " * 3000)
+    assert np.array_equal(cx.compile(pat).find_all_submatch_index(hay), oracle.Regex(pat).find_all_submatch_index(hay))
