@@ -147,7 +147,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": _pmc_traffic(args, nbytes),
-            "kernel": {"1": "k_scan_dfa<digit>", "2": "k_scan_digit_flat", "3": "k_scan_digit_list", "4": "k_scan_digit_chain", "5": "k_scan_digit_wave"}.get(os.environ.get("CXG_DIGIT_KERNEL", "6"), "k_scan_chain_wave<2,false,false>") if rx.strategy == "UseDigitPrefilter" else rx.strategy,
+            "kernel": {"1": "k_scan_dfa<digit>", "2": "k_scan_digit_flat", "3": "k_scan_digit_list", "4": "k_scan_digit_chain", "5": "k_scan_digit_wave"}.get(os.environ.get("CXG_DIGIT_KERNEL", "6"), "k_scan_chain_wave<2,false,false,false,4>") if rx.strategy == "UseDigitPrefilter" else rx.strategy,
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
             "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),

@@ -27,6 +27,7 @@
 // Fallback flag (err bit 8: the host reruns the scan with the table-walking kernels): no synchronising byte
 // in a halo, row buffer overflow (> 512 matches per wave and group), or a violated pairing invariant.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "block_common.hpp"
@@ -163,7 +164,11 @@ struct Words4 {
 // next to the starts and ends (dynamic LDS, 4 KiB per run), and every slot is one of those positions plus a constant.
 // DENSE: two tiles per wave instead of eight (four times the row-buffer room per tile) for match-dense input; the host
 // switches after a row-buffer overflow (capi.hip).  A template parameter: a run-time tile count cost the default 1.2 %.
-template <int NCLS, bool SETS, bool CAP, bool DENSE>
+// ALTK > 0: the chain is run(class 0) (byte(separator) run(class 0)){ALTK-1} — fields of one class with single-byte
+// separators (`\d+\.\d+\.\d+\.\d+`, `\d+:\d+:\d+`, `\w+@\w+\.\w+`): the step loops unroll with constant step kinds, the
+// runs use class 0 without a select (with two classes the separator is class 1, with more it is read from the
+// description), no loop control; 0: any chain, steps read from the description.
+template <int NCLS, bool SETS, bool CAP, bool DENSE, int ALTK>
 __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
@@ -214,6 +219,12 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
   if (group >= a.ngroups) return;
+  if (ALTK > 0) {                                                  // compile-time shape: everything derived from these folds
+    ch.nops = 2u * ALTK - 1u;
+    ch.op_is_run = 0x55555555u & ((1u << (2 * ALTK - 1)) - 1u);   // steps 0, 2, 4, ... are runs
+    if (NCLS == 2) ch.op_cls2 = 0x44444444u & ((1u << (2 * (2 * ALTK - 1))) - 1u);   // step k uses class k & 1
+    else ch.op_cls2 &= 0xCCCCCCCCu;                                // runs: class 0; separators: as described
+  }
   const uint32_t nops = ch.nops;
   const bool lead_run = (ch.op_is_run & 1u) != 0;
   const uint32_t lead_cls = ch.op_cls2 & 3u;
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
       // ---- B: chain, right to left, on the reversed words
       uint64_t G = ~0ull;
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
-      for (int k = (CXG_ABL == 1 || CXG_ABL == 4) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) {
+      auto bwd_step = [&](const int k) {
         const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
         const uint64_t Ck = R.pick<NCLS>(ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
@@ -345,6 +356,12 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
           const unsigned long long recv = (PP + G1) ^ PP;           // lanes that receive a carry
           G = Ck & ~add_carry_mask(s1, recv);
         }
+      };
+      if constexpr (ALTK > 0) {
+#pragma unroll
+        for (int k = 2 * ALTK - 2; k >= 0; k--) bwd_step(k);
+      } else {
+        for (int k = (CXG_ABL == 1 || CXG_ABL == 4) ? -1 : static_cast<int>(nops) - 1; k >= 0; k--) bwd_step(k);
       }
       PHASE_MARK(3);                                                // backward chain
       // starts, reversed orientation: with a leading run only the first byte of the run is a candidate
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
           const uint64_t lower = from_lower64(S);
           M = (S << nops) | ((lane == 0) ? 0ull : (lower >> (64u - nops)));
         }
-        for (uint32_t k = 0; k < (fixed_len ? 0u : nops); k++) {
+        auto fwd_step = [&](const uint32_t k) {
           if (!((ch.op_is_run >> k) & 1u)) {
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
@@ -401,6 +418,12 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
               }
             }
           }
+        };
+        if constexpr (ALTK > 0) {
+#pragma unroll
+          for (uint32_t k = 0; k < static_cast<uint32_t>(2 * ALTK - 1); k++) fwd_step(k);
+        } else {
+          for (uint32_t k = 0; k < (fixed_len ? 0u : nops); k++) fwd_step(k);
         }
         if (restart_check && lead_run) {                            // a match that ends inside a run of the first class: FindAll would
           const uint64_t A = F.pick<NCLS>(lead_cls);                 // resume there, mid-run — not a run start.  Rare; the table kernel takes over.
@@ -547,18 +570,47 @@ template <int NCLS, bool SETS>
 void launch_chain(const ScanArgs& a, bool caps, bool dense, dim3 grid, dim3 block, hipStream_t stream) {
   const size_t dyn = caps ? static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t) : 0;
   if (caps) {
-    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, true>), grid, block, dyn, stream, a);
-    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, false>), grid, block, dyn, stream, a);
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, true, 0>), grid, block, dyn, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, false, 0>), grid, block, dyn, stream, a);
   } else {
-    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, false>), grid, block, 0, stream, a);
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, true, 0>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, false, 0>), grid, block, 0, stream, a);
   }
 }
 }  // namespace
 
+// Number of runs of a chain run(0) (byte(sep) run(0))* — every run of class 0, single-byte separators — else 0.
+int alternating_runs(const ChainAux& c) {
+  if (c.ncls < 2 || (c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7) return 0;
+  for (uint32_t k = 0; k < c.nops; k++) {
+    if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return 0;
+    if (!(k & 1u) && c.op_cls[k] != 0) return 0;
+    if ((k & 1u) && (c.op_cls[k] == 0 || (c.ncls == 2 && c.op_cls[k] != 1))) return 0;
+  }
+  return static_cast<int>((c.nops + 1) / 2);
+}
+
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
+  static const bool altOk = getenv("CXG_NO_SHAPE_KERNELS") == nullptr;
+  const int altk = (altOk && !dense) ? alternating_runs(*reinterpret_cast<const ChainAux*>(a.chain)) : 0;
+  if (altk && ncls == 2 && !sets && !caps) {                          // unrolled instantiations for the alternating shapes
+    switch (altk) {
+      case 2: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 2>), grid, block, 0, stream, a); return hipGetLastError();
+      case 3: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 3>), grid, block, 0, stream, a); return hipGetLastError();
+      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 4>), grid, block, 0, stream, a); return hipGetLastError();
+      default: break;
+    }
+  }
+  if (altk == 3 && ncls == 3) {                                       // field@field.field: three fields, two different separators
+    const size_t dyn = caps ? static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t) : 0;
+    if (sets && caps) hipLaunchKernelGGL((k_scan_chain_wave<3, true, true, false, 3>), grid, block, dyn, stream, a);
+    else if (sets) hipLaunchKernelGGL((k_scan_chain_wave<3, true, false, false, 3>), grid, block, 0, stream, a);
+    else if (caps) hipLaunchKernelGGL((k_scan_chain_wave<3, false, true, false, 3>), grid, block, dyn, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<3, false, false, false, 3>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   switch (ncls * 2 + (sets ? 1 : 0)) {
     case 2: launch_chain<1, false>(a, caps, dense, grid, block, stream); break;
     case 3: launch_chain<1, true>(a, caps, dense, grid, block, stream); break;
