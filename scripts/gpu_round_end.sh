@@ -2,7 +2,7 @@
 # all five configurations.  Run on the GPU box via gpurun; summaries are copied into profiles/ by hand afterwards.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; rm -rf gpurun_out/prof gpurun_out/prof_cfgs
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo pytest=$?; tail -3 gpurun_out/pytest_gpu.log
-/usr/bin/time -v timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo bench=$?; tail -1 gpurun_out/bench.log | cut -c1-1500; grep -E "Elapsed|Maximum resident" gpurun_out/bench.err
+S=$(date +%s); timeout 600 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo bench=$? wall=$(( $(date +%s) - S ))s; tail -1 gpurun_out/bench.log | cut -c1-1500
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o ip1g -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1; echo prof=$?

@@ -200,7 +200,7 @@ def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
     assert np.array_equal(got, oracle.Regex(pats[0]).find_all_index(hay))
 
 
-@pytest.mark.parametrize("env", [{"CXG_TICKETS": "1"}, {"CXG_NO_EPOCH": "1"}, {"CXG_DIGIT_KERNEL": "5"}, {"CXG_DIGIT_KERNEL": "2"}, {"CXG_NO_FUSED_CAPTURES": "1"}, {"CXG_NO_ZERO_COPY": "1"},
+@pytest.mark.parametrize("env", [{"CXG_TICKETS": "1"}, {"CXG_NO_EPOCH": "1"}, {"CXG_DIGIT_KERNEL": "5"}, {"CXG_DIGIT_KERNEL": "2"}, {"CXG_NO_FUSED_CAPTURES": "1"}, {"CXG_NO_ZERO_COPY": "1"}, {"CXG_NO_SHAPE_KERNELS": "1"},
                                  {"CXG_TEDDY_KERNEL": "1", "CXG_CC_KERNEL": "1"}])
 def test_alternative_kernel_modes(need_gpu, env):
     """The modes behind the defaults (ticket atomics instead of static groups, zeroed status words instead of epochs,
