@@ -116,8 +116,10 @@ __device__ __forceinline__ void classify_tile_set(const u32x4 (&x)[4], const Set
 template <int NCLS, bool SETS>
 struct ChainRegs {
   uint32_t nops;
-  uint32_t op_is_run;      // bit k: step k is a run
-  uint32_t op_cls2;        // 2 bits per step: its class
+  uint64_t op_is_run;      // bit k: step k is a run
+  uint64_t op_cls2, op_cls2_hi;   // 2 bits per step: its class (steps 0..31, 32..63)
+  __device__ __forceinline__ bool is_run(uint32_t k) const { return ((op_is_run >> k) & 1ull) != 0; }
+  __device__ __forceinline__ uint32_t cls(uint32_t k) const { return static_cast<uint32_t>(((k < 32u ? op_cls2 >> (2u * k) : op_cls2_hi >> (2u * (k - 32u)))) & 3ull); }
   uint32_t kind[NCLS], lo[NCLS], hi[NCLS];
   const ChainAux* aux;     // uniform address: the ranges of kClsSet classes are read through the scalar cache at use
   __device__ __forceinline__ bool has(int c, uint32_t b) const {
@@ -196,19 +198,19 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   ch.nops = gch->nops;
   const bool restart_check = __builtin_amdgcn_readfirstlane(static_cast<int>(gch->restart_check)) != 0;
   constexpr int tpw = DENSE ? kDenseTilesPerWave : kTilesPerWave;
-  ch.op_is_run = 0; ch.op_cls2 = 0;
-#pragma unroll
-  for (int k = 0; k < kChainMaxOps; k++) {
-    ch.op_is_run |= (gch->op_kind[k] == kChainRun ? 1u : 0u) << k;
-    ch.op_cls2 |= static_cast<uint32_t>(gch->op_cls[k] & 3u) << (2 * k);
-  }
+  ch.op_is_run = gch->run_bits; ch.op_cls2 = gch->cls2_lo; ch.op_cls2_hi = gch->cls2_hi;
 #pragma unroll
   for (int c = 0; c < NCLS; c++) { ch.kind[c] = gch->cls_kind[c]; ch.lo[c] = gch->cls_lo[c]; ch.hi[c] = gch->cls_hi[c]; }
   // the blob is read with vector loads (its address comes out of a loaded header field): make the description
   // provably wave-uniform so that everything derived from it stays on the scalar unit
   ch.nops = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.nops)));
-  ch.op_is_run = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.op_is_run)));
-  ch.op_cls2 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.op_cls2)));
+  auto uniform64 = [](uint64_t v) -> uint64_t {
+    return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)))) << 32) |
+           static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+  };
+  ch.op_is_run = uniform64(ch.op_is_run);
+  ch.op_cls2 = uniform64(ch.op_cls2);
+  ch.op_cls2_hi = uniform64(ch.op_cls2_hi);
 #pragma unroll
   for (int c = 0; c < NCLS; c++) {
     ch.kind[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ch.kind[c])));
@@ -221,13 +223,14 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   if (group >= a.ngroups) return;
   if (ALTK > 0) {                                                  // compile-time shape: everything derived from these folds
     ch.nops = 2u * ALTK - 1u;
-    ch.op_is_run = 0x55555555u & ((1u << (2 * ALTK - 1)) - 1u);   // steps 0, 2, 4, ... are runs
-    if (NCLS == 2) ch.op_cls2 = 0x44444444u & ((1u << (2 * (2 * ALTK - 1))) - 1u);   // step k uses class k & 1
-    else ch.op_cls2 &= 0xCCCCCCCCu;                                // runs: class 0; separators: as described
+    ch.op_is_run = 0x55555555ull & ((1ull << (2 * ALTK - 1)) - 1ull);   // steps 0, 2, 4, ... are runs
+    if (NCLS == 2) ch.op_cls2 = 0x44444444ull & ((1ull << (2 * (2 * ALTK - 1))) - 1ull);   // step k uses class k & 1
+    else ch.op_cls2 &= 0xCCCCCCCCull;                              // runs: class 0; separators: as described
+    ch.op_cls2_hi = 0;
   }
   const uint32_t nops = ch.nops;
-  const bool lead_run = (ch.op_is_run & 1u) != 0;
-  const uint32_t lead_cls = ch.op_cls2 & 3u;
+  const bool lead_run = ch.is_run(0);
+  const uint32_t lead_cls = ch.cls(0);
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
 
@@ -336,10 +339,10 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
       uint64_t G = ~0ull;
       const bool at_eoi_edge = (stage == rend) && (stage == kWaveTile + kWaveHalo);   // byte 4095 is the last of the input
       auto bwd_step = [&](const int k) {
-        const uint32_t ci = (ch.op_cls2 >> (2 * k)) & 3u;
+        const uint32_t ci = ch.cls(static_cast<uint32_t>(k));
         const uint64_t Ck = R.pick<NCLS>(ci);
         const uint64_t inject = (at_eoi_edge && k == static_cast<int>(nops) - 1) ? 1ull : 0ull;   // G_{n+1} holds at end of input
-        if (!((ch.op_is_run >> k) & 1u)) {
+        if (!ch.is_run(static_cast<uint32_t>(k))) {
           uint64_t low = from_lower64(G) >> 63;                     // DPP outside any lane-dependent branch: a
           if (lane == 0) low = inject;                              // disabled source lane would not be read
           G = Ck & ((G << 1) | low);
@@ -382,18 +385,18 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
         // ---- F: chain left to right on the forward words
         uint64_t M = S;
         uint32_t capcnt[kCapMaxRuns] = {0, 0, 0, 0};                  // CAP: run ends compacted (wave-uniform)
-        const bool fixed_len = ch.op_is_run == 0u;                   // a literal: every match is nops bytes long
+        const bool fixed_len = ch.op_is_run == 0ull;                   // a literal: every match is nops bytes long
         if (fixed_len) {                                            // ends = starts shifted by the length (< 64)
           const uint64_t lower = from_lower64(S);
           M = (S << nops) | ((lane == 0) ? 0ull : (lower >> (64u - nops)));
         }
         auto fwd_step = [&](const uint32_t k) {
-          if (!((ch.op_is_run >> k) & 1u)) {
+          if (!ch.is_run(static_cast<uint32_t>(k))) {
             uint64_t low = from_lower64(M) >> 63;
             if (lane == 0) low = 0ull;
             M = (M << 1) | low;
           } else {
-            const uint64_t Ck = F.pick<NCLS>((ch.op_cls2 >> (2 * k)) & 3u);
+            const uint64_t Ck = F.pick<NCLS>(ch.cls(static_cast<uint32_t>(k)));
             const uint64_t s1 = Ck + M;
             const unsigned long long GG = __builtin_amdgcn_uicmpl(s1, M, 36 /*ult*/);
             const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);

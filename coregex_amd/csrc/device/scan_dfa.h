@@ -54,7 +54,7 @@ struct ScanArgs {
   uint64_t ngroups;     // look-back units: == ntiles, except for kernels that process kGroupTiles tiles per workgroup
   uint64_t* prof;       // optional [8] phase cycle counters (CXG_PROF=1), else nullptr
   uint32_t row_width;   // int64 per output row: 2, or 2*groups when a capture pass follows
-  uint8_t chain[96];    // scan_chain_wave.hip: copy of the program's ChainAux (walk.hpp) — kernel arguments are read with
+  uint8_t chain[224];   // scan_chain_wave.hip: copy of the program's ChainAux (walk.hpp) — kernel arguments are read with
                         // scalar loads before the first instruction needs them, the blob would cost two dependent global loads per workgroup
   uint32_t epoch;          // wave kernels: launch epoch 1..1023 tagging the status words (0: array was zeroed, legacy)
   uint32_t static_groups;  // wave kernels: group = blockIdx.x instead of an atomic ticket (block_common.hpp claim_group)

@@ -407,7 +407,7 @@ CXG_HD void lane_select(const Mem& m, const DfaView& d, const uint8_t* info, con
 // All bitmaps of this scheme are stored reversed: bit i of word w describes byte N-1-(64w+i), N = 64*words.
 enum ChainOpKind : uint8_t { kChainByte = 0, kChainRun = 1 };
 enum ChainClassKind : uint8_t { kClsDigit = 0, kClsByte = 1, kClsRange = 2, kClsSet = 3 };   // set: union of 2..4 ASCII ranges (\w)
-constexpr int kChainMaxOps = 16, kChainMaxCls = 4, kChainMaxRanges = 4;
+constexpr int kChainMaxOps = 64, kChainMaxCls = 4, kChainMaxRanges = 4;   // 63 steps at most (a 64-bit shift by the length): UUIDs, timestamps, MACs
 
 struct ChainAux {             // aux section of a kKindDigit blob when kFlagChain is set (follows sflags[256])
   uint32_t nops, ncls;
@@ -419,6 +419,8 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
   uint8_t cls_nr[kChainMaxCls];                       // kClsSet: number of ranges, then the ranges
   uint8_t cls_rlo[kChainMaxCls][kChainMaxRanges];
   uint8_t cls_rhi[kChainMaxCls][kChainMaxRanges];
+  uint64_t run_bits;            // bit k: step k is a run            } the steps once more, packed for the scalar unit
+  uint64_t cls2_lo, cls2_hi;    // 2 bits per step: its class (0..31, 32..63) } (scan_chain_wave.hip ChainRegs)
   uint8_t restart_check;        // the chain begins with a run and a match may end INSIDE a run of that class (last class meets the
                                 // first): FindAll would resume there, which run-start candidates cannot express — the kernel hands
                                 // the scan over when it sees such an end (program.cc extractChain)

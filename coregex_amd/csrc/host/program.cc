@@ -356,7 +356,7 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
   uint32_t q = d.start;
   for (int b = 0; b < 256; b++)                          // `x*...`: an optional leading run is not a chain step
     if (d.table[static_cast<size_t>(q) * 256 + b] == q) return;
-  for (int step = 0; step < cxgdev::kChainMaxOps; step++) {
+  for (int step = 0; step < cxgdev::kChainMaxOps - 1; step++) {
     if (q >= d.firstAccept) break;                       // a match may end here: later steps are not necessary
     int target = -1; bool branching = false;
     bool F[256] = {false};
@@ -390,6 +390,11 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
     q = static_cast<uint32_t>(target);
   }
   if (chain.nops == 0) return;
+  for (uint32_t k = 0; k < chain.nops; k++) {              // packed copy of the steps for the kernel's scalar registers
+    if (chain.op_kind[k] == cxgdev::kChainRun) chain.run_bits |= 1ull << k;
+    const uint64_t c = chain.op_cls[k] & 3u;
+    if (k < 32) chain.cls2_lo |= c << (2 * k); else chain.cls2_hi |= c << (2 * (k - 32));
+  }
   complete = q >= d.firstAccept && d.firstAccept == d.nstates - 1;
   if (complete) {
     const bool lastRun = chain.op_kind[chain.nops - 1] == cxgdev::kChainRun;

@@ -600,3 +600,37 @@ def test_match_dense_input_switches_to_two_tiles_per_wave(need_gpu, oracle):
     pat = r"([a-z]+)=(\d+)"
     hay = (b"ab=12 c=3 zz=456 " * 3000)
     assert np.array_equal(cx.compile(pat).find_all_submatch_index(hay), oracle.Regex(pat).find_all_submatch_index(hay))
+
+
+def test_long_fixed_chains_uuid_mac_timestamp(need_gpu, oracle):
+    """Chains of up to 63 steps (walk.hpp kChainMaxOps): UUIDs (36 steps), MAC addresses (17), ISO timestamps (19) run
+    on the chain kernel — one launch — and equal the oracle."""
+    import torch
+    rng = np.random.default_rng(9)
+    hexd = b"0123456789abcdef"
+    lines = []
+    for i in range(6000):
+        u = bytes(hexd[j] for j in rng.integers(0, 16, size=32))
+        uuid = u[:8] + b"-" + u[8:12] + b"-" + u[12:16] + b"-" + u[16:20] + b"-" + u[20:32]
+        mac = b":".join(u[2 * k:2 * k + 2] for k in range(6))
+        ts = b"2026-%02d-%02dT%02d:%02d:%02d" % (1 + i % 12, 1 + i % 28, i % 24, i % 60, (7 * i) % 60)
+        decoy = uuid[:20] + b"g" + uuid[21:] if i % 5 == 0 else b""
+        lines.append(b"%s req=%s dev %s took %dms %s\n" % (ts, uuid, mac, i % 977, decoy))
+    text = b"".join(lines)
+    n = len(text) // 4096 * 4096
+    hay = np.frombuffer(text[:n], dtype=np.uint8)
+    buf = cx.DeviceBuffer(n)
+    buf.upload(hay)
+    for pat in (r"[0-9a-f]{8}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{12}", r"[0-9a-f]{2}(:[0-9a-f]{2}){5}",
+                r"\d{4}-\d{2}-\d{2}T\d{2}:\d{2}:\d{2}"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported, pat
+        exp = o.find_all_index(hay)
+        assert len(exp) >= 5000, (pat, len(exp))
+        assert np.array_equal(rx.find_all_index(hay), exp), pat
+        cnt = rx.find_all_device(buf.ptr, n)
+        out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+        t = cx.Timing()
+        assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt == len(exp)
+        assert t.n_launches == 1, (pat, t.n_launches)
+        assert np.array_equal(out[:cnt].cpu().numpy(), exp), pat

@@ -190,7 +190,7 @@ def _restart_check(blob) -> int:
     run of the chain's first class."""
     import struct
     aux_off = struct.unpack_from("<I", blob, 56)[0]
-    return blob[aux_off + 256 + 88]
+    return blob[aux_off + 256 + 208]                                # after the class tables and the three packed step words
 
 
 def _fallback_ok(got: int, blob) -> bool:
@@ -486,11 +486,11 @@ def _chain_of(span_blob):
     """ChainAux (walk.hpp) of a span program: [(is_run, membership[256])]."""
     import struct
     aux_off = struct.unpack_from("<I", span_blob, 56)[0]
-    raw = span_blob[aux_off + 256:aux_off + 256 + 88]
+    raw = span_blob[aux_off + 256:aux_off + 256 + 184]
     nops, ncls = struct.unpack_from("<II", raw, 0)
-    op_kind, op_cls = raw[8:24], raw[24:40]
-    cls_kind, cls_lo, cls_hi, cls_nr = raw[40:44], raw[44:48], raw[48:52], raw[52:56]
-    rlo, rhi = raw[56:72], raw[72:88]
+    op_kind, op_cls = raw[8:72], raw[72:136]                       # kChainMaxOps = 64
+    cls_kind, cls_lo, cls_hi, cls_nr = raw[136:140], raw[140:144], raw[144:148], raw[148:152]
+    rlo, rhi = raw[152:168], raw[168:184]
     members = []
     for c in range(ncls):
         m = np.zeros(256, dtype=bool)
