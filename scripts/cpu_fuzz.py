@@ -52,7 +52,7 @@ for seed in range(seed0, seed1):
                     for geom in ((192,64),(3840,256)):
                         g6 = emu.find_all_chain6(blob, hay, *geom)
                         if not isinstance(g6,int) and g6.tolist()!=exp: print('CHAIN6', repr(pat), len(hay), geom, len(g6), len(exp)); bad+=1
-                if rx.strategy=='UseTeddy':
+                if kind == 4:                     # literal image: UseTeddy, or a UseDFA program that is one plain literal
                     g = emu.find_all_teddy_wave(blob, hay)
                     if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('TEDDYW', repr(pat), len(hay)); bad+=1
                 if rx.strategy=='UseCharClassSearcher' and (fl & 64):

@@ -634,3 +634,26 @@ def test_long_fixed_chains_uuid_mac_timestamp(need_gpu, oracle):
         assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt == len(exp)
         assert t.n_launches == 1, (pat, t.n_launches)
         assert np.array_equal(out[:cnt].cpu().numpy(), exp), pat
+
+
+def test_plain_literals_with_many_distinct_bytes(need_gpu, oracle):
+    """A UseDFA program that is one plain literal with more than four distinct bytes (`warning`, `Exception`) is not a
+    chain for the bit-parallel kernel; it gets the literal image (fingerprint + exact compare) instead of the DFA pair.
+    Same rows as the oracle, one launch of the literal wave kernel."""
+    import torch
+    hay = cx.synth_pages(1, 0xC0FFEE01, 0, 512)
+    text = hay.tobytes() + b" warningwarning Exceptionwarning abcabcabcabd " * 50
+    for pat in ("warning", "Exception", "critical", "abcabcabd", "timeout"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.strategy == o.strategy == "UseDFA" and rx.supported, pat
+        assert np.array_equal(rx.find_all_index(text), o.find_all_index(text)), pat
+        assert rx.count(text) == len(o.find_all_index(text))
+    n = hay.size
+    buf = cx.DeviceBuffer(n)
+    buf.upload(hay)
+    rx = cx.compile("warning")
+    cnt = rx.find_all_device(buf.ptr, n)
+    out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
+    assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex("warning").find_all_index(hay))
