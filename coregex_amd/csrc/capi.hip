@@ -29,7 +29,7 @@ hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipSt
 hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_teddy_wave(const ScanArgs& a, hipStream_t stream);
+hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
 }  // namespace cxgdev
 
@@ -314,6 +314,10 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
     gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
+  if (gen == 0 && !submatch && h->kind == cxgdev::kKindBidir && (h->flags & cxgdev::kFlagPrefixLiteral)) {
+    static const bool noPrefix = getenv("CXG_NO_PREFIX_KERNEL") != nullptr;
+    if (!noPrefix) gen = 9;                                        // literal occurrences + anchored DFA walk (scan_teddy_wave.hip VERIFY)
+  }
   // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
@@ -326,7 +330,7 @@ relaunch:
   a.ngroups = a.ntiles;
   if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
-  if (gen == 5 || gen == 6 || gen == 7) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  if (gen == 5 || gen == 6 || gen == 7 || gen == 9) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (gen == 6 && denseChain) {                                     // four times the row-buffer room per wave-tile
     a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
@@ -360,7 +364,11 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
-  else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, stream);
+  else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
+  else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
+    const uint8_t* hb = p->blob.data();
+    le = cxgdev::launch_scan_teddy_wave(a, reinterpret_cast<const cxgdev::TeddyAux*>(hb + h->aux_off)->dfa_states, stream);
+  }
   else if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     std::memcpy(a.chain, hb + h->aux_off + 256, sizeof(cxgdev::ChainAux));

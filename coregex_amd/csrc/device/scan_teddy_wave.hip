@@ -69,7 +69,12 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
 
 }  // namespace
 
-__global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
+// VERIFY: the image is a UseDFA program behind its required literal prefix (walk.hpp kFlagPrefixLiteral): an occurrence
+// of the literal is extended to the match end by walking the anchored forward DFA (table in dynamic LDS) over the
+// window's bytes; a walk still alive at the window edge hands the scan to the DFA-pair kernel.
+template <bool VERIFY>
+__global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_dfa[];   // VERIFY: [dfa_states][256]
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
   __shared__ uint32_t s_T[256];                                    // A | B<<8 | C<<16 | sync<<24 per byte value
   __shared__ uint8_t s_boff[16];                                   // bucket b: its literals are order[s_boff[b] .. s_boff[b+1])
@@ -101,6 +106,11 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(s_aux + ax->off_off);
   const uint8_t* t_bytes = s_aux + ax->bytes_off;
   const uint32_t nlits = ax->nlits;
+  const uint32_t dfa_start = VERIFY ? ax->dfa_start : 0u, dfa_fa = VERIFY ? ax->dfa_first_accept : 0u;
+  if (VERIFY) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off + ax->dfa_off);
+    for (uint32_t i = tid; i < ax->dfa_states * 64u; i += kThreads) reinterpret_cast<uint32_t*>(s_dfa)[i] = src[i];
+  }
   s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x1000000u : 0u);
   __syncthreads();
   if (static_cast<uint32_t>(tid) < nlits) atomicOr(&s_T[t_bytes[t_off[tid] + 2]], 0x10000u << t_bucket[tid]);   // third-byte masks
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   if (group >= a.ngroups) return;
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
+  uint32_t long_hit = 0, edge_hit = 0;                             // VERIFY, per lane: match longer than the UseBoth restart span / walk cut by the window
 
   u32x4 x[4];
   uint32_t xprev = 0;
@@ -257,6 +268,20 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
                 if (q == len) mlen = len;
               }
             }
+            if (VERIFY && mlen) {                                   // literal found: the anchored DFA gives the match end
+              uint32_t q = dfa_start;
+              int32_t last = -1, i = c;
+              const int32_t lim = rend < kWin ? rend : kWin;
+              for (;; i++) {
+                if (q >= dfa_fa) last = i;
+                if (i >= lim) break;
+                q = s_dfa[q * 256u + wb[i]];
+                if (q == 0u) break;
+              }
+              if (q != 0u && i >= kWin && rend > kWin) edge_hit = 1;    // alive at the window edge: the match may go on
+              mlen = last > c ? last - c : 0;
+              if (a.max_len != 0 && static_cast<uint32_t>(mlen) > a.max_len) long_hit = 1;
+            }
           }
           // ---- D: FindAll order inside the round (candidates ascend with the lane)
           const int32_t e = mlen ? c + mlen : 0;
@@ -303,7 +328,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
     nrows_w += emitted_here;
   }
   if (nrows_w > static_cast<uint32_t>(kTRows)) fallback |= 16;
+  if (VERIFY && __ballot(edge_hit != 0) != 0ull) fallback |= 32;
   if (fallback != 0 && lane == 0) raise_err(a.err, 8u | (fallback << 8));
+  if (VERIFY && __ballot(long_hit != 0) != 0ull && lane == 0) raise_err(a.err, kErrLongMatch);
   __syncthreads();
 
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
@@ -336,8 +363,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_scan_teddy_wave(ScanArgs a) {
   }
 }
 
-hipError_t launch_scan_teddy_wave(const ScanArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_teddy_wave, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream) {
+  if (verify_dfa_states) hipLaunchKernelGGL(k_scan_teddy_wave<true>, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), verify_dfa_states * 256u, stream, a);
+  else hipLaunchKernelGGL(k_scan_teddy_wave<false>, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -265,6 +265,9 @@ struct TeddyView {
 struct TeddyAux {           // layout of the blob's aux section (all offsets relative to aux start)
   uint32_t nlits, nbuckets, minlen, maxlen;
   uint32_t ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len, _pad;
+  // kFlagPrefixLiteral images (a UseDFA program behind its required literal prefix): the anchored forward DFA,
+  // [dfa_states][256] u8, that turns a prefix occurrence into the match end (0 states: plain literal set)
+  uint32_t dfa_off, dfa_states, dfa_start, dfa_first_accept;
 };
 
 template <class Mem>
@@ -426,6 +429,8 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
                                 // the scan over when it sees such an end (program.cc extractChain)
   uint8_t pad[7];
 };
+constexpr uint32_t kFlagPrefixLiteral = 256u;  // kKindBidir image whose aux section is a TeddyAux: every match begins with one literal (>= 3 bytes);
+                                                // scan_teddy_wave.hip finds the occurrences and walks the anchored DFA from each, the DFA pair stays the fallback
 constexpr uint32_t kFlagBothRestart = 128u;    // UseBoth program: the reference restarts its PikeVM 100 bytes before the DFA's match end
                                                 // (find_indices.go:425-431) — identical to leftmost-first unless a match is longer than that
 constexpr uint32_t kBothRestartSpan = 100u;

@@ -8,6 +8,7 @@
 namespace cxg {
 
 void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count);
+bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why);
 
 namespace {
 
@@ -460,6 +461,8 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     std::vector<uint8_t> blob(sizeof h, 0);
     std::vector<uint8_t> sflags;
     std::vector<uint8_t> pureLiteral;              // UseDFA program that is one plain literal the chain kernel does not take
+    std::vector<uint8_t> prefixLiteral;            // ... or that begins with a required literal of >= 3 bytes:
+    Dfa prefixDfa;                                 //     the anchored DFA that extends an occurrence to the match end
     cxgdev::ChainAux chain;
     std::memset(&chain, 0, sizeof chain);
     if (strategy == CXG_USE_DIGIT_PREFILTER) {
@@ -563,9 +566,34 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           if (plain && q >= anch.firstAccept && anch.firstAccept == anch.nstates - 1) {
             for (int b = 0; b < 256; b++) if (anch.table[static_cast<size_t>(q) * 256 + b] != 0) plain = false;   // nothing follows the literal
             if (plain && lit.size() >= 3 && lit.size() <= 255) pureLiteral = lit;
+          } else if (!plain && lit.size() >= 3 && anch.nstates <= 64) {
+            // every match begins with `lit` (the anchored DFA leaves each of its first states on exactly one byte): the
+            // literal kernels find the occurrences, the anchored DFA gives each its end (the reference runs the same
+            // split as prefilter + DFA, a18); leftmost-first, non-overlapping, as the DFA pair would answer
+            if (lit.size() > 32) lit.resize(32);
+            prefixLiteral = lit;
+            prefixDfa = anch;
           }
         }
       } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
+      if (!prefixLiteral.empty()) {
+        std::vector<uint8_t> aux;
+        std::string why;
+        if (makeLiteralAux({prefixLiteral}, 1, aux, why) && aux.size() <= 2048) {
+          cxgdev::TeddyAux ax;
+          std::memcpy(&ax, aux.data(), sizeof ax);
+          ax.dfa_off = static_cast<uint32_t>(aux.size());
+          ax.dfa_states = prefixDfa.nstates; ax.dfa_start = prefixDfa.start; ax.dfa_first_accept = prefixDfa.firstAccept;
+          aux.insert(aux.end(), prefixDfa.table.begin(), prefixDfa.table.end());
+          while (aux.size() % 16) aux.push_back(0);
+          std::memcpy(aux.data(), &ax, sizeof ax);
+          while (blob.size() % 16) blob.push_back(0);
+          h.aux_off = static_cast<uint32_t>(blob.size());
+          h.aux_len = static_cast<uint32_t>(aux.size());
+          blob.insert(blob.end(), aux.begin(), aux.end());
+          h.flags |= cxgdev::kFlagPrefixLiteral;
+        }
+      }
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
     }
@@ -895,18 +923,19 @@ void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint
 // NewTeddy / buildMasks (prefilter/teddy.go:189-311): 2..32 literals of >= 3 bytes, bucket = id mod 8,
 // 2-byte fingerprint.  33..64 literals (Fat Teddy) and > 64 (Aho-Corasick) are outside the device subset.
 // min_count 1: a single literal of a UseDFA program (buildProgramFromNfa) searched with the same kernels.
-void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count) {
-  p->supported = false;
-  if (lits.size() < min_count || lits.size() > 32) { p->whyNot = "Slim Teddy takes 2..32 literals"; return; }
+// Literal tables of the Teddy kernels (walk.hpp TeddyAux + arrays), appended to `aux`; false + why when the set is
+// outside the device subset.
+bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why) {
+  if (lits.size() < min_count || lits.size() > 32) { why = "Slim Teddy takes 2..32 literals"; return false; }
   size_t minlen = SIZE_MAX, maxlen = 0;
   for (auto& l : lits) { minlen = std::min(minlen, l.size()); maxlen = std::max(maxlen, l.size()); }
-  if (minlen < 3) { p->whyNot = "Teddy literal shorter than 3 bytes"; return; }
-  if (maxlen > 255) { p->whyNot = "Teddy literal longer than 255 bytes"; return; }
+  if (minlen < 3) { why = "Teddy literal shorter than 3 bytes"; return false; }
+  if (maxlen > 255) { why = "Teddy literal longer than 255 bytes"; return false; }
   for (size_t i = 0; i < lits.size(); i++)
     for (size_t j = 0; j < lits.size(); j++)
       if (i != j && lits[i].size() <= lits[j].size() && std::equal(lits[i].begin(), lits[i].end(), lits[j].begin())) {
-        p->whyNot = "literal set is not prefix-free (the reference's verification order becomes observable)";
-        return;
+        why = "literal set is not prefix-free (the reference's verification order becomes observable)";
+        return false;
       }
   const uint32_t nb = static_cast<uint32_t>(std::min<size_t>(8, lits.size()));
   uint16_t ab[256] = {0};
@@ -918,21 +947,10 @@ void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& 
     }
     for (int b = 0; b < 256; b++) ab[b] = static_cast<uint16_t>((lo[0][b & 15] & hi[0][b >> 4]) | ((lo[1][b & 15] & hi[1][b >> 4]) << 8));
   }
-  cxgdev::BlobHeader h;
-  std::memset(&h, 0, sizeof h);
-  h.magic = cxgdev::kBlobMagic;
-  h.kind = cxgdev::kKindTeddy;
-  h.ngroups = 1;
-  std::vector<uint8_t> blob(sizeof h, 0);
-  h.info_off = static_cast<uint32_t>(blob.size());
-  bool inAlpha[256] = {false};
-  for (auto& l : lits) for (uint8_t b : l) inAlpha[b] = true;
-  for (int b = 0; b < 256; b++) blob.push_back(inAlpha[b] ? 0 : cxgdev::kInfoSync);
-  h.aux_off = static_cast<uint32_t>(blob.size());
   cxgdev::TeddyAux ax;
   std::memset(&ax, 0, sizeof ax);
   ax.nlits = static_cast<uint32_t>(lits.size()); ax.nbuckets = nb; ax.minlen = static_cast<uint32_t>(minlen); ax.maxlen = static_cast<uint32_t>(maxlen);
-  std::vector<uint8_t> aux(sizeof ax, 0);
+  aux.assign(sizeof ax, 0);
   auto align = [&](size_t a) { while (aux.size() % a) aux.push_back(0); };
   ax.ab_off = static_cast<uint32_t>(aux.size());
   aux.insert(aux.end(), reinterpret_cast<uint8_t*>(ab), reinterpret_cast<uint8_t*>(ab) + sizeof ab);
@@ -952,8 +970,26 @@ void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& 
   for (auto& l : lits) aux.insert(aux.end(), l.begin(), l.end());
   ax.bytes_len = static_cast<uint32_t>(aux.size()) - ax.bytes_off;
   align(16);
-  if (aux.size() > 4096) { p->whyNot = "literal table exceeds the kernels' LDS budget (4 KiB)"; return; }
+  if (aux.size() > 4096) { why = "literal table exceeds the kernels' LDS budget (4 KiB)"; return false; }
   std::memcpy(aux.data(), &ax, sizeof ax);
+  return true;
+}
+
+void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count) {
+  p->supported = false;
+  std::vector<uint8_t> aux;
+  if (!makeLiteralAux(lits, min_count, aux, p->whyNot)) return;
+  cxgdev::BlobHeader h;
+  std::memset(&h, 0, sizeof h);
+  h.magic = cxgdev::kBlobMagic;
+  h.kind = cxgdev::kKindTeddy;
+  h.ngroups = 1;
+  std::vector<uint8_t> blob(sizeof h, 0);
+  h.info_off = static_cast<uint32_t>(blob.size());
+  bool inAlpha[256] = {false};
+  for (auto& l : lits) for (uint8_t b : l) inAlpha[b] = true;
+  for (int b = 0; b < 256; b++) blob.push_back(inAlpha[b] ? 0 : cxgdev::kInfoSync);
+  h.aux_off = static_cast<uint32_t>(blob.size());
   h.aux_len = static_cast<uint32_t>(aux.size());
   blob.insert(blob.end(), aux.begin(), aux.end());
   h.total_bytes = static_cast<uint32_t>(blob.size());

@@ -9,7 +9,7 @@ seed0, seed1 = int(sys.argv[1]), int(sys.argv[2])
 atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?", "(?:a|b|c)+",
-         "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
+         "abcabc", "abc", "xyz", "a:c", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
 alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff", dtype=np.uint8)
 bad=0; tot=0; strat={}
 t0=time.time()
@@ -52,7 +52,7 @@ for seed in range(seed0, seed1):
                     for geom in ((192,64),(3840,256)):
                         g6 = emu.find_all_chain6(blob, hay, *geom)
                         if not isinstance(g6,int) and g6.tolist()!=exp: print('CHAIN6', repr(pat), len(hay), geom, len(g6), len(exp)); bad+=1
-                if kind == 4:                     # literal image: UseTeddy, or a UseDFA program that is one plain literal
+                if kind == 4 or (fl & 256):       # literal image (UseTeddy / one plain literal), or required literal prefix + anchored DFA
                     g = emu.find_all_teddy_wave(blob, hay)
                     if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('TEDDYW', repr(pat), len(hay)); bad+=1
                 if rx.strategy=='UseCharClassSearcher' and (fl & 64):

@@ -334,10 +334,12 @@ extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, 
 extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                                            int tile_bytes, int halo_bytes) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
-  if (h->magic != kBlobMagic || h->kind != kKindTeddy) return -1;
+  const bool verify_dfa = h->magic == kBlobMagic && h->kind == kKindBidir && (h->flags & kFlagPrefixLiteral);   // prefix literal + anchored DFA
+  if (h->magic != kBlobMagic || (h->kind != kKindTeddy && !verify_dfa)) return -1;
   const uint8_t* info = blob + h->info_off;
   const uint8_t* aux = blob + h->aux_off;
   const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(aux);
+  const uint8_t* dfa = aux + ax->dfa_off;
   TeddyView tv{reinterpret_cast<const uint16_t*>(aux + ax->ab_off), aux + ax->order_off, aux + ax->lens_off,
                aux + ax->bucket_off, reinterpret_cast<const uint16_t*>(aux + ax->off_off), aux + ax->bytes_off, ax->nlits};
   uint32_t T[256];
@@ -387,6 +389,19 @@ extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* h
           if (c + ln > rend) continue;
           if (std::memcmp(g + c, tv.bytes + tv.off[id], static_cast<size_t>(ln)) == 0) mlen = ln;
         }
+      }
+      if (mlen && verify_dfa) {                  // the occurrence of the prefix is extended by the anchored DFA (window bytes only)
+        uint32_t q = ax->dfa_start;
+        int64_t last = -1, i = c;
+        const int64_t lim = rend < N ? rend : N;
+        for (;; i++) {
+          if (q >= ax->dfa_first_accept) last = i;
+          if (i >= lim) break;
+          q = dfa[q * 256 + g[i]];
+          if (q == 0) break;
+        }
+        if (q != 0 && i >= N && rend > N) return -(16 + 32);   // still alive at the window edge: the kernel hands the scan over
+        mlen = last > c ? last - c : 0;
       }
       if (mlen && c >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + c); res.push_back(static_cast<int64_t>(tile_lo) + c + mlen); cur_end = c + mlen; }
     }

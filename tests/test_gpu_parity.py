@@ -657,3 +657,30 @@ def test_plain_literals_with_many_distinct_bytes(need_gpu, oracle):
     t = cx.Timing()
     assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
     assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex("warning").find_all_index(hay))
+
+
+def test_required_literal_prefix_programs(need_gpu, oracle):
+    """UseDFA programs that are neither a chain nor a plain literal but begin with a required literal of >= 3 bytes
+    (`HTTP/\\d\\.\\d`, `status=\\d+`, `GET /[a-z/]+`): the literal kernel finds the occurrences and the anchored DFA, walked
+    over the window's bytes, gives each its end (walk.hpp kFlagPrefixLiteral).  One launch; a match that outlasts the
+    window hands the scan to the DFA-pair kernel.  Rows equal the oracle's either way."""
+    import torch
+    line = b'10.1.2.3 - - "GET /api/v1/items HTTP/1.1" 200 512 status=404 user_id=ab12ff HTTP/1. statu status=x HTTP/2.0' + b" " * 160 + b"\n"   # sparse enough for the row buffers
+    text = line * 6000 + b"GET /" + b"a" * 6000 + b" status=1"            # the long path outlasts a window: fallback
+    calm = (line * 6000)
+    for pat in (r"HTTP/\d\.\d", r"status=\d+", r"user_id=[a-f0-9]+", r"GET /[a-z/]+", r"HTTP/\d\.\d+x?"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported and rx.strategy == o.strategy, pat
+        for hay in (calm, text, b"", b"HTTP/1.1", b"xHTTP/1.1HTTP/2.2"):
+            assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), (pat, len(hay))
+            assert rx.count(hay) == len(o.find_all_index(hay))
+    n = len(calm) // 4096 * 4096
+    hay = np.frombuffer(calm[:n], dtype=np.uint8)
+    buf = cx.DeviceBuffer(n)
+    buf.upload(hay)
+    rx = cx.compile(r"HTTP/\d\.\d")
+    cnt = rx.find_all_device(buf.ptr, n)
+    out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
+    assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"HTTP/\d\.\d").find_all_index(hay))

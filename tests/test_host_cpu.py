@@ -465,7 +465,7 @@ def test_wide_fuzz_host_and_twins(oracle):
                     twins = []
                     if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter", "UseBoth"):
                         twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
-                    elif struct.unpack_from("<I", blob, 4)[0] == 4:          # literal image: UseTeddy, or a UseDFA program that is one literal
+                    elif struct.unpack_from("<I", blob, 4)[0] == 4 or (flags & 256):   # literal image, or required literal prefix + anchored DFA
                         twins = [emu.find_all_teddy_wave(blob, hay)]
                     elif rx.strategy == "UseCharClassSearcher" and (flags & 64):
                         twins = [emu.find_all_charclass_wave(blob, hay)]
