@@ -461,7 +461,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     std::vector<uint8_t> blob(sizeof h, 0);
     std::vector<uint8_t> sflags;
     std::vector<uint8_t> pureLiteral;              // UseDFA program that is one plain literal the chain kernel does not take
-    std::vector<uint8_t> prefixLiteral;            // ... or that begins with a required literal of >= 3 bytes:
+    std::vector<std::vector<uint8_t>> prefixLiterals;   // ... or that begins with one of a few required literals of >= 3 bytes:
     Dfa prefixDfa;                                 //     the anchored DFA that extends an occurrence to the match end
     cxgdev::ChainAux chain;
     std::memset(&chain, 0, sizeof chain);
@@ -566,20 +566,40 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           if (plain && q >= anch.firstAccept && anch.firstAccept == anch.nstates - 1) {
             for (int b = 0; b < 256; b++) if (anch.table[static_cast<size_t>(q) * 256 + b] != 0) plain = false;   // nothing follows the literal
             if (plain && lit.size() >= 3 && lit.size() <= 255) pureLiteral = lit;
-          } else if (!plain && lit.size() >= 3 && anch.nstates <= 64) {
-            // every match begins with `lit` (the anchored DFA leaves each of its first states on exactly one byte): the
-            // literal kernels find the occurrences, the anchored DFA gives each its end (the reference runs the same
-            // split as prefilter + DFA, a18); leftmost-first, non-overlapping, as the DFA pair would answer
-            if (lit.size() > 32) lit.resize(32);
-            prefixLiteral = lit;
-            prefixDfa = anch;
+          } else if (anch.nstates <= 64) {
+            // Every match begins with one of at most 32 byte strings of one length D >= 3 (all paths of length D from
+            // the anchored start; no match is shorter): the literal kernels find the occurrences, the anchored DFA gives
+            // each its end (the reference runs the same split as prefilter + DFA, a18); leftmost-first, non-overlapping,
+            // as the DFA pair would answer.  The largest D <= 8 that keeps the set within 32 wins (fewest false candidates).
+            struct Item { uint32_t q; std::vector<uint8_t> bytes; };
+            std::vector<Item> cur{{anch.start, {}}};
+            for (int depth = 0; depth < 8; depth++) {
+              std::vector<Item> nxt;
+              bool ok = true;
+              for (const Item& it : cur) {
+                if (it.q >= anch.firstAccept) { ok = false; break; }          // a match of `depth` bytes: no longer prefix
+                for (int b = 0; b < 256 && ok; b++) {
+                  const uint32_t t = anch.table[static_cast<size_t>(it.q) * 256 + b];
+                  if (!t) continue;
+                  Item n{t, it.bytes};
+                  n.bytes.push_back(static_cast<uint8_t>(b));
+                  nxt.push_back(std::move(n));
+                  if (nxt.size() > 32) ok = false;
+                }
+                if (!ok) break;
+              }
+              if (!ok || nxt.empty()) break;
+              cur.swap(nxt);
+              if (depth + 1 >= 3) { prefixLiterals.clear(); for (const Item& it : cur) prefixLiterals.push_back(it.bytes); }
+            }
+            if (!prefixLiterals.empty()) prefixDfa = anch;
           }
         }
       } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
-      if (!prefixLiteral.empty()) {
+      if (!prefixLiterals.empty()) {
         std::vector<uint8_t> aux;
         std::string why;
-        if (makeLiteralAux({prefixLiteral}, 1, aux, why) && aux.size() <= 2048) {
+        if (makeLiteralAux(prefixLiterals, 1, aux, why) && aux.size() <= 2048) {
           cxgdev::TeddyAux ax;
           std::memcpy(&ax, aux.data(), sizeof ax);
           ax.dfa_off = static_cast<uint32_t>(aux.size());

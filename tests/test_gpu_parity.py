@@ -311,7 +311,7 @@ def test_random_patterns(need_gpu, oracle):
     rng = np.random.default_rng(78)
     atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
              "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
-             "abcx|bcxy|cxyz|xyza", "z+"]
+             "abcx|bcxy|cxyz|xyza", "z+", "abc", "xyz", "a:c"]
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
     tile = 3840
     skew = np.ones(len(alphabet)); skew[:6] = 8; skew /= skew.sum()
@@ -668,7 +668,8 @@ def test_required_literal_prefix_programs(need_gpu, oracle):
     line = b'10.1.2.3 - - "GET /api/v1/items HTTP/1.1" 200 512 status=404 user_id=ab12ff HTTP/1. statu status=x HTTP/2.0' + b" " * 160 + b"\n"   # sparse enough for the row buffers
     text = line * 6000 + b"GET /" + b"a" * 6000 + b" status=1"            # the long path outlasts a window: fallback
     calm = (line * 6000)
-    for pat in (r"HTTP/\d\.\d", r"status=\d+", r"user_id=[a-f0-9]+", r"GET /[a-z/]+", r"HTTP/\d\.\d+x?"):
+    for pat in (r"HTTP/\d\.\d", r"status=\d+", r"user_id=[a-f0-9]+", r"GET /[a-z/]+", r"HTTP/\d\.\d+x?", r"(GET|POST|PUT) /[a-z/]+",
+                r"[GP][EO][TS]T? /\w+", r"(user_id|status)=\w+"):      # several required literals of one length: alternations, small classes
         rx, o = cx.compile(pat), oracle.Regex(pat)
         assert rx.supported and rx.strategy == o.strategy, pat
         for hay in (calm, text, b"", b"HTTP/1.1", b"xHTTP/1.1HTTP/2.2"):

@@ -417,7 +417,7 @@ def test_wide_fuzz_host_and_twins(oracle):
     atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
              "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
              "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?",
-             "(?:a|b|c)+", "abcabc", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
+             "(?:a|b|c)+", "abcabc", "abc", "xyz", "a:c", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX", dtype=np.uint8)
     n_dev, n_sub, n_chain, n_both, n_both_long = 0, 0, 0, 0, 0
     for seed in (300, 301, 302, 303):
