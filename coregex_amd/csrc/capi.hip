@@ -314,7 +314,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
     gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
-  if (gen == 0 && !submatch && h->kind == cxgdev::kKindBidir && (h->flags & cxgdev::kFlagPrefixLiteral)) {
+  if (gen == 0 && h->kind == cxgdev::kKindBidir && (h->flags & cxgdev::kFlagPrefixLiteral)) {
     static const bool noPrefix = getenv("CXG_NO_PREFIX_KERNEL") != nullptr;
     if (!noPrefix) gen = 9;                                        // literal occurrences + anchored DFA walk (scan_teddy_wave.hip VERIFY)
   }
@@ -366,7 +366,7 @@ relaunch:
   if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
-    const uint8_t* hb = p->blob.data();
+    const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     le = cxgdev::launch_scan_teddy_wave(a, reinterpret_cast<const cxgdev::TeddyAux*>(hb + h->aux_off)->dfa_states, stream);
   }
   else if (gen == 6) {

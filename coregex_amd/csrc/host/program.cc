@@ -441,6 +441,56 @@ void extractChain(const Dfa& d, const uint8_t info[256], cxgdev::ChainAux& chain
 
 }  // namespace
 
+// Every match begins with one of at most 32 byte strings of one length D, 3 <= D <= 8: all paths of length D from the
+// anchored start, no match shorter.  The literal kernels find the occurrences, the anchored DFA gives each its end
+// (the reference runs the same split as prefilter + DFA, a18); leftmost-first, non-overlapping, as the DFA pair would
+// answer.  The largest D that keeps the set within 32 wins (fewest false candidates).
+bool requiredPrefixes(const Dfa& anch, std::vector<std::vector<uint8_t>>& lits) {
+  lits.clear();
+  if (anch.nstates > 64) return false;               // the walk table lives in LDS: 16 KiB at most
+  struct Item { uint32_t q; std::vector<uint8_t> bytes; };
+  std::vector<Item> cur{{anch.start, {}}};
+  for (int depth = 0; depth < 8; depth++) {
+    std::vector<Item> nxt;
+    bool ok = true;
+    for (const Item& it : cur) {
+      if (it.q >= anch.firstAccept) { ok = false; break; }          // a match of `depth` bytes: no longer prefix
+      for (int b = 0; b < 256 && ok; b++) {
+        const uint32_t t = anch.table[static_cast<size_t>(it.q) * 256 + b];
+        if (!t) continue;
+        Item n{t, it.bytes};
+        n.bytes.push_back(static_cast<uint8_t>(b));
+        nxt.push_back(std::move(n));
+        if (nxt.size() > 32) ok = false;
+      }
+      if (!ok) break;
+    }
+    if (!ok || nxt.empty()) break;
+    cur.swap(nxt);
+    if (depth + 1 >= 3) { lits.clear(); for (const Item& it : cur) lits.push_back(it.bytes); }
+  }
+  return !lits.empty();
+}
+
+// Appends the literal tables + the anchored DFA as the aux section of a DFA-pair image (kFlagPrefixLiteral).
+void appendPrefixAux(std::vector<uint8_t>& blob, cxgdev::BlobHeader& h, const std::vector<std::vector<uint8_t>>& lits, const Dfa& anch) {
+  std::vector<uint8_t> aux;
+  std::string why;
+  if (!makeLiteralAux(lits, 1, aux, why) || aux.size() > 2048) return;
+  cxgdev::TeddyAux ax;
+  std::memcpy(&ax, aux.data(), sizeof ax);
+  ax.dfa_off = static_cast<uint32_t>(aux.size());
+  ax.dfa_states = anch.nstates; ax.dfa_start = anch.start; ax.dfa_first_accept = anch.firstAccept;
+  aux.insert(aux.end(), anch.table.begin(), anch.table.end());
+  while (aux.size() % 16) aux.push_back(0);
+  std::memcpy(aux.data(), &ax, sizeof ax);
+  while (blob.size() % 16) blob.push_back(0);
+  h.aux_off = static_cast<uint32_t>(blob.size());
+  h.aux_len = static_cast<uint32_t>(aux.size());
+  blob.insert(blob.end(), aux.begin(), aux.end());
+  h.flags |= cxgdev::kFlagPrefixLiteral;
+}
+
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
   p->strategy = strategy;
   p->flags = flags;
@@ -566,54 +616,12 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           if (plain && q >= anch.firstAccept && anch.firstAccept == anch.nstates - 1) {
             for (int b = 0; b < 256; b++) if (anch.table[static_cast<size_t>(q) * 256 + b] != 0) plain = false;   // nothing follows the literal
             if (plain && lit.size() >= 3 && lit.size() <= 255) pureLiteral = lit;
-          } else if (anch.nstates <= 64) {
-            // Every match begins with one of at most 32 byte strings of one length D >= 3 (all paths of length D from
-            // the anchored start; no match is shorter): the literal kernels find the occurrences, the anchored DFA gives
-            // each its end (the reference runs the same split as prefilter + DFA, a18); leftmost-first, non-overlapping,
-            // as the DFA pair would answer.  The largest D <= 8 that keeps the set within 32 wins (fewest false candidates).
-            struct Item { uint32_t q; std::vector<uint8_t> bytes; };
-            std::vector<Item> cur{{anch.start, {}}};
-            for (int depth = 0; depth < 8; depth++) {
-              std::vector<Item> nxt;
-              bool ok = true;
-              for (const Item& it : cur) {
-                if (it.q >= anch.firstAccept) { ok = false; break; }          // a match of `depth` bytes: no longer prefix
-                for (int b = 0; b < 256 && ok; b++) {
-                  const uint32_t t = anch.table[static_cast<size_t>(it.q) * 256 + b];
-                  if (!t) continue;
-                  Item n{t, it.bytes};
-                  n.bytes.push_back(static_cast<uint8_t>(b));
-                  nxt.push_back(std::move(n));
-                  if (nxt.size() > 32) ok = false;
-                }
-                if (!ok) break;
-              }
-              if (!ok || nxt.empty()) break;
-              cur.swap(nxt);
-              if (depth + 1 >= 3) { prefixLiterals.clear(); for (const Item& it : cur) prefixLiterals.push_back(it.bytes); }
-            }
-            if (!prefixLiterals.empty()) prefixDfa = anch;
+          } else if (requiredPrefixes(anch, prefixLiterals)) {
+            prefixDfa = anch;
           }
         }
       } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
-      if (!prefixLiterals.empty()) {
-        std::vector<uint8_t> aux;
-        std::string why;
-        if (makeLiteralAux(prefixLiterals, 1, aux, why) && aux.size() <= 2048) {
-          cxgdev::TeddyAux ax;
-          std::memcpy(&ax, aux.data(), sizeof ax);
-          ax.dfa_off = static_cast<uint32_t>(aux.size());
-          ax.dfa_states = prefixDfa.nstates; ax.dfa_start = prefixDfa.start; ax.dfa_first_accept = prefixDfa.firstAccept;
-          aux.insert(aux.end(), prefixDfa.table.begin(), prefixDfa.table.end());
-          while (aux.size() % 16) aux.push_back(0);
-          std::memcpy(aux.data(), &ax, sizeof ax);
-          while (blob.size() % 16) blob.push_back(0);
-          h.aux_off = static_cast<uint32_t>(blob.size());
-          h.aux_len = static_cast<uint32_t>(aux.size());
-          blob.insert(blob.end(), aux.begin(), aux.end());
-          h.flags |= cxgdev::kFlagPrefixLiteral;
-        }
-      }
+      if (!prefixLiterals.empty()) appendPrefixAux(blob, h, prefixLiterals, prefixDfa);
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
     }
@@ -823,6 +831,9 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
           while (blob.size() % 16) blob.push_back(0);
           h.aux_len = static_cast<uint32_t>(blob.size()) - h.aux_off;
           spanChain = chain;
+        } else {
+          std::vector<std::vector<uint8_t>> lits;
+          if (requiredPrefixes(anch, lits)) appendPrefixAux(blob, h, lits, anch);
         }
       } catch (const BuildError&) {}
       h.total_bytes = static_cast<uint32_t>(blob.size());

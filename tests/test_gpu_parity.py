@@ -675,6 +675,10 @@ def test_required_literal_prefix_programs(need_gpu, oracle):
         for hay in (calm, text, b"", b"HTTP/1.1", b"xHTTP/1.1HTTP/2.2"):
             assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), (pat, len(hay))
             assert rx.count(hay) == len(o.find_all_index(hay))
+    for pat in (r"(GET|POST|PUT) /([a-z/]+)", r"(status|user_id)=(\w+)", r"HTTP/(\d)\.(\d)"):     # captures: spans from the same kernel
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        for hay in (calm, text, b"GET /a POST /b"):
+            assert np.array_equal(rx.find_all_submatch_index(hay), o.find_all_submatch_index(hay)), (pat, len(hay))
     n = len(calm) // 4096 * 4096
     hay = np.frombuffer(calm[:n], dtype=np.uint8)
     buf = cx.DeviceBuffer(n)
