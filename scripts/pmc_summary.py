@@ -20,7 +20,7 @@ if "--json" in sys.argv:
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
             rec = {"kernel": k, "pattern": r"\d+\.\d+\.\d+\.\d+", "synth_config": 2, "bytes_per_gpu": 1 << 30, "digit_kernel": "6",
-                   "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (scripts/gpu_experiment.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
+                   "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (scripts/gpu_pmc_traffic.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
                    "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb,
                    "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE as reported (uncalibrated)",
                    "traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
