@@ -332,7 +332,7 @@ relaunch:
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 5 || gen == 6 || gen == 7 || gen == 9) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
-  if (gen == 6 && denseChain) {                                     // four times the row-buffer room per wave-tile
+  if ((gen == 6 || gen == 7 || gen == 9) && denseChain) {           // four times the row-buffer room per wave-tile
     a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
     const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * cxgdev::kDenseTilesPerWave;
     a.ngroups = (len + gb - 1) / gb;
@@ -457,8 +457,8 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
-    if (gen == 6 && (err >> 8) == 0x10u && !denseChain) {           // only the row buffers overflowed: same kernel, two tiles per wave
-      if (verbose) fprintf(stderr, "[cxg] chain kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
+    if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain) {   // only the row buffers overflowed: same kernel, two tiles per wave
+      if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
       denseChain = true;
       p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
       relaunches++;

@@ -72,8 +72,11 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
 // VERIFY: the image is a UseDFA program behind its required literal prefix (walk.hpp kFlagPrefixLiteral): an occurrence
 // of the literal is extended to the match end by walking the anchored forward DFA (table in dynamic LDS) over the
 // window's bytes; a walk still alive at the window edge hands the scan to the DFA-pair kernel.
-template <bool VERIFY>
+// DENSE: two tiles per wave instead of eight — four times the row-buffer room per tile — after a row-buffer overflow
+// on match-dense input (capi.hip), as in scan_chain_wave.hip.
+template <bool VERIFY, bool DENSE>
 __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(ScanArgs a) {
+  constexpr int tpw = DENSE ? kDenseTilesPerWave : kTilesPerWave;
   extern __shared__ __attribute__((aligned(16))) uint8_t s_dfa[];   // VERIFY: [dfa_states][256]
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
   __shared__ uint32_t s_T[256];                                    // A | B<<8 | C<<16 | sync<<24 per byte value
@@ -130,10 +133,10 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   u32x4 x[4];
   uint32_t xprev = 0;
   auto issue_loads = [&](int jj) {
-    const uint64_t wtn = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
-    if (jj < kTilesPerWave && lo < a.len) {
+    if (jj < tpw && lo < a.len) {
       const uint64_t rem = a.len - lo;
       nrec = rem >= static_cast<uint64_t>(kWin) ? kWin : static_cast<int>((rem + 3) & ~3ull);
     }
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   };
   issue_loads(0);
 
-  for (int j = 0; j < kTilesPerWave; j++) {
+  for (int j = 0; j < tpw; j++) {
     lane = lane0;
     asm volatile("" : "+v"(lane));                                  // see scan_chain_wave.hip: no hoisted-and-spilled lane constants
-    const uint64_t wt = group * (kWavesPerBlock * kTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
+    const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
     uint32_t emitted_here = 0;
     if (tile_lo < a.len) {
@@ -336,19 +339,19 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
   if (tid < 64) {
     const int q = tid;
-    const uint32_t v = (q < kWavesPerBlock * kTilesPerWave) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t v = (q < kWavesPerBlock * tpw) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
     const uint32_t incl = wave_inclusive_sum(v);
-    if (q < kWavesPerBlock * kTilesPerWave) s_qbase[q] = incl - v;
-    if (q == kWavesPerBlock * kTilesPerWave - 1) s_qbase[kWavesPerBlock * kTilesPerWave] = incl;
+    if (q < kWavesPerBlock * tpw) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * tpw - 1) s_qbase[kWavesPerBlock * tpw] = incl;
   }
   __syncthreads();
-  const uint32_t total = s_qbase[kWavesPerBlock * kTilesPerWave];
+  const uint32_t total = s_qbase[kWavesPerBlock * tpw];
   tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
-  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave);
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);
   uint32_t start = 0;
-  for (int j = 0; j < kTilesPerWave; j++) {
+  for (int j = 0; j < tpw; j++) {
     const uint32_t n = s_cnt[wave][j];
     const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
     for (uint32_t i = lane0; i < n; i += 64) {
@@ -364,8 +367,15 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
 }
 
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream) {
-  if (verify_dfa_states) hipLaunchKernelGGL(k_scan_teddy_wave<true>, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), verify_dfa_states * 256u, stream, a);
-  else hipLaunchKernelGGL(k_scan_teddy_wave<false>, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+  const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
+  if (verify_dfa_states) {
+    if (dense) hipLaunchKernelGGL((k_scan_teddy_wave<true, true>), grid, block, verify_dfa_states * 256u, stream, a);
+    else hipLaunchKernelGGL((k_scan_teddy_wave<true, false>), grid, block, verify_dfa_states * 256u, stream, a);
+  } else {
+    if (dense) hipLaunchKernelGGL((k_scan_teddy_wave<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_teddy_wave<false, false>), grid, block, 0, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -596,6 +596,19 @@ def test_match_dense_input_switches_to_two_tiles_per_wave(need_gpu, oracle):
             assert t.n_launches == 1, t.n_launches          # the count call above already switched the program to two tiles per wave
         else:
             assert t.n_launches >= 2, t.n_launches          # denser than 256 rows per tile: table-walking kernel
+    # the literal kernels switch the same way: one literal hit per 33 bytes overflows 320 rows per wave and group
+    lit_hay = np.frombuffer(((b"xyz" + b" " * 30) * 8000 + (b"abcd" + b" " * 29) * 8000)[: 96 * 4096], dtype=np.uint8)
+    for pat in ("abcd|xyz|qrst", r"abc[a-z]"):                      # UseTeddy literal set / required prefix + anchored DFA
+        rx = cx.compile(pat)
+        buf = cx.DeviceBuffer(lit_hay.size)
+        buf.upload(lit_hay)
+        exp = oracle.Regex(pat).find_all_index(lit_hay)
+        cnt = rx.find_all_device(buf.ptr, lit_hay.size)
+        out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+        t = cx.Timing()
+        assert rx.find_all_device(buf.ptr, lit_hay.size, out.data_ptr(), cnt + 4, timing=t) == cnt == len(exp)
+        assert t.n_launches == 1, (pat, t.n_launches)
+        assert np.array_equal(out[:cnt].cpu().numpy(), exp), pat
     # captures on dense key=value text
     pat = r"([a-z]+)=(\d+)"
     hay = (b"ab=12 c=3 zz=456 " * 3000)
