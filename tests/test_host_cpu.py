@@ -547,6 +547,41 @@ def test_chain_captures_mapping(oracle):
     assert n_on >= 8
 
 
+def test_program_routing_table():
+    """Which device image a pattern gets (README "Which kernel a program gets"): kind and flags of the program blob.
+    kind 1 digit / 2 DFA pair / 3 char class / 4 literal set; flags 16 ordered chain, 256 required literal prefix,
+    128 UseBoth restart span."""
+    import struct
+
+    def image(pat, sub=False):
+        rx = cx.compile(pat)
+        assert rx.submatch_supported if sub else rx.supported, (pat, rx.why_unsupported)
+        blob = rx.submatch_blobs()[0] if sub else rx.blob()
+        return rx.strategy, struct.unpack_from("<I", blob, 4)[0], struct.unpack_from("<I", blob, 8)[0]
+
+    chain, prefix, both = 16, 256, 128
+    for pat, strategy, kind, must, must_not in [
+            (r"\d+\.\d+\.\d+\.\d+", "UseDigitPrefilter", 1, chain, 0),
+            (r"\d+:\d+:\d+", "UseDigitPrefilter", 1, chain, 0),
+            (r"\d{4}-\d{2}-\d{2}T\d{2}:\d{2}:\d{2}", "UseDigitPrefilter", 1, chain, 0),
+            (r"error", "UseDFA", 2, chain, prefix),
+            (r"[A-Z]{3}-\d{4}", "UseDFA", 2, chain, prefix),
+            (r"[0-9a-f]{8}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{12}", "UseBoth", 2, chain | both, prefix),
+            (r"warning", "UseDFA", 4, 0, chain),
+            (r"error|warning|fatal|critical", "UseTeddy", 4, 0, chain),
+            (r"[\w]+", "UseCharClassSearcher", 3, 64, 0),
+            (r"HTTP/\d\.\d", "UseDFA", 2, prefix, chain),
+            (r"(?:GET|POST|PUT) /[a-z/]+", "UseDFA", 2, prefix, chain),
+            (r"a?c", "UseDFA", 2, 0, chain | prefix)]:
+        got = image(pat)
+        assert got[0] == strategy and got[1] == kind and (got[2] & must) == must and (got[2] & must_not) == 0, (pat, got)
+    assert image(r"(\w+)@(\w+)\.(\w+)", sub=True)[2] & chain and cx.compile(r"(\w+)@(\w+)\.(\w+)").chain_captures() is not None
+    assert image(r"(GET|POST|PUT) /([a-z/]+)", sub=True)[2] & prefix
+    for pat, why in [(r"a?(a|b)", "cache history"), (r"\w+@\w+\.\w+", "has no device kernel"), (r"\bfoo\b", "look-around")]:
+        rx = cx.compile(pat)
+        assert not rx.supported and why in rx.why_unsupported, (pat, rx.strategy, rx.why_unsupported)
+
+
 def test_emulated_no_sync_bytes_at_all(oracle):
     """A haystack made only of pattern-alphabet bytes: one lane walks everything, results still exact."""
     pat = r"\d+\.\d+\.\d+\.\d+"
