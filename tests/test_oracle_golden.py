@@ -222,3 +222,37 @@ def test_oracle_agrees_with_python_re_except_documented_quirks(oracle):
             else:
                 assert o.strategy == "UseBoth" and any(b - a > 100 for a, b in diff[2]), (pat, o.strategy, diff[1][:3], diff[2][:3])
     assert n_same >= 700 and n_history >= 1 and n_digit >= 1, (n_same, n_history, n_digit)
+
+
+def test_oracle_captures_agree_with_python_re(oracle):
+    """FindAllSubmatch of the oracle (PikeVM with slot tables, nfa/pikevm.go:2186-2432) against Python `re` group spans
+    on random non-nullable patterns with nested, optional and repeated groups: leftmost-first captures, -1 for unset."""
+    import re
+    atoms = ["a", "b", "c", "x", r"\.", ":", r"\d", "[a-c]", r"\d+", "[a-c]+", "a+", "(a|b)", "(ab)+", "(a)?", r"(\d{2})", r"(\d{1,3})", "(x*)y",
+             "(xy|ab|ca)", "(a+)(b+)", "(b+?)", "((?:a|b|c)+)", "(abc)", r"(\w+)", r"(\w)", "=", "@", r"([a-z]+)", "(a(b)c)", "((a)|(b))"]
+    alphabet = np.frombuffer(b"abcxy.:=@0123456789 \n", dtype=np.uint8)
+    n = 0
+    for seed in (1, 2, 3):
+        rng = np.random.default_rng(seed)
+        hays = [alphabet[rng.integers(0, len(alphabet), size=k)].tobytes() for k in (3, 200, 3000)]
+        hays += [alphabet[rng.choice(len(alphabet), size=3000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))].tobytes() for _ in range(2)]
+        seen = set()
+        while len(seen) < 150:
+            pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 4))))
+            if pat in seen:
+                continue
+            seen.add(pat)
+            if "(" not in pat:
+                continue
+            try:
+                o = oracle.Regex(pat)
+            except oracle.OracleError:
+                continue
+            pr = re.compile(pat.encode())
+            if pr.search(b"") is not None:
+                continue
+            n += 1
+            for hay in hays:
+                exp = [[v for g in range(pr.groups + 1) for v in m.span(g)] for m in pr.finditer(hay)]
+                assert o.find_all_submatch_index(hay).tolist() == exp, (pat, o.strategy, len(hay))
+    assert n >= 250, n
