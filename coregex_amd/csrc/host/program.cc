@@ -615,7 +615,8 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           }
           if (plain && q >= anch.firstAccept && anch.firstAccept == anch.nstates - 1) {
             for (int b = 0; b < 256; b++) if (anch.table[static_cast<size_t>(q) * 256 + b] != 0) plain = false;   // nothing follows the literal
-            if (plain && lit.size() >= 3 && lit.size() <= 255) pureLiteral = lit;
+            // (a UseBoth literal longer than the 100-byte restart span keeps the DFA-pair image, whose kernels check the span)
+            if (plain && lit.size() >= 3 && lit.size() <= 255 && (strategy != CXG_USE_BOTH || lit.size() <= cxgdev::kBothRestartSpan)) pureLiteral = lit;
           } else if (requiredPrefixes(anch, prefixLiterals)) {
             prefixDfa = anch;
           }
