@@ -569,7 +569,11 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
           std::memset(&chain, 0, sizeof chain);
         }
       }
-    } else if ((strategy == CXG_USE_DFA && (flags & CXG_FLAG_HAS_REVERSE_DFA)) || strategy == CXG_USE_BOTH) {
+    } else if (strategy == CXG_USE_DFA || strategy == CXG_USE_BOTH) {
+      // (UseDFA without the reference's reverse DFA — non-greedy quantifiers, meta/compile.go:184-205 — answers through its
+      // PikeVM, find_indices.go:647: plain leftmost-first, which this forward + reverse pair computes as well: the end of
+      // the leftmost-first match, then the smallest start that reaches it — no match starts earlier, or it would be the
+      // leftmost one.  No lazy DFA is involved there, so there is no cache history to depend on.)
       // useDFADirect (meta/findall.go:216-239): unanchored forward DFA + anchored reverse DFA.
       // UseBoth (findIndicesAdaptiveAtWithState, find_indices.go:408-441): the DFA's match end only picks where the
       // PikeVM starts — `at`, or end-100 when end > at+100.  The PikeVM is leftmost-first, and nothing starts between
@@ -580,7 +584,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
-      refuseOrderConflict(nfa, {nfa.start_unanchored});
+      if (strategy == CXG_USE_BOTH || (flags & CXG_FLAG_HAS_REVERSE_DFA)) refuseOrderConflict(nfa, {nfa.start_unanchored});
       HostNfa rn = reverseOf(nfa);
       cxg_nfa rv = rn.view();
       p->rev = determinize(rv, rv.start_anchored, false, kMaxDfaStates);
