@@ -256,3 +256,34 @@ def test_oracle_captures_agree_with_python_re(oracle):
                 exp = [[v for g in range(pr.groups + 1) for v in m.span(g)] for m in pr.finditer(hay)]
                 assert o.find_all_submatch_index(hay).tolist() == exp, (pat, o.strategy, len(hay))
     assert n >= 250, n
+
+
+def test_findall_index_api_vectors(oracle):
+    for c in VEC["findall_index_api"]["cases"]:
+        rx = oracle.Regex(c["pattern"])
+        assert rx.find_all_index(_inp(c), c["n"]).tolist() == c["want"], c
+    blk = VEC["charclass_find_all_indices_digit"]
+    rx = oracle.Regex(blk["pattern"])
+    assert rx.strategy == "UseCharClassSearcher"
+    for c in blk["cases"]:
+        assert rx.find_all_index(_inp(c)).tolist() == c["want"], c["name"]
+
+
+def test_find_indices_dispatch_vectors(oracle):
+    """First-match tables of meta/find_indices_test.go through the oracle's FindAll(n=1); the `at` variants as the first
+    match of the suffix (these rows have no look-around, so the byte in front of `at` does not matter)."""
+    for c in VEC["find_indices_dispatch"]["cases"]:
+        got = oracle.Regex(c["pattern"]).find_all_index(_inp(c), 1).tolist()
+        assert got == ([c["want"]] if c["found"] else []), c["name"]
+    for c in VEC["find_indices_at_dispatch"]["cases"]:
+        at = c["at"]
+        got = oracle.Regex(c["pattern"]).find_all_index(_inp(c)[at:], 1).tolist()
+        assert got == ([[c["want"][0] - at, c["want"][1] - at]] if c["found"] else []), c["name"]
+
+
+def test_nongreedy_and_count_vectors(oracle):
+    for c in VEC["nongreedy_first_match"]["cases"]:
+        assert oracle.Regex(c["pattern"]).find_all_index(_inp(c), 1).tolist() == [c["want"]], c["name"]
+    for c in VEC["count_dispatch"]["cases"]:
+        rx = oracle.Regex(c["pattern"])
+        assert rx.count(_inp(c)) == c["want"] == len(rx.find_all_index(_inp(c))), c["name"]
