@@ -702,3 +702,44 @@ def test_required_literal_prefix_programs(need_gpu, oracle):
     t = cx.Timing()
     assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
     assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"HTTP/\d\.\d").find_all_index(hay))
+
+
+def test_reference_kats_through_the_c_abi(need_gpu):
+    """The reference's own known-answer tables (tests/golden/reference_vectors.json) against the DEVICE path, not just the
+    oracle: every row whose program the device accepts must give the table's answer."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")) as f:
+        vec = json.load(f)
+    n = 0
+
+    def check(pat, hay, want_rows, limit=-1):
+        nonlocal n
+        try:
+            rx = cx.compile(pat)
+        except cx.CoregexError:
+            return
+        if not rx.supported:
+            return
+        n += 1
+        assert rx.find_all_index(hay, limit).tolist() == want_rows, (pat, hay)
+        assert rx.count(hay, limit) == len(want_rows), (pat, hay)
+
+    for c in vec["findall_index_api"]["cases"]:
+        check(c["pattern"], c["input"].encode(), c["want"], c["n"])
+    for c in vec["charclass_find_all_indices"]["cases"]:
+        hay = bytes.fromhex(c["input_hex"]) if "input_hex" in c else c["input"].encode("latin-1")
+        check(vec["charclass_find_all_indices"]["pattern"], hay, c["want"])
+    for c in vec["charclass_find_all_indices_digit"]["cases"]:
+        check("[0-9]+", c["input"].encode(), c["want"])
+    for c in vec["find_indices_dispatch"]["cases"] + vec["nongreedy_first_match"]["cases"]:
+        check(c["pattern"], c["input"].encode(), [c["want"]] if c.get("found", True) else [], 1)
+    for c in vec["count_dispatch"]["cases"]:
+        try:
+            rx = cx.compile(c["pattern"])
+        except cx.CoregexError:
+            continue
+        if rx.supported:
+            n += 1
+            assert rx.count(c["input"].encode()) == c["want"], c["name"]
+    assert n >= 30, n
