@@ -127,6 +127,15 @@ class Regex:
         n = raw[1]
         return {"run_op": tuple(raw[4:4 + raw[2]]), "slots": [(raw[8 + k], int.from_bytes(raw[24 + k:25 + k], "little", signed=True)) for k in range(n)]}
 
+    def chain_bounds(self):
+        """None, or (raw 40-byte record, [(min, max), ...] per field; max 0 = unbounded) of a bounded-repetition program
+        served by the chain kernel."""
+        buf = C.create_string_buffer(40)
+        if not _lib.lib().cxg_program_chain_bounds(self._h, buf):
+            return None
+        raw = buf.raw
+        return raw, [(raw[8 + f], raw[16 + f]) for f in range(raw[2] + 1)]
+
     def blob(self) -> bytes:
         p, n = C.c_void_p(), C.c_size_t()
         _check(_lib.lib().cxg_program_blob(self._h, C.byref(p), C.byref(n)))

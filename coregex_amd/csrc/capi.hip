@@ -372,6 +372,7 @@ relaunch:
   else if (gen == 6) {
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     std::memcpy(a.chain, hb + h->aux_off + 256, sizeof(cxgdev::ChainAux));
+    if (!submatch && (h->flags & cxgdev::kFlagChainBounded)) std::memcpy(a.caps, p->chainBounds, sizeof a.caps);   // BND instantiation
     if (submatch && a.out && fuseCapsOk && p->chainCaps[0] && p->chainCaps[1] == a.row_width) {   // ChainCaps.on / .nslots
       std::memcpy(a.caps, p->chainCaps, sizeof a.caps);
       fusedCaps = true;
@@ -457,7 +458,7 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
-    if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain) {   // only the row buffers overflowed: same kernel, two tiles per wave
+    if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain && !(h->flags & cxgdev::kFlagChainBounded)) {   // only the row buffers overflowed: same kernel, two tiles per wave
       if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
       denseChain = true;
       p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
@@ -626,6 +627,18 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
       p->whyNot = "the reference may route this pattern to a reverse-search strategy outside the device subset";
     }
     if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view);   // FindAllSubmatchIndex path (spans + one-pass captures)
+    if (p->supported && p->ngroups == 1) {                     // bounded repetition (`\d{1,3}\.\d{1,3}`...) on the chain kernel
+      static const bool noBounded = getenv("CXG_NO_BOUNDED_CHAIN") != nullptr;
+      cxg::Ast sur;
+      std::vector<std::pair<int, int>> bounds;
+      if (!noBounded && cxg::boundedSurrogate(ast, sur, bounds)) {
+        try {
+          cxg::HostNfa sn = cxg::buildNfa(sur);
+          cxg::attachBoundedChain(p, sn.view(), bounds);
+        } catch (const cxg::FrontendError&) {
+        }
+      }
+    }
     *out = p;
     return CXG_OK;
   } catch (const cxg::FrontendError& e) {
@@ -696,6 +709,11 @@ int cxg_program_submatch_blobs(const cxg_program* p, const void** sb, size_t* sl
 int cxg_program_chain_captures(const cxg_program* p, uint8_t out[40]) {
   if (!p || !out || !p->subSupported || !p->chainCaps[0]) return 0;
   std::memcpy(out, p->chainCaps, 40);
+  return 1;
+}
+int cxg_program_chain_bounds(const cxg_program* p, uint8_t out[40]) {
+  if (!p || !out || !p->supported || p->chainBounds[0] != 2) return 0;
+  std::memcpy(out, p->chainBounds, 40);
   return 1;
 }
 int cxg_program_submatch_supported(const cxg_program* p) {

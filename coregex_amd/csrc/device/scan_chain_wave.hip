@@ -170,8 +170,12 @@ struct Words4 {
 // separators (`\d+\.\d+\.\d+\.\d+`, `\d+:\d+:\d+`, `\w+@\w+\.\w+`): the step loops unroll with constant step kinds, the
 // runs use class 0 without a select (with two classes the separator is class 1, with more it is read from the
 // description), no loop control; 0: any chain, steps read from the description.
-template <int NCLS, bool SETS, bool CAP, bool DENSE, int ALTK>
-__global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
+// BND: bounded repetition (`\d{1,3}\.\d{1,3}`...).  The chain evaluated is the surrogate with every run unbounded; the
+// rows are then filtered by field length with the run ends compacted as for CAP (ScanArgs::caps carries the bounds):
+// a middle field outside its bounds drops the row, a longer first field moves the start to run end - max, a longer
+// last field would truncate the match and let FindAll resume inside the run: the tile hands the scan over.
+template <int NCLS, bool SETS, bool CAP, bool DENSE, int ALTK, bool BND>
+__global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
   __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
   const ChainCaps* gcp = reinterpret_cast<const ChainCaps*>(a.caps);   // kernel argument segment: scalar loads
   uint32_t cap_op[kCapMaxRuns];
 #pragma unroll
-  for (int x = 0; x < kCapMaxRuns; x++) cap_op[x] = CAP ? gcp->run_op[x] : 0xFFu;
+  for (int x = 0; x < kCapMaxRuns; x++) cap_op[x] = (CAP || BND) ? gcp->run_op[x] : 0xFFu;
+  const uint32_t bnd_nruns = BND ? gcp->nruns : 0u;                // fields that end at a compacted run end (all but the last)
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
   ChainRegs<NCLS, SETS> ch;
   ch.aux = gch;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
             const unsigned long long PP = __builtin_amdgcn_uicmpl(s1, ~0ull, 32 /*eq*/);
             const unsigned long long recv = (PP + (GG << 1)) ^ PP;
             M = add_carry_mask(s1, recv) & ~Ck;
-            if (CAP) {
+            if (CAP || BND) {
 #pragma unroll
               for (int x = 0; x < kCapMaxRuns; x++) {
                 if (k != cap_op[x]) continue;                          // a captured run: its ends, in match order
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
           }
           fallback |= 4; n = 0;
         }
-        if (CAP && n != 0) {
+        if ((CAP || BND) && n != 0) {
 #pragma unroll
           for (int x = 0; x < kCapMaxRuns; x++) if (cap_op[x] != 0xFFu && capcnt[x] != n) fallback |= 32;   // a marker merged or left the window
           if (fallback & 32) n = 0;
@@ -487,6 +492,55 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP) ? 6 : (NCLS >= 3 ? 7 : CXG
           if (cout && !fixed_len && lane == 0 && nrows_w + (tot >> 16) < static_cast<uint32_t>(kWRows)) s_re[wave][nrows_w + (tot >> 16)] = static_cast<uint16_t>(kWaveTile + kWaveHalo);
         }
         emitted_here = n;
+        if (BND) {
+          ov = 0;                                                   // overlaps are judged on the filtered rows below
+          if (n != 0 && nrows_w + n <= static_cast<uint32_t>(kWRows)) {
+            wave_lds_sync();
+            uint32_t kept = 0, trunc = 0;                           // kept: wave-uniform
+            for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+              const uint32_t q = r0 + static_cast<uint32_t>(lane);
+              const bool have = q < n;
+              const uint32_t r = nrows_w + (have ? q : 0u);
+              int32_t s = s_rs[wave][r];
+              const int32_t e = s_re[wave][r];
+              bool valid = have;
+              int32_t field_lo = s;
+#pragma unroll
+              for (int x = 0; x < kCapMaxRuns; x++) {
+                if (static_cast<uint32_t>(x) >= bnd_nruns) continue;
+                const int32_t re = s_rb[(x * kWavesPerBlock + wave) * kWRows + r];
+                const int32_t mn = gcp->src[x], mx = gcp->src[8 + x];      // scalar loads (kernel arguments)
+                int32_t len = re - field_lo;
+                if (x == 0 && mx != 0 && len > mx) { s = re - mx; len = mx; }   // the match starts inside the first run
+                valid = valid && len >= mn && (mx == 0 || len <= mx);
+                field_lo = re + 1;                                  // past the single-byte separator
+              }
+              {
+                const int32_t mn = gcp->src[bnd_nruns], mx = gcp->src[8 + bnd_nruns];
+                const int32_t len = e - field_lo;
+                if (have && mx != 0 && len > mx) trunc = 1;         // FindAll would resume inside this run
+                valid = valid && len >= mn;
+              }
+              const unsigned long long vm = __ballot(valid);
+              if (valid) {                                          // in place: the target row is never behind the rows still to read
+                const uint32_t w = nrows_w + kept + static_cast<uint32_t>(__popcll(vm & ((1ull << lane) - 1ull)));
+                s_rs[wave][w] = static_cast<uint16_t>(s);
+                s_re[wave][w] = static_cast<uint16_t>(e);
+              }
+              kept += static_cast<uint32_t>(__popcll(vm));
+              wave_lds_sync();
+            }
+            if (__ballot(trunc != 0) != 0ull) fallback |= 64;
+            uint32_t ovr = 0;
+            for (uint32_t r0 = 0; r0 < kept; r0 += 64) {
+              const uint32_t q = r0 + static_cast<uint32_t>(lane);
+              if (q > 0 && q < kept) ovr |= (s_rs[wave][nrows_w + q] < s_re[wave][nrows_w + q - 1]) ? 1u : 0u;
+            }
+            n = kept;
+            emitted_here = kept;
+            ov = ovr;
+          }
+        }
         if (CAP && __ballot(ov != 0) != 0ull) fallback |= 32;        // dropped rows would have to drop their run ends too: two-kernel path
         if (__ballot(ov != 0) != 0ull && nrows_w + n <= static_cast<uint32_t>(kWRows)) {   // rare: resolve serially, in place
           wave_lds_sync();
@@ -573,11 +627,11 @@ template <int NCLS, bool SETS>
 void launch_chain(const ScanArgs& a, bool caps, bool dense, dim3 grid, dim3 block, hipStream_t stream) {
   const size_t dyn = caps ? static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t) : 0;
   if (caps) {
-    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, true, 0>), grid, block, dyn, stream, a);
-    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, false, 0>), grid, block, dyn, stream, a);
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, true, 0, false>), grid, block, dyn, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, true, false, 0, false>), grid, block, dyn, stream, a);
   } else {
-    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, true, 0>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, false, 0>), grid, block, 0, stream, a);
+    if (dense) hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, true, 0, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<NCLS, SETS, false, false, 0, false>), grid, block, 0, stream, a);
   }
 }
 }  // namespace
@@ -598,20 +652,31 @@ hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, b
   const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
   static const bool altOk = getenv("CXG_NO_SHAPE_KERNELS") == nullptr;
   const int altk = (altOk && !dense) ? alternating_runs(*reinterpret_cast<const ChainAux*>(a.chain)) : 0;
+  if (reinterpret_cast<const ChainCaps*>(a.caps)->on == 2) {         // bounded repetition: only the unrolled two-class shapes
+    if (ncls != 2 || sets || caps || dense) return hipErrorInvalidValue;
+    const int k = alternating_runs(*reinterpret_cast<const ChainAux*>(a.chain));
+    const size_t dyn = static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t);
+    switch (k) {
+      case 2: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 2, true>), grid, block, dyn, stream, a); return hipGetLastError();
+      case 3: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 3, true>), grid, block, dyn, stream, a); return hipGetLastError();
+      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 4, true>), grid, block, dyn, stream, a); return hipGetLastError();
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (altk && ncls == 2 && !sets && !caps) {                          // unrolled instantiations for the alternating shapes
     switch (altk) {
-      case 2: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 2>), grid, block, 0, stream, a); return hipGetLastError();
-      case 3: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 3>), grid, block, 0, stream, a); return hipGetLastError();
-      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 4>), grid, block, 0, stream, a); return hipGetLastError();
+      case 2: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 2, false>), grid, block, 0, stream, a); return hipGetLastError();
+      case 3: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 3, false>), grid, block, 0, stream, a); return hipGetLastError();
+      case 4: hipLaunchKernelGGL((k_scan_chain_wave<2, false, false, false, 4, false>), grid, block, 0, stream, a); return hipGetLastError();
       default: break;
     }
   }
   if (altk == 3 && ncls == 3) {                                       // field@field.field: three fields, two different separators
     const size_t dyn = caps ? static_cast<size_t>(reinterpret_cast<const ChainCaps*>(a.caps)->nruns) * kWavesPerBlock * kWRows * sizeof(uint16_t) : 0;
-    if (sets && caps) hipLaunchKernelGGL((k_scan_chain_wave<3, true, true, false, 3>), grid, block, dyn, stream, a);
-    else if (sets) hipLaunchKernelGGL((k_scan_chain_wave<3, true, false, false, 3>), grid, block, 0, stream, a);
-    else if (caps) hipLaunchKernelGGL((k_scan_chain_wave<3, false, true, false, 3>), grid, block, dyn, stream, a);
-    else hipLaunchKernelGGL((k_scan_chain_wave<3, false, false, false, 3>), grid, block, 0, stream, a);
+    if (sets && caps) hipLaunchKernelGGL((k_scan_chain_wave<3, true, true, false, 3, false>), grid, block, dyn, stream, a);
+    else if (sets) hipLaunchKernelGGL((k_scan_chain_wave<3, true, false, false, 3, false>), grid, block, 0, stream, a);
+    else if (caps) hipLaunchKernelGGL((k_scan_chain_wave<3, false, true, false, 3, false>), grid, block, dyn, stream, a);
+    else hipLaunchKernelGGL((k_scan_chain_wave<3, false, false, false, 3, false>), grid, block, 0, stream, a);
     return hipGetLastError();
   }
   switch (ncls * 2 + (sets ? 1 : 0)) {

@@ -429,6 +429,8 @@ struct ChainAux {             // aux section of a kKindDigit blob when kFlagChai
                                 // the scan over when it sees such an end (program.cc extractChain)
   uint8_t pad[7];
 };
+constexpr uint32_t kFlagChainBounded = 512u;   // the ChainAux in aux describes the SURROGATE with unbounded runs of a bounded-repetition program
+                                                // (`\d{1,3}\.\d{1,3}`...); the kernel filters rows by field length (scan_chain_wave.hip BND, cxg_program::chainBounds)
 constexpr uint32_t kFlagPrefixLiteral = 256u;  // kKindBidir image whose aux section is a TeddyAux: every match begins with one literal (>= 3 bytes);
                                                 // scan_teddy_wave.hip finds the occurrences and walks the anchored DFA from each, the DFA pair stays the fallback
 constexpr uint32_t kFlagBothRestart = 128u;    // UseBoth program: the reference restarts its PikeVM 100 bytes before the DFA's match end
@@ -582,7 +584,8 @@ struct CapView {
 constexpr uint8_t kCapSrcStart = 0, kCapSrcEnd = 1, kCapSrcRun0 = 2, kCapSrcUnset = 7;   // Run0 + i: end of captured run i
 constexpr int kCapMaxRuns = 4;
 struct ChainCaps {            // 40 bytes, travels in ScanArgs
-  uint8_t on;                 // 1: valid for this program
+  uint8_t on;                 // 1: capture slots; 2: bounded repetition — nruns = fields but the last, src[x] = min and src[8 + x] = max
+                              //    (0 = unbounded) of field x, no slots
   uint8_t nslots;             // 2 * groups (<= 16)
   uint8_t nruns;              // run ends the kernel compacts (0..4): 4 KiB of LDS each
   uint8_t pad;

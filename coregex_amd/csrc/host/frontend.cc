@@ -1313,4 +1313,54 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   return p;
 }
 
+
+bool boundedSurrogate(const Ast& ast, Ast& out, std::vector<std::pair<int, int>>& bounds) {
+  bounds.clear();
+  out = Ast();
+  if (ast.root < 0 || ast.ncap != 0) return false;
+  auto singleByte = [&](int n) {                       // one byte of input, no case folding, ASCII
+    const Ast::N& x = ast.at(n);
+    if (x.kind == Node::Lit) return x.r.size() == 1 && !x.fold && x.r[0] >= 0 && x.r[0] < 128;
+    if (x.kind != Node::Class || x.r.empty()) return false;
+    for (int32_t r : x.r) if (r < 0 || r > 127) return false;
+    return true;
+  };
+  // items of the top-level concatenation, `(?:...){k}` and `x{k}` unrolled
+  std::vector<int> items;
+  std::function<bool(int, int)> flatten = [&](int n, int depth) -> bool {
+    const Ast::N& x = ast.at(n);
+    if (depth > 4 || items.size() > 64) return false;
+    if (x.kind == Node::Concat) { for (int k : x.kids) if (!flatten(k, depth + 1)) return false; return true; }
+    if (x.kind == Node::Repeat && x.min == x.max && x.min >= 1 && x.min <= 16 && !x.lazy) {
+      for (int c = 0; c < x.min; c++) if (!flatten(x.kids[0], depth + 1)) return false;
+      return true;
+    }
+    items.push_back(n);
+    return true;
+  };
+  if (!flatten(ast.root, 0) || items.empty()) return false;
+  bool anyBounded = false;
+  std::vector<int> outItems;
+  auto copyLeaf = [&](int n) { const int id = out.add(ast.at(n).kind); out.at(id) = ast.at(n); out.at(id).kids.clear(); return id; };
+  for (int n : items) {
+    const Ast::N& x = ast.at(n);
+    if (singleByte(n)) { outItems.push_back(copyLeaf(n)); continue; }
+    const bool plus = x.kind == Node::Plus, rep = x.kind == Node::Repeat && x.min >= 1 && (x.max == -1 || x.max > x.min);
+    if (!(plus || rep) || x.lazy || x.kids.size() != 1 || !singleByte(x.kids[0])) return false;
+    const int kid = copyLeaf(x.kids[0]);
+    const int run = out.add(Node::Plus);
+    out.at(run).kids.push_back(kid);
+    outItems.push_back(run);
+    const int mx = plus || x.max == -1 ? 0 : x.max;
+    if (mx > 255 || x.min > 255) return false;
+    bounds.emplace_back(plus ? 1 : x.min, mx);
+    anyBounded = anyBounded || mx != 0 || (rep && x.min > 1);
+  }
+  if (!anyBounded) return false;
+  if (outItems.size() == 1) out.root = outItems[0];
+  else { const int c = out.add(Node::Concat); out.at(c).kids = outItems; out.root = c; }
+  out.ncap = 0;
+  return true;
+}
+
 }  // namespace cxg

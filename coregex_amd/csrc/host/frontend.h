@@ -14,6 +14,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/coregex_hip.h"
@@ -75,5 +76,11 @@ struct Plan {
 };
 
 Plan selectStrategy(const Ast& ast, const HostNfa& nfa);
+
+// Bounded repetition on the chain kernel (program.cc attachBoundedChain): when the pattern is a concatenation of
+// single-byte items (a literal byte, a class) and runs of one (`x+`, `x{m,n}` with m >= 1, greedy) — `(?:...){k}` groups
+// unrolled — returns the surrogate pattern with every run unbounded (`\d{1,3}\.\d{1,3}` -> `\d+\.\d+`) and the
+// (min, max) of each run in order (max 0 = unbounded).  False when the pattern has another shape or no bounded run.
+bool boundedSurrogate(const Ast& ast, Ast& out, std::vector<std::pair<int, int>>& bounds);
 
 }  // namespace cxg

@@ -911,6 +911,54 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
   }
 }
 
+void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vector<std::pair<int, int>>& bounds) {
+  if (!p->supported || p->blob.size() < sizeof(cxgdev::BlobHeader)) return;
+  cxgdev::BlobHeader h;
+  std::memcpy(&h, p->blob.data(), sizeof h);
+  if (h.kind != cxgdev::kKindDigit && h.kind != cxgdev::kKindBidir) return;
+  if (h.flags & (cxgdev::kFlagChainOrdered | cxgdev::kFlagPrefixLiteral)) return;     // already on a fast path
+  try {
+    const Dfa anch = determinize(surrogate, surrogate.start_anchored, true, kMaxDfaStates);
+    uint8_t syncInfo[256];
+    for (int b = 0; b < 256; b++) syncInfo[b] = p->blob[h.info_off + b] & cxgdev::kInfoSync;
+    if (h.kind == cxgdev::kKindDigit) for (int b = '0'; b <= '9'; b++) syncInfo[b] = 0;
+    cxgdev::ChainAux chain;
+    bool complete = false, ordered = false;
+    extractChain(anch, syncInfo, chain, complete, ordered);
+    if (!complete || !ordered || chain.ncls != 2 || chain.restart_check) return;
+    if ((chain.nops & 1u) == 0 || chain.nops < 3 || chain.nops > 7) return;              // run (byte run){1..3}: the unrolled shapes
+    for (uint32_t k = 0; k < chain.nops; k++) {
+      if (chain.op_kind[k] != ((k & 1u) ? cxgdev::kChainByte : cxgdev::kChainRun) || chain.op_cls[k] != (k & 1u)) return;
+      if (chain.cls_kind[chain.op_cls[k]] == cxgdev::kClsSet) return;
+    }
+    const uint32_t nfields = (chain.nops + 1) / 2;
+    if (bounds.size() != nfields) return;
+    cxgdev::ChainCaps cc;
+    std::memset(&cc, 0, sizeof cc);
+    cc.on = 2;
+    cc.nruns = static_cast<uint8_t>(nfields - 1);
+    for (int i = 0; i < cxgdev::kCapMaxRuns; i++) cc.run_op[i] = static_cast<uint32_t>(i) < nfields - 1 ? static_cast<uint8_t>(2 * i) : 0xFF;
+    for (uint32_t f = 0; f < nfields; f++) { cc.src[f] = static_cast<uint8_t>(bounds[f].first); cc.src[8 + f] = static_cast<uint8_t>(bounds[f].second); }
+    // new aux section at the end of the image: [256 B per-state flags of the old aux, or zeros][ChainAux of the surrogate]
+    std::vector<uint8_t> blob = p->blob;
+    while (blob.size() % 16) blob.push_back(0);
+    const uint32_t newAux = static_cast<uint32_t>(blob.size());
+    if (h.aux_len >= 256) blob.insert(blob.end(), p->blob.begin() + h.aux_off, p->blob.begin() + h.aux_off + 256);
+    else blob.insert(blob.end(), 256, 0);
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(&chain);
+    blob.insert(blob.end(), cb, cb + sizeof chain);
+    while (blob.size() % 16) blob.push_back(0);
+    h.aux_off = newAux;
+    h.aux_len = static_cast<uint32_t>(blob.size()) - newAux;
+    h.flags |= cxgdev::kFlagChainComplete | cxgdev::kFlagChainOrdered | cxgdev::kFlagChainBounded;
+    h.total_bytes = static_cast<uint32_t>(blob.size());
+    std::memcpy(blob.data(), &h, sizeof h);
+    p->blob.swap(blob);
+    std::memcpy(p->chainBounds, &cc, sizeof cc);
+  } catch (const BuildError&) {
+  }
+}
+
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch) {
   p->strategy = CXG_USE_CHARCLASS_SEARCHER;
   p->ngroups = 1;

@@ -56,6 +56,7 @@ struct cxg_program {
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: the chain kernel overflowed its row buffers on this
                                                               // program's input once: later calls start with two tiles per wave (capi.hip)
+  uint8_t chainBounds[40] = {0}; // cxgdev::ChainCaps with on == 2: field bounds of a bounded-repetition program (kFlagChainBounded)
   uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
   // device copies, one per device, created on first use (capi.hip)
   void* dev[16] = {nullptr};
@@ -67,7 +68,11 @@ namespace cxg {
 // Fills p->fwd/rev/blob/supported from (nfa, strategy, flags).  Never throws: unsupported programs
 // get supported=false + whyNot.
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags);
-void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa);   // fills subBlob/capBlob/subSupported
+void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa);
+// Bounded repetition: `surrogate` is the NFA of the pattern with every bounded run made unbounded (frontend.h
+// boundedSurrogate), bounds the (min, max) of its runs in order.  Adds the surrogate's chain to an already built,
+// supported digit / DFA-pair program when that chain has a shape the BND kernels take; otherwise leaves p alone.
+void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vector<std::pair<int, int>>& bounds);   // fills subBlob/capBlob/subSupported
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch);
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits);
 }  // namespace cxg

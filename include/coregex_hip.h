@@ -129,6 +129,10 @@ int cxg_program_submatch_blobs(const cxg_program* p, const void** span_blob, siz
  * written by the chain kernel itself (slot = match start / match end / end of one of two runs, plus a constant).
  * Returns 1 and fills out[40] when the program has one, 0 otherwise (captures then come from the one-pass table). */
 int cxg_program_chain_captures(const cxg_program* p, uint8_t out[40]);
+/* Diagnostics: the field bounds of a bounded-repetition program served by the chain kernel (`\d{1,3}\.\d{1,3}`...): same
+ * 40-byte record with on == 2, nruns = fields but the last, src[x] = min and src[8 + x] = max (0: unbounded) of field x.
+ * Returns 1 when the program has one. */
+int cxg_program_chain_bounds(const cxg_program* p, uint8_t out[40]);
 int cxg_program_submatch_supported(const cxg_program* p);
 /* Host-side copy of the NFA a program was compiled from (cxg_compile only); pointers live as long as p. */
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);

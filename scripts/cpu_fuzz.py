@@ -50,7 +50,7 @@ for seed in range(seed0, seed1):
                 if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
                 if fl & 16 and rx.strategy in ('UseDFA','UseDigitPrefilter','UseBoth'):
                     for geom in ((192,64),(3840,256)):
-                        g6 = emu.find_all_chain6(blob, hay, *geom)
+                        g6 = emu.find_all_chain6_bounded(blob, rx.chain_bounds()[0], hay, *geom) if fl & 512 else emu.find_all_chain6(blob, hay, *geom)
                         if not isinstance(g6,int) and g6.tolist()!=exp: print('CHAIN6', repr(pat), len(hay), geom, len(g6), len(exp)); bad+=1
                 if kind == 4 or (fl & 256):       # literal image (UseTeddy / one plain literal), or required literal prefix + anchored DFA
                     g = emu.find_all_teddy_wave(blob, hay)

@@ -21,6 +21,8 @@ def lib():
         L.emu_find_all_chain.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.emu_find_all_chain6.restype = C.c_int64
         L.emu_find_all_chain6.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.emu_find_all_chain6_bounded.restype = C.c_int64
+        L.emu_find_all_chain6_bounded.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         for name in ("emu_find_all_teddy_wave", "emu_find_all_charclass_wave"):
             f = getattr(L, name)
             f.restype = C.c_int64
@@ -83,6 +85,23 @@ def find_all_chain6(blob: bytes, hay, tile: int = 3840, halo: int = 256):
     while True:
         out = np.empty(cap, dtype=np.int64)
         n = lib().emu_find_all_chain6(blob, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, halo)
+        if n <= -16:
+            return int(n)
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
+            return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
+
+
+def find_all_chain6_bounded(blob: bytes, bounds40: bytes, hay, tile: int = 3840, halo: int = 256):
+    """Bounded-repetition mode of the chain kernel (BND instantiations), emulated: the surrogate chain of `blob`, rows
+    filtered by the field bounds.  Returns the int reason (< 0) when a tile would raise the fallback flag."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_chain6_bounded(blob, bounds40, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, halo)
         if n <= -16:
             return int(n)
         assert n >= 0, f"emulator error {n}"

@@ -233,8 +233,9 @@ struct MW {                       // little multiword helpers on forward or reve
 };
 }  // namespace
 
-extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
-                                       int tile_bytes, int halo_bytes) {
+static int64_t chain6_impl(const uint8_t* blob, const uint8_t* bounds, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                           int tile_bytes, int halo_bytes) {
+  const ChainCaps* bnd = reinterpret_cast<const ChainCaps*>(bounds);   // on == 2: bounded repetition (scan_chain_wave.hip BND)
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic) return -1;
   if (!(h->flags & kFlagChainOrdered)) return -4;
@@ -318,6 +319,28 @@ extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, 
       for (int64_t e : ep)
         if (e > 0 && e < stage && chain_class_has(ch, lc, g[e]) && chain_class_has(ch, lc, g[e - 1])) reason |= 64;
     if (reason) return -(16 + static_cast<int64_t>(reason));
+    if (bnd && bnd->on == 2) {                   // filter the rows of the unbounded surrogate by field length
+      std::vector<int64_t> fs, fe;
+      const uint32_t nfields = bnd->nruns + 1u;
+      for (size_t i = 0; i < sp.size(); i++) {
+        int64_t s = sp[i], pos = sp[i];
+        const int64_t e = ep[i];
+        bool valid = true;
+        for (uint32_t f = 0; f < nfields; f++) {
+          int64_t fend = pos;                     // the field: a run of class 0 (every run of these chains uses class 0)
+          while (fend < e && chain_class_has(ch, 0, g[fend])) fend++;
+          if (f + 1 == nfields) fend = e;
+          int64_t flen = fend - pos;
+          const int64_t mn = bnd->src[f], mx = bnd->src[8 + f];
+          if (f == 0 && mx != 0 && flen > mx) { s = fend - mx; flen = mx; }
+          if (f + 1 == nfields && mx != 0 && flen > mx) return -(16 + 64);   // FindAll would resume inside the run
+          if (flen < mn || (mx != 0 && flen > mx && f + 1 != nfields)) valid = false;
+          pos = fend + 1;
+        }
+        if (valid) { fs.push_back(s); fe.push_back(e); }
+      }
+      sp.swap(fs); ep.swap(fe);
+    }
     int64_t cur_end = -1;
     for (size_t i = 0; i < sp.size(); i++)
       if (sp[i] >= cur_end) { res.push_back(static_cast<int64_t>(tile_lo) + sp[i]); res.push_back(static_cast<int64_t>(tile_lo) + ep[i]); cur_end = ep[i]; }
@@ -325,6 +348,15 @@ extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, 
   const int64_t n = static_cast<int64_t>(res.size());
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
+}
+
+extern "C" int64_t emu_find_all_chain6(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                       int tile_bytes, int halo_bytes) {
+  return chain6_impl(blob, nullptr, hay, len, out, cap_vals, tile_bytes, halo_bytes);
+}
+extern "C" int64_t emu_find_all_chain6_bounded(const uint8_t* blob, const uint8_t* bounds40, const uint8_t* hay, uint64_t len, int64_t* out,
+                                               int64_t cap_vals, int tile_bytes, int halo_bytes) {
+  return chain6_impl(blob, bounds40, hay, len, out, cap_vals, tile_bytes, halo_bytes);
 }
 
 // ---------------------------------------------------------------------------------------------------------

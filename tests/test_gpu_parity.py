@@ -743,3 +743,34 @@ def test_reference_kats_through_the_c_abi(need_gpu):
             n += 1
             assert rx.count(c["input"].encode()) == c["want"], c["name"]
     assert n >= 30, n
+
+
+def test_bounded_repetition_on_the_chain_kernel(need_gpu, oracle):
+    """The everyday IPv4 pattern `\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}` (and other field{m,n} / separator shapes): surrogate
+    chain with unbounded runs + row filter by field length (scan_chain_wave.hip BND).  One launch on log text; a last
+    field longer than its bound (FindAll would resume inside the run) hands the scan to the table-walking kernel."""
+    import torch
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"0123456789.. x-:ab", dtype=np.uint8)
+    w = np.array([1] * 10 + [4, 4, 1, 1, 1, 1, 1, 1], dtype=float)
+    w /= w.sum()
+    synth = cx.synth_pages(2, 0xC0FFEE02, 0, 2048)                       # 8 MiB of access-log lines
+    hays = [synth, b"", b"1234.5.6.7 1.2.3.4 999.999.999.999x", b"10.0.0.1 - 1.22.333.4 - 1.2.3", b"1.2.3.4567 1.2.3.4",
+            b"12-3 1234-56 12345-6 1-2 1:23:4 12:345:6"]
+    hays += [alphabet[rng.choice(len(alphabet), size=int(n), p=w)] for n in (50, 3000, 40000, 200000)]
+    for pat in (r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\d{1,3}(?:\.\d{1,3}){3}", r"\d{2,4}-\d{1,2}", r"\d{1,2}:\d{2,}:\d+"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported and rx.chain_bounds() is not None, pat
+        for hay in hays:
+            exp = o.find_all_index(hay)
+            assert np.array_equal(rx.find_all_index(hay), exp), (pat, len(hay))
+            assert rx.count(hay) == len(exp), (pat, len(hay))
+    n = synth.size
+    buf = cx.DeviceBuffer(n)
+    buf.upload(synth)
+    rx = cx.compile(r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}")
+    cnt = rx.find_all_device(buf.ptr, n)
+    out = torch.empty((cnt + 4, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
+    assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}").find_all_index(synth))

@@ -464,7 +464,11 @@ def test_wide_fuzz_host_and_twins(oracle):
                         assert emu.find_all(blob, hay).tolist() == exp, (pat, rx.strategy, len(hay))
                     twins = []
                     if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter", "UseBoth"):
-                        twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
+                        if flags & 512:                              # bounded repetition: surrogate chain + field bounds
+                            raw = rx.chain_bounds()[0]
+                            twins = [emu.find_all_chain6_bounded(blob, raw, hay, 192, 64), emu.find_all_chain6_bounded(blob, raw, hay, 3840, 256)]
+                        else:
+                            twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
                     elif struct.unpack_from("<I", blob, 4)[0] == 4 or (flags & 256):   # literal image, or required literal prefix + anchored DFA
                         twins = [emu.find_all_teddy_wave(blob, hay)]
                     elif rx.strategy == "UseCharClassSearcher" and (flags & 64):
@@ -580,6 +584,51 @@ def test_program_routing_table():
     for pat, why in [(r"a?(a|b)", "cache history"), (r"\w+@\w+\.\w+", "has no device kernel"), (r"\bfoo\b", "look-around")]:
         rx = cx.compile(pat)
         assert not rx.supported and why in rx.why_unsupported, (pat, rx.strategy, rx.why_unsupported)
+
+
+def test_bounded_repetition_chain_emulated(oracle):
+    """`\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}` and friends: the chain kernel evaluates the surrogate with unbounded runs and filters
+    the rows by field length (scan_chain_wave.hip BND; program.cc attachBoundedChain; frontend.cc boundedSurrogate).  The
+    twin must equal the oracle whenever it does not hand the scan over (no synchronising byte in a halo, or a last field
+    longer than its bound: FindAll would resume inside the run)."""
+    import struct
+    rng = np.random.default_rng(41)
+    alphabet = np.frombuffer(b"0123456789.. x-:ab", dtype=np.uint8)
+    w = np.array([1] * 10 + [4, 4, 1, 1, 1, 1, 1, 1], dtype=float)
+    w /= w.sum()
+    synth = cx.synth_pages(2, 0xC0FFEE02, 5, 24).tobytes()
+    n_ok = 0
+    for pat, fields in [(r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", [(1, 3)] * 4), (r"\d{1,3}(?:\.\d{1,3}){3}", [(1, 3)] * 4),
+                        (r"\d{2,4}-\d{1,2}", [(2, 4), (1, 2)]), (r"\d{1,2}:\d{2,}:\d+", [(1, 2), (2, 0), (1, 0)])]:
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported and rx.strategy == o.strategy
+        assert struct.unpack_from("<I", rx.blob(), 8)[0] & 512, pat
+        raw, got_fields = rx.chain_bounds()
+        assert got_fields == fields, (pat, got_fields)
+        hays = [synth, b"", b"1234.5.6.7 1.2.3.4 999.999.999.999x", b"10.0.0.1 - 1.22.333.4 - 1.2.3", b"12-3 1234-56 12345-6 1-2"]
+        hays += [alphabet[rng.choice(len(alphabet), size=int(rng.integers(0, 5000)), p=w)].tobytes() for _ in range(40)]
+        exact = 0
+        for hay in hays:
+            exp = o.find_all_index(hay).tolist()
+            assert emu.find_all(rx.blob(), hay).tolist() == exp, (pat, len(hay))          # the table-walking fallback
+            for geom in ((3840, 256), (192, 64)):
+                got = emu.find_all_chain6_bounded(rx.blob(), raw, hay, *geom)
+                if isinstance(got, int):
+                    assert (-got - 16) & ~(1 | 64) == 0, (pat, got)
+                    continue
+                exact += 1
+                assert got.tolist() == exp, (pat, len(hay), geom)
+        assert exact >= 10, (pat, exact)
+        n_ok += 1
+    assert n_ok == 4
+    # the synthetic access-log corpus never needs the fallback: octets have one to three digits
+    rx = cx.compile(r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}")
+    got = emu.find_all_chain6_bounded(rx.blob(), rx.chain_bounds()[0], synth)
+    assert not isinstance(got, int) and len(got) > 500
+    # shapes the BND kernels do not take keep their table-walking image
+    for pat in (r"x\d{1,3}", r"\d{1,3}[a-z]{1,3}\d{1,3}[a-z]{1,2}\d+[a-z]+\d+[a-z]+\d+"):
+        rx = cx.compile(pat)
+        assert rx.chain_bounds() is None or not rx.supported, pat
 
 
 def test_emulated_no_sync_bytes_at_all(oracle):
