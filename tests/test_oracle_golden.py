@@ -287,3 +287,10 @@ def test_nongreedy_and_count_vectors(oracle):
     for c in VEC["count_dispatch"]["cases"]:
         rx = oracle.Regex(c["pattern"])
         assert rx.count(_inp(c)) == c["want"] == len(rx.find_all_index(_inp(c))), c["name"]
+
+
+def test_use_both_vectors(oracle):
+    blk = VEC["use_both_find"]
+    for c in blk["cases"]:
+        rx = oracle.Regex(c.get("pattern", blk["pattern"]))
+        assert rx.find_all_index(_inp(c)).tolist() == c["want"], c["name"]
