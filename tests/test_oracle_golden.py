@@ -294,3 +294,9 @@ def test_use_both_vectors(oracle):
     for c in blk["cases"]:
         rx = oracle.Regex(c.get("pattern", blk["pattern"]))
         assert rx.find_all_index(_inp(c)).tolist() == c["want"], c["name"]
+
+
+def test_find_all_submatch_index_vector(oracle):
+    blk = VEC["find_all_submatch_index"]
+    rows = oracle.Regex(blk["pattern"]).find_all_submatch_index(blk["input"].encode())
+    assert len(rows) == blk["want_rows"] and rows[0].tolist() == blk["want_first"]
