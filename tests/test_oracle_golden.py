@@ -300,3 +300,8 @@ def test_find_all_submatch_index_vector(oracle):
     blk = VEC["find_all_submatch_index"]
     rows = oracle.Regex(blk["pattern"]).find_all_submatch_index(blk["input"].encode())
     assert len(rows) == blk["want_rows"] and rows[0].tolist() == blk["want_first"]
+
+
+def test_dfa_search_at_vectors(oracle):
+    for c in VEC["dfa_search_at"]["cases"]:
+        assert oracle.Regex(c["pattern"]).dfa_search_at(_inp(c), c["at"]) == c["want"], c
