@@ -87,6 +87,10 @@ class Regex:
         return STRATEGY_NAMES[_lib.lib().cxg_program_strategy(self._h)]
 
     @property
+    def flags(self) -> int:
+        return _lib.lib().cxg_program_flags(self._h)
+
+    @property
     def num_groups(self) -> int:
         return _lib.lib().cxg_program_num_groups(self._h)
 
@@ -209,6 +213,47 @@ def compile(pattern) -> Regex:  # noqa: A001  (mirrors coregex.Compile)
 
 def must_compile(pattern) -> Regex:
     return compile(pattern)
+
+
+# --- the constructors a cgo shim calls once per compiled *meta.Engine ------------------
+def flatten_nfa(view: "_lib.Nfa"):
+    """flattenNFA of the shim: copies an NFA description into freshly allocated C arrays (what Go does with C.malloc;
+    the library must not depend on the source arrays staying alive).  Returns (Nfa, keepalive)."""
+    states = (_lib.NfaState * max(1, view.n_states))()
+    C.memmove(states, view.states, C.sizeof(_lib.NfaState) * view.n_states)
+    trans = (_lib.NfaTrans * max(1, view.n_trans))()
+    if view.n_trans:
+        C.memmove(trans, view.trans, C.sizeof(_lib.NfaTrans) * view.n_trans)
+    out = _lib.Nfa(C.cast(states, C.POINTER(_lib.NfaState)), view.n_states, C.cast(trans, C.POINTER(_lib.NfaTrans)),
+                   view.n_trans, view.start_anchored, view.start_unanchored, view.capture_count)
+    return out, (states, trans)
+
+
+def program_from_nfa(nfa: "_lib.Nfa", strategy, flags: int = 0, pattern: bytes = b"") -> Regex:
+    """cxg_program_from_nfa: e.nfa + e.strategy + {digitRunSkipSafe, reverseDFA != nil} -> device program."""
+    st = STRATEGY_NAMES.index(strategy) if isinstance(strategy, str) else int(strategy)
+    h = C.c_void_p()
+    _check(_lib.lib().cxg_program_from_nfa(C.byref(nfa), st, flags, C.byref(h)))
+    return Regex(h, pattern)
+
+
+def program_from_literals(lits, pattern: bytes = b"") -> Regex:
+    """cxg_program_from_literals: prefilter.Teddy patterns in pattern-ID order (UseTeddy)."""
+    lits = [bytes(x) for x in lits]
+    arr = (C.c_char_p * max(1, len(lits)))(*lits)
+    lens = (C.c_uint32 * max(1, len(lits)))(*[len(x) for x in lits])
+    h = C.c_void_p()
+    _check(_lib.lib().cxg_program_from_literals(arr, lens, len(lits), C.byref(h)))
+    return Regex(h, pattern)
+
+
+def program_from_charclass(membership, min_match: int = 1, pattern: bytes = b"") -> Regex:
+    """cxg_program_from_charclass: nfa.CharClassSearcher.membership[256] (UseCharClassSearcher)."""
+    m = bytes(1 if x else 0 for x in membership)
+    assert len(m) == 256
+    h = C.c_void_p()
+    _check(_lib.lib().cxg_program_from_charclass(m, min_match, C.byref(h)))
+    return Regex(h, pattern)
 
 
 class DeviceBuffer:

@@ -19,7 +19,7 @@ CXG_E_DEVICE, CXG_E_NO_GPU, CXG_E_SYNTAX, CXG_E_INTERNAL, CXG_E_INPUT = -4, -5, 
 
 # every symbol declared in include/coregex_hip.h (tests check the exports against the header)
 SYMBOLS = [
-    "cxg_last_error", "cxg_version", "cxg_device_count", "cxg_set_device", "cxg_compile",
+    "cxg_last_error", "cxg_version", "cxg_device_count", "cxg_set_device", "cxg_thread_release", "cxg_compile", "cxg_program_flags",
     "cxg_program_from_nfa", "cxg_program_from_literals", "cxg_program_from_charclass",
     "cxg_program_destroy", "cxg_program_strategy", "cxg_strategy_name", "cxg_program_num_groups",
     "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_blob",
@@ -55,7 +55,7 @@ def build(force: bool = False) -> str:
     """Compile libcoregex_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
     if force or not os.path.exists(LIB_PATH) or _stale(src):
-        subprocess.check_call(["make", "-s", "-C", src])
+        subprocess.check_call(["make", "-s", "-j8", "-C", src])
     return LIB_PATH
 
 
@@ -98,6 +98,10 @@ def lib():
     for n in ("cxg_program_strategy", "cxg_program_num_groups", "cxg_program_nfa_states",
               "cxg_program_dfa_states", "cxg_program_supported"):
         getattr(L, n).argtypes = [vp]
+    L.cxg_program_flags.argtypes = [vp]
+    L.cxg_program_flags.restype = u32
+    L.cxg_thread_release.argtypes = []
+    L.cxg_thread_release.restype = None
     L.cxg_program_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_nfa.argtypes = [vp, C.POINTER(Nfa)]
     L.cxg_program_submatch_blobs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <mutex>
@@ -24,9 +25,6 @@ hipError_t launch_scan_dfa(uint32_t kind, const ScanArgs& a, uint32_t fwd_states
 size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
-hipError_t launch_scan_digit_list(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
-hipError_t launch_scan_digit_chain(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
-hipError_t launch_scan_digit_wave(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
@@ -49,12 +47,15 @@ int failHip(hipError_t e, const char* what) {
     if (_e != hipSuccess) return failHip(_e, #expr);    \
   } while (0)
 
+std::atomic<bool> g_exiting{false};   // set by an atexit hook: the HIP runtime may already be gone, leave its memory to the OS
+
 int deviceCount() {
   static int n = -1;
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   if (n >= 0) return n;
   int c = 0;
+  std::atexit([] { g_exiting.store(true); });
   if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
   int ok = 0;
   for (int d = 0; d < c; d++) {
@@ -81,8 +82,33 @@ struct Scratch {
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
+  // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
+  // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
+  void release() {
+    if (device < 0) return;
+    if (hipSetDevice(device) == hipSuccess) {
+      if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+      for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+      if (ctl) (void)hipFree(ctl);
+      if (prof) (void)hipFree(prof);
+      if (hay) (void)hipFree(hay);
+      if (out) (void)hipFree(out);
+      if (hostCtl) (void)hipHostFree(hostCtl);
+      if (pinHay) (void)hipHostFree(pinHay);
+      if (pinOut) (void)hipHostFree(pinOut);
+    }
+    (void)hipGetLastError();
+    *this = Scratch();
+  }
 };
-thread_local Scratch t_scratch[16];
+struct ScratchSet {
+  Scratch s[16];
+  ~ScratchSet() { if (!g_exiting.load()) for (auto& x : s) x.release(); }
+};
+thread_local ScratchSet t_scratch_set;
+#define t_scratch t_scratch_set.s
+// Staging buffers above this size are returned after the call instead of being kept for the thread's lifetime.
+constexpr uint64_t kKeepStagingBytes = 256ull << 20;
 
 int getScratch(Scratch** out) {
   if (deviceCount() <= 0) return fail(CXG_E_NO_GPU, "no gfx950 device visible (this library has no CPU search path)");
@@ -129,13 +155,13 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 
-// CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) generation (A/B profiling);
-// default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain),
-// 5 = wave-local chain-prefilter kernel, 4 = workgroup chain kernel, 3 = candidate-list kernel, each only when
-// the program allows it; all hand the scan to generation 2 (UseDFA: the bidirectional table kernel) when a
-// tile raises the fallback flag.
+// CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) table-walking generation (A/B profiling);
+// default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain) when
+// the program allows it, else generation 2; a tile that raises the fallback flag hands the scan to generation 2
+// (UseDFA: the bidirectional table kernel).  Generations 3-5 (candidate list, workgroup chain, wave prefilter) were
+// stepping stones of round 1 and are gone (git history).
 int digitKernelGeneration() {
-  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); return e ? atoi(e) : 6; }();
+  static const int g = [] { const char* e = getenv("CXG_DIGIT_KERNEL"); const int v = e ? atoi(e) : 6; return (v == 1 || v == 2) ? v : 6; }();
   return g;
 }
 
@@ -300,12 +326,9 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   }
   int gen = digitKernelGeneration();
   uint32_t relaunches = 0;
-  if (gen > 6) gen = 6;
-  if (gen == 6 && !(h->flags & cxgdev::kFlagChainOrdered)) gen = 5;
+  if (gen == 6 && !(h->flags & cxgdev::kFlagChainOrdered)) gen = 2;   // not a complete ordered chain: table-walking kernels
   if (h->kind == cxgdev::kKindDigit) {
-    if ((gen == 4 || gen == 5) && (h->flags & cxgdev::kFlagChainSets)) gen = 3;   // only generation 6 evaluates set classes
-    if ((gen == 4 || gen == 5) && !(h->flags & cxgdev::kFlagChain)) gen = 3;
-    if (gen >= 3 && gen != 6 && !(h->flags & cxgdev::kFlagFastDigit)) gen = 2;
+    // gen stays 1, 2 or 6
   } else if (h->kind == cxgdev::kKindTeddy) {
     static const bool oldTeddy = getenv("CXG_TEDDY_KERNEL") && atoi(getenv("CXG_TEDDY_KERNEL")) == 1;
     gen = (oldTeddy || h->aux_len > 2048u) ? 0 : 7;                 // the wave kernel stages at most 2 KiB of literal tables
@@ -328,9 +351,8 @@ relaunch:
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
-  if (h->kind == cxgdev::kKindDigit && gen == 4) a.ngroups = (a.ntiles + cxgdev::kGroupTiles - 1) / cxgdev::kGroupTiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
-  if (gen == 5 || gen == 6 || gen == 7 || gen == 9) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  if (gen == 6 || gen == 7 || gen == 9) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if ((gen == 6 || gen == 7 || gen == 9) && denseChain) {           // four times the row-buffer room per wave-tile
     a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
@@ -383,10 +405,7 @@ relaunch:
   else switch (h->kind) {
     case cxgdev::kKindDigit:
       if (gen == 1) le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream);
-      else if (gen == 2) le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
-      else if (gen == 3) le = cxgdev::launch_scan_digit_list(a, h->fwd_states, stream);
-      else if (gen == 4) le = cxgdev::launch_scan_digit_chain(a, h->fwd_states, stream);
-      else le = cxgdev::launch_scan_digit_wave(a, h->fwd_states, stream);
+      else le = cxgdev::launch_scan_digit_flat(a, h->fwd_states, stream);
       break;
     case cxgdev::kKindBidir: le = cxgdev::launch_scan_dfa(h->kind, a, h->fwd_states, h->rev_states, stream); break;
     case cxgdev::kKindCharClass: le = cxgdev::launch_scan_charclass(a, stream); break;
@@ -558,9 +577,14 @@ int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64
   uint64_t n = 0;
   int rc = scanDevice(p, s.hay, len, 0, limit, rows ? s.out : nullptr, want, &n, nullptr, nullptr, width);
   if (n_out) *n_out = n;
-  if (rc) return rc;
-  if (rows && n) HIP_TRY(hipMemcpy(rows, s.out, n * width * sizeof(int64_t), hipMemcpyDeviceToHost));
-  return CXG_OK;
+  if (rc == CXG_OK && rows && n) {
+    const hipError_t ce = hipMemcpy(rows, s.out, n * width * sizeof(int64_t), hipMemcpyDeviceToHost);
+    if (ce != hipSuccess) rc = failHip(ce, "hipMemcpy(rows)");
+  }
+  // a thread keeps at most kKeepStagingBytes of HBM staging between calls
+  if (s.hayCap > kKeepStagingBytes) { (void)hipFree(s.hay); s.hay = nullptr; s.hayCap = 0; }
+  if (s.outCap * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.out); s.out = nullptr; s.outCap = 0; }
+  return rc;
 }
 
 }  // namespace
@@ -580,6 +604,10 @@ int cxg_set_device(int device) {
   if (device < 0 || device >= 16) return fail(CXG_E_INVALID, "bad device index");
   t_device = device;
   return CXG_OK;
+}
+
+void cxg_thread_release(void) {
+  for (auto& x : t_scratch) x.release();
 }
 
 const char* cxg_strategy_name(int s) {
@@ -648,30 +676,87 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
   }
 }
 
+// The three constructors a cgo shim calls.  Foreign data: every index of the NFA is validated
+// (CXG_E_INVALID + message), nothing thrown crosses the C ABI, and *out is only set on CXG_OK.  A program outside the
+// device subset is still CXG_OK with cxg_program_supported() == 0 (the reason in cxg_last_error), like cxg_compile.
 int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_program** out) {
-  if (!nfa || !out || !nfa->states) return fail(CXG_E_INVALID, "null argument");
-  auto* p = new cxg_program();
-  cxg::buildProgramFromNfa(p, *nfa, strategy, flags);
-  *out = p;
-  return CXG_OK;
+  if (!nfa || !out) return fail(CXG_E_INVALID, "null argument");
+  *out = nullptr;
+  if (strategy < 0 || strategy > CXG_USE_MULTILINE_REVERSE_SUFFIX) return fail(CXG_E_INVALID, "strategy outside meta.Strategy (0..16)");
+  if (flags & ~(CXG_FLAG_DIGIT_RUN_SKIP_SAFE | CXG_FLAG_HAS_REVERSE_DFA)) return fail(CXG_E_INVALID, "unknown flag bits");
+  cxg_program* p = nullptr;
+  try {
+    std::string why;
+    if (!cxg::validateNfa(*nfa, why)) return fail(CXG_E_INVALID, why);
+    p = new cxg_program();
+    cxg::buildProgramFromNfa(p, *nfa, strategy, flags);
+    // FindAllSubmatch hook (meta/findall.go:390): spans + capture table, same call as cxg_compile makes
+    if (nfa->capture_count > 1) cxg::buildSubmatchProgram(p, *nfa);
+    else p->subWhyNot = "pattern has no capture groups (cxg_find_all_submatch then returns the spans)";
+    if (!p->supported) t_err = p->whyNot;
+    *out = p;
+    return CXG_OK;
+  } catch (const cxg::BuildError& e) {
+    delete p;
+    return fail(e.code, e.msg);
+  } catch (const std::exception& e) {
+    delete p;
+    return fail(CXG_E_INTERNAL, e.what());
+  } catch (...) {
+    delete p;
+    return fail(CXG_E_INTERNAL, "unknown exception");
+  }
 }
 
 int cxg_program_from_literals(const uint8_t* const* lits, const uint32_t* lens, uint32_t n, cxg_program** out) {
   if (!lits || !lens || !out) return fail(CXG_E_INVALID, "null argument");
-  std::vector<std::vector<uint8_t>> v;
-  for (uint32_t i = 0; i < n; i++) v.emplace_back(lits[i], lits[i] + lens[i]);
-  auto* p = new cxg_program();
-  cxg::buildProgramFromLiterals(p, v);
-  *out = p;
-  return CXG_OK;
+  *out = nullptr;
+  if (n == 0 || n > 4096) return fail(CXG_E_INVALID, "literal count must be 1..4096");
+  cxg_program* p = nullptr;
+  try {
+    std::vector<std::vector<uint8_t>> v;
+    for (uint32_t i = 0; i < n; i++) {
+      if (!lits[i] && lens[i]) return fail(CXG_E_INVALID, "null literal pointer");
+      if (lens[i] > (1u << 16)) return fail(CXG_E_INVALID, "literal longer than 64 KiB");
+      v.emplace_back(lits[i], lits[i] + lens[i]);
+    }
+    p = new cxg_program();
+    cxg::buildProgramFromLiterals(p, v);
+    p->subWhyNot = "literal set has no capture groups";
+    if (!p->supported) t_err = p->whyNot;
+    *out = p;
+    return CXG_OK;
+  } catch (const std::exception& e) {
+    delete p;
+    return fail(CXG_E_INTERNAL, e.what());
+  } catch (...) {
+    delete p;
+    return fail(CXG_E_INTERNAL, "unknown exception");
+  }
 }
 
 int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match, cxg_program** out) {
   if (!membership || !out) return fail(CXG_E_INVALID, "null argument");
-  auto* p = new cxg_program();
-  cxg::buildProgramFromCharClass(p, membership, min_match);
-  *out = p;
-  return CXG_OK;
+  *out = nullptr;
+  if (min_match == 0) return fail(CXG_E_INVALID, "min_match must be >= 1 (CharClassSearcher.minMatch, nfa/charclass_searcher.go:26)");
+  cxg_program* p = nullptr;
+  try {
+    bool any = false;
+    for (int b = 0; b < 256; b++) any = any || membership[b] != 0;
+    if (!any) return fail(CXG_E_INVALID, "empty membership table");
+    p = new cxg_program();
+    cxg::buildProgramFromCharClass(p, membership, min_match);
+    p->subWhyNot = "char-class searcher has no capture groups";
+    if (!p->supported) t_err = p->whyNot;
+    *out = p;
+    return CXG_OK;
+  } catch (const std::exception& e) {
+    delete p;
+    return fail(CXG_E_INTERNAL, e.what());
+  } catch (...) {
+    delete p;
+    return fail(CXG_E_INTERNAL, "unknown exception");
+  }
 }
 
 void cxg_program_destroy(cxg_program* p) {
@@ -686,6 +771,7 @@ void cxg_program_destroy(cxg_program* p) {
 }
 
 int cxg_program_strategy(const cxg_program* p) { return p ? p->strategy : -1; }
+uint32_t cxg_program_flags(const cxg_program* p) { return p ? p->flags : 0u; }
 int cxg_program_num_groups(const cxg_program* p) { return p ? p->ngroups : 0; }
 int cxg_program_nfa_states(const cxg_program* p) { return p ? p->nfaStates : -1; }
 int cxg_program_dfa_states(const cxg_program* p) { return p ? static_cast<int>(p->fwd.nstates) : 0; }

@@ -491,6 +491,48 @@ void appendPrefixAux(std::vector<uint8_t>& blob, cxgdev::BlobHeader& h, const st
   h.flags |= cxgdev::kFlagPrefixLiteral;
 }
 
+// A caller-supplied NFA (cgo shim: flattenNFA) is foreign data: every index is checked before anything walks it.
+// nfa.InvalidState (0xFFFFFFFF) is a legal "no target" in every next/left/right field (nfa/nfa.go:62-64).
+bool validateNfa(const cxg_nfa& nfa, std::string& why) {
+  auto bad = [&](uint32_t i, const char* what) { why = "malformed NFA: state " + std::to_string(i) + ": " + what; return false; };
+  if (!nfa.states || nfa.n_states == 0) { why = "malformed NFA: no states"; return false; }
+  if (nfa.n_states > (1u << 20)) { why = "malformed NFA: more than 2^20 states"; return false; }
+  if (nfa.n_trans && !nfa.trans) { why = "malformed NFA: n_trans > 0 with a null transition array"; return false; }
+  if (nfa.start_anchored >= nfa.n_states || nfa.start_unanchored >= nfa.n_states) { why = "malformed NFA: start state out of range"; return false; }
+  if (nfa.capture_count == 0 || nfa.capture_count > 1024) { why = "malformed NFA: capture_count must be 1..1024 (group 0 included)"; return false; }
+  auto target = [&](uint32_t t) { return t == CXG_NFA_INVALID || t < nfa.n_states; };
+  for (uint32_t i = 0; i < nfa.n_states; i++) {
+    const cxg_nfa_state& s = nfa.states[i];
+    switch (s.kind) {
+      case CXG_NFA_MATCH: case CXG_NFA_FAIL: break;
+      case CXG_NFA_BYTE_RANGE:
+        if (s.lo > s.hi) return bad(i, "byte range with lo > hi");
+        if (!target(s.next)) return bad(i, "next out of range");
+        break;
+      case CXG_NFA_SPARSE:
+        if (s.trans_off > nfa.n_trans || s.trans_len > nfa.n_trans - s.trans_off) return bad(i, "sparse transitions outside the transition array");
+        for (uint32_t k = 0; k < s.trans_len; k++) {
+          const cxg_nfa_trans& t = nfa.trans[s.trans_off + k];
+          if (t.lo > t.hi) return bad(i, "sparse transition with lo > hi");
+          if (!target(t.next)) return bad(i, "sparse transition target out of range");
+        }
+        break;
+      case CXG_NFA_SPLIT:
+        if (!target(s.left) || !target(s.right)) return bad(i, "split target out of range");
+        break;
+      case CXG_NFA_EPSILON: case CXG_NFA_LOOK:
+        if (!target(s.next)) return bad(i, "next out of range");
+        break;
+      case CXG_NFA_CAPTURE:
+        if (!target(s.next)) return bad(i, "next out of range");
+        if (s.cap_index >= nfa.capture_count) return bad(i, "capture index >= capture_count");
+        break;
+      default: return bad(i, "unknown state kind");
+    }
+  }
+  return true;
+}
+
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
   p->strategy = strategy;
   p->flags = flags;
@@ -498,8 +540,8 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
   p->nfaStates = static_cast<int>(nfa.n_states);
   p->supported = false;
   try {
-    if (nfa.n_states == 0 || nfa.start_anchored >= nfa.n_states || nfa.start_unanchored >= nfa.n_states)
-      throw BuildError{CXG_E_INVALID, "malformed NFA"};
+    std::string why;
+    if (!validateNfa(nfa, why)) throw BuildError{CXG_E_INVALID, why};
     cxgdev::BlobHeader h;
     std::memset(&h, 0, sizeof h);
     h.magic = cxgdev::kBlobMagic;

@@ -65,6 +65,8 @@ struct cxg_program {
 };
 
 namespace cxg {
+// False + why when a caller-supplied NFA has an index out of range / an unknown kind (cxg_program_from_nfa -> CXG_E_INVALID).
+bool validateNfa(const cxg_nfa& nfa, std::string& why);
 // Fills p->fwd/rev/blob/supported from (nfa, strategy, flags).  Never throws: unsupported programs
 // get supported=false + whyNot.
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags);

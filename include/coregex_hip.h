@@ -106,6 +106,9 @@ const char* cxg_last_error(void);          /* thread-local text of the last fail
 const char* cxg_version(void);
 int cxg_device_count(void);                /* gfx950 devices visible; 0 => every search returns CXG_E_NO_GPU */
 int cxg_set_device(int device);            /* per-thread device for subsequent calls (default 0) */
+/* Frees the calling thread's stream, events, pinned buffers and HBM staging (they are per OS thread and are also freed
+ * when the thread exits).  A host whose callers hop across threads (cgo) may call it when a thread goes idle. */
+void cxg_thread_release(void);
 
 /* ---- program construction ------------------------------------------------------------ */
 int cxg_compile(const char* pattern, size_t len, cxg_program** out);
@@ -115,6 +118,8 @@ int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match
 void cxg_program_destroy(cxg_program* p);
 
 int cxg_program_strategy(const cxg_program* p);         /* cxg_strategy */
+uint32_t cxg_program_flags(const cxg_program* p);       /* CXG_FLAG_* the program was built with (cxg_compile: what the
+                                                           front-end derived, i.e. Engine.digitRunSkipSafe / reverseDFA != nil) */
 const char* cxg_strategy_name(int strategy);
 int cxg_program_num_groups(const cxg_program* p);       /* NumSubexp()+1 */
 int cxg_program_nfa_states(const cxg_program* p);       /* -1 if built without an NFA */

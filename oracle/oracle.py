@@ -83,6 +83,8 @@ def lib():
         L.orc_teddy_free.argtypes = [vp]
         L.orc_teddy_find_match.restype = C.c_int
         L.orc_teddy_find_match.argtypes = [vp, C.c_void_p, i64, i64, i64p, i64p]
+        L.orc_scan_synth.restype = C.c_int
+        L.orc_scan_synth.argtypes = [C.c_char_p, i64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         L.orc_dump.restype = C.c_int
         L.orc_dump.argtypes = [vp, C.c_char_p, C.c_int]
         _ = (u8p,)
@@ -206,6 +208,20 @@ class Regex:
         buf = C.create_string_buffer(1 << 16)
         lib().orc_dump(self._h, buf, 1 << 16)
         return buf.value.decode()
+
+
+def scan_synth(pattern, config: int, seed: int, first_page: int, npages: int, nthreads: int = 0, width: int = 2):
+    """The oracle over synthlog-v1 pages, multi-threaded (oracle/scale.cpp): returns dict(rows, sums[width], scan_s, gen_s,
+    threads).  sums[j] = sum over rows k of value * (k + 1 + 7 j) mod 2^64, offsets relative to page `first_page`."""
+    p = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
+    if nthreads <= 0:
+        nthreads = max(1, len(os.sched_getaffinity(0)))
+    out = np.zeros(19, dtype=np.uint64)
+    rc = lib().orc_scan_synth(p, len(p), config, seed, first_page, npages, nthreads, width, out.ctypes.data)
+    if rc != 0:
+        raise OracleError("orc_scan_synth failed")
+    return {"rows": int(out[0]), "sums": [int(x) for x in out[1:1 + width]], "scan_s": float(out[17]) * 1e-9,
+            "gen_s": float(out[18]) * 1e-9, "threads": nthreads}
 
 
 def memchr_digit_at(hay, at: int) -> int:

@@ -1,0 +1,237 @@
+"""The drop-in boundary as the cgo shim uses it: programs are built through
+cxg_program_from_nfa / _from_literals / _from_charclass from freshly allocated arrays — never through the program that
+cxg_compile returned — and must be the same programs (CPU tier: byte-identical device images, malformed descriptions
+rejected) and give the oracle's rows on the GPU for all five BASELINE configurations (GPU tier), including
+FindAllSubmatch through the constructor (meta/findall.go:390) and the C stand-in of the shim (examples/shim_harness.c)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from coregex_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LITS16 = ["error", "warning", "fatal", "critical", "panic", "timeout", "refused", "denied", "googlebot", "bingbot", "yandexbot",
+          "crawler", "spider", "failure", "exception", "overflow"]
+WORD = [1 if (48 <= b <= 57 or 65 <= b <= 90 or b == 95 or 97 <= b <= 122) else 0 for b in range(256)]
+
+NFA_PATTERNS = [
+    r"\d+\.\d+\.\d+\.\d+", r"error", r"(\w+)@(\w+)\.(\w+)", r"\d+\.\d+\.\d+", r"\d+:\d+:\d+", r"ab|abc", r"((a+)(b+))", r"a+?",
+    r"[a-zA-Z]+[0-9]+", r"(?:0[0-9]|1[0-9]|2[0-3]):[0-5][0-9]:[0-5][0-9]", r"[1-9][0-9]*|0", r"x[ab]+?y", r"(a|ab)(c|bcd)",
+    r"[0-5]+x", r"(foo|foobar)\d+", r"\d+[a-z]", r"\d+\.\d+x?", r"[a-z]+@[a-z]+", r"a{2,4}b", r"(?:ab)*c", r"HTTP/\d\.\d",
+    r"(GET|POST|PUT) /([a-z/]+)", r"([a-z]+)=(\d+)", r"warning", r"\d{4}-\d{2}-\d{2}", r"(\d+)\.(\d+)\.(\d+)\.(\d+)",
+]
+
+
+def via_constructor(pat):
+    """What buildHipProgram does for an NFA-carrying strategy: flatten e.nfa into fresh arrays, pass strategy + flags."""
+    eng = cx.compile(pat)                                   # stands for meta.Compile: e.nfa, e.strategy, flags
+    nfa, keep = cx.flatten_nfa(eng.nfa())
+    prog = cx.program_from_nfa(nfa, eng.strategy, eng.flags, eng.pattern)
+    del keep, nfa                                           # the program must not point into the caller's arrays
+    return eng, prog
+
+
+@pytest.mark.parametrize("pat", NFA_PATTERNS)
+def test_from_nfa_builds_the_program_cxg_compile_builds(pat):
+    eng, prog = via_constructor(pat)
+    if eng.strategy not in ("UseDFA", "UseBoth", "UseDigitPrefilter"):
+        assert not prog.supported
+        return
+    assert prog.strategy == eng.strategy and prog.num_groups == eng.num_groups and prog.nfa_states == eng.nfa_states
+    if eng.supported:
+        assert prog.supported, prog.why_unsupported
+        if eng.chain_bounds() is None:                      # bounded-repetition chains need the AST
+            assert prog.blob() == eng.blob(), "device image differs from cxg_compile's"
+    assert prog.submatch_supported == eng.submatch_supported, (pat, prog.submatch_supported)
+    if eng.submatch_supported:                              # FindAllSubmatch hook reachable through the binding
+        assert prog.submatch_blobs() == eng.submatch_blobs()
+        assert prog.chain_captures() == eng.chain_captures()
+
+
+def test_from_literals_and_from_charclass_build_the_compile_images():
+    t = cx.program_from_literals([s.encode() for s in LITS16])
+    e = cx.compile("|".join(LITS16))
+    assert e.strategy == t.strategy == "UseTeddy" and t.supported and t.blob() == e.blob()
+    c = cx.program_from_charclass(WORD)
+    e = cx.compile(r"[\w]+")
+    assert e.strategy == c.strategy == "UseCharClassSearcher" and c.supported and c.blob() == e.blob()
+    assert not t.submatch_supported and not c.submatch_supported
+    # outside the device subset: CXG_OK, supported == 0, reason available (the shim leaves e.hip nil)
+    fat = cx.program_from_literals([b"lit%02d" % i for i in range(70)])
+    assert not fat.supported and fat.why_unsupported
+    short = cx.program_from_literals([b"ab", b"cde"])
+    assert not short.supported and "shorter" in short.why_unsupported
+
+
+def _raw_from_nfa(nfa, strategy=1, flags=0):
+    h = C.c_void_p(0xDEAD)
+    rc = _lib.lib().cxg_program_from_nfa(C.byref(nfa), strategy, flags, C.byref(h))
+    return rc, h.value, _lib.lib().cxg_last_error().decode()
+
+
+def test_malformed_nfa_descriptions_are_rejected():
+    """Foreign data: every index is validated before anything walks it — CXG_E_INVALID, a message naming the state, *out
+    NULL; never CXG_OK with supported == 0, never an out-of-bounds read."""
+    eng = cx.compile(r"(\w+)@(\w+)\.(\w+)")
+    good, keep = cx.flatten_nfa(eng.nfa())
+    assert _raw_from_nfa(good, 2, 2)[0] == 0
+    states, trans = keep
+    kinds = {s.kind for s in states}
+    assert {1, 2, 3, 5} <= kinds or {2, 3, 5} <= kinds       # byte range or sparse, split, capture present
+
+    def mutate(fn):
+        nfa, (st, tr) = cx.flatten_nfa(eng.nfa())
+        fn(nfa, st, tr)
+        rc, out, msg = _raw_from_nfa(nfa, 2, 2)
+        assert rc == _lib.CXG_E_INVALID and not out and "malformed NFA" in msg, (rc, out, msg)
+        return msg
+
+    def first(st, kind):
+        return next(i for i, s in enumerate(st) if s.kind == kind)
+
+    mutate(lambda n, st, tr: setattr(n, "start_anchored", n.n_states))
+    mutate(lambda n, st, tr: setattr(n, "start_unanchored", 0x7FFFFFFF))
+    mutate(lambda n, st, tr: setattr(n, "capture_count", 0))
+    assert "split" in mutate(lambda n, st, tr: setattr(st[first(st, 3)], "left", n.n_states + 5))
+    mutate(lambda n, st, tr: setattr(st[first(st, 3)], "right", 0xFFFFFFF0))
+    assert "sparse" in mutate(lambda n, st, tr: setattr(st[first(st, 2)], "trans_len", n.n_trans + 1))
+    mutate(lambda n, st, tr: setattr(st[first(st, 2)], "trans_off", 0xFFFFFFFF))
+    mutate(lambda n, st, tr: setattr(tr[0], "next", n.n_states))
+    mutate(lambda n, st, tr: (setattr(tr[0], "lo", 9), setattr(tr[0], "hi", 3)))
+    mutate(lambda n, st, tr: setattr(st[first(st, 5)], "cap_index", 99))
+    mutate(lambda n, st, tr: setattr(st[first(st, 5)], "next", n.n_states))
+    mutate(lambda n, st, tr: setattr(st[0], "kind", 42))
+    mutate(lambda n, st, tr: setattr(n, "n_states", 0))
+    # InvalidState (0xFFFFFFFF) is a legal "no target" (nfa/nfa.go:62-64)
+    nfa, (st, tr) = cx.flatten_nfa(eng.nfa())
+    assert _raw_from_nfa(nfa, 2, 2)[0] == 0
+    # bad scalar arguments
+    assert _raw_from_nfa(good, 99, 0)[0] == _lib.CXG_E_INVALID
+    assert _raw_from_nfa(good, 2, 0x80)[0] == _lib.CXG_E_INVALID
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.cxg_program_from_nfa(None, 1, 0, C.byref(h)) == _lib.CXG_E_INVALID
+    assert L.cxg_program_from_literals(None, None, 3, C.byref(h)) == _lib.CXG_E_INVALID
+    assert L.cxg_program_from_charclass(None, 1, C.byref(h)) == _lib.CXG_E_INVALID
+    assert L.cxg_program_from_charclass(bytes(256), 1, C.byref(h)) == _lib.CXG_E_INVALID       # empty class
+    assert L.cxg_program_from_charclass(bytes(WORD), 0, C.byref(h)) == _lib.CXG_E_INVALID      # minMatch 0
+    arr = (C.c_char_p * 1)(b"abc")
+    lens = (C.c_uint32 * 1)(3)
+    assert L.cxg_program_from_literals(arr, lens, 0, C.byref(h)) == _lib.CXG_E_INVALID
+    # a stale message must not survive a successful call that yields an unsupported program
+    rc, out, msg = _raw_from_nfa(good, 4, 0)                 # UseReverseSuffix: no device kernel
+    assert rc == 0 and out and "no device kernel" in msg
+    L.cxg_program_destroy(out)
+
+
+def test_shim_harness_compiles_as_c99(tmp_path):
+    obj = tmp_path / "shim_harness.o"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-c", os.path.join(ROOT, "examples", "shim_harness.c"), "-o", str(obj)])
+    assert obj.stat().st_size > 0
+
+
+# ---------------------------------------------------------------------------------------------- GPU tier
+CONFIGS = [
+    (1, "nfa", r"error", None),
+    (2, "nfa", r"\d+\.\d+\.\d+\.\d+", None),
+    (3, "literals", "|".join(LITS16), LITS16),
+    (4, "charclass", r"[\w]+", WORD),
+    (5, "nfa", r"(\w+)@(\w+)\.(\w+)", None),
+]
+
+
+def _program(kind, pat, spec):
+    if kind == "nfa":
+        return via_constructor(pat)[1]
+    if kind == "literals":
+        return cx.program_from_literals([s.encode() for s in spec], pat.encode())
+    return cx.program_from_charclass(spec, 1, pat.encode())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,kind,pat,spec", CONFIGS)
+def test_constructor_programs_give_the_oracle_rows(oracle, cfg, kind, pat, spec):
+    """All five BASELINE configurations through the constructor the shim calls: host haystack (cxg_find_all / cxg_count),
+    device-resident haystack, limit; equal to the oracle and to the cxg_compile program."""
+    import torch
+    assert cx.device_count() >= 1
+    prog = _program(kind, pat, spec)
+    eng = cx.compile(pat)
+    assert prog.supported and prog.strategy == eng.strategy == oracle.Regex(pat).strategy
+    o = oracle.Regex(pat)
+    npages = 4096                                            # 16 MiB of the configuration's corpus
+    host = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 5, npages)
+    exp = o.find_all_index(host)
+    assert len(exp) > 1000
+    got = prog.find_all_index(host)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    assert np.array_equal(eng.find_all_index(host), exp)
+    assert prog.count(host) == len(exp)
+    assert np.array_equal(prog.find_all_index(host, 11), exp[:11])
+    for small in (b"", host[:1000].tobytes(), host[:70000].tobytes()):        # zero-copy path and the copying path
+        assert np.array_equal(prog.find_all_index(small), o.find_all_index(small))
+    buf = cx.DeviceBuffer(npages * 4096)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 5)
+    out = torch.empty((len(exp) + 8, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert prog.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t) == len(exp)
+    assert t.n_launches == 1, "the constructor's program must land on the same wave kernel as cxg_compile's"
+    assert np.array_equal(out[:len(exp)].cpu().numpy(), exp)
+    if cfg == 5:                                             # FindAllSubmatch through the binding (meta/findall.go:390)
+        assert prog.submatch_supported
+        exps = o.find_all_submatch_index(host)
+        gots = prog.find_all_submatch_index(host)
+        assert gots.shape == exps.shape and np.array_equal(gots, exps)
+        assert np.array_equal(prog.find_all_submatch_index(host, 5), exps[:5])
+        outs = torch.empty((len(exps) + 8, 8), dtype=torch.int64, device="cuda")
+        assert prog.find_all_submatch_device(buf.ptr, npages * 4096, outs.data_ptr(), len(exps) + 8, timing=t) == len(exps)
+        assert t.n_launches == 1 and np.array_equal(outs[:len(exps)].cpu().numpy(), exps)
+
+
+@pytest.mark.gpu
+def test_constructor_programs_other_shapes(oracle):
+    """Beyond the five configurations: non-chain DFAs, non-greedy, one-pass captures, required literal prefixes."""
+    corpus = cx.synth_pages(2, 0xC0FFEE02, 0, 64).tobytes() + b" GET /a/b HTTP/1.1 k=12 ab abc aab abbc x1y22z 00:12:59 " * 50
+    for pat in NFA_PATTERNS:
+        eng, prog = via_constructor(pat)
+        o = oracle.Regex(pat)
+        if prog.supported:
+            assert np.array_equal(prog.find_all_index(corpus), o.find_all_index(corpus)), pat
+        if prog.submatch_supported and prog.num_groups > 1:
+            assert np.array_equal(prog.find_all_submatch_index(corpus), o.find_all_submatch_index(corpus)), pat
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,spec,cfg,pat", [
+    ("nfa", r"\d+\.\d+\.\d+\.\d+", 2, r"\d+\.\d+\.\d+\.\d+"), ("nfa", "error", 1, "error"),
+    ("literals", ",".join(LITS16), 3, "|".join(LITS16)), ("charclass", "0-9,A-Z,_-_,a-z", 4, r"[\w]+"),
+    ("submatch", r"(\w+)@(\w+)\.(\w+)", 5, r"(\w+)@(\w+)\.(\w+)"),
+])
+def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
+    """examples/shim_harness.c — the Go shim statement for statement in C (flattenNFA into malloc'ed arrays, constructor,
+    engine destroyed and arrays freed before the first search, capacity retry loop) — linked against the /opt/rocm
+    build, prints the oracle's rows for every configuration."""
+    lib = os.path.join(ROOT, "coregex_amd", "libcoregex_hip_rocm.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "coregex_amd", "csrc"), "rocm"])
+    exe = tmp_path / "shim_harness"
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shim_harness.c"),
+                           "-L", os.path.join(ROOT, "coregex_amd"), "-lcoregex_hip_rocm", "-o", str(exe)])
+    hay = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 21, 256).tobytes()          # 1 MiB: the shim's hipThreshold
+    f = tmp_path / "hay.log"
+    f.write_bytes(hay)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "coregex_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outp = subprocess.run([str(exe), mode, spec, str(f)], env=env, capture_output=True, text=True, timeout=180)
+    assert outp.returncode == 0, outp.stderr
+    rows = [list(map(int, ln.split())) for ln in outp.stdout.splitlines() if ln and not ln.startswith("#")]
+    o = oracle.Regex(pat)
+    exp = o.find_all_submatch_index(hay) if mode == "submatch" else o.find_all_index(hay)
+    assert rows == exp.tolist()
+    if cfg == 4:                                             # [\w]+: ~1 row per 5.5 bytes >> len/100+1: the retry loop ran
+        assert "1 capacity retries" in outp.stdout
