@@ -145,6 +145,13 @@ class Regex:
         _check(_lib.lib().cxg_program_blob(self._h, C.byref(p), C.byref(n)))
         return C.string_at(p, n.value)
 
+    def fsm_image(self, submatch: bool = False):
+        """None, or the FindAll transducer image (device/fsm.hpp) the general-DFA kernel runs for this program."""
+        p, n = C.c_void_p(), C.c_size_t()
+        if _lib.lib().cxg_program_fsm_image(self._h, 1 if submatch else 0, C.byref(p), C.byref(n)) != 0:
+            return None
+        return C.string_at(p, n.value)
+
     def nfa(self):
         """Host copy of the NFA as (states ndarray-of-tuples, trans, start_anchored, start_unanchored, captures)."""
         v = _lib.Nfa()

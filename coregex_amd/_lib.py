@@ -21,9 +21,9 @@ CXG_E_DEVICE, CXG_E_NO_GPU, CXG_E_SYNTAX, CXG_E_INTERNAL, CXG_E_INPUT = -4, -5, 
 SYMBOLS = [
     "cxg_last_error", "cxg_version", "cxg_device_count", "cxg_set_device", "cxg_thread_release", "cxg_compile", "cxg_program_flags",
     "cxg_program_from_nfa", "cxg_program_from_literals", "cxg_program_from_charclass",
-    "cxg_program_destroy", "cxg_program_strategy", "cxg_strategy_name", "cxg_program_num_groups",
+    "cxg_program_destroy", "cxg_program_strategy", "cxg_strategy_name", "cxg_kernel_name", "cxg_program_num_groups",
     "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_blob",
-    "cxg_program_nfa", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
+    "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device",
     "cxg_find_all_submatch_device",
@@ -32,7 +32,8 @@ SYMBOLS = [
 
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("n_launches", C.c_uint32),
-                ("grid", C.c_uint32), ("block", C.c_uint32), ("tiles", C.c_uint64)]
+                ("grid", C.c_uint32), ("block", C.c_uint32), ("tiles", C.c_uint64), ("kernel", C.c_uint32),
+                ("fallback_reason", C.c_uint32)]
 
 
 class NfaTrans(C.Structure):
@@ -88,6 +89,8 @@ def lib():
     L.cxg_version.restype = C.c_char_p
     L.cxg_strategy_name.restype = C.c_char_p
     L.cxg_strategy_name.argtypes = [C.c_int]
+    L.cxg_kernel_name.restype = C.c_char_p
+    L.cxg_kernel_name.argtypes = [C.c_int]
     L.cxg_set_device.argtypes = [C.c_int]
     L.cxg_compile.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
     L.cxg_program_from_nfa.argtypes = [C.POINTER(Nfa), C.c_int, u32, C.POINTER(vp)]
@@ -104,6 +107,7 @@ def lib():
     L.cxg_thread_release.restype = None
     L.cxg_program_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_nfa.argtypes = [vp, C.POINTER(Nfa)]
+    L.cxg_program_fsm_image.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_submatch_blobs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_chain_captures.argtypes = [vp, C.c_char_p]
     L.cxg_program_chain_captures.restype = C.c_int

@@ -17,6 +17,7 @@
 #include "device/synth.hpp"
 #include "device/block_common.hpp"
 #include "device/walk.hpp"
+#include "device/fsm.hpp"
 #include "host/frontend.h"
 #include "host/program.h"
 
@@ -29,6 +30,7 @@ hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, b
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, hipStream_t stream);
 }  // namespace cxgdev
 
 namespace {
@@ -298,6 +300,17 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     if (int rc = deviceCopy(p->subBlob, &mp->devSub[t_device], &d_blob)) return rc;
     if (int rc = deviceCopy(p->capBlob, &mp->devCap[t_device], &d_cap)) return rc;
   } else if (int rc = deviceBlob(p, t_device, &d_blob)) return rc;
+  // general-DFA kernel (scan_fsm.hip): first choice for programs the bit-parallel / literal kernels do not take, and
+  // the fallback of those kernels (match-dense input, input without synchronising bytes)
+  static const bool fsmOk = getenv("CXG_NO_FSM") == nullptr;
+  const std::vector<uint8_t>& fsmImg = submatch ? p->subFsmBlob : p->fsmBlob;
+  const uint8_t* d_fsm = nullptr;
+  if (fsmOk && !fsmImg.empty()) {
+    cxg_program* mp = const_cast<cxg_program*>(p);
+    if (int rc = deviceCopy(fsmImg, submatch ? &mp->devSubFsm[t_device] : &mp->devFsm[t_device], &d_fsm)) return rc;
+  }
+  bool fsmTried = false;
+  uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.hay = static_cast<const uint8_t*>(d_hay);
   a.len = len;
@@ -341,6 +354,10 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     static const bool noPrefix = getenv("CXG_NO_PREFIX_KERNEL") != nullptr;
     if (!noPrefix) gen = 9;                                        // literal occurrences + anchored DFA walk (scan_teddy_wave.hip VERIFY)
   }
+  if (d_fsm && (gen == 0 || (gen == 2 && digitKernelGeneration() == 6)) && (h->kind == cxgdev::kKindBidir || h->kind == cxgdev::kKindDigit)) {
+    gen = 10;                                                       // table-walking kernels only when the transducer is unavailable or gives up
+    fsmTried = true;
+  }
   // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
@@ -352,7 +369,7 @@ relaunch:
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
-  if (gen == 6 || gen == 7 || gen == 9) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if ((gen == 6 || gen == 7 || gen == 9) && denseChain) {           // four times the row-buffer room per wave-tile
     a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
@@ -385,7 +402,9 @@ relaunch:
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
-  if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
+  a.blob = gen == 10 ? d_fsm : d_blob;
+  if (gen == 10) le = cxgdev::launch_scan_fsm(a, reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data())->lds_bytes, stream);
+  else if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
@@ -450,6 +469,9 @@ relaunch:
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
+    timing->kernel = static_cast<uint32_t>(gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+                                           : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
+    timing->fallback_reason = lastReason;
   }
   if (profOn) {
     uint64_t pc[16];
@@ -484,8 +506,13 @@ relaunch:
       relaunches++;
       goto relaunch;
     }
+    lastReason = err >> 8;
+    if (d_fsm && !fsmTried) {                                       // dense tile / no sync byte in a halo: the transducer kernel
+      if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the transducer kernel\n", gen, err >> 8);
+      relaunches++; gen = 10; fsmTried = true; goto relaunch;
+    }
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
-    relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // dense tile / no sync byte in a halo: table kernels
+    relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
   }
   err &= 0xFFu;
   if (err & cxgdev::kErrLongMatch)
@@ -608,6 +635,21 @@ int cxg_set_device(int device) {
 
 void cxg_thread_release(void) {
   for (auto& x : t_scratch) x.release();
+}
+
+const char* cxg_kernel_name(int k) {
+  switch (k) {
+    case CXG_K_DFA_TABLE: return "k_scan_dfa";
+    case CXG_K_DIGIT_FLAT: return "k_scan_digit_flat";
+    case CXG_K_CHAIN_WAVE: return "k_scan_chain_wave";
+    case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
+    case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
+    case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
+    case CXG_K_FSM: return "k_scan_fsm";
+    case CXG_K_TEDDY_TABLE: return "k_scan_teddy";
+    case CXG_K_CHARCLASS_TABLE: return "k_scan_charclass";
+    default: return "none";
+  }
 }
 
 const char* cxg_strategy_name(int s) {
@@ -762,10 +804,12 @@ int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match
 void cxg_program_destroy(cxg_program* p) {
   if (!p) return;
   for (int d = 0; d < 16; d++) {
-    if (p->dev[d] || p->devSub[d] || p->devCap[d]) (void)hipSetDevice(d);
+    if (p->dev[d] || p->devSub[d] || p->devCap[d] || p->devFsm[d] || p->devSubFsm[d]) (void)hipSetDevice(d);
     if (p->dev[d]) (void)hipFree(p->dev[d]);
     if (p->devSub[d]) (void)hipFree(p->devSub[d]);
     if (p->devCap[d]) (void)hipFree(p->devCap[d]);
+    if (p->devFsm[d]) (void)hipFree(p->devFsm[d]);
+    if (p->devSubFsm[d]) (void)hipFree(p->devSubFsm[d]);
   }
   delete p;
 }
@@ -784,6 +828,14 @@ int cxg_program_blob(const cxg_program* p, const void** data, size_t* len) {
   if (!p->supported) return fail(CXG_E_UNSUPPORTED, p->whyNot);
   *data = p->blob.data();
   *len = p->blob.size();
+  return CXG_OK;
+}
+int cxg_program_fsm_image(const cxg_program* p, int submatch, const void** data, size_t* len) {
+  if (!p || !data || !len) return fail(CXG_E_INVALID, "null argument");
+  const std::vector<uint8_t>& b = submatch ? p->subFsmBlob : p->fsmBlob;
+  if (b.empty()) return fail(CXG_E_UNSUPPORTED, p->fsmWhyNot.empty() ? "program has no FindAll transducer image" : p->fsmWhyNot);
+  *data = b.data();
+  *len = b.size();
   return CXG_OK;
 }
 int cxg_program_submatch_blobs(const cxg_program* p, const void** sb, size_t* sl, const void** cb, size_t* cl) {

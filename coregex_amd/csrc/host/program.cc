@@ -1,5 +1,6 @@
 // See program.h.
 #include "program.h"
+#include "fsm.h"
 
 #include <algorithm>
 #include <cstring>
@@ -672,6 +673,22 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
     }
+    // General-DFA kernel (scan_fsm.hip): the FindAll transducer of the pattern.  For UseDFA / UseBoth it IS the
+    // reference's loop (forward DFA with break-at-match, restart at the match end, reverse DFA for the start).  A
+    // UseDigitPrefilter program qualifies when its digit-scan order equals plain leftmost-first: run skip safe and tail
+    // closed (kFlagFastDigit) or no run skip at all (see above); the others keep the reference's quirk on the
+    // table-walking kernel.  Programs that already are complete ordered chains / plain literals get the image too: it is
+    // their fallback for match-dense or synchronisation-free input.
+    {
+      const bool plainOrder = h.kind == cxgdev::kKindBidir || (h.flags & cxgdev::kFlagFastDigit) || !(flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE);
+      if (plainOrder && nfa.start_unanchored != nfa.start_anchored) {
+        try {
+          Dfa rv = p->rev;
+          if (rv.nstates == 0) { HostNfa rn = reverseOf(nfa); cxg_nfa rvw = rn.view(); rv = determinize(rvw, rvw.start_anchored, false, kMaxDfaStates); }
+          if (!buildFsmImage(nfa, rv, (h.flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u, p->fsmBlob, p->fsmWhyNot)) p->fsmBlob.clear();
+        } catch (const BuildError& e) { p->fsmBlob.clear(); p->fsmWhyNot = e.msg; }
+      } else p->fsmWhyNot = "digit-scan order differs from leftmost-first (run-skip quirk)";
+    }
     h.fwd_states = p->fwd.nstates; h.fwd_start = p->fwd.start; h.fwd_first_accept = p->fwd.firstAccept;
     appendTable(blob, p->fwd, h.fwd_off);
     if (h.kind == cxgdev::kKindBidir) {
@@ -886,6 +903,10 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
       h.total_bytes = static_cast<uint32_t>(blob.size());
       std::memcpy(blob.data(), &h, sizeof h);
       p->subBlob.swap(blob);
+    }
+    {  // spans by the general-DFA kernel (plain leftmost-first: what the reference's PikeVM reports as group 0)
+      std::string w;
+      if (!buildFsmImage(nfa, rev, 0u, p->subFsmBlob, w)) p->subFsmBlob.clear();
     }
     // ---- one-pass capture table
     CapClosure cc(nfa);

@@ -47,6 +47,10 @@ struct cxg_program {
   cxg::HostNfa nfa;              // kept for cxg_program_nfa (cxg_compile only)
   cxg::Dfa fwd, rev;
   std::vector<uint8_t> blob;     // cxgdev::BlobHeader + tables
+  // FindAll transducer (device/fsm.hpp, host/fsm.cc): the general-DFA kernel scan_fsm.hip.  Empty when the program is
+  // served by a bit-parallel / literal / char-class kernel alone or the transducer exceeds its budget (fsmWhyNot).
+  std::vector<uint8_t> fsmBlob, subFsmBlob;   // FindAllIndex / Count; spans of FindAllSubmatchIndex
+  std::string fsmWhyNot;
   // FindAllSubmatchIndex: spans from a bidirectional DFA image + one-pass capture table (any strategy:
   // the reference sends FindAllSubmatch of DFA/Both/NFA/DigitPrefilter engines to the PikeVM, whose
   // result is plain leftmost-first, meta/findall.go:89-98)
@@ -62,6 +66,8 @@ struct cxg_program {
   void* dev[16] = {nullptr};
   void* devSub[16] = {nullptr};
   void* devCap[16] = {nullptr};
+  void* devFsm[16] = {nullptr};
+  void* devSubFsm[16] = {nullptr};
 };
 
 namespace cxg {

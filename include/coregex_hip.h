@@ -100,7 +100,16 @@ typedef struct cxg_timing {  /* filled by the *_device entry points when non-NUL
   uint32_t n_launches;
   uint32_t grid, block;
   uint64_t tiles;
+  uint32_t kernel;           /* cxg_kernel id of the LAST scan launch (after fallbacks): see cxg_kernel_name */
+  uint32_t fallback_reason;  /* reason bits of the last fallback a wave kernel raised in this call, 0: none */
 } cxg_timing;
+
+/* Kernel families (cxg_timing.kernel). */
+enum cxg_kernel {
+  CXG_K_NONE = 0, CXG_K_DFA_TABLE = 1, CXG_K_DIGIT_FLAT = 2, CXG_K_CHAIN_WAVE = 6, CXG_K_TEDDY_WAVE = 7,
+  CXG_K_CHARCLASS_WAVE = 8, CXG_K_PREFIX_WAVE = 9, CXG_K_FSM = 10, CXG_K_TEDDY_TABLE = 11, CXG_K_CHARCLASS_TABLE = 12
+};
+const char* cxg_kernel_name(int kernel);
 
 const char* cxg_last_error(void);          /* thread-local text of the last failure */
 const char* cxg_version(void);
@@ -127,6 +136,10 @@ int cxg_program_dfa_states(const cxg_program* p);       /* eager forward DFA sta
 int cxg_program_supported(const cxg_program* p);        /* 1 if the device path accepts it */
 /* Device image of the program (what every kernel stages into LDS); for tests and the emulator. */
 int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
+/* Diagnostics: the FindAll transducer image of the general-DFA kernel (coregex_amd/csrc/device/fsm.hpp): of the
+ * FindAllIndex program (submatch == 0) or of the span program of FindAllSubmatchIndex (submatch != 0).
+ * CXG_E_UNSUPPORTED when the program has none (served by other kernels alone, or outside the table budget). */
+int cxg_program_fsm_image(const cxg_program* p, int submatch, const void** data, size_t* len);
 /* Images used by the FindAllSubmatch path: bidirectional-DFA span program + one-pass capture table. */
 int cxg_program_submatch_blobs(const cxg_program* p, const void** span_blob, size_t* span_len,
                                const void** cap_blob, size_t* cap_len);

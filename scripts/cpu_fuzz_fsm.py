@@ -1,0 +1,60 @@
+"""CPU fuzz of the FindAll transducer (host/fsm.cc tables + device/fsm.hpp lane functions run by tests/emu/emu_fsm.cc)
+against the oracle: random patterns, small tile/chunk geometries, few-symbol haystacks.  python scripts/cpu_fuzz_fsm.py [n] [seed]"""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import coregex_amd as cx
+import emu
+from oracle import oracle as O
+
+ATOMS = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d+", "[a-c]+", "[x-z]+", "a+", r"\.+", "[0-4]+", "[5-9]",
+         "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
+         "abcx|bcxy|cxyz|xyza", "z+", "abc", "xyz", "a:c", "(b*c)?", "(a|ab)", "(abc|ab|a)", "b*", "(ab*c|a|bb)", "a+?", "[ab]*?c"]
+
+def main(n=300, seed=1):
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+    seen, n_img, n_checked, reasons = set(), 0, 0, {}
+    t0 = time.time()
+    while len(seen) < n:
+        pat = "".join(ATOMS[int(rng.integers(0, len(ATOMS)))] for _ in range(int(rng.integers(1, 5))))
+        if pat in seen: continue
+        seen.add(pat)
+        try: rx = cx.compile(pat)
+        except cx.CoregexError: continue
+        img = rx.fsm_image()
+        simg = rx.fsm_image(True) if rx.num_groups > 1 else None
+        if img is None and simg is None: continue
+        n_img += 1
+        o = O.Regex(pat)
+        hays = [alphabet[rng.integers(0, len(alphabet), size=int(k))] for k in (0, 1, 7, 63, 64, 65, 300, 2000)]
+        hays += [alphabet[rng.integers(0, 6, size=700)], alphabet[rng.integers(0, 3, size=500)],
+                 np.frombuffer(b"1.2.3.4.5.6.7.8.9 " * 30, dtype=np.uint8), np.frombuffer(b"abcabcabxyzxyz" * 40, dtype=np.uint8)]
+        for hay in hays:
+            for tile, chunk in ((3840, 64), (64, 8), (32, 4), (256, 16)):
+                for which, image in (("idx", img), ("sub", simg)):
+                    if image is None: continue
+                    exp = o.find_all_index(hay) if which == "idx" else o.find_all_submatch_index(hay)[:, :2]
+                    if which == "idx" and rx.strategy == "UseBoth":      # the reference restarts its PikeVM inside matches > 100 bytes: kernel raises CXG_E_INPUT
+                        plain = o.find_all_submatch_index(hay)[:, :2]
+                        if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100: continue
+                    try:
+                        got = emu.find_all_fsm(image, hay, tile, chunk)
+                    except AssertionError as ex:
+                        np.save("/tmp/fsm_fail_hay.npy", hay)
+                        print("EMU ERROR", ex, repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), exp[:6].tolist())
+                        return 1
+                    if isinstance(got, int):
+                        reasons[got] = reasons.get(got, 0) + 1
+                        continue
+                    n_checked += 1
+                    if got.shape != exp.shape or not np.array_equal(got, exp):
+                        np.save("/tmp/fsm_fail_hay.npy", hay)
+                        print("MISMATCH", repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), got[:6].tolist(), exp[:6].tolist())
+                        return 1
+    print(f"{len(seen)} patterns, {n_img} with a transducer image, {n_checked} comparisons clean, fallback reasons {reasons}, {time.time()-t0:.1f}s")
+    return 0
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1))

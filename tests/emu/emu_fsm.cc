@@ -1,0 +1,100 @@
+// TEST INFRASTRUCTURE ONLY — sequential twin of scan_fsm.hip (the FindAll-transducer kernel).
+//
+// Runs the very lane functions the kernel instantiates (coregex_amd/csrc/device/fsm.hpp) tile by tile, lane by lane:
+// entry state by a warm-up walk over the previous chunk from the "any state" row, replay of the own chunk + walk-ahead,
+// rows gathered in lane order, starts by the reverse DFA bounded by the previous row's end.  Geometry (tile, chunk) is
+// a parameter so that the CPU tier can stress chunk and tile edges with tiny sizes.  Nothing in coregex_amd/ links it.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../coregex_amd/csrc/device/fsm.hpp"
+
+using namespace cxgdev;
+
+namespace {
+struct HostMem {
+  const uint8_t* g;   // hay + tile origin
+  uint32_t byte(int32_t r) const { return g[r]; }
+  uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
+};
+struct LaneRows {
+  int32_t end[kFsmLaneRows];
+  void set_end(uint32_t r, int32_t e) { end[r] = e; }
+};
+FsmView view_of(const uint8_t* img) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  FsmView v;
+  v.cls = img + h->cls_off;
+  v.tab = reinterpret_cast<const uint16_t*>(img + h->tab_off);
+  v.ev = reinterpret_cast<const uint16_t*>(img + h->ev_off);
+  v.lev = img + h->lev_off;
+  v.rev = img + h->rev_off;
+  v.stride = h->stride; v.n_t = h->n_t; v.top_row = h->top_row; v.ncls = h->ncls;
+  v.rev_start = h->rev_start; v.rev_first_accept = h->rev_first_accept;
+  return v;
+}
+}  // namespace
+
+// Returns the number of int64 values written (2 per match) or needed; -16 - reason when a tile would raise the
+// fallback flag (reason 1: a lane's entry state did not collapse, 2: more than kFsmLaneRows rows in a chunk,
+// 4: level stack overflow, 8: walk budget), -1 on a bad image.  stats (optional, 4 values): chunks, chunks whose entry
+// needed the full warm-up, walk-ahead bytes, rows fixed against the previous row.
+extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                    int tile, int chunk, int budget_bytes, uint64_t* stats) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
+  const FsmView v = view_of(img);
+  std::vector<int64_t> res;
+  const int lanes = tile / chunk;
+  const uint64_t ntiles = (len + static_cast<uint64_t>(tile) - 1) / static_cast<uint64_t>(tile);
+  int64_t prev_end = 0;                                   // absolute end of the previous row
+  uint64_t st[4] = {0, 0, 0, 0};
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile);
+    const uint64_t remaining = len - tile_lo;
+    const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+    const int32_t budget = rend < tile + budget_bytes ? rend : tile + budget_bytes;
+    const int32_t lowest = tile_lo > static_cast<uint64_t>(budget_bytes) ? -budget_bytes : -static_cast<int32_t>(tile_lo);
+    HostMem m{hay + tile_lo};
+    bool first_in_tile = true;
+    for (int lane = 0; lane < lanes; lane++) {
+      const int32_t c0 = lane * chunk, c1 = c0 + chunk;
+      if (c0 >= rend) break;
+      st[0]++;
+      uint32_t entry = 0;
+      if (tile_lo + static_cast<uint64_t>(c0) > 0) {
+        entry = fsm_walk(v, m, v.top_row, c0 - chunk, c0, true);
+        st[1]++;
+        if (entry >= v.n_t) return -16 - 1;
+      }
+      FsmLane L;
+      LaneRows rows;
+      fsm_replay(v, m, entry, c0, c1, rend, budget, L, rows);
+      if (L.flags) return -16 - static_cast<int64_t>(L.flags << 1);
+      for (uint32_t r = 0; r < L.nrows; r++) {
+        const int32_t e = rows.end[r];
+        uint32_t over = 0;
+        // the kernel knows the previous row's end only inside the tile; the tile's first row is walked without a bound
+        // and checked afterwards
+        const int64_t bound_abs = first_in_tile ? static_cast<int64_t>(tile_lo) + lowest : prev_end;
+        int32_t s = fsm_match_start(v, m, e, static_cast<int32_t>(bound_abs - static_cast<int64_t>(tile_lo)), lowest, over);
+        if (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end) {
+          st[3]++;
+          over = 0;
+          s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), lowest, over);
+        }
+        if (over) return -16 - 8;
+        if (s == kFsmNoStart) return -2;
+        first_in_tile = false;
+        res.push_back(static_cast<int64_t>(tile_lo) + s);
+        res.push_back(static_cast<int64_t>(tile_lo) + e);
+        prev_end = static_cast<int64_t>(tile_lo) + e;
+      }
+    }
+  }
+  if (stats) std::memcpy(stats, st, sizeof st);
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), static_cast<size_t>(n) * sizeof(int64_t));
+  return n;
+}

@@ -1,0 +1,103 @@
+"""GPU tier: the general-DFA kernel (scan_fsm.hip, FindAll transducer) against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from coregex_amd import _lib
+from refcorpus import COMPAT_PATTERNS, generate_test_input
+
+pytestmark = pytest.mark.gpu
+
+K_FSM = 10
+README_IP = r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"
+GENERAL = [README_IP, COMPAT_PATTERNS["la_peak_hours"], r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|foo)\d*",
+           r"[1-9][0-9]*|0", r"a(b*c)?", r"x[ab]+?y", r"[a-f0-9]{8}-[a-f0-9]{4}", r"ab|abc", r"GET|POST /[a-z]+", r"\d+(\.\d+)?%"]
+
+
+def _device_rows(rx, hay, sub=False):
+    import torch
+    a = np.ascontiguousarray(np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else hay)
+    n = (a.size + 15) // 16 * 16
+    buf = cx.DeviceBuffer(max(n, 16))
+    if a.size:
+        buf.upload(a)
+    scan = rx.find_all_submatch_device if sub else rx.find_all_device
+    w = 2 * rx.num_groups if sub else 2
+    cnt = scan(buf.ptr, a.size)
+    out = torch.empty((cnt + 4, w), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert scan(buf.ptr, a.size, out.data_ptr(), cnt + 4, timing=t) == cnt
+    return out[:cnt].cpu().numpy(), t
+
+
+@pytest.mark.parametrize("pat", GENERAL)
+def test_general_dfas_run_on_the_transducer_kernel(oracle, pat):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.supported and rx.fsm_image() is not None, (pat, rx.why_unsupported)
+    rng = np.random.default_rng(len(pat))
+    alphabet = np.frombuffer(b"abcfoxy.:-0123456789 %=/GETPOS\n", dtype=np.uint8)
+    hays = [generate_test_input(), cx.synth_pages(2, 0xC0FFEE02, 3, 300), b"", b"a", b"ab", b"abbbbbc abbbbbd bb",
+            alphabet[rng.integers(0, len(alphabet), size=200000)], alphabet[rng.integers(0, 8, size=50000)],
+            np.frombuffer((b"foobar12 foo3 foob " * 9000), dtype=np.uint8)]
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
+        assert rx.count(hay) == len(exp)
+    rows, t = _device_rows(rx, hays[1])
+    assert np.array_equal(rows, o.find_all_index(hays[1]))
+    assert t.kernel == K_FSM and t.n_launches == 1, (pat, t.kernel, t.n_launches, t.fallback_reason)
+
+
+def test_transducer_kernel_edges(oracle):
+    """Matches across chunk, wave-tile and group edges; matches that end with the input; rows whose start lies in the
+    previous tile / group (the unbounded reverse walk + the cross-tile and cross-group checks)."""
+    group = 3840 * 32
+    pat = r"a[0-9]*b|a\."
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    lit = np.frombuffer(b"a0123456789012345678901234567890123456789b", dtype=np.uint8)
+    base = np.full(2 * group + 5000, ord(" "), dtype=np.uint8)
+    offs = list(range(3840 - 45, 3840 + 3, 3)) + list(range(4096 - 45, 4096 + 3, 5)) + list(range(20, 70, 7)) + list(range(group - 45, group + 3, 3)) + [2 * 3840 - 1, group + 3840 - 6]
+    for off in offs:
+        hay = base.copy()
+        hay[off:off + len(lit)] = lit
+        hay[off + len(lit) + 1:off + len(lit) + 3] = np.frombuffer(b"a.", dtype=np.uint8)
+        exp = o.find_all_index(hay)
+        assert np.array_equal(rx.find_all_index(hay), exp), off
+        rows, t = _device_rows(rx, hay)
+        assert np.array_equal(rows, exp) and t.kernel == K_FSM, off
+    for n in (1, 63, 64, 65, 3839, 3840, 3841, 4095, 4096, 4097, group - 1, group, group + 1):
+        rep = (b"a12b a. ab x" * (n // 12 + 2))[:n]
+        assert np.array_equal(rx.find_all_index(rep), o.find_all_index(rep)), n
+        tail = np.full(n, ord(" "), dtype=np.uint8)
+        tail[max(0, n - 4):] = np.frombuffer(b"a12b", dtype=np.uint8)[-min(4, n):]
+        assert np.array_equal(rx.find_all_index(tail), o.find_all_index(tail)), n
+    # a second match found by a search that started inside the unbounded reverse walk of the first row of a tile:
+    # `ab|b+` on "...abb": [.., ab] then [b]; the reverse DFA from the second end accepts "bb" — the bound must cut it
+    pat2 = r"ab|b+"
+    rx2, o2 = cx.compile(pat2), oracle.Regex(pat2)
+    for off in (3838, 3839, 3840, group - 2, group - 1, group):
+        hay = base.copy()
+        hay[off - 1:off + 2] = np.frombuffer(b"abb", dtype=np.uint8)
+        exp = o2.find_all_index(hay)
+        rows, t = _device_rows(rx2, hay)
+        assert np.array_equal(rows, exp), (off, rows.tolist(), exp.tolist())
+
+
+def test_captures_take_their_spans_from_the_transducer_kernel(oracle):
+    hay = cx.synth_pages(5, 0xC0FFEE05, 0, 256).tobytes() + b" k=12 key=7;x=y GET /a/b POST /c " * 2000
+    for pat in (r"(GET|POST|PUT) /([a-z/]+)", r"([a-z]+)=(\d+|[a-z])", r"(\d+)(\.\d+)?"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.submatch_supported, pat
+        exp = o.find_all_submatch_index(hay)
+        got = rx.find_all_submatch_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), pat
+
+
+def test_dense_and_unconverged_input_falls_back_exactly(oracle):
+    """More than 8 matches in a 64-byte chunk, or a chunk whose entry state does not collapse (few-symbol input without
+    synchronising bytes): the kernel raises its flag and the table-walking kernel answers — same rows."""
+    pat = r"\d+\.\d+x?"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    for hay in (b"1.2 " * 20000, b"1.1" * 9000, b"1.2.3.4.5.6.7.8.9 " * 500):
+        assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))
