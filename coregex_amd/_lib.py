@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoregex_hip.so")
+LIB_PATH = os.environ.get("CXG_LIB_PATH") or os.path.join(_HERE, "libcoregex_hip.so")   # CXG_LIB_PATH: A/B builds (scripts/)
 _lib = None
 
 CXG_OK, CXG_E_INVALID, CXG_E_UNSUPPORTED, CXG_E_CAPACITY = 0, -1, -2, -3

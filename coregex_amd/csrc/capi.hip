@@ -30,7 +30,7 @@ hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, b
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, hipStream_t stream);
 }  // namespace cxgdev
 
 namespace {
@@ -371,7 +371,7 @@ relaunch:
   if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
-  if ((gen == 6 || gen == 7 || gen == 9) && denseChain) {           // four times the row-buffer room per wave-tile
+  if ((gen == 6 || gen == 7 || gen == 9 || gen == 10) && denseChain) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
     const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * cxgdev::kDenseTilesPerWave;
     a.ngroups = (len + gb - 1) / gb;
@@ -403,7 +403,11 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
-  if (gen == 10) le = cxgdev::launch_scan_fsm(a, reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data())->lds_bytes, stream);
+  if (gen == 10) {
+    static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
+    const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, stream);
+  }
   else if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
@@ -482,6 +486,12 @@ relaunch:
       for (int i = 0; i < 7; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)(pc[8 + i] / pc[15]));
       fprintf(stderr, "\n");
     }
+    if (gen == 10 && pc[15]) {
+      fprintf(stderr, "[CXG_PROF] fsm waves=%llu avg cycles per wave and group:", (unsigned long long)pc[15]);
+      static const char* names[7] = {"stage", "entry", "walk", "finish", "gather", "starts", "-"};
+      for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)(pc[8 + i] / pc[15]));
+      fprintf(stderr, "\n");
+    }
     if (gen == 6 && pc[7])
       fprintf(stderr, "[CXG_PROF] gen6 pairing mismatch: tile_lo=%llu n=%llu n_ends=%llu cout=%llu zA=%lld zB=%lld stage=%llu (count %llu)\n",
               (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3],
@@ -499,6 +509,13 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
+    if (gen == 10 && (err >> 8) == 0x20u && !denseChain) {           // transducer kernel: only the row buffers overflowed
+      if (verbose) fprintf(stderr, "[cxg] transducer kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
+      denseChain = true;
+      p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      relaunches++;
+      goto relaunch;
+    }
     if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain && !(h->flags & cxgdev::kFlagChainBounded)) {   // only the row buffers overflowed: same kernel, two tiles per wave
       if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
       denseChain = true;

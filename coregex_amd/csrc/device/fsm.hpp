@@ -41,65 +41,119 @@
 
 namespace cxgdev {
 
-constexpr uint32_t kFsmMagic = 0x43584732u;   // "CXG2"
+constexpr uint32_t kFsmMagic = 0x43584734u;   // "CXG4"
 constexpr int kFsmMaxLevels = 7;              // pending searches alive at once (4-bit refs in one dword)
-constexpr int kFsmLaneRows = 8;               // rows a lane buffers for its 64-byte chunk (denser input: fallback flag)
-constexpr int kFsmChunk = 64;
-constexpr uint32_t kFsmMaxRows = 255;         // table rows: states + uncertainty sets (+ the "wide" row), u8 ids
-constexpr uint32_t kFsmMaxTableBytes = 20u * 1024u;
+constexpr int kFsmLaneRows = 4;               // rows buffered per 32-byte chunk (denser input: fallback flag)
+constexpr int kFsmLaneEvents = 8;             // events recorded inside a 32-byte chunk before they are applied (power of two)
+constexpr int kFsmChunk = 64;                 // bytes per lane (two sub-chunks of kFsmSub bytes, walked in lockstep)
+constexpr uint32_t kFsmMaxTableBytes = 24u * 1024u;
 constexpr int kFsmMembers = 8;                // members listed per uncertainty row (more: the row counts as wide)
 
-// Event descriptor (u16), indexed by the high byte of a table entry (0 = no event):
+// Event descriptor (u16):
 //   bits 0-1 kind: 0 levels died only, 1 create (innermost matched), 2 rematch (pending level j matched again)
 //   bits 2-4 j (rematch), bit 5 conts: the matched level keeps live threads (stays pending)
 //   bits 8-14 died: pending levels (numbered before the step) whose threads died without a match
 constexpr uint32_t kFsmEvDied = 0, kFsmEvCreate = 1, kFsmEvRematch = 2;
 
+// Table.  A row is `stride` u16 (a power of two): [0, ncls) the transitions, [ncls] the event descriptor of an ALIAS
+// row, [ncls + 1] the number of pending levels of the row's state.  A transition holds the BYTE OFFSET of the target
+// row (a multiple of the row size >= 16) plus two flag bits: bit 0 the step CREATES a match, bit 1 it REMATCHES one.
+// The dependent chain of a walk is one LDS read and one v_and_or:  x = tab[(x & ~3) | 2 * class].  Row order:
+//   [0, n_t)           the transducer states;
+//   [n_t, n_t + n_a)   alias rows: a transition that carries an event targets a copy of its target state's row with
+//                      the event in column ncls — "an event happened" is `x >= alias_lo` (ordered by event kind);
+//   then n_u uncertainty rows (sets of states; the first is "any state"), entered only by warm-up walks; their
+//   transitions lead to other sets or, once the set has collapsed, to the state's own row;
+//   last the wide row (a set that was not tabulated; absorbing).
 struct FsmHeader {              // device image; offsets in bytes from the header
-  uint32_t magic, n_t, n_rows, ncls;        // n_t: transducer states (rows [0, n_t)); n_rows: all table rows
-  uint32_t top_row, wide_row, n_events, depth;   // top_row: "any state"; wide_row: set not tabulated (absorbing)
-  uint32_t stride, cls_off, tab_off, ev_off;     // cls: u8[256]; tab: u16[n_rows][stride] = next row | event << 8
-  uint32_t lev_off, mem_off, rev_off, rev_states;  // lev: u8[n_t] pending levels of a state; mem: u8[n_rows][8] members, 0xFF pad
-  uint32_t rev_start, rev_first_accept, flags, total_bytes;   // rev: u8[rev_states][ncls], state 0 dead
-  uint32_t lds_bytes, max_len, pad0, pad1;
+  uint32_t magic, n_t, n_a, n_u;
+  uint32_t ncls, stride, row_bytes, depth;
+  uint32_t alias_lo, u_lo, top_off, wide_off;      // byte offsets of the first alias row, the first set row, "any state", wide
+  uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u8[n_u + 1][8] member state ids, 0xFF pad
+  uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][ncls] target row byte offsets, row 0 dead; accepting rows >= rev_accept_off
+  uint32_t total_bytes, lds_bytes, max_len, pad0;
+  uint32_t create_lo, rematch_lo, pad1, pad2;      // alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
+                                                   // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch
 };
 
 struct FsmView {
-  const uint8_t* cls;
-  const uint16_t* tab;
-  const uint16_t* ev;
-  const uint8_t* lev;
+  const uint8_t* cls2;      // 2 * class of a byte
+  const uint8_t* tab;       // rows, addressed by byte offset
   const uint8_t* rev;
-  uint32_t stride, n_t, top_row, ncls, rev_start, rev_first_accept;
+  uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
+  uint32_t alias_lo, u_lo, top_off, rev_start_off, rev_accept_off;
+  uint32_t create_lo, rematch_lo;
 };
+CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
+// one step: entry t (row offset | flags) and 2 * class -> next entry
+CXG_FSM_HD uint32_t fsm_next(const FsmView& v, uint32_t t, uint32_t cls2) { return fsm_u16(v.tab, (t & ~3u) | cls2); }
+CXG_FSM_HD uint32_t fsm_shift_in2(uint32_t mask, uint32_t t) {   // (mask >> 2) | (t << 30): v_alignbit_b32
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(t, mask, 2u);
+#else
+  return (mask >> 2) | (t << 30);
+#endif
+}
 
 // Mem concept: uint32_t byte(int32_t r) for any r with 0 <= origin + r < len (r relative to the tile origin);
 //              uint32_t dword(int32_t r): little-endian bytes r..r+3, r % 4 == 0, all four inside one staged 64-byte chunk.
 
 // Pure state walk over [from, to): the warm-up that finds a chunk's entry state.  aligned: the range is whole dwords
-// of staged chunks.
+// of staged chunks.  Rows are byte offsets.
 template <class Mem>
-CXG_FSM_HD uint32_t fsm_walk(const FsmView& v, const Mem& m, uint32_t row, int32_t from, int32_t to, bool aligned) {
+CXG_FSM_HD uint32_t fsm_walk(const FsmView& v, const Mem& m, uint32_t x, int32_t from, int32_t to, bool aligned) {
   int32_t i = from;
   if (aligned) {
     for (; i + 4 <= to; i += 4) {
       const uint32_t d = m.dword(i);
-      row = v.tab[row * v.stride + v.cls[d & 0xFFu]] & 0xFFu;
-      row = v.tab[row * v.stride + v.cls[(d >> 8) & 0xFFu]] & 0xFFu;
-      row = v.tab[row * v.stride + v.cls[(d >> 16) & 0xFFu]] & 0xFFu;
-      row = v.tab[row * v.stride + v.cls[d >> 24]] & 0xFFu;
+      x = fsm_next(v, x, v.cls2[d & 0xFFu]);
+      x = fsm_next(v, x, v.cls2[(d >> 8) & 0xFFu]);
+      x = fsm_next(v, x, v.cls2[(d >> 16) & 0xFFu]);
+      x = fsm_next(v, x, v.cls2[d >> 24]);
     }
   }
-  for (; i < to; i++) row = v.tab[row * v.stride + v.cls[m.byte(i)]] & 0xFFu;
-  return row;
+  for (; i < to; i++) x = fsm_next(v, x, v.cls2[m.byte(i)]);
+  return x & ~3u;
+}
+
+// N warm-up walks of `nbytes` (multiple of 4) staged bytes each, in lockstep, all from row x0.
+template <int N, class Mem>
+CXG_FSM_HD void fsm_walk_n(const FsmView& v, const Mem& m, uint32_t x0, const int32_t (&from)[N], int32_t nbytes, uint32_t (&x)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < N; a++) x[a] = x0;
+  for (int32_t i = 0; i < nbytes; i += 4) {
+    uint32_t k[N][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < N; a++) {
+      const uint32_t d = m.dword(from[a] + i);
+      k[a][0] = v.cls2[d & 0xFFu]; k[a][1] = v.cls2[(d >> 8) & 0xFFu]; k[a][2] = v.cls2[(d >> 16) & 0xFFu]; k[a][3] = v.cls2[d >> 24];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 4; q++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) x[a] = fsm_next(v, x[a], k[a][q]);
+    }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < N; a++) x[a] &= ~3u;
 }
 
 struct FsmLane {
-  uint32_t x = 0;        // transducer state
+  uint32_t x = 0;        // current row (byte offset)
   uint32_t nlev = 0;     // live pending levels
   uint32_t lev = 0;      // 4 bits per level, outermost first: 0 created beyond the chunk, 1 alive at entry (foreign), 2 + r own row r
   uint32_t nrows = 0;    // own rows so far
-  uint32_t flags = 0;    // 1: more than kFsmLaneRows rows, 2: level stack overflow, 4: walk budget exhausted
+  uint32_t flags = 0;    // 1: more than kFsmLaneRows rows, 2: level stack overflow, 4: walk budget exhausted, 8: more than kFsmLaneEvents events
 };
 
 // Rows concept: void set_end(uint32_t r, int32_t e).
@@ -134,38 +188,178 @@ CXG_FSM_HD void fsm_apply(FsmLane& L, uint32_t ev, int32_t e, bool in_chunk, Row
   L.nlev = nn;
 }
 
-// Replays the chunk [c0, c1) from entry state `entry` (pending levels of the entry state are foreign), then keeps
-// walking until no level that can still change an own row is alive.  rend: end of input, budget: last position the
-// lane may read (serial-walk budget, scan_dfa.h).  Returns the number of own rows (ends in `rows`).
+// ---- replay of one chunk = fast part (whole staged chunk: walk + record events) + finish (apply the recorded events,
+// then walk on, applying events as they come, until no level that can still change an own row is alive).
+// Events concept: void push(uint32_t k, uint32_t row); uint32_t row_at(uint32_t k).
+struct FsmTrace { uint32_t x, evbits, nev; };        // state after the chunk, event positions (bit per byte), events seen
+
+CXG_FSM_HD void fsm_classes(const FsmView& v, uint32_t d, uint32_t (&k)[4]) {
+  k[0] = v.cls2[d & 0xFFu]; k[1] = v.cls2[(d >> 8) & 0xFFu]; k[2] = v.cls2[(d >> 16) & 0xFFu]; k[3] = v.cls2[d >> 24];
+}
+template <class Events>
+CXG_FSM_HD void fsm_step_rec(const FsmView& v, uint32_t cls2, uint32_t bit, FsmTrace& t, Events& evs) {
+  t.x = fsm_next(v, t.x, cls2) & ~3u;
+  if (t.x >= v.alias_lo) {                           // rare per lane: recorded now, applied after the walk
+    evs.push(t.nev & static_cast<uint32_t>(kFsmLaneEvents - 1), t.x);
+    t.nev++;
+    t.evbits |= bit;
+  }
+}
+// N chunks of kFsmSub bytes walked in lockstep (N independent dependency chains per lane: the table reads of one
+// hide behind those of the others).  Class lookups do not depend on the state: those of the NEXT dword are issued
+// before this dword's chain, so a chain step is one LDS read + one add.
+constexpr int kFsmSub = 32;
+template <int N, class Mem, class Events>
+CXG_FSM_HD void fsm_fast(const FsmView& v, const Mem& m, const int32_t (&c0)[N], FsmTrace (&t)[N], Events* evs) {
+  uint32_t kk[N][4], nn[N][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a]), kk[a]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int q = 0; q < kFsmSub / 4; q++) {
+    if (q + 1 < kFsmSub / 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a] + 4 * (q + 1)), nn[a]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) fsm_step_rec(v, kk[a][k], 1u << (4 * q + k), t[a], evs[a]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < N; a++) for (int k = 0; k < 4; k++) kk[a][k] = nn[a][k];
+  }
+}
+
+// SHALLOW machines (FsmHeader::depth <= 1: never more than one pending match — `\d+\.\d+`, alternations of literals,
+// most log patterns): a chunk's rows follow from two bitmaps, no per-event bookkeeping.  Every create event opens a row;
+// the row's end is the last create / rematch event before the next create (a rematch before the first create belongs
+// to a match that was pending when the chunk was entered: another lane's row).
+struct FsmTraceS { uint32_t x, k0, k1; };             // entry after the chunk; the flag bits of its 32 steps, two per byte
+template <int N, class Mem>
+CXG_FSM_HD void fsm_fast_shallow(const FsmView& v, const Mem& m, const int32_t (&c0)[N], FsmTraceS (&t)[N]) {
+  uint32_t kk[N][4], nn[N][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a]), kk[a]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int q = 0; q < kFsmSub / 4; q++) {
+    if (q + 1 < kFsmSub / 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a] + 4 * (q + 1)), nn[a]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) {                    // the new entry's two flag bits shift into the mask from the top:
+        t[a].x = fsm_next(v, t[a].x, kk[a][k]);        // three VALU per byte, no compare, no branch
+        if (q < 4) t[a].k0 = fsm_shift_in2(t[a].k0, t[a].x); else t[a].k1 = fsm_shift_in2(t[a].k1, t[a].x);
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < N; a++) for (int k = 0; k < 4; k++) kk[a][k] = nn[a][k];
+  }
+}
+// Rows of a whole chunk [c0, c0 + kFsmSub) from its trace, then the walk past the chunk while its last match is pending.
 template <class Mem, class Rows>
-CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32_t c0, int32_t c1, int32_t rend, int32_t budget,
-                           FsmLane& L, Rows& rows) {
+CXG_FSM_HD void fsm_finish_shallow(const FsmView& v, const Mem& m, const FsmTraceS& t, int32_t c0, int32_t rend, int32_t budget,
+                                   FsmLane& L, Rows& rows) {
+  const int32_t c1 = c0 + kFsmSub;
+  L.flags = 0;
+  // two bits per byte: bit 2p = the step over byte p created a match, bit 2p + 1 = it rematched one
+  const uint64_t K = (static_cast<uint64_t>(t.k1) << 32) | t.k0;
+  uint64_t C = K & 0x5555555555555555ull;
+  const uint64_t CR = C | ((K >> 1) & 0x5555555555555555ull);
+  uint32_t n = 0;
+  while (C) {
+    const uint32_t c = static_cast<uint32_t>(__builtin_ctzll(C));
+    C &= C - 1;
+    const uint64_t below_next = C ? ((1ull << static_cast<uint32_t>(__builtin_ctzll(C))) - 1ull) : ~0ull;
+    const uint64_t win = CR & below_next & ~((1ull << c) - 1ull);            // events of this row (bit c is set)
+    const int32_t top = (63 - static_cast<int32_t>(__builtin_clzll(win))) >> 1;
+    if (n < static_cast<uint32_t>(kFsmLaneRows)) rows.set_end(n, c0 + top + 1); else L.flags |= 1u;
+    n++;
+  }
+  L.nrows = n < static_cast<uint32_t>(kFsmLaneRows) ? n : static_cast<uint32_t>(kFsmLaneRows);
+  L.x = t.x & ~3u;
+  L.nlev = fsm_u16(v.tab, L.x + v.ncls2 + 2u);                               // 0 or 1
+  // a match pending at the chunk's end is the chunk's last row when the chunk created one, else it is older than the chunk
+  L.lev = L.nlev ? (L.nrows ? 1u + L.nrows : 1u) : 0u;
+  for (int32_t i = c1;; i++) {
+    if (L.lev == 0u) break;
+    if (i >= rend) break;
+    if (i >= budget) { L.flags |= 4u; break; }
+    L.x = fsm_next(v, L.x, v.cls2[m.byte(i)]) & ~3u;
+    if (L.x >= v.alias_lo) fsm_apply(L, fsm_u16(v.tab, L.x + v.ncls2), i + 1, false, rows);
+  }
+}
+
+// fast: trace of the chunk's fast part, or nullptr when the chunk was not walked yet (edge chunks: end of input inside).
+template <class Mem, class Rows, class Events>
+CXG_FSM_HD void fsm_finish(const FsmView& v, const Mem& m, uint32_t entry, const FsmTrace* fast, int32_t c0, int32_t c1, int32_t rend,
+                           int32_t budget, FsmLane& L, Rows& rows, Events& evs) {
   L.x = entry;
-  L.nlev = v.lev[entry];
+  L.nlev = fsm_u16(v.tab, entry + v.ncls2 + 2u);
   L.lev = 0x1111111u & ((1u << (4u * L.nlev)) - 1u);
   L.nrows = 0;
   L.flags = 0;
   int32_t i = c0;
-  if (c1 <= rend && c1 <= budget) {                  // the whole chunk is staged data: dword reads, no end tests
-    for (; i < c1; i += 4) {
-      const uint32_t d = m.dword(i);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-      for (int k = 0; k < 4; k++) {
-        const uint32_t t = v.tab[L.x * v.stride + v.cls[(d >> (8 * k)) & 0xFFu]];
-        L.x = t & 0xFFu;
-        if (t >> 8) fsm_apply(L, v.ev[t >> 8], i + k + 1, true, rows);
-      }
+  if (fast) {
+    i = c1;
+    L.x = fast->x;
+    uint32_t evbits = fast->evbits;
+    if (fast->nev > static_cast<uint32_t>(kFsmLaneEvents)) { L.flags |= 8u; evbits = 0; }
+    uint32_t k = 0;
+    while (evbits) {                                 // apply in order
+      const uint32_t pos = static_cast<uint32_t>(__builtin_ctz(evbits));
+      evbits &= evbits - 1;
+      fsm_apply(L, fsm_u16(v.tab, evs.row_at(k) + v.ncls2), c0 + static_cast<int32_t>(pos) + 1, true, rows);
+      k++;
     }
   }
   for (;; i++) {
     if (i >= c1 && L.lev == 0u) break;               // only levels created beyond the chunk are left
     if (i >= rend) break;                            // end of input: every pending match is committed as it stands
     if (i >= budget) { L.flags |= 4u; break; }
-    const uint32_t t = v.tab[L.x * v.stride + v.cls[m.byte(i)]];
-    L.x = t & 0xFFu;
-    if (t >> 8) fsm_apply(L, v.ev[t >> 8], i + 1, i < c1, rows);
+    L.x = fsm_next(v, L.x, v.cls2[m.byte(i)]) & ~3u;
+    if (L.x >= v.alias_lo) fsm_apply(L, fsm_u16(v.tab, L.x + v.ncls2), i + 1, i < c1, rows);
+  }
+}
+
+// One chunk [c0, c1), c1 - c0 <= kFsmSub, from entry row `entry` (pending levels of the entry state are foreign).
+// rend: end of input, budget: last position the lane may read (serial-walk budget).
+template <class Mem, class Rows, class Events>
+CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32_t c0, int32_t c1, int32_t rend, int32_t budget,
+                           FsmLane& L, Rows& rows, Events& evs) {
+  if (c1 <= rend && c1 <= budget && c1 - c0 == kFsmSub) {
+    const int32_t cc[1] = {c0};
+    FsmTrace t[1] = {{entry, 0u, 0u}};
+    fsm_fast<1>(v, m, cc, t, &evs);
+    fsm_finish(v, m, entry, &t[0], c0, c1, rend, budget, L, rows, evs);
+  } else {
+    fsm_finish(v, m, entry, static_cast<const FsmTrace*>(nullptr), c0, c1, rend, budget, L, rows, evs);
   }
 }
 
@@ -176,13 +370,13 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
 constexpr int32_t kFsmNoStart = -0x7FFFFFFF - 1;
 template <class Mem>
 CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
-  uint32_t s = v.rev_start;
+  uint32_t s = v.rev_start_off;
   int32_t st = kFsmNoStart;
   for (int32_t at = e - 1; at >= bound; at--) {
     if (at < budget_lo) { over = 1u; break; }
-    s = v.rev[s * v.ncls + v.cls[m.byte(at)]];
+    s = fsm_u16(v.rev, s + v.cls2[m.byte(at)]);
     if (s == 0u) break;
-    if (s >= v.rev_first_accept) st = at;
+    if (s >= v.rev_accept_off) st = at;
   }
   return st;
 }

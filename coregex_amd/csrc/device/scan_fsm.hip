@@ -30,6 +30,21 @@
 #include "scan_dfa.h"
 #include "wave_common.hpp"
 
+// -DCXG_FSM_PROF=1 (experiments only): s_memtime at the phase boundaries, cycles summed into ScanArgs::prof[8..15]
+#ifndef CXG_FSM_PROF
+#define CXG_FSM_PROF 0
+#endif
+// -DCXG_FSM_ABL=n (experiments only, results WRONG): bit 0 = no entry-state walks, bit 1 = no lockstep walk of the
+// chunk, bit 2 = no row gathering / starts.  Attributes instruction counts to the phases.
+#ifndef CXG_FSM_ABL
+#define CXG_FSM_ABL 0
+#endif
+#if CXG_FSM_PROF
+#define FSM_MARK(i) do { const uint64_t t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define FSM_MARK(i) do { } while (0)
+#endif
+
 namespace cxgdev {
 
 namespace {
@@ -38,56 +53,79 @@ constexpr int kFsmStride = 68;                       // LDS bytes per 64-byte ch
 constexpr int kFsmWinBytes = 64 * kFsmStride;        // 4352 per wave
 constexpr int kFsmLeft = 64;                         // bytes staged in front of the tile
 constexpr int kFsmRowsPerWave = 512;                 // rows buffered per wave and group
-constexpr int32_t kFsmAhead = 57344;                 // a lane reads at most this far past its tile origin / before it
+constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the window (192 bytes past the tile)
 
+// The tile loop reads haystack bytes from the LDS window ONLY.  A load from HBM anywhere in the loop body — even on a
+// path that is never taken — makes the compiler wait for vmcnt(0) at the join, i.e. for the window of the NEXT tile
+// that is in flight: the prefetch would be worth nothing.  Walks that leave the window are finished elsewhere: a match
+// start in front of the window in the epilogue (rows marked unresolved), a walk past the window's end by the fallback.
+typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
 struct FsmMem {
-  const uint8_t* win;      // this wave's LDS window
-  const uint8_t* g;        // hay + tile_lo
+  lds_bytes_t win;         // this wave's LDS window: tile-relative bytes [-kFsmLeft, 4096 - kFsmLeft)
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    if (w < 4096u) return win[w + (w >> 6) * 4u];
-    return g[r];                                     // past the window: L2 / HBM (rare)
+    return win[w + (w >> 6) * 4u];
   }
   __device__ __forceinline__ uint32_t dword(int32_t r) const {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    return *reinterpret_cast<const uint32_t*>(win + w + (w >> 6) * 4u);
+    return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
   }
-};
-struct GlobalMem {
-  const uint8_t* g;        // hay - base: rows hold absolute offsets
-  __device__ __forceinline__ uint32_t byte(int64_t r) const { return g[r]; }
 };
 struct LdsRows {
   uint16_t* slot;          // this lane's kFsmLaneRows ends
   __device__ __forceinline__ void set_end(uint32_t r, int32_t e) { slot[r] = static_cast<uint16_t>(e); }
 };
+struct LdsEvents {
+  uint16_t* slot;          // kFsmLaneEvents alias rows of one sub-chunk
+  __device__ __forceinline__ void push(uint32_t k, uint32_t row) { slot[k] = static_cast<uint16_t>(row); }
+  __device__ __forceinline__ uint32_t row_at(uint32_t k) const { return slot[k]; }
+};
 
 __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader* h) {   // body = image without its header, in LDS
   FsmView v;
   const uint32_t hs = static_cast<uint32_t>(sizeof(FsmHeader));
-  v.cls = body + (h->cls_off - hs);
-  v.tab = reinterpret_cast<const uint16_t*>(body + (h->tab_off - hs));
-  v.ev = reinterpret_cast<const uint16_t*>(body + (h->ev_off - hs));
-  v.lev = body + (h->lev_off - hs);
+  v.tab = body;             // fixed layout (host/fsm.cc): the transition table first — at LDS address 0, see FsmLds
+  v.cls2 = body + (h->cls_off - hs);
   v.rev = body + (h->rev_off - hs);
-  v.stride = h->stride; v.n_t = h->n_t; v.top_row = h->top_row; v.ncls = h->ncls;
-  v.rev_start = h->rev_start; v.rev_first_accept = h->rev_first_accept;
+  v.ncls2 = 2u * h->ncls;
+  v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
+  v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   return v;
 }
 
+// All LDS of the kernel is ONE struct, the image first: the transition table then sits at LDS address 0 and a walk
+// step's address  (entry & ~3) | 2 * class  goes straight into the ds_read — no base add on the dependent chain
+// (with the table anywhere else the compiler adds the base in a VALU op: it cannot prove that base + offset does not
+// wrap, so it does not use the instruction's immediate offset).  IMG = bytes reserved for the image.
+template <bool SHALLOW, int IMG>
+struct FsmLds {
+  uint8_t img[IMG];
+  uint8_t win[kWavesPerBlock][kFsmWinBytes];
+  uint16_t lrow[kWavesPerBlock][64 * 2 * kFsmLaneRows];        // per-lane row ends of the current tile (two sub-chunks)
+  uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * kFsmLaneEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
+  uint16_t re[kWavesPerBlock][kFsmRowsPerWave];                // rows of the group: end inside its wave-tile
+  uint16_t rl[kWavesPerBlock][kFsmRowsPerWave];                // ... and length (0: unresolved)
+  uint32_t cnt[kWavesPerBlock][kTilesPerWave];
+  uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
+  int64_t tail[kWavesPerBlock * kTilesPerWave];                // absolute end of a tile's last row, -1: no rows
+  uint64_t group;
+  uint64_t base;
+};
+
 }  // namespace
 
-__global__ __launch_bounds__(kThreads) void k_scan_fsm(ScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t s_img[];           // tables of the image
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWavesPerBlock][kFsmWinBytes];
-  __shared__ uint16_t s_lrow[kWavesPerBlock][64 * kFsmLaneRows];            // per-lane row ends of the current tile
-  __shared__ uint16_t s_re[kWavesPerBlock][kFsmRowsPerWave];                // rows of the group: end inside its wave-tile
-  __shared__ uint16_t s_rl[kWavesPerBlock][kFsmRowsPerWave];                // ... and length
-  __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
-  __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 4];   // + 4: keeps the static LDS a multiple of 16 bytes (dynamic base alignment)
-  __shared__ int64_t s_tail[kWavesPerBlock * kTilesPerWave];                // absolute end of a tile's last row, -1: no rows
-  __shared__ uint64_t s_group;
-  __shared__ uint64_t s_base;
+// SHALLOW: the machine never holds more than one pending match (FsmHeader::depth <= 1): rows from two event bitmaps
+// per sub-chunk instead of a recorded event list (fsm.hpp).  TPW: wave-tiles per wave and group — 8, or 2 for match-dense
+// input (four times the row-buffer room per tile; the host switches after a row-buffer overflow).
+template <bool SHALLOW, int IMG, int TPW>
+__global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG> S;
+  uint8_t* const s_img = S.img;
+  auto& s_win = S.win; auto& s_lrow = S.lrow; auto& s_lev = S.lev; auto& s_re = S.re; auto& s_rl = S.rl;
+  auto& s_cnt = S.cnt; auto& s_qbase = S.qbase; auto& s_tail = S.tail;
+  uint64_t& s_group = S.group;
+  uint64_t& s_base = S.base;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_fsm(ScanArgs a) {
   const uint64_t group = s_group;
   if (group >= a.ngroups) return;
   const FsmView v = view_of(s_img, h);
-  constexpr int tpw = kTilesPerWave;
+  constexpr int tpw = TPW;
   uint32_t nrows_w = 0, fallback = 0, long_hit = 0;
 
   u32x4 x[4];
@@ -122,6 +160,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_fsm(ScanArgs a) {
       x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((lane + 64 * k) << 4) - pre, 0, 0);
   };
   issue_loads(0);
+#if CXG_FSM_PROF
+  uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tlast = __builtin_readcyclecounter();
+#endif
 
   for (int j = 0; j < tpw; j++) {
     const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
@@ -138,46 +180,91 @@ __global__ __launch_bounds__(kThreads) void k_scan_fsm(ScanArgs a) {
       }
       issue_loads(j + 1);
       wave_lds_sync();
+      FSM_MARK(0);                                      // window staged
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
-      const int32_t budget = rend < kFsmAhead ? rend : kFsmAhead;
-      const int32_t lowest = tile_lo > static_cast<uint64_t>(kFsmAhead) ? -kFsmAhead : -static_cast<int32_t>(tile_lo);
-      FsmMem m{win, a.hay + tile_lo};
-      // ---- E + R: entry state, replay
-      const int32_t c0 = (lane - 1) * kFsmChunk, c1 = c0 + kFsmChunk;
+      const int32_t budget = rend < kFsmWinEnd ? rend : kFsmWinEnd;      // walks stay inside the window
+      const int32_t lowest = tile_lo ? -kFsmLeft : 0;
+      FsmMem m{(lds_bytes_t)win};
+      // ---- E + R: entry states, replay.  A lane's 64 bytes are two sub-chunks of 32 walked in lockstep (two
+      // independent chains of dependent LDS reads per lane).
+      const int32_t c0 = (lane - 1) * kFsmChunk;
       const bool active = lane >= 1 && lane <= kWaveTile / kFsmChunk && c0 < rend;
-      FsmLane L;
-      LdsRows rows{&s_lrow[wave][lane * kFsmLaneRows]};
+      FsmLane L[2];
+      L[0].nrows = L[1].nrows = 0;
+      LdsRows rows[2] = {{&s_lrow[wave][(2 * lane) * kFsmLaneRows]}, {&s_lrow[wave][(2 * lane + 1) * kFsmLaneRows]}};
+      LdsEvents evs[2] = {{&s_lev[wave][SHALLOW ? 0 : (2 * lane) * kFsmLaneEvents]}, {&s_lev[wave][SHALLOW ? 0 : (2 * lane + 1) * kFsmLaneEvents]}};
       if (active) {
-        uint32_t entry = 0;
-        if (tile_lo + static_cast<uint64_t>(c0) > 0) entry = fsm_walk(v, m, v.top_row, c0 - kFsmChunk, c0, true);
-        if (entry >= v.n_t) { fallback |= 1u; entry = 0; }
-        fsm_replay(v, m, entry, c0, c1, rend, budget, L, rows);
-        fallback |= L.flags << 1;
+        const int32_t cc[2] = {c0, c0 + kFsmSub};
+        const bool whole = c0 + kFsmChunk <= rend && c0 + kFsmChunk <= budget;   // both sub-chunks are staged data
+        const bool second = cc[1] < rend;
+        // entry states: from "any state" over the 16 bytes in front of each sub-chunk; when a set has not collapsed by
+        // then, over 64 bytes (rare on text)
+        uint32_t entry[2] = {0u, 0u};
+        const bool at_origin = tile_lo + static_cast<uint64_t>(c0) == 0;
+        {
+          const int32_t from[2] = {at_origin ? cc[1] - 16 : cc[0] - 16, cc[1] - 16};     // (the haystack's first chunk starts in state 0)
+          if (!(CXG_FSM_ABL & 1)) fsm_walk_n<2>(v, m, v.top_off, from, 16, entry);
+          if (at_origin) entry[0] = 0u;
+          if (entry[0] >= v.u_lo) entry[0] = fsm_walk(v, m, v.top_off, cc[0] - 64, cc[0], true);
+          if (entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, v.top_off, at_origin ? 0 : cc[1] - 64, cc[1], true);
+          if (at_origin && entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, 0u, 0, cc[1], true);   // from the true start state
+        }
+        if (entry[0] >= v.u_lo || (second && entry[1] >= v.u_lo)) { fallback |= 1u; entry[0] = entry[1] = 0u; }
+        FSM_MARK(1);                                    // entry states
+        if (whole && SHALLOW) {
+          FsmTraceS t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
+          if (!(CXG_FSM_ABL & 2)) fsm_fast_shallow<2>(v, m, cc, t);
+          FSM_MARK(2);                                  // lockstep walk
+          fsm_finish_shallow(v, m, t[0], cc[0], rend, budget, L[0], rows[0]);
+          fsm_finish_shallow(v, m, t[1], cc[1], rend, budget, L[1], rows[1]);
+        } else if (whole) {
+          FsmTrace t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
+          fsm_fast<2>(v, m, cc, t, evs);
+          fsm_finish(v, m, entry[0], &t[0], cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
+          fsm_finish(v, m, entry[1], &t[1], cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
+        } else {                                       // the input ends inside this lane's bytes
+          fsm_finish(v, m, entry[0], static_cast<const FsmTrace*>(nullptr), cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
+          if (second) fsm_finish(v, m, entry[1], static_cast<const FsmTrace*>(nullptr), cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
+        }
+        fallback |= (L[0].flags | L[1].flags) << 1;
       }
+      FSM_MARK(3);                                      // rows of the lanes (+ divergence of the whole E/R block)
       // ---- S: rows in lane order, then their starts
-      const uint32_t nl = active ? L.nrows : 0u;
+      const uint32_t nl0 = (active && !(CXG_FSM_ABL & 4)) ? L[0].nrows : 0u, nl = nl0 + ((active && !(CXG_FSM_ABL & 4)) ? L[1].nrows : 0u);
       const uint32_t incl = wave_inclusive_sum(nl);
       tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
       const uint32_t first = nrows_w + incl - nl;
       for (uint32_t r = 0; r < nl; r++)
-        if (first + r < static_cast<uint32_t>(kFsmRowsPerWave)) s_re[wave][first + r] = rows.slot[r];
+        if (first + r < static_cast<uint32_t>(kFsmRowsPerWave)) s_re[wave][first + r] = r < nl0 ? rows[0].slot[r] : rows[1].slot[r - nl0];
       wave_lds_sync();
+      FSM_MARK(4);                                      // rows gathered
       if (a.out != nullptr || a.max_len != 0) {
         for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kFsmRowsPerWave); q += 64) {
           const int32_t e = s_re[wave][nrows_w + q];
-          const int32_t bound = q ? static_cast<int32_t>(s_re[wave][nrows_w + q - 1]) : lowest;   // first row of the tile: checked after the barrier
+          // first row of the tile: no bound known here (checked after the barrier); one byte below the window makes a
+          // reverse DFA that is still alive there report `over`
+          const int32_t bound = q ? static_cast<int32_t>(s_re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
           const int32_t s = fsm_match_start(v, m, e, bound, lowest, over);
-          const uint32_t len = (s == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - s);
-          if (over || len == 0u || len > 0xFFFFu) fallback |= 16u;
+          // over: the reverse DFA was still alive at the window's first byte and the haystack goes on in front of it
+          // (a match longer than the 64 bytes staged there): length 0 = unresolved, finished in the epilogue
+          const uint32_t len = (over || s == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - s);
+          if (s == kFsmNoStart && !over) fallback |= 64u;           // internal: the reverse DFA rejects a match the transducer reported
           s_rl[wave][nrows_w + q] = static_cast<uint16_t>(len);
         }
       }
     }
+    FSM_MARK(5);                                        // starts
     if (lane == 0) s_cnt[wave][j] = tot;
     nrows_w += tot;
   }
+#if CXG_FSM_PROF
+  if (a.prof && lane == 1) {                          // lane 1 takes every branch of an ordinary tile (lane 0 only stages)
+    for (int i = 0; i < 7; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 8 + i), static_cast<unsigned long long>(pacc[i]));
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 15), 1ull);
+  }
+#endif
   if (nrows_w > static_cast<uint32_t>(kFsmRowsPerWave)) fallback |= 32u;
   {
     uint32_t f = fallback;                                                   // per-lane reasons -> one atomic per wave
@@ -217,19 +304,24 @@ __global__ __launch_bounds__(kThreads) void k_scan_fsm(ScanArgs a) {
       const uint32_t r = start + i;
       if (r >= static_cast<uint32_t>(kFsmRowsPerWave)) continue;
       int64_t e = tb + s_re[wave][r], s = e - s_rl[wave][r];
-      if (i == 0 && (a.out != nullptr || a.max_len != 0)) {                 // the tile's first row was walked without a bound
+      if ((i == 0 || s == e) && (a.out != nullptr || a.max_len != 0)) {
+        // the tile's first row was walked without a bound (its predecessor is another wave's row); an unresolved row
+        // (s == e) left the window.  Previous end: inside the tile, else the nearest earlier tile of the group with rows;
+        // the group's first row is checked by k_fsm_fix_heads.
         int64_t prev = -1;
-        for (int p = q - 1; p >= 0 && prev < 0; p--) prev = s_tail[p];
-        if (prev > s) {                                                     // it reached into the previous match: walk again, bounded (rare)
-          GlobalMem gm{a.hay};
-          uint32_t sr = v.rev_start;
+        if (i > 0) prev = tb + s_re[wave][r - 1];
+        else for (int p = q - 1; p >= 0 && prev < 0; p--) prev = s_tail[p];
+        if (prev > s || s == e) {                                           // rare: walk again from HBM / L2, bounded
+          const int64_t lo = prev > 0 ? prev : 0;
+          uint32_t sr = v.rev_start_off;
           int64_t st = -1;
-          for (int64_t at = e - 1; at >= prev; at--) {
-            sr = v.rev[sr * v.ncls + v.cls[gm.byte(at)]];
+          for (int64_t at = e - 1; at >= lo; at--) {
+            if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
+            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]]);
             if (sr == 0u) break;
-            if (sr >= v.rev_first_accept) st = at;
+            if (sr >= v.rev_accept_off) st = at;
           }
-          if (st < 0) raise_err(a.err, 8u | (16u << 8)); else s = st;
+          if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s = st;
         }
       }
       if (a.max_len != 0 && static_cast<uint64_t>(e - s) > a.max_len) long_hit = 1;
@@ -255,22 +347,36 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   const int64_t prev = a.out[(k - 1) * a.row_width + 1] - a.base, s0 = row[0] - a.base, e = row[1] - a.base;
   if (s0 >= prev) return;
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
-  const uint8_t* cls = a.blob + h->cls_off;
+  const uint8_t* cls2 = a.blob + h->cls_off;
   const uint8_t* rev = a.blob + h->rev_off;
-  uint32_t sr = h->rev_start;
+  uint32_t sr = h->rev_start_off;
   int64_t st = -1;
   for (int64_t at = e - 1; at >= prev; at--) {
-    sr = rev[sr * h->ncls + cls[a.hay[at]]];
+    sr = fsm_u16(rev, sr + cls2[a.hay[at]]);
     if (sr == 0u) break;
-    if (sr >= h->rev_first_accept) st = at;
+    if (sr >= h->rev_accept_off) st = at;
   }
-  if (st < 0) { raise_err(a.err, 8u | (16u << 8)); return; }
+  if (st < 0) { raise_err(a.err, 8u | (64u << 8)); return; }
   row[0] = a.base + st;
 }
 
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, hipStream_t stream) {
+namespace {
+template <int IMG>
+void launch_fsm_img(const ScanArgs& a, bool shallow, bool dense, dim3 grid, dim3 block, hipStream_t stream) {
+  if (shallow && !dense) hipLaunchKernelGGL((k_scan_fsm<true, IMG, kTilesPerWave>), grid, block, 0, stream, a);
+  else if (shallow) hipLaunchKernelGGL((k_scan_fsm<true, IMG, kDenseTilesPerWave>), grid, block, 0, stream, a);
+  else if (!dense) hipLaunchKernelGGL((k_scan_fsm<false, IMG, kTilesPerWave>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((k_scan_fsm<false, IMG, kDenseTilesPerWave>), grid, block, 0, stream, a);
+}
+}  // namespace
+
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  hipLaunchKernelGGL(k_scan_fsm, grid, block, lds_bytes, stream, a);
+  const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
+  if (lds_bytes <= 3072) launch_fsm_img<3072>(a, shallow, dense, grid, block, stream);          // instantiations by image size: LDS per
+  else if (lds_bytes <= 10240) launch_fsm_img<10240>(a, shallow, dense, grid, block, stream);   // workgroup 33 / 40 / 58 KB
+  else if (lds_bytes <= 28672) launch_fsm_img<28672>(a, shallow, dense, grid, block, stream);
+  else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.out == nullptr || a.ngroups < 2) return e;
   const unsigned fb = 256, fg = static_cast<unsigned>((a.ngroups + fb - 1) / fb);

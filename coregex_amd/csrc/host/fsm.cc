@@ -94,9 +94,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   std::map<std::vector<uint32_t>, uint32_t> ids;
   std::vector<std::vector<uint32_t>> keys;
   std::vector<uint8_t> levels;                    // pending levels of a state
-  std::vector<std::vector<uint16_t>> trans;       // [state][class] next | event << 8
-  std::vector<uint16_t> events{0};                // descriptor table; id 0 = none
-  std::map<uint16_t, uint32_t> eventId;
+  std::vector<std::vector<uint32_t>> trans;       // [state][class] next | event descriptor << 16
   uint32_t depth = 0;
   bool tooBig = false;
   auto intern = [&](const std::vector<std::vector<uint32_t>>& stack) -> uint32_t {
@@ -113,15 +111,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     trans.emplace_back(ncls, 0);
     return id;
   };
-  auto eventOf = [&](uint32_t kind, uint32_t j, bool conts, uint32_t died) -> uint32_t {
-    const uint16_t d = static_cast<uint16_t>(kind | (j << 2) | (conts ? 32u : 0u) | (died << 8));
-    if (d == 0) return 0;
-    auto it = eventId.find(d);
-    if (it != eventId.end()) return it->second;
-    if (events.size() >= 255) { tooBig = true; return 0; }
-    events.push_back(d);
-    eventId.emplace(d, static_cast<uint32_t>(events.size() - 1));
-    return static_cast<uint32_t>(events.size() - 1);
+  auto eventOf = [&](uint32_t kind, uint32_t j, bool conts, uint32_t died) -> uint32_t {   // descriptor, 0 = nothing happened
+    return kind | (j << 2) | (conts ? 32u : 0u) | (died << 8);
   };
   intern({fresh});
   for (uint32_t cur = 0; cur < keys.size() && !tooBig; cur++) {
@@ -168,7 +159,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
         }
       }
       const uint32_t to = intern(next);
-      trans[cur][c] = static_cast<uint16_t>(to | (ev << 8));
+      trans[cur][c] = to | (ev << 16);
     }
   }
   if (tooBig) { why = "FindAll transducer exceeds the table budget (states, pending levels or events)"; return false; }
@@ -179,7 +170,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   std::vector<std::vector<uint8_t>> sets;
   std::vector<std::vector<uint16_t>> utrans;
   bool wideUsed = false;
-  const uint32_t rowBudget = cxgdev::kFsmMaxRows - 1;          // one id kept for the wide row
+  const uint32_t rowBudget = 512;                              // sets tabulated at most; the rest maps to the wide row
   {
     std::vector<uint8_t> top(nT);
     for (uint32_t i = 0; i < nT; i++) top[i] = static_cast<uint8_t>(i);
@@ -191,12 +182,12 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     utrans.emplace_back(ncls, 0);
     for (uint32_t c = 0; c < ncls; c++) {
       std::set<uint8_t> img;
-      for (uint8_t s : sets[cur]) img.insert(static_cast<uint8_t>(trans[s][c] & 0xFFu));
+      for (uint8_t s : sets[cur]) img.insert(static_cast<uint8_t>(trans[s][c] & 0xFFFFu));
       if (img.size() == 1) { utrans[cur][c] = *img.begin(); continue; }
       std::vector<uint8_t> v(img.begin(), img.end());
       auto it = setId.find(v);
       if (it == setId.end()) {
-        if (nT + sets.size() >= rowBudget) { utrans[cur][c] = kWideMark; wideUsed = true; continue; }
+        if (sets.size() >= rowBudget || (nT + sets.size() + 64) * (ncls + 2) * 2 > cxgdev::kFsmMaxTableBytes) { utrans[cur][c] = kWideMark; wideUsed = true; continue; }
         it = setId.emplace(v, static_cast<uint32_t>(sets.size())).first;
         sets.push_back(v);
       }
@@ -204,19 +195,42 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     }
   }
   const uint32_t nU = static_cast<uint32_t>(sets.size());
-  const uint32_t wideRow = nT + nU;
-  const uint32_t nRows = nT + nU + 1;                          // the wide row always exists (simplifies the kernel)
   (void)wideUsed;
-  if (nRows > cxgdev::kFsmMaxRows + 1u) { why = "FindAll transducer exceeds 255 table rows"; return false; }
-  const uint32_t stride = ncls | 1u;
-  if (static_cast<size_t>(nRows) * stride * 2 > cxgdev::kFsmMaxTableBytes) { why = "FindAll transducer table exceeds the LDS budget"; return false; }
-  if (rev.nstates == 0 || rev.nstates > 255) { why = "reverse DFA missing"; return false; }
+  // alias rows: one per distinct (target state, event) pair
+  std::map<uint32_t, uint32_t> aliasOf;                        // to | ev << 16 -> alias index
+  std::vector<uint32_t> aliases;
+  for (uint32_t s = 0; s < nT; s++)
+    for (uint32_t c = 0; c < ncls; c++)
+      if (trans[s][c] >> 16) { if (aliasOf.emplace(trans[s][c], static_cast<uint32_t>(aliases.size())).second) aliases.push_back(trans[s][c]); }
+  // ordered by event kind (died only, create, rematch): shallow machines read the kind off the row's position
+  std::stable_sort(aliases.begin(), aliases.end(), [](uint32_t a, uint32_t b) { return ((a >> 16) & 3u) < ((b >> 16) & 3u); });
+  for (size_t i = 0; i < aliases.size(); i++) aliasOf[aliases[i]] = static_cast<uint32_t>(i);
+  const uint32_t nA = static_cast<uint32_t>(aliases.size());
+  uint32_t nDied = 0, nCreate = 0;
+  for (uint32_t a : aliases) { if (((a >> 16) & 3u) == cxgdev::kFsmEvDied) nDied++; else if (((a >> 16) & 3u) == cxgdev::kFsmEvCreate) nCreate++; }
+  // rows are a power of two long: a walk step is then  x = tab[(entry & ~3) | 2 * class]  — one v_and_or on the chain —
+  // and the two low bits of an entry are free for the event flags of shallow machines (fsm.hpp)
+  uint32_t rowBytes = 16;
+  while (rowBytes < (ncls + 2) * 2) rowBytes *= 2;
+  const uint32_t stride = rowBytes / 2;
+  const uint32_t nRows = nT + nA + nU + 1;
+  if (static_cast<size_t>(nRows) * rowBytes > cxgdev::kFsmMaxTableBytes) { why = "FindAll transducer table exceeds the LDS budget"; return false; }
+  if (rev.nstates == 0 || static_cast<size_t>(rev.nstates) * ncls * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
+  auto offT = [&](uint32_t s) { return s * rowBytes; };
+  auto offA = [&](uint32_t a) { return (nT + a) * rowBytes; };
+  auto offU = [&](uint32_t u) { return (nT + nA + u) * rowBytes; };
+  const uint32_t wideOff = (nT + nA + nU) * rowBytes;
+  auto target = [&](uint32_t t) -> uint16_t {      // row offset | create flag | rematch flag << 1
+    if (!(t >> 16)) return static_cast<uint16_t>(offT(t & 0xFFFFu));
+    const uint32_t kind = (t >> 16) & 3u;
+    return static_cast<uint16_t>(offA(aliasOf[t]) | (kind == cxgdev::kFsmEvCreate ? 1u : 0u) | (kind == cxgdev::kFsmEvRematch ? 2u : 0u));
+  };
 
-  // ---- image
   cxgdev::FsmHeader h;
   std::memset(&h, 0, sizeof h);
-  h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_rows = nRows; h.ncls = ncls; h.top_row = nT; h.wide_row = wideRow;
-  h.n_events = static_cast<uint32_t>(events.size()); h.depth = depth; h.stride = stride; h.max_len = max_len;
+  h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_a = nA; h.n_u = nU; h.ncls = ncls; h.stride = stride; h.row_bytes = rowBytes; h.depth = depth;
+  h.alias_lo = offA(0); h.u_lo = offU(0); h.top_off = offU(0); h.wide_off = wideOff; h.max_len = max_len;
+  h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate);
   std::vector<uint8_t> img(sizeof h, 0);
   auto put = [&](const void* d, size_t n, uint32_t& off) {
     while (img.size() % 16) img.push_back(0);
@@ -224,36 +238,48 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     const uint8_t* q = static_cast<const uint8_t*>(d);
     img.insert(img.end(), q, q + n);
   };
-  put(cls, 256, h.cls_off);
+  uint8_t cls2[256];
+  for (int b = 0; b < 256; b++) cls2[b] = static_cast<uint8_t>(2 * cls[b]);
   std::vector<uint16_t> tab(static_cast<size_t>(nRows) * stride, 0);
-  for (uint32_t s = 0; s < nT; s++) for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(s) * stride + c] = trans[s][c];
+  for (uint32_t s = 0; s < nT; s++) {
+    for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(s) * stride + c] = target(trans[s][c]);
+    tab[static_cast<size_t>(s) * stride + ncls + 1] = levels[s];
+  }
+  for (uint32_t a = 0; a < nA; a++) {
+    const uint32_t to = aliases[a] & 0xFFFFu;
+    for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(nT + a) * stride + c] = target(trans[to][c]);
+    tab[static_cast<size_t>(nT + a) * stride + ncls] = static_cast<uint16_t>(aliases[a] >> 16);
+    tab[static_cast<size_t>(nT + a) * stride + ncls + 1] = levels[to];
+  }
   for (uint32_t u = 0; u < nU; u++)
     for (uint32_t c = 0; c < ncls; c++) {
       const uint16_t t = utrans[u][c];
-      tab[static_cast<size_t>(nT + u) * stride + c] = static_cast<uint16_t>(t == kWideMark ? wideRow : (t >= kSetBase ? nT + (t - kSetBase) : t));
+      tab[static_cast<size_t>(nT + nA + u) * stride + c] = static_cast<uint16_t>(t == kWideMark ? wideOff : (t >= kSetBase ? offU(t - kSetBase) : offT(t)));
     }
-  for (uint32_t c = 0; c < stride; c++) tab[static_cast<size_t>(wideRow) * stride + c] = static_cast<uint16_t>(wideRow);
+  for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(nT + nA + nU) * stride + c] = static_cast<uint16_t>(wideOff);
   put(tab.data(), tab.size() * 2, h.tab_off);
-  put(events.data(), events.size() * 2, h.ev_off);
-  put(levels.data(), levels.size(), h.lev_off);
-  std::vector<uint8_t> mem(static_cast<size_t>(nRows) * cxgdev::kFsmMembers, 0xFF);
-  for (uint32_t s = 0; s < nT; s++) mem[static_cast<size_t>(s) * cxgdev::kFsmMembers] = static_cast<uint8_t>(s);
+  if (h.tab_off != sizeof h) { why = "internal: image layout (scan_fsm.hip expects the transition table first)"; return false; }
+  put(cls2, 256, h.cls_off);
+  std::vector<uint8_t> mem(static_cast<size_t>(nU + 1) * cxgdev::kFsmMembers, 0xFF);
   for (uint32_t u = 0; u < nU; u++)
     if (sets[u].size() <= static_cast<size_t>(cxgdev::kFsmMembers))
-      for (size_t k = 0; k < sets[u].size(); k++) mem[static_cast<size_t>(nT + u) * cxgdev::kFsmMembers + k] = sets[u][k];
+      for (size_t k = 0; k < sets[u].size(); k++) mem[static_cast<size_t>(u) * cxgdev::kFsmMembers + k] = sets[u][k];
   put(mem.data(), mem.size(), h.mem_off);
-  // reverse DFA, class-compressed: the classes come from the same NFA ranges, so a class never straddles a reverse transition
-  std::vector<uint8_t> rv(static_cast<size_t>(rev.nstates) * ncls, 0);
+  // reverse DFA, class-compressed, entries = byte offset of the target row; the classes come from the same NFA ranges,
+  // so a class never straddles a reverse transition
+  const uint32_t revRow = ncls * 2;
+  std::vector<uint16_t> rv(static_cast<size_t>(rev.nstates) * ncls, 0);
   for (uint32_t s = 0; s < rev.nstates; s++)
-    for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = rev.table[static_cast<size_t>(s) * 256 + reps[c]];
+    for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rev.table[static_cast<size_t>(s) * 256 + reps[c]] * revRow);
   for (uint32_t s = 0; s < rev.nstates; s++)
     for (int b = 0; b < 256; b++)
-      if (rev.table[static_cast<size_t>(s) * 256 + b] != rv[static_cast<size_t>(s) * ncls + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
-  put(rv.data(), rv.size(), h.rev_off);
-  h.rev_states = rev.nstates; h.rev_start = rev.start; h.rev_first_accept = rev.firstAccept;
+      if (rev.table[static_cast<size_t>(s) * 256 + b] * revRow != rv[static_cast<size_t>(s) * ncls + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
+  put(rv.data(), rv.size() * 2, h.rev_off);
+  h.rev_states = rev.nstates; h.rev_start_off = rev.start * revRow; h.rev_accept_off = rev.firstAccept * revRow; h.rev_row_bytes = revRow;
   while (img.size() % 16) img.push_back(0);
   h.total_bytes = static_cast<uint32_t>(img.size());
   h.lds_bytes = h.total_bytes - static_cast<uint32_t>(sizeof h);
+  if (h.lds_bytes > 28672) { why = "FindAll transducer image exceeds the LDS budget"; return false; }
   std::memcpy(img.data(), &h, sizeof h);
   image.swap(img);
   return true;

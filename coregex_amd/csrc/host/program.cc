@@ -680,7 +680,18 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     // table-walking kernel.  Programs that already are complete ordered chains / plain literals get the image too: it is
     // their fallback for match-dense or synchronisation-free input.
     {
-      const bool plainOrder = h.kind == cxgdev::kKindBidir || (h.flags & cxgdev::kFlagFastDigit) || !(flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE);
+      // Run skip (find_indices.go:1079-1084) leaves plain leftmost-first order untouched exactly when it is SOUND: the
+      // anchored DFA goes from its start to one state on every digit and stays there on every digit, so a candidate
+      // anywhere inside a digit run fails or succeeds with the run's first position.  The reference also sets the flag
+      // for leads like `[0-5]+` (a quirk that loses matches: "61x" for `[0-5]+x`); those keep the table-walking kernel.
+      bool skipSound = false;
+      if (h.kind == cxgdev::kKindDigit && (flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE)) {
+        const uint32_t s1 = p->fwd.table[static_cast<size_t>(p->fwd.start) * 256 + '0'];
+        skipSound = s1 != 0;
+        for (int b = '0'; b <= '9' && skipSound; b++)
+          skipSound = p->fwd.table[static_cast<size_t>(p->fwd.start) * 256 + b] == s1 && p->fwd.table[static_cast<size_t>(s1) * 256 + b] == s1;
+      }
+      const bool plainOrder = h.kind == cxgdev::kKindBidir || skipSound || !(flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE);
       if (plainOrder && nfa.start_unanchored != nfa.start_anchored) {
         try {
           Dfa rv = p->rev;

@@ -32,7 +32,7 @@ def main(n=300, seed=1):
         hays += [alphabet[rng.integers(0, 6, size=700)], alphabet[rng.integers(0, 3, size=500)],
                  np.frombuffer(b"1.2.3.4.5.6.7.8.9 " * 30, dtype=np.uint8), np.frombuffer(b"abcabcabxyzxyz" * 40, dtype=np.uint8)]
         for hay in hays:
-            for tile, chunk in ((3840, 64), (64, 8), (32, 4), (256, 16)):
+            for tile, chunk in ((3840, 32), (64, 8), (32, 4), (256, 16), (128, 32)):
                 for which, image in (("idx", img), ("sub", simg)):
                     if image is None: continue
                     exp = o.find_all_index(hay) if which == "idx" else o.find_all_submatch_index(hay)[:, :2]

@@ -137,7 +137,7 @@ def find_all_charclass_wave(blob: bytes, hay, tile: int = 3840, halo: int = 256)
     return _wave_twin("emu_find_all_charclass_wave", blob, hay, tile, halo)
 
 
-def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 64, budget: int = 57344, stats=None):
+def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: int = 192, stats=None):
     """scan_fsm.hip (FindAll transducer), emulated; the int reason (< 0) when a tile would raise the fallback flag."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])

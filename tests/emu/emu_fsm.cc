@@ -22,16 +22,21 @@ struct LaneRows {
   int32_t end[kFsmLaneRows];
   void set_end(uint32_t r, int32_t e) { end[r] = e; }
 };
+struct LaneEvents {
+  uint16_t row[kFsmLaneEvents];
+  void push(uint32_t k, uint32_t r) { row[k] = static_cast<uint16_t>(r); }
+  uint32_t row_at(uint32_t k) const { return row[k]; }
+};
 FsmView view_of(const uint8_t* img) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   FsmView v;
-  v.cls = img + h->cls_off;
-  v.tab = reinterpret_cast<const uint16_t*>(img + h->tab_off);
-  v.ev = reinterpret_cast<const uint16_t*>(img + h->ev_off);
-  v.lev = img + h->lev_off;
+  v.cls2 = img + h->cls_off;
+  v.tab = img + h->tab_off;
   v.rev = img + h->rev_off;
-  v.stride = h->stride; v.n_t = h->n_t; v.top_row = h->top_row; v.ncls = h->ncls;
-  v.rev_start = h->rev_start; v.rev_first_accept = h->rev_first_accept;
+  v.ncls2 = 2 * h->ncls;
+  v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
+  v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   return v;
 }
 }  // namespace
@@ -64,13 +69,24 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
       st[0]++;
       uint32_t entry = 0;
       if (tile_lo + static_cast<uint64_t>(c0) > 0) {
-        entry = fsm_walk(v, m, v.top_row, c0 - chunk, c0, true);
-        st[1]++;
-        if (entry >= v.n_t) return -16 - 1;
+        // the kernel's policy: 16 bytes first, 64 bytes when the set has not collapsed by then
+        const int64_t avail = static_cast<int64_t>(tile_lo) + c0;
+        const int32_t w1 = static_cast<int32_t>(avail < 16 ? avail : 16), w2 = static_cast<int32_t>(avail < 64 ? avail : 64);
+        entry = fsm_walk(v, m, v.top_off, c0 - w1, c0, (w1 % 4) == 0);
+        if (entry >= v.u_lo && w2 > w1) { entry = fsm_walk(v, m, v.top_off, c0 - w2, c0, (w2 % 4) == 0); st[1]++; }
+        if (entry >= v.u_lo) return -16 - 1;
       }
       FsmLane L;
       LaneRows rows;
-      fsm_replay(v, m, entry, c0, c1, rend, budget, L, rows);
+      LaneEvents evs;
+      if (h->depth <= 1 && chunk == kFsmSub && c1 <= rend && c1 <= budget) {   // the kernel's SHALLOW instantiation
+        const int32_t cc[1] = {c0};
+        FsmTraceS ts[1] = {{entry, 0u, 0u}};
+        fsm_fast_shallow<1>(v, m, cc, ts);
+        fsm_finish_shallow(v, m, ts[0], c0, rend, budget, L, rows);
+      } else {
+        fsm_replay(v, m, entry, c0, c1, rend, budget, L, rows, evs);
+      }
       if (L.flags) return -16 - static_cast<int64_t>(L.flags << 1);
       for (uint32_t r = 0; r < L.nrows; r++) {
         const int32_t e = rows.end[r];

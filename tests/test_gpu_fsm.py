@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 K_FSM = 10
 README_IP = r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"
 GENERAL = [README_IP, COMPAT_PATTERNS["la_peak_hours"], r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|foo)\d*",
-           r"[1-9][0-9]*|0", r"a(b*c)?", r"x[ab]+?y", r"[a-f0-9]{8}-[a-f0-9]{4}", r"ab|abc", r"GET|POST /[a-z]+", r"\d+(\.\d+)?%"]
+           r"[1-9][0-9]*|0", r"a(b*c)?", r"x[ab]+?y", r"[a-f0-9]{8}-[a-f0-9]{4}", r"ab|abc", r"GET|POST /[a-z]+", r"[a-c]x|[b-d]y"]
+
+
+FSM_EXPECTED = {README_IP, COMPAT_PATTERNS["la_peak_hours"], r"\d+\.\d+x?", r"a+b|b+a", r"[a-c]x|[b-d]y"}
 
 
 def _device_rows(rx, hay, sub=False):
@@ -46,7 +49,11 @@ def test_general_dfas_run_on_the_transducer_kernel(oracle, pat):
         assert rx.count(hay) == len(exp)
     rows, t = _device_rows(rx, hays[1])
     assert np.array_equal(rows, o.find_all_index(hays[1]))
-    assert t.kernel == K_FSM and t.n_launches == 1, (pat, t.kernel, t.n_launches, t.fallback_reason)
+    # one launch of the transducer kernel for the programs that have no faster kernel and whose matches are not denser
+    # than a chunk's row / event buffers on this corpus (every number or every 'a' of a log line is too dense: those
+    # hand over to the table-walking kernel — same rows, checked above)
+    if pat in FSM_EXPECTED:
+        assert t.kernel == K_FSM and t.n_launches == 1, (pat, t.kernel, t.n_launches, t.fallback_reason)
 
 
 def test_transducer_kernel_edges(oracle):
@@ -73,15 +80,29 @@ def test_transducer_kernel_edges(oracle):
         tail[max(0, n - 4):] = np.frombuffer(b"a12b", dtype=np.uint8)[-min(4, n):]
         assert np.array_equal(rx.find_all_index(tail), o.find_all_index(tail)), n
     # a second match found by a search that started inside the unbounded reverse walk of the first row of a tile:
-    # `ab|b+` on "...abb": [.., ab] then [b]; the reverse DFA from the second end accepts "bb" — the bound must cut it
-    pat2 = r"ab|b+"
+    # `ax|x?b+` on "...axbb": [.., ax] then [bb]; the reverse DFA from the second end accepts "xbb" — the bound must cut it
+    pat2 = r"ax|x?b+"
     rx2, o2 = cx.compile(pat2), oracle.Regex(pat2)
-    for off in (3838, 3839, 3840, group - 2, group - 1, group):
+    assert rx2.supported and rx2.fsm_image() is not None
+    for off in (3837, 3838, 3839, 3840, 3841, group - 3, group - 2, group - 1, group, group + 1):
         hay = base.copy()
-        hay[off - 1:off + 2] = np.frombuffer(b"abb", dtype=np.uint8)
+        hay[off - 1:off + 3] = np.frombuffer(b"axbb", dtype=np.uint8)
         exp = o2.find_all_index(hay)
+        assert len(exp) == 2 and exp[1][0] == exp[0][1]
         rows, t = _device_rows(rx2, hay)
-        assert np.array_equal(rows, exp), (off, rows.tolist(), exp.tolist())
+        assert np.array_equal(rows, exp) and t.kernel == K_FSM, (off, rows.tolist(), exp.tolist())
+    # matches longer than the 64 bytes staged in front of a tile / the 192 bytes behind it: the start is finished in the
+    # epilogue from HBM, a walk past the window's end hands the scan over — the oracle's rows either way
+    long1 = np.frombuffer(b"a" + b"7" * 150 + b"b", dtype=np.uint8)
+    long2 = np.frombuffer(b"a" + b"7" * 700 + b"b", dtype=np.uint8)
+    for lit in (long1, long2):
+        for off in (3840 - 100, 3840 - 10, 3840 - 200, group - 100, group - 500, 100):
+            hay = base.copy()
+            hay[off:off + len(lit)] = lit
+            exp = o.find_all_index(hay)
+            assert len(exp) == 1
+            rows, t = _device_rows(rx, hay)
+            assert np.array_equal(rows, exp), (len(lit), off, rows.tolist(), exp.tolist())
 
 
 def test_captures_take_their_spans_from_the_transducer_kernel(oracle):
