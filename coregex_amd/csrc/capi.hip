@@ -132,7 +132,7 @@ int ensureStatus(Scratch& s, uint64_t ntiles) {
   if (s.ctl) HIP_TRY(hipFree(s.ctl));
   s.ctl = nullptr; s.status = nullptr; s.statusCap = 0;
   uint64_t cap = ntiles + ntiles / 4 + 1024;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + cap * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + 2 * cap * sizeof(uint64_t)));   // look-back words, then the exit-state words of scan_fsm.hip
   s.status = reinterpret_cast<uint64_t*>(s.ctl + 64);
   s.statusCap = cap;
   s.needZero = true;
@@ -324,6 +324,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
   if (int rc = ensureStatus(s, a.ntiles)) return rc;
   a.status = s.status;
+  a.status2 = s.status + s.statusCap;
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
@@ -363,6 +364,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
+  int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
   std::memset(a.caps, 0, sizeof a.caps);
@@ -372,8 +374,8 @@ relaunch:
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if ((gen == 6 || gen == 7 || gen == 9 || gen == 10) && denseChain) {   // four times the row-buffer room per wave-tile
-    a.tiles_per_wave = cxgdev::kDenseTilesPerWave;
-    const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * cxgdev::kDenseTilesPerWave;
+    a.tiles_per_wave = (gen == 10 && fsmMode == 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, mode 2: one tile, 2048 rows
+    const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * a.tiles_per_wave;
     a.ngroups = (len + gb - 1) / gb;
   }
   // Wave kernels with static groups tag their look-back words with a launch epoch and clear the next launch's error
@@ -386,7 +388,7 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
-      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + s.statusCap * sizeof(uint64_t), stream));
+      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
       s.epoch = 0; s.needZero = false;
     }
     a.epoch = ++s.epoch;
@@ -398,6 +400,7 @@ relaunch:
   } else {
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
+    if (gen == 10) HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
@@ -509,10 +512,13 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
-    if (gen == 10 && (err >> 8) == 0x20u && !denseChain) {           // transducer kernel: only the row buffers overflowed
-      if (verbose) fprintf(stderr, "[cxg] transducer kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
+    if (gen == 10 && ((err >> 8) & ~0x32u) == 0u && fsmMode < 2) {    // transducer kernel: only row / event buffers overflowed
+      // 0x20 alone: the wave's row list -> mode 1 (2 tiles per wave); a sub-chunk's own buffers (0x02 rows, 0x10 events), or
+      // mode 1 was not enough -> mode 2 (1 tile, 2048 rows, 16 rows / 32 events per 32 bytes)
+      fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : 2;
+      if (verbose) fprintf(stderr, "[cxg] transducer kernel: match-dense input (reason bits 0x%x), rerunning in mode %d\n", err >> 8, fsmMode);
       denseChain = true;
-      p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      p->denseChain[submatch ? 1 : 0].store(static_cast<uint8_t>(fsmMode), std::memory_order_relaxed);
       relaunches++;
       goto relaunch;
     }

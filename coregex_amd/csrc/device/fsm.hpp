@@ -41,10 +41,11 @@
 
 namespace cxgdev {
 
-constexpr uint32_t kFsmMagic = 0x43584734u;   // "CXG4"
+constexpr uint32_t kFsmMagic = 0x43584735u;   // "CXG5"
 constexpr int kFsmMaxLevels = 7;              // pending searches alive at once (4-bit refs in one dword)
-constexpr int kFsmLaneRows = 4;               // rows buffered per 32-byte chunk (denser input: fallback flag)
-constexpr int kFsmLaneEvents = 8;             // events recorded inside a 32-byte chunk before they are applied (power of two)
+constexpr int kFsmLaneRows = 4;               // rows buffered per 32-byte chunk (denser input: fallback flag) ...
+constexpr int kFsmLaneEvents = 8;             // events recorded inside a 32-byte chunk before they are applied (power of two) ...
+constexpr int kFsmLaneRowsMax = 16, kFsmLaneEventsMax = 32;   // ... in the kernel's mode for very dense matches (one per 2 bytes)
 constexpr int kFsmChunk = 64;                 // bytes per lane (two sub-chunks of kFsmSub bytes, walked in lockstep)
 constexpr uint32_t kFsmMaxTableBytes = 24u * 1024u;
 constexpr int kFsmMembers = 8;                // members listed per uncertainty row (more: the row counts as wide)
@@ -56,7 +57,8 @@ constexpr int kFsmMembers = 8;                // members listed per uncertainty 
 constexpr uint32_t kFsmEvDied = 0, kFsmEvCreate = 1, kFsmEvRematch = 2;
 
 // Table.  A row is `stride` u16 (a power of two): [0, ncls) the transitions, [ncls] the event descriptor of an ALIAS
-// row, [ncls + 1] the number of pending levels of the row's state.  A transition holds the BYTE OFFSET of the target
+// row, [ncls + 1] the number of pending levels of the row's state, [ncls + 2] the row of the state itself (an alias
+// row names the state it copies).  A transition holds the BYTE OFFSET of the target
 // row (a multiple of the row size >= 16) plus two flag bits: bit 0 the step CREATES a match, bit 1 it REMATCHES one.
 // The dependent chain of a walk is one LDS read and one v_and_or:  x = tab[(x & ~3) | 2 * class].  Row order:
 //   [0, n_t)           the transducer states;
@@ -69,10 +71,10 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t magic, n_t, n_a, n_u;
   uint32_t ncls, stride, row_bytes, depth;
   uint32_t alias_lo, u_lo, top_off, wide_off;      // byte offsets of the first alias row, the first set row, "any state", wide
-  uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u8[n_u + 1][8] member state ids, 0xFF pad
+  uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u16[n_u + 1][8] rows of a set's members, 0xFFFF pad / not listed
   uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][ncls] target row byte offsets, row 0 dead; accepting rows >= rev_accept_off
   uint32_t total_bytes, lds_bytes, max_len, pad0;
-  uint32_t create_lo, rematch_lo, pad1, pad2;      // alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
+  uint32_t create_lo, rematch_lo, row_shift, pad2; // row_bytes == 1 << row_shift; alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
                                                    // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch
 };
 
@@ -83,7 +85,14 @@ struct FsmView {
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
   uint32_t alias_lo, u_lo, top_off, rev_start_off, rev_accept_off;
   uint32_t create_lo, rematch_lo;
+  const uint8_t* mem;       // members of the set rows
+  uint32_t row_shift;
 };
+// the state's own row (an alias row is a copy of it)
+CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off);
+CXG_FSM_HD uint32_t fsm_canon(const FsmView& v, uint32_t x) { return fsm_u16(v.tab, x + v.ncls2 + 4u); }
+// member j (0..7) of the set row u, as a row offset; 0xFFFF: none / the set is not listed
+CXG_FSM_HD uint32_t fsm_member(const FsmView& v, uint32_t u, uint32_t j) { return fsm_u16(v.mem, (((u - v.u_lo) >> v.row_shift) * 8u + j) * 2u); }
 CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
 // one step: entry t (row offset | flags) and 2 * class -> next entry
 CXG_FSM_HD uint32_t fsm_next(const FsmView& v, uint32_t t, uint32_t cls2) { return fsm_u16(v.tab, (t & ~3u) | cls2); }
@@ -151,9 +160,11 @@ CXG_FSM_HD void fsm_walk_n(const FsmView& v, const Mem& m, uint32_t x0, const in
 struct FsmLane {
   uint32_t x = 0;        // current row (byte offset)
   uint32_t nlev = 0;     // live pending levels
-  uint32_t lev = 0;      // 4 bits per level, outermost first: 0 created beyond the chunk, 1 alive at entry (foreign), 2 + r own row r
+  uint64_t lev = 0;      // 8 bits per level, outermost first: 0 created beyond the chunk, 1 alive at entry (foreign), 2 + r own row r
   uint32_t nrows = 0;    // own rows so far
   uint32_t flags = 0;    // 1: more than kFsmLaneRows rows, 2: level stack overflow, 4: walk budget exhausted, 8: more than kFsmLaneEvents events
+  uint32_t xc1 = 0;      // row at the chunk's end (or at the end of input inside it): the next chunk's true entry state
+  uint32_t max_rows = kFsmLaneRows, max_events = kFsmLaneEvents;   // buffer sizes of the caller (set before a replay)
 };
 
 // Rows concept: void set_end(uint32_t r, int32_t e).
@@ -161,28 +172,29 @@ template <class Rows>
 CXG_FSM_HD void fsm_apply(FsmLane& L, uint32_t ev, int32_t e, bool in_chunk, Rows& rows) {
   const uint32_t kind = ev & 3u, j = (ev >> 2) & 7u, conts = (ev >> 5) & 1u, died = ev >> 8;
   const uint32_t keep_n = kind == kFsmEvRematch ? j : L.nlev;   // levels that survive unless they died
-  uint32_t nl = 0, nn = 0;
+  uint64_t nl = 0;
+  uint32_t nn = 0;
   for (uint32_t q = 0; q < keep_n; q++) {
     if ((died >> q) & 1u) continue;
-    nl |= ((L.lev >> (4u * q)) & 15u) << (4u * nn);
+    nl |= ((L.lev >> (8u * q)) & 255ull) << (8u * nn);
     nn++;
   }
-  uint32_t ref = 0xFFu;                                         // level to push, if any
+  uint32_t ref = 0xFFFFu;                                       // level to push, if any
   if (kind == kFsmEvRematch) {
-    ref = (L.lev >> (4u * j)) & 15u;
+    ref = static_cast<uint32_t>((L.lev >> (8u * j)) & 255ull);
     if (ref >= 2u) { L.nrows = ref - 1u; rows.set_end(ref - 2u, e); }   // its row keeps its place, later rows are gone
     else if (ref == 1u) L.nrows = 0;                            // a level older than the chunk grew: every own row was inside it
-    if (!conts) ref = 0xFFu;
+    if (!conts) ref = 0xFFFFu;
   } else if (kind == kFsmEvCreate) {
     if (in_chunk) {
-      if (L.nrows >= static_cast<uint32_t>(kFsmLaneRows)) { L.flags |= 1u; ref = 0u; }
+      if (L.nrows >= L.max_rows) { L.flags |= 1u; ref = 0u; }
       else { rows.set_end(L.nrows, e); ref = 2u + L.nrows; L.nrows++; }
     } else ref = 0u;
-    if (!conts) ref = 0xFFu;
+    if (!conts) ref = 0xFFFFu;
   }
-  if (ref != 0xFFu) {
+  if (ref != 0xFFFFu) {
     if (nn >= static_cast<uint32_t>(kFsmMaxLevels)) L.flags |= 2u;
-    else { nl |= ref << (4u * nn); nn++; }
+    else { nl |= static_cast<uint64_t>(ref) << (8u * nn); nn++; }
   }
   L.lev = nl;
   L.nlev = nn;
@@ -191,7 +203,7 @@ CXG_FSM_HD void fsm_apply(FsmLane& L, uint32_t ev, int32_t e, bool in_chunk, Row
 // ---- replay of one chunk = fast part (whole staged chunk: walk + record events) + finish (apply the recorded events,
 // then walk on, applying events as they come, until no level that can still change an own row is alive).
 // Events concept: void push(uint32_t k, uint32_t row); uint32_t row_at(uint32_t k).
-struct FsmTrace { uint32_t x, evbits, nev; };        // state after the chunk, event positions (bit per byte), events seen
+struct FsmTrace { uint32_t x, evbits, nev, cap; };   // state after the chunk, event positions (bit per byte), events seen, event slots (power of two)
 
 CXG_FSM_HD void fsm_classes(const FsmView& v, uint32_t d, uint32_t (&k)[4]) {
   k[0] = v.cls2[d & 0xFFu]; k[1] = v.cls2[(d >> 8) & 0xFFu]; k[2] = v.cls2[(d >> 16) & 0xFFu]; k[3] = v.cls2[d >> 24];
@@ -200,7 +212,7 @@ template <class Events>
 CXG_FSM_HD void fsm_step_rec(const FsmView& v, uint32_t cls2, uint32_t bit, FsmTrace& t, Events& evs) {
   t.x = fsm_next(v, t.x, cls2) & ~3u;
   if (t.x >= v.alias_lo) {                           // rare per lane: recorded now, applied after the walk
-    evs.push(t.nev & static_cast<uint32_t>(kFsmLaneEvents - 1), t.x);
+    evs.push(t.nev & (t.cap - 1u), t.x);
     t.nev++;
     t.evbits |= bit;
   }
@@ -299,11 +311,12 @@ CXG_FSM_HD void fsm_finish_shallow(const FsmView& v, const Mem& m, const FsmTrac
     const uint64_t below_next = C ? ((1ull << static_cast<uint32_t>(__builtin_ctzll(C))) - 1ull) : ~0ull;
     const uint64_t win = CR & below_next & ~((1ull << c) - 1ull);            // events of this row (bit c is set)
     const int32_t top = (63 - static_cast<int32_t>(__builtin_clzll(win))) >> 1;
-    if (n < static_cast<uint32_t>(kFsmLaneRows)) rows.set_end(n, c0 + top + 1); else L.flags |= 1u;
+    if (n < L.max_rows) rows.set_end(n, c0 + top + 1); else L.flags |= 1u;
     n++;
   }
-  L.nrows = n < static_cast<uint32_t>(kFsmLaneRows) ? n : static_cast<uint32_t>(kFsmLaneRows);
+  L.nrows = n < L.max_rows ? n : L.max_rows;
   L.x = t.x & ~3u;
+  L.xc1 = L.x;
   L.nlev = fsm_u16(v.tab, L.x + v.ncls2 + 2u);                               // 0 or 1
   // a match pending at the chunk's end is the chunk's last row when the chunk created one, else it is older than the chunk
   L.lev = L.nlev ? (L.nrows ? 1u + L.nrows : 1u) : 0u;
@@ -322,15 +335,17 @@ CXG_FSM_HD void fsm_finish(const FsmView& v, const Mem& m, uint32_t entry, const
                            int32_t budget, FsmLane& L, Rows& rows, Events& evs) {
   L.x = entry;
   L.nlev = fsm_u16(v.tab, entry + v.ncls2 + 2u);
-  L.lev = 0x1111111u & ((1u << (4u * L.nlev)) - 1u);
+  L.lev = 0x01010101010101ull & ((1ull << (8u * L.nlev)) - 1ull);
   L.nrows = 0;
   L.flags = 0;
   int32_t i = c0;
+  L.xc1 = entry;
   if (fast) {
     i = c1;
     L.x = fast->x;
+    L.xc1 = fast->x;
     uint32_t evbits = fast->evbits;
-    if (fast->nev > static_cast<uint32_t>(kFsmLaneEvents)) { L.flags |= 8u; evbits = 0; }
+    if (fast->nev > fast->cap) { L.flags |= 8u; evbits = 0; }
     uint32_t k = 0;
     while (evbits) {                                 // apply in order
       const uint32_t pos = static_cast<uint32_t>(__builtin_ctz(evbits));
@@ -344,6 +359,7 @@ CXG_FSM_HD void fsm_finish(const FsmView& v, const Mem& m, uint32_t entry, const
     if (i >= rend) break;                            // end of input: every pending match is committed as it stands
     if (i >= budget) { L.flags |= 4u; break; }
     L.x = fsm_next(v, L.x, v.cls2[m.byte(i)]) & ~3u;
+    if (i < c1) L.xc1 = L.x;
     if (L.x >= v.alias_lo) fsm_apply(L, fsm_u16(v.tab, L.x + v.ncls2), i + 1, i < c1, rows);
   }
 }
@@ -355,7 +371,7 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
                            FsmLane& L, Rows& rows, Events& evs) {
   if (c1 <= rend && c1 <= budget && c1 - c0 == kFsmSub) {
     const int32_t cc[1] = {c0};
-    FsmTrace t[1] = {{entry, 0u, 0u}};
+    FsmTrace t[1] = {{entry, 0u, 0u, L.max_events}};
     fsm_fast<1>(v, m, cc, t, &evs);
     fsm_finish(v, m, entry, &t[0], c0, c1, rend, budget, L, rows, evs);
   } else {

@@ -47,6 +47,7 @@ struct ScanArgs {
   int64_t* out;         // [cap][2] or nullptr to count only
   uint64_t cap;
   uint64_t* status;     // [ntiles] look-back words, zeroed before launch
+  uint64_t* status2;    // scan_fsm.hip: [ngroups] exit state of every group (epoch << 32 | valid | state), same life cycle as status
   uint32_t* ticket;     // zeroed before launch
   uint64_t* total;      // match count (written by the last tile); wave kernels: pinned host memory, read without a copy
   uint32_t* err;        // bit0 lane overflow, bit1 look-back watchdog, bit2 capture table, bit3 fallback; host memory likewise

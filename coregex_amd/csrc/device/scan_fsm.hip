@@ -52,7 +52,6 @@ namespace {
 constexpr int kFsmStride = 68;                       // LDS bytes per 64-byte chunk
 constexpr int kFsmWinBytes = 64 * kFsmStride;        // 4352 per wave
 constexpr int kFsmLeft = 64;                         // bytes staged in front of the tile
-constexpr int kFsmRowsPerWave = 512;                 // rows buffered per wave and group
 constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the window (192 bytes past the tile)
 
 // The tile loop reads haystack bytes from the LDS window ONLY.  A load from HBM anywhere in the loop body — even on a
@@ -91,6 +90,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
   v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
+  v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   return v;
 }
 
@@ -98,29 +98,65 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
 // step's address  (entry & ~3) | 2 * class  goes straight into the ds_read — no base add on the dependent chain
 // (with the table anywhere else the compiler adds the base in a VALU op: it cannot prove that base + offset does not
 // wrap, so it does not use the instruction's immediate offset).  IMG = bytes reserved for the image.
-template <bool SHALLOW, int IMG>
+// MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per
+// tile, match-dense input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match
+// per 2 bytes).  The host escalates after an overflow and remembers the mode for the program (capi.hip).
+template <int MODE> struct FsmMode {
+  static constexpr int kTpw = MODE == 0 ? kTilesPerWave : (MODE == 1 ? kDenseTilesPerWave : 1);
+  static constexpr int kRows = MODE == 2 ? kFsmLaneRowsMax : kFsmLaneRows;
+  static constexpr int kEvents = MODE == 2 ? kFsmLaneEventsMax : kFsmLaneEvents;
+  static constexpr int kRowsPerWave = MODE == 2 ? 2048 : 512;
+};
+template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
-  uint16_t lrow[kWavesPerBlock][64 * 2 * kFsmLaneRows];        // per-lane row ends of the current tile (two sub-chunks)
-  uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * kFsmLaneEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
-  uint16_t re[kWavesPerBlock][kFsmRowsPerWave];                // rows of the group: end inside its wave-tile
-  uint16_t rl[kWavesPerBlock][kFsmRowsPerWave];                // ... and length (0: unresolved)
+  uint16_t lrow[kWavesPerBlock][64 * 2 * FsmMode<MODE>::kRows];      // per-lane row ends of the current tile (two sub-chunks)
+  uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
+  uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // rows of the group: end inside its wave-tile
+  uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // ... and length (0: unresolved)
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
   uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
   int64_t tail[kWavesPerBlock * kTilesPerWave];                // absolute end of a tile's last row, -1: no rows
   uint64_t group;
   uint64_t base;
+  uint32_t exit[kWavesPerBlock * kTilesPerWave];               // exit state of every tile of the group | 0x80000000 once known
 };
+
+// Exit state of a tile, handed to the next tile (needed only when that tile's first set of possible states does not
+// collapse): inside the workgroup through LDS, to the next group through one epoch-tagged word in HBM (relaxed
+// agent-scope accesses, self-contained word: block_common.hpp).
+constexpr uint32_t kExitValid = 0x80000000u;
+__device__ __forceinline__ void publish_tile_exit(uint32_t* s_exit, uint64_t* status2, uint64_t group, int q, int ntiles_group, uint32_t epoch, uint32_t ex) {
+  __hip_atomic_store(s_exit + q, ex | kExitValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (q == ntiles_group - 1)
+    __hip_atomic_store(status2 + group, (static_cast<uint64_t>(epoch) << 32) | kExitValid | ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Wave-uniform: the exit state of the tile in front of tile q of this group.
+__device__ __forceinline__ uint32_t wait_tile_exit(uint32_t* s_exit, uint64_t* status2, uint32_t* err, uint64_t group, int q, uint32_t epoch, int lane) {
+  uint32_t w = 0;
+  for (uint32_t spins = 0;; spins++) {
+    if (q > 0) w = __hip_atomic_load(s_exit + (q - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else {
+      const uint64_t g = __hip_atomic_load(status2 + (group - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w = (static_cast<uint32_t>(g >> 32) == epoch) ? static_cast<uint32_t>(g) : 0u;
+    }
+    w = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
+    if (w & kExitValid) break;
+    if (spins > (kSpinLimit << 4)) { if (lane == 0) raise_err(err, 2u); break; }   // (a hand-off chain over every tile of the input is legitimate)
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return w & 0xFFFFu;
+}
 
 }  // namespace
 
 // SHALLOW: the machine never holds more than one pending match (FsmHeader::depth <= 1): rows from two event bitmaps
-// per sub-chunk instead of a recorded event list (fsm.hpp).  TPW: wave-tiles per wave and group — 8, or 2 for match-dense
-// input (four times the row-buffer room per tile; the host switches after a row-buffer overflow).
-template <bool SHALLOW, int IMG, int TPW>
-__global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG> S;
+// per sub-chunk instead of a recorded event list (fsm.hpp).  MODE: buffer geometry by match density (FsmMode).
+template <bool SHALLOW, int IMG, int MODE>
+__global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE> S;
+  constexpr int kLaneRows = FsmMode<MODE>::kRows, kLaneEvents = FsmMode<MODE>::kEvents, kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   uint8_t* const s_img = S.img;
   auto& s_win = S.win; auto& s_lrow = S.lrow; auto& s_lev = S.lev; auto& s_re = S.re; auto& s_rl = S.rl;
   auto& s_cnt = S.cnt; auto& s_qbase = S.qbase; auto& s_tail = S.tail;
@@ -130,6 +166,7 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
+  if (tid < kWavesPerBlock * kTilesPerWave) S.exit[tid] = 0u;
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.blob + sizeof(FsmHeader));
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
   const uint64_t group = s_group;
   if (group >= a.ngroups) return;
   const FsmView v = view_of(s_img, h);
-  constexpr int tpw = TPW;
+  constexpr int tpw = FsmMode<MODE>::kTpw;
   uint32_t nrows_w = 0, fallback = 0, long_hit = 0;
 
   u32x4 x[4];
@@ -190,44 +227,167 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
       // independent chains of dependent LDS reads per lane).
       const int32_t c0 = (lane - 1) * kFsmChunk;
       const bool active = lane >= 1 && lane <= kWaveTile / kFsmChunk && c0 < rend;
+      const int32_t cc[2] = {c0, c0 + kFsmSub};
+      const bool second = active && cc[1] < rend;
+      const bool whole = c0 + kFsmChunk <= rend && c0 + kFsmChunk <= budget;   // both sub-chunks are staged data
+      const int q_tile = j * kWavesPerBlock + wave;    // index of the tile inside the group
       FsmLane L[2];
       L[0].nrows = L[1].nrows = 0;
-      LdsRows rows[2] = {{&s_lrow[wave][(2 * lane) * kFsmLaneRows]}, {&s_lrow[wave][(2 * lane + 1) * kFsmLaneRows]}};
-      LdsEvents evs[2] = {{&s_lev[wave][SHALLOW ? 0 : (2 * lane) * kFsmLaneEvents]}, {&s_lev[wave][SHALLOW ? 0 : (2 * lane + 1) * kFsmLaneEvents]}};
+      L[0].xc1 = L[1].xc1 = 0;
+      L[0].max_rows = L[1].max_rows = kLaneRows;
+      L[0].max_events = L[1].max_events = kLaneEvents;
+      LdsRows rows[2] = {{&s_lrow[wave][(2 * lane) * kLaneRows]}, {&s_lrow[wave][(2 * lane + 1) * kLaneRows]}};
+      LdsEvents evs[2] = {{&s_lev[wave][SHALLOW ? 0 : (2 * lane) * kLaneEvents]}, {&s_lev[wave][SHALLOW ? 0 : (2 * lane + 1) * kLaneEvents]}};
+      // entry states: from "any state" over the 16 bytes in front of each sub-chunk; when a set has not collapsed by
+      // then, over 64 bytes (rare on text)
+      uint32_t entry[2] = {0u, 0u};
       if (active) {
-        const int32_t cc[2] = {c0, c0 + kFsmSub};
-        const bool whole = c0 + kFsmChunk <= rend && c0 + kFsmChunk <= budget;   // both sub-chunks are staged data
-        const bool second = cc[1] < rend;
-        // entry states: from "any state" over the 16 bytes in front of each sub-chunk; when a set has not collapsed by
-        // then, over 64 bytes (rare on text)
-        uint32_t entry[2] = {0u, 0u};
         const bool at_origin = tile_lo + static_cast<uint64_t>(c0) == 0;
-        {
-          const int32_t from[2] = {at_origin ? cc[1] - 16 : cc[0] - 16, cc[1] - 16};     // (the haystack's first chunk starts in state 0)
-          if (!(CXG_FSM_ABL & 1)) fsm_walk_n<2>(v, m, v.top_off, from, 16, entry);
-          if (at_origin) entry[0] = 0u;
-          if (entry[0] >= v.u_lo) entry[0] = fsm_walk(v, m, v.top_off, cc[0] - 64, cc[0], true);
-          if (entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, v.top_off, at_origin ? 0 : cc[1] - 64, cc[1], true);
-          if (at_origin && entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, 0u, 0, cc[1], true);   // from the true start state
+        const int32_t from[2] = {at_origin ? cc[1] - 16 : cc[0] - 16, cc[1] - 16};     // (the haystack's first chunk starts in state 0)
+        if (!(CXG_FSM_ABL & 1)) fsm_walk_n<2>(v, m, v.top_off, from, 16, entry);
+        if (at_origin) entry[0] = 0u;
+        if (entry[0] >= v.u_lo) entry[0] = fsm_walk(v, m, v.top_off, cc[0] - 64, cc[0], true);
+        if (entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, v.top_off, at_origin ? 0 : cc[1] - 64, cc[1], true);
+        if (at_origin && entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, 0u, 0, cc[1], true);   // from the true start state
+      }
+      FSM_MARK(1);                                      // entry states
+      const bool unres0 = active && entry[0] >= v.u_lo, unres1 = second && entry[1] >= v.u_lo;
+      const unsigned long long um0 = __ballot(unres0), um1 = __ballot(unres1);
+      if ((um0 | um1) == 0ull) {
+        if (active) {
+          if (whole && SHALLOW) {
+            FsmTraceS t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
+            if (!(CXG_FSM_ABL & 2)) fsm_fast_shallow<2>(v, m, cc, t);
+            FSM_MARK(2);                                // lockstep walk
+            fsm_finish_shallow(v, m, t[0], cc[0], rend, budget, L[0], rows[0]);
+            fsm_finish_shallow(v, m, t[1], cc[1], rend, budget, L[1], rows[1]);
+          } else if (whole) {
+            FsmTrace t[2] = {{entry[0], 0u, 0u, kLaneEvents}, {entry[1], 0u, 0u, kLaneEvents}};
+            fsm_fast<2>(v, m, cc, t, evs);
+            fsm_finish(v, m, entry[0], &t[0], cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
+            fsm_finish(v, m, entry[1], &t[1], cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
+          } else {                                     // the input ends inside this lane's bytes
+            fsm_finish(v, m, entry[0], static_cast<const FsmTrace*>(nullptr), cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
+            if (second) fsm_finish(v, m, entry[1], static_cast<const FsmTrace*>(nullptr), cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
+          }
         }
-        if (entry[0] >= v.u_lo || (second && entry[1] >= v.u_lo)) { fallback |= 1u; entry[0] = entry[1] = 0u; }
-        FSM_MARK(1);                                    // entry states
-        if (whole && SHALLOW) {
-          FsmTraceS t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
-          if (!(CXG_FSM_ABL & 2)) fsm_fast_shallow<2>(v, m, cc, t);
-          FSM_MARK(2);                                  // lockstep walk
-          fsm_finish_shallow(v, m, t[0], cc[0], rend, budget, L[0], rows[0]);
-          fsm_finish_shallow(v, m, t[1], cc[1], rend, budget, L[1], rows[1]);
-        } else if (whole) {
-          FsmTrace t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
-          fsm_fast<2>(v, m, cc, t, evs);
-          fsm_finish(v, m, entry[0], &t[0], cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
-          fsm_finish(v, m, entry[1], &t[1], cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
-        } else {                                       // the input ends inside this lane's bytes
-          fsm_finish(v, m, entry[0], static_cast<const FsmTrace*>(nullptr), cc[0], cc[1], rend, budget, L[0], rows[0], evs[0]);
-          if (second) fsm_finish(v, m, entry[1], static_cast<const FsmTrace*>(nullptr), cc[1], cc[1] + kFsmSub, rend, budget, L[1], rows[1], evs[1]);
+      } else {
+        // ---- Some sub-chunk's set of possible entry states did not collapse: input without synchronising structure
+        // (`1.1.1.1...` for the IPv4 pattern).  Exact, in four steps.  (1) Sub-chunks with a known entry are replayed;
+        // their end state is the next sub-chunk's true entry.  (2) Every unresolved sub-chunk walks its 32 bytes once
+        // from each member of its set (<= 8, listed in the image): a MAP member -> end state.  (3) One pass in order over
+        // the unresolved sub-chunks chains the maps: true entry = end state of the sub-chunk in front (a replayed one,
+        // the previous link of the chain, or — for the tile's first — the exit the previous tile published).
+        // (4) The unresolved sub-chunks are replayed from their true entries.  Serial only in step 3: ~20 scalar
+        // operations per unresolved sub-chunk.
+        auto replay_one = [&](int sb, uint32_t from_state) {   // one sub-chunk from a known entry state
+          const int32_t c1s = cc[sb] + kFsmSub;
+          if (SHALLOW && c1s <= rend && c1s <= budget) {          // (shallow instantiations have no event buffers)
+            const int32_t c1a[1] = {cc[sb]};
+            FsmTraceS ts[1] = {{from_state, 0u, 0u}};
+            fsm_fast_shallow<1>(v, m, c1a, ts);
+            fsm_finish_shallow(v, m, ts[0], cc[sb], rend, budget, L[sb], rows[sb]);
+          } else if (SHALLOW) {
+            fsm_finish(v, m, from_state, static_cast<const FsmTrace*>(nullptr), cc[sb], c1s, rend, budget, L[sb], rows[sb], evs[sb]);
+          } else {
+            fsm_replay(v, m, from_state, cc[sb], c1s, rend, budget, L[sb], rows[sb], evs[sb]);
+          }
+        };
+        uint32_t xc[2] = {0u, 0u};                     // end state of a replayed sub-chunk (own row of the state)
+        uint32_t F[2][kFsmMembers];
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+#pragma unroll
+          for (int jm = 0; jm < kFsmMembers; jm++) F[sb][jm] = 0xFFFFu;
+          const bool has = sb ? second : active;
+          const bool unres = sb ? unres1 : unres0;
+          const int32_t c1s = cc[sb] + kFsmSub;
+          if (has && !unres) {
+            replay_one(sb, entry[sb]);
+            xc[sb] = fsm_canon(v, L[sb].xc1);
+          } else if (has) {
+            if (fsm_member(v, entry[sb], 0) == 0xFFFFu) fallback |= 1u;      // more than 8 possible states: not listed
+            const int32_t to = c1s < rend ? c1s : rend;
+            for (int jm = 0; jm < kFsmMembers; jm++) {
+              const uint32_t mj = fsm_member(v, entry[sb], static_cast<uint32_t>(jm));
+              if (mj != 0xFFFFu) F[sb][jm] = fsm_canon(v, fsm_walk(v, m, mj, cc[sb], to, true));
+            }
+          }
         }
-        fallback |= (L[0].flags | L[1].flags) << 1;
+        // (2b) The tile's first sub-chunk is unresolved: every tile in front of it may be in the same situation, and
+        // the hand-off from tile to tile is a serial chain over the whole input.  Keep that chain to one lookup per
+        // tile: lanes 0..7 chase the (<= 8) candidates of the first set through the tile's maps BEFORE the true entry is
+        // known; when it arrives, this tile's exit is the chased value of the matching candidate and is published at
+        // once — the tile's own chain and replays then run off the critical path.
+        const unsigned long long am_all = __ballot(active);
+        const int last_lane = 63 - __builtin_clzll(am_all | 1ull);
+        uint32_t pred_exit = 0u;
+        if ((um0 >> 1) & 1ull) {
+          const uint32_t u1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[0]), 1));
+          uint32_t cand = lane < kFsmMembers ? fsm_member(v, u1, static_cast<uint32_t>(lane)) : 0xFFFFu;
+          const uint32_t cand0 = cand;
+          for (int l = 1; l <= last_lane; l++) {
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++) {
+              if (sb == 1 && !static_cast<bool>(__builtin_amdgcn_readlane(static_cast<int>(second), l))) continue;
+              if (((sb ? um1 : um0) >> l) & 1ull) {
+                const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[sb]), l));
+                uint32_t nxt = 0xFFFFu;
+#pragma unroll
+                for (int jm = 0; jm < kFsmMembers; jm++) {
+                  const uint32_t fj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
+                  if (fsm_member(v, u, static_cast<uint32_t>(jm)) == cand) nxt = fj;
+                }
+                cand = cand == 0xFFFFu ? 0xFFFFu : nxt;
+              } else {
+                const uint32_t xr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[sb]), l));
+                cand = cand == 0xFFFFu ? 0xFFFFu : xr;
+              }
+            }
+          }
+          pred_exit = wait_tile_exit(S.exit, a.status2, a.err, group, q_tile, a.epoch, lane);
+          const unsigned long long hit = __ballot(lane < kFsmMembers && cand0 == pred_exit);
+          if (hit) {
+            const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), __builtin_ctzll(hit)));
+            if (lane == 0 && ex != 0xFFFFu) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
+          } else fallback |= 1u;                        // the true state is not in the listed set: cannot happen
+        }
+        // (3) the chain, wave-uniform
+        uint32_t cur = 0u;                              // end state of the sub-chunk in front of the one being resolved
+        uint32_t true_entry[2] = {entry[0], entry[1]};
+        unsigned long long todo = um0 | um1;
+        while (todo) {
+          const int l = __builtin_ctzll(todo);
+          todo &= todo - 1;
+#pragma unroll
+          for (int sb = 0; sb < 2; sb++) {
+            if (!(((sb ? um1 : um0) >> l) & 1ull)) continue;
+            // the sub-chunk in front: (l, 0) for sb == 1, (l - 1, 1) for sb == 0, the previous tile for the tile's first
+            if (sb == 1) { if (!((um0 >> l) & 1ull)) cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[0]), l)); }
+            else if (l == 1) cur = pred_exit;
+            else if (!((um1 >> (l - 1)) & 1ull)) cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[1]), l - 1));
+            if (lane == l) true_entry[sb] = cur;
+            const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[sb]), l));
+            uint32_t nxt = 0xFFFFu;
+#pragma unroll
+            for (int jm = 0; jm < kFsmMembers; jm++)
+              if (fsm_member(v, u, static_cast<uint32_t>(jm)) == cur) nxt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
+            if (nxt == 0xFFFFu) { fallback |= 1u; nxt = 0u; }                 // the true state is not in the listed set: cannot happen
+            cur = nxt;
+          }
+        }
+        // (4) replay of the unresolved sub-chunks
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++)
+          if (sb ? unres1 : unres0) replay_one(sb, true_entry[sb]);
+      }
+      if (active) fallback |= (L[0].flags | L[1].flags) << 1;
+      {  // this tile's exit state, for a following tile whose first set does not collapse
+        const unsigned long long am = __ballot(active);
+        const int ll = 63 - __builtin_clzll(am | 1ull);
+        const uint32_t xl = second ? L[1].xc1 : L[0].xc1;
+        const uint32_t ex = fsm_canon(v, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xl), ll)));
+        if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
       }
       FSM_MARK(3);                                      // rows of the lanes (+ divergence of the whole E/R block)
       // ---- S: rows in lane order, then their starts
@@ -236,11 +396,11 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
       tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
       const uint32_t first = nrows_w + incl - nl;
       for (uint32_t r = 0; r < nl; r++)
-        if (first + r < static_cast<uint32_t>(kFsmRowsPerWave)) s_re[wave][first + r] = r < nl0 ? rows[0].slot[r] : rows[1].slot[r - nl0];
+        if (first + r < static_cast<uint32_t>(kRowsPerWave)) s_re[wave][first + r] = r < nl0 ? rows[0].slot[r] : rows[1].slot[r - nl0];
       wave_lds_sync();
       FSM_MARK(4);                                      // rows gathered
       if (a.out != nullptr || a.max_len != 0) {
-        for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kFsmRowsPerWave); q += 64) {
+        for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kRowsPerWave); q += 64) {
           const int32_t e = s_re[wave][nrows_w + q];
           // first row of the tile: no bound known here (checked after the barrier); one byte below the window makes a
           // reverse DFA that is still alive there report `over`
@@ -265,7 +425,7 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
     atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 15), 1ull);
   }
 #endif
-  if (nrows_w > static_cast<uint32_t>(kFsmRowsPerWave)) fallback |= 32u;
+  if (nrows_w > static_cast<uint32_t>(kRowsPerWave)) fallback |= 32u;
   {
     uint32_t f = fallback;                                                   // per-lane reasons -> one atomic per wave
 #pragma unroll
@@ -288,7 +448,7 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
     uint32_t st = 0;
     for (int k = 0; k < jj; k++) st += s_cnt[w][k];
     const uint32_t n = s_cnt[w][jj];
-    s_tail[q] = (n && st + n <= static_cast<uint32_t>(kFsmRowsPerWave)) ? gorigin + static_cast<int64_t>(q) * kWaveTile + s_re[w][st + n - 1] : -1;
+    s_tail[q] = (n && st + n <= static_cast<uint32_t>(kRowsPerWave)) ? gorigin + static_cast<int64_t>(q) * kWaveTile + s_re[w][st + n - 1] : -1;
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * tpw];
@@ -302,7 +462,7 @@ __global__ __launch_bounds__(kThreads, (IMG > 10240 ? 2 : 4)) void k_scan_fsm(Sc
     const int64_t tb = gorigin + static_cast<int64_t>(q) * kWaveTile;
     for (uint32_t i = lane; i < n; i += 64) {
       const uint32_t r = start + i;
-      if (r >= static_cast<uint32_t>(kFsmRowsPerWave)) continue;
+      if (r >= static_cast<uint32_t>(kRowsPerWave)) continue;
       int64_t e = tb + s_re[wave][r], s = e - s_rl[wave][r];
       if ((i == 0 || s == e) && (a.out != nullptr || a.max_len != 0)) {
         // the tile's first row was walked without a bound (its predecessor is another wave's row); an unresolved row
@@ -362,20 +522,25 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
 
 namespace {
 template <int IMG>
-void launch_fsm_img(const ScanArgs& a, bool shallow, bool dense, dim3 grid, dim3 block, hipStream_t stream) {
-  if (shallow && !dense) hipLaunchKernelGGL((k_scan_fsm<true, IMG, kTilesPerWave>), grid, block, 0, stream, a);
-  else if (shallow) hipLaunchKernelGGL((k_scan_fsm<true, IMG, kDenseTilesPerWave>), grid, block, 0, stream, a);
-  else if (!dense) hipLaunchKernelGGL((k_scan_fsm<false, IMG, kTilesPerWave>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((k_scan_fsm<false, IMG, kDenseTilesPerWave>), grid, block, 0, stream, a);
+void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 block, hipStream_t stream) {
+  if (shallow) {
+    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 0>), grid, block, 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 1>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<true, IMG, 2>), grid, block, 0, stream, a);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 0>), grid, block, 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 1>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<false, IMG, 2>), grid, block, 0, stream, a);
+  }
 }
 }  // namespace
 
 hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  const bool dense = a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave);
-  if (lds_bytes <= 3072) launch_fsm_img<3072>(a, shallow, dense, grid, block, stream);          // instantiations by image size: LDS per
-  else if (lds_bytes <= 10240) launch_fsm_img<10240>(a, shallow, dense, grid, block, stream);   // workgroup 33 / 40 / 58 KB
-  else if (lds_bytes <= 28672) launch_fsm_img<28672>(a, shallow, dense, grid, block, stream);
+  const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
+  if (lds_bytes <= 3072) launch_fsm_img<3072>(a, shallow, mode, grid, block, stream);          // instantiations by image size
+  else if (lds_bytes <= 10240) launch_fsm_img<10240>(a, shallow, mode, grid, block, stream);
+  else if (lds_bytes <= 28672) launch_fsm_img<28672>(a, shallow, mode, grid, block, stream);
   else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.out == nullptr || a.ngroups < 2) return e;

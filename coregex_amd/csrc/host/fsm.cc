@@ -211,7 +211,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   // rows are a power of two long: a walk step is then  x = tab[(entry & ~3) | 2 * class]  — one v_and_or on the chain —
   // and the two low bits of an entry are free for the event flags of shallow machines (fsm.hpp)
   uint32_t rowBytes = 16;
-  while (rowBytes < (ncls + 2) * 2) rowBytes *= 2;
+  uint32_t rowShift = 4;
+  while (rowBytes < (ncls + 3) * 2) { rowBytes *= 2; rowShift++; }
   const uint32_t stride = rowBytes / 2;
   const uint32_t nRows = nT + nA + nU + 1;
   if (static_cast<size_t>(nRows) * rowBytes > cxgdev::kFsmMaxTableBytes) { why = "FindAll transducer table exceeds the LDS budget"; return false; }
@@ -230,7 +231,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   std::memset(&h, 0, sizeof h);
   h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_a = nA; h.n_u = nU; h.ncls = ncls; h.stride = stride; h.row_bytes = rowBytes; h.depth = depth;
   h.alias_lo = offA(0); h.u_lo = offU(0); h.top_off = offU(0); h.wide_off = wideOff; h.max_len = max_len;
-  h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate);
+  h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate); h.row_shift = rowShift;
   std::vector<uint8_t> img(sizeof h, 0);
   auto put = [&](const void* d, size_t n, uint32_t& off) {
     while (img.size() % 16) img.push_back(0);
@@ -244,12 +245,14 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   for (uint32_t s = 0; s < nT; s++) {
     for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(s) * stride + c] = target(trans[s][c]);
     tab[static_cast<size_t>(s) * stride + ncls + 1] = levels[s];
+    tab[static_cast<size_t>(s) * stride + ncls + 2] = static_cast<uint16_t>(offT(s));
   }
   for (uint32_t a = 0; a < nA; a++) {
     const uint32_t to = aliases[a] & 0xFFFFu;
     for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(nT + a) * stride + c] = target(trans[to][c]);
     tab[static_cast<size_t>(nT + a) * stride + ncls] = static_cast<uint16_t>(aliases[a] >> 16);
     tab[static_cast<size_t>(nT + a) * stride + ncls + 1] = levels[to];
+    tab[static_cast<size_t>(nT + a) * stride + ncls + 2] = static_cast<uint16_t>(offT(to));
   }
   for (uint32_t u = 0; u < nU; u++)
     for (uint32_t c = 0; c < ncls; c++) {
@@ -260,11 +263,11 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   put(tab.data(), tab.size() * 2, h.tab_off);
   if (h.tab_off != sizeof h) { why = "internal: image layout (scan_fsm.hip expects the transition table first)"; return false; }
   put(cls2, 256, h.cls_off);
-  std::vector<uint8_t> mem(static_cast<size_t>(nU + 1) * cxgdev::kFsmMembers, 0xFF);
+  std::vector<uint16_t> mem(static_cast<size_t>(nU + 1) * cxgdev::kFsmMembers, 0xFFFF);
   for (uint32_t u = 0; u < nU; u++)
     if (sets[u].size() <= static_cast<size_t>(cxgdev::kFsmMembers))
-      for (size_t k = 0; k < sets[u].size(); k++) mem[static_cast<size_t>(u) * cxgdev::kFsmMembers + k] = sets[u][k];
-  put(mem.data(), mem.size(), h.mem_off);
+      for (size_t k = 0; k < sets[u].size(); k++) mem[static_cast<size_t>(u) * cxgdev::kFsmMembers + k] = static_cast<uint16_t>(offT(sets[u][k]));
+  put(mem.data(), mem.size() * 2, h.mem_off);
   // reverse DFA, class-compressed, entries = byte offset of the target row; the classes come from the same NFA ranges,
   // so a class never straddles a reverse transition
   const uint32_t revRow = ncls * 2;

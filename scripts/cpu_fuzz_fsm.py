@@ -45,6 +45,13 @@ def main(n=300, seed=1):
                         np.save("/tmp/fsm_fail_hay.npy", hay)
                         print("EMU ERROR", ex, repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), exp[:6].tolist())
                         return 1
+                    if isinstance(got, int) and got in (-18, -32):       # a chunk's row / event buffers: the kernel's mode 2
+                        try:
+                            got = emu.find_all_fsm(image, hay, tile, chunk, dense=1)
+                        except AssertionError as ex:
+                            np.save("/tmp/fsm_fail_hay.npy", hay)
+                            print("EMU ERROR (dense)", ex, repr(pat), which, tile, chunk)
+                            return 1
                     if isinstance(got, int):
                         reasons[got] = reasons.get(got, 0) + 1
                         continue

@@ -28,7 +28,7 @@ def lib():
             f.restype = C.c_int64
             f.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.emu_find_all_fsm.restype = C.c_int64
-        L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
         L.emu_find_all_submatch.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64]
         _lib = L
@@ -137,7 +137,7 @@ def find_all_charclass_wave(blob: bytes, hay, tile: int = 3840, halo: int = 256)
     return _wave_twin("emu_find_all_charclass_wave", blob, hay, tile, halo)
 
 
-def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: int = 192, stats=None):
+def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: int = 192, stats=None, dense: int = 0):
     """scan_fsm.hip (FindAll transducer), emulated; the int reason (< 0) when a tile would raise the fallback flag."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
@@ -145,7 +145,7 @@ def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: i
     st = np.zeros(4, dtype=np.uint64)
     while True:
         out = np.empty(cap, dtype=np.int64)
-        n = lib().emu_find_all_fsm(image, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, chunk, budget, st.ctypes.data)
+        n = lib().emu_find_all_fsm(image, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, chunk, budget, st.ctypes.data, dense)
         if n <= -16:
             return int(n)
         assert n >= 0, f"emulator error {n}"

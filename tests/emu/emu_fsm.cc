@@ -19,11 +19,11 @@ struct HostMem {
   uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
 };
 struct LaneRows {
-  int32_t end[kFsmLaneRows];
+  int32_t end[kFsmLaneRowsMax];
   void set_end(uint32_t r, int32_t e) { end[r] = e; }
 };
 struct LaneEvents {
-  uint16_t row[kFsmLaneEvents];
+  uint16_t row[kFsmLaneEventsMax];
   void push(uint32_t k, uint32_t r) { row[k] = static_cast<uint16_t>(r); }
   uint32_t row_at(uint32_t k) const { return row[k]; }
 };
@@ -37,6 +37,7 @@ FsmView view_of(const uint8_t* img) {
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
   v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
+  v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   return v;
 }
 }  // namespace
@@ -44,9 +45,9 @@ FsmView view_of(const uint8_t* img) {
 // Returns the number of int64 values written (2 per match) or needed; -16 - reason when a tile would raise the
 // fallback flag (reason 1: a lane's entry state did not collapse, 2: more than kFsmLaneRows rows in a chunk,
 // 4: level stack overflow, 8: walk budget), -1 on a bad image.  stats (optional, 4 values): chunks, chunks whose entry
-// needed the full warm-up, walk-ahead bytes, rows fixed against the previous row.
+// needed the full warm-up, chunks whose entry set did not collapse, rows fixed against the previous row.
 extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
-                                    int tile, int chunk, int budget_bytes, uint64_t* stats) {
+                                    int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
   const FsmView v = view_of(img);
@@ -54,6 +55,7 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
   const int lanes = tile / chunk;
   const uint64_t ntiles = (len + static_cast<uint64_t>(tile) - 1) / static_cast<uint64_t>(tile);
   int64_t prev_end = 0;                                   // absolute end of the previous row
+  uint32_t cur_exit = 0;                                  // state at the end of the previous chunk
   uint64_t st[4] = {0, 0, 0, 0};
   for (uint64_t t = 0; t < ntiles; t++) {
     const uint64_t tile_lo = t * static_cast<uint64_t>(tile);
@@ -74,9 +76,20 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
         const int32_t w1 = static_cast<int32_t>(avail < 16 ? avail : 16), w2 = static_cast<int32_t>(avail < 64 ? avail : 64);
         entry = fsm_walk(v, m, v.top_off, c0 - w1, c0, (w1 % 4) == 0);
         if (entry >= v.u_lo && w2 > w1) { entry = fsm_walk(v, m, v.top_off, c0 - w2, c0, (w2 % 4) == 0); st[1]++; }
-        if (entry >= v.u_lo) return -16 - 1;
+        if (entry >= v.u_lo) {
+          // the set of possible states did not collapse.  The kernel then takes the true entry state from the chunk in
+          // front (scan_fsm.hip: maps over the set's members + a chain through the unresolved chunks); the twin walks
+          // in order and simply knows it.  The set must be listed (<= 8 members) and must hold the true state.
+          st[2]++;
+          if (fsm_member(v, entry, 0) == 0xFFFFu) return -16 - 1;
+          bool found = false;
+          for (uint32_t j = 0; j < static_cast<uint32_t>(kFsmMembers); j++) found = found || fsm_member(v, entry, j) == cur_exit;
+          if (!found) return -3;
+          entry = cur_exit;
+        }
       }
       FsmLane L;
+      if (dense) { L.max_rows = kFsmLaneRowsMax; L.max_events = kFsmLaneEventsMax; }   // the kernel's mode 2
       LaneRows rows;
       LaneEvents evs;
       if (h->depth <= 1 && chunk == kFsmSub && c1 <= rend && c1 <= budget) {   // the kernel's SHALLOW instantiation
@@ -88,6 +101,7 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
         fsm_replay(v, m, entry, c0, c1, rend, budget, L, rows, evs);
       }
       if (L.flags) return -16 - static_cast<int64_t>(L.flags << 1);
+      cur_exit = fsm_canon(v, L.xc1);
       for (uint32_t r = 0; r < L.nrows; r++) {
         const int32_t e = rows.end[r];
         uint32_t over = 0;
