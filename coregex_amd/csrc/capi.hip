@@ -512,7 +512,8 @@ relaunch:
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
-    if (gen == 10 && ((err >> 8) & ~0x32u) == 0u && fsmMode < 2) {    // transducer kernel: only row / event buffers overflowed
+    if (gen == 10 && ((err >> 8) & 0x32u) != 0u && ((err >> 8) & ~0x72u) == 0u && fsmMode < 2) {   // transducer kernel: row / event buffers overflowed
+      // (0x40 — a row without a start — beside an overflow bit is a consequence of the dropped rows, not a finding)
       // 0x20 alone: the wave's row list -> mode 1 (2 tiles per wave); a sub-chunk's own buffers (0x02 rows, 0x10 events), or
       // mode 1 was not enough -> mode 2 (1 tile, 2048 rows, 16 rows / 32 events per 32 bytes)
       fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : 2;

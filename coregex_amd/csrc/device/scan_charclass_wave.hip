@@ -9,16 +9,19 @@
 //           buffer_load_dwordx4 per lane, membership by SWAR range tests (the class is a union of <= 4 ASCII
 //           ranges) + v_dot4 gather, 16-bit pieces through LDS -> word M per lane;
 //             starts S = M & ~(M << 1 | carry),  ends E = ~M & (M << 1 | carry)   (exclusive ends)
-//           the tile owns the runs that START in its first 3840 bytes; S and E words stay in LDS, counts are
-//           summed per tile;
+//           starts and ends are owned SEPARATELY: the tile owns the starts at its bytes [0, 3840) and the exclusive
+//           ends at (0, 3840] — a run may be as long as the haystack, nobody has to see both of its ends.  Runs
+//           alternate start, end, start, end, so the k-th start and the k-th end of the haystack are row k: with
+//           B = number of starts in front of the tile (look-back), the tile's i-th start is row B + i and its j-th
+//           end is row B - open + j, open = 1 when a run crosses the tile's first byte.  S and E words stay in LDS,
+//           the start counts are summed per tile;
 //   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, one look-back -> global base of every tile;
 //   pass 2  per wave-tile every lane drops the starts and ends it holds into the wave's LDS staging at their
-//           ranks (both compactions keep the order, so start k and end k meet in row k without ever meeting in a
-//           register), then the wave writes the rows as fully coalesced 16-byte stores (1 KiB per instruction).
-//           The first end of a window that begins inside a run belongs to the previous tile and is skipped.
-// Fallback flag (err bit 8: the host reruns the scan with scan_charclass.hip): a run that starts in the tile and
-// does not end inside the window (longer than the 256-byte halo) unless it ends with the input; more than 1024
-// runs in one wave-tile.
+//           ranks, then the wave writes the rows that have both halves here as fully coalesced 16-byte stores
+//           (1 KiB per instruction); the end of a run begun in an earlier tile and the start of a run that ends in a
+//           later one go out as lone 8-byte stores.
+// Fallback flag (err bit 8: the host reruns the scan with scan_charclass.hip): more than 1024 starts or ends in one
+// wave-tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -119,36 +122,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       const uint64_t P = (M << 1) | carry;                          // "the previous byte is a member"
       S = M & ~P;
       E = ~M & P;                                                   // exclusive end: first non-member after a run
-      S &= word_range(lane, 0, kWaveTile - 1);                      // runs that start in the halo belong to the next tile
-      // ends: skip the one that closes a run begun in front of the tile, keep as many as there are owned starts
+      S &= word_range(lane, 0, kWaveTile - 1);                      // starts at [0, 3840), exclusive ends at (0, 3840]
+      E &= word_range(lane, 1, kWaveTile);
       const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
       const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
       const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
       n = tot & 0xFFFFu;
-      const uint32_t skip = prev_member;                            // (prev member: the window starts inside or right behind a run)
-      const uint32_t have = (tot >> 16) >= skip ? (tot >> 16) - skip : 0u;
-      // a run reaching the last byte of a full window ends at 4096: fine at the end of input, else unknown
-      const bool at_eoi_edge = (stage == rend) && (stage == kWin);
-      if (have < n && !(at_eoi_edge && have + 1 == n)) fallback |= 1;
-      if (n > static_cast<uint32_t>(kCcStage)) fallback |= 8;
-      // keep the ends with rank in [skip, skip + n): mask off the others
-      {
-        const uint32_t ie = (incl >> 16) - ne;                      // ends in lower lanes
-        uint64_t keep = 0, eb = E;
-        uint32_t r = ie;
-        while (eb) {
-          const int bit = __builtin_ctzll(eb);
-          eb &= eb - 1;
-          if (r >= skip && r < skip + n) keep |= 1ull << bit;
-          r++;
-        }
-        E = keep;
-      }
-      // the rank bookkeeping of pass 2 needs the exclusive prefixes again: keep them packed in the words' place
+      const uint32_t n_ends = tot >> 16;
+      // a run crosses the tile's first byte: the byte in front and the first byte are both members
+      const uint32_t open = prev_member & static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(M) & 1u)));
+      if (n > static_cast<uint32_t>(kCcStage) || n_ends > static_cast<uint32_t>(kCcStage)) fallback |= 8;
       s_S[wave][j][lane] = S;
       s_E[wave][j][lane] = E;
-      if (lane == 0 && at_eoi_edge && have + 1 == n) s_cnt[wave][j] = n | 0x80000000u;   // last end = 4096 (written by pass 2)
-      else if (lane == 0) s_cnt[wave][j] = n;
+      if (lane == 0) s_cnt[wave][j] = n | (n_ends << 12) | (open << 31);   // n, n_ends <= 3840 < 4096
     } else {
       s_S[wave][j][lane] = 0; s_E[wave][j][lane] = 0;
       if (lane == 0) s_cnt[wave][j] = 0;
@@ -160,7 +146,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   // ---- group: exclusive prefix over the wave-tiles q = j*4 + wave, look-back
   if (tid < 64) {
     const int q = tid;
-    const uint32_t v = (q < kWavesPerBlock * kCcTilesPerWave) ? (s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] & 0x7FFFFFFFu) : 0u;
+    const uint32_t v = (q < kWavesPerBlock * kCcTilesPerWave) ? (s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] & 0xFFFu) : 0u;
     const uint32_t incl = wave_inclusive_sum(v);
     if (q < kWavesPerBlock * kCcTilesPerWave) s_qbase[q] = incl - v;
     if (q == kWavesPerBlock * kCcTilesPerWave - 1) s_qbase[kWavesPerBlock * kCcTilesPerWave] = incl;
@@ -175,8 +161,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave);
   for (int j = 0; j < kCcTilesPerWave; j++) {
     const uint32_t cn = s_cnt[wave][j];
-    const uint32_t n = cn & 0x7FFFFFFFu;
-    if (n == 0) continue;
+    const uint32_t n = cn & 0xFFFu, n_ends = (cn >> 12) & 0xFFFu, open = cn >> 31;
+    if (n == 0 && n_ends == 0) continue;
     const uint64_t S = s_S[wave][j][lane0], E = s_E[wave][j][lane0];
     const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
     const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
@@ -197,16 +183,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
       r++;
     }
-    if ((cn & 0x80000000u) && lane0 == 0 && n - 1 < static_cast<uint32_t>(kCcStage)) s_re[wave][n - 1] = static_cast<uint16_t>(kWin);   // run ending with the input
     wave_lds_sync();
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
     const uint32_t nst = n < static_cast<uint32_t>(kCcStage) ? n : static_cast<uint32_t>(kCcStage);
+    const uint32_t nen = n_ends < static_cast<uint32_t>(kCcStage) ? n_ends : static_cast<uint32_t>(kCcStage);
     for (uint32_t i = lane0; i < nst; i += 64) {
       if (row0 + i < a.cap) {
-        longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i];
-        *reinterpret_cast<longlong2*>(a.out + (row0 + i) * 2) = v;
+        if (i + open < nen) {                                       // both halves of the row are this tile's
+          longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i + open];
+          *reinterpret_cast<longlong2*>(a.out + (row0 + i) * 2) = v;
+        } else a.out[(row0 + i) * 2] = tb + s_rs[wave][i];         // the run ends in a later tile
       }
     }
+    if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) a.out[(row0 - 1) * 2 + 1] = tb + s_re[wave][0];   // a run begun in an earlier tile ends here
     wave_lds_sync();                                                // staging is reused by the next tile
   }
 }

@@ -1071,10 +1071,54 @@ void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], ui
   p->supported = true;
 }
 
+namespace {
+// Thompson NFA of `lit0|lit1|...` (alternation in pattern-ID order) behind the unanchored prefix: for a prefix-free
+// set at most one literal matches at a position, so leftmost-first over this NFA is what Teddy.FindMatch + the FindAll
+// loop report (prefilter/teddy.go:391-444, meta/find_indices.go:925-951).  Only the transducer kernel uses it — the
+// fallback of the literal kernels for input they cannot take (match-dense, no synchronising bytes).
+HostNfa literalNfa(const std::vector<std::vector<uint8_t>>& lits) {
+  HostNfa n;
+  auto blank = [](uint8_t kind) { cxg_nfa_state s; std::memset(&s, 0, sizeof s); s.kind = kind; s.next = s.left = s.right = CXG_NFA_INVALID; return s; };
+  auto add = [&](cxg_nfa_state s) { n.states.push_back(s); return static_cast<uint32_t>(n.states.size() - 1); };
+  const uint32_t match = add(blank(CXG_NFA_MATCH));
+  std::vector<uint32_t> heads;
+  for (const auto& l : lits) {
+    uint32_t next = match;
+    for (size_t i = l.size(); i-- > 0;) {
+      cxg_nfa_state b = blank(CXG_NFA_BYTE_RANGE);
+      b.lo = b.hi = l[i]; b.next = next;
+      next = add(b);
+    }
+    heads.push_back(next);
+  }
+  uint32_t alt = heads.back();
+  for (size_t i = heads.size() - 1; i-- > 0;) { cxg_nfa_state sp = blank(CXG_NFA_SPLIT); sp.left = heads[i]; sp.right = alt; alt = add(sp); }
+  n.startAnchored = alt;
+  cxg_nfa_state any = blank(CXG_NFA_BYTE_RANGE);
+  any.lo = 0; any.hi = 255;
+  const uint32_t anyId = add(any);
+  cxg_nfa_state pre = blank(CXG_NFA_SPLIT);
+  pre.left = alt; pre.right = anyId;
+  n.startUnanchored = add(pre);
+  n.states[anyId].next = n.startUnanchored;
+  n.captureCount = 1;
+  return n;
+}
+}  // namespace
+
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits) {
   p->strategy = CXG_USE_TEDDY;
   p->ngroups = 1;
   buildLiteralImage(p, lits, 2);
+  if (!p->supported) return;
+  try {                                              // transducer image: the literal kernels' fallback
+    const HostNfa ln = literalNfa(lits);
+    const cxg_nfa lv = ln.view();
+    HostNfa rn = reverseOf(lv);
+    cxg_nfa rvw = rn.view();
+    const Dfa rv = determinize(rvw, rvw.start_anchored, false, kMaxDfaStates);
+    if (!buildFsmImage(lv, rv, 0u, p->fsmBlob, p->fsmWhyNot)) p->fsmBlob.clear();
+  } catch (const BuildError& e) { p->fsmBlob.clear(); p->fsmWhyNot = e.msg; }
 }
 
 // Device image of a literal set (kKindTeddy): fingerprint tables + the literals for exact verification.

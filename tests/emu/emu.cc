@@ -461,23 +461,26 @@ extern "C" int64_t emu_find_all_charclass_wave(const uint8_t* blob, const uint8_
     const int64_t stage = rend < N ? rend : N;
     const uint8_t* g = hay + tile_lo;
     const bool prev_member = tile_lo > 0 && member(g[-1]);
-    std::vector<int64_t> S, E;                      // E: exclusive ends seen inside the window [0, N)
-    for (int64_t p = 0; p < N; p++) {
+    // starts owned at [0, tile), exclusive ends owned at (0, tile]; row of the i-th start: B + i, of the j-th end:
+    // B - open + j with B = starts in front of the tile (scan_charclass_wave.hip)
+    std::vector<int64_t> S, E;
+    for (int64_t p = 0; p <= tile_bytes && p < N; p++) {
       const bool m = p < stage && member(g[p]);
       const bool pm = p == 0 ? prev_member : (p - 1 < stage && member(g[p - 1]));
       if (m && !pm && p < tile_bytes) S.push_back(p);
-      if (!m && pm) E.push_back(p);
+      if (!m && pm && p >= 1) E.push_back(p);
     }
-    const size_t skip = prev_member ? 1 : 0;
-    const size_t have = E.size() >= skip ? E.size() - skip : 0;
-    const bool at_eoi_edge = stage == rend && stage == N;
-    if (have < S.size() && !(at_eoi_edge && have + 1 == S.size())) return -(16 + 1);
-    if (S.size() > 1024) return -(16 + 8);
-    for (size_t i = 0; i < S.size(); i++) {
-      const int64_t e = (skip + i < E.size()) ? E[skip + i] : N;
-      res.push_back(static_cast<int64_t>(tile_lo) + S[i]); res.push_back(static_cast<int64_t>(tile_lo) + e);
+    if (S.size() > 1024 || E.size() > 1024) return -(16 + 8);
+    const size_t open = (prev_member && stage > 0 && member(g[0])) ? 1 : 0;
+    const size_t B = res.size() / 2;
+    for (size_t i = 0; i < S.size(); i++) { res.push_back(static_cast<int64_t>(tile_lo) + S[i]); res.push_back(-1); }
+    for (size_t j = 0; j < E.size(); j++) {
+      const size_t row = B - open + j;
+      if (row >= res.size() / 2) return -3;
+      res[2 * row + 1] = static_cast<int64_t>(tile_lo) + E[j];
     }
   }
+  for (size_t i = 1; i < res.size(); i += 2) if (res[i] < 0) return -3;   // every run found its end
   const int64_t n = static_cast<int64_t>(res.size());
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
