@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — FindAllIndex throughput of the MI355X path on BASELINE.json's headline workload.
+"""bench.py — FindAll throughput of the MI355X path on BASELINE.json's workloads.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config C]     (N > 1: one rank per GPU via torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): FindAllIndex of `\\d+\\.\\d+\\.\\d+\\.\\d+` over 1 GiB of synthetic
-log lines ("synthlog-v1" config 2) per GPU, corpus resident in HBM before the timed region,
-match spans written to HBM as int64 pairs inside it.  A step = one full pass over the rank's shard.
-The path shards by byte range with no data-path collective (page-aligned shards are independent,
-DESIGN.md "Multi-GPU"), so scaling is weak: value = all ranks' bytes / max-over-ranks time.
+Default workload = BASELINE.json configs[1] (--config 2): FindAllIndex of `\\d+\\.\\d+\\.\\d+\\.\\d+` over 1 GiB of
+synthetic log lines ("synthlog-v1" config 2) per GPU, corpus resident in HBM before the timed region, match
+spans written to HBM as int64 pairs inside it.  A step = one full pass of the hot path over the rank's shard.
+--config 1/3/4/5 run the other BASELINE configurations the same way (their lines are kept under profiles/).
+The path shards by byte range with no data-path collective (page-aligned shards are independent, DESIGN.md
+"Multi-GPU"): by default every rank scans --gib-per-gpu (weak scaling, value = all ranks' bytes / max-over-ranks time);
+--total-gib T splits a fixed corpus (north star: 64 GiB over 8 GPUs = 8 GiB per GPU) and reports "strong".
 
 Extra objects on the JSON line:
-  roofline     — HBM-bound; achieved = algorithmic bytes (N + 16*M) per launch / mean kernel time,
-                 the kernel time measured with HIP events on the launch stream inside the library.
-  cpu_baseline — rank 0, N=1 only: C++ port of the reference's CPU algorithm for this strategy
-                 (oracle/cpu_baseline.cpp), 1 thread, on the same corpus; its spans double as a
-                 full-size parity check of the GPU result.
+  roofline     — HBM-bound; achieved = algorithmic bytes (N + W*M, W = 16 B per span, 64 B per e-mail capture row) per
+                 launch / mean kernel time, the kernel time measured with HIP events on the launch stream inside the
+                 library (cxg_timing.kernel_ms); `kernel` is the family that really ran (cxg_timing.kernel).
+  cpu_baseline — rank 0, N = 1 only: C++ port of the reference's CPU algorithm for the configuration's strategy
+                 (oracle/cpu_baseline.cpp: AVX2 digit scan + flat DFA, memmem, SSSE3 Teddy, scalar LUT, PikeVM), one
+                 thread (the reference runs a search on the caller's goroutine) on a bounded sample of the same corpus,
+                 plus the same port on all host cores over page-aligned blocks; its rows double as a parity check of the
+                 GPU's rows on the sample.
 """
 import argparse
 import ctypes as C
@@ -27,24 +32,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PATTERN = r"\d+\.\d+\.\d+\.\d+"
-SYNTH_CONFIG = 2
-SEED = 0xC0FFEE02
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+LITS16 = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
+CONFIGS = {   # BASELINE.json configs[c - 1]; synthlog-v1 config c, seed 0xC0FFEE00 + c
+    1: {"pattern": r"error", "op": "FindAllIndex", "label": "configs[0] (`error` literal; run on the device here)", "cpu_sample_mib": 1024},
+    2: {"pattern": r"\d+\.\d+\.\d+\.\d+", "op": "FindAllIndex", "label": "configs[1]", "cpu_sample_mib": 1024},
+    3: {"pattern": LITS16, "op": "FindAllIndex", "label": "configs[2] (16-literal alternation)", "cpu_sample_mib": 1024},
+    4: {"pattern": r"[\w]+", "op": "FindAllIndex", "label": "configs[3]", "cpu_sample_mib": 1024},
+    5: {"pattern": r"(\w+)@(\w+)\.(\w+)", "op": "FindAllSubmatchIndex", "label": "configs[4]", "cpu_sample_mib": 32},
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # The kernel time of this workload drifts for the first ~30 launches after idle (0.31 -> 0.34 -> 0.30 ms, clock /
-    # power management, scripts/time_dist.py): --settle passes run before the W warm-up steps.
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    # The kernel time drifts for the first ~30 launches after idle (0.31 -> 0.34 -> 0.30 ms, clock / power management):
+    # --settle untimed passes run before the W warm-up steps so that a short --warmup still times the steady state.
     ap.add_argument("--settle", type=int, default=40, help="untimed passes before the warm-up steps (clock settling)")
-    ap.add_argument("--gib-per-gpu", type=float, default=1.0)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE configuration (2 = headline)")
+    ap.add_argument("--gib-per-gpu", type=float, default=1.0, help="weak scaling: bytes per rank (BASELINE configs[1]: 1 GiB)")
+    ap.add_argument("--total-gib", type=float, default=0.0, help="strong scaling: fixed corpus split over the ranks (north star: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pattern", default=PATTERN)
-    ap.add_argument("--synth-config", type=int, default=SYNTH_CONFIG)
+    ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
+    ap.add_argument("--synth-config", type=int, default=None)
     args = ap.parse_args()
 
     import numpy as np
@@ -59,26 +71,34 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max-over-ranks only
 
     import coregex_amd as cx
     cx.set_device(local_rank)
     assert cx.device_count() > local_rank, "no MI355X visible to the HIP library"
 
-    rx = cx.compile(args.pattern)
-    if not rx.supported:
+    cfg = CONFIGS[args.config]
+    pattern = args.pattern or cfg["pattern"]
+    synth = args.synth_config or args.config
+    seed = 0xC0FFEE00 + synth
+    submatch = cfg["op"] == "FindAllSubmatchIndex" and args.pattern is None
+    rx = cx.compile(pattern)
+    if not (rx.submatch_supported if submatch else rx.supported):
         raise SystemExit(f"pattern not supported by the device path: {rx.why_unsupported}")
-    npages = int(args.gib_per_gpu * (1 << 30)) // 4096
+    gib = args.total_gib / world if args.total_gib > 0 else args.gib_per_gpu
+    npages = int(gib * (1 << 30)) // 4096
     nbytes = npages * 4096
     buf = cx.DeviceBuffer(nbytes)
-    buf.fill_synth(args.synth_config, SEED, rank * npages)          # shard = pages [rank*npages, (rank+1)*npages)
+    buf.fill_synth(synth, seed, rank * npages)                      # shard = pages [rank * npages, (rank + 1) * npages)
     base = rank * nbytes
-    nmatch = rx.find_all_device(buf.ptr, nbytes)                     # sizes the output array
-    out = torch.empty((nmatch + 16, 2), dtype=torch.int64, device="cuda")
-    stream = 0                                                        # the library's own stream; events are recorded on it
+    width = 2 * rx.num_groups if submatch else 2
+    scan = rx.find_all_submatch_device if submatch else rx.find_all_device
+    nmatch = scan(buf.ptr, nbytes)                                   # sizes the output array
+    out = torch.empty((nmatch + 16, width), dtype=torch.int64, device="cuda")
+    stream = 0                                                       # the library's own stream; events are recorded on it
 
     def step(timing=None):
-        n = rx.find_all_device(buf.ptr, nbytes, out.data_ptr(), nmatch + 16, base=base, stream=stream, timing=timing)
+        n = scan(buf.ptr, nbytes, out.data_ptr(), nmatch + 16, base=base, stream=stream, timing=timing)
         assert n == nmatch or os.environ.get("CXG_DEBUG"), (n, nmatch)
         return n
 
@@ -87,21 +107,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Clock settling: the first ~30 launches after idle drift (scripts/time_dist.py); these untimed passes come
-    # before the W warm-up steps of the contract so that a short --warmup still times the steady state.
     for _ in range(args.settle):
         step()
     for _ in range(args.warmup):
         step()
     t = cx.Timing()
-    kernel_ms = []
+    kernel_ms, kernels, launches = [], set(), 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(t)
         kernel_ms.append(t.kernel_ms)
+        kernels.add(int(t.kernel))
+        launches = max(launches, int(t.n_launches))
     barrier()
     elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean(kernel_ms))
+    per_rank_ms = [k_ms]
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -109,18 +131,23 @@ def main():
         tm = torch.tensor([float(nmatch)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tm, op=dist.ReduceOp.SUM)
         total_matches = int(tm.item())
+        tk = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tk[rank] = k_ms
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
     else:
         total_matches = nmatch
 
     ms_per_step = elapsed * 1e3 / args.steps
     total_bytes = nbytes * world
     value = total_bytes / (elapsed / args.steps) / 1e9
-    k_ms = float(np.mean(kernel_ms))
-    alg_bytes = nbytes + 16 * nmatch                                  # per launch, this rank (DESIGN.md "Roofline")
+    row_bytes = 8 * width
+    alg_bytes = nbytes + row_bytes * nmatch                          # per launch, this rank (DESIGN.md "Roofline")
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    kname = "+".join(cx._lib.lib().cxg_kernel_name(k).decode() for k in sorted(kernels))
 
     result = {
-        "metric": "GB/s haystack scanned, FindAllIndex IP-regex",
+        "metric": "GB/s haystack scanned, FindAllIndex IP-regex" if args.config == 2 and args.pattern is None else f"GB/s haystack scanned, {cfg['op']}",
         "value": round(value, 3),
         "unit": "GB/s",
         "n_gpus": world,
@@ -128,17 +155,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.total_gib > 0 else "weak",
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": f"FindAllIndex `{args.pattern}` over {args.gib_per_gpu:g} GiB/GPU synthlog-v1 config {args.synth_config} "
-                        f"(BASELINE.json configs[1]), corpus resident in HBM, int64 span pairs written to HBM",
+            "workload": f"{cfg['op']} `{pattern}` over {gib:g} GiB/GPU synthlog-v1 config {synth} (BASELINE.json {cfg['label']}), "
+                        f"corpus resident in HBM, int64 rows of {width} written to HBM",
+            "baseline_config": args.config,
             "strategy": rx.strategy,
             "bytes_per_gpu": nbytes,
             "matches_total": total_matches,
             "sharding": f"byte-range x{world}, page-aligned, no collective on the data path",
+            "rccl_world_size": world,
+            "per_rank_kernel_ms": per_rank_ms,
         },
         "roofline": {
             "bound": "hbm",
@@ -146,55 +176,107 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic(args, nbytes),
-            "kernel": {"1": "k_scan_dfa<digit>", "2": "k_scan_digit_flat", "3": "k_scan_digit_list", "4": "k_scan_digit_chain", "5": "k_scan_digit_wave"}.get(os.environ.get("CXG_DIGIT_KERNEL", "6"), "k_scan_chain_wave<2,false,false,false,4>") if rx.strategy == "UseDigitPrefilter" else rx.strategy,
+            "traffic": _pmc_traffic(args.config if args.pattern is None else 0, nbytes, kname),
+            "kernel": kname,
+            "launches_per_step": launches,
             "kernel_ms_avg": round(k_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_row": row_bytes,
             "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),
         },
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and rx.strategy == "UseDigitPrefilter" and not os.environ.get("CXG_DEBUG"):
-        from oracle import oracle as O
-        L = O.lib()
-        L.orc_baseline_digit_find_all.restype = C.c_int64
-        L.orc_baseline_digit_find_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
-        sample_bytes = min(nbytes, 1 << 30)
-        host = buf.download(0, sample_bytes)                          # the very bytes the GPU scanned
-        orx = O.Regex(args.pattern)
-        spans = np.empty(2 * (nmatch + 16), dtype=np.int64)
-        c0 = time.perf_counter()
-        nv = L.orc_baseline_digit_find_all(orx._h, host.ctypes.data, host.size, spans.ctypes.data, spans.size)
-        cpu_s = time.perf_counter() - c0
-        cpu_spans = spans[:nv].reshape(-1, 2)
-        gpu_spans = out[:nmatch].cpu().numpy() - base
-        if sample_bytes == nbytes:
-            same = cpu_spans.shape == gpu_spans.shape and bool(np.array_equal(cpu_spans, gpu_spans))
-        else:
-            k = len(cpu_spans)
-            same = bool(np.array_equal(cpu_spans[: k - 1], gpu_spans[: k - 1]))
-        if not same:
-            raise SystemExit("PARITY FAILURE: GPU spans differ from the CPU port on the benchmark corpus")
-        result["cpu_baseline"] = {
-            "value": round(sample_bytes / cpu_s / 1e9, 4),
-            "unit": "GB/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": f"first {sample_bytes >> 20} MiB of the same corpus (downloaded from HBM), {cpu_s:.1f} s, "
-                      f"AVX2 digit scan + flat-table anchored DFA + run skip, g++ -O2 -mavx2; spans equal the GPU's",
-            "host_cpu": _cpu_model(),
-            "host_threads_available": os.cpu_count(),
-        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
+        result["cpu_baseline"] = _cpu_baseline(args.config, cfg, pattern, buf, out, nmatch, nbytes, width, base)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def _pmc_traffic(args, nbytes):
+def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
+    """One thread and all cores, on a bounded sample of the very bytes the GPU scanned; parity of the rows on the sample."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    L = O.lib()
+    i64, vp = C.c_int64, C.c_void_p
+    for name in ("orc_baseline_digit_find_all", "orc_baseline_teddy_find_all", "orc_baseline_charclass_find_all"):
+        getattr(L, name).restype = i64
+        getattr(L, name).argtypes = [vp, vp, i64, vp, i64]
+    L.orc_baseline_literal_find_all.restype = i64
+    L.orc_baseline_literal_find_all.argtypes = [C.c_char_p, i64, vp, i64, vp, i64]
+    lit = pattern.encode()
+    ports = {
+        1: ("glibc memmem (the reference: rare-byte pair scan, simd/memmem.go:53) + FindAll loop", lambda h, p, n, o, c: L.orc_baseline_literal_find_all(lit, len(lit), p, n, o, c)),
+        2: ("AVX2 digit scan + flat-table anchored DFA + run skip", lambda h, p, n, o, c: L.orc_baseline_digit_find_all(h, p, n, o, c)),
+        3: ("SSSE3 Slim Teddy (PSHUFB nibble masks, 2-byte fingerprint) + verifyBucket", lambda h, p, n, o, c: L.orc_baseline_teddy_find_all(h, p, n, o, c)),
+        4: ("scalar 256-entry membership LUT, one byte per iteration", lambda h, p, n, o, c: L.orc_baseline_charclass_find_all(h, p, n, o, c)),
+        5: ("PikeVM with slot tables (the oracle's restatement of nfa/pikevm.go)", lambda h, p, n, o, c: L.orc_find_all_submatch(h, p, n, -1, o, c)),
+    }
+    what, port = ports[config]
+    sample = min(nbytes, cfg["cpu_sample_mib"] << 20)
+    host = buf.download(0, sample)                                    # the very bytes the GPU scanned
+    gpu_rows = out[:nmatch].cpu().numpy()
+    gpu_rows = np.where(gpu_rows < 0, gpu_rows, gpu_rows - base)
+    k_in = int(np.searchsorted(gpu_rows[:, 1], sample, side="right"))   # rows that end inside the sample
+    # ---- one thread
+    eng = O.Regex(pattern)
+    rows = np.empty((k_in + 64) * width, dtype=np.int64)
+    c0 = time.perf_counter()
+    nv = port(eng._h, host.ctypes.data, host.size, rows.ctypes.data, rows.size)
+    cpu_s = time.perf_counter() - c0
+    if nv < 0 or nv > rows.size:
+        raise SystemExit(f"cpu baseline port failed for config {config} ({nv})")
+    cpu_rows = rows[:nv].reshape(-1, width)
+    same = len(cpu_rows) >= k_in and bool(np.array_equal(cpu_rows[:k_in], gpu_rows[:k_in]))
+    if not same:
+        raise SystemExit("PARITY FAILURE: GPU rows differ from the CPU port on the benchmark corpus")
+    # ---- all cores: page-aligned blocks are independent (every page ends in '\n'), one engine per thread
+    threads = max(1, len(os.sched_getaffinity(0)))
+    rate1 = sample / cpu_s                                            # bound the all-cores leg to ~10 s of wall time
+    all_sample = int(min(nbytes, 1 << 30, max(sample, rate1 * threads * 10.0))) // 4096 * 4096
+    big = host if all_sample == sample else buf.download(0, all_sample)
+    nblk = threads * 4
+    pages = all_sample // 4096
+    cuts = [(pages * i // nblk) * 4096 for i in range(nblk + 1)]
+    engines = [O.Regex(pattern) for _ in range(threads)]
+    counts = [0] * nblk
+
+    def work(tid):
+        e = engines[tid]
+        scratch = np.empty(max(4096, (cuts[1] - cuts[0]) // 4), dtype=np.int64)   # the ports count past the capacity
+        for b in range(tid, nblk, threads):
+            lo, hi = cuts[b], cuts[b + 1]
+            if hi > lo:
+                counts[b] = port(e._h, big.ctypes.data + lo, hi - lo, scratch.ctypes.data, scratch.size)
+
+    a0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(work, range(threads)))
+    all_s = time.perf_counter() - a0
+    k_all = int(np.searchsorted(gpu_rows[:, 1], all_sample, side="right"))
+    if sum(counts) // width != k_all:
+        raise SystemExit(f"PARITY FAILURE: all-cores CPU port counted {sum(counts) // width} rows, the GPU {k_all}")
+    return {
+        "value": round(sample / cpu_s / 1e9, 4),
+        "unit": "GB/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample >> 20} MiB of the same corpus (downloaded from HBM), {cpu_s:.1f} s, {what}, g++ -O3 -mavx2; "
+                  f"rows equal the GPU's.  Digit-dense synthlog text: not comparable with the reference's published "
+                  f"figures on sparse input (BASELINE.md)",
+        "all_cores": {"value": round(all_sample / all_s / 1e9, 3), "unit": "GB/s", "cores": threads,
+                      "sample": f"first {all_sample >> 20} MiB in {nblk} page-aligned blocks, one engine per thread, {all_s:.2f} s wall; row count equals the GPU's"},
+        "host_cpu": _cpu_model(),
+        "host_threads_available": os.cpu_count(),
+    }
+
+
+def _pmc_traffic(config, nbytes, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this very command
-    (profiles/*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled
-    per MI355X_MICROARCH.md "HBM" for wide coalesced reads on gfx950).  None when no profile matches the workload:
+    (profiles/r*_cfgN_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md "HBM" for wide coalesced reads on gfx950).  None when no profile matches workload and kernel:
     counters cannot be read from inside the timed process."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
@@ -202,8 +284,8 @@ def _pmc_traffic(args, nbytes):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("pattern") == args.pattern and d.get("synth_config") == args.synth_config and d.get("bytes_per_gpu") == nbytes \
-                and d.get("digit_kernel", "6") == os.environ.get("CXG_DIGIT_KERNEL", "6"):
+        if d.get("baseline_config", 2 if d.get("synth_config") == 2 else None) == config and d.get("bytes_per_gpu") == nbytes \
+                and kernel.split("<")[0] in d.get("kernel", ""):
             return d.get("traffic_bytes_per_launch")
     return None
 

@@ -97,3 +97,99 @@ extern "C" int64_t orc_baseline_digit_find_all(void* ev, const uint8_t* h, int64
   }
   return n;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ports of the reference's CPU paths for the other BASELINE configurations (bench.py --config N, cpu_baseline leg).
+// Same rule as above: written the way the reference runs on amd64, results checked against the plain oracle / the GPU
+// by the caller.  All single-threaded; bench.py runs them on page-aligned blocks from many threads for the all-cores leg.
+
+// Config 3, UseTeddy: Slim Teddy, 2-byte fingerprint, 16 bytes per iteration with SSSE3 PSHUFB nibble lookups
+// (prefilter/teddy_ssse3_amd64.s:273-480: lo/hi nibble masks of fingerprint byte 0 and of byte 1 shifted by one
+// position, AND, PMOVMSKB of the non-zero bytes), then verifyBucket (prefilter/teddy.go:532-550) per candidate, buckets
+// low to high, ids ascending; FindAll loop of meta/find_indices.go:925-951 / meta/findall.go:176-283 around it.
+extern "C" int64_t orc_baseline_teddy_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
+  Engine* e = static_cast<Engine*>(ev);
+  if (e->strategy != UseTeddy) return -1;
+  const Teddy& t = e->teddy;
+  const __m128i lo0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.lo[0])), hi0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.hi[0]));
+  const __m128i lo1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.lo[1])), hi1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.hi[1]));
+  const __m128i nib = _mm_set1_epi8(0x0F), zero = _mm_setzero_si128();
+  auto verify = [&](int64_t pos, uint32_t mask, int64_t& ms, int64_t& me) -> bool {
+    while (mask) {
+      const int bucket = __builtin_ctz(mask);
+      mask &= mask - 1;
+      if (bucket >= static_cast<int>(t.buckets.size())) continue;
+      for (int id : t.buckets[bucket]) {
+        const auto& p = t.patterns[id];
+        if (pos + static_cast<int64_t>(p.size()) <= len && std::memcmp(h + pos, p.data(), p.size()) == 0) { ms = pos; me = pos + static_cast<int64_t>(p.size()); return true; }
+      }
+    }
+    return false;
+  };
+  auto maskAt = [&](int64_t i) -> uint32_t {       // scalar tail, teddy.go:491-530
+    if (i + 1 >= len) return 0;
+    return (t.lo[0][h[i] & 15] & t.hi[0][h[i] >> 4]) & (t.lo[1][h[i + 1] & 15] & t.hi[1][h[i + 1] >> 4]);
+  };
+  int64_t n = 0, pos = 0;
+  while (pos < len) {
+    int64_t ms = -1, me = -1;
+    int64_t i = pos;
+    bool found = false;
+    for (; i + 17 <= len && !found; i += 16) {
+      const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(h + i));
+      const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(h + i + 1));
+      const __m128i m0 = _mm_and_si128(_mm_shuffle_epi8(lo0, _mm_and_si128(a, nib)), _mm_shuffle_epi8(hi0, _mm_and_si128(_mm_srli_epi16(a, 4), nib)));
+      const __m128i m1 = _mm_and_si128(_mm_shuffle_epi8(lo1, _mm_and_si128(b, nib)), _mm_shuffle_epi8(hi1, _mm_and_si128(_mm_srli_epi16(b, 4), nib)));
+      const __m128i c = _mm_and_si128(m0, m1);
+      uint32_t hits = static_cast<uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(c, zero))) ^ 0xFFFFu;
+      while (hits) {
+        const int k = __builtin_ctz(hits);
+        hits &= hits - 1;
+        alignas(16) uint8_t cm[16];
+        _mm_store_si128(reinterpret_cast<__m128i*>(cm), c);
+        if (verify(i + k, cm[k], ms, me)) { found = true; break; }
+      }
+      if (found) break;
+    }
+    if (!found) for (; i < len; i++) { const uint32_t m = maskAt(i); if (m && verify(i, m, ms, me)) { found = true; break; } }
+    if (!found) break;
+    if (out && n + 2 <= capVals) { out[n] = ms; out[n + 1] = me; }
+    n += 2;
+    pos = me > pos ? me : pos + 1;
+  }
+  return n;
+}
+
+// Config 4, UseCharClassSearcher: the scalar 256-entry membership LUT loop, one byte per iteration
+// (nfa/charclass_searcher.go:158-211 FindAllIndices: state machine over `matching`, trailing run closed at the end).
+extern "C" int64_t orc_baseline_charclass_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
+  Engine* e = static_cast<Engine*>(ev);
+  if (e->strategy != UseCharClassSearcher) return -1;
+  bool lut[256];
+  for (int b = 0; b < 256; b++) lut[b] = e->ccs.membership[b];
+  int64_t n = 0, start = 0;
+  bool matching = false;
+  for (int64_t i = 0; i < len; i++) {
+    const bool m = lut[h[i]];
+    if (!matching) { if (m) { start = i; matching = true; } }
+    else if (!m) { if (out && n + 2 <= capVals) { out[n] = start; out[n + 1] = i; } n += 2; matching = false; }
+  }
+  if (matching) { if (out && n + 2 <= capVals) { out[n] = start; out[n + 1] = len; } n += 2; }
+  return n;
+}
+
+// Config 1, UseDFA with a complete literal prefix (`error`): the reference's memmem prefilter finds every occurrence
+// (prefilter/prefilter.go:440-506 -> simd/memmem.go:53-152, rare-byte pair scan with AVX2) and the literal being the
+// whole pattern each hit is a match.  Port: glibc memmem (AVX2 two-way / pair scan of the same family), FindAll loop.
+extern "C" int64_t orc_baseline_literal_find_all(const uint8_t* lit, int64_t litLen, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
+  int64_t n = 0, pos = 0;
+  while (pos + litLen <= len) {
+    const void* p = memmem(h + pos, static_cast<size_t>(len - pos), lit, static_cast<size_t>(litLen));
+    if (!p) break;
+    const int64_t s = static_cast<const uint8_t*>(p) - h;
+    if (out && n + 2 <= capVals) { out[n] = s; out[n + 1] = s + litLen; }
+    n += 2;
+    pos = s + litLen;
+  }
+  return n;
+}
