@@ -18,6 +18,7 @@
 #include "device/block_common.hpp"
 #include "device/walk.hpp"
 #include "device/fsm.hpp"
+#include "device/bt.hpp"
 #include "host/frontend.h"
 #include "host/program.h"
 
@@ -84,6 +85,7 @@ struct Scratch {
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
+  uint8_t* bt = nullptr; size_t btCap = 0;         // k_captures_bt: per-thread visited bitmap + stack
   // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
   // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
   void release() {
@@ -95,6 +97,7 @@ struct Scratch {
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
+      if (bt) (void)hipFree(bt);
       if (hostCtl) (void)hipHostFree(hostCtl);
       if (pinHay) (void)hipHostFree(pinHay);
       if (pinOut) (void)hipHostFree(pinOut);
@@ -261,6 +264,26 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
     }
   }
   if (bad) cxgdev::raise_err(err, 4u);
+}
+
+// Capture pass, general form (patterns that are not one-pass): bounded backtracking over the NFA per match row
+// (device/bt.hpp).  One thread per row, grid-stride; every thread owns 16 KiB of scratch in HBM (visited bitmap + stack).
+__global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+                                                    const uint8_t* btblob, uint8_t* scratch, uint32_t* err) {
+  const cxgdev::BtHeader* h = reinterpret_cast<const cxgdev::BtHeader*>(btblob);
+  const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
+  uint32_t* visited = reinterpret_cast<uint32_t*>(scratch + tid * (cxgdev::kBtVisitedWords * 4ull + cxgdev::kBtStackEntries * 8ull));
+  uint64_t* stack = reinterpret_cast<uint64_t*>(visited + cxgdev::kBtVisitedWords);
+  uint32_t bad = 0;
+  for (uint64_t r = tid; r < nrows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    int64_t* row = rows + r * width;
+    const uint64_t bits = (static_cast<uint64_t>(row[1] - row[0]) + 1) * h->n_states;
+    const uint32_t nw = bits > static_cast<uint64_t>(cxgdev::kBtVisitedWords) * 32u ? 0u : static_cast<uint32_t>((bits + 31) >> 5);
+    for (uint32_t i = 0; i < nw; i++) visited[i] = 0u;
+    bad |= cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack);   // rows hold absolute offsets (hay_base added)
+  }
+  if (bad & 1u) cxgdev::raise_err(err, cxgdev::kErrSerialLimit);   // a match too long for the per-row budget: this haystack is left to the caller
+  if (bad & 2u) cxgdev::raise_err(err, 4u);
 }
 
 // One resident round of capture workgroups: as many as the LDS footprint lets a CU hold (grid-stride over the rows),
@@ -450,8 +473,18 @@ relaunch:
     if (static_cast<uint32_t>(s.hostCtl[2]) & (8u | 2u)) nrows = 0;   // the span kernel asked for a rerun: its rows are not final
     if (nrows) {
       const cxgdev::CapHeader* chh = reinterpret_cast<const cxgdev::CapHeader*>(p->capBlob.data());
-      const bool lds_ok = chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
-      if (lds_ok && a.row_width <= 8) {
+      const bool lds_ok = chh->magic != cxgdev::kBtMagic && chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
+      if (chh->magic == cxgdev::kBtMagic) {                        // not one-pass: backtracking per row
+        const unsigned blk = 64, grd = static_cast<unsigned>(std::min<uint64_t>((nrows + blk - 1) / blk, 64));   // <= 4096 threads x 16 KiB
+        const size_t need = static_cast<size_t>(grd) * blk * (cxgdev::kBtVisitedWords * 4ull + cxgdev::kBtStackEntries * 8ull);
+        if (s.btCap < need) {
+          if (s.bt) HIP_TRY(hipFree(s.bt));
+          s.bt = nullptr; s.btCap = 0;
+          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bt), need));
+          s.btCap = need;
+        }
+        hipLaunchKernelGGL(k_captures_bt, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+      } else if (lds_ok && a.row_width <= 8) {
         const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
         hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
       } else if (lds_ok && a.row_width <= 16) {

@@ -1,6 +1,7 @@
 // See program.h.
 #include "program.h"
 #include "fsm.h"
+#include "../device/bt.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -919,7 +920,8 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
       std::string w;
       if (!buildFsmImage(nfa, rev, 0u, p->subFsmBlob, w)) p->subFsmBlob.clear();
     }
-    // ---- one-pass capture table
+    // ---- one-pass capture table; patterns that are not one-pass get the backtracking image instead (device/bt.hpp)
+    try {
     CapClosure cc(nfa);
     std::vector<uint32_t> entryState;             // entry id -> NFA state whose closure is taken
     std::map<uint32_t, uint32_t> entryOf;
@@ -979,6 +981,43 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
     std::memcpy(cb.data(), &ch, sizeof ch);
     p->capBlob.swap(cb);
     if (spanChain.nops) deriveChainCaps(spanChain, p->capBlob, nfa.capture_count * 2, p->chainCaps);
+    } catch (const BuildError& onePassErr) {
+      // General capture pass: the NFA itself, walked depth-first in priority order per match row.
+      if (nfa.n_states > 4096 || nfa.n_trans > (1u << 20)) throw;
+      cxgdev::BtHeader bh;
+      std::memset(&bh, 0, sizeof bh);
+      bh.magic = cxgdev::kBtMagic; bh.n_states = nfa.n_states; bh.n_trans = nfa.n_trans; bh.start = nfa.start_anchored;
+      bh.nslots = nfa.capture_count * 2;
+      std::vector<uint8_t> bb(sizeof bh, 0);
+      bh.states_off = static_cast<uint32_t>(bb.size());
+      for (uint32_t i = 0; i < nfa.n_states; i++) {
+        const cxg_nfa_state& x = nfa.states[i];
+        cxgdev::BtState t;
+        std::memset(&t, 0, sizeof t);
+        t.kind = x.kind; t.lo = x.lo; t.hi = x.hi;
+        t.next = x.kind == CXG_NFA_SPLIT ? x.left : x.next;
+        t.alt = x.kind == CXG_NFA_SPLIT ? x.right : cxgdev::kBtInvalid;
+        if (x.kind == CXG_NFA_CAPTURE) { const uint32_t sl = x.cap_index * 2 + (x.cap_start ? 0u : 1u); t.cap_slot = static_cast<uint8_t>(sl < 255 ? sl : 255); }
+        if (x.kind == CXG_NFA_SPARSE) {
+          if (x.trans_len > 0xFFFu) throw BuildError{CXG_E_UNSUPPORTED, "sparse state with more than 4095 transitions"};
+          t.trans_off_len = (x.trans_off << 12) | x.trans_len;
+        }
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
+        bb.insert(bb.end(), q, q + sizeof t);
+      }
+      bh.trans_off = static_cast<uint32_t>(bb.size());
+      for (uint32_t i = 0; i < nfa.n_trans; i++) {
+        cxgdev::BtTrans t{nfa.trans[i].lo, nfa.trans[i].hi, 0, nfa.trans[i].next};
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
+        bb.insert(bb.end(), q, q + sizeof t);
+      }
+      while (bb.size() % 16) bb.push_back(0);
+      bh.total_bytes = static_cast<uint32_t>(bb.size());
+      std::memcpy(bb.data(), &bh, sizeof bh);
+      p->capBlob.swap(bb);
+      std::memset(p->chainCaps, 0, sizeof p->chainCaps);
+      (void)onePassErr;
+    }
     p->subSupported = true;
   } catch (const BuildError& e) {
     p->subWhyNot = e.msg;

@@ -11,6 +11,7 @@
 
 #include "../../coregex_amd/csrc/device/scan_dfa.h"
 #include "../../coregex_amd/csrc/device/walk.hpp"
+#include "../../coregex_amd/csrc/device/bt.hpp"
 
 using namespace cxgdev;
 
@@ -121,6 +122,22 @@ extern "C" int64_t emu_find_all_submatch(const uint8_t* span_blob, const uint8_t
   if (n > static_cast<int64_t>(spans.size())) {
     spans.resize(n);
     n = emu_find_all(span_blob, hay, len, chunk, spans.data(), n, 0);
+  }
+  if (reinterpret_cast<const BtHeader*>(cap_blob)->magic == kBtMagic) {     // not one-pass: backtracking per row (k_captures_bt)
+    const BtHeader* bh = reinterpret_cast<const BtHeader*>(cap_blob);
+    const uint32_t w = bh->nslots;
+    const int64_t rows = n / 2;
+    if (!out || rows * w > cap_vals) return rows * w;
+    std::vector<uint32_t> visited(kBtVisitedWords);
+    std::vector<uint64_t> stack(kBtStackEntries);
+    for (int64_t i = 0; i < rows; i++) {
+      int64_t* row = out + i * w;
+      row[0] = spans[2 * i]; row[1] = spans[2 * i + 1];
+      std::fill(visited.begin(), visited.end(), 0u);
+      const uint32_t rc = bt_captures(bh, hay, row, w, visited.data(), stack.data());
+      if (rc) return -3 - static_cast<int64_t>(rc);
+    }
+    return rows * w;
   }
   const CapHeader* ch = reinterpret_cast<const CapHeader*>(cap_blob);
   CapView cv{cap_blob + ch->next_off, cap_blob + ch->maskid_off, cap_blob + ch->fin_off,

@@ -600,7 +600,8 @@ def test_find_all_submatch_index(need_gpu, oracle):
     """BASELINE config 5: `(\\w+)@(\\w+)\\.(\\w+)` FindAllSubmatchIndex, rows of 2*groups int64, -1 unset."""
     import torch
     pats = [r"(\w+)@(\w+)\.(\w+)", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a)(b)?c", r"(\w+)=(\d+)", r"((a+)(b+))", r"([a-z]+)=(\d+)", r"(ab)c(d)",
-            r"x(\d+)y(\d+)z", r"([a-z])+@", r"(\d+)-(\d+)"]
+            r"x(\d+)y(\d+)z", r"([a-z])+@", r"(\d+)-(\d+)",
+            r"(a|ab)(c|bcd)", r"(a+)(a*)", r"(ab|a)(bc|c)?", r"(\w+)=(\w+|\d+)", r"((a)|(ab))((c)|(bcd))"]     # not one-pass: backtracking capture pass
     corpus = generate_test_input()
     for pat in pats:
         rx = cx.compile(pat)

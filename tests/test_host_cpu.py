@@ -674,8 +674,22 @@ def test_submatch_programs_emulated(oracle):
         checked += 1
     assert checked >= 8
     assert cx.compile(r"(\w+)@(\w+)\.(\w+)").submatch_supported
-    amb = cx.compile(r"(a|ab)(c|bcd)")       # two NFA paths accept 'a': not one-pass
-    assert not amb.submatch_supported and "one-pass" in cx._lib.lib().cxg_last_error().decode()
+    # not one-pass (two NFA paths accept 'a'; `a+` then `a*`): the general capture pass — bounded backtracking over the NFA
+    # per match row, device/bt.hpp — gives the PikeVM's slots
+    import struct
+    for pat in (r"(a|ab)(c|bcd)", r"(a+)(a*)", r"(a*)(a+)b", r"((a)|(ab))((c)|(bcd))", r"(ab|a)(bc|c)?", r"(a+|b+)*c", r"(\w+)=(\w+|\d+)"):
+        p = cx.compile(pat)
+        assert p.submatch_supported, pat
+        sb, cb = p.submatch_blobs()
+        if pat != r"(a+|b+)*c":
+            assert struct.unpack_from("<I", cb, 0)[0] == 0x43584254, pat      # "CXBT": the backtracking image
+        o = oracle.Regex(pat)
+        w = 2 * p.num_groups
+        for _ in range(80):
+            hay = alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(0, 300)))].tobytes()
+            assert emu.find_all_submatch(sb, cb, hay, w, 4).tolist() == o.find_all_submatch_index(hay).tolist(), (pat, hay)
+        hay = (b"abcd ab abc abcd aaaa b a=1 ab=cd " * 200)
+        assert emu.find_all_submatch(sb, cb, hay, w, 64).tolist() == o.find_all_submatch_index(hay).tolist(), pat
 
 
 def test_teddy_programs(oracle):
