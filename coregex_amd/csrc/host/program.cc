@@ -4,6 +4,7 @@
 #include "../device/bt.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <map>
 
@@ -1162,12 +1163,16 @@ void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint
 
 // Device image of a literal set (kKindTeddy): fingerprint tables + the literals for exact verification.
 // NewTeddy / buildMasks (prefilter/teddy.go:189-311): 2..32 literals of >= 3 bytes, bucket = id mod 8,
-// 2-byte fingerprint.  33..64 literals (Fat Teddy) and > 64 (Aho-Corasick) are outside the device subset.
+// 2-byte fingerprint.  33..64 literals are the reference's Fat Teddy (prefilter/teddy_fat.go:127-253, bucket = id mod 16):
+// the device keeps ONE 8-bit mask per fingerprint byte and folds bucket b and b+8 together.  That only widens the
+// candidate set; every candidate is verified against the literals, and for a prefix-free set (required below) at most
+// one literal matches at a position, so the bucket order of verifyBucket (teddy_fat.go:471-487) cannot be observed.
+// > 64 literals (Aho-Corasick) are outside the device subset.
 // min_count 1: a single literal of a UseDFA program (buildProgramFromNfa) searched with the same kernels.
 // Literal tables of the Teddy kernels (walk.hpp TeddyAux + arrays), appended to `aux`; false + why when the set is
 // outside the device subset.
 bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why) {
-  if (lits.size() < min_count || lits.size() > 32) { why = "Slim Teddy takes 2..32 literals"; return false; }
+  if (lits.size() < min_count || lits.size() > 64) { why = "Teddy takes 2..64 literals"; return false; }
   size_t minlen = SIZE_MAX, maxlen = 0;
   for (auto& l : lits) { minlen = std::min(minlen, l.size()); maxlen = std::max(maxlen, l.size()); }
   if (minlen < 3) { why = "Teddy literal shorter than 3 bytes"; return false; }
@@ -1178,15 +1183,28 @@ bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_co
         why = "literal set is not prefix-free (the reference's verification order becomes observable)";
         return false;
       }
-  const uint32_t nb = static_cast<uint32_t>(std::min<size_t>(8, lits.size()));
-  uint16_t ab[256] = {0};
+  // Buckets.  The reference deals literals round-robin (bucket = id mod 8, teddy.go:283; mod 16 for Fat Teddy,
+  // teddy_fat.go:209) and filters with nibble-mask products.  Neither is observable here: the set is prefix-free, so at
+  // most one literal matches at a position whatever order the buckets are verified in, and any superset of the match
+  // starts is a valid candidate set.  The device therefore (i) keeps EXACT per-byte masks (its lookup table has 256
+  // entries anyway) and (ii) puts literals that share their first three bytes into one bucket and deals the distinct
+  // prefixes, in lexicographic order, contiguously over the 8 buckets: a bucket's false candidates are the mixed
+  // triples of its prefixes, and neighbours in that order share leading bytes.  48 literals with 8 distinct prefixes
+  // then filter exactly on three bytes (round robin: 7 % of all bytes of a word-like text were candidates).
+  std::vector<uint8_t> bucketOf(lits.size(), 0);
+  uint32_t nb = 0;
   {
-    uint8_t lo[2][16] = {{0}}, hi[2][16] = {{0}};
-    for (size_t id = 0; id < lits.size(); id++) {
-      const uint8_t bit = static_cast<uint8_t>(1u << (id % nb));
-      for (int pos = 0; pos < 2; pos++) { lo[pos][lits[id][pos] & 15] |= bit; hi[pos][lits[id][pos] >> 4] |= bit; }
-    }
-    for (int b = 0; b < 256; b++) ab[b] = static_cast<uint16_t>((lo[0][b & 15] & hi[0][b >> 4]) | ((lo[1][b & 15] & hi[1][b >> 4]) << 8));
+    std::map<std::array<uint8_t, 3>, std::vector<size_t>> byPrefix;
+    for (size_t id = 0; id < lits.size(); id++) byPrefix[{lits[id][0], lits[id][1], lits[id][2]}].push_back(id);
+    const size_t ng = byPrefix.size();
+    nb = static_cast<uint32_t>(std::min<size_t>(8, ng));
+    size_t g = 0;
+    for (auto& kv : byPrefix) { for (size_t id : kv.second) bucketOf[id] = static_cast<uint8_t>(g * nb / ng); g++; }
+  }
+  uint16_t ab[256] = {0};
+  for (size_t id = 0; id < lits.size(); id++) {
+    ab[lits[id][0]] |= static_cast<uint16_t>(1u << bucketOf[id]);
+    ab[lits[id][1]] |= static_cast<uint16_t>(0x100u << bucketOf[id]);
   }
   cxgdev::TeddyAux ax;
   std::memset(&ax, 0, sizeof ax);
@@ -1196,13 +1214,13 @@ bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_co
   ax.ab_off = static_cast<uint32_t>(aux.size());
   aux.insert(aux.end(), reinterpret_cast<uint8_t*>(ab), reinterpret_cast<uint8_t*>(ab) + sizeof ab);
   ax.order_off = static_cast<uint32_t>(aux.size());
-  for (uint32_t b = 0; b < nb; b++) for (size_t id = b; id < lits.size(); id += nb) aux.push_back(static_cast<uint8_t>(id));
+  for (uint32_t b = 0; b < nb; b++) for (size_t id = 0; id < lits.size(); id++) if (bucketOf[id] == b) aux.push_back(static_cast<uint8_t>(id));
   align(4);
   ax.lens_off = static_cast<uint32_t>(aux.size());
   for (auto& l : lits) aux.push_back(static_cast<uint8_t>(l.size()));
   align(4);
   ax.bucket_off = static_cast<uint32_t>(aux.size());
-  for (size_t id = 0; id < lits.size(); id++) aux.push_back(static_cast<uint8_t>(id % nb));
+  for (size_t id = 0; id < lits.size(); id++) aux.push_back(bucketOf[id]);
   align(4);
   ax.off_off = static_cast<uint32_t>(aux.size());
   { uint16_t o = 0; for (auto& l : lits) { aux.push_back(o & 0xFF); aux.push_back(o >> 8); o = static_cast<uint16_t>(o + l.size()); } }

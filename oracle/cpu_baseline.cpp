@@ -111,8 +111,11 @@ extern "C" int64_t orc_baseline_teddy_find_all(void* ev, const uint8_t* h, int64
   Engine* e = static_cast<Engine*>(ev);
   if (e->strategy != UseTeddy) return -1;
   const Teddy& t = e->teddy;
-  const __m128i lo0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.lo[0])), hi0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.hi[0]));
-  const __m128i lo1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.lo[1])), hi1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.hi[1]));
+  if (t.buckets.size() > 8) return -1;                 // Fat Teddy (AVX2, 16 buckets) has no SIMD port here
+  alignas(16) uint8_t l8[2][16], h8[2][16];            // the oracle keeps u16 masks (fat); slim uses the low byte
+  for (int p = 0; p < 2; p++) for (int k = 0; k < 16; k++) { l8[p][k] = static_cast<uint8_t>(t.lo[p][k]); h8[p][k] = static_cast<uint8_t>(t.hi[p][k]); }
+  const __m128i lo0 = _mm_load_si128(reinterpret_cast<const __m128i*>(l8[0])), hi0 = _mm_load_si128(reinterpret_cast<const __m128i*>(h8[0]));
+  const __m128i lo1 = _mm_load_si128(reinterpret_cast<const __m128i*>(l8[1])), hi1 = _mm_load_si128(reinterpret_cast<const __m128i*>(h8[1]));
   const __m128i nib = _mm_set1_epi8(0x0F), zero = _mm_setzero_si128();
   auto verify = [&](int64_t pos, uint32_t mask, int64_t& ms, int64_t& me) -> bool {
     while (mask) {

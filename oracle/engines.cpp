@@ -521,8 +521,11 @@ bool PikeVM::searchAt(Bytes h, int64_t n, int64_t at, int64_t& s, int64_t& e) {
 
 // =============================================================== Teddy
 bool Teddy::build(const std::vector<std::vector<uint8_t>>& pats) {
-  // NewTeddy teddy.go:189-253 (2..32 patterns, each >= 3 bytes), buildMasks :271-311
-  if (pats.size() < 2 || pats.size() > 32) return false;
+  // NewTeddy teddy.go:189-253 (2..32 patterns, each >= 3 bytes), buildMasks :271-311.
+  // 33..64 patterns: NewFatTeddy teddy_fat.go:127-185, buildFatMasks :198-236 — the same tables with 16 buckets
+  // (bucket = id mod 16; the reference keeps buckets 8-15 in a second 16-byte lane, here bits 8-15 of a u16), chosen
+  // by newTeddyFromSeq teddy.go:629-660.
+  if (pats.size() < 2 || pats.size() > 64) return false;
   minLen = static_cast<int>(pats[0].size());
   for (auto& p : pats) {
     if (p.size() < 3) return false;
@@ -530,14 +533,14 @@ bool Teddy::build(const std::vector<std::vector<uint8_t>>& pats) {
   }
   fpLen = std::min(2, minLen);
   patterns = pats;
-  int nb = std::min<int>(8, static_cast<int>(pats.size()));
+  int nb = pats.size() > 32 ? 16 : std::min<int>(8, static_cast<int>(pats.size()));
   buckets.assign(nb, {});
   std::memset(lo, 0, sizeof lo);
   std::memset(hi, 0, sizeof hi);
   for (size_t id = 0; id < pats.size(); id++) {
     int bucket = static_cast<int>(id % nb);
     buckets[bucket].push_back(static_cast<int>(id));
-    uint8_t bit = static_cast<uint8_t>(1u << bucket);
+    uint16_t bit = static_cast<uint16_t>(1u << bucket);
     for (int p = 0; p < fpLen; p++) {
       uint8_t b = pats[id][p];
       lo[p][b & 15] |= bit;
@@ -547,10 +550,10 @@ bool Teddy::build(const std::vector<std::vector<uint8_t>>& pats) {
   return true;
 }
 
-void Teddy::findCandidate(Bytes h, int64_t n, int64_t& pos, uint8_t& mask) const {
-  // findScalarCandidate teddy.go:491-519 (== asm incl. its tail, teddy_ssse3_amd64.s:369-420)
+void Teddy::findCandidate(Bytes h, int64_t n, int64_t& pos, uint16_t& mask) const {
+  // findScalarCandidate teddy.go:491-519 (== asm incl. its tail, teddy_ssse3_amd64.s:369-420); Fat: teddy_fat.go:432-468
   for (int64_t i = 0; i + fpLen <= n; i++) {
-    uint8_t m = 0xFF;
+    uint16_t m = 0xFFFF;
     for (int p = 0; p < fpLen; p++) {
       uint8_t b = h[i + p];
       m &= lo[p][b & 15] & hi[p][b >> 4];
@@ -564,7 +567,7 @@ bool Teddy::findMatch(Bytes hay, int64_t len, int64_t start, int64_t& s, int64_t
   if (start < 0 || start >= len) return false;
   Bytes h = hay + start;
   int64_t n = len - start;
-  if (n < 16) {  // findMatchScalar teddy.go:447-458: position-major, pattern-id-minor
+  if (n < 16) {  // findMatchScalar teddy.go:447-458 (Fat: teddy_fat.go:418-429): position-major, pattern-id-minor
     for (int64_t i = 0; i < n - minLen + 1; i++)
       for (auto& p : patterns) {
         int64_t pl = static_cast<int64_t>(p.size());
@@ -572,12 +575,12 @@ bool Teddy::findMatch(Bytes hay, int64_t len, int64_t start, int64_t& s, int64_t
       }
     return false;
   }
-  int64_t acc = 0, pos; uint8_t mask;
+  int64_t acc = 0, pos; uint16_t mask;   // FindMatch teddy.go:391-445, Fat: teddy_fat.go:346-392 (bits.TrailingZeros16)
   findCandidate(h, n, pos, mask);
   while (pos != -1) {
     while (mask) {
       int bucket = __builtin_ctz(mask);
-      mask &= static_cast<uint8_t>(~(1u << bucket));
+      mask &= static_cast<uint16_t>(~(1u << bucket));
       // verifyBucket teddy.go:532-550 on haystack[acc:]
       int64_t rem = n - acc;
       if (pos >= 0 && pos < rem && bucket < static_cast<int>(buckets.size())) {

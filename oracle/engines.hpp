@@ -75,14 +75,14 @@ struct PikeVM {
   bool searchAt(Bytes h, int64_t n, int64_t at, int64_t& s, int64_t& e);
 };
 
-// ---------------------------------------------------------------- Teddy (slim)
+// ---------------------------------------------------------------- Teddy (slim: 2..32 patterns, fat: 33..64)
 struct Teddy {
   std::vector<std::vector<uint8_t>> patterns;
   std::vector<std::vector<int>> buckets;
-  uint8_t lo[2][16] = {}, hi[2][16] = {};
+  uint16_t lo[2][16] = {}, hi[2][16] = {};   // bit = bucket (8 buckets slim, 16 fat)
   int fpLen = 2, minLen = 0;
   bool build(const std::vector<std::vector<uint8_t>>& pats);   // NewTeddy, teddy.go:189
-  void findCandidate(Bytes h, int64_t n, int64_t& pos, uint8_t& mask) const;  // teddy.go:491
+  void findCandidate(Bytes h, int64_t n, int64_t& pos, uint16_t& mask) const;  // teddy.go:491
   bool findMatch(Bytes h, int64_t n, int64_t start, int64_t& s, int64_t& e) const;  // teddy.go:391
 };
 

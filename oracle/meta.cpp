@@ -597,7 +597,7 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
     case UseTeddy: {
       std::vector<std::vector<uint8_t>> pats;
       for (auto& l : e->prefixes.lits) pats.push_back(l.bytes);
-      if (pats.size() > 32 || !e->teddy.build(pats)) {   // Fat Teddy (33-64) is out of scope
+      if (!e->teddy.build(pats)) {   // Slim (2..32) or Fat (33..64) Teddy
         e->strategyRestated = false;
       }
       break;

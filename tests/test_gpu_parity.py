@@ -125,6 +125,43 @@ def test_teddy_wave_paths(need_gpu, oracle):
     _check(oracle, pat, tail)                                                  # match ends exactly at the end of input
 
 
+def test_fat_teddy_33_to_64_literals(need_gpu, oracle):
+    """33..64 exact literals (the reference's Fat Teddy, prefilter/teddy_fat.go): same wave kernel, 16 buckets folded
+    onto its 8 mask bits, exact verification.  Rows == oracle on a mixed text and at tile edges; kernel by name."""
+    words = ["word%02d" % i for i in range(20)] + ["key%02dx" % i for i in range(12)] + ["val%d" % i for i in range(10)] + \
+            ["item", "timeout", "refused", "denied", "ordinal", "keyword"]
+    pat = "|".join(words)
+    o = oracle.Regex(pat)
+    assert o.strategy == "UseTeddy" and o.strategy_restated
+    rx = cx.compile(pat)
+    assert rx.strategy == "UseTeddy" and rx.supported
+    rng = np.random.default_rng(4800)
+    lit = [w.encode() for w in words]
+    near = [b"word", b"wor", b"key1", b"val", b"word9", b"xx", b"ite", b"keywor"]
+    fill = [b"lorem", b"ipsum", b"dolor", b"sit", b"amet", b"consectetur", b" ", b" ", b" ", b"\n"]
+    kind = rng.random(600000)
+    pick = rng.integers(0, 1 << 30, size=600000)
+    hay = b"".join((lit[k % 48] if u < 0.06 else near[k % 8] if u < 0.09 else fill[k % 10]) for u, k in zip(kind, pick))
+    exp = o.find_all_index(hay)
+    assert np.array_equal(rx.find_all_index(hay), exp) and len(exp) > 30000
+    import torch
+    a = np.frombuffer(hay, dtype=np.uint8)
+    buf = cx.DeviceBuffer((a.size + 15) // 16 * 16)
+    buf.upload(a)
+    out = torch.empty((len(exp) + 4, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    assert rx.find_all_device(buf.ptr, a.size, out.data_ptr(), len(exp) + 4, timing=t) == len(exp)
+    assert np.array_equal(out[:len(exp)].cpu().numpy(), exp)
+    assert t.kernel == 7 and t.n_launches == 1, (t.kernel, t.n_launches, t.fallback_reason)      # CXG_K_TEDDY_WAVE
+    for n in (33, 64):
+        lits = ["lit%02dz" % i for i in range(n)]
+        base = np.full(3840 * 3, ord(" "), dtype=np.uint8)
+        for off in (3840 - 6, 3840 - 3, 3840, 7680 - 1):
+            h = base.copy()
+            h[off:off + 6] = np.frombuffer(lits[n - 1].encode(), dtype=np.uint8)
+            _check(oracle, "|".join(lits), h)
+
+
 def test_charclass_wave_paths(need_gpu, oracle):
     """Wave char-class kernel: runs across lane words, the tile edge, the halo edge and the group edge; runs that
     end with the input; the fallbacks (a run longer than the halo, > 1024 runs in a wave-tile)."""
@@ -859,3 +896,48 @@ def test_bounded_repetition_on_the_chain_kernel(need_gpu, oracle):
     t = cx.Timing()
     assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 4, timing=t) == cnt and t.n_launches == 1
     assert np.array_equal(out[:cnt].cpu().numpy(), oracle.Regex(r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}").find_all_index(synth))
+
+
+def test_single_process_drives_several_devices_from_threads(need_gpu, oracle):
+    """What INTEGRATION.md prescribes for a host that holds one corpus in several shards: one OS thread per GPU
+    (`cxg_set_device`), each scans its page-aligned shard with `base` = its byte offset (`cxg_find_all_device`), rows are
+    concatenated in shard order on the host, an `n > 0` limit is applied after the concatenation.  With fewer GPUs than
+    shards the shards share devices (here: every visible device is used; on a 1-GPU box both threads use device 0)."""
+    import threading
+    import torch
+    from coregex_amd import sharding
+    ndev = cx.device_count()
+    nshards = max(2, min(ndev, 8))
+    pat = r"\d+\.\d+\.\d+\.\d+"
+    npages = 3000
+    plan = sharding.plan_shards(npages * 4096, nshards)
+    rx = cx.compile(pat)                                   # one immutable program shared by all threads / devices
+    parts, errors = [None] * nshards, []
+
+    def worker(i):
+        try:
+            dev = i % ndev
+            cx.set_device(dev)                             # per-thread device of the library
+            torch.cuda.set_device(dev)
+            lo, hi = plan[i]
+            buf = cx.DeviceBuffer(hi - lo)
+            buf.fill_synth(2, 0xC0FFEE02, lo // 4096)
+            n = rx.find_all_device(buf.ptr, hi - lo)
+            out = torch.empty((n + 8, 2), dtype=torch.int64, device=f"cuda:{dev}")
+            assert rx.find_all_device(buf.ptr, hi - lo, out.data_ptr(), n + 8, base=lo) == n
+            parts[i] = out[:n].cpu().numpy()
+        except Exception as ex:                            # noqa: BLE001 - reported from the main thread
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(nshards)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    got = np.concatenate(parts)
+    whole = cx.synth_pages(2, 0xC0FFEE02, 0, npages)
+    exp = oracle.Regex(pat).find_all_index(whole)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(sharding.apply_limit(got, 17), oracle.Regex(pat).find_all_index(whole, 17))
+    cx.set_device(0)

@@ -332,7 +332,9 @@ def test_teddy_and_charclass_wave_twins(oracle):
     rng = np.random.default_rng(31)
     corpus = generate_test_input()
     lits = "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"
-    for pat, alpha, cfg in ((lits, b"erowanigftlcpmusdbyxv  \n.", 3), ("spider|error|crawler|denied", b"spidercawln  \n", 3)):
+    fat = "|".join(FAT_WORDS)      # 48 literals: the reference's Fat Teddy (teddy_fat.go), buckets folded 16 -> 8 on the device
+    for pat, alpha, cfg in ((lits, b"erowanigftlcpmusdbyxv  \n.", 3), ("spider|error|crawler|denied", b"spidercawln  \n", 3),
+                            (fat, b"wordkeyvalitm0123456789  \n", 3)):
         p = cx.compile(pat)
         assert p.strategy == "UseTeddy" and p.supported
         o = oracle.Regex(pat)
@@ -690,6 +692,36 @@ def test_submatch_programs_emulated(oracle):
             assert emu.find_all_submatch(sb, cb, hay, w, 4).tolist() == o.find_all_submatch_index(hay).tolist(), (pat, hay)
         hay = (b"abcd ab abc abcd aaaa b a=1 ab=cd " * 200)
         assert emu.find_all_submatch(sb, cb, hay, w, 64).tolist() == o.find_all_submatch_index(hay).tolist(), pat
+
+
+FAT_WORDS = ["word%02d" % i for i in range(20)] + ["key%02dx" % i for i in range(12)] + ["val%d" % i for i in range(10)] + \
+            ["item", "timeout", "refused", "denied", "ordinal", "keyword"]
+
+
+def test_fat_teddy_programs(oracle):
+    """33..64 exact literals: UseTeddy through Fat Teddy in the reference (newTeddyFromSeq, prefilter/teddy.go:629-660);
+    the device image folds the 16 buckets onto 8 and verifies exactly.  65 literals go to Aho-Corasick: refused."""
+    assert len(FAT_WORDS) == 48
+    pat = "|".join(FAT_WORDS)
+    p = cx.compile(pat)
+    o = oracle.Regex(pat)
+    assert o.strategy == "UseTeddy" and o.strategy_restated
+    assert p.strategy == "UseTeddy" and p.supported, p.why_unsupported
+    rng = np.random.default_rng(48)
+    pieces = [w.encode() for w in FAT_WORDS] + [b"word", b"wor", b"key1", b"val", b" ", b"\n", b"word9", b"xx", b"ite", b"keywor"]
+    for _ in range(20):
+        hay = b"".join(pieces[i] for i in rng.integers(0, len(pieces), size=int(rng.integers(0, 3000))))
+        exp = o.find_all_index(hay).tolist()
+        for chunk in (4, 64):
+            assert emu.find_all(p.blob(), hay, chunk).tolist() == exp
+    for n in (33, 64):
+        words = ["lit%02dz" % i for i in range(n)]
+        q = cx.compile("|".join(words))
+        assert q.strategy == "UseTeddy" and q.supported, (n, q.why_unsupported)
+        hay = (" ".join(words[::-1]) + " lit0 lit00 lit99z").encode()
+        assert emu.find_all(q.blob(), hay, 4).tolist() == oracle.Regex("|".join(words)).find_all_index(hay).tolist()
+    q = cx.compile("|".join("lit%02dz" % i for i in range(65)))
+    assert not q.supported
 
 
 def test_teddy_programs(oracle):

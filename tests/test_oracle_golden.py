@@ -84,6 +84,22 @@ def test_teddy_find(oracle):
         assert t.find(_inp(c), c["start"]) == c["want"], c
 
 
+def test_fat_teddy_find(oracle):
+    for c in VEC["fat_teddy_find"]["cases"]:
+        pats = [(c["patterns"]["fmt"] % i).encode() for i in range(c["patterns"]["count"])]
+        t = oracle.Teddy(pats)
+        h = _inp(c)
+        want = c["want"]
+        assert t.find(h, c["start"]) == (want[0] if want else -1), c
+        if want:
+            assert t.find_match(h, c["start"]) == tuple(want), c
+        # the meta engine reaches it through UseTeddy (newTeddyFromSeq, teddy.go:629-660)
+        rx = oracle.Regex("|".join(p.decode() for p in pats))
+        assert rx.strategy == "UseTeddy" and rx.strategy_restated
+        got = rx.find_all_index(h[c["start"]:], 1)
+        assert ([int(got[0][0]) + c["start"], int(got[0][1]) + c["start"]] if len(got) else None) == want, c
+
+
 def test_strategy_selection(oracle):
     for c in VEC["strategy_selection"]["cases"]:
         assert oracle.Regex(c["pattern"]).strategy == c["want"], c["pattern"]
