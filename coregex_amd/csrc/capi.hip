@@ -31,7 +31,7 @@ hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, b
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, hipStream_t stream);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream);
 }  // namespace cxgdev
 
 namespace {
@@ -382,6 +382,11 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     gen = 10;                                                       // table-walking kernels only when the transducer is unavailable or gives up
     fsmTried = true;
   }
+  if (h->kind == cxgdev::kKindFsmOnly) {                            // UseNFA programs (word boundaries): the transducer kernel is the only one
+    if (!d_fsm) return fail(CXG_E_UNSUPPORTED, "program runs on the transducer kernel only (CXG_NO_FSM is set)");
+    gen = 10;
+    fsmTried = true;
+  }
   // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
@@ -432,7 +437,7 @@ relaunch:
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
-    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, stream);
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream);
   }
   else if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
@@ -568,6 +573,9 @@ relaunch:
       if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the transducer kernel\n", gen, err >> 8);
       relaunches++; gen = 10; fsmTried = true; goto relaunch;
     }
+    if (h->kind == cxgdev::kKindFsmOnly)                            // no table-walking image: degrade for THIS haystack
+      return fail(CXG_E_INPUT, "haystack outside the transducer kernel's budgets (reason bits " + std::to_string(err >> 8) +
+                               "): matches denser than one per 2 bytes, a match reaching > 190 bytes past its tile, or an unresolvable entry state");
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
   }

@@ -41,7 +41,7 @@
 
 namespace cxgdev {
 
-constexpr uint32_t kFsmMagic = 0x43584735u;   // "CXG5"
+constexpr uint32_t kFsmMagic = 0x43584736u;   // "CXG6"
 constexpr int kFsmMaxLevels = 7;              // pending searches alive at once (4-bit refs in one dword)
 constexpr int kFsmLaneRows = 4;               // rows buffered per 32-byte chunk (denser input: fallback flag) ...
 constexpr int kFsmLaneEvents = 8;             // events recorded inside a 32-byte chunk before they are applied (power of two) ...
@@ -73,13 +73,26 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t alias_lo, u_lo, top_off, wide_off;      // byte offsets of the first alias row, the first set row, "any state", wide
   uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u16[n_u + 1][8] rows of a set's members, 0xFFFF pad / not listed
   uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][ncls] target row byte offsets, row 0 dead; accepting rows >= rev_accept_off
-  uint32_t total_bytes, lds_bytes, max_len, pad0;
-  uint32_t create_lo, rematch_lo, row_shift, pad2; // row_bytes == 1 << row_shift; alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
-                                                   // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch
+  uint32_t total_bytes, lds_bytes, max_len, nk;    // nk: kinds of the byte BEHIND a step that the step depends on (1: none; 2: word / not word, see "Look-around")
+  uint32_t create_lo, rematch_lo, row_shift, knd_off; // row_bytes == 1 << row_shift; alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
+                                                   // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch.  knd: u8[256] = 2 * kind of a byte (nk > 1)
+  uint32_t start_off[2];                           // row of the search at the haystack's first byte, by the kind of that byte (nk == 1: both 0)
+  uint32_t rev_start4[4];                          // reverse start row for a match that ends at e, by 2 * kind(hay[e-1]) + kind(hay[e]) (nk == 1: all rev_start_off)
+  uint32_t pad3[2];
 };
 
+// Look-around (word boundaries `\b`, `\B`; nfa.Look, nfa/nfa.go:92-117).  An assertion at position p reads the bytes
+// on both sides of p.  The machine stays a plain left-to-right transducer with IMMEDIATE acceptance when the step over
+// byte i also sees the KIND of byte i + 1 (word / not word; the byte behind the haystack's end — and the one in front of
+// its start — count as "not word", nfa/pikevm.go:1646-1674): the input symbol of a step is the pair (class of hay[i],
+// kind of hay[i+1]), column  nk * class + kind.  After the step both sides of position i + 1 are known, so every
+// assertion there is decided on the host when the table is built (host/fsm.cc) and a match that ends at i + 1 is
+// reported by the step over byte i as always.  The reverse DFA mirrors it: the step over byte i (walking down) sees
+// the kind of hay[i-1].  Only the class lookup changes — it is part of the Mem concept below, so programs without
+// assertions (nk == 1) compile to the same instructions as before.
 struct FsmView {
-  const uint8_t* cls2;      // 2 * class of a byte
+  const uint8_t* cls2;      // 2 * nk * class of a byte: byte offset of the class's first column
+  const uint8_t* knd;       // 2 * kind of a byte (nk > 1)
   const uint8_t* tab;       // rows, addressed by byte offset
   const uint8_t* rev;
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
@@ -87,6 +100,46 @@ struct FsmView {
   uint32_t create_lo, rematch_lo;
   const uint8_t* mem;       // members of the set rows
   uint32_t row_shift;
+  uint32_t start1;          // start row when the haystack's first byte has kind 1 (kind 0: row 0)
+  uint32_t rev_start4[4];
+};
+// Class lookups of a Mem type, from its byte() / dword(): CRTP base shared by the kernel's LDS window and the twin's
+// host memory.  LOOK = the image has nk == 2.
+template <class Derived, bool LOOK>
+struct FsmClassify {
+  CXG_FSM_HD const Derived& self() const { return *static_cast<const Derived*>(this); }
+  // column offset of the forward step over byte i
+  CXG_FSM_HD uint32_t cls(const FsmView& v, int32_t i) const {
+    uint32_t c = v.cls2[self().byte(i)];
+    if (LOOK) c += v.knd[self().byte(i + 1)];
+    return c;
+  }
+  // ... of the four steps over the aligned dword at r
+  CXG_FSM_HD void classes4(const FsmView& v, int32_t r, uint32_t (&k)[4]) const {
+    const uint32_t d = self().dword(r);
+    k[0] = v.cls2[d & 0xFFu]; k[1] = v.cls2[(d >> 8) & 0xFFu]; k[2] = v.cls2[(d >> 16) & 0xFFu]; k[3] = v.cls2[d >> 24];
+    if (LOOK) {
+      k[0] += v.knd[(d >> 8) & 0xFFu]; k[1] += v.knd[(d >> 16) & 0xFFu]; k[2] += v.knd[d >> 24];
+      k[3] += v.knd[self().byte(r + 4)];
+    }
+  }
+  // column offset of the reverse step over byte i (walking down)
+  CXG_FSM_HD uint32_t rcls(const FsmView& v, int32_t i) const {
+    uint32_t c = v.cls2[self().byte(i)];
+    if (LOOK) c += v.knd[self().byte(i - 1)];
+    return c;
+  }
+  // reverse start row for a match that ends at e
+  CXG_FSM_HD uint32_t rstart(const FsmView& v, int32_t e) const {
+    if (!LOOK) return v.rev_start_off;
+    return v.rev_start4[v.knd[self().byte(e - 1)] + (v.knd[self().byte(e)] >> 1)];
+  }
+  // start row of the search at the haystack's first byte (tile-relative position 0 of the first tile)
+  CXG_FSM_HD uint32_t origin(const FsmView& v) const {
+    if (!LOOK) return 0u;
+    return v.knd[self().byte(0)] ? v.start1 : 0u;
+  }
+  static constexpr bool kLook = LOOK;
 };
 // the state's own row (an alias row is a copy of it)
 CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off);
@@ -104,8 +157,10 @@ CXG_FSM_HD uint32_t fsm_shift_in2(uint32_t mask, uint32_t t) {   // (mask >> 2) 
 #endif
 }
 
-// Mem concept: uint32_t byte(int32_t r) for any r with 0 <= origin + r < len (r relative to the tile origin);
-//              uint32_t dword(int32_t r): little-endian bytes r..r+3, r % 4 == 0, all four inside one staged 64-byte chunk.
+// Mem concept: uint32_t byte(int32_t r) for any r with 0 <= origin + r < len (r relative to the tile origin) — with
+//              look-around also one position outside on either side, which reads as 0;
+//              uint32_t dword(int32_t r): little-endian bytes r..r+3, r % 4 == 0, all four inside one staged 64-byte chunk;
+//              the class lookups of FsmClassify.
 
 // Pure state walk over [from, to): the warm-up that finds a chunk's entry state.  aligned: the range is whole dwords
 // of staged chunks.  Rows are byte offsets.
@@ -114,14 +169,15 @@ CXG_FSM_HD uint32_t fsm_walk(const FsmView& v, const Mem& m, uint32_t x, int32_t
   int32_t i = from;
   if (aligned) {
     for (; i + 4 <= to; i += 4) {
-      const uint32_t d = m.dword(i);
-      x = fsm_next(v, x, v.cls2[d & 0xFFu]);
-      x = fsm_next(v, x, v.cls2[(d >> 8) & 0xFFu]);
-      x = fsm_next(v, x, v.cls2[(d >> 16) & 0xFFu]);
-      x = fsm_next(v, x, v.cls2[d >> 24]);
+      uint32_t k[4];
+      m.classes4(v, i, k);
+      x = fsm_next(v, x, k[0]);
+      x = fsm_next(v, x, k[1]);
+      x = fsm_next(v, x, k[2]);
+      x = fsm_next(v, x, k[3]);
     }
   }
-  for (; i < to; i++) x = fsm_next(v, x, v.cls2[m.byte(i)]);
+  for (; i < to; i++) x = fsm_next(v, x, m.cls(v, i));
   return x & ~3u;
 }
 
@@ -137,10 +193,7 @@ CXG_FSM_HD void fsm_walk_n(const FsmView& v, const Mem& m, uint32_t x0, const in
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int a = 0; a < N; a++) {
-      const uint32_t d = m.dword(from[a] + i);
-      k[a][0] = v.cls2[d & 0xFFu]; k[a][1] = v.cls2[(d >> 8) & 0xFFu]; k[a][2] = v.cls2[(d >> 16) & 0xFFu]; k[a][3] = v.cls2[d >> 24];
-    }
+    for (int a = 0; a < N; a++) m.classes4(v, from[a] + i, k[a]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -205,9 +258,6 @@ CXG_FSM_HD void fsm_apply(FsmLane& L, uint32_t ev, int32_t e, bool in_chunk, Row
 // Events concept: void push(uint32_t k, uint32_t row); uint32_t row_at(uint32_t k).
 struct FsmTrace { uint32_t x, evbits, nev, cap; };   // state after the chunk, event positions (bit per byte), events seen, event slots (power of two)
 
-CXG_FSM_HD void fsm_classes(const FsmView& v, uint32_t d, uint32_t (&k)[4]) {
-  k[0] = v.cls2[d & 0xFFu]; k[1] = v.cls2[(d >> 8) & 0xFFu]; k[2] = v.cls2[(d >> 16) & 0xFFu]; k[3] = v.cls2[d >> 24];
-}
 template <class Events>
 CXG_FSM_HD void fsm_step_rec(const FsmView& v, uint32_t cls2, uint32_t bit, FsmTrace& t, Events& evs) {
   t.x = fsm_next(v, t.x, cls2) & ~3u;
@@ -227,7 +277,7 @@ CXG_FSM_HD void fsm_fast(const FsmView& v, const Mem& m, const int32_t (&c0)[N],
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a]), kk[a]);
+  for (int a = 0; a < N; a++) m.classes4(v, c0[a], kk[a]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -236,7 +286,7 @@ CXG_FSM_HD void fsm_fast(const FsmView& v, const Mem& m, const int32_t (&c0)[N],
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a] + 4 * (q + 1)), nn[a]);
+      for (int a = 0; a < N; a++) m.classes4(v, c0[a] + 4 * (q + 1), nn[a]);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -265,7 +315,7 @@ CXG_FSM_HD void fsm_fast_shallow(const FsmView& v, const Mem& m, const int32_t (
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a]), kk[a]);
+  for (int a = 0; a < N; a++) m.classes4(v, c0[a], kk[a]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -274,7 +324,7 @@ CXG_FSM_HD void fsm_fast_shallow(const FsmView& v, const Mem& m, const int32_t (
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-      for (int a = 0; a < N; a++) fsm_classes(v, m.dword(c0[a] + 4 * (q + 1)), nn[a]);
+      for (int a = 0; a < N; a++) m.classes4(v, c0[a] + 4 * (q + 1), nn[a]);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -324,7 +374,7 @@ CXG_FSM_HD void fsm_finish_shallow(const FsmView& v, const Mem& m, const FsmTrac
     if (L.lev == 0u) break;
     if (i >= rend) break;
     if (i >= budget) { L.flags |= 4u; break; }
-    L.x = fsm_next(v, L.x, v.cls2[m.byte(i)]) & ~3u;
+    L.x = fsm_next(v, L.x, m.cls(v, i)) & ~3u;
     if (L.x >= v.alias_lo) fsm_apply(L, fsm_u16(v.tab, L.x + v.ncls2), i + 1, false, rows);
   }
 }
@@ -358,7 +408,7 @@ CXG_FSM_HD void fsm_finish(const FsmView& v, const Mem& m, uint32_t entry, const
     if (i >= c1 && L.lev == 0u) break;               // only levels created beyond the chunk are left
     if (i >= rend) break;                            // end of input: every pending match is committed as it stands
     if (i >= budget) { L.flags |= 4u; break; }
-    L.x = fsm_next(v, L.x, v.cls2[m.byte(i)]) & ~3u;
+    L.x = fsm_next(v, L.x, m.cls(v, i)) & ~3u;
     if (i < c1) L.xc1 = L.x;
     if (L.x >= v.alias_lo) fsm_apply(L, fsm_u16(v.tab, L.x + v.ncls2), i + 1, i < c1, rows);
   }
@@ -386,11 +436,11 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
 constexpr int32_t kFsmNoStart = -0x7FFFFFFF - 1;
 template <class Mem>
 CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
-  uint32_t s = v.rev_start_off;
+  uint32_t s = m.rstart(v, e);
   int32_t st = kFsmNoStart;
   for (int32_t at = e - 1; at >= bound; at--) {
     if (at < budget_lo) { over = 1u; break; }
-    s = fsm_u16(v.rev, s + v.cls2[m.byte(at)]);
+    s = fsm_u16(v.rev, s + m.rcls(v, at));
     if (s == 0u) break;
     if (s >= v.rev_accept_off) st = at;
   }

@@ -59,7 +59,8 @@ constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the
 // that is in flight: the prefetch would be worth nothing.  Walks that leave the window are finished elsewhere: a match
 // start in front of the window in the epilogue (rows marked unresolved), a walk past the window's end by the fallback.
 typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
-struct FsmMem {
+template <bool LOOK>
+struct FsmMem : FsmClassify<FsmMem<LOOK>, LOOK> {
   lds_bytes_t win;         // this wave's LDS window: tile-relative bytes [-kFsmLeft, 4096 - kFsmLeft)
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
@@ -91,6 +92,9 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
+  v.knd = body + (h->knd_off - hs);
+  v.start1 = h->start_off[1];
+  for (int q = 0; q < 4; q++) v.rev_start4[q] = h->rev_start4[q];
   return v;
 }
 
@@ -153,7 +157,8 @@ __device__ __forceinline__ uint32_t wait_tile_exit(uint32_t* s_exit, uint64_t* s
 
 // SHALLOW: the machine never holds more than one pending match (FsmHeader::depth <= 1): rows from two event bitmaps
 // per sub-chunk instead of a recorded event list (fsm.hpp).  MODE: buffer geometry by match density (FsmMode).
-template <bool SHALLOW, int IMG, int MODE>
+// LOOK: the image has word-boundary assertions (nk == 2): a step's class also reads the next byte (fsm.hpp "Look-around").
+template <bool SHALLOW, int IMG, int MODE, bool LOOK>
 __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE> S;
   constexpr int kLaneRows = FsmMode<MODE>::kRows, kLaneEvents = FsmMode<MODE>::kEvents, kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
@@ -220,9 +225,15 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       FSM_MARK(0);                                      // window staged
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
-      const int32_t budget = rend < kFsmWinEnd ? rend : kFsmWinEnd;      // walks stay inside the window
+      // walks stay inside the window; with look-around a step also reads the byte behind its own (past the end of input
+      // the window holds zeros: "not a word byte", as the reference treats the end of the text)
+      constexpr int32_t kWinEnd = kFsmWinEnd - (LOOK ? 1 : 0);
+      const int32_t budget = rend < kWinEnd ? rend : kWinEnd;
       const int32_t lowest = tile_lo ? -kFsmLeft : 0;
-      FsmMem m{(lds_bytes_t)win};
+      // ... and a reverse step the byte in front (in front of the haystack's first byte the window holds zeros as well)
+      const int32_t rev_lowest = (LOOK && tile_lo) ? lowest + 1 : lowest;
+      FsmMem<LOOK> m;
+      m.win = (lds_bytes_t)win;
       // ---- E + R: entry states, replay.  A lane's 64 bytes are two sub-chunks of 32 walked in lockstep (two
       // independent chains of dependent LDS reads per lane).
       const int32_t c0 = (lane - 1) * kFsmChunk;
@@ -245,10 +256,10 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         const bool at_origin = tile_lo + static_cast<uint64_t>(c0) == 0;
         const int32_t from[2] = {at_origin ? cc[1] - 16 : cc[0] - 16, cc[1] - 16};     // (the haystack's first chunk starts in state 0)
         if (!(CXG_FSM_ABL & 1)) fsm_walk_n<2>(v, m, v.top_off, from, 16, entry);
-        if (at_origin) entry[0] = 0u;
+        if (at_origin) entry[0] = m.origin(v);
         if (entry[0] >= v.u_lo) entry[0] = fsm_walk(v, m, v.top_off, cc[0] - 64, cc[0], true);
         if (entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, v.top_off, at_origin ? 0 : cc[1] - 64, cc[1], true);
-        if (at_origin && entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, 0u, 0, cc[1], true);   // from the true start state
+        if (at_origin && entry[1] >= v.u_lo) entry[1] = fsm_walk(v, m, m.origin(v), 0, cc[1], true);   // from the true start state
       }
       FSM_MARK(1);                                      // entry states
       const bool unres0 = active && entry[0] >= v.u_lo, unres1 = second && entry[1] >= v.u_lo;
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           // reverse DFA that is still alive there report `over`
           const int32_t bound = q ? static_cast<int32_t>(s_re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
-          const int32_t s = fsm_match_start(v, m, e, bound, lowest, over);
+          const int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over);
           // over: the reverse DFA was still alive at the window's first byte and the haystack goes on in front of it
           // (a match longer than the 64 bytes staged there): length 0 = unresolved, finished in the epilogue
           const uint32_t len = (over || s == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - s);
@@ -474,10 +485,11 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         if (prev > s || s == e) {                                           // rare: walk again from HBM / L2, bounded
           const int64_t lo = prev > 0 ? prev : 0;
           uint32_t sr = v.rev_start_off;
+          if (LOOK) sr = v.rev_start4[v.knd[a.hay[e - 1]] + (v.knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : 0] >> 1)];
           int64_t st = -1;
           for (int64_t at = e - 1; at >= lo; at--) {
             if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]]);
+            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : 0] : 0u));
             if (sr == 0u) break;
             if (sr >= v.rev_accept_off) st = at;
           }
@@ -508,11 +520,13 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   if (s0 >= prev) return;
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
   const uint8_t* cls2 = a.blob + h->cls_off;
+  const uint8_t* knd = a.blob + h->knd_off;
   const uint8_t* rev = a.blob + h->rev_off;
-  uint32_t sr = h->rev_start_off;
+  const bool look = h->nk > 1;
+  uint32_t sr = look ? h->rev_start4[knd[a.hay[e - 1]] + (knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : 0] >> 1)] : h->rev_start_off;
   int64_t st = -1;
   for (int64_t at = e - 1; at >= prev; at--) {
-    sr = fsm_u16(rev, sr + cls2[a.hay[at]]);
+    sr = fsm_u16(rev, sr + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : 0] : 0u));
     if (sr == 0u) break;
     if (sr >= h->rev_accept_off) st = at;
   }
@@ -521,27 +535,32 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
 }
 
 namespace {
-template <int IMG>
+template <int IMG, bool LOOK>
 void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 block, hipStream_t stream) {
   if (shallow) {
-    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 0>), grid, block, 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 1>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_fsm<true, IMG, 2>), grid, block, 0, stream, a);
+    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 0, LOOK>), grid, block, 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 1, LOOK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<true, IMG, 2, LOOK>), grid, block, 0, stream, a);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 0>), grid, block, 0, stream, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 1>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_fsm<false, IMG, 2>), grid, block, 0, stream, a);
+    if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 0, LOOK>), grid, block, 0, stream, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 1, LOOK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<false, IMG, 2, LOOK>), grid, block, 0, stream, a);
   }
 }
 }  // namespace
 
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, hipStream_t stream) {
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
-  if (lds_bytes <= 3072) launch_fsm_img<3072>(a, shallow, mode, grid, block, stream);          // instantiations by image size
-  else if (lds_bytes <= 10240) launch_fsm_img<10240>(a, shallow, mode, grid, block, stream);
-  else if (lds_bytes <= 28672) launch_fsm_img<28672>(a, shallow, mode, grid, block, stream);
-  else return hipErrorInvalidValue;
+  if (lds_bytes > 28672) return hipErrorInvalidValue;
+  if (look) {                                                                                   // word-boundary programs
+    if (lds_bytes <= 3072) launch_fsm_img<3072, true>(a, shallow, mode, grid, block, stream);
+    else if (lds_bytes <= 10240) launch_fsm_img<10240, true>(a, shallow, mode, grid, block, stream);
+    else launch_fsm_img<28672, true>(a, shallow, mode, grid, block, stream);
+  }
+  else if (lds_bytes <= 3072) launch_fsm_img<3072, false>(a, shallow, mode, grid, block, stream);   // instantiations by image size
+  else if (lds_bytes <= 10240) launch_fsm_img<10240, false>(a, shallow, mode, grid, block, stream);
+  else launch_fsm_img<28672, false>(a, shallow, mode, grid, block, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.out == nullptr || a.ngroups < 2) return e;
   const unsigned fb = 256, fg = static_cast<unsigned>((a.ngroups + fb - 1) / fb);

@@ -34,7 +34,8 @@
 namespace cxgdev {
 
 constexpr uint32_t kBlobMagic = 0x43584731u;  // "CXG1"
-enum BlobKind : uint32_t { kKindDigit = 1, kKindBidir = 2, kKindCharClass = 3, kKindTeddy = 4 };
+enum BlobKind : uint32_t { kKindDigit = 1, kKindBidir = 2, kKindCharClass = 3, kKindTeddy = 4,
+                           kKindFsmOnly = 5 };   // header + info table only: the program runs on the transducer kernel alone (UseNFA)
 constexpr uint32_t kInfoSync = 1u;       // byte is outside the pattern alphabet
 constexpr uint32_t kInfoMember = 2u;     // char-class membership (kKindCharClass)
 constexpr uint32_t kInfoStartIdle = 4u;  // fwd.start --byte--> fwd.start (skippable while idle)

@@ -798,8 +798,14 @@ struct NfaB {
       case Node::Class: return cls(x);
       case Node::Empty: { uint32_t e = eps(); return {e, e}; }
       case Node::Any: case Node::AnyNotNL: unsupported("'.' (UTF-8 rune states)");
-      case Node::BeginLine: case Node::EndLine: case Node::BeginText: case Node::EndText: case Node::WordB: case Node::NoWordB:
-        unsupported("look-around assertions (^ $ \\b \\A \\z)");
+      case Node::BeginLine: case Node::EndLine: case Node::BeginText: case Node::EndText:
+        unsupported("line / text anchors (^ $ \\A \\z)");
+      case Node::WordB: case Node::NoWordB: {       // compile.go:288-289 addLook; cxg_nfa_state.lo = nfa.Look (nfa/nfa.go:92-117)
+        auto s = blank(CXG_NFA_LOOK);
+        s.lo = x.kind == Node::WordB ? 4 : 5;
+        const uint32_t id = push(s);
+        return {id, id};
+      }
       case Node::NoMatch: unsupported("empty character class");
       case Node::Concat: {
         std::vector<std::function<F()>> parts;
@@ -819,7 +825,7 @@ struct NfaB {
         uint32_t join = eps();
         for (auto& f : fs) {
           auto& s = out.states[f.out];
-          if (s.kind == CXG_NFA_BYTE_RANGE || s.kind == CXG_NFA_EPSILON || s.kind == CXG_NFA_CAPTURE) s.next = join;
+          if (s.kind == CXG_NFA_BYTE_RANGE || s.kind == CXG_NFA_EPSILON || s.kind == CXG_NFA_CAPTURE || s.kind == CXG_NFA_LOOK) s.next = join;
         }
         return {sp, join};
       }
@@ -1184,8 +1190,11 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   Plan p;
   Shape sh{ast};
   int root = ast.root;
-  // The NFA builder already rejected look-around, '.', non-ASCII classes; (?i) literals survive it.
+  // The NFA builder already rejected line / text anchors, '.', non-ASCII classes; (?i) literals survive it.
   if (sh.foldAny(root)) p.confident = false;
+  // Word boundaries (\b \B) are the one kind of look-around that reaches here: hasWordBoundary strategy.go, and they
+  // count as anchor assertions / non-line anchors in the rules below.
+  const bool wordB = sh.has(root, {Node::WordB, Node::NoWordB});
   LitX lx(ast);
   Lits pre = lx.prefixes(root, 0);  // ExtractPrefixes extractor.go:128-156 (trim cascade for > 64 literals)
   if (pre.v.size() > 64) {
@@ -1246,7 +1255,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     const auto& f = ast.at(x.kids[0]);
     return f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class;
   };
-  if (!fastPrefix) {
+  if (!fastPrefix && !wordB) {                                 // selectReverseStrategy returns at once for word boundaries (:975)
     int reverse = 0;
     bool decided = false;
     Lits suf = lx.suffixes(root, 0);
@@ -1286,7 +1295,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     if (comp) { p.strategy = CXG_USE_COMPOSITE_SEARCHER; return p; }
   }
   if (!good && !teddyLits && sh.simpleClass(root)) { p.strategy = CXG_USE_BOUNDED_BACKTRACKER; return p; }
-  if (teddyLits && allExact) { p.strategy = CXG_USE_TEDDY; return p; }   // selectLiteralStrategy :1143-1170
+  if (teddyLits && allExact && !wordB) { p.strategy = CXG_USE_TEDDY; return p; }   // selectLiteralStrategy :1143-1170 (no non-line anchors)
   if (acLits && allExact) { p.strategy = CXG_USE_AHO_CORASICK; return p; }
   if (nfaSize <= 100 && sh.digitLead(root)) {                              // shouldUseDigitPrefilter :511-523
     p.strategy = CXG_USE_DIGIT_PREFILTER;
@@ -1296,7 +1305,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   NfaB probe(ast);
   bool nullablePattern = probe.nullable(root);
   if (nfaSize < 20) {
-    if (nullablePattern) { p.strategy = CXG_USE_NFA; return p; }
+    if (nullablePattern || wordB) { p.strategy = CXG_USE_NFA; return p; }   // (hasWordBoundary && anchors) || canMatchEmpty, :1500-1510
     p.strategy = CXG_USE_DFA;
     if (!sh.lazyAny(root)) p.flags |= CXG_FLAG_HAS_REVERSE_DFA;             // buildReverseDFA compile.go:184-205
     return p;

@@ -18,13 +18,23 @@ namespace cxg {
 namespace {
 
 constexpr uint32_t kSep = 0xFFFFFFFEu;     // separates the levels of a stack in its key vector
+constexpr uint8_t kLookWordBoundary = 4, kLookNoWordBoundary = 5;   // nfa.Look (nfa/nfa.go:92-117), carried in cxg_nfa_state.lo
+inline int wordKind(int b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z'); }
 
 struct Stepper {
   const cxg_nfa& n;
   std::vector<uint32_t> mark;
   uint32_t gen = 0;
   std::vector<uint32_t> stack;
+  // look-around context of the position the closure is taken at: kinds (0 not word / outside the haystack, 1 word) of the
+  // byte in front of it and of the byte behind it; checkLook, nfa/pikevm.go:1646-1674
+  int left = 0, right = 0;
   explicit Stepper(const cxg_nfa& nfa) : n(nfa), mark(nfa.n_states, 0) {}
+  bool lookHolds(uint8_t look) const {
+    if (look == kLookWordBoundary) return left != right;
+    if (look == kLookNoWordBoundary) return left == right;
+    return false;                                                // line / text anchors: refused before any closure is taken
+  }
   void closure(std::vector<uint32_t>& out, uint32_t seed) {      // epsilonClosureInto, builder.go:245-293
     stack.clear();
     stack.push_back(seed);
@@ -36,6 +46,7 @@ struct Stepper {
       out.push_back(cur);
       const cxg_nfa_state& s = n.states[cur];
       if (s.kind == CXG_NFA_EPSILON || s.kind == CXG_NFA_CAPTURE) { if (s.next != CXG_NFA_INVALID) stack.push_back(s.next); }
+      else if (s.kind == CXG_NFA_LOOK) { if (lookHolds(s.lo) && s.next != CXG_NFA_INVALID) stack.push_back(s.next); }
       else if (s.kind == CXG_NFA_SPLIT) {
         if (s.right != CXG_NFA_INVALID) stack.push_back(s.right);
         if (s.left != CXG_NFA_INVALID) stack.push_back(s.left);
@@ -65,10 +76,16 @@ struct Stepper {
 
 }  // namespace
 
-bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why) {
+bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa) {
   image.clear();
+  bool hasLook = false;
   for (uint32_t i = 0; i < nfa.n_states; i++)
-    if (nfa.states[i].kind == CXG_NFA_LOOK) { why = "look-around assertion in NFA"; return false; }
+    if (nfa.states[i].kind == CXG_NFA_LOOK) {
+      if (nfa.states[i].lo != kLookWordBoundary && nfa.states[i].lo != kLookNoWordBoundary) { why = "line / text anchor in NFA (only \\b and \\B are served)"; return false; }
+      hasLook = true;
+    }
+  if (hasLook && !revNfa) { why = "internal: look-around program without its reversed NFA"; return false; }
+  const uint32_t nk = hasLook ? 2u : 1u;          // kinds of the byte behind a step (fsm.hpp "Look-around")
   if (nfa.start_unanchored == nfa.start_anchored) { why = "start-anchored pattern"; return false; }
   // byte classes (nfa/alphabet.go:100-166)
   bool boundary[256] = {false};
@@ -78,17 +95,25 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     if (s.kind == CXG_NFA_BYTE_RANGE) markb(s.lo, s.hi);
     else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) markb(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
   }
+  if (hasLook) { markb('0', '9'); markb('A', 'Z'); markb('_', '_'); markb('a', 'z'); }   // a class is all word bytes or none
   std::vector<int> reps;
   uint8_t cls[256];
   for (int b = 0; b < 256; b++) { if (b == 0 || boundary[b - 1]) reps.push_back(b); cls[b] = static_cast<uint8_t>(reps.size() - 1); }
-  const uint32_t ncls = static_cast<uint32_t>(reps.size());
-  if (ncls > 64) { why = "more than 64 byte classes"; return false; }
+  const uint32_t nbc = static_cast<uint32_t>(reps.size());      // byte classes
+  const uint32_t ncls = nbc * nk;                               // input symbols = table columns: nk * class + kind of the next byte
+  if (ncls > 64) { why = "more than 64 input symbols (byte classes x kinds)"; return false; }
+  auto kindOf = [&](uint32_t bc) { return hasLook ? wordKind(reps[bc]) : 0; };
 
   Stepper st(nfa);
-  std::vector<uint32_t> fresh;
-  st.gen++;
-  st.closure(fresh, nfa.start_unanchored);
-  if (st.matchIndex(fresh) >= 0) { why = "nullable pattern (empty matches)"; return false; }
+  // the search that starts at a position, by the kinds of the bytes on its two sides
+  std::vector<uint32_t> freshLR[2][2];
+  for (int l = 0; l < 2; l++)
+    for (int r = 0; r < 2; r++) {
+      st.gen++;
+      st.left = l; st.right = r;
+      st.closure(freshLR[l][r], nfa.start_unanchored);
+      if (st.matchIndex(freshLR[l][r]) >= 0) { why = "nullable pattern (empty matches)"; return false; }
+    }
 
   // ---- transducer states: stacks of thread lists
   std::map<std::vector<uint32_t>, uint32_t> ids;
@@ -114,7 +139,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   auto eventOf = [&](uint32_t kind, uint32_t j, bool conts, uint32_t died) -> uint32_t {   // descriptor, 0 = nothing happened
     return kind | (j << 2) | (conts ? 32u : 0u) | (died << 8);
   };
-  intern({fresh});
+  intern({freshLR[0][0]});                        // row 0: the search at the haystack's first byte (in front of it: nothing = not word)
+  const uint32_t start1 = hasLook ? intern({freshLR[0][1]}) : 0u;   // ... when that byte is a word byte
   for (uint32_t cur = 0; cur < keys.size() && !tooBig; cur++) {
     // split the key into its levels
     std::vector<std::pair<size_t, size_t>> lv;    // [begin, end) in keys[cur]
@@ -125,7 +151,9 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     }
     const size_t nl = lv.size() - 1;              // pending levels; lv[nl] is the innermost search
     for (uint32_t c = 0; c < ncls && !tooBig; c++) {
-      const int b = reps[c];
+      const int b = reps[c / nk];
+      st.left = kindOf(c / nk); st.right = static_cast<int>(c % nk);   // both sides of the position behind this byte
+      const std::vector<uint32_t>& fresh = freshLR[st.left][st.right];
       const std::vector<uint32_t> key = keys[cur];   // copy: keys grows
       std::vector<std::vector<uint32_t>> next;
       uint32_t died = 0, ev = 0;
@@ -216,7 +244,58 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   const uint32_t stride = rowBytes / 2;
   const uint32_t nRows = nT + nA + nU + 1;
   if (static_cast<size_t>(nRows) * rowBytes > cxgdev::kFsmMaxTableBytes) { why = "FindAll transducer table exceeds the LDS budget"; return false; }
-  if (rev.nstates == 0 || static_cast<size_t>(rev.nstates) * ncls * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
+  // Reverse automaton of a look-around program: subset construction over the same symbols, mirrored — the step over byte i
+  // (walking down) sees the kind of hay[i-1], so both sides of position i are known when its closure is taken.  Sets, not
+  // lists: the reverse search runs without break-at-match (meta/compile.go:193-194).  Row 0 dead, accepting rows last.
+  std::vector<std::vector<uint32_t>> rtab;          // [state][ncls] (renumbered)
+  uint32_t rStates = rev.nstates, rFirstAccept = rev.firstAccept, rStart = rev.start;
+  uint32_t rStart4[4] = {0, 0, 0, 0};
+  if (hasLook) {
+    Stepper rs(*revNfa);
+    std::map<std::vector<uint32_t>, uint32_t> rid;
+    std::vector<std::vector<uint32_t>> rsets;
+    std::vector<std::vector<uint32_t>> rnext;
+    auto rintern = [&](std::vector<uint32_t> set) -> uint32_t {
+      std::sort(set.begin(), set.end());
+      set.erase(std::unique(set.begin(), set.end()), set.end());
+      auto it = rid.find(set);
+      if (it != rid.end()) return it->second;
+      const uint32_t id = static_cast<uint32_t>(rsets.size());
+      rid.emplace(set, id);
+      rsets.push_back(set);
+      rnext.emplace_back(ncls, 0u);
+      return id;
+    };
+    rintern({});                                   // 0: dead
+    uint32_t s4[4];
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < 2; r++) {
+        std::vector<uint32_t> set;
+        rs.gen++;
+        rs.left = l; rs.right = r;
+        rs.closure(set, revNfa->start_anchored);
+        s4[2 * l + r] = rintern(set);
+      }
+    for (uint32_t cur = 1; cur < rsets.size(); cur++) {
+      if (rsets.size() > 4096) { why = "reverse automaton too large"; return false; }
+      for (uint32_t c = 0; c < ncls; c++) {
+        rs.left = static_cast<int>(c % nk); rs.right = kindOf(c / nk);
+        const std::vector<uint32_t> lst = rsets[cur];
+        rnext[cur][c] = rintern(rs.step(lst.data(), lst.size(), reps[c / nk]));
+      }
+    }
+    std::vector<uint32_t> order, renum(rsets.size(), 0);
+    auto accepting = [&](uint32_t i) { return rs.matchIndex(rsets[i]) >= 0; };
+    for (uint32_t i = 0; i < rsets.size(); i++) if (!accepting(i)) { renum[i] = static_cast<uint32_t>(order.size()); order.push_back(i); }
+    rFirstAccept = static_cast<uint32_t>(order.size());
+    for (uint32_t i = 0; i < rsets.size(); i++) if (accepting(i)) { renum[i] = static_cast<uint32_t>(order.size()); order.push_back(i); }
+    rStates = static_cast<uint32_t>(order.size());
+    rtab.assign(rStates, std::vector<uint32_t>(ncls, 0u));
+    for (uint32_t i = 0; i < rStates; i++) for (uint32_t c = 0; c < ncls; c++) rtab[i][c] = renum[rnext[order[i]][c]];
+    for (int q = 0; q < 4; q++) { rStart4[q] = renum[s4[q]]; if (rStart4[q] >= rFirstAccept) { why = "nullable pattern (empty matches)"; return false; } }
+    rStart = rStart4[0];
+  }
+  if (rStates == 0 || static_cast<size_t>(rStates) * ncls * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
   auto offT = [&](uint32_t s) { return s * rowBytes; };
   auto offA = [&](uint32_t a) { return (nT + a) * rowBytes; };
   auto offU = [&](uint32_t u) { return (nT + nA + u) * rowBytes; };
@@ -230,6 +309,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   cxgdev::FsmHeader h;
   std::memset(&h, 0, sizeof h);
   h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_a = nA; h.n_u = nU; h.ncls = ncls; h.stride = stride; h.row_bytes = rowBytes; h.depth = depth;
+  h.nk = nk; h.start_off[0] = offT(0); h.start_off[1] = offT(start1);
   h.alias_lo = offA(0); h.u_lo = offU(0); h.top_off = offU(0); h.wide_off = wideOff; h.max_len = max_len;
   h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate); h.row_shift = rowShift;
   std::vector<uint8_t> img(sizeof h, 0);
@@ -239,8 +319,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     const uint8_t* q = static_cast<const uint8_t*>(d);
     img.insert(img.end(), q, q + n);
   };
-  uint8_t cls2[256];
-  for (int b = 0; b < 256; b++) cls2[b] = static_cast<uint8_t>(2 * cls[b]);
+  uint8_t cls2[256], knd[256];
+  for (int b = 0; b < 256; b++) { cls2[b] = static_cast<uint8_t>(2 * nk * cls[b]); knd[b] = static_cast<uint8_t>(hasLook ? 2 * wordKind(b) : 0); }
   std::vector<uint16_t> tab(static_cast<size_t>(nRows) * stride, 0);
   for (uint32_t s = 0; s < nT; s++) {
     for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(s) * stride + c] = target(trans[s][c]);
@@ -263,6 +343,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   put(tab.data(), tab.size() * 2, h.tab_off);
   if (h.tab_off != sizeof h) { why = "internal: image layout (scan_fsm.hip expects the transition table first)"; return false; }
   put(cls2, 256, h.cls_off);
+  if (hasLook) put(knd, 256, h.knd_off); else h.knd_off = h.cls_off;
   std::vector<uint16_t> mem(static_cast<size_t>(nU + 1) * cxgdev::kFsmMembers, 0xFFFF);
   for (uint32_t u = 0; u < nU; u++)
     if (sets[u].size() <= static_cast<size_t>(cxgdev::kFsmMembers))
@@ -271,14 +352,20 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   // reverse DFA, class-compressed, entries = byte offset of the target row; the classes come from the same NFA ranges,
   // so a class never straddles a reverse transition
   const uint32_t revRow = ncls * 2;
-  std::vector<uint16_t> rv(static_cast<size_t>(rev.nstates) * ncls, 0);
-  for (uint32_t s = 0; s < rev.nstates; s++)
-    for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rev.table[static_cast<size_t>(s) * 256 + reps[c]] * revRow);
-  for (uint32_t s = 0; s < rev.nstates; s++)
-    for (int b = 0; b < 256; b++)
-      if (rev.table[static_cast<size_t>(s) * 256 + b] * revRow != rv[static_cast<size_t>(s) * ncls + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
+  std::vector<uint16_t> rv(static_cast<size_t>(rStates) * ncls, 0);
+  if (hasLook) {
+    for (uint32_t s = 0; s < rStates; s++)
+      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rtab[s][c] * revRow);
+  } else {
+    for (uint32_t s = 0; s < rev.nstates; s++)
+      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rev.table[static_cast<size_t>(s) * 256 + reps[c]] * revRow);
+    for (uint32_t s = 0; s < rev.nstates; s++)
+      for (int b = 0; b < 256; b++)
+        if (rev.table[static_cast<size_t>(s) * 256 + b] * revRow != rv[static_cast<size_t>(s) * ncls + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
+  }
   put(rv.data(), rv.size() * 2, h.rev_off);
-  h.rev_states = rev.nstates; h.rev_start_off = rev.start * revRow; h.rev_accept_off = rev.firstAccept * revRow; h.rev_row_bytes = revRow;
+  h.rev_states = rStates; h.rev_start_off = rStart * revRow; h.rev_accept_off = rFirstAccept * revRow; h.rev_row_bytes = revRow;
+  for (int q = 0; q < 4; q++) h.rev_start4[q] = (hasLook ? rStart4[q] : rStart) * revRow;
   while (img.size() % 16) img.push_back(0);
   h.total_bytes = static_cast<uint32_t>(img.size());
   h.lds_bytes = h.total_bytes - static_cast<uint32_t>(sizeof h);

@@ -269,6 +269,7 @@ HostNfa reverseOf(const cxg_nfa& fwd) {
   const uint32_t N = fwd.n_states;
   std::vector<std::vector<cxg_nfa_trans>> byteIn(N);
   std::vector<std::vector<uint32_t>> epsIn(N);
+  std::vector<std::vector<std::pair<uint32_t, uint8_t>>> lookIn(N);   // (source state, nfa.Look): an assertion holds at a POSITION, so it reads the same backwards
   std::vector<uint8_t> skip(N, 0);
   if (fwd.start_unanchored != fwd.start_anchored && fwd.start_unanchored < N) {
     skip[fwd.start_unanchored] = 1;
@@ -290,6 +291,7 @@ HostNfa reverseOf(const cxg_nfa& fwd) {
         if (st.right < N) epsIn[st.right].push_back(s);
         break;
       case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE: if (st.next < N) epsIn[st.next].push_back(s); break;
+      case CXG_NFA_LOOK: if (st.next < N) lookIn[st.next].push_back({s, st.lo}); break;
       default: break;
     }
   }
@@ -310,6 +312,7 @@ HostNfa reverseOf(const cxg_nfa& fwd) {
       alts.push_back(add(sp));
     }
     for (uint32_t s : epsIn[t]) alts.push_back(s);
+    for (auto& lk : lookIn[t]) { cxg_nfa_state ls = blank(CXG_NFA_LOOK); ls.lo = lk.second; ls.next = lk.first; alts.push_back(add(ls)); }
     if (alts.empty()) continue;
     uint32_t chain = alts.back();
     for (size_t i = alts.size() - 1; i-- > 0;) { cxg_nfa_state sp = blank(CXG_NFA_SPLIT); sp.left = alts[i]; sp.right = chain; chain = add(sp); }
@@ -523,8 +526,12 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why) {
       case CXG_NFA_SPLIT:
         if (!target(s.left) || !target(s.right)) return bad(i, "split target out of range");
         break;
-      case CXG_NFA_EPSILON: case CXG_NFA_LOOK:
+      case CXG_NFA_EPSILON:
         if (!target(s.next)) return bad(i, "next out of range");
+        break;
+      case CXG_NFA_LOOK:
+        if (!target(s.next)) return bad(i, "next out of range");
+        if (s.lo > 5) return bad(i, "unknown look-around kind (nfa.Look is 0..5)");
         break;
       case CXG_NFA_CAPTURE:
         if (!target(s.next)) return bad(i, "next out of range");
@@ -672,6 +679,27 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         }
       } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
       if (!prefixLiterals.empty()) appendPrefixAux(blob, h, prefixLiterals, prefixDfa);
+    } else if (strategy == CXG_USE_NFA) {
+      // UseNFA: the reference answers through its PikeVM (find_indices.go:520-560 -> nfa/pikevm.go SearchAt): plain
+      // leftmost-first with the assertions of nfa.Look checked at each position (pikevm.go:1646-1674).  Reached by small
+      // patterns with word boundaries (meta/strategy.go:1377-1546: `\berror\b`, `\b\d+\b`), which no DFA strategy takes.
+      // Served by the transducer kernel alone (fsm.hpp "Look-around"): no table-walking image exists for such programs.
+      if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+      HostNfa rn = reverseOf(nfa);
+      cxg_nfa rvw = rn.view();
+      bool look = false;
+      for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;
+      Dfa rv;
+      if (!look) rv = determinize(rvw, rvw.start_anchored, false, kMaxDfaStates);
+      if (!buildFsmImage(nfa, rv, 0u, p->fsmBlob, p->fsmWhyNot, look ? &rvw : nullptr)) { p->fsmBlob.clear(); throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
+      h.kind = cxgdev::kKindFsmOnly;
+      h.info_off = static_cast<uint32_t>(blob.size());
+      blob.insert(blob.end(), info, info + 256);
+      h.total_bytes = static_cast<uint32_t>(blob.size());
+      std::memcpy(blob.data(), &h, sizeof h);
+      p->blob.swap(blob);
+      p->supported = true;
+      return;
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
     }

@@ -74,7 +74,8 @@ typedef struct cxg_nfa_trans {  /* nfa.Transition (nfa/nfa.go:138-142) */
 
 typedef struct cxg_nfa_state {  /* nfa.State (nfa/nfa.go:119-154), flattened */
   uint8_t kind;        /* cxg_nfa_kind */
-  uint8_t lo, hi;      /* BYTE_RANGE */
+  uint8_t lo, hi;      /* BYTE_RANGE; LOOK: lo = nfa.Look (nfa/nfa.go:92-117: 0 StartText, 1 EndText, 2 StartLine,
+                          3 EndLine, 4 WordBoundary, 5 NoWordBoundary) */
   uint8_t cap_start;   /* CAPTURE: 1 = opening */
   uint32_t next;       /* BYTE_RANGE / EPSILON / CAPTURE / LOOK */
   uint32_t left, right;/* SPLIT (left is explored first) */

@@ -12,17 +12,28 @@ ATOMS = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", "abc", "xyz", "a:c", "(b*c)?", "(a|ab)", "(abc|ab|a)", "b*", "(ab*c|a|bb)", "a+?", "[ab]*?c"]
 
-def main(n=300, seed=1):
+LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+", r"(a|\b)", r"(\bab|xy\b)", r"\b\b", r"(?:\bx)+"]
+
+def main(n=300, seed=1, look=False):
     rng = np.random.default_rng(seed)
-    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n", dtype=np.uint8)
+    alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n" + (b"_A  __" if look else b""), dtype=np.uint8)
+    atoms = ATOMS + LOOK_ATOMS * 3 if look else ATOMS
+    n_strat = 0
     seen, n_img, n_checked, reasons = set(), 0, 0, {}
     t0 = time.time()
     while len(seen) < n:
-        pat = "".join(ATOMS[int(rng.integers(0, len(ATOMS)))] for _ in range(int(rng.integers(1, 5))))
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
         if pat in seen: continue
+        if look and "\\b" not in pat and "\\B" not in pat: continue
         seen.add(pat)
         try: rx = cx.compile(pat)
         except cx.CoregexError: continue
+        if look:                                                      # the front-end's strategy for word-boundary patterns == the oracle's
+            os_ = O.Regex(pat)
+            if os_.strategy_restated and rx.strategy != os_.strategy:
+                print("STRATEGY", repr(pat), rx.strategy, os_.strategy)
+                return 1
+            n_strat += 1
         img = rx.fsm_image()
         simg = rx.fsm_image(True) if rx.num_groups > 1 else None
         if img is None and simg is None: continue
@@ -60,8 +71,9 @@ def main(n=300, seed=1):
                         np.save("/tmp/fsm_fail_hay.npy", hay)
                         print("MISMATCH", repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), got[:6].tolist(), exp[:6].tolist())
                         return 1
+    if look: print(f"{n_strat} strategies compared with the oracle")
     print(f"{len(seen)} patterns, {n_img} with a transducer image, {n_checked} comparisons clean, fallback reasons {reasons}, {time.time()-t0:.1f}s")
     return 0
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1, len(sys.argv) > 3 and sys.argv[3] == "look"))

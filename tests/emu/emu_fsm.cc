@@ -13,10 +13,13 @@
 using namespace cxgdev;
 
 namespace {
-struct HostMem {
-  const uint8_t* g;   // hay + tile origin
-  uint32_t byte(int32_t r) const { return g[r]; }
-  uint32_t dword(int32_t r) const { uint32_t v; std::memcpy(&v, g + r, 4); return v; }
+template <bool LOOK>
+struct HostMem : FsmClassify<HostMem<LOOK>, LOOK> {
+  const uint8_t* hay;   // whole haystack
+  int64_t origin_abs;   // absolute position of the tile origin
+  int64_t len;
+  uint32_t byte(int32_t r) const { const int64_t p = origin_abs + r; return (p >= 0 && p < len) ? hay[p] : 0u; }   // outside: zeros, as in the kernel's window
+  uint32_t dword(int32_t r) const { return byte(r) | (byte(r + 1) << 8) | (byte(r + 2) << 16) | (byte(r + 3) << 24); }
 };
 struct LaneRows {
   int32_t end[kFsmLaneRowsMax];
@@ -38,6 +41,9 @@ FsmView view_of(const uint8_t* img) {
   v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
+  v.knd = img + h->knd_off;
+  v.start1 = h->start_off[1];
+  for (int q = 0; q < 4; q++) v.rev_start4[q] = h->rev_start4[q];
   return v;
 }
 }  // namespace
@@ -46,10 +52,10 @@ FsmView view_of(const uint8_t* img) {
 // fallback flag (reason 1: a lane's entry state did not collapse, 2: more than kFsmLaneRows rows in a chunk,
 // 4: level stack overflow, 8: walk budget), -1 on a bad image.  stats (optional, 4 values): chunks, chunks whose entry
 // needed the full warm-up, chunks whose entry set did not collapse, rows fixed against the previous row.
-extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
-                                    int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
+template <bool LOOK>
+static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                       int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
-  if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
   const FsmView v = view_of(img);
   std::vector<int64_t> res;
   const int lanes = tile / chunk;
@@ -63,13 +69,14 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
     const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
     const int32_t budget = rend < tile + budget_bytes ? rend : tile + budget_bytes;
     const int32_t lowest = tile_lo > static_cast<uint64_t>(budget_bytes) ? -budget_bytes : -static_cast<int32_t>(tile_lo);
-    HostMem m{hay + tile_lo};
+    HostMem<LOOK> m;
+    m.hay = hay; m.origin_abs = static_cast<int64_t>(tile_lo); m.len = static_cast<int64_t>(len);
     bool first_in_tile = true;
     for (int lane = 0; lane < lanes; lane++) {
       const int32_t c0 = lane * chunk, c1 = c0 + chunk;
       if (c0 >= rend) break;
       st[0]++;
-      uint32_t entry = 0;
+      uint32_t entry = m.origin(v);                       // (only used at the haystack's first byte)
       if (tile_lo + static_cast<uint64_t>(c0) > 0) {
         // the kernel's policy: 16 bytes first, 64 bytes when the set has not collapsed by then
         const int64_t avail = static_cast<int64_t>(tile_lo) + c0;
@@ -105,14 +112,19 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
       for (uint32_t r = 0; r < L.nrows; r++) {
         const int32_t e = rows.end[r];
         uint32_t over = 0;
-        // the kernel knows the previous row's end only inside the tile; the tile's first row is walked without a bound
-        // and checked afterwards
-        const int64_t bound_abs = first_in_tile ? static_cast<int64_t>(tile_lo) + lowest : prev_end;
-        int32_t s = fsm_match_start(v, m, e, static_cast<int32_t>(bound_abs - static_cast<int64_t>(tile_lo)), lowest, over);
-        if (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end) {
+        // the kernel knows the previous row's end only inside the tile; the tile's first row is walked without a bound —
+        // one byte below the window, so that a reverse DFA still alive at the window's first byte reports `over` — and
+        // checked afterwards.  With look-around a reverse step also reads the byte in front of its own: the walk stops
+        // one byte earlier (scan_fsm.hip rev_lowest).
+        const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;      // bytes exist in front of the window
+        const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
+        const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
+        int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over);
+        if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
+          // the kernel's epilogue: the walk again, bounded by the previous row's end, bytes from HBM / L2
           st[3]++;
           over = 0;
-          s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), lowest, over);
+          s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), -static_cast<int32_t>(tile_lo), over);
         }
         if (over) return -16 - 8;
         if (s == kFsmNoStart) return -2;
@@ -127,4 +139,13 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
   const int64_t n = static_cast<int64_t>(res.size());
   if (out && n <= cap_vals) std::memcpy(out, res.data(), static_cast<size_t>(n) * sizeof(int64_t));
   return n;
+}
+
+
+extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                    int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
+  return h->nk > 1 ? emu_fsm<true>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
+                   : emu_fsm<false>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
 }

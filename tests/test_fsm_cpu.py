@@ -1,0 +1,84 @@
+"""CPU tier for the FindAll transducer (host/fsm.cc tables + the lane functions of device/fsm.hpp, run sequentially by
+tests/emu/emu_fsm.cc): rows == oracle for general DFAs, inputs without synchronising bytes and word-boundary programs,
+over several tile / chunk geometries.  The GPU tier (test_gpu_fsm.py) runs the same functions inside scan_fsm.hip."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+import emu
+from refcorpus import generate_test_input
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+GEOMS = ((3840, 32), (256, 16), (64, 8), (32, 4), (128, 32))
+GENERAL = [r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|foo)\d*", r"[1-9][0-9]*|0", r"x[ab]+?y", r"ab|abc", r"[a-c]x|[b-d]y",
+           r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal", r"ax|x?b+",
+           r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"]
+LOOK = [r"\berror\b", r"\b\d+\b", r"\bGET\b", r"\b(GET|PUT)\b", r"\Berror", r"error\B", r"\b[A-Z]+\b", r"ab(a|\b)", r"(ab)+(a|\b)\b\b", r"\b\d+\.\d+\b",
+        r"\berror\w*", r"\b[a-z]+\b", r"\b0x[0-9a-f]+\b", r"\w+\b", r"a\B", r"(?:\bx)+", r"x\b|\By", r"\b_+\b"]
+
+
+def _check(oracle, pat, hays, look):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.supported, (pat, rx.why_unsupported)
+    img = rx.fsm_image()
+    assert img is not None, pat
+    if look:
+        assert o.strategy == "UseNFA" and o.strategy_restated and rx.strategy == "UseNFA", (pat, o.strategy, rx.strategy)
+    n_ok = 0
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        for tile, chunk in GEOMS:
+            got = emu.find_all_fsm(img, hay, tile, chunk)
+            if isinstance(got, int) and got in (-18, -32):           # a chunk's row / event buffers: the kernel's mode 2
+                got = emu.find_all_fsm(img, hay, tile, chunk, dense=1)
+            if isinstance(got, int):
+                assert got in (-17, -18, -20, -24, -32), (pat, tile, chunk, got)   # fallback reasons the kernel raises too
+                continue
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, tile, chunk, len(hay))
+            n_ok += 1
+    assert n_ok >= len(hays), (pat, n_ok)                               # most geometries must actually answer
+
+
+def _hays(seed):
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"abcxyz_A.:-0123456789  \n", dtype=np.uint8)
+    hays = [generate_test_input(), cx.synth_pages(2, 0xC0FFEE02, 3, 8).tobytes(), cx.synth_pages(1, 0xC0FFEE01, 5, 8).tobytes(),
+            b"", b"a", b"error", b" error", b"error ", b"xerror error_ error", b"GET /a PUT x GETS", b"1.2.3.4.5.6.7.8.9 " * 40,
+            b"abcabcabxyzxyz" * 50, b"0x1f 0xZZ x0x12 0x12_ 0xab"]
+    hays += [alpha[rng.integers(0, len(alpha), size=int(k))].tobytes() for k in (7, 63, 64, 65, 300, 3000)]
+    hays += [alpha[rng.integers(0, 5, size=900)].tobytes(), alpha[rng.integers(6, 12, size=700)].tobytes()]
+    return hays
+
+
+@pytest.mark.parametrize("pat", GENERAL)
+def test_transducer_twin_general(oracle, pat):
+    _check(oracle, pat, _hays(len(pat)), look=False)
+
+
+@pytest.mark.parametrize("pat", LOOK)
+def test_transducer_twin_word_boundaries(oracle, pat):
+    """\\b / \\B: the step over a byte also reads the kind of the next one (fsm.hpp "Look-around"); the reverse automaton is
+    built look-aware on the host; the byte on either side of the haystack counts as "not a word byte"."""
+    _check(oracle, pat, _hays(100 + len(pat)), look=True)
+
+
+def test_word_boundary_scope(oracle):
+    """Served: UseNFA programs (small patterns; PikeVM semantics in the reference).  Refused at build time: line / text
+    anchors, nullable patterns, and the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)."""
+    for pat, frag in ((r"(?m)^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"\b(GET|POST|PUT)\b", "look-around"),
+                      (r"\b[a-f0-9]{8}\b", "look-around")):
+        rx = cx.compile(pat)
+        assert not rx.supported and frag in rx.why_unsupported, (pat, rx.why_unsupported)
+    img = cx.compile(r"\berror\b").fsm_image()
+    hdr = np.frombuffer(img[:4 * 40], dtype=np.uint32)
+    assert hdr[0] == 0x43584736                                        # "CXG6"
+
+
+def test_transducer_fuzz_smoke():
+    import cpu_fuzz_fsm
+    assert cpu_fuzz_fsm.main(120, 20260927) == 0
+    assert cpu_fuzz_fsm.main(250, 20260928, look=True) == 0

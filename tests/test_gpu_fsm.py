@@ -122,3 +122,96 @@ def test_dense_and_unconverged_input_falls_back_exactly(oracle):
     rx, o = cx.compile(pat), oracle.Regex(pat)
     for hay in (b"1.2 " * 20000, b"1.1" * 9000, b"1.2.3.4.5.6.7.8.9 " * 500):
         assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))
+
+
+# ---- word boundaries (\b \B): UseNFA in the reference (PikeVM, nfa/pikevm.go:1646-1674), the transducer kernel here with
+# (class of this byte, kind of the next byte) as input symbol (fsm.hpp "Look-around").  No table-walking fallback exists.
+LOOK = [r"\berror\b", r"\b\d+\b", r"\bGET\b", r"\b(GET|PUT)\b", r"\Berror", r"error\B", r"\b[A-Z]+\b", r"ab(a|\b)", r"\b\d+\.\d+\b", r"\berror\w*",
+        r"\b[a-z]+\b", r"\b0x[0-9a-f]+\b"]
+
+
+@pytest.mark.parametrize("pat", LOOK)
+def test_word_boundary_programs(oracle, pat):
+    rx = cx.compile(pat)
+    o = oracle.Regex(pat)
+    assert o.strategy == "UseNFA" and o.strategy_restated and rx.strategy == "UseNFA", (pat, o.strategy, rx.strategy)
+    assert rx.supported, rx.why_unsupported
+    hays = [generate_test_input()]
+    hays += [cx.synth_pages(c, 0xC0FFEE00 + c, 3, 256).tobytes() for c in (1, 2, 3)]
+    hays += [b"", b"error", b"error ", b" error", b"xerror error_ error", b"GET", b"12", b"a", b"POST /x GET", b"aba ab ab_ abab", b"deadbeef 0deadbeef deadbeef0 12345678"]
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
+        assert rx.count(hay) == len(exp)
+    rows, t = _device_rows(rx, hays[1])
+    assert np.array_equal(rows, o.find_all_index(hays[1]))
+    assert t.kernel == K_FSM, (pat, t.kernel)
+
+
+def test_word_boundary_edges(oracle):
+    """The assertion reads the byte on either side of a position: word / non-word neighbours across chunk (32 / 64 B),
+    wave-tile (3840 B), window (4032 B) and group (120 KiB) edges, at the haystack's first and last byte, and for inputs that
+    end exactly on such an edge (the byte behind the end counts as "not a word byte")."""
+    group = 3840 * 32
+    for pat in (r"\berror\b", r"\Berror", r"error\B", r"\b[a-z]+\b"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        base = np.full(2 * group + 5000, ord(" "), dtype=np.uint8)
+        offs = [0, 1, 27, 31, 32, 59, 63, 64, 3835, 3839, 3840, 3841, 4027, 4031, 4032, 4091, 4096, group - 5, group - 1, group, group + 1, 2 * group - 3]
+        for off in offs:
+            for lit in (b"error", b"xerror", b"errorx", b"_error_", b"error error"):
+                hay = base.copy()
+                a = np.frombuffer(lit, dtype=np.uint8)
+                hay[off:off + len(a)] = a
+                exp = o.find_all_index(hay)
+                rows, t = _device_rows(rx, hay)
+                assert np.array_equal(rows, exp) and t.kernel == K_FSM, (pat, off, lit, rows.tolist(), exp.tolist())
+        for n in (1, 5, 6, 31, 32, 33, 63, 64, 65, 3839, 3840, 3841, 4031, 4032, 4033, 4095, 4096, 4097, group - 1, group, group + 1):
+            for tail in (b"error", b"xerror", b" error", b"errorx"):
+                hay = np.full(n, ord(" "), dtype=np.uint8)
+                k = min(len(tail), n)
+                hay[n - k:] = np.frombuffer(tail, dtype=np.uint8)[len(tail) - k:]
+                assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), (pat, n, tail)
+                head = np.full(n, ord(" "), dtype=np.uint8)
+                head[:k] = np.frombuffer(tail, dtype=np.uint8)[:k]
+                assert np.array_equal(rx.find_all_index(head), o.find_all_index(head)), (pat, n, tail, "head")
+
+
+def test_word_boundary_long_words_and_budgets(oracle):
+    """A word longer than the window: `\\b[a-z]+\\b` creates its match only where the closing assertion holds, the start
+    is then found from HBM in the epilogue (exact).  `\\berror\\w*` keeps a match pending while the word goes on: past the
+    window that is the kernel's walk budget and, with no table-walking image to fall back to, CXG_E_INPUT."""
+    group = 3840 * 32
+    rx, o = cx.compile(r"\b[a-z]+\b"), oracle.Regex(r"\b[a-z]+\b")
+    for n, off in ((150, 3800), (700, 3000), (5000, 100), (70000, group - 1000)):
+        hay = np.full(2 * group + 5000, ord(" "), dtype=np.uint8)
+        hay[off:off + n] = ord("q")
+        hay[off + n + 1:off + n + 4] = np.frombuffer(b"abc", dtype=np.uint8)
+        exp = o.find_all_index(hay)
+        assert len(exp) == 2
+        assert np.array_equal(rx.find_all_index(hay), exp), (n, off)
+    rx2, o2 = cx.compile(r"\berror\w*"), oracle.Regex(r"\berror\w*")
+    hay = np.full(20000, ord(" "), dtype=np.uint8)
+    hay[100:105] = np.frombuffer(b"error", dtype=np.uint8)
+    hay[105:165] = ord("z")
+    assert np.array_equal(rx2.find_all_index(hay), o2.find_all_index(hay))          # 65 bytes: inside the window
+    hay[105:5000] = ord("z")
+    with pytest.raises(cx.CoregexError) as ei:
+        rx2.find_all_index(hay)
+    assert ei.value.code == _lib.CXG_E_INPUT
+    assert np.array_equal(rx2.find_all_index(hay[:90]), o2.find_all_index(hay[:90]))  # the program stays usable
+
+
+def test_word_boundary_program_from_nfa(oracle):
+    """The cgo shim's route: nfa.State with StateLook (cxg_nfa_state.lo = nfa.Look) through cxg_program_from_nfa."""
+    pat = r"\bGET\b"
+    src = cx.compile(pat)
+    nfa, keep = cx.flatten_nfa(src.nfa())
+    prog = cx.program_from_nfa(nfa, "UseNFA", 0)
+    assert prog.supported, prog.why_unsupported
+    hay = cx.synth_pages(1, 0xC0FFEE01, 0, 64).tobytes() + b" GET POSTS xGET GET_ POST"
+    assert np.array_equal(prog.find_all_index(hay), oracle.Regex(pat).find_all_index(hay))
+    # larger patterns with word boundaries are UseDFA / UseBoth in the reference (its lazy DFA carries the look state,
+    # dfa/lazy/builder.go:183-242 — not restated, not served): refused at build time, the caller keeps its CPU loop
+    big = cx.compile(r"\b(GET|POST|PUT)\b")
+    assert big.strategy == "UseDFA" and not big.supported

@@ -56,7 +56,12 @@ PATTERNS = [
 ]
 
 
-@pytest.mark.parametrize("pat", PATTERNS)
+# word boundaries: UseNFA in the reference (PikeVM), the transducer kernel here (fsm.hpp "Look-around")
+LOOK_PATTERNS = [r"\berror\b", r"\b\d+\b", r"\bfoo\w+", r"\b(GET|POST)\b", r"\w+\b", r"\Btest", r"ab(a|\b)", r"(ab)+(a|\b)\b\b", r"\b[a-z]+\b",
+                 r"(?:\bx)+", r"a\B", r"\b\b", r"x\b|\By"]
+
+
+@pytest.mark.parametrize("pat", PATTERNS + LOOK_PATTERNS)
 def test_frontend_agrees_with_oracle(oracle, pat):
     o = oracle.Regex(pat)
     p = cx.compile(pat)
@@ -68,8 +73,8 @@ def test_frontend_agrees_with_oracle(oracle, pat):
 
 def test_nfa_view_matches_oracle_dump(oracle):
     """State-by-state comparison of the product NFA with the oracle's (creation order is semantic)."""
-    kinds = {0: "Match", 1: "ByteRange", 2: "Sparse", 3: "Split", 4: "Eps", 5: "Cap"}
-    for pat in PATTERNS:
+    kinds = {0: "Match", 1: "ByteRange", 2: "Sparse", 3: "Split", 4: "Eps", 5: "Cap", 7: "Look"}
+    for pat in PATTERNS + LOOK_PATTERNS:
         p = cx.compile(pat)
         v = p.nfa()
         lines = oracle.Regex(pat).dump().strip().split("\n")[2:]
@@ -91,6 +96,8 @@ def test_nfa_view_matches_oracle_dump(oracle):
                 assert body == "Match"
             elif k == "Cap":
                 assert body == f"Cap{st.cap_index}{'(' if st.cap_start else ')'}->{st.next}", (pat, i, body)
+            elif k == "Look":
+                assert body == f"Look{st.lo}->{st.next}", (pat, i, body)      # cxg_nfa_state.lo = nfa.Look
             else:
                 nxt = -1 if st.next == 0xFFFFFFFF else st.next
                 assert body == f"Eps->{nxt}", (pat, i, body)
@@ -583,9 +590,12 @@ def test_program_routing_table():
         assert got[0] == strategy and got[1] == kind and (got[2] & must) == must and (got[2] & must_not) == 0, (pat, got)
     assert image(r"(\w+)@(\w+)\.(\w+)", sub=True)[2] & chain and cx.compile(r"(\w+)@(\w+)\.(\w+)").chain_captures() is not None
     assert image(r"(GET|POST|PUT) /([a-z/]+)", sub=True)[2] & prefix
-    for pat, why in [(r"a?(a|b)", "cache history"), (r"\w+@\w+\.\w+", "has no device kernel"), (r"\bfoo\b", "look-around")]:
+    for pat, why in [(r"a?(a|b)", "cache history"), (r"\w+@\w+\.\w+", "has no device kernel"), (r"\b(foo|bar|bazz|quux)\b", "look-around"),
+                     (r"(?m)^foo", "anchor")]:
         rx = cx.compile(pat)
         assert not rx.supported and why in rx.why_unsupported, (pat, rx.strategy, rx.why_unsupported)
+    wb = cx.compile(r"\bfoo\b")                       # small word-boundary patterns: UseNFA, transducer kernel only (kind 5, no tables)
+    assert wb.supported and wb.strategy == "UseNFA" and image(r"\bfoo\b")[1] == 5 and wb.fsm_image() is not None
 
 
 def test_bounded_repetition_chain_emulated(oracle):
@@ -720,8 +730,14 @@ def test_fat_teddy_programs(oracle):
         assert q.strategy == "UseTeddy" and q.supported, (n, q.why_unsupported)
         hay = (" ".join(words[::-1]) + " lit0 lit00 lit99z").encode()
         assert emu.find_all(q.blob(), hay, 4).tolist() == oracle.Regex("|".join(words)).find_all_index(hay).tolist()
-    q = cx.compile("|".join("lit%02dz" % i for i in range(65)))
-    assert not q.supported
+    # 65 literals with a common prefix: regexp/syntax factors it, the NFA passes 200 states: UseNFA (PikeVM) in the reference —
+    # the transducer kernel serves it since round 2 (plain leftmost-first), no literal kernel involved
+    words = ["lit%02dz" % i for i in range(65)]
+    q = cx.compile("|".join(words))
+    oq = oracle.Regex("|".join(words))
+    assert q.strategy == "UseNFA" and oq.strategy == "UseNFA" and q.supported and q.fsm_image() is not None
+    hay = ("    ".join(words[::-1]) + " lit0 lit00 lit99z").encode()
+    assert emu.find_all_fsm(q.fsm_image(), hay, 256, 32).tolist() == oq.find_all_index(hay).tolist()
 
 
 def test_teddy_programs(oracle):
