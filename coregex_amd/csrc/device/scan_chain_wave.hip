@@ -593,6 +593,41 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? 6 : (NCLS >= 3 ? 
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);
   uint32_t start = 0;
+  if (CAP) {
+    // Rows of 2 * groups int64 (64 B for three groups): PARTS lanes share a row, each writes one 16-byte slot pair, so a
+    // store instruction covers 64 / PARTS whole rows = 1 KiB of contiguous output (one lane per row wrote 64 pieces of 16 B
+    // at a 64-byte stride per instruction: four times the requests into L2 for the same bytes).
+    const uint32_t parts = a.row_width >> 1;                          // 2..8, uniform
+    const uint32_t inv = (65536u + parts - 1u) / parts;               // i / parts == (i * inv) >> 16 for i < 4096
+    for (int j = 0; j < tpw; j++) {
+      const uint32_t n = s_cnt[wave][j];
+      const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
+      const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+      for (uint32_t i = lane; i < n * parts; i += 64) {
+        const uint32_t ri = (i * inv) >> 16, part = i - ri * parts;
+        const uint32_t r = start + ri;
+        if (r < static_cast<uint32_t>(kWRows) && dst + ri < a.cap) {
+          const int64_t ms = tb + s_rs[wave][r], me = tb + s_re[wave][r];
+          uint32_t sc0 = gcp->src[0], sc1 = gcp->src[1];
+          int32_t of0 = gcp->off[0], of1 = gcp->off[1];
+#pragma unroll
+          for (uint32_t q = 1; q < 8u; q++)                            // the lane's slot pair: uniform table, per-lane selects
+            if (part == q) { sc0 = gcp->src[2 * q]; sc1 = gcp->src[2 * q + 1]; of0 = gcp->off[2 * q]; of1 = gcp->off[2 * q + 1]; }
+          auto slot = [&](uint32_t sc, int32_t of) -> int64_t {
+            if (sc == kCapSrcUnset) return -1;
+            const int64_t ps = sc == kCapSrcStart ? ms : sc == kCapSrcEnd ? me : tb + s_rb[((sc - kCapSrcRun0) * kWavesPerBlock + wave) * kWRows + r];
+            return ps + of;
+          };
+          longlong2 o;
+          if (part == 0) { o.x = ms; o.y = me; }
+          else { o.x = slot(sc0, of0); o.y = slot(sc1, of1); }
+          *reinterpret_cast<longlong2*>(a.out + (dst + ri) * a.row_width + 2u * part) = o;
+        }
+      }
+      start += n;
+    }
+    return;
+  }
   for (int j = 0; j < tpw; j++) {
     const uint32_t n = s_cnt[wave][j];
     const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
@@ -601,21 +636,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? 6 : (NCLS >= 3 ? 
       if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
         const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
         longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
-        int64_t* row = a.out + (dst + i) * a.row_width;
-        *reinterpret_cast<longlong2*>(row) = v;                        // row_width > 2 without CAP: a capture pass fills the rest
-        if (CAP) {
-          auto slot = [&](uint32_t sc, int32_t of) -> int64_t {       // source and offset: scalar loads, uniform selects
-            if (sc == kCapSrcUnset) return -1;
-            const int64_t ps = sc == kCapSrcStart ? v.x : sc == kCapSrcEnd ? v.y : tb + s_rb[((sc - kCapSrcRun0) * kWavesPerBlock + wave) * kWRows + r];
-            return ps + of;
-          };
-          for (uint32_t q = 2; q + 1 < a.row_width && q + 1 < 16u; q += 2) {
-            longlong2 o;
-            o.x = slot(gcp->src[q], gcp->off[q]);
-            o.y = slot(gcp->src[q + 1], gcp->off[q + 1]);
-            *reinterpret_cast<longlong2*>(row + q) = o;
-          }
-        }
+        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;   // row_width > 2 without CAP: a capture pass fills the rest
       }
     }
     start += n;
