@@ -746,6 +746,12 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
     switch (plan.strategy) {
       case CXG_USE_CHARCLASS_SEARCHER: cxg::buildProgramFromCharClass(p, plan.membership, 1); break;
       case CXG_USE_TEDDY: {
+        if (plan.lineStart && !plan.lineStartAll) {
+          p->supported = false;
+          p->whyNot = "(?m)^ on some alternatives only: the reference applies its line-start check to every literal candidate (prefilter.WrapLineAnchor)";
+          break;
+        }
+        if (plan.lineStart) { cxg::buildProgramFromNfa(p, view, CXG_USE_TEDDY, 0); break; }   // (?m)^ + literals: the pattern's transducer
         std::vector<std::vector<uint8_t>> lits;
         for (auto& l : plan.prefixes) lits.push_back(l.bytes);
         cxg::buildProgramFromLiterals(p, lits);

@@ -73,26 +73,29 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t alias_lo, u_lo, top_off, wide_off;      // byte offsets of the first alias row, the first set row, "any state", wide
   uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u16[n_u + 1][8] rows of a set's members, 0xFFFF pad / not listed
   uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][ncls] target row byte offsets, row 0 dead; accepting rows >= rev_accept_off
-  uint32_t total_bytes, lds_bytes, max_len, nk;    // nk: kinds of the byte BEHIND a step that the step depends on (1: none; 2: word / not word, see "Look-around")
+  uint32_t total_bytes, lds_bytes, max_len, nk;    // nk: kinds of the byte BEHIND a step that the step depends on (1: none; 2 or 3, see "Look-around")
   uint32_t create_lo, rematch_lo, row_shift, knd_off; // row_bytes == 1 << row_shift; alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
-                                                   // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch.  knd: u8[256] = 2 * kind of a byte (nk > 1)
-  uint32_t start_off[2];                           // row of the search at the haystack's first byte, by the kind of that byte (nk == 1: both 0)
-  uint32_t rev_start4[4];                          // reverse start row for a match that ends at e, by 2 * kind(hay[e-1]) + kind(hay[e]) (nk == 1: all rev_start_off)
-  uint32_t pad3[2];
+                                                   // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch.  nk > 1: knd = u8[256] 2 * kind of a byte, then
+                                                   // u16[nk] start rows by the kind of the haystack's first byte, then u16[nk * nk] reverse start rows by
+                                                   // nk * kind(hay[e-1]) + kind(hay[e]) for a match that ends at e
+  uint32_t outside_byte, pad3[3];                  // what the positions in front of and behind the haystack read as ('\n' with line anchors, else 0)
 };
 
-// Look-around (word boundaries `\b`, `\B`; nfa.Look, nfa/nfa.go:92-117).  An assertion at position p reads the bytes
-// on both sides of p.  The machine stays a plain left-to-right transducer with IMMEDIATE acceptance when the step over
-// byte i also sees the KIND of byte i + 1 (word / not word; the byte behind the haystack's end — and the one in front of
-// its start — count as "not word", nfa/pikevm.go:1646-1674): the input symbol of a step is the pair (class of hay[i],
-// kind of hay[i+1]), column  nk * class + kind.  After the step both sides of position i + 1 are known, so every
+// Look-around (word boundaries `\b` `\B`, multi-line anchors `(?m)^` `(?m)$`; nfa.Look, nfa/nfa.go:92-117).  An assertion
+// at position p reads the bytes on both sides of p.  The machine stays a plain left-to-right transducer with IMMEDIATE
+// acceptance when the step over byte i also sees the KIND of byte i + 1 — word / other, newline / other, or all three,
+// whatever the pattern's assertions distinguish; the positions outside the haystack read as "not a word byte" and, for
+// the line anchors, as a newline (nfa/pikevm.go:1646-1674: pos == 0 / pos == len) — : the input symbol of a step is the
+// pair (class of hay[i], kind of hay[i+1]), column  nk * class + kind.  After the step both sides of position i + 1 are known, so every
 // assertion there is decided on the host when the table is built (host/fsm.cc) and a match that ends at i + 1 is
 // reported by the step over byte i as always.  The reverse DFA mirrors it: the step over byte i (walking down) sees
 // the kind of hay[i-1].  Only the class lookup changes — it is part of the Mem concept below, so programs without
 // assertions (nk == 1) compile to the same instructions as before.
+CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
 struct FsmView {
   const uint8_t* cls2;      // 2 * nk * class of a byte: byte offset of the class's first column
-  const uint8_t* knd;       // 2 * kind of a byte (nk > 1)
+  const uint8_t* knd;       // 2 * kind of a byte (nk > 1); behind it the start-row tables (FsmHeader::knd_off)
+  uint32_t nk;
   const uint8_t* tab;       // rows, addressed by byte offset
   const uint8_t* rev;
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
@@ -100,8 +103,6 @@ struct FsmView {
   uint32_t create_lo, rematch_lo;
   const uint8_t* mem;       // members of the set rows
   uint32_t row_shift;
-  uint32_t start1;          // start row when the haystack's first byte has kind 1 (kind 0: row 0)
-  uint32_t rev_start4[4];
 };
 // Class lookups of a Mem type, from its byte() / dword(): CRTP base shared by the kernel's LDS window and the twin's
 // host memory.  LOOK = the image has nk == 2.
@@ -132,21 +133,20 @@ struct FsmClassify {
   // reverse start row for a match that ends at e
   CXG_FSM_HD uint32_t rstart(const FsmView& v, int32_t e) const {
     if (!LOOK) return v.rev_start_off;
-    return v.rev_start4[v.knd[self().byte(e - 1)] + (v.knd[self().byte(e)] >> 1)];
+    const uint32_t idx = (v.knd[self().byte(e - 1)] >> 1) * v.nk + (v.knd[self().byte(e)] >> 1);
+    return fsm_u16(v.knd, 256u + 2u * v.nk + 2u * idx);
   }
   // start row of the search at the haystack's first byte (tile-relative position 0 of the first tile)
   CXG_FSM_HD uint32_t origin(const FsmView& v) const {
     if (!LOOK) return 0u;
-    return v.knd[self().byte(0)] ? v.start1 : 0u;
+    return fsm_u16(v.knd, 256u + v.knd[self().byte(0)]);
   }
   static constexpr bool kLook = LOOK;
 };
 // the state's own row (an alias row is a copy of it)
-CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off);
 CXG_FSM_HD uint32_t fsm_canon(const FsmView& v, uint32_t x) { return fsm_u16(v.tab, x + v.ncls2 + 4u); }
 // member j (0..7) of the set row u, as a row offset; 0xFFFF: none / the set is not listed
 CXG_FSM_HD uint32_t fsm_member(const FsmView& v, uint32_t u, uint32_t j) { return fsm_u16(v.mem, (((u - v.u_lo) >> v.row_shift) * 8u + j) * 2u); }
-CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
 // one step: entry t (row offset | flags) and 2 * class -> next entry
 CXG_FSM_HD uint32_t fsm_next(const FsmView& v, uint32_t t, uint32_t cls2) { return fsm_u16(v.tab, (t & ~3u) | cls2); }
 CXG_FSM_HD uint32_t fsm_shift_in2(uint32_t mask, uint32_t t) {   // (mask >> 2) | (t << 30): v_alignbit_b32

@@ -93,8 +93,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   v.knd = body + (h->knd_off - hs);
-  v.start1 = h->start_off[1];
-  for (int q = 0; q < 4; q++) v.rev_start4[q] = h->rev_start4[q];
+  v.nk = h->nk;
   return v;
 }
 
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
   const uint64_t group = s_group;
   if (group >= a.ngroups) return;
   const FsmView v = view_of(s_img, h);
+  const uint32_t outside = LOOK ? h->outside_byte : 0u;           // what the positions around the haystack read as
   constexpr int tpw = FsmMode<MODE>::kTpw;
   uint32_t nrows_w = 0, fallback = 0, long_hit = 0;
 
@@ -221,10 +221,14 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
       }
       issue_loads(j + 1);
-      wave_lds_sync();
-      FSM_MARK(0);                                      // window staged
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      if (LOOK && lane == 0) {                          // the byte in front of the haystack and the one behind its end (DS ops of a wave keep their order)
+        if (tile_lo == 0) win[kFsmLeft - 1] = static_cast<uint8_t>(outside);
+        if (rend < kFsmWinEnd) { const uint32_t w = static_cast<uint32_t>(rend + kFsmLeft); win[w + (w >> 6) * 4u] = static_cast<uint8_t>(outside); }
+      }
+      wave_lds_sync();
+      FSM_MARK(0);                                      // window staged
       // walks stay inside the window; with look-around a step also reads the byte behind its own (past the end of input
       // the window holds zeros: "not a word byte", as the reference treats the end of the text)
       constexpr int32_t kWinEnd = kFsmWinEnd - (LOOK ? 1 : 0);
@@ -485,11 +489,11 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         if (prev > s || s == e) {                                           // rare: walk again from HBM / L2, bounded
           const int64_t lo = prev > 0 ? prev : 0;
           uint32_t sr = v.rev_start_off;
-          if (LOOK) sr = v.rev_start4[v.knd[a.hay[e - 1]] + (v.knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : 0] >> 1)];
+          if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + (v.knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : outside] >> 1)));
           int64_t st = -1;
           for (int64_t at = e - 1; at >= lo; at--) {
             if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : 0] : 0u));
+            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
             if (sr == 0u) break;
             if (sr >= v.rev_accept_off) st = at;
           }
@@ -523,10 +527,11 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   const uint8_t* knd = a.blob + h->knd_off;
   const uint8_t* rev = a.blob + h->rev_off;
   const bool look = h->nk > 1;
-  uint32_t sr = look ? h->rev_start4[knd[a.hay[e - 1]] + (knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : 0] >> 1)] : h->rev_start_off;
+  const uint32_t outside = h->outside_byte;
+  uint32_t sr = look ? fsm_u16(knd, 256u + 2u * h->nk + 2u * ((knd[a.hay[e - 1]] >> 1) * h->nk + (knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : outside] >> 1))) : h->rev_start_off;
   int64_t st = -1;
   for (int64_t at = e - 1; at >= prev; at--) {
-    sr = fsm_u16(rev, sr + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : 0] : 0u));
+    sr = fsm_u16(rev, sr + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
     if (sr == 0u) break;
     if (sr >= h->rev_accept_off) st = at;
   }

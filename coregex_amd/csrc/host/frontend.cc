@@ -798,11 +798,12 @@ struct NfaB {
       case Node::Class: return cls(x);
       case Node::Empty: { uint32_t e = eps(); return {e, e}; }
       case Node::Any: case Node::AnyNotNL: unsupported("'.' (UTF-8 rune states)");
-      case Node::BeginLine: case Node::EndLine: case Node::BeginText: case Node::EndText:
-        unsupported("line / text anchors (^ $ \\A \\z)");
-      case Node::WordB: case Node::NoWordB: {       // compile.go:288-289 addLook; cxg_nfa_state.lo = nfa.Look (nfa/nfa.go:92-117)
+      case Node::BeginText: case Node::EndText:
+        unsupported("text anchors (\\A \\z, ^ $ without (?m))");
+      case Node::BeginLine: case Node::EndLine:
+      case Node::WordB: case Node::NoWordB: {       // compile.go:286-289 addLook; cxg_nfa_state.lo = nfa.Look (nfa/nfa.go:92-117)
         auto s = blank(CXG_NFA_LOOK);
-        s.lo = x.kind == Node::WordB ? 4 : 5;
+        s.lo = x.kind == Node::BeginLine ? 2 : x.kind == Node::EndLine ? 3 : x.kind == Node::WordB ? 4 : 5;
         const uint32_t id = push(s);
         return {id, id};
       }
@@ -1195,6 +1196,30 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   // Word boundaries (\b \B) are the one kind of look-around that reaches here: hasWordBoundary strategy.go, and they
   // count as anchor assertions / non-line anchors in the rules below.
   const bool wordB = sh.has(root, {Node::WordB, Node::NoWordB});
+  // Multi-line anchors (?m)^ (?m)$: hasMultilineLineAnchor strategy.go:1197-1210.  (?m)$ is a "non-line anchor" for the
+  // literal engines (hasNonLineAnchors compile.go:686-703), (?m)^ is not: Teddy keeps its complete literals behind a
+  // line-start check (prefilter.WrapLineAnchor, compile.go:670-677).  The multi-line reverse-suffix strategy needs a
+  // `.` wildcard (isMultilineLineAnchored strategy.go:728-730), which the NFA builder has refused already.
+  const bool lineAnchor = sh.has(root, {Node::BeginLine, Node::EndLine});
+  const bool nonLineAnchors = wordB || sh.has(root, {Node::EndLine});
+  p.lineStart = sh.has(root, {Node::BeginLine});
+  {
+    // Does every match begin at a line start?  (Used for UseTeddy below: the reference wraps the WHOLE literal prefilter
+    // in the line-start check as soon as the pattern holds a (?m)^ anywhere — `(?m)^foo|barr` then loses "barr" in mid-line,
+    // compile.go:670-677 — which equals the pattern's meaning only when all alternatives are anchored.)
+    std::function<bool(int)> needs = [&](int n) -> bool {
+      const auto& x = ast.at(n);
+      switch (x.kind) {
+        case Node::BeginLine: return true;
+        case Node::Capture: case Node::Plus: return !x.kids.empty() && needs(x.kids[0]);
+        case Node::Repeat: return x.min >= 1 && !x.kids.empty() && needs(x.kids[0]);
+        case Node::Concat: return !x.kids.empty() && needs(x.kids[0]);
+        case Node::Alt: if (x.kids.empty()) return false; for (int c : x.kids) if (!needs(c)) return false; return true;
+        default: return false;
+      }
+    };
+    p.lineStartAll = needs(root);
+  }
   LitX lx(ast);
   Lits pre = lx.prefixes(root, 0);  // ExtractPrefixes extractor.go:128-156 (trim cascade for > 64 literals)
   if (pre.v.size() > 64) {
@@ -1245,7 +1270,10 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
       const auto& y = ast.at(c);
       if ((y.kind == Node::Plus && ast.at(y.kids[0]).kind == Node::Class) || (y.kind == Node::Repeat && y.min >= 1)) wc++;
     }
-    return wc > 0;
+    if (wc == 0) return false;
+    for (size_t k = 1; k + 1 < x.kids.size(); k++)            // containsAnchor in a middle element (:628-632)
+      if (sh.has(x.kids[k], {Node::BeginLine, Node::EndLine, Node::BeginText, Node::EndText})) return false;
+    return true;
   };
   auto safeInner = [&](int n0) {    // isSafeForReverseInner :874-907
     int n = n0;
@@ -1255,7 +1283,9 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     const auto& f = ast.at(x.kids[0]);
     return f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class;
   };
-  if (!fastPrefix && !wordB) {                                 // selectReverseStrategy returns at once for word boundaries (:975)
+  // selectReverseStrategy returns at once for word boundaries (:988) and for an end anchor that does not end the pattern
+  // in the sense of nfa.isEndAnchored — which (?m)$ never does (nfa.HasImpossibleEndAnchor, nfa/compile.go:1858-1888)
+  if (!fastPrefix && !wordB && !sh.has(root, {Node::EndLine})) {
     int reverse = 0;
     bool decided = false;
     Lits suf = lx.suffixes(root, 0);
@@ -1295,7 +1325,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     if (comp) { p.strategy = CXG_USE_COMPOSITE_SEARCHER; return p; }
   }
   if (!good && !teddyLits && sh.simpleClass(root)) { p.strategy = CXG_USE_BOUNDED_BACKTRACKER; return p; }
-  if (teddyLits && allExact && !wordB) { p.strategy = CXG_USE_TEDDY; return p; }   // selectLiteralStrategy :1143-1170 (no non-line anchors)
+  if (teddyLits && allExact && !nonLineAnchors) { p.strategy = CXG_USE_TEDDY; return p; }   // selectLiteralStrategy :1143-1170 (no non-line anchors)
   if (acLits && allExact) { p.strategy = CXG_USE_AHO_CORASICK; return p; }
   if (nfaSize <= 100 && sh.digitLead(root)) {                              // shouldUseDigitPrefilter :511-523
     p.strategy = CXG_USE_DIGIT_PREFILTER;
@@ -1305,7 +1335,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   NfaB probe(ast);
   bool nullablePattern = probe.nullable(root);
   if (nfaSize < 20) {
-    if (nullablePattern || wordB) { p.strategy = CXG_USE_NFA; return p; }   // (hasWordBoundary && anchors) || canMatchEmpty, :1500-1510
+    if (nullablePattern || wordB || lineAnchor) { p.strategy = CXG_USE_NFA; return p; }   // hasWordBoundaryAnchorCombo || canMatchEmpty || hasMultilineLineAnchor, :1503
     p.strategy = CXG_USE_DFA;
     if (!sh.lazyAny(root)) p.flags |= CXG_FLAG_HAS_REVERSE_DFA;             // buildReverseDFA compile.go:184-205
     return p;

@@ -73,6 +73,8 @@ struct Plan {
   std::vector<PrefixLit> prefixes;
   uint8_t membership[256] = {0};   // UseCharClassSearcher
   bool confident = true;           // false: a strategy outside the subset may apply (reverse searchers etc.)
+  bool lineStartAll = false;       // ... and every match of the pattern begins at a line start
+  bool lineStart = false;          // the pattern holds (?m)^: a UseTeddy program checks its candidates for a line start (prefilter.WrapLineAnchor)
 };
 
 Plan selectStrategy(const Ast& ast, const HostNfa& nfa);

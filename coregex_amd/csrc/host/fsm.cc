@@ -18,7 +18,7 @@ namespace cxg {
 namespace {
 
 constexpr uint32_t kSep = 0xFFFFFFFEu;     // separates the levels of a stack in its key vector
-constexpr uint8_t kLookWordBoundary = 4, kLookNoWordBoundary = 5;   // nfa.Look (nfa/nfa.go:92-117), carried in cxg_nfa_state.lo
+constexpr uint8_t kLookStartLine = 2, kLookEndLine = 3, kLookWordBoundary = 4, kLookNoWordBoundary = 5;   // nfa.Look (nfa/nfa.go:92-117), carried in cxg_nfa_state.lo
 inline int wordKind(int b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z'); }
 
 struct Stepper {
@@ -26,14 +26,18 @@ struct Stepper {
   std::vector<uint32_t> mark;
   uint32_t gen = 0;
   std::vector<uint32_t> stack;
-  // look-around context of the position the closure is taken at: kinds (0 not word / outside the haystack, 1 word) of the
-  // byte in front of it and of the byte behind it; checkLook, nfa/pikevm.go:1646-1674
+  // look-around context of the position the closure is taken at: kinds of the byte in front of it and of the byte
+  // behind it (word[k] / newline[k] say what kind k is; the positions outside the haystack have a kind too: not a word
+  // byte, and a line edge); checkLook, nfa/pikevm.go:1646-1674
   int left = 0, right = 0;
+  bool word[3] = {false, false, false}, newline[3] = {false, false, false};
   explicit Stepper(const cxg_nfa& nfa) : n(nfa), mark(nfa.n_states, 0) {}
   bool lookHolds(uint8_t look) const {
-    if (look == kLookWordBoundary) return left != right;
-    if (look == kLookNoWordBoundary) return left == right;
-    return false;                                                // line / text anchors: refused before any closure is taken
+    if (look == kLookWordBoundary) return word[left] != word[right];
+    if (look == kLookNoWordBoundary) return word[left] == word[right];
+    if (look == kLookStartLine) return newline[left];            // pos == 0 || hay[pos-1] == '\n'
+    if (look == kLookEndLine) return newline[right];             // pos == len || hay[pos] == '\n'
+    return false;                                                // text anchors: refused before any closure is taken
   }
   void closure(std::vector<uint32_t>& out, uint32_t seed) {      // epsilonClosureInto, builder.go:245-293
     stack.clear();
@@ -78,14 +82,22 @@ struct Stepper {
 
 bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa) {
   image.clear();
-  bool hasLook = false;
+  bool hasWord = false, hasLine = false;
   for (uint32_t i = 0; i < nfa.n_states; i++)
     if (nfa.states[i].kind == CXG_NFA_LOOK) {
-      if (nfa.states[i].lo != kLookWordBoundary && nfa.states[i].lo != kLookNoWordBoundary) { why = "line / text anchor in NFA (only \\b and \\B are served)"; return false; }
-      hasLook = true;
+      const uint8_t lk = nfa.states[i].lo;
+      if (lk == kLookWordBoundary || lk == kLookNoWordBoundary) hasWord = true;
+      else if (lk == kLookStartLine || lk == kLookEndLine) hasLine = true;
+      else { why = "text anchor in NFA (\\A, \\z, ^ and $ without (?m) are not served)"; return false; }
     }
+  const bool hasLook = hasWord || hasLine;
   if (hasLook && !revNfa) { why = "internal: look-around program without its reversed NFA"; return false; }
-  const uint32_t nk = hasLook ? 2u : 1u;          // kinds of the byte behind a step (fsm.hpp "Look-around")
+  // kinds of the byte behind a step (fsm.hpp "Look-around"): what the pattern's assertions tell apart
+  const uint32_t nk = (hasWord && hasLine) ? 3u : (hasLook ? 2u : 1u);
+  const int kWord = hasWord ? 1 : -1, kNl = hasLine ? (hasWord ? 2 : 1) : -1;
+  auto kindOfByte = [&](int b) { return (hasWord && wordKind(b)) ? kWord : ((hasLine && b == '\n') ? kNl : 0); };
+  const int outsideKind = hasLine ? kNl : 0;     // in front of / behind the haystack: a line edge, not a word byte
+  const uint32_t outsideByte = hasLine ? '\n' : 0u;
   if (nfa.start_unanchored == nfa.start_anchored) { why = "start-anchored pattern"; return false; }
   // byte classes (nfa/alphabet.go:100-166)
   bool boundary[256] = {false};
@@ -95,20 +107,23 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     if (s.kind == CXG_NFA_BYTE_RANGE) markb(s.lo, s.hi);
     else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) markb(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
   }
-  if (hasLook) { markb('0', '9'); markb('A', 'Z'); markb('_', '_'); markb('a', 'z'); }   // a class is all word bytes or none
+  if (hasWord) { markb('0', '9'); markb('A', 'Z'); markb('_', '_'); markb('a', 'z'); }   // a class is of one kind
+  if (hasLine) markb('\n', '\n');
   std::vector<int> reps;
   uint8_t cls[256];
   for (int b = 0; b < 256; b++) { if (b == 0 || boundary[b - 1]) reps.push_back(b); cls[b] = static_cast<uint8_t>(reps.size() - 1); }
   const uint32_t nbc = static_cast<uint32_t>(reps.size());      // byte classes
   const uint32_t ncls = nbc * nk;                               // input symbols = table columns: nk * class + kind of the next byte
   if (ncls > 64) { why = "more than 64 input symbols (byte classes x kinds)"; return false; }
-  auto kindOf = [&](uint32_t bc) { return hasLook ? wordKind(reps[bc]) : 0; };
+  auto kindOf = [&](uint32_t bc) { return kindOfByte(reps[bc]); };
+  auto setKinds = [&](Stepper& x) { if (kWord >= 0) x.word[kWord] = true; if (kNl >= 0) x.newline[kNl] = true; };
 
   Stepper st(nfa);
+  setKinds(st);
   // the search that starts at a position, by the kinds of the bytes on its two sides
-  std::vector<uint32_t> freshLR[2][2];
-  for (int l = 0; l < 2; l++)
-    for (int r = 0; r < 2; r++) {
+  std::vector<uint32_t> freshLR[3][3];
+  for (int l = 0; l < static_cast<int>(nk); l++)
+    for (int r = 0; r < static_cast<int>(nk); r++) {
       st.gen++;
       st.left = l; st.right = r;
       st.closure(freshLR[l][r], nfa.start_unanchored);
@@ -139,8 +154,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   auto eventOf = [&](uint32_t kind, uint32_t j, bool conts, uint32_t died) -> uint32_t {   // descriptor, 0 = nothing happened
     return kind | (j << 2) | (conts ? 32u : 0u) | (died << 8);
   };
-  intern({freshLR[0][0]});                        // row 0: the search at the haystack's first byte (in front of it: nothing = not word)
-  const uint32_t start1 = hasLook ? intern({freshLR[0][1]}) : 0u;   // ... when that byte is a word byte
+  uint32_t startOf[3] = {0, 0, 0};                // the search at the haystack's first byte, by the kind of that byte; row 0 = kind 0
+  for (uint32_t k = 0; k < nk; k++) startOf[k] = intern({freshLR[outsideKind][k]});
   for (uint32_t cur = 0; cur < keys.size() && !tooBig; cur++) {
     // split the key into its levels
     std::vector<std::pair<size_t, size_t>> lv;    // [begin, end) in keys[cur]
@@ -249,9 +264,10 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   // lists: the reverse search runs without break-at-match (meta/compile.go:193-194).  Row 0 dead, accepting rows last.
   std::vector<std::vector<uint32_t>> rtab;          // [state][ncls] (renumbered)
   uint32_t rStates = rev.nstates, rFirstAccept = rev.firstAccept, rStart = rev.start;
-  uint32_t rStart4[4] = {0, 0, 0, 0};
+  uint32_t rStart9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hasLook) {
     Stepper rs(*revNfa);
+    setKinds(rs);
     std::map<std::vector<uint32_t>, uint32_t> rid;
     std::vector<std::vector<uint32_t>> rsets;
     std::vector<std::vector<uint32_t>> rnext;
@@ -267,14 +283,14 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
       return id;
     };
     rintern({});                                   // 0: dead
-    uint32_t s4[4];
-    for (int l = 0; l < 2; l++)
-      for (int r = 0; r < 2; r++) {
+    uint32_t s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < static_cast<int>(nk); l++)
+      for (int r = 0; r < static_cast<int>(nk); r++) {
         std::vector<uint32_t> set;
         rs.gen++;
         rs.left = l; rs.right = r;
         rs.closure(set, revNfa->start_anchored);
-        s4[2 * l + r] = rintern(set);
+        s9[static_cast<int>(nk) * l + r] = rintern(set);
       }
     for (uint32_t cur = 1; cur < rsets.size(); cur++) {
       if (rsets.size() > 4096) { why = "reverse automaton too large"; return false; }
@@ -292,8 +308,8 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     rStates = static_cast<uint32_t>(order.size());
     rtab.assign(rStates, std::vector<uint32_t>(ncls, 0u));
     for (uint32_t i = 0; i < rStates; i++) for (uint32_t c = 0; c < ncls; c++) rtab[i][c] = renum[rnext[order[i]][c]];
-    for (int q = 0; q < 4; q++) { rStart4[q] = renum[s4[q]]; if (rStart4[q] >= rFirstAccept) { why = "nullable pattern (empty matches)"; return false; } }
-    rStart = rStart4[0];
+    for (uint32_t q = 0; q < nk * nk; q++) { rStart9[q] = renum[s9[q]]; if (rStart9[q] >= rFirstAccept) { why = "nullable pattern (empty matches)"; return false; } }
+    rStart = rStart9[0];
   }
   if (rStates == 0 || static_cast<size_t>(rStates) * ncls * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
   auto offT = [&](uint32_t s) { return s * rowBytes; };
@@ -309,7 +325,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   cxgdev::FsmHeader h;
   std::memset(&h, 0, sizeof h);
   h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_a = nA; h.n_u = nU; h.ncls = ncls; h.stride = stride; h.row_bytes = rowBytes; h.depth = depth;
-  h.nk = nk; h.start_off[0] = offT(0); h.start_off[1] = offT(start1);
+  h.nk = nk; h.outside_byte = outsideByte;
   h.alias_lo = offA(0); h.u_lo = offU(0); h.top_off = offU(0); h.wide_off = wideOff; h.max_len = max_len;
   h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate); h.row_shift = rowShift;
   std::vector<uint8_t> img(sizeof h, 0);
@@ -320,7 +336,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     img.insert(img.end(), q, q + n);
   };
   uint8_t cls2[256], knd[256];
-  for (int b = 0; b < 256; b++) { cls2[b] = static_cast<uint8_t>(2 * nk * cls[b]); knd[b] = static_cast<uint8_t>(hasLook ? 2 * wordKind(b) : 0); }
+  for (int b = 0; b < 256; b++) { cls2[b] = static_cast<uint8_t>(2 * nk * cls[b]); knd[b] = static_cast<uint8_t>(2 * kindOfByte(b)); }
   std::vector<uint16_t> tab(static_cast<size_t>(nRows) * stride, 0);
   for (uint32_t s = 0; s < nT; s++) {
     for (uint32_t c = 0; c < ncls; c++) tab[static_cast<size_t>(s) * stride + c] = target(trans[s][c]);
@@ -343,7 +359,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   put(tab.data(), tab.size() * 2, h.tab_off);
   if (h.tab_off != sizeof h) { why = "internal: image layout (scan_fsm.hip expects the transition table first)"; return false; }
   put(cls2, 256, h.cls_off);
-  if (hasLook) put(knd, 256, h.knd_off); else h.knd_off = h.cls_off;
+  std::vector<uint8_t> kndBlock(knd, knd + 256);   // kinds, then the start rows by kind, then the reverse start rows by pair of kinds
   std::vector<uint16_t> mem(static_cast<size_t>(nU + 1) * cxgdev::kFsmMembers, 0xFFFF);
   for (uint32_t u = 0; u < nU; u++)
     if (sets[u].size() <= static_cast<size_t>(cxgdev::kFsmMembers))
@@ -365,7 +381,12 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   }
   put(rv.data(), rv.size() * 2, h.rev_off);
   h.rev_states = rStates; h.rev_start_off = rStart * revRow; h.rev_accept_off = rFirstAccept * revRow; h.rev_row_bytes = revRow;
-  for (int q = 0; q < 4; q++) h.rev_start4[q] = (hasLook ? rStart4[q] : rStart) * revRow;
+  if (hasLook) {
+    auto put16 = [&](uint32_t v16) { kndBlock.push_back(static_cast<uint8_t>(v16 & 0xFF)); kndBlock.push_back(static_cast<uint8_t>(v16 >> 8)); };
+    for (uint32_t k = 0; k < nk; k++) put16(offT(startOf[k]));
+    for (uint32_t q = 0; q < nk * nk; q++) put16(rStart9[q] * revRow);
+    put(kndBlock.data(), kndBlock.size(), h.knd_off);
+  } else h.knd_off = h.cls_off;
   while (img.size() % 16) img.push_back(0);
   h.total_bytes = static_cast<uint32_t>(img.size());
   h.lds_bytes = h.total_bytes - static_cast<uint32_t>(sizeof h);

@@ -679,11 +679,15 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         }
       } catch (const BuildError&) { std::memset(&chain, 0, sizeof chain); }
       if (!prefixLiterals.empty()) appendPrefixAux(blob, h, prefixLiterals, prefixDfa);
-    } else if (strategy == CXG_USE_NFA) {
+    } else if (strategy == CXG_USE_NFA || strategy == CXG_USE_TEDDY) {
       // UseNFA: the reference answers through its PikeVM (find_indices.go:520-560 -> nfa/pikevm.go SearchAt): plain
       // leftmost-first with the assertions of nfa.Look checked at each position (pikevm.go:1646-1674).  Reached by small
-      // patterns with word boundaries (meta/strategy.go:1377-1546: `\berror\b`, `\b\d+\b`), which no DFA strategy takes.
-      // Served by the transducer kernel alone (fsm.hpp "Look-around"): no table-walking image exists for such programs.
+      // patterns with word boundaries or multi-line anchors (meta/strategy.go:1377-1546: `\berror\b`, `(?m)^line`), which no
+      // DFA strategy takes.  Served by the transducer kernel alone (fsm.hpp "Look-around"): no table-walking image exists.
+      // UseTeddy reaches here with the NFA of a literal alternation behind (?m)^ (`(?m)^(GET|POST|PUT)`): the reference
+      // filters Teddy's candidates by a line-start check (prefilter.WrapLineAnchor, prefilter/wrap.go:45-66) and — literals
+      // of different lengths — runs the PikeVM from the first candidate that passes (find_indices.go:941-950): the
+      // leftmost-first match of the whole pattern, which is what the transducer computes.
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
       HostNfa rn = reverseOf(nfa);
       cxg_nfa rvw = rn.view();

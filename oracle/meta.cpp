@@ -2,6 +2,7 @@
 #include "meta.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <set>
 
 namespace orc {
@@ -438,6 +439,53 @@ bool isWildcardSubexpression(ReP re) {  // strategy.go:586-603
   return false;
 }
 bool containsAnchor(const ReP& re) { return anyOp(re, {OpBeginLine, OpEndLine, OpBeginText, OpEndText}); }
+// (?m)^ + wildcard + suffix literal -> UseMultilineReverseSuffix (strategy.go:718-861)
+bool containsLineStartAnchor(const ReP& re) {  // strategy.go:734-768
+  switch (re->op) {
+    case OpBeginLine: return true;
+    case OpBeginText: return false;
+    case OpConcat:
+      if (!re->sub.empty() && re->sub[0]->op == OpBeginLine) return true;
+      for (auto& s : re->sub) if (containsLineStartAnchor(s)) return true;
+      return false;
+    case OpAlternate:
+      if (re->sub.empty()) return false;
+      for (auto& s : re->sub) if (!containsLineStartAnchor(s)) return false;
+      return true;
+    case OpCapture: return !re->sub.empty() && containsLineStartAnchor(re->sub[0]);
+    default: return false;
+  }
+}
+bool containsWildcard(const ReP& re) {  // strategy.go:771-793
+  switch (re->op) {
+    case OpStar: case OpPlus:
+      return !re->sub.empty() && (re->sub[0]->op == OpAnyChar || re->sub[0]->op == OpAnyCharNotNL);
+    case OpConcat: case OpAlternate:
+      for (auto& s : re->sub) if (containsWildcard(s)) return true;
+      return false;
+    case OpCapture: case OpQuest: case OpRepeat: return !re->sub.empty() && containsWildcard(re->sub[0]);
+    default: return false;
+  }
+}
+bool isWildcardOp(const ReP& re) {  // strategy.go:846-861
+  if ((re->op == OpStar || re->op == OpPlus) && !re->sub.empty()) {
+    const ReP& sub = re->sub[0];
+    if (sub->op == OpAnyChar || sub->op == OpAnyCharNotNL) return true;
+    if (re->op == OpPlus && sub->op == OpCharClass) return true;
+  }
+  return false;
+}
+bool isSafeForMultilineReverseSuffix(const ReP& re) {  // strategy.go:805-843
+  if (!(containsLineStartAnchor(re) && containsWildcard(re))) return false;   // isMultilineLineAnchored :728-730
+  if (re->op == OpCapture) return !re->sub.empty() && isSafeForMultilineReverseSuffix(re->sub[0]);
+  if (re->op != OpConcat || re->sub.size() < 2) return false;
+  bool line = false, wild = false;
+  for (size_t i = 0; i < re->sub.size(); i++) {
+    if (i == 0 && re->sub[i]->op == OpBeginLine) { line = true; continue; }
+    if (isWildcardOp(re->sub[i])) wild = true;
+  }
+  return line && wild;
+}
 bool isSafeForReverseSuffix(const ReP& re) {  // strategy.go:605-634
   if (re->op == OpCapture) return !re->sub.empty() && isSafeForReverseSuffix(re->sub[0]);
   if (re->op != OpConcat || re->sub.size() < 2) return false;
@@ -493,8 +541,24 @@ static Strategy selectStrategy(const NFA& nfa, const ReP& re, const Seq& lits, b
 
   // selectReverseStrategy strategy.go:974-1093
   auto reverse = [&]() -> int {
+    // nfa.HasImpossibleEndAnchor (nfa/compile.go:1858-1888): an end anchor — (?m)$ counts — that does not END the pattern
+    // in the sense of isEndAnchored (\z / non-multiline $ only): no reverse strategy (strategy.go:980-985)
+    std::function<bool(const ReP&)> containsEndAnchor = [&](const ReP& r) -> bool {
+      switch (r->op) {
+        case OpEndText: case OpEndLine: return true;
+        case OpConcat: case OpAlternate:
+          for (auto& x : r->sub) if (containsEndAnchor(x)) return true;
+          return false;
+        case OpCapture: case OpStar: case OpPlus: case OpQuest: case OpRepeat: return !r->sub.empty() && containsEndAnchor(r->sub[0]);
+        default: return false;
+      }
+    };
+    if (containsEndAnchor(re) && !isEndAnchoredTail(re)) return 0;
     if (hasWordBoundary(re)) return 0;
-    if (anyOp(re, {OpBeginLine})) restated = false;  // (?m)^ multiline-suffix path not restated
+    if (isSafeForMultilineReverseSuffix(re)) {          // strategy.go:1004-1012, before the fast-prefix check
+      Seq suf = extractSuffixes(re);
+      if (!suf.empty() && suf.lcs().size() >= 1) return UseMultilineReverseSuffix;
+    }
     bool fast = false;  // hasFastPrefixPrefilter strategy.go:948-967
     if (!lits.empty()) {
       if (lits.lcp().size() >= 1) fast = true;
@@ -600,6 +664,9 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
       if (!e->teddy.build(pats)) {   // Slim (2..32) or Fat (33..64) Teddy
         e->strategyRestated = false;
       }
+      // adjustForAnchors compile.go:660-680: the only anchor a UseTeddy pattern can hold is (?m)^ (selectLiteralStrategy
+      // excludes the others); the complete prefilter is wrapped with a line-start check
+      e->teddyLineAnchor = anyOp(e->re, {OpBeginLine});
       break;
     }
     case UseCharClassSearcher: {
@@ -633,6 +700,20 @@ bool Engine::findAt(Bytes h, int64_t len, int64_t at, int64_t& s, int64_t& e) {
     }
     case UseTeddy:  // find_indices.go:925-951
       if (!strategyRestated || at >= len) return pikevm.searchAt(h, len, at, s, e);
+      if (teddyLineAnchor) {
+        // lineAnchorWrapper has Find but no FindMatch (prefilter/wrap.go:52-82): findIndicesTeddyAt takes its fallback,
+        // Find + LiteralLen (:941-950).  Find: Teddy candidates until one sits at a line start (wrap.go:52-66).
+        int64_t pos = at, cs, ce;
+        for (;;) {
+          if (!teddy.findMatch(h, len, pos, cs, ce)) return false;
+          if (cs == 0 || h[cs - 1] == '\n') break;
+          pos = cs + 1;
+        }
+        size_t uniform = teddy.patterns[0].size();            // Teddy.LiteralLen teddy.go:566-571 (complete, uniformLen)
+        for (auto& p : teddy.patterns) if (p.size() != uniform) uniform = 0;
+        if (uniform > 0) { s = cs; e = cs + static_cast<int64_t>(uniform); return true; }
+        return pikevm.searchAt(h, len, cs, s, e);              // findIndicesNFAAt(haystack, pos)
+      }
       return teddy.findMatch(h, len, at, s, e);
     case UseCharClassSearcher: return ccs.searchAt(h, len, at, s, e);   // :841-848
     case UseDFA:

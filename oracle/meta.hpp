@@ -50,6 +50,7 @@ struct Engine {
   bool strategyRestated = true;
   Seq prefixes;
   bool digitRunSkipSafe = false;
+  bool teddyLineAnchor = false;   // UseTeddy behind (?m)^: prefilter.WrapLineAnchor (compile.go:670-677, prefilter/wrap.go:45-66)
   bool hasReverseDFA = false;
   LazyDFA dfa, revDfa;
   PikeVM pikevm;

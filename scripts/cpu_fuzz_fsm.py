@@ -12,7 +12,8 @@ ATOMS = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", "abc", "xyz", "a:c", "(b*c)?", "(a|ab)", "(abc|ab|a)", "b*", "(ab*c|a|bb)", "a+?", "[ab]*?c"]
 
-LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+", r"(a|\b)", r"(\bab|xy\b)", r"\b\b", r"(?:\bx)+"]
+LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+", r"(a|\b)", r"(\bab|xy\b)", r"\b\b", r"(?:\bx)+",
+              "^", "$", "^", "$", r"\n", r"(^a|b$)", r"[a-c\n]+", r"(?:$\n^)?", "^ab|xy$"]
 
 def main(n=300, seed=1, look=False):
     rng = np.random.default_rng(seed)
@@ -24,7 +25,9 @@ def main(n=300, seed=1, look=False):
     while len(seen) < n:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
         if pat in seen: continue
-        if look and "\\b" not in pat and "\\B" not in pat: continue
+        if look:
+            if "\\b" not in pat and "\\B" not in pat and "^" not in pat and "$" not in pat: continue
+            pat = "(?m)" + pat
         seen.add(pat)
         try: rx = cx.compile(pat)
         except cx.CoregexError: continue

@@ -18,7 +18,8 @@ struct HostMem : FsmClassify<HostMem<LOOK>, LOOK> {
   const uint8_t* hay;   // whole haystack
   int64_t origin_abs;   // absolute position of the tile origin
   int64_t len;
-  uint32_t byte(int32_t r) const { const int64_t p = origin_abs + r; return (p >= 0 && p < len) ? hay[p] : 0u; }   // outside: zeros, as in the kernel's window
+  uint32_t outside;     // FsmHeader::outside_byte: what the kernel writes into its window around the haystack
+  uint32_t byte(int32_t r) const { const int64_t p = origin_abs + r; return (p >= 0 && p < len) ? hay[p] : outside; }
   uint32_t dword(int32_t r) const { return byte(r) | (byte(r + 1) << 8) | (byte(r + 2) << 16) | (byte(r + 3) << 24); }
 };
 struct LaneRows {
@@ -42,8 +43,7 @@ FsmView view_of(const uint8_t* img) {
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   v.knd = img + h->knd_off;
-  v.start1 = h->start_off[1];
-  for (int q = 0; q < 4; q++) v.rev_start4[q] = h->rev_start4[q];
+  v.nk = h->nk;
   return v;
 }
 }  // namespace
@@ -70,7 +70,7 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
     const int32_t budget = rend < tile + budget_bytes ? rend : tile + budget_bytes;
     const int32_t lowest = tile_lo > static_cast<uint64_t>(budget_bytes) ? -budget_bytes : -static_cast<int32_t>(tile_lo);
     HostMem<LOOK> m;
-    m.hay = hay; m.origin_abs = static_cast<int64_t>(tile_lo); m.len = static_cast<int64_t>(len);
+    m.hay = hay; m.origin_abs = static_cast<int64_t>(tile_lo); m.len = static_cast<int64_t>(len); m.outside = LOOK ? h->outside_byte : 0u;
     bool first_in_tile = true;
     for (int lane = 0; lane < lanes; lane++) {
       const int32_t c0 = lane * chunk, c1 = c0 + chunk;

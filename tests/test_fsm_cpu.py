@@ -18,7 +18,10 @@ GENERAL = [r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|f
            r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal", r"ax|x?b+",
            r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"]
 LOOK = [r"\berror\b", r"\b\d+\b", r"\bGET\b", r"\b(GET|PUT)\b", r"\Berror", r"error\B", r"\b[A-Z]+\b", r"ab(a|\b)", r"(ab)+(a|\b)\b\b", r"\b\d+\.\d+\b",
-        r"\berror\w*", r"\b[a-z]+\b", r"\b0x[0-9a-f]+\b", r"\w+\b", r"a\B", r"(?:\bx)+", r"x\b|\By", r"\b_+\b"]
+        r"\berror\w*", r"\b[a-z]+\b", r"\b0x[0-9a-f]+\b", r"\w+\b", r"a\B", r"(?:\bx)+", r"x\b|\By", r"\b_+\b",
+        # multi-line anchors: a third kind of neighbour byte (newline); outside the haystack counts as a line edge
+        r"(?m)^line", r"(?m)error$", r"(?m)^\w+$", r"(?m)^line\b", r"(?m)[a-z]+$", r"(?m)^GET|POST$", r"(?m)^\d+", r"(?m)\n^a", r"(?m)a$\n^b"]
+LOOK_TEDDY = [r"(?m)^(GET|POST|PUT|DELETE|PATCH)", r"(?m)^(GET|PUT)", r"(?m)^GET|^POST|^PUT"]   # UseTeddy behind prefilter.WrapLineAnchor
 
 
 def _check(oracle, pat, hays, look):
@@ -27,7 +30,7 @@ def _check(oracle, pat, hays, look):
     img = rx.fsm_image()
     assert img is not None, pat
     if look:
-        assert o.strategy == "UseNFA" and o.strategy_restated and rx.strategy == "UseNFA", (pat, o.strategy, rx.strategy)
+        assert o.strategy == look and o.strategy_restated and rx.strategy == look, (pat, o.strategy, rx.strategy)
     n_ok = 0
     for hay in hays:
         exp = o.find_all_index(hay)
@@ -63,14 +66,22 @@ def test_transducer_twin_general(oracle, pat):
 def test_transducer_twin_word_boundaries(oracle, pat):
     """\\b / \\B: the step over a byte also reads the kind of the next one (fsm.hpp "Look-around"); the reverse automaton is
     built look-aware on the host; the byte on either side of the haystack counts as "not a word byte"."""
-    _check(oracle, pat, _hays(100 + len(pat)), look=True)
+    _check(oracle, pat, _hays(100 + len(pat)), look="UseNFA")
 
+
+@pytest.mark.parametrize("pat", LOOK_TEDDY)
+def test_transducer_twin_line_anchored_literals(oracle, pat):
+    """`(?m)^(GET|POST|...)`: UseTeddy in the reference, its candidates filtered by a line-start check
+    (prefilter.WrapLineAnchor) and, for literals of different lengths, the PikeVM from the first one that passes — the
+    pattern's leftmost-first match, which the transducer computes (no literal kernel involved)."""
+    hays = _hays(7) + [b"GET /a\nPOST /b\n GET\nPUTS\nDELETE\nPATCH x GET\nGET", b"\nGET\n\nPUT\n"]
+    _check(oracle, pat, hays, look="UseTeddy")
 
 def test_word_boundary_scope(oracle):
     """Served: UseNFA programs (small patterns; PikeVM semantics in the reference).  Refused at build time: line / text
     anchors, nullable patterns, and the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)."""
-    for pat, frag in ((r"(?m)^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"\b(GET|POST|PUT)\b", "look-around"),
-                      (r"\b[a-f0-9]{8}\b", "look-around")):
+    for pat, frag in ((r"^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"(?m)^", "nullable"), (r"\b(GET|POST|PUT)\b", "look-around"),
+                      (r"\b[a-f0-9]{8}\b", "look-around"), (r"(?m)^foo|barr", "some alternatives only"), (r"(?m)\d+$", "look-around")):
         rx = cx.compile(pat)
         assert not rx.supported and frag in rx.why_unsupported, (pat, rx.why_unsupported)
     img = cx.compile(r"\berror\b").fsm_image()

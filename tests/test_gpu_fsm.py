@@ -215,3 +215,52 @@ def test_word_boundary_program_from_nfa(oracle):
     # dfa/lazy/builder.go:183-242 — not restated, not served): refused at build time, the caller keeps its CPU loop
     big = cx.compile(r"\b(GET|POST|PUT)\b")
     assert big.strategy == "UseDFA" and not big.supported
+
+
+# ---- multi-line anchors (?m)^ (?m)$: a third kind of neighbour byte (newline); the positions around the haystack read as a
+# line edge (the kernel writes '\n' into its window there)
+LINE = [r"(?m)^line", r"(?m)error$", r"(?m)^\w+$", r"(?m)[a-z]+$", r"(?m)^GET|POST$", r"(?m)^\d+", r"(?m)^line\b"]
+LINE_TEDDY = [r"(?m)^(GET|POST|PUT|DELETE|PATCH)", r"(?m)^GET|^POST|^PUT"]
+
+
+@pytest.mark.parametrize("pat", LINE + LINE_TEDDY)
+def test_multiline_anchor_programs(oracle, pat):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert o.strategy_restated and rx.strategy == o.strategy and o.strategy == ("UseTeddy" if pat in LINE_TEDDY else "UseNFA"), (pat, o.strategy, rx.strategy)
+    assert rx.supported, rx.why_unsupported
+    hays = [generate_test_input()] + [cx.synth_pages(c, 0xC0FFEE00 + c, 3, 256).tobytes() for c in (1, 2, 3)]
+    hays += [b"", b"line", b"line\n", b"\nline", b"error", b"error\n", b"x error\nerror x\nerror", b"GET /\nPOST\n GET\nPOST", b"12\n34 56\n\n78", b"\n\n\n", b"a\nb\n"]
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), hay[:40])
+        assert rx.count(hay) == len(exp)
+    rows, t = _device_rows(rx, hays[1])
+    assert np.array_equal(rows, o.find_all_index(hays[1])) and t.kernel == K_FSM
+
+
+def test_multiline_anchor_edges(oracle):
+    """Line starts and ends across chunk / wave-tile / window / group edges, at the first and last byte of the haystack,
+    and for inputs that end exactly on such an edge."""
+    group = 3840 * 32
+    for pat in (r"(?m)^line", r"(?m)error$", r"(?m)^\w+$"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        base = np.full(2 * group + 5000, ord(" "), dtype=np.uint8)
+        offs = [0, 1, 27, 31, 32, 59, 63, 64, 3835, 3839, 3840, 3841, 4027, 4031, 4032, 4091, 4096, group - 5, group - 1, group, group + 1, 2 * group - 3]
+        for off in offs:
+            for lit in (b"\nline\n", b"line\n", b"\nerror\n", b"error\n", b"\nerror x", b"\nline error\n", b"\n\nline\n\n"):
+                hay = base.copy()
+                a = np.frombuffer(lit, dtype=np.uint8)
+                hay[off:off + len(a)] = a
+                exp = o.find_all_index(hay)
+                rows, t = _device_rows(rx, hay)
+                assert np.array_equal(rows, exp) and t.kernel == K_FSM, (pat, off, lit, rows.tolist(), exp.tolist())
+        for n in (1, 4, 5, 6, 31, 32, 33, 63, 64, 65, 3839, 3840, 3841, 4031, 4032, 4033, 4095, 4096, 4097, group - 1, group, group + 1):
+            for tail in (b"line", b"\nline", b"error", b" error", b"\nerror"):
+                hay = np.full(n, ord(" "), dtype=np.uint8)
+                k = min(len(tail), n)
+                hay[n - k:] = np.frombuffer(tail, dtype=np.uint8)[len(tail) - k:]
+                assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), (pat, n, tail)
+                head = np.full(n, ord(" "), dtype=np.uint8)
+                head[:k] = np.frombuffer(tail, dtype=np.uint8)[:k]
+                assert np.array_equal(rx.find_all_index(head), o.find_all_index(head)), (pat, n, tail, "head")

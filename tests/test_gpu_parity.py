@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEVICE_PATTERNS = {
     "la_ips": r"\d+\.\d+\.\d+\.\d+", "version": r"\d+\.\d+\.\d+", "la_peak_hours": COMPAT_PATTERNS["la_peak_hours"],
     "ip": COMPAT_PATTERNS["ip"], "char_class": r"[\w]+", "error_literal": r"error", "alternation_overlap": r"ab|abc",
-    "word_boundary": COMPAT_PATTERNS["word_boundary"], "nested_groups_as_index": r"((a+)(b+))", "literal_alt": COMPAT_PATTERNS["literal_alt"], "multi_literal": COMPAT_PATTERNS["multi_literal"], "non_greedy_has_no_reverse": r"a+?", "digits": r"[0-9]+", "lower": r"[a-z]+",
+    "word_boundary": COMPAT_PATTERNS["word_boundary"], "http_methods": COMPAT_PATTERNS["http_methods"], "multiline_anchor": COMPAT_PATTERNS["multiline_anchor"], "nested_groups_as_index": r"((a+)(b+))", "literal_alt": COMPAT_PATTERNS["literal_alt"], "multi_literal": COMPAT_PATTERNS["multi_literal"], "non_greedy_has_no_reverse": r"a+?", "digits": r"[0-9]+", "lower": r"[a-z]+",
 }
 
 

@@ -3,6 +3,7 @@ front-end agrees with the oracle (strategy, NFA size), and the device lane walks
 host by tests/emu — reproduce the oracle's spans for every chunk geometry.  No GPU compute here."""
 import os
 import re
+import struct
 
 import numpy as np
 import pytest
@@ -58,7 +59,7 @@ PATTERNS = [
 
 # word boundaries: UseNFA in the reference (PikeVM), the transducer kernel here (fsm.hpp "Look-around")
 LOOK_PATTERNS = [r"\berror\b", r"\b\d+\b", r"\bfoo\w+", r"\b(GET|POST)\b", r"\w+\b", r"\Btest", r"ab(a|\b)", r"(ab)+(a|\b)\b\b", r"\b[a-z]+\b",
-                 r"(?:\bx)+", r"a\B", r"\b\b", r"x\b|\By"]
+                 r"(?:\bx)+", r"a\B", r"\b\b", r"x\b|\By", r"(?m)^line", r"(?m)error$", r"(?m)^(GET|POST|PUT|DELETE|PATCH)", r"(?m)^\w+$", r"(?m)a$\n^b"]
 
 
 @pytest.mark.parametrize("pat", PATTERNS + LOOK_PATTERNS)
@@ -111,6 +112,11 @@ def _fast_digit(p) -> bool:
     return bool(struct.unpack_from("<I", p.blob(), 8)[0] & 2)
 
 
+def _table_free(p):
+    """Programs of kind 5 run on the transducer kernel alone (word boundaries, (?m)^ literals): no table-walking image."""
+    return struct.unpack_from("<I", p.blob(), 4)[0] == 5
+
+
 @pytest.mark.parametrize("chunk", [4, 16, 64])
 def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
     corpus = generate_test_input()
@@ -120,7 +126,7 @@ def test_emulated_lane_walks_match_oracle_on_reference_corpus(oracle, chunk):
             p = cx.compile(pat)
         except cx.CoregexError:
             continue
-        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy"):
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy") or _table_free(p):
             continue
         got = emu.find_all(p.blob(), corpus, chunk)
         exp = oracle.Regex(pat).find_all_index(corpus)
@@ -139,7 +145,7 @@ def test_emulated_lane_walks_random(oracle):
     tried = 0
     for pat in EMU_PATTERNS:
         p = cx.compile(pat)
-        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy"):
+        if not p.supported or p.strategy not in ("UseDigitPrefilter", "UseDFA", "UseTeddy") or _table_free(p):
             continue
         o = oracle.Regex(pat)
         blob = p.blob()
@@ -591,7 +597,7 @@ def test_program_routing_table():
     assert image(r"(\w+)@(\w+)\.(\w+)", sub=True)[2] & chain and cx.compile(r"(\w+)@(\w+)\.(\w+)").chain_captures() is not None
     assert image(r"(GET|POST|PUT) /([a-z/]+)", sub=True)[2] & prefix
     for pat, why in [(r"a?(a|b)", "cache history"), (r"\w+@\w+\.\w+", "has no device kernel"), (r"\b(foo|bar|bazz|quux)\b", "look-around"),
-                     (r"(?m)^foo", "anchor")]:
+                     (r"^foo", "anchor")]:
         rx = cx.compile(pat)
         assert not rx.supported and why in rx.why_unsupported, (pat, rx.strategy, rx.why_unsupported)
     wb = cx.compile(r"\bfoo\b")                       # small word-boundary patterns: UseNFA, transducer kernel only (kind 5, no tables)
