@@ -35,6 +35,9 @@
 #include "walk.hpp"
 #include "wave_common.hpp"
 
+#ifndef CXG_CAP_WAVES
+#define CXG_CAP_WAVES 5       // SETS / CAP / BND instantiations: 90 VGPRs without scratch (6 waves: 80 VGPRs + 7 spilled, 3 % slower on config 5)
+#endif
 #ifndef CXG_CHAIN_WAVES
 #define CXG_CHAIN_WAVES 8
 #endif
@@ -175,7 +178,7 @@ struct Words4 {
 // a middle field outside its bounds drops the row, a longer first field moves the start to run end - max, a longer
 // last field would truncate the match and let FindAll resume inside the run: the tile hands the scan over.
 template <int NCLS, bool SETS, bool CAP, bool DENSE, int ALTK, bool BND>
-__global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? 6 : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
+__global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? CXG_CAP_WAVES : (NCLS >= 3 ? 7 : CXG_CHAIN_WAVES))) void k_scan_chain_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_cls[kWavesPerBlock][NCLS][64];   // forward class bitmaps
   __shared__ __attribute__((aligned(16))) uint64_t s_x[kWavesPerBlock][64];       // starts, reversed -> forward
   __shared__ uint16_t s_rs[kWavesPerBlock][kWRows];               // rows of the group, per wave: start / end inside their wave-tile

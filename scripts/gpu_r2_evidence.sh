@@ -27,7 +27,8 @@ for i in (1, 2):
         for r in csv.DictReader(open(f)):
             if kname in r["Kernel_Name"]:
                 acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, d in acc.items():
+# the instantiation the timed steps launch = the one with the most dispatches (a counting pass may use another one)
+for k, d in sorted(acc.items(), key=lambda kv: -len(kv[1].get("FETCH_SIZE", []))):
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fk = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); wk = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         rec = {"baseline_config": n, "kernel": k, "bytes_per_gpu": bench["config"]["bytes_per_gpu"],
