@@ -11,7 +11,7 @@ atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?", "a+?", "[a-c]+?", "(?:a|b|c)+",
          "abcabc", "abc", "xyz", "a:c", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
 alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff", dtype=np.uint8)
-bad=0; tot=0; strat={}
+bad=0; tot=0; strat={}; n_long=0; n_cc_unchecked=0; n_cc_fallback=0
 t0=time.time()
 for seed in range(seed0, seed1):
     rng = np.random.default_rng(seed)
@@ -42,12 +42,16 @@ for seed in range(seed0, seed1):
             blob = rx.blob(); kind = struct.unpack_from("<I", blob, 4)[0]; fl = struct.unpack_from("<I", blob, 8)[0]
             for hay in hays:
                 exp = o.find_all_index(hay).tolist()
-                if rx.strategy == 'UseBoth':     # plain leftmost-first unless a match is longer than 100 bytes (device: CXG_E_INPUT)
-                    plain = o.find_all_submatch_index(hay)[:, :2]
+                if rx.strategy == 'UseBoth':     # a match longer than 100 bytes: the device refuses the haystack (CXG_E_INPUT, asserted by
+                    plain = o.find_all_submatch_index(hay)[:, :2]   # tests/test_gpu_parity.py::test_use_both_programs); nothing to compare here
                     if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100:
-                        exp = plain.tolist()
-                got = emu.find_all(blob, hay).tolist() if rx.strategy!='UseCharClassSearcher' else exp
-                if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
+                        n_long += 1
+                        continue
+                if rx.strategy != 'UseCharClassSearcher':   # (scan_charclass.hip has no lane walk in walk.hpp: its wave twin is checked below)
+                    got = emu.find_all(blob, hay).tolist()
+                    if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
+                elif not (fl & 64):
+                    n_cc_unchecked += 1
                 if fl & 16 and rx.strategy in ('UseDFA','UseDigitPrefilter','UseBoth'):
                     for geom in ((192,64),(3840,256)):
                         g6 = emu.find_all_chain6_bounded(blob, rx.chain_bounds()[0], hay, *geom) if fl & 512 else emu.find_all_chain6(blob, hay, *geom)
@@ -57,7 +61,9 @@ for seed in range(seed0, seed1):
                     if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('TEDDYW', repr(pat), len(hay)); bad+=1
                 if rx.strategy=='UseCharClassSearcher' and (fl & 64):
                     g = emu.find_all_charclass_wave(blob, hay)
-                    if g is not None and not isinstance(g,int) and g.tolist()!=exp: print('CCW', repr(pat), len(hay)); bad+=1
+                    if g is None: print('CCW-NO-TWIN', repr(pat)); bad+=1
+                    elif isinstance(g,int): n_cc_fallback += 1
+                    elif g.tolist()!=exp: print('CCW', repr(pat), len(hay)); bad+=1
         if "(" in pat and rx.submatch_supported:
             sb, cb = rx.submatch_blobs()[:2]
             w = 2*(o.num_groups if hasattr(o,'num_groups') else rx.num_groups)
@@ -65,4 +71,4 @@ for seed in range(seed0, seed1):
                 exp = o.find_all_submatch_index(hay)
                 got = emu.find_all_submatch(sb, cb, hay, exp.shape[1])
                 if got.shape!=exp.shape or not np.array_equal(got,exp): print('SUBMATCH', repr(pat), len(hay), got.shape, exp.shape); bad+=1; break
-print('seeds', seed0, seed1, 'checked', tot, 'bad', bad, strat, '%.0fs'%(time.time()-t0))
+print('seeds', seed0, seed1, 'checked', tot, 'bad', bad, 'UseBoth-long-skipped', n_long, 'charclass-without-ranges-unchecked', n_cc_unchecked, 'charclass-wave-fallbacks', n_cc_fallback, strat, '%.0fs'%(time.time()-t0))

@@ -192,7 +192,9 @@ def _device_checksums(rows, first=0):
     return [int((rows[:, j] * (k + 7 * j)).sum().item()) & ((1 << 64) - 1) for j in range(w)]
 
 
-@pytest.mark.parametrize("cfg,pat,gib", [(2, r"\d+\.\d+\.\d+\.\d+", 8), (1, r"error", 8), (3, LITS16_EARLY, 8), (4, r"[\w]+", 8), (5, r"(\w+)@(\w+)\.(\w+)", 8)])
+@pytest.mark.parametrize("cfg,pat,gib", [(2, r"\d+\.\d+\.\d+\.\d+", 8), (1, r"error", 8), (3, LITS16_EARLY, 8), (4, r"[\w]+", 8), (5, r"(\w+)@(\w+)\.(\w+)", 8),
+                                         # the transducer kernel at the same size: a branching DFA, a word-boundary and a line-anchor program
+                                         (2, COMPAT_PATTERNS["ip"], 8), (1, r"\berror\b", 8), (2, r"(?m)^\d+", 8)])
 def test_full_size_shard_property(need_gpu, oracle, cfg, pat, gib):
     """Every BASELINE configuration at its stated per-GPU size (8 GiB = the 64 GiB / 8 north-star shard) in ONE launch:
     (a) sorted, disjoint, non-empty rows; (b) FindAll(whole) == concat(FindAll(page-aligned shards) + base) through an
