@@ -268,6 +268,31 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
 
 // Capture pass, general form (patterns that are not one-pass): bounded backtracking over the NFA per match row
 // (device/bt.hpp).  One thread per row, grid-stride; every thread owns 16 KiB of scratch in HBM (visited bitmap + stack).
+// Two tiers: k_captures_bt_lds first (256 threads per workgroup, 256 bytes of LDS scratch per thread, the NFA image in LDS when
+// it fits: as many resident threads as the CUs hold), rows it cannot finish are marked and redone by k_captures_bt.
+__global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+                                                         const uint8_t* btblob, uint32_t img_lds_bytes, uint32_t* err) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_bt[];   // [img_lds_bytes] image, then per-thread scratch
+  __shared__ uint64_t s_stack[256 * cxgdev::kBtSmallStack];
+  __shared__ uint32_t s_vis[256 * cxgdev::kBtSmallVisited];
+  const cxgdev::BtHeader* gh = reinterpret_cast<const cxgdev::BtHeader*>(btblob);
+  for (uint32_t i = threadIdx.x; i < img_lds_bytes / 4u; i += blockDim.x) reinterpret_cast<uint32_t*>(s_bt)[i] = reinterpret_cast<const uint32_t*>(btblob)[i];
+  __syncthreads();
+  const cxgdev::BtHeader* h = img_lds_bytes ? reinterpret_cast<const cxgdev::BtHeader*>(s_bt) : gh;
+  uint64_t* stack = s_stack + threadIdx.x * cxgdev::kBtSmallStack;
+  uint32_t* visited = s_vis + threadIdx.x * cxgdev::kBtSmallVisited;
+  uint32_t bad = 0;
+  for (uint64_t r = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; r < nrows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    int64_t* row = rows + r * width;
+#pragma unroll
+    for (uint32_t i = 0; i < cxgdev::kBtSmallVisited; i++) visited[i] = 0u;
+    const uint32_t rc = cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtSmallVisited, cxgdev::kBtSmallStack);
+    if (rc == 1u) row[2] = cxgdev::kBtRowPending;                 // left to the large tier (its slots are rewritten there)
+    else bad |= rc;
+  }
+  if (bad & 2u) cxgdev::raise_err(err, 4u);
+}
+
 __global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
                                                     const uint8_t* btblob, uint8_t* scratch, uint32_t* err) {
   const cxgdev::BtHeader* h = reinterpret_cast<const cxgdev::BtHeader*>(btblob);
@@ -277,6 +302,7 @@ __global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t 
   uint32_t bad = 0;
   for (uint64_t r = tid; r < nrows; r += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     int64_t* row = rows + r * width;
+    if (row[2] != cxgdev::kBtRowPending) continue;                 // the small tier finished this row
     const uint64_t bits = (static_cast<uint64_t>(row[1] - row[0]) + 1) * h->n_states;
     const uint32_t nw = bits > static_cast<uint64_t>(cxgdev::kBtVisitedWords) * 32u ? 0u : static_cast<uint32_t>((bits + 31) >> 5);
     for (uint32_t i = 0; i < nw; i++) visited[i] = 0u;
@@ -487,6 +513,14 @@ relaunch:
           s.bt = nullptr; s.btCap = 0;
           HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bt), need));
           s.btCap = need;
+        }
+        {
+          const uint32_t img = reinterpret_cast<const cxgdev::BtHeader*>(p->capBlob.data())->total_bytes;
+          const uint32_t img_lds = img <= 16384u ? ((img + 3u) & ~3u) : 0u;
+          int dev = 0, cus = 256;
+          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * 2u));
+          hipLaunchKernelGGL(k_captures_bt_lds, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
         }
         hipLaunchKernelGGL(k_captures_bt, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
       } else if (lds_ok && a.row_width <= 8) {

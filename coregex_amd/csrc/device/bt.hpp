@@ -38,15 +38,24 @@ constexpr uint32_t kBtInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kBtStackEntries = 1024;     // per thread: 8 KiB
 constexpr uint32_t kBtVisitedWords = 2048;     // per thread: 8 KiB = 65 536 (state, position) pairs
 
-// hay: absolute haystack; row: 2 * ngroups int64 with row[0], row[1] = s, e.  visited: kBtVisitedWords zeroed words,
-// stack: kBtStackEntries entries.  Returns 0 ok, 1 the span is too long for the visited bitmap / the stack overflowed,
-// 2 no path reaches Match at e (cannot happen for a real match).
-CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* row, uint32_t nslots, uint32_t* visited, uint64_t* stack) {
+// Small tier of the device kernel (capi.hip k_captures_bt_lds): scratch of one thread in LDS.  Rows that do not fit are
+// left to the large tier (k_captures_bt, scratch in HBM): log matches are short, so the small tier takes almost all rows
+// with sixteen times the threads in flight.
+constexpr uint32_t kBtSmallStack = 24, kBtSmallVisited = 16;   // 192 + 64 = 256 bytes per thread
+constexpr int64_t kBtRowPending = -0x7FFFFFFFFFFFFFFFll - 1;   // row[2] of a row the small tier left to the large tier
+
+// hay: absolute haystack; row: 2 * ngroups int64 with row[0], row[1] = s, e.  visited: `visited_words` zeroed words,
+// stack: `stack_entries` entries (defaults: the large tier's kBtVisitedWords / kBtStackEntries).  Returns 0 ok, 1 the span
+// is too long for the visited bitmap / the stack overflowed (the row's slots are then undefined), 2 no path reaches Match
+// at e (cannot happen for a real match).  Visited / Stack: plain pointers or LDS pointers.
+template <class Visited, class Stack>
+CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* row, uint32_t nslots, Visited visited, Stack stack,
+                               uint32_t visited_words = kBtVisitedWords, uint32_t stack_entries = kBtStackEntries) {
   const BtState* st = reinterpret_cast<const BtState*>(reinterpret_cast<const uint8_t*>(h) + h->states_off);
   const BtTrans* tr = reinterpret_cast<const BtTrans*>(reinterpret_cast<const uint8_t*>(h) + h->trans_off);
   const int64_t s = row[0], e = row[1];
   const uint64_t span = static_cast<uint64_t>(e - s) + 1;
-  if (span * h->n_states > static_cast<uint64_t>(kBtVisitedWords) * 32u) return 1u;
+  if (span * h->n_states > static_cast<uint64_t>(visited_words) * 32u) return 1u;
   for (uint32_t k = 2; k < nslots; k++) row[k] = -1;
   // stack entry: kind (2 bits) | payload.  0: explore (state << 32 | position offset << 2), 1: restore slot
   // (slot << 34 | (old offset + 1) << 2 | 1), old offset + 1 == 0 means "was unset"
@@ -85,7 +94,7 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
         if (nx == kBtInvalid) break;
         q = nx; off++;
       } else if (x.kind == 3 /*SPLIT*/) {
-        if (sp >= kBtStackEntries) return 1u;
+        if (sp >= stack_entries) return 1u;
         stack[sp++] = (static_cast<uint64_t>(x.alt) << 32) | (static_cast<uint64_t>(off) << 2);   // right: after everything the left branch tries
         q = x.next;
       } else if (x.kind == 4 /*EPSILON*/) {
@@ -93,7 +102,7 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
       } else if (x.kind == 5 /*CAPTURE*/) {
         const uint32_t slot = x.cap_slot;
         if (slot >= 2 && slot < nslots) {
-          if (sp >= kBtStackEntries) return 1u;
+          if (sp >= stack_entries) return 1u;
           const int64_t old = row[slot];
           const uint32_t old1 = old < 0 ? 0u : static_cast<uint32_t>(old - s) + 1u;
           stack[sp++] = (static_cast<uint64_t>(slot) << 34) | (static_cast<uint64_t>(old1) << 2) | 1ull;
