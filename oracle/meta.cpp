@@ -640,6 +640,12 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
   e->strategy = selectStrategy(e->nfa, e->re, e->prefixes, e->strategyRestated);
   e->pikevm.init(&e->nfa);
   bool dfaOK = !e->nfa.hasLook;
+  // The reference's lazy DFA carries look-around state (dfa/lazy/start.go:64-172, builder.go:183-242 resolveWordBoundaries,
+  // lazy.go:1350-1354 the $ re-closure, :1413-1421 matchAtWordBoundary): NOT restated here.  A DFA strategy over an NFA
+  // with assertions is answered by the PikeVM below — authoritative for leftmost-first semantics, but not a restatement of
+  // what the reference executes (resolveWordBoundaries appends the states behind a \b after the others, which can change
+  // the priority order): say so.
+  if (!dfaOK && (e->strategy == UseDFA || e->strategy == UseBoth || e->strategy == UseDigitPrefilter)) e->strategyRestated = false;
   switch (e->strategy) {
     case UseDFA:
       if (dfaOK) {
