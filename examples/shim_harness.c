@@ -54,7 +54,9 @@ static cxg_program* build_from_engine(const char* pattern) {
   const int strategy = cxg_program_strategy(engine);
   cxg_program* prog = NULL;
   switch (strategy) {
-    case CXG_USE_DIGIT_PREFILTER: case CXG_USE_DFA: case CXG_USE_BOTH: {
+    case CXG_USE_DIGIT_PREFILTER: case CXG_USE_DFA: case CXG_USE_BOTH:
+    case CXG_USE_NFA:                                          /* word boundaries / multi-line anchors: nfa.StateLook, lo = nfa.Look */
+    case CXG_USE_TEDDY: {                                      /* reached in this mode by (?m)^ literal alternations (lineAnchorWrapper) */
       cxg_nfa e_nfa;
       rc = cxg_program_nfa(engine, &e_nfa);
       if (rc != CXG_OK) { fprintf(stderr, "nfa: %d %s\n", rc, cxg_last_error()); exit(1); }

@@ -24,6 +24,8 @@ NFA_PATTERNS = [
     r"[a-zA-Z]+[0-9]+", r"(?:0[0-9]|1[0-9]|2[0-3]):[0-5][0-9]:[0-5][0-9]", r"[1-9][0-9]*|0", r"x[ab]+?y", r"(a|ab)(c|bcd)",
     r"[0-5]+x", r"(foo|foobar)\d+", r"\d+[a-z]", r"\d+\.\d+x?", r"[a-z]+@[a-z]+", r"a{2,4}b", r"(?:ab)*c", r"HTTP/\d\.\d",
     r"(GET|POST|PUT) /([a-z/]+)", r"([a-z]+)=(\d+)", r"warning", r"\d{4}-\d{2}-\d{2}", r"(\d+)\.(\d+)\.(\d+)\.(\d+)",
+    # look-around: nfa.StateLook travels as kind 7 with lo = nfa.Look; UseNFA programs (and UseTeddy behind (?m)^) run on the transducer
+    r"\berror\b", r"\b\d+\b", r"(?m)^\d+", r"(?m)[a-z]+$", r"(?m)^(GET|POST|PUT|DELETE|PATCH)", r"\Berror",
 ]
 
 
@@ -39,7 +41,7 @@ def via_constructor(pat):
 @pytest.mark.parametrize("pat", NFA_PATTERNS)
 def test_from_nfa_builds_the_program_cxg_compile_builds(pat):
     eng, prog = via_constructor(pat)
-    if eng.strategy not in ("UseDFA", "UseBoth", "UseDigitPrefilter"):
+    if eng.strategy not in ("UseDFA", "UseBoth", "UseDigitPrefilter", "UseNFA", "UseTeddy"):
         assert not prog.supported
         return
     assert prog.strategy == eng.strategy and prog.num_groups == eng.num_groups and prog.nfa_states == eng.nfa_states
@@ -212,6 +214,7 @@ def test_constructor_programs_other_shapes(oracle):
     ("nfa", r"\d+\.\d+\.\d+\.\d+", 2, r"\d+\.\d+\.\d+\.\d+"), ("nfa", "error", 1, "error"),
     ("literals", ",".join(LITS16), 3, "|".join(LITS16)), ("charclass", "0-9,A-Z,_-_,a-z", 4, r"[\w]+"),
     ("submatch", r"(\w+)@(\w+)\.(\w+)", 5, r"(\w+)@(\w+)\.(\w+)"),
+    ("nfa", r"\berror\b", 1, r"\berror\b"), ("nfa", r"(?m)^\d+", 2, r"(?m)^\d+"),
 ])
 def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
     """examples/shim_harness.c — the Go shim statement for statement in C (flattenNFA into malloc'ed arrays, constructor,
