@@ -451,7 +451,32 @@ template <class Mem>
 CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
   uint32_t s = m.rstart(v, e);
   int32_t st = kFsmNoStart;
-  for (int32_t at = e - 1; at >= bound; at--) {
+  int32_t at = e - 1;
+  // Four steps at a time while four bytes are available: the byte reads and the class lookups of a group do not depend
+  // on the automaton's state and are issued together, so the dependent chain per step is ONE table read instead of
+  // three (byte -> class -> row).  This walk runs once per row with a single chain per lane: it is latency, not issue, that
+  // it costs (0.27 of 0.78 ms/GiB on the README IP pattern before).
+  const int32_t low = bound > budget_lo ? bound : budget_lo;
+  while (at - 3 >= low) {
+    uint32_t c[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) c[k] = m.rcls(v, at - k);
+    bool dead = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+      if (dead) break;
+      s = fsm_u16(v.rev, s + c[k]);
+      if (s == 0u) { dead = true; break; }
+      if (s >= v.rev_accept_off) st = at - k;
+    }
+    if (dead) return st;
+    at -= 4;
+  }
+  for (; at >= bound; at--) {
     if (at < budget_lo) { over = 1u; break; }
     s = fsm_u16(v.rev, s + m.rcls(v, at));
     if (s == 0u) break;
