@@ -50,6 +50,31 @@ int orc_prefix_literal(void* e, int i, uint8_t* buf, int cap, int* complete) {
   return n;
 }
 
+// Literal extractor alone (literal/extractor_test.go vectors): which = 0 ExtractPrefixes, 1 ExtractSuffixes, 2 ExtractInner.
+// Output: one record per literal = length byte, complete byte, the bytes.  Returns the number of literals, -1 on a parse
+// error, -2 when the records do not fit.
+int orc_extract_literals(const char* pattern, int64_t len, int which, uint8_t* buf, int cap) {
+  try {
+    ReP re = parse(std::string(pattern, static_cast<size_t>(len)));
+    Seq seq = which == 0 ? extractPrefixes(re) : which == 1 ? extractSuffixes(re) : extractInner(re);
+    int used = 0;
+    for (auto& l : seq.lits) {
+      const int n = static_cast<int>(l.bytes.size());
+      if (n > 255 || used + 2 + n > cap) return -2;
+      buf[used++] = static_cast<uint8_t>(n);
+      buf[used++] = l.complete ? 1 : 0;
+      std::memcpy(buf + used, l.bytes.data(), static_cast<size_t>(n));
+      used += n;
+    }
+    return static_cast<int>(seq.lits.size());
+  } catch (const ParseError& e) {
+    g_err = "parse: " + e.msg;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+  }
+  return -1;
+}
+
 static int64_t copyOut(const std::vector<int64_t>& v, int64_t* out, int64_t capVals) {
   int64_t n = static_cast<int64_t>(v.size());
   if (out && n <= capVals) std::memcpy(out, v.data(), n * sizeof(int64_t));

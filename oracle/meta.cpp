@@ -528,6 +528,7 @@ Seq extractPrefixes(const ReP& re) {  // ExtractPrefixes extractor.go:128-156
   return seq;
 }
 Seq extractSuffixes(const ReP& re) { Extractor e; return e.suffixes(re, 0); }
+Seq extractInner(const ReP& re) { Extractor e; return e.inner(re, 0); }
 
 // ----------------------------------------------------------------- SelectStrategy
 static Strategy selectStrategy(const NFA& nfa, const ReP& re, const Seq& lits, bool& restated) {

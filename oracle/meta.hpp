@@ -41,6 +41,7 @@ struct Seq {
 };
 Seq extractPrefixes(const ReP& re);
 Seq extractSuffixes(const ReP& re);
+Seq extractInner(const ReP& re);      // ExtractInner extractor.go:744-810
 
 struct Engine {
   std::string pattern;

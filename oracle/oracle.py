@@ -229,6 +229,25 @@ def memchr_digit_at(hay, at: int) -> int:
     return int(lib().orc_memchr_digit_at(ptr, ln, at))
 
 
+def extract_literals(pattern: str, which: str = "prefix"):
+    """literal.Extractor of the reference on a parsed pattern (no engine): [(bytes, complete), ...]."""
+    L = lib()
+    L.orc_extract_literals.restype = C.c_int
+    L.orc_extract_literals.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
+    p = pattern.encode()
+    buf = (C.c_uint8 * 65536)()
+    n = L.orc_extract_literals(p, len(p), {"prefix": 0, "suffix": 1, "inner": 2}[which], buf, 65536)
+    if n < 0:
+        raise OracleError(L.orc_last_error().decode() if n == -1 else "literal records do not fit")
+    out, off = [], 0
+    raw = bytes(buf)
+    for _ in range(n):
+        ln, comp = raw[off], raw[off + 1]
+        out.append((raw[off + 2:off + 2 + ln], bool(comp)))
+        off += 2 + ln
+    return out
+
+
 class Teddy:
     def __init__(self, patterns):
         packed = b"".join(bytes([len(p)]) + bytes(p) for p in patterns)

@@ -84,6 +84,19 @@ def test_teddy_find(oracle):
         assert t.find(_inp(c), c["start"]) == c["want"], c
 
 
+def test_literal_extraction(oracle):
+    """literal.Extractor (prefixes, suffixes, inner literals) against the tables of literal/extractor_test.go."""
+    for c in VEC["literal_extraction"]["cases"]:
+        got = oracle.extract_literals(c["pattern"], c["which"])
+        lits = [b.decode() for b, _ in got]
+        if c.get("unordered"):
+            assert sorted(lits) == sorted(c["want"]), c
+        else:
+            assert lits == c["want"], (c, lits)
+        if c["complete"] is not None:
+            assert all(comp == c["complete"] for _, comp in got), c
+
+
 def test_fat_teddy_find(oracle):
     for c in VEC["fat_teddy_find"]["cases"]:
         pats = [(c["patterns"]["fmt"] % i).encode() for i in range(c["patterns"]["count"])]
