@@ -77,6 +77,22 @@ def test_transducer_twin_line_anchored_literals(oracle, pat):
     hays = _hays(7) + [b"GET /a\nPOST /b\n GET\nPUTS\nDELETE\nPATCH x GET\nGET", b"\nGET\n\nPUT\n"]
     _check(oracle, pat, hays, look="UseTeddy")
 
+def test_lookaround_golden_rows_on_the_twin():
+    """The look-around rows of tests/golden (the reference's differential pairs, spans by Python re) through the product's
+    front-end, transducer tables and lane functions — no oracle in between."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    n = 0
+    for c in vec["lookaround_compat"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        assert rx.supported, (c["pattern"], rx.why_unsupported)
+        for tile, chunk in ((3840, 32), (64, 8), (32, 4)):
+            got = emu.find_all_fsm(rx.fsm_image(), c["input"].encode(), tile, chunk, dense=1)
+            assert not isinstance(got, int) and got.tolist() == c["want"], (c, tile, chunk)
+            n += 1
+    assert n >= 45
+
+
 def test_word_boundary_scope(oracle):
     """Served: UseNFA programs (small patterns; PikeVM semantics in the reference).  Refused at build time: line / text
     anchors, nullable patterns, and the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)."""

@@ -264,3 +264,21 @@ def test_multiline_anchor_edges(oracle):
                 head = np.full(n, ord(" "), dtype=np.uint8)
                 head[:k] = np.frombuffer(tail, dtype=np.uint8)[:k]
                 assert np.array_equal(rx.find_all_index(head), o.find_all_index(head)), (pat, n, tail, "head")
+
+
+def test_lookaround_golden_rows_on_the_device():
+    """tests/golden "lookaround_compat": the reference's own differential pairs for (?m)^ (?m)$ \\b \\B with spans computed by
+    Python re — device rows against the fixture, no oracle in between."""
+    import json, os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    for c in vec["lookaround_compat"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        assert rx.supported, (c["pattern"], rx.why_unsupported)
+        hay = c["input"].encode()
+        assert rx.find_all_index(hay).tolist() == c["want"], c
+        big = (hay + b"\n") * 3000                                   # the same lines repeated past several wave-tiles
+        exp = [[s + k * (len(hay) + 1), e + k * (len(hay) + 1)] for k in range(3000) for s, e in c["want"]]
+        import re as pyre
+        assert exp == [[m.start(), m.end()] for m in pyre.finditer(c["pattern"].encode(), big)], "fixture arithmetic"
+        got = rx.find_all_index(big)
+        assert got.tolist() == exp, c["pattern"]

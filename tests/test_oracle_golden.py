@@ -84,6 +84,13 @@ def test_teddy_find(oracle):
         assert t.find(_inp(c), c["start"]) == c["want"], c
 
 
+def test_lookaround_compat(oracle):
+    """(?m)^ (?m)$ \\b \\B: the reference's own differential pairs, spans by Python re (gen_lookaround_expected.py)."""
+    for c in VEC["lookaround_compat"]["cases"]:
+        got = oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist()
+        assert got == c["want"], c
+
+
 def test_literal_extraction(oracle):
     """literal.Extractor (prefixes, suffixes, inner literals) against the tables of literal/extractor_test.go."""
     for c in VEC["literal_extraction"]["cases"]:
