@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=1.0, help="weak scaling: bytes per rank (BASELINE configs[1]: 1 GiB)")
     ap.add_argument("--total-gib", type=float, default=0.0, help="strong scaling: fixed corpus split over the ranks (north star: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
     args = ap.parse_args()
@@ -186,6 +187,16 @@ def main():
         },
     }
 
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if rank == 0 and world == 1 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
+        # HBM traffic of the dominant kernel, measured NOW: two child runs of this very workload under rocprofv3, one PMC
+        # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.
+        live = _pmc_traffic_live(args, kname)
+        if live is not None:
+            result["roofline"]["traffic"] = live["traffic_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = live["source"]
+        elif result["roofline"]["traffic"] is not None:
+            result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
         result["cpu_baseline"] = _cpu_baseline(args.config, cfg, pattern, buf, out, nmatch, nbytes, width, base)
     if rank == 0:
@@ -271,6 +282,51 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
         "host_cpu": _cpu_model(),
         "host_threads_available": os.cpu_count(),
     }
+
+
+def _pmc_traffic_live(args, kernel):
+    """2 x FETCH_SIZE + WRITE_SIZE per launch of `kernel`, from two child invocations of this script under
+    `rocprofv3 --kernel-trace --pmc <one counter>` (separate passes, kernel trace only beside the counters —
+    MI355X_MICROARCH.md "HBM"; FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads).  None on any failure."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "3", "--warmup", "1", "--settle", "2",
+             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc"]
+    if args.pattern is not None:
+        child += ["--pattern", args.pattern]
+    if args.synth_config is not None:
+        child += ["--synth-config", str(args.synth_config)]
+    fam = kernel.split("+")[-1].split("<")[0]
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="cxg_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "pmc", "--output-format", "csv", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            per_kernel = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if fam in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per_kernel.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None
+            name, vals = max(per_kernel.items(), key=lambda kv: len(kv[1]))     # the instantiation the steps launch
+            means[counter] = (name, sum(vals) / len(vals), len(vals))
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, write_kb = means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]
+    return {"traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+            "source": f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one counter per child pass of this command "
+                      f"({means['FETCH_SIZE'][2]} launches of {means['FETCH_SIZE'][0]}), 2 x FETCH_SIZE + WRITE_SIZE"}
 
 
 def _pmc_traffic(config, nbytes, kernel):

@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 for N in ${CFGS:-1 2 3 4 5}; do
   timeout 400 python $R/bench.py --config $N --steps 20 --warmup 5 > $R/gpurun_out/r02_cfg${N}_bench.json 2> $R/gpurun_out/r02_cfg${N}_bench.err; echo "cfg $N bench rc=$?"
   rm -rf /tmp/prof_$N
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$N -o cfg$N -- python $R/bench.py --config $N --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_$N.log 2>&1; echo "cfg $N stats rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$N -o cfg$N -- python $R/bench.py --config $N --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > /tmp/prof_$N.log 2>&1; echo "cfg $N stats rc=$?"
   db=$(find /tmp/prof_$N -name "*.db" | head -1)
-  [ -n "$db" ] && python $R/scripts/rocprof_summary.py $db $R/gpurun_out/r02_cfg${N}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $N --steps 20 --warmup 5 --no-cpu-baseline" > /dev/null
+  [ -n "$db" ] && python $R/scripts/rocprof_summary.py $db $R/gpurun_out/r02_cfg${N}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $N --steps 20 --warmup 5 --no-cpu-baseline --no-pmc" > /dev/null
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1)); rm -rf /tmp/pmc_${N}_$i
-    timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_${N}_$i -o pmc --output-format csv -- python $R/bench.py --config $N --steps 3 --warmup 1 --settle 2 --no-cpu-baseline > /tmp/pmc_${N}_$i.log 2>&1; echo "cfg $N pmc $set rc=$?"
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_${N}_$i -o pmc --output-format csv -- python $R/bench.py --config $N --steps 3 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc > /tmp/pmc_${N}_$i.log 2>&1; echo "cfg $N pmc $set rc=$?"
   done
   python - $N $R <<'PY'
 import csv, glob, json, sys, collections
@@ -32,7 +32,7 @@ for k, d in sorted(acc.items(), key=lambda kv: -len(kv[1].get("FETCH_SIZE", []))
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fk = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]); wk = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         rec = {"baseline_config": n, "kernel": k, "bytes_per_gpu": bench["config"]["bytes_per_gpu"],
-               "command": f"rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --config {n} --steps 3 --warmup 1 --settle 2 --no-cpu-baseline (scripts/gpu_r2_evidence.sh; one counter per pass)",
+               "command": f"rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- python bench.py --config {n} --steps 3 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc (scripts/gpu_r2_evidence.sh; one counter per pass)",
                "FETCH_SIZE_KB_mean": fk, "WRITE_SIZE_KB_mean": wk, "launches_averaged": len(d["FETCH_SIZE"]),
                "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE as reported (uncalibrated)",
                "traffic_bytes_per_launch": int(2 * fk * 1024 + wk * 1024),

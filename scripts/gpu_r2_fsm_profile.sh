@@ -6,15 +6,15 @@ IP='(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][
 i=0
 for PAT in "$IP" '\berror\b'; do
   i=$((i+1)); tag=$([ $i = 1 ] && echo readme_ip || echo word_boundary); cfg=$([ $i = 1 ] && echo 2 || echo 1)
-  timeout 300 python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r02_fsm_${tag}_bench.json 2>/dev/null; echo "$tag bench rc=$?"
+  timeout 300 python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $R/gpurun_out/r02_fsm_${tag}_bench.json 2>/dev/null; echo "$tag bench rc=$?"
   rm -rf /tmp/prof_f$i
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_f$i -o f$i -- python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 20 --warmup 5 --no-cpu-baseline > /tmp/prof_f$i.log 2>&1; echo "$tag stats rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_f$i -o f$i -- python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > /tmp/prof_f$i.log 2>&1; echo "$tag stats rc=$?"
   db=$(find /tmp/prof_f$i -name "*.db" | head -1)
-  [ -n "$db" ] && python $R/scripts/rocprof_summary.py $db $R/gpurun_out/r02_fsm_${tag}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --pattern '$tag' --synth-config $cfg --steps 20 --warmup 5 --no-cpu-baseline" > /dev/null
+  [ -n "$db" ] && python $R/scripts/rocprof_summary.py $db $R/gpurun_out/r02_fsm_${tag}_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --pattern '$tag' --synth-config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-pmc" > /dev/null
   j=0
   for set in "FETCH_SIZE" "WRITE_SIZE"; do
     j=$((j+1)); rm -rf /tmp/pmc_f${i}_$j
-    timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_f${i}_$j -o pmc --output-format csv -- python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 3 --warmup 1 --settle 2 --no-cpu-baseline > /dev/null 2>&1; echo "$tag pmc $set rc=$?"
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_f${i}_$j -o pmc --output-format csv -- python $R/bench.py --pattern "$PAT" --synth-config $cfg --config $cfg --steps 3 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc > /dev/null 2>&1; echo "$tag pmc $set rc=$?"
   done
   python - $i $tag $R <<'PY'
 import csv, glob, json, sys, collections
