@@ -307,7 +307,7 @@ def _pmc_traffic_live(args, kernel):
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "pmc", "--output-format", "csv", "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
                 return None
             per_kernel = {}
