@@ -109,6 +109,17 @@ def test_malformed_nfa_descriptions_are_rejected():
     mutate(lambda n, st, tr: setattr(st[first(st, 5)], "next", n.n_states))
     mutate(lambda n, st, tr: setattr(st[0], "kind", 42))
     mutate(lambda n, st, tr: setattr(n, "n_states", 0))
+    # look-around states: kind 7, lo = nfa.Look (0..5)
+    wb = cx.compile(r"\berror\b")
+    nfa, (st, tr) = cx.flatten_nfa(wb.nfa())
+    assert _raw_from_nfa(nfa, 0, 0)[0] == 0                                   # strategy 0 = UseNFA
+    look = next(i for i, s in enumerate(st) if s.kind == 7)
+    st[look].lo = 9
+    rc, out, msg = _raw_from_nfa(nfa, 0, 0)
+    assert rc == _lib.CXG_E_INVALID and not out and "look-around kind" in msg, (rc, msg)
+    st[look].lo = 4
+    st[look].next = nfa.n_states + 3
+    assert _raw_from_nfa(nfa, 0, 0)[0] == _lib.CXG_E_INVALID
     # InvalidState (0xFFFFFFFF) is a legal "no target" (nfa/nfa.go:62-64)
     nfa, (st, tr) = cx.flatten_nfa(eng.nfa())
     assert _raw_from_nfa(nfa, 2, 2)[0] == 0
