@@ -136,6 +136,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   std::vector<uint8_t> levels;                    // pending levels of a state
   std::vector<std::vector<uint32_t>> trans;       // [state][class] next | event descriptor << 16
   uint32_t depth = 0;
+  bool createUnderPending = false;                // some step creates a match while an older pending level stays alive
   bool tooBig = false;
   auto intern = [&](const std::vector<std::vector<uint32_t>>& stack) -> uint32_t {
     std::vector<uint32_t> key;
@@ -195,6 +196,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
           if (conts) next.push_back(std::move(moved));
           next.push_back(fresh);
           ev = eventOf(cxgdev::kFsmEvCreate, 0, conts, died);
+          if (died != (nl ? (1u << nl) - 1u : 0u)) createUnderPending = true;
         } else {
           if (moved.empty()) { why = "internal: innermost search died (unanchored prefix missing)"; return false; }
           next.push_back(std::move(moved));
@@ -206,6 +208,11 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
     }
   }
   if (tooBig) { why = "FindAll transducer exceeds the table budget (states, pending levels or events)"; return false; }
+  // FsmHeader::depth <= 1 selects the two-bitmap row derivation of the kernel (fsm.hpp fsm_finish_shallow), which
+  // attributes a rematch to the LATEST created row.  That holds only when no match is created while an older pending level
+  // survives the step: `(?:ab)*[ab]` on "abb" creates [1,2) under the pending [0,1) — no threads of its own, so the stack
+  // stays one deep — and the parent then grows to [0,3) and must drop it.  Such machines take the event-list path.
+  if (createUnderPending && depth < 2) depth = 2;
   const uint32_t nT = static_cast<uint32_t>(keys.size());
 
   // ---- uncertainty rows: sets of states, from "any state" (top) until they collapse to one state

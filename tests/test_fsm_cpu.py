@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 GEOMS = ((3840, 32), (256, 16), (64, 8), (32, 4), (128, 32))
 GENERAL = [r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|foo)\d*", r"[1-9][0-9]*|0", r"x[ab]+?y", r"ab|abc", r"[a-c]x|[b-d]y",
-           r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal", r"ax|x?b+",
+           r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal", r"ax|x?b+", r"(?:ab)*[ab]", r"(?:ab)*[a-c]", r"(?:xy)*[x-z]",
            r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"]
 LOOK = [r"\berror\b", r"\b\d+\b", r"\bGET\b", r"\b(GET|PUT)\b", r"\Berror", r"error\B", r"\b[A-Z]+\b", r"ab(a|\b)", r"(ab)+(a|\b)\b\b", r"\b\d+\.\d+\b",
         r"\berror\w*", r"\b[a-z]+\b", r"\b0x[0-9a-f]+\b", r"\w+\b", r"a\B", r"(?:\bx)+", r"x\b|\By", r"\b_+\b",
@@ -91,6 +91,23 @@ def test_lookaround_golden_rows_on_the_twin():
             assert not isinstance(got, int) and got.tolist() == c["want"], (c, tile, chunk)
             n += 1
     assert n >= 45
+
+
+def test_match_created_under_a_pending_match_that_later_grows(oracle):
+    """`(?:ab)*[ab]` on "abb": [0,1) is pending (the thread inside `ab` lives), [1,2) is created under it — with no threads of
+    its own, so the stack stays one level deep — then the pending match grows to [0,3) and the row under it must go.  The
+    two-bitmap row derivation cannot express that: such machines carry depth 2 and take the event-list path (found by the
+    device fuzz, seed 73)."""
+    for pat in (r"(?:ab)*[ab]", r"(?:ab)*[a-c]"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        img = rx.fsm_image()
+        assert np.frombuffer(img[:32], dtype=np.uint32)[7] >= 2          # FsmHeader::depth
+        for hay in (b"2x00xa8z\x7fX\xa9y8abbzc\x7fyxccbz2cyxazx", b"abb" + b" " * 29, b" " * 29 + b"abb", b"ababb" * 13, (b"xabb ab abb ababa " * 20)[:320]):
+            for geom in GEOMS:
+                got = emu.find_all_fsm(img, hay, *geom, dense=1)
+                assert not isinstance(got, int) and got.tolist() == o.find_all_index(hay).tolist(), (pat, hay, geom)
+    for pat in (r"\d+\.\d+x?", r"a+b|b+a", r"\d+\.\d+\.\d+\.\d+", r"\berror\b"):     # these stay on the two-bitmap path
+        assert np.frombuffer(cx.compile(pat).fsm_image()[:32], dtype=np.uint32)[7] <= 1
 
 
 def test_word_boundary_scope(oracle):
