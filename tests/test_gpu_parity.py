@@ -562,7 +562,8 @@ def test_concurrent_callers_share_programs(need_gpu, oracle):
     thread has its own stream and scratch.  Eight threads hammer five shared programs (all kernel families, host and
     zero-copy paths, limits) and every answer equals the oracle's."""
     import threading
-    pats = [r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal|critical", r"[\w]+", r"error", r"(\w+)@(\w+)\.(\w+)"]
+    pats = [r"\d+\.\d+\.\d+\.\d+", r"error|warning|fatal|critical", r"[\w]+", r"error", r"(\w+)@(\w+)\.(\w+)",
+            r"\d+\.\d+x?", r"\berror\b", r"(?m)^\d+"]        # transducer kernel: density-mode escalation shared through the program; look-around
     progs = [cx.compile(p) for p in pats]
     hays = [cx.synth_pages(c, 0xC0FFEE00 + c, 11, n) for c, n in ((2, 16), (3, 300), (4, 40), (1, 700), (5, 100))]
     exp = [[oracle.Regex(p).find_all_index(h) for h in hays] for p in pats]
