@@ -27,6 +27,11 @@ sk2 = np.ones(len(alphabet)); sk2[9:19] = 10; sk2 /= sk2.sum()
 hays = [rnd(0), rnd(5), rnd(T - 1), rnd(T + 1), rnd(32 * T), rnd(32 * T + 7, skew), rnd(70000, sk2), rnd(200000, skew),
         np.frombuffer((b"xyab" + b"." * 28) * 4000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 9000, dtype=np.uint8),
         np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 3000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
+if os.environ.get("FUZZ_FEW"):
+    # few-symbol haystacks of several groups (120 KiB each): the sets of possible entry states stay unresolved for long
+    # stretches, so the transducer kernel's member maps, its serial chain and the tile / group hand-off do the work
+    few = [np.frombuffer(a, dtype=np.uint8) for a in (b"ab", b"abc", b"ab ", b"xyz", b"1.", b"a:c", b"abx\n", b"01 .")]
+    hays = [f[rng.integers(0, len(f), size=int(n))] for f in few for n in (70000, 260000)]
 ORACLE_ONLY = bool(os.environ.get('FUZZ_ORACLE_ONLY'))
 seen, n_dev, n_sub, bad = set(), 0, 0, 0
 n_refused = 0
@@ -95,7 +100,18 @@ while len(seen) < npat:
             exp = o.find_all_submatch_index(hay)
             if ORACLE_ONLY:
                 continue
-            got = rx.find_all_submatch_index(hay)
+            try:
+                got = rx.find_all_submatch_index(hay)
+            except cx.UnsupportedInput as ex:                 # a match longer than the serial-walk / per-row budgets (few-symbol haystacks)
+                if 'serial-walk budget' in str(ex) and len(hay) > 64 * 1024:
+                    n_nosync += 1
+                    continue
+                plain = exp[:, :2]
+                if rx.strategy == 'UseBoth' and len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100:
+                    n_refused += 1
+                    continue
+                print("SUBMATCH-REFUSED", repr(pat), "hay", hi, len(hay), ex); bad += 1
+                continue
             if got.shape != exp.shape or not np.array_equal(got, exp):
                 print("SUBMATCH", repr(pat), "hay", hi, len(hay), got.shape, exp.shape); bad += 1
 print("seed", seed, "patterns", len(seen), "device", n_dev, "submatch", n_sub, "refused-long-UseBoth", n_refused, "refused-no-sync", n_nosync, "refused-budget", n_budget, "bad", bad, by_strategy, "%.1fs" % (time.time() - t0))
