@@ -12,7 +12,9 @@ ATOMS = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", "abc", "xyz", "a:c", "(b*c)?", "(a|ab)", "(abc|ab|a)", "b*", "(ab*c|a|bb)", "a+?", "[ab]*?c",
          # (found by the device fuzz: a match created under a pending one that later grows — `(?:ab)*[ab]` on "abb")
-         "(?:ab)*", "(?:a|b|c)+", "(?:ab)*[ab]", "(?:xy)*[x-z]", "(?:ab|a)*", "a*", r"\d{2,}", "(a+)(b+)", "b+?", "[a-c]+?", "(?:abc)*"]
+         "(?:ab)*", "(?:a|b|c)+", "(?:ab)*[ab]", "(?:xy)*[x-z]", "(?:ab|a)*", "a*", r"\d{2,}", "(a+)(b+)", "b+?", "[a-c]+?", "(?:abc)*",
+         "(a|b)*c", "(?:a+b)*", "(a?b)+", "(?:ab|a)(?:c|bc)", "x{2,3}", "(?:a{2})+", "[ab]{2}", "(?:x|xy)+z", "a*b", "(?:ab)+?c", "(?:a|ab|abc)", "(?:b|bc)*c",
+         "(?:xy?)+", "[a-c]?[x-z]", "(?:a:)*c", r"(?:\d\.)*\d"]
 
 LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+", r"(a|\b)", r"(\bab|xy\b)", r"\b\b", r"(?:\bx)+",
               "^", "$", "^", "$", r"\n", r"(^a|b$)", r"[a-c\n]+", r"(?:$\n^)?", "^ab|xy$"]
