@@ -689,6 +689,32 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       // of different lengths — runs the PikeVM from the first candidate that passes (find_indices.go:941-950): the
       // leftmost-first match of the whole pattern, which is what the transducer computes.
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+      if (strategy == CXG_USE_TEDDY) {
+        // The reference's line-start check sits in front of EVERY literal candidate as soon as the pattern holds a (?m)^
+        // anywhere (compile.go:670-677): that equals the pattern's meaning only when no byte can be consumed before a
+        // StartLine assertion has been crossed.  (cxg_compile checks the same on the AST; a caller's NFA is checked here.)
+        bool anyLine = false;
+        for (uint32_t i = 0; i < nfa.n_states; i++) anyLine = anyLine || (nfa.states[i].kind == CXG_NFA_LOOK && nfa.states[i].lo == 2);
+        if (!anyLine) throw BuildError{CXG_E_UNSUPPORTED, "UseTeddy program without (?m)^ handed over as an NFA: use cxg_program_from_literals"};
+        std::vector<uint8_t> seen(nfa.n_states, 0);
+        std::vector<uint32_t> st{nfa.start_anchored};
+        bool sawLine = false;
+        while (!st.empty()) {
+          const uint32_t q = st.back(); st.pop_back();
+          if (q == CXG_NFA_INVALID || q >= nfa.n_states || seen[q]) continue;
+          seen[q] = 1;
+          const cxg_nfa_state& x = nfa.states[q];
+          switch (x.kind) {
+            case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE: st.push_back(x.next); break;
+            case CXG_NFA_SPLIT: st.push_back(x.left); st.push_back(x.right); break;
+            case CXG_NFA_LOOK: if (x.lo == 2 /* StartLine */) sawLine = true; else st.push_back(x.next); break;
+            case CXG_NFA_BYTE_RANGE: case CXG_NFA_SPARSE: case CXG_NFA_MATCH:
+              throw BuildError{CXG_E_UNSUPPORTED, "(?m)^ on some alternatives only: the reference applies its line-start check to every literal candidate (prefilter.WrapLineAnchor)"};
+            default: break;
+          }
+        }
+        (void)sawLine;
+      }
       HostNfa rn = reverseOf(nfa);
       cxg_nfa rvw = rn.view();
       bool look = false;

@@ -55,6 +55,18 @@ def test_from_nfa_builds_the_program_cxg_compile_builds(pat):
         assert prog.chain_captures() == eng.chain_captures()
 
 
+def test_from_nfa_with_strategy_teddy_needs_a_line_start_on_every_path():
+    """UseTeddy behind (?m)^ travels as an NFA: the reference filters EVERY literal candidate by a line-start
+    check, which is the pattern's meaning only when every alternative is anchored — checked on the caller's NFA."""
+    for pat, ok, frag in ((r"(?m)^(GET|POST|PUT)", True, ""), (r"(?m)^GET|^POST|^PUT", True, ""),
+                          (r"(?m)^foo|barr", False, "some alternatives only"), (r"foo|bar|baz", False, "cxg_program_from_literals")):
+        src = cx.compile(pat)
+        nfa, keep = cx.flatten_nfa(src.nfa())
+        nfa.capture_count = 1 if src.num_groups == 1 else nfa.capture_count
+        prog = cx.program_from_nfa(nfa, "UseTeddy", 0)
+        assert prog.supported == ok and frag in prog.why_unsupported, (pat, prog.supported, prog.why_unsupported)
+
+
 def test_from_literals_and_from_charclass_build_the_compile_images():
     t = cx.program_from_literals([s.encode() for s in LITS16])
     e = cx.compile("|".join(LITS16))
