@@ -7,8 +7,32 @@
 namespace orc {
 
 // =============================================================== lazy DFA
-void LazyDFA::closureInto(std::vector<StateID>& out, std::vector<uint8_t>& in, StateID seed) const {
-  // builder.go:245-293: explicit stack, add-on-pop, push right then left.
+void LazyDFA::init(const NFA* n, bool brk) {
+  nfa = n; breakAtMatch = brk;
+  hasWordBoundary = hasEndLine = false;   // builder.go:714-750
+  for (const NState& s : n->states)
+    if (s.kind == StateLook) {
+      if (s.look == LookWordBoundary || s.look == LookNoWordBoundary) hasWordBoundary = true;
+      if (s.look == LookEndLine) hasEndLine = true;
+    }
+  for (auto& row : starts) for (int32_t& x : row) x = -2;
+  states.clear();
+  cache.clear();
+}
+
+static bool lookSatisfied(uint32_t have, Look l) {  // LookSet.Contains, look.go:43-60: \b and \B are never in a LookSet
+  switch (l) {
+    case LookStartText: return have & LazyDFA::HaveStartText;
+    case LookEndText: return have & LazyDFA::HaveEndText;
+    case LookStartLine: return have & LazyDFA::HaveStartLine;
+    case LookEndLine: return have & LazyDFA::HaveEndLine;
+    default: return false;
+  }
+}
+
+void LazyDFA::closureInto(std::vector<StateID>& out, std::vector<uint8_t>& in, StateID seed, uint32_t lookHave) const {
+  // builder.go:245-293: explicit stack, add-on-pop, push right then left; a Look state is added, and passed only when
+  // its assertion is in lookHave.
   std::vector<StateID> stack{seed};
   while (!stack.empty()) {
     StateID cur = stack.back();
@@ -25,10 +49,58 @@ void LazyDFA::closureInto(std::vector<StateID>& out, std::vector<uint8_t>& in, S
         if (s.left != kInvalidState) stack.push_back(s.left);
         break;
       case StateCapture: if (s.next != kInvalidState) stack.push_back(s.next); break;
-      case StateLook: break;  // looks unsupported here (supported() is false)
+      case StateLook: if (lookSatisfied(lookHave, s.look) && s.next != kInvalidState) stack.push_back(s.next); break;
       default: break;
     }
   }
+}
+
+std::vector<StateID> LazyDFA::closureOf(const std::vector<StateID>& seeds, uint32_t lookHave) const {
+  std::vector<StateID> out;
+  std::vector<uint8_t> in(nfa->states.size(), 0);
+  for (StateID s : seeds) closureInto(out, in, s, lookHave);
+  return out;
+}
+
+bool LazyDFA::holdsMatch(const std::vector<StateID>& set) const {
+  for (StateID s : set) if (nfa->isMatch(s)) return true;
+  return false;
+}
+
+std::vector<StateID> LazyDFA::resolveWordBoundaries(const std::vector<StateID>& set, bool satisfied) const {
+  // builder.go:295-425.  Only states BEHIND a crossed \b / \B are added; when any was crossed the result is the union
+  // in SORTED order (StateSet.ToSlice, state.go:487-497) — the priority order of the input is gone.
+  std::vector<uint8_t> crossed(nfa->states.size(), 0);
+  std::vector<StateID> stack;
+  auto cross = [&](const NState& st) {
+    if (st.next == kInvalidState) return;
+    const bool ok = (st.look == LookWordBoundary && satisfied) || (st.look == LookNoWordBoundary && !satisfied);
+    if (ok && st.next < crossed.size() && !crossed[st.next]) { crossed[st.next] = 1; stack.push_back(st.next); }
+  };
+  auto follow = [&](StateID t) { if (t != kInvalidState && t < crossed.size() && !crossed[t]) { crossed[t] = 1; stack.push_back(t); } };
+  for (StateID sid : set) {
+    if (sid >= nfa->states.size()) continue;
+    const NState& st = nfa->states[sid];
+    if (st.kind == StateLook) cross(st);
+  }
+  if (stack.empty()) return set;
+  while (!stack.empty()) {
+    const StateID cur = stack.back();
+    stack.pop_back();
+    const NState& st = nfa->states[cur];
+    switch (st.kind) {
+      case StateLook: cross(st); break;
+      case StateEpsilon: follow(st.next); break;
+      case StateSplit: follow(st.left); follow(st.right); break;
+      case StateCapture: follow(st.next); break;
+      default: break;
+    }
+  }
+  std::vector<uint8_t> in(crossed);
+  for (StateID sid : set) if (sid < in.size()) in[sid] = 1;
+  std::vector<StateID> out;
+  for (StateID i = 0; i < in.size(); i++) if (in[i]) out.push_back(i);
+  return out;
 }
 
 static std::vector<uint32_t> makeKey(const std::vector<StateID>& ids, bool fromWord, bool isMatch) {
@@ -39,24 +111,40 @@ static std::vector<uint32_t> makeKey(const std::vector<StateID>& ids, bool fromW
   return k;
 }
 
-int32_t LazyDFA::startState(Bytes h, int64_t pos, bool anchored) {
-  // lazy.go:1569-1613; start.go:96-109 (prev-byte kind), :205-235 (never match).
-  bool fromWord = pos > 0 && isWordByte(h[pos - 1]);
-  int32_t& slot = starts[anchored ? 1 : 0][fromWord ? 1 : 0];
+int32_t LazyDFA::startStateOfKind(StartKind kind, bool anchored) {
+  // lazy.go:1569-1613 + start.go:205-254.  The assertions a start position satisfies (look.go:88-107): StartText \A and ^,
+  // StartLineLF ^ only; \b and \B wait for the first byte (isFromWord = kind == StartWord).  Never a match state.
+  int32_t& slot = starts[anchored ? 1 : 0][kind];
   if (slot != -2) return slot;
-  std::vector<StateID> set;
-  std::vector<uint8_t> in(nfa->states.size(), 0);
-  closureInto(set, in, anchored ? nfa->startAnchored : nfa->startUnanchored);
+  const uint32_t have = kind == StartText ? (HaveStartText | HaveStartLine) : kind == StartLineLF ? HaveStartLine : 0u;
+  std::vector<StateID> set = closureOf({anchored ? nfa->startAnchored : nfa->startUnanchored}, have);
+  const bool fromWord = kind == StartWord;
   auto key = makeKey(set, fromWord, false);
   auto it = cache.find(key);
-  if (it != cache.end()) return slot = it->second;
-  DState d;
-  d.nfaStates = set; d.isMatch = false; d.isFromWord = fromWord;
-  d.trans.assign(nfa->alphabetLen, kUnknown);
-  states.push_back(std::move(d));
-  int32_t id = static_cast<int32_t>(states.size() - 1);
-  cache[key] = id;
+  int32_t id;
+  if (it != cache.end()) id = it->second;   // GetOrInsert: an existing state (its order, its flags) is kept
+  else {
+    DState d;
+    d.nfaStates = std::move(set); d.isMatch = false; d.isFromWord = fromWord;   // no matchAt* flags: ComputeStartState sets none
+    d.trans.assign(nfa->alphabetLen, kUnknown);
+    states.push_back(std::move(d));
+    id = static_cast<int32_t>(states.size() - 1);
+    cache[key] = id;
+  }
+  // WithStartTag marks the State object (lazy.go:1607).  (Transitions cached BEFORE the tag keep the untagged id in the
+  // reference; here the tag shows on every way in.  Observable only through the skipped word-boundary check in searchAt,
+  // i.e. for patterns that match empty at a start position.)
+  states[id].startTagged = true;
   return slot = id;
+}
+
+int32_t LazyDFA::startState(Bytes h, int64_t pos, bool anchored) {
+  StartKind kind = StartText;   // start.go:96-109, :128-133
+  if (pos > 0) {
+    const uint8_t p = h[pos - 1];
+    kind = p == '\n' ? StartLineLF : p == '\r' ? StartLineCR : isWordByte(p) ? StartWord : StartNonWord;
+  }
+  return startStateOfKind(kind, anchored);
 }
 
 int32_t LazyDFA::next(int32_t sid, uint8_t b) {
@@ -65,19 +153,22 @@ int32_t LazyDFA::next(int32_t sid, uint8_t b) {
   if (t != kUnknown) return t;
   // determinize, lazy.go:1336-1446
   std::vector<StateID> cur = states[sid].nfaStates;  // copy: states may reallocate
-  bool sourceHasMatch = false;
-  for (StateID s : cur) if (nfa->isMatch(s)) { sourceHasMatch = true; break; }
-  bool brk = sourceHasMatch && breakAtMatch;
+  if (hasEndLine && b == '\n') cur = closureOf(cur, HaveEndLine);   // :1350-1354: $ holds in front of this byte
+  const bool sourceHasMatch = holdsMatch(cur);
+  const bool brk = sourceHasMatch && breakAtMatch;
+  // moveWithWordContextBreak, builder.go:183-242
+  const std::vector<StateID> resolved = hasWordBoundary ? resolveWordBoundaries(cur, states[sid].isFromWord != isWordByte(b)) : cur;
+  const uint32_t lookAfter = b == '\n' ? HaveStartLine : 0u;
   std::vector<StateID> nextSet;
   std::vector<uint8_t> in(nfa->states.size(), 0);
-  for (StateID s : cur) {  // builder.go:183-242
+  for (StateID s : resolved) {
     const NState& st = nfa->states[s];
     if (brk && st.kind == StateMatch) break;
     if (st.kind == StateByteRange) {
-      if (b >= st.lo && b <= st.hi) closureInto(nextSet, in, st.next);
+      if (b >= st.lo && b <= st.hi) closureInto(nextSet, in, st.next, lookAfter);
     } else if (st.kind == StateSparse) {
       for (auto& tr : st.trans)
-        if (b >= tr.lo && b <= tr.hi) closureInto(nextSet, in, tr.next);
+        if (b >= tr.lo && b <= tr.hi) closureInto(nextSet, in, tr.next, lookAfter);
     }
   }
   bool isMatch = sourceHasMatch;
@@ -87,7 +178,12 @@ int32_t LazyDFA::next(int32_t sid, uint8_t b) {
   auto it = cache.find(key);
   if (it != cache.end()) { states[sid].trans[cls] = it->second; return it->second; }
   DState d;
-  d.nfaStates = std::move(nextSet); d.isMatch = isMatch; d.isFromWord = nextFromWord;
+  d.isMatch = isMatch; d.isFromWord = nextFromWord;
+  if (hasWordBoundary && !isMatch) {   // :1413-1421
+    d.matchAtWordBoundary = holdsMatch(resolveWordBoundaries(nextSet, true));
+    d.matchAtNonWordBoundary = holdsMatch(resolveWordBoundaries(nextSet, false));
+  }
+  d.nfaStates = std::move(nextSet);
   d.trans.assign(nfa->alphabetLen, kUnknown);
   states.push_back(std::move(d));
   int32_t id = static_cast<int32_t>(states.size() - 1);
@@ -96,17 +192,29 @@ int32_t LazyDFA::next(int32_t sid, uint8_t b) {
   return id;
 }
 
-bool LazyDFA::eoiMatch(int32_t sid) const {  // lazy.go:318-321 -> builder.go:454-472
-  for (StateID s : states[sid].nfaStates) if (nfa->isMatch(s)) return true;
-  return false;
+bool LazyDFA::eoiMatch(int32_t sid) const {
+  // checkEOIMatch lazy.go:1512-1522 -> CheckEOIMatch builder.go:437-472: outside the haystack counts as a non-word byte,
+  // \z and $ hold.
+  const DState& st = states[sid];
+  return holdsMatch(closureOf(resolveWordBoundaries(st.nfaStates, st.isFromWord), HaveEndText | HaveEndLine));
 }
 
-bool LazyDFA::matchesEmpty() {  // lazy.go:1640-1655
-  std::vector<StateID> set;
-  std::vector<uint8_t> in(nfa->states.size(), 0);
-  closureInto(set, in, nfa->startUnanchored);
-  for (StateID s : set) if (nfa->isMatch(s)) return true;
-  return false;
+bool LazyDFA::wordBoundaryMatch(int32_t sid, uint8_t b) const {
+  // checkWordBoundaryMatch lazy.go:1533-1560.  True as soon as the state's own NFA set holds a match state, crossed
+  // boundary or not: a match-holding state that is not match-TAGGED (1-byte delay) ends the search at this byte.
+  const DState& st = states[sid];
+  if (st.isMatch) return false;
+  return holdsMatch(resolveWordBoundaries(st.nfaStates, st.isFromWord != isWordByte(b)));
+}
+
+bool LazyDFA::matchesEmpty() {
+  // lazy.go:1636-1648.  cache.getState(StartState) is nil until a cache clear (ids start at `stride`, cache.go:99-107,
+  // :317-321), so this is the PikeVM asked about the EMPTY haystack — not about the position the caller stands at.
+  PikeVM pv;
+  pv.init(nfa);
+  int64_t s = -1, e = -1;
+  const uint8_t none = 0;
+  return pv.searchAt(&none, 0, 0, s, e) && s == 0 && e == 0;
 }
 
 int64_t LazyDFA::searchAtAnchored(Bytes h, int64_t n, int64_t at) {
@@ -115,6 +223,10 @@ int64_t LazyDFA::searchAtAnchored(Bytes h, int64_t n, int64_t at) {
   int32_t sid = startState(h, at, true);
   int64_t lastMatch = -1;
   for (int64_t pos = at; pos < n; pos++) {
+    if (hasWordBoundary) {   // checkWordBoundaryFast state.go:238-247: the flags determinize stored
+      const DState& st = states[sid];
+      if (!st.isMatch && ((st.isFromWord != isWordByte(h[pos])) ? st.matchAtWordBoundary : st.matchAtNonWordBoundary)) return pos;
+    }
     int32_t nx = next(sid, h[pos]);
     if (nx == kDead) return lastMatch;
     sid = nx;
@@ -131,6 +243,21 @@ int64_t LazyDFA::searchAt(Bytes h, int64_t n, int64_t at) {
   int32_t sid = startState(h, at, false);
   int64_t lastMatch = -1;
   for (int64_t pos = at; pos < n; pos++) {
+    if (states[sid].startTagged) {
+      if (prefilterFind && lastMatch < 0 && pos > at) {   // lazy.go:1210-1227: skip ahead, restart at the candidate
+        const int64_t cand = prefilterFind(h, n, pos);
+        if (cand == -1) return lastMatch;
+        if (cand > pos) { pos = cand; sid = startState(h, pos, false); pos--; continue; }
+      }
+      // lazy.go:1229-1243: cached transition out of a start state, no boundary check
+      const int32_t t = states[sid].trans[nfa->byteClasses[h[pos]]];
+      if (t != kUnknown && t != kDead) {
+        sid = t;
+        if (states[sid].isMatch) lastMatch = pos;
+        continue;
+      }
+    }
+    if (hasWordBoundary && wordBoundaryMatch(sid, h[pos])) return pos;   // :1262-1264
     int32_t nx = next(sid, h[pos]);
     if (nx == kDead) return lastMatch;
     sid = nx;
@@ -142,26 +269,11 @@ int64_t LazyDFA::searchAt(Bytes h, int64_t n, int64_t at) {
 
 int64_t LazyDFA::searchReverse(Bytes h, int64_t n, int64_t start, int64_t end) {
   if (end <= start || end > n) return -1;
-  // reverse start context: byte at 'end' (irrelevant without look-around)
-  bool fromWord = end < n && isWordByte(h[end]);
-  int32_t& slot = starts[1][fromWord ? 1 : 0];
-  if (slot == -2) {
-    std::vector<StateID> set;
-    std::vector<uint8_t> in(nfa->states.size(), 0);
-    closureInto(set, in, nfa->startAnchored);
-    auto key = makeKey(set, fromWord, false);
-    auto it = cache.find(key);
-    if (it != cache.end()) slot = it->second;
-    else {
-      DState d;
-      d.nfaStates = set; d.isFromWord = fromWord;
-      d.trans.assign(nfa->alphabetLen, kUnknown);
-      states.push_back(std::move(d));
-      slot = static_cast<int32_t>(states.size() - 1);
-      cache[key] = slot;
-    }
-  }
-  int32_t sid = slot;
+  // getStartStateForReverse lazy.go:2123-2158: the kind of the byte at `end` (StartText at the end of the haystack).
+  // The reverse NFA holds no assertions (nfa/reverse.go:124-129 turns them into epsilon edges), so only the key differs.
+  StartKind kind = StartText;
+  if (end < n) { const uint8_t p = h[end]; kind = p == '\n' ? StartLineLF : p == '\r' ? StartLineCR : isWordByte(p) ? StartWord : StartNonWord; }
+  int32_t sid = startStateOfKind(kind, true);
   int64_t lastMatch = -1;
   for (int64_t at = end - 1; at >= start; at--) {
     int32_t nx = next(sid, h[at]);
@@ -169,7 +281,7 @@ int64_t LazyDFA::searchReverse(Bytes h, int64_t n, int64_t start, int64_t end) {
     sid = nx;
     if (states[sid].isMatch) lastMatch = at + 1;  // lazy.go:1905-1907
   }
-  if (eoiMatch(sid)) lastMatch = start;           // lazy.go:1914-1917
+  if (holdsMatch(states[sid].nfaStates)) lastMatch = start;   // lazy.go:1914-1917
   return lastMatch;
 }
 

@@ -2,6 +2,7 @@
 #include "meta.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <functional>
 #include <set>
 
@@ -640,17 +641,33 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
   if (!e->nfa.anchored) e->prefixes = extractPrefixes(e->re);   // compile.go:466-478
   e->strategy = selectStrategy(e->nfa, e->re, e->prefixes, e->strategyRestated);
   e->pikevm.init(&e->nfa);
-  bool dfaOK = !e->nfa.hasLook;
-  // The reference's lazy DFA carries look-around state (dfa/lazy/start.go:64-172, builder.go:183-242 resolveWordBoundaries,
-  // lazy.go:1350-1354 the $ re-closure, :1413-1421 matchAtWordBoundary): NOT restated here.  A DFA strategy over an NFA
-  // with assertions is answered by the PikeVM below — authoritative for leftmost-first semantics, but not a restatement of
-  // what the reference executes (resolveWordBoundaries appends the states behind a \b after the others, which can change
-  // the priority order): say so.
-  if (!dfaOK && (e->strategy == UseDFA || e->strategy == UseBoth || e->strategy == UseDigitPrefilter)) e->strategyRestated = false;
+  // The lazy DFA carries the look-around state itself (engines.hpp "look-around"): five start kinds, \b / \B resolved when
+  // the next byte is known, $ re-closed in front of '\n', \z and $ at the end of input.  Restated with its quirks — the
+  // answers of a DFA strategy over an NFA with assertions are the reference's, not always stdlib's.
+  const bool dfaOK = true;
+  // prefilter.NewBuilder(prefixes, nil).Build() (compile.go:472-476 -> prefilter/prefilter.go:261-297): one literal ->
+  // memchr / memmem; 2..64 literals of >= 3 bytes -> Teddy, more -> Aho-Corasick; otherwise none.  Whatever the kind, Find
+  // returns the first position at which one of the literals occurs (prefilter.go:77).
+  bool hasPrefilter = false;
+  if (!e->prefixes.empty()) {
+    size_t minLen = ~size_t(0);
+    for (auto& l : e->prefixes.lits) minLen = std::min(minLen, l.bytes.size());
+    hasPrefilter = minLen >= 1 && (e->prefixes.lits.size() == 1 || minLen >= 3);
+  }
+  auto prefilterFind = [lits = e->prefixes.lits](Bytes h, int64_t n, int64_t pos) -> int64_t {
+    for (int64_t i = pos; i < n; i++)
+      for (auto& l : lits) {
+        const int64_t m = static_cast<int64_t>(l.bytes.size());
+        if (i + m <= n && std::memcmp(h + i, l.bytes.data(), static_cast<size_t>(m)) == 0) return i;
+      }
+    return -1;
+  };
   switch (e->strategy) {
     case UseDFA:
       if (dfaOK) {
         e->dfa.init(&e->nfa, true);
+        // The skip only shows in results when the NFA holds assertions (engines.hpp); otherwise keep the plain walk.
+        if (hasPrefilter && e->nfa.hasLook) e->dfa.prefilterFind = prefilterFind;
         if (!hasNonGreedy(e->re)) {  // buildReverseDFA compile.go:184-205
           e->revNfa = reverseNFA(e->nfa);
           e->revDfa.init(&e->revNfa, false);

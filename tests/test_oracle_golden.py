@@ -341,3 +341,26 @@ def test_find_all_submatch_index_vector(oracle):
 def test_dfa_search_at_vectors(oracle):
     for c in VEC["dfa_search_at"]["cases"]:
         assert oracle.Regex(c["pattern"]).dfa_search_at(_inp(c), c["at"]) == c["want"], c
+
+
+def test_lazy_dfa_look_vectors(oracle):
+    """The look-aware lazy DFA restated in oracle/engines.cpp against the reference's own tables for it."""
+    blk = VEC["lazy_dfa_look_search_at_anchored"]
+    rx = oracle.Regex(blk["pattern"])                       # one DFA = one cache, rows in order
+    for c in blk["cases"]:
+        assert rx.dfa_search_at_anchored(c["input"].encode(), c["at"]) == c["want"], c
+    for grp in ("lazy_dfa_look_find", "lazy_dfa_look_known_limitation"):
+        for c in VEC[grp]["cases"]:
+            assert (oracle.Regex(c["pattern"]).dfa_search_at(c["input"].encode(), 0) != -1) == c["want"], c
+
+
+def test_lazy_dfa_look_known_limitation_and_history(oracle):
+    """What the reference documents as a known limitation falls out of the restatement: a transition is cached per byte
+    class although its target depends on the byte being a word byte.  The same DFA answers differently after a different
+    history — the reason a DFA strategy over an NFA with assertions has no single answer to reproduce on a device."""
+    lim = VEC["lazy_dfa_look_known_limitation"]["limitation"]
+    assert (oracle.Regex(lim["pattern"]).dfa_search_at(lim["input"].encode(), 0) != -1) == lim["lazy_dfa"] != lim["stdlib"]
+    a, b = oracle.Regex(r"\bfoo\b"), oracle.Regex(r"\bfoo\b")
+    a.dfa_search_at(b"a ", 0)                                # the class of ' ' and 'a' (bytes below 'f') is first met, in the
+    b.dfa_search_at(b"aa", 0)                                # state behind a word byte, on a non-word byte ... or on a word byte
+    assert (a.dfa_search_at(b"a foo", 0), b.dfa_search_at(b"a foo", 0)) == (5, -1)
