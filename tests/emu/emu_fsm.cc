@@ -137,7 +137,7 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
   }
   if (stats) std::memcpy(stats, st, sizeof st);
   const int64_t n = static_cast<int64_t>(res.size());
-  if (out && n <= cap_vals) std::memcpy(out, res.data(), static_cast<size_t>(n) * sizeof(int64_t));
+  if (out && n > 0 && n <= cap_vals) std::memcpy(out, res.data(), static_cast<size_t>(n) * sizeof(int64_t));
   return n;
 }
 

@@ -775,3 +775,12 @@ def test_synth_corpus_is_frozen():
 
 
 SYNTH_CRC = {1: 1650641072, 2: 4080580921, 3: 4062772577, 4: 2183380067, 5: 32623048}
+
+
+def test_host_side_under_address_and_ub_sanitizers():
+    """tests/emu/san_driver: front-end, program builder, transducer builder and the transducer twin compiled with
+    g++ -fsanitize=address,undefined, fed with the golden patterns, random (also malformed) patterns and damaged NFAs."""
+    import subprocess, sys as _sys
+    r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "cpu_sanitize.py"), "600", "11"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"no sanitizer report" in r.stdout, r.stdout.decode()[-3000:]
