@@ -1,6 +1,7 @@
 // See program.h.
 #include "program.h"
 #include "fsm.h"
+#include "lookdfa.h"
 #include "../device/bt.hpp"
 
 #include <algorithm>
@@ -634,6 +635,33 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       // longer match (kFlagBothRestart): CXG_E_INPUT, the caller keeps its CPU loop for that haystack.
       if (strategy == CXG_USE_BOTH) h.flags |= cxgdev::kFlagBothRestart;
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+      bool look = false;
+      for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;
+      if (look) {
+        // Assertions inside a lazy-DFA strategy: the reference answers with its look-aware lazy DFA, which is leftmost-first
+        // only for some programs and history-free only when its byte classes are pure in word-ness / newline-ness
+        // (lookdfa.cc).  Those that pass the proof are the pattern's transducer, like a UseNFA program; UseBoth keeps its
+        // 100-byte restart span.  UseDFA without the reverse DFA (non-greedy quantifiers) first asks DFA.IsMatchAt
+        // (find_indices.go:396-403), a third search loop with its own boundary shortcuts: not modelled, refused.
+        if (strategy == CXG_USE_DFA && !(flags & CXG_FLAG_HAS_REVERSE_DFA))
+          throw BuildError{CXG_E_UNSUPPORTED, "assertions in a UseDFA program without reverse DFA (the reference's IsMatchAt loop is not modelled)"};
+        HostNfa rn = reverseOf(nfa);
+        cxg_nfa rvw = rn.view();
+        refuseLookDfaQuirks(nfa, strategy == CXG_USE_DFA ? &rvw : nullptr);
+        Dfa none;
+        if (!buildFsmImage(nfa, none, strategy == CXG_USE_BOTH ? cxgdev::kBothRestartSpan : 0u, p->fsmBlob, p->fsmWhyNot, &rvw)) {
+          p->fsmBlob.clear();
+          throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot};
+        }
+        h.kind = cxgdev::kKindFsmOnly;
+        h.info_off = static_cast<uint32_t>(blob.size());
+        blob.insert(blob.end(), info, info + 256);
+        h.total_bytes = static_cast<uint32_t>(blob.size());
+        std::memcpy(blob.data(), &h, sizeof h);
+        p->blob.swap(blob);
+        p->supported = true;
+        return;
+      }
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
       if (strategy == CXG_USE_BOTH || (flags & CXG_FLAG_HAS_REVERSE_DFA)) refuseOrderConflict(nfa, {nfa.start_unanchored});

@@ -112,9 +112,10 @@ def test_match_created_under_a_pending_match_that_later_grows(oracle):
 
 def test_word_boundary_scope(oracle):
     """Served: UseNFA programs (small patterns; PikeVM semantics in the reference).  Refused at build time: line / text
-    anchors, nullable patterns, and the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)."""
-    for pat, frag in ((r"^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"(?m)^", "nullable"), (r"\b(GET|POST|PUT)\b", "look-around"),
-                      (r"\b[a-f0-9]{8}\b", "look-around"), (r"(?m)^foo|barr", "some alternatives only"), (r"(?m)\d+$", "look-around")):
+    anchors, nullable patterns, and those of the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)
+    for which that DFA's answer depends on cache history or is not leftmost-first (host/lookdfa.cc; the served ones are below)."""
+    for pat, frag in ((r"^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"(?m)^", "nullable"), (r"\b(GET|POST|PUT)\b", "mixes word and non-word"),
+                      (r"\b[a-f0-9]{8}\b", "mixes word and non-word"), (r"(?m)^foo|barr", "some alternatives only"), (r"(?m)\d+$", "look-around")):
         rx = cx.compile(pat)
         assert not rx.supported and frag in rx.why_unsupported, (pat, rx.why_unsupported)
     img = cx.compile(r"\berror\b").fsm_image()
@@ -126,3 +127,50 @@ def test_transducer_fuzz_smoke():
     import cpu_fuzz_fsm
     assert cpu_fuzz_fsm.main(120, 20260927) == 0
     assert cpu_fuzz_fsm.main(250, 20260928, look=True) == 0
+
+
+# ---- look-around inside the reference's lazy-DFA strategies (host/lookdfa.cc): served only when the build-time proof holds
+LOOK_DFA_OK = [(r"\b\w+\s+\w+\s+\w+\b", "UseBoth"), (r"\buser=\w+ ip=\w+ status=\w+\b", "UseDFA"), (r"\b\w+=\w+;\w+=\w+\b", "UseBoth"),
+               (r"\b\w+@\w+\.\w+\.com\b", "UseBoth"), (r"\b\w+ing\b \b\w+ed\b \b\w+s\b", "UseBoth"), (r"\w+\b \w+\b \w+\b \w+\b!", "UseBoth")]
+LOOK_DFA_REFUSED = [(r"\b(DEBUG|INFO|WARN|ERROR)\b", "mixes word and non-word"),          # class of ' ' and '1': cache history decides
+                    (r"(?m)^\w+: \w+ \w+ \w+$", "'\\n' shares a class"),
+                    (r"\b(GET|POST|PUT|DELETE|PATCH) /[a-z/]+", "mixes word and non-word"),
+                    (r"\b[\w.]+@[\w.]+\.(com|org|net)\b", "does not answer leftmost-first"),  # early return at the first possible end
+                    (r"\bfoo\w+bar\w+baz\w+qux\b", "conflates priority orders")]
+
+
+@pytest.mark.parametrize("pat,strategy", LOOK_DFA_OK)
+def test_look_programs_of_lazy_dfa_strategies(oracle, pat, strategy):
+    """The oracle answers with the reference's look-aware lazy DFA (restated); ONE engine is reused over the haystacks, the
+    proof claims independence of cache history too.  The twin runs the transducer the device runs."""
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == strategy and o.strategy_restated and rx.supported, (pat, rx.strategy, o.strategy, rx.why_unsupported)
+    img = rx.fsm_image()
+    assert img is not None
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"abingedsuser=ip status_09 .=:@;com\n  ", dtype=np.uint8)
+    hays = [alphabet[rng.integers(0, len(alphabet), size=k)] for k in (0, 1, 9, 70, 300, 2000)]
+    hays += [np.frombuffer(b"user=bob ip=10 status=ok  a=b;c=d  me@ex.am.com going moved bars  a b c d! xuser=a ip=b status=c_ " * 7, dtype=np.uint8),
+             np.frombuffer(b" " * 140 + b"a=b;c=d user=a ip=b status=c one two three" + b"." * 120 + b"q r s t!", dtype=np.uint8)]
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        for tile, chunk in ((3840, 32), (64, 8), (256, 16)):
+            got = emu.find_all_fsm(img, hay, tile, chunk)
+            if isinstance(got, int) and got in (-18, -32): got = emu.find_all_fsm(img, hay, tile, chunk, dense=1)
+            if isinstance(got, int):                      # a budget of the toy geometries (match pending across too many tiny tiles)
+                assert tile != 3840, (pat, got)
+                continue
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, tile, chunk, got[:5].tolist(), exp[:5].tolist())
+
+
+@pytest.mark.parametrize("pat,why", LOOK_DFA_REFUSED)
+def test_look_programs_the_reference_answers_differently_are_refused(oracle, pat, why):
+    rx = cx.compile(pat)
+    assert rx.strategy == oracle.Regex(pat).strategy and rx.strategy in ("UseDFA", "UseBoth")
+    assert not rx.supported and why in rx.why_unsupported, (pat, rx.why_unsupported)
+
+
+def test_look_dfa_fuzz_smoke():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import cpu_fuzz_lookdfa
+    assert cpu_fuzz_lookdfa.main(120, 4242) == 0

@@ -150,6 +150,31 @@ def test_word_boundary_programs(oracle, pat):
     assert t.kernel == K_FSM, (pat, t.kernel)
 
 
+# ---- assertions inside the reference's lazy-DFA strategies: served when host/lookdfa.cc proves that the reference's look-aware
+# lazy DFA answers leftmost-first, history-free; the oracle answers with that DFA, restated.
+LOOK_DFA = [(r"\b\w+\s+\w+\s+\w+\b", "UseBoth"), (r"\buser=\w+ ip=\w+ status=\w+\b", "UseDFA"), (r"\b\w+=\w+;\w+=\w+\b", "UseBoth"), (r"\w+\b \w+\b \w+\b \w+\b!", "UseBoth")]
+
+
+@pytest.mark.parametrize("pat,strategy", LOOK_DFA)
+def test_look_programs_of_lazy_dfa_strategies(oracle, pat, strategy):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == strategy and o.strategy_restated and rx.supported, (pat, rx.strategy, o.strategy, rx.why_unsupported)
+    line = b"user=bob ip=10 status=ok  a=b;c=d  going moved bars  a b c d! xuser=a ip=b status=c_ k=v;w=x\n"
+    hays = [generate_test_input(), b"", line * 4000, b"a b c", b"a=b;c=d", b" " * 150 + line + b"." * 130 + b"q r s t!", b"aaa" + b" " * 120 + b"bbb ccc " + line]
+    for hay in hays:
+        exp = o.find_all_index(hay)                                   # ONE oracle engine over all haystacks: no cache-history effect
+        plain = o.find_all_submatch_index(hay)[:, :2]                 # (PikeVM spans: plain leftmost-first)
+        if strategy == "UseBoth" and len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100:
+            with pytest.raises(cx.CoregexError): rx.find_all_index(hay)   # the 100-byte restart span: CXG_E_INPUT, the caller keeps its CPU loop
+            continue
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
+        assert rx.count(hay) == len(exp)
+    rows, t = _device_rows(rx, hays[2])
+    assert np.array_equal(rows, o.find_all_index(hays[2])) and t.kernel == K_FSM, (pat, t.kernel)
+    assert not cx.compile(r"\b(DEBUG|INFO|WARN|ERROR)\b").supported          # byte class mixes word and non-word bytes: history-dependent reference
+
+
 def test_word_boundary_edges(oracle):
     """The assertion reads the byte on either side of a position: word / non-word neighbours across chunk (32 / 64 B),
     wave-tile (3840 B), window (4032 B) and group (120 KiB) edges, at the haystack's first and last byte, and for inputs that
