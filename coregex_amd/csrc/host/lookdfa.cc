@@ -145,7 +145,8 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
   Machine m(n);
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;       // ordered list + flags word
-  std::map<std::vector<uint32_t>, int32_t> filedAs;   // sorted set + flags word (state.go:329-373)
+  std::map<std::vector<uint32_t>, std::vector<int32_t>> filedAs;   // sorted set + flags word (state.go:329-373) -> orders filed there
+  bool anyConflict = false;
   std::vector<std::vector<uint32_t>> tuples;
   auto intern = [&](std::vector<uint32_t>&& list, uint32_t flagsWord) -> int32_t {
     std::vector<uint32_t> key(list);
@@ -156,8 +157,9 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
     if (it != ids.end()) return it->second;
     const int32_t id = static_cast<int32_t>(tuples.size());
     if (tuples.size() >= kMaxStates) throw Refuse{"look-aware reference DFA exceeds the build-time exploration budget"};
-    auto f = filedAs.emplace(std::move(key), id);
-    if (!f.second) throw Refuse{"reference DFA cache conflates priority orders of one NFA set (result depends on cache history)"};
+    std::vector<int32_t>& filed = filedAs[key];
+    if (!filed.empty()) anyConflict = true;
+    filed.push_back(id);
     ids.emplace(list, id);
     tuples.push_back(std::move(list));
     return id;
@@ -214,6 +216,33 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
     a.flag.push_back(std::move(fl));
   }
   a.computeLive();
+  if (anyConflict) {
+    // The cache keeps whichever order of a set it determinized first (state.go:329-373).  Harmless exactly when the orders filed
+    // under one key behave alike — same flags for every symbol sequence: Moore partition of the un-conflated machine (states
+    // that can never flag again count as dead), as program.cc priorityOrderConflict does for programs without assertions.
+    const size_t ns = a.next.size();
+    std::vector<uint32_t> cls(ns);
+    {
+      std::map<std::vector<uint8_t>, uint32_t> byFlags;
+      for (size_t i = 0; i < ns; i++) cls[i] = byFlags.emplace(a.flag[i], static_cast<uint32_t>(byFlags.size())).first->second;
+    }
+    for (size_t nclasses = 0;;) {
+      std::map<std::vector<uint32_t>, uint32_t> sig;
+      std::vector<uint32_t> ncls(ns);
+      for (size_t i = 0; i < ns; i++) {
+        std::vector<uint32_t> k{cls[i]};
+        for (int32_t t : a.next[i]) k.push_back(t < 0 || !a.live[static_cast<size_t>(t)] ? 0xFFFFFFFFu : cls[static_cast<size_t>(t)]);
+        ncls[i] = sig.emplace(std::move(k), static_cast<uint32_t>(sig.size())).first->second;
+      }
+      cls.swap(ncls);
+      if (sig.size() == nclasses) break;
+      nclasses = sig.size();
+    }
+    for (const auto& kv : filedAs)
+      for (int32_t id : kv.second)
+        if (cls[static_cast<size_t>(id)] != cls[static_cast<size_t>(kv.second[0])])
+          throw Refuse{"reference DFA cache conflates priority orders of one NFA set (result depends on cache history)"};
+  }
   return a;
 }
 
@@ -302,6 +331,54 @@ void compareForward(const Automaton& r, const Automaton& t, size_t nsym) {
       if (tn >= 0 && !t.live[static_cast<size_t>(tn)]) tn = -1;
       if ((rn < 0) != (tn < 0)) throw Refuse{"the reference's look-aware lazy DFA does not answer leftmost-first for this program (it stops or goes on where leftmost-first does not)"};
       if (rn >= 0 && seen.emplace(rn, tn).second) todo.emplace_back(rn, tn);
+    }
+  }
+}
+
+// UseBoth takes the DFA's match end only to choose where its PikeVM starts — at the search start, or 100 bytes in front of that
+// end when it lies further away (find_indices.go:425-431) — and the PikeVM is leftmost-first.  With no match longer than the
+// span (checked per haystack by the kernel) the answer is the leftmost-first one whenever the DFA's end is NOT BEHIND the
+// leftmost-first end; too early, or none at all, only moves the PikeVM's start further left.  So only this can hurt: R raises a
+// flag at a position where T does not, T has raised one before, and the input can go on (or end) without T raising another.
+void compareForwardNoLaterEnd(const Automaton& r, const Automaton& t, size_t nsym) {
+  const size_t nt = t.next.size();
+  std::vector<uint8_t> canAvoid(nt, 0);   // some continuation, possibly empty, on which T raises no further flag (end of input included)
+  for (size_t i = 0; i < nt; i++) canAvoid[i] = !t.flag[i][nsym];
+  for (bool changed = true; changed;) {
+    changed = false;
+    for (size_t i = 0; i < nt; i++) {
+      if (canAvoid[i]) continue;
+      for (size_t s = 0; s < nsym && !canAvoid[i]; s++) {
+        if (t.flag[i][s]) continue;
+        const int32_t tn = t.next[i][s];
+        if (tn < 0 || canAvoid[static_cast<size_t>(tn)]) { canAvoid[i] = 1; changed = true; }
+      }
+    }
+  }
+  std::set<std::array<int32_t, 3>> seen;
+  std::vector<std::array<int32_t, 3>> todo;
+  for (int k = 0; k < 4; k++) {
+    for (size_t s = 0; s <= nsym; s++)
+      if (t.flag[static_cast<size_t>(t.start[k])][s] || r.flag[static_cast<size_t>(r.start[k])][s]) throw Refuse{"pattern matches the empty string at some position (nullable)"};
+    const std::array<int32_t, 3> st{r.start[k], t.start[k], 0};
+    if (seen.insert(st).second) todo.push_back(st);
+  }
+  const char* why = "the reference's look-aware lazy DFA can report a match end behind the leftmost-first one for this program: its PikeVM restart (UseBoth) would skip the leftmost match";
+  while (!todo.empty()) {
+    const auto [rs, ts, flagged] = todo.back();
+    todo.pop_back();
+    for (size_t s = 0; s <= nsym; s++) {
+      const bool rf = r.flag[static_cast<size_t>(rs)][s] != 0;
+      const bool tf = ts >= 0 && t.flag[static_cast<size_t>(ts)][s] != 0;
+      const int32_t tn = (s < nsym && ts >= 0) ? t.next[static_cast<size_t>(ts)][s] : -1;
+      if (rf && !tf && flagged && (s == nsym || tn < 0 || canAvoid[static_cast<size_t>(tn)])) throw Refuse{why};
+      if (s == nsym) continue;
+      const int32_t rn = r.next[static_cast<size_t>(rs)][s];
+      if (rn < 0 || !r.live[static_cast<size_t>(rn)]) continue;                // R raises nothing further
+      const int32_t nowFlagged = (flagged || tf) ? 1 : 0;
+      if (tn < 0 && !nowFlagged) continue;                                        // T never matches on this input: any R end is harmless
+      const std::array<int32_t, 3> nx{rn, tn, nowFlagged};
+      if (seen.insert(nx).second) todo.push_back(nx);
     }
   }
 }
@@ -411,8 +488,12 @@ void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
   try {
     const Automaton r = buildReference(nfa, reps, hasWordB, hasEndLine);
     const Automaton t = buildLeftmostFirst(nfa, reps);
-    compareForward(r, t, reps.size());
-    if (reverse) compareReverse(*reverse, reps);
+    if (reverse) {
+      compareForward(r, t, reps.size());
+      compareReverse(*reverse, reps);
+    } else {
+      compareForwardNoLaterEnd(r, t, reps.size());
+    }
   } catch (const Refuse& e) {
     throw BuildError{CXG_E_UNSUPPORTED, e.why};
   }

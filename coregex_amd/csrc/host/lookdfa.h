@@ -5,9 +5,11 @@
 
 namespace cxg {
 
-// Returns when the reference's look-aware lazy DFA (and, with `reverse` = the reversed NFA of program.cc reverseOf, its
-// assertion-blind reverse DFA) provably gives the leftmost-first answer on every haystack and independent of cache history;
-// throws BuildError(CXG_E_UNSUPPORTED) with the reason otherwise.  Non-nullable patterns only (also checked here).
+// `reverse` = the reversed NFA of program.cc reverseOf (UseDFA: forward DFA for the end, reverse DFA for the start): returns when
+// the reference's look-aware lazy DFA and its assertion-blind reverse DFA provably give the leftmost-first answer on every
+// haystack, independent of cache history.  `reverse` == nullptr (UseBoth: the DFA's end only places the PikeVM's start):
+// returns when that end is provably never behind the leftmost-first end.  Throws BuildError(CXG_E_UNSUPPORTED) with the reason
+// otherwise.  Non-nullable patterns only (also checked here).
 void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse);
 
 }  // namespace cxg

@@ -130,13 +130,14 @@ def test_transducer_fuzz_smoke():
 
 
 # ---- look-around inside the reference's lazy-DFA strategies (host/lookdfa.cc): served only when the build-time proof holds
-LOOK_DFA_OK = [(r"\b\w+\s+\w+\s+\w+\b", "UseBoth"), (r"\buser=\w+ ip=\w+ status=\w+\b", "UseDFA"), (r"\b\w+=\w+;\w+=\w+\b", "UseBoth"),
+LOOK_DFA_OK = [(r"\b[\w.]+@[\w.]+\.(com|org|net)\b", "UseBoth"), (r"\bfoo=\w+;bar=\w+\b", "UseDFA"), (r"\b\w+\s+\w+\s+\w+\b", "UseBoth"), (r"\buser=\w+ ip=\w+ status=\w+\b", "UseDFA"), (r"\b\w+=\w+;\w+=\w+\b", "UseBoth"),
                (r"\b\w+@\w+\.\w+\.com\b", "UseBoth"), (r"\b\w+ing\b \b\w+ed\b \b\w+s\b", "UseBoth"), (r"\w+\b \w+\b \w+\b \w+\b!", "UseBoth")]
 LOOK_DFA_REFUSED = [(r"\b(DEBUG|INFO|WARN|ERROR)\b", "mixes word and non-word"),          # class of ' ' and '1': cache history decides
                     (r"(?m)^\w+: \w+ \w+ \w+$", "'\\n' shares a class"),
                     (r"\b(GET|POST|PUT|DELETE|PATCH) /[a-z/]+", "mixes word and non-word"),
-                    (r"\b[\w.]+@[\w.]+\.(com|org|net)\b", "does not answer leftmost-first"),  # early return at the first possible end
-                    (r"\bfoo\w+bar\w+baz\w+qux\b", "conflates priority orders")]
+                    (r"\buser=\w+ host=\w+", "does not answer leftmost-first"),           # UseDFA: early return at the first possible end
+                    (r"(?m)(\w+)(?:\b|x)$(?:=\w+)?\n", "match end behind the leftmost-first one"),   # UseBoth: the PikeVM restart would skip a match
+                    (r"(?m)\Bbar(?:com|org)x(\w+)(\w+)\sbar", "would report an earlier match start")]   # UseDFA: the reverse DFA ignores \B
 
 
 @pytest.mark.parametrize("pat,strategy", LOOK_DFA_OK)
@@ -168,6 +169,16 @@ def test_look_programs_the_reference_answers_differently_are_refused(oracle, pat
     rx = cx.compile(pat)
     assert rx.strategy == oracle.Regex(pat).strategy and rx.strategy in ("UseDFA", "UseBoth")
     assert not rx.supported and why in rx.why_unsupported, (pat, rx.why_unsupported)
+
+
+def test_refused_look_program_really_differs_in_the_reference(oracle):
+    """`\\buser=\\w+ host=\\w+` is UseDFA; the restated look-aware lazy DFA returns at the first byte at which its state holds a match
+    state (checkWordBoundaryMatch, lazy.go:1262-1264, :1533-1560) — one byte into the greedy tail.  Leftmost-first takes it all."""
+    import re
+    pat, hay = r"\buser=\w+ host=\w+", b"user=ab host=cde f"
+    assert oracle.Regex(pat).find_all_index(hay).tolist() == [[0, 14]]
+    assert [list(m.span()) for m in re.finditer(pat.encode(), hay)] == [[0, 16]]
+    assert not cx.compile(pat).supported
 
 
 def test_look_dfa_fuzz_smoke():
