@@ -4,6 +4,7 @@ import sys, os, subprocess, json, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import cpu_fuzz_fsm as F
+import cpu_fuzz_lookdfa as L
 
 def main(n=3000, seed=1):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "san"])
@@ -18,7 +19,7 @@ def main(n=3000, seed=1):
         elif isinstance(x, list):
             for v in x: walk(v)
     walk(vec)
-    atoms = F.ATOMS + F.LOOK_ATOMS + ["(", ")", "[", "]", "{2,", "}", "|", "*", "+", "?", "\\", "(?i)", "(?m)", "(?s)", ".", "[^a]", r"\x41", r"\pL", "{1000}", "(?:", "(?P<n>a)", "[a-", "\\Q.\\E", "a{,3}"]
+    atoms = F.ATOMS + F.LOOK_ATOMS + L.ATOMS * 2 + ["(", ")", "[", "]", "{2,", "}", "|", "*", "+", "?", "\\", "(?i)", "(?m)", "(?s)", ".", "[^a]", r"\x41", r"\pL", "{1000}", "(?:", "(?P<n>a)", "[a-", "\\Q.\\E", "a{,3}"]
     while len(pats) < n:
         pats.add("".join(rng.choice(atoms) for _ in range(rng.randint(1, 6))))
     data = "\n".join(p for p in pats if "\n" not in p).encode()
