@@ -26,6 +26,8 @@ NFA_PATTERNS = [
     r"(GET|POST|PUT) /([a-z/]+)", r"([a-z]+)=(\d+)", r"warning", r"\d{4}-\d{2}-\d{2}", r"(\d+)\.(\d+)\.(\d+)\.(\d+)",
     # look-around: nfa.StateLook travels as kind 7 with lo = nfa.Look; UseNFA programs (and UseTeddy behind (?m)^) run on the transducer
     r"\berror\b", r"\b\d+\b", r"(?m)^\d+", r"(?m)[a-z]+$", r"(?m)^(GET|POST|PUT|DELETE|PATCH)", r"\Berror",
+    # ... and UseDFA / UseBoth programs with assertions that pass the build-time proof of host/lookdfa.cc (the flags say whether e.reverseDFA exists)
+    r"\buser=\w+ ip=\w+ status=\w+\b", r"\b\w+=\w+;\w+=\w+\b",
 ]
 
 
