@@ -124,6 +124,7 @@ struct Refuse { std::string why; };
 struct Automaton {
   std::vector<std::vector<int32_t>> next;   // [state][symbol index]; the kSymEnd column is not stored
   std::vector<std::vector<uint8_t>> flag;   // [state][symbol index], last column = kSymEnd
+  std::vector<std::vector<uint8_t>> early;  // R only: the flag is searchAt's early return (decided on the byte itself, never cached)
   std::vector<uint8_t> live;                // some symbol sequence from here raises a flag
   int32_t start[4] = {-1, -1, -1, -1};      // by the byte behind the search start: non-word, word, '\n', none (text start)
   void computeLive() {
@@ -141,7 +142,7 @@ struct Automaton {
 enum StartKind { kAfterNonWord = 0, kAfterWord = 1, kAfterNewline = 2, kAtTextStart = 3 };
 
 // R: the reference's lazy DFA + searchAt, as a finite machine (classes are kind-pure here, so a representative decides).
-Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool hasWordB, bool hasEndLine) {
+Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, const std::vector<int>& classOf, bool hasWordB, bool hasEndLine) {
   Machine m(n);
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;       // ordered list + flags word
@@ -180,13 +181,13 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
     const size_t cnt = src.size() - 1;
     const bool fromWord = src[cnt] & 1u, tagged = src[cnt] & 2u;
     std::vector<int32_t> nx(reps.size(), -1);
-    std::vector<uint8_t> fl(reps.size() + 1, 0);
+    std::vector<uint8_t> fl(reps.size() + 1, 0), er(reps.size(), 0);
     for (size_t ri = 0; ri < reps.size(); ri++) {
       const int b = reps[ri];
       // checkWordBoundaryMatch (lazy.go:1533-1560): the search returns here
       if (hasWordB && !tagged) {
         const std::vector<uint32_t> atB = resolveWordBoundaries(n, src, cnt, fromWord != isWord(b));
-        if (m.holdsMatch(atB, atB.size())) { fl[ri] = 1; continue; }
+        if (m.holdsMatch(atB, atB.size())) { fl[ri] = 1; er[ri] = 1; continue; }
       }
       // determinize (lazy.go:1336-1446)
       std::vector<uint32_t> curSet(src.begin(), src.begin() + static_cast<long>(cnt));
@@ -214,12 +215,18 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
     }
     a.next.push_back(std::move(nx));
     a.flag.push_back(std::move(fl));
+    a.early.push_back(std::move(er));
   }
   a.computeLive();
-  if (anyConflict) {
-    // The cache keeps whichever order of a set it determinized first (state.go:329-373).  Harmless exactly when the orders filed
-    // under one key behave alike — same flags for every symbol sequence: Moore partition of the un-conflated machine (states
-    // that can never flag again count as dead), as program.cc priorityOrderConflict does for programs without assertions.
+  {
+    // What the cache can do to this machine.  (1) It keeps whichever ORDER of a set it determinized first (state.go:329-373).
+    // (2) It keeps one successor per byte CLASS (lazy.go:1341,1397) although the successor depends on the byte — is it a word
+    // byte, is it '\n' — and the classes are not refined by that: the byte that reached determinize first decides for its
+    // class.  (The early return is decided on the byte itself before the lookup, so bytes that return early never fill or read
+    // the entry.)  Both are harmless exactly when the alternatives behave alike — same flags on every symbol sequence: Moore
+    // partition of the exact, un-conflated machine built above (states that can never flag again count as dead), as
+    // program.cc priorityOrderConflict does for programs without assertions.
+    (void)anyConflict;
     const size_t ns = a.next.size();
     std::vector<uint32_t> cls(ns);
     {
@@ -242,6 +249,19 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, bool ha
       for (int32_t id : kv.second)
         if (cls[static_cast<size_t>(id)] != cls[static_cast<size_t>(kv.second[0])])
           throw Refuse{"reference DFA cache conflates priority orders of one NFA set (result depends on cache history)"};
+    auto target = [&](size_t st, size_t sym) -> uint64_t {
+      const int32_t t = a.next[st][sym];
+      return (static_cast<uint64_t>(a.flag[st][sym]) << 32) | (t < 0 || !a.live[static_cast<size_t>(t)] ? 0xFFFFFFFFu : cls[static_cast<size_t>(t)]);
+    };
+    for (size_t st = 0; st < ns; st++) {
+      if (!a.live[st]) continue;
+      for (size_t i = 0; i < reps.size(); i++) {
+        if (a.early[st][i]) continue;
+        for (size_t j = i + 1; j < reps.size() && classOf[j] == classOf[i]; j++)
+          if (!a.early[st][j] && target(st, i) != target(st, j))
+            throw Refuse{"the reference caches lazy-DFA transitions per byte class, and bytes of one class (word / non-word / newline) lead to different states in this program: its answer depends on cache history"};
+      }
+    }
   }
   return a;
 }
@@ -472,21 +492,25 @@ void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
     if (s.kind == CXG_NFA_BYTE_RANGE) markRange(s.lo, s.hi);
     else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) markRange(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
   }
-  std::vector<int> reps;
+  // Symbols: one representative byte per (reference class, kind) — kinds the assertions of this pattern can tell apart.
+  std::vector<int> reps, classOf;
+  int nclass = 0;
   for (int b = 0, lo = 0; b < 256; b++) {
     if (b == 255 || boundary[b]) {
+      bool seen[2][2] = {{false, false}, {false, false}};
       for (int x = lo; x <= b; x++) {
-        if (hasWordB && isWord(x) != isWord(lo))
-          throw BuildError{CXG_E_UNSUPPORTED, "the reference caches lazy-DFA transitions per byte class and a class of this pattern mixes word and non-word bytes: its answer depends on cache history"};
-        if (hasLine && (x == '\n') != (lo == '\n'))
-          throw BuildError{CXG_E_UNSUPPORTED, "the reference caches lazy-DFA transitions per byte class and '\\n' shares a class with other bytes: its answer depends on cache history"};
+        const int w = hasWordB && isWord(x), nl = hasLine && x == '\n';
+        if (seen[w][nl]) continue;
+        seen[w][nl] = true;
+        reps.push_back(x);
+        classOf.push_back(nclass);
       }
-      reps.push_back(lo);
+      nclass++;
       lo = b + 1;
     }
   }
   try {
-    const Automaton r = buildReference(nfa, reps, hasWordB, hasEndLine);
+    const Automaton r = buildReference(nfa, reps, classOf, hasWordB, hasEndLine);
     const Automaton t = buildLeftmostFirst(nfa, reps);
     if (reverse) {
       compareForward(r, t, reps.size());

@@ -47,8 +47,15 @@ def main(n=400, seed=1):
             parts = [words[int(rng.integers(0, len(words)))] if rng.random() < 0.6 else bytes(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(1, 4)))]) for _ in range(k // 3 + 1)]
             hays.append(np.frombuffer(b"".join(parts), dtype=np.uint8))
         hays.append(np.frombuffer(b" " * 150 + b"foo bar ab" + b"." * 130 + b"user_1 k=v; a@b.com\n" + b"-" * 101 + b"x", dtype=np.uint8))   # gaps > 100 bytes: the UseBoth restart point
-        for hay in hays:
+        o_rev = O.Regex(pat)                              # a second engine that meets the haystacks in the opposite order,
+        exp_rev = {}                                      # and a fresh one per haystack: three cache histories, one answer
+        for i in range(len(hays) - 1, -1, -1): exp_rev[i] = o_rev.find_all_index(hays[i])
+        for hi, hay in enumerate(hays):
             exp = o.find_all_index(hay)
+            fresh = O.Regex(pat).find_all_index(hay)
+            if not (np.array_equal(exp, fresh) and np.array_equal(exp, exp_rev[hi])):
+                print("HISTORY", repr(pat), rx.strategy, bytes(hay[:160]), exp[:6].tolist(), fresh[:6].tolist(), exp_rev[hi][:6].tolist())
+                return 1
             if rx.strategy == "UseBoth":
                 plain = O.Regex(pat).find_all_submatch_index(hay)[:, :2]
                 if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100: continue
