@@ -142,7 +142,7 @@ struct Automaton {
 enum StartKind { kAfterNonWord = 0, kAfterWord = 1, kAfterNewline = 2, kAtTextStart = 3 };
 
 // R: the reference's lazy DFA + searchAt, as a finite machine (classes are kind-pure here, so a representative decides).
-Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, const std::vector<int>& classOf, bool hasWordB, bool hasEndLine) {
+Automaton buildReference(const cxg_nfa& n, uint32_t startState, const std::vector<int>& reps, const std::vector<int>& classOf, bool hasWordB, bool hasEndLine) {
   Machine m(n);
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;       // ordered list + flags word
@@ -169,7 +169,7 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, const s
   for (int k = 0; k < 4; k++) {
     std::vector<uint32_t> set;
     m.begin();
-    m.into(set, n.start_unanchored, [&](uint8_t l) { return (have[k] >> l) & 1u; });
+    m.into(set, startState, [&](uint8_t l) { return (have[k] >> l) & 1u; });
     // the four kinds may share a state (same set, same from-word flag): GetOrInsert, lazy.go:1592-1601
     std::vector<uint32_t> probe(set);
     probe.push_back(0x80000000u | (k == kAfterWord ? 1u : 0u));
@@ -269,7 +269,7 @@ Automaton buildReference(const cxg_nfa& n, const std::vector<int>& reps, const s
 // T: leftmost-first.  A state is the ordered thread list at a position (assertions not yet passed) plus the kind of the byte
 // behind the position; the symbol ahead completes the context, then every assertion is decided, a match state in the
 // expanded list ends a match in front of the symbol and cuts the lower-priority threads, and the rest moves on.
-Automaton buildLeftmostFirst(const cxg_nfa& n, const std::vector<int>& reps) {
+Automaton buildLeftmostFirst(const cxg_nfa& n, uint32_t startState, const std::vector<int>& reps) {
   Machine m(n);
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;
@@ -288,7 +288,7 @@ Automaton buildLeftmostFirst(const cxg_nfa& n, const std::vector<int>& reps) {
   for (int k = 0; k < 4; k++) {
     std::vector<uint32_t> set;
     m.begin();
-    m.into(set, n.start_unanchored, none);
+    m.into(set, startState, none);
     a.start[k] = intern(std::move(set), static_cast<uint32_t>(k));
   }
   for (size_t cur = 0; cur < tuples.size(); cur++) {
@@ -474,15 +474,20 @@ void compareReverse(const cxg_nfa& rv, const std::vector<int>& reps) {
 
 }  // namespace
 
-void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
-  bool hasWordB = false, hasLine = false, hasEndLine = false;
+namespace {
+
+struct Symbols { std::vector<int> reps, classOf; bool hasWordB = false, hasLine = false, hasEndLine = false; };
+
+// One representative byte per (byte class of the reference, kind the pattern's assertions can tell apart).
+Symbols symbolsOf(const cxg_nfa& nfa) {
+  Symbols sy;
   for (uint32_t i = 0; i < nfa.n_states; i++) {
     const cxg_nfa_state& s = nfa.states[i];
     if (s.kind != CXG_NFA_LOOK) continue;
     if (s.lo == kLkStartText || s.lo == kLkEndText) throw BuildError{CXG_E_UNSUPPORTED, "text anchor (\\A, \\z, ^ or $ without (?m)) in a lazy-DFA program"};
-    if (s.lo == kLkWordB || s.lo == kLkNoWordB) hasWordB = true;
-    if (s.lo == kLkStartLine || s.lo == kLkEndLine) hasLine = true;
-    if (s.lo == kLkEndLine) hasEndLine = true;
+    if (s.lo == kLkWordB || s.lo == kLkNoWordB) sy.hasWordB = true;
+    if (s.lo == kLkStartLine || s.lo == kLkEndLine) sy.hasLine = true;
+    if (s.lo == kLkEndLine) sy.hasEndLine = true;
   }
   // byte classes of the reference (nfa/alphabet.go:100-166): boundaries at the ends of the pattern's byte ranges only
   bool boundary[256] = {false};
@@ -492,31 +497,70 @@ void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
     if (s.kind == CXG_NFA_BYTE_RANGE) markRange(s.lo, s.hi);
     else if (s.kind == CXG_NFA_SPARSE) for (uint32_t k = 0; k < s.trans_len; k++) markRange(nfa.trans[s.trans_off + k].lo, nfa.trans[s.trans_off + k].hi);
   }
-  // Symbols: one representative byte per (reference class, kind) — kinds the assertions of this pattern can tell apart.
-  std::vector<int> reps, classOf;
   int nclass = 0;
   for (int b = 0, lo = 0; b < 256; b++) {
     if (b == 255 || boundary[b]) {
       bool seen[2][2] = {{false, false}, {false, false}};
       for (int x = lo; x <= b; x++) {
-        const int w = hasWordB && isWord(x), nl = hasLine && x == '\n';
+        const int w = sy.hasWordB && isWord(x), nl = sy.hasLine && x == '\n';
         if (seen[w][nl]) continue;
         seen[w][nl] = true;
-        reps.push_back(x);
-        classOf.push_back(nclass);
+        sy.reps.push_back(x);
+        sy.classOf.push_back(nclass);
       }
       nclass++;
       lo = b + 1;
     }
   }
+  return sy;
+}
+
+}  // namespace
+
+void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
+  const Symbols sy = symbolsOf(nfa);
   try {
-    const Automaton r = buildReference(nfa, reps, classOf, hasWordB, hasEndLine);
-    const Automaton t = buildLeftmostFirst(nfa, reps);
+    const Automaton r = buildReference(nfa, nfa.start_unanchored, sy.reps, sy.classOf, sy.hasWordB, sy.hasEndLine);
+    const Automaton t = buildLeftmostFirst(nfa, nfa.start_unanchored, sy.reps);
     if (reverse) {
-      compareForward(r, t, reps.size());
-      compareReverse(*reverse, reps);
+      compareForward(r, t, sy.reps.size());
+      compareReverse(*reverse, sy.reps);
     } else {
-      compareForwardNoLaterEnd(r, t, reps.size());
+      compareForwardNoLaterEnd(r, t, sy.reps.size());
+    }
+  } catch (const Refuse& e) {
+    throw BuildError{CXG_E_UNSUPPORTED, e.why};
+  }
+}
+
+// UseDigitPrefilter (find_indices.go:1050-1088): at each digit position in turn, SearchAtAnchored — the same lazy DFA from its
+// ANCHORED start state of the kind of the byte in front (lazy.go:219-324; its boundary check reads the flags determinize
+// stored, state.go:238-247, which equal checkWordBoundaryMatch for every state determinize made, and a start state of a
+// pattern that begins with a digit holds no match behind a boundary).  First position that succeeds wins: leftmost-first over
+// matches that begin with a digit, i.e. over all matches of such a pattern — provided the anchored machine is the leftmost-
+// first one, and provided the digit-run skip (digitRunSkipSafe, compile.go:176, find_indices.go:1079-1084) is sound: after a
+// failure at the first digit of a run every later digit of the run must fail too.  Sound when the first digit leads, from every
+// start kind, to ONE state that every further digit keeps: then a start inside the run walks through the same states at the
+// same bytes as the start at its head.
+void refuseLookDigitQuirks(const cxg_nfa& nfa, bool runSkip) {
+  const Symbols sy = symbolsOf(nfa);
+  try {
+    const Automaton r = buildReference(nfa, nfa.start_anchored, sy.reps, sy.classOf, sy.hasWordB, sy.hasEndLine);
+    const Automaton t = buildLeftmostFirst(nfa, nfa.start_anchored, sy.reps);
+    compareForward(r, t, sy.reps.size());
+    if (runSkip) {
+      int32_t s1 = -2;
+      for (size_t i = 0; i < sy.reps.size(); i++) {
+        if (sy.reps[i] < '0' || sy.reps[i] > '9') continue;
+        for (int k = 0; k < 4; k++) {
+          const int32_t to = t.next[static_cast<size_t>(t.start[k])][i];
+          if (s1 == -2) s1 = to;
+          if (to != s1 || to < 0) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
+        }
+      }
+      for (size_t i = 0; i < sy.reps.size() && s1 >= 0; i++)
+        if (sy.reps[i] >= '0' && sy.reps[i] <= '9' && t.next[static_cast<size_t>(s1)][i] != s1) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
+      if (s1 < 0) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
     }
   } catch (const Refuse& e) {
     throw BuildError{CXG_E_UNSUPPORTED, e.why};

@@ -12,4 +12,8 @@ namespace cxg {
 // otherwise.  Non-nullable patterns only (also checked here).
 void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse);
 
+// UseDigitPrefilter over an NFA with assertions: returns when SearchAtAnchored of the look-aware lazy DFA is provably the
+// leftmost-first anchored search, history-free, and (runSkip = CXG_FLAG_DIGIT_RUN_SKIP_SAFE) the digit-run skip is sound.
+void refuseLookDigitQuirks(const cxg_nfa& nfa, bool runSkip);
+
 }  // namespace cxg

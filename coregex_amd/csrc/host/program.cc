@@ -568,6 +568,31 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     Dfa prefixDfa;                                 //     the anchored DFA that extends an occurrence to the match end
     cxgdev::ChainAux chain;
     std::memset(&chain, 0, sizeof chain);
+    bool hasLook = false;
+    for (uint32_t i = 0; i < nfa.n_states; i++) hasLook = hasLook || nfa.states[i].kind == CXG_NFA_LOOK;
+    // A look-around program that passed its proof (lookdfa.cc) is the pattern's transducer and nothing else: no table-walking image.
+    auto finishFsmOnly = [&](uint32_t maxLen) {
+      HostNfa rn = reverseOf(nfa);
+      cxg_nfa rvw = rn.view();
+      Dfa none;
+      if (!buildFsmImage(nfa, none, maxLen, p->fsmBlob, p->fsmWhyNot, &rvw)) { p->fsmBlob.clear(); throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
+      h.kind = cxgdev::kKindFsmOnly;
+      h.info_off = static_cast<uint32_t>(blob.size());
+      blob.insert(blob.end(), info, info + 256);
+      h.total_bytes = static_cast<uint32_t>(blob.size());
+      std::memcpy(blob.data(), &h, sizeof h);
+      p->blob.swap(blob);
+      p->supported = true;
+    };
+    if (strategy == CXG_USE_DIGIT_PREFILTER && hasLook) {
+      // Assertions behind the leading digits (`\d+\.\d+\.\d+\.\d+\b`): the reference runs SearchAtAnchored of its look-aware lazy
+      // DFA at every digit (find_indices.go:1050-1088).  Served when that is provably the leftmost-first anchored search and the
+      // digit-run skip is sound (lookdfa.cc refuseLookDigitQuirks); then FindAll is plain leftmost-first: the transducer.
+      if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
+      refuseLookDigitQuirks(nfa, (flags & CXG_FLAG_DIGIT_RUN_SKIP_SAFE) != 0);
+      finishFsmOnly(0u);
+      return;
+    }
     if (strategy == CXG_USE_DIGIT_PREFILTER) {
       // findIndicesDigitPrefilterAtWithState: anchored DFA at each digit candidate
       p->fwd = determinize(nfa, nfa.start_anchored, true, kMaxDfaStates);
@@ -648,18 +673,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         HostNfa rn = reverseOf(nfa);
         cxg_nfa rvw = rn.view();
         refuseLookDfaQuirks(nfa, strategy == CXG_USE_DFA ? &rvw : nullptr);
-        Dfa none;
-        if (!buildFsmImage(nfa, none, strategy == CXG_USE_BOTH ? cxgdev::kBothRestartSpan : 0u, p->fsmBlob, p->fsmWhyNot, &rvw)) {
-          p->fsmBlob.clear();
-          throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot};
-        }
-        h.kind = cxgdev::kKindFsmOnly;
-        h.info_off = static_cast<uint32_t>(blob.size());
-        blob.insert(blob.end(), info, info + 256);
-        h.total_bytes = static_cast<uint32_t>(blob.size());
-        std::memcpy(blob.data(), &h, sizeof h);
-        p->blob.swap(blob);
-        p->supported = true;
+        finishFsmOnly(strategy == CXG_USE_BOTH ? cxgdev::kBothRestartSpan : 0u);
         return;
       }
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);

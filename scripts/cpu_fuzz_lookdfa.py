@@ -1,4 +1,4 @@
-"""CPU fuzz of host/lookdfa.cc: look-around programs of the reference's lazy-DFA strategies (UseDFA / UseBoth) that the build-time
+"""CPU fuzz of host/lookdfa.cc: look-around programs of the reference's lazy-DFA strategies (UseDFA / UseBoth / UseDigitPrefilter) that the build-time
 proof accepts must give, on the transducer's sequential twin, exactly what the oracle's restated look-aware lazy DFA gives — with
 ONE oracle engine per pattern reused over all haystacks (the proof also claims independence of cache history).
 python scripts/cpu_fuzz_lookdfa.py [n_patterns] [seed]"""
@@ -14,27 +14,31 @@ ATOMS = [r"\b", r"\b", r"\B", r"\w", r"\w+", r"\w+", r"\w*", r"\w?", r"[\w.]+", 
          r"\d+", "[a-z]+", "[A-Z]", r"(\w+)", r"(?:\w+ )+", r"(?:foo|bar)", r"(?:ab|\w)", r"\w{2}", r"\w{2,}", r"(?:\b|x)", r"(?:\w+\b)", r"\n", "^", "$", r"[^\n]", r"[^\n]+", r"\w+\n",
          r"(?:=\w+)?", r"(?:\.\w+)+", r"\w+?", r"(?:com|org)", r"\s", r"\s+", r"[ \t]+"]
 
+DIGIT_LEADS = [r"\d+", r"\d+", r"\d", r"\d{2}", r"[0-9]+", r"\d+\.", r"\d+\.\d+", r"[0-5]+", r"\d{2,}", r"\d+-"]
+
 def main(n=400, seed=1):
     rng = np.random.default_rng(seed)
-    alphabet = np.frombuffer(b"abfor xyERZ_09 .=:@-;\n\t  ", dtype=np.uint8)
-    words = [b"foo", b"bar", b"ab", b"err", b"x=y", b"a@b.com", b" ", b"  ", b"\n", b"foo bar", b"user_1", b"k=v;", b"ab.cd.org", b"9", b"_", b"-", b"x"]
-    seen, n_dfa, n_ok, n_cmp, why = set(), 0, 0, 0, {}
+    alphabet = np.frombuffer(b"abfor xyERZ_0912 .=:@-;\n\t  ", dtype=np.uint8)
+    words = [b"12", b"3.4", b"56-", b"007 ", b"foo", b"bar", b"ab", b"err", b"x=y", b"a@b.com", b" ", b"  ", b"\n", b"foo bar", b"user_1", b"k=v;", b"ab.cd.org", b"9", b"_", b"-", b"x"]
+    seen, n_dfa, n_ok, n_cmp, why, n_digit = set(), 0, 0, 0, {}, 0
     t0 = time.time()
     tries = 0
     while n_dfa < n and tries < n * 400:
         tries += 1
         pat = "".join(ATOMS[int(rng.integers(0, len(ATOMS)))] for _ in range(int(rng.integers(3, 9))))
+        if rng.random() < 0.25: pat = DIGIT_LEADS[int(rng.integers(0, len(DIGIT_LEADS)))] + pat      # digit-lead: UseDigitPrefilter
         if pat in seen or not any(t in pat for t in (r"\b", r"\B", "^", "$")): continue
         seen.add(pat)
         pat = "(?m)" + pat
         try: o = O.Regex(pat)
         except O.OracleError: continue
-        if o.strategy not in ("UseDFA", "UseBoth"): continue
+        if o.strategy not in ("UseDFA", "UseBoth", "UseDigitPrefilter"): continue
         try: rx = cx.compile(pat)
         except cx.CoregexError: continue
         if rx.strategy != o.strategy:
             print("STRATEGY", repr(pat), rx.strategy, o.strategy); return 1
         n_dfa += 1
+        n_digit += o.strategy == "UseDigitPrefilter"
         if not rx.supported:
             k = rx.why_unsupported[:60]; why[k] = why.get(k, 0) + 1
             continue
@@ -68,7 +72,7 @@ def main(n=400, seed=1):
                     np.save("/tmp/lookdfa_fail_hay.npy", hay)
                     print("MISMATCH", repr(pat), rx.strategy, tile, chunk, bytes(hay[:160]), got[:6].tolist(), exp[:6].tolist())
                     return 1
-    print(f"{n_dfa} look-around programs of UseDFA/UseBoth, {n_ok} accepted by the proof, {n_cmp} comparisons with the restated reference DFA clean, {time.time()-t0:.1f}s")
+    print(f"{n_dfa} look-around programs of UseDFA/UseBoth/UseDigitPrefilter ({n_digit} digit), {n_ok} accepted by the proof, {n_cmp} comparisons with the restated reference DFA clean, {time.time()-t0:.1f}s")
     for k, v in sorted(why.items(), key=lambda kv: -kv[1]): print(f"  refused {v:5d}: {k}")
     return 0
 

@@ -115,7 +115,7 @@ def test_word_boundary_scope(oracle):
     anchors, nullable patterns, and those of the larger patterns the reference gives to its look-aware lazy DFA (UseDFA / UseBoth)
     for which that DFA's answer depends on cache history or is not leftmost-first (host/lookdfa.cc; the served ones are below)."""
     for pat, frag in ((r"^error", "anchor"), (r"error$", "anchor"), (r"\b", "nullable"), (r"(?m)^", "nullable"), (r"\b(GET|POST|PUT)\b", "depends on cache history"),
-                      (r"\b[a-f0-9]{8}\b", "depends on cache history"), (r"(?m)^foo|barr", "some alternatives only"), (r"(?m)\d+$", "look-around")):
+                      (r"\b[a-f0-9]{8}\b", "depends on cache history"), (r"(?m)^foo|barr", "some alternatives only"), (r"(?m)\d+$", "depends on cache history")):
         rx = cx.compile(pat)
         assert not rx.supported and frag in rx.why_unsupported, (pat, rx.why_unsupported)
     img = cx.compile(r"\berror\b").fsm_image()
@@ -130,7 +130,8 @@ def test_transducer_fuzz_smoke():
 
 
 # ---- look-around inside the reference's lazy-DFA strategies (host/lookdfa.cc): served only when the build-time proof holds
-LOOK_DFA_OK = [(r"timeout=\d+\b ms elapsed", "UseDFA"), (r"(GET|POST|PUT|DELETE)\b /[a-z/]+ HTTP", "UseDFA"), (r"[a-z]+=\d+\b; [a-z]+=\d+\b", "UseBoth"),   # classes that mix word and non-word bytes, harmlessly
+LOOK_DFA_OK = [(r"\d+\.\d+\.\d+\.\d+\b", "UseDigitPrefilter"), (r"\d{4}-\d{2}-\d{2}\b", "UseDigitPrefilter"), (r"\d+\b ms", "UseDigitPrefilter"),   # SearchAtAnchored at each digit
+               (r"timeout=\d+\b ms elapsed", "UseDFA"), (r"(GET|POST|PUT|DELETE)\b /[a-z/]+ HTTP", "UseDFA"), (r"[a-z]+=\d+\b; [a-z]+=\d+\b", "UseBoth"),   # classes that mix word and non-word bytes, harmlessly
                (r"\b[\w.]+@[\w.]+\.(com|org|net)\b", "UseBoth"), (r"\bfoo=\w+;bar=\w+\b", "UseDFA"), (r"\b\w+\s+\w+\s+\w+\b", "UseBoth"), (r"\buser=\w+ ip=\w+ status=\w+\b", "UseDFA"), (r"\b\w+=\w+;\w+=\w+\b", "UseBoth"),
                (r"\b\w+@\w+\.\w+\.com\b", "UseBoth"), (r"\b\w+ing\b \b\w+ed\b \b\w+s\b", "UseBoth"), (r"\w+\b \w+\b \w+\b \w+\b!", "UseBoth")]
 LOOK_DFA_REFUSED = [(r"\b(DEBUG|INFO|WARN|ERROR)\b", "depends on cache history"),          # class of ' ' and '1': cache history decides
@@ -138,7 +139,8 @@ LOOK_DFA_REFUSED = [(r"\b(DEBUG|INFO|WARN|ERROR)\b", "depends on cache history")
                     (r"\b(GET|POST|PUT|DELETE|PATCH) /[a-z/]+", "depends on cache history"),
                     (r"\buser=\w+ host=\w+", "does not answer leftmost-first"),           # UseDFA: early return at the first possible end
                     (r"(?m)(\w+)(?:\b|x)$(?:=\w+)?\n", "match end behind the leftmost-first one"),   # UseBoth: the PikeVM restart would skip a match
-                    (r"(?m)\Bbar(?:com|org)x(\w+)(\w+)\sbar", "would report an earlier match start")]   # UseDFA: the reverse DFA ignores \B
+                    (r"(?m)\Bbar(?:com|org)x(\w+)(\w+)\sbar", "would report an earlier match start"),
+                    (r"\d+\B[a-z]+ [a-z]+", "does not answer leftmost-first")]              # UseDigitPrefilter: early return inside [a-z]+   # UseDFA: the reverse DFA ignores \B
 
 
 @pytest.mark.parametrize("pat,strategy", LOOK_DFA_OK)
@@ -154,7 +156,8 @@ def test_look_programs_of_lazy_dfa_strategies(oracle, pat, strategy):
     hays = [alphabet[rng.integers(0, len(alphabet), size=k)] for k in (0, 1, 9, 70, 300, 2000)]
     hays += [np.frombuffer(b"user=bob ip=10 status=ok  a=b;c=d  me@ex.am.com going moved bars  a b c d! xuser=a ip=b status=c_ " * 7, dtype=np.uint8),
              np.frombuffer(b" " * 140 + b"a=b;c=d user=a ip=b status=c one two three" + b"." * 120 + b"q r s t!", dtype=np.uint8),
-             np.frombuffer(b"timeout=30 ms elapsed timeout=5ms elapsed GET /a/b HTTP GETX /a HTTP k=1; v=22 k=1;v=2 k=1_; v=2 x@y.z.org " * 9, dtype=np.uint8)]
+             np.frombuffer(b"timeout=30 ms elapsed timeout=5ms elapsed GET /a/b HTTP GETX /a HTTP k=1; v=22 k=1;v=2 k=1_; v=2 x@y.z.org " * 9, dtype=np.uint8),
+             np.frombuffer(b"10.0.0.1 10.0.0.1x 1.2.3.4.5 1.2.3 2024-01-02 2024-01-023 2024-01-02_ 15 ms 15ms 7 ms. 1234567.8.9.0\n" * 9, dtype=np.uint8)]
     for hay in hays:
         exp = o.find_all_index(hay)
         for tile, chunk in ((3840, 32), (64, 8), (256, 16)):
@@ -169,7 +172,7 @@ def test_look_programs_of_lazy_dfa_strategies(oracle, pat, strategy):
 @pytest.mark.parametrize("pat,why", LOOK_DFA_REFUSED)
 def test_look_programs_the_reference_answers_differently_are_refused(oracle, pat, why):
     rx = cx.compile(pat)
-    assert rx.strategy == oracle.Regex(pat).strategy and rx.strategy in ("UseDFA", "UseBoth")
+    assert rx.strategy == oracle.Regex(pat).strategy and rx.strategy in ("UseDFA", "UseBoth", "UseDigitPrefilter")
     assert not rx.supported and why in rx.why_unsupported, (pat, rx.why_unsupported)
 
 

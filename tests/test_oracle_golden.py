@@ -364,3 +364,7 @@ def test_lazy_dfa_look_known_limitation_and_history(oracle):
     a.dfa_search_at(b"a ", 0)                                # the class of ' ' and 'a' (bytes below 'f') is first met, in the
     b.dfa_search_at(b"aa", 0)                                # state behind a word byte, on a non-word byte ... or on a word byte
     assert (a.dfa_search_at(b"a foo", 0), b.dfa_search_at(b"a foo", 0)) == (5, -1)
+    # the same through FindAll of a UseDigitPrefilter engine: ' ' and '\n' share a class of `(?m)\d+$`; after "1 2" the entry is "dead"
+    c = oracle.Regex(r"(?m)\d+$")
+    assert c.strategy == "UseDigitPrefilter" and c.find_all_index(b"1 2").tolist() == [[2, 3]]
+    assert c.find_all_index(b"1\n").tolist() == [] and oracle.Regex(r"(?m)\d+$").find_all_index(b"1\n").tolist() == [[0, 1]]
