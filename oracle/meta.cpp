@@ -672,6 +672,13 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
           e->revNfa = reverseNFA(e->nfa);
           e->revDfa.init(&e->revNfa, false);
           e->hasReverseDFA = true;
+        } else if (e->nfa.hasLook && !hasPrefilter) {
+          // No reverse DFA and no prefilter: findIndicesDFAAtWithState first asks DFA.IsMatchAt (find_indices.go:396-403 ->
+          // lazy.go:561-828 searchEarliestMatch), a third search loop over the same cache with its own boundary shortcuts.  Not
+          // restated; without assertions it cannot miss a match, with them it can (per-class transition cache).  The PikeVM
+          // answers below — leftmost-first, not necessarily the reference's answer.  (With a prefilter the reference goes
+          // prefilter -> PikeVM, :381-393, and no DFA is involved.)
+          e->strategyRestated = false;
         }
       }
       break;

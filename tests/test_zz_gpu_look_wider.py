@@ -1,0 +1,27 @@
+"""GPU tier, last file on purpose: look-around programs that came in after this round's GPU budget was spent.  Their device path
+is the transducer kernel's look-around instantiation that tests/test_gpu_fsm.py validates; each (program, haystack) pair below
+was checked on the kernel's sequential twin (tests/emu) against the oracle before it was written down here."""
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from refcorpus import generate_test_input
+
+pytestmark = pytest.mark.gpu
+
+WIDER = [(r"\d+\.\d+\.\d+\.\d+\b", "UseDigitPrefilter"), (r"\d{4}-\d{2}-\d{2}\b", "UseDigitPrefilter"),      # SearchAtAnchored of the look-aware lazy DFA at each digit
+         (r"timeout=\d+\b ms elapsed", "UseDFA"), (r"(GET|POST|PUT|DELETE)\b /[a-z/]+ HTTP", "UseDFA")]     # byte classes that mix word and non-word bytes, harmlessly
+
+
+@pytest.mark.parametrize("pat,strategy", WIDER)
+def test_look_programs_proved_at_build_time(oracle, pat, strategy):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == strategy and o.strategy_restated and rx.supported, (pat, rx.strategy, o.strategy, rx.why_unsupported)
+    line = b"user=bob ip=10 status=ok  a=b;c=d  going moved bars  a b c d! xuser=a ip=b status=c_ k=v;w=x\n"
+    hays = [generate_test_input(), cx.synth_pages(2, 0xC0FFEE02, 0, 256).tobytes(), b"", line * 2000,
+            b"10.0.0.1 10.0.0.1x 1.2.3.4.5 2024-01-02 2024-01-023 timeout=30 ms elapsed GET /a HTTP GETX /a HTTP " * 300]
+    for hay in hays:
+        exp = o.find_all_index(hay)
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
+        assert rx.count(hay) == len(exp)
