@@ -13,15 +13,16 @@
 // The device serves leftmost-first (the transducer of fsm.cc).  This file decides, at build time, whether the two agree on
 // EVERY haystack: it builds the reference's forward machine R state by state (un-conflated: ordered NFA list, from-word flag,
 // delayed-match flag) and the leftmost-first machine T (ordered list, kind of the byte behind; every assertion resolved when
-// the next byte is known), and walks their product; then the same for the two reverse machines.  Any difference, any class
-// that mixes kinds, any pair of priority orders filed under one cache key: CXG_E_UNSUPPORTED, the caller keeps its CPU loop.
+// the next byte is known), and walks their product; then the same for the two reverse machines (UseDFA), or only "R's end is
+// never behind T's" (UseBoth, whose answer comes from the PikeVM), or both machines from the anchored start (UseDigitPrefilter).
+// Any difference that can show in an answer, any state in which bytes of one class lead to different behaviour, any pair of
+// priority orders filed under one cache key that behave differently: CXG_E_UNSUPPORTED, the caller keeps its CPU loop.
 // Sound by construction (only "equal on all inputs" passes); scripts/cpu_fuzz_lookdfa.py checks it against the restated
 // reference DFA of the oracle (test infrastructure) through the transducer's sequential twin.
 #include "lookdfa.h"
 
 #include <algorithm>
 #include <array>
-#include <cstring>
 #include <map>
 #include <set>
 
@@ -147,7 +148,6 @@ Automaton buildReference(const cxg_nfa& n, uint32_t startState, const std::vecto
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;       // ordered list + flags word
   std::map<std::vector<uint32_t>, std::vector<int32_t>> filedAs;   // sorted set + flags word (state.go:329-373) -> orders filed there
-  bool anyConflict = false;
   std::vector<std::vector<uint32_t>> tuples;
   auto intern = [&](std::vector<uint32_t>&& list, uint32_t flagsWord) -> int32_t {
     std::vector<uint32_t> key(list);
@@ -159,7 +159,6 @@ Automaton buildReference(const cxg_nfa& n, uint32_t startState, const std::vecto
     const int32_t id = static_cast<int32_t>(tuples.size());
     if (tuples.size() >= kMaxStates) throw Refuse{"look-aware reference DFA exceeds the build-time exploration budget"};
     std::vector<int32_t>& filed = filedAs[key];
-    if (!filed.empty()) anyConflict = true;
     filed.push_back(id);
     ids.emplace(list, id);
     tuples.push_back(std::move(list));
@@ -226,7 +225,6 @@ Automaton buildReference(const cxg_nfa& n, uint32_t startState, const std::vecto
     // the entry.)  Both are harmless exactly when the alternatives behave alike — same flags on every symbol sequence: Moore
     // partition of the exact, un-conflated machine built above (states that can never flag again count as dead), as
     // program.cc priorityOrderConflict does for programs without assertions.
-    (void)anyConflict;
     const size_t ns = a.next.size();
     std::vector<uint32_t> cls(ns);
     {
