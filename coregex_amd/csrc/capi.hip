@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
 // (device/bt.hpp).  One thread per row, grid-stride; every thread owns 16 KiB of scratch in HBM (visited bitmap + stack).
 // Two tiers: k_captures_bt_lds first (256 threads per workgroup, 256 bytes of LDS scratch per thread, the NFA image in LDS when
 // it fits: as many resident threads as the CUs hold), rows it cannot finish are marked and redone by k_captures_bt.
-__global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+__global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int64_t hay_base, uint64_t hay_len, int64_t* rows, uint64_t nrows, uint32_t width,
                                                          const uint8_t* btblob, uint32_t img_lds_bytes, uint32_t* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_bt[];   // [img_lds_bytes] image, then per-thread scratch
   __shared__ uint64_t s_stack[256 * cxgdev::kBtSmallStack];
@@ -286,14 +286,15 @@ __global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int
     int64_t* row = rows + r * width;
 #pragma unroll
     for (uint32_t i = 0; i < cxgdev::kBtSmallVisited; i++) visited[i] = 0u;
-    const uint32_t rc = cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtSmallVisited, cxgdev::kBtSmallStack);
+    const uint32_t rc = cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtSmallVisited, cxgdev::kBtSmallStack,
+                                            hay_base, hay_base + static_cast<int64_t>(hay_len));   // (bounds: read by assertion states only)
     if (rc == 1u) row[2] = cxgdev::kBtRowPending;                 // left to the large tier (its slots are rewritten there)
     else bad |= rc;
   }
   if (bad & 2u) cxgdev::raise_err(err, 4u);
 }
 
-__global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t hay_base, int64_t* rows, uint64_t nrows, uint32_t width,
+__global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t hay_base, uint64_t hay_len, int64_t* rows, uint64_t nrows, uint32_t width,
                                                     const uint8_t* btblob, uint8_t* scratch, uint32_t* err) {
   const cxgdev::BtHeader* h = reinterpret_cast<const cxgdev::BtHeader*>(btblob);
   const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x;
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t 
     const uint64_t bits = (static_cast<uint64_t>(row[1] - row[0]) + 1) * h->n_states;
     const uint32_t nw = bits > static_cast<uint64_t>(cxgdev::kBtVisitedWords) * 32u ? 0u : static_cast<uint32_t>((bits + 31) >> 5);
     for (uint32_t i = 0; i < nw; i++) visited[i] = 0u;
-    bad |= cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack);   // rows hold absolute offsets (hay_base added)
+    bad |= cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtVisitedWords, cxgdev::kBtStackEntries,
+                               hay_base, hay_base + static_cast<int64_t>(hay_len));   // rows hold absolute offsets (hay_base added)
   }
   if (bad & 1u) cxgdev::raise_err(err, cxgdev::kErrSerialLimit);   // a match too long for the per-row budget: this haystack is left to the caller
   if (bad & 2u) cxgdev::raise_err(err, 4u);
@@ -520,9 +522,9 @@ relaunch:
           int dev = 0, cus = 256;
           if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
           const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * 2u));
-          hipLaunchKernelGGL(k_captures_bt_lds, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
+          hipLaunchKernelGGL(k_captures_bt_lds, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
         }
-        hipLaunchKernelGGL(k_captures_bt, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+        hipLaunchKernelGGL(k_captures_bt, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
       } else if (lds_ok && a.row_width <= 8) {
         const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
         hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
@@ -801,7 +803,7 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
       p->supported = false;
       p->whyNot = "the reference may route this pattern to a reverse-search strategy outside the device subset";
     }
-    if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view);   // FindAllSubmatchIndex path (spans + one-pass captures)
+    if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view, plan.strategy);   // FindAllSubmatchIndex path (spans + one-pass captures)
     if (p->supported && p->ngroups == 1) {                     // bounded repetition (`\d{1,3}\.\d{1,3}`...) on the chain kernel
       static const bool noBounded = getenv("CXG_NO_BOUNDED_CHAIN") != nullptr;
       cxg::Ast sur;
@@ -838,7 +840,7 @@ int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_p
     p = new cxg_program();
     cxg::buildProgramFromNfa(p, *nfa, strategy, flags);
     // FindAllSubmatch hook (meta/findall.go:390): spans + capture table, same call as cxg_compile makes
-    if (nfa->capture_count > 1) cxg::buildSubmatchProgram(p, *nfa);
+    if (nfa->capture_count > 1) cxg::buildSubmatchProgram(p, *nfa, strategy);
     else p->subWhyNot = "pattern has no capture groups (cxg_find_all_submatch then returns the spans)";
     if (!p->supported) t_err = p->whyNot;
     *out = p;

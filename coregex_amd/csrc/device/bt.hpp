@@ -9,6 +9,9 @@
 // first path that reaches Match is the winner, and it ends at e because e is that winner's end.  The haystack is cut at
 // e, as the reference's SearchWithCapturesInSpan does (pikevm.go:1210).  A (state, position) pair that failed once fails
 // again: a visited bitmap bounds the work by states x (e - s + 1).
+// Assertions (LOOK states, lo = nfa.Look 2..5: (?m)^ (?m)$ \b \B; pikevm.go:1646-1674) read the haystack bytes on both sides of
+// the position — also in front of s and behind e — inside [hay_lo, hay_hi); outside of it counts as a line break, not a
+// word byte (what the transducer kernel assumes around a shard, fsm.hpp "Look-around").
 // Shared by capi.hip (device) and tests/emu (host twin); plain C++.
 #pragma once
 #include <stdint.h>
@@ -47,10 +50,14 @@ constexpr int64_t kBtRowPending = -0x7FFFFFFFFFFFFFFFll - 1;   // row[2] of a ro
 // hay: absolute haystack; row: 2 * ngroups int64 with row[0], row[1] = s, e.  visited: `visited_words` zeroed words,
 // stack: `stack_entries` entries (defaults: the large tier's kBtVisitedWords / kBtStackEntries).  Returns 0 ok, 1 the span
 // is too long for the visited bitmap / the stack overflowed (the row's slots are then undefined), 2 no path reaches Match
-// at e (cannot happen for a real match).  Visited / Stack: plain pointers or LDS pointers.
+// at e (cannot happen for a real match).  Visited / Stack: plain pointers or LDS pointers.  hay_lo / hay_hi: the absolute
+// positions the haystack buffer covers (only read by LOOK states).
+CXG_BT_HD bool bt_word_byte(uint32_t b) { return (b - '0' < 10u) || ((b | 0x20u) - 'a' < 26u) || b == '_'; }
+
 template <class Visited, class Stack>
 CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* row, uint32_t nslots, Visited visited, Stack stack,
-                               uint32_t visited_words = kBtVisitedWords, uint32_t stack_entries = kBtStackEntries) {
+                               uint32_t visited_words = kBtVisitedWords, uint32_t stack_entries = kBtStackEntries,
+                               int64_t hay_lo = 0, int64_t hay_hi = 0) {
   const BtState* st = reinterpret_cast<const BtState*>(reinterpret_cast<const uint8_t*>(h) + h->states_off);
   const BtTrans* tr = reinterpret_cast<const BtTrans*>(reinterpret_cast<const uint8_t*>(h) + h->trans_off);
   const int64_t s = row[0], e = row[1];
@@ -109,7 +116,19 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
           row[slot] = s + static_cast<int64_t>(off);
         }
         q = x.next;
-      } else break;                                                    // FAIL, LOOK (not in the device subset)
+      } else if (x.kind == 7 /*LOOK*/) {
+        const int64_t pos = s + static_cast<int64_t>(off);
+        const bool has_left = pos > hay_lo, has_right = pos < hay_hi;
+        const uint32_t left = has_left ? hay[pos - 1] : '\n', right = has_right ? hay[pos] : '\n';
+        bool ok;
+        if (x.lo == 2) ok = left == '\n';                                   // StartLine
+        else if (x.lo == 3) ok = right == '\n';                             // EndLine
+        else if (x.lo == 4) ok = bt_word_byte(left) != bt_word_byte(right);  // WordBoundary
+        else if (x.lo == 5) ok = bt_word_byte(left) == bt_word_byte(right);  // NoWordBoundary
+        else ok = false;                                                    // text anchors: not in the device subset
+        if (!ok) break;
+        q = x.next;
+      } else break;                                                    // FAIL
     }
   }
   return 2u;

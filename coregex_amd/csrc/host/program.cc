@@ -958,7 +958,7 @@ void deriveChainCaps(const cxgdev::ChainAux& chain, const std::vector<uint8_t>& 
 
 }  // namespace
 
-void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
+void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
   p->subSupported = false;
   try {
     if (nfa.capture_count > 16) throw BuildError{CXG_E_UNSUPPORTED, "more than 15 capture groups"};
@@ -966,6 +966,36 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
     cxgdev::ChainAux spanChain;                   // set when the spans come from the chain kernel
     std::memset(&spanChain, 0, sizeof spanChain);
     std::memset(p->chainCaps, 0, sizeof p->chainCaps);
+    bool hasLook = false;
+    for (uint32_t i = 0; i < nfa.n_states; i++) hasLook = hasLook || nfa.states[i].kind == CXG_NFA_LOOK;
+    if (hasLook) {
+      // Assertions.  FindAllSubmatch of a UseNFA / UseDFA / UseBoth / UseDigitPrefilter / UseBoundedBacktracker engine is the
+      // PikeVM over the whole haystack (meta/findall.go:89-98 -> nfa/pikevm.go:2186-2328): plain leftmost-first with the
+      // assertions checked at each position (pikevm.go:1646-1674) — no lazy DFA, so none of lookdfa.cc's conditions apply.
+      // UseTeddy behind (?m)^ finds the span first (line-filtered literal candidates, find_indices.go:925-951) and the slots
+      // inside it: the same rows when the program itself is served (every alternative behind the assertion).
+      // Spans: the look-aware transducer; slots: the backtracking pass, whose LOOK states read the bytes around the position
+      // (device/bt.hpp).  No table-walking image, no one-pass table (a table walk cannot test an assertion).
+      const bool pike = strategy == CXG_USE_NFA || strategy == CXG_USE_DFA || strategy == CXG_USE_BOTH || strategy == CXG_USE_DIGIT_PREFILTER ||
+                        strategy == CXG_USE_BOUNDED_BACKTRACKER;
+      if (!pike && !(strategy == CXG_USE_TEDDY && p->supported))
+        throw BuildError{CXG_E_UNSUPPORTED, "assertions: FindAllSubmatch of this strategy is not the PikeVM over the whole haystack"};
+      HostNfa rn = reverseOf(nfa);
+      cxg_nfa rvw = rn.view();
+      Dfa none;
+      std::string w;
+      if (!buildFsmImage(nfa, none, 0u, p->subFsmBlob, w, &rvw)) { p->subFsmBlob.clear(); throw BuildError{CXG_E_UNSUPPORTED, w}; }
+      cxgdev::BlobHeader h;
+      std::memset(&h, 0, sizeof h);
+      h.magic = cxgdev::kBlobMagic; h.kind = cxgdev::kKindFsmOnly; h.ngroups = nfa.capture_count;
+      bool inAlpha[256]; alphabetOf(nfa, inAlpha);
+      std::vector<uint8_t> blob(sizeof h, 0);
+      h.info_off = static_cast<uint32_t>(blob.size());
+      for (int b = 0; b < 256; b++) blob.push_back(inAlpha[b] ? 0 : cxgdev::kInfoSync);
+      h.total_bytes = static_cast<uint32_t>(blob.size());
+      std::memcpy(blob.data(), &h, sizeof h);
+      p->subBlob.swap(blob);
+    } else {
     // ---- spans: unanchored forward + reverse DFA (the bidirectional image of buildProgramFromNfa)
     Dfa fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
     if (fwd.start >= fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
@@ -1021,8 +1051,10 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa) {
       std::string w;
       if (!buildFsmImage(nfa, rev, 0u, p->subFsmBlob, w)) p->subFsmBlob.clear();
     }
+    }
     // ---- one-pass capture table; patterns that are not one-pass get the backtracking image instead (device/bt.hpp)
     try {
+    if (hasLook) throw BuildError{CXG_E_UNSUPPORTED, "assertions: slots by the backtracking pass"};
     CapClosure cc(nfa);
     std::vector<uint32_t> entryState;             // entry id -> NFA state whose closure is taken
     std::map<uint32_t, uint32_t> entryOf;

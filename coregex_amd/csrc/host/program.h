@@ -76,7 +76,9 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why);
 // Fills p->fwd/rev/blob/supported from (nfa, strategy, flags).  Never throws: unsupported programs
 // get supported=false + whyNot.
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags);
-void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa);
+// `strategy` (meta.Strategy of the engine, -1 unknown) only matters for an NFA with assertions: their captures are served for the
+// strategies whose FindAllSubmatch is the PikeVM (meta/findall.go:89-98) and for UseTeddy behind (?m)^ when the program itself is served.
+void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy = -1);
 // Bounded repetition: `surrogate` is the NFA of the pattern with every bounded run made unbounded (frontend.h
 // boundedSurrogate), bounds the (min, max) of its runs in order.  Adds the surrogate's chain to an already built,
 // supported digit / DFA-pair program when that chain has a shape the BND kernels take; otherwise leaves p alone.

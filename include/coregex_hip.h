@@ -156,6 +156,10 @@ int cxg_program_chain_captures(const cxg_program* p, uint8_t out[40]);
  * 40-byte record with on == 2, nruns = fields but the last, src[x] = min and src[8 + x] = max (0: unbounded) of field x.
  * Returns 1 when the program has one. */
 int cxg_program_chain_bounds(const cxg_program* p, uint8_t out[40]);
+/* 1 when cxg_find_all_submatch is served.  Independent of cxg_program_supported for an NFA with assertions: FindAllSubmatch
+ * of a UseNFA / UseDFA / UseBoth / UseDigitPrefilter / UseBoundedBacktracker engine is the PikeVM over the whole haystack
+ * (meta/findall.go:89-98), which the device reproduces (look-around transducer for the spans, backtracking pass with the
+ * assertions for the slots) whatever that engine's lazy DFA does for FindAllIndex. */
 int cxg_program_submatch_supported(const cxg_program* p);
 /* Host-side copy of the NFA a program was compiled from (cxg_compile only); pointers live as long as p. */
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);

@@ -25,6 +25,7 @@ def main(n=300, seed=1, look=False):
     atoms = ATOMS + LOOK_ATOMS * 3 if look else ATOMS
     n_strat = 0
     seen, n_img, n_checked, reasons = set(), 0, 0, {}
+    n_caps = 0
     t0 = time.time()
     while len(seen) < n:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
@@ -43,6 +44,10 @@ def main(n=300, seed=1, look=False):
             n_strat += 1
         img = rx.fsm_image()
         simg = rx.fsm_image(True) if rx.num_groups > 1 else None
+        cap_bt = None
+        if simg is not None and rx.submatch_supported:
+            cb = rx.submatch_blobs()[1]
+            if cb[:4] == b"TBXC": cap_bt = cb                                 # cxgdev::kBtMagic "CXBT", little endian
         if img is None and simg is None: continue
         n_img += 1
         o = O.Regex(pat)
@@ -78,7 +83,16 @@ def main(n=300, seed=1, look=False):
                         np.save("/tmp/fsm_fail_hay.npy", hay)
                         print("MISMATCH", repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), got[:6].tolist(), exp[:6].tolist())
                         return 1
+                    if which == "sub" and look and tile == 3840 and cap_bt is not None:      # slots by the backtracking pass, assertions included
+                        full = o.find_all_submatch_index(hay)
+                        caps = emu.captures_bt(cap_bt, hay, got, 2 * rx.num_groups)
+                        n_caps += 1
+                        if caps.shape != full.shape or not np.array_equal(caps, full):
+                            np.save("/tmp/fsm_fail_hay.npy", hay)
+                            print("CAPTURE MISMATCH", repr(pat), rx.strategy, bytes(hay[:120]), caps[:4].tolist(), full[:4].tolist())
+                            return 1
     if look: print(f"{n_strat} strategies compared with the oracle")
+    if look: print(f"{n_caps} capture-row comparisons (backtracking pass with assertions) clean")
     print(f"{len(seen)} patterns, {n_img} with a transducer image, {n_checked} comparisons clean, fallback reasons {reasons}, {time.time()-t0:.1f}s")
     return 0
 

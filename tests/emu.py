@@ -31,6 +31,8 @@ def lib():
         L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
         L.emu_find_all_submatch.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64]
+        L.emu_captures_bt.restype = C.c_int64
+        L.emu_captures_bt.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -60,6 +62,17 @@ def find_all_submatch(span_blob: bytes, cap_blob: bytes, hay, width: int, chunk:
         if n <= cap:
             return out[:n].reshape(-1, width).copy()
         cap = int(n)
+
+
+def captures_bt(cap_blob: bytes, hay, spans: np.ndarray, width: int) -> np.ndarray:
+    """Rows of FindAllSubmatchIndex from given spans: the backtracking capture pass (both tiers), as capi.hip runs it."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
+    sp = np.ascontiguousarray(spans, dtype=np.int64).reshape(-1, 2)
+    out = np.empty((len(sp), width), dtype=np.int64)
+    n = lib().emu_captures_bt(cap_blob, padded.ctypes.data, a.size, sp.ctypes.data, len(sp), out.ctypes.data)
+    assert n == len(sp) * width, f"emulator error {n}"
+    return out
 
 
 def find_all_chain(blob: bytes, hay, tile: int = 16384, halo: int = 256):

@@ -158,6 +158,29 @@ extern "C" int64_t emu_find_all_submatch(const uint8_t* span_blob, const uint8_t
   return rows * w;
 }
 
+// The backtracking capture pass alone (k_captures_bt_lds, then k_captures_bt for the rows it leaves), rows = spans from any span
+// twin — the transducer's for programs with assertions, which have no table-walking span image.  [hay_lo, hay_hi): what the
+// device buffer covers (assertion states read the bytes around a position; outside counts as a line break).
+extern "C" int64_t emu_captures_bt(const uint8_t* cap_blob, const uint8_t* hay, uint64_t len, const int64_t* spans, int64_t nrows, int64_t* out) {
+  const BtHeader* bh = reinterpret_cast<const BtHeader*>(cap_blob);
+  if (bh->magic != kBtMagic) return -1;
+  const uint32_t w = bh->nslots;
+  std::vector<uint32_t> visited(kBtVisitedWords);
+  std::vector<uint64_t> stack(kBtStackEntries);
+  for (int64_t i = 0; i < nrows; i++) {
+    int64_t* row = out + i * w;
+    row[0] = spans[2 * i]; row[1] = spans[2 * i + 1];
+    std::fill(visited.begin(), visited.end(), 0u);
+    uint32_t rc = bt_captures(bh, hay, row, w, visited.data(), stack.data(), kBtSmallVisited, kBtSmallStack, static_cast<int64_t>(0), static_cast<int64_t>(len));
+    if (rc == 1u) {
+      std::fill(visited.begin(), visited.end(), 0u);
+      rc = bt_captures(bh, hay, row, w, visited.data(), stack.data(), kBtVisitedWords, kBtStackEntries, static_cast<int64_t>(0), static_cast<int64_t>(len));
+    }
+    if (rc) return -3 - static_cast<int64_t>(rc);
+  }
+  return nrows * w;
+}
+
 // Fourth-generation digit kernel (scan_digit_chain.hip), tile by tile: reversed class bitmaps, the chain
 // evaluated with chain_eval_seq, survivors verified with verify_jump, ownership by segment start, greedy
 // FindAll order.  Returns -5 when a tile would raise the "rerun with the flat kernel" flag.

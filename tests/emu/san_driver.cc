@@ -4,12 +4,14 @@
 // Nothing in coregex_amd/ links it; no oracle involved (this looks for memory / UB errors, not for wrong answers).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <vector>
 
 #include "../../coregex_amd/csrc/host/program.h"
 
+extern "C" int64_t emu_captures_bt(const uint8_t* cap_blob, const uint8_t* hay, uint64_t len, const int64_t* spans, int64_t nrows, int64_t* out);
 extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int tile, int chunk,
                                     int budget_bytes, uint64_t* stats, int dense);
 
@@ -17,7 +19,7 @@ extern "C" const char* cxg_strategy_name(int) { return "strategy"; }   // capi.h
 
 int main() {
   std::string line;
-  size_t n = 0, nprog = 0, nimg = 0, nrun = 0, nrejected = 0, naccepted = 0;
+  size_t n = 0, nprog = 0, nimg = 0, nrun = 0, nrejected = 0, naccepted = 0, ncap = 0;
   uint64_t seed = 0x9E3779B97F4A7C15ull;
   auto rnd = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
   const char alphabet[] = "abcxyz.:-0123456789 \n_A@";
@@ -42,7 +44,7 @@ int main() {
           }
           default: cxg::buildProgramFromNfa(&p, view, plan.strategy, plan.flags); break;
         }
-        if (p.nfa.captureCount > 1) cxg::buildSubmatchProgram(&p, view);
+        if (p.nfa.captureCount > 1) cxg::buildSubmatchProgram(&p, view, plan.strategy);
         cxg::Ast sur;
         std::vector<std::pair<int, int>> bounds;
         if (p.supported && p.nfa.captureCount == 1 && cxg::boundedSurrogate(ast, sur, bounds)) {
@@ -75,7 +77,7 @@ int main() {
         cxg_program q;
         try {
           cxg::buildProgramFromNfa(&q, bv, plan.strategy == CXG_USE_CHARCLASS_SEARCHER ? CXG_USE_DFA : plan.strategy, plan.flags);
-          if (bv.capture_count > 1) cxg::buildSubmatchProgram(&q, bv);
+          if (bv.capture_count > 1) cxg::buildSubmatchProgram(&q, bv, plan.strategy);
         } catch (const cxg::BuildError&) {}
         naccepted++;
       }
@@ -89,16 +91,24 @@ int main() {
           for (size_t i = 0; i < len; i++) hay[i] = static_cast<uint8_t>(alphabet[rnd() % na]);
           std::vector<int64_t> out(2 * (len + 2));
           uint64_t stats[8] = {0};
+          int64_t nvals = 0;
           for (auto g : {std::pair<int, int>{64, 8}, {256, 16}, {3840, 32}}) {
-            emu_find_all_fsm(img->data(), hay.data(), len, out.data(), static_cast<int64_t>(out.size()), g.first, g.second, 0, stats, 0);
+            nvals = emu_find_all_fsm(img->data(), hay.data(), len, out.data(), static_cast<int64_t>(out.size()), g.first, g.second, 0, stats, 0);
             nrun++;
+          }
+          // the backtracking capture pass over the spans of the last run (exactly `len` bytes: an assertion state must not read past them)
+          if (img == &p.subFsmBlob && nvals > 0 && nvals <= static_cast<int64_t>(out.size()) && p.capBlob.size() >= 4 && std::memcmp(p.capBlob.data(), "TBXC", 4) == 0) {
+            std::vector<uint8_t> exact(hay.begin(), hay.begin() + static_cast<long>(len));
+            std::vector<int64_t> rows(static_cast<size_t>(nvals / 2) * 2 * p.nfa.captureCount);
+            emu_captures_bt(p.capBlob.data(), exact.data(), len, out.data(), nvals / 2, rows.data());
+            ncap++;
           }
         }
       }
     } catch (const cxg::FrontendError&) {
     }
   }
-  std::printf("%zu patterns, %zu programs, %zu transducer images, %zu twin runs, damaged NFAs: %zu rejected by validateNfa, %zu built: no sanitizer report\n",
-              n, nprog, nimg, nrun, nrejected, naccepted);
+  std::printf("%zu patterns, %zu programs, %zu transducer images, %zu twin runs, %zu capture passes, damaged NFAs: %zu rejected by validateNfa, %zu built: no sanitizer report\n",
+              n, nprog, nimg, nrun, ncap, nrejected, naccepted);
   return 0;
 }

@@ -190,3 +190,29 @@ def test_look_dfa_fuzz_smoke():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import cpu_fuzz_lookdfa
     assert cpu_fuzz_lookdfa.main(120, 4242) == 0
+
+
+# ---- FindAllSubmatchIndex of programs with assertions: spans by the look-aware transducer, slots by the backtracking pass whose
+# LOOK states read the bytes around the position (device/bt.hpp).  The reference's FindAllSubmatch of these strategies is its
+# PikeVM over the whole haystack (meta/findall.go:89-98), so `\b(DEBUG|INFO|WARN|ERROR)\b` has rows although its FindAllIndex —
+# the lazy DFA's business there — is refused.
+LOOK_CAPTURES = [r"\b(\w+)=(\w+)\b", r"\b(error|warn)\b", r"(?m)^(\d+) (\w+)", r"(\d+)\.(\d+)\b", r"\b(\w+)@(\w+)\.com\b", r"(?m)^(GET|POST) ",
+                 r"\b(DEBUG|INFO|WARN|ERROR)\b", r"(?m)(\w+)$", r"(a|\b)(b|c)x", r"(\w+)\B(\d)", r"(?m)^(\w+): (\w+)$"]
+
+
+@pytest.mark.parametrize("pat", LOOK_CAPTURES)
+def test_captures_of_look_programs(oracle, pat):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.submatch_supported and rx.strategy == o.strategy, (pat, rx.strategy, o.strategy)
+    simg, cap = rx.fsm_image(True), rx.submatch_blobs()[1]
+    assert simg is not None and cap[:4] == b"TBXC"                   # cxgdev::kBtMagic: the backtracking image
+    hays = [generate_test_input(), b"", b"a=b c=d; e=f\n12 ab\nGET /x\nPOST y\n3.4 5.6x me@x.com ERROR error warn_ warn\n7 z\nkey: val\nkey: val x\n",
+            b"k=v", b"x=y\n" * 300, b"bx cx abx a1 ab12 x9\n" * 50, b"\n\n12 ab", b"1.2"]
+    for hay in hays:
+        h = np.frombuffer(hay, dtype=np.uint8)
+        exp = o.find_all_submatch_index(h)
+        spans = emu.find_all_fsm(simg, h, 3840, 32)
+        if isinstance(spans, int) and spans in (-18, -32): spans = emu.find_all_fsm(simg, h, 3840, 32, dense=1)
+        assert not isinstance(spans, int), (pat, spans)
+        got = emu.captures_bt(cap, h, spans, 2 * rx.num_groups)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), got[:4].tolist(), exp[:4].tolist())

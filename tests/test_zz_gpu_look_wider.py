@@ -25,3 +25,20 @@ def test_look_programs_proved_at_build_time(oracle, pat, strategy):
         got = rx.find_all_index(hay)
         assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
         assert rx.count(hay) == len(exp)
+
+
+LOOK_CAPTURES = [r"\b(\w+)=(\w+)\b", r"(?m)^(\d+) (\w+)", r"(\d+)\.(\d+)\b", r"\b(DEBUG|INFO|WARN|ERROR)\b", r"(?m)^(GET|POST) "]
+
+
+@pytest.mark.parametrize("pat", LOOK_CAPTURES)
+def test_captures_of_look_programs(oracle, pat):
+    """FindAllSubmatchIndex with assertions: spans by the look-around transducer, slots by the backtracking pass (bt.hpp LOOK states).
+    The reference's FindAllSubmatch of these strategies is its PikeVM (meta/findall.go:89-98): served even where FindAllIndex is not."""
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.submatch_supported and rx.strategy == o.strategy, (pat, rx.strategy, o.strategy)
+    hays = [generate_test_input(), b"", b"a=b c=d; e=f\n12 ab\nGET /x\nPOST y\n3.4 5.6x me@x.com ERROR error warn_ warn\n7 z\nkey: val\n", b"k=v", b"x=y\n" * 3000,
+            b"12 ab", b"1.2"]
+    for hay in hays:
+        exp = o.find_all_submatch_index(hay)
+        got = rx.find_all_submatch_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
