@@ -230,7 +230,7 @@ def test_constructor_programs_other_shapes(oracle):
         o = oracle.Regex(pat)
         if prog.supported:
             assert np.array_equal(prog.find_all_index(corpus), o.find_all_index(corpus)), pat
-        if prog.submatch_supported and prog.num_groups > 1:
+        if prog.submatch_supported and prog.num_groups > 1 and not any(t in pat for t in (r"\b", r"\B", "(?m)")):   # (captures with assertions: tests/test_zz_gpu_look_wider.py)
             assert np.array_equal(prog.find_all_submatch_index(corpus), o.find_all_submatch_index(corpus)), pat
 
 
