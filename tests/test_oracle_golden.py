@@ -84,6 +84,16 @@ def test_teddy_find(oracle):
         assert t.find(_inp(c), c["start"]) == c["want"], c
 
 
+def test_lookaround_compat_rows_answered_by_the_lazy_dfa(oracle):
+    """A row of the reference's differential tests that its UseDFA engine answers with the look-aware lazy DFA (restated): fresh
+    engine, FindAllIndex and — through the PikeVM — FindAllSubmatchIndex."""
+    for c in VEC["lookaround_compat_lazy_dfa"]["cases"]:
+        rx = oracle.Regex(c["pattern"])
+        assert rx.strategy == "UseDFA" and rx.strategy_restated
+        assert rx.find_all_index(c["input"].encode()).tolist() == c["want"], c
+        assert oracle.Regex(c["pattern"]).find_all_submatch_index(c["input"].encode())[:, :2].tolist() == c["want"], c
+
+
 def test_lookaround_compat(oracle):
     """(?m)^ (?m)$ \\b \\B: the reference's own differential pairs, spans by Python re (gen_lookaround_expected.py)."""
     for c in VEC["lookaround_compat"]["cases"]:
