@@ -353,14 +353,10 @@ void compareForward(const Automaton& r, const Automaton& t, size_t nsym) {
   }
 }
 
-// UseBoth takes the DFA's match end only to choose where its PikeVM starts — at the search start, or 100 bytes in front of that
-// end when it lies further away (find_indices.go:425-431) — and the PikeVM is leftmost-first.  With no match longer than the
-// span (checked per haystack by the kernel) the answer is the leftmost-first one whenever the DFA's end is NOT BEHIND the
-// leftmost-first end; too early, or none at all, only moves the PikeVM's start further left.  So only this can hurt: R raises a
-// flag at a position where T does not, T has raised one before, and the input can go on (or end) without T raising another.
-void compareForwardNoLaterEnd(const Automaton& r, const Automaton& t, size_t nsym) {
+// States from which some continuation, possibly empty, raises no further flag (the end of input included).
+std::vector<uint8_t> statesThatCanAvoidFlags(const Automaton& t, size_t nsym) {
   const size_t nt = t.next.size();
-  std::vector<uint8_t> canAvoid(nt, 0);   // some continuation, possibly empty, on which T raises no further flag (end of input included)
+  std::vector<uint8_t> canAvoid(nt, 0);
   for (size_t i = 0; i < nt; i++) canAvoid[i] = !t.flag[i][nsym];
   for (bool changed = true; changed;) {
     changed = false;
@@ -373,6 +369,16 @@ void compareForwardNoLaterEnd(const Automaton& r, const Automaton& t, size_t nsy
       }
     }
   }
+  return canAvoid;
+}
+
+// UseBoth takes the DFA's match end only to choose where its PikeVM starts — at the search start, or 100 bytes in front of that
+// end when it lies further away (find_indices.go:425-431) — and the PikeVM is leftmost-first.  With no match longer than the
+// span (checked per haystack by the kernel) the answer is the leftmost-first one whenever the DFA's end is NOT BEHIND the
+// leftmost-first end; too early, or none at all, only moves the PikeVM's start further left.  So only this can hurt: R raises a
+// flag at a position where T does not, T has raised one before, and the input can go on (or end) without T raising another.
+void compareForwardNoLaterEnd(const Automaton& r, const Automaton& t, size_t nsym) {
+  const std::vector<uint8_t> canAvoid = statesThatCanAvoidFlags(t, nsym);
   std::set<std::array<int32_t, 3>> seen;
   std::vector<std::array<int32_t, 3>> todo;
   for (int k = 0; k < 4; k++) {
@@ -531,35 +537,71 @@ void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
   }
 }
 
+namespace {
+
+// The digit-run skip (find_indices.go:1079-1084): after a failure at the first digit of a run the reference goes on behind the
+// run.  Sound iff no later digit of the run would have matched: walk the search from the head of the run (X, any start kind,
+// at least one digit in) and a fresh search from a later digit (Y, start kind "after a word byte") over the same bytes; wherever
+// Y reports a match, X must have reported one or be unable to avoid reporting one.  (The criterion of the plain digit programs —
+// the first digit leads to one state that every digit keeps — is the special case in which X and Y coincide at once.)
+void runSkipIsSound(const Automaton& t, const std::vector<int>& reps) {
+  const size_t nsym = reps.size();
+  const std::vector<uint8_t> canAvoid = statesThatCanAvoidFlags(t, nsym);
+  const char* why = "digit-scan order differs from leftmost-first (run-skip quirk)";
+  std::vector<size_t> digits;
+  for (size_t i = 0; i < nsym; i++) if (reps[i] >= '0' && reps[i] <= '9') digits.push_back(i);
+  std::set<std::array<int32_t, 3>> seen;            // (X or -1, Y, X has reported)
+  std::vector<std::array<int32_t, 3>> todo;
+  {                                                 // heads: every state X reaches inside a run, paired with a fresh Y
+    std::set<std::pair<int32_t, int32_t>> heads;
+    std::vector<std::pair<int32_t, int32_t>> hq;
+    for (int k = 0; k < 4; k++) if (heads.emplace(t.start[k], 0).second) hq.emplace_back(t.start[k], 0);
+    while (!hq.empty()) {
+      const auto [x, xf] = hq.back();
+      hq.pop_back();
+      for (size_t d : digits) {
+        const int32_t xf2 = (xf || t.flag[static_cast<size_t>(x)][d]) ? 1 : 0;
+        const int32_t xn = t.next[static_cast<size_t>(x)][d];
+        const std::array<int32_t, 3> st{xn, t.start[kAfterWord], xf2};
+        if (!xf2 && seen.insert(st).second) todo.push_back(st);      // (a head that has reported is a success: nothing is skipped)
+        if (xn >= 0 && heads.emplace(xn, xf2).second) hq.emplace_back(xn, xf2);
+      }
+    }
+  }
+  while (!todo.empty()) {
+    const auto [x, y, unused] = todo.back();
+    (void)unused;
+    todo.pop_back();
+    for (size_t s = 0; s <= nsym; s++) {
+      const bool yf = t.flag[static_cast<size_t>(y)][s] != 0;
+      const bool xf = x >= 0 && t.flag[static_cast<size_t>(x)][s] != 0;
+      const int32_t xn = (s < nsym && x >= 0) ? t.next[static_cast<size_t>(x)][s] : -1;
+      if (yf && !xf && (s == nsym || xn < 0 || canAvoid[static_cast<size_t>(xn)])) throw Refuse{why};
+      if (s == nsym || xf || yf) continue;           // X has reported, or is bound to: this input is no failure of the head
+      const int32_t yn = t.next[static_cast<size_t>(y)][s];
+      if (yn < 0 || !t.live[static_cast<size_t>(yn)]) continue;
+      const std::array<int32_t, 3> nx{xn, yn, 0};
+      if (seen.insert(nx).second) todo.push_back(nx);
+    }
+  }
+}
+
+}  // namespace
+
 // UseDigitPrefilter (find_indices.go:1050-1088): at each digit position in turn, SearchAtAnchored — the same lazy DFA from its
 // ANCHORED start state of the kind of the byte in front (lazy.go:219-324; its boundary check reads the flags determinize
 // stored, state.go:238-247, which equal checkWordBoundaryMatch for every state determinize made, and a start state of a
 // pattern that begins with a digit holds no match behind a boundary).  First position that succeeds wins: leftmost-first over
 // matches that begin with a digit, i.e. over all matches of such a pattern — provided the anchored machine is the leftmost-
 // first one, and provided the digit-run skip (digitRunSkipSafe, compile.go:176, find_indices.go:1079-1084) is sound: after a
-// failure at the first digit of a run every later digit of the run must fail too.  Sound when the first digit leads, from every
-// start kind, to ONE state that every further digit keeps: then a start inside the run walks through the same states at the
-// same bytes as the start at its head.
+// failure at the first digit of a run every later digit of the run must fail too (runSkipIsSound).
 void refuseLookDigitQuirks(const cxg_nfa& nfa, bool runSkip) {
   const Symbols sy = symbolsOf(nfa);
   try {
     const Automaton r = buildReference(nfa, nfa.start_anchored, sy.reps, sy.classOf, sy.hasWordB, sy.hasEndLine);
     const Automaton t = buildLeftmostFirst(nfa, nfa.start_anchored, sy.reps);
     compareForward(r, t, sy.reps.size());
-    if (runSkip) {
-      int32_t s1 = -2;
-      for (size_t i = 0; i < sy.reps.size(); i++) {
-        if (sy.reps[i] < '0' || sy.reps[i] > '9') continue;
-        for (int k = 0; k < 4; k++) {
-          const int32_t to = t.next[static_cast<size_t>(t.start[k])][i];
-          if (s1 == -2) s1 = to;
-          if (to != s1 || to < 0) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
-        }
-      }
-      for (size_t i = 0; i < sy.reps.size() && s1 >= 0; i++)
-        if (sy.reps[i] >= '0' && sy.reps[i] <= '9' && t.next[static_cast<size_t>(s1)][i] != s1) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
-      if (s1 < 0) throw Refuse{"digit-scan order differs from leftmost-first (run-skip quirk)"};
-    }
+    if (runSkip) runSkipIsSound(t, sy.reps);
   } catch (const Refuse& e) {
     throw BuildError{CXG_E_UNSUPPORTED, e.why};
   }
