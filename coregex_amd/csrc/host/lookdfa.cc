@@ -407,6 +407,39 @@ void compareForwardNoLaterEnd(const Automaton& r, const Automaton& t, size_t nsy
   }
 }
 
+// UseDFA without a reverse DFA (non-greedy quantifiers, meta/compile.go:184-205) and without a prefilter: the reference asks
+// DFA.IsMatchAt first (find_indices.go:396-403 -> lazy.go:561-828 searchEarliestMatch: true at the first match-tagged state, at
+// a boundary flag, or at the end of input; false when the walk dies) and runs its PikeVM — leftmost-first — only on a yes.  A
+// wrong yes costs nothing (the PikeVM then finds nothing); a wrong no loses the match.  So: wherever T raises a flag, R must have
+// raised one or be unable to avoid raising one, and R must not die while T can still raise one.
+void compareForwardNoMiss(const Automaton& r, const Automaton& t, size_t nsym) {
+  const std::vector<uint8_t> canAvoid = statesThatCanAvoidFlags(r, nsym);
+  std::set<std::pair<int32_t, int32_t>> seen;
+  std::vector<std::pair<int32_t, int32_t>> todo;
+  for (int k = 0; k < 4; k++) {
+    for (size_t s = 0; s <= nsym; s++)
+      if (t.flag[static_cast<size_t>(t.start[k])][s] || r.flag[static_cast<size_t>(r.start[k])][s]) throw Refuse{"pattern matches the empty string at some position (nullable)"};
+    if (seen.emplace(r.start[k], t.start[k]).second) todo.emplace_back(r.start[k], t.start[k]);
+  }
+  const char* why = "the reference's DFA.IsMatchAt can miss a match of this program (look-aware lazy DFA), and the PikeVM is then never asked";
+  while (!todo.empty()) {
+    const auto [rs, ts] = todo.back();
+    todo.pop_back();
+    for (size_t s = 0; s <= nsym; s++) {
+      const bool rf = r.flag[static_cast<size_t>(rs)][s] != 0, tf = t.flag[static_cast<size_t>(ts)][s] != 0;
+      if (rf) continue;                                                       // IsMatchAt says yes here
+      const int32_t rn = s < nsym ? r.next[static_cast<size_t>(rs)][s] : -1;
+      const bool rCanStayQuiet = s == nsym || rn < 0 || canAvoid[static_cast<size_t>(rn)];
+      if (tf) { if (rCanStayQuiet) throw Refuse{why}; continue; }             // a real match: R must be bound to say yes later
+      if (s == nsym) continue;
+      const int32_t tn = t.next[static_cast<size_t>(ts)][s];
+      if (tn < 0 || !t.live[static_cast<size_t>(tn)]) continue;               // no match on this input any more
+      if (rn < 0 || !r.live[static_cast<size_t>(rn)]) throw Refuse{why};      // R is done, T is not
+      if (seen.emplace(rn, tn).second) todo.emplace_back(rn, tn);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------- reverse
 // Backwards from a match end: the reference's reverse DFA passes every assertion (they became epsilon edges) and reports the
 // smallest start it accepts; leftmost-first needs the smallest start of a real match.  States are sets here (no priorities:
@@ -521,12 +554,14 @@ Symbols symbolsOf(const cxg_nfa& nfa) {
 
 }  // namespace
 
-void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse) {
+void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse, bool existenceOnly) {
   const Symbols sy = symbolsOf(nfa);
   try {
     const Automaton r = buildReference(nfa, nfa.start_unanchored, sy.reps, sy.classOf, sy.hasWordB, sy.hasEndLine);
     const Automaton t = buildLeftmostFirst(nfa, nfa.start_unanchored, sy.reps);
-    if (reverse) {
+    if (existenceOnly) {
+      compareForwardNoMiss(r, t, sy.reps.size());
+    } else if (reverse) {
       compareForward(r, t, sy.reps.size());
       compareReverse(*reverse, sy.reps);
     } else {

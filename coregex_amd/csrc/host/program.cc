@@ -667,9 +667,13 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         // only for some programs and history-free only when its byte classes are pure in word-ness / newline-ness
         // (lookdfa.cc).  Those that pass the proof are the pattern's transducer, like a UseNFA program; UseBoth keeps its
         // 100-byte restart span.  UseDFA without the reverse DFA (non-greedy quantifiers) first asks DFA.IsMatchAt
-        // (find_indices.go:396-403), a third search loop with its own boundary shortcuts: not modelled, refused.
-        if (strategy == CXG_USE_DFA && !(flags & CXG_FLAG_HAS_REVERSE_DFA))
-          throw BuildError{CXG_E_UNSUPPORTED, "assertions in a UseDFA program without reverse DFA (the reference's IsMatchAt loop is not modelled)"};
+        // (find_indices.go:396-403) and then runs its PikeVM: served when that question provably never gets a wrong "no".
+        // (With a prefilter the reference skips the question, :381-393; the ABI does not say, so the proof is asked for anyway.)
+        if (strategy == CXG_USE_DFA && !(flags & CXG_FLAG_HAS_REVERSE_DFA)) {
+          refuseLookDfaQuirks(nfa, nullptr, true);
+          finishFsmOnly(0u);
+          return;
+        }
         HostNfa rn = reverseOf(nfa);
         cxg_nfa rvw = rn.view();
         refuseLookDfaQuirks(nfa, strategy == CXG_USE_DFA ? &rvw : nullptr);

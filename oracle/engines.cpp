@@ -267,6 +267,47 @@ int64_t LazyDFA::searchAt(Bytes h, int64_t n, int64_t at) {
   return lastMatch;
 }
 
+bool LazyDFA::isMatchAt(Bytes h, int64_t n, int64_t at) {
+  // IsMatchAt lazy.go:546-557 -> searchEarliestMatch :561-828: true at the first match-tagged state, at a byte at which the
+  // boundary flags of the state hold (checkWordBoundaryFast, the flags determinize stored: a start state has none), or at
+  // the end of input through checkEOIMatch; false when the walk dies.  With a prefilter a dead walk restarts at the next
+  // candidate (:805-825) and a start-tagged state skips ahead (:682-700).
+  if (at > n) return false;
+  if (at == n) return matchesEmpty();
+  if (nfa->anchored && at > 0) return false;
+  int32_t sid = startState(h, at, false);
+  int64_t pos = at;
+  while (pos < n) {
+    if (states[sid].startTagged) {
+      if (prefilterFind && pos > at) {
+        const int64_t cand = prefilterFind(h, n, pos);
+        if (cand == -1) return false;
+        if (cand > pos) { pos = cand; sid = startState(h, pos, false); continue; }
+      }
+      const int32_t t = states[sid].trans[nfa->byteClasses[h[pos]]];
+      if (t != kUnknown && t != kDead) { sid = t; pos++; if (states[sid].isMatch) return true; continue; }
+    }
+    const uint8_t b = h[pos];
+    if (hasWordBoundary) {
+      const DState& st = states[sid];
+      if (!st.isMatch && ((st.isFromWord != isWordByte(b)) ? st.matchAtWordBoundary : st.matchAtNonWordBoundary)) return true;
+    }
+    const int32_t nx = next(sid, b);
+    if (nx == kDead) {
+      if (!prefilterFind) return false;
+      pos++;
+      if (pos >= n) return false;
+      const int64_t cand = prefilterFind(h, n, pos);
+      if (cand == -1) return false;
+      pos = cand; sid = startState(h, pos, false);
+      continue;
+    }
+    sid = nx; pos++;
+    if (states[sid].isMatch) return true;
+  }
+  return eoiMatch(sid);
+}
+
 int64_t LazyDFA::searchReverse(Bytes h, int64_t n, int64_t start, int64_t end) {
   if (end <= start || end > n) return -1;
   // getStartStateForReverse lazy.go:2123-2158: the kind of the byte at `end` (StartText at the end of the haystack).

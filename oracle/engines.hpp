@@ -77,6 +77,7 @@ struct LazyDFA {
 
   int64_t searchAtAnchored(Bytes h, int64_t n, int64_t at);   // lazy.go:219
   int64_t searchAt(Bytes h, int64_t n, int64_t at);           // lazy.go:190 -> :1102
+  bool isMatchAt(Bytes h, int64_t n, int64_t at);             // lazy.go:546 -> :561 searchEarliestMatch
   int64_t searchReverse(Bytes h, int64_t n, int64_t start, int64_t end);  // lazy.go:1769
   size_t numStates() const { return states.size(); }
 

@@ -674,11 +674,10 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
           e->hasReverseDFA = true;
         } else if (e->nfa.hasLook && !hasPrefilter) {
           // No reverse DFA and no prefilter: findIndicesDFAAtWithState first asks DFA.IsMatchAt (find_indices.go:396-403 ->
-          // lazy.go:561-828 searchEarliestMatch), a third search loop over the same cache with its own boundary shortcuts.  Not
-          // restated; without assertions it cannot miss a match, with them it can (per-class transition cache).  The PikeVM
-          // answers below — leftmost-first, not necessarily the reference's answer.  (With a prefilter the reference goes
-          // prefilter -> PikeVM, :381-393, and no DFA is involved.)
-          e->strategyRestated = false;
+          // lazy.go:561-828 searchEarliestMatch) and gives up when that says no; without assertions it cannot miss a match,
+          // with them it can (per-class transition cache, boundary flags).  Restated: LazyDFA::isMatchAt, used in findAt below.
+          // (With a prefilter the reference goes prefilter -> PikeVM, :381-393, and no DFA is involved.)
+          e->dfaGatesPikeVM = true;
         }
       }
       break;
@@ -756,6 +755,7 @@ bool Engine::findAt(Bytes h, int64_t len, int64_t at, int64_t& s, int64_t& e) {
         if (st < 0) return false;
         s = st; e = end; return true;
       }
+      if (dfaGatesPikeVM && at < len && !dfa.isMatchAt(h, len, at)) return false;   // find_indices.go:396-400
       return pikevm.searchAt(h, len, at, s, e);
     case UseBoth:  // findIndicesAdaptiveAtWithState :408-441
       if (dfa.nfa && prefixes.empty()) {

@@ -49,6 +49,7 @@ struct Engine {
   NFA nfa, revNfa;
   Strategy strategy = UseNFA;
   bool strategyRestated = true;
+  bool dfaGatesPikeVM = false;   // UseDFA over assertions, no reverse DFA, no prefilter: DFA.IsMatchAt decides whether the PikeVM runs
   Seq prefixes;
   bool digitRunSkipSafe = false;
   bool teddyLineAnchor = false;   // UseTeddy behind (?m)^: prefilter.WrapLineAnchor (compile.go:670-677, prefilter/wrap.go:45-66)
