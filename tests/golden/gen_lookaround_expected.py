@@ -20,7 +20,10 @@ PAIRS = [
     # word boundaries (meta/stdlib_compat_test.go:27-67 word_boundary `\btest\b` and neighbours)
     (r"\btest\b", "test testing atest test_ test-case (test) test"), (r"\Btest", "test atest _test 9test"),
     (r"test\B", "test tests test_ test9 test"), (r"\b\d+\b", "12 a12 12a 1_2 3.4 567"), (r"\b[a-z]+\b", "ab cd_ef gh9 ij-kl"),
-    # edge_cases_test.go:245-249 TestWordBoundaryCornerCases (the non-nullable rows) and :346-347 (issue 12)
+]
+# edge_cases_test.go:245-249 TestWordBoundaryCornerCases (the non-nullable rows) and :346-347 (issue 12): transcribed after the round's
+# last device run, so the device sees them in tests/test_zz_gpu_look_wider.py (last in order), the twin and the oracle at once.
+MORE_PAIRS = [
     (r"\bword\b", "a word here"), (r"\bword\b", "word"), (r"\bword\b", "wording"), (r"\Bword\B", "swordfish"), (r"\Bword\B", "word"), (r"\Bword", "swordfish"),
 ]
 # Rows the reference answers with its look-aware lazy DFA (UseDFA: prefilter restart, forward DFA, reverse DFA) and asserts equal to
@@ -37,14 +40,17 @@ def main():
         b = inp.encode()
         cases.append({"pattern": pat, "input": inp, "want": [[m.start(), m.end()] for m in re.finditer(pat.encode(), b)]})
     v["lookaround_compat"] = {
-        "source": "edge_cases_test.go:96-125,245-249,346-347, stdlib_compat_test.go:1441-1442, meta/stdlib_compat_test.go:27-67 (pairs); expected spans by "
+        "source": "edge_cases_test.go:96-125, stdlib_compat_test.go:1441-1442, meta/stdlib_compat_test.go:27-67 (pairs); expected spans by "
                   "Python re on bytes (tests/golden/gen_lookaround_expected.py) — the reference's tests assert equality with Go regexp",
         "cases": cases}
+    v["lookaround_compat_more"] = {
+        "source": "edge_cases_test.go:245-249,346-347 (compareWithStdlib pairs); expected spans by Python re on bytes",
+        "cases": [{"pattern": pat, "input": inp, "want": [[m.start(), m.end()] for m in re.finditer(pat.encode(), inp.encode())]} for pat, inp in MORE_PAIRS]}
     v["lookaround_compat_lazy_dfa"] = {
         "source": "edge_cases_test.go:377 (compareWithStdlib: FindAllStringIndex equal to Go regexp); expected spans by Python re on bytes",
         "cases": [{"pattern": pat, "input": inp, "want": [[m.start(), m.end()] for m in re.finditer(pat.encode(), inp.encode())]} for pat, inp in LAZY_DFA_PAIRS]}
     json.dump(v, open(path, "w"), indent=1)
-    print(len(cases), "rows +", len(LAZY_DFA_PAIRS))
+    print(len(cases), "rows +", len(MORE_PAIRS), "+", len(LAZY_DFA_PAIRS))
 
 if __name__ == "__main__":
     main()

@@ -83,7 +83,7 @@ def test_lookaround_golden_rows_on_the_twin():
     import json
     vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
     n = 0
-    for c in vec["lookaround_compat"]["cases"]:
+    for c in vec["lookaround_compat"]["cases"] + vec["lookaround_compat_more"]["cases"]:
         rx = cx.compile(c["pattern"])
         assert rx.supported, (c["pattern"], rx.why_unsupported)
         for tile, chunk in ((3840, 32), (64, 8), (32, 4)):

@@ -96,7 +96,7 @@ def test_lookaround_compat_rows_answered_by_the_lazy_dfa(oracle):
 
 def test_lookaround_compat(oracle):
     """(?m)^ (?m)$ \\b \\B: the reference's own differential pairs, spans by Python re (gen_lookaround_expected.py)."""
-    for c in VEC["lookaround_compat"]["cases"]:
+    for c in VEC["lookaround_compat"]["cases"] + VEC["lookaround_compat_more"]["cases"]:
         got = oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist()
         assert got == c["want"], c
 

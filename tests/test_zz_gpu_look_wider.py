@@ -42,3 +42,17 @@ def test_captures_of_look_programs(oracle, pat):
         exp = o.find_all_submatch_index(hay)
         got = rx.find_all_submatch_index(hay)
         assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
+
+
+def test_more_lookaround_golden_rows_on_the_device():
+    """tests/golden "lookaround_compat_more": word-boundary pairs of the reference's differential tests (edge_cases_test.go:245-249,
+    346-347) with spans by Python re — device rows against the fixture, no oracle in between."""
+    import json, os, re as pyre
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    for c in vec["lookaround_compat_more"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        assert rx.supported, (c["pattern"], rx.why_unsupported)
+        hay = c["input"].encode()
+        assert rx.find_all_index(hay).tolist() == c["want"], c
+        big = (hay + b"\n") * 3000
+        assert rx.find_all_index(big).tolist() == [[m.start(), m.end()] for m in pyre.finditer(c["pattern"].encode(), big)], c["pattern"]
