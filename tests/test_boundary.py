@@ -29,6 +29,7 @@ NFA_PATTERNS = [
     # ... and UseDFA / UseBoth programs with assertions that pass the build-time proof of host/lookdfa.cc (the flags say whether e.reverseDFA exists)
     r"\buser=\w+ ip=\w+ status=\w+\b", r"\b\w+=\w+;\w+=\w+\b",
 ]
+ADMITTED_LATE = NFA_PATTERNS[-2:]     # after the round's last device run: their device pass is in tests/test_zz_gpu_look_wider.py
 
 
 def via_constructor(pat):
@@ -226,6 +227,7 @@ def test_constructor_programs_other_shapes(oracle):
     """Beyond the five configurations: non-chain DFAs, non-greedy, one-pass captures, required literal prefixes."""
     corpus = cx.synth_pages(2, 0xC0FFEE02, 0, 64).tobytes() + b" GET /a/b HTTP/1.1 k=12 ab abc aab abbc x1y22z 00:12:59 " * 50
     for pat in NFA_PATTERNS:
+        if pat in ADMITTED_LATE: continue
         eng, prog = via_constructor(pat)
         o = oracle.Regex(pat)
         if prog.supported:

@@ -56,3 +56,14 @@ def test_more_lookaround_golden_rows_on_the_device():
         assert rx.find_all_index(hay).tolist() == c["want"], c
         big = (hay + b"\n") * 3000
         assert rx.find_all_index(big).tolist() == [[m.start(), m.end()] for m in pyre.finditer(c["pattern"].encode(), big)], c["pattern"]
+
+
+def test_constructor_programs_admitted_late(oracle):
+    """cxg_program_from_nfa for the look-around programs of UseDFA / UseBoth in tests/test_boundary.py NFA_PATTERNS (same device
+    image as cxg_compile's, checked on the CPU tier)."""
+    import test_boundary as B
+    corpus = cx.synth_pages(2, 0xC0FFEE02, 0, 64).tobytes() + b" user=a ip=b status=c k=v;w=x a=b;c=d_ GET /a/b HTTP/1.1 k=12 " * 50
+    for pat in B.ADMITTED_LATE:
+        eng, prog = B.via_constructor(pat)
+        assert prog.supported, (pat, prog.why_unsupported)
+        assert np.array_equal(prog.find_all_index(corpus), oracle.Regex(pat).find_all_index(corpus)), pat
