@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void k_captures_lds(const uint8_t* hay, int64_
 // (device/bt.hpp).  One thread per row, grid-stride; every thread owns 16 KiB of scratch in HBM (visited bitmap + stack).
 // Two tiers: k_captures_bt_lds first (256 threads per workgroup, 256 bytes of LDS scratch per thread, the NFA image in LDS when
 // it fits: as many resident threads as the CUs hold), rows it cannot finish are marked and redone by k_captures_bt.
+template <bool LOOK>
 __global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int64_t hay_base, uint64_t hay_len, int64_t* rows, uint64_t nrows, uint32_t width,
                                                          const uint8_t* btblob, uint32_t img_lds_bytes, uint32_t* err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t s_bt[];   // [img_lds_bytes] image, then per-thread scratch
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int
     int64_t* row = rows + r * width;
 #pragma unroll
     for (uint32_t i = 0; i < cxgdev::kBtSmallVisited; i++) visited[i] = 0u;
-    const uint32_t rc = cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtSmallVisited, cxgdev::kBtSmallStack,
+    const uint32_t rc = cxgdev::bt_captures<LOOK>(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtSmallVisited, cxgdev::kBtSmallStack,
                                             hay_base, hay_base + static_cast<int64_t>(hay_len));   // (bounds: read by assertion states only)
     if (rc == 1u) row[2] = cxgdev::kBtRowPending;                 // left to the large tier (its slots are rewritten there)
     else bad |= rc;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void k_captures_bt_lds(const uint8_t* hay, int
   if (bad & 2u) cxgdev::raise_err(err, 4u);
 }
 
+template <bool LOOK>
 __global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t hay_base, uint64_t hay_len, int64_t* rows, uint64_t nrows, uint32_t width,
                                                     const uint8_t* btblob, uint8_t* scratch, uint32_t* err) {
   const cxgdev::BtHeader* h = reinterpret_cast<const cxgdev::BtHeader*>(btblob);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(64) void k_captures_bt(const uint8_t* hay, int64_t 
     const uint64_t bits = (static_cast<uint64_t>(row[1] - row[0]) + 1) * h->n_states;
     const uint32_t nw = bits > static_cast<uint64_t>(cxgdev::kBtVisitedWords) * 32u ? 0u : static_cast<uint32_t>((bits + 31) >> 5);
     for (uint32_t i = 0; i < nw; i++) visited[i] = 0u;
-    bad |= cxgdev::bt_captures(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtVisitedWords, cxgdev::kBtStackEntries,
+    bad |= cxgdev::bt_captures<LOOK>(h, hay - hay_base, row, width, visited, stack, cxgdev::kBtVisitedWords, cxgdev::kBtStackEntries,
                                hay_base, hay_base + static_cast<int64_t>(hay_len));   // rows hold absolute offsets (hay_base added)
   }
   if (bad & 1u) cxgdev::raise_err(err, cxgdev::kErrSerialLimit);   // a match too long for the per-row budget: this haystack is left to the caller
@@ -522,9 +524,12 @@ relaunch:
           int dev = 0, cus = 256;
           if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
           const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * 2u));
-          hipLaunchKernelGGL(k_captures_bt_lds, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
+          if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt_lds<true>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
+          else hipLaunchKernelGGL(k_captures_bt_lds<false>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
         }
-        hipLaunchKernelGGL(k_captures_bt, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+        // (patterns without assertions run the instantiation without the assertion branch: the walk of round 2's device runs)
+        if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt<true>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+        else hipLaunchKernelGGL(k_captures_bt<false>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
       } else if (lds_ok && a.row_width <= 8) {
         const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
         hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);

@@ -54,7 +54,9 @@ constexpr int64_t kBtRowPending = -0x7FFFFFFFFFFFFFFFll - 1;   // row[2] of a ro
 // positions the haystack buffer covers (only read by LOOK states).
 CXG_BT_HD bool bt_word_byte(uint32_t b) { return (b - '0' < 10u) || ((b | 0x20u) - 'a' < 26u) || b == '_'; }
 
-template <class Visited, class Stack>
+// LOOK = false compiles the walk without the assertion branch: the instantiation for patterns that hold none (a LOOK state then
+// ends the path, as every other kind the walk does not know).
+template <bool LOOK, class Visited, class Stack>
 CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* row, uint32_t nslots, Visited visited, Stack stack,
                                uint32_t visited_words = kBtVisitedWords, uint32_t stack_entries = kBtStackEntries,
                                int64_t hay_lo = 0, int64_t hay_hi = 0) {
@@ -116,7 +118,7 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
           row[slot] = s + static_cast<int64_t>(off);
         }
         q = x.next;
-      } else if (x.kind == 7 /*LOOK*/) {
+      } else if (LOOK && x.kind == 7 /*LOOK*/) {
         const int64_t pos = s + static_cast<int64_t>(off);
         const bool has_left = pos > hay_lo, has_right = pos < hay_hi;
         const uint32_t left = has_left ? hay[pos - 1] : '\n', right = has_right ? hay[pos] : '\n';

@@ -1152,6 +1152,7 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
       bh.total_bytes = static_cast<uint32_t>(bb.size());
       std::memcpy(bb.data(), &bh, sizeof bh);
       p->capBlob.swap(bb);
+      p->capHasLook = hasLook;
       std::memset(p->chainCaps, 0, sizeof p->chainCaps);
       (void)onePassErr;
     }

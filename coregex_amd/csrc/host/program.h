@@ -58,6 +58,7 @@ struct cxg_program {
   std::string subWhyNot;
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
+  bool capHasLook = false;       // the backtracking image holds assertion states: capi.hip launches the LOOK instantiation of its kernels
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: the chain kernel overflowed its row buffers on this
                                                               // program's input once: later calls start with two tiles per wave (capi.hip)
   uint8_t chainBounds[40] = {0}; // cxgdev::ChainCaps with on == 2: field bounds of a bounded-repetition program (kFlagChainBounded)

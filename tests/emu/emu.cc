@@ -135,10 +135,10 @@ extern "C" int64_t emu_find_all_submatch(const uint8_t* span_blob, const uint8_t
       row[0] = spans[2 * i]; row[1] = spans[2 * i + 1];
       std::fill(visited.begin(), visited.end(), 0u);
       // the kernel's two tiers: small scratch first (k_captures_bt_lds), rows that do not fit again with the large one
-      uint32_t rc = bt_captures(bh, hay, row, w, visited.data(), stack.data(), kBtSmallVisited, kBtSmallStack);
+      uint32_t rc = bt_captures<false>(bh, hay, row, w, visited.data(), stack.data(), kBtSmallVisited, kBtSmallStack);
       if (rc == 1u) {
         std::fill(visited.begin(), visited.end(), 0u);
-        rc = bt_captures(bh, hay, row, w, visited.data(), stack.data());
+        rc = bt_captures<false>(bh, hay, row, w, visited.data(), stack.data());
       }
       if (rc) return -3 - static_cast<int64_t>(rc);
     }
@@ -171,10 +171,10 @@ extern "C" int64_t emu_captures_bt(const uint8_t* cap_blob, const uint8_t* hay, 
     int64_t* row = out + i * w;
     row[0] = spans[2 * i]; row[1] = spans[2 * i + 1];
     std::fill(visited.begin(), visited.end(), 0u);
-    uint32_t rc = bt_captures(bh, hay, row, w, visited.data(), stack.data(), kBtSmallVisited, kBtSmallStack, static_cast<int64_t>(0), static_cast<int64_t>(len));
+    uint32_t rc = bt_captures<true>(bh, hay, row, w, visited.data(), stack.data(), kBtSmallVisited, kBtSmallStack, static_cast<int64_t>(0), static_cast<int64_t>(len));
     if (rc == 1u) {
       std::fill(visited.begin(), visited.end(), 0u);
-      rc = bt_captures(bh, hay, row, w, visited.data(), stack.data(), kBtVisitedWords, kBtStackEntries, static_cast<int64_t>(0), static_cast<int64_t>(len));
+      rc = bt_captures<true>(bh, hay, row, w, visited.data(), stack.data(), kBtVisitedWords, kBtStackEntries, static_cast<int64_t>(0), static_cast<int64_t>(len));
     }
     if (rc) return -3 - static_cast<int64_t>(rc);
   }
