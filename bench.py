@@ -58,7 +58,14 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (one rank per GPU); gloo + --stub-scan: launcher test on CPU")
+    ap.add_argument("--stub-scan", action="store_true", help="tests only: no device work, every step sleeps 1 ms (exercises launcher, barriers and the JSON line on CPU)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_one_rank_per_gpu(args.gpus, args.stub_scan)          # does not return
 
     import numpy as np
     import torch
@@ -66,13 +73,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (plain `python bench.py --gpus N` does that itself)")
+    if args.stub_scan:
+        return _stub_main(args, rank, world)
     dist = None
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible) — refusing to share a device")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max-over-ranks only
+        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max-over-ranks only
 
     import coregex_amd as cx
     cx.set_device(local_rank)
@@ -202,6 +213,63 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.destroy_process_group()
+
+
+def _relaunch_one_rank_per_gpu(n, stub):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this very command line under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and become that launcher.  Fails loudly
+    when the node shows fewer than N devices — N ranks never share a GPU."""
+    import socket
+    if not stub:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"--gpus {n} but this node shows {have} GPU(s): one rank per GPU, no oversubscription")
+    with socket.socket() as s:                                       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # RCCL on this pool: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    os.execvpe(cmd[0], cmd, env)
+
+
+def _stub_main(args, rank, world):
+    """Launcher / protocol test without a device (tests/test_bench_launcher.py): the same barrier + max-over-ranks timing
+    and the same JSON keys as the real run, a step is a 1 ms sleep.  Marked `"data": "stub"` — never a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    nbytes = int(args.gib_per_gpu * (1 << 30)) // 4096 * 4096
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed * 1e3 / args.steps]
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        tk = torch.zeros(world, dtype=torch.float64)
+        tk[rank] = per_rank[0]
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        per_rank = tk.tolist()
+    if rank == 0:
+        print(json.dumps({"metric": "GB/s haystack scanned, FindAllIndex IP-regex", "value": round(nbytes * world / (elapsed / args.steps) / 1e9, 3),
+                          "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+                          "higher_is_better": True, "scaling": "strong" if args.total_gib > 0 else "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "stub", "config": {"workload": "launcher test: no scan", "rccl_world_size": world,
+                                                       "per_rank_kernel_ms": [round(x, 4) for x in per_rank]}}))
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,43 @@
+"""`python bench.py --gpus N` must start N ranks by itself: without WORLD_SIZE in the
+environment the script re-executes under torch.distributed.run, one rank per GPU.  Here on CPU: `--stub-scan` (no device
+work) over gloo, world size 2 — launcher, rendezvous, barriers, max-over-ranks timing and the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_plain_invocation_starts_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-scan"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                 # rank 0 prints, nobody else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["rccl_world_size"] == 2 and len(d["config"]["per_rank_kernel_ms"]) == 2
+    assert all(ms >= 1.0 for ms in d["config"]["per_rank_kernel_ms"])   # both ranks really stepped
+    assert d["data"] == "stub" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    # whole-job value: both ranks' bytes over the max-over-ranks time
+    assert abs(d["value"] - 2 * (1 << 30) / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 0.01
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "2", "--stub-scan"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+
+
+def test_more_ranks_than_gpus_is_refused():
+    # no GPU in the CPU tier: the real (non-stub) launcher must refuse instead of stacking ranks on one device
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "one rank per GPU" in r.stderr
