@@ -28,6 +28,8 @@ size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
+int fields_shape(const ChainAux& c);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
@@ -421,10 +423,12 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
+  bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
   int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
+  fieldsKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
@@ -483,7 +487,13 @@ relaunch:
       std::memcpy(a.caps, p->chainCaps, sizeof a.caps);
       fusedCaps = true;
     }
-    le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
+    // fields programs (one field class, one separator class: the headline `\d+\.\d+\.\d+\.\d+`): the forward-only kernel;
+    // match-dense input (a row buffer overflowed before) stays on the chain kernel's dense mode
+    static const bool fieldsOk = getenv("CXG_NO_FIELDS_KERNEL") == nullptr;
+    fieldsKernel = fieldsOk && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
+                   cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+    if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
+    else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
   else switch (h->kind) {
@@ -555,7 +565,7 @@ relaunch:
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
-    timing->kernel = static_cast<uint32_t>(gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+    timing->kernel = static_cast<uint32_t>(fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
   }
@@ -748,6 +758,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_DFA_TABLE: return "k_scan_dfa";
     case CXG_K_DIGIT_FLAT: return "k_scan_digit_flat";
     case CXG_K_CHAIN_WAVE: return "k_scan_chain_wave";
+    case CXG_K_FIELDS_WAVE: return "k_scan_fields_wave";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";

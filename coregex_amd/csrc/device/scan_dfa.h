@@ -15,7 +15,10 @@ constexpr int kGroupTiles = 8;                // tiles per workgroup in the grou
 constexpr int kWaveTile = 3840;
 constexpr int kWaveHalo = 256;
 constexpr int kWavesPerBlock = 4;
-constexpr int kTilesPerWave = 8;
+#ifndef CXG_TPW
+#define CXG_TPW 8                         // -DCXG_TPW=n: experiments with the group size (scripts/build_variant.sh), all sources
+#endif
+constexpr int kTilesPerWave = CXG_TPW;
 constexpr int kDenseTilesPerWave = 2;          // chain kernel on match-dense input: 256 rows of buffer per wave-tile instead of 64
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
 constexpr int kCcTilesPerWave = 4;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup

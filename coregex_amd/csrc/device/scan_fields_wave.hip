@@ -1,0 +1,444 @@
+// scan_fields_wave.hip — FindAll for "fields" programs: the complete ordered chain  run(F) (byte(S) run(F)){K-1}  with ONE
+// field class F and ONE separator class S, F and S disjoint: `\d+\.\d+\.\d+\.\d+` (BASELINE configs[1], the headline),
+// `\d+:\d+:\d+`, `\d+\.\d+`, `[a-f]+-[a-f]+`.  Seventh generation of the headline kernel (round 3): forward only.
+//
+// Reference semantics kept (meta/findall.go:176-283 over findIndicesDigitPrefilterAtWithState, meta/find_indices.go:1050-1088,
+// resp. the DFA searches of dfa/lazy/lazy.go for UseDFA programs): leftmost-first, non-empty, next search from the match end.
+//
+// Why no backward pass is needed.  Call a separator byte with a field byte on BOTH sides a LINK, and a maximal stretch of
+// field bytes and links a SUPER-RUN: f+ (s f+)*, n fields joined by n-1 links.  A match lies inside one super-run (all its
+// separators are links) and consists of K consecutive fields.  Leftmost-first from the super-run's first byte takes fields
+// 1..K; FindAll resumes at the end of field K, where a link follows (no match can start on it), so the next match is fields
+// K+1..2K, and so on: FindAll over a super-run = its fields in groups of K, from its START.  Nothing outside the super-run
+// matters, so the scan needs no synchronising byte and no ownership search: a wave-tile owns the super-runs that START in its
+// 3840 bytes.  (scan_chain_wave.hip proved every start by a right-to-left chain first and searched the ownership bounds
+// (zA, zB] in the synchronising bytes: 184 of its 515 VALU instructions per tile; this kernel has neither.)
+//
+// One wave64 per wave-tile; window = 64 bytes in front of the tile + 3840 + 192 behind = 4096 bytes = 64 bitmap words, word l
+// in lane l, lanes 1..60 own.  Per tile:
+//   A  class bitmaps D (field) and P (separator): SWAR compare + v_dot4_u32_u8 gather per dword, 16-bit pieces transposed
+//      through the wave's LDS scratch.  Each 16-byte vector is classified as soon as it has arrived and its register is
+//      refilled with the NEXT tile's vector at once: up to four loads per lane stay in flight through the whole tile.
+//   B  L = P & (D << 1) & (D >> 1) (links), WS = D & ~(D << 1) & ~(L << 1) (super-run starts), restricted to the owned lanes.
+//   C  markers M = WS hop over K fields: s = D + M (a multiword addition: the carry ripples through the field and lands behind
+//      it), then K-1 times M' = s & L, s = (D | M') + M' (the link bit is added to itself: the carry enters the next field).
+//      Carries between lanes: generate = the v_addc carry-out (an SGPR pair, no compare), propagate = words of 64 field
+//      bytes, resolved on the scalar unit, fed back as the carry-in of a second v_addc.  E = s & ~D = the match ends.
+//   D  an end that sits on a link (a super-run with more than K fields): the byte behind it starts the next group — rare
+//      loop, same hop.  B = all group starts.
+//   E  rows: per end bit, start = highest bit of B below it (this lane's word or the previous lane's), one packed
+//      (start | end << 16) store into the wave's row buffer at its rank (DPP prefix sum over the lanes' end counts).
+// A workgroup (4 waves x 8 tiles = 120 KiB) orders its rows after ONE barrier, looks back (block_common.hpp) and writes
+// coalesced int64 pairs, as scan_chain_wave.hip does.
+// Fallback flag (err bit 8; the host reruns the scan on scan_chain_wave.hip's dense mode resp. the transducer kernel): a
+// super-run that reaches past its window (> 192 bytes behind its tile), a match longer than its start search (64..127
+// bytes), row-buffer overflow (reason 0x10: match-dense input).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#include "block_common.hpp"
+#include "scan_dfa.h"
+#include "walk.hpp"
+#include "wave_common.hpp"
+
+#ifndef CXG_FIELDS_WAVES
+#define CXG_FIELDS_WAVES 8
+#endif
+// -DCXG_FABL=n (experiments only, results WRONG): 1 = no rows, 2 = no chain and no rows, 3 = no class masks either,
+// 4 = no LDS transpose either (the window is only read), 5 = 4 without barrier / look-back / epilogue
+#ifndef CXG_FABL
+#define CXG_FABL 0
+#endif
+// -DCXG_FIELDS_REISSUE=0 (experiment): the next tile's four loads are issued together behind the last class mask
+// -DCXG_FIELDS_DEPTH=2 (experiment): two window buffers, loads run two tiles ahead (16 more VGPRs)
+#ifndef CXG_FIELDS_DEPTH
+#define CXG_FIELDS_DEPTH 1
+#endif
+#ifndef CXG_FIELDS_REISSUE
+#define CXG_FIELDS_REISSUE 1
+#endif
+
+namespace cxgdev {
+
+namespace {
+
+constexpr int kFPre = 64;                                  // window bytes in front of the tile
+constexpr int kFWin = kWaveTile + kWaveHalo;               // 4096
+constexpr int kFRows = 64 * kTilesPerWave;                                // rows buffered per wave and group
+constexpr unsigned long long kFOwn = 0x1FFFFFFFFFFFFFFEull;   // lanes 1..60 own their words
+
+// 0x80 in every byte of x that IS in the class.
+template <int KIND>
+__device__ __forceinline__ uint32_t incls4(uint32_t x, uint32_t lo4, uint32_t hi4) {   // lo4 / hi4: bounds splat over the bytes (hi4 = 0x7F - hi)
+  if (KIND == kClsDigit) return ~((((x ^ 0x30303030u) & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u;
+  if (KIND == kClsByte) return ~((((x ^ lo4) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+  const uint32_t ge = (x | 0x80808080u) - lo4;
+  const uint32_t gt = (x & 0x7F7F7F7Fu) + hi4;
+  return ge & ~gt & ~x & 0x80808080u;
+}
+// 16 class bits of a 16-byte vector: the four flags of a dword are gathered by one v_dot4_u32_u8 (weights 1,2,4,8 resp.
+// 16,32,64,128: 128 x the byte of flags accumulates over a dword pair).  Bits above 15 are garbage (ds_write_b16 drops them).
+template <int KIND>
+__device__ __forceinline__ uint32_t piece16(const u32x4& x, uint32_t lo4, uint32_t hi4) {
+  const uint32_t lo = __builtin_amdgcn_udot4(incls4<KIND>(x.y, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.x, lo4, hi4), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(incls4<KIND>(x.w, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.z, lo4, hi4), 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1);
+}
+// (a1:a0) + (b1:b0) -> (s1:s0), carry-out of the 64-bit addition of every lane as a wave mask (the v_addc's own carry
+// output: no compare instruction).
+__device__ __forceinline__ void add64_co(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t& s0, uint32_t& s1, unsigned long long& cout) {
+  unsigned long long c0;
+  asm("v_add_co_u32_e64 %0, %2, %4, %5\n\tv_addc_co_u32_e64 %1, %3, %6, %7, %2"
+      : "=&v"(s0), "=&v"(s1), "=&s"(c0), "=&s"(cout)
+      : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+// (s1:s0) += bit `lane` of mask (carry-in straight from the scalar mask)
+__device__ __forceinline__ void add64_cin(uint32_t& s0, uint32_t& s1, unsigned long long mask) {
+  uint32_t lo, hi;
+  unsigned long long c;
+  asm("v_addc_co_u32_e64 %0, %2, %3, 0, %5\n\tv_addc_co_u32_e64 %1, %2, %4, 0, %2"
+      : "=&v"(lo), "=&v"(hi), "=&s"(c)
+      : "v"(s0), "v"(s1), "s"(mask));
+  s0 = lo; s1 = hi;
+}
+__device__ __forceinline__ uint32_t sel_lanes(uint32_t v, unsigned long long mask) {   // v in the lanes of mask, else 0
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ uint32_t ffbh_raw(uint32_t v) {   // leading zeros; 0xFFFFFFFF for v == 0 (the instruction's own convention)
+  uint32_t r;
+  asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t dpp_from_lower_z(uint32_t v) {   // lane i <- lane i-1, lane 0 <- 0
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, true));
+}
+__device__ __forceinline__ uint32_t dpp_from_upper_ones(uint32_t v) {   // lane i <- lane i+1, lane 63 <- all ones
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(-1, static_cast<int>(v), 0x130 /*wave_shl:1*/, 0xF, 0xF, false));
+}
+
+// Inclusive prefix sum over the 64 lanes with the addition inside the DPP instruction (wave_common.hpp's version costs a
+// v_mov_dpp + v_add per step: the compiler does not fuse them).  s_nop 1: two wait states between a VALU write and a DPP read.
+__device__ __forceinline__ uint32_t wave_inclusive_sum_fused(uint32_t v) {
+  asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+      : "+v"(v));
+  return v;
+}
+
+}  // namespace
+
+// K: number of fields (2..4).  KD / KP: kind of the field / separator class (walk.hpp ChainClassKind; kClsRange also
+// serves single bytes and digits as separators).
+template <int K, int KD, int KP>
+__global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];     // field-class bitmap of the wave's window
+  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64];     // separator-class bitmap
+  __shared__ uint32_t s_row[kWavesPerBlock][kFRows];                            // start | end << 16, window bit indices
+  __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
+  __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
+  __shared__ uint64_t s_group;
+  __shared__ uint64_t s_base;
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  uint64_t group = blockIdx.x;
+  if (!a.static_groups) {                                            // uniform: kernel argument
+    if (tid == 0) s_group = claim_group(false, a.ticket, a.ngroups);
+    __syncthreads();
+    group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  }
+  if (group >= a.ngroups) return;
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);   // kernel argument segment: scalar loads
+  const uint32_t dlo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[0] * 0x01010101u)));
+  const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
+  const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
+  const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
+  constexpr int tpw = kTilesPerWave;
+  uint32_t nrows_w = 0;                                              // wave-uniform
+  uint32_t fallback = 0;
+
+  // Window of wave-tile jj: haystack bytes [lo - 64, lo + 4032).  Buffer resource sized to the bytes that exist (rounded
+  // up to a dword): lanes past the end of the input read zeros, no tail path.  The window of the haystack's first tile
+  // starts 64 bytes in front of the haystack: those lanes are sent out of range (`first`, prologue only).
+  auto window_rsrc = [&](int jj, int32_t& nvalid) -> __amdgpu_buffer_rsrc_t {
+    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nrec = 0;
+    uint64_t wlo = 0;
+    nvalid = 0;
+    if (jj < tpw && lo < a.len) {
+      wlo = lo >= static_cast<uint64_t>(kFPre) ? lo - kFPre : 0;
+      const uint64_t rem = a.len - wlo;
+      const uint64_t full = static_cast<uint64_t>(kFWin) - (lo - wlo == 0 ? kFPre : 0);
+      nrec = rem >= full ? static_cast<int>(full) : static_cast<int>((rem + 3) & ~3ull);
+      const uint64_t nv = a.len - lo + kFPre;                          // window bytes that hold data or lie in front of the haystack
+      nvalid = nv >= static_cast<uint64_t>(kFWin) ? kFWin : static_cast<int32_t>(nv);
+    }
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + wlo, 0, nrec, 0x00020000);
+  };
+  u32x4 x[4];
+#if CXG_FIELDS_DEPTH == 2
+  u32x4 xb[4];                                                         // second window buffer: loads run two tiles ahead
+  int32_t nvalid_b = 0;
+#endif
+  uint32_t sink = 0;                                                   // ablations only
+  int32_t nvalid_a = 0;
+  {
+    const __amdgpu_buffer_rsrc_t r0 = window_rsrc(0, nvalid_a);
+    const bool first = group == 0 && wave == 0;                       // the haystack's first tile: window bytes 0..63 do not exist
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t off = static_cast<uint32_t>(lane + 64 * k) << 4;
+      if (first) off = off >= static_cast<uint32_t>(kFPre) ? off - kFPre : 0x7FFFFFF0u;
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, 0);
+    }
+#if CXG_FIELDS_DEPTH == 2
+    const __amdgpu_buffer_rsrc_t r1 = window_rsrc(1, nvalid_b);
+#pragma unroll
+    for (int k = 0; k < 4; k++) xb[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, static_cast<uint32_t>(lane + 64 * k) << 4, 0, 0);
+#endif
+  }
+
+  // One wave-tile: window j sits in x[] (or is about to arrive), x[] is refilled with window j + ahead.
+  auto tile = [&](const int j, u32x4 (&x)[4], int32_t& nvalid_cur, const int ahead) {
+    int32_t nvalid_next = 0;
+    // Opaque copy of the lane id per wave-tile: lane-derived values are recomputed (a few ALU ops) instead of being hoisted
+    // out of the loop and spilled — a scratch reload waits on vmcnt and would drain the loads in flight.
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const __amdgpu_buffer_rsrc_t rnext = window_rsrc(j + ahead, nvalid_next);
+    // ---- A: class pieces of each vector as it arrives; its register is refilled with the next tile's vector at once
+    {
+      uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
+      uint16_t* pp = reinterpret_cast<uint16_t*>(s_p[wave]);
+      const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (CXG_FABL >= 4) {
+          sink ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
+        } else if (CXG_FABL == 3) {
+          pd[lane + 64 * k] = static_cast<uint16_t>(x[k].x ^ x[k].z ^ x[k].y ^ x[k].w);
+          pp[lane + 64 * k] = 0;
+        } else {
+          pd[lane + 64 * k] = static_cast<uint16_t>(piece16<KD>(x[k], dlo4, dhi4));
+          pp[lane + 64 * k] = static_cast<uint16_t>(piece16<KP>(x[k], plo4, phi4));
+        }
+        if (CXG_FIELDS_REISSUE) {
+          x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);                            // keep the refill right behind its vector's last use
+        }
+      }
+      if (!CXG_FIELDS_REISSUE) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+      }
+    }
+    if (CXG_FABL >= 4) { nvalid_cur = nvalid_next; return; }
+    wave_lds_sync();
+    uint32_t emitted_here = 0;
+    {
+      int lw = lane;                                                  // second opaque copy: word address = base + 8 * lane by shift, not (piece address) + 6 * lane by v_mul_lo
+      asm volatile("" : "+v"(lw));
+      const uint64_t Dw = s_d[wave][lw], Pw = s_p[wave][lw];
+      uint32_t d0 = static_cast<uint32_t>(Dw), d1 = static_cast<uint32_t>(Dw >> 32);
+      uint32_t p0 = static_cast<uint32_t>(Pw), p1 = static_cast<uint32_t>(Pw >> 32);
+      if (nvalid_cur != kFWin) {                                      // short last window: the up to 3 bytes behind the input in its last dword are not data
+        const int32_t nf = nvalid_cur - 64 * lane;
+        const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+        d0 &= static_cast<uint32_t>(vf); d1 &= static_cast<uint32_t>(vf >> 32);
+        p0 &= static_cast<uint32_t>(vf); p1 &= static_cast<uint32_t>(vf >> 32);
+      }
+      // words of 64 field bytes pass a carry on (with no marker of their own; a word that generates needs no propagate)
+      const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
+      // ---- B: links and super-run starts
+      const uint32_t prev_d1 = dpp_from_lower(d1);                    // lane 0: its own word — that lane owns nothing
+      const uint32_t next_d0 = dpp_from_upper_ones(d0);               // lane 63: "a field byte follows the window": a link there sends its marker out of the window (fallback)
+      const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
+      const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
+      const uint32_t L0 = p0 & Dl0 & Dr0, L1 = p1 & Dl1 & Dr1;
+      const uint32_t prev_l1 = dpp_from_lower(L1);
+      const uint32_t Ll0 = __builtin_amdgcn_alignbit(L0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(L1, L0, 31);   // L << 1
+      uint32_t b0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), b1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // B: group starts (first: the owned super-run starts)
+      if (CXG_FABL >= 2) { b0 = 0; b1 = 0; }
+      // ---- C: hop over K fields
+      unsigned long long ovf = 0;                                     // bit 63: a marker left the window (scalar)
+      auto carry_in = [&](unsigned long long GG) -> unsigned long long {
+        const unsigned long long Pe = PPd & ~GG;
+        const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;        // lanes that receive a carry
+        ovf |= GG | (Pe & recv);                                      // lane 63 generates, or passes one on
+        return recv;
+      };
+      auto hop = [&](uint32_t m0, uint32_t m1, uint32_t& r0, uint32_t& r1) {
+        uint32_t s0, s1;
+        unsigned long long GG;
+        add64_co(d0, d1, m0, m1, s0, s1, GG);
+        add64_cin(s0, s1, carry_in(GG));
+#pragma unroll
+        for (int i = 1; i < K; i++) {
+          const uint32_t q0 = s0 & L0, q1 = s1 & L1;                  // markers that stand on a link
+          add64_co(d0 | q0, d1 | q1, q0, q1, s0, s1, GG);
+          add64_cin(s0, s1, carry_in(GG));
+        }
+        r0 = s0; r1 = s1;
+      };
+      uint32_t r0, r1;
+      hop(b0, b1, r0, r1);
+      uint32_t e0 = r0 & ~d0, e1 = r1 & ~d1;                          // ends (exclusive) of the first group of every owned super-run
+      uint32_t el0 = r0 & L0, el1 = r1 & L1;
+      // ---- D: super-runs with more than K fields (`1.2.3.4.5.6.7.8`): the byte behind an end that sits on a link starts the next group
+      while (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(el1) << 32) | el0, 0ull, 33 /*ne*/) != 0ull) {
+        const uint32_t prev_e1 = dpp_from_lower_z(el1);
+        if ((static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(el1), 63)) >> 31) != 0u) ovf |= 1ull << 63;
+        const uint32_t n0 = __builtin_amdgcn_alignbit(el0, prev_e1, 31), n1 = __builtin_amdgcn_alignbit(el1, el0, 31);
+        b0 |= n0; b1 |= n1;
+        hop(n0, n1, r0, r1);
+        e0 |= r0 & ~d0; e1 |= r1 & ~d1;
+        el0 = r0 & L0; el1 = r1 & L1;
+      }
+      if (ovf >> 63) fallback |= 1u;
+      // ---- E: rows
+      const uint32_t c = static_cast<uint32_t>(__popc(e0)) + static_cast<uint32_t>(__popc(e1));
+      const uint32_t incl = wave_inclusive_sum_fused(c);
+      uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      if (CXG_FABL >= 1) tot = 0;
+      if (tot != 0 && (a.out != nullptr || a.max_len != 0)) {
+        // start of the match that ends at bit b: the highest bit of B below b — in this word, else in the previous lane's
+        // (a start further back: the row comes out with start > end and the epilogue raises the fallback flag)
+        const uint32_t pb0 = dpp_from_lower_z(b0), pb1 = dpp_from_lower_z(b1);
+        const uint32_t lane64 = static_cast<uint32_t>(lane) << 6;
+        uint32_t r = nrows_w + incl - c;
+        uint32_t* rows = s_row[wave];
+        {
+          const uint32_t tp = min(ffbh_raw(pb1) | 32u, ffbh_raw(pb0) | 64u);
+          uint32_t xx = e0;
+          while (xx) {
+            const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+            xx &= xx - 1u;
+            const uint32_t d = min(ffbh_raw(b0 & ((1u << b) - 1u)), tp);
+            rows[min(r, static_cast<uint32_t>(kFRows - 1))] = (lane64 + 31u - d) | ((lane64 + b) << 16);   // overflow: flagged below, rows void
+            r++;
+          }
+        }
+        {
+          const uint32_t tp = min(min(ffbh_raw(b0) | 32u, ffbh_raw(pb1) | 64u), ffbh_raw(pb0) | 96u);
+          uint32_t xx = e1;
+          while (xx) {
+            const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+            xx &= xx - 1u;
+            const uint32_t d = min(ffbh_raw(b1 & ((1u << b) - 1u)), tp);
+            rows[min(r, static_cast<uint32_t>(kFRows - 1))] = (lane64 + 63u - d) | ((lane64 + 32u + b) << 16);
+            r++;
+          }
+        }
+      }
+      emitted_here = tot;
+    }
+    if (lane == 0) s_cnt[wave][j] = emitted_here;
+    nrows_w += emitted_here;
+    nvalid_cur = nvalid_next;
+  };
+#if CXG_FIELDS_DEPTH == 2
+  static_assert(tpw % 2 == 0, "two window buffers: an even number of tiles per wave");
+  for (int j = 0; j < tpw; j += 2) { tile(j, x, nvalid_a, 2); tile(j + 1, xb, nvalid_b, 2); }
+#else
+  for (int j = 0; j < tpw; j++) tile(j, x, nvalid_a, 1);
+#endif
+  if (CXG_FABL >= 4 && sink == 0x12345u) fallback |= 4u;              // keeps the loads alive
+  if (CXG_FABL == 5) { if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8)); return; }
+  if (CXG_FABL == 4 && lane0 == 0) { for (int j = 0; j < tpw; j++) s_cnt[wave][j] = 0; }
+  if (nrows_w > static_cast<uint32_t>(kFRows)) fallback |= 16u;
+  wave_lds_sync();
+  {                                                                   // rows whose start was not found (start > end), UseBoth restart span
+    bool bad = false, long_hit = false;
+    if (a.out != nullptr || a.max_len != 0) {
+      for (uint32_t r = lane0; r < nrows_w && r < static_cast<uint32_t>(kFRows); r += 64) {
+        const uint32_t v = s_row[wave][r];
+        const uint32_t s = v & 0xFFFFu, e = v >> 16;
+        bad = bad || s >= e;
+        long_hit = long_hit || (a.max_len != 0 && e - s > a.max_len);
+      }
+    }
+    if (__ballot(bad) != 0ull) fallback |= 2u;
+    if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+  }
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+  __syncthreads();
+
+  // ---- order the group's rows: wave-tile q = j*4 + wave; exclusive prefix over q
+  if (tid < 64) {
+    const int q = tid;
+    const uint32_t v = (q < kWavesPerBlock * tpw) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t incl = wave_inclusive_sum(v);
+    if (q < kWavesPerBlock * tpw) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * tpw - 1) s_qbase[kWavesPerBlock * tpw] = incl;
+  }
+  __syncthreads();
+  const uint32_t total = s_qbase[kWavesPerBlock * tpw];
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
+  if (a.out == nullptr) return;
+  const uint64_t base = s_base;
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw) - kFPre;
+  uint32_t start = 0;
+  for (int j = 0; j < tpw; j++) {
+    const uint32_t n = s_cnt[wave][j];
+    const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
+    const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+    for (uint32_t i = lane0; i < n; i += 64) {
+      const uint32_t r = start + i;
+      if (r < static_cast<uint32_t>(kFRows) && dst + i < a.cap) {
+        const uint32_t v = s_row[wave][r];
+        longlong2 o; o.x = tb + (v & 0xFFFFu); o.y = tb + (v >> 16);
+        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = o;
+      }
+    }
+    start += n;
+  }
+}
+
+// Does the chain have the shape this kernel evaluates?  run(0) (byte(1) run(0)){K-1}, two classes of one range each,
+// disjoint, K = 2..4, no restart check.  Returns K, else 0.
+int fields_shape(const ChainAux& c) {
+  if (c.ncls != 2 || (c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7 || c.restart_check) return 0;
+  for (uint32_t k = 0; k < c.nops; k++) {
+    if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return 0;
+    if (c.op_cls[k] != (k & 1u)) return 0;
+  }
+  for (int q = 0; q < 2; q++) if (c.cls_kind[q] == kClsSet || c.cls_hi[q] > 0x7Fu || c.cls_lo[q] > c.cls_hi[q]) return 0;
+  if (c.cls_lo[0] <= c.cls_hi[1] && c.cls_lo[1] <= c.cls_hi[0]) return 0;   // the classes meet
+  return static_cast<int>((c.nops + 1) / 2);
+}
+
+namespace {
+template <int K>
+void launch_fields_k(const ScanArgs& a, uint32_t kd, uint32_t kp, dim3 grid, dim3 block, hipStream_t stream) {
+  const bool dd = kd == kClsDigit, pb = kp == kClsByte;
+  if (dd && pb) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsDigit, kClsByte>), grid, block, 0, stream, a);
+  else if (dd) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsDigit, kClsRange>), grid, block, 0, stream, a);
+  else if (pb) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsRange, kClsByte>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((k_scan_fields_wave<K, kClsRange, kClsRange>), grid, block, 0, stream, a);
+}
+}  // namespace
+
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
+  const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
+  const int k = fields_shape(c);
+  const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  switch (k) {
+    case 2: launch_fields_k<2>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
+    case 3: launch_fields_k<3>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
+    case 4: launch_fields_k<4>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace cxgdev

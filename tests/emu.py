@@ -27,6 +27,10 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int64
             f.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.emu_find_all_fields.restype = C.c_int64
+        L.emu_find_all_fields.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
+        L.emu_fields_shape.restype = C.c_int
+        L.emu_fields_shape.argtypes = [C.c_char_p]
         L.emu_find_all_fsm.restype = C.c_int64
         L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
@@ -165,5 +169,26 @@ def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: i
         if n <= cap:
             if stats is not None:
                 stats[:] = st
+            return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
+
+
+def fields_shape(blob: bytes) -> int:
+    """Number of fields when scan_fields_wave.hip serves the program (run(F) (byte(S) run(F))*, two disjoint classes), else 0."""
+    return int(lib().emu_fields_shape(blob))
+
+
+def find_all_fields(blob: bytes, hay, own_words: int = 60):
+    """Sequential twin of scan_fields_wave.hip.  Returns None where a tile would raise the fallback flag."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_fields(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words))
+        if n <= -16:
+            return None
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
             return out[:n].reshape(-1, 2).copy()
         cap = int(n)

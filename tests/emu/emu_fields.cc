@@ -1,0 +1,152 @@
+// TEST INFRASTRUCTURE ONLY — sequential twin of coregex_amd/csrc/device/scan_fields_wave.hip.
+//
+// The same steps as the kernel, word by word over "lanes" 0..63 of a 4096-byte window: class bitmaps, links, super-run
+// starts of the owned lanes, the K-field hop as multiword additions with the kernel's generate / propagate carry
+// resolution, the rare loop for super-runs with more than K fields, and the start search of every end in the bitmap of
+// group starts (this lane's word, else the previous lane's).  Returns -(16 + reason) where the kernel would raise its
+// fallback flag.  `own_words` (60 on the device) is a parameter so that the CPU tests put many more tile borders on a
+// kilobyte of text.  Nothing in coregex_amd/ links or loads this file.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../coregex_amd/csrc/device/scan_dfa.h"
+#include "../../coregex_amd/csrc/device/walk.hpp"
+
+using namespace cxgdev;
+
+namespace {
+int fields_shape_host(const ChainAux& c) {      // scan_fields_wave.hip fields_shape
+  if (c.ncls != 2 || (c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7 || c.restart_check) return 0;
+  for (uint32_t k = 0; k < c.nops; k++) {
+    if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return 0;
+    if (c.op_cls[k] != (k & 1u)) return 0;
+  }
+  for (int q = 0; q < 2; q++) if (c.cls_kind[q] == kClsSet || c.cls_hi[q] > 0x7Fu || c.cls_lo[q] > c.cls_hi[q]) return 0;
+  if (c.cls_lo[0] <= c.cls_hi[1] && c.cls_lo[1] <= c.cls_hi[0]) return 0;
+  return static_cast<int>((c.nops + 1) / 2);
+}
+inline uint32_t ffbh_raw(uint32_t v) { return v ? static_cast<uint32_t>(__builtin_clz(v)) : 0xFFFFFFFFu; }
+inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+}  // namespace
+
+extern "C" int emu_fields_shape(const uint8_t* blob) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || !(h->flags & kFlagChainOrdered) || (h->flags & (kFlagChainBounded | kFlagChainSets))) return 0;
+  return fields_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));
+}
+
+extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic) return -1;
+  if (!(h->flags & kFlagChainOrdered)) return -4;
+  const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
+  const int K = fields_shape_host(ch);
+  if (!K) return -5;
+  if (own_words < 1 || own_words > 62) return -2;
+  const int NW = 64;
+  const int64_t tile_bytes = 64LL * own_words, pre = 64, N = 64LL * NW;
+  const unsigned long long own_mask = ((own_words == 63 ? ~0ull : ((1ull << own_words) - 1ull)) << 1);   // lanes 1..own_words
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_lo = static_cast<int64_t>(t) * tile_bytes;
+    const int64_t wlo = tile_lo - pre;                                 // haystack position of window bit 0
+    uint64_t D[64] = {0}, P[64] = {0};
+    for (int64_t b = 0; b < N; b++) {
+      const int64_t p = wlo + b;
+      if (p < 0 || p >= static_cast<int64_t>(len)) continue;           // in front of the haystack / past the input: no class
+      if (chain_class_has(ch, 0, hay[p])) D[b >> 6] |= 1ull << (b & 63);
+      if (chain_class_has(ch, 1, hay[p])) P[b >> 6] |= 1ull << (b & 63);
+    }
+    unsigned long long PPd = 0;
+    for (int l = 0; l < 64; l++) if (D[l] == ~0ull) PPd |= 1ull << l;
+    uint64_t L[64], B[64];
+    for (int l = 0; l < 64; l++) {
+      const uint64_t prev_top = l ? (D[l - 1] >> 63) : (D[0] >> 63);   // lane 0 sees its own word (DPP keeps the old value): it owns nothing
+      const uint64_t next_bot = l < 63 ? (D[l + 1] & 1ull) : 1ull;     // behind the window: "a field byte follows"
+      const uint64_t Dl = (D[l] << 1) | prev_top, Dr = (D[l] >> 1) | (next_bot << 63);
+      L[l] = P[l] & Dl & Dr;
+    }
+    for (int l = 0; l < 64; l++) {
+      const uint64_t prev_top = l ? (D[l - 1] >> 63) : (D[0] >> 63);
+      const uint64_t prev_ltop = l ? (L[l - 1] >> 63) : (L[0] >> 63);
+      const uint64_t Dl = (D[l] << 1) | prev_top, Ll = (L[l] << 1) | prev_ltop;
+      B[l] = ((own_mask >> l) & 1ull) ? (D[l] & ~Dl & ~Ll) : 0ull;
+    }
+    unsigned long long ovf = 0;
+    auto carry_in = [&](unsigned long long GG) {
+      const unsigned long long Pe = PPd & ~GG;
+      const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;
+      ovf |= GG | (Pe & recv);
+      return recv;
+    };
+    auto add_words = [&](const uint64_t* A, const uint64_t* Bv, uint64_t* S) {   // per-lane 64-bit addition + the kernel's carry resolution
+      unsigned long long GG = 0;
+      for (int l = 0; l < 64; l++) {
+        const unsigned __int128 s = static_cast<unsigned __int128>(A[l]) + Bv[l];
+        S[l] = static_cast<uint64_t>(s);
+        if (s >> 64) GG |= 1ull << l;
+      }
+      const unsigned long long recv = carry_in(GG);
+      for (int l = 0; l < 64; l++) S[l] += (recv >> l) & 1ull;
+    };
+    auto hop = [&](const uint64_t* M, uint64_t* R) {
+      uint64_t S[64], T[64], Q[64];
+      add_words(D, M, S);
+      for (int i = 1; i < K; i++) {
+        for (int l = 0; l < 64; l++) { Q[l] = S[l] & L[l]; T[l] = D[l] | Q[l]; }
+        add_words(T, Q, S);
+      }
+      std::memcpy(R, S, sizeof S);
+    };
+    uint64_t R[64], E[64], EL[64];
+    hop(B, R);
+    bool more = false;
+    for (int l = 0; l < 64; l++) { E[l] = R[l] & ~D[l]; EL[l] = R[l] & L[l]; more = more || EL[l]; }
+    while (more) {
+      uint64_t M2[64];
+      if (EL[63] >> 63) ovf |= 1ull << 63;
+      for (int l = 0; l < 64; l++) M2[l] = (EL[l] << 1) | (l ? (EL[l - 1] >> 63) : 0ull);
+      for (int l = 0; l < 64; l++) B[l] |= M2[l];
+      hop(M2, R);
+      more = false;
+      for (int l = 0; l < 64; l++) { E[l] |= R[l] & ~D[l]; EL[l] = R[l] & L[l]; more = more || EL[l]; }
+    }
+    uint32_t reason = (ovf >> 63) ? 1u : 0u;
+    // rows: lane-major, low half first
+    for (int l = 0; l < 64 && !reason; l++) {
+      const uint32_t b0 = static_cast<uint32_t>(B[l]), b1 = static_cast<uint32_t>(B[l] >> 32);
+      const uint32_t pb0 = l ? static_cast<uint32_t>(B[l - 1]) : 0u, pb1 = l ? static_cast<uint32_t>(B[l - 1] >> 32) : 0u;
+      const uint32_t lane64 = static_cast<uint32_t>(l) << 6;
+      auto emit = [&](uint32_t s, uint32_t e) {
+        if (s >= e) { reason |= 2u; return; }
+        res.push_back(wlo + s); res.push_back(wlo + e);
+      };
+      {
+        const uint32_t tp = umin(ffbh_raw(pb1) | 32u, ffbh_raw(pb0) | 64u);
+        uint32_t xx = static_cast<uint32_t>(E[l]);
+        while (xx) {
+          const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+          xx &= xx - 1u;
+          const uint32_t d = umin(ffbh_raw(b0 & ((1u << b) - 1u)), tp);
+          emit((lane64 + 31u - d) & 0xFFFFu, lane64 + b);
+        }
+      }
+      {
+        const uint32_t tp = umin(umin(ffbh_raw(b0) | 32u, ffbh_raw(pb1) | 64u), ffbh_raw(pb0) | 96u);
+        uint32_t xx = static_cast<uint32_t>(E[l] >> 32);
+        while (xx) {
+          const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+          xx &= xx - 1u;
+          const uint32_t d = umin(ffbh_raw(b1 & ((1u << b) - 1u)), tp);
+          emit((lane64 + 63u - d) & 0xFFFFu, lane64 + 32u + b);
+        }
+      }
+    }
+    if (reason) return -(16 + static_cast<int64_t>(reason));
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}
