@@ -28,7 +28,10 @@ size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
-hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip: grouped kernel
+hipError_t launch_scan_fields_stream(const ScanArgs& a, unsigned producers, hipStream_t stream);   // ... persistent streaming kernel
+int fields_stream_capacity(const ScanArgs& a, int device);
+int stream_scan_workgroups();
 int fields_shape(const ChainAux& c);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
@@ -79,6 +82,9 @@ struct Scratch {
   uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) ... 8 XCD tickets at +32 -> 64 B, in front of `status`
   uint64_t* status = nullptr;    // ctl + 64: one allocation, one memset per launch
   uint64_t statusCap = 0;
+  uint16_t* cnt16 = nullptr;     // streaming kernels: 16-bit count words, one per wave-tile (stream_common.hpp)
+  uint64_t cnt16Cap = 0;
+  uint32_t epoch4 = 0;           // last 4-bit epoch used on cnt16 (1..15); the array is zeroed when it wraps
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
   uint32_t epoch = 0;            // last launch epoch used on `status` (block_common.hpp kEpochShift), 1..1023
   bool needZero = true;          // the next epoch launch must start from a zeroed control block + status array
@@ -96,6 +102,7 @@ struct Scratch {
       if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (ctl) (void)hipFree(ctl);
+      if (cnt16) (void)hipFree(cnt16);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
@@ -377,7 +384,9 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   a.row_width = static_cast<uint32_t>(row_width);
   a.ntiles = tilesFor(h->kind, len);
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
-  if (int rc = ensureStatus(s, a.ntiles)) return rc;
+  // (the streaming fields kernel keeps one count word and one base word per 3840-byte wave-tile: 4.27 x the 16 KiB tiles)
+  const uint64_t waveTiles = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
+  if (int rc = ensureStatus(s, std::max<uint64_t>(a.ntiles, waveTiles))) return rc;
   a.status = s.status;
   a.status2 = s.status + s.statusCap;
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
@@ -387,6 +396,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const uint32_t dbgBits = getenv("CXG_DEBUG") ? static_cast<uint32_t>(atoi(getenv("CXG_DEBUG"))) : 0u;
   a.prof = nullptr;
   a.dbg = dbgBits;
+  a.cnt16 = nullptr; a.epoch4 = 0;
   a.max_len = (h->flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u;
   if (profOn) {
     if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));
@@ -424,11 +434,15 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
+  bool fieldsStream = false;                                       // ... by its persistent streaming variant
+  unsigned streamProducers = 0;
+  static std::atomic<bool> fieldsStreamOk{true};                  // false once a watchdog fired under the streaming kernel
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
   int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
   fieldsKernel = false;
+  fieldsStream = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
@@ -492,7 +506,39 @@ relaunch:
     static const bool fieldsOk = getenv("CXG_NO_FIELDS_KERNEL") == nullptr;
     fieldsKernel = fieldsOk && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                    cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
-    if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
+    // Its streaming variant (persistent grid, dense window, scan server: stream_common.hpp) needs every workgroup resident
+    // at once: grid = the device's capacity for this kernel.  CXG_FIELDS_GROUPED=1 (A/B) or a watchdog that ever fired in
+    // this process select the grouped variant.
+    static const bool groupedOnly = getenv("CXG_FIELDS_GROUPED") != nullptr;
+    fieldsStream = false;
+    if (fieldsKernel && !groupedOnly && fieldsStreamOk.load() && useEpoch) {
+      static std::atomic<int> capCache[16][8];                         // [device][fields - 1]: 0 unknown, -1 unusable
+      const int kf = cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
+      int cap = capCache[t_device & 15][kf & 7].load();
+      const int nscan = cxgdev::stream_scan_workgroups();
+      if (cap == 0) { cap = cxgdev::fields_stream_capacity(a, t_device); if (cap < 2 * nscan) cap = -1; capCache[t_device & 15][kf & 7].store(cap); }
+      if (cap > nscan) {
+        static const int capEnv = getenv("CXG_FIELDS_WORKGROUPS") ? atoi(getenv("CXG_FIELDS_WORKGROUPS")) : 0;   // experiments: total workgroups incl. the scan server's
+        if (capEnv > nscan) cap = capEnv;
+        a.ngroups = waveTiles;
+        // 16-bit count words, one per wave-tile (+ slack: the scan server reads whole quads); own array, own 4-bit epoch
+        if (waveTiles + 8 > s.cnt16Cap) {
+          if (s.cnt16) HIP_TRY(hipFree(s.cnt16));
+          s.cnt16 = nullptr; s.cnt16Cap = 0;
+          const uint64_t c = waveTiles + waveTiles / 4 + 4096;
+          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.cnt16), c * sizeof(uint16_t)));
+          s.cnt16Cap = c; s.epoch4 = 15;                              // fresh memory: zero it below
+        }
+        if (s.epoch4 >= 15u) { HIP_TRY(hipMemsetAsync(s.cnt16, 0, s.cnt16Cap * sizeof(uint16_t), stream)); s.epoch4 = 0; }
+        a.cnt16 = s.cnt16;
+        a.epoch4 = ++s.epoch4;
+        const uint64_t want = (waveTiles + cxgdev::kWavesPerBlock - 1) / cxgdev::kWavesPerBlock;
+        streamProducers = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(cap - nscan)));
+        fieldsStream = true;
+      }
+    }
+    if (fieldsStream) le = cxgdev::launch_scan_fields_stream(a, streamProducers, stream);
+    else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
@@ -564,7 +610,7 @@ relaunch:
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
-    timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
+    timing->grid = fieldsStream ? streamProducers + static_cast<uint32_t>(cxgdev::stream_scan_workgroups()) : static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
     timing->kernel = static_cast<uint32_t>(fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
@@ -572,6 +618,7 @@ relaunch:
   if (profOn) {
     uint64_t pc[16];
     HIP_TRY(hipMemcpy(pc, s.prof, 128, hipMemcpyDeviceToHost));
+    if (fieldsStream) fprintf(stderr, "[CXG_PROF] streaming fields kernel: %llu rounds waited for the scan server (ring or list of held-back tiles full)\n", (unsigned long long)pc[0]);
     if (gen == 6 && pc[15]) {
       fprintf(stderr, "[CXG_PROF] gen6 waves=%llu avg cycles per wave and group:", (unsigned long long)pc[15]);
       static const char* names[7] = {"A", "ldsT", "own", "B", "starts", "F", "rows"};
@@ -592,6 +639,13 @@ relaunch:
       fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
+  }
+  if ((err & 2u) && fieldsStream) {                                 // the persistent grid was not resident as a whole (or a producer gave up): grouped kernels from now on
+    fieldsStreamOk.store(false);
+    s.needZero = true;
+    fprintf(stderr, "[cxg] streaming fields kernel: a wait timed out (persistent grid not resident?): switching to the grouped kernel\n");
+    relaunches++;
+    goto relaunch;
   }
   if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
     staticGroupsOk.store(false);

@@ -125,4 +125,5 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
   __syncthreads();
 }
 
+
 }  // namespace cxgdev

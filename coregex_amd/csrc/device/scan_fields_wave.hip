@@ -41,22 +41,16 @@
 #include "scan_dfa.h"
 #include "walk.hpp"
 #include "wave_common.hpp"
+#include "stream_common.hpp"
 
 #ifndef CXG_FIELDS_WAVES
 #define CXG_FIELDS_WAVES 8
 #endif
 // -DCXG_FABL=n (experiments only, results WRONG): 1 = no rows, 2 = no chain and no rows, 3 = no class masks either,
-// 4 = no LDS transpose either (the window is only read), 5 = 4 without barrier / look-back / epilogue
+// 4 = no LDS transpose either (the window is only read), 5 = 4 without any output ordering (grouped: no barrier / look-back;
+// stream: no count words, no scanner)
 #ifndef CXG_FABL
 #define CXG_FABL 0
-#endif
-// -DCXG_FIELDS_REISSUE=0 (experiment): the next tile's four loads are issued together behind the last class mask
-// -DCXG_FIELDS_DEPTH=2 (experiment): two window buffers, loads run two tiles ahead (16 more VGPRs)
-#ifndef CXG_FIELDS_DEPTH
-#define CXG_FIELDS_DEPTH 1
-#endif
-#ifndef CXG_FIELDS_REISSUE
-#define CXG_FIELDS_REISSUE 1
 #endif
 
 namespace cxgdev {
@@ -132,10 +126,170 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum_fused(uint32_t v) {
   return v;
 }
 
+// ---- the tile mathematics shared by both kernels ------------------------------------------------------------------------
+struct FieldsTile { uint32_t e0, e1, b0, b1; bool ovf; };   // ends / group starts of the lane's word; ovf (uniform): a marker left the window
+
+// Phases B-D for one window: (d1:d0) / (p1:p0) = field / separator bitmap word of this lane.
+template <int K>
+__device__ __forceinline__ FieldsTile fields_core(uint32_t d0, uint32_t d1, uint32_t p0, uint32_t p1) {
+  // words of 64 field bytes pass a carry on (with no marker of their own; a word that generates needs no propagate)
+  const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
+  // ---- B: links and super-run starts
+  const uint32_t prev_d1 = dpp_from_lower(d1);                    // lane 0: its own word — that lane owns nothing
+  const uint32_t next_d0 = dpp_from_upper_ones(d0);               // lane 63: "a field byte follows the window": a link there sends its marker out of the window (fallback)
+  const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
+  const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
+  const uint32_t L0 = p0 & Dl0 & Dr0, L1 = p1 & Dl1 & Dr1;
+  const uint32_t prev_l1 = dpp_from_lower(L1);
+  const uint32_t Ll0 = __builtin_amdgcn_alignbit(L0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(L1, L0, 31);   // L << 1
+  uint32_t b0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), b1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // B: group starts (first: the owned super-run starts)
+  if (CXG_FABL >= 2) { b0 = 0; b1 = 0; }
+  // ---- C: hop over K fields
+  unsigned long long ovf = 0;                                     // bit 63: a marker left the window (scalar)
+  auto carry_in = [&](unsigned long long GG) -> unsigned long long {
+    const unsigned long long Pe = PPd & ~GG;
+    const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;        // lanes that receive a carry
+    ovf |= GG | (Pe & recv);                                      // lane 63 generates, or passes one on
+    return recv;
+  };
+  auto hop = [&](uint32_t m0, uint32_t m1, uint32_t& r0, uint32_t& r1) {
+    uint32_t s0, s1;
+    unsigned long long GG;
+    add64_co(d0, d1, m0, m1, s0, s1, GG);
+    add64_cin(s0, s1, carry_in(GG));
+#pragma unroll
+    for (int i = 1; i < K; i++) {
+      const uint32_t q0 = s0 & L0, q1 = s1 & L1;                  // markers that stand on a link
+      add64_co(d0 | q0, d1 | q1, q0, q1, s0, s1, GG);
+      add64_cin(s0, s1, carry_in(GG));
+    }
+    r0 = s0; r1 = s1;
+  };
+  uint32_t r0, r1;
+  hop(b0, b1, r0, r1);
+  uint32_t e0 = r0 & ~d0, e1 = r1 & ~d1;                          // ends (exclusive) of the first group of every owned super-run
+  uint32_t el0 = r0 & L0, el1 = r1 & L1;
+  // ---- D: super-runs with more than K fields (`1.2.3.4.5.6.7.8`): the byte behind an end that sits on a link starts the next group
+  while (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(el1) << 32) | el0, 0ull, 33 /*ne*/) != 0ull) {
+    const uint32_t prev_e1 = dpp_from_lower_z(el1);
+    if ((static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(el1), 63)) >> 31) != 0u) ovf |= 1ull << 63;
+    const uint32_t n0 = __builtin_amdgcn_alignbit(el0, prev_e1, 31), n1 = __builtin_amdgcn_alignbit(el1, el0, 31);
+    b0 |= n0; b1 |= n1;
+    hop(n0, n1, r0, r1);
+    e0 |= r0 & ~d0; e1 |= r1 & ~d1;
+    el0 = r0 & L0; el1 = r1 & L1;
+  }
+  return FieldsTile{e0, e1, b0, b1, (ovf >> 63) != 0ull};
+}
+
+// Phase E: one packed row (start | end << 16, window bit indices) per end bit of the lane's word, rows[index(r)], r counting
+// up from r0.  Start of the match that ends at bit b: the highest bit of B below b — in this word, else in the previous
+// lane's (a start further back: the row comes out with start >= end and is caught when the rows are written).
+template <typename IndexFn>
+__device__ __forceinline__ void fields_rows(const FieldsTile& t, int lane, uint32_t* rows, uint32_t r, IndexFn index) {
+  const uint32_t pb0 = dpp_from_lower_z(t.b0), pb1 = dpp_from_lower_z(t.b1);
+  const uint32_t lane64 = static_cast<uint32_t>(lane) << 6;
+  {
+    const uint32_t tp = min(ffbh_raw(pb1) | 32u, ffbh_raw(pb0) | 64u);
+    uint32_t xx = t.e0;
+    while (xx) {
+      const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+      xx &= xx - 1u;
+      const uint32_t d = min(ffbh_raw(t.b0 & ((1u << b) - 1u)), tp);
+      rows[index(r)] = (lane64 + 31u - d) | ((lane64 + b) << 16);
+      r++;
+    }
+  }
+  {
+    const uint32_t tp = min(min(ffbh_raw(t.b0) | 32u, ffbh_raw(pb1) | 64u), ffbh_raw(pb0) | 96u);
+    uint32_t xx = t.e1;
+    while (xx) {
+      const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+      xx &= xx - 1u;
+      const uint32_t d = min(ffbh_raw(t.b1 & ((1u << b) - 1u)), tp);
+      rows[index(r)] = (lane64 + 63u - d) | ((lane64 + 32u + b) << 16);
+      r++;
+    }
+  }
+}
+
+// Window of the wave-tile that starts at haystack byte lo: bytes [lo - 64, lo + 4032) through a buffer resource sized to the
+// bytes that exist (rounded up to a dword): lanes past the end of the input read zeros, no tail path.  nvalid = window bytes
+// that are data (or lie in front of the haystack); the window of the haystack's first tile starts 64 bytes in front of the
+// haystack: those lanes are sent out of range by the caller.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fields_window(const uint8_t* hay, uint64_t len, uint64_t lo, bool live, int32_t& nvalid) {
+  int nrec = 0;
+  uint64_t wlo = 0;
+  nvalid = 0;
+  if (live && lo < len) {
+    wlo = lo >= static_cast<uint64_t>(kFPre) ? lo - kFPre : 0;
+    const uint64_t rem = len - wlo;
+    const uint64_t full = static_cast<uint64_t>(kFWin) - (lo - wlo == 0 ? kFPre : 0);
+    nrec = rem >= full ? static_cast<int>(full) : static_cast<int>((rem + 3) & ~3ull);
+    const uint64_t nv = len - lo + kFPre;
+    nvalid = nv >= static_cast<uint64_t>(kFWin) ? kFWin : static_cast<int32_t>(nv);
+  }
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hay) + wlo, 0, nrec, 0x00020000);
+}
+// Phase A for one window held in x[]: class pieces into the wave's LDS scratch; every vector's register is refilled from
+// `rnext` right behind its last use.  Returns the lane's words (d1:d0), (p1:p0), masked to the valid bytes of a short window.
+template <int KD, int KP>
+__device__ __forceinline__ void fields_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t rnext, int lane, uint64_t* sd, uint64_t* sp, int32_t nvalid,
+                                             uint32_t dlo4, uint32_t dhi4, uint32_t plo4, uint32_t phi4, uint32_t& sink,
+                                             uint32_t& d0, uint32_t& d1, uint32_t& p0, uint32_t& p1) {
+  {
+    uint16_t* pd = reinterpret_cast<uint16_t*>(sd);
+    uint16_t* pp = reinterpret_cast<uint16_t*>(sp);
+    const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (CXG_FABL >= 4) {
+        sink ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
+      } else if (CXG_FABL == 3) {
+        pd[lane + 64 * k] = static_cast<uint16_t>(x[k].x ^ x[k].z ^ x[k].y ^ x[k].w);
+        pp[lane + 64 * k] = 0;
+      } else {
+        pd[lane + 64 * k] = static_cast<uint16_t>(piece16<KD>(x[k], dlo4, dhi4));
+        pp[lane + 64 * k] = static_cast<uint16_t>(piece16<KP>(x[k], plo4, phi4));
+      }
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                            // keep the refill right behind its vector's last use
+    }
+  }
+  d0 = d1 = p0 = p1 = 0;
+  if (CXG_FABL >= 4) return;
+  wave_lds_sync();
+  int lw = lane;                                                  // second opaque copy: word address = base + 8 * lane by shift, not (piece address) + 6 * lane by v_mul_lo
+  asm volatile("" : "+v"(lw));
+  const uint64_t Dw = sd[lw], Pw = sp[lw];
+  d0 = static_cast<uint32_t>(Dw); d1 = static_cast<uint32_t>(Dw >> 32);
+  p0 = static_cast<uint32_t>(Pw); p1 = static_cast<uint32_t>(Pw >> 32);
+  if (nvalid != kFWin) {                                          // short last window: the up to 3 bytes behind the input in its last dword are not data
+    const int32_t nf = nvalid - 64 * lane;
+    const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+    d0 &= static_cast<uint32_t>(vf); d1 &= static_cast<uint32_t>(vf >> 32);
+    p0 &= static_cast<uint32_t>(vf); p1 &= static_cast<uint32_t>(vf >> 32);
+  }
+}
+// The first loads of a wave (window of the tile at `lo`); `first`: the haystack's first tile, window bytes 0..63 do not exist.
+__device__ __forceinline__ void fields_first_loads(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t r0, int lane, bool first) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t off = static_cast<uint32_t>(lane + 64 * k) << 4;
+    if (first) off = off >= static_cast<uint32_t>(kFPre) ? off - kFPre : 0x7FFFFFF0u;
+    x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);                              // issue order = use order: the tile loop waits for x[0] with vmcnt(3), not for all four
+  }
+}
+
 }  // namespace
 
 // K: number of fields (2..4).  KD / KP: kind of the field / separator class (walk.hpp ChainClassKind; kClsRange also
 // serves single bytes and digits as separators).
+//
+// GROUPED variant: a workgroup takes 32 consecutive wave-tiles (120 KiB), orders its rows after one barrier and looks back
+// (block_common.hpp), as the other wave kernels do.  Kept as the A/B partner of the streaming kernel below
+// (CXG_FIELDS_GROUPED=1) and as its fallback when the persistent grid cannot be resident.
 template <int K, int KD, int KP>
 __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];     // field-class bitmap of the wave's window
@@ -165,199 +319,41 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   constexpr int tpw = kTilesPerWave;
   uint32_t nrows_w = 0;                                              // wave-uniform
   uint32_t fallback = 0;
+  auto tile_lo_of = [&](int jj) { return (group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave) * static_cast<uint64_t>(kWaveTile); };
 
-  // Window of wave-tile jj: haystack bytes [lo - 64, lo + 4032).  Buffer resource sized to the bytes that exist (rounded
-  // up to a dword): lanes past the end of the input read zeros, no tail path.  The window of the haystack's first tile
-  // starts 64 bytes in front of the haystack: those lanes are sent out of range (`first`, prologue only).
-  auto window_rsrc = [&](int jj, int32_t& nvalid) -> __amdgpu_buffer_rsrc_t {
-    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
-    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
-    int nrec = 0;
-    uint64_t wlo = 0;
-    nvalid = 0;
-    if (jj < tpw && lo < a.len) {
-      wlo = lo >= static_cast<uint64_t>(kFPre) ? lo - kFPre : 0;
-      const uint64_t rem = a.len - wlo;
-      const uint64_t full = static_cast<uint64_t>(kFWin) - (lo - wlo == 0 ? kFPre : 0);
-      nrec = rem >= full ? static_cast<int>(full) : static_cast<int>((rem + 3) & ~3ull);
-      const uint64_t nv = a.len - lo + kFPre;                          // window bytes that hold data or lie in front of the haystack
-      nvalid = nv >= static_cast<uint64_t>(kFWin) ? kFWin : static_cast<int32_t>(nv);
-    }
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + wlo, 0, nrec, 0x00020000);
-  };
   u32x4 x[4];
-#if CXG_FIELDS_DEPTH == 2
-  u32x4 xb[4];                                                         // second window buffer: loads run two tiles ahead
-  int32_t nvalid_b = 0;
-#endif
   uint32_t sink = 0;                                                   // ablations only
-  int32_t nvalid_a = 0;
-  {
-    const __amdgpu_buffer_rsrc_t r0 = window_rsrc(0, nvalid_a);
-    const bool first = group == 0 && wave == 0;                       // the haystack's first tile: window bytes 0..63 do not exist
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint32_t off = static_cast<uint32_t>(lane + 64 * k) << 4;
-      if (first) off = off >= static_cast<uint32_t>(kFPre) ? off - kFPre : 0x7FFFFFF0u;
-      x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, 0);
-    }
-#if CXG_FIELDS_DEPTH == 2
-    const __amdgpu_buffer_rsrc_t r1 = window_rsrc(1, nvalid_b);
-#pragma unroll
-    for (int k = 0; k < 4; k++) xb[k] = __builtin_amdgcn_raw_buffer_load_b128(r1, static_cast<uint32_t>(lane + 64 * k) << 4, 0, 0);
-#endif
-  }
+  int32_t nvalid_cur = 0;
+  fields_first_loads(x, fields_window(a.hay, a.len, tile_lo_of(0), true, nvalid_cur), lane, group == 0 && wave == 0);
 
-  // One wave-tile: window j sits in x[] (or is about to arrive), x[] is refilled with window j + ahead.
-  auto tile = [&](const int j, u32x4 (&x)[4], int32_t& nvalid_cur, const int ahead) {
-    int32_t nvalid_next = 0;
+  for (int j = 0; j < tpw; j++) {
     // Opaque copy of the lane id per wave-tile: lane-derived values are recomputed (a few ALU ops) instead of being hoisted
     // out of the loop and spilled — a scratch reload waits on vmcnt and would drain the loads in flight.
     lane = lane0;
     asm volatile("" : "+v"(lane));
-    const __amdgpu_buffer_rsrc_t rnext = window_rsrc(j + ahead, nvalid_next);
-    // ---- A: class pieces of each vector as it arrives; its register is refilled with the next tile's vector at once
-    {
-      uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
-      uint16_t* pp = reinterpret_cast<uint16_t*>(s_p[wave]);
-      const uint32_t voff = static_cast<uint32_t>(lane) << 4;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (CXG_FABL >= 4) {
-          sink ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
-        } else if (CXG_FABL == 3) {
-          pd[lane + 64 * k] = static_cast<uint16_t>(x[k].x ^ x[k].z ^ x[k].y ^ x[k].w);
-          pp[lane + 64 * k] = 0;
-        } else {
-          pd[lane + 64 * k] = static_cast<uint16_t>(piece16<KD>(x[k], dlo4, dhi4));
-          pp[lane + 64 * k] = static_cast<uint16_t>(piece16<KP>(x[k], plo4, phi4));
-        }
-        if (CXG_FIELDS_REISSUE) {
-          x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);                            // keep the refill right behind its vector's last use
-        }
-      }
-      if (!CXG_FIELDS_REISSUE) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
-      }
-    }
-    if (CXG_FABL >= 4) { nvalid_cur = nvalid_next; return; }
-    wave_lds_sync();
-    uint32_t emitted_here = 0;
-    {
-      int lw = lane;                                                  // second opaque copy: word address = base + 8 * lane by shift, not (piece address) + 6 * lane by v_mul_lo
-      asm volatile("" : "+v"(lw));
-      const uint64_t Dw = s_d[wave][lw], Pw = s_p[wave][lw];
-      uint32_t d0 = static_cast<uint32_t>(Dw), d1 = static_cast<uint32_t>(Dw >> 32);
-      uint32_t p0 = static_cast<uint32_t>(Pw), p1 = static_cast<uint32_t>(Pw >> 32);
-      if (nvalid_cur != kFWin) {                                      // short last window: the up to 3 bytes behind the input in its last dword are not data
-        const int32_t nf = nvalid_cur - 64 * lane;
-        const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
-        d0 &= static_cast<uint32_t>(vf); d1 &= static_cast<uint32_t>(vf >> 32);
-        p0 &= static_cast<uint32_t>(vf); p1 &= static_cast<uint32_t>(vf >> 32);
-      }
-      // words of 64 field bytes pass a carry on (with no marker of their own; a word that generates needs no propagate)
-      const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
-      // ---- B: links and super-run starts
-      const uint32_t prev_d1 = dpp_from_lower(d1);                    // lane 0: its own word — that lane owns nothing
-      const uint32_t next_d0 = dpp_from_upper_ones(d0);               // lane 63: "a field byte follows the window": a link there sends its marker out of the window (fallback)
-      const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
-      const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
-      const uint32_t L0 = p0 & Dl0 & Dr0, L1 = p1 & Dl1 & Dr1;
-      const uint32_t prev_l1 = dpp_from_lower(L1);
-      const uint32_t Ll0 = __builtin_amdgcn_alignbit(L0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(L1, L0, 31);   // L << 1
-      uint32_t b0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), b1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // B: group starts (first: the owned super-run starts)
-      if (CXG_FABL >= 2) { b0 = 0; b1 = 0; }
-      // ---- C: hop over K fields
-      unsigned long long ovf = 0;                                     // bit 63: a marker left the window (scalar)
-      auto carry_in = [&](unsigned long long GG) -> unsigned long long {
-        const unsigned long long Pe = PPd & ~GG;
-        const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;        // lanes that receive a carry
-        ovf |= GG | (Pe & recv);                                      // lane 63 generates, or passes one on
-        return recv;
-      };
-      auto hop = [&](uint32_t m0, uint32_t m1, uint32_t& r0, uint32_t& r1) {
-        uint32_t s0, s1;
-        unsigned long long GG;
-        add64_co(d0, d1, m0, m1, s0, s1, GG);
-        add64_cin(s0, s1, carry_in(GG));
-#pragma unroll
-        for (int i = 1; i < K; i++) {
-          const uint32_t q0 = s0 & L0, q1 = s1 & L1;                  // markers that stand on a link
-          add64_co(d0 | q0, d1 | q1, q0, q1, s0, s1, GG);
-          add64_cin(s0, s1, carry_in(GG));
-        }
-        r0 = s0; r1 = s1;
-      };
-      uint32_t r0, r1;
-      hop(b0, b1, r0, r1);
-      uint32_t e0 = r0 & ~d0, e1 = r1 & ~d1;                          // ends (exclusive) of the first group of every owned super-run
-      uint32_t el0 = r0 & L0, el1 = r1 & L1;
-      // ---- D: super-runs with more than K fields (`1.2.3.4.5.6.7.8`): the byte behind an end that sits on a link starts the next group
-      while (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(el1) << 32) | el0, 0ull, 33 /*ne*/) != 0ull) {
-        const uint32_t prev_e1 = dpp_from_lower_z(el1);
-        if ((static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(el1), 63)) >> 31) != 0u) ovf |= 1ull << 63;
-        const uint32_t n0 = __builtin_amdgcn_alignbit(el0, prev_e1, 31), n1 = __builtin_amdgcn_alignbit(el1, el0, 31);
-        b0 |= n0; b1 |= n1;
-        hop(n0, n1, r0, r1);
-        e0 |= r0 & ~d0; e1 |= r1 & ~d1;
-        el0 = r0 & L0; el1 = r1 & L1;
-      }
-      if (ovf >> 63) fallback |= 1u;
-      // ---- E: rows
-      const uint32_t c = static_cast<uint32_t>(__popc(e0)) + static_cast<uint32_t>(__popc(e1));
-      const uint32_t incl = wave_inclusive_sum_fused(c);
-      uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-      if (CXG_FABL >= 1) tot = 0;
-      if (tot != 0 && (a.out != nullptr || a.max_len != 0)) {
-        // start of the match that ends at bit b: the highest bit of B below b — in this word, else in the previous lane's
-        // (a start further back: the row comes out with start > end and the epilogue raises the fallback flag)
-        const uint32_t pb0 = dpp_from_lower_z(b0), pb1 = dpp_from_lower_z(b1);
-        const uint32_t lane64 = static_cast<uint32_t>(lane) << 6;
-        uint32_t r = nrows_w + incl - c;
-        uint32_t* rows = s_row[wave];
-        {
-          const uint32_t tp = min(ffbh_raw(pb1) | 32u, ffbh_raw(pb0) | 64u);
-          uint32_t xx = e0;
-          while (xx) {
-            const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
-            xx &= xx - 1u;
-            const uint32_t d = min(ffbh_raw(b0 & ((1u << b) - 1u)), tp);
-            rows[min(r, static_cast<uint32_t>(kFRows - 1))] = (lane64 + 31u - d) | ((lane64 + b) << 16);   // overflow: flagged below, rows void
-            r++;
-          }
-        }
-        {
-          const uint32_t tp = min(min(ffbh_raw(b0) | 32u, ffbh_raw(pb1) | 64u), ffbh_raw(pb0) | 96u);
-          uint32_t xx = e1;
-          while (xx) {
-            const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
-            xx &= xx - 1u;
-            const uint32_t d = min(ffbh_raw(b1 & ((1u << b) - 1u)), tp);
-            rows[min(r, static_cast<uint32_t>(kFRows - 1))] = (lane64 + 63u - d) | ((lane64 + 32u + b) << 16);
-            r++;
-          }
-        }
-      }
-      emitted_here = tot;
-    }
-    if (lane == 0) s_cnt[wave][j] = emitted_here;
-    nrows_w += emitted_here;
+    int32_t nvalid_next = 0;
+    const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, tile_lo_of(j + 1), j + 1 < tpw, nvalid_next);
+    uint32_t d0, d1, p0, p1;
+    fields_words<KD, KP>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1);
     nvalid_cur = nvalid_next;
-  };
-#if CXG_FIELDS_DEPTH == 2
-  static_assert(tpw % 2 == 0, "two window buffers: an even number of tiles per wave");
-  for (int j = 0; j < tpw; j += 2) { tile(j, x, nvalid_a, 2); tile(j + 1, xb, nvalid_b, 2); }
-#else
-  for (int j = 0; j < tpw; j++) tile(j, x, nvalid_a, 1);
-#endif
+    if (CXG_FABL >= 4) continue;
+    const FieldsTile t = fields_core<K>(d0, d1, p0, p1);
+    if (t.ovf) fallback |= 1u;
+    const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
+    const uint32_t incl = wave_inclusive_sum_fused(c);
+    uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    if (CXG_FABL >= 1) tot = 0;
+    if (tot != 0 && (a.out != nullptr || a.max_len != 0))
+      fields_rows(t, lane, s_row[wave], nrows_w + incl - c, [](uint32_t r) { return min(r, static_cast<uint32_t>(kFRows - 1)); });   // overflow: flagged below, rows void
+    if (lane == 0) s_cnt[wave][j] = tot;
+    nrows_w += tot;
+  }
   if (CXG_FABL >= 4 && sink == 0x12345u) fallback |= 4u;              // keeps the loads alive
   if (CXG_FABL == 5) { if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8)); return; }
   if (CXG_FABL == 4 && lane0 == 0) { for (int j = 0; j < tpw; j++) s_cnt[wave][j] = 0; }
   if (nrows_w > static_cast<uint32_t>(kFRows)) fallback |= 16u;
   wave_lds_sync();
-  {                                                                   // rows whose start was not found (start > end), UseBoth restart span
+  {                                                                   // rows whose start was not found (start >= end), UseBoth restart span
     bool bad = false, long_hit = false;
     if (a.out != nullptr || a.max_len != 0) {
       for (uint32_t r = lane0; r < nrows_w && r < static_cast<uint32_t>(kFRows); r += 64) {
@@ -404,6 +400,223 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   }
 }
 
+// STREAMING variant (the default): a persistent grid; in round r wave W (of NW producer waves) takes wave-tile r * NW + W,
+// so that at every moment the resident waves read ONE dense window of the haystack (6.2 TB/s against 3.7 TB/s for 120 KiB
+// per workgroup, stream_common.hpp).  No barrier, no look-back: a wave publishes the row count of its tile, keeps the rows
+// in its LDS ring, and writes them out a few tiles later when the scan server (workgroup 0) has published the base of the
+// tile's quad.  a.cnt16 = count words (one per wave-tile), a.status2 = base words (one per quad), a.status = the server's
+// super-batch words, a.ngroups = wave-tiles.
+constexpr int kSRing = 512;                          // rows a wave can hold back (power of two)
+constexpr int kSPend = 16;                           // tiles a wave can hold back
+template <int K, int KD, int KP>
+__global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_stream(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64];
+  __shared__ uint32_t s_row[kWavesPerBlock][kSRing];
+  __shared__ uint32_t s_ptile[kWavesPerBlock][kSPend];                // held-back tiles: index (low 32 bits suffice: < 2^31 tiles per launch) ...
+  __shared__ uint32_t s_pcnt[kWavesPerBlock][kSPend];                 // ... and row count
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint64_t ntiles = a.ngroups;
+  if (blockIdx.x < kScanWorkgroups) {                                 // the scan server (its LDS: the hand-off slots, in s_d's place)
+    if (CXG_FABL < 5) stream_scanner(a.cnt16, a.status2, a.status, ntiles, a.epoch4, a.epoch, a.total, a.err, reinterpret_cast<StreamChain*>(&s_d[0][0]));
+    return;
+  }
+  int lane = lane0;
+  const uint64_t NW = static_cast<uint64_t>(gridDim.x - kScanWorkgroups) * kWavesPerBlock;
+  const uint64_t W = static_cast<uint64_t>(blockIdx.x - kScanWorkgroups) * kWavesPerBlock + wave;
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
+  const uint32_t dlo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[0] * 0x01010101u)));
+  const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
+  const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
+  const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
+  const bool want_rows = a.out != nullptr || a.max_len != 0;
+  uint32_t fallback = 0;
+  uint32_t ring_head = 0, ring_tail = 0;                              // rows [head, tail) of the ring are held back (free-running counters)
+  uint32_t pend_head = 0, pend_tail = 0;                              // tiles [head, tail) likewise
+  bool dead = false;                                                  // a watchdog fired: stop waiting, the launch is void
+  uint32_t* const rows = s_row[wave];
+  const uint64_t* const cw = reinterpret_cast<const uint64_t*>(a.cnt16);
+
+  // Rows leave the ring in the order of their tiles.  State of the OLDEST held-back tile: cur_known = the base of its rows
+  // (cur_base) has arrived, cur_done = rows of it already written.
+  //
+  // The memory instructions of a round form a STATIC sequence — 4 window loads, 1 count store, 2 row stores, 2 poll loads,
+  // none of them under a branch: lanes that have nothing to store are sent out of range of a buffer resource (the hardware
+  // drops them), a poll with nothing to ask reads a word anyway.  Reason: the compiler's wait-count pass is path-insensitive;
+  // with a store under `if`, the wait for a window vector assumes the path WITHOUT the store and so also waits for the
+  // store's acknowledgement (a round trip to the memory side, ~2 us) — measured 0.23 instead of 0.17 ms per GiB for the
+  // bare skeleton.  With a static sequence every wait names exactly the instruction it needs.
+  bool cur_known = false;
+  uint64_t cur_base = 0;
+  uint32_t cur_done = 0;
+  const uint32_t row_bytes = a.row_width * 8u;
+  // rows [cur_done, cur_done + 64) of the oldest tile: one 16-byte store per lane, out-of-range lanes dropped by the hardware
+  auto flush_step = [&]() {
+    const uint32_t slot = pend_head & (kSPend - 1);
+    const uint64_t t = s_ptile[wave][slot];
+    const uint32_t n = cur_known ? s_pcnt[wave][slot] : 0u;
+    const int64_t tb = a.base + static_cast<int64_t>(t * static_cast<uint64_t>(kWaveTile)) - kFPre;
+    // resource over the rows this step may write: [cur_base + cur_done, min(cur_base + n, cap))
+    const uint64_t first = cur_base + cur_done;
+    uint64_t room = (a.out != nullptr && cur_known && a.cap > first) ? a.cap - first : 0ull;
+    if (room > n - cur_done) room = n - cur_done;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.out) + (a.out ? first * row_bytes : 0ull), 0,
+                                                                      static_cast<int>(room * row_bytes), 0x00020000);
+    const uint32_t i = static_cast<uint32_t>(lane0);
+    const uint32_t v = rows[(ring_head + cur_done + i) & (kSRing - 1)];
+    const uint32_t s = v & 0xFFFFu, e = v >> 16;
+    const bool live = cur_done + i < n;
+    const int64_t ms = tb + s, me = tb + e;
+    u32x4 o;
+    o.x = static_cast<uint32_t>(ms); o.y = static_cast<uint32_t>(ms >> 32); o.z = static_cast<uint32_t>(me); o.w = static_cast<uint32_t>(me >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(o, ro, i * row_bytes, 0, 0);
+    if (__ballot(live && s >= e) != 0ull) fallback |= 2u;            // a start that was not found (fields_rows)
+    if (a.max_len != 0 && __ballot(live && e - s > a.max_len) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+    if (cur_known) {
+      cur_done = min(n, cur_done + 64u);
+      if (cur_done == n) { ring_head += n; pend_head++; cur_done = 0; cur_known = false; }
+    }
+  };
+  // base of the oldest tile from the two words of its quad (base word, count word); `asked`: the words answer a poll for it
+  auto take_base = [&](uint64_t bw, uint64_t qw, bool asked) {
+    const uint64_t t = s_ptile[wave][pend_head & (kSPend - 1)];
+    const uint32_t blo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(bw)));
+    const uint32_t bhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(bw >> 32)));
+    const uint64_t u = (static_cast<uint64_t>(bhi) << 32) | blo;
+    const uint32_t qlo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(qw)));
+    const uint32_t qhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(qw >> 32)));
+    if (!asked || cur_known || (u & kFlagMask) != kStreamReady || (u & kEpochMask) != (static_cast<uint64_t>(a.epoch) << kEpochShift)) return;
+    const uint32_t wq = static_cast<uint32_t>(t & 3u);                // position of this wave's tile inside the quad
+    uint32_t below = 0;
+    if (wq > 0) below += qlo & kCntRowsMask;
+    if (wq > 1) below += (qlo >> 16) & kCntRowsMask;
+    if (wq > 2) below += qhi & kCntRowsMask;
+    cur_base = (u & kValueMask) + below;
+    cur_known = true;
+  };
+  // the slow way (ring or list full, and at the end): wait for the oldest tile's base and write all its rows
+  auto flush_blocking = [&]() {
+    const uint64_t t = s_ptile[wave][pend_head & (kSPend - 1)];
+    uint32_t spins = 0;
+    while (!cur_known && !dead) {
+      const uint64_t bw = __hip_atomic_load(a.status2 + (t >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      take_base(bw, 0ull, false);                                     // (looks at the word only)
+      if ((bw & kFlagMask) == kStreamReady && (bw & kEpochMask) == (static_cast<uint64_t>(a.epoch) << kEpochShift)) {
+        const uint64_t qw = __hip_atomic_load(cw + (t >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // complete: the server has seen all four counts
+        take_base(bw, qw, true);
+        break;
+      }
+      if (++spins > kSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); dead = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (dead) { ring_head += s_pcnt[wave][pend_head & (kSPend - 1)]; pend_head++; cur_done = 0; cur_known = false; return; }
+    const uint32_t want = pend_head + 1;
+    while (pend_head != want) flush_step();
+  };
+
+  u32x4 x[4];
+  uint32_t sink = 0;
+  int32_t nvalid_cur = 0;
+  uint64_t t = W;
+  // The polls of the previous round — in flight across a whole round — for the oldest held-back tile (A) and the one behind
+  // it (B): two tiles can leave per round, so a wave that fell behind the scan server for a moment catches up again.  (One
+  // poll per round: every unanswered poll raised the number of held-back tiles for good, at 16 every round took the slow
+  // way: 48 % of all rounds, measured.)
+  u32x2 pollA_b = {0u, 0u}, pollA_q = {0u, 0u}, pollB_b = {0u, 0u}, pollB_q = {0u, 0u};
+  bool askedA = false, askedB = false;
+  fields_first_loads(x, fields_window(a.hay, a.len, t * static_cast<uint64_t>(kWaveTile), t < ntiles, nvalid_cur), lane, W == 0);
+  if (CXG_FABL < 5) {
+    // The round's other memory instructions once in front of the loop, all out of range / unasked: the loop is then entered
+    // with the same instructions in flight, in the same order, as a round leaves behind — otherwise the first round's
+    // shorter list decides the loop's wait counts, and every round waits for its predecessor's polls with its window loads.
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay), 0, 0, 0x00020000);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>(0), rz, 64, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(z, rz, 64, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);                              // (two stores, not one merged)
+    __builtin_amdgcn_raw_buffer_store_b128(z, rz, 80 + (lane0 << 4), 0, 0);
+    const uint64_t q0 = (W < ntiles ? W : 0) >> 2;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.status2 + q0), 0, 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(cw + q0)), 0, 8, 0x00020000);
+    pollA_b = __builtin_amdgcn_raw_buffer_load_b64(rb, 0, 0, 16);
+    pollA_q = __builtin_amdgcn_raw_buffer_load_b64(rq, 0, 0, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    pollB_b = __builtin_amdgcn_raw_buffer_load_b64(rb, 0, 0, 16);
+    pollB_q = __builtin_amdgcn_raw_buffer_load_b64(rq, 0, 0, 16);
+  }
+  auto u64of = [](const u32x2& w) { return (static_cast<uint64_t>(w.y) << 32) | w.x; };
+  for (; t < ntiles; t += NW) {
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    int32_t nvalid_next = 0;
+    const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, (t + NW) * static_cast<uint64_t>(kWaveTile), t + NW < ntiles, nvalid_next);
+    uint32_t d0, d1, p0, p1;
+    fields_words<KD, KP>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1);
+    nvalid_cur = nvalid_next;
+    if (CXG_FABL >= 5) continue;
+    uint32_t tot = 0;
+    FieldsTile ft{0, 0, 0, 0, false};
+    uint32_t c = 0, incl = 0;
+    if (CXG_FABL < 4) {
+      ft = fields_core<K>(d0, d1, p0, p1);
+      if (ft.ovf) fallback |= 1u;
+      c = static_cast<uint32_t>(__popc(ft.e0)) + static_cast<uint32_t>(__popc(ft.e1));
+      incl = wave_inclusive_sum_fused(c);
+      tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      if (CXG_FABL >= 1) tot = 0;
+    }
+    if (tot > static_cast<uint32_t>(kSRing)) { fallback |= 16u; tot = 0; }   // more rows in one tile than the ring holds (and than a count word): match-dense input
+    if (want_rows) {
+      // room in the ring and in the list of held-back tiles (only when the scan server is far behind: the slow way)
+      while (pend_tail != pend_head && (ring_tail - ring_head + tot > static_cast<uint32_t>(kSRing) || pend_tail - pend_head >= static_cast<uint32_t>(kSPend))) {
+        if (a.prof && lane0 == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.prof), 1ull);   // CXG_PROF: rounds that had to wait for the scan server
+        flush_blocking();
+      }
+      if (tot != 0) fields_rows(ft, lane, rows, ring_tail + incl - c, [](uint32_t r) { return r & static_cast<uint32_t>(kSRing - 1); });
+      if (lane == 0) { s_ptile[wave][pend_tail & (kSPend - 1)] = static_cast<uint32_t>(t); s_pcnt[wave][pend_tail & (kSPend - 1)] = tot; }
+      ring_tail += tot;
+      pend_tail++;
+      wave_lds_sync();
+    }
+    // ---- the round's memory instructions behind the window loads, always in this order
+    {                                                                 // 1. the count of this tile: the scan server can move on (lane 0 stores, the others are out of range)
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.cnt16 + t), 0, 2, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b16(static_cast<short>((a.epoch4 << 11) | tot), rc, lane == 0 ? 0 : 64, 0, 16 /*sc1: agent scope*/);
+    }
+    // 2. rows of the two oldest held-back tiles whose bases last round's polls brought (asked a whole round ago: the words
+    //    travel to the memory side and back, ~3 us); 64 rows per tile and round, the rest of a denser tile in later rounds
+    {
+      const uint32_t before = pend_head;
+      take_base(u64of(pollA_b), u64of(pollA_q), askedA);
+      flush_step();
+      take_base(u64of(pollB_b), u64of(pollB_q), askedB && pend_head != before);   // B answers for the tile behind A: only if A is gone
+      flush_step();
+    }
+    {                                                                 // 3. ask for the bases of the (now) two oldest tiles; looked at in the next round
+      const uint32_t np = pend_tail - pend_head;
+      askedA = want_rows && np != 0 && !cur_known;
+      askedB = want_rows && np > 1u;
+      const uint64_t qa = (askedA || cur_known) ? static_cast<uint64_t>(s_ptile[wave][pend_head & (kSPend - 1)]) >> 2 : (t >> 2);
+      const uint64_t qb = askedB ? static_cast<uint64_t>(s_ptile[wave][(pend_head + 1) & (kSPend - 1)]) >> 2 : (t >> 2);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.status2 + qa), 0, 8, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(cw + qa)), 0, 8, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(a.status2 + qb), 0, 8, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rq2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(cw + qb)), 0, 8, 0x00020000);
+      pollA_b = __builtin_amdgcn_raw_buffer_load_b64(rb, 0, 0, 16);
+      pollA_q = __builtin_amdgcn_raw_buffer_load_b64(rq, 0, 0, 16);
+      pollB_b = __builtin_amdgcn_raw_buffer_load_b64(rb2, 0, 0, 16);
+      pollB_q = __builtin_amdgcn_raw_buffer_load_b64(rq2, 0, 0, 16);
+    }
+  }
+  if (CXG_FABL >= 4 && sink == 0x12345u) fallback |= 4u;
+  take_base(u64of(pollA_b), u64of(pollA_q), askedA);
+  take_base(u64of(pollB_b), u64of(pollB_q), false);
+  while (pend_tail != pend_head) flush_blocking();
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+}
+
 // Does the chain have the shape this kernel evaluates?  run(0) (byte(1) run(0)){K-1}, two classes of one range each,
 // disjoint, K = 2..4, no restart check.  Returns K, else 0.
 int fields_shape(const ChainAux& c) {
@@ -418,26 +631,70 @@ int fields_shape(const ChainAux& c) {
 }
 
 namespace {
+template <int K, int KD, int KP>
+int fields_stream_capacity_of(int device) {                         // workgroups of the streaming kernel the device holds at once
+  int occ = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_scan_fields_stream<K, KD, KP>, kThreads, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  // MI355X_MICROARCH.md "Correctness boundaries": the occupancy API can be one block per CU high for kernels with more than
+  // 80 SGPRs; this kernel is built to stay at or below 8 waves per SIMD with <= 80 SGPRs, and 8 workgroups of 4 waves are
+  // the hardware's wave limit anyway
+  if (occ > 8) occ = 8;
+  return occ * cus;
+}
 template <int K>
-void launch_fields_k(const ScanArgs& a, uint32_t kd, uint32_t kp, dim3 grid, dim3 block, hipStream_t stream) {
+void launch_fields_k(const ScanArgs& a, uint32_t kd, uint32_t kp, bool streaming, int device, int* capacity, dim3 grid, dim3 block, hipStream_t stream) {
   const bool dd = kd == kClsDigit, pb = kp == kClsByte;
+  if (capacity) {
+    *capacity = dd && pb ? fields_stream_capacity_of<K, kClsDigit, kClsByte>(device) : dd ? fields_stream_capacity_of<K, kClsDigit, kClsRange>(device)
+              : pb ? fields_stream_capacity_of<K, kClsRange, kClsByte>(device) : fields_stream_capacity_of<K, kClsRange, kClsRange>(device);
+    return;
+  }
+  if (streaming) {
+    if (dd && pb) hipLaunchKernelGGL((k_scan_fields_stream<K, kClsDigit, kClsByte>), grid, block, 0, stream, a);
+    else if (dd) hipLaunchKernelGGL((k_scan_fields_stream<K, kClsDigit, kClsRange>), grid, block, 0, stream, a);
+    else if (pb) hipLaunchKernelGGL((k_scan_fields_stream<K, kClsRange, kClsByte>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fields_stream<K, kClsRange, kClsRange>), grid, block, 0, stream, a);
+    return;
+  }
   if (dd && pb) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsDigit, kClsByte>), grid, block, 0, stream, a);
   else if (dd) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsDigit, kClsRange>), grid, block, 0, stream, a);
   else if (pb) hipLaunchKernelGGL((k_scan_fields_wave<K, kClsRange, kClsByte>), grid, block, 0, stream, a);
   else hipLaunchKernelGGL((k_scan_fields_wave<K, kClsRange, kClsRange>), grid, block, 0, stream, a);
 }
+void dispatch_fields(const ScanArgs& a, int k, bool streaming, int device, int* capacity, dim3 grid, hipStream_t stream) {
+  const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
+  const dim3 block(kThreads);
+  switch (k) {
+    case 2: launch_fields_k<2>(a, c.cls_kind[0], c.cls_kind[1], streaming, device, capacity, grid, block, stream); break;
+    case 3: launch_fields_k<3>(a, c.cls_kind[0], c.cls_kind[1], streaming, device, capacity, grid, block, stream); break;
+    case 4: launch_fields_k<4>(a, c.cls_kind[0], c.cls_kind[1], streaming, device, capacity, grid, block, stream); break;
+    default: break;
+  }
+}
 }  // namespace
 
+// Grouped kernel: a.ngroups = number of 120 KiB groups (one workgroup each).
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
-  const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
-  const int k = fields_shape(c);
-  const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  switch (k) {
-    case 2: launch_fields_k<2>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
-    case 3: launch_fields_k<3>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
-    case 4: launch_fields_k<4>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
-    default: return hipErrorInvalidValue;
-  }
+  const int k = fields_shape(*reinterpret_cast<const ChainAux*>(a.chain));
+  if (!k) return hipErrorInvalidValue;
+  dispatch_fields(a, k, false, 0, nullptr, dim3(static_cast<unsigned>(a.ngroups)), stream);
+  return hipGetLastError();
+}
+// Workgroups of the streaming kernel that are resident at once on `device` (0: unknown — do not use the kernel).
+int fields_stream_capacity(const ScanArgs& a, int device) {
+  const int k = fields_shape(*reinterpret_cast<const ChainAux*>(a.chain));
+  int cap = 0;
+  if (k) dispatch_fields(a, k, true, device, &cap, dim3(1), nullptr);
+  return cap;
+}
+// Streaming kernel: a.ngroups = number of wave-tiles; `producers` workgroups + the scan server's (stream_scan_workgroups()),
+// all of which must be resident together (<= fields_stream_capacity).
+int stream_scan_workgroups() { return kScanWorkgroups; }
+hipError_t launch_scan_fields_stream(const ScanArgs& a, unsigned producers, hipStream_t stream) {
+  const int k = fields_shape(*reinterpret_cast<const ChainAux*>(a.chain));
+  if (!k || producers == 0) return hipErrorInvalidValue;
+  dispatch_fields(a, k, true, 0, nullptr, dim3(producers + kScanWorkgroups), stream);
   return hipGetLastError();
 }
 

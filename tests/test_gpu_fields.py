@@ -120,25 +120,33 @@ def test_long_fields_and_handover(oracle):
     _check(oracle, IP, b"y" * 100 + b"1." * 300 + b"1 z")                                       # 600-byte super-run inside one window: 75 groups of four
 
 
-def test_dense_input_overflows_to_the_chain_kernel(oracle):
-    hay = b"1.2.3.4 " * 60000                       # 480 rows per wave-tile: the row buffer of a wave (512 per 8 tiles) overflows
-    t = _check(oracle, IP, hay, want_kernel=None)
+def test_dense_input(oracle):
+    """480 rows per wave-tile fit the streaming kernel's ring (512 rows per wave); 960 (`1.2 ` for `\\d+\\.\\d+`) do not: the
+    count word cannot even hold them, the tile raises reason 0x10 and the call reruns on the chain kernel's dense mode."""
+    _check(oracle, IP, b"1.2.3.4 " * 60000)
+    t = _check(oracle, r"\d+\.\d+", b"1.2 " * 120000, want_kernel=None)
     assert t.n_launches >= 2
 
 
-def test_no_fields_kernel_env_is_an_ab_switch(oracle):
-    """The program still runs (on scan_chain_wave.hip) when the fields kernel is disabled — what the A/B scripts use."""
+@pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_FIELDS_GROUPED": "1"}, K_FIELDS), ({"CXG_FIELDS_WORKGROUPS": "12"}, K_FIELDS)])
+def test_ab_switches(oracle, env, kernel):
+    """The A/B switches of the scripts: the chain kernel instead of the fields kernel, the grouped instead of the streaming
+    variant, a persistent grid of 8 producer workgroups (many rounds per wave, long row hold-back).  Rows == oracle in a
+    fresh process for each."""
     import os
     import subprocess
     import sys
-    code = ("import numpy as np, coregex_amd as cx\n"
+    code = ("import numpy as np, torch, zlib, coregex_amd as cx\n"
             "rx = cx.compile(r'\\d+\\.\\d+\\.\\d+\\.\\d+'); t = cx.Timing()\n"
-            "h = cx.synth_pages(2, 0xC0FFEE02, 0, 256)\n"
-            "import torch; d = torch.from_numpy(h).cuda(); n = rx.find_all_device(d.data_ptr(), h.size, timing=t)\n"
-            "print(n, t.kernel)\n")
+            "h = cx.synth_pages(2, 0xC0FFEE02, 0, 2048)\n"
+            "d = torch.from_numpy(h).cuda(); n = rx.find_all_device(d.data_ptr(), h.size, timing=t)\n"
+            "out = torch.empty((n + 8, 2), dtype=torch.int64, device='cuda'); n2 = rx.find_all_device(d.data_ptr(), h.size, out.data_ptr(), n + 8, timing=t)\n"
+            "print(t.fallback_reason, n, n2, t.kernel, t.n_launches, zlib.crc32(out[:n].cpu().numpy().tobytes()))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, CXG_NO_FIELDS_KERNEL="1", PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, PYTHONPATH=root, CXG_VERBOSE="1", **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
-    n, k = r.stdout.split()[-2:]
-    exp = oracle.Regex(IP).find_all_index(cx.synth_pages(2, 0xC0FFEE02, 0, 256))
-    assert int(n) == len(exp) and int(k) == 6
+    print(r.stdout[-300:], r.stderr[-600:])
+    n, n2, k, nl, crc = (int(v) for v in r.stdout.split()[-5:])
+    import zlib
+    exp = oracle.Regex(IP).find_all_index(cx.synth_pages(2, 0xC0FFEE02, 0, 2048))
+    assert n == len(exp) and n2 == n and k == kernel and nl == 1 and crc == zlib.crc32(exp.tobytes())
