@@ -30,7 +30,9 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip: grouped kernel
 hipError_t launch_scan_fields_stream(const ScanArgs& a, unsigned producers, hipStream_t stream);   // ... persistent streaming kernel
-int fields_stream_capacity(const ScanArgs& a, int device);
+int fields_capacity(const ScanArgs& a, int device, int mode);
+hipError_t launch_scan_fields_pers(const ScanArgs& a, unsigned workgroups, hipStream_t stream);   // ... persistent variant (deferred look-back)
+uint64_t fields_pers_unit_bytes();
 int stream_scan_workgroups();
 int fields_shape(const ChainAux& c);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
@@ -144,7 +146,7 @@ int ensureStatus(Scratch& s, uint64_t ntiles) {
   if (s.ctl) HIP_TRY(hipFree(s.ctl));
   s.ctl = nullptr; s.status = nullptr; s.statusCap = 0;
   uint64_t cap = ntiles + ntiles / 4 + 1024;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + 2 * cap * sizeof(uint64_t)));   // look-back words, then the exit-state words of scan_fsm.hip
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + 3 * cap * sizeof(uint64_t)));   // + the block words of the two-level look-back (a third region: needs cap / 64 + 1)   // look-back words, then the exit-state words of scan_fsm.hip
   s.status = reinterpret_cast<uint64_t*>(s.ctl + 64);
   s.statusCap = cap;
   s.needZero = true;
@@ -389,6 +391,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   if (int rc = ensureStatus(s, std::max<uint64_t>(a.ntiles, waveTiles))) return rc;
   a.status = s.status;
   a.status2 = s.status + s.statusCap;
+  a.status3 = s.status + 2 * s.statusCap;
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
@@ -435,6 +438,8 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
   bool fieldsStream = false;                                       // ... by its persistent streaming variant
+  bool fieldsPers = false;                                         // ... by its persistent variant with the deferred look-back (default)
+  unsigned persWorkgroups = 0;
   unsigned streamProducers = 0;
   static std::atomic<bool> fieldsStreamOk{true};                  // false once a watchdog fired under the streaming kernel
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
@@ -443,6 +448,7 @@ relaunch:
   fusedCaps = false;
   fieldsKernel = false;
   fieldsStream = false;
+  fieldsPers = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
@@ -464,7 +470,7 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
-      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
+      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 3 * s.statusCap * sizeof(uint64_t), stream));
       s.epoch = 0; s.needZero = false;
     }
     a.epoch = ++s.epoch;
@@ -477,6 +483,7 @@ relaunch:
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
     if (gen == 10) HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
+    HIP_TRY(hipMemsetAsync(a.status3, 0, (a.ngroups / 64 + 2) * sizeof(uint64_t), stream));   // block words of the two-level look-back
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
@@ -509,14 +516,14 @@ relaunch:
     // Its streaming variant (persistent grid, dense window, scan server: stream_common.hpp) needs every workgroup resident
     // at once: grid = the device's capacity for this kernel.  CXG_FIELDS_GROUPED=1 (A/B) or a watchdog that ever fired in
     // this process select the grouped variant.
-    static const bool groupedOnly = getenv("CXG_FIELDS_GROUPED") != nullptr;
+    static const bool groupedOnly = getenv("CXG_FIELDS_STREAM") == nullptr;   // the streaming variant is opt-in (round 3: slower than the grouped one)
     fieldsStream = false;
     if (fieldsKernel && !groupedOnly && fieldsStreamOk.load() && useEpoch) {
       static std::atomic<int> capCache[16][8];                         // [device][fields - 1]: 0 unknown, -1 unusable
       const int kf = cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
       int cap = capCache[t_device & 15][kf & 7].load();
       const int nscan = cxgdev::stream_scan_workgroups();
-      if (cap == 0) { cap = cxgdev::fields_stream_capacity(a, t_device); if (cap < 2 * nscan) cap = -1; capCache[t_device & 15][kf & 7].store(cap); }
+      if (cap == 0) { cap = cxgdev::fields_capacity(a, t_device, 1); if (cap < 2 * nscan) cap = -1; capCache[t_device & 15][kf & 7].store(cap); }
       if (cap > nscan) {
         static const int capEnv = getenv("CXG_FIELDS_WORKGROUPS") ? atoi(getenv("CXG_FIELDS_WORKGROUPS")) : 0;   // experiments: total workgroups incl. the scan server's
         if (capEnv > nscan) cap = capEnv;
@@ -537,7 +544,25 @@ relaunch:
         fieldsStream = true;
       }
     }
+    // The persistent variant (default): resident workgroups claim 60 KiB units by ticket and defer each unit's look-back
+    // behind the scan of the next one.  CXG_FIELDS_GROUPED=1 selects the grouped variant (A/B).
+    static const bool persOk = getenv("CXG_FIELDS_GROUPED") == nullptr && getenv("CXG_FIELDS_STREAM") == nullptr;
+    fieldsPers = false;
+    if (fieldsKernel && !fieldsStream && persOk && useEpoch) {
+      static std::atomic<int> capCacheP[16][8];
+      const int kf = cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
+      int cap = capCacheP[t_device & 15][kf & 7].load();
+      if (cap == 0) { cap = cxgdev::fields_capacity(a, t_device, 2); if (cap < 1) cap = -1; capCacheP[t_device & 15][kf & 7].store(cap); }
+      if (cap > 0) {
+        const uint64_t ub = cxgdev::fields_pers_unit_bytes();
+        a.ngroups = (len + ub - 1) / ub;
+        persWorkgroups = static_cast<unsigned>(std::min<uint64_t>(a.ngroups, static_cast<uint64_t>(cap)));
+        HIP_TRY(hipMemsetAsync(a.status3, 0, 1024, stream));          // the 256 ticket counters (scan_fields_wave.hip kPCounters)
+        fieldsPers = true;
+      }
+    }
     if (fieldsStream) le = cxgdev::launch_scan_fields_stream(a, streamProducers, stream);
+    else if (fieldsPers) le = cxgdev::launch_scan_fields_pers(a, persWorkgroups, stream);
     else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
@@ -610,7 +635,7 @@ relaunch:
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
-    timing->grid = fieldsStream ? streamProducers + static_cast<uint32_t>(cxgdev::stream_scan_workgroups()) : static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
+    timing->grid = fieldsPers ? persWorkgroups : fieldsStream ? streamProducers + static_cast<uint32_t>(cxgdev::stream_scan_workgroups()) : static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
     timing->kernel = static_cast<uint32_t>(fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
@@ -618,6 +643,8 @@ relaunch:
   if (profOn) {
     uint64_t pc[16];
     HIP_TRY(hipMemcpy(pc, s.prof, 128, hipMemcpyDeviceToHost));
+    if (fieldsKernel && !fieldsStream && !fieldsPers && pc[4]) fprintf(stderr, "[CXG_PROF] grouped fields kernel, wave 0, cycles per workgroup (%llu workgroups): tile loop %llu, first barrier %llu, prefix + look-back %llu\n",
+                                                              (unsigned long long)pc[4], (unsigned long long)(pc[1] / pc[4]), (unsigned long long)(pc[2] / pc[4]), (unsigned long long)(pc[3] / pc[4]));
     if (fieldsStream) fprintf(stderr, "[CXG_PROF] streaming fields kernel: %llu rounds waited for the scan server (ring or list of held-back tiles full)\n", (unsigned long long)pc[0]);
     if (gen == 6 && pc[15]) {
       fprintf(stderr, "[CXG_PROF] gen6 waves=%llu avg cycles per wave and group:", (unsigned long long)pc[15]);

@@ -44,9 +44,9 @@ constexpr uint32_t kCntRowsMask = 0x7FFu;             // cnt16: rows in bits 0..
 __device__ __forceinline__ void stream_publish_count(uint16_t* cnt16, uint64_t t, uint32_t rows, uint32_t epoch4) {
   __hip_atomic_store(cnt16 + t, static_cast<uint16_t>((epoch4 << 11) | rows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Wave-uniform: the base of quad q if the server has published it.
-__device__ __forceinline__ bool stream_try_base(const uint64_t* base4, uint64_t q, uint32_t epoch, uint64_t& base) {
-  const uint64_t w = __hip_atomic_load(base4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Wave-uniform: the base of unit q if the server has published it.
+__device__ __forceinline__ bool stream_try_base(const uint64_t* baseu, uint64_t q, uint32_t epoch, uint64_t& base) {
+  const uint64_t w = __hip_atomic_load(baseu + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
   const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w >> 32)));
   const uint64_t u = (static_cast<uint64_t>(hi) << 32) | lo;
@@ -58,31 +58,48 @@ struct StreamChain { uint32_t seq[8]; uint64_t base[8]; };   // LDS of a server 
 constexpr int kScanWorkgroups = 4;                    // server workgroups (blockIdx.x < kScanWorkgroups): 16 waves
 constexpr uint32_t kScanFastPolls = 256;              // full-batch polls before a wave publishes its batch piecemeal
 
-// The scan server: kScanWorkgroups workgroups of four waves.  ntiles tiles, quads q = t / 4, batches of kScanGroups * 64
-// quads, SUPER-BATCHES of four batches.  Workgroup s takes super-batches s, s + S, ...; its wave v the v-th batch of each.
-// The running base travels from batch to batch through LDS inside a super-batch (~0.2 us per hop) and from super-batch to
-// super-batch through one epoch-tagged word in HBM (gchain[], ~1-2 us per hop, 8 192 tiles each at kScanGroups = 8).
+// The scan server: kScanWorkgroups workgroups of four waves.  nunits units (a unit = the consecutive wave-tiles one producer
+// wave takes per round; its 16-bit count word holds the rows of all of them), quads q = unit / 4, batches of
+// kScanGroups * 64 quads, SUPER-BATCHES of four batches.  Workgroup s takes super-batches s, s + S, ...; its wave v the
+// v-th batch of each.  The running base travels from batch to batch through LDS inside a super-batch (~0.2 us per hop) and
+// from super-batch to super-batch through one epoch-tagged word in HBM (gchain[], ~1-2 us per hop).
 // A wave first polls its whole batch (all loads in flight at once) and, when every count is there, publishes the batch
 // total before anything else — the waves behind it never wait for its stores.  When the batch does not complete (a small
 // grid: the producers themselves wait for bases of this very batch before they can publish more), the wave takes its base
 // first and publishes group by group: the earliest unpublished quad never waits on anything later, so the server cannot
-// deadlock with the producers.
-__device__ __forceinline__ void stream_scanner(const uint16_t* cnt16, uint64_t* base4, uint64_t* gchain, uint64_t ntiles, uint32_t epoch4, uint32_t epoch,
+// deadlock with the producers.  Output: baseu[unit] = {ready, epoch, rows in front of the unit}, four words per lane
+// (two 16-byte stores).
+__device__ __forceinline__ void stream_scanner(const uint16_t* cnt16, uint64_t* baseu, uint64_t* gchain, uint64_t nunits, uint32_t epoch4, uint32_t epoch,
                                                uint64_t* total_out, uint32_t* err, StreamChain* chain) {
   const int lane = threadIdx.x & 63;
   const int v = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const uint64_t etag = kStreamReady | (static_cast<uint64_t>(epoch) << kEpochShift);
   const uint64_t* cw = reinterpret_cast<const uint64_t*>(cnt16);
-  const uint64_t nquads = (ntiles + 3) >> 2;
+  const uint64_t nquads = (nunits + 3) >> 2;
   constexpr uint64_t kBatch = static_cast<uint64_t>(kScanGroups) * 64;
   const uint64_t nbatches = (nquads + kBatch - 1) / kBatch;
   if (threadIdx.x < 8) { chain->seq[threadIdx.x] = 0u; chain->base[threadIdx.x] = 0ull; }
   __syncthreads();
+#ifndef CXG_SCAN_NOPRIO
+  __builtin_amdgcn_s_setprio(3);                                      // the server's waves share their SIMDs with seven producer waves each: they go first
+#endif
   const uint64_t e4x4 = static_cast<uint64_t>(epoch4) * 0x0800080008000800ull;   // the epoch in all four fields
   constexpr uint64_t kEpochBits = 0x7800780078007800ull;
   auto quad_rows = [](uint64_t q) -> uint32_t {
     const uint32_t lo = static_cast<uint32_t>(q), hi = static_cast<uint32_t>(q >> 32);
     return (lo & kCntRowsMask) + ((lo >> 16) & kCntRowsMask) + (hi & kCntRowsMask) + ((hi >> 16) & kCntRowsMask);
+  };
+  // the four unit bases of quad q (counts w, rows in front of the quad b): two 16-byte stores, words behind nunits dropped
+  const __amdgpu_buffer_rsrc_t rbase = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t*>(baseu), 0,
+                                                                         static_cast<int>(nunits < 0x0FFFFFFFull ? nunits * 8 : 0x7FFFFFF8ull), 0x00020000);
+  auto put_quad = [&](uint64_t q, uint64_t w, uint64_t b) {
+    const uint32_t lo = static_cast<uint32_t>(w), hi = static_cast<uint32_t>(w >> 32);
+    const uint64_t b0 = etag | b, b1 = b0 + (lo & kCntRowsMask), b2 = b1 + ((lo >> 16) & kCntRowsMask), b3 = b2 + (hi & kCntRowsMask);
+    const u32x4 s0 = {static_cast<uint32_t>(b0), static_cast<uint32_t>(b0 >> 32), static_cast<uint32_t>(b1), static_cast<uint32_t>(b1 >> 32)};
+    const u32x4 s1 = {static_cast<uint32_t>(b2), static_cast<uint32_t>(b2 >> 32), static_cast<uint32_t>(b3), static_cast<uint32_t>(b3 >> 32)};
+    const uint32_t off = static_cast<uint32_t>(q) * 32u;              // (q < 2^26: checked by the host through nunits)
+    __builtin_amdgcn_raw_buffer_store_b128(s0, rbase, off, 0, 16 /*sc1*/);
+    __builtin_amdgcn_raw_buffer_store_b128(s1, rbase, off + 16u, 0, 16);
   };
   // running base in front of batch b: 0, the word of its super-batch (first batch of a super-batch), else this workgroup's LDS
   auto get_base = [&](uint64_t b, uint64_t& bbase) -> bool {
@@ -142,20 +159,19 @@ __device__ __forceinline__ void stream_scanner(const uint16_t* cnt16, uint64_t* 
         uint64_t bbase = 0;
         if (!get_base(b, bbase)) return;
         put_base(b + 1, bbase + btotal);
-        // the bases of the batch's quads: one prefix sum per group of 64
-        uint64_t* dst = base4 + pos + lane;
+        // the bases of the batch's units: one prefix sum per group of 64 quads
         uint64_t run = bbase;
 #pragma unroll
         for (int i = 0; i < kScanGroups; i++) {
           const uint32_t sq = quad_rows(w[i]);
           const uint32_t incl = wave_inclusive_sum(sq);
-          __hip_atomic_store(dst + i * 64, etag | (run + incl - sq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          put_quad(pos + static_cast<uint64_t>(i) * 64 + lane, w[i], run + incl - sq);
           run += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
         }
       }
     }
     if (piecemeal) {
-      // ---- group by group, with bounds (the last quad may hold fewer than four tiles)
+      // ---- group by group, with bounds (the last quad may hold fewer than four units)
       uint64_t run = 0;
       if (!get_base(b, run)) return;
       const uint64_t end = pos + kBatch < nquads ? pos + kBatch : nquads;
@@ -167,7 +183,7 @@ __device__ __forceinline__ void stream_scanner(const uint16_t* cnt16, uint64_t* 
           uint64_t m = kEpochBits;
           if (q < nquads) {
             w = __hip_atomic_load(cw + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (q * 4 + 4 > ntiles) { const uint32_t nv = static_cast<uint32_t>(ntiles - q * 4); m >>= 16 * (4 - nv); w &= (1ull << (16 * nv)) - 1ull; }
+            if (q * 4 + 4 > nunits) { const uint32_t nv = static_cast<uint32_t>(nunits - q * 4); m >>= 16 * (4 - nv); w &= (1ull << (16 * nv)) - 1ull; }
           }
           if (__ballot(((w ^ e4x4) & m) == 0ull) == ~0ull) break;
           if (++spins > (kSpinLimit >> 2)) { if (lane == 0) raise_err(err, 2u); return; }
@@ -175,7 +191,7 @@ __device__ __forceinline__ void stream_scanner(const uint16_t* cnt16, uint64_t* 
         }
         const uint32_t sq = quad_rows(w);
         const uint32_t incl = wave_inclusive_sum(sq);
-        if (q < nquads) __hip_atomic_store(base4 + q, etag | (run + incl - sq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q < nquads) put_quad(q, w, run + incl - sq);
         run += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
       }
       if (b + 1 < nbatches) put_base(b + 1, run);
