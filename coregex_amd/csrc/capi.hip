@@ -28,12 +28,7 @@ size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
-hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip: grouped kernel
-hipError_t launch_scan_fields_stream(const ScanArgs& a, unsigned producers, hipStream_t stream);   // ... persistent streaming kernel
-int fields_capacity(const ScanArgs& a, int device, int mode);
-hipError_t launch_scan_fields_pers(const ScanArgs& a, unsigned workgroups, hipStream_t stream);   // ... persistent variant (deferred look-back)
-uint64_t fields_pers_unit_bytes();
-int stream_scan_workgroups();
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 int fields_shape(const ChainAux& c);
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
@@ -84,9 +79,6 @@ struct Scratch {
   uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) ... 8 XCD tickets at +32 -> 64 B, in front of `status`
   uint64_t* status = nullptr;    // ctl + 64: one allocation, one memset per launch
   uint64_t statusCap = 0;
-  uint16_t* cnt16 = nullptr;     // streaming kernels: 16-bit count words, one per wave-tile (stream_common.hpp)
-  uint64_t cnt16Cap = 0;
-  uint32_t epoch4 = 0;           // last 4-bit epoch used on cnt16 (1..15); the array is zeroed when it wraps
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
   uint32_t epoch = 0;            // last launch epoch used on `status` (block_common.hpp kEpochShift), 1..1023
   bool needZero = true;          // the next epoch launch must start from a zeroed control block + status array
@@ -104,7 +96,6 @@ struct Scratch {
       if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (ctl) (void)hipFree(ctl);
-      if (cnt16) (void)hipFree(cnt16);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
@@ -146,7 +137,7 @@ int ensureStatus(Scratch& s, uint64_t ntiles) {
   if (s.ctl) HIP_TRY(hipFree(s.ctl));
   s.ctl = nullptr; s.status = nullptr; s.statusCap = 0;
   uint64_t cap = ntiles + ntiles / 4 + 1024;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + 3 * cap * sizeof(uint64_t)));   // + the block words of the two-level look-back (a third region: needs cap / 64 + 1)   // look-back words, then the exit-state words of scan_fsm.hip
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.ctl), 64 + 2 * cap * sizeof(uint64_t)));   // look-back words, then the exit-state words of scan_fsm.hip
   s.status = reinterpret_cast<uint64_t*>(s.ctl + 64);
   s.statusCap = cap;
   s.needZero = true;
@@ -386,12 +377,9 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   a.row_width = static_cast<uint32_t>(row_width);
   a.ntiles = tilesFor(h->kind, len);
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
-  // (the streaming fields kernel keeps one count word and one base word per 3840-byte wave-tile: 4.27 x the 16 KiB tiles)
-  const uint64_t waveTiles = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
-  if (int rc = ensureStatus(s, std::max<uint64_t>(a.ntiles, waveTiles))) return rc;
+  if (int rc = ensureStatus(s, a.ntiles)) return rc;
   a.status = s.status;
   a.status2 = s.status + s.statusCap;
-  a.status3 = s.status + 2 * s.statusCap;
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
@@ -399,7 +387,6 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const uint32_t dbgBits = getenv("CXG_DEBUG") ? static_cast<uint32_t>(atoi(getenv("CXG_DEBUG"))) : 0u;
   a.prof = nullptr;
   a.dbg = dbgBits;
-  a.cnt16 = nullptr; a.epoch4 = 0;
   a.max_len = (h->flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u;
   if (profOn) {
     if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));
@@ -437,18 +424,11 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
-  bool fieldsStream = false;                                       // ... by its persistent streaming variant
-  bool fieldsPers = false;                                         // ... by its persistent variant with the deferred look-back (default)
-  unsigned persWorkgroups = 0;
-  unsigned streamProducers = 0;
-  static std::atomic<bool> fieldsStreamOk{true};                  // false once a watchdog fired under the streaming kernel
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
   int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
   fieldsKernel = false;
-  fieldsStream = false;
-  fieldsPers = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
@@ -470,7 +450,7 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
-      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 3 * s.statusCap * sizeof(uint64_t), stream));
+      HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
       s.epoch = 0; s.needZero = false;
     }
     a.epoch = ++s.epoch;
@@ -483,7 +463,6 @@ relaunch:
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
     if (gen == 10) HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
-    HIP_TRY(hipMemsetAsync(a.status3, 0, (a.ngroups / 64 + 2) * sizeof(uint64_t), stream));   // block words of the two-level look-back
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
@@ -513,57 +492,7 @@ relaunch:
     static const bool fieldsOk = getenv("CXG_NO_FIELDS_KERNEL") == nullptr;
     fieldsKernel = fieldsOk && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                    cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
-    // Its streaming variant (persistent grid, dense window, scan server: stream_common.hpp) needs every workgroup resident
-    // at once: grid = the device's capacity for this kernel.  CXG_FIELDS_GROUPED=1 (A/B) or a watchdog that ever fired in
-    // this process select the grouped variant.
-    static const bool groupedOnly = getenv("CXG_FIELDS_STREAM") == nullptr;   // the streaming variant is opt-in (round 3: slower than the grouped one)
-    fieldsStream = false;
-    if (fieldsKernel && !groupedOnly && fieldsStreamOk.load() && useEpoch) {
-      static std::atomic<int> capCache[16][8];                         // [device][fields - 1]: 0 unknown, -1 unusable
-      const int kf = cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
-      int cap = capCache[t_device & 15][kf & 7].load();
-      const int nscan = cxgdev::stream_scan_workgroups();
-      if (cap == 0) { cap = cxgdev::fields_capacity(a, t_device, 1); if (cap < 2 * nscan) cap = -1; capCache[t_device & 15][kf & 7].store(cap); }
-      if (cap > nscan) {
-        static const int capEnv = getenv("CXG_FIELDS_WORKGROUPS") ? atoi(getenv("CXG_FIELDS_WORKGROUPS")) : 0;   // experiments: total workgroups incl. the scan server's
-        if (capEnv > nscan) cap = capEnv;
-        a.ngroups = waveTiles;
-        // 16-bit count words, one per wave-tile (+ slack: the scan server reads whole quads); own array, own 4-bit epoch
-        if (waveTiles + 8 > s.cnt16Cap) {
-          if (s.cnt16) HIP_TRY(hipFree(s.cnt16));
-          s.cnt16 = nullptr; s.cnt16Cap = 0;
-          const uint64_t c = waveTiles + waveTiles / 4 + 4096;
-          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.cnt16), c * sizeof(uint16_t)));
-          s.cnt16Cap = c; s.epoch4 = 15;                              // fresh memory: zero it below
-        }
-        if (s.epoch4 >= 15u) { HIP_TRY(hipMemsetAsync(s.cnt16, 0, s.cnt16Cap * sizeof(uint16_t), stream)); s.epoch4 = 0; }
-        a.cnt16 = s.cnt16;
-        a.epoch4 = ++s.epoch4;
-        const uint64_t want = (waveTiles + cxgdev::kWavesPerBlock - 1) / cxgdev::kWavesPerBlock;
-        streamProducers = static_cast<unsigned>(std::min<uint64_t>(want, static_cast<uint64_t>(cap - nscan)));
-        fieldsStream = true;
-      }
-    }
-    // The persistent variant (default): resident workgroups claim 60 KiB units by ticket and defer each unit's look-back
-    // behind the scan of the next one.  CXG_FIELDS_GROUPED=1 selects the grouped variant (A/B).
-    static const bool persOk = getenv("CXG_FIELDS_GROUPED") == nullptr && getenv("CXG_FIELDS_STREAM") == nullptr;
-    fieldsPers = false;
-    if (fieldsKernel && !fieldsStream && persOk && useEpoch) {
-      static std::atomic<int> capCacheP[16][8];
-      const int kf = cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
-      int cap = capCacheP[t_device & 15][kf & 7].load();
-      if (cap == 0) { cap = cxgdev::fields_capacity(a, t_device, 2); if (cap < 1) cap = -1; capCacheP[t_device & 15][kf & 7].store(cap); }
-      if (cap > 0) {
-        const uint64_t ub = cxgdev::fields_pers_unit_bytes();
-        a.ngroups = (len + ub - 1) / ub;
-        persWorkgroups = static_cast<unsigned>(std::min<uint64_t>(a.ngroups, static_cast<uint64_t>(cap)));
-        HIP_TRY(hipMemsetAsync(a.status3, 0, 1024, stream));          // the 256 ticket counters (scan_fields_wave.hip kPCounters)
-        fieldsPers = true;
-      }
-    }
-    if (fieldsStream) le = cxgdev::launch_scan_fields_stream(a, streamProducers, stream);
-    else if (fieldsPers) le = cxgdev::launch_scan_fields_pers(a, persWorkgroups, stream);
-    else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
+    if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
@@ -635,7 +564,7 @@ relaunch:
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
-    timing->grid = fieldsPers ? persWorkgroups : fieldsStream ? streamProducers + static_cast<uint32_t>(cxgdev::stream_scan_workgroups()) : static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
+    timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
     timing->kernel = static_cast<uint32_t>(fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
@@ -643,9 +572,8 @@ relaunch:
   if (profOn) {
     uint64_t pc[16];
     HIP_TRY(hipMemcpy(pc, s.prof, 128, hipMemcpyDeviceToHost));
-    if (fieldsKernel && !fieldsStream && !fieldsPers && pc[4]) fprintf(stderr, "[CXG_PROF] grouped fields kernel, wave 0, cycles per workgroup (%llu workgroups): tile loop %llu, first barrier %llu, prefix + look-back %llu\n",
-                                                              (unsigned long long)pc[4], (unsigned long long)(pc[1] / pc[4]), (unsigned long long)(pc[2] / pc[4]), (unsigned long long)(pc[3] / pc[4]));
-    if (fieldsStream) fprintf(stderr, "[CXG_PROF] streaming fields kernel: %llu rounds waited for the scan server (ring or list of held-back tiles full)\n", (unsigned long long)pc[0]);
+    if (fieldsKernel && pc[4]) fprintf(stderr, "[CXG_PROF] fields kernel, wave 0, cycles per workgroup (%llu workgroups): tile loop %llu, first barrier %llu, prefix + look-back %llu\n",
+                                       (unsigned long long)pc[4], (unsigned long long)(pc[1] / pc[4]), (unsigned long long)(pc[2] / pc[4]), (unsigned long long)(pc[3] / pc[4]));
     if (gen == 6 && pc[15]) {
       fprintf(stderr, "[CXG_PROF] gen6 waves=%llu avg cycles per wave and group:", (unsigned long long)pc[15]);
       static const char* names[7] = {"A", "ldsT", "own", "B", "starts", "F", "rows"};
@@ -666,13 +594,6 @@ relaunch:
       fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
-  }
-  if ((err & 2u) && fieldsStream) {                                 // the persistent grid was not resident as a whole (or a producer gave up): grouped kernels from now on
-    fieldsStreamOk.store(false);
-    s.needZero = true;
-    fprintf(stderr, "[cxg] streaming fields kernel: a wait timed out (persistent grid not resident?): switching to the grouped kernel\n");
-    relaunches++;
-    goto relaunch;
   }
   if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
     staticGroupsOk.store(false);

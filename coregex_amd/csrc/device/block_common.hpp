@@ -11,9 +11,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef CXG_LB_SLEEP
-#define CXG_LB_SLEEP 2                     // look-back polls: s_sleep units of 64 cycles between two attempts
-#endif
 namespace cxgdev {
 
 // Error / fallback bits: the word may live in pinned host memory (wave kernels: the host reads it without a copy),
@@ -105,7 +102,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
         const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
         if (!__all(ready)) {
           if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
-          __builtin_amdgcn_s_sleep(CXG_LB_SLEEP);
+          __builtin_amdgcn_s_sleep(2);
           continue;
         }
         const unsigned long long incl_mask = __ballot((w & kFlagMask) == kFlagInclusive);
@@ -128,125 +125,5 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
   __syncthreads();
 }
 
-// Two-level look-back (round 3).  The flat version above lets every tile walk back over its predecessors 64 at a time until
-// it meets one that knows its inclusive sum; tiles dispatched together finish together, so with 2 048 resident workgroups
-// that walk is up to 32 dependent round trips to the memory side (~1.5 us each) with the workgroup's slot idle — measured
-// on the fields kernel: 0.264 ms per GiB with it, 0.199 without (profiles/r03_fields_ablation.txt), and the epilogue of an
-// otherwise empty kernel cost 0.13 ms.  Here tiles are grouped into BLOCKS of 64:
-//   every tile   publishes its aggregate, sums the aggregates of the tiles in front of it IN ITS BLOCK (one coalesced
-//                512-byte load, repeated until all are there), and looks back over BLOCK words for the block's base;
-//   the last tile of a block (the leader) also publishes the block's aggregate before that look-back and its inclusive sum
-//   after it.
-// With 2 048 resident tiles there are 32 resident blocks: the block-level look-back meets an inclusive word in its first
-// iteration.  Every wait is for tiles / blocks with SMALLER indices (same progress argument as above); chains are 2-3 round
-// trips deep instead of 32.  blk[] holds one word per block, same format and epoch tagging as status[].
-__device__ __forceinline__ void tile_lookback2(uint64_t* status, uint64_t* blk, uint64_t* total_out, uint32_t* err, uint64_t tile,
-                                               uint64_t ntiles, uint32_t total, uint64_t* s_base, uint32_t epoch) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t etag = static_cast<uint64_t>(epoch) << kEpochShift;
-  if (wave == 0) {
-    const uint64_t b = tile >> 6;
-    const int i = static_cast<int>(tile & 63);
-    const bool leader = i == 63 || tile == ntiles - 1;
-    if (lane == 0) __hip_atomic_store(status + tile, kFlagAggregate | etag | static_cast<uint64_t>(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (1) aggregates of the tiles in front of this one in its block
-    uint64_t part = 0;
-    uint32_t spins = 0;
-    if (i > 0) {
-      for (;;) {
-        uint64_t w = kFlagAggregate | etag;
-        if (lane < i) w = __hip_atomic_load(status + (b << 6) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
-        if (__all(ready)) {
-          uint64_t v = lane < i ? (w & kValueMask) : 0ull;
-#pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-          part = v;
-          break;
-        }
-        if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
-        __builtin_amdgcn_s_sleep(CXG_LB_SLEEP);
-      }
-    }
-    if (leader && lane == 0)
-      __hip_atomic_store(blk + b, (b == 0 ? kFlagInclusive : kFlagAggregate) | etag | (part + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (2) base of the block: decoupled look-back over the block words
-    uint64_t bbase = 0;
-    if (b > 0) {
-      int64_t look = static_cast<int64_t>(b) - 1;
-      spins = 0;
-      for (;;) {
-        const int64_t idx = look - lane;
-        uint64_t w = kFlagInclusive | etag;            // "blocks" before 0 contribute an inclusive 0
-        if (idx >= 0) w = __hip_atomic_load(blk + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // only the words up to the nearest inclusive one matter: a later block that is not published yet does not hold us up
-        const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
-        const unsigned long long incl_mask = __ballot(ready && (w & kFlagMask) == kFlagInclusive);
-        const int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
-        const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
-        if ((__ballot(ready) & need) != need) {
-          if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
-          __builtin_amdgcn_s_sleep(CXG_LB_SLEEP);
-          continue;
-        }
-        uint64_t v = (lane <= first_incl) ? (w & kValueMask) : 0ull;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        bbase += v;
-        if (first_incl < 64) break;
-        look -= 64;
-      }
-      if (leader && lane == 0)
-        __hip_atomic_store(blk + b, kFlagInclusive | etag | (bbase + part + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) {
-      *s_base = bbase + part;
-      if (tile == ntiles - 1) *total_out = bbase + part + total;
-    }
-  }
-  __syncthreads();
-}
-// The two halves of tile_lookback for kernels that DEFER the wait (scan_fields_wave.hip k_scan_fields_pers): a persistent
-// workgroup publishes the aggregate of the unit it has just scanned, scans its next unit, and only then resolves the base of
-// the earlier one — by then every unit in front of it has long been published, so the look-back returns at once.  (With the
-// wait right behind the scan, a workgroup's slot idles until every workgroup dispatched before it has finished: measured
-// 0.264 ms per GiB against 0.199 without any ordering, profiles/r03_fields_ablation.txt.)  Executed by wave 0.
-__device__ __forceinline__ void lookback_publish(uint64_t* status, uint64_t tile, uint32_t total, uint32_t epoch) {
-  if ((threadIdx.x & 63) == 0)
-    __hip_atomic_store(status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | (static_cast<uint64_t>(epoch) << kEpochShift) | static_cast<uint64_t>(total),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t lookback_resolve(uint64_t* status, uint64_t* total_out, uint32_t* err, uint64_t tile, uint64_t ntiles, uint32_t total, uint32_t epoch) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t etag = static_cast<uint64_t>(epoch) << kEpochShift;
-  uint64_t base = 0;
-  if (tile > 0) {
-    int64_t look = static_cast<int64_t>(tile) - 1;
-    uint32_t spins = 0;
-    for (;;) {
-      const int64_t idx = look - lane;
-      uint64_t w = kFlagInclusive | etag;
-      if (idx >= 0) w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
-      const unsigned long long incl_mask = __ballot(ready && (w & kFlagMask) == kFlagInclusive);
-      const int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
-      const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);   // words behind the nearest inclusive one do not matter
-      if ((__ballot(ready) & need) != need) {
-        if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
-        __builtin_amdgcn_s_sleep(CXG_LB_SLEEP);
-        continue;
-      }
-      uint64_t v = (lane <= first_incl) ? (w & kValueMask) : 0ull;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-      base += v;
-      if (first_incl < 64) break;
-      look -= 64;
-    }
-    if (lane == 0) __hip_atomic_store(status + tile, kFlagInclusive | etag | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (lane == 0 && tile == ntiles - 1) *total_out = base + total;
-  return base;
-}
 
 }  // namespace cxgdev

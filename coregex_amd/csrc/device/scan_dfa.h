@@ -66,9 +66,6 @@ struct ScanArgs {
   uint32_t tiles_per_wave;  // scan_chain_wave.hip: kTilesPerWave, or kDenseTilesPerWave after a row-buffer overflow
   uint32_t max_len;     // != 0: a match longer than this raises error bit 64 (UseBoth programs, walk.hpp kFlagBothRestart)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
-  uint64_t* status3;    // wave kernels: block words of the two-level look-back (block_common.hpp tile_lookback2), [ngroups / 64 + 1], same life cycle as status
-  uint16_t* cnt16;      // streaming kernels (stream_common.hpp): one 16-bit count word per wave-tile, {epoch4, rows}
-  uint32_t epoch4;      // ... and the 4-bit epoch (1..15) of that array for this launch
 };
 
 }  // namespace cxgdev

@@ -8,7 +8,6 @@
 namespace cxgdev {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // A class that is a union of up to four ASCII ranges (\w = [0-9A-Z_a-z]): range tests share x|0x80 and x&0x7F.
 struct SetRanges { uint32_t n; uint32_t lo4[4], hi4[4]; };   // splat bounds, hi4 = (0x7F - hi) splat

@@ -121,19 +121,17 @@ def test_long_fields_and_handover(oracle):
 
 
 def test_dense_input(oracle):
-    """Rows are buffered per wave and unit of four tiles (256): 96 rows per wave-tile overflow that buffer (reason 0x10) and
+    """Rows are buffered per wave and group of eight tiles (512): 96 rows per wave-tile overflow that buffer (reason 0x10) and
     the call reruns on the chain kernel's dense mode, as do 480 — with the oracle's rows either way."""
     _check(oracle, IP, b"10.0.0.1 - some words of padding here..\n" * 12000, want_kernel=None)      # 96 rows per wave-tile
     t = _check(oracle, IP, b"1.2.3.4 " * 60000, want_kernel=None)                    # 480 rows per wave-tile
     assert t.n_launches >= 2
 
 
-@pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_FIELDS_GROUPED": "1"}, K_FIELDS), ({"CXG_FIELDS_STREAM": "1"}, K_FIELDS),
-                                        ({"CXG_FIELDS_STREAM": "1", "CXG_FIELDS_WORKGROUPS": "12"}, K_FIELDS)])
+@pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_TICKETS": "1"}, K_FIELDS), ({"CXG_NO_EPOCH": "1"}, K_FIELDS)])
 def test_ab_switches(oracle, env, kernel):
-    """The A/B switches of the scripts: the chain kernel instead of the fields kernel; the grouped variant and the streaming
-    variant (scan server) instead of the persistent one; the streaming variant on a grid of 8 producer workgroups (many
-    rounds per wave, long row hold-back).  Rows == oracle in a fresh process for each."""
+    """The A/B switches of the scripts: the chain kernel instead of the fields kernel; tickets instead of static group
+    assignment; zeroed look-back words instead of launch epochs.  Rows == oracle in a fresh process for each."""
     import os
     import subprocess
     import sys
