@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=1.0, help="weak scaling: bytes per rank (BASELINE configs[1]: 1 GiB)")
     ap.add_argument("--total-gib", type=float, default=0.0, help="strong scaling: fixed corpus split over the ranks (north star: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-all-rows", action="store_true",
+                    help="after the timed region: count + order-sensitive 64-bit checksum of ALL rows of this rank's shard against the oracle run on all host "
+                         "cores over the same pages (oracle/scale.cpp); meant for shards larger than the cpu_baseline sample, e.g. --total-gib 64 --gpus 1")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
@@ -210,10 +213,34 @@ def main():
             result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
         result["cpu_baseline"] = _cpu_baseline(args.config, cfg, pattern, buf, out, nmatch, nbytes, width, base)
+    if args.check_all_rows and not os.environ.get("CXG_DEBUG"):
+        result.setdefault("cpu_baseline", {})["all_rows_check"] = _check_all_rows(pattern, synth, seed, rank * npages, npages, out, nmatch, width, base)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _check_all_rows(pattern, synth, seed, first_page, npages, out, nmatch, width, base):
+    """Count and order-sensitive checksum (row k, column j weighs k + 1 + 7 j, mod 2^64) of every row the device wrote, against the
+    oracle over the same synthlog pages on all host cores.  The oracle is the checker here, after the timed region."""
+    import torch
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    ref = O.scan_synth(pattern, synth, seed, first_page, npages, width=width)
+    dt = time.perf_counter() - t0
+    rows = out[:nmatch]
+    k = torch.arange(1, nmatch + 1, dtype=torch.int64, device=rows.device)
+    got = []
+    for j in range(width):
+        col = rows[:, j]
+        col = torch.where(col < 0, col, col - base)                   # oracle offsets are relative to the shard's first page; -1 (unset group) stays
+        got.append(int((col * (k + 7 * j)).sum().item()) & ((1 << 64) - 1))
+    ok = nmatch == ref["rows"] and got == ref["sums"]
+    if not ok:
+        raise SystemExit(f"PARITY FAILURE at full size: device {nmatch} rows, checksums {got}; oracle {ref['rows']} rows, {ref['sums']}")
+    return {"rows": nmatch, "checksums_equal": True, "oracle_threads": ref["threads"], "oracle_wall_s": round(dt, 2),
+            "oracle_GBps_all_cores": round(npages * 4096 / dt / 1e9, 2)}
 
 
 def _relaunch_one_rank_per_gpu(n, stub):

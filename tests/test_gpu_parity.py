@@ -249,24 +249,27 @@ def test_full_size_shard_property(need_gpu, oracle, cfg, pat, gib):
         assert got.shape == exp.shape and np.array_equal(got, exp), (cfg, p0)
 
 
-def test_config2_8gib_count_and_checksum_vs_multithreaded_oracle(need_gpu, oracle):
-    """the headline configuration at the north-star shard size — total count and the order-sensitive
-    64-bit checksum of ALL rows of one 8 GiB launch against the oracle run multi-threaded over the same pages
-    (oracle/scale.cpp); config 4 likewise on 2 GiB (391 M rows)."""
+@pytest.mark.parametrize("cfg,pat,gib", [(2, r"\d+\.\d+\.\d+\.\d+", 8), (1, r"error", 8), (3, LITS16_EARLY, 8), (4, r"[\w]+", 8), (5, r"(\w+)@(\w+)\.(\w+)", 8)])
+def test_8gib_count_and_checksum_vs_multithreaded_oracle(need_gpu, oracle, cfg, pat, gib):
+    """every BASELINE configuration at the north-star shard size (64 GiB / 8) — total count and the
+    order-sensitive 64-bit checksum of ALL rows of one 8 GiB launch against the oracle run multi-threaded over the same pages
+    (oracle/scale.cpp); config 5: FindAllSubmatchIndex rows of 8 values."""
     import torch
-    for cfg, pat, gib in ((2, r"\d+\.\d+\.\d+\.\d+", 8), (4, r"[\w]+", 2)):
-        nbytes = gib << 30
-        buf = cx.DeviceBuffer(nbytes)
-        buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
-        rx = cx.compile(pat)
-        n = rx.find_all_device(buf.ptr, nbytes)
-        out = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
-        assert rx.find_all_device(buf.ptr, nbytes, out.data_ptr(), n + 8) == n
-        got = _device_checksums(out[:n])
-        ref = oracle.scan_synth(pat, cfg, 0xC0FFEE00 + cfg, 0, nbytes // 4096)
-        assert n == ref["rows"], (cfg, n, ref["rows"])
-        assert got == ref["sums"], (cfg, got, ref["sums"])
-        del out, buf
+    nbytes = gib << 30
+    buf = cx.DeviceBuffer(nbytes)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+    rx = cx.compile(pat)
+    sub = cfg == 5
+    width = 2 * rx.num_groups if sub else 2
+    scan = rx.find_all_submatch_device if sub else rx.find_all_device
+    n = scan(buf.ptr, nbytes)
+    out = torch.empty((n + 8, width), dtype=torch.int64, device="cuda")
+    assert scan(buf.ptr, nbytes, out.data_ptr(), n + 8) == n
+    got = _device_checksums(out[:n])
+    ref = oracle.scan_synth(pat, cfg, 0xC0FFEE00 + cfg, 0, nbytes // 4096, width=width)
+    assert n == ref["rows"], (cfg, n, ref["rows"])
+    assert got == ref["sums"], (cfg, got, ref["sums"])
+    del out, buf
 
 
 def test_many_launches_epochs_and_legacy_mix(need_gpu, oracle):
