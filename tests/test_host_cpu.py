@@ -784,3 +784,50 @@ def test_host_side_under_address_and_ub_sanitizers():
     r = subprocess.run([_sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "cpu_sanitize.py"), "600", "11"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0 and b"no sanitizer report" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_product_frontend_pinned_on_reference_strategy_rows():
+    """`cxg_compile` (the product's own C++ front-end, not the oracle) directly against the rows of the
+    reference's strategy table (meta/strategy_selection_test.go:16-63, :323-352, transcribed in tests/golden/reference_vectors.json).
+    Every row inside the accepted subset must give the reference's strategy; the rows the front-end refuses are the three
+    end-of-text patterns (text anchors: `frontend.cc` unsupported()) — named here so that a silent change shows."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    refused = []
+    for c in vec["strategy_selection"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        if rx.strategy != c["want"]:
+            refused.append((c["pattern"], c["want"], rx.strategy, rx.supported))
+    assert sorted(p for p, *_ in refused) == sorted(["hello$", "world$", r"\.txt$"]), refused
+    assert all(not sup for *_, sup in refused)           # never served with another strategy's semantics
+
+
+def _teddy_literals_of(blob: bytes):
+    """The literal table of a UseTeddy program image (walk.hpp BlobHeader / TeddyAux): literals by id."""
+    magic, kind, flags, ngroups, fs, fst, ffa, foff, rs, rst, rfa, roff, info_off, total, aux_off, aux_len = struct.unpack_from("<16I", blob, 0)
+    assert kind == 4, kind                                           # kKindTeddy
+    nlits, nb, mn, mx, ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len, _pad = struct.unpack_from("<12I", blob, aux_off)
+    lens = blob[aux_off + lens_off: aux_off + lens_off + nlits]
+    offs = struct.unpack_from("<%dH" % nlits, blob, aux_off + off_off)
+    return [bytes(blob[aux_off + bytes_off + offs[i]: aux_off + bytes_off + offs[i] + lens[i]]) for i in range(nlits)]
+
+
+def test_product_literal_sets_pinned_on_reference_rows():
+    """The literal sets the product front-end hands to the Teddy kernels (program image of UseTeddy patterns) against the
+    reference's extractor table (literal/extractor_test.go, prefix rows of plain alternations): the same literals."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    checked = 0
+    for c in vec["literal_extraction"]["cases"]:
+        if c["which"] != "prefix":
+            continue
+        try:
+            rx = cx.compile(c["pattern"])
+            if rx.strategy != "UseTeddy" or not rx.supported:
+                continue
+            blob = rx.blob()
+        except cx.CoregexError:
+            continue
+        assert sorted(_teddy_literals_of(blob)) == sorted(x.encode("latin-1") for x in c["want"]), c
+        checked += 1
+    assert checked >= 3, checked
