@@ -387,6 +387,8 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   static const uint32_t dbgBits = getenv("CXG_DEBUG") ? static_cast<uint32_t>(atoi(getenv("CXG_DEBUG"))) : 0u;
   a.prof = nullptr;
   a.dbg = dbgBits;
+  a.limit = limit > 0 ? static_cast<uint64_t>(limit) : 0;
+  a.stop = reinterpret_cast<uint32_t*>(s.ctl + 24);                   // device word of the control block (zeroed with it; epoch-tagged otherwise)
   a.max_len = (h->flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u;
   if (profOn) {
     if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));

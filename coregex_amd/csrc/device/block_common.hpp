@@ -82,8 +82,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t mine, uint32_t
 
 // Publishes this tile's count and resolves its exclusive global base into *s_base (LDS).
 // Executed by wave 0; ends with __syncthreads() for the whole block.
+// limit / stop (optional): FindAll with n > 0 (meta/findall.go:196).  The tile whose inclusive sum reaches `limit` stores
+// epoch + 1 into *stop; kernels that look at it let later workgroups skip their scan (they publish zero rows), so a call
+// for the first ten matches of 8 GiB costs the groups that were resident when the tenth was counted, not the haystack.
 __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_out, uint32_t* err, uint64_t tile,
-                                              uint64_t ntiles, uint32_t total, uint64_t* s_base, uint32_t epoch = 0) {
+                                              uint64_t ntiles, uint32_t total, uint64_t* s_base, uint32_t epoch = 0,
+                                              uint64_t limit = 0, uint32_t* stop = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t etag = static_cast<uint64_t>(epoch) << kEpochShift;
   if (wave == 0) {
@@ -120,6 +124,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
     if (lane == 0) {
       *s_base = base;
       if (tile == ntiles - 1) *total_out = base + total;
+      if (limit != 0 && stop != nullptr && base + total >= limit) __hip_atomic_store(stop, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();

@@ -318,6 +318,10 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   constexpr int tpw = kTilesPerWave;
   uint32_t nrows_w = 0;                                              // wave-uniform
   uint32_t fallback = 0;
+  // FindAll with n > 0: enough rows counted in front of this group — it contributes nothing (block_common.hpp tile_lookback)
+  const bool skip = a.limit != 0 && __builtin_amdgcn_readfirstlane(static_cast<int>(__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == static_cast<int>(a.epoch + 1u);
+  const int ntile = skip ? 0 : tpw;
+  if (skip && lane0 < tpw) s_cnt[wave][lane0] = 0;
   auto tile_lo_of = [&](int jj) { return (group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave) * static_cast<uint64_t>(kWaveTile); };
   const uint64_t pt0 = a.prof ? __builtin_readcyclecounter() : 0ull;   // CXG_PROF=1: cycles of wave 0 per phase, summed over the workgroups
 
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   int32_t nvalid_cur = 0;
   fields_first_loads(x, fields_window(a.hay, a.len, tile_lo_of(0), true, nvalid_cur), lane, group == 0 && wave == 0);
 
-  for (int j = 0; j < tpw; j++) {
+  for (int j = 0; j < ntile; j++) {
     // Opaque copy of the lane id per wave-tile: lane-derived values are recomputed (a few ALU ops) instead of being hoisted
     // out of the loop and spilled — a scratch reload waits on vmcnt and would drain the loads in flight.
     lane = lane0;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * tpw];
   if (a.dbg & 2u) { if (tid == 0) s_base = 0; __syncthreads(); }     // CXG_DEBUG=2 (timing experiments, rows land in the wrong places): no look-back
-  else tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
+  else tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (a.prof && tid == 0) {
     const uint64_t pt3 = __builtin_readcyclecounter();
     atomicAdd(reinterpret_cast<unsigned long long*>(a.prof + 1), static_cast<unsigned long long>(pt1 - pt0));   // tile loop

@@ -146,8 +146,11 @@ __device__ __forceinline__ uint32_t wait_tile_exit(uint32_t* s_exit, uint64_t* s
     }
     w = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
     if (w & kExitValid) break;
-    if (spins > (kSpinLimit << 4)) { if (lane == 0) raise_err(err, 2u); break; }   // (a hand-off chain over every tile of the input is legitimate)
-    __builtin_amdgcn_s_sleep(4);
+    if (spins > (kSpinLimit << 6)) { if (lane == 0) raise_err(err, 2u); break; }   // (a hand-off chain over every tile of the input is legitimate)
+    // Input without synchronising structure makes this a serial chain over every tile (17 476 hops for 64 MiB): the poll
+    // interval IS the hop latency.  s_sleep 4 (256 cycles) gave 323 ns per tile = 5.65 ms; the LDS hop inside a workgroup
+    // is polled back to back, the HBM hop between workgroups with the shortest sleep.
+    if (q == 0) __builtin_amdgcn_s_sleep(1);
   }
   return w & 0xFFFFu;
 }

@@ -149,3 +149,24 @@ def test_ab_switches(oracle, env, kernel):
     import zlib
     exp = oracle.Regex(IP).find_all_index(cx.synth_pages(2, 0xC0FFEE02, 0, 2048))
     assert n == len(exp) and n2 == n and k == kernel and nl == 1 and crc == zlib.crc32(exp.tobytes())
+
+
+def test_limit_stops_the_scan_early(oracle):
+    """FindAllIndex(b, n) with n > 0 (meta/findall.go:196): the first n rows, and — on the fields kernel — without scanning the
+    whole haystack: groups dispatched after the n-th row was counted publish nothing (block_common.hpp tile_lookback)."""
+    import torch
+    npages = (2 << 30) // 4096
+    buf = cx.DeviceBuffer(npages * 4096)
+    buf.fill_synth(2, 0xC0FFEE02, 0)
+    rx = cx.compile(IP)
+    head = cx.synth_pages(2, 0xC0FFEE02, 0, 64)
+    exp = oracle.Regex(IP).find_all_index(head)
+    out = torch.empty((1 << 20, 2), dtype=torch.int64, device="cuda")
+    t_full, t_lim = cx.Timing(), cx.Timing()
+    full = rx.find_all_device(buf.ptr, npages * 4096, timing=t_full)
+    for n in (1, 10, 1000):
+        got = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), out.shape[0], n=n, timing=t_lim)
+        assert got == n and np.array_equal(out[:n].cpu().numpy(), exp[:n]), n
+        assert t_lim.kernel == K_FIELDS
+    assert full > 1000 and t_lim.kernel_ms < 0.5 * t_full.kernel_ms, (t_lim.kernel_ms, t_full.kernel_ms)
+    assert rx.find_all_device(buf.ptr, npages * 4096, n=7) == 7          # Count(b, 7)
