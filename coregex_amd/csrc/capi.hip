@@ -79,6 +79,8 @@ struct Scratch {
   uint8_t* ctl = nullptr;        // ticket(4) pad(4) total(8) err(4) pad(4) ... 8 XCD tickets at +32 -> 64 B, in front of `status`
   uint64_t* status = nullptr;    // ctl + 64: one allocation, one memset per launch
   uint64_t statusCap = 0;
+  uint64_t* fsmMaps = nullptr;   // scan_fsm.hip: three map words per group
+  uint64_t fsmMapsCap = 0;
   uint64_t* hostCtl = nullptr;   // pinned mirror of ctl
   uint32_t epoch = 0;            // last launch epoch used on `status` (block_common.hpp kEpochShift), 1..1023
   bool needZero = true;          // the next epoch launch must start from a zeroed control block + status array
@@ -96,6 +98,7 @@ struct Scratch {
       if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (ctl) (void)hipFree(ctl);
+      if (fsmMaps) (void)hipFree(fsmMaps);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
@@ -449,10 +452,22 @@ relaunch:
   a.epoch = 0;
   a.total = reinterpret_cast<uint64_t*>(s.ctl + 8);
   a.err = reinterpret_cast<uint32_t*>(s.ctl + 16);
+  if (gen == 10) {                                                 // three map words per group (scan_fsm.hip fsm_group_entry), epoch-tagged like the rest
+    if (3 * a.ngroups > s.fsmMapsCap) {
+      if (s.fsmMaps) HIP_TRY(hipFree(s.fsmMaps));
+      s.fsmMaps = nullptr; s.fsmMapsCap = 0;
+      const uint64_t cap = 3 * a.ngroups + 3 * a.ngroups / 4 + 1024;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.fsmMaps), cap * sizeof(uint64_t)));
+      s.fsmMapsCap = cap;
+      HIP_TRY(hipMemsetAsync(s.fsmMaps, 0, cap * sizeof(uint64_t), stream));
+    }
+    a.fsm_maps = s.fsmMaps;
+  }
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
       HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
+      if (s.fsmMaps) HIP_TRY(hipMemsetAsync(s.fsmMaps, 0, s.fsmMapsCap * sizeof(uint64_t), stream));
       s.epoch = 0; s.needZero = false;
     }
     a.epoch = ++s.epoch;
@@ -464,7 +479,10 @@ relaunch:
   } else {
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
-    if (gen == 10) HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
+    if (gen == 10) {
+      HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
+      HIP_TRY(hipMemsetAsync(a.fsm_maps, 0, 3 * a.ngroups * sizeof(uint64_t), stream));
+    }
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));

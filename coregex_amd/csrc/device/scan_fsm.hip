@@ -119,11 +119,18 @@ struct FsmLds {
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // rows of the group: end inside its wave-tile
   uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // ... and length (0: unresolved)
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
-  uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
-  int64_t tail[kWavesPerBlock * kTilesPerWave];                // absolute end of a tile's last row, -1: no rows
+  union {                                                      // (the 10 KiB-image instantiations sit 320 bytes below 4 workgroups per CU)
+    struct {                                                   // after the tile loop
+      uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
+      int64_t tail[kWavesPerBlock * kTilesPerWave];            // absolute end of a tile's last row, -1: no rows
+    };
+    uint16_t mapx[kWavesPerBlock * kTilesPerWave][kFsmMembers];   // inside it — deferred tiles: exit for the j-th member of the tile's first set (fsm_resolve_exits)
+  };
   uint64_t group;
   uint64_t base;
   uint32_t exit[kWavesPerBlock * kTilesPerWave];               // exit state of every tile of the group | 0x80000000 once known
+ uint16_t mapu[kWavesPerBlock * kTilesPerWave];               // ... and that set (uncertainty row)
+  uint32_t ndefer;                                             // some wave left tiles to the second pass
 };
 
 // Exit state of a tile, handed to the next tile (needed only when that tile's first set of possible states does not
@@ -154,6 +161,166 @@ __device__ __forceinline__ uint32_t wait_tile_exit(uint32_t* s_exit, uint64_t* s
   }
   return w & 0xFFFFu;
 }
+// Wave-uniform: the same word without insisting — kExitValid clear after `tries` looks.
+__device__ __forceinline__ uint32_t peek_tile_exit(uint32_t* s_exit, uint64_t* status2, uint64_t group, int q, uint32_t epoch, uint32_t tries) {
+  uint32_t w = 0;
+  if (q == 0 && group == 0) return kExitValid;
+  for (uint32_t spins = 0; spins < tries; spins++) {
+    if (q > 0) w = __hip_atomic_load(s_exit + (q - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else {
+      const uint64_t g = __hip_atomic_load(status2 + (group - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w = (static_cast<uint32_t>(g >> 32) == epoch) ? static_cast<uint32_t>(g) : 0u;
+    }
+    w = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
+    if (w & kExitValid) break;
+  }
+  return w;
+}
+
+// The exit of the group in front of `group` when that group's own exit depends on ITS entry, and so on: a decoupled look-back
+// over MAPS instead of sums.  Every group whose first tile left a map publishes the group's map (first set u, exit for each
+// of its <= 8 members: three epoch-tagged words behind the exit words in status2); a group with a known exit publishes the
+// exit VALUE (status2[group]).  Lane l reads group look - l; the maps in front are composed nearest first —
+// C := C o M, starting from the identity on this group's candidates — until a VALUE ends the walk: 64 groups per round
+// trip, and no group waits for the one in front to finish (a hop from workgroup to workgroup costs ~5 us across XCDs:
+// 546 of them for 64 MiB were 2.8 ms).  keys / vals: lanes 0..7, this group's candidate entries and its exits for them.
+__device__ __forceinline__ uint32_t fsm_group_entry(const FsmView& v, const ScanArgs& a, uint64_t group, uint32_t u_own, uint32_t keys, uint32_t vals,
+                                                    bool publish, int lane) {
+  constexpr uint64_t kF = 0xFFFFull;
+  const uint64_t tag = static_cast<uint64_t>(a.epoch + 1u) << 48;
+  uint64_t* const maps = a.fsm_maps;
+  uint32_t sv[kFsmMembers], ck[kFsmMembers], cv[kFsmMembers];
+#pragma unroll
+  for (int i = 0; i < kFsmMembers; i++) {
+    sv[i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(vals), i));
+    ck[i] = cv[i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(keys), i));   // identity on the candidates
+  }
+  if (publish && lane < 3) {
+    const uint64_t w = lane == 0 ? (u_own | (static_cast<uint64_t>(sv[0]) << 16) | (static_cast<uint64_t>(sv[1]) << 32))
+                     : lane == 1 ? (sv[2] | (static_cast<uint64_t>(sv[3]) << 16) | (static_cast<uint64_t>(sv[4]) << 32))
+                                 : (sv[5] | (static_cast<uint64_t>(sv[6]) << 16) | (static_cast<uint64_t>(sv[7]) << 32));
+    __hip_atomic_store(maps + 3 * group + lane, tag | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // this lane's field of a broadcast map: member j = lane & 7 is field j + 1 of the 9 (u, v0..v7), three per word
+  // (opaque lane id: with the plain one the compiler evaluates every readlane(res, i) below as scalar code for lane i — 64
+  // compare-and-select chains of five SALU operations per step, 2 us; as eight lanes of VALU work a step is ~50 instructions)
+  int lane_o = lane;
+  asm volatile("" : "+v"(lane_o));
+  const int fld = (lane_o & (kFsmMembers - 1)) + 1, fw = fld / 3, fs = 16 * (fld % 3);
+  int64_t look = static_cast<int64_t>(group) - 1;
+  uint32_t spins = 0;
+  for (;;) {
+    const int64_t idx = look - lane;
+    uint64_t wv = (static_cast<uint64_t>(a.epoch) << 32) | kExitValid, m0 = 0, m1 = 0, m2 = 0;   // (in front of group 0: never reached, group 0 has a VALUE)
+    if (idx >= 0) {
+      wv = __hip_atomic_load(a.status2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m0 = __hip_atomic_load(maps + 3 * idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m1 = __hip_atomic_load(maps + 3 * idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m2 = __hip_atomic_load(maps + 3 * idx + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool isval = static_cast<uint32_t>(wv >> 32) == a.epoch && (wv & kExitValid) != 0;
+    const bool ismap = (m0 >> 48) == (tag >> 48) && (m1 >> 48) == (tag >> 48) && (m2 >> 48) == (tag >> 48);
+    const unsigned long long notready = ~__ballot(isval || ismap);
+    const int nready = notready ? __builtin_ctzll(notready) : 64;
+    if (nready == 0) {
+      if (++spins > kSpinLimit) { if (lane == 0) raise_err(a.err, 2u); return 0u; }
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    const unsigned long long vm = __ballot(isval) & (nready == 64 ? ~0ull : ((1ull << nready) - 1ull));
+    const int nsteps = vm ? __builtin_ctzll(vm) : nready;
+    uint32_t kk[kFsmMembers];                                      // this lane's map: its candidate entries
+    const uint32_t u_l = static_cast<uint32_t>(m0 & kF);
+#pragma unroll
+    for (int i = 0; i < kFsmMembers; i++) kk[i] = (ismap && !isval) ? fsm_member(v, u_l, static_cast<uint32_t>(i)) : 0xFFFFu;
+    for (int l = 0; l < nsteps; l++) {                             // C := C o M_l  (uniform loop)
+      const uint32_t a0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m0)), l)), a1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m0 >> 32)), l));
+      const uint32_t b0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m1)), l)), b1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m1 >> 32)), l));
+      const uint32_t c0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m2)), l)), c1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(m2 >> 32)), l));
+      const uint64_t w = fw == 0 ? ((static_cast<uint64_t>(a1) << 32) | a0) : fw == 1 ? ((static_cast<uint64_t>(b1) << 32) | b0) : ((static_cast<uint64_t>(c1) << 32) | c0);
+      const uint32_t x = static_cast<uint32_t>((w >> fs) & kF);       // M_l's exit for its member lane & 7
+      uint32_t res = 0xFFFFu;
+#pragma unroll
+      for (int i = 0; i < kFsmMembers; i++) res = (x == ck[i]) ? cv[i] : res;
+      if (x == 0xFFFFu) res = 0xFFFFu;
+#pragma unroll
+      for (int i = 0; i < kFsmMembers; i++) {
+        cv[i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(res), i));
+        ck[i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(kk[i]), l));
+      }
+    }
+    if (vm) {
+      const uint32_t e = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(wv)), nsteps)) & 0xFFFFu;
+      uint32_t r = 0xFFFFu;
+#pragma unroll
+      for (int i = 0; i < kFsmMembers; i++) r = (e == ck[i] && e != 0xFFFFu) ? cv[i] : r;
+      if (r == 0xFFFFu && lane == 0) raise_err(a.err, 8u | (1u << 8));                 // the true state is not in the listed set: cannot happen
+      return r;
+    }
+    look -= nsteps;
+  }
+}
+
+// Input without synchronising structure (`1.1.1.1...` for the IPv4 pattern): a tile's first set of possible states does not
+// collapse, its true entry is the exit of the tile in front, and so on back to the start of the input — a serial chain over
+// every tile.  Round 2 walked that chain with a blocked wave per tile (323 ns per tile: the wave in front had to finish ITS
+// tile and stage the next before the chain moved on).  Now a tile that would have to wait leaves its MAP (candidate entry ->
+// exit, <= 8 pairs) in LDS and the wave goes on to its other tiles, which do the same; after the group's barrier one wave
+// (a) composes the group's maps into one, (b) waits for the exit of the group in front, (c) publishes its own group's exit —
+// ONE lookup behind the arrival, the only serial step between groups — and (d) fills in the exit of every tile; the deferred
+// tiles then run as usual (second pass), their waits already answered.  NT = tiles per group.
+template <int NT>
+__device__ __forceinline__ void fsm_resolve_exits(const FsmView& v, uint32_t* s_exit, const uint16_t (*s_mapx)[kFsmMembers], const uint16_t* s_mapu, const ScanArgs& a, uint64_t group, int lane) {
+  const uint64_t tiles_all = (a.len + kWaveTile - 1) / static_cast<uint64_t>(kWaveTile), first = group * static_cast<uint64_t>(NT);
+  const int nlive = tiles_all - first >= static_cast<uint64_t>(NT) ? NT : static_cast<int>(tiles_all - first);
+  const int l8 = lane & (kFsmMembers - 1);
+  const bool open = (s_exit[0] & kExitValid) == 0u;             // the group's first tile left a map: its exit depends on the group in front
+  auto pair_of = [&](int q) -> uint32_t {                       // lanes 0..7: member | exit << 16 of tile q's map
+    return (lane < kFsmMembers ? fsm_member(v, s_mapu[q], static_cast<uint32_t>(l8)) : 0xFFFFu) | (static_cast<uint32_t>(s_mapx[q][l8]) << 16);
+  };
+  uint32_t cur = open ? (pair_of(0) & 0xFFFFu) : 0u;
+  const uint32_t cur0 = cur;
+#pragma unroll 1
+  for (int q = 0; q < NT; q++) {
+    const uint32_t ev = q < nlive ? s_exit[q] : 0u;
+    if (q >= nlive) {}
+    else if (ev & kExitValid) cur = ev & 0xFFFFu;               // a tile whose exit does not depend on its entry: the chain restarts
+    else {
+      const uint32_t p = pair_of(q);
+      uint32_t nxt = 0xFFFFu;
+#pragma unroll
+      for (int jm = 0; jm < kFsmMembers; jm++) {
+        const uint32_t pj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(p), jm));
+        if ((pj & 0xFFFFu) == cur) nxt = pj >> 16;
+      }
+      cur = cur == 0xFFFFu ? 0xFFFFu : nxt;
+    }
+  }
+  uint32_t entry = 0u, gx;
+  if (open) {
+    if (group == 0) { if (lane == 0) raise_err(a.err, 8u | (1u << 8)); return; }      // cannot happen: the input's first state is known
+    entry = (a.dbg & 8u) ? 0u : fsm_group_entry(v, a, group, s_mapu[0], cur0, cur, nlive == NT, lane);   // (CXG_DEBUG=8: timing experiment, wrong rows)
+    const unsigned long long hit = __ballot(lane < kFsmMembers && cur0 == entry);
+    gx = hit ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur), __builtin_ctzll(hit))) : 0xFFFFu;
+  } else gx = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cur), 0));
+  if (gx == 0xFFFFu) { if (lane == 0) raise_err(a.err, 8u | (1u << 8)); }              // the true state is not in the listed set: cannot happen
+  else if (lane == 0 && nlive == NT)
+    __hip_atomic_store(a.status2 + group, (static_cast<uint64_t>(a.epoch) << 32) | kExitValid | gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t c = entry;
+#pragma unroll 1
+  for (int q = 0; q < NT; q++) {
+    const uint32_t ev = q < nlive ? s_exit[q] : 0u;
+    if (q >= nlive) {}
+    else if (ev & kExitValid) c = ev & 0xFFFFu;
+    else {
+      const uint32_t p = pair_of(q);
+      const unsigned long long hit = __ballot(lane < kFsmMembers && (p & 0xFFFFu) == c && c != 0xFFFFu);
+      c = hit ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(p >> 16), __builtin_ctzll(hit))) : 0xFFFFu;
+      if (c == 0xFFFFu) { if (lane == 0) raise_err(a.err, 8u | (1u << 8)); c = 0u; }
+      if (lane == 0) s_exit[q] = c | kExitValid;
+    }
+  }
+}
 
 }  // namespace
 
@@ -172,7 +339,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
+  if (tid == 0) { s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups); S.ndefer = 0u; }
   if (tid < kWavesPerBlock * kTilesPerWave) S.exit[tid] = 0u;
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
   {
@@ -210,7 +377,22 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
   uint64_t tlast = __builtin_readcyclecounter();
 #endif
 
-  for (int j = 0; j < tpw; j++) {
+  // Two passes over the wave's tiles; the second only for tiles left behind by the first (fsm_resolve_exits), which is none
+  // on input whose sets of possible states collapse.
+  int jd = tpw;                                        // first tile of this wave left to the second pass (wave-uniform)
+  for (int it = 0; it < 2 * tpw; it++) {
+    if (it == tpw) {
+      __syncthreads();
+      if (S.ndefer == 0u) break;                       // uniform
+      if (wave == 0) fsm_resolve_exits<kWavesPerBlock * tpw>(v, S.exit, S.mapx, S.mapu, a, group, lane);
+      __syncthreads();
+      if (a.dbg & 4u) break;                           // (CXG_DEBUG=4: timing experiment — no second pass, rows missing)
+      if (jd < tpw) issue_loads(jd);
+    }
+    const int j = it < tpw ? it : it - tpw;
+    if (it >= tpw && j < jd) continue;
+    const bool map_only = it < tpw && jd < tpw;        // a tile in front (same wave) was deferred: rows must stay in order, so only
+    bool deferred = false;                             // this tile's exit or map now, the tile itself in the second pass
     const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
     uint32_t tot = 0;
@@ -271,7 +453,16 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       FSM_MARK(1);                                      // entry states
       const bool unres0 = active && entry[0] >= v.u_lo, unres1 = second && entry[1] >= v.u_lo;
       const unsigned long long um0 = __ballot(unres0), um1 = __ballot(unres1);
-      if ((um0 | um1) == 0ull) {
+      if (map_only && (um0 | um1) == 0ull) {            // only the exit: the last sub-chunk of the tile from its known entry
+        const unsigned long long am = __ballot(active);
+        const int ll = 63 - __builtin_clzll(am | 1ull);
+        const int sbl = second ? 1 : 0;
+        const int32_t to = cc[sbl] + kFsmSub < rend ? cc[sbl] + kFsmSub : rend;
+        const uint32_t xe = (active && lane == ll) ? fsm_canon(v, fsm_walk(v, m, sbl ? entry[1] : entry[0], cc[sbl], to, true)) : 0u;
+        const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xe), ll));
+        if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
+        deferred = true;
+      } else if ((um0 | um1) == 0ull) {
         if (active) {
           if (whole && SHALLOW) {
             FsmTraceS t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
@@ -312,15 +503,20 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           }
         };
         uint32_t xc[2] = {0u, 0u};                     // end state of a replayed sub-chunk (own row of the state)
+        // F: member | end state << 16 — the serial steps below (one per unresolved sub-chunk of the tile, up to 126) take both
+        // from the lane's registers with one v_readlane; looking the member up in the image there (a dependent LDS read
+        // per member and step) was most of a tile's time on input without synchronising structure.
         uint32_t F[2][kFsmMembers];
 #pragma unroll
         for (int sb = 0; sb < 2; sb++) {
 #pragma unroll
-          for (int jm = 0; jm < kFsmMembers; jm++) F[sb][jm] = 0xFFFFu;
+          for (int jm = 0; jm < kFsmMembers; jm++) F[sb][jm] = 0xFFFFFFFFu;
           const bool has = sb ? second : active;
           const bool unres = sb ? unres1 : unres0;
           const int32_t c1s = cc[sb] + kFsmSub;
-          if (has && !unres) {
+          if (has && !unres && map_only) {
+            xc[sb] = fsm_canon(v, fsm_walk(v, m, entry[sb], cc[sb], c1s < rend ? c1s : rend, true));
+          } else if (has && !unres) {
             replay_one(sb, entry[sb]);
             xc[sb] = fsm_canon(v, L[sb].xc1);
           } else if (has) {
@@ -328,7 +524,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
             const int32_t to = c1s < rend ? c1s : rend;
             for (int jm = 0; jm < kFsmMembers; jm++) {
               const uint32_t mj = fsm_member(v, entry[sb], static_cast<uint32_t>(jm));
-              if (mj != 0xFFFFu) F[sb][jm] = fsm_canon(v, fsm_walk(v, m, mj, cc[sb], to, true));
+              if (mj != 0xFFFFu) F[sb][jm] = mj | (fsm_canon(v, fsm_walk(v, m, mj, cc[sb], to, true)) << 16);
             }
           }
         }
@@ -337,24 +533,25 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         // tile: lanes 0..7 chase the (<= 8) candidates of the first set through the tile's maps BEFORE the true entry is
         // known; when it arrives, this tile's exit is the chased value of the matching candidate and is published at
         // once — the tile's own chain and replays then run off the critical path.
+        FSM_MARK(2);                                    // (unresolved tiles: replays of the known sub-chunks + member maps)
         const unsigned long long am_all = __ballot(active);
         const int last_lane = 63 - __builtin_clzll(am_all | 1ull);
         uint32_t pred_exit = 0u;
-        if ((um0 >> 1) & 1ull) {
+        const bool first_open = (um0 >> 1) & 1ull;
+        if (first_open || map_only) {
           const uint32_t u1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[0]), 1));
-          uint32_t cand = lane < kFsmMembers ? fsm_member(v, u1, static_cast<uint32_t>(lane)) : 0xFFFFu;
+          uint32_t cand = !first_open ? 0u : (lane < kFsmMembers ? fsm_member(v, u1, static_cast<uint32_t>(lane)) : 0xFFFFu);   // (first set known: any start, the first link sets it)
           const uint32_t cand0 = cand;
           for (int l = 1; l <= last_lane; l++) {
 #pragma unroll
             for (int sb = 0; sb < 2; sb++) {
               if (sb == 1 && !static_cast<bool>(__builtin_amdgcn_readlane(static_cast<int>(second), l))) continue;
               if (((sb ? um1 : um0) >> l) & 1ull) {
-                const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[sb]), l));
                 uint32_t nxt = 0xFFFFu;
 #pragma unroll
                 for (int jm = 0; jm < kFsmMembers; jm++) {
                   const uint32_t fj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
-                  if (fsm_member(v, u, static_cast<uint32_t>(jm)) == cand) nxt = fj;
+                  if ((fj & 0xFFFFu) == cand) nxt = fj >> 16;
                 }
                 cand = cand == 0xFFFFu ? 0xFFFFu : nxt;
               } else {
@@ -363,17 +560,37 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
               }
             }
           }
-          pred_exit = wait_tile_exit(S.exit, a.status2, a.err, group, q_tile, a.epoch, lane);
-          const unsigned long long hit = __ballot(lane < kFsmMembers && cand0 == pred_exit);
-          if (hit) {
-            const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), __builtin_ctzll(hit)));
-            if (lane == 0 && ex != 0xFFFFu) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
-          } else fallback |= 1u;                        // the true state is not in the listed set: cannot happen
+          // The exit in front: a short look in the first pass (the wave of the tile in front runs beside this one), then
+          // rather the map than a blocked wave; in the second pass it is there.
+          uint32_t pw = 0u;
+          if (!map_only) pw = it < tpw ? peek_tile_exit(S.exit, a.status2, group, q_tile, a.epoch, q_tile ? 64u : 2u)
+                                       : (wait_tile_exit(S.exit, a.status2, a.err, group, q_tile, a.epoch, lane) | kExitValid);
+          if (!(pw & kExitValid)) {
+            if (first_open) {
+              if (lane < kFsmMembers) S.mapx[q_tile][lane] = static_cast<uint16_t>(cand);
+              if (lane == 0) S.mapu[q_tile] = static_cast<uint16_t>(u1);
+            }
+            else {                                       // (map_only) the exit does not depend on the entry
+              const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), 0));
+              if (ex == 0xFFFFu) fallback |= 1u;
+              else if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
+            }
+            if (!map_only) { jd = j; if (lane == 0) S.ndefer = 1u; }
+            deferred = true;
+          } else {
+            pred_exit = pw & 0xFFFFu;
+            const unsigned long long hit = __ballot(lane < kFsmMembers && cand0 == pred_exit);
+            if (hit) {
+              const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), __builtin_ctzll(hit)));
+              if (lane == 0 && ex != 0xFFFFu) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
+            } else fallback |= 1u;                        // the true state is not in the listed set: cannot happen
+          }
         }
+        FSM_MARK(6);                                    // (chase, look at the exit in front)
         // (3) the chain, wave-uniform
         uint32_t cur = 0u;                              // end state of the sub-chunk in front of the one being resolved
         uint32_t true_entry[2] = {entry[0], entry[1]};
-        unsigned long long todo = um0 | um1;
+        unsigned long long todo = deferred ? 0ull : (um0 | um1);
         while (todo) {
           const int l = __builtin_ctzll(todo);
           todo &= todo - 1;
@@ -385,11 +602,12 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
             else if (l == 1) cur = pred_exit;
             else if (!((um1 >> (l - 1)) & 1ull)) cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[1]), l - 1));
             if (lane == l) true_entry[sb] = cur;
-            const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[sb]), l));
             uint32_t nxt = 0xFFFFu;
 #pragma unroll
-            for (int jm = 0; jm < kFsmMembers; jm++)
-              if (fsm_member(v, u, static_cast<uint32_t>(jm)) == cur) nxt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
+            for (int jm = 0; jm < kFsmMembers; jm++) {
+              const uint32_t fj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
+              if ((fj & 0xFFFFu) == cur) nxt = fj >> 16;
+            }
             if (nxt == 0xFFFFu) { fallback |= 1u; nxt = 0u; }                 // the true state is not in the listed set: cannot happen
             cur = nxt;
           }
@@ -397,8 +615,9 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         // (4) replay of the unresolved sub-chunks
 #pragma unroll
         for (int sb = 0; sb < 2; sb++)
-          if (sb ? unres1 : unres0) replay_one(sb, true_entry[sb]);
+          if (!deferred && (sb ? unres1 : unres0)) replay_one(sb, true_entry[sb]);
       }
+      if (!deferred) {
       if (active) fallback |= (L[0].flags | L[1].flags) << 1;
       {  // this tile's exit state, for a following tile whose first set does not collapse
         const unsigned long long am = __ballot(active);
@@ -432,8 +651,10 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           s_rl[wave][nrows_w + q] = static_cast<uint16_t>(len);
         }
       }
+      }                                                 // !deferred
     }
     FSM_MARK(5);                                        // starts
+    if (deferred) continue;
     if (lane == 0) s_cnt[wave][j] = tot;
     nrows_w += tot;
   }

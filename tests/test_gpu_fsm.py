@@ -125,6 +125,25 @@ def test_dense_and_unconverged_input_falls_back_exactly(oracle):
         assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))
 
 
+@pytest.mark.parametrize("pat,unit", [(README_IP, b"1."), (r"\d+\.\d+x?", b"1."), (r"\d+\.\d+\.\d+\.\d+", b"12."), (r"\b\d+\.\d+\b", b"1.")])
+def test_input_without_synchronising_structure(oracle, pat, unit):
+    """`1.1.1.1...`: no tile's first set of possible states collapses, every group leaves a map and finds its entry by the
+    look-back over maps (scan_fsm.hip fsm_group_entry) — 137 groups here, more than two look-back windows; islands of other
+    text give some groups a known exit (the walk ends there), the tail of the input is a partial group.  Rows == oracle."""
+    n = 16 * (1 << 20) + 12345
+    body = bytearray((unit * (n // len(unit) + 1))[:n])
+    rng = np.random.default_rng(len(pat))
+    for at in rng.integers(0, n - 5000, 9):           # islands: a stretch of text with synchronising bytes, some a whole group long
+        ln = int(rng.choice([7, 300, 5000, 130000]))
+        body[at:at + ln] = (b"GET /index.html 10.0.0.1 x " * (ln // 27 + 1))[:ln]
+    hay = np.frombuffer(bytes(body), dtype=np.uint8)
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    rows, t = _device_rows(rx, hay)
+    exp = o.find_all_index(hay)
+    assert rows.shape == exp.shape and np.array_equal(rows, exp), (t.kernel, t.n_launches, t.fallback_reason)
+    assert t.kernel == K_FSM
+
+
 # ---- word boundaries (\b \B): UseNFA in the reference (PikeVM, nfa/pikevm.go:1646-1674), the transducer kernel here with
 # (class of this byte, kind of the next byte) as input symbol (fsm.hpp "Look-around").  No table-walking fallback exists.
 LOOK = [r"\berror\b", r"\b\d+\b", r"\bGET\b", r"\b(GET|PUT)\b", r"\Berror", r"error\B", r"\b[A-Z]+\b", r"ab(a|\b)", r"\b\d+\.\d+\b", r"\berror\w*",
