@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -90,6 +91,9 @@ struct Scratch {
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
   uint8_t* bt = nullptr; size_t btCap = 0;         // k_captures_bt: per-thread visited bitmap + stack
+  uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
+  int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
+  unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
   // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
   // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
   void release() {
@@ -103,6 +107,9 @@ struct Scratch {
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
       if (bt) (void)hipFree(bt);
+      if (bothHay) (void)hipFree(bothHay);
+      if (bothRows) (void)hipFree(bothRows);
+      if (bothFirst) (void)hipFree(bothFirst);
       if (hostCtl) (void)hipHostFree(hostCtl);
       if (pinHay) (void)hipHostFree(pinHay);
       if (pinOut) (void)hipHostFree(pinOut);
@@ -333,8 +340,11 @@ unsigned captureGrid(uint64_t nrows, uint32_t dyn_lds) {
   return static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * per_cu));
 }
 
-int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
-               uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+// scanDeviceOnce: one search from the haystack's first byte.  kRcLongMatch (internal): a UseBoth program met a match longer
+// than its restart span; *n_out = rows of plain leftmost-first iteration, the rows themselves are in d_out when it has room.
+constexpr int kRcLongMatch = -1000;
+int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
+                   uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
   const bool submatch = row_width > 2;
   if (submatch) {
@@ -653,8 +663,10 @@ relaunch:
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
   }
   err &= 0xFFu;
-  if (err & cxgdev::kErrLongMatch)
-    return fail(CXG_E_INPUT, "UseBoth program met a match longer than 100 bytes (the reference restarts its PikeVM inside such a match)");
+  if (err & cxgdev::kErrLongMatch) {
+    if (n_out) *n_out = total;
+    return kRcLongMatch;
+  }
   if (err & cxgdev::kErrSerialLimit)
     return fail(CXG_E_INPUT, "haystack has a stretch without synchronising bytes beyond the serial-walk budget (128 KiB)");
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
@@ -664,6 +676,126 @@ relaunch:
   if (n_out) *n_out = n;
   if (d_out && n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
   (void)row_width;
+  return CXG_OK;
+}
+
+__global__ void k_first_long(const int64_t* rows, uint64_t n, uint32_t width, int64_t max_len, unsigned long long* first) {
+  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+    if (rows[i * width + 1] - rows[i * width] > max_len) atomicMin(first, static_cast<unsigned long long>(i));
+}
+
+// UseBoth (findIndicesAdaptiveAtWithState, meta/find_indices.go:408-441): the DFA's match end `end` only picks where the
+// PikeVM starts — at the search position `at`, or at end - 100 when end > at + 100.  Nothing matches between `at` and the
+// leftmost match, so the PikeVM's answer is the plain leftmost-first match unless that match is longer than 100 bytes; then
+// the PikeVM starts INSIDE it and FindAll continues with whatever it finds from there.  On the device: the kernels iterate
+// plain leftmost-first and flag a longer match; every row in front of the first such match stands, and the search restarts
+// where the reference's PikeVM would — at that match's end - 100 — on an aligned copy of the haystack's suffix, with `base`
+// moved accordingly.  Each restart begins behind the start of the match that caused it, so the loop ends; more than
+// kMaxBothRestarts long matches in one haystack are refused (CXG_E_INPUT, the caller keeps its CPU loop).
+constexpr int kMaxBothRestarts = 64;
+int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
+               uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+  uint64_t n_cur = 0;
+  int rc = scanDeviceOnce(p, d_hay, len, base, limit, d_out, cap, &n_cur, user_stream, timing, row_width);
+  if (rc != kRcLongMatch) { if (n_out) *n_out = n_cur; return rc; }
+  const bool submatch = row_width > 2;
+  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(submatch ? p->subBlob.data() : p->blob.data());
+  const auto* fh = reinterpret_cast<const cxgdev::FsmHeader*>((submatch ? p->subFsmBlob : p->fsmBlob).data());
+  const bool look = !(submatch ? p->subFsmBlob : p->fsmBlob).empty() && fh->nk > 1;
+  (void)h;
+  if (look)   // the restarted search would need the byte in front of its first one as context
+    return fail(CXG_E_INPUT, "UseBoth program with assertions met a match longer than 100 bytes (the reference restarts its PikeVM inside such a match)");
+  Scratch* sp;
+  if (int r = getScratch(&sp)) return r;
+  Scratch& s = *sp;
+  hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
+  if (!s.bothFirst) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothFirst), 16));
+  cxg_timing acc;
+  std::memset(&acc, 0, sizeof acc);
+  auto add_timing = [&]() {
+    if (!timing) return;
+    acc.kernel_ms += timing->kernel_ms; acc.total_ms += timing->total_ms; acc.n_launches += timing->n_launches;
+    acc.grid = timing->grid; acc.block = timing->block; acc.tiles = timing->tiles; acc.kernel = timing->kernel; acc.fallback_reason = timing->fallback_reason;
+  };
+  add_timing();
+  const uint64_t width = static_cast<uint64_t>(row_width);
+  int64_t* const out = static_cast<int64_t*>(d_out);
+  uint64_t done = 0;                       // rows that stand
+  uint64_t abs_off = 0;                    // where the current search started, in the caller's haystack
+  const uint8_t* cur = static_cast<const uint8_t*>(d_hay);
+  for (int iter = 0; iter < kMaxBothRestarts; iter++) {
+    // the rows of the launch that met the long match
+    const uint64_t room = out ? (cap > done ? cap - done : 0) : 0;
+    const int64_t lim_rem = limit > 0 ? limit - static_cast<int64_t>(done) : limit;
+    const int64_t* rows = out ? out + done * width : nullptr;
+    uint64_t nscan = n_cur;                                        // rows that matter: FindAll(n) stops after n of them
+    if (lim_rem > 0 && nscan > static_cast<uint64_t>(lim_rem)) nscan = static_cast<uint64_t>(lim_rem);
+    if (room < nscan) {
+      if (nscan * width > s.bothRowsCap) {
+        if (s.bothRows) HIP_TRY(hipFree(s.bothRows));
+        s.bothRows = nullptr; s.bothRowsCap = 0;
+        const uint64_t c = nscan * width + nscan * width / 4 + 1024;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothRows), c * sizeof(int64_t)));
+        s.bothRowsCap = c;
+      }
+      uint64_t n2 = 0;
+      rc = scanDeviceOnce(p, cur, len - abs_off, base + static_cast<int64_t>(abs_off), -1, s.bothRows, nscan, &n2, user_stream, timing, row_width);
+      add_timing();
+      if (rc != kRcLongMatch || n2 != n_cur) return rc == kRcLongMatch || rc == CXG_OK ? fail(CXG_E_INTERNAL, "UseBoth restart: the rerun for rows disagrees with the count") : rc;
+      rows = s.bothRows;
+    }
+    HIP_TRY(hipMemsetAsync(s.bothFirst, 0xFF, 8, stream));
+    const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((nscan + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_first_long, dim3(blocks), dim3(256), 0, stream, rows, nscan, static_cast<uint32_t>(row_width), static_cast<int64_t>(cxgdev::kBothRestartSpan), s.bothFirst);
+    unsigned long long k = 0;
+    HIP_TRY(hipMemcpyAsync(&k, s.bothFirst, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (k >= nscan) {
+      if (nscan == n_cur) return fail(CXG_E_INTERNAL, "UseBoth restart: flagged launch holds no long row");
+      k = nscan;                                                   // the long match lies behind the n-th row: the first n stand
+    }
+    int64_t e = 0;
+    if (k < nscan) {
+      HIP_TRY(hipMemcpyAsync(&e, rows + k * width + 1, 8, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (rows == s.bothRows && out && room) {                       // the rows that stand, as far as the caller has room
+      const uint64_t ncopy = std::min<uint64_t>(k, room);
+      if (ncopy) HIP_TRY(hipMemcpyAsync(out + done * width, s.bothRows, ncopy * width * sizeof(int64_t), hipMemcpyDefault, stream));
+    }
+    done += k;
+    if (limit > 0 && done >= static_cast<uint64_t>(limit)) { n_cur = 0; done = static_cast<uint64_t>(limit); rc = CXG_OK; break; }
+    (void)lim_rem;
+    // restart where the reference's PikeVM starts: end - 100 (absolute), on an aligned copy of the suffix
+    const uint64_t e_abs = static_cast<uint64_t>(e - base);
+    const uint64_t next = e_abs - cxgdev::kBothRestartSpan;
+    if (next <= abs_off) return fail(CXG_E_INTERNAL, "UseBoth restart does not advance");
+    const uint64_t rest = len - next;
+    if (rest + 64 > s.bothHayCap) {
+      if (s.bothHay) HIP_TRY(hipFree(s.bothHay));
+      s.bothHay = nullptr; s.bothHayCap = 0;
+      const uint64_t c = rest + 4096;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothHay), c));
+      s.bothHayCap = c;
+    }
+    HIP_TRY(hipMemcpyAsync(s.bothHay, static_cast<const uint8_t*>(d_hay) + next, rest, hipMemcpyDefault, stream));
+    HIP_TRY(hipMemsetAsync(s.bothHay + rest, 0, 64, stream));
+    abs_off = next;
+    cur = s.bothHay;
+    const uint64_t room2 = out ? (cap > done ? cap - done : 0) : 0;
+    rc = scanDeviceOnce(p, cur, rest, base + static_cast<int64_t>(abs_off), limit > 0 ? limit - static_cast<int64_t>(done) : limit,
+                        room2 ? out + done * width : nullptr, room2, &n_cur, user_stream, timing, row_width);
+    add_timing();
+    if (rc == kRcLongMatch) continue;
+    if (rc == CXG_E_CAPACITY) { done += n_cur; n_cur = 0; }
+    break;
+  }
+  if (timing) *timing = acc;
+  if (rc == kRcLongMatch) return fail(CXG_E_INPUT, "UseBoth program met more than 64 matches longer than 100 bytes in one haystack");
+  if (rc != CXG_OK && rc != CXG_E_CAPACITY) return rc;
+  const uint64_t n = done + n_cur;
+  if (n_out) *n_out = n;
+  if (out && n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
   return CXG_OK;
 }
 

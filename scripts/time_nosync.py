@@ -7,7 +7,8 @@ import numpy as np, torch
 import coregex_amd as cx
 from oracle import oracle as O
 README_IP = r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"
-cases = [(r"\d+\.\d+\.\d+\.\d+", b"1."), (README_IP, b"1."), (r"\d+:\d+:\d+", b"12:"), (r"\d+\.\d+x?", b"1.")]
+cases = [(r"\d+\.\d+\.\d+\.\d+", b"1."), (README_IP, b"1."), (r"\d+:\d+:\d+", b"12:"), (r"\d+\.\d+x?", b"1."),
+         (r"a+b|b+a", b"a"), (r"[a-c]x|[b-d]y", b"b"), (r"error", b"error"), (r"error|warning|fatal|critical", b"error")]
 for pat, unit in cases:
     rx = cx.compile(pat)
     o = O.Regex(pat)

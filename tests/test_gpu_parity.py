@@ -391,8 +391,8 @@ def test_64mib_without_a_synchronising_byte(need_gpu, oracle):
 
 def test_use_both_programs(need_gpu, oracle):
     """UseBoth (find_indices.go:408-441): the DFA's end only picks where the PikeVM starts (end-100 for far ends), so
-    FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's answer starts
-    inside the match and the device path refuses the haystack (CXG_E_INPUT) instead of guessing."""
+    FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's PikeVM starts inside
+    the match.  The device path restarts its search at the same place (capi.hip scanDevice): rows == oracle."""
     pat = r"(\w+)@(\w+)\.(\w+)"
     rx, o = cx.compile(pat), oracle.Regex(pat)
     assert rx.strategy == o.strategy == "UseBoth" and rx.supported
@@ -406,13 +406,24 @@ def test_use_both_programs(need_gpu, oracle):
     assert np.array_equal(rx.find_all_index(exactly), o.find_all_index(exactly)) and len(o.find_all_index(exactly)) == 1
     longer = b"  " + b"u" * 95 + b"@b.com  k@l.mn "           # 101 bytes: the reference answers [3, 103)
     assert o.find_all_index(longer).tolist()[0] == [3, 103]
-    with pytest.raises(cx.UnsupportedInput):
-        rx.find_all_index(longer)
-    with pytest.raises(cx.UnsupportedInput):
-        rx.count(longer)
     big = np.concatenate([hay, np.frombuffer(longer, dtype=np.uint8), hay])      # one long match inside 4 MiB
+    many = (b"x y " + b"v" * 130 + b"@host.example.org  " + b"q@r.st " * 5) * 40          # 40 long matches: 40 restarts
+    ends = b"w" * 300 + b"@b.c" + b" mid a@b.c " + b"z" * 120 + b"@" + b"y" * 150 + b"." + b"x" * 200                 # long matches at both ends of the haystack
+    nested = b"k" * 250 + b"@" + b"l" * 250 + b"." + b"m" * 250 + b" tail t@u.vw"         # the restarted search meets another long match
+    for h in (longer, big, many, ends, nested):
+        exp = o.find_all_index(h)
+        got = rx.find_all_index(h)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (bytes(h[:40]), got[:3].tolist(), exp[:3].tolist())
+        assert rx.count(h) == len(exp)
+        sub = o.find_all_submatch_index(h)
+        gsub = rx.find_all_submatch_index(h)
+        assert gsub.shape == sub.shape and np.array_equal(gsub, sub), bytes(h[:40])
+        for n in (1, 2, len(exp) - 1, len(exp) + 5):
+            if n > 0:
+                assert np.array_equal(rx.find_all_index(h, n), exp[:n]) and rx.count(h, n) == min(n, len(exp))
+    too_many = (b"v" * 130 + b"@host.example.org  ") * 80                                    # more restarts than the loop allows: refused
     with pytest.raises(cx.UnsupportedInput):
-        rx.find_all_index(big)
+        rx.find_all_index(too_many)
     assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))        # the program stays usable
 
 
