@@ -311,10 +311,16 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
         getattr(L, name).restype = i64
         getattr(L, name).argtypes = [vp, vp, i64, vp, i64]
     L.orc_baseline_literal_find_all.restype = i64
-    L.orc_baseline_literal_find_all.argtypes = [C.c_char_p, i64, vp, i64, vp, i64]
+    L.orc_baseline_literal_find_all.argtypes = [C.c_char_p, i64, vp, vp, i64, vp, i64]
+    L.orc_baseline_rare_pair.argtypes = [C.c_char_p, i64, vp]
     lit = pattern.encode()
+    pair = np.zeros(4, dtype=np.int32)
+    if lit == b"error":
+        pair[:] = (ord("r"), 1, ord("o"), 3)                        # SelectRareBytes("error"), simd/byte_frequencies.go:88-135 (oracle/cpu_baseline.cpp)
+    elif config == 1:
+        L.orc_baseline_rare_pair(lit, len(lit), pair.ctypes.data)   # the port's own coarse ranking
     ports = {
-        1: ("glibc memmem (the reference: rare-byte pair scan, simd/memmem.go:53) + FindAll loop", lambda h, p, n, o, c: L.orc_baseline_literal_find_all(lit, len(lit), p, n, o, c)),
+        1: ("rare-byte pair scan (AVX2 MemchrPair 'r'@1 / 'o'@3 + verify; simd/memmem.go:53-152) + FindAll loop", lambda h, p, n, o, c: L.orc_baseline_literal_find_all(lit, len(lit), pair.ctypes.data, p, n, o, c)),
         2: ("AVX2 digit scan + flat-table anchored DFA + run skip", lambda h, p, n, o, c: L.orc_baseline_digit_find_all(h, p, n, o, c)),
         3: ("SSSE3 Slim Teddy (PSHUFB nibble masks, 2-byte fingerprint) + verifyBucket", lambda h, p, n, o, c: L.orc_baseline_teddy_find_all(h, p, n, o, c)),
         4: ("scalar 256-entry membership LUT, one byte per iteration", lambda h, p, n, o, c: L.orc_baseline_charclass_find_all(h, p, n, o, c)),
@@ -329,9 +335,14 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
     # ---- one thread
     eng = O.Regex(pattern)
     rows = np.empty((k_in + 64) * width, dtype=np.int64)
-    c0 = time.perf_counter()
-    nv = port(eng._h, host.ctypes.data, host.size, rows.ctypes.data, rows.size)
-    cpu_s = time.perf_counter() - c0
+    runs = []
+    for _ in range(5):                                               # median of five (the first run also pages the sample in)
+        c0 = time.perf_counter()
+        nv = port(eng._h, host.ctypes.data, host.size, rows.ctypes.data, rows.size)
+        runs.append(time.perf_counter() - c0)
+        if sum(runs) > 40.0:
+            break
+    cpu_s = sorted(runs)[len(runs) // 2]
     if nv < 0 or nv > rows.size:
         raise SystemExit(f"cpu baseline port failed for config {config} ({nv})")
     cpu_rows = rows[:nv].reshape(-1, width)
@@ -369,9 +380,15 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
         "unit": "GB/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {sample >> 20} MiB of the same corpus (downloaded from HBM), {cpu_s:.1f} s, {what}, g++ -O3 -mavx2; "
-                  f"rows equal the GPU's.  Digit-dense synthlog text: not comparable with the reference's published "
-                  f"figures on sparse input (BASELINE.md)",
+        "runs_s": [round(r, 3) for r in runs],
+        "sample": f"first {sample >> 20} MiB of the same corpus (downloaded from HBM), median of {len(runs)} runs {cpu_s:.2f} s, {what}, g++ -O3 -mavx2; "
+                  f"rows equal the GPU's.  " + {
+                      1: "The published memmem figures (BASELINE.md) are single Find calls on sparse text; here there is a hit every ~14 KiB and the loop restarts the scan behind it.",
+                      2: "Digit-dense synthlog text: not comparable with the reference's published figures on sparse input (BASELINE.md).",
+                      3: "The reference's Teddy figures through the regex API are 0.5-1.3 GB/s (BASELINE.md): each candidate there is a Go<->asm round trip, which the port's loop does not pay.",
+                      4: "The reference publishes ~0.15 GB/s for this pattern (README.md:78, 6 MB, 41.9 ms; BASELINE.md): its FindAll appends a [2]int per match through the slice-growth path and an interface call per match (findall.go:157-169), the port writes rows into a preallocated array — the port is the faster of the two by construction, so the GPU/CPU ratio below is a lower bound.",
+                      5: "PikeVM restatement (the oracle), not tuned.",
+                  }[config],
         "all_cores": {"value": round(all_sample / all_s / 1e9, 3), "unit": "GB/s", "cores": threads,
                       "sample": f"first {all_sample >> 20} MiB in {nblk} page-aligned blocks, one engine per thread, {all_s:.2f} s wall; row count equals the GPU's"},
         "host_cpu": _cpu_model(),

@@ -182,17 +182,71 @@ extern "C" int64_t orc_baseline_charclass_find_all(void* ev, const uint8_t* h, i
 }
 
 // Config 1, UseDFA with a complete literal prefix (`error`): the reference's memmem prefilter finds every occurrence
-// (prefilter/prefilter.go:440-506 -> simd/memmem.go:53-152, rare-byte pair scan with AVX2) and the literal being the
-// whole pattern each hit is a match.  Port: glibc memmem (AVX2 two-way / pair scan of the same family), FindAll loop.
-extern "C" int64_t orc_baseline_literal_find_all(const uint8_t* lit, int64_t litLen, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
+// (prefilter/prefilter.go:440-506 -> simd/memmem.go:53-152) and, the literal being the whole pattern, each hit is a match.
+// Port of the path a 2..6-byte needle takes there:
+//   SelectRareBytes (simd/byte_frequencies.go:88-135): the two rarest distinct bytes of the needle by its rank table, the
+//     rarest first.  The ranks are the reference's data and are not restated here; the caller passes the pair — for `error`
+//     that function yields ('r' at 1, 'o' at 3): ranks r 195 < o 205 < e 245 — or asks for this file's own coarse ranking
+//     (letters by English text frequency, everything else rarer), which picks the same pair for the 16 literals of config 3.
+//   memmemPaired (memmem.go:103-152): MemchrPair for byte1 at p and byte2 at p + (idx2 - idx1), then bytesEqual on the whole
+//     needle at p - idx1; on a miss the scan resumes one byte behind the candidate.
+//   memchrPairAVX2 (simd/memchr_amd64.s:355-): 32 bytes at p and 32 at p + offset, VPCMPEQB both, VPAND, VPMOVMSKB; scalar tail
+//     (memchr_generic_impl.go:253).
+// The FindAll loop around it is findall.go:176-283 without its per-call overhead (state pool, interface dispatch).
+namespace {
+inline int64_t memchrPair(const uint8_t* h, int64_t n, uint8_t b1, uint8_t b2, int64_t off) {
+  if (n <= off) return -1;
+  int64_t p = 0;
+  const __m256i v1 = _mm256_set1_epi8(static_cast<char>(b1)), v2 = _mm256_set1_epi8(static_cast<char>(b2));
+  for (; p + off + 32 <= n; p += 32) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(h + p));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(h + p + off));
+    const uint32_t m = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(a, v1), _mm256_cmpeq_epi8(b, v2))));
+    if (m) return p + __builtin_ctz(m);
+  }
+  for (; p + off < n; p++) if (h[p] == b1 && h[p + off] == b2) return p;
+  return -1;
+}
+inline int coarseRank(uint8_t b) {   // higher = more frequent; not the reference's table (see above)
+  static const char order[] = "zqxjkvbpygfwmucldrhsnioate";
+  const uint8_t c = (b >= 'A' && b <= 'Z') ? static_cast<uint8_t>(b + 32) : b;
+  for (int i = 0; order[i]; i++) if (order[i] == c) return 100 + 5 * i + (b == c ? 2 : 0);
+  return b == ' ' ? 255 : 50;
+}
+}  // namespace
+extern "C" void orc_baseline_rare_pair(const uint8_t* lit, int64_t n, int32_t* out4) {   // byte1, idx1, byte2, idx2 — the selection loop of byte_frequencies.go:104-134 over coarseRank
+  uint8_t b1 = lit[0], b2 = n > 1 ? lit[1] : lit[0];
+  int64_t i1 = 0, i2 = n > 1 ? 1 : 0;
+  if (coarseRank(b2) < coarseRank(b1)) { std::swap(b1, b2); std::swap(i1, i2); }
+  for (int64_t i = 2; i < n; i++) {
+    const uint8_t b = lit[i];
+    const int r = coarseRank(b);
+    if (r < coarseRank(b1)) { b2 = b1; i2 = i1; b1 = b; i1 = i; }
+    else if (b != b1 && r < coarseRank(b2)) { b2 = b; i2 = i; }
+  }
+  out4[0] = b1; out4[1] = static_cast<int32_t>(i1); out4[2] = b2; out4[3] = static_cast<int32_t>(i2);
+}
+extern "C" int64_t orc_baseline_literal_find_all(const uint8_t* lit, int64_t litLen, const int32_t* pair, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
+  uint8_t b1 = static_cast<uint8_t>(pair[0]), b2 = static_cast<uint8_t>(pair[2]);
+  int64_t i1 = pair[1], i2 = pair[3];
+  if (b1 == b2 || i1 == i2 || litLen > 6 || litLen < 2) return -1;          // (memmemSingle / memmemLong: not on config 1's path)
+  if (i1 > i2) { std::swap(b1, b2); std::swap(i1, i2); }
+  const int64_t off = i2 - i1;
   int64_t n = 0, pos = 0;
-  while (pos + litLen <= len) {
-    const void* p = memmem(h + pos, static_cast<size_t>(len - pos), lit, static_cast<size_t>(litLen));
-    if (!p) break;
-    const int64_t s = static_cast<const uint8_t*>(p) - h;
-    if (out && n + 2 <= capVals) { out[n] = s; out[n + 1] = s + litLen; }
+  while (pos + litLen <= len) {                                            // one Memmem call of the reference per iteration
+    int64_t found = -1, from = pos;
+    for (;;) {
+      const int64_t c = memchrPair(h + from, len - from, b1, b2, off);
+      if (c < 0) break;
+      const int64_t cand = from + c, s = cand - i1;
+      if (s >= pos && s + litLen <= len && std::memcmp(h + s, lit, static_cast<size_t>(litLen)) == 0) { found = s; break; }
+      from = cand + 1;
+      if (from >= len - off) break;
+    }
+    if (found < 0) break;
+    if (out && n + 2 <= capVals) { out[n] = found; out[n + 1] = found + litLen; }
     n += 2;
-    pos = s + litLen;
+    pos = found + litLen;
   }
   return n;
 }
