@@ -640,14 +640,20 @@ relaunch:
       fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : 2;
       if (verbose) fprintf(stderr, "[cxg] transducer kernel: match-dense input (reason bits 0x%x), rerunning in mode %d\n", err >> 8, fsmMode);
       denseChain = true;
-      p->denseChain[submatch ? 1 : 0].store(static_cast<uint8_t>(fsmMode), std::memory_order_relaxed);
+      {
+        uint8_t old = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);
+        while (old < fsmMode && !p->denseChain[submatch ? 1 : 0].compare_exchange_weak(old, static_cast<uint8_t>(fsmMode), std::memory_order_relaxed)) {}
+      }
       relaunches++;
       goto relaunch;
     }
     if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain && !(h->flags & cxgdev::kFlagChainBounded)) {   // only the row buffers overflowed: same kernel, two tiles per wave
       if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
       denseChain = true;
-      p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      {                                                             // remembered value only grows: a transducer mode 2 seen before stays
+        uint8_t old = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);
+        while (old < 1 && !p->denseChain[submatch ? 1 : 0].compare_exchange_weak(old, 1, std::memory_order_relaxed)) {}
+      }
       relaunches++;
       goto relaunch;
     }
@@ -750,9 +756,13 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     unsigned long long k = 0;
     HIP_TRY(hipMemcpyAsync(&k, s.bothFirst, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    bool over_estimate = false;
     if (k >= nscan) {
-      if (nscan == n_cur) return fail(CXG_E_INTERNAL, "UseBoth restart: flagged launch holds no long row");
-      k = nscan;                                                   // the long match lies behind the n-th row: the first n stand
+      // no long row among them: the long match lies behind the n-th row (the first n stand), or the kernel's flag was an
+      // over-estimate — the transducer kernel measures the first row of a group before its start is bounded by the previous
+      // row (k_fsm_fix_heads corrects the row afterwards): every row of the launch stands
+      over_estimate = nscan == n_cur;
+      k = nscan;
     }
     int64_t e = 0;
     if (k < nscan) {
@@ -764,6 +774,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
       if (ncopy) HIP_TRY(hipMemcpyAsync(out + done * width, s.bothRows, ncopy * width * sizeof(int64_t), hipMemcpyDefault, stream));
     }
     done += k;
+    if (over_estimate) { n_cur = 0; rc = CXG_OK; break; }
     if (limit > 0 && done >= static_cast<uint64_t>(limit)) { n_cur = 0; done = static_cast<uint64_t>(limit); rc = CXG_OK; break; }
     (void)lim_rem;
     // restart where the reference's PikeVM starts: end - 100 (absolute), on an aligned copy of the suffix
