@@ -368,10 +368,15 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
             if hi > lo:
                 counts[b] = port(e._h, big.ctypes.data + lo, hi - lo, scratch.ctypes.data, scratch.size)
 
-    a0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(work, range(threads)))
-    all_s = time.perf_counter() - a0
+    all_runs = []
+    with ThreadPoolExecutor(max_workers=threads) as ex:             # one pool: the first pass also starts its threads
+        for _ in range(5):
+            a0 = time.perf_counter()
+            list(ex.map(work, range(threads)))
+            all_runs.append(time.perf_counter() - a0)
+            if sum(all_runs) > 12.0:
+                break
+    all_s = sorted(all_runs)[len(all_runs) // 2]
     k_all = int(np.searchsorted(gpu_rows[:, 1], all_sample, side="right"))
     if sum(counts) // width != k_all:
         raise SystemExit(f"PARITY FAILURE: all-cores CPU port counted {sum(counts) // width} rows, the GPU {k_all}")
@@ -390,7 +395,8 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
                       5: "PikeVM restatement (the oracle), not tuned.",
                   }[config],
         "all_cores": {"value": round(all_sample / all_s / 1e9, 3), "unit": "GB/s", "cores": threads,
-                      "sample": f"first {all_sample >> 20} MiB in {nblk} page-aligned blocks, one engine per thread, {all_s:.2f} s wall; row count equals the GPU's"},
+                      "sample": f"first {all_sample >> 20} MiB in {nblk} page-aligned blocks, one engine per thread, median of {len(all_runs)} passes {all_s:.3f} s wall; row count equals the GPU's",
+                      "runs_s": [round(r, 3) for r in all_runs]},
         "host_cpu": _cpu_model(),
         "host_threads_available": os.cpu_count(),
     }
