@@ -131,4 +131,22 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
 }
 
 
+// FindAll with n > 0, at the start of a wave kernel's workgroup (kernel-argument-uniform branch, one barrier): true when the
+// stop word says that `limit` rows were counted before this group started.  The group that set the word had seen every
+// group in front of it published, i.e. started — so a group that sees it set at its start lies BEHIND the setter and at
+// least `limit` rows precede it: it publishes exactly that as its inclusive sum (no scan, no look-back) and ends; groups
+// behind it find an inclusive word at distance one.
+template <class Args>
+__device__ __forceinline__ bool limit_reached_skip(const Args& a, uint64_t group, uint64_t* s_tmp) {
+  if (a.limit == 0) return false;
+  if (threadIdx.x == 0) *s_tmp = __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const bool skip = static_cast<uint32_t>(*s_tmp) == a.epoch + 1u;
+  if (skip && threadIdx.x == 0) {
+    __hip_atomic_store(a.status + group, kFlagInclusive | (static_cast<uint64_t>(a.epoch) << kEpochShift) | a.limit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (group == a.ngroups - 1) *a.total = a.limit;
+  }
+  return skip;
+}
+
 }  // namespace cxgdev

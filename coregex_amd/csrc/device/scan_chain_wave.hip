@@ -229,6 +229,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? CXG_CAP_WAVES : (
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
   if (group >= a.ngroups) return;
+  if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   if (ALTK > 0) {                                                  // compile-time shape: everything derived from these folds
     ch.nops = 2u * ALTK - 1u;
     ch.op_is_run = 0x55555555ull & ((1ull << (2 * ALTK - 1)) - 1ull);   // steps 0, 2, 4, ... are runs
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? CXG_CAP_WAVES : (
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * tpw];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);

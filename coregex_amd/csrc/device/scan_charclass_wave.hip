@@ -62,6 +62,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
   if (group >= a.ngroups) return;
+  if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   uint32_t fallback = 0;
 
   u32x4 x[4];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kCcTilesPerWave];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (a.out == nullptr) return;
 
   // ---- pass 2: starts and ends straight to their rows

@@ -319,20 +319,7 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   uint32_t nrows_w = 0;                                              // wave-uniform
   uint32_t fallback = 0;
   // FindAll with n > 0: enough rows counted in front of this group — it contributes nothing (block_common.hpp tile_lookback)
-  // A group that starts after the stop word was set lies behind the group that set it (that one had seen every group in front
-  // of it published, i.e. started): at least `limit` rows precede it.  It publishes exactly that as its inclusive sum — no
-  // scan, no look-back — and ends; groups behind it find an inclusive word at distance one.
-  if (a.limit != 0) {                                                // uniform: kernel argument
-    if (tid == 0) s_base = __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (static_cast<uint32_t>(s_base) == a.epoch + 1u) {
-      if (tid == 0) {
-        __hip_atomic_store(a.status + group, kFlagInclusive | (static_cast<uint64_t>(a.epoch) << kEpochShift) | a.limit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (group == a.ngroups - 1) *a.total = a.limit;
-      }
-      return;
-    }
-  }
+  if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   constexpr int ntile = tpw;
   auto tile_lo_of = [&](int jj) { return (group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave) * static_cast<uint64_t>(kWaveTile); };
   const uint64_t pt0 = a.prof ? __builtin_readcyclecounter() : 0ull;   // CXG_PROF=1: cycles of wave 0 per phase, summed over the workgroups

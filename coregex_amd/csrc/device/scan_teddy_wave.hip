@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
   if (group >= a.ngroups) return;
+  if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   uint32_t nrows_w = 0;                                            // wave-uniform
   uint32_t fallback = 0;
   uint32_t long_hit = 0, edge_hit = 0;                             // VERIFY, per lane: match longer than the UseBoth restart span / walk cut by the window
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * tpw];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch);
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (a.out == nullptr) return;
   const uint64_t base = s_base;
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);

@@ -389,6 +389,33 @@ def test_64mib_without_a_synchronising_byte(need_gpu, oracle):
         del out, buf
 
 
+@pytest.mark.parametrize("cfg,pat,sub", [(1, r"error", False), (3, "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow", False),
+                                         (4, r"[\w]+", False), (5, r"(\w+)@(\w+)\.(\w+)", True), (5, r"(\w+)@(\w+)\.(\w+)", False)])
+def test_find_all_n_stops_the_wave_kernels_early(need_gpu, oracle, cfg, pat, sub):
+    """FindAll(b, n) with n > 0 (meta/findall.go:196) on the chain, literal and char-class kernels: the first n rows, and groups
+    that start after the n-th row was counted do not scan (block_common.hpp limit_reached_skip) — a call for the first rows of
+    1 GiB costs a fraction of the full scan."""
+    import torch
+    npages = (1 << 30) // 4096
+    buf = cx.DeviceBuffer(npages * 4096)
+    buf.fill_synth(cfg, 0xC0FFEE00 + cfg, 0)
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    head = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 0, {1: 20480, 3: 1024, 4: 256, 5: 256}[cfg])     # enough text for 5 000 rows
+    exp = o.find_all_submatch_index(head) if sub else o.find_all_index(head)
+    assert len(exp) > 5000
+    w = exp.shape[1]
+    scan = rx.find_all_submatch_device if sub else rx.find_all_device
+    out = torch.empty((1 << 16, w), dtype=torch.int64, device="cuda")
+    t_full, t_lim = cx.Timing(), cx.Timing()
+    full = scan(buf.ptr, npages * 4096, timing=t_full)
+    assert full > 5000
+    for n in (1, 37, 5000):
+        got = scan(buf.ptr, npages * 4096, out.data_ptr(), out.shape[0], n=n, timing=t_lim)
+        assert got == n and np.array_equal(out[:n].cpu().numpy(), exp[:n]), (pat, n)
+        assert scan(buf.ptr, npages * 4096, n=n) == n
+    assert t_lim.kernel_ms < 0.6 * t_full.kernel_ms, (pat, t_lim.kernel_ms, t_full.kernel_ms)
+
+
 def test_use_both_programs(need_gpu, oracle):
     """UseBoth (find_indices.go:408-441): the DFA's end only picks where the PikeVM starts (end-100 for far ends), so
     FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's PikeVM starts inside
