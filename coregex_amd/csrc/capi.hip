@@ -9,8 +9,6 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
-#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -96,9 +94,6 @@ struct Scratch {
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
   int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
   unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
-  hipStream_t copyStream = nullptr, rowStream = nullptr;  // pipelined host seam (scanHostPipelined): H2D of chunk k + 1 / rows of chunk k - 1
-  hipEvent_t copyDone = nullptr;
-  int64_t* pipeRows[2] = {nullptr, nullptr}; uint64_t pipeRowsCap[2] = {0, 0};   // ... device rows of a chunk, double-buffered
   // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
   // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
   void release() {
@@ -115,10 +110,6 @@ struct Scratch {
       if (bothHay) (void)hipFree(bothHay);
       if (bothRows) (void)hipFree(bothRows);
       if (bothFirst) (void)hipFree(bothFirst);
-      for (auto& r : pipeRows) if (r) (void)hipFree(r);
-      if (copyStream) (void)hipStreamDestroy(copyStream);
-      if (rowStream) (void)hipStreamDestroy(rowStream);
-      if (copyDone) (void)hipEventDestroy(copyDone);
       if (hostCtl) (void)hipHostFree(hostCtl);
       if (pinHay) (void)hipHostFree(pinHay);
       if (pinOut) (void)hipHostFree(pinOut);
@@ -835,128 +826,6 @@ __global__ void k_fill_synth(uint8_t* dst, uint64_t npages, uint32_t config, uin
 constexpr uint64_t kZeroCopyHay = 256ull << 10;     // bytes of haystack served from pinned host memory
 constexpr uint64_t kZeroCopyVals = 128ull << 10;    // int64 values of rows written to pinned host memory (1 MiB)
 
-// Host seam for large haystacks (cxg_find_all / cxg_find_all_submatch with a host buffer and room for rows): the haystack is
-// cut into chunks right after a byte outside the pattern's alphabet (the shard rule of INTEGRATION.md), chunk k + 1 travels to
-// the device while chunk k is scanned and the rows of chunk k - 1 travel back — PCIe is full duplex, and both ends of the
-// call are pageable memory (a Go slice, a numpy array), whose copies block the calling thread: the upload runs on the caller's
-// thread, the rows come back on a helper thread with its own stream, two device row buffers in flight.  Before: upload, a
-// counting scan, a scan for rows and the download of 160 MB of rows one after the other (30 GB/s at 1 GiB of config 2).
-// kRcNotPipelined: no cut found / program with assertions — the caller takes the one-shot path.
-constexpr int kRcNotPipelined = -1001;
-constexpr uint64_t kPipeMinBytes = 384ull << 20, kPipeChunk = 256ull << 20, kPipeCutSearch = 1ull << 20;
-int scanHostPipelined(const cxg_program* p, Scratch& s, const uint8_t* hay, uint64_t len, int64_t* rows, uint64_t cap, uint64_t* n_out, int width) {
-  const bool submatch = width > 2;
-  const std::vector<uint8_t>& blob = submatch ? p->subBlob : p->blob;
-  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(blob.data());
-  if (h->kind == cxgdev::kKindFsmOnly || h->info_off == 0 || h->info_off + 256 > blob.size()) return kRcNotPipelined;
-  const std::vector<uint8_t>& fimg = submatch ? p->subFsmBlob : p->fsmBlob;
-  if (!fimg.empty() && reinterpret_cast<const cxgdev::FsmHeader*>(fimg.data())->nk > 1) return kRcNotPipelined;   // assertions read across a cut
-  const uint8_t* info = blob.data() + h->info_off;
-  std::vector<uint64_t> cuts{0};
-  while (len - cuts.back() > kPipeChunk + kPipeChunk / 2) {
-    uint64_t q = cuts.back() + kPipeChunk;
-    const uint64_t lowest = q - kPipeCutSearch;
-    while (q > lowest && !((q & 15u) == 0 && (info[hay[q - 1]] & cxgdev::kInfoSync))) q--;   // (device haystacks start 16-byte aligned)
-    if (q == lowest) return kRcNotPipelined;
-    cuts.push_back(q);
-  }
-  cuts.push_back(len);
-  const size_t nchunks = cuts.size() - 1;
-  if (nchunks < 2) return kRcNotPipelined;
-  if (!s.copyStream) {
-    HIP_TRY(hipStreamCreateWithFlags(&s.copyStream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&s.rowStream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s.copyDone, hipEventDisableTiming));
-  }
-  if (len + 64 > s.hayCap) {
-    if (s.hay) HIP_TRY(hipFree(s.hay));
-    s.hay = nullptr; s.hayCap = 0;
-    const uint64_t c = len + len / 8 + 4096;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.hay), c));
-    s.hayCap = c;
-  }
-  // helper thread: rows of finished chunks, device -> caller's array
-  struct Job { const int64_t* src; int64_t* dst; size_t bytes; int slot; };
-  std::mutex mu;
-  std::condition_variable cv;
-  std::vector<Job> queue;
-  bool quit = false, slotBusy[2] = {false, false};
-  hipError_t workerErr = hipSuccess;
-  const int dev = t_device;
-  hipStream_t rowStream = s.rowStream;
-  std::thread worker([&] {
-    (void)hipSetDevice(dev);
-    for (;;) {
-      Job j;
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return quit || !queue.empty(); });
-        if (queue.empty()) return;
-        j = queue.front(); queue.erase(queue.begin());
-      }
-      hipError_t e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, rowStream);
-      if (e == hipSuccess) e = hipStreamSynchronize(rowStream);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        if (e != hipSuccess && workerErr == hipSuccess) workerErr = e;
-        slotBusy[j.slot] = false;
-      }
-      cv.notify_all();
-    }
-  });
-  auto stop_worker = [&] { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); worker.join(); };
-  uint64_t done = 0;
-  bool overflow = false;
-  int rc = CXG_OK;
-  for (size_t k = 0; k < nchunks && rc == CXG_OK; k++) {
-    const uint64_t lo = cuts[k], n = cuts[k + 1] - lo;
-    hipError_t e = hipMemcpyAsync(s.hay + lo, hay + lo, n, hipMemcpyHostToDevice, s.copyStream);   // pageable source: returns when staged
-    if (e == hipSuccess && k + 1 == nchunks) e = hipMemsetAsync(s.hay + len, 0, 64, s.copyStream);
-    if (e == hipSuccess) e = hipEventRecord(s.copyDone, s.copyStream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s.stream, s.copyDone, 0);
-    if (e != hipSuccess) { rc = failHip(e, "pipelined upload"); break; }
-    const int slot = static_cast<int>(k & 1);
-    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !slotBusy[slot]; }); }
-    uint64_t nk = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-      if (overflow) { rc = scanDevice(p, s.hay + lo, n, static_cast<int64_t>(lo), -1, nullptr, 0, &nk, nullptr, nullptr, width); break; }
-      uint64_t want = s.pipeRowsCap[slot] / static_cast<uint64_t>(width);
-      if (want == 0) {
-        want = n / 48 + 4096;                                       // first guess: one row per 48 bytes
-        const hipError_t me = hipMalloc(reinterpret_cast<void**>(&s.pipeRows[slot]), want * width * sizeof(int64_t));
-        if (me != hipSuccess) { rc = failHip(me, "hipMalloc(pipelined rows)"); break; }
-        s.pipeRowsCap[slot] = want * width;
-      }
-      rc = scanDevice(p, s.hay + lo, n, static_cast<int64_t>(lo), -1, s.pipeRows[slot], want, &nk, nullptr, nullptr, width);
-      if (rc != CXG_E_CAPACITY) break;
-      (void)hipFree(s.pipeRows[slot]); s.pipeRows[slot] = nullptr; s.pipeRowsCap[slot] = 0;   // denser than guessed: size by the count, scan again
-      const uint64_t c = nk + nk / 8 + 4096;
-      const hipError_t me = hipMalloc(reinterpret_cast<void**>(&s.pipeRows[slot]), c * width * sizeof(int64_t));
-      if (me != hipSuccess) { rc = failHip(me, "hipMalloc(pipelined rows)"); break; }
-      s.pipeRowsCap[slot] = c * width;
-      rc = CXG_OK;
-    }
-    if (rc != CXG_OK) break;
-    if (!overflow && done + nk > cap) overflow = true;              // the caller's array is too small: keep counting, CXG_E_CAPACITY at the end
-    if (!overflow && nk) {
-      { std::lock_guard<std::mutex> lk(mu); slotBusy[slot] = true; queue.push_back({s.pipeRows[slot], rows + done * width, nk * width * sizeof(int64_t), slot}); }
-      cv.notify_all();
-    }
-    done += nk;
-  }
-  { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !slotBusy[0] && !slotBusy[1]; }); }
-  stop_worker();
-  (void)hipStreamSynchronize(s.copyStream);
-  if (rc == CXG_OK && workerErr != hipSuccess) rc = failHip(workerErr, "pipelined row download");
-  for (int i = 0; i < 2; i++)
-    if (s.pipeRowsCap[i] * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.pipeRows[i]); s.pipeRows[i] = nullptr; s.pipeRowsCap[i] = 0; }
-  if (s.hayCap > kKeepStagingBytes) { (void)hipFree(s.hay); s.hay = nullptr; s.hayCap = 0; }
-  if (rc != CXG_OK) return rc;
-  if (n_out) *n_out = done;
-  if (overflow) return fail(CXG_E_CAPACITY, "output capacity too small");
-  return CXG_OK;
-}
-
 int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
              uint64_t* n_out, int width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
@@ -989,11 +858,6 @@ int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64
     }
     if (rc != CXG_E_CAPACITY || want >= cap) { if (n_out) *n_out = n; return rc; }
     // more rows than the pinned array holds and the caller has room for them: the copying path below
-  }
-  static const bool pipeOk = getenv("CXG_NO_PIPELINE") == nullptr;
-  if (pipeOk && rows && limit < 0 && len >= kPipeMinBytes) {
-    const int prc = scanHostPipelined(p, s, hay, len, rows, cap, n_out, width);
-    if (prc != kRcNotPipelined) return prc;
   }
   if (len + 64 > s.hayCap) {
     if (s.hay) HIP_TRY(hipFree(s.hay));

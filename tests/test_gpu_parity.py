@@ -416,40 +416,6 @@ def test_find_all_n_stops_the_wave_kernels_early(need_gpu, oracle, cfg, pat, sub
     assert t_lim.kernel_ms < 0.6 * t_full.kernel_ms, (pat, t_lim.kernel_ms, t_full.kernel_ms)
 
 
-@pytest.mark.parametrize("cfg,pat,sub", [(2, r"\d+\.\d+\.\d+\.\d+", False), (3, "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow", False),
-                                         (5, r"(\w+)@(\w+)\.(\w+)", True)])
-def test_pipelined_host_seam(need_gpu, oracle, cfg, pat, sub):
-    """cxg_find_all / cxg_find_all_submatch on a 200 MiB HOST haystack take the chunk-pipelined path (capi.hip scanHostPipelined:
-    cuts after bytes outside the pattern's alphabet, upload / scan / row download overlapped): rows equal the device-resident
-    scan of the same bytes (itself checked against the oracle above) and the oracle's on the head; a too-small array reports the
-    count; a haystack without a cut point takes the one-shot path."""
-    import torch
-    npages = (200 << 20) // 4096
-    host = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 0, npages)
-    rx, o = cx.compile(pat), oracle.Regex(pat)
-    got = rx.find_all_submatch_index(host) if sub else rx.find_all_index(host)
-    w = got.shape[1]
-    d = torch.from_numpy(np.concatenate([host, np.zeros(64, dtype=np.uint8)])).cuda()
-    scan = rx.find_all_submatch_device if sub else rx.find_all_device
-    n = scan(d.data_ptr(), host.size)
-    out = torch.empty((n + 8, w), dtype=torch.int64, device="cuda")
-    assert scan(d.data_ptr(), host.size, out.data_ptr(), n + 8) == n
-    assert got.shape == (n, w) and np.array_equal(got, out[:n].cpu().numpy())
-    head = host[: 512 * 4096]
-    exp = o.find_all_submatch_index(head) if sub else o.find_all_index(head)
-    assert np.array_equal(got[: len(exp)], exp)
-    # capacity: the call reports the count, the wrapper retries with room
-    import ctypes as C
-    small = np.empty((1000, w), dtype=np.int64)
-    cnt = C.c_uint64(0)
-    fn = cx._lib.lib().cxg_find_all_submatch if sub else cx._lib.lib().cxg_find_all
-    assert fn(rx._h, host.ctypes.data, host.size, -1, small.ctypes.data, 1000, C.byref(cnt)) == cx._lib.CXG_E_CAPACITY and cnt.value == n
-    if not sub:
-        solid = np.full(130 << 20, ord("7"), dtype=np.uint8)          # no byte outside the alphabet: no cut, one-shot path
-        solid[-9:] = np.frombuffer(b" 1.2.3.4 ", dtype=np.uint8)
-        assert rx.count(solid) == len(rx.find_all_index(solid))
-
-
 def test_use_both_programs(need_gpu, oracle):
     """UseBoth (find_indices.go:408-441): the DFA's end only picks where the PikeVM starts (end-100 for far ends), so
     FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's PikeVM starts inside
