@@ -1013,7 +1013,7 @@ int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_p
   if (!nfa || !out) return fail(CXG_E_INVALID, "null argument");
   *out = nullptr;
   if (strategy < 0 || strategy > CXG_USE_MULTILINE_REVERSE_SUFFIX) return fail(CXG_E_INVALID, "strategy outside meta.Strategy (0..16)");
-  if (flags & ~(CXG_FLAG_DIGIT_RUN_SKIP_SAFE | CXG_FLAG_HAS_REVERSE_DFA)) return fail(CXG_E_INVALID, "unknown flag bits");
+  if (flags & ~(CXG_FLAG_DIGIT_RUN_SKIP_SAFE | CXG_FLAG_HAS_REVERSE_DFA | CXG_FLAG_HAS_PREFILTER)) return fail(CXG_E_INVALID, "unknown flag bits");
   cxg_program* p = nullptr;
   try {
     std::string why;

@@ -528,88 +528,114 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
             }
           }
         }
-        // (2b) The tile's first sub-chunk is unresolved: every tile in front of it may be in the same situation, and
-        // the hand-off from tile to tile is a serial chain over the whole input.  Keep that chain to one lookup per
-        // tile: lanes 0..7 chase the (<= 8) candidates of the first set through the tile's maps BEFORE the true entry is
-        // known; when it arrives, this tile's exit is the chased value of the matching candidate and is published at
-        // once — the tile's own chain and replays then run off the critical path.
+        // (2b) + (3), round 3: ONE inclusive scan over the sub-chunk maps instead of two serial walks over them.  Every lane
+        // folds its two sub-chunks into one map (a sub-chunk with a known entry is a constant map: its end state whatever
+        // came before); six Hillis-Steele levels compose them — S_l = tile entry -> state behind lane l, keys = the members
+        // of the tile's first set, or a constant as soon as a known sub-chunk lies in front.  S of the last lane is the tile's
+        // map (published at once when the exit in front is not known yet: fsm_resolve_exits) resp. its exit; S of lane l - 1
+        // applied to the exit in front gives lane l its true entry — all lanes at once.  The serial versions (a chase of the
+        // <= 8 candidates and a chain of true entries, one step per unresolved sub-chunk, up to 126 per tile and ~35
+        // instructions each) were 13 k of the 31 k instructions of a tile on input without synchronising structure.
         FSM_MARK(2);                                    // (unresolved tiles: replays of the known sub-chunks + member maps)
         const unsigned long long am_all = __ballot(active);
         const int last_lane = 63 - __builtin_clzll(am_all | 1ull);
         uint32_t pred_exit = 0u;
         const bool first_open = (um0 >> 1) & 1ull;
-        if (first_open || map_only) {
-          const uint32_t u1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[0]), 1));
-          uint32_t cand = !first_open ? 0u : (lane < kFsmMembers ? fsm_member(v, u1, static_cast<uint32_t>(lane)) : 0xFFFFu);   // (first set known: any start, the first link sets it)
-          const uint32_t cand0 = cand;
-          for (int l = 1; l <= last_lane; l++) {
+        const uint32_t u1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(entry[0]), 1));
+        auto look = [](const uint32_t (&M)[kFsmMembers], uint32_t x) -> uint32_t {     // member -> end state; 0xFFFF: not listed
+          uint32_t r = 0xFFFFu;
 #pragma unroll
-            for (int sb = 0; sb < 2; sb++) {
-              if (sb == 1 && !static_cast<bool>(__builtin_amdgcn_readlane(static_cast<int>(second), l))) continue;
-              if (((sb ? um1 : um0) >> l) & 1ull) {
-                uint32_t nxt = 0xFFFFu;
+          for (int jm = 0; jm < kFsmMembers; jm++) r = ((M[jm] & 0xFFFFu) == x) ? (M[jm] >> 16) : r;
+          return r;
+        };
+        bool isc = !unres0;                              // this lane's map is a constant ...
+        uint32_t cv = xc[0];                             // ... this one
+        uint32_t P[kFsmMembers];
 #pragma unroll
-                for (int jm = 0; jm < kFsmMembers; jm++) {
-                  const uint32_t fj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
-                  if ((fj & 0xFFFFu) == cand) nxt = fj >> 16;
-                }
-                cand = cand == 0xFFFFu ? 0xFFFFu : nxt;
-              } else {
-                const uint32_t xr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[sb]), l));
-                cand = cand == 0xFFFFu ? 0xFFFFu : xr;
-              }
+        for (int jm = 0; jm < kFsmMembers; jm++) P[jm] = F[0][jm];
+        if (second) {
+          if (!unres1) { isc = true; cv = xc[1]; }
+          else if (isc) cv = look(F[1], cv);
+          else {
+#pragma unroll
+            for (int jm = 0; jm < kFsmMembers; jm++) P[jm] = (P[jm] & 0xFFFFu) | (look(F[1], P[jm] >> 16) << 16);
+          }
+        }
+#pragma unroll 1
+        for (int d = 1; d < 64; d <<= 1) {               // S_l := own o S_{l-d}
+          const int src = lane - d;
+          const bool pisc = __shfl(static_cast<int>(isc), src, 64) != 0;
+          const uint32_t pcv = static_cast<uint32_t>(__shfl(static_cast<int>(cv), src, 64));
+          uint32_t N[kFsmMembers];
+          const uint32_t ncv = look(P, pcv);
+#pragma unroll
+          for (int jm = 0; jm < kFsmMembers; jm++) {
+            const uint32_t q = static_cast<uint32_t>(__shfl(static_cast<int>(P[jm]), src, 64));
+            N[jm] = (q & 0xFFFFu) | (look(P, q >> 16) << 16);
+          }
+          if (src >= 1 && !isc) {                        // (a constant absorbs whatever lies in front of it; lanes 1.. are the active ones)
+            if (pisc) { isc = true; cv = ncv; }
+            else {
+#pragma unroll
+              for (int jm = 0; jm < kFsmMembers; jm++) P[jm] = N[jm];
             }
           }
+        }
+        // the tile as a whole
+        const bool t_isc = __builtin_amdgcn_readlane(static_cast<int>(isc), last_lane) != 0;
+        const uint32_t t_cv = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cv), last_lane));
+        if (t_isc) {                                     // its exit does not depend on its entry: successors need not wait for anything
+          if (t_cv == 0xFFFFu) fallback |= 1u;
+          else if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, t_cv);
+        }
+        if (map_only) {
+          if (!t_isc && lane == last_lane) {
+#pragma unroll
+            for (int jm = 0; jm < kFsmMembers; jm++) S.mapx[q_tile][jm] = static_cast<uint16_t>(P[jm] >> 16);
+            S.mapu[q_tile] = static_cast<uint16_t>(u1);
+          }
+          deferred = true;
+        } else if (first_open) {
           // The exit in front: a short look in the first pass (the wave of the tile in front runs beside this one), then
           // rather the map than a blocked wave; in the second pass it is there.
-          uint32_t pw = 0u;
-          if (!map_only) pw = it < tpw ? peek_tile_exit(S.exit, a.status2, group, q_tile, a.epoch, q_tile ? 64u : 2u)
+          const uint32_t pw = it < tpw ? peek_tile_exit(S.exit, a.status2, group, q_tile, a.epoch, q_tile ? 64u : 2u)
                                        : (wait_tile_exit(S.exit, a.status2, a.err, group, q_tile, a.epoch, lane) | kExitValid);
           if (!(pw & kExitValid)) {
-            if (first_open) {
-              if (lane < kFsmMembers) S.mapx[q_tile][lane] = static_cast<uint16_t>(cand);
-              if (lane == 0) S.mapu[q_tile] = static_cast<uint16_t>(u1);
+            if (!t_isc && lane == last_lane) {
+#pragma unroll
+              for (int jm = 0; jm < kFsmMembers; jm++) S.mapx[q_tile][jm] = static_cast<uint16_t>(P[jm] >> 16);
+              S.mapu[q_tile] = static_cast<uint16_t>(u1);
             }
-            else {                                       // (map_only) the exit does not depend on the entry
-              const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), 0));
-              if (ex == 0xFFFFu) fallback |= 1u;
-              else if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
-            }
-            if (!map_only) { jd = j; if (lane == 0) S.ndefer = 1u; }
+            jd = j;
+            if (lane == 0) S.ndefer = 1u;
             deferred = true;
           } else {
             pred_exit = pw & 0xFFFFu;
-            const unsigned long long hit = __ballot(lane < kFsmMembers && cand0 == pred_exit);
-            if (hit) {
-              const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand), __builtin_ctzll(hit)));
-              if (lane == 0 && ex != 0xFFFFu) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
-            } else fallback |= 1u;                        // the true state is not in the listed set: cannot happen
+            if (!t_isc) {
+              uint32_t TP[kFsmMembers];
+#pragma unroll
+              for (int jm = 0; jm < kFsmMembers; jm++) TP[jm] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(P[jm]), last_lane));
+              const uint32_t ex = look(TP, pred_exit);
+              if (ex == 0xFFFFu) fallback |= 1u;           // the true state is not in the listed set: cannot happen
+              else if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
+            }
           }
         }
-        FSM_MARK(6);                                    // (chase, look at the exit in front)
-        // (3) the chain, wave-uniform
-        uint32_t cur = 0u;                              // end state of the sub-chunk in front of the one being resolved
+        FSM_MARK(6);                                    // (scan over the maps, look at the exit in front)
+        // (3) true entries: the state behind lane l - 1 is this lane's entry
         uint32_t true_entry[2] = {entry[0], entry[1]};
-        unsigned long long todo = deferred ? 0ull : (um0 | um1);
-        while (todo) {
-          const int l = __builtin_ctzll(todo);
-          todo &= todo - 1;
+        if (!deferred) {
+          const bool eisc = __shfl(static_cast<int>(isc), lane - 1, 64) != 0;
+          const uint32_t ecv = static_cast<uint32_t>(__shfl(static_cast<int>(cv), lane - 1, 64));
+          uint32_t EP[kFsmMembers];
 #pragma unroll
-          for (int sb = 0; sb < 2; sb++) {
-            if (!(((sb ? um1 : um0) >> l) & 1ull)) continue;
-            // the sub-chunk in front: (l, 0) for sb == 1, (l - 1, 1) for sb == 0, the previous tile for the tile's first
-            if (sb == 1) { if (!((um0 >> l) & 1ull)) cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[0]), l)); }
-            else if (l == 1) cur = pred_exit;
-            else if (!((um1 >> (l - 1)) & 1ull)) cur = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xc[1]), l - 1));
-            if (lane == l) true_entry[sb] = cur;
-            uint32_t nxt = 0xFFFFu;
-#pragma unroll
-            for (int jm = 0; jm < kFsmMembers; jm++) {
-              const uint32_t fj = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(F[sb][jm]), l));
-              if ((fj & 0xFFFFu) == cur) nxt = fj >> 16;
-            }
-            if (nxt == 0xFFFFu) { fallback |= 1u; nxt = 0u; }                 // the true state is not in the listed set: cannot happen
-            cur = nxt;
+          for (int jm = 0; jm < kFsmMembers; jm++) EP[jm] = static_cast<uint32_t>(__shfl(static_cast<int>(P[jm]), lane - 1, 64));
+          const uint32_t before = lane <= 1 ? pred_exit : (eisc ? ecv : look(EP, pred_exit));
+          if (unres0) { true_entry[0] = before; if (before == 0xFFFFu) { fallback |= 1u; true_entry[0] = 0u; } }
+          if (unres1) {
+            const uint32_t mid = unres0 ? look(F[0], true_entry[0]) : xc[0];
+            true_entry[1] = mid;
+            if (mid == 0xFFFFu) { fallback |= 1u; true_entry[1] = 0u; }
           }
         }
         // (4) replay of the unresolved sub-chunks

@@ -1349,6 +1349,11 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   }
   if (nfaSize > 100) { p.strategy = CXG_USE_NFA; return p; }
   p.strategy = CXG_USE_BOTH;
+  {  // selectPrefilter (prefilter/prefilter.go:261-297) over the prefix literals: one literal, or 2+ literals of >= 3 bytes each
+    size_t minLen = ~size_t(0);
+    for (auto& l : p.prefixes) minLen = std::min(minLen, l.bytes.size());
+    if (!p.prefixes.empty() && minLen >= 1 && (p.prefixes.size() == 1 || minLen >= 3)) p.flags |= CXG_FLAG_HAS_PREFILTER;
+  }
   return p;
 }
 

@@ -658,7 +658,12 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       // `at` and the leftmost match, so the answer is the plain leftmost-first match unless that match is longer than
       // 100 bytes (then the PikeVM starts inside it).  The kernels compute leftmost-first and raise error bit 64 on a
       // longer match (kFlagBothRestart): CXG_E_INPUT, the caller keeps its CPU loop for that haystack.
-      if (strategy == CXG_USE_BOTH) h.flags |= cxgdev::kFlagBothRestart;
+      // (With a prefilter — CXG_FLAG_HAS_PREFILTER — the reference's PikeVM starts at the prefilter's position, in front of the
+      // leftmost match: plain leftmost-first whatever the length, find_indices.go:411-429.  Programs with assertions keep the flag:
+      // adjustForAnchors may have dropped the prefilter, compile.go:660-680.)
+      bool lookAny = false;
+      for (uint32_t i = 0; i < nfa.n_states; i++) lookAny = lookAny || nfa.states[i].kind == CXG_NFA_LOOK;
+      if (strategy == CXG_USE_BOTH && (lookAny || !(flags & CXG_FLAG_HAS_PREFILTER))) h.flags |= cxgdev::kFlagBothRestart;
       if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
       bool look = false;
       for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;

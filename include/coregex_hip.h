@@ -95,6 +95,9 @@ typedef struct cxg_nfa {
 
 #define CXG_FLAG_DIGIT_RUN_SKIP_SAFE 1u  /* Engine.digitRunSkipSafe (meta/compile.go:176) */
 #define CXG_FLAG_HAS_REVERSE_DFA 2u      /* Engine.reverseDFA != nil (meta/compile.go:184-205) */
+#define CXG_FLAG_HAS_PREFILTER 4u        /* Engine.prefilter != nil (meta/compile.go:466-478; prefilter/prefilter.go:261-297: one prefix literal, or 2+ of >= 3 bytes).
+                                            UseBoth: with a prefilter the reference runs its PikeVM from the prefilter's position (plain leftmost-first,
+                                            find_indices.go:411-429); without one it restarts the PikeVM at end - 100 inside a longer match (:432-441). */
 
 typedef struct cxg_program cxg_program;  /* opaque: strategy + tables, host and device copies */
 typedef struct cxg_buffer cxg_buffer;    /* opaque: device-resident haystack */

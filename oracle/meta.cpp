@@ -648,7 +648,8 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
   // prefilter.NewBuilder(prefixes, nil).Build() (compile.go:472-476 -> prefilter/prefilter.go:261-297): one literal ->
   // memchr / memmem; 2..64 literals of >= 3 bytes -> Teddy, more -> Aho-Corasick; otherwise none.  Whatever the kind, Find
   // returns the first position at which one of the literals occurs (prefilter.go:77).
-  bool hasPrefilter = false;
+  bool& hasPrefilter = e->hasPrefilter;
+  hasPrefilter = false;
   if (!e->prefixes.empty()) {
     size_t minLen = ~size_t(0);
     for (auto& l : e->prefixes.lits) minLen = std::min(minLen, l.bytes.size());
@@ -758,7 +759,7 @@ bool Engine::findAt(Bytes h, int64_t len, int64_t at, int64_t& s, int64_t& e) {
       if (dfaGatesPikeVM && at < len && !dfa.isMatchAt(h, len, at)) return false;   // find_indices.go:396-400
       return pikevm.searchAt(h, len, at, s, e);
     case UseBoth:  // findIndicesAdaptiveAtWithState :408-441
-      if (dfa.nfa && prefixes.empty()) {
+      if (dfa.nfa && !hasPrefilter) {   // e.prefilter == nil: selectPrefilter found nothing usable in the prefixes (NOT: no prefixes at all)
         int64_t end = dfa.searchAt(h, len, at);
         if (end != -1) {
           int64_t est = at;

@@ -49,6 +49,7 @@ struct Engine {
   NFA nfa, revNfa;
   Strategy strategy = UseNFA;
   bool strategyRestated = true;
+  bool hasPrefilter = false;     // Engine.prefilter != nil (prefilter/prefilter.go:261-297)
   bool dfaGatesPikeVM = false;   // UseDFA over assertions, no reverse DFA, no prefilter: DFA.IsMatchAt decides whether the PikeVM runs
   Seq prefixes;
   bool digitRunSkipSafe = false;

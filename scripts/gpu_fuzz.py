@@ -32,6 +32,8 @@ if os.environ.get("FUZZ_FEW"):
     # stretches, so the transducer kernel's member maps, its serial chain and the tile / group hand-off do the work
     few = [np.frombuffer(a, dtype=np.uint8) for a in (b"ab", b"abc", b"ab ", b"xyz", b"1.", b"a:c", b"abx\n", b"01 .")]
     hays = [f[rng.integers(0, len(f), size=int(n))] for f in few for n in (70000, 260000)]
+    # ... and two long ones: hundreds of groups in the kernel's dense modes, i.e. several windows of the look-back over maps (round 3)
+    hays += [few[4][rng.integers(0, 2, size=2 << 20)], np.frombuffer((b"1." * (1 << 20)), dtype=np.uint8)]
 ORACLE_ONLY = bool(os.environ.get('FUZZ_ORACLE_ONLY'))
 seen, n_dev, n_sub, bad = set(), 0, 0, 0
 n_refused = 0

@@ -454,6 +454,26 @@ def test_use_both_programs(need_gpu, oracle):
     assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay))        # the program stays usable
 
 
+def test_use_both_restart_without_a_usable_prefilter(need_gpu, oracle):
+    """`(xy|ab|ca)\\w+(ab)+`: prefix literals exist but are too short for a prefilter (prefilter/prefilter.go:261-297: 2+ literals
+    need >= 3 bytes each), so the reference's UseBoth path is DFA end + PikeVM restart at end - 100 (find_indices.go:432-441) —
+    found by the round-3 device fuzz, where the oracle had taken "prefixes non-empty" for "has a prefilter"."""
+    pat = r"(xy|ab|ca)\w+(ab)+"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == "UseBoth" and rx.supported and not (rx.flags & 4)
+    rng = np.random.default_rng(5)
+    hays = [b"zz " + b"ab" * 200 + b" q" + b"ba" * 120 + b"ab9 x" + b"abc" * 50 + b"y" + b"cab" * 40 + b"z7",
+            np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, 70000)], np.frombuffer(b"abc ", dtype=np.uint8)[rng.integers(0, 4, 260000)],
+            np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, 300)]]
+    for h in hays:
+        exp = o.find_all_index(h)
+        got = rx.find_all_index(h)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (got[:3].tolist(), exp[:3].tolist())
+        assert rx.count(h) == len(exp)
+    long_rows = o.find_all_index(hays[0])
+    assert int((o.find_all_submatch_index(hays[0])[:, 1] - o.find_all_submatch_index(hays[0])[:, 0]).max()) > 100 and int((long_rows[:, 1] - long_rows[:, 0]).max()) <= 100
+
+
 def test_random_patterns(need_gpu, oracle):
     """Fuzz: random concatenations of literal bytes, classes, class+, optional and alternation atoms — whatever the device
     path accepts (chain kernel, table-walking kernels, Teddy, char-class) must reproduce the oracle, spans and counts,
