@@ -65,7 +65,8 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
 #define CXG_SDWA_MOV3_PACK(S, e, K) \
   asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_" #K " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(S) : "v"(e))
 // one byte step: candidate flag of position i (entries ei, ei1, ei2) and its synchronising flag into byte K
-#define CXG_TEDDY_STEP(T, S, ei, ei1, ei2, K) do { uint32_t d_; CXG_SDWA_AND01(d_, ei, ei1); CXG_SDWA_AND2_PACK(T, d_, ei2, K); CXG_SDWA_MOV3_PACK(S, ei, K); } while (0)
+// (SYNC: the synchronising flags are only needed where the ownership bounds are searched — the first and the last KiB of the window)
+#define CXG_TEDDY_STEP(T, S, ei, ei1, ei2, K) do { uint32_t d_; CXG_SDWA_AND01(d_, ei, ei1); CXG_SDWA_AND2_PACK(T, d_, ei2, K); if (SYNC) CXG_SDWA_MOV3_PACK(S, ei, K); } while (0)
 
 }  // namespace
 
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   __shared__ __attribute__((aligned(16))) uint8_t s_aux[kTAuxMax];
   __shared__ uint32_t s_T[256];                                    // A | B<<8 | C<<16 | sync<<24 per byte value
   __shared__ uint8_t s_boff[16];                                   // bucket b: its literals are order[s_boff[b] .. s_boff[b+1])
+  __shared__ uint32_t s_lit[32][6];                                // literal id (Slim Teddy): first 12 bytes as three dwords, and their masks
   __shared__ __attribute__((aligned(16))) uint8_t s_bytes[kWavesPerBlock][kWin + 16];
   __shared__ __attribute__((aligned(16))) uint64_t s_cw[kWavesPerBlock][2][64];   // candidate / synchronising bitmaps
   __shared__ uint16_t s_cpos[kWavesPerBlock][kTCands];
@@ -117,6 +119,15 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x1000000u : 0u);
   __syncthreads();
   if (static_cast<uint32_t>(tid) < nlits) atomicOr(&s_T[t_bytes[t_off[tid] + 2]], 0x10000u << t_bucket[tid]);   // third-byte masks
+  if (static_cast<uint32_t>(tid) < nlits && tid < 32) {             // verification compares dwords (below)
+    const uint8_t* lb = t_bytes + t_off[tid];
+    const uint32_t len = t_lens[tid];
+    for (uint32_t k = 0; k < 3; k++) {
+      uint32_t L = 0, M = 0;
+      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) { L |= static_cast<uint32_t>(lb[4 * k + b]) << (8 * b); M |= 0xFFu << (8 * b); }
+      s_lit[tid][k] = L; s_lit[tid][3 + k] = M;
+    }
+  }
   if (tid < 16) {                                                  // order[] is bucket-major: first index of every bucket
     uint32_t first = nlits;
     for (uint32_t k = nlits; k-- > 0;) if (t_bucket[t_order[k]] >= static_cast<uint32_t>(tid)) first = k;
@@ -198,6 +209,8 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
         CXG_SDWA_ADDR(ad, x[k].w, 2); e[14] = *reinterpret_cast<const uint32_t*>(Tb + ad);
         CXG_SDWA_ADDR(ad, x[k].w, 3); e[15] = *reinterpret_cast<const uint32_t*>(Tb + ad);
         uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        constexpr bool SYNC_ALL = false;                              // (A/B: flags of every vector, as in round 2)
+        const bool SYNC = SYNC_ALL || k == 0 || k == 3;               // compile-time per unrolled k
         CXG_TEDDY_STEP(t0, s0, e[0], e[1], e[2], 0);   CXG_TEDDY_STEP(t0, s0, e[1], e[2], e[3], 1);
         CXG_TEDDY_STEP(t0, s0, e[2], e[3], e[4], 2);   CXG_TEDDY_STEP(t0, s0, e[3], e[4], e[5], 3);
         CXG_TEDDY_STEP(t1, s1, e[4], e[5], e[6], 0);   CXG_TEDDY_STEP(t1, s1, e[5], e[6], e[7], 1);
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
         CXG_TEDDY_STEP(t3, s3, e[12], e[13], e[14], 0); CXG_TEDDY_STEP(t3, s3, e[13], e[14], e[15], 1);
         CXG_TEDDY_STEP(t3, s3, e[14], e[15], e[16], 2); CXG_TEDDY_STEP(t3, s3, e[15], e[16], e[17], 3);
         pc[lane + 64 * k] = static_cast<uint16_t>(gather16_nz(t0, t1, t2, t3));
-        ps[lane + 64 * k] = static_cast<uint16_t>(gather16_01(s0, s1, s2, s3));
+        ps[lane + 64 * k] = SYNC ? static_cast<uint16_t>(gather16_01(s0, s1, s2, s3)) : static_cast<uint16_t>(0);
       }
       const uint32_t xprev_cur = xprev;
       issue_loads(j + 1);                                           // x[] is free from here on
@@ -225,7 +238,11 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
         const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
         if (!(s_T[pb] & 0x1000000u)) {                                // the segment at the tile's first byte began earlier
           const unsigned long long bz = __ballot(Z != 0ull);
-          if (bz) { const int L = __builtin_ctzll(bz); zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L))); }
+          if (bz) {
+            const int L = __builtin_ctzll(bz);
+            zA = 64 * L + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, L)));
+            if (L >= 16) fallback |= 1;                               // no synchronising byte in the first KiB: words 16..47 carry no flags (SYNC above)
+          }
           else zA = kTFar;
         }
       }
@@ -258,7 +275,13 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
           if (r0 + static_cast<uint32_t>(lane) < ncand) {
             c = s_cpos[wave][r0 + lane];
             const uint8_t* wb = s_bytes[wave];
-            uint32_t mask = (s_T[wb[c]] & 0xFFu) & ((s_T[wb[c + 1]] >> 8) & 0xFFu) & ((s_T[wb[c + 2]] >> 16) & 0xFFu);
+            // the 12 bytes at the candidate as three dwords (aligned LDS reads + v_alignbit): a literal is compared in three
+            // masked XORs instead of a byte loop of up to its length — the byte loop was ~200 VALU of a tile's 783
+            const uint32_t* wa = reinterpret_cast<const uint32_t*>(wb + (c & ~3));
+            const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
+            const uint32_t d0 = wa[0], d1 = wa[1], d2 = wa[2], d3 = wa[3];
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+            uint32_t mask = (s_T[w0 & 0xFFu] & 0xFFu) & ((s_T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((s_T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
             while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
               const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
               mask &= mask - 1;
@@ -266,8 +289,13 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
                 const uint32_t id = t_order[k];
                 const int32_t len = t_lens[id];
                 if (c + len > rend) continue;
+                if (id < 32u) {
+                  const uint32_t diff = ((w0 ^ s_lit[id][0]) & s_lit[id][3]) | ((w1 ^ s_lit[id][1]) & s_lit[id][4]) | ((w2 ^ s_lit[id][2]) & s_lit[id][5]);
+                  if (diff != 0u) continue;
+                  if (len <= 12) { mlen = len; continue; }
+                }
                 const uint8_t* lit = t_bytes + t_off[id];
-                int32_t q = 0;
+                int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
                 while (q < len && wb[c + q] == lit[q]) q++;
                 if (q == len) mlen = len;
               }
