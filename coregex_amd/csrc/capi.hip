@@ -390,7 +390,14 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.row_width = static_cast<uint32_t>(row_width);
   a.ntiles = tilesFor(h->kind, len);
   if (a.ntiles > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
-  if (int rc = ensureStatus(s, a.ntiles)) return rc;
+  {
+    // look-back / exit words are indexed by GROUP, and the smallest group any kernel mode uses is the transducer kernel's mode 2:
+    // one wave-tile per wave = 15 KiB, i.e. 1.07 groups per 16 KiB tile.  (Round 3 fix: a cached allocation that covered
+    // `ntiles` of this call but not its mode-2 groups was written past its end — found by the CXG_NO_EPOCH run of the no-sync test.)
+    const uint64_t smallest = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock;
+    const uint64_t maxGroups = (len + smallest - 1) / smallest + 1;
+    if (int rc = ensureStatus(s, a.ntiles > maxGroups ? a.ntiles : maxGroups)) return rc;
+  }
   a.status = s.status;
   a.status2 = s.status + s.statusCap;
   a.ticket = reinterpret_cast<uint32_t*>(s.ctl + 32);   // 8 per-XCD counters (block_common.hpp claim_tile)
@@ -455,6 +462,7 @@ relaunch:
     const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * a.tiles_per_wave;
     a.ngroups = (len + gb - 1) / gb;
   }
+  if (a.ngroups > s.statusCap) return fail(CXG_E_INTERNAL, "status words: more groups than the allocation covers");
   // Wave kernels with static groups tag their look-back words with a launch epoch and clear the next launch's error
   // word themselves: no memset between launches.  Everything else starts from a zeroed control block + status words.
   static const bool epochsOk = getenv("CXG_NO_EPOCH") == nullptr;
@@ -522,6 +530,8 @@ relaunch:
     static const bool fieldsOk = getenv("CXG_NO_FIELDS_KERNEL") == nullptr;
     fieldsKernel = fieldsOk && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                    cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+    static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
+    a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
     if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);

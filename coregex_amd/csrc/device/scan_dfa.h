@@ -66,6 +66,7 @@ struct ScanArgs {
   uint32_t tiles_per_wave;  // scan_chain_wave.hip: kTilesPerWave, or kDenseTilesPerWave after a row-buffer overflow
   uint32_t max_len;     // != 0: a match longer than this raises error bit 64 (UseBoth programs, walk.hpp kFlagBothRestart)
   uint32_t dbg;         // CXG_DEBUG bit0: skip the lane walk, bit1: skip the look-back (timing experiments only)
+  uint32_t count_sum;   // scan_fields_wave.hip, count-only call: groups leave their totals in status[], k_sum_counts adds them up (no look-back)
   uint64_t* fsm_maps;   // scan_fsm.hip: three epoch-tagged words per group (fsm_group_entry)
   uint64_t limit;       // FindAll's n when > 0, else 0: rows beyond it are not wanted (block_common.hpp tile_lookback: early stop)
   uint32_t* stop;       // device word: == epoch + 1 once `limit` rows have been counted

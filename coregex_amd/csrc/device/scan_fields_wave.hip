@@ -384,6 +384,9 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * tpw];
+  // Count (no rows wanted, no limit): nobody needs this group's place in the output, only the grand total — the look-back, in
+  // which a workgroup spends more time than scanning, is replaced by a plain store and a one-workgroup sum behind the kernel
+  if (a.count_sum) { if (tid == 0) a.status[group] = total; return; }
   if (a.dbg & 2u) { if (tid == 0) s_base = 0; __syncthreads(); }     // CXG_DEBUG=2 (timing experiments, rows land in the wrong places): no look-back
   else tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (a.prof && tid == 0) {
@@ -437,6 +440,17 @@ void launch_fields_k(const ScanArgs& a, uint32_t kd, uint32_t kp, dim3 grid, dim
 }
 }  // namespace
 
+__global__ __launch_bounds__(1024) void k_sum_counts(const uint64_t* counts, uint64_t n, uint64_t* total) {
+  __shared__ uint64_t s_part[16];
+  uint64_t v = 0;
+  for (uint64_t i = threadIdx.x; i < n; i += 1024) v += counts[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint64_t t = 0; for (int i = 0; i < 16; i++) t += s_part[i]; *total = t; }
+}
+
 // a.ngroups = number of 120 KiB groups (one workgroup each).
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
   const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
@@ -448,6 +462,7 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
     case 4: launch_fields_k<4>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
     default: return hipErrorInvalidValue;
   }
+  if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, a.ngroups, a.total);
   return hipGetLastError();
 }
 
