@@ -42,8 +42,10 @@ extern "C" {
 #define CXG_E_SYNTAX (-6)       /* cxg_compile: pattern does not parse */
 #define CXG_E_INTERNAL (-7)     /* device-side invariant violated (watchdog, scratch overflow) */
 #define CXG_E_INPUT (-8)        /* THIS haystack cannot be answered on the device; the caller keeps its CPU loop for this
-                                   call, the program stays usable.  Two cases: (a) a UseBoth program met a match longer than
-                                   100 bytes (the reference restarts its PikeVM inside it, meta/find_indices.go:425-431);
+                                   call, the program stays usable.  Two cases: (a) a UseBoth program WITH ASSERTIONS met a match
+                                   longer than 100 bytes, or any UseBoth program met more than 64 of them in one haystack (the
+                                   reference restarts its PikeVM inside such a match, meta/find_indices.go:425-431; without
+                                   assertions the device path restarts its search at the same place, round 3);
                                    (b) a program WITHOUT a transducer image (cxg_program_fsm_image: > 224 stack states, or
                                    a table beyond the LDS budget) met > 128 KiB without a synchronising byte.  Programs
                                    with the image have no such limit (64 MiB of "1.1.1.1..." is answered, tests). */
