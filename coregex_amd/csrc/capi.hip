@@ -31,6 +31,8 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 int fields_shape(const ChainAux& c);
+bool trio_shape(const ChainAux& c);
+hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
@@ -446,11 +448,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
+  bool trioKernel = false;                                         // gen 6 served by k_scan_trio_wave
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
   int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
   fieldsKernel = false;
+  trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   a.ngroups = a.ntiles;
@@ -532,7 +536,22 @@ relaunch:
                    cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
     a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
-    if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
+    // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
+    // start, the end or the end of the first / second run plus a constant (ChainCaps)
+    static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
+    if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) &&
+        cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain))) {
+      bool ok = !submatch || a.out == nullptr || fusedCaps;
+      if (fusedCaps) {
+        const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
+        for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] == 0 || cc->run_op[i] == 2 || cc->run_op[i] == 4);
+        for (uint32_t k = 0; k < cc->nslots; k++) ok = ok && (cc->src[k] <= cxgdev::kCapSrcEnd || (cc->src[k] >= cxgdev::kCapSrcRun0 && cc->src[k] < cxgdev::kCapSrcRun0 + cc->nruns));
+        ok = ok && (a.row_width & 1u) == 0u && cc->nslots == a.row_width;
+      }
+      trioKernel = ok;
+    }
+    if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream);
+    else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
@@ -605,7 +624,7 @@ relaunch:
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
-    timing->kernel = static_cast<uint32_t>(fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+    timing->kernel = static_cast<uint32_t>(trioKernel ? CXG_K_TRIO_WAVE : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
   }
@@ -934,6 +953,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_DIGIT_FLAT: return "k_scan_digit_flat";
     case CXG_K_CHAIN_WAVE: return "k_scan_chain_wave";
     case CXG_K_FIELDS_WAVE: return "k_scan_fields_wave";
+    case CXG_K_TRIO_WAVE: return "k_scan_trio_wave";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";

@@ -466,4 +466,307 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// =====================================================================================================================
+// k_scan_trio_wave — FindAll / FindAllSubmatch for the chain  run(F) byte(a) run(F) byte(b) run(F)  with a != b single bytes
+// outside F: `(\w+)@(\w+)\.(\w+)` (BASELINE configs[4]), `\d+-\d+:\d+`.  Same window, ownership and group structure as the
+// fields kernel above; what differs:
+//   A  all three class bitmaps from ONE byte table in LDS (T[b] = F | a << 1 | b << 2, built from the chain's class list):
+//      F may be a union of ranges (`\w`), where a compare per range and dword costs more than a lookup per byte.
+//   B  links LA = A & (D<<1) & (D>>1), LB likewise; super-run = maximal stretch of F bytes and links of either kind; the tile
+//      owns the super-runs that start in its bytes: OWN = X & ~(X + WS), X = D | LA | LB (one multiword addition).
+//   C  a match is a run, an LA link, a run, an LB link, a run; it starts at the START of its first run (leftmost-first: `\w+`
+//      takes the run from its first byte) and every owned LA link is a candidate: hop over the run behind it — it must end
+//      on an LB link — and over the run behind that: two additions give the ends of all candidates.
+//   D  FindAll resumes at a match's end, so a candidate whose first run is the third run of an earlier selected match is
+//      dropped (`a@b.c@d.e`: c belongs to the first match).  That is the case exactly when an end sits on the LA link of a
+//      candidate; rare on text — resolved by a loop (heads of such chains are selected, what they block is removed, repeat).
+//   E  rows: per end bit the nearest bytes outside F below it are the LB link, then the LA link, then the byte in front of the
+//      match — three bit scans over (previous lane's word : this word); a match that reaches further back hands the scan over.
+//      A row is four positions (start, LA link, LB link, end); the epilogue turns them into the program's capture slots
+//      (walk.hpp ChainCaps: start / end / end of the first / second run, plus a constant) or into [start, end).
+// Fallback flag: as for the fields kernel (the host reruns on scan_chain_wave.hip).
+namespace {
+constexpr int kTRows = 64 * kTilesPerWave;                 // rows buffered per wave and group
+
+struct TrioTile { uint32_t e0, e1; bool ovf; };
+
+__device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+  const uint32_t prev_d1 = dpp_from_lower(d1);
+  const uint32_t next_d0 = dpp_from_upper_ones(d0);
+  const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
+  const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
+  const uint32_t la0 = a0 & Dl0 & Dr0, la1 = a1 & Dl1 & Dr1;
+  const uint32_t lb0 = b0 & Dl0 & Dr0, lb1 = b1 & Dl1 & Dr1;
+  const uint32_t l0 = la0 | lb0, l1 = la1 | lb1;
+  const uint32_t x0 = d0 | l0, x1 = d1 | l1;                       // super-runs
+  const uint32_t prev_l1 = dpp_from_lower(l1);
+  const uint32_t Ll0 = __builtin_amdgcn_alignbit(l0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(l1, l0, 31);   // L << 1
+  const uint32_t ws0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), ws1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // owned super-run starts
+  const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
+  const unsigned long long PPx = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(x1) << 32) | x0, ~0ull, 32 /*eq*/);
+  unsigned long long ovf = 0;
+  auto carry_in = [&](unsigned long long GG, unsigned long long PP) -> unsigned long long {
+    const unsigned long long Pe = PP & ~GG;
+    const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;
+    ovf |= GG | (Pe & recv);
+    return recv;
+  };
+  // owned span: the bits of X that the addition of the owned starts clears
+  uint32_t s0, s1;
+  unsigned long long GG;
+  add64_co(x0, x1, ws0, ws1, s0, s1, GG);
+  add64_cin(s0, s1, carry_in(GG, PPx));
+  const uint32_t own0 = x0 & ~s0, own1 = x1 & ~s1;
+  // hop over one run from link bits q (subset of L): the carry of q + q runs through the F bytes behind the link
+  auto hop = [&](uint32_t q0, uint32_t q1, uint32_t& r0, uint32_t& r1) {
+    unsigned long long G2;
+    add64_co(d0 | q0, d1 | q1, q0, q1, r0, r1, G2);
+    add64_cin(r0, r1, carry_in(G2, PPd));
+  };
+  auto hop2 = [&](uint32_t q0, uint32_t q1, uint32_t& e0, uint32_t& e1) {   // ends of the candidates whose LA link is in q
+    uint32_t r0, r1;
+    hop(q0, q1, r0, r1);
+    const uint32_t m0 = r0 & lb0, m1 = r1 & lb1;                            // ... whose second run ends on an LB link
+    hop(m0, m1, r0, r1);
+    e0 = r0 & ~d0; e1 = r1 & ~d1;
+  };
+  uint32_t e0, e1;
+  hop2(la0 & own0, la1 & own1, e0, e1);
+  // ends that sit on an LA link: the candidate that begins with that link (if it is one) shares a run with this match
+  uint32_t xa0 = e0 & la0, xa1 = e1 & la1;
+  if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(xa1) << 32) | xa0, 0ull, 33 /*ne*/) != 0ull) {
+    uint32_t r0 = e0, r1 = e1, sel0 = 0, sel1 = 0;                          // undecided / selected (by their ends)
+    for (int guard = 0; guard < 64; guard++) {
+      uint32_t k0, k1;
+      hop2(r0 & la0, r1 & la1, k0, k1);                                     // ends of candidates blocked by undecided ones
+      const uint32_t h0 = r0 & ~k0, h1 = r1 & ~k1;                          // heads: undecided, not blocked by an undecided one
+      sel0 |= h0; sel1 |= h1;
+      hop2(h0 & la0, h1 & la1, k0, k1);                                     // what the heads block
+      r0 &= ~(h0 | k0); r1 &= ~(h1 | k1);
+      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(r1) << 32) | r0, 0ull, 33 /*ne*/) == 0ull) break;
+      if (guard == 63) ovf |= 1ull << 63;
+    }
+    e0 = sel0; e1 = sel1;
+  }
+  return TrioTile{e0, e1, (ovf >> 63) != 0ull};
+}
+
+// highest set bit of the 128-bit value (h : l), or -1; and the value with that bit cleared
+__device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
+  if (h) { const int32_t k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
+  if (l) { const int32_t k = 63 - __builtin_clzll(l); l &= ~(1ull << k); return k; }
+  return -1;
+}
+
+// rows of the lane's end bits: {start | end << 16, la | lb << 16} (window bit indices) at rows[2 r], r counting up from r0
+__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, uint32_t r, uint32_t cap) {
+  const uint64_t z = ~((static_cast<uint64_t>(d1) << 32) | d0);             // bytes outside F, this lane's word
+  const uint64_t pz = (static_cast<uint64_t>(dpp_from_lower_z(static_cast<uint32_t>(z >> 32))) << 32) | dpp_from_lower_z(static_cast<uint32_t>(z));   // previous lane's (lane 0: none)
+  const int32_t base = (lane << 6) - 64;                                    // window index of bit 0 of (pz : z)
+  uint64_t ee = (static_cast<uint64_t>(t.e1) << 32) | t.e0;
+  while (ee) {
+    const int32_t b = __builtin_ctzll(ee);
+    ee &= ee - 1ull;
+    uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;             // bytes outside F below the end, nearest first:
+    const int32_t pb = take_top(l, h);                                      // the LB link
+    const int32_t pa = take_top(l, h);                                      // the LA link
+    const int32_t ps = take_top(l, h);                                      // the byte in front of the match
+    uint32_t w0, w1;
+    if (ps < 0 || pa < 0 || pb < 0) { w0 = 0; w1 = 0; }                     // start not found within two words: row void (start >= end), caught below
+    else {
+      w0 = static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16);
+      w1 = static_cast<uint32_t>(base + pa) | (static_cast<uint32_t>(base + pb) << 16);
+    }
+    const uint32_t rr = r < cap ? r : cap - 1u;
+    rows[2u * rr] = w0; rows[2u * rr + 1u] = w1;
+    r++;
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(kThreads, 6) void k_scan_trio_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_a[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_b[kWavesPerBlock][64];
+  __shared__ uint32_t s_row[kWavesPerBlock][2 * kTRows];
+  __shared__ uint8_t s_cls[256];
+  __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
+  __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
+  __shared__ uint64_t s_group;
+  __shared__ uint64_t s_base;
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  uint64_t group = blockIdx.x;
+  if (!a.static_groups) {
+    if (tid == 0) s_group = claim_group(false, a.ticket, a.ngroups);
+    __syncthreads();
+    group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  }
+  if (group >= a.ngroups) return;
+  if (limit_reached_skip(a, group, &s_base)) return;
+  {
+    const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
+    const uint32_t b = static_cast<uint32_t>(tid);
+    s_cls[tid] = static_cast<uint8_t>((chain_class_has(*gch, 0, b) ? 1u : 0u) | (chain_class_has(*gch, 1, b) ? 2u : 0u) | (chain_class_has(*gch, 2, b) ? 4u : 0u));
+  }
+  __syncthreads();
+  constexpr int tpw = kTilesPerWave;
+  uint32_t nrows_w = 0, fallback = 0;
+  auto tile_lo_of = [&](int jj) { return (group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave) * static_cast<uint64_t>(kWaveTile); };
+  u32x4 x[4];
+  int32_t nvalid_cur = 0;
+  fields_first_loads(x, fields_window(a.hay, a.len, tile_lo_of(0), true, nvalid_cur), lane, group == 0 && wave == 0);
+  const bool want_rows = a.out != nullptr || a.max_len != 0;
+
+  for (int j = 0; j < tpw; j++) {
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    int32_t nvalid_next = 0;
+    const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, tile_lo_of(j + 1), j + 1 < tpw, nvalid_next);
+    // ---- A: one table lookup per byte; 16 flags per class and vector through the LDS scratch
+    {
+      uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
+      uint16_t* pa = reinterpret_cast<uint16_t*>(s_a[wave]);
+      uint16_t* pb = reinterpret_cast<uint16_t*>(s_b[wave]);
+      const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+        uint32_t fd = 0, fa = 0, fb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint32_t f = static_cast<uint32_t>(s_cls[w[q] & 0xFFu]) | (static_cast<uint32_t>(s_cls[(w[q] >> 8) & 0xFFu]) << 8) |
+                             (static_cast<uint32_t>(s_cls[(w[q] >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_cls[w[q] >> 24]) << 24);
+          const uint32_t wt = (q & 1) ? 0x80402010u : 0x08040201u;
+          // (flag bytes are 0/1 after the mask: the weighted sum is the four flags as bits q*4 .. q*4+3)
+          if (q < 2) {
+            fd = __builtin_amdgcn_udot4(f & 0x01010101u, wt, fd, false);
+            fa = __builtin_amdgcn_udot4((f >> 1) & 0x01010101u, wt, fa, false);
+            fb = __builtin_amdgcn_udot4((f >> 2) & 0x01010101u, wt, fb, false);
+          } else {
+            fd += __builtin_amdgcn_udot4(f & 0x01010101u, wt, 0u, false) << 8;
+            fa += __builtin_amdgcn_udot4((f >> 1) & 0x01010101u, wt, 0u, false) << 8;
+            fb += __builtin_amdgcn_udot4((f >> 2) & 0x01010101u, wt, 0u, false) << 8;
+          }
+        }
+        pd[lane + 64 * k] = static_cast<uint16_t>(fd);
+        pa[lane + 64 * k] = static_cast<uint16_t>(fa);
+        pb[lane + 64 * k] = static_cast<uint16_t>(fb);
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_lds_sync();
+    int lw = lane;
+    asm volatile("" : "+v"(lw));
+    uint64_t Dw = s_d[wave][lw], Aw = s_a[wave][lw], Bw = s_b[wave][lw];
+    if (nvalid_cur != kFWin) {
+      const int32_t nf = nvalid_cur - 64 * lane;
+      const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+      Dw &= vf; Aw &= vf; Bw &= vf;
+    }
+    nvalid_cur = nvalid_next;
+    const uint32_t d0 = static_cast<uint32_t>(Dw), d1 = static_cast<uint32_t>(Dw >> 32);
+    const TrioTile t = trio_core(d0, d1, static_cast<uint32_t>(Aw), static_cast<uint32_t>(Aw >> 32), static_cast<uint32_t>(Bw), static_cast<uint32_t>(Bw >> 32));
+    if (t.ovf) fallback |= 1u;
+    const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
+    const uint32_t incl = wave_inclusive_sum_fused(c);
+    const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    if (tot != 0 && want_rows) trio_rows(t, d0, d1, lane, s_row[wave], nrows_w + incl - c, static_cast<uint32_t>(kTRows));
+    if (lane == 0) s_cnt[wave][j] = tot;
+    nrows_w += tot;
+    wave_lds_sync();                                                // (the bitmap scratch is rewritten by the next tile)
+  }
+  if (nrows_w > static_cast<uint32_t>(kTRows)) fallback |= 16u;
+  wave_lds_sync();
+  {
+    bool bad = false, long_hit = false;
+    if (want_rows) {
+      for (uint32_t r = lane0; r < nrows_w && r < static_cast<uint32_t>(kTRows); r += 64) {
+        const uint32_t v = s_row[wave][2u * r];
+        const uint32_t st = v & 0xFFFFu, en = v >> 16;
+        bad = bad || st >= en;
+        long_hit = long_hit || (a.max_len != 0 && en - st > a.max_len);
+      }
+    }
+    if (__ballot(bad) != 0ull) fallback |= 2u;
+    if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+  }
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+  __syncthreads();
+  if (tid < 64) {
+    const int q = tid;
+    const uint32_t v = (q < kWavesPerBlock * tpw) ? s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
+    const uint32_t incl = wave_inclusive_sum(v);
+    if (q < kWavesPerBlock * tpw) s_qbase[q] = incl - v;
+    if (q == kWavesPerBlock * tpw - 1) s_qbase[kWavesPerBlock * tpw] = incl;
+  }
+  __syncthreads();
+  const uint32_t total = s_qbase[kWavesPerBlock * tpw];
+  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
+  if (a.out == nullptr) return;
+  const uint64_t base = s_base;
+  const ChainCaps* cp = reinterpret_cast<const ChainCaps*>(a.caps);
+  const bool caps = cp->on == 1u;
+  const uint32_t npairs = a.row_width >> 1;                          // 16-byte pairs per row
+  const bool pow2 = (npairs & (npairs - 1u)) == 0u;                  // then a lane always writes the same pair of a row
+  const uint32_t psh = 31u - static_cast<uint32_t>(__builtin_clz(npairs | 1u));
+  // what this lane's two slots are made of (lane-invariant for power-of-two widths; else per item below)
+  auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {      // sel: 0 start, 1 end, 2 LA link, 3 LB link, 4 unset
+    const uint32_t src = cp->src[k];
+    sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 4u;
+    if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = op == 0u ? 2u : op == 2u ? 3u : 1u; }
+    off = cp->off[k];
+  };
+  uint32_t lsel0 = 0, lsel1 = 1; int32_t loff0 = 0, loff1 = 0;
+  if (caps && pow2) { const uint32_t pr = static_cast<uint32_t>(lane0) & (npairs - 1u); slot_of(2u * pr, lsel0, loff0); slot_of(2u * pr + 1u, lsel1, loff1); }
+  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw) - kFPre;
+  uint32_t start = 0;
+  for (int j = 0; j < tpw; j++) {
+    const uint32_t n = s_cnt[wave][j];
+    const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
+    const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
+    for (uint32_t i = lane0; i < n * npairs; i += 64) {               // consecutive lanes write consecutive 16 bytes
+      const uint32_t rr = pow2 ? (i >> psh) : i / npairs, pr = i - rr * npairs;
+      const uint32_t r = start + rr;
+      if (r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
+        const uint32_t w0 = s_row[wave][2u * r], w1 = s_row[wave][2u * r + 1u];
+        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16), pla = tb + (w1 & 0xFFFFu), plb = tb + (w1 >> 16);
+        longlong2 o;
+        if (!caps) { o.x = ps; o.y = pe; }
+        else {
+          uint32_t sel0 = lsel0, sel1 = lsel1; int32_t off0 = loff0, off1 = loff1;
+          if (!pow2) { slot_of(2u * pr, sel0, off0); slot_of(2u * pr + 1u, sel1, off1); }
+          const int64_t v0 = sel0 == 0u ? ps : sel0 == 1u ? pe : sel0 == 2u ? pla : plb;
+          const int64_t v1 = sel1 == 0u ? ps : sel1 == 1u ? pe : sel1 == 2u ? pla : plb;
+          o.x = sel0 == 4u ? -1 : v0 + off0; o.y = sel1 == 4u ? -1 : v1 + off1;
+        }
+        *reinterpret_cast<longlong2*>(a.out + (dst + rr) * a.row_width + 2u * pr) = o;
+      }
+    }
+    start += n;
+  }
+}
+
+// Does the chain have the shape k_scan_trio_wave evaluates?  run(0) byte(1) run(0) byte(2) run(0), classes 1 and 2 single
+// bytes, different, outside class 0; no restart check.
+bool trio_shape(const ChainAux& c) {
+  if (c.ncls != 3 || c.nops != 5 || c.restart_check) return false;
+  for (uint32_t k = 0; k < 5; k++) if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return false;
+  if (c.op_cls[0] != 0 || c.op_cls[2] != 0 || c.op_cls[4] != 0 || c.op_cls[1] != 1 || c.op_cls[3] != 2) return false;
+  for (int q = 1; q <= 2; q++) {
+    if (c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return false;
+    if (chain_class_has(c, 0, c.cls_lo[q])) return false;
+  }
+  return c.cls_lo[1] != c.cls_lo[2];
+}
+
+hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(k_scan_trio_wave, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace cxgdev

@@ -118,7 +118,8 @@ typedef struct cxg_timing {  /* filled by the *_device entry points when non-NUL
 enum cxg_kernel {
   CXG_K_NONE = 0, CXG_K_DFA_TABLE = 1, CXG_K_DIGIT_FLAT = 2, CXG_K_CHAIN_WAVE = 6, CXG_K_TEDDY_WAVE = 7,
   CXG_K_CHARCLASS_WAVE = 8, CXG_K_PREFIX_WAVE = 9, CXG_K_FSM = 10, CXG_K_TEDDY_TABLE = 11, CXG_K_CHARCLASS_TABLE = 12,
-  CXG_K_FIELDS_WAVE = 13   /* scan_fields_wave.hip: fields programs such as `\d+\.\d+\.\d+\.\d+` (round 3) */
+  CXG_K_FIELDS_WAVE = 13,  /* scan_fields_wave.hip: fields programs such as `\d+\.\d+\.\d+\.\d+` (round 3) */
+  CXG_K_TRIO_WAVE = 14     /* scan_fields_wave.hip k_scan_trio_wave: run a run b run programs such as `(\w+)@(\w+)\.(\w+)` (round 3) */
 };
 const char* cxg_kernel_name(int kernel);
 
