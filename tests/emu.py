@@ -31,6 +31,10 @@ def lib():
         L.emu_find_all_fields.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
         L.emu_fields_shape.restype = C.c_int
         L.emu_fields_shape.argtypes = [C.c_char_p]
+        L.emu_find_all_trio.restype = C.c_int64
+        L.emu_find_all_trio.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
+        L.emu_trio_shape.restype = C.c_int
+        L.emu_trio_shape.argtypes = [C.c_char_p]
         L.emu_find_all_fsm.restype = C.c_int64
         L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
@@ -191,4 +195,25 @@ def find_all_fields(blob: bytes, hay, own_words: int = 60):
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
             return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
+
+
+def trio_shape(blob: bytes) -> bool:
+    """True when k_scan_trio_wave serves the program: run(F) byte(a) run(F) byte(b) run(F)."""
+    return bool(lib().emu_trio_shape(blob))
+
+
+def find_all_trio(blob: bytes, hay, own_words: int = 60):
+    """Sequential twin of k_scan_trio_wave: rows (start, LA link, LB link, end).  None where a tile would raise the fallback flag."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_trio(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words))
+        if n <= -16:
+            return None
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
+            return out[:n].reshape(-1, 4).copy()
         cap = int(n)

@@ -150,3 +150,137 @@ extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, 
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+// ---- twin of k_scan_trio_wave (scan_fields_wave.hip): run(F) byte(a) run(F) byte(b) run(F) ---------------------------------
+// Same steps as the kernel: bitmaps D / A / B of a 4096-byte window, links of both kinds, owned span by one multiword addition,
+// two hops per candidate, the loop for matches that share a run, and per end the three nearest bytes outside F in (previous
+// word : this word).  Rows of four positions: start, LA link, LB link, end.  Returns -(16 + reason) where the kernel would
+// raise its fallback flag.
+namespace {
+bool trio_shape_host(const ChainAux& c) {      // scan_fields_wave.hip trio_shape
+  if (c.ncls != 3 || c.nops != 5 || c.restart_check) return false;
+  for (uint32_t k = 0; k < 5; k++) if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return false;
+  if (c.op_cls[0] != 0 || c.op_cls[2] != 0 || c.op_cls[4] != 0 || c.op_cls[1] != 1 || c.op_cls[3] != 2) return false;
+  for (int q = 1; q <= 2; q++) {
+    if (c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return false;
+    if (chain_class_has(c, 0, c.cls_lo[q])) return false;
+  }
+  return c.cls_lo[1] != c.cls_lo[2];
+}
+int take_top(uint64_t& l, uint64_t& h) {
+  if (h) { const int k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
+  if (l) { const int k = 63 - __builtin_clzll(l); l &= ~(1ull << k); return k; }
+  return -1;
+}
+}  // namespace
+
+extern "C" int emu_trio_shape(const uint8_t* blob) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || !(h->flags & kFlagChainOrdered) || (h->flags & kFlagChainBounded)) return 0;
+  return trio_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256)) ? 1 : 0;
+}
+
+extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic) return -1;
+  if (!(h->flags & kFlagChainOrdered)) return -4;
+  const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
+  if (!trio_shape_host(ch)) return -5;
+  if (own_words < 1 || own_words > 62) return -2;
+  const int64_t tile_bytes = 64LL * own_words, pre = 64, N = 64LL * 64;
+  const unsigned long long own_mask = ((own_words == 63 ? ~0ull : ((1ull << own_words) - 1ull)) << 1);
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const int64_t tile_lo = static_cast<int64_t>(t) * tile_bytes, wlo = tile_lo - pre;
+    uint64_t D[64] = {0}, A[64] = {0}, B[64] = {0};
+    for (int64_t b = 0; b < N; b++) {
+      const int64_t p = wlo + b;
+      if (p < 0 || p >= static_cast<int64_t>(len)) continue;
+      if (chain_class_has(ch, 0, hay[p])) D[b >> 6] |= 1ull << (b & 63);
+      if (chain_class_has(ch, 1, hay[p])) A[b >> 6] |= 1ull << (b & 63);
+      if (chain_class_has(ch, 2, hay[p])) B[b >> 6] |= 1ull << (b & 63);
+    }
+    unsigned long long PPd = 0, PPx = 0, ovf = 0;
+    uint64_t LA[64], LB[64], L[64], X[64], WS[64];
+    for (int l = 0; l < 64; l++) {
+      const uint64_t prev_top = l ? (D[l - 1] >> 63) : (D[0] >> 63);
+      const uint64_t next_bot = l < 63 ? (D[l + 1] & 1ull) : 1ull;
+      const uint64_t Dl = (D[l] << 1) | prev_top, Dr = (D[l] >> 1) | (next_bot << 63);
+      LA[l] = A[l] & Dl & Dr; LB[l] = B[l] & Dl & Dr; L[l] = LA[l] | LB[l]; X[l] = D[l] | L[l];
+      if (D[l] == ~0ull) PPd |= 1ull << l;
+      if (X[l] == ~0ull) PPx |= 1ull << l;
+    }
+    for (int l = 0; l < 64; l++) {
+      const uint64_t prev_top = l ? (D[l - 1] >> 63) : (D[0] >> 63);
+      const uint64_t prev_ltop = l ? (L[l - 1] >> 63) : (L[0] >> 63);
+      const uint64_t Dl = (D[l] << 1) | prev_top, Ll = (L[l] << 1) | prev_ltop;
+      WS[l] = ((own_mask >> l) & 1ull) ? (D[l] & ~Dl & ~Ll) : 0ull;
+    }
+    auto add_words = [&](const uint64_t* P, const uint64_t* Q, uint64_t* S, unsigned long long PP) {
+      unsigned long long GG = 0;
+      for (int l = 0; l < 64; l++) {
+        const unsigned __int128 s = static_cast<unsigned __int128>(P[l]) + Q[l];
+        S[l] = static_cast<uint64_t>(s);
+        if (s >> 64) GG |= 1ull << l;
+      }
+      const unsigned long long Pe = PP & ~GG;
+      const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;
+      ovf |= GG | (Pe & recv);
+      for (int l = 0; l < 64; l++) S[l] += (recv >> l) & 1ull;
+    };
+    uint64_t S[64], OWN[64];
+    add_words(X, WS, S, PPx);
+    for (int l = 0; l < 64; l++) OWN[l] = X[l] & ~S[l];
+    auto hop = [&](const uint64_t* Q, uint64_t* R) {
+      uint64_t T[64];
+      for (int l = 0; l < 64; l++) T[l] = D[l] | Q[l];
+      add_words(T, Q, R, PPd);
+    };
+    auto hop2 = [&](const uint64_t* Q, uint64_t* E) {
+      uint64_t R[64], M[64];
+      hop(Q, R);
+      for (int l = 0; l < 64; l++) M[l] = R[l] & LB[l];
+      hop(M, R);
+      for (int l = 0; l < 64; l++) E[l] = R[l] & ~D[l];
+    };
+    uint64_t Q0[64], E[64];
+    for (int l = 0; l < 64; l++) Q0[l] = LA[l] & OWN[l];
+    hop2(Q0, E);
+    bool chains = false;
+    for (int l = 0; l < 64; l++) chains = chains || (E[l] & LA[l]);
+    if (chains) {
+      uint64_t R[64], SEL[64] = {0}, K[64], H[64], Q[64];
+      std::memcpy(R, E, sizeof R);
+      for (int guard = 0; guard < 64; guard++) {
+        for (int l = 0; l < 64; l++) Q[l] = R[l] & LA[l];
+        hop2(Q, K);
+        for (int l = 0; l < 64; l++) { H[l] = R[l] & ~K[l]; SEL[l] |= H[l]; Q[l] = H[l] & LA[l]; }
+        hop2(Q, K);
+        bool any = false;
+        for (int l = 0; l < 64; l++) { R[l] &= ~(H[l] | K[l]); any = any || R[l]; }
+        if (!any) break;
+        if (guard == 63) ovf |= 1ull << 63;
+      }
+      std::memcpy(E, SEL, sizeof E);
+    }
+    uint32_t reason = (ovf >> 63) ? 1u : 0u;
+    for (int l = 0; l < 64 && !reason; l++) {
+      const uint64_t z = ~D[l], pz = l ? ~D[l - 1] : 0ull;
+      const int64_t base = 64LL * l - 64;
+      uint64_t ee = E[l];
+      while (ee) {
+        const int b = __builtin_ctzll(ee);
+        ee &= ee - 1ull;
+        uint64_t lo = pz, hi = b ? (z & ((1ull << b) - 1ull)) : 0ull;
+        const int pb = take_top(lo, hi), pa = take_top(lo, hi), ps = take_top(lo, hi);
+        if (ps < 0 || pa < 0 || pb < 0) { reason |= 2u; break; }
+        res.push_back(wlo + base + ps + 1); res.push_back(wlo + base + pa); res.push_back(wlo + base + pb); res.push_back(wlo + base + 64 + b);
+      }
+    }
+    if (reason) return -(16 + static_cast<int64_t>(reason));
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}
