@@ -486,7 +486,13 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
 //      (walk.hpp ChainCaps: start / end / end of the first / second run, plus a constant) or into [start, end).
 // Fallback flag: as for the fields kernel (the host reruns on scan_chain_wave.hip).
 namespace {
-constexpr int kTRows = 64 * kTilesPerWave;                 // rows buffered per wave and group
+#ifndef CXG_TRIO_ROWS
+#define CXG_TRIO_ROWS (64 * kTilesPerWave)
+#endif
+#ifndef CXG_TRIO_WAVES
+#define CXG_TRIO_WAVES 8
+#endif
+constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per wave and group
 
 struct TrioTile { uint32_t e0, e1; bool ovf; };
 
@@ -558,8 +564,10 @@ __device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
   return -1;
 }
 
-// rows of the lane's end bits: {start | end << 16, la | lb << 16} (window bit indices) at rows[2 r], r counting up from r0
-__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, uint32_t r, uint32_t cap) {
+// rows of the lane's end bits: start | end << 16 (window bit indices) at rows[r], and the links as distances from the start,
+// (la - start) | (lb - start) << 8, at links[r] (all three lie within two words: < 128) — 6 bytes per row keep the kernel at 8
+// workgroups per CU with 512 rows per wave; r counts up from r0
+__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, uint16_t* links, uint32_t r, uint32_t cap) {
   const uint64_t z = ~((static_cast<uint64_t>(d1) << 32) | d0);             // bytes outside F, this lane's word
   const uint64_t pz = (static_cast<uint64_t>(dpp_from_lower_z(static_cast<uint32_t>(z >> 32))) << 32) | dpp_from_lower_z(static_cast<uint32_t>(z));   // previous lane's (lane 0: none)
   const int32_t base = (lane << 6) - 64;                                    // window index of bit 0 of (pz : z)
@@ -575,20 +583,21 @@ __device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32
     if (ps < 0 || pa < 0 || pb < 0) { w0 = 0; w1 = 0; }                     // start not found within two words: row void (start >= end), caught below
     else {
       w0 = static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16);
-      w1 = static_cast<uint32_t>(base + pa) | (static_cast<uint32_t>(base + pb) << 16);
+      w1 = static_cast<uint32_t>(pa - ps - 1) | (static_cast<uint32_t>(pb - ps - 1) << 8);
     }
     const uint32_t rr = r < cap ? r : cap - 1u;
-    rows[2u * rr] = w0; rows[2u * rr + 1u] = w1;
+    rows[rr] = w0; links[rr] = static_cast<uint16_t>(w1);
     r++;
   }
 }
 }  // namespace
 
-__global__ __launch_bounds__(kThreads, 6) void k_scan_trio_wave(ScanArgs a) {
+__global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
   __shared__ __attribute__((aligned(16))) uint64_t s_a[kWavesPerBlock][64];
   __shared__ __attribute__((aligned(16))) uint64_t s_b[kWavesPerBlock][64];
-  __shared__ uint32_t s_row[kWavesPerBlock][2 * kTRows];
+  __shared__ uint32_t s_row[kWavesPerBlock][kTRows];
+  __shared__ uint16_t s_lnk[kWavesPerBlock][kTRows];
   __shared__ uint8_t s_cls[256];
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_scan_trio_wave(ScanArgs a) {
     const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
     const uint32_t incl = wave_inclusive_sum_fused(c);
     const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-    if (tot != 0 && want_rows) trio_rows(t, d0, d1, lane, s_row[wave], nrows_w + incl - c, static_cast<uint32_t>(kTRows));
+    if (tot != 0 && want_rows) trio_rows(t, d0, d1, lane, s_row[wave], s_lnk[wave], nrows_w + incl - c, static_cast<uint32_t>(kTRows));
     if (lane == 0) s_cnt[wave][j] = tot;
     nrows_w += tot;
     wave_lds_sync();                                                // (the bitmap scratch is rewritten by the next tile)
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_scan_trio_wave(ScanArgs a) {
     bool bad = false, long_hit = false;
     if (want_rows) {
       for (uint32_t r = lane0; r < nrows_w && r < static_cast<uint32_t>(kTRows); r += 64) {
-        const uint32_t v = s_row[wave][2u * r];
+        const uint32_t v = s_row[wave][r];
         const uint32_t st = v & 0xFFFFu, en = v >> 16;
         bad = bad || st >= en;
         long_hit = long_hit || (a.max_len != 0 && en - st > a.max_len);
@@ -733,8 +742,8 @@ __global__ __launch_bounds__(kThreads, 6) void k_scan_trio_wave(ScanArgs a) {
       const uint32_t rr = pow2 ? (i >> psh) : i / npairs, pr = i - rr * npairs;
       const uint32_t r = start + rr;
       if (r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
-        const uint32_t w0 = s_row[wave][2u * r], w1 = s_row[wave][2u * r + 1u];
-        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16), pla = tb + (w1 & 0xFFFFu), plb = tb + (w1 >> 16);
+        const uint32_t w0 = s_row[wave][r], w1 = s_lnk[wave][r];
+        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16), pla = ps + (w1 & 0xFFu), plb = ps + (w1 >> 8);
         longlong2 o;
         if (!caps) { o.x = ps; o.y = pe; }
         else {

@@ -416,7 +416,7 @@ def test_find_all_n_stops_the_wave_kernels_early(need_gpu, oracle, cfg, pat, sub
         assert got == n and np.array_equal(out[:n].cpu().numpy(), exp[:n]), (pat, n)
         assert scan(buf.ptr, npages * 4096, n=n) == n
     if not os.environ.get("CXG_TICKETS"):             # (with ticket atomics every skipping group still draws its ticket: 73 ns each)
-        assert t_lim.kernel_ms < 0.6 * t_full.kernel_ms, (pat, t_lim.kernel_ms, t_full.kernel_ms)
+        assert t_lim.kernel_ms < 0.8 * t_full.kernel_ms, (pat, t_lim.kernel_ms, t_full.kernel_ms)    # (the groups resident when the n-th row is counted all scan: 2 048 of 8 738)
 
 
 def test_use_both_programs(need_gpu, oracle):
