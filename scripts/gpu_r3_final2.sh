@@ -5,3 +5,5 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 CFGS="5" bash scripts/gpu_r3_evidence.sh 2>&1 | grep -v "^W2026\|amdgpu.ids" | tail -6
 cd $R
 bash scripts/gpu_pmc_configs.sh > gpurun_out/r03_all_configs_pmc_counters.txt 2>&1; grep -A8 "trio_wave" gpurun_out/r03_all_configs_pmc_counters.txt | head -12
+timeout 300 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo bench=$?; python -c "
+import json; d=json.load(open('gpurun_out/r03_bench_default.json')); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['all_cores']['value'])"
