@@ -31,7 +31,7 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 int fields_shape(const ChainAux& c);
-bool trio_shape(const ChainAux& c);
+int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
@@ -540,11 +540,11 @@ relaunch:
     // start, the end or the end of the first / second run plus a constant (ChainCaps)
     static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
     if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) &&
-        cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain))) {
+        cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0) {
       bool ok = !submatch || a.out == nullptr || fusedCaps;
       if (fusedCaps) {
         const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
-        for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] == 0 || cc->run_op[i] == 2 || cc->run_op[i] == 4);
+        for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] & 1u) == 0u && cc->run_op[i] <= 6u;
         for (uint32_t k = 0; k < cc->nslots; k++) ok = ok && (cc->src[k] <= cxgdev::kCapSrcEnd || (cc->src[k] >= cxgdev::kCapSrcRun0 && cc->src[k] < cxgdev::kCapSrcRun0 + cc->nruns));
         ok = ok && (a.row_width & 1u) == 0u && cc->nslots == a.row_width;
       }

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "block_common.hpp"
 #include "scan_dfa.h"
@@ -496,14 +497,19 @@ constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per w
 
 struct TrioTile { uint32_t e0, e1; bool ovf; };
 
-__device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+// K fields, K - 1 links: lk[i] = bitmap of the bytes of the i-th separator class (word of this lane).  For K >= 3 the separator
+// classes are pairwise different (trio_shape): a candidate can then only share the LAST run of an earlier match.
+template <int K>
+__device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const uint32_t (&c0)[K - 1], const uint32_t (&c1)[K - 1]) {
   const uint32_t prev_d1 = dpp_from_lower(d1);
   const uint32_t next_d0 = dpp_from_upper_ones(d0);
   const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
   const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
-  const uint32_t la0 = a0 & Dl0 & Dr0, la1 = a1 & Dl1 & Dr1;
-  const uint32_t lb0 = b0 & Dl0 & Dr0, lb1 = b1 & Dl1 & Dr1;
-  const uint32_t l0 = la0 | lb0, l1 = la1 | lb1;
+  uint32_t lk0[K - 1], lk1[K - 1];
+  uint32_t l0 = 0, l1 = 0;
+#pragma unroll
+  for (int i = 0; i < K - 1; i++) { lk0[i] = c0[i] & Dl0 & Dr0; lk1[i] = c1[i] & Dl1 & Dr1; l0 |= lk0[i]; l1 |= lk1[i]; }
+  const uint32_t la0 = lk0[0], la1 = lk1[0];                       // the first link of a match
   const uint32_t x0 = d0 | l0, x1 = d1 | l1;                       // super-runs
   const uint32_t prev_l1 = dpp_from_lower(l1);
   const uint32_t Ll0 = __builtin_amdgcn_alignbit(l0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(l1, l0, 31);   // L << 1
@@ -529,25 +535,28 @@ __device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, uint32_t
     add64_co(d0 | q0, d1 | q1, q0, q1, r0, r1, G2);
     add64_cin(r0, r1, carry_in(G2, PPd));
   };
-  auto hop2 = [&](uint32_t q0, uint32_t q1, uint32_t& e0, uint32_t& e1) {   // ends of the candidates whose LA link is in q
+  auto hops = [&](uint32_t q0, uint32_t q1, uint32_t& e0, uint32_t& e1) {   // ends of the candidates whose first link is in q
     uint32_t r0, r1;
     hop(q0, q1, r0, r1);
-    const uint32_t m0 = r0 & lb0, m1 = r1 & lb1;                            // ... whose second run ends on an LB link
-    hop(m0, m1, r0, r1);
+#pragma unroll
+    for (int i = 1; i < K - 1; i++) {                                       // ... every further run must end on the link of its place
+      const uint32_t m0 = r0 & lk0[i], m1 = r1 & lk1[i];
+      hop(m0, m1, r0, r1);
+    }
     e0 = r0 & ~d0; e1 = r1 & ~d1;
   };
   uint32_t e0, e1;
-  hop2(la0 & own0, la1 & own1, e0, e1);
-  // ends that sit on an LA link: the candidate that begins with that link (if it is one) shares a run with this match
+  hops(la0 & own0, la1 & own1, e0, e1);
+  // ends that sit on a first link: the candidate that begins with that link (if it is one) shares a run with this match
   uint32_t xa0 = e0 & la0, xa1 = e1 & la1;
   if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(xa1) << 32) | xa0, 0ull, 33 /*ne*/) != 0ull) {
     uint32_t r0 = e0, r1 = e1, sel0 = 0, sel1 = 0;                          // undecided / selected (by their ends)
     for (int guard = 0; guard < 64; guard++) {
       uint32_t k0, k1;
-      hop2(r0 & la0, r1 & la1, k0, k1);                                     // ends of candidates blocked by undecided ones
+      hops(r0 & la0, r1 & la1, k0, k1);                                     // ends of candidates blocked by undecided ones
       const uint32_t h0 = r0 & ~k0, h1 = r1 & ~k1;                          // heads: undecided, not blocked by an undecided one
       sel0 |= h0; sel1 |= h1;
-      hop2(h0 & la0, h1 & la1, k0, k1);                                     // what the heads block
+      hops(h0 & la0, h1 & la1, k0, k1);                                     // what the heads block
       r0 &= ~(h0 | k0); r1 &= ~(h1 | k1);
       if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(r1) << 32) | r0, 0ull, 33 /*ne*/) == 0ull) break;
       if (guard == 63) ovf |= 1ull << 63;
@@ -567,7 +576,8 @@ __device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
 // rows of the lane's end bits: start | end << 16 (window bit indices) at rows[r], and the links as distances from the start,
 // (la - start) | (lb - start) << 8, at links[r] (all three lie within two words: < 128) — 6 bytes per row keep the kernel at 8
 // workgroups per CU with 512 rows per wave; r counts up from r0
-__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, uint16_t* links, uint32_t r, uint32_t cap) {
+template <int K, typename LinkT>
+__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, LinkT* links, uint32_t r, uint32_t cap) {
   const uint64_t z = ~((static_cast<uint64_t>(d1) << 32) | d0);             // bytes outside F, this lane's word
   const uint64_t pz = (static_cast<uint64_t>(dpp_from_lower_z(static_cast<uint32_t>(z >> 32))) << 32) | dpp_from_lower_z(static_cast<uint32_t>(z));   // previous lane's (lane 0: none)
   const int32_t base = (lane << 6) - 64;                                    // window index of bit 0 of (pz : z)
@@ -576,28 +586,30 @@ __device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32
     const int32_t b = __builtin_ctzll(ee);
     ee &= ee - 1ull;
     uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;             // bytes outside F below the end, nearest first:
-    const int32_t pb = take_top(l, h);                                      // the LB link
-    const int32_t pa = take_top(l, h);                                      // the LA link
+    int32_t pl[K - 1];                                                      // the links, last first
+#pragma unroll
+    for (int i = K - 2; i >= 0; i--) pl[i] = take_top(l, h);
     const int32_t ps = take_top(l, h);                                      // the byte in front of the match
-    uint32_t w0, w1;
-    if (ps < 0 || pa < 0 || pb < 0) { w0 = 0; w1 = 0; }                     // start not found within two words: row void (start >= end), caught below
-    else {
+    uint32_t w0 = 0, w1 = 0;                                                // start not found within two words: row void (start >= end), caught below
+    if (ps >= 0) {
       w0 = static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16);
-      w1 = static_cast<uint32_t>(pa - ps - 1) | (static_cast<uint32_t>(pb - ps - 1) << 8);
+#pragma unroll
+      for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(pl[i] - ps - 1) << (8 * i);
     }
     const uint32_t rr = r < cap ? r : cap - 1u;
-    rows[rr] = w0; links[rr] = static_cast<uint16_t>(w1);
+    rows[rr] = w0; links[rr] = static_cast<LinkT>(w1);
     r++;
   }
 }
 }  // namespace
 
-__global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(ScanArgs a) {
+template <int K>
+__global__ __launch_bounds__(kThreads, (K == 4 ? 7 : CXG_TRIO_WAVES)) void k_scan_trio_wave(ScanArgs a) {
+  typedef typename std::conditional<K == 4, uint32_t, uint16_t>::type LinkT;   // K - 1 byte distances per row
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
-  __shared__ __attribute__((aligned(16))) uint64_t s_a[kWavesPerBlock][64];
-  __shared__ __attribute__((aligned(16))) uint64_t s_b[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_c[K - 1][kWavesPerBlock][64];   // separator classes
   __shared__ uint32_t s_row[kWavesPerBlock][kTRows];
-  __shared__ uint16_t s_lnk[kWavesPerBlock][kTRows];
+  __shared__ LinkT s_lnk[kWavesPerBlock][kTRows];
   __shared__ uint8_t s_cls[256];
   __shared__ uint32_t s_cnt[kWavesPerBlock][kTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kTilesPerWave + 1];
@@ -619,7 +631,9 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
   {
     const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
     const uint32_t b = static_cast<uint32_t>(tid);
-    s_cls[tid] = static_cast<uint8_t>((chain_class_has(*gch, 0, b) ? 1u : 0u) | (chain_class_has(*gch, 1, b) ? 2u : 0u) | (chain_class_has(*gch, 2, b) ? 4u : 0u));
+    uint32_t f = chain_class_has(*gch, 0, b) ? 1u : 0u;             // bit 0: F; bit i + 1: the separator of link i
+    for (int i = 0; i < K - 1; i++) f |= chain_class_has(*gch, gch->op_cls[2 * i + 1], b) ? (2u << i) : 0u;
+    s_cls[tid] = static_cast<uint8_t>(f);
   }
   __syncthreads();
   constexpr int tpw = kTilesPerWave;
@@ -638,13 +652,13 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
     // ---- A: one table lookup per byte; 16 flags per class and vector through the LDS scratch
     {
       uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
-      uint16_t* pa = reinterpret_cast<uint16_t*>(s_a[wave]);
-      uint16_t* pb = reinterpret_cast<uint16_t*>(s_b[wave]);
       const uint32_t voff = static_cast<uint32_t>(lane) << 4;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const uint32_t w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
-        uint32_t fd = 0, fa = 0, fb = 0;
+        uint32_t fd = 0, fc[K - 1];
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) fc[i] = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const uint32_t f = static_cast<uint32_t>(s_cls[w[q] & 0xFFu]) | (static_cast<uint32_t>(s_cls[(w[q] >> 8) & 0xFFu]) << 8) |
@@ -653,17 +667,17 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
           // (flag bytes are 0/1 after the mask: the weighted sum is the four flags as bits q*4 .. q*4+3)
           if (q < 2) {
             fd = __builtin_amdgcn_udot4(f & 0x01010101u, wt, fd, false);
-            fa = __builtin_amdgcn_udot4((f >> 1) & 0x01010101u, wt, fa, false);
-            fb = __builtin_amdgcn_udot4((f >> 2) & 0x01010101u, wt, fb, false);
+#pragma unroll
+            for (int i = 0; i < K - 1; i++) fc[i] = __builtin_amdgcn_udot4((f >> (i + 1)) & 0x01010101u, wt, fc[i], false);
           } else {
             fd += __builtin_amdgcn_udot4(f & 0x01010101u, wt, 0u, false) << 8;
-            fa += __builtin_amdgcn_udot4((f >> 1) & 0x01010101u, wt, 0u, false) << 8;
-            fb += __builtin_amdgcn_udot4((f >> 2) & 0x01010101u, wt, 0u, false) << 8;
+#pragma unroll
+            for (int i = 0; i < K - 1; i++) fc[i] += __builtin_amdgcn_udot4((f >> (i + 1)) & 0x01010101u, wt, 0u, false) << 8;
           }
         }
         pd[lane + 64 * k] = static_cast<uint16_t>(fd);
-        pa[lane + 64 * k] = static_cast<uint16_t>(fa);
-        pb[lane + 64 * k] = static_cast<uint16_t>(fb);
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) reinterpret_cast<uint16_t*>(s_c[i][wave])[lane + 64 * k] = static_cast<uint16_t>(fc[i]);
         x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -671,20 +685,27 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
     wave_lds_sync();
     int lw = lane;
     asm volatile("" : "+v"(lw));
-    uint64_t Dw = s_d[wave][lw], Aw = s_a[wave][lw], Bw = s_b[wave][lw];
+    uint64_t Dw = s_d[wave][lw], Cw[K - 1];
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) Cw[i] = s_c[i][wave][lw];
     if (nvalid_cur != kFWin) {
       const int32_t nf = nvalid_cur - 64 * lane;
       const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
-      Dw &= vf; Aw &= vf; Bw &= vf;
+      Dw &= vf;
+#pragma unroll
+      for (int i = 0; i < K - 1; i++) Cw[i] &= vf;
     }
     nvalid_cur = nvalid_next;
     const uint32_t d0 = static_cast<uint32_t>(Dw), d1 = static_cast<uint32_t>(Dw >> 32);
-    const TrioTile t = trio_core(d0, d1, static_cast<uint32_t>(Aw), static_cast<uint32_t>(Aw >> 32), static_cast<uint32_t>(Bw), static_cast<uint32_t>(Bw >> 32));
+    uint32_t c0[K - 1], c1[K - 1];
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) { c0[i] = static_cast<uint32_t>(Cw[i]); c1[i] = static_cast<uint32_t>(Cw[i] >> 32); }
+    const TrioTile t = trio_core<K>(d0, d1, c0, c1);
     if (t.ovf) fallback |= 1u;
     const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
     const uint32_t incl = wave_inclusive_sum_fused(c);
     const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-    if (tot != 0 && want_rows) trio_rows(t, d0, d1, lane, s_row[wave], s_lnk[wave], nrows_w + incl - c, static_cast<uint32_t>(kTRows));
+    if (tot != 0 && want_rows) trio_rows<K, LinkT>(t, d0, d1, lane, s_row[wave], s_lnk[wave], nrows_w + incl - c, static_cast<uint32_t>(kTRows));
     if (lane == 0) s_cnt[wave][j] = tot;
     nrows_w += tot;
     wave_lds_sync();                                                // (the bitmap scratch is rewritten by the next tile)
@@ -724,10 +745,10 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
   const bool pow2 = (npairs & (npairs - 1u)) == 0u;                  // then a lane always writes the same pair of a row
   const uint32_t psh = 31u - static_cast<uint32_t>(__builtin_clz(npairs | 1u));
   // what this lane's two slots are made of (lane-invariant for power-of-two widths; else per item below)
-  auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {      // sel: 0 start, 1 end, 2 LA link, 3 LB link, 4 unset
+  auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {      // sel: 0 start, 1 end, 2 + i link i (the end of run i), 7 unset
     const uint32_t src = cp->src[k];
-    sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 4u;
-    if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = op == 0u ? 2u : op == 2u ? 3u : 1u; }
+    sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 7u;
+    if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = (op >> 1) < static_cast<uint32_t>(K - 1) ? 2u + (op >> 1) : 1u; }
     off = cp->off[k];
   };
   uint32_t lsel0 = 0, lsel1 = 1; int32_t loff0 = 0, loff1 = 0;
@@ -743,15 +764,14 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
       const uint32_t r = start + rr;
       if (r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
         const uint32_t w0 = s_row[wave][r], w1 = s_lnk[wave][r];
-        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16), pla = ps + (w1 & 0xFFu), plb = ps + (w1 >> 8);
+        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16);
+        auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
         longlong2 o;
         if (!caps) { o.x = ps; o.y = pe; }
         else {
           uint32_t sel0 = lsel0, sel1 = lsel1; int32_t off0 = loff0, off1 = loff1;
           if (!pow2) { slot_of(2u * pr, sel0, off0); slot_of(2u * pr + 1u, sel1, off1); }
-          const int64_t v0 = sel0 == 0u ? ps : sel0 == 1u ? pe : sel0 == 2u ? pla : plb;
-          const int64_t v1 = sel1 == 0u ? ps : sel1 == 1u ? pe : sel1 == 2u ? pla : plb;
-          o.x = sel0 == 4u ? -1 : v0 + off0; o.y = sel1 == 4u ? -1 : v1 + off1;
+          o.x = sel0 == 7u ? -1 : pos_of(sel0) + off0; o.y = sel1 == 7u ? -1 : pos_of(sel1) + off1;
         }
         *reinterpret_cast<longlong2*>(a.out + (dst + rr) * a.row_width + 2u * pr) = o;
       }
@@ -760,21 +780,33 @@ __global__ __launch_bounds__(kThreads, CXG_TRIO_WAVES) void k_scan_trio_wave(Sca
   }
 }
 
-// Does the chain have the shape k_scan_trio_wave evaluates?  run(0) byte(1) run(0) byte(2) run(0), classes 1 and 2 single
-// bytes, different, outside class 0; no restart check.
-bool trio_shape(const ChainAux& c) {
-  if (c.ncls != 3 || c.nops != 5 || c.restart_check) return false;
-  for (uint32_t k = 0; k < 5; k++) if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return false;
-  if (c.op_cls[0] != 0 || c.op_cls[2] != 0 || c.op_cls[4] != 0 || c.op_cls[1] != 1 || c.op_cls[3] != 2) return false;
-  for (int q = 1; q <= 2; q++) {
-    if (c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return false;
-    if (chain_class_has(c, 0, c.cls_lo[q])) return false;
+// Does the chain have the shape k_scan_trio_wave evaluates?  run(0) (byte(c_i) run(0)){K-1}, K = 2..4, every c_i a single byte
+// outside class 0; for K >= 3 the separators pairwise different (else two candidates could share more than one run, which the
+// overlap resolution does not look for; equal separators without captures are the fields kernel's).  Returns K, else 0.
+int trio_shape(const ChainAux& c) {
+  if ((c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7 || c.restart_check) return 0;
+  const int K = static_cast<int>((c.nops + 1) / 2);
+  uint8_t sep[3] = {0, 0, 0};
+  for (uint32_t k = 0; k < c.nops; k++) {
+    if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return 0;
+    if (!(k & 1u)) { if (c.op_cls[k] != 0) return 0; continue; }
+    const uint32_t q = c.op_cls[k];
+    if (q == 0 || q >= c.ncls || c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return 0;
+    if (chain_class_has(c, 0, c.cls_lo[q])) return 0;
+    sep[k >> 1] = c.cls_lo[q];
   }
-  return c.cls_lo[1] != c.cls_lo[2];
+  if (K >= 3) for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) if (sep[i] == sep[j]) return 0;
+  return K;
 }
 
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(k_scan_trio_wave, dim3(static_cast<unsigned>(a.ngroups)), dim3(kThreads), 0, stream, a);
+  const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  switch (trio_shape(*reinterpret_cast<const ChainAux*>(a.chain))) {
+    case 2: hipLaunchKernelGGL(k_scan_trio_wave<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(k_scan_trio_wave<3>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(k_scan_trio_wave<4>, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

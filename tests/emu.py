@@ -198,13 +198,13 @@ def find_all_fields(blob: bytes, hay, own_words: int = 60):
         cap = int(n)
 
 
-def trio_shape(blob: bytes) -> bool:
-    """True when k_scan_trio_wave serves the program: run(F) byte(a) run(F) byte(b) run(F)."""
-    return bool(lib().emu_trio_shape(blob))
+def trio_shape(blob: bytes) -> int:
+    """Number of fields K (2..4) when k_scan_trio_wave serves the program — run(F) (byte(c_i) run(F)){K-1} — else 0."""
+    return int(lib().emu_trio_shape(blob))
 
 
 def find_all_trio(blob: bytes, hay, own_words: int = 60):
-    """Sequential twin of k_scan_trio_wave: rows (start, LA link, LB link, end).  None where a tile would raise the fallback flag."""
+    """Sequential twin of k_scan_trio_wave: rows (start, link 1 .. link K-1, end).  None where a tile would raise the fallback flag."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
     cap = 1 << 12
@@ -215,5 +215,5 @@ def find_all_trio(blob: bytes, hay, own_words: int = 60):
             return None
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
-            return out[:n].reshape(-1, 4).copy()
+            return out[:n].reshape(-1, trio_shape(blob) + 1).copy()
         cap = int(n)

@@ -151,21 +151,26 @@ extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, 
   return n;
 }
 
-// ---- twin of k_scan_trio_wave (scan_fields_wave.hip): run(F) byte(a) run(F) byte(b) run(F) ---------------------------------
-// Same steps as the kernel: bitmaps D / A / B of a 4096-byte window, links of both kinds, owned span by one multiword addition,
-// two hops per candidate, the loop for matches that share a run, and per end the three nearest bytes outside F in (previous
-// word : this word).  Rows of four positions: start, LA link, LB link, end.  Returns -(16 + reason) where the kernel would
+// ---- twin of k_scan_trio_wave<K> (scan_fields_wave.hip): run(F) (byte(c_i) run(F)){K-1}, K = 2..4 ------------------------------
+// Same steps as the kernel: bitmaps D and one per separator class of a 4096-byte window, links, owned span by one multiword
+// addition, K - 1 hops per candidate, the loop for matches that share a run, and per end the K nearest bytes outside F in
+// (previous word : this word).  Rows of K + 1 positions: start, the links, end.  Returns -(16 + reason) where the kernel would
 // raise its fallback flag.
 namespace {
-bool trio_shape_host(const ChainAux& c) {      // scan_fields_wave.hip trio_shape
-  if (c.ncls != 3 || c.nops != 5 || c.restart_check) return false;
-  for (uint32_t k = 0; k < 5; k++) if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return false;
-  if (c.op_cls[0] != 0 || c.op_cls[2] != 0 || c.op_cls[4] != 0 || c.op_cls[1] != 1 || c.op_cls[3] != 2) return false;
-  for (int q = 1; q <= 2; q++) {
-    if (c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return false;
-    if (chain_class_has(c, 0, c.cls_lo[q])) return false;
+int trio_shape_host(const ChainAux& c) {      // scan_fields_wave.hip trio_shape
+  if ((c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7 || c.restart_check) return 0;
+  const int K = static_cast<int>((c.nops + 1) / 2);
+  uint8_t sep[3] = {0, 0, 0};
+  for (uint32_t k = 0; k < c.nops; k++) {
+    if (c.op_kind[k] != ((k & 1u) ? kChainByte : kChainRun)) return 0;
+    if (!(k & 1u)) { if (c.op_cls[k] != 0) return 0; continue; }
+    const uint32_t q = c.op_cls[k];
+    if (q == 0 || q >= c.ncls || c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q]) return 0;
+    if (chain_class_has(c, 0, c.cls_lo[q])) return 0;
+    sep[k >> 1] = c.cls_lo[q];
   }
-  return c.cls_lo[1] != c.cls_lo[2];
+  if (K >= 3) for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) if (sep[i] == sep[j]) return 0;
+  return K;
 }
 int take_top(uint64_t& l, uint64_t& h) {
   if (h) { const int k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
@@ -177,7 +182,7 @@ int take_top(uint64_t& l, uint64_t& h) {
 extern "C" int emu_trio_shape(const uint8_t* blob) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic || !(h->flags & kFlagChainOrdered) || (h->flags & kFlagChainBounded)) return 0;
-  return trio_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256)) ? 1 : 0;
+  return trio_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));
 }
 
 extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
@@ -185,7 +190,8 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
   if (h->magic != kBlobMagic) return -1;
   if (!(h->flags & kFlagChainOrdered)) return -4;
   const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
-  if (!trio_shape_host(ch)) return -5;
+  const int K = trio_shape_host(ch);
+  if (!K) return -5;
   if (own_words < 1 || own_words > 62) return -2;
   const int64_t tile_bytes = 64LL * own_words, pre = 64, N = 64LL * 64;
   const unsigned long long own_mask = ((own_words == 63 ? ~0ull : ((1ull << own_words) - 1ull)) << 1);
@@ -193,21 +199,22 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
   const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
   for (uint64_t t = 0; t < ntiles; t++) {
     const int64_t tile_lo = static_cast<int64_t>(t) * tile_bytes, wlo = tile_lo - pre;
-    uint64_t D[64] = {0}, A[64] = {0}, B[64] = {0};
+    uint64_t D[64] = {0}, C[3][64] = {{0}};
     for (int64_t b = 0; b < N; b++) {
       const int64_t p = wlo + b;
       if (p < 0 || p >= static_cast<int64_t>(len)) continue;
       if (chain_class_has(ch, 0, hay[p])) D[b >> 6] |= 1ull << (b & 63);
-      if (chain_class_has(ch, 1, hay[p])) A[b >> 6] |= 1ull << (b & 63);
-      if (chain_class_has(ch, 2, hay[p])) B[b >> 6] |= 1ull << (b & 63);
+      for (int i = 0; i < K - 1; i++) if (chain_class_has(ch, ch.op_cls[2 * i + 1], hay[p])) C[i][b >> 6] |= 1ull << (b & 63);
     }
     unsigned long long PPd = 0, PPx = 0, ovf = 0;
-    uint64_t LA[64], LB[64], L[64], X[64], WS[64];
+    uint64_t LK[3][64], L[64], X[64], WS[64];
     for (int l = 0; l < 64; l++) {
       const uint64_t prev_top = l ? (D[l - 1] >> 63) : (D[0] >> 63);
       const uint64_t next_bot = l < 63 ? (D[l + 1] & 1ull) : 1ull;
       const uint64_t Dl = (D[l] << 1) | prev_top, Dr = (D[l] >> 1) | (next_bot << 63);
-      LA[l] = A[l] & Dl & Dr; LB[l] = B[l] & Dl & Dr; L[l] = LA[l] | LB[l]; X[l] = D[l] | L[l];
+      L[l] = 0;
+      for (int i = 0; i < K - 1; i++) { LK[i][l] = C[i][l] & Dl & Dr; L[l] |= LK[i][l]; }
+      X[l] = D[l] | L[l];
       if (D[l] == ~0ull) PPd |= 1ull << l;
       if (X[l] == ~0ull) PPx |= 1ull << l;
     }
@@ -237,28 +244,31 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
       for (int l = 0; l < 64; l++) T[l] = D[l] | Q[l];
       add_words(T, Q, R, PPd);
     };
-    auto hop2 = [&](const uint64_t* Q, uint64_t* E) {
+    auto hops = [&](const uint64_t* Q, uint64_t* E) {
       uint64_t R[64], M[64];
       hop(Q, R);
-      for (int l = 0; l < 64; l++) M[l] = R[l] & LB[l];
-      hop(M, R);
+      for (int i = 1; i < K - 1; i++) {
+        for (int l = 0; l < 64; l++) M[l] = R[l] & LK[i][l];
+        hop(M, R);
+      }
       for (int l = 0; l < 64; l++) E[l] = R[l] & ~D[l];
     };
+    const uint64_t* LA = LK[0];
     uint64_t Q0[64], E[64];
     for (int l = 0; l < 64; l++) Q0[l] = LA[l] & OWN[l];
-    hop2(Q0, E);
+    hops(Q0, E);
     bool chains = false;
     for (int l = 0; l < 64; l++) chains = chains || (E[l] & LA[l]);
     if (chains) {
-      uint64_t R[64], SEL[64] = {0}, K[64], H[64], Q[64];
+      uint64_t R[64], SEL[64] = {0}, Kb[64], H[64], Q[64];
       std::memcpy(R, E, sizeof R);
       for (int guard = 0; guard < 64; guard++) {
         for (int l = 0; l < 64; l++) Q[l] = R[l] & LA[l];
-        hop2(Q, K);
-        for (int l = 0; l < 64; l++) { H[l] = R[l] & ~K[l]; SEL[l] |= H[l]; Q[l] = H[l] & LA[l]; }
-        hop2(Q, K);
+        hops(Q, Kb);
+        for (int l = 0; l < 64; l++) { H[l] = R[l] & ~Kb[l]; SEL[l] |= H[l]; Q[l] = H[l] & LA[l]; }
+        hops(Q, Kb);
         bool any = false;
-        for (int l = 0; l < 64; l++) { R[l] &= ~(H[l] | K[l]); any = any || R[l]; }
+        for (int l = 0; l < 64; l++) { R[l] &= ~(H[l] | Kb[l]); any = any || R[l]; }
         if (!any) break;
         if (guard == 63) ovf |= 1ull << 63;
       }
@@ -273,9 +283,13 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
         const int b = __builtin_ctzll(ee);
         ee &= ee - 1ull;
         uint64_t lo = pz, hi = b ? (z & ((1ull << b) - 1ull)) : 0ull;
-        const int pb = take_top(lo, hi), pa = take_top(lo, hi), ps = take_top(lo, hi);
-        if (ps < 0 || pa < 0 || pb < 0) { reason |= 2u; break; }
-        res.push_back(wlo + base + ps + 1); res.push_back(wlo + base + pa); res.push_back(wlo + base + pb); res.push_back(wlo + base + 64 + b);
+        int pl[3] = {0, 0, 0};
+        for (int i = K - 2; i >= 0; i--) pl[i] = take_top(lo, hi);
+        const int ps = take_top(lo, hi);
+        if (ps < 0) { reason |= 2u; break; }
+        res.push_back(wlo + base + ps + 1);
+        for (int i = 0; i < K - 1; i++) res.push_back(wlo + base + pl[i]);
+        res.push_back(wlo + base + 64 + b);
       }
     }
     if (reason) return -(16 + static_cast<int64_t>(reason));

@@ -73,7 +73,8 @@ def test_every_border(oracle):
         _check(oracle, EMAIL, text[:n])
 
 
-@pytest.mark.parametrize("pat,alpha", [(EMAIL, "ab_9@@..  x\n"), (r"\d+-\d+:\d+", "0123--:: \n"), (r"([a-c]+)x([a-c]+)y([a-c]+)", "abcxy z"), (r"(\w+)=(\w+);(\w+)", "ab_1==;; \n"), (r"(\d+)/(\d+) (\d+)", "0189// x")])
+@pytest.mark.parametrize("pat,alpha", [(EMAIL, "ab_9@@..  x\n"), (r"\d+-\d+:\d+", "0123--:: \n"), (r"([a-c]+)x([a-c]+)y([a-c]+)", "abcxy z"), (r"(\w+)=(\w+);(\w+)", "ab_1==;; \n"), (r"(\d+)/(\d+) (\d+)", "0189// x"),
+                                       (r"(\w+)=(\w+)", "ab_1== \n"), (r"(\d+):(\d+)", "xyz   \n,;w01:"), (r"(\d+)-(\d+):(\d+)/(\d+)", "019--::// x"), (r"(\w+)@(\w+)", "ab_9@@ x")])
 def test_random_text(oracle, pat, alpha):
     rng = random.Random(len(pat) * 7)
     served = 0
@@ -83,7 +84,7 @@ def test_random_text(oracle, pat, alpha):
         w = ([3, 3, 1] + [1] * len(alpha) if kind == 0 else [1] * len(alpha) if kind == 1 else [1] * (len(alpha) - 3) + [6, 6, 6])[: len(alpha)]
         hay = "".join(rng.choices(alpha, weights=w, k=n)).encode()
         t = _check(oracle, pat, hay, want_kernel=None)
-        served += t.kernel == K_TRIO and t.n_launches == 1
+        served += t.kernel in (K_TRIO, 13) and t.n_launches == 1      # (13: spans of a two-field program with one separator class are the fields kernel's)
     assert served >= 4, served
 
 
