@@ -35,6 +35,8 @@ def lib():
         L.emu_find_all_trio.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
         L.emu_trio_shape.restype = C.c_int
         L.emu_trio_shape.argtypes = [C.c_char_p]
+        L.emu_fsm_maps_check.restype = C.c_int64
+        L.emu_fsm_maps_check.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
         L.emu_find_all_fsm.restype = C.c_int64
         L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
@@ -217,3 +219,12 @@ def find_all_trio(blob: bytes, hay, own_words: int = 60):
         if n <= cap:
             return out[:n].reshape(-1, trio_shape(blob) + 1).copy()
         cap = int(n)
+
+
+def fsm_maps_check(image: bytes, hay, tile: int = 3840, tiles_per_group: int = 32) -> int:
+    """Round 3 (scan_fsm.hip "Maps instead of waits"): the kernel's compositions of sub-chunk / tile / group maps against a plain
+    left-to-right walk.  Returns the number of sub-chunk entries checked (>= 0), -17 where the kernel would raise its fallback flag
+    (a set that is not listed), -100 - k on a mismatch of kind k."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
+    return int(lib().emu_fsm_maps_check(image, padded.ctypes.data + 8, a.size, int(tile), int(tiles_per_group)))

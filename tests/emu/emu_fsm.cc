@@ -149,3 +149,152 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
   return h->nk > 1 ? emu_fsm<true>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
                    : emu_fsm<false>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
 }
+
+// ---- round 3: the kernel's way of finding entry states without waiting (scan_fsm.hip "Maps instead of waits") -------------------
+// For every tile: each 32-byte sub-chunk is a MAP (entry state -> end state): a constant when its warm-up set collapsed, else the
+// end state for each listed member.  A lane folds its two sub-chunks, six Hillis-Steele levels compose the lanes (a constant
+// absorbs what lies in front), the last lane's map is the tile's; a group composes its tiles' maps, and a group's entry comes
+// from the maps of the groups in front, nearest first, until one with a known exit.  This twin performs exactly those
+// compositions (same pair lists, same order, same canonical states) and compares every sub-chunk entry, tile exit and group
+// entry it derives with the state a plain left-to-right walk is in at that point.  Returns the number of sub-chunks checked;
+// -16 - 1: a set that is not listed (the kernel's fallback); -100 - k: a mismatch of kind k.
+namespace {
+struct EMap {                      // the kernel's (isc, cv, P[8])
+  bool isc = false;
+  uint32_t cv = 0;
+  uint32_t P[kFsmMembers];         // member | end << 16; 0xFFFFFFFF: unused
+  EMap() { for (auto& p : P) p = 0xFFFFFFFFu; }
+};
+uint32_t emap_look(const EMap& m, uint32_t x) {
+  uint32_t r = 0xFFFFu;
+  for (int j = 0; j < kFsmMembers; j++) if ((m.P[j] & 0xFFFFu) == x) r = m.P[j] >> 16;
+  return r;
+}
+uint32_t emap_apply(const EMap& m, uint32_t x) { return m.isc ? m.cv : emap_look(m, x); }
+EMap emap_then(const EMap& first, const EMap& second) {     // second o first (first lies in front)
+  if (second.isc) return second;
+  EMap r;
+  if (first.isc) { r.isc = true; r.cv = emap_look(second, first.cv); return r; }
+  for (int j = 0; j < kFsmMembers; j++) r.P[j] = first.P[j] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((first.P[j] & 0xFFFFu) | (emap_look(second, first.P[j] >> 16) << 16));
+  return r;
+}
+}  // namespace
+
+template <bool LOOK>
+static int64_t emu_fsm_maps(const uint8_t* img, const uint8_t* hay, uint64_t len, int tile, int tiles_per_group) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  const FsmView v = view_of(img);
+  const int sub = kFsmSub, lanes = tile / (2 * sub);
+  const uint64_t ntiles = (len + static_cast<uint64_t>(tile) - 1) / static_cast<uint64_t>(tile);
+  // ground truth: the canonical state in front of every sub-chunk, and behind the last one
+  HostMem<LOOK> g;
+  g.hay = hay; g.origin_abs = 0; g.len = static_cast<int64_t>(len); g.outside = LOOK ? h->outside_byte : 0u;
+  std::vector<uint32_t> truth;
+  {
+    uint32_t x = g.origin(v);
+    for (uint64_t p = 0; p < len; p += static_cast<uint64_t>(sub)) {
+      truth.push_back(fsm_canon(v, x));
+      const uint64_t to = p + sub < len ? p + sub : len;
+      x = fsm_walk(v, g, x, static_cast<int32_t>(p), static_cast<int32_t>(to), false);
+    }
+    truth.push_back(fsm_canon(v, x));
+  }
+  int64_t checked = 0;
+  std::vector<EMap> tileMap(ntiles);
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile);
+    const int32_t rend = static_cast<int32_t>(len - tile_lo < 0x7FFF0000ull ? len - tile_lo : 0x7FFF0000ull);
+    HostMem<LOOK> m;
+    m.hay = hay; m.origin_abs = static_cast<int64_t>(tile_lo); m.len = static_cast<int64_t>(len); m.outside = LOOK ? h->outside_byte : 0u;
+    std::vector<EMap> sc(2 * lanes), lane_map(lanes), S(lanes);
+    std::vector<bool> have(2 * lanes, false), unres(2 * lanes, false);
+    for (int k = 0; k < 2 * lanes; k++) {
+      const int32_t c0 = k * sub;
+      if (c0 >= rend) break;
+      have[k] = true;
+      const int32_t to = c0 + sub < rend ? c0 + sub : rend;
+      uint32_t entry = m.origin(v);
+      if (tile_lo + static_cast<uint64_t>(c0) > 0) {
+        const int64_t avail = static_cast<int64_t>(tile_lo) + c0;
+        const int32_t w1 = static_cast<int32_t>(avail < 16 ? avail : 16), w2 = static_cast<int32_t>(avail < 64 ? avail : 64);
+        entry = fsm_walk(v, m, v.top_off, c0 - w1, c0, (w1 % 4) == 0);
+        if (entry >= v.u_lo && w2 > w1) entry = fsm_walk(v, m, v.top_off, c0 - w2, c0, (w2 % 4) == 0);
+      }
+      EMap e;
+      if (entry >= v.u_lo) {
+        unres[k] = true;
+        if (fsm_member(v, entry, 0) == 0xFFFFu) return -16 - 1;
+        for (int j = 0; j < kFsmMembers; j++) {
+          const uint32_t mj = fsm_member(v, entry, static_cast<uint32_t>(j));
+          if (mj != 0xFFFFu) e.P[j] = mj | (fsm_canon(v, fsm_walk(v, m, mj, c0, to, true)) << 16);
+        }
+      } else {
+        if (fsm_canon(v, entry) != truth[(tile_lo + c0) / sub]) return -100 - 1;        // a collapsed set holds the true state
+        e.isc = true; e.cv = fsm_canon(v, fsm_walk(v, m, entry, c0, to, true));
+      }
+      sc[k] = e;
+    }
+    int last = -1;
+    for (int l = 0; l < lanes; l++) {
+      if (!have[2 * l]) break;
+      last = l;
+      lane_map[l] = have[2 * l + 1] ? emap_then(sc[2 * l], sc[2 * l + 1]) : sc[2 * l];
+    }
+    if (last < 0) break;
+    // inclusive scan, the kernel's level order
+    S = lane_map;
+    for (int d = 1; d < 64; d <<= 1) {
+      std::vector<EMap> N = S;
+      for (int l = 0; l <= last; l++) if (l - d >= 0) N[l] = emap_then(S[l - d], S[l]);
+      S = N;
+    }
+    const uint32_t tile_entry = truth[tile_lo / sub];
+    for (int l = 0; l <= last; l++) {
+      const uint32_t before = l == 0 ? tile_entry : emap_apply(S[l - 1], tile_entry);
+      if (before != truth[(tile_lo + 2ull * l * sub) / sub]) return -100 - 2;            // a lane's true entry
+      if (have[2 * l + 1]) {
+        const uint32_t mid = emap_apply(sc[2 * l], before);
+        if (mid != truth[(tile_lo + (2ull * l + 1) * sub) / sub]) return -100 - 3;
+        checked++;
+      }
+      checked++;
+    }
+    const uint64_t end_idx = (tile_lo + static_cast<uint64_t>(tile) < len ? tile_lo + tile : len + sub - 1) / sub;
+    if (emap_apply(S[last], tile_entry) != truth[end_idx < truth.size() ? end_idx : truth.size() - 1]) return -100 - 4;   // the tile's exit
+    tileMap[t] = S[last];
+  }
+  // groups: compose the tiles of a group; a group's entry from the groups in front, nearest first, until a known exit
+  const uint64_t ngroups = (ntiles + tiles_per_group - 1) / tiles_per_group;
+  std::vector<EMap> groupMap(ngroups);
+  for (uint64_t gq = 0; gq < ngroups; gq++) {
+    EMap c = tileMap[gq * tiles_per_group];
+    for (uint64_t q = gq * tiles_per_group + 1; q < ntiles && q < (gq + 1) * tiles_per_group; q++) c = emap_then(c, tileMap[q]);
+    groupMap[gq] = c;
+  }
+  for (uint64_t gq = 1; gq < ngroups; gq++) {
+    const uint32_t want = truth[gq * tiles_per_group * static_cast<uint64_t>(tile) / sub];
+    // C := identity on this group's candidates; C := C o M for the maps in front
+    EMap C;
+    const EMap& own = tileMap[gq * tiles_per_group];
+    if (own.isc) continue;                                 // the group's first tile has a known entry-independent exit: nothing to look back for
+    for (int j = 0; j < kFsmMembers; j++) if (own.P[j] != 0xFFFFFFFFu) C.P[j] = (own.P[j] & 0xFFFFu) | ((own.P[j] & 0xFFFFu) << 16);
+    uint32_t got = 0xFFFFu;
+    for (int64_t k = static_cast<int64_t>(gq) - 1; k >= 0; k--) {
+      const EMap& M = groupMap[k];
+      if (M.isc || k == 0) {                                                    // a VALUE: its exit is known (group 0: from the origin)
+        const uint32_t e = M.isc ? M.cv : emap_apply(M, truth[0]);
+        got = emap_look(C, e);
+        break;
+      }
+      C = emap_then(M, C);
+    }
+    if (got != want) return -100 - 5;
+  }
+  return checked;
+}
+
+extern "C" int64_t emu_fsm_maps_check(const uint8_t* img, const uint8_t* hay, uint64_t len, int tile, int tiles_per_group) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  if (h->magic != kFsmMagic || tile % (2 * kFsmSub) != 0 || tile > 64 * 2 * kFsmSub || tiles_per_group < 1) return -1;
+  return h->nk > 1 ? emu_fsm_maps<true>(img, hay, len, tile, tiles_per_group) : emu_fsm_maps<false>(img, hay, len, tile, tiles_per_group);
+}

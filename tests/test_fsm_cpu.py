@@ -220,3 +220,44 @@ def test_captures_of_look_programs(oracle, pat):
         assert not isinstance(spans, int), (pat, spans)
         got = emu.captures_bt(cap, h, spans, 2 * rx.num_groups)
         assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), got[:4].tolist(), exp[:4].tolist())
+
+
+# ---- round 3: maps instead of waits (scan_fsm.hip fsm_resolve_exits / fsm_group_entry and the scan over sub-chunk maps) ----------
+MAPS_PATS = [r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)",
+             r"\d+\.\d+x?", r"a+b|b+a", r"[a-c]x|[b-d]y", r"ab*c|a|bb", r"(?:ab)*[a-c]", r"\b\d+\.\d+\b", r"\berror\b", r"(?m)^\d+", r"\b[a-z]+\b"]
+
+
+@pytest.mark.parametrize("pat", MAPS_PATS)
+def test_map_compositions_give_the_true_entry_states(pat):
+    """Input without synchronising structure: the kernel composes maps (member of a set of possible states -> end state) over
+    sub-chunks, lanes, tiles and groups instead of waiting for the state in front.  The twin performs the same compositions and
+    compares every entry state, tile exit and group entry they yield with a plain left-to-right walk — on few-symbol haystacks
+    (sets stay unresolved for long stretches), with islands of ordinary text (constant maps in the chain), for the kernel's tile
+    and for tiny tiles and groups (many borders)."""
+    import random
+    rx = cx.compile(pat)
+    img = rx.fsm_image()
+    if img is None:
+        pytest.skip("no transducer image")
+    rng = random.Random(len(pat))
+    checked = unlisted = 0
+    units = [b"1.", b"12.", b"a", b"ab", b"b", b"by", b"1", b"1.1x", b"error", b"ab ", b"01 ."]
+    for it in range(40):
+        unit = rng.choice(units)
+        n = rng.choice([300, 4000, 9000, 40000, 130000])
+        body = bytearray((unit * (n // len(unit) + 1))[:n])
+        if it % 3 == 0:
+            alpha = bytes(set(unit)) + b" "
+            body = bytearray(rng.choices(alpha, k=n))
+        for _ in range(it % 4):                                   # islands of ordinary text
+            at = rng.randrange(0, max(1, n - 200))
+            ln = rng.choice([5, 70, 700])
+            body[at:at + ln] = (b"GET /index.html 10.0.0.1 error x=1 " * 30)[:ln]
+        for tile, tpg in ((3840, 32), (3840, 2), (128, 3), (256, 8), (64, 1)):
+            r = emu.fsm_maps_check(bytes(img), bytes(body), tile, tpg)
+            if r == -17:
+                unlisted += 1
+                continue
+            assert r >= 0, (pat, bytes(unit), n, tile, tpg, r)
+            checked += r
+    assert checked > 10000 or unlisted > 0, (checked, unlisted)
