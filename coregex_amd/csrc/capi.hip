@@ -781,10 +781,14 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     }
     HIP_TRY(hipMemsetAsync(s.bothFirst, 0xFF, 8, stream));
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((nscan + 255) / 256, 4096));
-    hipLaunchKernelGGL(k_first_long, dim3(blocks), dim3(256), 0, stream, rows, nscan, static_cast<uint32_t>(row_width), static_cast<int64_t>(cxgdev::kBothRestartSpan), s.bothFirst);
+    // The first row of a RESTARTED search is what the reference's PikeVM returned from end - 100: it stands whatever its length
+    // (the next match downstream can be a long one, reported in full); the 100-byte rule applies to the searches behind it.
+    const uint64_t skip = (iter > 0 && nscan > 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_first_long, dim3(blocks), dim3(256), 0, stream, rows + skip * width, nscan - skip, static_cast<uint32_t>(row_width), static_cast<int64_t>(cxgdev::kBothRestartSpan), s.bothFirst);
     unsigned long long k = 0;
     HIP_TRY(hipMemcpyAsync(&k, s.bothFirst, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    k = k >= nscan - skip ? nscan : k + skip;
     bool over_estimate = false;
     if (k >= nscan) {
       // no long row among them: the long match lies behind the n-th row (the first n stand), or the kernel's flag was an

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R
-timeout 900 python -m pytest tests/test_gpu_trio.py -q -x > gpurun_out/r3y_trio.log 2>&1; echo "trio rc=$?"; tail -12 gpurun_out/r3y_trio.log | cut -c1-300
-
-
-
+timeout 600 python -m pytest -m gpu -q -x tests/test_gpu_parity.py -k "use_both" 2>&1 | tail -6 | cut -c1-300
+timeout 300 python scripts/gpu_fuzz.py 95 400 2>&1 | grep -v amdgpu.ids | tail -3

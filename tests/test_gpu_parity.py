@@ -440,7 +440,8 @@ def test_use_both_programs(need_gpu, oracle):
     many = (b"x y " + b"v" * 130 + b"@host.example.org  " + b"q@r.st " * 5) * 40          # 40 long matches: 40 restarts
     ends = b"w" * 300 + b"@b.c" + b" mid a@b.c " + b"z" * 120 + b"@" + b"y" * 150 + b"." + b"x" * 200                 # long matches at both ends of the haystack
     nested = b"k" * 250 + b"@" + b"l" * 250 + b"." + b"m" * 250 + b" tail t@u.vw"         # the restarted search meets another long match
-    for h in (longer, big, many, ends, nested):
+    twice = (b"k" * 250 + b"@" + b"l" * 250 + b"." + b"m" * 250 + b" ") * 3 + b"t@u.vw uu" + b"u" * 130 + b"@h.org" + b"z" * 150     # the restarted search's first row is a long match: it stands
+    for h in (longer, big, many, ends, nested, twice):
         exp = o.find_all_index(h)
         got = rx.find_all_index(h)
         assert got.shape == exp.shape and np.array_equal(got, exp), (bytes(h[:40]), got[:3].tolist(), exp[:3].tolist())

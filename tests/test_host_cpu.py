@@ -831,3 +831,42 @@ def test_product_literal_sets_pinned_on_reference_rows():
         assert sorted(_teddy_literals_of(blob)) == sorted(x.encode("latin-1") for x in c["want"]), c
         checked += 1
     assert checked >= 3, checked
+
+
+def test_use_both_restart_rule_equals_the_reference_iteration(oracle):
+    """capi.hip scanDevice (round 3) answers a UseBoth program WITHOUT a usable prefilter by iterating plain leftmost-first rows
+    and, at the first match longer than 100 bytes, restarting the search at that match's end - 100 (find_indices.go:432-441: the
+    DFA's end only picks where the PikeVM starts).  The same loop in Python over the oracle's plain leftmost-first spans (its
+    PikeVM: FindAllSubmatch of a UseBoth program does not restart) must reproduce the oracle's UseBoth FindAllIndex.  (This test found that the first row of a
+    restarted search must be exempt from the rule: the PikeVM's answer from end - 100 can be the next long match, in full.)"""
+    rng = np.random.default_rng(11)
+
+    def by_rule(o, hay):
+        rows, off = [], 0
+        for _ in range(200):
+            plain = o.find_all_submatch_index(hay[off:])[:, :2] + off
+            lens = plain[:, 1] - plain[:, 0]
+            if off and len(lens):
+                lens[0] = 0                                    # the first row of a restarted search is the PikeVM's answer: it stands
+            long_ = np.nonzero(lens > 100)[0]
+            if len(long_) == 0:
+                rows.extend(plain.tolist())
+                return np.array(rows, dtype=np.int64).reshape(-1, 2)
+            k = int(long_[0])
+            rows.extend(plain[:k].tolist())
+            nxt = int(plain[k, 1]) - 100
+            assert nxt > off
+            off = nxt
+        raise AssertionError("no progress")
+
+    for pat in (r"(\w+)@(\w+)\.(\w+)", r"(xy|ab|ca)\w+(ab)+", r"(\w+)=(\w+);(\w+)"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.strategy == o.strategy == "UseBoth" and not (rx.flags & 4)
+        toks = [b"a@b.c", b"k=v;w", b"xyab", b"u" * 130 + b"@host.example.org", b"k" * 250 + b"@" + b"l" * 250 + b"." + b"m" * 250, b"ab" * 90, b"ca" + b"z" * 140 + b"ab",
+                b"key" * 40 + b"=" + b"v" * 70 + b";" + b"w" * 10, b" ", b"\n", b"--", b"x@y", b"q@r.st"]
+        for _ in range(60):
+            hay = b" ".join(toks[i] for i in rng.integers(0, len(toks), int(rng.integers(1, 25))))
+            a = np.frombuffer(hay, dtype=np.uint8)
+            exp = o.find_all_index(a)
+            got = by_rule(o, a)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:80])
