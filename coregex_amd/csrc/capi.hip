@@ -539,14 +539,15 @@ relaunch:
     // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
     // start, the end or the end of the first / second run plus a constant (ChainCaps)
     static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
-    if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) &&
-        cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0) {
+    const int trioShape = cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
+    if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
       bool ok = !submatch || a.out == nullptr || fusedCaps;
+      if ((trioShape & 8) && !submatch) ok = false;                 // spans with one separator for every link are the fields kernel's (or, with that switched off, the chain kernel's)
       if (fusedCaps) {
         const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
         for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] & 1u) == 0u && cc->run_op[i] <= 6u;
         for (uint32_t k = 0; k < cc->nslots; k++) ok = ok && (cc->src[k] <= cxgdev::kCapSrcEnd || (cc->src[k] >= cxgdev::kCapSrcRun0 && cc->src[k] < cxgdev::kCapSrcRun0 + cc->nruns));
-        ok = ok && (a.row_width & 1u) == 0u && cc->nslots == a.row_width;
+        ok = ok && (a.row_width & 1u) == 0u && a.row_width <= 128u && cc->nslots == a.row_width;   // <= 64 lanes write a row
       }
       trioKernel = ok;
     }

@@ -499,7 +499,9 @@ struct TrioTile { uint32_t e0, e1; bool ovf; };
 
 // K fields, K - 1 links: lk[i] = bitmap of the bytes of the i-th separator class (word of this lane).  For K >= 3 the separator
 // classes are pairwise different (trio_shape): a candidate can then only share the LAST run of an earlier match.
-template <int K>
+// EQ: one separator for every link (K >= 3).  Two candidates can then share up to K - 1 runs, but the selection needs no
+// resolution at all: the matches of a super-run are its fields K at a time from its start, as in the fields kernel.
+template <int K, bool EQ>
 __device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const uint32_t (&c0)[K - 1], const uint32_t (&c1)[K - 1]) {
   const uint32_t prev_d1 = dpp_from_lower(d1);
   const uint32_t next_d0 = dpp_from_upper_ones(d0);
@@ -523,12 +525,7 @@ __device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const ui
     ovf |= GG | (Pe & recv);
     return recv;
   };
-  // owned span: the bits of X that the addition of the owned starts clears
-  uint32_t s0, s1;
-  unsigned long long GG;
-  add64_co(x0, x1, ws0, ws1, s0, s1, GG);
-  add64_cin(s0, s1, carry_in(GG, PPx));
-  const uint32_t own0 = x0 & ~s0, own1 = x1 & ~s1;
+  (void)PPx;
   // hop over one run from link bits q (subset of L): the carry of q + q runs through the F bytes behind the link
   auto hop = [&](uint32_t q0, uint32_t q1, uint32_t& r0, uint32_t& r1) {
     unsigned long long G2;
@@ -546,6 +543,27 @@ __device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const ui
     e0 = r0 & ~d0; e1 = r1 & ~d1;
   };
   uint32_t e0, e1;
+  if (EQ) {
+    uint32_t r0, r1, q0, q1, sel0 = 0, sel1 = 0;
+    hop(ws0, ws1, r0, r1);                                                  // over the first run of every owned super-run:
+    q0 = r0 & l0; q1 = r1 & l1;                                             // its link, if it has one
+    for (int guard = 0; guard < 64; guard++) {
+      hops(q0, q1, e0, e1);
+      sel0 |= e0; sel1 |= e1;
+      const uint32_t n0 = e0 & l0, n1 = e1 & l1;                            // an end on a link: more fields behind it
+      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(n1) << 32) | n0, 0ull, 33 /*ne*/) == 0ull) break;
+      hop(n0, n1, r0, r1);                                                  // over the next match's first run
+      q0 = r0 & l0; q1 = r1 & l1;
+      if (guard == 63) ovf |= 1ull << 63;
+    }
+    return TrioTile{sel0, sel1, (ovf >> 63) != 0ull};
+  }
+  // owned span: the bits of X that the addition of the owned starts clears
+  uint32_t s0, s1;
+  unsigned long long GG;
+  add64_co(x0, x1, ws0, ws1, s0, s1, GG);
+  add64_cin(s0, s1, carry_in(GG, PPx));
+  const uint32_t own0 = x0 & ~s0, own1 = x1 & ~s1;
   hops(la0 & own0, la1 & own1, e0, e1);
   // ends that sit on a first link: the candidate that begins with that link (if it is one) shares a run with this match
   uint32_t xa0 = e0 & la0, xa1 = e1 & la1;
@@ -603,8 +621,8 @@ __device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32
 }
 }  // namespace
 
-template <int K>
-__global__ __launch_bounds__(kThreads, (K == 4 ? 7 : CXG_TRIO_WAVES)) void k_scan_trio_wave(ScanArgs a) {
+template <int K, bool EQ>
+__global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_scan_trio_wave(ScanArgs a) {
   typedef typename std::conditional<K == 4, uint32_t, uint16_t>::type LinkT;   // K - 1 byte distances per row
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
   __shared__ __attribute__((aligned(16))) uint64_t s_c[K - 1][kWavesPerBlock][64];   // separator classes
@@ -700,7 +718,7 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 7 : CXG_TRIO_WAVES)) void k_sca
     uint32_t c0[K - 1], c1[K - 1];
 #pragma unroll
     for (int i = 0; i < K - 1; i++) { c0[i] = static_cast<uint32_t>(Cw[i]); c1[i] = static_cast<uint32_t>(Cw[i] >> 32); }
-    const TrioTile t = trio_core<K>(d0, d1, c0, c1);
+    const TrioTile t = trio_core<K, EQ>(d0, d1, c0, c1);
     if (t.ovf) fallback |= 1u;
     const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
     const uint32_t incl = wave_inclusive_sum_fused(c);
@@ -742,37 +760,34 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 7 : CXG_TRIO_WAVES)) void k_sca
   const ChainCaps* cp = reinterpret_cast<const ChainCaps*>(a.caps);
   const bool caps = cp->on == 1u;
   const uint32_t npairs = a.row_width >> 1;                          // 16-byte pairs per row
-  const bool pow2 = (npairs & (npairs - 1u)) == 0u;                  // then a lane always writes the same pair of a row
-  const uint32_t psh = 31u - static_cast<uint32_t>(__builtin_clz(npairs | 1u));
-  // what this lane's two slots are made of (lane-invariant for power-of-two widths; else per item below)
+  // a row is written by the next power of two >= npairs lanes (<= 64, the host checks), so that a lane always writes the same
+  // pair of a row and what its two slots are made of is decided once, outside the loops
+  const uint32_t lsh = npairs <= 1u ? 0u : 32u - static_cast<uint32_t>(__builtin_clz(npairs - 1u));
+  const uint32_t pr = static_cast<uint32_t>(lane0) & ((1u << lsh) - 1u);
+  const bool lane_on = pr < npairs;
   auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {      // sel: 0 start, 1 end, 2 + i link i (the end of run i), 7 unset
     const uint32_t src = cp->src[k];
     sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 7u;
     if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = (op >> 1) < static_cast<uint32_t>(K - 1) ? 2u + (op >> 1) : 1u; }
     off = cp->off[k];
   };
-  uint32_t lsel0 = 0, lsel1 = 1; int32_t loff0 = 0, loff1 = 0;
-  if (caps && pow2) { const uint32_t pr = static_cast<uint32_t>(lane0) & (npairs - 1u); slot_of(2u * pr, lsel0, loff0); slot_of(2u * pr + 1u, lsel1, loff1); }
+  uint32_t sel0 = 0, sel1 = 1; int32_t off0 = 0, off1 = 0;
+  if (caps && lane_on) { slot_of(2u * pr, sel0, off0); slot_of(2u * pr + 1u, sel1, off1); }
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw) - kFPre;
   uint32_t start = 0;
   for (int j = 0; j < tpw; j++) {
     const uint32_t n = s_cnt[wave][j];
     const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
-    for (uint32_t i = lane0; i < n * npairs; i += 64) {               // consecutive lanes write consecutive 16 bytes
-      const uint32_t rr = pow2 ? (i >> psh) : i / npairs, pr = i - rr * npairs;
+    for (uint32_t i = lane0; i < (n << lsh); i += 64) {               // consecutive lanes write consecutive 16 bytes
+      const uint32_t rr = i >> lsh;
       const uint32_t r = start + rr;
-      if (r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
+      if (lane_on && r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
         const uint32_t w0 = s_row[wave][r], w1 = s_lnk[wave][r];
         const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16);
         auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
         longlong2 o;
-        if (!caps) { o.x = ps; o.y = pe; }
-        else {
-          uint32_t sel0 = lsel0, sel1 = lsel1; int32_t off0 = loff0, off1 = loff1;
-          if (!pow2) { slot_of(2u * pr, sel0, off0); slot_of(2u * pr + 1u, sel1, off1); }
-          o.x = sel0 == 7u ? -1 : pos_of(sel0) + off0; o.y = sel1 == 7u ? -1 : pos_of(sel1) + off1;
-        }
+        o.x = sel0 == 7u ? -1 : pos_of(sel0) + off0; o.y = sel1 == 7u ? -1 : pos_of(sel1) + off1;
         *reinterpret_cast<longlong2*>(a.out + (dst + rr) * a.row_width + 2u * pr) = o;
       }
     }
@@ -781,8 +796,9 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 7 : CXG_TRIO_WAVES)) void k_sca
 }
 
 // Does the chain have the shape k_scan_trio_wave evaluates?  run(0) (byte(c_i) run(0)){K-1}, K = 2..4, every c_i a single byte
-// outside class 0; for K >= 3 the separators pairwise different (else two candidates could share more than one run, which the
-// overlap resolution does not look for; equal separators without captures are the fields kernel's).  Returns K, else 0.
+// outside class 0; for K >= 3 the separators either pairwise different (two candidates then share at most one run, which the
+// overlap resolution looks for) or all the same (the EQ instantiation: `(\d+)\.(\d+)\.(\d+)\.(\d+)`; without captures that
+// shape is the fields kernel's).  Returns K, | 8 for one separator, else 0.
 int trio_shape(const ChainAux& c) {
   if ((c.nops & 1u) == 0 || c.nops < 3 || c.nops > 7 || c.restart_check) return 0;
   const int K = static_cast<int>((c.nops + 1) / 2);
@@ -795,16 +811,23 @@ int trio_shape(const ChainAux& c) {
     if (chain_class_has(c, 0, c.cls_lo[q])) return 0;
     sep[k >> 1] = c.cls_lo[q];
   }
-  if (K >= 3) for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) if (sep[i] == sep[j]) return 0;
+  if (K >= 3) {
+    int same = 0, pairs = 0;
+    for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) { pairs++; if (sep[i] == sep[j]) same++; }
+    if (same == pairs) return K | 8;
+    if (same) return 0;
+  }
   return K;
 }
 
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   switch (trio_shape(*reinterpret_cast<const ChainAux*>(a.chain))) {
-    case 2: hipLaunchKernelGGL(k_scan_trio_wave<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(k_scan_trio_wave<3>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(k_scan_trio_wave<4>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((k_scan_trio_wave<2, false>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_scan_trio_wave<3, false>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_scan_trio_wave<4, false>), grid, block, 0, stream, a); break;
+    case 3 | 8: hipLaunchKernelGGL((k_scan_trio_wave<3, true>), grid, block, 0, stream, a); break;
+    case 4 | 8: hipLaunchKernelGGL((k_scan_trio_wave<4, true>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

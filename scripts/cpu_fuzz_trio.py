@@ -19,6 +19,8 @@ for it in range(npat):
     cls, members = rng.choice(CLASSES)
     K = rng.choice([2, 2, 3, 3, 3, 4])
     seps = rng.sample([s for s in SEPS if s not in members], K - 1) if K >= 3 else [rng.choice([s for s in SEPS if s not in members])]
+    same = K >= 3 and rng.random() < 0.4               # one separator for every link (the shape with bit 3 set)
+    if same: seps = [seps[0]] * (K - 1)
     grp = rng.random() < 0.7
     esc = lambda s: "\\" + s if s in ".-/ " and s != " " else s
     parts = []
@@ -36,8 +38,8 @@ for it in range(npat):
         blob = rx.blob()
     except Exception:
         refused += 1; continue
-    if emu.trio_shape(blob) != K: refused += 1; continue
-    alpha = members + "".join(seps) + rng.choice(["  \n", " x", "#"]) + rng.choice(SEPS)
+    if emu.trio_shape(blob) != (K | 8 if same else K): refused += 1; continue
+    alpha = members + "".join(sorted(set(seps))) + rng.choice(["  \n", " x", "#"]) + rng.choice(SEPS)
     for _ in range(12):
         n = rng.choice([10, 70, 200, 700, 4100, 9000])
         w = [rng.choice([1, 2, 5]) for _ in alpha]

@@ -201,7 +201,8 @@ def find_all_fields(blob: bytes, hay, own_words: int = 60):
 
 
 def trio_shape(blob: bytes) -> int:
-    """Number of fields K (2..4) when k_scan_trio_wave serves the program — run(F) (byte(c_i) run(F)){K-1} — else 0."""
+    """Number of fields K (2..4) when k_scan_trio_wave serves the program — run(F) (byte(c_i) run(F)){K-1} — else 0; | 8 when
+    every link has the same separator (K >= 3)."""
     return int(lib().emu_trio_shape(blob))
 
 
@@ -217,7 +218,7 @@ def find_all_trio(blob: bytes, hay, own_words: int = 60):
             return None
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
-            return out[:n].reshape(-1, trio_shape(blob) + 1).copy()
+            return out[:n].reshape(-1, (trio_shape(blob) & 7) + 1).copy()
         cap = int(n)
 
 

@@ -169,7 +169,12 @@ int trio_shape_host(const ChainAux& c) {      // scan_fields_wave.hip trio_shape
     if (chain_class_has(c, 0, c.cls_lo[q])) return 0;
     sep[k >> 1] = c.cls_lo[q];
   }
-  if (K >= 3) for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) if (sep[i] == sep[j]) return 0;
+  if (K >= 3) {
+    int same = 0, pairs = 0;
+    for (int i = 0; i < K - 1; i++) for (int j = i + 1; j < K - 1; j++) { pairs++; if (sep[i] == sep[j]) same++; }
+    if (same == pairs) return K | 8;
+    if (same) return 0;
+  }
   return K;
 }
 int take_top(uint64_t& l, uint64_t& h) {
@@ -182,7 +187,7 @@ int take_top(uint64_t& l, uint64_t& h) {
 extern "C" int emu_trio_shape(const uint8_t* blob) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic || !(h->flags & kFlagChainOrdered) || (h->flags & kFlagChainBounded)) return 0;
-  return trio_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));
+  return trio_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));   // K, | 8: one separator for all links
 }
 
 extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
@@ -190,8 +195,10 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
   if (h->magic != kBlobMagic) return -1;
   if (!(h->flags & kFlagChainOrdered)) return -4;
   const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
-  const int K = trio_shape_host(ch);
-  if (!K) return -5;
+  const int shape = trio_shape_host(ch);
+  if (!shape) return -5;
+  const int K = shape & 7;
+  const bool eq = (shape & 8) != 0;
   if (own_words < 1 || own_words > 62) return -2;
   const int64_t tile_bytes = 64LL * own_words, pre = 64, N = 64LL * 64;
   const unsigned long long own_mask = ((own_words == 63 ? ~0ull : ((1ull << own_words) - 1ull)) << 1);
@@ -236,9 +243,11 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
       ovf |= GG | (Pe & recv);
       for (int l = 0; l < 64; l++) S[l] += (recv >> l) & 1ull;
     };
-    uint64_t S[64], OWN[64];
-    add_words(X, WS, S, PPx);
-    for (int l = 0; l < 64; l++) OWN[l] = X[l] & ~S[l];
+    uint64_t S[64], OWN[64] = {0};
+    if (!eq) {
+      add_words(X, WS, S, PPx);
+      for (int l = 0; l < 64; l++) OWN[l] = X[l] & ~S[l];
+    }
     auto hop = [&](const uint64_t* Q, uint64_t* R) {
       uint64_t T[64];
       for (int l = 0; l < 64; l++) T[l] = D[l] | Q[l];
@@ -255,10 +264,27 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
     };
     const uint64_t* LA = LK[0];
     uint64_t Q0[64], E[64];
-    for (int l = 0; l < 64; l++) Q0[l] = LA[l] & OWN[l];
-    hops(Q0, E);
     bool chains = false;
-    for (int l = 0; l < 64; l++) chains = chains || (E[l] & LA[l]);
+    if (eq) {
+      // one separator: the matches of a super-run are its fields K at a time from its start (what the fields kernel does)
+      uint64_t R[64], Q[64], SEL[64] = {0}, Nx[64];
+      hop(WS, R);                                                  // over the first run: its link, if it has one
+      for (int l = 0; l < 64; l++) Q[l] = R[l] & L[l];
+      for (int guard = 0; guard < 64; guard++) {
+        hops(Q, E);
+        bool any = false;
+        for (int l = 0; l < 64; l++) { SEL[l] |= E[l]; Nx[l] = E[l] & L[l]; any = any || Nx[l]; }
+        if (!any) break;
+        hop(Nx, R);                                                // an end on a link: over the next match's first run
+        for (int l = 0; l < 64; l++) Q[l] = R[l] & L[l];
+        if (guard == 63) ovf |= 1ull << 63;
+      }
+      std::memcpy(E, SEL, sizeof E);
+    } else {
+      for (int l = 0; l < 64; l++) Q0[l] = LA[l] & OWN[l];
+      hops(Q0, E);
+      for (int l = 0; l < 64; l++) chains = chains || (E[l] & LA[l]);
+    }
     if (chains) {
       uint64_t R[64], SEL[64] = {0}, Kb[64], H[64], Q[64];
       std::memcpy(R, E, sizeof R);

@@ -74,7 +74,8 @@ def test_every_border(oracle):
 
 
 @pytest.mark.parametrize("pat,alpha", [(EMAIL, "ab_9@@..  x\n"), (r"\d+-\d+:\d+", "0123--:: \n"), (r"([a-c]+)x([a-c]+)y([a-c]+)", "abcxy z"), (r"(\w+)=(\w+);(\w+)", "ab_1==;; \n"), (r"(\d+)/(\d+) (\d+)", "0189// x"),
-                                       (r"(\w+)=(\w+)", "ab_1== \n"), (r"(\d+):(\d+)", "xyz   \n,;w01:"), (r"(\d+)-(\d+):(\d+)/(\d+)", "019--::// x"), (r"(\w+)@(\w+)", "ab_9@@ x")])
+                                       (r"(\w+)=(\w+)", "ab_1== \n"), (r"(\d+):(\d+)", "xyz   \n,;w01:"), (r"(\d+)-(\d+):(\d+)/(\d+)", "019--::// x"), (r"(\w+)@(\w+)", "ab_9@@ x"),
+                                       (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", "0189.. x"), (r"(\w+)@(\w+)@(\w+)", "ab_9@@ x\n"), (r"([a-c]+)-([a-c]+)-([a-c]+)", "abc-- x")])
 def test_random_text(oracle, pat, alpha):
     rng = random.Random(len(pat) * 7)
     served = 0
@@ -86,6 +87,46 @@ def test_random_text(oracle, pat, alpha):
         t = _check(oracle, pat, hay, want_kernel=None)
         served += t.kernel in (K_TRIO, 13) and t.n_launches == 1      # (13: spans of a two-field program with one separator class are the fields kernel's)
     assert served >= 4, served
+
+
+def test_one_separator_for_every_link(oracle):
+    """`(\\d+)\\.(\\d+)\\.(\\d+)\\.(\\d+)`: the capture rows of the headline pattern.  Two candidates may share up to three runs; the
+    matches of a stretch of fields are its fields four at a time from its start.  Spans of this shape are the fields kernel's."""
+    pat = r"(\d+)\.(\d+)\.(\d+)\.(\d+)"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    for hay in [b"1.2.3.4", b"1.2.3.4.5.6.7.8.9", b"1.2.3.4.5.6.7.8", b".1.2.3.4.", b"1..2.3.4.5", b"1.2.3 4.5.6.7", b"10.20.30.40.50 1.2.3.4", b"1.2.3", b"",
+                b"1.2.3." + b"4.5.6.7." * 50, b"x" * (WT - 9) + b"192.168.100.200 and 10.0.0.1", b"GET / 172.16.254.1 - 8.8.8.8.8\n" * 400]:
+        a = _u8(hay)
+        exp = o.find_all_submatch_index(a)
+        subs, t = _dev(rx, a, True)
+        assert subs.shape == exp.shape and np.array_equal(subs, exp), (hay[:40], subs[:3].tolist(), exp[:3].tolist())
+        if a.size:
+            assert t.kernel == K_TRIO and t.n_launches == 1, (hay[:40], t.kernel, t.n_launches, t.fallback_reason)
+        rows, t = _dev(rx, a, False)
+        assert np.array_equal(rows, exp[:, :2]) and (not a.size or t.kernel == 13)
+    tok = b"192.168.100.200"
+    for off in list(range(50, 70)) + list(range(WT - 20, WT + 70)) + list(range(32 * WT - 20, 32 * WT + 4)):
+        h = np.full(33 * WT + 300, ord(" "), dtype=np.uint8)
+        h[off:off + len(tok)] = np.frombuffer(tok, dtype=np.uint8)
+        subs, t = _dev(rx, h, True)
+        assert np.array_equal(subs, o.find_all_submatch_index(h)) and t.kernel == K_TRIO and t.n_launches == 1, off
+    # the headline log, 16 MiB
+    import torch
+    npages = 4096
+    buf = cx.DeviceBuffer(npages * 4096)
+    buf.fill_synth(2, 0xC0FFEE02, 0)
+    host = cx.synth_pages(2, 0xC0FFEE02, 0, npages)
+    exp = o.find_all_submatch_index(host)
+    out = torch.empty((len(exp) + 8, 10), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    n = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t)
+    assert n == len(exp) and n > 100000 and np.array_equal(out[:n].cpu().numpy(), exp)
+    assert t.kernel == K_TRIO and t.n_launches == 1
+    for pat3 in (r"(\d+)\.(\d+)\.(\d+)", r"((\d+)\.(\d+))\.(\d+)\.(\d+)"):      # three fields; a group around two of them (12 slots: 6 pairs, 8 lanes per row)
+        rx3, o3 = cx.compile(pat3), oracle.Regex(pat3)
+        h = host[:1 << 20]
+        subs, t3 = _dev(rx3, h, True)
+        assert np.array_equal(subs, o3.find_all_submatch_index(h)) and t3.kernel == K_TRIO and t3.n_launches == 1, pat3
 
 
 def test_synthlog_16mib(oracle):

@@ -11,9 +11,11 @@ import coregex_amd as cx
 import emu
 
 PATS = [r"(\w+)@(\w+)\.(\w+)", r"([a-c]+)x([a-c]+)y([a-c]+)", r"(\w+)=(\w+);(\w+)", r"(\d+)/(\d+) (\d+)", r"\d+-\d+:\d+",
-        r"(\w+)=(\w+)", r"(\d+):(\d+)", r"(\d+)-(\d+):(\d+)/(\d+)", r"(\w+)@(\w+)"]
+        r"(\w+)=(\w+)", r"(\d+):(\d+)", r"(\d+)-(\d+):(\d+)/(\d+)", r"(\w+)@(\w+)",
+        r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(\w+)@(\w+)@(\w+)", r"\d+\.\d+\.\d+", r"([a-c]+)-([a-c]+)-([a-c]+)-([a-c]+)"]   # one separator: K | 8
 ALPHA = {PATS[0]: "ab_9@@..  x\n", PATS[1]: "abcxy z", PATS[2]: "ab_1==;; \n", PATS[3]: "0189// x", PATS[4]: "0123--:: \n",
-         PATS[5]: "ab_1== \n", PATS[6]: "0123:: x", PATS[7]: "019--::// x", PATS[8]: "ab_9@@ x"}
+         PATS[5]: "ab_1== \n", PATS[6]: "0123:: x", PATS[7]: "019--::// x", PATS[8]: "ab_9@@ x",
+         PATS[9]: "0189.. x", PATS[10]: "ab_9@@ x", PATS[11]: "0189.. x\n", PATS[12]: "abc-- x"}
 
 
 def _u8(b):
@@ -34,10 +36,13 @@ def _expected(o, rx, hay):
 @pytest.mark.parametrize("pat", PATS)
 def test_shape_is_served(pat):
     rx = cx.compile(pat)
-    assert rx.supported and emu.trio_shape(rx.blob()) == pat.count("+")
+    shape = emu.trio_shape(rx.blob())
+    assert rx.supported and (shape & 7) == pat.count("+")
+    seps = set(pat.replace("\\d+", "").replace("\\w+", "").replace("[a-c]+", "").replace("(", "").replace(")", "").replace("\\", ""))
+    assert bool(shape & 8) == (pat.count("+") >= 3 and len(seps) == 1)
 
 
-@pytest.mark.parametrize("pat", [r"\d+\.\d+\.\d+\.\d+", r"(\w+)@(\w+)@(\w+)", r"(\w+)@(\w+)\.(\w+)x", r"error", r"(\w+)w(\w+)\.(\w+)"])
+@pytest.mark.parametrize("pat", [r"(\d+)-(\d+)-(\d+) (\d+)", r"(\w+)@(\w+)\.(\w+)@(\w+)", r"(\w+)@(\w+)\.(\w+)x", r"error", r"(\w+)w(\w+)\.(\w+)"])
 def test_other_shapes_stay_on_the_other_kernels(pat):
     rx = cx.compile(pat)
     try:
