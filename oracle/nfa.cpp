@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see nfa.hpp header for the reference map).
 #include "nfa.hpp"
 
+#include <algorithm>
 #include <sstream>
 
 namespace orc {
@@ -130,10 +131,191 @@ struct Compiler {  // nfa/compile.go
     return {first, prev};
   }
 
+  // ---- UTF-8 automata: classes that reach past U+007F, and `.` ---------------------------------------------------------
+  struct SuffixCache {  // nfa/utf8_suffix.go:20-123: direct-mapped, 64 entries, FNV-1a over (target, lo, hi); collisions overwrite
+    struct Entry { bool used = false; StateID from = 0; uint8_t lo = 0, hi = 0; StateID val = 0; };
+    Entry e[64];
+    static int slot(StateID from, uint8_t lo, uint8_t hi) {  // utf8_suffix.go:70-77
+      uint64_t h = 14695981039346656037ull;
+      h = (h ^ static_cast<uint64_t>(from)) * 1099511628211ull;
+      h = (h ^ static_cast<uint64_t>(lo)) * 1099511628211ull;
+      h = (h ^ static_cast<uint64_t>(hi)) * 1099511628211ull;
+      return static_cast<int>(h % 64u);
+    }
+    StateID getOrCreate(Builder& b, StateID target, uint8_t lo, uint8_t hi) {  // utf8_suffix.go:112-123
+      Entry& x = e[slot(target, lo, hi)];
+      if (x.used && x.from == target && x.lo == lo && x.hi == hi) return x.val;
+      StateID id = b.addByteRange(lo, hi, target);
+      x.used = true; x.from = target; x.lo = lo; x.hi = hi; x.val = id;
+      return id;
+    }
+  };
+
+  Frag compileUTF8Any(bool includeNL) {  // compile.go:1142-1222 (the default configuration: no ASCIIOnly, no UseRuneStates)
+    StateID endState = b.addEpsilon(kInvalidState);
+    SuffixCache cache;
+    static const uint8_t seqs[8][4][2] = {
+        {{0xC2, 0xDF}, {0x80, 0xBF}, {0, 0}, {0, 0}},
+        {{0xE0, 0xE0}, {0xA0, 0xBF}, {0x80, 0xBF}, {0, 0}},
+        {{0xE1, 0xEC}, {0x80, 0xBF}, {0x80, 0xBF}, {0, 0}},
+        {{0xED, 0xED}, {0x80, 0x9F}, {0x80, 0xBF}, {0, 0}},
+        {{0xEE, 0xEF}, {0x80, 0xBF}, {0x80, 0xBF}, {0, 0}},
+        {{0xF0, 0xF0}, {0x90, 0xBF}, {0x80, 0xBF}, {0x80, 0xBF}},
+        {{0xF1, 0xF3}, {0x80, 0xBF}, {0x80, 0xBF}, {0x80, 0xBF}},
+        {{0xF4, 0xF4}, {0x80, 0x8F}, {0x80, 0xBF}, {0x80, 0xBF}}};
+    static const int seqLen[8] = {2, 3, 3, 3, 3, 4, 4, 4};
+    std::vector<StateID> branches;
+    if (includeNL) branches.push_back(b.addByteRange(0x00, 0x7F, endState));
+    else branches.push_back(b.addSparse({{0x00, 0x09, endState}, {0x0B, 0x7F, endState}}));
+    for (int q = 0; q < 8; q++) {
+      StateID target = endState;
+      for (int i = seqLen[q] - 1; i >= 0; i--) target = cache.getOrCreate(b, target, seqs[q][i][0], seqs[q][i][1]);
+      branches.push_back(target);
+    }
+    // bytes that begin no sequence match alone (the lead bytes C2..F4 do not: :1205-1209)
+    branches.push_back(b.addSparse({{0x80, 0xBF, endState}, {0xC0, 0xC1, endState}, {0xF5, 0xFF, endState}}));
+    return {buildSplitChain(branches, 0), endState};
+  }
+
+  std::vector<StateID> buildUTF8NonASCIIBranches(StateID endState) {  // compile.go:845-917 (no suffix sharing here)
+    std::vector<StateID> br;
+    auto cont = [&](StateID next) { return b.addByteRange(0x80, 0xBF, next); };
+    { StateID c1 = cont(endState); br.push_back(b.addByteRange(0xC2, 0xDF, c1)); }
+    { StateID c2 = cont(endState); StateID c1 = b.addByteRange(0xA0, 0xBF, c2); br.push_back(b.addByteRange(0xE0, 0xE0, c1)); }
+    { StateID c2 = cont(endState); StateID c1 = cont(c2); br.push_back(b.addByteRange(0xE1, 0xEC, c1)); }
+    { StateID c2 = cont(endState); StateID c1 = b.addByteRange(0x80, 0x9F, c2); br.push_back(b.addByteRange(0xED, 0xED, c1)); }
+    { StateID c2 = cont(endState); StateID c1 = cont(c2); br.push_back(b.addByteRange(0xEE, 0xEF, c1)); }
+    { StateID c3 = cont(endState); StateID c2 = cont(c3); StateID c1 = b.addByteRange(0x90, 0xBF, c2); br.push_back(b.addByteRange(0xF0, 0xF0, c1)); }
+    { StateID c3 = cont(endState); StateID c2 = cont(c3); StateID c1 = cont(c2); br.push_back(b.addByteRange(0xF1, 0xF3, c1)); }
+    { StateID c3 = cont(endState); StateID c2 = cont(c3); StateID c1 = b.addByteRange(0x80, 0x8F, c2); br.push_back(b.addByteRange(0xF4, 0xF4, c1)); }
+    return br;
+  }
+
+  void utf8Range2(int lo, int hi, StateID endState, std::vector<StateID>& starts) {  // compile.go:663-701
+    const uint8_t loLead = 0xC0 | (lo >> 6), loCont = 0x80 | (lo & 0x3F), hiLead = 0xC0 | (hi >> 6), hiCont = 0x80 | (hi & 0x3F);
+    if (loLead == hiLead) {
+      StateID cont = b.addByteRange(loCont, hiCont, endState);
+      starts.push_back(b.addByteRange(loLead, loLead, cont));
+      return;
+    }
+    StateID cont1 = b.addByteRange(loCont, 0xBF, endState);
+    starts.push_back(b.addByteRange(loLead, loLead, cont1));
+    if (hiLead > loLead + 1) {
+      StateID contM = b.addByteRange(0x80, 0xBF, endState);
+      starts.push_back(b.addByteRange(loLead + 1, hiLead - 1, contM));
+    }
+    StateID cont2 = b.addByteRange(0x80, hiCont, endState);
+    starts.push_back(b.addByteRange(hiLead, hiLead, cont2));
+  }
+
+  void utf8Range3Simple(int lo, int hi, StateID endState, std::vector<StateID>& starts) {  // compile.go:740-792
+    const int loLead = 0xE0 | (lo >> 12), loC1 = 0x80 | ((lo >> 6) & 0x3F), loC2 = 0x80 | (lo & 0x3F);
+    const int hiLead = 0xE0 | (hi >> 12), hiC1 = 0x80 | ((hi >> 6) & 0x3F), hiC2 = 0x80 | (hi & 0x3F);
+    auto seq = [&](int lead, int c1, int c2lo, int c2hi) {
+      StateID s2 = b.addByteRange(static_cast<uint8_t>(c2lo), static_cast<uint8_t>(c2hi), endState);
+      StateID s1 = b.addByteRange(static_cast<uint8_t>(c1), static_cast<uint8_t>(c1), s2);
+      starts.push_back(b.addByteRange(static_cast<uint8_t>(lead), static_cast<uint8_t>(lead), s1));
+    };
+    if (loLead == hiLead && loC1 == hiC1) { seq(loLead, loC1, loC2, hiC2); return; }
+    if (loLead == hiLead) {
+      for (int c1 = loC1; c1 <= hiC1; c1++) seq(loLead, c1, c1 == loC1 ? loC2 : 0x80, c1 == hiC1 ? hiC2 : 0xBF);   // :922-934
+      return;
+    }
+    for (int lead = loLead; lead <= hiLead; lead++) {
+      const int c1Lo = lead == loLead ? loC1 : lead == 0xE0 ? 0xA0 : 0x80;   // :937-946
+      const int c1Hi = lead == hiLead ? hiC1 : lead == 0xED ? 0x9F : 0xBF;   // :949-958
+      for (int c1 = c1Lo; c1 <= c1Hi; c1++)
+        seq(lead, c1, (lead == loLead && c1 == loC1) ? loC2 : 0x80, (lead == hiLead && c1 == hiC1) ? hiC2 : 0xBF);   // :960-972
+    }
+  }
+
+  void utf8Range3(int lo, int hi, StateID endState, std::vector<StateID>& starts) {  // compile.go:706-737
+    if (lo <= 0xD7FF && hi >= 0xE000) { utf8Range3Simple(lo, 0xD7FF, endState, starts); utf8Range3Simple(0xE000, hi, endState, starts); return; }
+    if (lo >= 0xD800 && hi <= 0xDFFF) return;
+    if (lo >= 0xD800 && lo <= 0xDFFF) lo = 0xE000;
+    if (hi >= 0xD800 && hi <= 0xDFFF) hi = 0xD7FF;
+    if (lo > hi) return;
+    utf8Range3Simple(lo, hi, endState, starts);
+  }
+
+  void utf8Range4(int lo, int hi, StateID endState, std::vector<StateID>& starts) {  // compile.go:796-840: whole lead bytes, not the exact range
+    if (hi > 0x10FFFF) hi = 0x10FFFF;
+    if (lo < 0x10000) lo = 0x10000;
+    if (lo > hi) return;
+    const int loLead = 0xF0 | (lo >> 18), hiLead = 0xF0 | (hi >> 18);
+    for (int lead = loLead; lead <= hiLead; lead++) {
+      const uint8_t c1Lo = lead == 0xF0 ? 0x90 : 0x80, c1Hi = lead == 0xF4 ? 0x8F : 0xBF;
+      StateID c3 = b.addByteRange(0x80, 0xBF, endState);
+      StateID c2 = b.addByteRange(0x80, 0xBF, c3);
+      StateID c1 = b.addByteRange(c1Lo, c1Hi, c2);
+      starts.push_back(b.addByteRange(static_cast<uint8_t>(lead), static_cast<uint8_t>(lead), c1));
+    }
+  }
+
+  std::vector<StateID> compileUTF8Range(int lo, int hi, StateID endState) {  // compile.go:600-654
+    std::vector<StateID> starts;
+    if (lo <= 0x7F) { starts.push_back(b.addByteRange(static_cast<uint8_t>(lo), static_cast<uint8_t>(std::min(hi, 0x7F)), endState)); lo = 0x80; }
+    if (lo > hi) return starts;
+    if (lo <= 0x7FF) { utf8Range2(lo, std::min(hi, 0x7FF), endState, starts); lo = 0x800; }
+    if (lo > hi) return starts;
+    if (lo <= 0xFFFF) { utf8Range3(lo, std::min(hi, 0xFFFF), endState, starts); lo = 0x10000; }
+    if (lo > hi) return starts;
+    utf8Range4(lo, hi, endState, starts);
+    return starts;
+  }
+
+  Frag compileUnicodeClassLarge(const std::vector<int>& ranges) {  // compile.go:491-590
+    std::vector<Transition> ascii;
+    std::vector<std::pair<int, int>> rest;
+    for (size_t i = 0; i + 1 < ranges.size(); i += 2) {
+      const int lo = ranges[i], hi = ranges[i + 1];
+      if (hi < 0x80) ascii.push_back({static_cast<uint8_t>(lo), static_cast<uint8_t>(hi), kInvalidState});
+      else if (lo >= 0x80) rest.push_back({lo, hi});
+      else { ascii.push_back({static_cast<uint8_t>(lo), 0x7F, kInvalidState}); rest.push_back({0x80, hi}); }
+    }
+    const bool coversAllNonASCII = rest.size() == 1 && rest[0].first <= 0x80 && rest[0].second >= 0x10FFFF;
+    StateID target = b.addEpsilon(kInvalidState);
+    std::vector<StateID> alts;
+    if (!ascii.empty()) {
+      for (auto& t : ascii) t.next = target;
+      if (ascii.size() == 1) alts.push_back(b.addByteRange(ascii[0].lo, ascii[0].hi, target));
+      else alts.push_back(b.addSparse(ascii));
+    }
+    if (!rest.empty()) {
+      if (coversAllNonASCII) {
+        for (StateID s : buildUTF8NonASCIIBranches(target)) alts.push_back(s);
+        alts.push_back(b.addByteRange(0x80, 0xFF, target));      // any other byte >= 0x80 alone (:557-567)
+      } else {
+        for (auto& r : rest) for (StateID s : compileUTF8Range(r.first, r.second, target)) alts.push_back(s);
+      }
+    }
+    if (alts.empty()) return compileNoMatch();
+    if (alts.size() == 1) return {alts[0], target};
+    return {buildSplitChain(alts, 0), target};
+  }
+
+  Frag compileUnicodeClass(const std::vector<int>& ranges) {  // compile.go:440-481
+    if (ranges.empty()) return compileNoMatch();
+    int64_t total = 0;
+    for (size_t i = 0; i + 1 < ranges.size(); i += 2) {
+      total += static_cast<int64_t>(ranges[i + 1]) - ranges[i] + 1;
+      if (total > 256) return compileUnicodeClassLarge(ranges);
+    }
+    std::vector<ReP> alts;                                        // small classes: an alternation of their characters
+    for (size_t i = 0; i + 1 < ranges.size(); i += 2)
+      for (int r = ranges[i]; r <= ranges[i + 1]; r++) {
+        auto lit = std::make_shared<Regexp>();
+        lit->op = OpLiteral; lit->rune = {r};
+        alts.push_back(lit);
+      }
+    if (alts.size() == 1) return compile(alts[0]);
+    return compileAlternate(alts);
+  }
+
   Frag compileCharClass(const std::vector<int>& ranges) {  // compile.go:384-437
     if (ranges.empty()) return compileNoMatch();
     for (int r : ranges)
-      if (r > 127) fail("unsupported: non-ASCII character class (UTF-8 automata are out of scope, SURVEY 2.1)");
+      if (r > 127) return compileUnicodeClass(ranges);
     std::vector<Transition> tr;
     for (size_t i = 0; i + 1 < ranges.size(); i += 2)
       tr.push_back({static_cast<uint8_t>(ranges[i]), static_cast<uint8_t>(ranges[i + 1]), kInvalidState});
@@ -272,8 +454,8 @@ struct Compiler {  // nfa/compile.go
     switch (re->op) {
       case OpLiteral: return compileLiteral(re);
       case OpCharClass: return compileCharClass(re->rune);
-      case OpAnyChar: case OpAnyCharNotNL:
-        fail("unsupported: '.' (UTF-8 rune states are out of scope, SURVEY 2.1)");
+      case OpAnyChar: return compileUTF8Any(true);          // compile.go:977-992
+      case OpAnyCharNotNL: return compileUTF8Any(false);    // compile.go:995-1010
       case OpConcat: return compileConcat(re->sub);
       case OpAlternate: return compileAlternate(re->sub);
       case OpStar: return compileStar(re->sub[0], ng);

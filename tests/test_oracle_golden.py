@@ -378,3 +378,57 @@ def test_lazy_dfa_look_known_limitation_and_history(oracle):
     c = oracle.Regex(r"(?m)\d+$")
     assert c.strategy == "UseDigitPrefilter" and c.find_all_index(b"1 2").tolist() == [[2, 3]]
     assert c.find_all_index(b"1\n").tolist() == [] and oracle.Regex(r"(?m)\d+$").find_all_index(b"1\n").tolist() == [[0, 1]]
+
+
+def test_utf8_dot_and_class_vectors(oracle):
+    """`.` and classes that reach past U+007F (nfa/compile.go:440-1222, restated in oracle/nfa.cpp): the reference's own rows —
+    match counts of `.` over multi-byte text, first matches of `a.c`, FindString of small Unicode classes, the state counts
+    that suffix sharing must reach.  Inputs are UTF-8."""
+    for c in VEC["utf8_dot_find_all_count"]["cases"]:
+        assert len(oracle.Regex(c["pattern"]).find_all_index(c["input"].encode("utf-8"))) == c["want"], c
+    for c in VEC["utf8_dot_first_match"]["cases"]:
+        assert oracle.Regex(c["pattern"]).find_all_index(c["input"].encode("utf-8"), 1).tolist() == [c["want"]], c
+    blk = VEC["unicode_class_find_string"]
+    for c in blk["cases"]:
+        hay = c["input"].encode("utf-8")
+        got = oracle.Regex(c["pattern"]).find_all_index(hay, 1).tolist()
+        text = hay[got[0][0]:got[0][1]].decode("utf-8") if got else ""
+        assert text == c["want"], (c, got)
+    for c in blk["index_cases"]:
+        assert oracle.Regex(c["pattern"]).find_all_index(c["input"].encode("utf-8"), 1).tolist() == [c["want"]], c
+    for c in VEC["utf8_dot_state_count"]["cases"]:
+        assert oracle.Regex(c["pattern"]).nfa_states <= c["max_states"], c
+
+
+def test_dot_and_negated_classes_against_python_re_on_ascii_text(oracle):
+    """On ASCII text `.` is `[^\\n]` and a negated class its ASCII complement, whatever the UTF-8 branches of the automaton look
+    like: Python's `re` (bytes) gives the leftmost-first rows for non-nullable patterns."""
+    import random
+    import re
+    rng = random.Random(20260927)
+    atoms = [".", ".", r"[^,]", r'[^"]', r"\S", r"\D", r"\W", "a", "b", ",", '"', r"\d", r"\w", " ", "x", "[a-c]", r"[^a-c]", r"[^\n]", r"[^ab,]"]
+
+    def gen(depth=0):
+        r = rng.random()
+        if depth > 2 or r < 0.45:
+            return rng.choice(atoms) + rng.choice(["", "", "+", "*", "?", "+?", "*?", "{1,3}"])
+        if r < 0.8:
+            return "".join(gen(depth + 1) for _ in range(rng.randint(2, 4)))
+        if r < 0.9:
+            return "(?:" + gen(depth + 1) + "|" + gen(depth + 1) + ")"
+        return "(" + gen(depth + 1) + ")"
+
+    checked = 0
+    for _ in range(250):
+        pat = gen()
+        pr = re.compile(pat.encode())
+        if pr.fullmatch(b"") is not None:
+            continue
+        o = oracle.Regex(pat)
+        if o.strategy == "UseCharClassSearcher":                    # (ignores `+?`: a reference quirk restated and tested elsewhere)
+            continue
+        for _ in range(4):
+            hay = "".join(rng.choices('ab," 1x\n', k=rng.choice([0, 1, 5, 30, 200]))).encode()
+            assert o.find_all_index(hay).tolist() == [list(m.span()) for m in pr.finditer(hay)], (pat, o.strategy, hay[:60])
+            checked += 1
+    assert checked > 500
