@@ -732,9 +732,152 @@ struct NfaB {
     return {first, prev};
   }
 
+  // ---- classes that reach past U+007F and `.`: byte automata over UTF-8, state for state the reference's -------------------
+  uint32_t rangeTo(int lo, int hi, uint32_t next) { auto s = blank(CXG_NFA_BYTE_RANGE); s.lo = static_cast<uint8_t>(lo); s.hi = static_cast<uint8_t>(hi); s.next = next; return push(s); }
+  uint32_t sparseTo(std::initializer_list<std::pair<int, int>> rs, uint32_t target) {
+    auto s = blank(CXG_NFA_SPARSE);
+    s.trans_off = static_cast<uint32_t>(out.trans.size());
+    for (auto& r : rs) out.trans.push_back({static_cast<uint8_t>(r.first), static_cast<uint8_t>(r.second), 0, target});
+    s.trans_len = static_cast<uint32_t>(rs.size());
+    return push(s);
+  }
+  uint32_t splitChain(const std::vector<uint32_t>& t, size_t from = 0) {  // buildSplitChain compile.go:1298-1311: the innermost split first
+    if (t.size() - from == 1) return t[from];
+    if (t.size() - from == 2) return split(t[from], t[from + 1]);
+    const uint32_t right = splitChain(t, from + 1);
+    return split(t[from], right);
+  }
+  // the eight shapes of a well-formed multi-byte sequence: lead range, then the continuation ranges
+  struct Utf8Shape { int n; uint8_t r[4][2]; };
+  static const Utf8Shape* utf8Shapes() {
+    static const Utf8Shape t[8] = {{2, {{0xC2, 0xDF}, {0x80, 0xBF}}},
+                                   {3, {{0xE0, 0xE0}, {0xA0, 0xBF}, {0x80, 0xBF}}}, {3, {{0xE1, 0xEC}, {0x80, 0xBF}, {0x80, 0xBF}}},
+                                   {3, {{0xED, 0xED}, {0x80, 0x9F}, {0x80, 0xBF}}}, {3, {{0xEE, 0xEF}, {0x80, 0xBF}, {0x80, 0xBF}}},
+                                   {4, {{0xF0, 0xF0}, {0x90, 0xBF}, {0x80, 0xBF}, {0x80, 0xBF}}}, {4, {{0xF1, 0xF3}, {0x80, 0xBF}, {0x80, 0xBF}, {0x80, 0xBF}}},
+                                   {4, {{0xF4, 0xF4}, {0x80, 0x8F}, {0x80, 0xBF}, {0x80, 0xBF}}}};
+    return t;
+  }
+
+  F dot(bool withNL) {  // compileUTF8Any compile.go:1142-1222: suffixes shared through a 64-entry direct-mapped cache (nfa/utf8_suffix.go)
+    const uint32_t end = eps();
+    struct Slot { bool used; uint32_t to; uint8_t lo, hi; uint32_t id; } cache[64] = {};
+    auto shared = [&](uint32_t to, uint8_t lo, uint8_t hi) {
+      uint64_t h = 14695981039346656037ull;                         // FNV-1a over (target, lo, hi), utf8_suffix.go:70-77
+      for (uint64_t v : {static_cast<uint64_t>(to), static_cast<uint64_t>(lo), static_cast<uint64_t>(hi)}) h = (h ^ v) * 1099511628211ull;
+      Slot& c = cache[h % 64u];
+      if (c.used && c.to == to && c.lo == lo && c.hi == hi) return c.id;
+      c = Slot{true, to, lo, hi, rangeTo(lo, hi, to)};              // a collision overwrites
+      return c.id;
+    };
+    std::vector<uint32_t> alts;
+    alts.push_back(withNL ? rangeTo(0x00, 0x7F, end) : sparseTo({{0x00, 0x09}, {0x0B, 0x7F}}, end));
+    const Utf8Shape* shp = utf8Shapes();
+    for (int q = 0; q < 8; q++) {
+      uint32_t to = end;
+      for (int k = shp[q].n - 1; k >= 0; k--) to = shared(to, shp[q].r[k][0], shp[q].r[k][1]);
+      alts.push_back(to);
+    }
+    alts.push_back(sparseTo({{0x80, 0xBF}, {0xC0, 0xC1}, {0xF5, 0xFF}}, end));   // bytes that begin no sequence match alone; C2..F4 alone do not
+    return {splitChain(alts), end};
+  }
+
+  // byte sequences of the code points lo..hi (>= U+0080), compileUTF8Range compile.go:600-840, appended to `alts`
+  void utf8Range(int32_t lo, int32_t hi, uint32_t end, std::vector<uint32_t>& alts) {
+    auto three = [&](int32_t a, int32_t z) {                        // compileUTF83ByteRangeSimple :740-792: one chain per (lead, first continuation)
+      const int la = 0xE0 | (a >> 12), ca = 0x80 | ((a >> 6) & 63), da = 0x80 | (a & 63);
+      const int lz = 0xE0 | (z >> 12), cz = 0x80 | ((z >> 6) & 63), dz = 0x80 | (z & 63);
+      for (int lead = la; lead <= lz; lead++) {
+        int c1a = lead == la ? ca : lead == 0xE0 ? 0xA0 : 0x80, c1z = lead == lz ? cz : lead == 0xED ? 0x9F : 0xBF;
+        if (la == lz) { c1a = ca; c1z = cz; }
+        for (int c1 = c1a; c1 <= c1z; c1++) {
+          const uint32_t s2 = rangeTo((lead == la && c1 == ca) ? da : 0x80, (lead == lz && c1 == cz) ? dz : 0xBF, end);
+          alts.push_back(rangeTo(lead, lead, rangeTo(c1, c1, s2)));
+        }
+      }
+    };
+    if (lo <= 0x7FF) {                                              // two bytes :663-701
+      const int32_t z = std::min<int32_t>(hi, 0x7FF);
+      const int la = 0xC0 | (lo >> 6), ca = 0x80 | (lo & 63), lz = 0xC0 | (z >> 6), cz = 0x80 | (z & 63);
+      if (la == lz) alts.push_back(rangeTo(la, la, rangeTo(ca, cz, end)));
+      else {
+        alts.push_back(rangeTo(la, la, rangeTo(ca, 0xBF, end)));
+        if (lz > la + 1) alts.push_back(rangeTo(la + 1, lz - 1, rangeTo(0x80, 0xBF, end)));
+        alts.push_back(rangeTo(lz, lz, rangeTo(0x80, cz, end)));
+      }
+      lo = 0x800;
+    }
+    if (lo > hi) return;
+    if (lo <= 0xFFFF) {                                             // three bytes, never a surrogate :706-737
+      int32_t a = lo, z = std::min<int32_t>(hi, 0xFFFF);
+      if (a <= 0xD7FF && z >= 0xE000) { three(a, 0xD7FF); three(0xE000, z); }
+      else if (!(a >= 0xD800 && z <= 0xDFFF)) {
+        if (a >= 0xD800 && a <= 0xDFFF) a = 0xE000;
+        if (z >= 0xD800 && z <= 0xDFFF) z = 0xD7FF;
+        if (a <= z) three(a, z);
+      }
+      lo = 0x10000;
+    }
+    if (lo > hi) return;
+    for (int lead = 0xF0 | (lo >> 18); lead <= (0xF0 | (std::min<int32_t>(hi, kMaxRune) >> 18)); lead++) {   // four bytes: whole lead bytes :796-840
+      const uint32_t c3 = rangeTo(0x80, 0xBF, end), c2 = rangeTo(0x80, 0xBF, c3);
+      alts.push_back(rangeTo(lead, lead, rangeTo(lead == 0xF0 ? 0x90 : 0x80, lead == 0xF4 ? 0x8F : 0xBF, c2)));
+    }
+  }
+
+  F wideClass(const Ast::N& x) {  // compileUnicodeClass / compileUnicodeClassLarge compile.go:440-590
+    int64_t total = 0;
+    for (size_t k = 0; k + 1 < x.r.size() && total <= 256; k += 2) total += static_cast<int64_t>(x.r[k + 1]) - x.r[k] + 1;
+    if (total <= 256) {                                             // few characters: an alternation of one-rune literals
+      std::vector<F> fs;
+      Ast::N one; one.kind = Node::Lit; one.fold = false;
+      for (size_t k = 0; k + 1 < x.r.size(); k += 2)
+        for (int32_t r = x.r[k]; r <= x.r[k + 1]; r++) { one.r = {r}; fs.push_back(runes(one)); }
+      if (fs.size() == 1) return fs[0];
+      std::vector<uint32_t> ins;
+      for (auto& f : fs) ins.push_back(f.in);
+      const uint32_t sp = splitChain(ins), join = eps();
+      for (auto& f : fs) out.states[f.out].next = join;
+      return {sp, join};
+    }
+    std::vector<std::pair<int, int>> low;                           // the part below U+0080, and the rest
+    std::vector<std::pair<int32_t, int32_t>> rest;
+    for (size_t k = 0; k + 1 < x.r.size(); k += 2) {
+      const int32_t lo = x.r[k], hi = x.r[k + 1];
+      if (hi < 0x80) low.emplace_back(lo, hi);
+      else if (lo >= 0x80) rest.emplace_back(lo, hi);
+      else { low.emplace_back(lo, 0x7F); rest.emplace_back(0x80, hi); }
+    }
+    const uint32_t target = eps();
+    std::vector<uint32_t> alts;
+    if (low.size() == 1) alts.push_back(rangeTo(low[0].first, low[0].second, target));
+    else if (!low.empty()) {
+      auto s = blank(CXG_NFA_SPARSE);
+      s.trans_off = static_cast<uint32_t>(out.trans.size());
+      for (auto& r : low) out.trans.push_back({static_cast<uint8_t>(r.first), static_cast<uint8_t>(r.second), 0, target});
+      s.trans_len = static_cast<uint32_t>(low.size());
+      alts.push_back(push(s));
+    }
+    if (rest.size() == 1 && rest[0].first <= 0x80 && rest[0].second >= kMaxRune) {
+      // everything past U+007F (`[^"]`, `\S`, `\D`): every well-formed sequence, unshared (buildUTF8NonASCIIBranches :845-917),
+      // and any byte >= 0x80 on its own behind them (:557-567)
+      const Utf8Shape* shp = utf8Shapes();
+      for (int q = 0; q < 8; q++) {
+        uint32_t to = target;
+        for (int k = shp[q].n - 1; k >= 0; k--) to = rangeTo(shp[q].r[k][0], shp[q].r[k][1], to);
+        alts.push_back(to);
+      }
+      alts.push_back(rangeTo(0x80, 0xFF, target));
+    } else {
+      for (auto& r : rest) utf8Range(r.first, r.second, target, alts);
+    }
+    if (alts.empty()) { uint32_t a = eps(), z = eps(); return {a, z}; }   // compileNoMatch (a class of surrogates only)
+    if (alts.size() == 1) return {alts[0], target};
+    return {splitChain(alts), target};
+  }
+
   F cls(const Ast::N& x) {  // compileCharClass compile.go:384-432
     if (x.r.empty()) { uint32_t a = eps(), b = eps(); return {a, b}; }
-    for (int32_t r : x.r) if (r > 127) unsupported("non-ASCII character class");
+    for (int32_t r : x.r) if (r > 127) return wideClass(x);
     if (x.r.size() == 2) { uint32_t id = byteRange(x.r[0], x.r[1]); return {id, id}; }
     uint32_t target = eps();
     auto s = blank(CXG_NFA_SPARSE);
@@ -797,7 +940,8 @@ struct NfaB {
       case Node::Lit: return runes(x);
       case Node::Class: return cls(x);
       case Node::Empty: { uint32_t e = eps(); return {e, e}; }
-      case Node::Any: case Node::AnyNotNL: unsupported("'.' (UTF-8 rune states)");
+      case Node::Any: return dot(true);            // compileAnyChar compile.go:977-992 (default configuration)
+      case Node::AnyNotNL: return dot(false);      // compileAnyCharNotNL compile.go:995-1010
       case Node::BeginText: case Node::EndText:
         unsupported("text anchors (\\A \\z, ^ $ without (?m))");
       case Node::BeginLine: case Node::EndLine:
@@ -1198,8 +1342,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   const bool wordB = sh.has(root, {Node::WordB, Node::NoWordB});
   // Multi-line anchors (?m)^ (?m)$: hasMultilineLineAnchor strategy.go:1197-1210.  (?m)$ is a "non-line anchor" for the
   // literal engines (hasNonLineAnchors compile.go:686-703), (?m)^ is not: Teddy keeps its complete literals behind a
-  // line-start check (prefilter.WrapLineAnchor, compile.go:670-677).  The multi-line reverse-suffix strategy needs a
-  // `.` wildcard (isMultilineLineAnchored strategy.go:728-730), which the NFA builder has refused already.
+  // line-start check (prefilter.WrapLineAnchor, compile.go:670-677).  (The multi-line reverse-suffix strategy: below.)
   const bool lineAnchor = sh.has(root, {Node::BeginLine, Node::EndLine});
   const bool nonLineAnchors = wordB || sh.has(root, {Node::EndLine});
   p.lineStart = sh.has(root, {Node::BeginLine});
@@ -1241,8 +1384,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   bool teddyLits = pre.v.size() >= 2 && pre.v.size() <= 64 && minLen >= 3;
   bool acLits = pre.v.size() > 64 && minLen >= 1;
 
-  // selectReverseStrategy (strategy.go:974-1093), restated for look-around-free patterns (the NFA builder
-  // has already refused ^ $ \b).  The reverse searchers themselves are outside the device subset: when
+  // selectReverseStrategy (strategy.go:974-1093).  The reverse searchers themselves are outside the device subset: when
   // one would be chosen the plan carries that strategy and the program is refused.
   bool fastPrefix = !pre.v.empty() && (good || pre.v.size() == 1 || minLen >= 3);   // hasFastPrefixPrefilter :948-967
   const auto& r = ast.at(root);
@@ -1258,6 +1400,10 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     for (auto& x : l.v) { size_t k = 0; while (k < n && k < x.bytes.size() && x.bytes[k] == l.v[0].bytes[k]) k++; n = k; }
     return n;
   };
+  auto dotLoop = [&](int n) {       // `.*` / `.+`
+    const auto& y = ast.at(n);
+    return (y.kind == Node::Star || y.kind == Node::Plus) && !y.kids.empty() && (ast.at(y.kids[0]).kind == Node::Any || ast.at(y.kids[0]).kind == Node::AnyNotNL);
+  };
   auto safeSuffix = [&](int n0) {   // isSafeForReverseSuffix :605-634
     int n = n0;
     while (ast.at(n).kind == Node::Capture && !ast.at(n).kids.empty()) n = ast.at(n).kids[0];
@@ -1268,7 +1414,7 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
       int c = x.kids[k];
       while (ast.at(c).kind == Node::Capture && !ast.at(c).kids.empty()) c = ast.at(c).kids[0];
       const auto& y = ast.at(c);
-      if ((y.kind == Node::Plus && ast.at(y.kids[0]).kind == Node::Class) || (y.kind == Node::Repeat && y.min >= 1)) wc++;
+      if (dotLoop(c) || (y.kind == Node::Plus && ast.at(y.kids[0]).kind == Node::Class) || (y.kind == Node::Repeat && y.min >= 1)) wc++;   // isWildcardSubexpression :586-603
     }
     if (wc == 0) return false;
     for (size_t k = 1; k + 1 < x.kids.size(); k++)            // containsAnchor in a middle element (:628-632)
@@ -1281,8 +1427,48 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
     const auto& x = ast.at(n);
     if (x.kind != Node::Concat || x.kids.size() < 2) return false;
     const auto& f = ast.at(x.kids[0]);
-    return f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class;
+    return dotLoop(x.kids[0]) || (f.kind == Node::Plus && ast.at(f.kids[0]).kind == Node::Class);
   };
+  // UseMultilineReverseSuffix (strategy.go:1004-1012, decided before the fast-prefix test): `(?m)^.*suffix` — a line-start anchor
+  // in front (isSafeForMultilineReverseSuffix :805-843), a wildcard somewhere, and suffix literals with a common suffix
+  {
+    std::function<bool(int)> lineStart = [&](int n) -> bool {      // containsLineStartAnchor :734-768
+      const auto& x = ast.at(n);
+      switch (x.kind) {
+        case Node::BeginLine: return true;
+        case Node::Concat: for (int c : x.kids) if (lineStart(c)) return true; return false;
+        case Node::Alt: if (x.kids.empty()) return false; for (int c : x.kids) if (!lineStart(c)) return false; return true;
+        case Node::Capture: return !x.kids.empty() && lineStart(x.kids[0]);
+        default: return false;
+      }
+    };
+    std::function<bool(int)> wild = [&](int n) -> bool {           // containsWildcard :771-793
+      const auto& x = ast.at(n);
+      switch (x.kind) {
+        case Node::Star: case Node::Plus: return dotLoop(n);
+        case Node::Concat: case Node::Alt: for (int c : x.kids) if (wild(c)) return true; return false;
+        case Node::Capture: case Node::Quest: case Node::Repeat: return !x.kids.empty() && wild(x.kids[0]);
+        default: return false;
+      }
+    };
+    std::function<bool(int)> safeMultiline = [&](int n) -> bool {
+      if (!(lineStart(n) && wild(n))) return false;
+      const auto& x = ast.at(n);
+      if (x.kind == Node::Capture) return !x.kids.empty() && safeMultiline(x.kids[0]);
+      if (x.kind != Node::Concat || x.kids.size() < 2) return false;
+      bool w = false;
+      for (size_t k = 0; k < x.kids.size(); k++) {
+        if (k == 0 && ast.at(x.kids[k]).kind == Node::BeginLine) continue;
+        const auto& y = ast.at(x.kids[k]);
+        if (dotLoop(x.kids[k]) || (y.kind == Node::Plus && !y.kids.empty() && ast.at(y.kids[0]).kind == Node::Class)) w = true;   // isWildcardOp :846-861
+      }
+      return ast.at(x.kids[0]).kind == Node::BeginLine && w;
+    };
+    if (!wordB && !sh.has(root, {Node::EndLine}) && safeMultiline(root)) {   // (after the word-boundary and end-anchor returns of :980-995)
+      Lits suf = lx.suffixes(root, 0);
+      if (!suf.v.empty() && lcSuffixLen(suf) >= 1) { p.strategy = CXG_USE_MULTILINE_REVERSE_SUFFIX; return p; }
+    }
+  }
   // selectReverseStrategy returns at once for word boundaries (:988) and for an end anchor that does not end the pattern
   // in the sense of nfa.isEndAnchored — which (?m)$ never does (nfa.HasImpossibleEndAnchor, nfa/compile.go:1858-1888)
   if (!fastPrefix && !wordB && !sh.has(root, {Node::EndLine})) {

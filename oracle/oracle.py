@@ -205,8 +205,8 @@ class Regex:
         return slots if ok else None
 
     def dump(self) -> str:
-        buf = C.create_string_buffer(1 << 16)
-        lib().orc_dump(self._h, buf, 1 << 16)
+        buf = C.create_string_buffer(1 << 20)
+        lib().orc_dump(self._h, buf, 1 << 20)
         return buf.value.decode()
 
 

@@ -1,5 +1,5 @@
 """CPU fuzz of the FindAll transducer (host/fsm.cc tables + device/fsm.hpp lane functions run by tests/emu/emu_fsm.cc)
-against the oracle: random patterns, small tile/chunk geometries, few-symbol haystacks.  python scripts/cpu_fuzz_fsm.py [n] [seed]"""
+against the oracle: random patterns, small tile/chunk geometries, few-symbol haystacks.  python scripts/cpu_fuzz_fsm.py [n] [seed] [look|wide]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,10 +19,15 @@ ATOMS = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
 LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+", r"(a|\b)", r"(\bab|xy\b)", r"\b\b", r"(?:\bx)+",
               "^", "$", "^", "$", r"\n", r"(^a|b$)", r"[a-c\n]+", r"(?:$\n^)?", "^ab|xy$"]
 
-def main(n=300, seed=1, look=False):
+# `.` and classes past U+007F (UTF-8 byte automata): mode "wide"; the haystacks then hold multi-byte sequences and stray bytes >= 0x80
+WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D", r"\W", r"[^a-c]+", r"[^\n]*", "(.)", r"(\S+)", r'"[^"]*"', "é", "[aé]", r"[^:]*:", ".+?", r"\D+?", "x.y", "(?s:.)"]
+
+def main(n=300, seed=1, look=False, wide=False):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n" + (b"_A  __" if look else b""), dtype=np.uint8)
-    atoms = ATOMS + LOOK_ATOMS * 3 if look else ATOMS
+    if wide:
+        alphabet = np.frombuffer(b'abcxyz.:-019 \n"' + "éé日😀".encode() + b"\x80\xc3\xff", dtype=np.uint8)
+    atoms = ATOMS + LOOK_ATOMS * 3 if look else ATOMS + WIDE_ATOMS * 3 if wide else ATOMS
     n_strat = 0
     seen, n_img, n_checked, reasons = set(), 0, 0, {}
     n_caps = 0
@@ -30,6 +35,7 @@ def main(n=300, seed=1, look=False):
     while len(seen) < n:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
         if pat in seen: continue
+        if wide and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")): continue
         if look:
             if "\\b" not in pat and "\\B" not in pat and "^" not in pat and "$" not in pat: continue
             pat = "(?m)" + pat
@@ -97,4 +103,4 @@ def main(n=300, seed=1, look=False):
     return 0
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1, len(sys.argv) > 3 and sys.argv[3] == "look"))
+    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1, len(sys.argv) > 3 and sys.argv[3] == "look", len(sys.argv) > 3 and sys.argv[3] == "wide"))
