@@ -1,0 +1,65 @@
+"""GPU tier: `.` and classes that reach past U+007F (UTF-8 byte automata, nfa/compile.go:440-1222) through the C ABI, against the
+oracle: log-shaped patterns on the synthetic corpus and on text with multi-byte sequences and stray bytes >= 0x80."""
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from refcorpus import generate_test_input
+
+pytestmark = pytest.mark.gpu
+
+SPANS = [r'"[^"]*"', r"GET .* HTTP", r"\[[^\]]+\]", r"/[^ ]+\.html", r"user=\S+", r"\d+ .* \d+", r"a.c", r"<[^>]+>", r"https?://[^\s]+", r"(?s)a.b", r"é+", r"k[^k]",
+         r"HTTP/1\.1. \d+", r"session_id=[^ ]+ ", r"x.y|a.b", r"/\*.*?\*/", r"ms=\d+."]
+CAPS = [r"user=(\S+)", r'"([^"]*)"', r"\[([^\]]+)\]", r"ms=(\d+)(.)", r'"(GET|POST) ([^ ]+) HTTP', r"(a)(.)(c)"]
+
+
+def _u8(b):
+    return b if isinstance(b, np.ndarray) else np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+def _hays():
+    rng = np.random.default_rng(7)
+    mixed = np.frombuffer(b'abckxy.:-019 \n"<>[]/=*' + "éé日😀".encode() + b"\x80\xc3\xff", dtype=np.uint8)
+    return [cx.synth_pages(2, 0xC0FFEE02, 0, 256), generate_test_input(), mixed[rng.integers(0, len(mixed), size=120000)],
+            mixed[rng.integers(0, 9, size=30000)], _u8('a😀c x日y "é" <ü> aéc a\nc [日本語] /*é*/ https://ü.example/é k😀'.encode() * 50), _u8(b""), _u8(b"a"), _u8("é".encode())]
+
+
+@pytest.mark.parametrize("pat", SPANS)
+def test_spans(oracle, pat):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.supported and rx.strategy == o.strategy, (pat, rx.why_unsupported)
+    for hay in _hays():
+        exp = o.find_all_index(hay)
+        if rx.strategy == "UseBoth":
+            plain = o.find_all_submatch_index(hay)[:, :2]
+            if len(plain) and int((plain[:, 1] - plain[:, 0]).max()) > 100 and len(plain) > 64 * 50:
+                continue                                    # more restarts than the device wrapper makes (CXG_E_INPUT)
+        got = rx.find_all_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), got[:3].tolist(), exp[:3].tolist())
+        assert rx.count(hay) == len(exp)
+
+
+@pytest.mark.parametrize("pat", CAPS)
+def test_capture_rows(oracle, pat):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.submatch_supported, pat
+    for hay in _hays()[:1] + _hays()[2:]:
+        hay = hay[:200000]
+        exp = o.find_all_submatch_index(hay)
+        got = rx.find_all_submatch_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), got[:2].tolist(), exp[:2].tolist())
+
+
+def test_dot_alone_and_every_byte_value(oracle):
+    """`.` / `.+` on the reference's own rows (regex_unicode_test.go:112-141) and over every byte value: ill-formed bytes match alone,
+    lead bytes C2..F4 without their continuation do not match at all."""
+    for pat, text, want in [(".", "日本語", 3), (".+", "日本語", 1), (".", "😀😁", 2), (".", "a日b", 3), (".", "Привет", 6), (".", "a\nb", 2), ("(?s).", "日\n本", 3)]:
+        rx = cx.compile(pat)
+        assert rx.supported, (pat, rx.why_unsupported)
+        assert len(rx.find_all_index(text.encode())) == want, (pat, text)
+    hay = _u8(bytes(range(256)) * 3 + "é日😀".encode() + bytes([0xC3, 0x41, 0xE6, 0x97, 0x41, 0xF0, 0x9F, 0x41]))
+    for pat in [".", ".+", r"[^a]", r"\S+x?", r"[^\n]y?"]:
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        if not rx.supported:
+            continue
+        assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), pat
