@@ -699,12 +699,14 @@ relaunch:
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
   }
   err &= 0xFFu;
+  // (first: a walk cut at the budget leaves a truncated row behind, which may also have raised the long-match flag — the rows
+  // of such a launch are not the reference's and must not reach the UseBoth restart loop)
+  if (err & cxgdev::kErrSerialLimit)
+    return fail(CXG_E_INPUT, "haystack has a stretch without synchronising bytes beyond the serial-walk budget (128 KiB)");
   if (err & cxgdev::kErrLongMatch) {
     if (n_out) *n_out = total;
     return kRcLongMatch;
   }
-  if (err & cxgdev::kErrSerialLimit)
-    return fail(CXG_E_INPUT, "haystack has a stretch without synchronising bytes beyond the serial-walk budget (128 KiB)");
   if (err) return fail(CXG_E_INTERNAL, "device-side watchdog/overflow flag " + std::to_string(err));
   if (dbgBits) { if (n_out) *n_out = total; return CXG_OK; }
   uint64_t n = total;

@@ -18,7 +18,11 @@ LOOK = bool(os.environ.get("FUZZ_LOOK"))      # word boundaries / multi-line anc
 if LOOK:
     atoms = atoms[:36] + [r"\b", r"\B", r"\b", "^", "$", "^", "$", "_", "[a-c_]+", r"\w+", " ", "A", r"\n", r"(a|\b)", r"(\bab|xy\b)", r"(^a|b$)", r"(?:$\n^)?", "^ab|xy$",
                          "abc", "xyz", r"\d+", "abcx|bcxy|cxyz|xyza"]
-alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff" + (b"_ \n_a \n" if LOOK else b""), dtype=np.uint8)
+WIDE = bool(os.environ.get("FUZZ_WIDE"))      # `.` and classes past U+007F in every pattern; multi-byte sequences and stray bytes >= 0x80 in the haystacks
+WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D", r"\W", r"[^a-c]+", r"[^\n]*", "(.)", r"(\S+)", r'"[^"]*"', "é", "[aé]", r"[^:]*:", ".+?", r"\D+?", "x.y", "(?s:.)"]
+if WIDE:
+    atoms = atoms + WIDE_ATOMS * 3
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff" + (b"_ \n_a \n" if LOOK else b"") + ('"éé日😀'.encode() if WIDE else b""), dtype=np.uint8)
 T = 3840
 def rnd(n, p=None):
     return alphabet[rng.integers(0, len(alphabet), size=int(n))] if p is None else alphabet[rng.choice(len(alphabet), size=int(n), p=p)]
@@ -47,6 +51,8 @@ while len(seen) < npat:
         if not any(t in pat for t in ("\\b", "\\B", "^", "$")):
             continue
         pat = "(?m)" + pat
+    if WIDE and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")):
+        continue
     if pat in seen:
         continue
     seen.add(pat)

@@ -63,3 +63,22 @@ def test_dot_alone_and_every_byte_value(oracle):
         if not rx.supported:
             continue
         assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), pat
+
+
+def test_a_match_longer_than_the_serial_walk_budget_is_refused_not_truncated(oracle):
+    """`[^a-c]+` runs across newlines: one match can be the whole haystack.  Up to the serial-walk budget (128 KiB) the UseBoth
+    restart rule answers (the reference's PikeVM starts 100 bytes before the end); past it the table-walking kernel cuts its walk
+    and flags it — the call must then fail (CXG_E_INPUT) instead of handing the cut row to the restart loop (found by the device
+    fuzz, `(.)[^a-c]+` on 171 000 bytes: rows [147612, 171000) instead of [170900, 171000))."""
+    for pat in (r"(.)[^a-c]+", r"[^a-c]+x?y?"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported and rx.strategy == "UseBoth"
+        for n in (200, 3000, 100000, 130000, 171000, 400000):
+            hay = _u8(((b"1.2.3.4 " * 7 + b"\n") * 8000)[:n])
+            exp = o.find_all_index(hay)
+            try:
+                got = rx.find_all_index(hay)
+            except cx.UnsupportedInput:
+                assert n > 128 * 1024, n
+                continue
+            assert np.array_equal(got, exp), (pat, n, got.tolist(), exp.tolist())
