@@ -68,6 +68,38 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
   for (uint32_t k = 2; k < nslots; k++) row[k] = -1;
   // stack entry: kind (2 bits) | payload.  0: explore (state << 32 | position offset << 2), 1: restore slot
   // (slot << 34 | (old offset + 1) << 2 | 1), old offset + 1 == 0 means "was unset"
+  // Is the branch that starts at state q dead at offset `off` — would the walk, entering it, end without consuming a byte or
+  // reaching Match at e?  Then it need not be kept for later: a greedy loop's exit (`(\S+)`: Epsilon, Capture, Match — not at
+  // e yet) and the other lead-byte branches of a UTF-8 class are not pushed, and the stack of a long repetition stays flat
+  // instead of growing by an entry per byte.  A leaf is followed through EPSILON / CAPTURE (not stamped); a right-leaning
+  // chain of SPLITs (buildSplitChain) whose left leaves are all dead is dead; anything else counts as alive.
+  auto dead_leaf = [&](uint32_t q, uint32_t off) -> bool {
+    for (int hops = 0; hops < 6; hops++) {
+      if (q == kBtInvalid || q >= h->n_states) return true;
+      const BtState x = st[q];
+      if (x.kind == 0) return s + static_cast<int64_t>(off) != e;
+      if (x.kind == 1) return s + static_cast<int64_t>(off) >= e || hay[s + off] < x.lo || hay[s + off] > x.hi;
+      if (x.kind == 2) {
+        if (s + static_cast<int64_t>(off) >= e) return true;
+        const uint32_t b = hay[s + off], t0 = x.trans_off_len >> 12, tn = x.trans_off_len & 0xFFFu;
+        for (uint32_t k = 0; k < tn; k++) if (b >= tr[t0 + k].lo && b <= tr[t0 + k].hi) return false;
+        return true;
+      }
+      if (x.kind == 4 || x.kind == 5) { q = x.next; continue; }
+      return false;
+    }
+    return false;
+  };
+  auto dead_branch = [&](uint32_t q, uint32_t off) -> bool {
+    for (int hops = 0; hops < 12; hops++) {
+      if (q == kBtInvalid || q >= h->n_states) return true;
+      const BtState x = st[q];
+      if (x.kind == 3) { if (!dead_leaf(x.next, off)) return false; q = x.alt; continue; }
+      if (x.kind == 4 || x.kind == 5) { q = x.next; continue; }
+      return dead_leaf(q, off);
+    }
+    return false;
+  };
   uint32_t sp = 0;
   stack[sp++] = (static_cast<uint64_t>(h->start) << 32);
   while (sp) {
@@ -103,8 +135,10 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
         if (nx == kBtInvalid) break;
         q = nx; off++;
       } else if (x.kind == 3 /*SPLIT*/) {
-        if (sp >= stack_entries) return 1u;
-        stack[sp++] = (static_cast<uint64_t>(x.alt) << 32) | (static_cast<uint64_t>(off) << 2);   // right: after everything the left branch tries
+        if (!dead_branch(x.alt, off)) {
+          if (sp >= stack_entries) return 1u;
+          stack[sp++] = (static_cast<uint64_t>(x.alt) << 32) | (static_cast<uint64_t>(off) << 2);   // right: after everything the left branch tries
+        }
         q = x.next;
       } else if (x.kind == 4 /*EPSILON*/) {
         q = x.next;

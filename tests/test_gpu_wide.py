@@ -82,3 +82,21 @@ def test_a_match_longer_than_the_serial_walk_budget_is_refused_not_truncated(ora
                 assert n > 128 * 1024, n
                 continue
             assert np.array_equal(got, exp), (pat, n, got.tolist(), exp.tolist())
+
+
+def test_long_capture_rows(oracle):
+    """Patterns with `\\S` / `[^"]` are not one-pass (a byte >= 0x80 is accepted by several NFA states): their slots come from the
+    backtracking pass.  Its stack stays flat over a long repetition (dead alternatives are not pushed, bt.hpp); what bounds a
+    row is the visited bitmap, states x span <= 65 536 — longer rows fail the call (CXG_E_INPUT), never a wrong slot."""
+    for pat, hay in [(r'"([^"]*)"', b'x "' + b"z" * 1200 + b'" "a" "' + "é日".encode() * 100 + b'"'),
+                     (r"user=(\S+)", b"user=" + b"a" * 700 + b" user=bob\nuser=\xff\xfe z"),
+                     (r"(xy|ab|ca)\S+", b"ab" + b"q" * 900 + b" xyzz ca\xc3\xa9"),
+                     (r"user=(\S+)", b"x user=" + b"a" * 5000 + b" y user=bob z")]:
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        exp = o.find_all_submatch_index(hay)
+        try:
+            got = rx.find_all_submatch_index(hay)
+        except cx.UnsupportedInput:
+            assert int((exp[:, 1] - exp[:, 0]).max()) * 40 > 65536, pat
+            continue
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, got.tolist(), exp.tolist())
