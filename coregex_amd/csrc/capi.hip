@@ -985,6 +985,17 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
   try {
     cxg::Ast ast = cxg::parsePattern(std::string(pattern, len));
     auto* p = new cxg_program();
+    {
+      bool exact = true;
+      const int as = cxg::textAnchorStrategy(ast, exact);             // anchored at the text's start or end: engines without a device kernel
+      if (as >= 0) {
+        p->supported = false; p->strategy = as; p->ngroups = ast.ncap + 1;
+        p->whyNot = std::string("strategy ") + cxg_strategy_name(as) + (exact ? "" : " (or UseAnchoredLiteral / UseBranchDispatch)") +
+                    " has no device kernel: the pattern is anchored at the " + (as == CXG_USE_REVERSE_ANCHORED ? "end" : "start") + " of the text";
+        *out = p;
+        return CXG_OK;
+      }
+    }
     try {
       p->nfa = cxg::buildNfa(ast);
     } catch (const cxg::FrontendError& e) {

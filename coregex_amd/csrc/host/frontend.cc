@@ -1544,6 +1544,61 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
 }
 
 
+int textAnchorStrategy(const Ast& ast, bool& exact) {
+  exact = true;
+  if (ast.root < 0) return -1;
+  std::function<bool(int)> startsWithText = [&](int n) -> bool {     // Compiler.isPatternAnchored nfa/compile.go:1755-1769
+    const auto& x = ast.at(n);
+    if (x.kind == Node::BeginText) return true;
+    if ((x.kind == Node::Concat || x.kind == Node::Capture) && !x.kids.empty()) return startsWithText(x.kids[0]);
+    return false;
+  };
+  std::function<bool(int)> endsWithText = [&](int n) -> bool {       // isEndAnchored :1798-1824
+    const auto& x = ast.at(n);
+    switch (x.kind) {
+      case Node::EndText: return true;
+      case Node::Concat: return !x.kids.empty() && endsWithText(x.kids.back());
+      case Node::Capture: return !x.kids.empty() && endsWithText(x.kids[0]);
+      case Node::Alt: if (x.kids.empty()) return false; for (int c : x.kids) if (!endsWithText(c)) return false; return true;
+      default: return false;
+    }
+  };
+  std::function<bool(int)> anyEnd = [&](int n) -> bool {             // containsEndAnchor :1872-1888
+    const auto& x = ast.at(n);
+    switch (x.kind) {
+      case Node::EndText: case Node::EndLine: return true;
+      case Node::Concat: case Node::Alt: for (int c : x.kids) if (anyEnd(c)) return true; return false;
+      case Node::Capture: case Node::Star: case Node::Plus: case Node::Quest: case Node::Repeat: return !x.kids.empty() && anyEnd(x.kids[0]);
+      default: return false;
+    }
+  };
+  std::function<bool(int)> innerEnd = [&](int n) -> bool {           // hasInternalEndAnchor :1828-1856
+    const auto& x = ast.at(n);
+    switch (x.kind) {
+      case Node::Concat:
+        for (size_t k = 0; k + 1 < x.kids.size(); k++) if (anyEnd(x.kids[k])) return true;
+        return !x.kids.empty() && innerEnd(x.kids.back());
+      case Node::Capture: return !x.kids.empty() && innerEnd(x.kids[0]);
+      case Node::Alt: for (int c : x.kids) if (innerEnd(c)) return true; return false;
+      default: return false;
+    }
+  };
+  std::function<bool(int)> anyStart = [&](int n) -> bool {           // containsStartAnchor :1902-1926
+    const auto& x = ast.at(n);
+    switch (x.kind) {
+      case Node::BeginText: case Node::BeginLine: return true;
+      case Node::Concat: case Node::Alt: for (int c : x.kids) if (anyStart(c)) return true; return false;
+      case Node::Capture: case Node::Star: case Node::Plus: case Node::Quest: case Node::Repeat: return !x.kids.empty() && anyStart(x.kids[0]);
+      default: return false;
+    }
+  };
+  const bool startAnchored = startsWithText(ast.root);
+  const bool endAnchored = endsWithText(ast.root) && !innerEnd(ast.root);
+  if (endAnchored && !startAnchored && !anyStart(ast.root)) return CXG_USE_REVERSE_ANCHORED;
+  if (startAnchored) { exact = false; return CXG_USE_BOUNDED_BACKTRACKER; }
+  return -1;
+}
+
 bool boundedSurrogate(const Ast& ast, Ast& out, std::vector<std::pair<int, int>>& bounds) {
   bounds.clear();
   out = Ast();

@@ -63,7 +63,7 @@ struct HostNfa {
   }
 };
 
-HostNfa buildNfa(const Ast& ast);  // throws FrontendError(CXG_E_UNSUPPORTED) for look-around / non-ASCII classes
+HostNfa buildNfa(const Ast& ast);  // throws FrontendError(CXG_E_UNSUPPORTED) for text anchors, \p classes
 
 struct PrefixLit { std::vector<uint8_t> bytes; bool exact; };
 
@@ -78,6 +78,12 @@ struct Plan {
 };
 
 Plan selectStrategy(const Ast& ast, const HostNfa& nfa);
+
+// The first two rules of meta.SelectStrategy (strategy.go:1377-1440), which need no NFA: a pattern anchored at the end of the text
+// only is UseReverseAnchored; one anchored at its start is UseAnchoredLiteral / UseBranchDispatch / UseBoundedBacktracker (the
+// last is returned, `exact` = false: the two detectors are not restated).  -1: neither rule applies.  None of these strategies has a
+// device kernel (a start-anchored FindAll has one match at most); the answer only makes the refusal name the reference's engine.
+int textAnchorStrategy(const Ast& ast, bool& exact);
 
 // Bounded repetition on the chain kernel (program.cc attachBoundedChain): when the pattern is a concatenation of
 // single-byte items (a literal byte, a class) and runs of one (`x+`, `x{m,n}` with m >= 1, greedy) — `(?:...){k}` groups

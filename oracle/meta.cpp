@@ -535,8 +535,27 @@ Seq extractInner(const ReP& re) { Extractor e; return e.inner(re, 0); }
 static Strategy selectStrategy(const NFA& nfa, const ReP& re, const Seq& lits, bool& restated) {
   restated = true;
   bool startAnchored = nfa.anchored;
-  bool endAnchored = isEndAnchoredTail(re);  // internal-end-anchor refinement not restated
-  bool hasStartAnchor = anyOp(re, {OpBeginText});
+  // nfa.IsPatternEndAnchored (nfa/compile.go:1785-1795): ends with \z / $ and holds no end anchor anywhere else (`(a$)b$`)
+  std::function<bool(const ReP&)> anyEndAnchor = [&](const ReP& r) -> bool {          // containsEndAnchor :1872-1888
+    switch (r->op) {
+      case OpEndText: case OpEndLine: return true;
+      case OpConcat: case OpAlternate: for (auto& x : r->sub) if (anyEndAnchor(x)) return true; return false;
+      case OpCapture: case OpStar: case OpPlus: case OpQuest: case OpRepeat: return !r->sub.empty() && anyEndAnchor(r->sub[0]);
+      default: return false;
+    }
+  };
+  std::function<bool(const ReP&)> internalEndAnchor = [&](const ReP& r) -> bool {     // hasInternalEndAnchor :1828-1856
+    switch (r->op) {
+      case OpConcat:
+        for (size_t i = 0; i + 1 < r->sub.size(); i++) if (anyEndAnchor(r->sub[i])) return true;
+        return !r->sub.empty() && internalEndAnchor(r->sub.back());
+      case OpCapture: return !r->sub.empty() && internalEndAnchor(r->sub[0]);
+      case OpAlternate: for (auto& x : r->sub) if (internalEndAnchor(x)) return true; return false;
+      default: return false;
+    }
+  };
+  bool endAnchored = isEndAnchoredTail(re) && !internalEndAnchor(re);
+  bool hasStartAnchor = anyOp(re, {OpBeginText, OpBeginLine});   // IsPatternStartAnchored :1897-1926: ^ of either kind, in any branch
   if (hasFold(re)) restated = false;
   if (endAnchored && !startAnchored && !hasStartAnchor) { restated = false; return UseReverseAnchored; }
   if (startAnchored) { restated = false; return UseBoundedBacktracker; }  // or AnchoredLiteral / BranchDispatch

@@ -810,17 +810,25 @@ def test_host_side_under_address_and_ub_sanitizers():
 def test_product_frontend_pinned_on_reference_strategy_rows():
     """`cxg_compile` (the product's own C++ front-end, not the oracle) directly against the rows of the
     reference's strategy table (meta/strategy_selection_test.go:16-63, :323-352, transcribed in tests/golden/reference_vectors.json).
-    Every row inside the accepted subset must give the reference's strategy; the rows the front-end refuses are the three
-    end-of-text patterns (text anchors: `frontend.cc` unsupported()) — named here so that a silent change shows."""
+    Every row gives the reference's strategy — since late round 3 also the three end-of-text patterns (UseReverseAnchored: the
+    anchor rules at the head of meta.SelectStrategy, frontend.cc textAnchorStrategy), which stay refused for the device as every
+    strategy without a kernel."""
     import json
     vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
-    refused = []
-    for c in vec["strategy_selection"]["cases"]:
+    rows = vec["strategy_selection"]["cases"]
+    assert len(rows) >= 27
+    for c in rows:
         rx = cx.compile(c["pattern"])
-        if rx.strategy != c["want"]:
-            refused.append((c["pattern"], c["want"], rx.strategy, rx.supported))
-    assert sorted(p for p, *_ in refused) == sorted(["hello$", "world$", r"\.txt$"]), refused
-    assert all(not sup for *_, sup in refused)           # never served with another strategy's semantics
+        assert rx.strategy == c["want"], (c, rx.strategy)
+        if c["want"] == "UseReverseAnchored":
+            assert not rx.supported and "UseReverseAnchored" in rx.why_unsupported
+    # the refinements of nfa.IsPatternEndAnchored / IsPatternStartAnchored (nfa/compile.go:1785-1926): an end anchor that is not
+    # the pattern's last element, or a start anchor of either kind in any branch, rule UseReverseAnchored out
+    for pat, rev in [("(foo$)", True), (r"x\z", True), ("a$|b$", True), ("(a$)b$", False), ("a$|b", False), (r"(?m)^foo\z", False), ("^a?$|^b?$", False)]:
+        assert (cx.compile(pat).strategy == "UseReverseAnchored") == rev, pat
+    for pat in ("^foo", r"\Afoo", "^foo$", "(^a)b"):
+        rx = cx.compile(pat)
+        assert rx.strategy == "UseBoundedBacktracker" and not rx.supported, pat      # (or UseAnchoredLiteral / UseBranchDispatch: not restated)
 
 
 def _teddy_literals_of(blob: bytes):
