@@ -11,11 +11,12 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from refcorpus import COMPAT_PATTERNS, generate_test_input, span_hash  # noqa: E402
+from refcorpus import COMPAT_PATTERNS, COMPAT_PATTERNS_WIDE, generate_test_input, span_hash  # noqa: E402
 
 corpus = generate_test_input()
 out = {"_generator": "tests/golden/gen_corpus_expected.py (python re, bytes mode)", "corpus_len": len(corpus), "patterns": {}}
-for name, pat in COMPAT_PATTERNS.items():
+out["patterns_wide"] = {}
+for name, pat, key in [(n, p, "patterns") for n, p in COMPAT_PATTERNS.items()] + [(n, p, "patterns_wide") for n, p in COMPAT_PATTERNS_WIDE.items()]:
     rx = re.compile(pat.encode())
     groups = rx.groups
     spans = [list(m.span()) for m in rx.finditer(corpus)]
@@ -24,7 +25,7 @@ for name, pat in COMPAT_PATTERNS.items():
         rows = [[x for g in range(groups + 1) for x in m.span(g)] for m in rx.finditer(corpus)]
         entry["submatch_first"] = rows[:2]
         entry["submatch_hash"] = "%016x" % span_hash(rows)
-    out["patterns"][name] = entry
+    out[key][name] = entry
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "corpus_expected.json")
 with open(path, "w") as f:
     json.dump(out, f, indent=1)

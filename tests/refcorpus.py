@@ -54,7 +54,7 @@ def generate_test_input() -> bytes:
 
 
 # Patterns of the reference's TestStdlibCompatibility table (meta/stdlib_compat_test.go:27-67)
-# that lie inside the restated ASCII subset (no '.', no negated / Unicode classes).
+# that lay inside the restated subset of rounds 1-3 (no '.', no negated / Unicode classes); COMPAT_PATTERNS_WIDE below has more.
 COMPAT_PATTERNS = {
     "literal_alt": r"error|warning|fatal|critical",
     "multi_literal": r"apple|banana|cherry|date|elderberry|fig|grape|honeydew|kiwi|lemon|mango|orange",
@@ -77,6 +77,23 @@ COMPAT_PATTERNS = {
     "multiline_anchor": r"(?m)^line",
     "error_literal": r"error",
     "email_captures": r"(\w+)@(\w+)\.(\w+)",
+}
+
+
+# More rows of the same table, expressible since `.` and negated classes are restated (late round 3).  CPU tier only: the oracle is
+# pinned on them, and the device twins where the product serves the pattern; the (?i) rows, `a*` and `.*` (empty matches) stay out.
+COMPAT_PATTERNS_WIDE = {
+    "anchored": r"^HTTP/[12]\.[01]",
+    "inner_literal": r".*@example\.com",
+    "suffix": r".*\.(txt|log|md)",
+    "uri": r"[\w]+://[^/\s?#]+[^\s?#]+(?:\?[^\s#]*)?(?:#[^\s]*)?",
+    "anchored_php": r"^/.*[\w-]+\.php",
+    "multiline_php": r"(?m)^/.*\.php",
+    "la_api_calls": r"(?m)^(?:GET|POST|PUT|DELETE|PATCH)\s+/api/\S+",
+    "la_post_requests": r"(?m)^POST\s+\S+",
+    "la_methods": r"(?m)^(GET|POST|PUT|DELETE|PATCH|HEAD|OPTIONS)\s",
+    "la_passwords": r"(?m)^(?:GET|POST)\s+\S*(?:password|passwd|pwd|pass)\S*",
+    "la_sessions": r"(?m)^(?:GET|POST)\s+\S*session\S*",
 }
 
 

@@ -899,3 +899,25 @@ def test_use_both_restart_rule_equals_the_reference_iteration(oracle):
             exp = o.find_all_index(a)
             got = by_rule(o, a)
             assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:80])
+
+
+def test_wide_rows_of_the_reference_compat_table(oracle):
+    """The rows of meta/stdlib_compat_test.go:27-67 with `.`, `\\S`, negated classes or text anchors (refcorpus.COMPAT_PATTERNS_WIDE):
+    the product front-end names the oracle's strategy for each — reverse searchers, the multi-line reverse suffix, the engines of
+    start-anchored patterns —, refuses what has no device kernel, and the rows it serves come out of the transducer twin as the
+    golden spans (tests/golden/corpus_expected.json, stdlib semantics)."""
+    import json
+    from refcorpus import COMPAT_PATTERNS_WIDE, generate_test_input, span_hash
+    corpus = np.frombuffer(generate_test_input(), dtype=np.uint8)
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus_expected.json")))["patterns_wide"]
+    served = 0
+    for name, pat in COMPAT_PATTERNS_WIDE.items():
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.strategy == o.strategy, (name, rx.strategy, o.strategy)
+        if not rx.supported:
+            assert rx.why_unsupported, name
+            continue
+        served += 1
+        got = emu.find_all_fsm(rx.fsm_image(), corpus, 3840, 32)
+        assert not isinstance(got, int) and len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name
+    assert served >= 1

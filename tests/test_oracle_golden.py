@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from refcorpus import COMPAT_PATTERNS, generate_test_input, span_hash
+from refcorpus import COMPAT_PATTERNS, COMPAT_PATTERNS_WIDE, generate_test_input, span_hash
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
@@ -432,3 +432,21 @@ def test_dot_and_negated_classes_against_python_re_on_ascii_text(oracle):
             assert o.find_all_index(hay).tolist() == [list(m.span()) for m in pr.finditer(hay)], (pat, o.strategy, hay[:60])
             checked += 1
     assert checked > 500
+
+
+@pytest.mark.parametrize("name", sorted(COMPAT_PATTERNS_WIDE))
+def test_compat_corpus_wide_rows(oracle, name):
+    """More rows of meta/stdlib_compat_test.go:27-67 — the ones with `.`, `\\S`, negated classes and text anchors — on the same
+    corpus: FindAllIndex and Count of the oracle against the stdlib answer (Python `re`, gen_corpus_expected.py).  Whatever
+    strategy the reference picks for them (reverse searchers, bounded backtracker, ...) the rows are the leftmost-first ones."""
+    corpus = generate_test_input()
+    exp = CORPUS["patterns_wide"][name]
+    rx = oracle.Regex(COMPAT_PATTERNS_WIDE[name])
+    got = rx.find_all_index(corpus)
+    assert len(got) == exp["count"], (name, rx.strategy)
+    assert got[:3].tolist() == exp["first"] and got[-1:].tolist() == exp["last"]
+    assert "%016x" % span_hash(got) == exp["hash"]
+    assert rx.count(corpus) == exp["count"]
+    if "submatch_hash" in exp:
+        rows = rx.find_all_submatch_index(corpus)
+        assert "%016x" % span_hash(rows) == exp["submatch_hash"]
