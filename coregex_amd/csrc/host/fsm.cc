@@ -8,6 +8,8 @@
 // see fsm.hpp — so the machine runs left to right without ever moving back.
 #include "fsm.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -80,7 +82,28 @@ struct Stepper {
 
 }  // namespace
 
+namespace {
+bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa, uint32_t rowBudget);
+}
+
+// The uncertainty rows (sets of possible entry states) are an optimisation of the table, not part of the machine: a set that is
+// not tabulated maps to the absorbing wide row and the chunk's entry is resolved by the maps / the fallback instead.  When the
+// image does not fit the LDS budget with 512 of them, fewer are tabulated before the program is given up (the
+// in-loop estimate undercounts a row — (classes + 3) entries rounded up to a power of two — and knows nothing of the alias rows,
+// the member lists and the reverse table, so the hard checks used to reject images that fit with fewer set rows).
 bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa) {
+  static const bool noRetry = getenv("CXG_FSM_NO_SET_ROW_RETRY") != nullptr;   // A/B: round 2's behaviour (512 rows or nothing)
+  for (uint32_t budget = 512; budget >= 1; budget /= 4) {
+    if (noRetry && budget != 512) break;
+    why.clear();
+    if (buildFsmImageCapped(nfa, rev, max_len, image, why, revNfa, budget)) return true;
+    if (why.find("exceeds the LDS budget") == std::string::npos) return false;
+  }
+  return false;
+}
+
+namespace {
+bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa, const uint32_t rowBudget) {
   image.clear();
   bool hasWord = false, hasLine = false;
   for (uint32_t i = 0; i < nfa.n_states; i++)
@@ -220,7 +243,7 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   std::vector<std::vector<uint8_t>> sets;
   std::vector<std::vector<uint16_t>> utrans;
   bool wideUsed = false;
-  const uint32_t rowBudget = 512;                              // sets tabulated at most; the rest maps to the wide row
+  // (rowBudget: sets tabulated at most; the rest maps to the wide row)
   {
     std::vector<uint8_t> top(nT);
     for (uint32_t i = 0; i < nT; i++) top[i] = static_cast<uint8_t>(i);
@@ -402,5 +425,6 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
   image.swap(img);
   return true;
 }
+}  // namespace
 
 }  // namespace cxg

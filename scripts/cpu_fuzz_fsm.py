@@ -22,6 +22,8 @@ LOOK_ATOMS = [r"\b", r"\B", r"\b", "_", "[a-c_]+", r"\w+", "ab", " ", "A", r"\d+
 # `.` and classes past U+007F (UTF-8 byte automata): mode "wide"; the haystacks then hold multi-byte sequences and stray bytes >= 0x80
 WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D", r"\W", r"[^a-c]+", r"[^\n]*", "(.)", r"(\S+)", r'"[^"]*"', "é", "[aé]", r"[^:]*:", ".+?", r"\D+?", "x.y", "(?s:.)"]
 
+LEN_RANGE = tuple(int(v) for v in os.environ.get("FUZZ_ATOMS", "1,5").split(","))   # atoms per pattern: [lo, hi)
+
 def main(n=300, seed=1, look=False, wide=False):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n" + (b"_A  __" if look else b""), dtype=np.uint8)
@@ -33,7 +35,7 @@ def main(n=300, seed=1, look=False, wide=False):
     n_caps = 0
     t0 = time.time()
     while len(seen) < n:
-        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+        pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(*LEN_RANGE))))
         if pat in seen: continue
         if wide and not look and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")): continue
         if look:
