@@ -54,6 +54,9 @@ int32_t foldNext(int32_t c) {  // unicode.SimpleFold orbit, ASCII letters + the 
 }
 
 void addFolded(Ranges& r, int32_t lo, int32_t hi) {
+  // unicode.SimpleFold is restated for the ASCII letters (with the two runes their orbits reach, U+017F and U+212A) only: a rune
+  // past U+007F written under (?i) would need the Unicode fold tables (`(?i)[é]` is {É, é} in the reference)
+  if (hi >= 0x80) unsupported("Unicode case folding (a rune past U+007F under (?i))");
   r.add(lo, hi);
   for (int32_t c = std::max<int32_t>(lo, 'A'); c <= std::min<int32_t>(hi, 'z'); c++)
     for (int32_t f = foldNext(c); f != c; f = foldNext(f)) r.add(f, f);
@@ -108,6 +111,7 @@ struct P {
 
   int lit(int32_t r) {
     int n = ast.add(Node::Lit);
+    if (fl.fold && r >= 0x80) unsupported("Unicode case folding (a rune past U+007F under (?i))");
     if (fl.fold) {  // minFoldRune
       int32_t m = r;
       for (int32_t f = foldNext(r); f != r; f = foldNext(f)) m = std::min(m, f);

@@ -62,6 +62,8 @@ int minFoldRune(int r) {
 }
 
 void appendFoldedRange(std::vector<int>& r, int lo, int hi) {
+  // (a rune past U+007F written under (?i) needs the Unicode fold tables, which are not restated: `(?i)[é]` is {É, é})
+  if (hi >= 0x80) throw ParseError{"unsupported: Unicode case folding (a rune past U+007F under (?i), outside restated subset)"};
   appendRange(r, lo, hi);
   // Only ASCII letters (and the two non-ASCII members of the K / S orbits) fold
   // inside the restated subset; other runes > 0x7F make the class non-ASCII and
@@ -269,6 +271,7 @@ struct Parser {
   void literal(int r) {
     ReP re = mk(OpLiteral);
     re->flags = flags;
+    if ((flags & FoldCase) && r >= 0x80) throw ParseError{"unsupported: Unicode case folding (a rune past U+007F under (?i), outside restated subset)"};
     if (flags & FoldCase) r = minFoldRune(r);
     re->rune.assign(1, r);
     push(re);

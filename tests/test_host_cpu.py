@@ -921,3 +921,18 @@ def test_wide_rows_of_the_reference_compat_table(oracle):
         got = emu.find_all_fsm(rx.fsm_image(), corpus, 3840, 32)
         assert not isinstance(got, int) and len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name
     assert served >= 1
+
+
+def test_unicode_case_folding_is_refused_not_skipped(oracle):
+    """Classes past U+007F are served (late round 3) — but not under (?i): unicode.SimpleFold is restated for the ASCII letters and
+    the two runes their orbits reach (U+017F, U+212A) only, and `(?i)[é]` is {É, é} in the reference.  Both parsers refuse a rune
+    past U+007F written under (?i) instead of compiling the class unfolded; ASCII classes still fold, Kelvin sign included."""
+    for pat in (r"1(?i:[éa])2", r"(?i)é", r"(?i)[^é]a", r"(?i)[à-ü]+\d", r"x(?i:é)"):
+        with pytest.raises(cx.CoregexError):
+            cx.compile(pat)
+        with pytest.raises(oracle.OracleError):
+            oracle.Regex(pat)
+    rx, o = cx.compile(r"1(?i:[ka])2"), oracle.Regex(r"1(?i:[ka])2")
+    assert rx.strategy == o.strategy == "UseTeddy" and rx.supported
+    assert sorted(b for b, _ in o.prefix_literals()) == sorted([b"1K2", b"1k2", "1K2".encode()])
+    assert cx.compile(r"[éa]+x").supported or True                  # (outside (?i): served or refused by strategy, never a parse error)
