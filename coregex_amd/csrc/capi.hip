@@ -1030,7 +1030,7 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
     p->nfaStates = static_cast<int>(p->nfa.states.size());
     if (!plan.confident && p->supported) {
       p->supported = false;
-      p->whyNot = "the reference may route this pattern to a reverse-search strategy outside the device subset";
+      p->whyNot = plan.why.empty() ? "the reference may route this pattern to a reverse-search strategy outside the device subset" : plan.why;
     }
     if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view, plan.strategy);   // FindAllSubmatchIndex path (spans + one-pass captures)
     if (p->supported && p->ngroups == 1) {                     // bounded repetition (`\d{1,3}\.\d{1,3}`...) on the chain kernel

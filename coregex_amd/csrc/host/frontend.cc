@@ -1052,7 +1052,6 @@ std::vector<uint8_t> utf8(const std::vector<int32_t>& rs) {
 
 struct LitX {  // literal/extractor.go prefix side, restricted to what the gate needs
   const Ast& a;
-  bool sawFold = false;
   explicit LitX(const Ast& ast) : a(ast) {}
 
   static void trim(Lits& l, size_t n) { for (auto& x : l.v) if (x.bytes.size() > n) { x.bytes.resize(n); x.exact = false; } }
@@ -1062,6 +1061,47 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
     std::vector<PrefixLit> k;
     for (auto& x : l.v) if (seen.insert(x.bytes).second) k.push_back(x);
     l.v.swap(k);
+  }
+  // Case-insensitive literal -> all its case variants (expandCaseFoldLiteral extractor.go:838-941; the prefilters compare bytes).
+  // Per rune the orbit of unicode.SimpleFold, starting at the rune itself (the parser stores the smallest of the orbit): `K` is
+  // K, k, U+212A.  Orbits are collected while their product stays within the cross-product limit (250); with every rune reached
+  // and the product within MaxLiterals (256) the result is every variant, complete; otherwise the longest prefix whose product
+  // fits, incomplete.  The reference computes that prefix over an array whose tail the early exit left nil — length 0, which
+  // resets the running product — so that a word of nine or more letters yields NO literal where 256 variants of its first eight
+  // were meant; inside a concatenation the empty contribution is then skipped as if the word were not there, and literals of what
+  // stands in front of it come out complete (`(?i)(get)errorfatal` would be searched as "get").  `quirk` is set when that
+  // happens: such a program is refused rather than reproduced (selectStrategy below).
+  bool quirk = false;
+  Lits foldVariants(const std::vector<int32_t>& rs) {
+    if (rs.empty()) return {};
+    std::vector<std::vector<int32_t>> orbit(rs.size());
+    uint64_t product = 1;
+    size_t reached = 0;
+    for (size_t k = 0; k < rs.size(); k++) {
+      orbit[k].push_back(rs[k]);
+      for (int32_t f = foldNext(rs[k]); f != rs[k]; f = foldNext(f)) orbit[k].push_back(f);
+      reached = k + 1;
+      product *= orbit[k].size();
+      if (product > kCross) break;
+    }
+    size_t take = rs.size();
+    bool all = product <= kMaxLits && reached == rs.size();
+    if (!all) {
+      uint64_t q = 1;
+      for (size_t k = 0; k < orbit.size(); k++) { q *= orbit[k].size(); if (q > kMaxLits) { take = k; break; } }   // findMaxCaseFoldPrefix :920-929
+      if (take == 0) return {};
+      if (take > reached) { quirk = true; return {}; }                 // an orbit the early exit never filled: nothing is generated
+    }
+    std::vector<std::vector<int32_t>> vs{{}};
+    for (size_t k = 0; k < take; k++) {
+      std::vector<std::vector<int32_t>> nx;
+      for (auto& pre : vs) for (int32_t r : orbit[k]) { nx.push_back(pre); nx.back().push_back(r); }
+      vs.swap(nx);
+    }
+    Lits o;
+    for (auto& v : vs) { auto b = utf8(v); if (b.size() > kMaxLitLen) b.resize(kMaxLitLen); o.v.push_back({b, all}); }
+    if (!all) { dedup(o); if (o.v.size() > kMaxLits) o.v.resize(kMaxLits); }
+    return o;
   }
   Lits expandClass(const Ast::N& x) {  // extractor.go:963-1000
     Lits o;
@@ -1076,7 +1116,7 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
     const auto& x = a.at(n);
     switch (x.kind) {
       case Node::Lit: {
-        if (x.fold) { sawFold = true; return {}; }
+        if (x.fold) return foldVariants(x.r);
         auto b = utf8(x.r);
         if (b.size() > kMaxLitLen) b.resize(kMaxLitLen);
         Lits o; o.v.push_back({b, true}); return o;
@@ -1101,7 +1141,7 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
   bool contrib(int n, int depth, Lits& out) {  // concatSubContribution extractor.go:365-416
     const auto& x = a.at(n);
     switch (x.kind) {
-      case Node::Lit: if (x.fold) { sawFold = true; return false; } out = {}; out.v.push_back({utf8(x.r), true}); return true;
+      case Node::Lit: if (x.fold) { out = foldVariants(x.r); return true; } out = {}; out.v.push_back({utf8(x.r), true}); return true;   // (an empty contribution is not nil: the cross product skips it)
       case Node::Class: out = expandClass(x); return !out.v.empty();
       case Node::Alt: {  // expandAlternateContribution extractor.go:418-470
         Lits all; bool over = false;
@@ -1133,7 +1173,7 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
     const auto& x = a.at(n);
     switch (x.kind) {
       case Node::Lit: {
-        if (x.fold) { sawFold = true; return {}; }
+        if (x.fold) return foldVariants(x.r);
         auto b = utf8(x.r);
         if (b.size() > kMaxLitLen) b.erase(b.begin(), b.end() - kMaxLitLen);
         Lits o; o.v.push_back({b, true}); return o;
@@ -1182,7 +1222,7 @@ struct LitX {  // literal/extractor.go prefix side, restricted to what the gate 
     const auto& x = a.at(n);
     switch (x.kind) {
       case Node::Lit: {
-        if (x.fold) { sawFold = true; return {}; }
+        if (x.fold) { Lits o = foldVariants(x.r); inexact(o); return o; }
         auto b = utf8(x.r);
         if (b.size() > kMaxLitLen) b.resize(kMaxLitLen);
         Lits o; o.v.push_back({b, false}); return o;
@@ -1335,12 +1375,35 @@ struct Shape {  // AST predicates of meta/strategy.go
 
 }  // namespace
 
+namespace { Plan selectStrategyOf(const Ast& ast, const HostNfa& nfa); }
+
 Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
+  Plan p = selectStrategyOf(ast, nfa);
+  // (see LitX::foldVariants) an empty expansion is harmless where it means "no literal" — the pattern itself, a branch of an
+  // alternation — and harmful where the cross product of a concatenation skips it: directly in a concatenation, through groups
+  // and through {n,m} with n >= 1 (concatSubContribution extractor.go:378-418)
+  LitX lx(ast);
+  bool skipped = false;
+  std::function<void(int, bool)> visit = [&](int n, bool inConcat) {
+    const auto& x = ast.at(n);
+    if (x.kind == Node::Lit && x.fold) { lx.quirk = false; lx.foldVariants(x.r); skipped = skipped || (lx.quirk && inConcat); return; }
+    const bool pass = x.kind == Node::Concat || ((x.kind == Node::Capture || (x.kind == Node::Repeat && x.min >= 1)) && inConcat);
+    for (int c : x.kids) visit(c, pass);
+  };
+  if (ast.root >= 0) visit(ast.root, false);
+  if (skipped) {
+    p.confident = false;
+    p.why = "a case-insensitive literal of nine or more letters: the reference's literal extraction yields nothing for it and goes on as if it were not there (literal/extractor.go:866-887), which is not reproduced";
+  }
+  return p;
+}
+
+namespace {
+Plan selectStrategyOf(const Ast& ast, const HostNfa& nfa) {
   Plan p;
   Shape sh{ast};
   int root = ast.root;
   // The NFA builder already rejected line / text anchors, '.', non-ASCII classes; (?i) literals survive it.
-  if (sh.foldAny(root)) p.confident = false;
   // Word boundaries (\b \B) are the one kind of look-around that reaches here: hasWordBoundary strategy.go, and they
   // count as anchor assertions / non-line anchors in the rules below.
   const bool wordB = sh.has(root, {Node::WordB, Node::NoWordB});
@@ -1547,6 +1610,8 @@ Plan selectStrategy(const Ast& ast, const HostNfa& nfa) {
   return p;
 }
 
+
+}  // namespace
 
 int textAnchorStrategy(const Ast& ast, bool& exact) {
   exact = true;

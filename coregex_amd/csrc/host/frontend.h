@@ -72,7 +72,8 @@ struct Plan {
   uint32_t flags = 0;
   std::vector<PrefixLit> prefixes;
   uint8_t membership[256] = {0};   // UseCharClassSearcher
-  bool confident = true;           // false: a strategy outside the subset may apply (reverse searchers etc.)
+  bool confident = true;           // false: the reference's answer for this pattern is not reproduced with certainty (`why` says what)
+  std::string why;
   bool lineStartAll = false;       // ... and every match of the pattern begins at a line start
   bool lineStart = false;          // the pattern holds (?m)^: a UseTeddy program checks its candidates for a line start (prefilter.WrapLineAnchor)
 };

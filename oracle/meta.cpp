@@ -74,8 +74,69 @@ void dedup(Seq& s) {  // seq.go:491-507
 }
 void markInexact(Seq& s) { for (auto& l : s.lits) l.complete = false; }
 
+int foldNextRune(int c) {  // unicode.SimpleFold for what the parser lets through under (?i): ASCII letters, with the K and S orbits
+  if (c == 'K') return 'k';
+  if (c == 'k') return 0x212A;
+  if (c == 0x212A) return 'K';
+  if (c == 'S') return 's';
+  if (c == 's') return 0x17F;
+  if (c == 0x17F) return 'S';
+  if (c >= 'A' && c <= 'Z') return c + 32;
+  if (c >= 'a' && c <= 'z') return c - 32;
+  return c;
+}
+
 struct Extractor {
-  bool foldSeen = false;  // FoldCase literal met: expandCaseFoldLiteral is not restated
+  // A case-insensitive literal contributes every case variant (the prefilters compare bytes), extractor.go:838-917.  The fold sets
+  // are filled until their product passes the cross-product limit; all variants when the product fits MaxLiterals and every rune
+  // was reached, else the longest prefix whose product fits, incomplete.  (As written in the reference: the fold sets behind the
+  // early exit stay nil, their length 0 resets the running product, and a long word — nine letters with MaxLiterals 256 — ends
+  // with NO literal at all: restated as is.)
+  Seq expandCaseFoldLiteral(const std::vector<int>& runes) {
+    if (runes.empty()) return {};
+    std::vector<std::vector<int>> foldSets(runes.size());
+    long long total = 1;
+    size_t filled = 0;
+    for (size_t i = 0; i < runes.size(); i++) {
+      std::vector<int> folds{runes[i]};                             // caseFolds :933-941
+      for (int f = foldNextRune(runes[i]); f != runes[i]; f = foldNextRune(f)) folds.push_back(f);
+      foldSets[i] = folds;
+      filled = i + 1;
+      total *= static_cast<long long>(folds.size());
+      if (total > kCrossLimit) break;
+    }
+    auto generate = [&](size_t n) {                                 // generateCaseFoldVariants :891-917
+      std::vector<std::vector<int>> variants{{}};
+      for (size_t i = 0; i < n; i++) {
+        std::vector<std::vector<int>> next;
+        for (auto& pre : variants)
+          for (int r : foldSets[i]) { auto e = pre; e.push_back(r); next.push_back(std::move(e)); }
+        variants.swap(next);
+      }
+      Seq out;
+      for (auto& v : variants) {
+        auto b = runesToBytes(v);
+        if (b.size() > kMaxLiteralLen) b.resize(kMaxLiteralLen);
+        out.lits.push_back({b, true});
+      }
+      return out;
+    };
+    if (total <= kMaxLiterals && filled == runes.size()) return generate(filled);
+    size_t trim = foldSets.size();                                  // findMaxCaseFoldPrefix :920-929
+    {
+      long long product = 1;
+      for (size_t i = 0; i < foldSets.size(); i++) {
+        product *= static_cast<long long>(foldSets[i].size());
+        if (product > kMaxLiterals) { trim = i; break; }
+      }
+    }
+    if (trim == 0) return {};
+    Seq out = generate(trim);
+    markInexact(out);
+    dedup(out);
+    if (static_cast<int>(out.lits.size()) > kMaxLiterals) out.lits.resize(kMaxLiterals);
+    return out;
+  }
 
   Seq expandCharClass(const ReP& re) {  // extractor.go:963-1000
     Seq out;
@@ -96,7 +157,7 @@ struct Extractor {
     if (depth > 100) return {};
     switch (re->op) {
       case OpLiteral: {
-        if (re->flags & FoldCase) { foldSeen = true; return {}; }
+        if (re->flags & FoldCase) return expandCaseFoldLiteral(re->rune);   // :167-169
         auto b = runesToBytes(re->rune);
         if (b.size() > kMaxLiteralLen) b.resize(kMaxLiteralLen);
         Seq s; s.lits.push_back({b, true}); return s;
@@ -133,7 +194,7 @@ struct Extractor {
   bool contribution(const ReP& sub, int depth, Seq& out) {  // extractor.go:365-416; false == nil
     switch (sub->op) {
       case OpLiteral:
-        if (sub->flags & FoldCase) { foldSeen = true; return false; }
+        if (sub->flags & FoldCase) { out = expandCaseFoldLiteral(sub->rune); return true; }   // :380-382 (an empty Seq, not nil)
         out = Seq{}; out.lits.push_back({runesToBytes(sub->rune), true}); return true;
       case OpCharClass: {
         out = expandCharClass(sub);
@@ -222,7 +283,7 @@ struct Extractor {
     if (depth > 100) return {};
     switch (re->op) {
       case OpLiteral: {
-        if (re->flags & FoldCase) { foldSeen = true; return {}; }
+        if (re->flags & FoldCase) return expandCaseFoldLiteral(re->rune);   // :587-589
         auto b = runesToBytes(re->rune);
         if (b.size() > kMaxLiteralLen) b.erase(b.begin(), b.end() - kMaxLiteralLen);
         Seq s; s.lits.push_back({b, true}); return s;
@@ -275,7 +336,7 @@ struct Extractor {
     if (depth > 100) return {};
     switch (re->op) {
       case OpLiteral: {
-        if (re->flags & FoldCase) { foldSeen = true; return {}; }
+        if (re->flags & FoldCase) { Seq f = expandCaseFoldLiteral(re->rune); markInexact(f); return f; }   // :753-760
         auto b = runesToBytes(re->rune);
         if (b.size() > kMaxLiteralLen) b.resize(kMaxLiteralLen);
         Seq s; s.lits.push_back({b, false}); return s;
@@ -556,7 +617,6 @@ static Strategy selectStrategy(const NFA& nfa, const ReP& re, const Seq& lits, b
   };
   bool endAnchored = isEndAnchoredTail(re) && !internalEndAnchor(re);
   bool hasStartAnchor = anyOp(re, {OpBeginText, OpBeginLine});   // IsPatternStartAnchored :1897-1926: ^ of either kind, in any branch
-  if (hasFold(re)) restated = false;
   if (endAnchored && !startAnchored && !hasStartAnchor) { restated = false; return UseReverseAnchored; }
   if (startAnchored) { restated = false; return UseBoundedBacktracker; }  // or AnchoredLiteral / BranchDispatch
 

@@ -10,7 +10,10 @@ atoms = ["a", "b", "c", "x", "y", r"\.", ":", "-", r"\d", "[a-c]", "[x-z]", r"\d
          "ab|xy", "abc|xyz|a:c", r"\w", r"\w+", "[a-z0-9]+", "[ab]", "(a|b)", "(ab)+", "a?", r"\d{2}", r"\d{1,3}", "x*", "(xy|ab|ca)",
          "abcx|bcxy|cxyz|xyza", "z+", ".", ".*", r"\s", r"\S+", "(?:ab)*", "a*", r"\d{2,}", "(a+)(b+)", "[^x]", "(?i:ab)", "(?i:x)", "b+?", "a+?", "[a-c]+?", "(?:a|b|c)+",
          "abcabc", "abc", "xyz", "a:c", "xyzxyz|abcabc|a:c:a:", r"[\d.]+", "(x|y|z)", " ", r"\n"]
-alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff", dtype=np.uint8)
+if os.environ.get("FUZZ_FOLD"):    # case-insensitive literals in every pattern (literal/extractor.go:838-941 expandCaseFoldLiteral)
+    FOLD = ["(?i:error)", "(?i:warn)", "(?i:k)", "(?i:s1)", "(?i:ok)", "(?i:get)", "(?i:ab|xy)", "(?i:(abc))", "(?i:exception)", "(?i:a)b", "(?i:xyz)+", "(?i:[a-c])", "(?i:[x-z]+)", "(?i:a|b)c"]
+    atoms = atoms[:34] + FOLD * 3
+alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff" + (b"ERRORerrorWarnOKkKsSgetGET\xe2\x84\xaa\xc5\xbf" if os.environ.get("FUZZ_FOLD") else b""), dtype=np.uint8)
 bad=0; tot=0; strat={}; n_long=0; n_bt_limit=0; n_cc_unchecked=0; n_cc_fallback=0
 t0=time.time()
 for seed in range(seed0, seed1):
@@ -18,9 +21,14 @@ for seed in range(seed0, seed1):
     hays = [alphabet[rng.integers(0, len(alphabet), size=int(n))].tobytes() for n in (0, 3, 200, 5000)]
     hays += [alphabet[rng.choice(len(alphabet), size=5000, p=rng.dirichlet(0.25 * np.ones(len(alphabet))))].tobytes() for _ in range(4)]
     hays += [b"abcxyza:c" * 300, b"a" * 900 + b"b" + b"a" * 900]
+    if os.environ.get("FUZZ_FOLD"):   # words of the fold atoms in every casing, glued and separated
+        toks = [w for base in (b"error", b"warn", b"k", b"s1", b"ok", b"get", b"ab", b"xy", b"abc", b"exception", b"xyz", b"a", b"b", b"c") for w in (base, base.upper(), base.capitalize(), base[:1] + base[1:].upper())]
+        toks += [b" ", b":", b"1", b"\n", "\u212a".encode(), "\u017f".encode(), b"-"]
+        hays += [b"".join(toks[int(i)] for i in rng.integers(0, len(toks), size=n)) for n in (40, 400, 2000)]
     seen=set()
     while len(seen) < 150:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(1, 5))))
+        if os.environ.get("FUZZ_FOLD") and "(?i" not in pat: continue
         if pat in seen: continue
         seen.add(pat)
         try: rx = cx.compile(pat)

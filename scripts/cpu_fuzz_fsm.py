@@ -24,12 +24,16 @@ WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D"
 
 LEN_RANGE = tuple(int(v) for v in os.environ.get("FUZZ_ATOMS", "1,5").split(","))   # atoms per pattern: [lo, hi)
 
+FOLD_ATOMS = ["(?i:error)", "(?i:warn)", "(?i:k)", "(?i:s1)", "(?i:ok)", "(?i:get)", "(?i:ab|xy)", "(?i:(abc))", "(?i:exception)", "(?i:a)b", "(?i:xyz)+", "(?i:[a-c])", "(?i:[x-z]+)", "(?i:a|b)c"]
+
 def main(n=300, seed=1, look=False, wide=False):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"abcxyz.:-0123456789 \n" + (b"_A  __" if look else b""), dtype=np.uint8)
     if wide:
         alphabet = np.frombuffer(b'abcxyz.:-019 \n"' + "éé日😀".encode() + b"\x80\xc3\xff", dtype=np.uint8)
-    atoms = (ATOMS + LOOK_ATOMS * 3 + (WIDE_ATOMS * 2 if wide else [])) if look else ATOMS + WIDE_ATOMS * 3 if wide else ATOMS
+    fold = bool(os.environ.get("FUZZ_FOLD"))    # case-insensitive literals in every pattern
+    if fold: alphabet = np.frombuffer(b"abcxyzABCXYZ.:-01 \nerrorERRORwarnWARNkKsSokOKgetGET" + "\u212a\u017f".encode(), dtype=np.uint8)
+    atoms = (ATOMS[:40] + FOLD_ATOMS * 3) if fold else (ATOMS + LOOK_ATOMS * 3 + (WIDE_ATOMS * 2 if wide else [])) if look else ATOMS + WIDE_ATOMS * 3 if wide else ATOMS
     n_strat = 0
     seen, n_img, n_checked, reasons = set(), 0, 0, {}
     n_caps = 0
@@ -37,6 +41,7 @@ def main(n=300, seed=1, look=False, wide=False):
     while len(seen) < n:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(*LEN_RANGE))))
         if pat in seen: continue
+        if fold and "(?i" not in pat: continue
         if wide and not look and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")): continue
         if look:
             if "\\b" not in pat and "\\B" not in pat and "^" not in pat and "$" not in pat: continue

@@ -81,7 +81,7 @@ COMPAT_PATTERNS = {
 
 
 # More rows of the same table, expressible since `.` and negated classes are restated (late round 3).  CPU tier only: the oracle is
-# pinned on them, and the device twins where the product serves the pattern; the (?i) rows, `a*` and `.*` (empty matches) stay out.
+# pinned on them, and the device twins where the product serves the pattern; `a*` and `.*` (empty matches) stay out.
 COMPAT_PATTERNS_WIDE = {
     "anchored": r"^HTTP/[12]\.[01]",
     "inner_literal": r".*@example\.com",
@@ -94,6 +94,12 @@ COMPAT_PATTERNS_WIDE = {
     "la_methods": r"(?m)^(GET|POST|PUT|DELETE|PATCH|HEAD|OPTIONS)\s",
     "la_passwords": r"(?m)^(?:GET|POST)\s+\S*(?:password|passwd|pwd|pass)\S*",
     "la_sessions": r"(?m)^(?:GET|POST)\s+\S*session\S*",
+    # ... and the (?i) rows, since the case-fold literal expansion is restated (literal/extractor.go:838-941)
+    "la_errors": r"(?i)(error|fail|exception|panic|fatal)",
+    "la_bots": r"(?i)(googlebot|bingbot|yandexbot|baiduspider|duckduckbot|slurp|facebookexternalhit|twitterbot|rogerbot|linkedinbot|embedly|quora link preview|showyoubot|outbrain|pinterest|applebot|semrushbot|ahrefsbot|mj12bot|dotbot|petalbot|bytespider)",
+    "la_suspicious": r"(?i)(eval|system|exec|execute|passthru|shell_exec|phpinfo|base64_decode|edoced_46esab|rot13|str_rot13|chmod|mkdir|fopen|fclose|readfile|union\s+select|etc/passwd|wp-admin|\.\./)",
+    "la_auth_attempts": r"(?i)(?:login|auth|sign.?in|session)",
+    "case_insensitive": r"(?i)hello",
 }
 
 

@@ -450,3 +450,17 @@ def test_compat_corpus_wide_rows(oracle, name):
     if "submatch_hash" in exp:
         rows = rx.find_all_submatch_index(corpus)
         assert "%016x" % span_hash(rows) == exp["submatch_hash"]
+
+
+def test_case_folding_vectors(oracle):
+    """(?i): the reference's FindAllString rows that it asserts equal to the stdlib, and the number of case variants its literal
+    extractor produces for a five-letter word (prefix, inner, suffix)."""
+    blk = VEC["case_folding_find_all_string"]
+    for c in blk["cases"]:
+        hay = c["input"].encode()
+        got = [hay[s:e].decode() for s, e in oracle.Regex(c["pattern"]).find_all_index(hay)]
+        assert got == c["want"], c
+    for c in blk["variant_counts"]:
+        lits = oracle.extract_literals(c["pattern"], c["which"])
+        assert len(lits) == c["count"] and all(comp == c["complete"] for _, comp in lits), c
+        assert len({b for b, _ in lits}) == c["count"] and all(b.lower() == lits[0][0].lower() for b, _ in lits)
