@@ -936,3 +936,39 @@ def test_unicode_case_folding_is_refused_not_skipped(oracle):
     assert rx.strategy == o.strategy == "UseTeddy" and rx.supported
     assert sorted(b for b, _ in o.prefix_literals()) == sorted([b"1A2", b"1a2", b"1K2", b"1k2", "1\u212a2".encode()])
     assert cx.compile(r"[éa]+x").supported or True                  # (outside (?i): served or refused by strategy, never a parse error)
+
+
+def test_case_insensitive_programs_through_the_twins(oracle):
+    """The CPU half of tests/test_gpu_wide.py::test_case_insensitive_literals: the same patterns and the same word-rich text through the
+    sequential twins of the kernels their programs name (lane walks, Teddy wave twin, transducer twin, capture twin)."""
+    import struct
+    from refcorpus import generate_test_input
+    from test_gpu_wide import FOLD
+    rng = np.random.default_rng(3)
+    toks = [w for base in (b"error", b"hello", b"login", b"auth", b"signin", b"sign-in", b"session", b"fail", b"panic", b"fatal", b"exception", b"warn", b"warning",
+                           b"xyzw", b"k1", b"googlebot", b"bingbot", b"GET /index", b"error: disk")
+            for w in (base, base.upper(), base.capitalize(), base[:1] + base[1:].upper())] + [b" ", b"\n", b": ", "K1".encode(), "ſession".encode()]
+    words = b"".join(toks[int(i)] for i in rng.integers(0, len(toks), size=6000))
+    for pat in FOLD:
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.supported and rx.strategy == o.strategy, (pat, rx.why_unsupported)
+        blob = rx.blob()
+        kind, flags = struct.unpack_from("<II", blob, 4)
+        for hay in (generate_test_input()[:60000], words, b"", b"ERROR"):
+            exp = o.find_all_index(hay).tolist()
+            a = np.frombuffer(hay, dtype=np.uint8)
+            if kind != 5:
+                assert emu.find_all(blob, hay).tolist() == exp, (pat, "lanes", len(hay))
+            if rx.fsm_image() is not None:
+                got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32)
+                if isinstance(got, int) and got in (-18, -32):
+                    got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32, dense=1)
+                assert isinstance(got, int) or got.tolist() == exp, (pat, "transducer", len(hay))
+            if kind == 4 or (flags & 256):
+                got = emu.find_all_teddy_wave(blob, hay)
+                assert got is None or isinstance(got, int) or got.tolist() == exp, (pat, "teddy wave", len(hay))
+        if rx.num_groups > 1 and rx.submatch_supported:
+            sb, cb = rx.submatch_blobs()[:2]
+            exps = o.find_all_submatch_index(words)
+            got = emu.find_all_submatch(sb, cb, words, exps.shape[1])
+            assert got.shape == exps.shape and np.array_equal(got, exps), (pat, "captures")
