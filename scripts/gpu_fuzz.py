@@ -20,8 +20,12 @@ if LOOK:
                          "abc", "xyz", r"\d+", "abcx|bcxy|cxyz|xyza"]
 WIDE = bool(os.environ.get("FUZZ_WIDE"))      # `.` and classes past U+007F in every pattern; multi-byte sequences and stray bytes >= 0x80 in the haystacks
 WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D", r"\W", r"[^a-c]+", r"[^\n]*", "(.)", r"(\S+)", r'"[^"]*"', "é", "[aé]", r"[^:]*:", ".+?", r"\D+?", "x.y", "(?s:.)"]
+FOLD = bool(os.environ.get("FUZZ_FOLD"))      # a case-insensitive literal in every pattern (literal sets of case variants; never run on a device in round 3)
+FOLD_ATOMS = ["(?i:error)", "(?i:warn)", "(?i:k)", "(?i:s1)", "(?i:ok)", "(?i:get)", "(?i:ab|xy)", "(?i:(abc))", "(?i:exception)", "(?i:a)b", "(?i:xyz)+", "(?i:[a-c])", "(?i:[x-z]+)", "(?i:a|b)c"]
 if WIDE:
     atoms = atoms + WIDE_ATOMS * 3
+if FOLD:
+    atoms = atoms[:34] + FOLD_ATOMS * 3
 alphabet = np.frombuffer(b"abcxyz.:-0123456789 \nABX\x00\x7f\x80\xc3\xa9\xff" + (b"_ \n_a \n" if LOOK else b"") + ('"éé日😀'.encode() if WIDE else b""), dtype=np.uint8)
 T = 3840
 def rnd(n, p=None):
@@ -31,6 +35,11 @@ sk2 = np.ones(len(alphabet)); sk2[9:19] = 10; sk2 /= sk2.sum()
 hays = [rnd(0), rnd(5), rnd(T - 1), rnd(T + 1), rnd(32 * T), rnd(32 * T + 7, skew), rnd(70000, sk2), rnd(200000, skew),
         np.frombuffer((b"xyab" + b"." * 28) * 4000, dtype=np.uint8), np.frombuffer(b"abcxyza:c" * 9000, dtype=np.uint8),
         np.frombuffer((b"1.2.3.4 " * 7 + b"\n") * 3000, dtype=np.uint8), np.frombuffer(b"a" * 9000 + b"b" + b"a" * 70000, dtype=np.uint8)]
+if FOLD:
+    toks = [w for base in (b"error", b"warn", b"k", b"s1", b"ok", b"get", b"ab", b"xy", b"abc", b"exception", b"xyz", b"a", b"b", b"c") for w in (base, base.upper(), base.capitalize(), base[:1] + base[1:].upper())]
+    toks += [b" ", b":", b"1", b"\n", "\u212a".encode(), "\u017f".encode(), b"-"]
+    hays += [b"".join(toks[int(i)] for i in rng.integers(0, len(toks), size=n)) for n in (40, 4000, 60000)]
+    hays = [np.frombuffer(bytes(h), dtype=np.uint8) if not isinstance(h, np.ndarray) else h for h in hays]
 if os.environ.get("FUZZ_FEW"):
     # few-symbol haystacks of several groups (120 KiB each): the sets of possible entry states stay unresolved for long
     # stretches, so the transducer kernel's member maps, its serial chain and the tile / group hand-off do the work
@@ -51,6 +60,8 @@ while len(seen) < npat:
         if not any(t in pat for t in ("\\b", "\\B", "^", "$")):
             continue
         pat = "(?m)" + pat
+    if FOLD and "(?i" not in pat:
+        continue
     if WIDE and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")):
         continue
     if pat in seen:
