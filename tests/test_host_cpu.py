@@ -939,11 +939,11 @@ def test_unicode_case_folding_is_refused_not_skipped(oracle):
 
 
 def test_case_insensitive_programs_through_the_twins(oracle):
-    """The CPU half of tests/test_gpu_wide.py::test_case_insensitive_literals: the same patterns and the same word-rich text through the
+    """The CPU half of tests/test_zzz_gpu_fold.py::test_case_insensitive_literals: the same patterns and the same word-rich text through the
     sequential twins of the kernels their programs name (lane walks, Teddy wave twin, transducer twin, capture twin)."""
     import struct
     from refcorpus import generate_test_input
-    from test_gpu_wide import FOLD
+    from test_zzz_gpu_fold import FOLD
     rng = np.random.default_rng(3)
     toks = [w for base in (b"error", b"hello", b"login", b"auth", b"signin", b"sign-in", b"session", b"fail", b"panic", b"fatal", b"exception", b"warn", b"warning",
                            b"xyzw", b"k1", b"googlebot", b"bingbot", b"GET /index", b"error: disk")
