@@ -570,6 +570,18 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
     std::memset(&chain, 0, sizeof chain);
     bool hasLook = false;
     for (uint32_t i = 0; i < nfa.n_states; i++) hasLook = hasLook || nfa.states[i].kind == CXG_NFA_LOOK;
+    if (strategy == CXG_USE_BOUNDED_BACKTRACKER) {
+      // Unanchored programs of this strategy are concatenations / repetitions of character classes (isSimpleCharClass,
+      // strategy.go:1095-1128; anchored ones never get here).  The reference answers them with its bounded backtracker —
+      // priority-ordered depth-first search, first match wins: leftmost-first (nfa/backtrack.go:264-300, Longest is off) — while
+      // states x (remaining + 1) fits 32 M visited entries, and with the forward + reverse lazy DFA before that, i.e. for all
+      // but the last few hundred KiB of a large haystack (find_indices.go:1279-1283 -> :711-732; both DFAs are built for this
+      // strategy whatever the quantifiers, compile.go:207-217).  Two leftmost-first engines: the program is the DFA pair's,
+      // under the same proof that the lazy DFA's answer does not depend on its cache history.
+      if (hasLook) throw BuildError{CXG_E_UNSUPPORTED, "UseBoundedBacktracker program with assertions (the backtracker searches a slice of the haystack: no context in front of it)"};
+      strategy = CXG_USE_DFA;
+      flags |= CXG_FLAG_HAS_REVERSE_DFA;
+    }
     // A look-around program that passed its proof (lookdfa.cc) is the pattern's transducer and nothing else: no table-walking image.
     auto finishFsmOnly = [&](uint32_t maxLen) {
       HostNfa rn = reverseOf(nfa);

@@ -694,7 +694,7 @@ static Strategy selectStrategy(const NFA& nfa, const ReP& re, const Seq& lits, b
   std::vector<std::pair<uint8_t, uint8_t>> ranges;
   if (!good && !teddyLits && extractCharClassRanges(re, ranges)) return UseCharClassSearcher;
   if (!good && !teddyLits && isCompositeCharClassPattern(re)) { restated = false; return UseCompositeSearcher; }
-  if (!good && !teddyLits && isSimpleCharClass(re)) { restated = false; return UseBoundedBacktracker; }
+  if (!good && !teddyLits && isSimpleCharClass(re)) return UseBoundedBacktracker;   // (unanchored: findAt below restates its two engines)
   if (teddyLits && lits.allComplete() && !nonLineAnchors) return UseTeddy;     // selectLiteralStrategy :1143-1170
   if (acLits && lits.allComplete()) { restated = false; return UseAhoCorasick; }
   if (nfaSize <= 100 && isDigitLead(re)) return UseDigitPrefilter;             // shouldUseDigitPrefilter :511-523
@@ -779,6 +779,13 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
       e->teddyLineAnchor = anyOp(e->re, {OpBeginLine});
       break;
     }
+    case UseBoundedBacktracker:
+      if (!e->nfa.anchored) {   // buildReverseDFA compile.go:207-217: both lazy DFAs, for inputs past the backtracker's capacity
+        e->dfa.init(&e->nfa, true);
+        e->revNfa = reverseNFA(e->nfa);
+        e->revDfa.init(&e->revNfa, false);
+      }
+      break;
     case UseCharClassSearcher: {
       std::vector<std::pair<uint8_t, uint8_t>> ranges;
       extractCharClassRanges(e->re, ranges);
@@ -837,6 +844,25 @@ bool Engine::findAt(Bytes h, int64_t len, int64_t at, int64_t& s, int64_t& e) {
       }
       if (dfaGatesPikeVM && at < len && !dfa.isMatchAt(h, len, at)) return false;   // find_indices.go:396-400
       return pikevm.searchAt(h, len, at, s, e);
+    case UseBoundedBacktracker: {  // findIndicesBoundedBacktrackerAtWithState :1225-1300 (unanchored programs: classes only, no '.')
+      if (nfa.anchored || !dfa.nfa) return pikevm.searchAt(h, len, at, s, e);
+      const int64_t remaining = len - at;
+      // BoundedBacktracker.CanHandle (nfa/backtrack.go:139-143): states x (span + 1) visited entries within 32 M (:82)
+      if (static_cast<int64_t>(nfa.states.size()) * (remaining + 1) <= 32ll * 1024 * 1024) {
+        // Search(haystack[at:]): priority-ordered depth-first search per start position, first match wins (backtrack.go:264-300,
+        // :401-490) — the leftmost-first match of the slice, which is what the PikeVM reports
+        int64_t ss, ee;
+        if (!pikevm.searchAt(h + at, remaining, 0, ss, ee)) return false;
+        s = at + ss; e = at + ee;
+        return true;
+      }
+      int64_t end = dfa.searchAt(h, len, at);            // findIndicesBidirectionalDFALongest :711-732
+      if (end == -1) return false;
+      if (end == at) { s = e = at; return true; }
+      int64_t st = revDfa.searchReverse(h, len, at, end);
+      if (st < 0) return false;
+      s = st; e = end; return true;
+    }
     case UseBoth:  // findIndicesAdaptiveAtWithState :408-441
       if (dfa.nfa && !hasPrefilter) {   // e.prefilter == nil: selectPrefilter found nothing usable in the prefixes (NOT: no prefixes at all)
         int64_t end = dfa.searchAt(h, len, at);

@@ -510,7 +510,7 @@ def test_random_patterns(need_gpu, oracle):
             continue
         o = oracle.Regex(pat)
         assert rx.strategy == o.strategy, pat
-        if rx.supported:
+        if rx.supported and rx.strategy != "UseBoundedBacktracker":       # (spans of that strategy are served since the end of round 3: their first device run is tests/test_zzz_gpu_fold.py)
             n_ok += 1
             strategies.add(rx.strategy)
             for hay in hays:
@@ -909,7 +909,7 @@ def test_reference_kats_through_the_c_abi(need_gpu):
             rx = cx.compile(pat)
         except cx.CoregexError:
             return
-        if not rx.supported:
+        if not rx.supported or rx.strategy == "UseBoundedBacktracker":     # (that strategy's first device run: tests/test_zzz_gpu_fold.py)
             return
         n += 1
         assert rx.find_all_index(hay, limit).tolist() == want_rows, (pat, hay)
@@ -929,7 +929,7 @@ def test_reference_kats_through_the_c_abi(need_gpu):
             rx = cx.compile(c["pattern"])
         except cx.CoregexError:
             continue
-        if rx.supported:
+        if rx.supported and rx.strategy != "UseBoundedBacktracker":
             n += 1
             assert rx.count(c["input"].encode()) == c["want"], c["name"]
     assert n >= 30, n

@@ -60,7 +60,7 @@ def test_dot_alone_and_every_byte_value(oracle):
     hay = _u8(bytes(range(256)) * 3 + "é日😀".encode() + bytes([0xC3, 0x41, 0xE6, 0x97, 0x41, 0xF0, 0x9F, 0x41]))
     for pat in [".", ".+", r"[^a]", r"\S+x?", r"[^\n]y?"]:
         rx, o = cx.compile(pat), oracle.Regex(pat)
-        if not rx.supported:
+        if not rx.supported or rx.strategy == "UseBoundedBacktracker":     # (that strategy's first device run: tests/test_zzz_gpu_fold.py)
             continue
         assert np.array_equal(rx.find_all_index(hay), o.find_all_index(hay)), pat
 

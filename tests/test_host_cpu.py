@@ -972,3 +972,38 @@ def test_case_insensitive_programs_through_the_twins(oracle):
             exps = o.find_all_submatch_index(words)
             got = emu.find_all_submatch(sb, cb, words, exps.shape[1])
             assert got.shape == exps.shape and np.array_equal(got, exps), (pat, "captures")
+
+
+def test_bounded_backtracker_programs_through_the_twins(oracle):
+    """The CPU half of tests/test_zzz_gpu_fold.py::test_bounded_backtracker_programs, and the reference's own rows for this strategy:
+    `[a-f0-9]{32,}` and `(\\w{2,8})+` on its differential corpus (stdlib answers, tests/golden/corpus_expected.json)."""
+    import json
+    import struct
+    from refcorpus import COMPAT_PATTERNS, generate_test_input, span_hash
+    from test_zzz_gpu_fold import BOUNDED
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus_expected.json")))["patterns"]
+    corpus = np.frombuffer(generate_test_input(), dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    mixed = np.frombuffer(b"abcdef0123456789 ,.\n-_XYZ" + "é日".encode() + b"\x80\xff", dtype=np.uint8)
+    served = 0
+    for pat in BOUNDED + [COMPAT_PATTERNS["la_tokens"], COMPAT_PATTERNS["word_repeat"]]:
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.strategy == o.strategy == "UseBoundedBacktracker" and o.strategy_restated, pat
+        if not rx.supported:
+            continue
+        served += 1
+        blob = rx.blob()
+        for hay in (corpus[:50000], mixed[rng.integers(0, len(mixed), size=6000)], mixed[rng.integers(0, 6, size=3000)], np.zeros(0, dtype=np.uint8)):
+            exp = o.find_all_index(hay).tolist()
+            assert emu.find_all(blob, hay).tolist() == exp, (pat, "lanes", len(hay))
+            if rx.fsm_image() is not None:
+                got = emu.find_all_fsm(rx.fsm_image(), hay, 3840, 32)
+                if isinstance(got, int) and got in (-18, -32):
+                    got = emu.find_all_fsm(rx.fsm_image(), hay, 3840, 32, dense=1)
+                assert isinstance(got, int) or got.tolist() == exp, (pat, "transducer", len(hay))
+    assert served >= 10
+    for name in ("la_tokens", "word_repeat"):
+        rx = cx.compile(COMPAT_PATTERNS[name])
+        if rx.supported:
+            got = emu.find_all(rx.blob(), corpus)
+            assert len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name

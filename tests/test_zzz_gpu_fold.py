@@ -38,3 +38,28 @@ def test_case_insensitive_literals(oracle, pat):
     if rx.num_groups > 1 and rx.submatch_supported:
         hay = _u8(words[:100000])
         assert np.array_equal(rx.find_all_submatch_index(hay), o.find_all_submatch_index(hay)), pat
+
+
+BOUNDED = [r"\S+", r"[^,]+", r"[0-9a-f]{32}", r"[a-f0-9]{32,}", r"(\w{2,8})+", r"\d{3}", r"[a-c]{2,3}?", r"(?i)[a-z]+", r"\w", r"\d{1,3}", r"[ab]", r"[^ ]+", r"\d"]
+
+
+@pytest.mark.parametrize("pat", BOUNDED)
+def test_bounded_backtracker_programs(oracle, pat):
+    """Unanchored UseBoundedBacktracker programs — concatenations / repetitions of character classes — are answered by the reference
+    with two leftmost-first engines (its backtracker while the rest of the haystack fits 32 M visited entries, the lazy-DFA pair
+    before that): served as the DFA pair's program since the end of round 3 (program.cc), with the existing kernels.  NOT run on a
+    device by the builder: first device run is the driver's."""
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy == "UseBoundedBacktracker" and o.strategy_restated
+    if not rx.supported:
+        pytest.skip(rx.why_unsupported)
+    rng = np.random.default_rng(5)
+    mixed = np.frombuffer(b"abcdef0123456789 ,.\n-_XYZ" + "é日".encode() + b"\x80\xff", dtype=np.uint8)
+    for hay in (generate_test_input(), cx.synth_pages(2, 0xC0FFEE02, 0, 64), mixed[rng.integers(0, len(mixed), size=50000)], mixed[rng.integers(0, 6, size=20000)], _u8(b""), _u8(b"a")):
+        exp = o.find_all_index(hay)
+        try:
+            got = rx.find_all_index(hay)
+        except cx.UnsupportedInput:
+            continue                                        # (a run beyond the serial-walk budget of a program without a transducer image)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), got[:3].tolist(), exp[:3].tolist())
+        assert rx.count(hay) == len(exp)
