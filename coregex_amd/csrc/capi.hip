@@ -532,8 +532,9 @@ relaunch:
     // fields programs (one field class, one separator class: the headline `\d+\.\d+\.\d+\.\d+`): the forward-only kernel;
     // match-dense input (a row buffer overflowed before) stays on the chain kernel's dense mode
     static const bool fieldsOk = getenv("CXG_NO_FIELDS_KERNEL") == nullptr;
-    fieldsKernel = fieldsOk && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
-                   cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+    const bool fieldsCould = !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
+                             cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+    fieldsKernel = fieldsOk && !submatch && !denseChain && fieldsCould;
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
     a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
     // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
@@ -542,7 +543,9 @@ relaunch:
     const int trioShape = cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
     if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
       bool ok = !submatch || a.out == nullptr || fusedCaps;
-      if ((trioShape & 8) && !submatch) ok = false;                 // spans with one separator for every link are the fields kernel's (or, with that switched off, the chain kernel's)
+      // spans with one separator for every link are the fields kernel's where it can serve the chain (with CXG_NO_FIELDS_KERNEL
+      // the chain kernel's: the A/B of tests/test_gpu_fields.py); a set class (`\w+@\w+@\w+`) stays here, on the EQ instantiation
+      if ((trioShape & 8) && !submatch && fieldsCould) ok = false;
       if (fusedCaps) {
         const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
         for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] & 1u) == 0u && cc->run_op[i] <= 6u;
@@ -779,7 +782,10 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
       uint64_t n2 = 0;
       rc = scanDeviceOnce(p, cur, len - abs_off, base + static_cast<int64_t>(abs_off), -1, s.bothRows, nscan, &n2, user_stream, timing, row_width);
       add_timing();
-      if (rc != kRcLongMatch || n2 != n_cur) return rc == kRcLongMatch || rc == CXG_OK ? fail(CXG_E_INTERNAL, "UseBoth restart: the rerun for rows disagrees with the count") : rc;
+      // (a launch WITH a limit lets groups behind the n-th row publish `limit` instead of their own count — block_common.hpp
+      // limit_reached_skip — so its total is a lower bound of the unlimited rerun's; only the first nscan rows are used)
+      const bool agrees = lim_rem > 0 ? n2 >= nscan : n2 == n_cur;
+      if (rc != kRcLongMatch || !agrees) return rc == kRcLongMatch || rc == CXG_OK ? fail(CXG_E_INTERNAL, "UseBoth restart: the rerun for rows disagrees with the count") : rc;
       rows = s.bothRows;
     }
     HIP_TRY(hipMemsetAsync(s.bothFirst, 0xFF, 8, stream));
@@ -838,6 +844,12 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     break;
   }
   if (timing) *timing = acc;
+  // the restart loop's own staging follows the rule of s.hay / s.out: at most kKeepStagingBytes stay with the thread
+  if (s.bothHayCap > kKeepStagingBytes || s.bothRowsCap * sizeof(int64_t) > kKeepStagingBytes) {
+    (void)hipStreamSynchronize(stream);
+    if (s.bothHayCap > kKeepStagingBytes) { (void)hipFree(s.bothHay); s.bothHay = nullptr; s.bothHayCap = 0; }
+    if (s.bothRowsCap * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.bothRows); s.bothRows = nullptr; s.bothRowsCap = 0; }
+  }
   if (rc == kRcLongMatch) return fail(CXG_E_INPUT, "UseBoth program met more than 64 matches longer than 100 bytes in one haystack");
   if (rc != CXG_OK && rc != CXG_E_CAPACITY) return rc;
   const uint64_t n = done + n_cur;

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import coregex_amd as cx
+from routing import routed
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +42,7 @@ def _check(oracle, pat, hay, want_kernel=K_FIELDS, launches=1):
     rows, t = _dev_rows(rx, hay)
     assert rows.shape == exp.shape and np.array_equal(rows, exp), (pat, bytes(_u8(hay)[:60]), rows[:4].tolist(), exp[:4].tolist())
     if want_kernel is not None:
-        assert t.kernel == want_kernel and t.n_launches == launches, (pat, t.kernel, t.n_launches, t.fallback_reason)
+        assert routed(t.kernel == want_kernel and t.n_launches == launches, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
     return t
 
 
@@ -79,7 +80,7 @@ def test_random_text(oracle, pat, alpha):
         hay = "".join(rng.choices(alpha, weights=w, k=n)).encode()
         t = _check(oracle, pat, hay, want_kernel=None)
         served += t.kernel == K_FIELDS and t.n_launches == 1
-    assert served >= 4, served                      # sparse mixes stay on the kernel; dense ones overflow its row buffers (64 rows per wave-tile)
+    assert routed(served >= 4, served)                      # sparse mixes stay on the kernel; dense ones overflow its row buffers (64 rows per wave-tile)
 
 
 def test_synthlog_16mib(oracle):
@@ -95,7 +96,7 @@ def test_synthlog_16mib(oracle):
     t = cx.Timing()
     n = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp)
-    assert t.kernel == K_FIELDS and t.n_launches == 1
+    assert routed(t.kernel == K_FIELDS and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason)
     # shard origin: rows move by `base`
     n = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, base=1 << 40, timing=t)
     assert np.array_equal(out[:n].cpu().numpy(), exp + (1 << 40))
@@ -167,7 +168,7 @@ def test_limit_stops_the_scan_early(oracle):
     for n in (1, 10, 1000):
         got = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), out.shape[0], n=n, timing=t_lim)
         assert got == n and np.array_equal(out[:n].cpu().numpy(), exp[:n]), n
-        assert t_lim.kernel == K_FIELDS
+        assert routed(t_lim.kernel == K_FIELDS, t_lim.kernel)
     import os
     assert full > 1000
     if not os.environ.get("CXG_TICKETS"):             # (with ticket atomics every skipping group still draws its ticket: 73 ns each)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import coregex_amd as cx
+from routing import routed
 
 pytestmark = pytest.mark.gpu
 
@@ -41,13 +42,13 @@ def _check(oracle, pat, hay, want_kernel=K_TRIO):
     rows, t = _dev(rx, a, False)
     assert rows.shape == exp.shape and np.array_equal(rows, exp), (pat, bytes(a[:60]), rows[:4].tolist(), exp[:4].tolist())
     if want_kernel is not None and a.size:
-        assert t.kernel == want_kernel and t.n_launches == 1, (pat, t.kernel, t.n_launches, t.fallback_reason)
+        assert routed(t.kernel == want_kernel and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
     if rx.num_groups > 1:
         exps = o.find_all_submatch_index(a)
         subs, ts = _dev(rx, a, True)
         assert subs.shape == exps.shape and np.array_equal(subs, exps), (pat, bytes(a[:60]), subs[:3].tolist(), exps[:3].tolist())
         if want_kernel is not None and a.size:
-            assert ts.kernel == want_kernel and ts.n_launches == 1, (pat, ts.kernel, ts.n_launches, ts.fallback_reason)
+            assert routed(ts.kernel == want_kernel and ts.n_launches == 1, ts.kernel, ts.n_launches, ts.fallback_reason), (pat, ts.kernel, ts.n_launches, ts.fallback_reason)
     return t
 
 
@@ -86,7 +87,7 @@ def test_random_text(oracle, pat, alpha):
         hay = "".join(rng.choices(alpha, weights=w, k=n)).encode()
         t = _check(oracle, pat, hay, want_kernel=None)
         served += t.kernel in (K_TRIO, 13) and t.n_launches == 1      # (13: spans of a two-field program with one separator class are the fields kernel's)
-    assert served >= 4, served
+    assert routed(served >= 4, served)
 
 
 def test_one_separator_for_every_link(oracle):
@@ -101,15 +102,15 @@ def test_one_separator_for_every_link(oracle):
         subs, t = _dev(rx, a, True)
         assert subs.shape == exp.shape and np.array_equal(subs, exp), (hay[:40], subs[:3].tolist(), exp[:3].tolist())
         if a.size:
-            assert t.kernel == K_TRIO and t.n_launches == 1, (hay[:40], t.kernel, t.n_launches, t.fallback_reason)
+            assert routed(t.kernel == K_TRIO and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason), (hay[:40], t.kernel, t.n_launches, t.fallback_reason)
         rows, t = _dev(rx, a, False)
-        assert np.array_equal(rows, exp[:, :2]) and (not a.size or t.kernel == 13)
+        assert np.array_equal(rows, exp[:, :2]) and (not a.size or routed(t.kernel == 13, t.kernel))
     tok = b"192.168.100.200"
     for off in list(range(50, 70)) + list(range(WT - 20, WT + 70)) + list(range(32 * WT - 20, 32 * WT + 4)):
         h = np.full(33 * WT + 300, ord(" "), dtype=np.uint8)
         h[off:off + len(tok)] = np.frombuffer(tok, dtype=np.uint8)
         subs, t = _dev(rx, h, True)
-        assert np.array_equal(subs, o.find_all_submatch_index(h)) and t.kernel == K_TRIO and t.n_launches == 1, off
+        assert np.array_equal(subs, o.find_all_submatch_index(h)) and routed(t.kernel == K_TRIO and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason), off
     # the headline log, 16 MiB
     import torch
     npages = 4096
@@ -121,12 +122,12 @@ def test_one_separator_for_every_link(oracle):
     t = cx.Timing()
     n = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t)
     assert n == len(exp) and n > 100000 and np.array_equal(out[:n].cpu().numpy(), exp)
-    assert t.kernel == K_TRIO and t.n_launches == 1
+    assert routed(t.kernel == K_TRIO and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason)
     for pat3 in (r"(\d+)\.(\d+)\.(\d+)", r"((\d+)\.(\d+))\.(\d+)\.(\d+)"):      # three fields; a group around two of them (12 slots: 6 pairs, 8 lanes per row)
         rx3, o3 = cx.compile(pat3), oracle.Regex(pat3)
         h = host[:1 << 20]
         subs, t3 = _dev(rx3, h, True)
-        assert np.array_equal(subs, o3.find_all_submatch_index(h)) and t3.kernel == K_TRIO and t3.n_launches == 1, pat3
+        assert np.array_equal(subs, o3.find_all_submatch_index(h)) and routed(t3.kernel == K_TRIO and t3.n_launches == 1, t3.kernel, t3.n_launches, t3.fallback_reason), pat3
 
 
 def test_synthlog_16mib(oracle):
@@ -141,13 +142,13 @@ def test_synthlog_16mib(oracle):
     t = cx.Timing()
     n = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp)
-    assert t.kernel == K_TRIO and t.n_launches == 1
+    assert routed(t.kernel == K_TRIO and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason)
     n = rx.find_all_submatch_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, base=1 << 40, timing=t)
     assert np.array_equal(out[:n].cpu().numpy(), exp + (1 << 40))
     assert rx.find_all_submatch_device(buf.ptr, npages * 4096) == len(exp) and rx.find_all_device(buf.ptr, npages * 4096) == len(exp)
     spans = torch.empty((len(exp) + 8, 2), dtype=torch.int64, device="cuda")
     assert rx.find_all_device(buf.ptr, npages * 4096, spans.data_ptr(), len(exp) + 8, timing=t) == len(exp)
-    assert np.array_equal(spans[:len(exp)].cpu().numpy(), exp[:, :2]) and t.kernel == K_TRIO
+    assert np.array_equal(spans[:len(exp)].cpu().numpy(), exp[:, :2]) and routed(t.kernel == K_TRIO, t.kernel)
 
 
 def test_long_tokens_and_handover(oracle):
