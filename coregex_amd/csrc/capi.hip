@@ -93,6 +93,7 @@ struct Scratch {
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
   uint8_t* bt = nullptr; size_t btCap = 0;         // k_captures_bt: per-thread visited bitmap + stack
+  uint32_t* pfStatus = nullptr; uint64_t pfCap = 0; uint32_t pfEpoch = 0;   // k_scan_fields_pers: one word per unit, own 16-bit launch epoch
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
   int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
   unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
@@ -105,6 +106,7 @@ struct Scratch {
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (ctl) (void)hipFree(ctl);
       if (fsmMaps) (void)hipFree(fsmMaps);
+      if (pfStatus) (void)hipFree(pfStatus);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
@@ -535,6 +537,23 @@ relaunch:
     const bool fieldsCould = !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                              cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
     fieldsKernel = fieldsOk && !submatch && !denseChain && fieldsCould;
+    // ... on a persistent grid with the ordering of the rows deferred by a round (k_scan_fields_pers) unless FindAll has an n
+    // (the early stop lives in the grouped kernel's look-back), the phase profile is on, or a watchdog ever fired
+    static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
+    a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
+    if (fieldsKernel && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0) {
+      const uint64_t need = len / (static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * 8u) + 2u * 2048u + 64u;   // (full rounds + 1) x G words
+      if (need > s.pfCap) {
+        if (s.pfStatus) HIP_TRY(hipFree(s.pfStatus));
+        s.pfStatus = nullptr; s.pfCap = 0;
+        const uint64_t c = need + need / 4;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfStatus), c * sizeof(uint32_t)));
+        s.pfCap = c; s.pfEpoch = 0;
+        HIP_TRY(hipMemsetAsync(s.pfStatus, 0, c * sizeof(uint32_t), stream));
+      }
+      if (s.pfEpoch >= 0xFFFFu) { HIP_TRY(hipMemsetAsync(s.pfStatus, 0, s.pfCap * sizeof(uint32_t), stream)); s.pfEpoch = 0; }
+      a.pf_status = s.pfStatus; a.pf_cap = s.pfCap; a.pf_epoch = ++s.pfEpoch;
+    }
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
     a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
     // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the

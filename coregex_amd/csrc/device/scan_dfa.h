@@ -70,6 +70,11 @@ struct ScanArgs {
   uint64_t* fsm_maps;   // scan_fsm.hip: three epoch-tagged words per group (fsm_group_entry)
   uint64_t limit;       // FindAll's n when > 0, else 0: rows beyond it are not wanted (block_common.hpp tile_lookback: early stop)
   uint32_t* stop;       // device word: == epoch + 1 once `limit` rows have been counted
+  // scan_fields_wave.hip k_scan_fields_pers (persistent grid, ordering deferred by a round); pf_status == nullptr: grouped kernel
+  uint32_t* pf_status;  // [pf_cap] one word per unit: pf_epoch << 16 | rows of the unit
+  uint64_t pf_cap;
+  uint32_t pf_epoch;    // 1..65535, own counter (the words are 4 bytes: block_common.hpp's 10-bit epoch words do not fit)
+  uint32_t pf_full, pf_tpw_last, pf_units_last;   // filled in by the launcher: full rounds, tiles per wave / units of the tapered last round
 };
 
 }  // namespace cxgdev

@@ -417,6 +417,201 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   }
 }
 
+// =====================================================================================================================
+// k_scan_fields_pers — the same tile mathematics on a PERSISTENT grid with the ordering of the rows DEFERRED by one round
+// (round 4).  Why: the grouped kernel above spends more of a workgroup's life waiting in the look-back than scanning
+// (profiles/r03_fields_ablation.txt section 4): workgroups that wait hold their slots, the next generation starts when the
+// convoy in front resolves, finishes together and queues up again — the launch runs as ~4 synchronised generations of
+// scan-then-wait.  Here G = CUs x occupancy workgroups stay for the whole launch; in round r workgroup g scans unit r*G + g
+// (4 waves x 8 wave-tiles = 120 KiB, the window of the next unit's first tile already in flight behind the last tile of
+// this one) and parks the rows in LDS, publishes the unit's row count (one 4-byte word: launch epoch << 16 | count), and
+// only THEN orders the rows of round r - 1: the counts of that round were published a whole scan ago, so the G words of the
+// round are read once, by all 256 threads, with the loads issued one tile before they are needed — no serial chain of
+// look-back windows, no waiting in steady state.  prefix(g) = rows in front of the round (carried in a register by every
+// wave) + sum of the words below g.  Rows of two rounds live in LDS (2 x 8 KiB).
+// The last round is tapered: what is left of the haystack behind the full rounds is spread over all workgroups (units of
+// 1..8 tiles per wave), so no workgroup idles through a whole unit at the end.
+// Co-residency: every workgroup of the grid must be resident (a waiting workgroup waits for words of others that run at
+// the same time).  G comes from the occupancy query; should a device admit fewer, the spin watchdog raises error bit 1
+// and the host reruns with the grouped kernel (capi.hip staticGroupsOk).
+#ifndef CXG_PF_OCC
+#define CXG_PF_OCC 6
+#endif
+constexpr int kPfMaxGrid = 2048;                              // words of a round: 256 threads x 8
+constexpr uint32_t kPfSpinLimit = 1u << 20;
+
+template <int K, int KD, int KP>
+__global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
+  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64];
+  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1
+  __shared__ uint32_t s_cnt[3][kWavesPerBlock * 8];                             // [round % 3][q = j * 4 + wave]
+  __shared__ uint32_t s_part[2][kWavesPerBlock][4];                             // [round & 1][wave]: words below g, all words, valid
+
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  const uint32_t G = gridDim.x, g = blockIdx.x;
+  const uint32_t full = a.pf_full, tpw_last = a.pf_tpw_last, units_last = a.pf_units_last;
+  const uint32_t R_me = full + (g < units_last ? 1u : 0u);            // rounds in which this workgroup has a unit
+  if (R_me == 0) return;
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
+  const uint32_t dlo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[0] * 0x01010101u)));
+  const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
+  const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
+  const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
+  const uint32_t ep = a.pf_epoch;
+  const bool want_rows = a.out != nullptr || a.max_len != 0;
+  const bool order = a.count_sum == 0u;                               // count-only calls need no place in the output
+
+  auto tpw_of = [&](uint32_t r) -> uint32_t { return r < full ? 8u : tpw_last; };
+  auto tile_lo_of = [&](uint32_t r, uint32_t j) -> uint64_t {
+    return (static_cast<uint64_t>(r) * 32u * G + static_cast<uint64_t>(g) * 4u * tpw_of(r) + j * 4u + static_cast<uint32_t>(wave)) * static_cast<uint64_t>(kWaveTile);
+  };
+  // the words of round rr: thread t reads words 8 t .. 8 t + 7 of the round (two 16-byte loads past the L1: sc0 sc1)
+  auto round_units = [&](uint32_t rr) -> uint32_t { return rr < full ? G : units_last; };
+  auto status_load = [&](uint32_t rr, u32x4& v0, u32x4& v1) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.pf_status + static_cast<uint64_t>(rr) * G, 0, static_cast<int>(round_units(rr) * 4u), 0x00020000);
+    v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>(tid) * 32u, 0, 17);
+    v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>(tid) * 32u + 16u, 0, 17);
+  };
+  // this wave's part of the round's sums -> s_part[par][wave]
+  auto status_reduce = [&](uint32_t rr, const u32x4& v0, const u32x4& v1, uint32_t par) -> bool {
+    const uint32_t U = round_units(rr);
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bool ok = true;
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const uint32_t idx = static_cast<uint32_t>(tid) * 8u + k;
+      ok = ok && (idx >= U || (w[k] >> 16) == ep);
+      const uint32_t c = idx < U ? (w[k] & 0xFFFFu) : 0u;
+      tot += c;
+      pre += idx < g ? c : 0u;
+    }
+    const bool all_ok = __ballot(!ok) == 0ull;
+    const uint32_t tot_w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(tot)), 63));
+    const uint32_t pre_w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(pre)), 63));
+    if (lane0 == 0) { s_part[par][wave][0] = pre_w; s_part[par][wave][1] = tot_w; s_part[par][wave][2] = all_ok ? 1u : 0u; }
+    return all_ok;
+  };
+
+  u32x4 x[4];
+  uint32_t sink = 0;
+  int32_t nvalid_cur = 0;
+  fields_first_loads(x, fields_window(a.hay, a.len, tile_lo_of(0, 0), true, nvalid_cur), lane, g == 0 && wave == 0);
+  uint64_t running = 0;                                               // rows in front of the round being ordered (uniform)
+  uint64_t my_total = 0;                                              // count-only: rows of this workgroup's units
+  uint32_t fallback = 0;
+
+  for (uint32_t r = 0; r <= R_me; r++) {
+    const bool scan = r < R_me;
+    const uint32_t par = r & 1u, c3 = r % 3u;
+    u32x4 sv0 = {0u, 0u, 0u, 0u}, sv1 = {0u, 0u, 0u, 0u};
+    uint32_t nrows_w = 0;
+    if (scan) {
+      const uint32_t tpw = tpw_of(r);
+      for (uint32_t j = 0; j < tpw; j++) {
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        int32_t nvalid_next = 0;
+        const bool last = j + 1 == tpw;
+        const bool more = !last || r + 1 < R_me;
+        const uint64_t lo_next = last ? tile_lo_of(r + 1, 0) : tile_lo_of(r, j + 1);
+        const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, lo_next, more, nvalid_next);
+        uint32_t d0, d1, p0, p1;
+        fields_words<KD, KP>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1);
+        nvalid_cur = nvalid_next;
+        if (last && order && r > 0) status_load(r - 1, sv0, sv1);     // consumed behind this tile's mathematics
+        const FieldsTile t = fields_core<K>(d0, d1, p0, p1);
+        if (t.ovf) fallback |= 1u;
+        const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
+        const uint32_t incl = wave_inclusive_sum_fused(c);
+        const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        if (tot != 0 && want_rows)
+          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kFRows - 1)); });
+        if (lane == 0) s_cnt[c3][j * 4u + static_cast<uint32_t>(wave)] = tot;
+        nrows_w += tot;
+      }
+      if (tpw < 8u && lane0 < 8) { if (static_cast<uint32_t>(lane0) >= tpw) s_cnt[c3][static_cast<uint32_t>(lane0) * 4u + static_cast<uint32_t>(wave)] = 0u; }
+      if (nrows_w > static_cast<uint32_t>(kFRows)) fallback |= 16u;
+      wave_lds_sync();
+      bool bad = false, long_hit = false;
+      if (want_rows) {
+        for (uint32_t q = lane0; q < nrows_w && q < static_cast<uint32_t>(kFRows); q += 64) {
+          const uint32_t v = s_row[par][wave][q];
+          const uint32_t sb = v & 0xFFFFu, eb = v >> 16;
+          bad = bad || sb >= eb;
+          long_hit = long_hit || (a.max_len != 0 && eb - sb > a.max_len);
+        }
+      }
+      if (__ballot(bad) != 0ull) fallback |= 2u;
+      if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+    } else if (order && r > 0) {
+      status_load(r - 1, sv0, sv1);
+    }
+    if (order && r > 0) status_reduce(r - 1, sv0, sv1, par);
+    __syncthreads();                                                  // A_r: the unit's counts, the parts of round r - 1
+    if (scan && wave == 0) {                                          // publish the unit's row count
+      const uint32_t v = lane0 < 32 ? s_cnt[c3][lane0] : 0u;
+      const uint32_t tot_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(v)), 63));
+      my_total += tot_u;
+      if (order && lane0 == 0)
+        __hip_atomic_store(a.pf_status + static_cast<uint64_t>(r) * G + g, (ep << 16) | tot_u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!order || r == 0) continue;
+    // ---- order and write the rows of round r - 1
+    const uint32_t rp = r - 1u, parp = rp & 1u, c3p = rp % 3u;
+    uint32_t pre = 0, tot = 0, ok = 1;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; w++) { pre += s_part[par][w][0]; tot += s_part[par][w][1]; ok &= s_part[par][w][2]; }
+    if (!ok) {                                                        // uniform over the workgroup: a word of the round was not there yet
+      __syncthreads();                                                // every wave has taken this branch on the same snapshot before a slot is rewritten
+      uint32_t spins = 0;
+      for (;;) {
+        status_load(rp, sv0, sv1);
+        if (status_reduce(rp, sv0, sv1, par)) break;                  // this wave's part is complete (rewritten in place: only this wave writes its slot)
+        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      pre = 0; tot = 0;
+#pragma unroll
+      for (int w = 0; w < kWavesPerBlock; w++) { pre += s_part[par][w][0]; tot += s_part[par][w][1]; }
+      __syncthreads();                                                // nobody rewrites s_part[par] (round r + 2) before all have read it — kept simple: rare path
+    }
+    pre = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pre)));
+    tot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tot)));
+    const uint64_t base = running + pre;
+    running += tot;
+    if (a.out != nullptr) {
+      const uint32_t cq = lane0 < 32 ? s_cnt[c3p][lane0] : 0u;
+      const uint32_t eq = wave_inclusive_sum_fused(cq) - cq;          // exclusive prefix over q
+      const uint32_t tpwp = tpw_of(rp);
+      const int64_t origin = a.base + static_cast<int64_t>((static_cast<uint64_t>(rp) * 32u * G + static_cast<uint64_t>(g) * 4u * tpwp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
+      uint32_t start = 0;
+      for (uint32_t j = 0; j < tpwp; j++) {
+        const uint32_t q = j * 4u + static_cast<uint32_t>(wave);
+        const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cq), static_cast<int>(q)));
+        const uint64_t dst = base + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eq), static_cast<int>(q)));
+        const int64_t tb = origin + static_cast<int64_t>(q) * kWaveTile;
+        for (uint32_t i = lane0; i < n; i += 64) {
+          const uint32_t rr = start + i;
+          if (rr < static_cast<uint32_t>(kFRows) && dst + i < a.cap) {
+            const uint32_t v = s_row[parp][wave][rr];
+            longlong2 o; o.x = tb + (v & 0xFFFFu); o.y = tb + (v >> 16);
+            *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = o;
+          }
+        }
+        start += n;
+      }
+    }
+  }
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+  if (!order) { if (tid == 0) a.status[g] = my_total; return; }       // k_sum_counts adds the G words up
+  if (g == 0 && tid == 0) *a.total = running;                         // workgroup 0 has a unit in every round
+}
+
 // Does the chain have the shape this kernel evaluates?  run(0) (byte(1) run(0)){K-1}, two classes of one range each,
 // disjoint, K = 2..4, no restart check.  Returns K, else 0.
 int fields_shape(const ChainAux& c) {
@@ -430,7 +625,50 @@ int fields_shape(const ChainAux& c) {
   return static_cast<int>((c.nops + 1) / 2);
 }
 
+__global__ void k_sum_counts(const uint64_t* counts, uint64_t n, uint64_t* total);
+
 namespace {
+template <int K, int KD, int KP>
+int pers_occupancy() {                                               // resident workgroups per CU of the persistent instantiation
+  static int occ = -1;
+  if (occ < 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_fields_pers<K, KD, KP>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    int want = CXG_PF_OCC;
+    if (const char* e = getenv("CXG_PF_OCC")) want = atoi(e);
+    occ = n < want ? n : want;
+    if (occ < 0) occ = 0;
+  }
+  return occ;
+}
+template <int K, int KD, int KP>
+bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
+  const int occ = pers_occupancy<K, KD, KP>();
+  if (occ <= 0) return false;
+  static int cus = 0;
+  if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+  const uint64_t nwt = (a.len + kWaveTile - 1) / kWaveTile;
+  uint64_t G = static_cast<uint64_t>(cus) * static_cast<uint64_t>(occ);
+  if (G > static_cast<uint64_t>(kPfMaxGrid)) G = kPfMaxGrid;
+  if (G > (nwt + 3) / 4) G = (nwt + 3) / 4;                           // short input: one tile per wave
+  const uint64_t per_round = 32ull * G;
+  const uint64_t full = nwt / per_round, rem = nwt - full * per_round;
+  const uint64_t tpw_last = (rem + 4 * G - 1) / (4 * G);
+  const uint64_t units_last = tpw_last ? (rem + 4 * tpw_last - 1) / (4 * tpw_last) : 0;
+  if ((full + 1) * G > a.pf_cap || full > 0x7FFFFFFFull) return false;
+  a.pf_full = static_cast<uint32_t>(full); a.pf_tpw_last = static_cast<uint32_t>(tpw_last); a.pf_units_last = static_cast<uint32_t>(units_last);
+  hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
+  if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, G, a.total);
+  return true;
+}
+template <int K>
+bool launch_pers_k(const ScanArgs& a, uint32_t kd, uint32_t kp, hipStream_t stream) {
+  const bool dd = kd == kClsDigit, pb = kp == kClsByte;
+  if (dd && pb) return launch_pers_inst<K, kClsDigit, kClsByte>(a, stream);
+  if (dd) return launch_pers_inst<K, kClsDigit, kClsRange>(a, stream);
+  if (pb) return launch_pers_inst<K, kClsRange, kClsByte>(a, stream);
+  return launch_pers_inst<K, kClsRange, kClsRange>(a, stream);
+}
 template <int K>
 void launch_fields_k(const ScanArgs& a, uint32_t kd, uint32_t kp, dim3 grid, dim3 block, hipStream_t stream) {
   const bool dd = kd == kClsDigit, pb = kp == kClsByte;
@@ -457,6 +695,16 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
   const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
   const int k = fields_shape(c);
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  if (a.pf_status != nullptr) {                                      // persistent grid, deferred ordering (k_scan_fields_pers)
+    bool done = false;
+    switch (k) {
+      case 2: done = launch_pers_k<2>(a, c.cls_kind[0], c.cls_kind[1], stream); break;
+      case 3: done = launch_pers_k<3>(a, c.cls_kind[0], c.cls_kind[1], stream); break;
+      case 4: done = launch_pers_k<4>(a, c.cls_kind[0], c.cls_kind[1], stream); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (done) return hipGetLastError();
+  }
   switch (k) {
     case 2: launch_fields_k<2>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
     case 3: launch_fields_k<3>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;
