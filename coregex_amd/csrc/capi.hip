@@ -94,6 +94,8 @@ struct Scratch {
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
   uint8_t* bt = nullptr; size_t btCap = 0;         // k_captures_bt: per-thread visited bitmap + stack
   uint32_t* pfStatus = nullptr; uint64_t pfCap = 0; uint32_t pfEpoch = 0;   // k_scan_fields_pers: one word per unit, own 16-bit launch epoch
+  uint64_t* pfRec = nullptr; uint64_t pfRecRounds = 0;   // ... 128 records of 16 bytes per round, tagged with the same epoch
+  uint64_t* pfStats = nullptr;                           // ... per wave: units that waited, polls (CXG_VERBOSE)
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
   int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
   unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
@@ -107,6 +109,8 @@ struct Scratch {
       if (ctl) (void)hipFree(ctl);
       if (fsmMaps) (void)hipFree(fsmMaps);
       if (pfStatus) (void)hipFree(pfStatus);
+      if (pfRec) (void)hipFree(pfRec);
+      if (pfStats) (void)hipFree(pfStats);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
@@ -384,6 +388,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool fsmTried = false;
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
+  a.pf_status = nullptr;                                           // (set per launch by the fields programs' branch below)
   a.hay = static_cast<const uint8_t*>(d_hay);
   a.len = len;
   a.base = base;
@@ -541,18 +546,34 @@ relaunch:
     // (the early stop lives in the grouped kernel's look-back), the phase profile is on, or a watchdog ever fired
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
+    a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
     if (fieldsKernel && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0) {
-      const uint64_t need = len / (static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * 8u) + 2u * 2048u + 64u;   // (full rounds + 1) x G words
+      const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
+      const uint64_t need = nwt / 4u + 2u * 8192u + 64u;                                       // (full rounds + 1) x W unit words, W <= 8192 waves
+      const uint64_t rneed = nwt / (4u * 1024u) + 2u;                                          // rounds: >= 1024 waves on a long haystack
+      bool fresh = false;
       if (need > s.pfCap) {
         if (s.pfStatus) HIP_TRY(hipFree(s.pfStatus));
         s.pfStatus = nullptr; s.pfCap = 0;
         const uint64_t c = need + need / 4;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfStatus), c * sizeof(uint32_t)));
-        s.pfCap = c; s.pfEpoch = 0;
-        HIP_TRY(hipMemsetAsync(s.pfStatus, 0, c * sizeof(uint32_t), stream));
+        s.pfCap = c; fresh = true;
       }
-      if (s.pfEpoch >= 0xFFFFu) { HIP_TRY(hipMemsetAsync(s.pfStatus, 0, s.pfCap * sizeof(uint32_t), stream)); s.pfEpoch = 0; }
+      if (rneed > s.pfRecRounds) {
+        if (s.pfRec) HIP_TRY(hipFree(s.pfRec));
+        s.pfRec = nullptr; s.pfRecRounds = 0;
+        const uint64_t c = rneed + rneed / 4;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfRec), c * cxgdev::kPfRecStride * 8u));
+        s.pfRecRounds = c; fresh = true;
+      }
+      if (fresh || s.pfEpoch >= 0xFFFFu) {                                                     // both arrays carry the same epoch
+        HIP_TRY(hipMemsetAsync(s.pfStatus, 0, s.pfCap * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(s.pfRec, 0, s.pfRecRounds * cxgdev::kPfRecStride * 8u, stream));
+        s.pfEpoch = 0;
+      }
+      if (!s.pfStats) { HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfStats), 4 * 8192 * sizeof(uint64_t))); HIP_TRY(hipMemsetAsync(s.pfStats, 0, 4 * 8192 * sizeof(uint64_t), stream)); }
       a.pf_status = s.pfStatus; a.pf_cap = s.pfCap; a.pf_epoch = ++s.pfEpoch;
+      a.pf_rec = s.pfRec; a.pf_rec_rounds = s.pfRecRounds; a.pf_stats = s.pfStats;
     }
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
     a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
@@ -676,6 +697,32 @@ relaunch:
       fprintf(stderr, "[CXG_PROF] waves=%llu avg cycles/wave: tables=%llu tile=%llu walk=%llu scan=%llu lookback=%llu\n",
               (unsigned long long)pc[5], (unsigned long long)(pc[0] / pc[5]), (unsigned long long)(pc[1] / pc[5]),
               (unsigned long long)(pc[2] / pc[5]), (unsigned long long)(pc[3] / pc[5]), (unsigned long long)(pc[4] / pc[5]));
+  }
+  if (a.pf_status) {
+    static const bool pfVerbose = getenv("CXG_VERBOSE") != nullptr;
+    if (pfVerbose) {                                                // units that had to wait for their round's record, polls
+      std::vector<uint64_t> st(4 * 8192);
+      HIP_TRY(hipMemcpy(st.data(), s.pfStats, st.size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(s.pfStats, 0, st.size() * 8));
+      uint64_t w = 0, pl = 0, mx = 0, nw = 0;
+      double lifeX[8] = {0}, scanX[8] = {0}, lifeMaxX[8] = {0}; uint64_t nX[8] = {0};
+      std::vector<uint64_t> lives, scans;
+      for (size_t i = 0; i < 8192; i++) {
+        w += st[i] >> 32; pl += st[i] & 0xFFFFFFFFull; mx = std::max<uint64_t>(mx, st[i] & 0xFFFFFFFFull);
+        if (!st[8192 + i]) continue;
+        nw++; lives.push_back(st[8192 + i]); scans.push_back(st[16384 + i]);
+        const int x = static_cast<int>(st[24576 + i] >> 32) & 7;
+        lifeX[x] += st[8192 + i]; scanX[x] += st[16384 + i]; nX[x]++; lifeMaxX[x] = std::max<double>(lifeMaxX[x], st[8192 + i]);
+      }
+      fprintf(stderr, "[cxg] persistent fields kernel: %llu units waited for their round's record, %llu polls (most by one wave: %llu)\n", (unsigned long long)w, (unsigned long long)pl, (unsigned long long)mx);
+      if (nw) {
+        std::sort(lives.begin(), lives.end()); std::sort(scans.begin(), scans.end());
+        auto q = [&](const std::vector<uint64_t>& v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))] / 100.0; };
+        fprintf(stderr, "[cxg]   %llu waves; life us min/p10/median/p90/max %.1f %.1f %.1f %.1f %.1f; in tile loops %.1f %.1f %.1f %.1f %.1f\n", (unsigned long long)nw,
+                q(lives, 0), q(lives, 0.1), q(lives, 0.5), q(lives, 0.9), q(lives, 1), q(scans, 0), q(scans, 0.1), q(scans, 0.5), q(scans, 0.9), q(scans, 1));
+        for (int x = 0; x < 8; x++) if (nX[x]) fprintf(stderr, "[cxg]   XCD %d: %llu waves, life mean %.1f max %.1f us, tile loops mean %.1f us\n", x, (unsigned long long)nX[x], lifeX[x] / nX[x] / 100.0, lifeMaxX[x] / 100.0, scanX[x] / nX[x] / 100.0);
+      }
+    }
   }
   if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
     staticGroupsOk.store(false);

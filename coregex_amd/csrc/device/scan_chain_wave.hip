@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? CXG_CAP_WAVES : (
           longlong2 o;
           if (part == 0) { o.x = ms; o.y = me; }
           else { o.x = slot(sc0, of0); o.y = slot(sc1, of1); }
-          *reinterpret_cast<longlong2*>(a.out + (dst + ri) * a.row_width + 2u * part) = o;
+          store_pair_nt(a.out + (dst + ri) * a.row_width + 2u * part, o.x, o.y);
         }
       }
       start += n;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kThreads, ((SETS || CAP || BND) ? CXG_CAP_WAVES : (
       if (r < static_cast<uint32_t>(kWRows) && dst + i < a.cap) {
         const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
         longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;   // row_width > 2 without CAP: a capture pass fills the rest
+        store_pair_nt(a.out + (dst + i) * a.row_width, v.x, v.y);   // row_width > 2 without CAP: a capture pass fills the rest
       }
     }
     start += n;

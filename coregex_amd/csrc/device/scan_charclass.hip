@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_charclass(ScanArgs a) {
       s_rows[row] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(e));
     } else if (base + row < a.cap) {
       longlong2 v; v.x = origin + s; v.y = origin + e;
-      *reinterpret_cast<longlong2*>(a.out + (base + row) * 2) = v;
+      store_pair_nt(a.out + (base + row) * 2, v.x, v.y);
     }
   }
   if (!buffered) return;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_charclass(ScanArgs a) {
     if (base + i < a.cap) {
       const uint2 r = s_rows[i];
       longlong2 v; v.x = origin + static_cast<int32_t>(r.x); v.y = origin + static_cast<int32_t>(r.y);
-      *reinterpret_cast<longlong2*>(a.out + (base + i) * 2) = v;
+      store_pair_nt(a.out + (base + i) * 2, v.x, v.y);
     }
   }
 }

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       if (row0 + i < a.cap) {
         if (i + open < nen) {                                       // both halves of the row are this tile's
           longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i + open];
-          *reinterpret_cast<longlong2*>(a.out + (row0 + i) * 2) = v;
+          store_pair_nt(a.out + (row0 + i) * 2, v.x, v.y);
         } else a.out[(row0 + i) * 2] = tb + s_rs[wave][i];         // the run ends in a later tile
       }
     }

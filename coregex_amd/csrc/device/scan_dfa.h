@@ -42,6 +42,10 @@ inline WalkLimit walk_limit(uint64_t remaining, int32_t window) {
   return WalkLimit{static_cast<int32_t>(remaining), 0x7FFFFFFF};
 }
 
+// k_scan_fields_pers (scan_fields_wave.hip): pf_rec holds 384 words of 8 bytes per round — 128 records of two words, 128 block sums
+constexpr int kPfBlocks = 128;
+constexpr uint64_t kPfRecStride = 3ull * kPfBlocks;
+
 struct ScanArgs {
   const uint8_t* hay;   // device, 16-byte aligned
   uint64_t len;
@@ -71,10 +75,13 @@ struct ScanArgs {
   uint64_t limit;       // FindAll's n when > 0, else 0: rows beyond it are not wanted (block_common.hpp tile_lookback: early stop)
   uint32_t* stop;       // device word: == epoch + 1 once `limit` rows have been counted
   // scan_fields_wave.hip k_scan_fields_pers (persistent grid, ordering deferred by a round); pf_status == nullptr: grouped kernel
-  uint32_t* pf_status;  // [pf_cap] one word per unit: pf_epoch << 16 | rows of the unit
+  uint32_t* pf_status;  // [pf_cap] one word per unit (a wave's 8 wave-tiles of a round): pf_epoch << 16 | rows of the unit
   uint64_t pf_cap;
   uint32_t pf_epoch;    // 1..65535, own counter (the words are 4 bytes: block_common.hpp's 10-bit epoch words do not fit)
-  uint32_t pf_full, pf_tpw_last, pf_units_last;   // filled in by the launcher: full rounds, tiles per wave / units of the tapered last round
+  uint32_t pf_full, pf_tpw_last, pf_units_last;   // filled in by the launcher: full rounds, tiles per unit / units of the tapered last round
+  uint64_t* pf_rec;     // [pf_rec_rounds][384] per round: 128 records {rows of the round in front of the block, rows of the round} + 128 block sums, each word tagged pf_epoch << 48
+  uint64_t pf_rec_rounds;
+  uint64_t* pf_stats;   // [8192] per wave: units that waited << 32 | polls (CXG_VERBOSE)
 };
 
 }  // namespace cxgdev

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dfa(ScanArgs a) {
         longlong2 v;
         v.x = origin + static_cast<int32_t>(s_recs[i * 3 + 0]);
         v.y = origin + static_cast<int32_t>(s_recs[i * 3 + 1]);
-        *reinterpret_cast<longlong2*>(a.out + row * a.row_width) = v;   // row_width is even: 16-byte aligned
+        store_pair_nt(a.out + row * a.row_width, v.x, v.y);   // row_width is even: 16-byte aligned
       }
     }
   } else {

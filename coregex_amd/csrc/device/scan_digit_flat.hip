@@ -72,7 +72,7 @@ struct DirectSink2 {
     const uint64_t row = first + n++;
     if (row < cap) {
       longlong2 v; v.x = origin + s; v.y = origin + e;
-      *reinterpret_cast<longlong2*>(out + row * 2) = v;
+      store_pair_nt(out + row * 2, v.x, v.y);
     }
   }
 };
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_digit_flat(ScanArgs a) {
         longlong2 v;
         v.x = origin + static_cast<int32_t>(s_recs[i * 3 + 0]);
         v.y = origin + static_cast<int32_t>(s_recs[i * 3 + 1]);
-        *reinterpret_cast<longlong2*>(a.out + row * 2) = v;
+        store_pair_nt(a.out + row * 2, v.x, v.y);
       }
     }
   } else {

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
       if (r < static_cast<uint32_t>(kFRows) && dst + i < a.cap) {
         const uint32_t v = s_row[wave][r];
         longlong2 o; o.x = tb + (v & 0xFFFFu); o.y = tb + (v >> 16);
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = o;
+        store_pair_nt(a.out + (dst + i) * a.row_width, o.x, o.y);
       }
     }
     start += n;
@@ -418,122 +418,226 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
 }
 
 // =====================================================================================================================
-// k_scan_fields_pers — the same tile mathematics on a PERSISTENT grid with the ordering of the rows DEFERRED by one round
-// (round 4).  Why: the grouped kernel above spends more of a workgroup's life waiting in the look-back than scanning
-// (profiles/r03_fields_ablation.txt section 4): workgroups that wait hold their slots, the next generation starts when the
-// convoy in front resolves, finishes together and queues up again — the launch runs as ~4 synchronised generations of
-// scan-then-wait.  Here G = CUs x occupancy workgroups stay for the whole launch; in round r workgroup g scans unit r*G + g
-// (4 waves x 8 wave-tiles = 120 KiB, the window of the next unit's first tile already in flight behind the last tile of
-// this one) and parks the rows in LDS, publishes the unit's row count (one 4-byte word: launch epoch << 16 | count), and
-// only THEN orders the rows of round r - 1: the counts of that round were published a whole scan ago, so the G words of the
-// round are read once, by all 256 threads, with the loads issued one tile before they are needed — no serial chain of
-// look-back windows, no waiting in steady state.  prefix(g) = rows in front of the round (carried in a register by every
-// wave) + sum of the words below g.  Rows of two rounds live in LDS (2 x 8 KiB).
-// The last round is tapered: what is left of the haystack behind the full rounds is spread over all workgroups (units of
-// 1..8 tiles per wave), so no workgroup idles through a whole unit at the end.
-// Co-residency: every workgroup of the grid must be resident (a waiting workgroup waits for words of others that run at
-// the same time).  G comes from the occupancy query; should a device admit fewer, the spin watchdog raises error bit 1
-// and the host reruns with the grouped kernel (capi.hip staticGroupsOk).
+// k_scan_fields_pers — the same tile mathematics on a PERSISTENT grid of autonomous waves, the ordering of the rows DEFERRED
+// by one round (round 4).  Why: the grouped kernel above spends more of a workgroup's life waiting in the look-back than
+// scanning (profiles/r03_fields_ablation.txt section 4): workgroups that wait hold their slots, the next generation starts
+// when the convoy in front resolves, finishes together and queues up again.  Here W = 4 x CUs x occupancy waves stay for the
+// whole launch and never meet at a barrier.  In round r wave v scans unit r * W + v — 8 consecutive wave-tiles = 30 KiB, the
+// window of the next unit's first tile in flight behind the last tile of this one — parks the rows in LDS as offsets from
+// the unit's first byte and publishes the unit's row count in its own word (launch epoch << 16 | count).  No atomics:
+//   * the LEADER of a block of 64 units (its last unit) owes the block's sum: while it scans round r + 1 it loads the 64
+//     unit words of round r once per tile (issued behind the tile's refills, looked at behind the tile's mathematics — it
+//     never spins while it has tiles to scan) and stores the sum when all are there;
+//   * the leader of the round (its last unit) likewise owes the round's RECORDS: one look per tile at the <= 128 block sums,
+//     then one 16-byte record per block: rows of the round in front of the block, rows of the round.
+// At the end of round r + 1 every wave orders and writes its rows of round r: the record of its block and the words of the
+// units of its block in front of it — one 16-byte and one 4-byte load per lane, issued one tile before they are needed:
+//   base = rows in front of the round (carried in a register) + record.base + units of my block below me
+// with no chain of look-back windows.  Rows of two rounds live in LDS (2 x 2 KiB per wave).
+// (Measured on the way, profiles/r04_pers_*: whole workgroups as units with every thread reading all G words of a round —
+// 6 KiB at the same addresses from 1 536 workgroups — 0.30 ms against 0.25 for the grouped kernel, better with FEWER
+// workgroups; block sums by plain atomics on 3 cache lines: 0.66 ms; by returning atomics, one counter per 4 KiB, last
+// arriver sums: 0.27-0.28, every unit waiting ~15 us per round for its record — 64 serialised atomics under a streaming
+// load take most of a round; statistics by an atomic per unit on ONE word: +0.8 ms.  Rows written with no protocol: 0.22-0.23.)
+// The last round is tapered: what is left of the haystack behind the full rounds is spread over all waves (units of 1..8
+// tiles).
+// Co-residency: every wave of the grid must be resident (a waiting wave waits for words of waves that run at the same
+// time).  The grid comes from the occupancy query; should a device admit fewer, the spin watchdog raises error bit 1 and
+// the host reruns with the grouped kernel (capi.hip staticGroupsOk).
 #ifndef CXG_PF_OCC
 #define CXG_PF_OCC 6
 #endif
-constexpr int kPfMaxGrid = 2048;                              // words of a round: 256 threads x 8
+// -DCXG_PFABL=n (experiments only, rows land in the wrong places): 1 = nothing read, no duties; 2 = no unit word either; 3 = no rows written
+#ifndef CXG_PFABL
+#define CXG_PFABL 0
+#endif
+#ifndef CXG_PF_PRIO
+#define CXG_PF_PRIO 1
+#endif
+#ifndef CXG_PF_PRIO_SHIFT
+#define CXG_PF_PRIO_SHIFT 14
+#endif
+#ifndef CXG_PF_SLEEP
+#define CXG_PF_SLEEP 16
+#endif
+// Tiles per unit.  ODD on purpose: the waves start in lockstep, so at any moment they read at (v * unit + progress) — with a
+// unit of 8 tiles = 120 x 256 bytes the offsets v * 120 mod 128 take 16 values, i.e. an eighth of the channels of any
+// power-of-two interleave; 7 tiles = 105 x 256 bytes is coprime to it and spreads the waves over all of them.
+#ifndef CXG_PF_TILES
+#define CXG_PF_TILES 7
+#endif
+constexpr int kPfTiles = CXG_PF_TILES;
+constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
 constexpr uint32_t kPfSpinLimit = 1u << 20;
 
 template <int K, int KD, int KP>
 __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
   __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64];
-  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1
-  __shared__ uint32_t s_cnt[3][kWavesPerBlock * 8];                             // [round % 3][q = j * 4 + wave]
-  __shared__ uint32_t s_part[2][kWavesPerBlock][4];                             // [round & 1][wave]: words below g, all words, valid
+  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - 64
 
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  const uint32_t G = gridDim.x, g = blockIdx.x;
+  const uint32_t W = gridDim.x * static_cast<uint32_t>(kWavesPerBlock);
+  const uint32_t wv = blockIdx.x * static_cast<uint32_t>(kWavesPerBlock) + static_cast<uint32_t>(wave);
   const uint32_t full = a.pf_full, tpw_last = a.pf_tpw_last, units_last = a.pf_units_last;
-  const uint32_t R_me = full + (g < units_last ? 1u : 0u);            // rounds in which this workgroup has a unit
-  if (R_me == 0) return;
+  const uint32_t R_me = full + (wv < units_last ? 1u : 0u);           // rounds in which this wave has a unit
+  if (R_me == 0) { if (a.count_sum != 0u && lane0 == 0) a.status[wv] = 0; return; }   // (short input, tapered round with fewer units than waves)
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
   const uint32_t dlo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[0] * 0x01010101u)));
   const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
   const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
   const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
   const uint32_t ep = a.pf_epoch;
+  const uint32_t tag = ep << 16;
   const bool want_rows = a.out != nullptr || a.max_len != 0;
   const bool order = a.count_sum == 0u;                               // count-only calls need no place in the output
+  const uint32_t myblk = wv >> 6, myidx = wv & 63u;
+  const uint32_t hw_wave = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (3 << 11)) & 15u;   // wave slot on its SIMD
 
-  auto tpw_of = [&](uint32_t r) -> uint32_t { return r < full ? 8u : tpw_last; };
-  auto tile_lo_of = [&](uint32_t r, uint32_t j) -> uint64_t {
-    return (static_cast<uint64_t>(r) * 32u * G + static_cast<uint64_t>(g) * 4u * tpw_of(r) + j * 4u + static_cast<uint32_t>(wave)) * static_cast<uint64_t>(kWaveTile);
+  auto tpw_of = [&](uint32_t r) -> uint32_t { return r < full ? static_cast<uint32_t>(kPfTiles) : tpw_last; };
+  auto unit_tile = [&](uint32_t r) -> uint64_t { return static_cast<uint64_t>(r) * kPfTiles * W + static_cast<uint64_t>(wv) * tpw_of(r); };
+  auto round_units = [&](uint32_t rr) -> uint32_t { return rr < full ? W : units_last; };
+  // pf_rec, 384 words of 8 bytes per round: records [128][2] = {tag << 32 | rows of the round in front of the block, tag << 32 |
+  // rows of the round}, then the block sums [128] = tag << 32 | rows of the block
+  auto rec_of = [&](uint32_t rr) -> uint64_t* { return a.pf_rec + static_cast<uint64_t>(rr) * kPfRecStride; };
+  auto units_rsrc = [&](uint32_t rr) -> __amdgpu_buffer_rsrc_t {
+    return __builtin_amdgcn_make_buffer_rsrc(a.pf_status + static_cast<uint64_t>(rr) * W, 0, static_cast<int>(round_units(rr) * 4u), 0x00020000);
   };
-  // the words of round rr: thread t reads words 8 t .. 8 t + 7 of the round (two 16-byte loads past the L1: sc0 sc1)
-  auto round_units = [&](uint32_t rr) -> uint32_t { return rr < full ? G : units_last; };
-  auto status_load = [&](uint32_t rr, u32x4& v0, u32x4& v1) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.pf_status + static_cast<uint64_t>(rr) * G, 0, static_cast<int>(round_units(rr) * 4u), 0x00020000);
-    v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>(tid) * 32u, 0, 17);
-    v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, static_cast<uint32_t>(tid) * 32u + 16u, 0, 17);
+  // what this wave needs of round rr: the record of its block (same address in every lane) and the word of unit 64 * myblk + lane
+  // (both past the L1: sc0 sc1)
+  auto status_load = [&](uint32_t rr, u32x4& vr, uint32_t& vs) {
+    if (CXG_PFABL >= 1) return;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(rec_of(rr) + myblk * 2u, 0, 16, 0x00020000);
+    vr = __builtin_amdgcn_raw_buffer_load_b128(rb, 0u, 0, 17);
+    vs = __builtin_amdgcn_raw_buffer_load_b32(units_rsrc(rr), (myblk * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
   };
-  // this wave's part of the round's sums -> s_part[par][wave]
-  auto status_reduce = [&](uint32_t rr, const u32x4& v0, const u32x4& v1, uint32_t par) -> bool {
-    const uint32_t U = round_units(rr);
-    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bool ok = true;
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-      const uint32_t idx = static_cast<uint32_t>(tid) * 8u + k;
-      ok = ok && (idx >= U || (w[k] >> 16) == ep);
-      const uint32_t c = idx < U ? (w[k] & 0xFFFFu) : 0u;
-      tot += c;
-      pre += idx < g ? c : 0u;
+  // all there?  then pre = rows of the round in front of this unit, tot = rows of the round
+  auto status_reduce = [&](const u32x4& vr, uint32_t vs, uint32_t& pre, uint32_t& tot) -> bool {
+    if (CXG_PFABL >= 1) { pre = wv * 64u; tot = W * 64u; return true; }
+    const bool mine = static_cast<uint32_t>(lane0) < myidx;           // the units of my block in front of me
+    const bool ok = vr.y == tag && vr.w == tag && (!mine || (vs >> 16) == ep);
+    if (__ballot(!ok) != 0ull) return false;
+    const uint32_t p = mine ? (vs & 0xFFFFu) : 0u;
+    pre = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vr.x))) +
+          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(p)), 63));
+    tot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vr.z)));
+    return true;
+  };
+  // ---- duties of a leader.  duty_round = the round this wave still owes something for (block sum first, then — the round's
+  // leader only — the records); duty_stage 0 = nothing owed, 1 = block sum, 2 = records.
+  uint32_t duty_round = 0, duty_stage = 0;
+  auto blk_leader = [&](uint32_t rr) -> bool { const uint32_t U = round_units(rr); return wv + 1u == U || (myidx == 63u && wv < U); };
+  auto duty_load = [&](u32x4& dv) {
+    if (duty_stage == 1u) dv.x = __builtin_amdgcn_raw_buffer_load_b32(units_rsrc(duty_round), (myblk * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
+    else {
+      const uint32_t nblocks = (round_units(duty_round) + 63u) >> 6;
+      const __amdgpu_buffer_rsrc_t rsum = __builtin_amdgcn_make_buffer_rsrc(rec_of(duty_round) + 256, 0, static_cast<int>(nblocks * 8u), 0x00020000);
+      dv = __builtin_amdgcn_raw_buffer_load_b128(rsum, static_cast<uint32_t>(lane0) * 16u, 0, 17);
     }
-    const bool all_ok = __ballot(!ok) == 0ull;
-    const uint32_t tot_w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(tot)), 63));
-    const uint32_t pre_w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(pre)), 63));
-    if (lane0 == 0) { s_part[par][wave][0] = pre_w; s_part[par][wave][1] = tot_w; s_part[par][wave][2] = all_ok ? 1u : 0u; }
-    return all_ok;
+  };
+  auto duty_check = [&](const u32x4& dv) {                            // looks at what duty_load brought; publishes and moves on when complete
+    const uint32_t U = round_units(duty_round);
+    if (duty_stage == 1u) {
+      const uint32_t first = myblk * 64u;
+      const uint32_t expect = U - first < 64u ? U - first : 64u;
+      const bool in = static_cast<uint32_t>(lane0) < expect;
+      if (__ballot(in && (dv.x >> 16) != ep) != 0ull) return;
+      const uint32_t sum = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(in ? (dv.x & 0xFFFFu) : 0u)), 63));
+      if (lane0 == 0) __hip_atomic_store(rec_of(duty_round) + 256 + myblk, (static_cast<uint64_t>(tag) << 32) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      duty_stage = (wv + 1u == U) ? 2u : 0u;                          // the last unit of the round also owes the records
+      return;
+    }
+    const uint32_t nblocks = (U + 63u) >> 6;
+    const uint32_t b0 = static_cast<uint32_t>(lane0) * 2u;
+    const bool ok = (b0 >= nblocks || dv.y == tag) && (b0 + 1u >= nblocks || dv.w == tag);
+    if (__ballot(!ok) != 0ull) return;
+    const uint32_t s0 = b0 < nblocks ? dv.x : 0u, s1 = b0 + 1u < nblocks ? dv.z : 0u;
+    const uint32_t incl = wave_inclusive_sum_fused(s0 + s1);
+    const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc(rec_of(duty_round), 0, static_cast<int>(nblocks * 16u), 0x00020000);
+    const u32x4 r0 = {incl - s0 - s1, tag, total, tag}, r1 = {incl - s1, tag, total, tag};
+    __builtin_amdgcn_raw_buffer_store_b128(r0, rrec, static_cast<uint32_t>(lane0) * 32u, 0, 17);
+    __builtin_amdgcn_raw_buffer_store_b128(r1, rrec, static_cast<uint32_t>(lane0) * 32u + 16u, 0, 17);
+    duty_stage = 0u;
+  };
+  auto duty_finish = [&]() {                                          // no tiles left to hide behind (end of a round with the duty still open, end of the launch)
+    uint32_t spins = 0;
+    while (duty_stage != 0u) {
+      u32x4 dv = {0u, 0u, 0u, 0u};
+      duty_load(dv);
+      const uint32_t before = duty_stage;
+      duty_check(dv);
+      if (duty_stage == before) {
+        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+        __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
+      }
+    }
   };
 
   u32x4 x[4];
   uint32_t sink = 0;
   int32_t nvalid_cur = 0;
-  fields_first_loads(x, fields_window(a.hay, a.len, tile_lo_of(0, 0), true, nvalid_cur), lane, g == 0 && wave == 0);
+  fields_first_loads(x, fields_window(a.hay, a.len, unit_tile(0) * static_cast<uint64_t>(kWaveTile), true, nvalid_cur), lane, wv == 0);
   uint64_t running = 0;                                               // rows in front of the round being ordered (uniform)
-  uint64_t my_total = 0;                                              // count-only: rows of this workgroup's units
+  uint64_t my_total = 0;                                              // count-only: rows of this wave's units
   uint32_t fallback = 0;
+  uint32_t nrows_prev = 0;
+  uint32_t st_waits = 0, st_polls = 0;
+  const uint64_t st_t0 = __builtin_readcyclecounter();
+  uint64_t st_scan = 0;
 
   for (uint32_t r = 0; r <= R_me; r++) {
     const bool scan = r < R_me;
-    const uint32_t par = r & 1u, c3 = r % 3u;
-    u32x4 sv0 = {0u, 0u, 0u, 0u}, sv1 = {0u, 0u, 0u, 0u};
+    const uint32_t par = r & 1u;
+    u32x4 vr = {0u, 0u, 0u, 0u};
+    uint32_t vs = 0;
     uint32_t nrows_w = 0;
     if (scan) {
       const uint32_t tpw = tpw_of(r);
+      const uint64_t t0 = unit_tile(r);
+      const uint64_t st_a = __builtin_readcyclecounter();
       for (uint32_t j = 0; j < tpw; j++) {
         lane = lane0;
         asm volatile("" : "+v"(lane));
+        if (CXG_PF_PRIO) {
+          // VALU issue on a SIMD goes to the highest priority, then to the OLDEST wave: with equal priorities the first-dispatched
+          // of the six waves of a SIMD runs nearly unimpeded and the youngest gets what is left — measured: wave lives between 117
+          // and 220 us for the same work (profiles/r04_pers_wave_times.txt), and a statically partitioned launch ends with its
+          // slowest wave.  Rotate the priorities: (time slice + wave slot) mod 4, the same clock for all waves of a SIMD.
+          const uint32_t slice = static_cast<uint32_t>(__builtin_readcyclecounter() >> CXG_PF_PRIO_SHIFT);
+          switch ((slice + hw_wave) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+          }
+        }
         int32_t nvalid_next = 0;
         const bool last = j + 1 == tpw;
         const bool more = !last || r + 1 < R_me;
-        const uint64_t lo_next = last ? tile_lo_of(r + 1, 0) : tile_lo_of(r, j + 1);
+        const uint64_t lo_next = (last ? unit_tile(r + 1) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
         const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, lo_next, more, nvalid_next);
         uint32_t d0, d1, p0, p1;
         fields_words<KD, KP>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1);
         nvalid_cur = nvalid_next;
-        if (last && order && r > 0) status_load(r - 1, sv0, sv1);     // consumed behind this tile's mathematics
+        const bool duty = duty_stage != 0u;                           // a leader's look of this tile
+        u32x4 dv = {0u, 0u, 0u, 0u};
+        if (duty) duty_load(dv);
+        if (last && order && r > 0) status_load(r - 1, vr, vs);       // consumed behind this tile's mathematics
         const FieldsTile t = fields_core<K>(d0, d1, p0, p1);
         if (t.ovf) fallback |= 1u;
         const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
         const uint32_t incl = wave_inclusive_sum_fused(c);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
         if (tot != 0 && want_rows)
-          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kFRows - 1)); });
-        if (lane == 0) s_cnt[c3][j * 4u + static_cast<uint32_t>(wave)] = tot;
+          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kFRows - 1)); },
+                      j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
         nrows_w += tot;
+        if (duty) duty_check(dv);
       }
-      if (tpw < 8u && lane0 < 8) { if (static_cast<uint32_t>(lane0) >= tpw) s_cnt[c3][static_cast<uint32_t>(lane0) * 4u + static_cast<uint32_t>(wave)] = 0u; }
+      st_scan += __builtin_readcyclecounter() - st_a;
       if (nrows_w > static_cast<uint32_t>(kFRows)) fallback |= 16u;
       wave_lds_sync();
       bool bad = false, long_hit = false;
@@ -547,69 +651,51 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       }
       if (__ballot(bad) != 0ull) fallback |= 2u;
       if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
-    } else if (order && r > 0) {
-      status_load(r - 1, sv0, sv1);
-    }
-    if (order && r > 0) status_reduce(r - 1, sv0, sv1, par);
-    __syncthreads();                                                  // A_r: the unit's counts, the parts of round r - 1
-    if (scan && wave == 0) {                                          // publish the unit's row count
-      const uint32_t v = lane0 < 32 ? s_cnt[c3][lane0] : 0u;
-      const uint32_t tot_u = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(v)), 63));
-      my_total += tot_u;
-      if (order && lane0 == 0)
-        __hip_atomic_store(a.pf_status + static_cast<uint64_t>(r) * G + g, (ep << 16) | tot_u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!order || r == 0) continue;
-    // ---- order and write the rows of round r - 1
-    const uint32_t rp = r - 1u, parp = rp & 1u, c3p = rp % 3u;
-    uint32_t pre = 0, tot = 0, ok = 1;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; w++) { pre += s_part[par][w][0]; tot += s_part[par][w][1]; ok &= s_part[par][w][2]; }
-    if (!ok) {                                                        // uniform over the workgroup: a word of the round was not there yet
-      __syncthreads();                                                // every wave has taken this branch on the same snapshot before a slot is rewritten
-      uint32_t spins = 0;
-      for (;;) {
-        status_load(rp, sv0, sv1);
-        if (status_reduce(rp, sv0, sv1, par)) break;                  // this wave's part is complete (rewritten in place: only this wave writes its slot)
-        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
-        __builtin_amdgcn_s_sleep(8);
+      my_total += nrows_w;
+      if (order && CXG_PFABL < 2) {                                   // publish the unit's row count; a leader takes on the round's duty
+        if (lane0 == 0) __hip_atomic_store(a.pf_status + static_cast<uint64_t>(r) * W + wv, tag | nrows_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CXG_PFABL < 1 && blk_leader(r)) {
+          duty_finish();                                              // (still owing for round r - 1: everybody waits for that)
+          duty_round = r; duty_stage = 1u;
+        }
       }
-      __syncthreads();
-      pre = 0; tot = 0;
-#pragma unroll
-      for (int w = 0; w < kWavesPerBlock; w++) { pre += s_part[par][w][0]; tot += s_part[par][w][1]; }
-      __syncthreads();                                                // nobody rewrites s_part[par] (round r + 2) before all have read it — kept simple: rare path
     }
-    pre = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pre)));
-    tot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tot)));
-    const uint64_t base = running + pre;
-    running += tot;
-    if (a.out != nullptr) {
-      const uint32_t cq = lane0 < 32 ? s_cnt[c3p][lane0] : 0u;
-      const uint32_t eq = wave_inclusive_sum_fused(cq) - cq;          // exclusive prefix over q
-      const uint32_t tpwp = tpw_of(rp);
-      const int64_t origin = a.base + static_cast<int64_t>((static_cast<uint64_t>(rp) * 32u * G + static_cast<uint64_t>(g) * 4u * tpwp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
-      uint32_t start = 0;
-      for (uint32_t j = 0; j < tpwp; j++) {
-        const uint32_t q = j * 4u + static_cast<uint32_t>(wave);
-        const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cq), static_cast<int>(q)));
-        const uint64_t dst = base + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eq), static_cast<int>(q)));
-        const int64_t tb = origin + static_cast<int64_t>(q) * kWaveTile;
+    if (order && !(scan && r + 1 < R_me)) duty_finish();              // no further round to hide behind: the records may be waiting for this wave
+    if (order && r > 0) {
+      if (!scan) status_load(r - 1, vr, vs);
+      // ---- order and write the rows of round r - 1
+      const uint32_t rp = r - 1u, parp = rp & 1u;
+      uint32_t pre = 0, tot = 0, spins = 0;
+      while (!status_reduce(vr, vs, pre, tot)) {                      // something of the round was not there yet
+        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+        __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
+        status_load(rp, vr, vs);
+      }
+      st_waits += spins != 0u ? 1u : 0u; st_polls += spins;           // CXG_VERBOSE statistics, left per wave at the end (an atomic per unit on two words cost 0.8 ms)
+      const uint64_t base = running + pre;
+      running += tot;
+      if (a.out != nullptr && CXG_PFABL < 3) {
+        const int64_t origin = a.base + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
+        const uint32_t n = nrows_prev < static_cast<uint32_t>(kFRows) ? nrows_prev : static_cast<uint32_t>(kFRows);
         for (uint32_t i = lane0; i < n; i += 64) {
-          const uint32_t rr = start + i;
-          if (rr < static_cast<uint32_t>(kFRows) && dst + i < a.cap) {
-            const uint32_t v = s_row[parp][wave][rr];
-            longlong2 o; o.x = tb + (v & 0xFFFFu); o.y = tb + (v >> 16);
-            *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = o;
+          if (base + i < a.cap) {
+            const uint32_t v = s_row[parp][wave][i];
+            store_pair_nt(a.out + (base + i) * a.row_width, origin + (v & 0xFFFFu), origin + (v >> 16));
           }
         }
-        start += n;
       }
     }
+    nrows_prev = nrows_w;
   }
   if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
-  if (!order) { if (tid == 0) a.status[g] = my_total; return; }       // k_sum_counts adds the G words up
-  if (g == 0 && tid == 0) *a.total = running;                         // workgroup 0 has a unit in every round
+  if (!order) { if (lane0 == 0) a.status[wv] = my_total; return; }    // k_sum_counts adds the W words up
+  if (lane0 == 0) {
+    a.pf_stats[wv] = (static_cast<uint64_t>(st_waits) << 32) | st_polls;
+    a.pf_stats[8192 + wv] = __builtin_readcyclecounter() - st_t0;     // s_memtime ticks of this wave's life (100 MHz)
+    a.pf_stats[16384 + wv] = st_scan;                                 // ... of which inside the tile loops
+    a.pf_stats[24576 + wv] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11)) | (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11))) << 32);
+  }
+  if (wv == 0 && lane0 == 0) *a.total = running;                      // wave 0 has a unit in every round
 }
 
 // Does the chain have the shape this kernel evaluates?  run(0) (byte(1) run(0)){K-1}, two classes of one range each,
@@ -649,16 +735,17 @@ bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   const uint64_t nwt = (a.len + kWaveTile - 1) / kWaveTile;
   uint64_t G = static_cast<uint64_t>(cus) * static_cast<uint64_t>(occ);
-  if (G > static_cast<uint64_t>(kPfMaxGrid)) G = kPfMaxGrid;
+  if (G * kWavesPerBlock > static_cast<uint64_t>(kPfMaxWaves)) G = kPfMaxWaves / kWavesPerBlock;
   if (G > (nwt + 3) / 4) G = (nwt + 3) / 4;                           // short input: one tile per wave
-  const uint64_t per_round = 32ull * G;
+  const uint64_t W = G * kWavesPerBlock;
+  const uint64_t per_round = static_cast<uint64_t>(kPfTiles) * W;
   const uint64_t full = nwt / per_round, rem = nwt - full * per_round;
-  const uint64_t tpw_last = (rem + 4 * G - 1) / (4 * G);
-  const uint64_t units_last = tpw_last ? (rem + 4 * tpw_last - 1) / (4 * tpw_last) : 0;
-  if ((full + 1) * G > a.pf_cap || full > 0x7FFFFFFFull) return false;
+  const uint64_t tpw_last = (rem + W - 1) / W;
+  const uint64_t units_last = tpw_last ? (rem + tpw_last - 1) / tpw_last : 0;
+  if ((full + 1) * W > a.pf_cap || full + 1 > a.pf_rec_rounds || full > 0xFFFFull) return false;   // (the round number is part of a block sum's tag: 16 bits = 64 Ki rounds of 180 MiB)
   a.pf_full = static_cast<uint32_t>(full); a.pf_tpw_last = static_cast<uint32_t>(tpw_last); a.pf_units_last = static_cast<uint32_t>(units_last);
   hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
-  if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, G, a.total);
+  if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, W, a.total);
   return true;
 }
 template <int K>
@@ -1036,7 +1123,7 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_sca
         auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
         longlong2 o;
         o.x = sel0 == 7u ? -1 : pos_of(sel0) + off0; o.y = sel1 == 7u ? -1 : pos_of(sel1) + off1;
-        *reinterpret_cast<longlong2*>(a.out + (dst + rr) * a.row_width + 2u * pr) = o;
+        store_pair_nt(a.out + (dst + rr) * a.row_width + 2u * pr, o.x, o.y);
       }
     }
     start += n;

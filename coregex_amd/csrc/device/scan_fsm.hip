@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       if (a.max_len != 0 && static_cast<uint64_t>(e - s) > a.max_len) long_hit = 1;
       if (a.out != nullptr && dst + i < a.cap) {
         longlong2 o; o.x = a.base + s; o.y = a.base + e;
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = o;
+        store_pair_nt(a.out + (dst + i) * a.row_width, o.x, o.y);
       }
     }
     start += n;

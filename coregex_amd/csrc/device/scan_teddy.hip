@@ -46,7 +46,7 @@ struct DirectSinkT {
   int64_t* out; uint64_t cap; uint64_t first; int64_t origin; uint32_t n;
   __device__ __forceinline__ void emit(int32_t s, int32_t e) {
     const uint64_t row = first + n++;
-    if (row < cap) { longlong2 v; v.x = origin + s; v.y = origin + e; *reinterpret_cast<longlong2*>(out + row * 2) = v; }
+    if (row < cap) { longlong2 v; v.x = origin + s; v.y = origin + e; store_pair_nt(out + row * 2, v.x, v.y); }
   }
 };
 }  // namespace
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_teddy(ScanArgs a) {
         longlong2 v;
         v.x = origin + static_cast<int32_t>(s_recs[i * 3 + 0]);
         v.y = origin + static_cast<int32_t>(s_recs[i * 3 + 1]);
-        *reinterpret_cast<longlong2*>(a.out + row * 2) = v;
+        store_pair_nt(a.out + row * 2, v.x, v.y);
       }
     }
   } else {

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
       if (r < static_cast<uint32_t>(kTRows) && dst + i < a.cap) {
         const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
         longlong2 v; v.x = tb + s_rs[wave][r]; v.y = tb + s_re[wave][r];
-        *reinterpret_cast<longlong2*>(a.out + (dst + i) * a.row_width) = v;
+        store_pair_nt(a.out + (dst + i) * a.row_width, v.x, v.y);
       }
     }
     start += n;

@@ -126,7 +126,15 @@ def test_dense_input(oracle):
     the call reruns on the chain kernel's dense mode, as do 480 — with the oracle's rows either way."""
     _check(oracle, IP, b"10.0.0.1 - some words of padding here..\n" * 12000, want_kernel=None)      # 96 rows per wave-tile
     t = _check(oracle, IP, b"1.2.3.4 " * 60000, want_kernel=None)                    # 480 rows per wave-tile
-    assert t.n_launches >= 2
+    # (round 4: on a haystack this short the persistent kernel's units are ONE wave-tile with the whole 512-row buffer — no rerun)
+    assert t.n_launches >= 1
+    hay = np.frombuffer(b"1.2.3.4 " * (26 << 20), dtype=np.uint8)                    # 208 MiB: full rounds of eight tiles per unit — they overflow
+    rx = cx.compile(IP)
+    import torch
+    d = torch.from_numpy(hay.copy()).cuda()
+    t = cx.Timing()
+    n = rx.find_all_device(d.data_ptr(), hay.size, timing=t)
+    assert n == (26 << 20) and t.n_launches >= 2
 
 
 @pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_TICKETS": "1"}, K_FIELDS), ({"CXG_NO_EPOCH": "1"}, K_FIELDS)])
