@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
   SetRanges rg;
   rg.n = ax->nr;
+  const uint32_t flip = ax->neg ? 0u : 0xFFFFu;                     // notset4 flags the bytes OUTSIDE the ranges: the members of a complemented class
 #pragma unroll
   for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
   __syncthreads();
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       for (int k = 0; k < 4; k++) {
         const uint32_t lo = __builtin_amdgcn_udot4(notset4(x[k].y, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].x, rg), 0x08040201u, 0u, false), false);
         const uint32_t hi = __builtin_amdgcn_udot4(notset4(x[k].w, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].z, rg), 0x08040201u, 0u, false), false);
-        pieces[lane + 64 * k] = static_cast<uint16_t>(((lo >> 7) | (hi << 1)) ^ 0xFFFFu);
+        pieces[lane + 64 * k] = static_cast<uint16_t>(((lo >> 7) | (hi << 1)) ^ flip);
         __builtin_amdgcn_sched_barrier(0);
       }
       const uint32_t xprev_cur = xprev;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
         const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
 #pragma unroll
         for (int q = 0; q < 4; q++) if (static_cast<uint32_t>(q) < ax->nr && pb >= ax->lo[q] && pb <= ax->hi[q]) prev_member = 1;
+        prev_member ^= ax->neg ? 1u : 0u;
       }
       uint64_t carry = from_lower64(M) >> 63;                      // DPP outside lane-dependent branches
       if (lane == 0) carry = prev_member;

@@ -544,6 +544,30 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why) {
   return true;
 }
 
+// Is the language of the anchored break-at-match DFA `C+` for one byte set C — every live state leaves on exactly the bytes of
+// C, every state but the start accepts?  (The DFA need not be minimal: `[^,]+` over UTF-8 has a state per pending sequence
+// shape, all of them accepting with the same exits, because the reference's automaton of a class that covers everything past
+// U+007F also takes any byte >= 0x80 alone, nfa/compile.go:440-590.)  Then leftmost-first FindAll = the maximal runs of C.
+bool isClassPlus(const Dfa& d, uint8_t member[256]) {
+  if (d.start == 0 || d.start >= d.firstAccept) return false;
+  for (int b = 0; b < 256; b++) member[b] = d.table[static_cast<size_t>(d.start) * 256 + b] != 0;
+  std::vector<uint8_t> seen(d.nstates, 0);
+  std::vector<uint32_t> st{d.start};
+  seen[d.start] = 1;
+  bool any = false;
+  while (!st.empty()) {
+    const uint32_t q = st.back(); st.pop_back();
+    if (q != d.start && q < d.firstAccept) return false;
+    for (int b = 0; b < 256; b++) {
+      const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+      if ((t != 0) != (member[b] != 0)) return false;
+      if (t == d.start) return false;                              // (cannot happen for a break-at-match DFA of a non-nullable pattern)
+      if (t != 0) { any = true; if (!seen[t]) { seen[t] = 1; st.push_back(t); } }
+    }
+  }
+  return any;
+}
+
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
   p->strategy = strategy;
   p->flags = flags;
@@ -696,6 +720,25 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         refuseLookDfaQuirks(nfa, strategy == CXG_USE_DFA ? &rvw : nullptr);
         finishFsmOnly(strategy == CXG_USE_BOTH ? cxgdev::kBothRestartSpan : 0u);
         return;
+      }
+      if (strategy == CXG_USE_DFA) {
+        // `\S+`, `[^,]+`, `[^"]+`, `[a-z0-9_.-]+` ...: one class, one or more times.  The DFA pair's leftmost-first FindAll (forward
+        // DFA to the end of the run, reverse DFA back to its start, dfa/lazy/lazy.go:1102-1315, 1769-1920) is the list of the
+        // maximal runs of the class — the char-class kernels' job (scan_charclass_wave.hip: runs as long as the haystack,
+        // rows straight from the bitmaps), not the transducer's: 7.9 ms -> per GiB for `\S+`, 1.4 s for `[^,]+` on the table kernel.
+        static const bool noClassRuns = getenv("CXG_NO_CLASS_RUNS") != nullptr;
+        uint8_t member[256];
+        bool plus = false;
+        if (!noClassRuns) {
+          try { plus = isClassPlus(determinize(nfa, nfa.start_anchored, true, kMaxDfaStates), member); } catch (const BuildError&) { plus = false; }
+        }
+        if (plus) {
+          const int keepStrategy = p->strategy;
+          const int keepGroups = p->ngroups;
+          buildProgramFromCharClass(p, member, 1);
+          p->strategy = keepStrategy; p->ngroups = keepGroups;
+          if (p->supported) return;
+        }
       }
       p->fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
       if (p->fwd.start >= p->fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
@@ -1250,6 +1293,20 @@ void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], ui
       while (e + 1 < 256 && membership[e + 1]) e++;
       if (e > 127 || ax.nr >= 4) { ok = false; break; }
       ax.lo[ax.nr] = static_cast<uint8_t>(b); ax.hi[ax.nr] = static_cast<uint8_t>(e); ax.nr++;
+    }
+    if (!ok || ax.nr < 1) {
+      // ... or the COMPLEMENT of such a union with every byte >= 0x80 a member: `\S`, `[^,]`, `[^"]` as byte sets (round 4)
+      std::memset(&ax, 0, sizeof ax);
+      ok = true;
+      for (int b = 128; b < 256 && ok; b++) ok = membership[b] != 0;
+      for (int b = 0; b < 128 && ok; b++) {
+        if (membership[b] || (b > 0 && !membership[b - 1])) continue;
+        int e = b;
+        while (e + 1 < 128 && !membership[e + 1]) e++;
+        if (ax.nr >= 4) { ok = false; break; }
+        ax.lo[ax.nr] = static_cast<uint8_t>(b); ax.hi[ax.nr] = static_cast<uint8_t>(e); ax.nr++;
+      }
+      ax.neg = 1;
     }
     if (ok && ax.nr >= 1) {
       h.flags |= cxgdev::kFlagCcRanges;

@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONPATH=$GRAFT_REPO_ROOT
-{ echo "product"; timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1
-  echo "variant nt (nontemporal row stores)"; CXG_LIB_PATH=$GRAFT_REPO_ROOT/coregex_amd/variants/libcoregex_hip_nt.so timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1
-  echo grouped; CXG_NO_PERSIST=1 timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1
-  echo "64 GiB, persistent"; timeout 300 python bench.py --total-gib 64 --steps 5 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms_avg": [0-9.]*\|"frac": [0-9.]*'
-  echo "64 GiB, grouped"; CXG_NO_PERSIST=1 timeout 300 python bench.py --total-gib 64 --steps 5 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms_avg": [0-9.]*\|"frac": [0-9.]*'
-  echo "64 GiB, nt"; CXG_LIB_PATH=$GRAFT_REPO_ROOT/coregex_amd/variants/libcoregex_hip_nt.so timeout 300 python bench.py --total-gib 64 --steps 5 --warmup 1 --settle 2 --no-cpu-baseline --no-pmc 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"kernel_ms_avg": [0-9.]*\|"frac": [0-9.]*'
-} > gpurun_out/r04_pers_64g.txt 2>&1; cat gpurun_out/r04_pers_64g.txt
+{ for occ in 6 5 4; do echo "product (7 tiles per unit), CXG_PF_OCC=$occ"; CXG_PF_OCC=$occ timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1; done
+  for v in t9 t5 t11 noprio pf1; do echo "variant $v"; CXG_LIB_PATH=$GRAFT_REPO_ROOT/coregex_amd/variants/libcoregex_hip_$v.so timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1; done
+  echo "variant t9 occ 5"; CXG_PF_OCC=5 CXG_LIB_PATH=$GRAFT_REPO_ROOT/coregex_amd/variants/libcoregex_hip_t9.so timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "verbose"; CXG_VERBOSE=1 timeout 120 python scripts/time_modes.py 2>&1 | grep -v amdgpu.ids | grep -v XCD | tail -3
+} > gpurun_out/r04_pers_tune_nt.txt 2>&1; cat gpurun_out/r04_pers_tune_nt.txt

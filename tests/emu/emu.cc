@@ -496,7 +496,7 @@ extern "C" int64_t emu_find_all_charclass_wave(const uint8_t* blob, const uint8_
   if (h->magic != kBlobMagic || h->kind != kKindCharClass) return -1;
   if (!(h->flags & kFlagCcRanges)) return -4;
   const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(blob + h->aux_off);
-  auto member = [&](uint32_t b) { for (uint32_t q = 0; q < ax->nr; q++) if (b >= ax->lo[q] && b <= ax->hi[q]) return true; return false; };
+  auto member = [&](uint32_t b) { bool in = false; for (uint32_t q = 0; q < ax->nr; q++) if (b >= ax->lo[q] && b <= ax->hi[q]) in = true; return in != (ax->neg != 0); };
   const int64_t N = tile_bytes + halo_bytes;
   std::vector<int64_t> res;
   const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;

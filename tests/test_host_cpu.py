@@ -487,7 +487,8 @@ def test_wide_fuzz_host_and_twins(oracle):
                             got = emu.find_all_fsm(rx.fsm_image(), np.frombuffer(hay, dtype=np.uint8), 3840, 32, dense=1)
                         assert isinstance(got, int) or got.tolist() == exp, (pat, rx.strategy, len(hay))
                         continue
-                    if rx.strategy != "UseCharClassSearcher":
+                    is_cc = struct.unpack_from("<I", blob, 4)[0] == 3    # kKindCharClass: UseCharClassSearcher, or (round 4) a `C+` program of a DFA strategy
+                    if not is_cc:
                         assert emu.find_all(blob, hay).tolist() == exp, (pat, rx.strategy, len(hay))
                     twins = []
                     if (flags & 16) and rx.strategy in ("UseDFA", "UseDigitPrefilter", "UseBoth"):
@@ -498,7 +499,7 @@ def test_wide_fuzz_host_and_twins(oracle):
                             twins = [emu.find_all_chain6(blob, hay, 192, 64), emu.find_all_chain6(blob, hay, 3840, 256)]
                     elif struct.unpack_from("<I", blob, 4)[0] == 4 or (flags & 256):   # literal image, or required literal prefix + anchored DFA
                         twins = [emu.find_all_teddy_wave(blob, hay)]
-                    elif rx.strategy == "UseCharClassSearcher" and (flags & 64):
+                    elif is_cc and (flags & 64):
                         twins = [emu.find_all_charclass_wave(blob, hay)]
                     for got in twins:
                         if got is not None and not isinstance(got, int):
@@ -995,6 +996,10 @@ def test_bounded_backtracker_programs_through_the_twins(oracle):
         blob = rx.blob()
         for hay in (corpus[:50000], mixed[rng.integers(0, len(mixed), size=6000)], mixed[rng.integers(0, 6, size=3000)], np.zeros(0, dtype=np.uint8)):
             exp = o.find_all_index(hay).tolist()
+            if struct.unpack_from("<I", blob, 4)[0] == 3:           # round 4: `C+` programs (`\\S+`, `[^,]+`) are the char-class kernels'
+                got = emu.find_all_charclass_wave(blob, hay) if struct.unpack_from("<I", blob, 8)[0] & 64 else None
+                assert got is None or isinstance(got, int) or got.tolist() == exp, (pat, "class runs", len(hay))
+                continue
             assert emu.find_all(blob, hay).tolist() == exp, (pat, "lanes", len(hay))
             if rx.fsm_image() is not None:
                 got = emu.find_all_fsm(rx.fsm_image(), hay, 3840, 32)
@@ -1005,5 +1010,5 @@ def test_bounded_backtracker_programs_through_the_twins(oracle):
     for name in ("la_tokens", "word_repeat"):
         rx = cx.compile(COMPAT_PATTERNS[name])
         if rx.supported:
-            got = emu.find_all(rx.blob(), corpus)
+            got = emu.find_all_charclass_wave(rx.blob(), corpus) if struct.unpack_from("<I", rx.blob(), 4)[0] == 3 else emu.find_all(rx.blob(), corpus)
             assert len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name
