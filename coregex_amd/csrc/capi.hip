@@ -96,6 +96,8 @@ struct Scratch {
   uint32_t* pfStatus = nullptr; uint64_t pfCap = 0; uint32_t pfEpoch = 0;   // k_scan_fields_pers: one word per unit, own 16-bit launch epoch
   uint64_t* pfRec = nullptr; uint64_t pfRecRounds = 0;   // ... 128 records of 16 bytes per round, tagged with the same epoch
   uint64_t* pfStats = nullptr;                           // ... per wave: units that waited, polls (CXG_VERBOSE)
+  int64_t* nullRows = nullptr; uint64_t nullRowsCap = 0;  // nullable programs (scanNullable): rows of the non-empty variant,
+  uint64_t* nullCov = nullptr; uint64_t nullCovCap = 0;   // ... inclusive sums of the positions they cover, + one sum per block of 4096 rows
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
   int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
   unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
@@ -115,6 +117,8 @@ struct Scratch {
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
       if (bt) (void)hipFree(bt);
+      if (nullRows) (void)hipFree(nullRows);
+      if (nullCov) (void)hipFree(nullCov);
       if (bothHay) (void)hipFree(bothHay);
       if (bothRows) (void)hipFree(bothRows);
       if (bothFirst) (void)hipFree(bothFirst);
@@ -179,6 +183,8 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 }
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
+int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                 uint64_t* n_out, void* user_stream, cxg_timing* timing);
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) table-walking generation (A/B profiling);
 // default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain) when
@@ -802,6 +808,7 @@ __global__ void k_first_long(const int64_t* rows, uint64_t n, uint32_t width, in
 constexpr int kMaxBothRestarts = 64;
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+  if (p && p->nullable && row_width == 2 && p->supported) return scanNullable(p, d_hay, len, base, limit, d_out, cap, n_out, user_stream, timing);
   uint64_t n_cur = 0;
   int rc = scanDeviceOnce(p, d_hay, len, base, limit, d_out, cap, &n_cur, user_stream, timing, row_width);
   if (rc != kRcLongMatch) { if (n_out) *n_out = n_cur; return rc; }
@@ -924,6 +931,178 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
   return CXG_OK;
 }
 
+// ---- nullable programs -------------------------------------------------------------------------------------------------------
+// FindAll of a pattern that matches the empty string (meta/findall.go:216-283): the rows R of its non-empty variant
+// (program.cc nonEmptyVariant), and an empty match [p, p] at every position p in 0..len outside the closed intervals [s, e] of
+// R — inside a match the loop does not search, at its end the empty match is skipped (`start == end && start == lastMatchEnd`,
+// :251-257), everywhere else the search at p answers at once with the empty path.  All in position order.
+// cov[i] = size of the union of the closed intervals of rows 0..i (adjacent rows share their common point).
+constexpr uint32_t kNullBlock = 4096;                              // rows per block of the prefix sum
+__global__ __launch_bounds__(1024) void k_null_cover(const int64_t* rows, uint64_t n, uint64_t* cov, uint64_t* bsum) {
+  __shared__ uint64_t s_w[16];
+  const uint64_t b0 = static_cast<uint64_t>(blockIdx.x) * kNullBlock;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t c[4], t = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = b0 + static_cast<uint64_t>(threadIdx.x) * 4 + k;
+    c[k] = 0;
+    if (i < n) {
+      const int64_t s = rows[2 * i], e = rows[2 * i + 1];
+      c[k] = static_cast<uint64_t>(e - s + 1) - ((i > 0 && rows[2 * i - 1] == s) ? 1u : 0u);
+    }
+    t += c[k];
+    c[k] = t;                                                       // inclusive inside the thread
+  }
+  uint64_t incl = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint64_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint64_t off = incl - t;
+  for (int w = 0; w < wave; w++) off += s_w[w];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t i = b0 + static_cast<uint64_t>(threadIdx.x) * 4 + k;
+    if (i < n) cov[i] = off + c[k];
+  }
+  if (threadIdx.x == 1023) bsum[blockIdx.x] = off + t;
+}
+__global__ __launch_bounds__(1024) void k_null_block_offsets(uint64_t* bsum, uint64_t nb) {   // exclusive sums of the block totals, one workgroup
+  __shared__ uint64_t s_w[16];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const uint64_t i = b0 + threadIdx.x;
+    const uint64_t v = i < nb ? bsum[i] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint64_t off = s_carry + incl - v;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    if (i < nb) bsum[i] = off;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = off + v;
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ uint64_t null_cov_incl(const uint64_t* cov, const uint64_t* bsum, uint64_t i) { return cov[i] + bsum[i / kNullBlock]; }
+// the non-empty rows at their places: rows in front + uncovered positions in front
+__global__ void k_null_rows(const int64_t* rows, uint64_t n, const uint64_t* cov, const uint64_t* bsum, int64_t base, int64_t* out, uint64_t cap) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = rows[2 * i], e = rows[2 * i + 1];
+  const uint64_t adj = (i > 0 && rows[2 * i - 1] == s) ? 1u : 0u;
+  const uint64_t own = static_cast<uint64_t>(e - s + 1) - adj;
+  const uint64_t below = null_cov_incl(cov, bsum, i) - own - adj;   // covered positions strictly below s
+  const uint64_t at = i + (static_cast<uint64_t>(s) - below);
+  if (at < cap) cxgdev::store_pair_nt(out + 2 * at, base + s, base + e);
+}
+// the empty matches: one thread per position 0..len
+__global__ void k_null_empties(const int64_t* rows, uint64_t n, const uint64_t* cov, const uint64_t* bsum, uint64_t len, int64_t base, int64_t* out, uint64_t cap) {
+  const uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p > len) return;
+  uint64_t lo = 0, hi = n;                                          // number of rows with start <= p
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (static_cast<uint64_t>(rows[2 * mid]) <= p) lo = mid + 1; else hi = mid;
+  }
+  uint64_t at = p;
+  if (lo > 0) {
+    if (p <= static_cast<uint64_t>(rows[2 * (lo - 1) + 1])) return; // inside a match, or at its end
+    at = lo + (p - null_cov_incl(cov, bsum, lo - 1));
+  }
+  if (at < cap) cxgdev::store_pair_nt(out + 2 * at, base + static_cast<int64_t>(p), base + static_cast<int64_t>(p));
+}
+
+int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                 uint64_t* n_out, void* user_stream, cxg_timing* timing) {
+  if (n_out) *n_out = 0;
+  if (timing) std::memset(timing, 0, sizeof *timing);
+  if (limit == 0) return CXG_OK;
+  if (len >= (1ull << 40)) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
+  if (d_out && (reinterpret_cast<uintptr_t>(d_out) & 15u)) return fail(CXG_E_INVALID, "device output must be 16-byte aligned");
+  uint64_t n = 0;
+  cxg_timing inner;
+  std::memset(&inner, 0, sizeof inner);
+  float kernel_ms = 0, total_ms = 0;
+  uint32_t launches = 0;
+  if (!p->nullableOnlyEmpty && len > 0) {
+    if (int rc = scanDeviceOnce(p, d_hay, len, 0, -1, nullptr, 0, &n, user_stream, &inner, 2)) return rc;
+    kernel_ms += inner.kernel_ms; total_ms += inner.total_ms; launches += inner.n_launches;
+    if (n > 0) {
+      if (2 * n > s.nullRowsCap) {
+        if (s.nullRows) HIP_TRY(hipFree(s.nullRows));
+        s.nullRows = nullptr; s.nullRowsCap = 0;
+        const uint64_t c = 2 * n + n / 2 + 1024;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.nullRows), c * sizeof(int64_t)));
+        s.nullRowsCap = c;
+      }
+      uint64_t n2 = 0;
+      if (int rc = scanDeviceOnce(p, d_hay, len, 0, -1, s.nullRows, n, &n2, user_stream, &inner, 2)) return rc;
+      if (n2 != n) return fail(CXG_E_INTERNAL, "nullable program: the rerun for rows disagrees with the count");
+      kernel_ms += inner.kernel_ms; total_ms += inner.total_ms; launches += inner.n_launches;
+    }
+  }
+  const uint64_t nb = (n + kNullBlock - 1) / kNullBlock;
+  uint64_t covered = 0;
+  HIP_TRY(hipEventRecord(s.ev[0], stream));
+  if (n > 0) {
+    if (n + nb + 8 > s.nullCovCap) {
+      if (s.nullCov) HIP_TRY(hipFree(s.nullCov));
+      s.nullCov = nullptr; s.nullCovCap = 0;
+      const uint64_t c = n + nb + n / 2 + 1024;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.nullCov), c * sizeof(uint64_t)));
+      s.nullCovCap = c;
+    }
+    uint64_t* cov = s.nullCov;
+    uint64_t* bsum = s.nullCov + n;
+    hipLaunchKernelGGL(k_null_cover, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, stream, s.nullRows, n, cov, bsum);
+    hipLaunchKernelGGL(k_null_block_offsets, dim3(1), dim3(1024), 0, stream, bsum, nb);
+    HIP_TRY(hipGetLastError());
+    uint64_t last[2] = {0, 0};                                      // cov[n - 1] inside its block, offset of the last block
+    HIP_TRY(hipMemcpyAsync(&last[0], cov + (n - 1), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&last[1], bsum + (nb - 1), 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    covered = last[0] + last[1];
+    launches += 2;
+  }
+  if (covered > len + 1) return fail(CXG_E_INTERNAL, "nullable program: rows cover more positions than the haystack has");
+  uint64_t total = n + (len + 1 - covered);
+  if (limit > 0 && total > static_cast<uint64_t>(limit)) total = static_cast<uint64_t>(limit);
+  if (n_out) *n_out = total;
+  if (d_out) {
+    const uint64_t room = std::min<uint64_t>(cap, total);          // rows at places >= room are not wanted (FindAll's n) or do not fit
+    int64_t* out = static_cast<int64_t*>(d_out);
+    if (n > 0) hipLaunchKernelGGL(k_null_rows, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, s.nullRows, n, s.nullCov, s.nullCov + n, base, out, room);
+    const uint64_t npos = len + 1;
+    if ((npos + 255) / 256 > 0x7FFFFFFFull) return fail(CXG_E_INVALID, "haystack too large for one launch; shard it");
+    hipLaunchKernelGGL(k_null_empties, dim3(static_cast<unsigned>((npos + 255) / 256)), dim3(256), 0, stream, s.nullRows, n, s.nullCov, s.nullCov + n, len, base, out, room);
+    HIP_TRY(hipGetLastError());
+    launches += n > 0 ? 2 : 1;
+  }
+  HIP_TRY(hipEventRecord(s.ev[2], stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (timing) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
+    *timing = inner;
+    timing->kernel_ms = kernel_ms + t; timing->total_ms = total_ms + t; timing->n_launches = launches;
+  }
+  if (s.nullRowsCap * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.nullRows); s.nullRows = nullptr; s.nullRowsCap = 0; }
+  if (s.nullCovCap * sizeof(uint64_t) > kKeepStagingBytes) { (void)hipFree(s.nullCov); s.nullCov = nullptr; s.nullCovCap = 0; }
+  if (d_out && total > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
+  return CXG_OK;
+}
+
 uint64_t tilesFor(uint32_t kind, uint64_t len) {
   (void)kind;
   return (len + cxgdev::kTile - 1) / cxgdev::kTile;
@@ -946,7 +1125,7 @@ int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64
   if (width > 2 ? !p->subSupported : !p->supported)
     return fail(CXG_E_UNSUPPORTED, width > 2 ? p->subWhyNot : (p->whyNot.empty() ? "unsupported program" : p->whyNot));
   if (n_out) *n_out = 0;
-  if (limit == 0 || len == 0) return CXG_OK;
+  if (limit == 0 || (len == 0 && !(p->nullable && width == 2))) return CXG_OK;   // (a nullable pattern matches the empty haystack once)
   Scratch* sp;
   if (int rc = getScratch(&sp)) return rc;
   Scratch& s = *sp;

@@ -544,6 +544,86 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why) {
   return true;
 }
 
+// Nullable patterns.  At a search position `at` the leftmost-first match of a pattern that can match the empty string starts
+// AT `at` — the empty path is always there — and is the first accepting path in priority order: a path that consumes bytes wins
+// only if it ranks ABOVE the empty path, and paths below the empty one never win.  So FindAll (meta/findall.go:216-283: report,
+// skip an empty match at the end of the previous non-empty one, advance by one byte behind an empty match) is
+//   * the leftmost-first FindAll of the NON-EMPTY VARIANT — the pattern restricted to the consuming threads that precede Match
+//     in the closure of its start (order of dfa/lazy/builder.go:245-293 = order of pikevm.go's thread list) —, and
+//   * an empty match at every position 0..len that no non-empty match [s, e) covers with its closed interval [s, e].
+// The variant is the same NFA entered through a chain of splits over those threads (their continuations are untouched); the
+// device serves it like any UseNFA program, capi.hip scanNullable adds the empty matches.  Returns false when the start's
+// closure holds no Match (not nullable); sawLook: an assertion stands in front of it (refused: nullable at SOME positions only).
+bool nonEmptyVariant(const cxg_nfa& nfa, HostNfa& out, bool& sawLook, size_t& nthreads) {
+  sawLook = false;
+  nthreads = 0;
+  std::vector<uint8_t> seen(nfa.n_states, 0);
+  std::vector<uint32_t> stack{nfa.start_anchored}, threads;
+  bool nullable = false;
+  while (!stack.empty() && !nullable) {
+    const uint32_t cur = stack.back();
+    stack.pop_back();
+    if (cur == CXG_NFA_INVALID || cur >= nfa.n_states || seen[cur]) continue;
+    seen[cur] = 1;
+    const cxg_nfa_state& st = nfa.states[cur];
+    switch (st.kind) {
+      case CXG_NFA_MATCH: nullable = true; break;
+      case CXG_NFA_BYTE_RANGE: case CXG_NFA_SPARSE: threads.push_back(cur); break;
+      case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE: stack.push_back(st.next); break;
+      case CXG_NFA_SPLIT: stack.push_back(st.right); stack.push_back(st.left); break;
+      case CXG_NFA_LOOK: sawLook = true; break;                     // (whether it holds depends on the position)
+      default: break;
+    }
+  }
+  if (!nullable) return false;
+  nthreads = threads.size();
+  out = HostNfa();
+  out.states.assign(nfa.states, nfa.states + nfa.n_states);
+  out.trans.assign(nfa.trans, nfa.trans + nfa.n_trans);
+  out.captureCount = nfa.capture_count;
+  if (threads.empty()) return true;
+  auto blank = [](uint8_t kind) { cxg_nfa_state x; std::memset(&x, 0, sizeof x); x.kind = kind; x.next = x.left = x.right = CXG_NFA_INVALID; return x; };
+  uint32_t entry = threads.back();
+  for (size_t i = threads.size() - 1; i-- > 0;) {
+    cxg_nfa_state sp = blank(CXG_NFA_SPLIT);
+    sp.left = threads[i]; sp.right = entry;
+    out.states.push_back(sp);
+    entry = static_cast<uint32_t>(out.states.size() - 1);
+  }
+  cxg_nfa_state any = blank(CXG_NFA_BYTE_RANGE);                   // unanchored prefix: Split(pattern, [00-FF] -> self), compile.go:1633-1650
+  any.lo = 0x00; any.hi = 0xFF;
+  out.states.push_back(any);
+  const uint32_t anyIdx = static_cast<uint32_t>(out.states.size() - 1);
+  cxg_nfa_state sp = blank(CXG_NFA_SPLIT);
+  sp.left = entry; sp.right = anyIdx;
+  out.states.push_back(sp);
+  const uint32_t spIdx = static_cast<uint32_t>(out.states.size() - 1);
+  out.states[anyIdx].next = spIdx;
+  out.startAnchored = entry;
+  out.startUnanchored = spIdx;
+  // What the new starts do not reach — the pattern's own unanchored prefix above all — must not stay behind: reverseOf() reverses
+  // every state it finds, and the old prefix loop, entered backwards from the old start, would keep the reverse DFA alive for ever
+  // (a start walk over the whole haystack; found on the device: 300 000-byte haystacks refused with the serial-walk error).
+  {
+    std::vector<uint8_t> reach(out.states.size(), 0);
+    std::vector<uint32_t> st{spIdx};
+    while (!st.empty()) {
+      const uint32_t q = st.back(); st.pop_back();
+      if (q == CXG_NFA_INVALID || q >= out.states.size() || reach[q]) continue;
+      reach[q] = 1;
+      const cxg_nfa_state& x = out.states[q];
+      switch (x.kind) {
+        case CXG_NFA_BYTE_RANGE: case CXG_NFA_EPSILON: case CXG_NFA_CAPTURE: case CXG_NFA_LOOK: st.push_back(x.next); break;
+        case CXG_NFA_SPLIT: st.push_back(x.left); st.push_back(x.right); break;
+        case CXG_NFA_SPARSE: for (uint32_t k = 0; k < x.trans_len; k++) st.push_back(out.trans[x.trans_off + k].next); break;
+        default: break;
+      }
+    }
+    for (size_t q = 0; q < out.states.size(); q++) if (!reach[q]) out.states[q] = blank(CXG_NFA_FAIL);
+  }
+  return true;
+}
+
 // Is the language of the anchored break-at-match DFA `C+` for one byte set C — every live state leaves on exactly the bytes of
 // C, every state but the start accepts?  (The DFA need not be minimal: `[^,]+` over UTF-8 has a state per pending sequence
 // shape, all of them accepting with the same exits, because the reference's automaton of a class that covers everything past
@@ -605,6 +685,14 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       if (hasLook) throw BuildError{CXG_E_UNSUPPORTED, "UseBoundedBacktracker program with assertions (the backtracker searches a slice of the haystack: no context in front of it)"};
       strategy = CXG_USE_DFA;
       flags |= CXG_FLAG_HAS_REVERSE_DFA;
+      {  // `\d*`, `[a-z]*`: nullable, and still this strategy (isSimpleCharClass is asked before canMatchEmpty, strategy.go:1095-1128).
+         // Both of its engines are leftmost-first, so FindAll is the loop of meta/findall.go:216-283 over plain leftmost-first
+         // matches: the UseNFA branch's non-empty variant + scanNullable.
+        HostNfa probe;
+        bool sawLook = false;
+        size_t nthreads = 0;
+        if (nonEmptyVariant(nfa, probe, sawLook, nthreads)) strategy = CXG_USE_NFA;
+      }
     }
     // A look-around program that passed its proof (lookdfa.cc) is the pattern's transducer and nothing else: no table-walking image.
     auto finishFsmOnly = [&](uint32_t maxLen) {
@@ -821,13 +909,41 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
         }
         (void)sawLine;
       }
-      HostNfa rn = reverseOf(nfa);
-      cxg_nfa rvw = rn.view();
       bool look = false;
       for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;
+      // Nullable pattern (the reference sends every one of them here: canMatchEmpty, meta/strategy.go:1503): the program is the
+      // non-empty variant's transducer, the empty matches are added behind the scan (capi.hip scanNullable).
+      HostNfa variant;
+      const cxg_nfa* prog = &nfa;
+      cxg_nfa variantView;
+      if (strategy == CXG_USE_NFA) {
+        bool sawLook = false;
+        size_t nthreads = 0;
+        if (nonEmptyVariant(nfa, variant, sawLook, nthreads)) {
+          if (look) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern with assertions (empty matches at some positions only)"};
+          p->nullable = true;
+          if (nthreads == 0) {                                      // `a*?`, `(|a)`: only empty matches
+            p->nullableOnlyEmpty = true;
+            h.kind = cxgdev::kKindFsmOnly;
+            h.info_off = static_cast<uint32_t>(blob.size());
+            blob.insert(blob.end(), info, info + 256);
+            h.total_bytes = static_cast<uint32_t>(blob.size());
+            std::memcpy(blob.data(), &h, sizeof h);
+            p->blob.swap(blob);
+            p->supported = true;
+            return;
+          }
+          variantView = variant.view();
+          prog = &variantView;
+        } else if (sawLook && !look) {
+          throw BuildError{CXG_E_INTERNAL, "assertion met in a program without LOOK states"};
+        }
+      }
+      HostNfa rn = reverseOf(*prog);
+      cxg_nfa rvw = rn.view();
       Dfa rv;
       if (!look) rv = determinize(rvw, rvw.start_anchored, false, kMaxDfaStates);
-      if (!buildFsmImage(nfa, rv, 0u, p->fsmBlob, p->fsmWhyNot, look ? &rvw : nullptr)) { p->fsmBlob.clear(); throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
+      if (!buildFsmImage(*prog, rv, 0u, p->fsmBlob, p->fsmWhyNot, look ? &rvw : nullptr)) { p->fsmBlob.clear(); p->nullable = false; throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
       h.kind = cxgdev::kKindFsmOnly;
       h.info_off = static_cast<uint32_t>(blob.size());
       blob.insert(blob.end(), info, info + 256);

@@ -44,6 +44,10 @@ struct cxg_program {
   int nfaStates = -1;
   bool supported = false;
   std::string whyNot;
+  // Nullable pattern (`a*`, `x?y*`; always UseNFA, meta/strategy.go:1503): the device program is the pattern's NON-EMPTY variant;
+  // capi.hip scanNullable merges its rows with the empty matches of meta/findall.go:251-275.  nullableOnlyEmpty: no path of
+  // higher priority than the empty one consumes a byte (`a*?`, `(|a)`): every match is empty, no device program at all.
+  bool nullable = false, nullableOnlyEmpty = false;
   cxg::HostNfa nfa;              // kept for cxg_program_nfa (cxg_compile only)
   cxg::Dfa fwd, rev;
   std::vector<uint8_t> blob;     // cxgdev::BlobHeader + tables
