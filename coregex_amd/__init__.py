@@ -107,6 +107,11 @@ class Regex:
         return bool(_lib.lib().cxg_program_supported(self._h))
 
     @property
+    def nullable(self) -> int:
+        """0: not nullable; 1: the device program is the non-empty variant (empty matches merged behind the scan); 2: only empty matches."""
+        return int(_lib.lib().cxg_program_nullable(self._h))
+
+    @property
     def why_unsupported(self) -> str:
         if self.supported:
             return ""

@@ -1412,6 +1412,7 @@ uint32_t cxg_program_flags(const cxg_program* p) { return p ? p->flags : 0u; }
 int cxg_program_num_groups(const cxg_program* p) { return p ? p->ngroups : 0; }
 int cxg_program_nfa_states(const cxg_program* p) { return p ? p->nfaStates : -1; }
 int cxg_program_dfa_states(const cxg_program* p) { return p ? static_cast<int>(p->fwd.nstates) : 0; }
+int cxg_program_nullable(const cxg_program* p) { return !p || !p->nullable ? 0 : (p->nullableOnlyEmpty ? 2 : 1); }
 int cxg_program_supported(const cxg_program* p) {
   if (p && !p->supported) t_err = p->whyNot;
   return p && p->supported ? 1 : 0;

@@ -146,6 +146,9 @@ int cxg_program_num_groups(const cxg_program* p);       /* NumSubexp()+1 */
 int cxg_program_nfa_states(const cxg_program* p);       /* -1 if built without an NFA */
 int cxg_program_dfa_states(const cxg_program* p);       /* eager forward DFA states incl. dead */
 int cxg_program_supported(const cxg_program* p);        /* 1 if the device path accepts it */
+/* Nullable pattern (`a*`, `x?y*`: matches the empty string; meta/findall.go:251-275 is its FindAll rule)?  0 no; 1 the device
+   program is the pattern's non-empty variant and the empty matches are merged behind the scan; 2 every match is empty (`a*?`). */
+int cxg_program_nullable(const cxg_program* p);
 /* Device image of the program (what every kernel stages into LDS); for tests and the emulator. */
 int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
 /* Diagnostics: the FindAll transducer image of the general-DFA kernel (coregex_amd/csrc/device/fsm.hpp): of the

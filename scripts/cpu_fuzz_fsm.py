@@ -92,6 +92,8 @@ def main(n=300, seed=1, look=False, wide=False):
                         reasons[got] = reasons.get(got, 0) + 1
                         continue
                     n_checked += 1
+                    if which == "idx" and rx.nullable:                   # the image is the non-empty variant's: the empty matches are merged behind the scan
+                        got = emu.merge_empty_matches(got, len(hay))
                     if got.shape != exp.shape or not np.array_equal(got, exp):
                         np.save("/tmp/fsm_fail_hay.npy", hay)
                         print("MISMATCH", repr(pat), rx.strategy, which, tile, chunk, bytes(hay[:120]), got[:6].tolist(), exp[:6].tolist())

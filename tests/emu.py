@@ -229,3 +229,14 @@ def fsm_maps_check(image: bytes, hay, tile: int = 3840, tiles_per_group: int = 3
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
     return int(lib().emu_fsm_maps_check(image, padded.ctypes.data + 8, a.size, int(tile), int(tiles_per_group)))
+
+
+def merge_empty_matches(rows: np.ndarray, n: int) -> np.ndarray:
+    """FindAll of a NULLABLE pattern from the rows of its non-empty variant over a haystack of n bytes (meta/findall.go:216-283;
+    what capi.hip scanNullable computes on the device): an empty match at every position 0..n outside the closed intervals [s, e]."""
+    covered = np.zeros(n + 2, dtype=bool)
+    for s, e in np.asarray(rows).reshape(-1, 2).tolist():
+        covered[s:e + 1] = True
+    out = [(int(s), int(e)) for s, e in np.asarray(rows).reshape(-1, 2).tolist()] + [(p, p) for p in range(n + 1) if not covered[p]]
+    out.sort()
+    return np.array(out, dtype=np.int64).reshape(-1, 2)

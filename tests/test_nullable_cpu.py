@@ -14,14 +14,7 @@ import emu
 PATTERNS = [r"a*", r"x?y*", r"\d*", r"[a-z]*", r"(?:ab)*", r"\w*x?", r"(a|b)*c?", r"a*b*", r"(?:a|bc)*", r"\S*", r"a*?", r"(|a)", r"(?:a*)*", r"b*a?b*"]
 
 
-def merge_empty_matches(rows: np.ndarray, n: int) -> np.ndarray:
-    """FindAll of the nullable pattern from the rows of its non-empty variant over a haystack of n bytes."""
-    covered = np.zeros(n + 2, dtype=bool)
-    for s, e in rows.tolist():
-        covered[s:e + 1] = True
-    out = [(int(s), int(e)) for s, e in rows.tolist()] + [(p, p) for p in range(n + 1) if not covered[p]]
-    out.sort(key=lambda r: (r[0], r[1] != r[0]))          # an empty match at p sorts in front of a row that starts at p — which cannot exist
-    return np.array(out, dtype=np.int64).reshape(-1, 2)
+merge_empty_matches = emu.merge_empty_matches
 
 
 def variant_rows(rx, hay: np.ndarray) -> np.ndarray:
