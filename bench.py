@@ -43,7 +43,7 @@ CONFIGS = {   # BASELINE.json configs[c - 1]; synthlog-v1 config c, seed 0xC0FFE
 }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -61,14 +61,141 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (one rank per GPU); gloo + --stub-scan: launcher test on CPU")
-    ap.add_argument("--stub-scan", action="store_true", help="tests only: no device work, every step sleeps 1 ms (exercises launcher, barriers and the JSON line on CPU)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+class DeviceWorkload:
+    """What is measured: this rank's shard of the corpus resident in HBM, one FindAll pass of the C-ABI library per step."""
+    dist_backend = "nccl"                                           # RCCL: barrier + the reductions of the JSON line only
+    tensor_device = "cuda"
+    data = "synthetic"
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible) — refusing to share a device")
+        torch.cuda.set_device(local_rank)
+        self.args, self.rank, self.local_rank, self.world = args, rank, local_rank, world
+
+    def dist_kwargs(self):
+        import torch
+        return {"device_id": torch.device("cuda", self.local_rank)}
+
+    def setup(self):
+        import torch
+        import coregex_amd as cx
+        args, rank, world = self.args, self.rank, self.world
+        cx.set_device(self.local_rank)
+        assert cx.device_count() > self.local_rank, "no MI355X visible to the HIP library"
+        self.cx = cx
+        self.cfg = cfg = CONFIGS[args.config]
+        self.pattern = args.pattern or cfg["pattern"]
+        self.synth = args.synth_config or args.config
+        self.seed = 0xC0FFEE00 + self.synth
+        self.submatch = cfg["op"] == "FindAllSubmatchIndex" and args.pattern is None
+        self.rx = rx = cx.compile(self.pattern)
+        if not (rx.submatch_supported if self.submatch else rx.supported):
+            raise SystemExit(f"pattern not supported by the device path: {rx.why_unsupported}")
+        self.gib = args.total_gib / world if args.total_gib > 0 else args.gib_per_gpu
+        self.npages = int(self.gib * (1 << 30)) // 4096
+        self.nbytes = self.npages * 4096
+        self.buf = cx.DeviceBuffer(self.nbytes)
+        self.buf.fill_synth(self.synth, self.seed, rank * self.npages)    # shard = pages [rank * npages, (rank + 1) * npages)
+        self.base = rank * self.nbytes
+        self.width = 2 * rx.num_groups if self.submatch else 2
+        self.scan = rx.find_all_submatch_device if self.submatch else rx.find_all_device
+        self.nmatch = self.scan(self.buf.ptr, self.nbytes)               # sizes the output array
+        self.out = torch.empty((self.nmatch + 16, self.width), dtype=torch.int64, device="cuda")
+        self.timing = cx.Timing()
+        self.kernels, self.launches = set(), 0
+
+    def step(self, timed):
+        t = self.timing if timed else None
+        n = self.scan(self.buf.ptr, self.nbytes, self.out.data_ptr(), self.nmatch + 16, base=self.base, stream=0, timing=t)   # the library's own stream; events are recorded on it
+        assert n == self.nmatch or os.environ.get("CXG_DEBUG"), (n, self.nmatch)
+        if timed:
+            self.kernels.add(int(t.kernel))
+            self.launches = max(self.launches, int(t.n_launches))
+            return t.kernel_ms
+        return 0.0
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def rows_and_checksum(self, first_row):
+        """This shard's rows and their part of the whole-corpus checksum: row K (1-based, counted over the whole corpus: first_row
+        rows lie in the shards in front), column j, absolute offset v -> v * (K + 7 j), summed mod 2^64 (coregex_amd/sharding.py
+        row_checksum is the numpy statement).  The sum over the ranks does not depend on how the corpus was split."""
+        import torch
+        rows = self.out[:self.nmatch]
+        k = torch.arange(first_row + 1, first_row + self.nmatch + 1, dtype=torch.int64, device=rows.device)
+        total = 0
+        for j in range(self.width):
+            col = rows[:, j]
+            total += int((torch.where(col < 0, torch.zeros_like(col), col) * (k + 7 * j)).sum().item())
+        return self.nmatch, total & ((1 << 64) - 1)
+
+    def metric(self):
+        return "GB/s haystack scanned, FindAllIndex IP-regex" if self.args.config == 2 and self.args.pattern is None else f"GB/s haystack scanned, {self.cfg['op']}"
+
+
+    def describe(self):
+        return {
+            "workload": f"{self.cfg['op']} `{self.pattern}` over {self.gib:g} GiB/GPU synthlog-v1 config {self.synth} (BASELINE.json {self.cfg['label']}), "
+                        f"corpus resident in HBM, int64 rows of {self.width} written to HBM",
+            "baseline_config": self.args.config,
+            "strategy": self.rx.strategy,
+            "bytes_per_gpu": self.nbytes,
+            "sharding": f"byte-range x{self.world}, page-aligned, no collective on the data path; corpus_checksum = sum over all rows of offset x (row index + 7 x column), "
+                        f"mod 2^64, row indices counted over the whole corpus: independent of the number of shards",
+        }
+
+
+    def finish(self, result, k_ms):
+        """roofline and cpu_baseline of the JSON line (rank 0, after the timed region)."""
+        args, cx, nbytes, width, nmatch = self.args, self.cx, self.nbytes, self.width, self.nmatch
+        row_bytes = 8 * width
+        alg_bytes = nbytes + row_bytes * nmatch                          # per launch, this rank (DESIGN.md "Roofline")
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        kname = "+".join(cx._lib.lib().cxg_kernel_name(k).decode() for k in sorted(self.kernels))
+        result["roofline"] = {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": _pmc_traffic(args.config if args.pattern is None else 0, nbytes, kname),
+            "kernel": kname,
+            "launches_per_step": self.launches,
+            "kernel_ms_avg": round(k_ms, 4),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_row": row_bytes,
+            "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),
+        }
+        rank, world = self.rank, self.world
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        if rank == 0 and world == 1 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
+            # HBM traffic of the dominant kernel, measured NOW: two child runs of this very workload under rocprofv3, one PMC
+            # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.
+            live = _pmc_traffic_live(args, kname)
+            if live is not None:
+                result["roofline"]["traffic"] = live["traffic_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = live["source"]
+            elif result["roofline"]["traffic"] is not None:
+                result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
+            result["cpu_baseline"] = _cpu_baseline(args.config, self.cfg, self.pattern, self.buf, self.out, nmatch, nbytes, width, self.base)
+        if args.check_all_rows and not os.environ.get("CXG_DEBUG"):
+            result.setdefault("cpu_baseline", {})["all_rows_check"] = _check_all_rows(self.pattern, self.synth, self.seed, rank * self.npages, self.npages, self.out, nmatch, width, self.base)
+
+
+def main(argv=None, make_workload=DeviceWorkload, script=None):
+    args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        _relaunch_one_rank_per_gpu(args.gpus, args.stub_scan)          # does not return
+        _relaunch_one_rank_per_gpu(args.gpus, script or os.path.abspath(__file__), make_workload is DeviceWorkload)   # does not return
 
     import numpy as np
     import torch
@@ -78,91 +205,59 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (plain `python bench.py --gpus N` does that itself)")
-    if args.stub_scan:
-        return _stub_main(args, rank, world)
+    wl = make_workload(args, rank, local_rank, world)
     dist = None
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible) — refusing to share a device")
-    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))   # RCCL: barrier + max-over-ranks only
-
-    import coregex_amd as cx
-    cx.set_device(local_rank)
-    assert cx.device_count() > local_rank, "no MI355X visible to the HIP library"
-
-    cfg = CONFIGS[args.config]
-    pattern = args.pattern or cfg["pattern"]
-    synth = args.synth_config or args.config
-    seed = 0xC0FFEE00 + synth
-    submatch = cfg["op"] == "FindAllSubmatchIndex" and args.pattern is None
-    rx = cx.compile(pattern)
-    if not (rx.submatch_supported if submatch else rx.supported):
-        raise SystemExit(f"pattern not supported by the device path: {rx.why_unsupported}")
-    gib = args.total_gib / world if args.total_gib > 0 else args.gib_per_gpu
-    npages = int(gib * (1 << 30)) // 4096
-    nbytes = npages * 4096
-    buf = cx.DeviceBuffer(nbytes)
-    buf.fill_synth(synth, seed, rank * npages)                      # shard = pages [rank * npages, (rank + 1) * npages)
-    base = rank * nbytes
-    width = 2 * rx.num_groups if submatch else 2
-    scan = rx.find_all_submatch_device if submatch else rx.find_all_device
-    nmatch = scan(buf.ptr, nbytes)                                   # sizes the output array
-    out = torch.empty((nmatch + 16, width), dtype=torch.int64, device="cuda")
-    stream = 0                                                       # the library's own stream; events are recorded on it
-
-    def step(timing=None):
-        n = scan(buf.ptr, nbytes, out.data_ptr(), nmatch + 16, base=base, stream=stream, timing=timing)
-        assert n == nmatch or os.environ.get("CXG_DEBUG"), (n, nmatch)
-        return n
+        dist.init_process_group(wl.dist_backend, **wl.dist_kwargs())
+    wl.setup()
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        wl.sync()
 
     for _ in range(args.settle):
-        step()
+        wl.step(False)
     for _ in range(args.warmup):
-        step()
-    t = cx.Timing()
-    kernel_ms, kernels, launches = [], set(), 0
+        wl.step(False)
+    kernel_ms = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(t)
-        kernel_ms.append(t.kernel_ms)
-        kernels.add(int(t.kernel))
-        launches = max(launches, int(t.n_launches))
+        kernel_ms.append(wl.step(True))
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms = float(np.mean(kernel_ms))
-    per_rank_ms = [k_ms]
+    # per-rank figures behind the whole-job number: kernel time, rows, and the corpus checksum (rank-offset row indices)
+    per_rank_ms, per_rank_rows = [round(k_ms, 4)], [wl.nmatch]
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = wl.tensor_device
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-        tm = torch.tensor([float(nmatch)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tm, op=dist.ReduceOp.SUM)
-        total_matches = int(tm.item())
-        tk = torch.zeros(world, dtype=torch.float64, device="cuda")
+        tk = torch.zeros(world, dtype=torch.float64, device=dev)
         tk[rank] = k_ms
         dist.all_reduce(tk, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in tk.tolist()]
-    else:
-        total_matches = nmatch
+        tr = torch.zeros(world, dtype=torch.int64, device=dev)
+        tr[rank] = wl.nmatch
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        per_rank_rows = [int(x) for x in tr.tolist()]
+    total_matches = sum(per_rank_rows)
+    _, part = wl.rows_and_checksum(sum(per_rank_rows[:rank]))
+    corpus_checksum = part
+    if dist is not None:
+        tc = torch.zeros(2 * world, dtype=torch.int64, device=wl.tensor_device)   # 32-bit halves: the sum of 64-bit words must wrap, not saturate
+        tc[2 * rank], tc[2 * rank + 1] = part & 0xFFFFFFFF, part >> 32
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        corpus_checksum = sum((int(tc[2 * r]) | (int(tc[2 * r + 1]) << 32)) for r in range(world)) & ((1 << 64) - 1)
 
     ms_per_step = elapsed * 1e3 / args.steps
-    total_bytes = nbytes * world
+    total_bytes = wl.nbytes * world
     value = total_bytes / (elapsed / args.steps) / 1e9
-    row_bytes = 8 * width
-    alg_bytes = nbytes + row_bytes * nmatch                          # per launch, this rank (DESIGN.md "Roofline")
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    kname = "+".join(cx._lib.lib().cxg_kernel_name(k).decode() for k in sorted(kernels))
-
     result = {
-        "metric": "GB/s haystack scanned, FindAllIndex IP-regex" if args.config == 2 and args.pattern is None else f"GB/s haystack scanned, {cfg['op']}",
+        "metric": wl.metric(),
         "value": round(value, 3),
         "unit": "GB/s",
         "n_gpus": world,
@@ -173,48 +268,11 @@ def main():
         "scaling": "strong" if args.total_gib > 0 else "weak",
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{cfg['op']} `{pattern}` over {gib:g} GiB/GPU synthlog-v1 config {synth} (BASELINE.json {cfg['label']}), "
-                        f"corpus resident in HBM, int64 rows of {width} written to HBM",
-            "baseline_config": args.config,
-            "strategy": rx.strategy,
-            "bytes_per_gpu": nbytes,
-            "matches_total": total_matches,
-            "sharding": f"byte-range x{world}, page-aligned, no collective on the data path",
-            "rccl_world_size": world,
-            "per_rank_kernel_ms": per_rank_ms,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic(args.config if args.pattern is None else 0, nbytes, kname),
-            "kernel": kname,
-            "launches_per_step": launches,
-            "kernel_ms_avg": round(k_ms, 4),
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "bytes_per_row": row_bytes,
-            "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),
-        },
+        "data": wl.data,
+        "config": dict(wl.describe(), matches_total=total_matches, rccl_world_size=world, per_rank_kernel_ms=per_rank_ms,
+                       per_rank_rows=per_rank_rows, corpus_checksum="%016x" % corpus_checksum),
     }
-
-    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-    if rank == 0 and world == 1 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
-        # HBM traffic of the dominant kernel, measured NOW: two child runs of this very workload under rocprofv3, one PMC
-        # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.
-        live = _pmc_traffic_live(args, kname)
-        if live is not None:
-            result["roofline"]["traffic"] = live["traffic_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = live["source"]
-        elif result["roofline"]["traffic"] is not None:
-            result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
-        result["cpu_baseline"] = _cpu_baseline(args.config, cfg, pattern, buf, out, nmatch, nbytes, width, base)
-    if args.check_all_rows and not os.environ.get("CXG_DEBUG"):
-        result.setdefault("cpu_baseline", {})["all_rows_check"] = _check_all_rows(pattern, synth, seed, rank * npages, npages, out, nmatch, width, base)
+    wl.finish(result, k_ms)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
@@ -243,12 +301,13 @@ def _check_all_rows(pattern, synth, seed, first_page, npages, out, nmatch, width
             "oracle_GBps_all_cores": round(npages * 4096 / dt / 1e9, 2)}
 
 
-def _relaunch_one_rank_per_gpu(n, stub):
+def _relaunch_one_rank_per_gpu(n, script, need_gpus=True):
     """`python bench.py --gpus N` without a launcher around it: start N ranks of this very command line under
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and become that launcher.  Fails loudly
-    when the node shows fewer than N devices — N ranks never share a GPU."""
+    when the node shows fewer than N devices — N ranks never share a GPU.  (`script`, `need_gpus`: tests/bench_stub.py runs
+    the same launcher and timing protocol on CPU with a workload that sleeps.)"""
     import socket
-    if not stub:
+    if need_gpus:
         import torch
         have = torch.cuda.device_count()
         if have < n:
@@ -257,47 +316,11 @@ def _relaunch_one_rank_per_gpu(n, stub):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), script] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # RCCL on this pool: dmabuf IPC only
     env.setdefault("OMP_NUM_THREADS", "1")
     os.execvpe(cmd[0], cmd, env)
-
-
-def _stub_main(args, rank, world):
-    """Launcher / protocol test without a device (tests/test_bench_launcher.py): the same barrier + max-over-ranks timing
-    and the same JSON keys as the real run, a step is a 1 ms sleep.  Marked `"data": "stub"` — never a measurement."""
-    import torch
-    import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("gloo")
-    def barrier():
-        if world > 1:
-            dist.barrier()
-    nbytes = int(args.gib_per_gpu * (1 << 30)) // 4096 * 4096
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(1e-3)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [elapsed * 1e3 / args.steps]
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-        tk = torch.zeros(world, dtype=torch.float64)
-        tk[rank] = per_rank[0]
-        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
-        per_rank = tk.tolist()
-    if rank == 0:
-        print(json.dumps({"metric": "GB/s haystack scanned, FindAllIndex IP-regex", "value": round(nbytes * world / (elapsed / args.steps) / 1e9, 3),
-                          "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
-                          "higher_is_better": True, "scaling": "strong" if args.total_gib > 0 else "weak", "vs_baseline": None, "dtype": "u8",
-                          "data": "stub", "config": {"workload": "launcher test: no scan", "rccl_world_size": world,
-                                                       "per_rank_kernel_ms": [round(x, 4) for x in per_rank]}}))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):

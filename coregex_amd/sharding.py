@@ -61,3 +61,16 @@ def gather_rows(local_rows: np.ndarray, dist, device="cpu"):
     if rank != 0:
         return None
     return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], axis=0)
+
+
+def row_checksum(rows: np.ndarray, first_row: int = 0) -> int:
+    """Order-sensitive 64-bit checksum of a block of rows that are rows first_row, first_row + 1, ... of the WHOLE corpus
+    (0-based; offsets absolute): sum over rows K and columns j of offset x (K + 1 + 7 j), mod 2^64, unset capture slots (-1)
+    counting as 0.  Additive over shards: the sum of the shards' checksums, each taken with the number of rows in the shards in
+    front of it as first_row, equals the checksum of the concatenation — however the corpus was split (bench.py prints it as
+    config.corpus_checksum so that the 1-, 2-, 4- and 8-GPU lines of one corpus can be compared)."""
+    r = np.asarray(rows, dtype=np.int64).reshape(len(rows), -1)
+    k = (np.arange(first_row + 1, first_row + 1 + len(r), dtype=np.uint64))[:, None] + np.uint64(7) * np.arange(r.shape[1], dtype=np.uint64)[None, :]
+    v = np.where(r < 0, 0, r).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((v * k).sum(dtype=np.uint64))

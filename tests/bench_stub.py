@@ -1,0 +1,59 @@
+"""TEST SCAFFOLDING (not a measurement): bench.py's launcher, barrier + max-over-ranks timing and JSON line on CPU, with a workload
+whose step is a 1 ms sleep and whose "rows" are a fixed synthetic table split over the ranks (so the per-rank rows and the
+corpus checksum of the line can be checked without a device).  tests/test_bench_launcher.py runs it; the line says "data": "stub".
+(Round 3 kept this inside bench.py as --stub-scan; VERDICT round 3 asked for it to live here.)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+TOTAL_ROWS = 1000                                                   # row k of the corpus: [100 k, 100 k + 7]
+
+
+class StubWorkload:
+    dist_backend = "gloo"
+    tensor_device = "cpu"
+    data = "stub"
+
+    def __init__(self, args, rank, local_rank, world):
+        self.args, self.rank, self.world = args, rank, world
+
+    def dist_kwargs(self):
+        return {}
+
+    def setup(self):
+        self.nbytes = int(self.args.gib_per_gpu * (1 << 30)) // 4096 * 4096
+        lo = TOTAL_ROWS * self.rank // self.world
+        hi = TOTAL_ROWS * (self.rank + 1) // self.world
+        self.first, self.nmatch = lo, hi - lo
+
+    def step(self, timed):
+        time.sleep(1e-3)
+        return 1.0
+
+    def sync(self):
+        pass
+
+    def rows_and_checksum(self, first_row):
+        import numpy as np
+        from coregex_amd import sharding
+        assert first_row == self.first
+        k = np.arange(self.first, self.first + self.nmatch, dtype=np.int64)
+        rows = np.stack([100 * k, 100 * k + 7], axis=1)
+        return self.nmatch, sharding.row_checksum(rows, first_row)
+
+    def metric(self):
+        return "launcher test: no scan"
+
+    def describe(self):
+        return {"workload": "launcher test: no scan"}
+
+    def finish(self, result, k_ms):
+        pass
+
+
+if __name__ == "__main__":
+    bench.main(make_workload=StubWorkload, script=os.path.abspath(__file__))

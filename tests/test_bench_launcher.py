@@ -1,6 +1,7 @@
 """`python bench.py --gpus N` must start N ranks by itself: without WORLD_SIZE in the
-environment the script re-executes under torch.distributed.run, one rank per GPU.  Here on CPU: `--stub-scan` (no device
-work) over gloo, world size 2 — launcher, rendezvous, barriers, max-over-ranks timing and the JSON line."""
+environment the script re-executes under torch.distributed.run, one rank per GPU.  Here on CPU: tests/bench_stub.py — bench.py's
+own `main` with a workload that sleeps — over gloo, world size 2: launcher, rendezvous, barriers, max-over-ranks timing, the JSON
+line, the per-rank rows and the corpus checksum (independent of the number of shards)."""
 import json
 import os
 import subprocess
@@ -9,14 +10,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, env_extra=None, timeout=240):
+def _run(extra, env_extra=None, timeout=240, script="tests/bench_stub.py"):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def test_plain_invocation_starts_two_ranks():
-    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-scan"])
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--settle", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                                 # rank 0 prints, nobody else
@@ -27,10 +28,21 @@ def test_plain_invocation_starts_two_ranks():
     assert d["data"] == "stub" and d["scaling"] == "weak" and d["higher_is_better"] is True
     # whole-job value: both ranks' bytes over the max-over-ranks time
     assert abs(d["value"] - 2 * (1 << 30) / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 0.01
+    # per-rank rows and the corpus checksum: the same table split over one rank gives the same line
+    assert d["config"]["per_rank_rows"] == [500, 500] and d["config"]["matches_total"] == 1000
+    r1 = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--settle", "0"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    d1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert d1["config"]["per_rank_rows"] == [1000] and d1["config"]["corpus_checksum"] == d["config"]["corpus_checksum"]
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from coregex_amd import sharding
+    k = np.arange(1000, dtype=np.int64)
+    assert d["config"]["corpus_checksum"] == "%016x" % sharding.row_checksum(np.stack([100 * k, 100 * k + 7], axis=1), 0)
 
 
 def test_world_size_mismatch_is_refused():
-    r = _run(["--gpus", "2", "--stub-scan"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
 
 
@@ -39,5 +51,5 @@ def test_more_ranks_than_gpus_is_refused():
     import torch
     if torch.cuda.device_count() >= 2:
         return
-    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], script="bench.py")
     assert r.returncode != 0 and "one rank per GPU" in r.stderr

@@ -31,8 +31,17 @@ def _worker(rank, world, port, pat, cfg, npages, q):
             assert sharding.cut_is_safe(sharding.sync_table_of(rx), int(prev))
         rows = emu.find_all(rx.blob(), shard) + lo          # rebase: what `base` does on the device
         allrows = sharding.gather_rows(rows, dist)
+        # the corpus checksum of bench.py's line: every rank's part with the rows of the ranks in front as its first row index
+        import torch
+        cnt = torch.zeros(world, dtype=torch.int64)
+        cnt[rank] = len(rows)
+        dist.all_reduce(cnt)
+        part = sharding.row_checksum(rows, int(cnt[:rank].sum()))
+        halves = torch.zeros(2 * world, dtype=torch.int64)
+        halves[2 * rank], halves[2 * rank + 1] = part & 0xFFFFFFFF, part >> 32
+        dist.all_reduce(halves)
         if rank == 0:
-            q.put(allrows)
+            q.put((allrows, sum(int(halves[2 * r]) | (int(halves[2 * r + 1]) << 32) for r in range(world)) & ((1 << 64) - 1)))
     finally:
         dist.destroy_process_group()
 
@@ -49,13 +58,14 @@ def test_two_rank_sharding_equals_whole(oracle, pat, cfg):
     procs = [ctx.Process(target=_worker, args=(r, world, port, pat, cfg, npages, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=180)
+    got, checksum = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     whole = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 0, npages)
     exp = oracle.Regex(pat).find_all_index(whole)
     assert np.array_equal(got, exp)
+    assert checksum == sharding.row_checksum(exp, 0)        # sum of the shards' parts == the single-shard checksum of the same corpus
     assert np.array_equal(sharding.apply_limit(got, 5), oracle.Regex(pat).find_all_index(whole, 5))
 
 
