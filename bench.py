@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
+    ap.add_argument("--u32-rows", action="store_true",
+                    help="rows through cxg_find_all_device_u32 (two uint32 relative to the shard, 8 bytes per match) instead of the int64 ABI; "
+                         "the algorithmic bytes of the roofline follow the layout.  Char-class and fields programs only (configs 4 and 2)")
     return ap.parse_args(argv)
 
 
@@ -103,15 +106,19 @@ class DeviceWorkload:
         self.buf.fill_synth(self.synth, self.seed, rank * self.npages)    # shard = pages [rank * npages, (rank + 1) * npages)
         self.base = rank * self.nbytes
         self.width = 2 * rx.num_groups if self.submatch else 2
-        self.scan = rx.find_all_submatch_device if self.submatch else rx.find_all_device
+        self.u32 = bool(args.u32_rows)
+        if self.u32 and self.submatch:
+            raise SystemExit("--u32-rows: FindAllIndex programs only")
+        self.scan = rx.find_all_submatch_device if self.submatch else (rx.find_all_device_u32 if self.u32 else rx.find_all_device)
         self.nmatch = self.scan(self.buf.ptr, self.nbytes)               # sizes the output array
-        self.out = torch.empty((self.nmatch + 16, self.width), dtype=torch.int64, device="cuda")
+        self.out = torch.empty((self.nmatch + 16, self.width), dtype=torch.int32 if self.u32 else torch.int64, device="cuda")
         self.timing = cx.Timing()
         self.kernels, self.launches = set(), 0
 
     def step(self, timed):
         t = self.timing if timed else None
-        n = self.scan(self.buf.ptr, self.nbytes, self.out.data_ptr(), self.nmatch + 16, base=self.base, stream=0, timing=t)   # the library's own stream; events are recorded on it
+        kw = {} if self.u32 else {"base": self.base}                # compact rows are relative to the shard
+        n = self.scan(self.buf.ptr, self.nbytes, self.out.data_ptr(), self.nmatch + 16, stream=0, timing=t, **kw)   # the library's own stream; events are recorded on it
         assert n == self.nmatch or os.environ.get("CXG_DEBUG"), (n, self.nmatch)
         if timed:
             self.kernels.add(int(t.kernel))
@@ -129,6 +136,8 @@ class DeviceWorkload:
         row_checksum is the numpy statement).  The sum over the ranks does not depend on how the corpus was split."""
         import torch
         rows = self.out[:self.nmatch]
+        if self.u32:
+            rows = (rows.to(torch.int64) & 0xFFFFFFFF) + self.base
         k = torch.arange(first_row + 1, first_row + self.nmatch + 1, dtype=torch.int64, device=rows.device)
         total = 0
         for j in range(self.width):
@@ -143,7 +152,7 @@ class DeviceWorkload:
     def describe(self):
         return {
             "workload": f"{self.cfg['op']} `{self.pattern}` over {self.gib:g} GiB/GPU synthlog-v1 config {self.synth} (BASELINE.json {self.cfg['label']}), "
-                        f"corpus resident in HBM, int64 rows of {self.width} written to HBM",
+                        f"corpus resident in HBM, {'uint32 (shard-relative)' if self.u32 else 'int64'} rows of {self.width} written to HBM",
             "baseline_config": self.args.config,
             "strategy": self.rx.strategy,
             "bytes_per_gpu": self.nbytes,
@@ -155,7 +164,7 @@ class DeviceWorkload:
     def finish(self, result, k_ms):
         """roofline and cpu_baseline of the JSON line (rank 0, after the timed region)."""
         args, cx, nbytes, width, nmatch = self.args, self.cx, self.nbytes, self.width, self.nmatch
-        row_bytes = 8 * width
+        row_bytes = (4 if self.u32 else 8) * width
         alg_bytes = nbytes + row_bytes * nmatch                          # per launch, this rank (DESIGN.md "Roofline")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         kname = "+".join(cx._lib.lib().cxg_kernel_name(k).decode() for k in sorted(self.kernels))
@@ -184,7 +193,7 @@ class DeviceWorkload:
                 result["roofline"]["traffic_source"] = live["source"]
             elif result["roofline"]["traffic"] is not None:
                 result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
-        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not os.environ.get("CXG_DEBUG"):
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not self.u32 and not os.environ.get("CXG_DEBUG"):
             result["cpu_baseline"] = _cpu_baseline(args.config, self.cfg, self.pattern, self.buf, self.out, nmatch, nbytes, width, self.base)
         if args.check_all_rows and not os.environ.get("CXG_DEBUG"):
             result.setdefault("cpu_baseline", {})["all_rows_check"] = _check_all_rows(self.pattern, self.synth, self.seed, rank * self.npages, self.npages, self.out, nmatch, width, self.base)
@@ -439,6 +448,8 @@ def _pmc_traffic_live(args, kernel):
         child += ["--pattern", args.pattern]
     if args.synth_config is not None:
         child += ["--synth-config", str(args.synth_config)]
+    if args.u32_rows:
+        child += ["--u32-rows"]
     fam = kernel.split("+")[-1].split("<")[0]
     means = {}
     tmp = tempfile.mkdtemp(prefix="cxg_pmc_", dir="/tmp")

@@ -216,6 +216,19 @@ class Regex:
         return int(got.value)
 
 
+def _find_all_device_u32(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, n: int = -1, stream: int = 0,
+                         timing: "Timing | None" = None) -> int:
+    """cxg_find_all_device_u32: rows of two uint32 relative to d_hay (8 bytes per match); d_out == 0 counts."""
+    got = C.c_uint64(0)
+    rc = _lib.lib().cxg_find_all_device_u32(self._h, d_hay, length, n, d_out or None, cap, C.byref(got), stream or None,
+                                            C.byref(timing) if timing is not None else None)
+    _check(rc)
+    return int(got.value)
+
+
+Regex.find_all_device_u32 = _find_all_device_u32
+
+
 def compile(pattern) -> Regex:  # noqa: A001  (mirrors coregex.Compile)
     p = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
     h = C.c_void_p()

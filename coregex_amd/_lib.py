@@ -25,7 +25,7 @@ SYMBOLS = [
     "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_nullable", "cxg_program_blob",
     "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
-    "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device",
+    "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
     "cxg_find_all_submatch_device",
 ]
 
@@ -129,6 +129,7 @@ def lib():
     L.cxg_buffer_fill_synth.argtypes = [vp, u32, u64, u64]
     L.cxg_synth_page_host.argtypes = [u32, u64, u64, vp]
     L.cxg_find_all_device.argtypes = [vp, vp, u64, i64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
+    L.cxg_find_all_device_u32.argtypes = [vp, vp, u64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
     L.cxg_find_all_submatch_device.argtypes = [vp, vp, u64, i64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
     _lib = L
     return L

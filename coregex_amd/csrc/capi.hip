@@ -29,7 +29,7 @@ size_t scan_dfa_dynamic_lds(uint32_t fwd_states, uint32_t rev_states);
 hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
-hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
 int fields_shape(const ChainAux& c);
 int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
@@ -185,6 +185,7 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
                  uint64_t* n_out, void* user_stream, cxg_timing* timing);
+thread_local bool t_u32Rows = false;                               // cxg_find_all_device_u32 in progress on this thread (ScanArgs::u32_rows)
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) table-walking generation (A/B profiling);
 // default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain) when
@@ -395,6 +396,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.pf_status = nullptr;                                           // (set per launch by the fields programs' branch below)
+  a.u32_rows = t_u32Rows ? 1u : 0u;
+  if (a.u32_rows && (len >> 32) != 0) return fail(CXG_E_INVALID, "compact rows: the haystack must be shorter than 4 GiB (shard it)");
   a.hay = static_cast<const uint8_t*>(d_hay);
   a.len = len;
   a.base = base;
@@ -462,11 +465,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
   bool trioKernel = false;                                         // gen 6 served by k_scan_trio_wave
+  bool persKernel = false;                                         // ... by k_scan_fields_pers (the launcher says)
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
   int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
 relaunch:
   fusedCaps = false;
   fieldsKernel = false;
+  persKernel = false;
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
@@ -523,6 +528,8 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
+  if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6)       // (gen 6: checked below, the persistent fields kernel only)
+    return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
@@ -600,8 +607,10 @@ relaunch:
       }
       trioKernel = ok;
     }
+    if (a.u32_rows && a.out != nullptr && !(fieldsKernel && a.pf_status != nullptr))
+      return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
     if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream);
-    else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream);
+    else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream, &persKernel);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
   }
@@ -674,7 +683,7 @@ relaunch:
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
-    timing->kernel = static_cast<uint32_t>(trioKernel ? CXG_K_TRIO_WAVE : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+    timing->kernel = static_cast<uint32_t>(trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
   }
@@ -1218,6 +1227,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_CHAIN_WAVE: return "k_scan_chain_wave";
     case CXG_K_FIELDS_WAVE: return "k_scan_fields_wave";
     case CXG_K_TRIO_WAVE: return "k_scan_trio_wave";
+    case CXG_K_FIELDS_PERS: return "k_scan_fields_pers";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
@@ -1525,6 +1535,15 @@ int cxg_synth_page_host(uint32_t config, uint64_t seed, uint64_t page, uint8_t o
 int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                         uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
   return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
+}
+int cxg_find_all_device_u32(const cxg_program* p, const void* d_hay, uint64_t len, int64_t limit, void* d_out_u32, uint64_t cap,
+                            uint64_t* n_out, void* stream, cxg_timing* timing) {
+  if (p && (p->nullable || (p->supported && (reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data())->flags & cxgdev::kFlagBothRestart))))
+    return fail(CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): not for nullable or UseBoth programs");
+  t_u32Rows = true;
+  const int rc = scanDevice(p, d_hay, len, 0, limit, d_out_u32, cap, n_out, stream, timing, 2);
+  t_u32Rows = false;
+  return rc;
 }
 int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
                                  void* d_out, uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {

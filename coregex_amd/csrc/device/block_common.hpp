@@ -33,6 +33,13 @@ __device__ __forceinline__ void store_pair_nt(int64_t* p, int64_t x, int64_t y) 
 #endif
 }
 
+// The same for a compact row (cxg_find_all_device_u32): two uint32, 8 bytes.
+__device__ __forceinline__ void store_pair32_nt(uint32_t* p, uint32_t x, uint32_t y) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  u2 o; o.x = x; o.y = y;
+  __builtin_nontemporal_store(o, reinterpret_cast<u2*>(p));
+}
+
 constexpr uint64_t kFlagAggregate = 1ull << 62;
 constexpr uint64_t kFlagInclusive = 2ull << 62;
 constexpr uint64_t kFlagMask = 3ull << 62;

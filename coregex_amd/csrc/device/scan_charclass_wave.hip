@@ -161,7 +161,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
 
   // ---- pass 2: starts and ends straight to their rows
   const uint64_t base = s_base;
-  const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave);
+  const bool u32 = a.u32_rows != 0u;                                 // compact rows: (start, end) as uint32 relative to the haystack
+  uint32_t* const out32 = reinterpret_cast<uint32_t*>(a.out);
+  const int64_t origin = (u32 ? 0 : a.base) + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave);
   for (int j = 0; j < kCcTilesPerWave; j++) {
     const uint32_t cn = s_cnt[wave][j];
     const uint32_t n = cn & 0xFFFu, n_ends = (cn >> 12) & 0xFFFu, open = cn >> 31;
@@ -194,11 +196,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       if (row0 + i < a.cap) {
         if (i + open < nen) {                                       // both halves of the row are this tile's
           longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i + open];
-          store_pair_nt(a.out + (row0 + i) * 2, v.x, v.y);
-        } else a.out[(row0 + i) * 2] = tb + s_rs[wave][i];         // the run ends in a later tile
+          if (u32) store_pair32_nt(out32 + (row0 + i) * 2, static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
+          else store_pair_nt(a.out + (row0 + i) * 2, v.x, v.y);
+        } else if (u32) out32[(row0 + i) * 2] = static_cast<uint32_t>(tb + s_rs[wave][i]);
+        else a.out[(row0 + i) * 2] = tb + s_rs[wave][i];           // the run ends in a later tile
       }
     }
-    if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) a.out[(row0 - 1) * 2 + 1] = tb + s_re[wave][0];   // a run begun in an earlier tile ends here
+    if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) {       // a run begun in an earlier tile ends here
+      if (u32) out32[(row0 - 1) * 2 + 1] = static_cast<uint32_t>(tb + s_re[wave][0]);
+      else a.out[(row0 - 1) * 2 + 1] = tb + s_re[wave][0];
+    }
     wave_lds_sync();                                                // staging is reused by the next tile
   }
 }

@@ -82,6 +82,7 @@ struct ScanArgs {
   uint64_t* pf_rec;     // [pf_rec_rounds][384] per round: 128 records {rows of the round in front of the block, rows of the round} + 128 block sums, each word tagged pf_epoch << 48
   uint64_t pf_rec_rounds;
   uint64_t* pf_stats;   // [8192] per wave: units that waited << 32 | polls (CXG_VERBOSE)
+  uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };
 
 }  // namespace cxgdev

@@ -675,12 +675,13 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       const uint64_t base = running + pre;
       running += tot;
       if (a.out != nullptr && CXG_PFABL < 3) {
-        const int64_t origin = a.base + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
+        const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
         const uint32_t n = nrows_prev < static_cast<uint32_t>(kFRows) ? nrows_prev : static_cast<uint32_t>(kFRows);
         for (uint32_t i = lane0; i < n; i += 64) {
           if (base + i < a.cap) {
             const uint32_t v = s_row[parp][wave][i];
-            store_pair_nt(a.out + (base + i) * a.row_width, origin + (v & 0xFFFFu), origin + (v >> 16));
+            if (a.u32_rows) store_pair32_nt(reinterpret_cast<uint32_t*>(a.out) + (base + i) * 2u, static_cast<uint32_t>(origin + (v & 0xFFFFu)), static_cast<uint32_t>(origin + (v >> 16)));
+            else store_pair_nt(a.out + (base + i) * a.row_width, origin + (v & 0xFFFFu), origin + (v >> 16));
           }
         }
       }
@@ -778,7 +779,8 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const uint64_t* counts, uin
 }
 
 // a.ngroups = number of 120 KiB groups (one workgroup each).
-hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
+hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent) {
+  if (persistent) *persistent = false;
   const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
   const int k = fields_shape(c);
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
@@ -790,7 +792,7 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream) {
       case 4: done = launch_pers_k<4>(a, c.cls_kind[0], c.cls_kind[1], stream); break;
       default: return hipErrorInvalidValue;
     }
-    if (done) return hipGetLastError();
+    if (done) { if (persistent) *persistent = true; return hipGetLastError(); }
   }
   switch (k) {
     case 2: launch_fields_k<2>(a, c.cls_kind[0], c.cls_kind[1], grid, block, stream); break;

@@ -119,7 +119,8 @@ enum cxg_kernel {
   CXG_K_NONE = 0, CXG_K_DFA_TABLE = 1, CXG_K_DIGIT_FLAT = 2, CXG_K_CHAIN_WAVE = 6, CXG_K_TEDDY_WAVE = 7,
   CXG_K_CHARCLASS_WAVE = 8, CXG_K_PREFIX_WAVE = 9, CXG_K_FSM = 10, CXG_K_TEDDY_TABLE = 11, CXG_K_CHARCLASS_TABLE = 12,
   CXG_K_FIELDS_WAVE = 13,  /* scan_fields_wave.hip: fields programs such as `\d+\.\d+\.\d+\.\d+` (round 3) */
-  CXG_K_TRIO_WAVE = 14     /* scan_fields_wave.hip k_scan_trio_wave: run a run b run programs such as `(\w+)@(\w+)\.(\w+)` (round 3) */
+  CXG_K_TRIO_WAVE = 14,    /* scan_fields_wave.hip k_scan_trio_wave: run a run b run programs such as `(\w+)@(\w+)\.(\w+)` (round 3) */
+  CXG_K_FIELDS_PERS = 15   /* scan_fields_wave.hip k_scan_fields_pers: the fields mathematics on a persistent grid, ordering deferred by a round (round 4) */
 };
 const char* cxg_kernel_name(int kernel);
 
@@ -201,6 +202,16 @@ int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, i
 int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base,
                                  int64_t limit, void* d_out, uint64_t cap, uint64_t* n_out, void* stream,
                                  cxg_timing* timing);
+
+/* Compact rows for shard-sized, device-resident haystacks: rows of two uint32 — (start, end) relative to d_hay, no `base` —
+ * 8 bytes per match instead of 16.  Device-only entry point beside the int64 ABI above (which the cgo binding keeps using): a
+ * consumer on the device (a later kernel, a gather that rebases per shard) reads half the bytes, and the write-bound programs —
+ * nfa.CharClassSearcher.FindAllIndices (nfa/charclass_searcher.go:158-211) emits 16 bytes per run of ~5.5 bytes of log text —
+ * write half of them.  len must be below 4 GiB.  Served for the programs whose span kernel has the compact row epilogue
+ * (char-class programs incl. `\S+`-style class runs; fields programs such as `\d+\.\d+\.\d+\.\d+`); CXG_E_UNSUPPORTED
+ * otherwise, CXG_E_INPUT when the haystack needs a kernel without it (the caller uses cxg_find_all_device). */
+int cxg_find_all_device_u32(const cxg_program* p, const void* d_hay, uint64_t len, int64_t limit, void* d_out_u32,
+                            uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing);
 
 #ifdef __cplusplus
 }

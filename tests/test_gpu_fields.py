@@ -14,7 +14,12 @@ from routing import routed
 
 pytestmark = pytest.mark.gpu
 
-K_FIELDS = 13       # CXG_K_FIELDS_WAVE
+K_FIELDS = 13       # CXG_K_FIELDS_WAVE (the grouped kernel: FindAll with an n, tickets, CXG_NO_PERSIST)
+K_PERS = 15         # CXG_K_FIELDS_PERS (round 4: the same mathematics on a persistent grid — what a plain call gets)
+
+
+def _is(k, want):
+    return k == want or (want == K_FIELDS and k == K_PERS)
 WT = 3840           # bytes per wave-tile
 IP = r"\d+\.\d+\.\d+\.\d+"
 
@@ -42,7 +47,7 @@ def _check(oracle, pat, hay, want_kernel=K_FIELDS, launches=1):
     rows, t = _dev_rows(rx, hay)
     assert rows.shape == exp.shape and np.array_equal(rows, exp), (pat, bytes(_u8(hay)[:60]), rows[:4].tolist(), exp[:4].tolist())
     if want_kernel is not None:
-        assert routed(t.kernel == want_kernel and t.n_launches == launches, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
+        assert routed(_is(t.kernel, want_kernel) and t.n_launches == launches, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
     return t
 
 
@@ -79,7 +84,7 @@ def test_random_text(oracle, pat, alpha):
         w = ([3, 3, 1] + [1] * len(alpha) if kind == 0 else [1] * len(alpha) if kind == 1 else [5] + [1] * len(alpha))[: len(alpha)]
         hay = "".join(rng.choices(alpha, weights=w, k=n)).encode()
         t = _check(oracle, pat, hay, want_kernel=None)
-        served += t.kernel == K_FIELDS and t.n_launches == 1
+        served += _is(t.kernel, K_FIELDS) and t.n_launches == 1
     assert routed(served >= 4, served)                      # sparse mixes stay on the kernel; dense ones overflow its row buffers (64 rows per wave-tile)
 
 
@@ -96,7 +101,7 @@ def test_synthlog_16mib(oracle):
     t = cx.Timing()
     n = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp)
-    assert routed(t.kernel == K_FIELDS and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason)
+    assert routed(_is(t.kernel, K_FIELDS) and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason)
     # shard origin: rows move by `base`
     n = rx.find_all_device(buf.ptr, npages * 4096, out.data_ptr(), len(exp) + 8, base=1 << 40, timing=t)
     assert np.array_equal(out[:n].cpu().numpy(), exp + (1 << 40))
@@ -115,7 +120,7 @@ def test_long_fields_and_handover(oracle):
                 _check(oracle, pat, hay, want_kernel=None)
     _check(oracle, pat, b"x" * 10 + b"5" * 20 + b"." + b"6" * 30 + b" 1.5 y")                 # 51 bytes: on the kernel
     t = _check(oracle, IP, b"y" * 3800 + b"1." * 300 + b"1", want_kernel=None)                  # super-run past its window
-    assert t.kernel != K_FIELDS and t.n_launches >= 2
+    assert t.kernel not in (K_FIELDS, K_PERS) and t.n_launches >= 2
     t = _check(oracle, IP, b"1." * (1 << 16), want_kernel=None)                                  # no synchronising structure at all
     assert t.n_launches >= 2
     _check(oracle, IP, b"y" * 100 + b"1." * 300 + b"1 z")                                       # 600-byte super-run inside one window: 75 groups of four
@@ -137,7 +142,8 @@ def test_dense_input(oracle):
     assert n == (26 << 20) and t.n_launches >= 2
 
 
-@pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_TICKETS": "1"}, K_FIELDS), ({"CXG_NO_EPOCH": "1"}, K_FIELDS)])
+@pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_TICKETS": "1"}, K_FIELDS), ({"CXG_NO_EPOCH": "1"}, K_PERS), ({"CXG_NO_PERSIST": "1"}, K_FIELDS),
+                                        ({"CXG_NO_PERSIST": "1", "CXG_NO_EPOCH": "1"}, K_FIELDS), ({}, K_PERS)])
 def test_ab_switches(oracle, env, kernel):
     """The A/B switches of the scripts: the chain kernel instead of the fields kernel; tickets instead of static group
     assignment; zeroed look-back words instead of launch epochs.  Rows == oracle in a fresh process for each."""
