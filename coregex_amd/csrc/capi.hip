@@ -445,6 +445,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   } else if (h->kind == cxgdev::kKindCharClass) {
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
     gen = (!oldCc && (h->flags & cxgdev::kFlagCcRanges)) ? 8 : 0;   // 8 = wave kernel (scan_charclass_wave.hip), 0 = scan_charclass.hip
+    if ((h->flags & cxgdev::kFlagCcRanges) && reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs) gen = 8;   // (the table kernel knows runs only)
   } else if (gen != 6) gen = 0;                                   // table kernels of the other kinds
   if (gen == 0 && h->kind == cxgdev::kKindBidir && (h->flags & cxgdev::kFlagPrefixLiteral)) {
     static const bool noPrefix = getenv("CXG_NO_PREFIX_KERNEL") != nullptr;
@@ -535,7 +536,13 @@ relaunch:
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
     le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream);
   }
-  else if (gen == 8) le = cxgdev::launch_scan_charclass_wave(a, stream);
+  else if (gen == 8) {
+    // `Q[^Q]*Q` programs count EVENTS (occurrences of Q, two per row) in the look-back: FindAll's n is 2 n events
+    const bool pairsProg = reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs != 0u;
+    cxgdev::ScanArgs b = a;
+    if (pairsProg) b.limit = a.limit * 2u;
+    le = cxgdev::launch_scan_charclass_wave(b, stream);
+  }
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
@@ -779,6 +786,8 @@ relaunch:
     if (h->kind == cxgdev::kKindFsmOnly)                            // no table-walking image: degrade for THIS haystack
       return fail(CXG_E_INPUT, "haystack outside the transducer kernel's budgets (reason bits " + std::to_string(err >> 8) +
                                "): matches denser than one per 2 bytes, a match reaching > 190 bytes past its tile, or an unresolvable entry state");
+    if (h->kind == cxgdev::kKindCharClass && (h->flags & cxgdev::kFlagCcRanges) && reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs)
+      return fail(CXG_E_INPUT, "more than 1024 occurrences of the quote byte in one 3840-byte tile (no table kernel pairs them)");
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
     relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
   }

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   SetRanges rg;
   rg.n = ax->nr;
   const uint32_t flip = ax->neg ? 0u : 0xFFFFu;                     // notset4 flags the bytes OUTSIDE the ranges: the members of a complemented class
+  // `Q[^Q]*Q` programs (walk.hpp CharClassAux::pairs): the EVENTS are the occurrences of Q; the k-th of the haystack opens row
+  // k / 2 when k is even and closes it (exclusive end: the byte behind it) when k is odd.  Pass 1 keeps the occurrence bitmap and
+  // counts events; which of them are starts is known behind the look-back, from the parity of the events in front of the tile.
+  const bool pairs = ax->pairs != 0u;
 #pragma unroll
   for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
   __syncthreads();
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       const uint64_t P = (M << 1) | carry;                          // "the previous byte is a member"
       S = M & ~P;
       E = ~M & P;                                                   // exclusive end: first non-member after a run
+      if (pairs) { S = M; E = 0; prev_member = 0; }                 // every occurrence is an event of the tile that holds it
       S &= word_range(lane, 0, kWaveTile - 1);                      // starts at [0, 3840), exclusive ends at (0, 3840]
       E &= word_range(lane, 1, kWaveTile);
       const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kCcTilesPerWave];
   tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
+  if (pairs && group == a.ngroups - 1 && tid == 0) *a.total = (s_base + total) >> 1;   // rows = events / 2 (an unpaired last Q opens nothing)
   if (a.out == nullptr) return;
 
   // ---- pass 2: starts and ends straight to their rows
@@ -166,12 +172,35 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const int64_t origin = (u32 ? 0 : a.base) + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave);
   for (int j = 0; j < kCcTilesPerWave; j++) {
     const uint32_t cn = s_cnt[wave][j];
-    const uint32_t n = cn & 0xFFFu, n_ends = (cn >> 12) & 0xFFFu, open = cn >> 31;
+    uint32_t n = cn & 0xFFFu, n_ends = (cn >> 12) & 0xFFFu, open = cn >> 31;
     if (n == 0 && n_ends == 0) continue;
     const uint64_t S = s_S[wave][j][lane0], E = s_E[wave][j][lane0];
     const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
     const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
-    const uint64_t row0 = base + s_qbase[j * kWavesPerBlock + wave];
+    uint64_t row0 = base + s_qbase[j * kWavesPerBlock + wave];
+    if (pairs) {
+      // events in front of the tile: row0 of them; event k of the haystack is the start of row k / 2 (k even) or its end (k odd)
+      const uint32_t par = static_cast<uint32_t>(row0) & 1u;
+      uint32_t k = par + (incl & 0xFFFFu) - ns;                    // parity-true index of this lane's first event, counted from an even event
+      uint64_t sb = S;
+      while (sb) {
+        const int bit = __builtin_ctzll(sb);
+        sb &= sb - 1;
+        // k = par + (rank in the tile): even k opens, odd k closes.  Ranks among the tile's starts / ends: (k >> 1) - par / k >> 1
+        // (par == 1: the tile's first event, k = 1, is end 0 and closes a row opened in front of the tile)
+        const uint32_t slot = (k & 1u) ? (k >> 1) : (k >> 1) - par;
+        if (slot < static_cast<uint32_t>(kCcStage)) {
+          if (k & 1u) s_re[wave][slot] = static_cast<uint16_t>(64 * lane0 + bit + 1);   // closes: exclusive end behind the Q
+          else s_rs[wave][slot] = static_cast<uint16_t>(64 * lane0 + bit);
+        }
+        k++;
+      }
+      // starts: events with even k; ends: odd k.  par == 1: the tile's first event closes a row opened earlier (open)
+      n_ends = par ? (n + 1u) >> 1 : n >> 1;
+      n = par ? n >> 1 : (n + 1u) >> 1;
+      open = par;
+      row0 = (row0 + 1u) >> 1;                                       // rows opened in front of the tile
+    } else {
     uint32_t r = (incl & 0xFFFFu) - ns;
     uint64_t sb = S;
     while (sb) {
@@ -187,6 +216,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       eb &= eb - 1;
       if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
       r++;
+    }
     }
     wave_lds_sync();
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;

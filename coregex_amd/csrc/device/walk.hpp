@@ -438,7 +438,10 @@ constexpr uint32_t kFlagBothRestart = 128u;    // UseBoth program: the reference
                                                 // (find_indices.go:425-431) — identical to leftmost-first unless a match is longer than that
 constexpr uint32_t kBothRestartSpan = 100u;
 constexpr uint32_t kFlagCcRanges = 64u;         // kKindCharClass: membership is a union of <= 4 ASCII ranges (CharClassAux in aux)
-struct CharClassAux { uint32_t nr; uint8_t lo[4], hi[4]; uint32_t neg; };   // neg: the class is the COMPLEMENT of the ranges (bytes >= 0x80 are members)
+struct CharClassAux { uint32_t nr; uint8_t lo[4], hi[4]; uint32_t neg; uint32_t pairs; };
+// neg: the class is the COMPLEMENT of the ranges (bytes >= 0x80 are members).  pairs (round 4): the program is `Q[^Q]*Q` for the one
+// byte Q of the class — the matches are the occurrences of Q taken two at a time from the start of the haystack (no byte
+// synchronises: the parity of the occurrences in front decides whether a Q opens or closes).
 constexpr uint32_t kFlagChainSets = 32u;        // some class is a kClsSet: only scan_chain_wave.hip evaluates those
 constexpr uint32_t kFlagChain = 4u;
 constexpr uint32_t kFlagChainOrdered = 16u;    // complete, and the k-th match start pairs with the k-th match end (program.cc extractChain)

@@ -88,6 +88,6 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy = -1)
 // boundedSurrogate), bounds the (min, max) of its runs in order.  Adds the surrogate's chain to an already built,
 // supported digit / DFA-pair program when that chain has a shape the BND kernels take; otherwise leaves p alone.
 void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vector<std::pair<int, int>>& bounds);   // fills subBlob/capBlob/subSupported
-void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch);
+void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch, bool pairs = false);
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits);
 }  // namespace cxg

@@ -500,6 +500,29 @@ extern "C" int64_t emu_find_all_charclass_wave(const uint8_t* blob, const uint8_
   const int64_t N = tile_bytes + halo_bytes;
   std::vector<int64_t> res;
   const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  if (ax->pairs) {
+    // `Q[^Q]*Q`: the tile owns the occurrences of Q in its bytes; with B of them in front of the tile, its event of rank r is event
+    // k = B + r of the haystack: even k opens row k / 2, odd k closes it behind the Q (scan_charclass_wave.hip, pairs)
+    uint64_t B = 0;
+    for (uint64_t t = 0; t < ntiles; t++) {
+      const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
+      const uint64_t tile_hi = tile_lo + tile_bytes < len ? tile_lo + tile_bytes : len;
+      uint64_t n = 0;
+      for (uint64_t p = tile_lo; p < tile_hi; p++) {
+        if (!member(hay[p])) continue;
+        const uint64_t k = B + n++;
+        const size_t row = static_cast<size_t>(k >> 1);
+        if (res.size() < 2 * (row + 1)) res.resize(2 * (row + 1), -1);
+        res[2 * row + (k & 1)] = static_cast<int64_t>(p) + static_cast<int64_t>(k & 1);
+      }
+      if (n > 1024) return -(16 + 8);
+      B += n;
+    }
+    res.resize(2 * (B >> 1));                                      // an unpaired last Q opens nothing
+    const int64_t n = static_cast<int64_t>(res.size());
+    if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+    return n;
+  }
   for (uint64_t t = 0; t < ntiles; t++) {
     const uint64_t tile_lo = t * static_cast<uint64_t>(tile_bytes);
     const int64_t rend = static_cast<int64_t>(len - tile_lo);
