@@ -107,6 +107,14 @@ class Regex:
         return bool(_lib.lib().cxg_program_supported(self._h))
 
     @property
+    def delimiters(self):
+        """(open byte, close byte, plus) of an `O [^E]+ E` / `O [^E]* E` program, else None."""
+        o, c, pl = C.c_int(0), C.c_int(0), C.c_int(0)
+        if not _lib.lib().cxg_program_delimiters(self._h, C.byref(o), C.byref(c), C.byref(pl)):
+            return None
+        return o.value, c.value, bool(pl.value)
+
+    @property
     def nullable(self) -> int:
         """0: not nullable; 1: the device program is the non-empty variant (empty matches merged behind the scan); 2: only empty matches."""
         return int(_lib.lib().cxg_program_nullable(self._h))

@@ -30,6 +30,7 @@ hipError_t launch_scan_charclass(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStream_t stream);
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
+hipError_t launch_scan_delim_wave(const ScanArgs& a, hipStream_t stream);   // scan_delim_wave.hip
 int fields_shape(const ChainAux& c);
 int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
@@ -455,6 +456,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     gen = 10;                                                       // table-walking kernels only when the transducer is unavailable or gives up
     fsmTried = true;
   }
+  // `O [^E]+ E` programs: the delimiter kernel first (spans, no FindAll n: its kind look-back has no early stop), the transducer behind it
+  static const bool delimOk = getenv("CXG_NO_DELIM_KERNEL") == nullptr;
+  static std::atomic<bool> delimWatchdog{false};
+  if (delimOk && !delimWatchdog.load() && !submatch && gen == 10 && p->delim[3] != 0u && limit <= 0 && d_fsm && getenv("CXG_TICKETS") == nullptr) {
+    gen = 11;
+    fsmTried = false;
+  }
   if (h->kind == cxgdev::kKindFsmOnly) {                            // UseNFA programs (word boundaries): the transducer kernel is the only one
     if (!d_fsm) return fail(CXG_E_UNSUPPORTED, "program runs on the transducer kernel only (CXG_NO_FSM is set)");
     gen = 10;
@@ -476,8 +484,9 @@ relaunch:
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
+  if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
-  if (gen == 8) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
+  if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if ((gen == 6 || gen == 7 || gen == 9 || gen == 10) && denseChain) {   // four times the row-buffer room per wave-tile
@@ -520,6 +529,7 @@ relaunch:
   } else {
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
+    if (gen == 11) HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
     if (gen == 10) {
       HIP_TRY(hipMemsetAsync(a.status2, 0, a.ngroups * sizeof(uint64_t), stream));
       HIP_TRY(hipMemsetAsync(a.fsm_maps, 0, 3 * a.ngroups * sizeof(uint64_t), stream));
@@ -529,12 +539,16 @@ relaunch:
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
-  if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6)       // (gen 6: checked below, the persistent fields kernel only)
+  if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6 && gen != 11)       // (gen 6: checked below, the persistent fields kernel only)
     return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
     le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream);
+  }
+  else if (gen == 11) {
+    std::memcpy(a.chain, p->delim, sizeof p->delim);
+    le = cxgdev::launch_scan_delim_wave(a, stream);
   }
   else if (gen == 8) {
     // `Q[^Q]*Q` programs count EVENTS (occurrences of Q, two per row) in the look-back: FindAll's n is 2 n events
@@ -690,7 +704,7 @@ relaunch:
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
-    timing->kernel = static_cast<uint32_t>(trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+    timing->kernel = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                            : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
     timing->fallback_reason = lastReason;
   }
@@ -745,6 +759,10 @@ relaunch:
         for (int x = 0; x < 8; x++) if (nX[x]) fprintf(stderr, "[cxg]   XCD %d: %llu waves, life mean %.1f max %.1f us, tile loops mean %.1f us\n", x, (unsigned long long)nX[x], lifeX[x] / nX[x] / 100.0, lifeMaxX[x] / 100.0, scanX[x] / nX[x] / 100.0);
       }
     }
+  }
+  if ((err & 2u) && gen == 11) {                                    // the delimiter kernel needs dispatch in index order: never again, the transducer
+    delimWatchdog.store(true);
+    relaunches++; gen = 10; fsmTried = true; goto relaunch;
   }
   if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
     staticGroupsOk.store(false);
@@ -1237,6 +1255,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_FIELDS_WAVE: return "k_scan_fields_wave";
     case CXG_K_TRIO_WAVE: return "k_scan_trio_wave";
     case CXG_K_FIELDS_PERS: return "k_scan_fields_pers";
+    case CXG_K_DELIM_WAVE: return "k_scan_delim_wave";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
@@ -1431,6 +1450,13 @@ uint32_t cxg_program_flags(const cxg_program* p) { return p ? p->flags : 0u; }
 int cxg_program_num_groups(const cxg_program* p) { return p ? p->ngroups : 0; }
 int cxg_program_nfa_states(const cxg_program* p) { return p ? p->nfaStates : -1; }
 int cxg_program_dfa_states(const cxg_program* p) { return p ? static_cast<int>(p->fwd.nstates) : 0; }
+int cxg_program_delimiters(const cxg_program* p, int* open_byte, int* close_byte, int* plus) {
+  if (!p || !p->supported || p->delim[3] == 0u) return 0;
+  if (open_byte) *open_byte = static_cast<int>(p->delim[0]);
+  if (close_byte) *close_byte = static_cast<int>(p->delim[1]);
+  if (plus) *plus = static_cast<int>(p->delim[2]);
+  return 1;
+}
 int cxg_program_nullable(const cxg_program* p) { return !p || !p->nullable ? 0 : (p->nullableOnlyEmpty ? 2 : 1); }
 int cxg_program_supported(const cxg_program* p) {
   if (p && !p->supported) t_err = p->whyNot;

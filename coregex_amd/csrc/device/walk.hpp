@@ -442,6 +442,9 @@ struct CharClassAux { uint32_t nr; uint8_t lo[4], hi[4]; uint32_t neg; uint32_t 
 // neg: the class is the COMPLEMENT of the ranges (bytes >= 0x80 are members).  pairs (round 4): the program is `Q[^Q]*Q` for the one
 // byte Q of the class — the matches are the occurrences of Q taken two at a time from the start of the haystack (no byte
 // synchronises: the parity of the occurrences in front decides whether a Q opens or closes).
+// scan_delim_wave.hip: `O [^E]+ E` / `O [^E]* E` programs (`\[[^\]]+\]`, `<[^>]+>`); kept by cxg_program beside the DFA-pair / transducer
+// images (the fallback), copied into ScanArgs::chain for the launch
+struct DelimAux { uint32_t open_byte, close_byte, plus, on; };
 constexpr uint32_t kFlagChainSets = 32u;        // some class is a kClsSet: only scan_chain_wave.hip evaluates those
 constexpr uint32_t kFlagChain = 4u;
 constexpr uint32_t kFlagChainOrdered = 16u;    // complete, and the k-th match start pairs with the k-th match end (program.cc extractChain)

@@ -678,6 +678,56 @@ bool isQuotePairs(const Dfa& d, int& quote) {
   return true;
 }
 
+// Is the language of the anchored break-at-match DFA `O [^E]+ E` or `O [^E]* E` for two different bytes O, E?  The start leaves on
+// O alone; behind it every state stays inside on every byte but E (all 255: see isQuotePairs) and is not accepting; E leads to
+// an accepting state nothing leaves — from every inside state (`*`), or from every inside state but the one behind O, where E
+// is dead (`+`).
+bool isDelimited(const Dfa& d, int& open, int& close, bool& plus) {
+  if (d.start == 0 || d.start >= d.firstAccept) return false;
+  open = close = -1;
+  for (int b = 0; b < 256; b++)
+    if (d.table[static_cast<size_t>(d.start) * 256 + b] != 0) { if (open >= 0) return false; open = b; }
+  if (open < 0) return false;
+  const uint32_t first = d.table[static_cast<size_t>(d.start) * 256 + open];
+  if (first == 0 || first >= d.firstAccept || first == d.start) return false;
+  // E: the one byte that does not keep an inside state inside — found on the state behind the first non-E byte
+  auto terminal = [&](uint32_t t) { if (t < d.firstAccept) return false; for (int c = 0; c < 256; c++) if (d.table[static_cast<size_t>(t) * 256 + c] != 0) return false; return true; };
+  int dead = -1, term = -1;
+  for (int b = 0; b < 256; b++) {
+    const uint32_t t = d.table[static_cast<size_t>(first) * 256 + b];
+    if (t == 0) { if (dead >= 0) return false; dead = b; }
+    else if (t >= d.firstAccept) { if (term >= 0 || !terminal(t)) return false; term = b; }
+  }
+  if ((dead >= 0) == (term >= 0)) return false;
+  plus = dead >= 0;
+  close = plus ? dead : term;
+  if (close == open) return false;
+  std::vector<uint8_t> seen(d.nstates, 0);
+  std::vector<uint32_t> st;
+  seen[first] = 1;
+  for (int b = 0; b < 256; b++) {
+    if (b == close) continue;
+    const uint32_t t = d.table[static_cast<size_t>(first) * 256 + b];
+    if (t == 0 || t >= d.firstAccept) return false;
+    if (!seen[t]) { seen[t] = 1; st.push_back(t); }
+  }
+  if (!plus) st.push_back(first);                                  // `*`: the state behind O is an inside state like the others
+  bool firstChecked = plus;
+  while (!st.empty()) {
+    const uint32_t q = st.back(); st.pop_back();
+    if (q == first && firstChecked) return false;                  // `+`: nothing leads back behind O
+    if (q == first) firstChecked = true;
+    if (q >= d.firstAccept || q == d.start) return false;
+    for (int b = 0; b < 256; b++) {
+      const uint32_t t = d.table[static_cast<size_t>(q) * 256 + b];
+      if (b == close) { if (!terminal(t)) return false; continue; }
+      if (t == 0 || t >= d.firstAccept) return false;
+      if (!seen[t]) { seen[t] = 1; st.push_back(t); }
+    }
+  }
+  return true;
+}
+
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
   p->strategy = strategy;
   p->flags = flags;
@@ -860,6 +910,10 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
               member[quote] = 1;
               plus = true;
             } else quote = -1;
+            // `\[[^\]]+\]`, `<[^>]+>`: the delimiter kernel in front of the images built below (which stay: its fallback)
+            int dOpen = -1, dClose = -1;
+            bool dPlus = false;
+            if (!plus && isDelimited(anch, dOpen, dClose, dPlus)) { p->delim[0] = static_cast<uint32_t>(dOpen); p->delim[1] = static_cast<uint32_t>(dClose); p->delim[2] = dPlus ? 1u : 0u; p->delim[3] = 1u; }
           } catch (const BuildError&) { plus = false; }
         }
         if (plus) {

@@ -65,6 +65,7 @@ struct cxg_program {
   bool capHasLook = false;       // the backtracking image holds assertion states: capi.hip launches the LOOK instantiation of its kernels
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: the chain kernel overflowed its row buffers on this
                                                               // program's input once: later calls start with two tiles per wave (capi.hip)
+  uint32_t delim[4] = {0, 0, 0, 0};   // cxgdev::DelimAux: `O [^E]+ E` / `O [^E]* E` programs ([3] != 0), the delimiter kernel in front of the transducer
   uint8_t chainBounds[40] = {0}; // cxgdev::ChainCaps with on == 2: field bounds of a bounded-repetition program (kFlagChainBounded)
   uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
   // device copies, one per device, created on first use (capi.hip)

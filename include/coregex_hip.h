@@ -120,7 +120,8 @@ enum cxg_kernel {
   CXG_K_CHARCLASS_WAVE = 8, CXG_K_PREFIX_WAVE = 9, CXG_K_FSM = 10, CXG_K_TEDDY_TABLE = 11, CXG_K_CHARCLASS_TABLE = 12,
   CXG_K_FIELDS_WAVE = 13,  /* scan_fields_wave.hip: fields programs such as `\d+\.\d+\.\d+\.\d+` (round 3) */
   CXG_K_TRIO_WAVE = 14,    /* scan_fields_wave.hip k_scan_trio_wave: run a run b run programs such as `(\w+)@(\w+)\.(\w+)` (round 3) */
-  CXG_K_FIELDS_PERS = 15   /* scan_fields_wave.hip k_scan_fields_pers: the fields mathematics on a persistent grid, ordering deferred by a round (round 4) */
+  CXG_K_FIELDS_PERS = 15,  /* scan_fields_wave.hip k_scan_fields_pers: the fields mathematics on a persistent grid, ordering deferred by a round (round 4) */
+  CXG_K_DELIM_WAVE = 16    /* scan_delim_wave.hip: `O [^E]+ E` programs such as `\[[^\]]+\]` (round 4) */
 };
 const char* cxg_kernel_name(int kernel);
 
@@ -150,6 +151,9 @@ int cxg_program_supported(const cxg_program* p);        /* 1 if the device path 
 /* Nullable pattern (`a*`, `x?y*`: matches the empty string; meta/findall.go:251-275 is its FindAll rule)?  0 no; 1 the device
    program is the pattern's non-empty variant and the empty matches are merged behind the scan; 2 every match is empty (`a*?`). */
 int cxg_program_nullable(const cxg_program* p);
+/* `O [^E]+ E` / `O [^E]* E` program (`\[[^\]]+\]`, `<[^>]+>`: served by scan_delim_wave.hip in front of the transducer)?  1 and the two
+   bytes + whether the class must be taken at least once; else 0. */
+int cxg_program_delimiters(const cxg_program* p, int* open_byte, int* close_byte, int* plus);
 /* Device image of the program (what every kernel stages into LDS); for tests and the emulator. */
 int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
 /* Diagnostics: the FindAll transducer image of the general-DFA kernel (coregex_amd/csrc/device/fsm.hpp): of the

@@ -240,3 +240,20 @@ def merge_empty_matches(rows: np.ndarray, n: int) -> np.ndarray:
     out = [(int(s), int(e)) for s, e in np.asarray(rows).reshape(-1, 2).tolist()] + [(p, p) for p in range(n + 1) if not covered[p]]
     out.sort()
     return np.array(out, dtype=np.int64).reshape(-1, 2)
+
+
+def find_all_delim(open_byte: int, close_byte: int, plus: bool, hay, tile: int = 3840):
+    """scan_delim_wave.hip (`O [^E]+ E` / `O [^E]* E`), emulated; the int reason (< 0) when a tile would raise the fallback flag."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    L = lib()
+    L.emu_find_all_delim.restype = C.c_int64
+    L.emu_find_all_delim.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = L.emu_find_all_delim(open_byte, close_byte, int(plus), a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, tile)
+        if n < 0:
+            return int(n)
+        if n <= cap:
+            return out[:n].reshape(-1, 2).copy()
+        cap = int(n)

@@ -553,3 +553,60 @@ extern "C" int64_t emu_find_all_charclass_wave(const uint8_t* blob, const uint8_
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+
+// Sequential twin of scan_delim_wave.hip (`O [^E]+ E` / `O [^E]* E`): per tile the carry-less addition R + O' bit by bit, the
+// correction bits and the kind; kinds chained over the tiles; starts and matched ends placed as the kernel places them (the
+// i-th start of a tile is row B + i, its j-th end row B - open + j).  Returns the rows (2 values each), or -(16 + 8) when a
+// tile holds more than 1023 starts or ends (the kernel's fallback flag).
+extern "C" int64_t emu_find_all_delim(int open_byte, int close_byte, int plus, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int tile_bytes) {
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  uint32_t carry = 0;                                               // entry carry of the tile
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t lo = t * static_cast<uint64_t>(tile_bytes);
+    const int64_t n = static_cast<int64_t>(len - lo < static_cast<uint64_t>(tile_bytes) ? len - lo : static_cast<uint64_t>(tile_bytes));
+    std::vector<uint8_t> O(n), E(n), S(n, 0), M(n, 0);
+    for (int64_t i = 0; i < n; i++) {
+      E[i] = hay[lo + i] == close_byte;
+      O[i] = hay[lo + i] == open_byte && !(plus && lo + i + 1 < len && hay[lo + i + 1] == close_byte);
+    }
+    uint32_t c = 0;                                                 // carry-less: sum = R + O'
+    int64_t fe = -1, fs = -1, fm = -1;
+    bool anyO = false;
+    for (int64_t i = 0; i < n; i++) {
+      const uint32_t sum = (E[i] ? 0u : 1u) + O[i] + c;
+      const uint32_t bit = sum & 1u;
+      c = sum >> 1;
+      S[i] = O[i] && !bit;
+      M[i] = E[i] && bit;
+      anyO = anyO || O[i];
+      if (E[i] && fe < 0) fe = i;
+      if (S[i] && fs < 0) fs = i;
+      if (M[i] && fm < 0) fm = i;
+    }
+    const uint32_t g0 = c;                                          // (beyond the tile's bytes the kernel sees ones: the carry leaves through the top)
+    const uint32_t kind = fe >= 0 ? g0 : (anyO ? 1u : 2u);
+    if (carry) {                                                    // under a carry-in: the start below the first E is none, the first E is matched
+      if (fs >= 0 && (fe < 0 || fs < fe)) S[fs] = 0;
+      if (fe >= 0) M[fe] = 1;
+    }
+    size_t ns = 0, ne = 0;
+    for (int64_t i = 0; i < n; i++) { ns += S[i]; ne += M[i]; }
+    if (ns + 1 > 1024 || ne + 1 > 1024) return -(16 + 8);
+    const size_t B = res.size() / 2;
+    for (int64_t i = 0; i < n; i++) if (S[i]) { res.push_back(static_cast<int64_t>(lo) + i); res.push_back(-1); }
+    size_t j = 0;
+    for (int64_t i = 0; i < n; i++) if (M[i]) {
+      const size_t row = B - carry + j++;
+      if (row >= res.size() / 2) return -3;
+      res[2 * row + 1] = static_cast<int64_t>(lo) + i + 1;
+    }
+    if (kind != 2u) carry = kind;
+  }
+  if (carry && !res.empty()) { res.pop_back(); res.pop_back(); }   // an opening without its E at the end of the haystack is no row
+  for (size_t i = 1; i < res.size(); i += 2) if (res[i] < 0) return -3;
+  const int64_t nv = static_cast<int64_t>(res.size());
+  if (out && nv <= cap_vals) std::memcpy(out, res.data(), nv * sizeof(int64_t));
+  return nv;
+}
