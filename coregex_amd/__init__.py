@@ -107,6 +107,14 @@ class Regex:
         return bool(_lib.lib().cxg_program_supported(self._h))
 
     @property
+    def offset_captures(self):
+        """[(src, delta)] per capture slot — src 0 = match start, 1 = match end — when every capture boundary sits at a fixed distance
+        from one of them (FindAllSubmatch = FindAll + an expansion kernel), else None."""
+        src, delta = (C.c_int * 32)(), (C.c_int * 32)()
+        n = _lib.lib().cxg_program_offset_captures(self._h, src, delta, 32)
+        return [(src[k], delta[k]) for k in range(n)] if n else None
+
+    @property
     def delimiters(self):
         """(open byte, close byte, plus) of an `O [^E]+ E` / `O [^E]* E` program, else None."""
         o, c, pl = C.c_int(0), C.c_int(0), C.c_int(0)

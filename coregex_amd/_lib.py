@@ -22,7 +22,7 @@ SYMBOLS = [
     "cxg_last_error", "cxg_version", "cxg_device_count", "cxg_set_device", "cxg_thread_release", "cxg_compile", "cxg_program_flags",
     "cxg_program_from_nfa", "cxg_program_from_literals", "cxg_program_from_charclass",
     "cxg_program_destroy", "cxg_program_strategy", "cxg_strategy_name", "cxg_kernel_name", "cxg_program_num_groups",
-    "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_nullable", "cxg_program_delimiters", "cxg_program_blob",
+    "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_nullable", "cxg_program_delimiters", "cxg_program_offset_captures", "cxg_program_blob",
     "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
@@ -102,6 +102,7 @@ def lib():
               "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_nullable"):
         getattr(L, n).argtypes = [vp]
     L.cxg_program_delimiters.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cxg_program_offset_captures.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.cxg_program_flags.argtypes = [vp]
     L.cxg_program_flags.restype = u32
     L.cxg_thread_release.argtypes = []

@@ -97,6 +97,7 @@ struct Scratch {
   uint32_t* pfStatus = nullptr; uint64_t pfCap = 0; uint32_t pfEpoch = 0;   // k_scan_fields_pers: one word per unit, own 16-bit launch epoch
   uint64_t* pfRec = nullptr; uint64_t pfRecRounds = 0;   // ... 128 records of 16 bytes per round, tagged with the same epoch
   uint64_t* pfStats = nullptr;                           // ... per wave: units that waited, polls (CXG_VERBOSE)
+  int64_t* offSpans = nullptr; uint64_t offSpansCap = 0;  // offset captures (scanOffsetCaps): the spans in front of the expansion kernel
   int64_t* nullRows = nullptr; uint64_t nullRowsCap = 0;  // nullable programs (scanNullable): rows of the non-empty variant,
   uint64_t* nullCov = nullptr; uint64_t nullCovCap = 0;   // ... inclusive sums of the positions they cover, + one sum per block of 4096 rows
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
@@ -118,6 +119,7 @@ struct Scratch {
       if (hay) (void)hipFree(hay);
       if (out) (void)hipFree(out);
       if (bt) (void)hipFree(bt);
+      if (offSpans) (void)hipFree(offSpans);
       if (nullRows) (void)hipFree(nullRows);
       if (nullCov) (void)hipFree(nullCov);
       if (bothHay) (void)hipFree(bothHay);
@@ -186,6 +188,8 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
                  uint64_t* n_out, void* user_stream, cxg_timing* timing);
+int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                   uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width);
 thread_local bool t_u32Rows = false;                               // cxg_find_all_device_u32 in progress on this thread (ScanArgs::u32_rows)
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) table-walking generation (A/B profiling);
@@ -845,6 +849,11 @@ constexpr int kMaxBothRestarts = 64;
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (p && p->nullable && row_width == 2 && p->supported) return scanNullable(p, d_hay, len, base, limit, d_out, cap, n_out, user_stream, timing);
+  // capture slots at fixed distances from the span's ends: FindAll + one expansion kernel (no capture pass per row), unless the
+  // chain kernels write the slots themselves
+  static const bool offCapsOk = getenv("CXG_NO_OFFSET_CAPS") == nullptr;
+  if (p && row_width > 2 && p->offCapsOn && p->supported && offCapsOk && !(p->subSupported && p->chainCaps[0]))
+    return scanOffsetCaps(p, d_hay, len, base, limit, d_out, cap, n_out, user_stream, timing, row_width);
   uint64_t n_cur = 0;
   int rc = scanDeviceOnce(p, d_hay, len, base, limit, d_out, cap, &n_cur, user_stream, timing, row_width);
   if (rc != kRcLongMatch) { if (n_out) *n_out = n_cur; return rc; }
@@ -1139,6 +1148,71 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
   return CXG_OK;
 }
 
+// ---- offset captures ---------------------------------------------------------------------------------------------------------
+struct OffCapsArg { uint8_t src[32]; int32_t delta[32]; };
+__global__ void k_caps_offsets(const int64_t* spans, uint64_t n, uint32_t width, OffCapsArg oc, int64_t* out) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // one thread per PAIR of slots: 16-byte stores
+  const uint32_t pairs = width >> 1;
+  const uint64_t i = t / pairs;
+  const uint32_t k = static_cast<uint32_t>(t % pairs) * 2u;
+  if (i >= n) return;
+  const int64_t s = spans[2 * i], e = spans[2 * i + 1];
+  cxgdev::store_pair_nt(out + i * width + k, (oc.src[k] ? e : s) + oc.delta[k], (oc.src[k + 1] ? e : s) + oc.delta[k + 1]);
+}
+int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                   uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+  if (n_out) *n_out = 0;
+  if (!d_out) return scanDevice(p, d_hay, len, base, limit, nullptr, 0, n_out, user_stream, timing, 2);   // a row per span
+  if (reinterpret_cast<uintptr_t>(d_out) & 15u) return fail(CXG_E_INVALID, "device output must be 16-byte aligned");
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
+  uint64_t want = cap;
+  if (limit > 0 && static_cast<uint64_t>(limit) < want) want = static_cast<uint64_t>(limit);
+  cxg_timing t0;
+  std::memset(&t0, 0, sizeof t0);
+  float kernel_ms = 0, total_ms = 0;
+  uint32_t launches = 0;
+  if (want * 16u > (256ull << 20)) {                               // a generous cap: size the spans by the count
+    uint64_t n = 0;
+    if (int rc = scanDevice(p, d_hay, len, base, limit, nullptr, 0, &n, user_stream, &t0, 2)) return rc;
+    kernel_ms += t0.kernel_ms; total_ms += t0.total_ms; launches += t0.n_launches;
+    if (n > cap) { if (n_out) *n_out = n; return fail(CXG_E_CAPACITY, "output capacity too small"); }
+    want = n;
+  }
+  if (2 * want + 2 > s.offSpansCap) {
+    if (s.offSpans) HIP_TRY(hipFree(s.offSpans));
+    s.offSpans = nullptr; s.offSpansCap = 0;
+    const uint64_t c = 2 * want + want / 2 + 1024;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.offSpans), c * sizeof(int64_t)));
+    s.offSpansCap = c;
+  }
+  uint64_t n = 0;
+  int rc = scanDevice(p, d_hay, len, base, limit, s.offSpans, want, &n, user_stream, &t0, 2);
+  kernel_ms += t0.kernel_ms; total_ms += t0.total_ms; launches += t0.n_launches;
+  if (n_out) *n_out = n;
+  if (rc != CXG_OK) return rc;
+  if (n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
+  if (n) {
+    OffCapsArg oc;
+    std::memcpy(oc.src, p->offSrc, sizeof oc.src);
+    std::memcpy(oc.delta, p->offDelta, sizeof oc.delta);
+    const uint64_t threads = n * static_cast<uint64_t>(row_width / 2);
+    HIP_TRY(hipEventRecord(s.ev[0], stream));
+    hipLaunchKernelGGL(k_caps_offsets, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream, s.offSpans, n, static_cast<uint32_t>(row_width), oc, static_cast<int64_t*>(d_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s.ev[2], stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float t = 0;
+    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
+    kernel_ms += t; total_ms += t; launches++;
+  }
+  if (timing) { *timing = t0; timing->kernel_ms = kernel_ms; timing->total_ms = total_ms; timing->n_launches = launches; }
+  if (s.offSpansCap * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.offSpans); s.offSpans = nullptr; s.offSpansCap = 0; }
+  return CXG_OK;
+}
+
 uint64_t tilesFor(uint32_t kind, uint64_t len) {
   (void)kind;
   return (len + cxgdev::kTile - 1) / cxgdev::kTile;
@@ -1328,6 +1402,7 @@ int cxg_compile(const char* pattern, size_t len, cxg_program** out) {
       p->whyNot = plan.why.empty() ? "the reference may route this pattern to a reverse-search strategy outside the device subset" : plan.why;
     }
     if (p->ngroups > 1) cxg::buildSubmatchProgram(p, view, plan.strategy);   // FindAllSubmatchIndex path (spans + one-pass captures)
+    if (p->ngroups > 1) cxg::deriveOffsetCaps(p, view);
     if (p->supported && p->ngroups == 1) {                     // bounded repetition (`\d{1,3}\.\d{1,3}`...) on the chain kernel
       static const bool noBounded = getenv("CXG_NO_BOUNDED_CHAIN") != nullptr;
       cxg::Ast sur;
@@ -1365,6 +1440,7 @@ int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_p
     cxg::buildProgramFromNfa(p, *nfa, strategy, flags);
     // FindAllSubmatch hook (meta/findall.go:390): spans + capture table, same call as cxg_compile makes
     if (nfa->capture_count > 1) cxg::buildSubmatchProgram(p, *nfa, strategy);
+    if (nfa->capture_count > 1) cxg::deriveOffsetCaps(p, *nfa);
     else p->subWhyNot = "pattern has no capture groups (cxg_find_all_submatch then returns the spans)";
     if (!p->supported) t_err = p->whyNot;
     *out = p;
@@ -1494,8 +1570,14 @@ int cxg_program_chain_bounds(const cxg_program* p, uint8_t out[40]) {
   return 1;
 }
 int cxg_program_submatch_supported(const cxg_program* p) {
-  if (p && !p->subSupported) t_err = p->subWhyNot;
-  return p && p->subSupported ? 1 : 0;
+  if (p && !p->subSupported && !(p->offCapsOn && p->supported)) t_err = p->subWhyNot;
+  return p && (p->subSupported || (p->offCapsOn && p->supported)) ? 1 : 0;
+}
+int cxg_program_offset_captures(const cxg_program* p, int* src, int* delta, int max_slots) {
+  if (!p || !p->offCapsOn) return 0;
+  const int n = 2 * p->ngroups;
+  for (int k = 0; k < n && k < max_slots; k++) { if (src) src[k] = p->offSrc[k]; if (delta) delta[k] = p->offDelta[k]; }
+  return n;
 }
 int cxg_program_nfa(const cxg_program* p, cxg_nfa* out) {
   if (!p || !out) return fail(CXG_E_INVALID, "null argument");

@@ -1482,6 +1482,92 @@ void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vec
   }
 }
 
+void deriveOffsetCaps(cxg_program* p, const cxg_nfa& nfa) {
+  p->offCapsOn = 0;
+  if (!p->supported || p->nullable || nfa.capture_count < 2 || nfa.capture_count > 16 || nfa.start_unanchored == nfa.start_anchored) return;
+  const uint32_t N = nfa.n_states;
+  // the pattern's states: what the anchored start reaches (the unanchored prefix in front of it does not count as a way in)
+  std::vector<uint8_t> reach(N, 0);
+  std::vector<uint32_t> indeg(N, 0), pred(N, CXG_NFA_INVALID);
+  std::vector<uint32_t> st{nfa.start_anchored};
+  auto edge = [&](uint32_t from, uint32_t to) { if (to != CXG_NFA_INVALID && to < N) { indeg[to]++; pred[to] = from; if (!reach[to]) { reach[to] = 1; st.push_back(to); } } };
+  if (nfa.start_anchored >= N) return;
+  reach[nfa.start_anchored] = 1;
+  uint32_t match = CXG_NFA_INVALID;
+  int perSlot[32] = {0};
+  while (!st.empty()) {
+    const uint32_t q = st.back(); st.pop_back();
+    const cxg_nfa_state& x = nfa.states[q];
+    switch (x.kind) {
+      case CXG_NFA_MATCH: if (match != CXG_NFA_INVALID && match != q) return; match = q; break;
+      case CXG_NFA_BYTE_RANGE: case CXG_NFA_EPSILON: case CXG_NFA_LOOK: edge(q, x.next); break;
+      case CXG_NFA_CAPTURE: {
+        const uint32_t slot = x.cap_index * 2u + (x.cap_start ? 0u : 1u);
+        if (slot >= 32) return;
+        perSlot[slot]++;
+        edge(q, x.next);
+        break;
+      }
+      case CXG_NFA_SPLIT: edge(q, x.left); edge(q, x.right); break;
+      case CXG_NFA_SPARSE: {
+        std::vector<uint32_t> seen;
+        for (uint32_t k = 0; k < x.trans_len; k++) { const uint32_t t = nfa.trans[x.trans_off + k].next; if (std::find(seen.begin(), seen.end(), t) == seen.end()) { seen.push_back(t); edge(q, t); } }
+        break;
+      }
+      default: break;
+    }
+  }
+  if (match == CXG_NFA_INVALID) return;
+  const uint32_t nslots = nfa.capture_count * 2u;
+  bool have[32] = {false};
+  // one consuming step to exactly one state?
+  auto single = [&](const cxg_nfa_state& x, uint32_t& to) -> bool {
+    if (x.kind == CXG_NFA_BYTE_RANGE) { to = x.next; return true; }
+    if (x.kind != CXG_NFA_SPARSE || x.trans_len == 0) return false;
+    to = nfa.trans[x.trans_off].next;
+    for (uint32_t k = 1; k < x.trans_len; k++) if (nfa.trans[x.trans_off + k].next != to) return false;
+    return true;
+  };
+  {  // forward: start, then states entered from one place only, until the first branch
+    uint32_t cur = nfa.start_anchored;
+    int32_t consumed = 0;
+    for (uint32_t steps = 0; steps < N + 1 && cur != CXG_NFA_INVALID && cur < N; steps++) {
+      if (cur == nfa.start_anchored ? indeg[cur] != 0u : indeg[cur] != 1u) break;
+      const cxg_nfa_state& x = nfa.states[cur];
+      uint32_t to = CXG_NFA_INVALID;
+      if (x.kind == CXG_NFA_EPSILON) cur = x.next;
+      else if (x.kind == CXG_NFA_CAPTURE) {
+        const uint32_t slot = x.cap_index * 2u + (x.cap_start ? 0u : 1u);
+        if (perSlot[slot] == 1) { have[slot] = true; p->offSrc[slot] = 0; p->offDelta[slot] = consumed; }
+        cur = x.next;
+      } else if (single(x, to)) { consumed++; cur = to; }
+      else break;
+    }
+  }
+  {  // backward: Match, then its one predecessor, and so on while every state has one way in and one way out
+    uint32_t cur = match;
+    int32_t consumed = 0;
+    for (uint32_t steps = 0; steps < N + 1; steps++) {
+      if (indeg[cur] != 1u) break;
+      const uint32_t q = pred[cur];
+      if (q == CXG_NFA_INVALID || q >= N) break;
+      const cxg_nfa_state& x = nfa.states[q];
+      uint32_t to = CXG_NFA_INVALID;
+      if (x.kind == CXG_NFA_EPSILON) cur = q;
+      else if (x.kind == CXG_NFA_CAPTURE) {
+        const uint32_t slot = x.cap_index * 2u + (x.cap_start ? 0u : 1u);
+        if (perSlot[slot] == 1 && !have[slot]) { have[slot] = true; p->offSrc[slot] = 1; p->offDelta[slot] = -consumed; }
+        cur = q;
+      } else if (single(x, to) && to == cur) { consumed++; cur = q; }
+      else break;
+      if (cur == nfa.start_anchored) break;
+    }
+  }
+  for (uint32_t k = 2; k < nslots; k++) if (!have[k]) return;
+  p->offSrc[0] = 0; p->offDelta[0] = 0; p->offSrc[1] = 1; p->offDelta[1] = 0;
+  p->offCapsOn = 1;
+}
+
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch, bool pairs) {
   p->strategy = CXG_USE_CHARCLASS_SEARCHER;
   p->ngroups = 1;

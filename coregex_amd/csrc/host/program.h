@@ -65,6 +65,11 @@ struct cxg_program {
   bool capHasLook = false;       // the backtracking image holds assertion states: capi.hip launches the LOOK instantiation of its kernels
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: the chain kernel overflowed its row buffers on this
                                                               // program's input once: later calls start with two tiles per wave (capi.hip)
+  // Offset captures (round 4): every capture boundary lies a fixed number of bytes behind the match's start or in front of its end
+  // (`user=(\S+)`, `"([^"]*)"`, `\[([^\]]+)\]`).  FindAllSubmatch is then FindAll + one expansion kernel (capi.hip scanOffsetCaps)
+  // instead of a backtracking pass per row.  offCaps[0] != 0: on; slot k >= 2: offSrc[k] 0 = start, 1 = end; offDelta[k] added.
+  uint8_t offCapsOn = 0, offSrc[32] = {0};
+  int32_t offDelta[32] = {0};
   uint32_t delim[4] = {0, 0, 0, 0};   // cxgdev::DelimAux: `O [^E]+ E` / `O [^E]* E` programs ([3] != 0), the delimiter kernel in front of the transducer
   uint8_t chainBounds[40] = {0}; // cxgdev::ChainCaps with on == 2: field bounds of a bounded-repetition program (kFlagChainBounded)
   uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
@@ -89,6 +94,9 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy = -1)
 // boundedSurrogate), bounds the (min, max) of its runs in order.  Adds the surrogate's chain to an already built,
 // supported digit / DFA-pair program when that chain has a shape the BND kernels take; otherwise leaves p alone.
 void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vector<std::pair<int, int>>& bounds);   // fills subBlob/capBlob/subSupported
+// Fills p->offCapsOn / offSrc / offDelta from the NFA when every capture slot sits on the split-free chain behind the pattern's
+// start or in front of its Match (each of those states entered from exactly one place, each slot written by one CAPTURE state).
+void deriveOffsetCaps(cxg_program* p, const cxg_nfa& nfa);
 void buildProgramFromCharClass(cxg_program* p, const uint8_t membership[256], uint32_t minMatch, bool pairs = false);
 void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits);
 }  // namespace cxg

@@ -150,6 +150,10 @@ int cxg_program_dfa_states(const cxg_program* p);       /* eager forward DFA sta
 int cxg_program_supported(const cxg_program* p);        /* 1 if the device path accepts it */
 /* Nullable pattern (`a*`, `x?y*`: matches the empty string; meta/findall.go:251-275 is its FindAll rule)?  0 no; 1 the device
    program is the pattern's non-empty variant and the empty matches are merged behind the scan; 2 every match is empty (`a*?`). */
+/* Offset captures: every capture boundary of the pattern lies a fixed number of bytes behind the match's start or in front of its
+   end (`user=(\S+)`, `"([^"]*)"`); FindAllSubmatch is then FindAll + one expansion kernel.  Returns the number of slots (2 x groups)
+   and, per slot, src (0 = start, 1 = end) and the delta added to it; 0 when the program has no such description. */
+int cxg_program_offset_captures(const cxg_program* p, int* src, int* delta, int max_slots);
 int cxg_program_nullable(const cxg_program* p);
 /* `O [^E]+ E` / `O [^E]* E` program (`\[[^\]]+\]`, `<[^>]+>`: served by scan_delim_wave.hip in front of the transducer)?  1 and the two
    bytes + whether the class must be taken at least once; else 0. */
