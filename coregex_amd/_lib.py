@@ -33,7 +33,12 @@ SYMBOLS = [
 class Timing(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("n_launches", C.c_uint32),
                 ("grid", C.c_uint32), ("block", C.c_uint32), ("tiles", C.c_uint64), ("kernel", C.c_uint32),
-                ("fallback_reason", C.c_uint32)]
+                ("fallback_reason", C.c_uint32), ("n_ladder", C.c_uint32), ("ladder", C.c_uint8 * 12)]
+
+    @property
+    def kernels(self):
+        """cxg_kernel id of every span launch of the call, in order (a fallback adds a rung)."""
+        return [int(self.ladder[i]) for i in range(min(int(self.n_ladder), 12))]
 
 
 class NfaTrans(C.Structure):

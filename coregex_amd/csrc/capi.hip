@@ -360,6 +360,55 @@ unsigned captureGrid(uint64_t nrows, uint32_t dyn_lds) {
   return static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * per_cu));
 }
 
+// Capture pass of FindAllSubmatch: one thread per match row behind the span kernel on the same stream — the one-pass table from LDS
+// or HBM, or bounded backtracking per row (device/bt.hpp) for patterns that are not one-pass.  The row count is only known on the
+// device, so it is read back first (one 8-byte copy).
+int launchCapturePass(const cxg_program* p, Scratch& s, const cxgdev::ScanArgs& a, const uint8_t* d_cap, hipStream_t stream, uint32_t& launches) {
+  if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  uint64_t nrows = s.hostCtl[1];
+  if (nrows > a.cap) nrows = a.cap;
+  if (static_cast<uint32_t>(s.hostCtl[2]) & (8u | 2u)) nrows = 0;   // the span kernel asked for a rerun: its rows are not final
+  if (nrows) {
+    const cxgdev::CapHeader* chh = reinterpret_cast<const cxgdev::CapHeader*>(p->capBlob.data());
+    const bool lds_ok = chh->magic != cxgdev::kBtMagic && chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
+    if (chh->magic == cxgdev::kBtMagic) {                        // not one-pass: backtracking per row
+      const unsigned blk = 64, grd = static_cast<unsigned>(std::min<uint64_t>((nrows + blk - 1) / blk, 64));   // <= 4096 threads x 16 KiB
+      const size_t need = static_cast<size_t>(grd) * blk * (cxgdev::kBtVisitedWords * 4ull + cxgdev::kBtStackEntries * 8ull);
+      if (s.btCap < need) {
+        if (s.bt) HIP_TRY(hipFree(s.bt));
+        s.bt = nullptr; s.btCap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bt), need));
+        s.btCap = need;
+      }
+      {
+        const uint32_t img = reinterpret_cast<const cxgdev::BtHeader*>(p->capBlob.data())->total_bytes;
+        const uint32_t img_lds = img <= 16384u ? ((img + 3u) & ~3u) : 0u;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * 2u));
+        if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt_lds<true>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
+        else hipLaunchKernelGGL(k_captures_bt_lds<false>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
+      }
+      // (patterns without assertions run the instantiation without the assertion branch: the walk of round 2's device runs)
+      if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt<true>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+      else hipLaunchKernelGGL(k_captures_bt<false>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
+    } else if (lds_ok && a.row_width <= 8) {
+      const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
+      hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
+    } else if (lds_ok && a.row_width <= 16) {
+      const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
+      hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
+    } else {
+      const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
+      hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
+    }
+    HIP_TRY(hipGetLastError());
+    launches = 2;
+  }
+    return CXG_OK;
+}
+
 // scanDeviceOnce: one search from the haystack's first byte.  kRcLongMatch (internal): a UseBoth program met a match longer
 // than its restart span; *n_out = rows of plain leftmost-first iteration, the rows themselves are in d_out when it has room.
 constexpr int kRcLongMatch = -1000;
@@ -479,9 +528,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
   bool trioKernel = false;                                         // gen 6 served by k_scan_trio_wave
   bool persKernel = false;                                         // ... by k_scan_fields_pers (the launcher says)
-  bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // match-dense input seen before
-  int fsmMode = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);             // transducer kernel: 0, 1 (dense), 2 (very dense)
-relaunch:
+  bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // wave kernels: match-dense input seen before
+  int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 (very dense)
+  uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
+  uint32_t nladder = 0;
+  // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:
+  // done; the same family in a denser mode; the transducer; the table-walking kernels — each `continue` below is one rung.
+  for (;;) {
   fusedCaps = false;
   fieldsKernel = false;
   persKernel = false;
@@ -493,7 +546,7 @@ relaunch:
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
-  if ((gen == 6 || gen == 7 || gen == 9 || gen == 10) && denseChain) {   // four times the row-buffer room per wave-tile
+  if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = (gen == 10 && fsmMode == 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, mode 2: one tile, 2048 rows
     const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * a.tiles_per_wave;
     a.ngroups = (len + gb - 1) / gb;
@@ -650,53 +703,13 @@ relaunch:
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
+                                                  : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
+                                                  : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
+  if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
+  nladder++;
   uint32_t launches = 1;
-  if (submatch && a.out && !fusedCaps) {
-    // capture pass: one thread per match row, after the span kernel on the same stream.  The row count is
-    // only known on the device, so read it back first (one 8-byte copy).
-    if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    uint64_t nrows = s.hostCtl[1];
-    if (nrows > a.cap) nrows = a.cap;
-    if (static_cast<uint32_t>(s.hostCtl[2]) & (8u | 2u)) nrows = 0;   // the span kernel asked for a rerun: its rows are not final
-    if (nrows) {
-      const cxgdev::CapHeader* chh = reinterpret_cast<const cxgdev::CapHeader*>(p->capBlob.data());
-      const bool lds_ok = chh->magic != cxgdev::kBtMagic && chh->n_entries <= kCapLdsEntries && chh->n_masks <= 256u;
-      if (chh->magic == cxgdev::kBtMagic) {                        // not one-pass: backtracking per row
-        const unsigned blk = 64, grd = static_cast<unsigned>(std::min<uint64_t>((nrows + blk - 1) / blk, 64));   // <= 4096 threads x 16 KiB
-        const size_t need = static_cast<size_t>(grd) * blk * (cxgdev::kBtVisitedWords * 4ull + cxgdev::kBtStackEntries * 8ull);
-        if (s.btCap < need) {
-          if (s.bt) HIP_TRY(hipFree(s.bt));
-          s.bt = nullptr; s.btCap = 0;
-          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bt), need));
-          s.btCap = need;
-        }
-        {
-          const uint32_t img = reinterpret_cast<const cxgdev::BtHeader*>(p->capBlob.data())->total_bytes;
-          const uint32_t img_lds = img <= 16384u ? ((img + 3u) & ~3u) : 0u;
-          int dev = 0, cus = 256;
-          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-          const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((nrows + 255) / 256, static_cast<uint64_t>(cus) * 2u));
-          if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt_lds<true>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
-          else hipLaunchKernelGGL(k_captures_bt_lds<false>, dim3(g1), dim3(256), img_lds, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, img_lds, a.err);
-        }
-        // (patterns without assertions run the instantiation without the assertion branch: the walk of round 2's device runs)
-        if (p->capHasLook) hipLaunchKernelGGL(k_captures_bt<true>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
-        else hipLaunchKernelGGL(k_captures_bt<false>, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, s.bt, a.err);
-      } else if (lds_ok && a.row_width <= 8) {
-        const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
-        hipLaunchKernelGGL(k_captures_lds<8>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
-      } else if (lds_ok && a.row_width <= 16) {
-        const unsigned grd = captureGrid(nrows, chh->n_entries * 512u);
-        hipLaunchKernelGGL(k_captures_lds<16>, dim3(grd), dim3(256), chh->n_entries * 512u, stream, a.hay, a.base, a.len, a.out, nrows, a.row_width, d_cap, a.err);
-      } else {
-        const unsigned blk = 128, grd = static_cast<unsigned>((nrows + blk - 1) / blk);
-        hipLaunchKernelGGL(k_captures, dim3(grd), dim3(blk), 0, stream, a.hay, a.base, a.out, nrows, a.row_width, d_cap, a.err);
-      }
-      HIP_TRY(hipGetLastError());
-      launches = 2;
-    }
-  }
+  if (submatch && a.out && !fusedCaps) { if (int rc = launchCapturePass(p, s, a, d_cap, stream, launches)) return rc; }
   HIP_TRY(hipEventRecord(s.ev[2], stream));
   if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));   // wave kernels wrote hostCtl themselves
   HIP_TRY(hipStreamSynchronize(stream));
@@ -707,9 +720,10 @@ relaunch:
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
+    timing->n_ladder = nladder;
+    std::memcpy(timing->ladder, ladder, sizeof ladder);
     timing->grid = static_cast<uint32_t>(a.ntiles); timing->block = cxgdev::kThreads; timing->tiles = a.ntiles;
-    timing->kernel = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
-                                           : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
+    timing->kernel = kernelId;
     timing->fallback_reason = lastReason;
   }
   if (profOn) {
@@ -766,13 +780,13 @@ relaunch:
   }
   if ((err & 2u) && gen == 11) {                                    // the delimiter kernel needs dispatch in index order: never again, the transducer
     delimWatchdog.store(true);
-    relaunches++; gen = 10; fsmTried = true; goto relaunch;
+    relaunches++; gen = 10; fsmTried = true; continue;
   }
   if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
     staticGroupsOk.store(false);
     fprintf(stderr, "[cxg] look-back watchdog fired with static group assignment: switching to tickets\n");
     relaunches++;
-    goto relaunch;
+    continue;
   }
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
@@ -782,28 +796,25 @@ relaunch:
       // mode 1 was not enough -> mode 2 (1 tile, 2048 rows, 16 rows / 32 events per 32 bytes)
       fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : 2;
       if (verbose) fprintf(stderr, "[cxg] transducer kernel: match-dense input (reason bits 0x%x), rerunning in mode %d\n", err >> 8, fsmMode);
-      denseChain = true;
-      {
-        uint8_t old = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);
-        while (old < fsmMode && !p->denseChain[submatch ? 1 : 0].compare_exchange_weak(old, static_cast<uint8_t>(fsmMode), std::memory_order_relaxed)) {}
+      {                                                             // remembered per program; only grows
+        uint8_t old = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);
+        while (old < fsmMode && !p->fsmMode[submatch ? 1 : 0].compare_exchange_weak(old, static_cast<uint8_t>(fsmMode), std::memory_order_relaxed)) {}
       }
       relaunches++;
-      goto relaunch;
+      continue;
     }
     if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain && !(h->flags & cxgdev::kFlagChainBounded)) {   // only the row buffers overflowed: same kernel, two tiles per wave
       if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);
       denseChain = true;
-      {                                                             // remembered value only grows: a transducer mode 2 seen before stays
-        uint8_t old = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed);
-        while (old < 1 && !p->denseChain[submatch ? 1 : 0].compare_exchange_weak(old, 1, std::memory_order_relaxed)) {}
-      }
+      p->denseChain[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      if (fsmMode == 0) fsmMode = 1;                                // (should this call still reach the transducer: the input is match-dense)
       relaunches++;
-      goto relaunch;
+      continue;
     }
     lastReason = err >> 8;
     if (d_fsm && !fsmTried) {                                       // dense tile / no sync byte in a halo: the transducer kernel
       if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the transducer kernel\n", gen, err >> 8);
-      relaunches++; gen = 10; fsmTried = true; goto relaunch;
+      relaunches++; gen = 10; fsmTried = true; continue;
     }
     if (h->kind == cxgdev::kKindFsmOnly)                            // no table-walking image: degrade for THIS haystack
       return fail(CXG_E_INPUT, "haystack outside the transducer kernel's budgets (reason bits " + std::to_string(err >> 8) +
@@ -811,7 +822,7 @@ relaunch:
     if (h->kind == cxgdev::kKindCharClass && (h->flags & cxgdev::kFlagCcRanges) && reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs)
       return fail(CXG_E_INPUT, "more than 1024 occurrences of the quote byte in one 3840-byte tile (no table kernel pairs them)");
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);
-    relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; goto relaunch;   // table-walking kernels: exact, serial inside a stretch
+    relaunches++; gen = h->kind == cxgdev::kKindDigit ? 2 : 0; continue;   // table-walking kernels: exact, serial inside a stretch
   }
   err &= 0xFFu;
   // (first: a walk cut at the budget leaves a truncated row behind, which may also have raised the long-match flag — the rows
@@ -830,6 +841,7 @@ relaunch:
   if (d_out && n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
   (void)row_width;
   return CXG_OK;
+  }   // one span launch
 }
 
 __global__ void k_first_long(const int64_t* rows, uint64_t n, uint32_t width, int64_t max_len, unsigned long long* first) {
@@ -875,6 +887,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     if (!timing) return;
     acc.kernel_ms += timing->kernel_ms; acc.total_ms += timing->total_ms; acc.n_launches += timing->n_launches;
     acc.grid = timing->grid; acc.block = timing->block; acc.tiles = timing->tiles; acc.kernel = timing->kernel; acc.fallback_reason = timing->fallback_reason;
+    for (uint32_t i = 0; i < timing->n_ladder && i < sizeof timing->ladder; i++) { if (acc.n_ladder < sizeof acc.ladder) acc.ladder[acc.n_ladder] = timing->ladder[i]; acc.n_ladder++; }
   };
   add_timing();
   const uint64_t width = static_cast<uint64_t>(row_width);

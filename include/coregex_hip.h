@@ -112,6 +112,8 @@ typedef struct cxg_timing {  /* filled by the *_device entry points when non-NUL
   uint64_t tiles;
   uint32_t kernel;           /* cxg_kernel id of the LAST scan launch (after fallbacks): see cxg_kernel_name */
   uint32_t fallback_reason;  /* reason bits of the last fallback a wave kernel raised in this call, 0: none */
+  uint32_t n_ladder;         /* span launches of this call (a fallback adds a rung: wave kernel -> denser mode -> transducer -> table kernel) */
+  uint8_t ladder[12];        /* cxg_kernel id of each of them, in order (the first 12) */
 } cxg_timing;
 
 /* Kernel families (cxg_timing.kernel). */
