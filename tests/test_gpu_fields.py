@@ -140,6 +140,8 @@ def test_dense_input(oracle):
     t = cx.Timing()
     n = rx.find_all_device(d.data_ptr(), hay.size, timing=t)
     assert n == (26 << 20) and t.n_launches >= 2
+    # the rungs of the call (cxg_timing.ladder): the persistent fields kernel first, then whatever took the dense input
+    assert len(t.kernels) >= 2 and t.kernels[0] == K_PERS and t.kernels[-1] == t.kernel, t.kernels
 
 
 @pytest.mark.parametrize("env,kernel", [({"CXG_NO_FIELDS_KERNEL": "1"}, 6), ({"CXG_TICKETS": "1"}, K_FIELDS), ({"CXG_NO_EPOCH": "1"}, K_PERS), ({"CXG_NO_PERSIST": "1"}, K_FIELDS),
