@@ -495,6 +495,11 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   } else if (h->kind == cxgdev::kKindTeddy) {
     static const bool oldTeddy = getenv("CXG_TEDDY_KERNEL") && atoi(getenv("CXG_TEDDY_KERNEL")) == 1;
     gen = (oldTeddy || h->aux_len > 2048u) ? 0 : 7;                 // the wave kernel stages at most 2 KiB of literal tables
+    // literals between assertions (walk.hpp TeddyAux::looks): the table kernel knows no assertions — wave kernel, else the transducer
+    if (gen == 0 && reinterpret_cast<const cxgdev::TeddyAux*>(p->blob.data() + h->aux_off)->looks != 0u && !submatch) {
+      if (!d_fsm) return fail(CXG_E_UNSUPPORTED, "literals between assertions: neither the wave kernel nor the transducer can take this program");
+      gen = 10; fsmTried = true;
+    }
     // 7 = wave kernel (scan_teddy_wave.hip), 0 = scan_teddy.hip
   } else if (h->kind == cxgdev::kKindCharClass) {
     static const bool oldCc = getenv("CXG_CC_KERNEL") && atoi(getenv("CXG_CC_KERNEL")) == 1;
@@ -819,6 +824,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     if (h->kind == cxgdev::kKindFsmOnly)                            // no table-walking image: degrade for THIS haystack
       return fail(CXG_E_INPUT, "haystack outside the transducer kernel's budgets (reason bits " + std::to_string(err >> 8) +
                                "): matches denser than one per 2 bytes, a match reaching > 190 bytes past its tile, or an unresolvable entry state");
+    if (h->kind == cxgdev::kKindTeddy && !submatch && reinterpret_cast<const cxgdev::TeddyAux*>(p->blob.data() + h->aux_off)->looks != 0u)
+      return fail(CXG_E_INPUT, "haystack outside the literal kernel's and the transducer kernel's budgets (reason bits " + std::to_string(err >> 8) + "); the table kernel knows no assertions");
     if (h->kind == cxgdev::kKindCharClass && (h->flags & cxgdev::kFlagCcRanges) && reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs)
       return fail(CXG_E_INPUT, "more than 1024 occurrences of the quote byte in one 3840-byte tile (no table kernel pairs them)");
     if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the table kernel\n", gen, err >> 8);

@@ -39,9 +39,15 @@ struct LdsMem {
   int32_t lim;          // bytes [0, lim) are staged
   int32_t flag_at = 0x7FFFFFFF;   // reading this byte or beyond means the walk ran into the serial-walk cut
   mutable uint32_t over = 0;
+  mutable uint32_t slow = 0;    // bytes this lane read from HBM / L2 one at a time (~1.6 us each)
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[lds_pad(r)];
     over |= static_cast<uint32_t>(r >= flag_at);
+    // Total budget of a lane (scan_dfa.h kSerialReads): a program whose every search runs to the end of a stretch without
+    // synchronising bytes (`\D+?xyz|bc` on text without digits: the lazy alternative stays alive, as in the reference) walks
+    // matches x stretch bytes — minutes for 80 KB, with the other workgroups spinning in the look-back until their watchdog
+    // fires.  Past the budget the call is refused (kErrSerialLimit -> CXG_E_INPUT) and the remaining reads cost nothing.
+    if (++slow > kSerialReads) { over = 1u; return 0u; }
     return g[r];
   }
   __device__ __forceinline__ uint32_t dword(int32_t r) const {

@@ -37,9 +37,11 @@ struct FlatMem {
   int32_t lim;
   int32_t flag_at = 0x7FFFFFFF;   // serial-walk cut (scan_dfa.h walk_limit)
   mutable uint32_t over = 0;
+  mutable uint32_t slow = 0;    // one-byte reads beyond the staged window (scan_dfa.h kSerialReads)
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     if (static_cast<uint32_t>(r) < static_cast<uint32_t>(lim)) return lds[lds_pad2(r)];
     over |= static_cast<uint32_t>(r >= flag_at);
+    if (++slow > kSerialReads) { over = 1u; return 0u; }
     return g[r];
   }
   __device__ __forceinline__ uint64_t digits(int32_t w) const { return bits[w]; }

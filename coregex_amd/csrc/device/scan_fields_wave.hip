@@ -51,6 +51,10 @@
 #ifndef CXG_FABL
 #define CXG_FABL 0
 #endif
+// cache policy of the haystack loads (buffer intrinsic aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): -DCXG_HAY_LOAD_AUX=2 for A/B
+#ifndef CXG_HAY_LOAD_AUX
+#define CXG_HAY_LOAD_AUX 2                                   // nt: the haystack is read once (count-only 0.187 -> 0.176 ms, rows 0.234 -> 0.231; profiles/r04_time_wrapped.txt)
+#endif
 
 namespace cxgdev {
 
@@ -251,7 +255,7 @@ __device__ __forceinline__ void fields_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc
         pd[lane + 64 * k] = static_cast<uint16_t>(piece16<KD>(x[k], dlo4, dhi4));
         pp[lane + 64 * k] = static_cast<uint16_t>(piece16<KP>(x[k], plo4, phi4));
       }
-      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, CXG_HAY_LOAD_AUX);
       __builtin_amdgcn_sched_barrier(0);                            // keep the refill right behind its vector's last use
     }
   }
@@ -276,7 +280,7 @@ __device__ __forceinline__ void fields_first_loads(u32x4 (&x)[4], __amdgpu_buffe
   for (int k = 0; k < 4; k++) {
     uint32_t off = static_cast<uint32_t>(lane + 64 * k) << 4;
     if (first) off = off >= static_cast<uint32_t>(kFPre) ? off - kFPre : 0x7FFFFFF0u;
-    x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, 0);
+    x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, CXG_HAY_LOAD_AUX);
     __builtin_amdgcn_sched_barrier(0);                              // issue order = use order: the tile loop waits for x[0] with vmcnt(3), not for all four
   }
 }
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_sca
         pd[lane + 64 * k] = static_cast<uint16_t>(fd);
 #pragma unroll
         for (int i = 0; i < K - 1; i++) reinterpret_cast<uint16_t*>(s_c[i][wave])[lane + 64 * k] = static_cast<uint16_t>(fc[i]);
-        x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, 0);
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, CXG_HAY_LOAD_AUX);
         __builtin_amdgcn_sched_barrier(0);
       }
     }

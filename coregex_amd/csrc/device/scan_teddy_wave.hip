@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(s_aux + ax->off_off);
   const uint8_t* t_bytes = s_aux + ax->bytes_off;
   const uint32_t nlits = ax->nlits;
+  const uint32_t look_pre = ax->looks & 0xFFu, look_post = (ax->looks >> 8) & 0xFFu;   // literals between assertions (walk.hpp TeddyAux::looks)
   const uint32_t dfa_start = VERIFY ? ax->dfa_start : 0u, dfa_fa = VERIFY ? ax->dfa_first_accept : 0u;
   if (VERIFY) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off + ax->dfa_off);
@@ -300,6 +301,12 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
                 if (q == len) mlen = len;
               }
             }
+            if (!VERIFY && mlen && (look_pre | look_post) != 0u) {   // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
+              const int pb = c > 0 ? static_cast<int>(wb[c - 1]) : (tile_lo > 0 ? static_cast<int>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1);
+              const int nb = c + mlen < rend ? (c + mlen < kWin ? static_cast<int>(wb[c + mlen]) : -2) : -1;
+              if (nb == -2) { edge_hit = 1; mlen = 0; }                 // the byte behind the occurrence lies behind the window: hand the scan over
+              else if (!teddy_look_holds(look_pre, pb, static_cast<int>(wb[c])) || !teddy_look_holds(look_post, static_cast<int>(wb[c + mlen - 1]), nb)) mlen = 0;
+            }
             if (VERIFY && mlen) {                                   // literal found: the anchored DFA gives the match end
               uint32_t q = dfa_start;
               int32_t last = -1, i = c;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
     nrows_w += emitted_here;
   }
   if (nrows_w > static_cast<uint32_t>(kTRows)) fallback |= 16;
-  if (VERIFY && __ballot(edge_hit != 0) != 0ull) fallback |= 32;
+  if (__ballot(edge_hit != 0) != 0ull) fallback |= 32;
   if (fallback != 0 && lane == 0) raise_err(a.err, 8u | (fallback << 8));
   if (VERIFY && __ballot(long_hit != 0) != 0ull && lane == 0) raise_err(a.err, kErrLongMatch);
   __syncthreads();

@@ -265,11 +265,29 @@ struct TeddyView {
 
 struct TeddyAux {           // layout of the blob's aux section (all offsets relative to aux start)
   uint32_t nlits, nbuckets, minlen, maxlen;
-  uint32_t ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len, _pad;
+  uint32_t ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len;
+  // Literals between two assertions (`\berror\b`, `(?m)^(GET|POST)`, round 4): looks = pre | post << 8, each 0 (none) or nfa.Look + 1
+  // (3 StartLine, 4 EndLine, 5 WordBoundary, 6 NoWordBoundary); an occurrence counts when both hold around it (teddy_look_holds)
+  uint32_t looks;
   // kFlagPrefixLiteral images (a UseDFA program behind its required literal prefix): the anchored forward DFA,
   // [dfa_states][256] u8, that turns a prefix occurrence into the match end (0 states: plain literal set)
   uint32_t dfa_off, dfa_states, dfa_start, dfa_first_accept;
 };
+
+// checkLook (nfa/pikevm.go:1646-1674) for one assertion at a position with the byte in front of it and the byte behind it; outside the
+// haystack: -1 (a line edge, not a word byte)
+CXG_HD bool teddy_look_holds(uint32_t look1, int prevb, int nextb) {
+  if (look1 == 0u) return true;
+  const bool pw = prevb >= 0 && ((prevb >= '0' && prevb <= '9') || (prevb >= 'A' && prevb <= 'Z') || prevb == '_' || (prevb >= 'a' && prevb <= 'z'));
+  const bool nw = nextb >= 0 && ((nextb >= '0' && nextb <= '9') || (nextb >= 'A' && nextb <= 'Z') || nextb == '_' || (nextb >= 'a' && nextb <= 'z'));
+  switch (look1) {
+    case 3: return prevb < 0 || prevb == '\n';
+    case 4: return nextb < 0 || nextb == '\n';
+    case 5: return pw != nw;
+    case 6: return pw == nw;
+    default: return false;
+  }
+}
 
 template <class Mem>
 CXG_HD uint32_t teddy_mask_at(const Mem& m, const TeddyView& t, int32_t i, int32_t rend) {

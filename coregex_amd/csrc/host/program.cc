@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <functional>
 #include <map>
 
 namespace cxg {
@@ -544,6 +545,64 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why) {
   return true;
 }
 
+// Literals between assertions: `\berror\b`, `(?m)^(GET|POST|PUT)`, `\b(warn|fatal)\b` — UseNFA programs in the reference (a small
+// pattern with a word boundary or a multi-line anchor, meta/strategy.go:1503), i.e. its PikeVM: leftmost-first over an assertion,
+// an alternation of plain literals, an assertion.  For a prefix-free literal set at most one alternative matches at a position, so
+// the answer is: the occurrences of the literals around which both assertions hold, leftmost first, non-overlapping — the
+// literal kernel's candidates with one more test in their verification (scan_teddy_wave.hip), instead of the look-around
+// transducer over every byte.  Reads the shape off the NFA (so that cxg_program_from_nfa gets it as well): start, captures /
+// epsilons, an optional LOOK, a tree of splits over chains of single-byte states, an optional LOOK, Match.
+bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits, uint32_t& looks) {
+  lits.clear();
+  looks = 0;
+  const uint32_t N = nfa.n_states;
+  auto skip = [&](uint32_t q) {                                      // over epsilons and captures
+    for (uint32_t g = 0; g < N && q < N; g++) {
+      const cxg_nfa_state& x = nfa.states[q];
+      if (x.kind == CXG_NFA_EPSILON || x.kind == CXG_NFA_CAPTURE) q = x.next; else break;
+    }
+    return q;
+  };
+  uint32_t cur = skip(nfa.start_anchored);
+  if (cur >= N) return false;
+  uint32_t pre = 0, post = 0;
+  if (nfa.states[cur].kind == CXG_NFA_LOOK) { if (nfa.states[cur].lo < 2) return false; pre = nfa.states[cur].lo + 1u; cur = skip(nfa.states[cur].next); }
+  if (cur >= N) return false;
+  uint32_t terminal = CXG_NFA_INVALID;
+  std::vector<uint8_t> path;
+  size_t visited = 0;
+  bool ok = true;
+  std::function<void(uint32_t)> dfs = [&](uint32_t q) {
+    if (!ok) return;
+    q = skip(q);
+    if (q >= N || ++visited > 8192 || path.size() > 255) { ok = false; return; }
+    const cxg_nfa_state& x = nfa.states[q];
+    switch (x.kind) {
+      case CXG_NFA_SPLIT: dfs(x.left); dfs(x.right); return;
+      case CXG_NFA_BYTE_RANGE:
+        if (x.lo != x.hi) { ok = false; return; }
+        path.push_back(x.lo); dfs(x.next); path.pop_back(); return;
+      case CXG_NFA_SPARSE:
+        if (x.trans_len != 1 || nfa.trans[x.trans_off].lo != nfa.trans[x.trans_off].hi) { ok = false; return; }
+        path.push_back(nfa.trans[x.trans_off].lo); dfs(nfa.trans[x.trans_off].next); path.pop_back(); return;
+      case CXG_NFA_LOOK: case CXG_NFA_MATCH:
+        if (terminal == CXG_NFA_INVALID) terminal = q;
+        if (terminal != q || path.empty() || lits.size() >= 64) { ok = false; return; }
+        lits.push_back(path);
+        return;
+      default: ok = false; return;
+    }
+  };
+  dfs(cur);
+  if (!ok || lits.empty() || terminal == CXG_NFA_INVALID) return false;
+  uint32_t t = terminal;
+  if (nfa.states[t].kind == CXG_NFA_LOOK) { if (nfa.states[t].lo < 2) return false; post = nfa.states[t].lo + 1u; t = skip(nfa.states[t].next); }
+  if (t >= N || nfa.states[t].kind != CXG_NFA_MATCH) return false;
+  if (pre == 0 && post == 0) return false;
+  looks = pre | (post << 8);
+  return true;
+}
+
 // Nullable patterns.  At a search position `at` the leftmost-first match of a pattern that can match the empty string starts
 // AT `at` — the empty path is always there — and is the first accepting path in priority order: a path that consumes bytes wins
 // only if it ranks ABOVE the empty path, and paths below the empty one never win.  So FindAll (meta/findall.go:216-283: report,
@@ -1047,6 +1106,19 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       std::memcpy(blob.data(), &h, sizeof h);
       p->blob.swap(blob);
       p->supported = true;
+      // literals between assertions: the literal kernel in front of the transducer (which stays: its fallback)
+      const bool noWrapped = getenv("CXG_NO_WRAPPED_LITERALS") != nullptr;   // (read per build: tests/test_gpu_fsm.py keeps these programs on the transducer)
+      std::vector<std::vector<uint8_t>> wl;
+      uint32_t wlooks = 0;
+      if (look && !p->nullable && !noWrapped && wrappedLiterals(nfa, wl, wlooks)) {
+        cxg_program tmp;
+        buildLiteralImage(&tmp, wl, 1);
+        if (tmp.supported) {
+          const cxgdev::BlobHeader* th = reinterpret_cast<const cxgdev::BlobHeader*>(tmp.blob.data());
+          reinterpret_cast<cxgdev::TeddyAux*>(tmp.blob.data() + th->aux_off)->looks = wlooks;
+          p->blob.swap(tmp.blob);
+        }
+      }
       return;
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
@@ -1485,6 +1557,13 @@ void attachBoundedChain(cxg_program* p, const cxg_nfa& surrogate, const std::vec
 void deriveOffsetCaps(cxg_program* p, const cxg_nfa& nfa) {
   p->offCapsOn = 0;
   if (!p->supported || p->nullable || nfa.capture_count < 2 || nfa.capture_count > 16 || nfa.start_unanchored == nfa.start_anchored) return;
+  // The spans must be what the reference's FindAllSubmatch reports as group 0: its PikeVM over the whole haystack, plain
+  // leftmost-first (meta/findall.go:89-98).  FindAllIndex of a UseBoth program restarts inside matches longer than 100 bytes
+  // (find_indices.go:425-431) and the digit prefilter has its run-skip rule: their FindAll spans are not always those.  (Found by
+  // the device fuzz: `[\d.]+[x-z]+.*(a|b)`, UseBoth, 230 rows with other spans than the PikeVM's.)
+  if (!(p->strategy == CXG_USE_DFA || p->strategy == CXG_USE_NFA || p->strategy == CXG_USE_TEDDY || p->strategy == CXG_USE_CHARCLASS_SEARCHER ||
+        p->strategy == CXG_USE_BOUNDED_BACKTRACKER)) return;
+  if (p->blob.size() >= sizeof(cxgdev::BlobHeader) && (reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data())->flags & cxgdev::kFlagBothRestart)) return;
   const uint32_t N = nfa.n_states;
   // the pattern's states: what the anchored start reaches (the unanchored prefix in front of it does not count as a way in)
   std::vector<uint8_t> reach(N, 0);

@@ -67,6 +67,8 @@ while len(seen) < npat:
     if pat in seen:
         continue
     seen.add(pat)
+    if os.environ.get("FUZZ_TRACE"):                      # which pattern is running (a hang or a very slow program shows as the last line)
+        print("[%6.1fs] %r" % (time.time() - t0, pat), file=sys.stderr, flush=True)
     try:
         rx = cx.compile(pat)
     except cx.CoregexError:

@@ -467,6 +467,12 @@ extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* h
           if (std::memcmp(g + c, tv.bytes + tv.off[id], static_cast<size_t>(ln)) == 0) mlen = ln;
         }
       }
+      if (mlen && !verify_dfa && ax->looks) {    // literals between assertions: both must hold around the occurrence
+        const int pb = (tile_lo + c) > 0 ? g[c - 1] : -1;
+        const int nb = c + mlen < rend ? (c + mlen < N ? g[c + mlen] : -2) : -1;
+        if (nb == -2) return -(16 + 32);
+        if (!teddy_look_holds(ax->looks & 0xFFu, pb, g[c]) || !teddy_look_holds((ax->looks >> 8) & 0xFFu, g[c + mlen - 1], nb)) mlen = 0;
+      }
       if (mlen && verify_dfa) {                  // the occurrence of the prefix is extended by the anchored DFA (window bytes only)
         uint32_t q = ax->dfa_start;
         int64_t last = -1, i = c;

@@ -10,6 +10,13 @@ from refcorpus import COMPAT_PATTERNS, generate_test_input
 pytestmark = pytest.mark.gpu
 
 K_FSM = 10
+
+
+@pytest.fixture(autouse=True)
+def _literals_between_assertions_stay_on_the_transducer(monkeypatch):
+    """Round 4 serves `\\berror\\b`-style programs by the literal kernel (tests/test_gpu_wrapped.py); this file is the transducer
+    kernel's tier and keeps them there."""
+    monkeypatch.setenv("CXG_NO_WRAPPED_LITERALS", "1")
 README_IP = r"(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"
 GENERAL = [README_IP, COMPAT_PATTERNS["la_peak_hours"], r"\d+\.\d+x?", r"a+b|b+a", r"ab*c|a|bb", r"a[0-9]*b|a\.", r"(foobar|foo)\d*",
            r"[1-9][0-9]*|0", r"a(b*c)?", r"x[ab]+?y", r"[a-f0-9]{8}-[a-f0-9]{4}", r"ab|abc", r"GET|POST /[a-z]+", r"[a-c]x|[b-d]y",

@@ -47,3 +47,20 @@ def test_synthlog_user_and_quotes(oracle):
         small = torch.empty((10, 4), dtype=torch.int64, device="cuda")
         with pytest.raises(cx.CoregexError):
             rx.find_all_submatch_device(d.data_ptr(), hay.size, small.data_ptr(), 10)
+
+
+def test_use_both_programs_keep_the_pikevm_spans(oracle):
+    """Found by the device fuzz (round 4): FindAllIndex of a UseBoth program restarts inside matches longer than 100 bytes
+    (find_indices.go:425-431), FindAllSubmatch is the PikeVM over the whole haystack — the spans differ, so such a program gets no
+    offset captures although its group sits at a fixed distance from the end."""
+    pat = r"[\d.]+[x-z]+.*(a|b)"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == "UseBoth" and rx.offset_captures is None
+    hay = _u8((b"12.5xyz" + b"q" * 300 + b"a \n" + b"7.z" + b"c" * 40 + b"b\n") * 200)
+    exp = o.find_all_submatch_index(hay)
+    if rx.submatch_supported:
+        try:
+            got = rx.find_all_submatch_index(hay)
+        except cx.UnsupportedInput:
+            return
+        assert np.array_equal(got, exp)

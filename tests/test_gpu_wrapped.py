@@ -1,0 +1,48 @@
+"""Literals between assertions on the device (round 4): `k_scan_teddy_wave` with the assertions in its verification, against the
+oracle; the transducer as its fallback (dense haystacks)."""
+import random
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from routing import routed
+from test_wrapped_cpu import TOKS, WRAPPED
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("pat", WRAPPED)
+def test_rows(pat, oracle):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    rng = random.Random(len(pat) * 3 + 1)
+    served = 0
+    for n in [0, 1, 7, 3839, 3840, 3841, 61441, 500000, 3_000_000]:
+        for sparse in (False, True):
+            toks = TOKS + ([b" pad pad pad pad pad pad pad pad "] * 12 if sparse else [])
+            hay = np.frombuffer(b"".join(rng.choice(toks) for _ in range(max(1, n // 3)))[:n], dtype=np.uint8)
+            exp = o.find_all_index(hay)
+            t = cx.Timing()
+            if hay.size:
+                import torch
+                d = torch.from_numpy(hay.copy()).cuda()
+                cnt = rx.find_all_device(d.data_ptr(), hay.size, timing=t)
+                assert cnt == len(exp), (pat, n, sparse)
+                served += t.kernels[0] == 7
+            got = rx.find_all_index(hay)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, n, sparse, bytes(hay[:60]), got[:4].tolist(), exp[:4].tolist())
+            assert np.array_equal(rx.find_all_index(hay, 2), exp[:2])
+    assert routed(served >= 8, served)
+
+
+def test_error_on_the_config_1_corpus(oracle):
+    import torch
+    hay = cx.synth_pages(1, 0xC0FFEE01, 0, 8192)
+    d = torch.from_numpy(hay).cuda()
+    for pat in (r"\berror\b", r"(?m)^(GET|POST|PUT|DELETE|PATCH)"):
+        rx = cx.compile(pat)
+        exp = oracle.Regex(pat).find_all_index(hay)
+        out = torch.empty((len(exp) + 4, 2), dtype=torch.int64, device="cuda")
+        t = cx.Timing()
+        assert rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), len(exp) + 4, timing=t) == len(exp)
+        assert np.array_equal(out[:len(exp)].cpu().numpy(), exp) and routed(t.kernels == [7], t.kernels)

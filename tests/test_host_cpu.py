@@ -119,8 +119,15 @@ def _fast_digit(p) -> bool:
 
 
 def _table_free(p):
-    """Programs of kind 5 run on the transducer kernel alone (word boundaries, (?m)^ literals): no table-walking image."""
-    return struct.unpack_from("<I", p.blob(), 4)[0] == 5
+    """Programs of kind 5 run on the transducer kernel alone (word boundaries, (?m)^ literals): no table-walking image.  Round 4:
+    literals between assertions are a literal image (kind 4) with TeddyAux::looks set — the wave kernel and the transducer only
+    (tests/test_wrapped_cpu.py is their twin tier)."""
+    b = p.blob()
+    kind = struct.unpack_from("<I", b, 4)[0]
+    if kind == 4:
+        aux_off = struct.unpack_from("<I", b, 4 * 14)[0]
+        return struct.unpack_from("<I", b, aux_off + 4 * 11)[0] != 0     # walk.hpp TeddyAux::looks
+    return kind == 5
 
 
 @pytest.mark.parametrize("chunk", [4, 16, 64])
@@ -627,8 +634,10 @@ def test_program_routing_table():
                      (r"^foo", "anchor")]:
         rx = cx.compile(pat)
         assert not rx.supported and why in rx.why_unsupported, (pat, rx.strategy, rx.why_unsupported)
-    wb = cx.compile(r"\bfoo\b")                       # small word-boundary patterns: UseNFA, transducer kernel only (kind 5, no tables)
-    assert wb.supported and wb.strategy == "UseNFA" and image(r"\bfoo\b")[1] == 5 and wb.fsm_image() is not None
+    wb = cx.compile(r"\bfoo\b")                       # a literal between assertions (round 4): UseNFA, literal image with looks + the transducer as fallback
+    assert wb.supported and wb.strategy == "UseNFA" and image(r"\bfoo\b")[1] == 4 and wb.fsm_image() is not None
+    wb2 = cx.compile(r"\b\w+=\d\b")                  # other small word-boundary patterns: transducer kernel only (kind 5, no tables)
+    assert wb2.supported and wb2.strategy == "UseNFA" and image(r"\b\w+=\d\b")[1] == 5 and wb2.fsm_image() is not None
 
 
 def test_bounded_repetition_chain_emulated(oracle):
