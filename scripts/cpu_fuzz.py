@@ -57,10 +57,27 @@ for seed in range(seed0, seed1):
                         continue
                 if kind == 5:                                # kKindFsmOnly (UseNFA, > 100 NFA states): the transducer twin
                     a = np.frombuffer(hay, dtype=np.uint8)
+                    if rx.nullable == 2:                     # round 4: every match is empty, no device program
+                        if emu.merge_empty_matches(np.zeros((0, 2), dtype=np.int64), len(hay)).tolist() != exp: print('NULL2', repr(pat), len(hay)); bad+=1; break
+                        continue
                     got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32)
                     if isinstance(got, int) and got in (-18, -32): got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32, dense=1)
+                    if rx.nullable and not isinstance(got, int): got = emu.merge_empty_matches(got, len(hay))   # the image is the non-empty variant's
                     if not isinstance(got, int) and got.tolist() != exp: print('FSM', repr(pat), rx.strategy, len(hay)); bad+=1; break
                     continue
+                if kind == 3 and rx.strategy != 'UseCharClassSearcher':   # round 4: `C+` / quote-pair programs of the DFA strategies on the char-class kernels
+                    g = emu.find_all_charclass_wave(blob, hay) if (fl & 64) else None
+                    if g is None: n_cc_unchecked += 1
+                    elif isinstance(g, int): n_cc_fallback += 1
+                    elif g.tolist() != exp: print('CCW-RUNS', repr(pat), rx.strategy, len(hay)); bad+=1; break
+                    continue
+                if kind == 4 and struct.unpack_from("<I", blob, struct.unpack_from("<I", blob, 56)[0] + 44)[0]:   # literals between assertions (TeddyAux::looks): wave twin + the transducer fallback
+                    g = emu.find_all_teddy_wave(blob, hay)
+                    if g is not None and not isinstance(g, int) and g.tolist() != exp: print('WRAPPED', repr(pat), len(hay)); bad+=1; break
+                    continue
+                if rx.delimiters is not None:               # round 4: delimiter kernel in front of the images checked below
+                    g = emu.find_all_delim(*rx.delimiters, np.frombuffer(hay, dtype=np.uint8))
+                    if not isinstance(g, int) and g.tolist() != exp: print('DELIM', repr(pat), len(hay)); bad+=1; break
                 if rx.strategy != 'UseCharClassSearcher':   # (scan_charclass.hip has no lane walk in walk.hpp: its wave twin is checked below)
                     got = emu.find_all(blob, hay).tolist()
                     if got != exp: print('LANES', repr(pat), rx.strategy, len(hay), len(got), len(exp)); bad+=1; break
@@ -81,8 +98,13 @@ for seed in range(seed0, seed1):
         if "(" in pat and rx.submatch_supported:
             sb, cb = rx.submatch_blobs()[:2]
             w = 2*(o.num_groups if hasattr(o,'num_groups') else rx.num_groups)
+            oc = rx.offset_captures
             for hay in hays[:6]:
                 exp = o.find_all_submatch_index(hay)
+                if oc is not None:                           # round 4: slots at fixed distances from the span's ends (FindAll + expansion kernel)
+                    for k, (src, d) in enumerate(oc):
+                        if not np.array_equal(exp[:, k], exp[:, 1 if src else 0] + d): print('OFFSET-CAPS', repr(pat), k, len(hay)); bad+=1; break
+                    continue
                 try: got = emu.find_all_submatch(sb, cb, hay, exp.shape[1])
                 except AssertionError as e:
                     if 'error -4' in str(e): n_bt_limit += 1; break      # a long match of a pattern that is not one-pass: the backtracking pass runs out of stack and the call fails (kErrSerialLimit), INTEGRATION.md
