@@ -173,13 +173,6 @@ class Regex:
             return None
         return C.string_at(p, n.value)
 
-    def runs_image(self):
-        """None, or the image of the alphabet-run kernel (device/runs.hpp) that runs in front of the transducer for this program."""
-        p, n = C.c_void_p(), C.c_size_t()
-        if _lib.lib().cxg_program_runs_image(self._h, C.byref(p), C.byref(n)) != 0:
-            return None
-        return C.string_at(p, n.value)
-
     def nfa(self):
         """Host copy of the NFA as (states ndarray-of-tuples, trans, start_anchored, start_unanchored, captures)."""
         v = _lib.Nfa()

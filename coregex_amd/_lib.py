@@ -23,7 +23,7 @@ SYMBOLS = [
     "cxg_program_from_nfa", "cxg_program_from_literals", "cxg_program_from_charclass",
     "cxg_program_destroy", "cxg_program_strategy", "cxg_strategy_name", "cxg_kernel_name", "cxg_program_num_groups",
     "cxg_program_nfa_states", "cxg_program_dfa_states", "cxg_program_supported", "cxg_program_nullable", "cxg_program_delimiters", "cxg_program_offset_captures", "cxg_program_blob",
-    "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_runs_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
+    "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
     "cxg_find_all_submatch_device",
@@ -115,7 +115,6 @@ def lib():
     L.cxg_program_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_nfa.argtypes = [vp, C.POINTER(Nfa)]
     L.cxg_program_fsm_image.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
-    L.cxg_program_runs_image.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_submatch_blobs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.cxg_program_chain_captures.argtypes = [vp, C.c_char_p]
     L.cxg_program_chain_captures.restype = C.c_int

@@ -31,7 +31,6 @@ hipError_t launch_scan_digit_flat(const ScanArgs& a, uint32_t fwd_states, hipStr
 hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, bool caps, hipStream_t stream);
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
 hipError_t launch_scan_delim_wave(const ScanArgs& a, hipStream_t stream);   // scan_delim_wave.hip
-hipError_t launch_scan_runs_wave(const ScanArgs& a, hipStream_t stream);    // scan_runs_wave.hip
 int fields_shape(const ChainAux& c);
 int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
@@ -447,13 +446,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     cxg_program* mp = const_cast<cxg_program*>(p);
     if (int rc = deviceCopy(fsmImg, submatch ? &mp->devSubFsm[t_device] : &mp->devFsm[t_device], &d_fsm)) return rc;
   }
-  // alphabet-run kernel (scan_runs_wave.hip): in front of the transducer for programs that have its image (program.cc)
-  const bool runsOk = getenv("CXG_RUNS_KERNEL") != nullptr;          // opt-in (read per call: tests switch it)
-  const uint8_t* d_runs = nullptr;
-  if (runsOk && !submatch && d_fsm && !p->runsBlob.empty() && !p->runsOff.load(std::memory_order_relaxed)) {
-    cxg_program* mp = const_cast<cxg_program*>(p);
-    if (int rc = deviceCopy(p->runsBlob, &mp->devRuns[t_device], &d_runs)) return rc;
-  }
   bool fsmTried = false;
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
@@ -534,11 +526,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     gen = 10;
     fsmTried = true;
   }
-  // patterns over a few ASCII ranges: the alphabet-run kernel first, the transducer behind it (runs too long / too many per tile)
-  if (gen == 10 && d_runs) {
-    gen = 12;
-    fsmTried = false;
-  }
   // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
   static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
@@ -561,7 +548,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
   if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
-  if (gen == 8 || gen == 11 || gen == 12) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
+  if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
@@ -613,8 +600,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   }
   HIP_TRY(hipEventRecord(s.ev[1], stream));
   hipError_t le;
-  a.blob = gen == 10 ? d_fsm : gen == 12 ? d_runs : d_blob;
-  if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6 && gen != 11 && gen != 12)       // (gen 6: checked below, the persistent fields kernel only)
+  a.blob = gen == 10 ? d_fsm : d_blob;
+  if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6 && gen != 11)       // (gen 6: checked below, the persistent fields kernel only)
     return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
@@ -625,7 +612,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     std::memcpy(a.chain, p->delim, sizeof p->delim);
     le = cxgdev::launch_scan_delim_wave(a, stream);
   }
-  else if (gen == 12) le = cxgdev::launch_scan_runs_wave(a, stream);
   else if (gen == 8) {
     // `Q[^Q]*Q` programs count EVENTS (occurrences of Q, two per row) in the look-back: FindAll's n is 2 n events
     const bool pairsProg = reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs != 0u;
@@ -722,7 +708,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : gen == 12 ? CXG_K_RUNS_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -831,7 +817,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       continue;
     }
     lastReason = err >> 8;
-    if (gen == 12) p->runsOff.store(1, std::memory_order_relaxed);   // this program's input has long or crowded runs: the transducer from now on
     if (d_fsm && !fsmTried) {                                       // dense tile / no sync byte in a halo: the transducer kernel
       if (verbose) fprintf(stderr, "[cxg] gen %d raised the fallback flag (reason bits 0x%x): rerunning with the transducer kernel\n", gen, err >> 8);
       relaunches++; gen = 10; fsmTried = true; continue;
@@ -1365,7 +1350,6 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_TRIO_WAVE: return "k_scan_trio_wave";
     case CXG_K_FIELDS_PERS: return "k_scan_fields_pers";
     case CXG_K_DELIM_WAVE: return "k_scan_delim_wave";
-    case CXG_K_RUNS_WAVE: return "k_scan_runs_wave";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
@@ -1547,13 +1531,12 @@ int cxg_program_from_charclass(const uint8_t membership[256], uint32_t min_match
 void cxg_program_destroy(cxg_program* p) {
   if (!p) return;
   for (int d = 0; d < 16; d++) {
-    if (p->dev[d] || p->devSub[d] || p->devCap[d] || p->devFsm[d] || p->devSubFsm[d] || p->devRuns[d]) (void)hipSetDevice(d);
+    if (p->dev[d] || p->devSub[d] || p->devCap[d] || p->devFsm[d] || p->devSubFsm[d]) (void)hipSetDevice(d);
     if (p->dev[d]) (void)hipFree(p->dev[d]);
     if (p->devSub[d]) (void)hipFree(p->devSub[d]);
     if (p->devCap[d]) (void)hipFree(p->devCap[d]);
     if (p->devFsm[d]) (void)hipFree(p->devFsm[d]);
     if (p->devSubFsm[d]) (void)hipFree(p->devSubFsm[d]);
-    if (p->devRuns[d]) (void)hipFree(p->devRuns[d]);
   }
   delete p;
 }
@@ -1588,13 +1571,6 @@ int cxg_program_fsm_image(const cxg_program* p, int submatch, const void** data,
   if (b.empty()) return fail(CXG_E_UNSUPPORTED, p->fsmWhyNot.empty() ? "program has no FindAll transducer image" : p->fsmWhyNot);
   *data = b.data();
   *len = b.size();
-  return CXG_OK;
-}
-int cxg_program_runs_image(const cxg_program* p, const void** data, size_t* len) {
-  if (!p || !data || !len) return fail(CXG_E_INVALID, "null argument");
-  if (p->runsBlob.empty()) return fail(CXG_E_UNSUPPORTED, p->runsWhyNot.empty() ? "program has no alphabet-run image" : p->runsWhyNot);
-  *data = p->runsBlob.data();
-  *len = p->runsBlob.size();
   return CXG_OK;
 }
 int cxg_program_submatch_blobs(const cxg_program* p, const void** sb, size_t* sl, const void** cb, size_t* cl) {

@@ -21,10 +21,7 @@
 // reference DFA of the oracle (test infrastructure) through the transducer's sequential twin.
 #include "lookdfa.h"
 
-#include "../device/runs.hpp"
-
 #include <algorithm>
-#include <cstring>
 #include <array>
 #include <map>
 #include <set>
@@ -270,7 +267,7 @@ Automaton buildReference(const cxg_nfa& n, uint32_t startState, const std::vecto
 // T: leftmost-first.  A state is the ordered thread list at a position (assertions not yet passed) plus the kind of the byte
 // behind the position; the symbol ahead completes the context, then every assertion is decided, a match state in the
 // expanded list ends a match in front of the symbol and cuts the lower-priority threads, and the rest moves on.
-Automaton buildLeftmostFirst(const cxg_nfa& n, uint32_t startState, const std::vector<int>& reps, bool trackBehind = true, bool textAnchors = true) {
+Automaton buildLeftmostFirst(const cxg_nfa& n, uint32_t startState, const std::vector<int>& reps) {
   Machine m(n);
   Automaton a;
   std::map<std::vector<uint32_t>, int32_t> ids;
@@ -290,8 +287,7 @@ Automaton buildLeftmostFirst(const cxg_nfa& n, uint32_t startState, const std::v
     std::vector<uint32_t> set;
     m.begin();
     m.into(set, startState, none);
-    // (a program without assertions needs no context; one that knows no text anchor starts a text like a line)
-    a.start[k] = intern(std::move(set), !trackBehind ? 0u : (k == kAtTextStart && !textAnchors) ? static_cast<uint32_t>(kAfterNewline) : static_cast<uint32_t>(k));
+    a.start[k] = intern(std::move(set), static_cast<uint32_t>(k));
   }
   for (size_t cur = 0; cur < tuples.size(); cur++) {
     const std::vector<uint32_t> src = tuples[cur];
@@ -323,7 +319,7 @@ Automaton buildLeftmostFirst(const cxg_nfa& n, uint32_t startState, const std::v
       std::vector<uint32_t> out;
       m.move(full, keep, b, false, out, none);
       if (out.empty()) continue;
-      nx[ri] = intern(std::move(out), !trackBehind ? 0u : b == '\n' ? kAfterNewline : isWord(b) ? kAfterWord : kAfterNonWord);
+      nx[ri] = intern(std::move(out), b == '\n' ? kAfterNewline : isWord(b) ? kAfterWord : kAfterNonWord);
     }
     a.next.push_back(std::move(nx));
     a.flag.push_back(std::move(fl));
@@ -517,7 +513,7 @@ void compareReverse(const cxg_nfa& rv, const std::vector<int>& reps) {
 
 namespace {
 
-struct Symbols { std::vector<int> reps, classOf; bool hasWordB = false, hasLine = false, hasEndLine = false; uint8_t symOf[256]; };
+struct Symbols { std::vector<int> reps, classOf; bool hasWordB = false, hasLine = false, hasEndLine = false; };
 
 // One representative byte per (byte class of the reference, kind the pattern's assertions can tell apart).
 Symbols symbolsOf(const cxg_nfa& nfa) {
@@ -541,15 +537,13 @@ Symbols symbolsOf(const cxg_nfa& nfa) {
   int nclass = 0;
   for (int b = 0, lo = 0; b < 256; b++) {
     if (b == 255 || boundary[b]) {
-      int seen[2][2] = {{-1, -1}, {-1, -1}};
+      bool seen[2][2] = {{false, false}, {false, false}};
       for (int x = lo; x <= b; x++) {
         const int w = sy.hasWordB && isWord(x), nl = sy.hasLine && x == '\n';
-        if (seen[w][nl] < 0) {
-          seen[w][nl] = static_cast<int>(sy.reps.size());
-          sy.reps.push_back(x);
-          sy.classOf.push_back(nclass);
-        }
-        sy.symOf[x] = static_cast<uint8_t>(seen[w][nl] > 255 ? 255 : seen[w][nl]);
+        if (seen[w][nl]) continue;
+        seen[w][nl] = true;
+        sy.reps.push_back(x);
+        sy.classOf.push_back(nclass);
       }
       nclass++;
       lo = b + 1;
@@ -646,114 +640,6 @@ void refuseLookDigitQuirks(const cxg_nfa& nfa, bool runSkip) {
   } catch (const Refuse& e) {
     throw BuildError{CXG_E_UNSUPPORTED, e.why};
   }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------- alphabet runs
-// Image of the alphabet-run kernel (device/runs.hpp): the anchored leftmost-first automaton T over the kind-refined byte
-// classes, minimised, + the alphabet as ASCII ranges + the shortest match.  False + why when the program is outside the
-// kernel's shape (the caller serves it with the transducer as before).
-bool buildRunsImage(const cxg_nfa& nfa, std::vector<uint8_t>& image, std::string& why) {
-  image.clear();
-  try {
-    bool inAlpha[256];
-    alphabetOf(nfa, inAlpha);
-    cxgdev::RunsHeader h;
-    std::memset(&h, 0, sizeof h);
-    for (int b = 0; b < 256;) {
-      if (!inAlpha[b]) { b++; continue; }
-      int e = b;
-      while (e + 1 < 256 && inAlpha[e + 1]) e++;
-      if (e >= 128) { why = "alphabet reaches beyond ASCII"; return false; }
-      if (h.nr == 4) { why = "alphabet needs more than four ranges"; return false; }
-      h.lo[h.nr] = static_cast<uint8_t>(b); h.hi[h.nr] = static_cast<uint8_t>(e); h.nr++;
-      b = e + 1;
-    }
-    if (h.nr == 0) { why = "empty alphabet"; return false; }
-    const Symbols sy = symbolsOf(nfa);                 // (text anchors: BuildError, caught below)
-    const size_t nsym = sy.reps.size();
-    if (nsym + 1 > cxgdev::kRunsMaxSym) { why = "more than 31 byte symbols"; return false; }
-    bool look = false;
-    for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;
-    const Automaton t = buildLeftmostFirst(nfa, nfa.start_anchored, sy.reps, look, false);
-    const size_t ns = t.next.size();
-    for (int k = 0; k < 4; k++)
-      for (size_t s = 0; s <= nsym; s++)
-        if (t.flag[static_cast<size_t>(t.start[k])][s]) { why = "nullable pattern"; return false; }
-    // Moore partition; states that can never flag again are the dead state
-    std::vector<uint32_t> cls(ns);
-    {
-      std::map<std::vector<uint8_t>, uint32_t> byFlags;
-      for (size_t i = 0; i < ns; i++) cls[i] = t.live[i] ? 1u + byFlags.emplace(t.flag[i], static_cast<uint32_t>(byFlags.size())).first->second : 0u;
-    }
-    for (size_t nclasses = 0;;) {
-      std::map<std::vector<uint32_t>, uint32_t> sig;
-      std::vector<uint32_t> ncls(ns);
-      for (size_t i = 0; i < ns; i++) {
-        if (!t.live[i]) { ncls[i] = 0; continue; }
-        std::vector<uint32_t> k{cls[i]};
-        for (int32_t x : t.next[i]) k.push_back(x < 0 ? 0u : cls[static_cast<size_t>(x)]);
-        ncls[i] = 1u + sig.emplace(std::move(k), static_cast<uint32_t>(sig.size())).first->second;
-      }
-      cls.swap(ncls);
-      if (sig.size() == nclasses) { nclasses = sig.size(); break; }
-      nclasses = sig.size();
-    }
-    uint32_t nstates = 1;
-    for (size_t i = 0; i < ns; i++) nstates = std::max(nstates, cls[i] + 1u);
-    const uint32_t rowBytes = 2u * static_cast<uint32_t>(nsym + 1);
-    if (sizeof h + 256u + nstates * rowBytes + 16u > cxgdev::kRunsMaxImage || nstates * rowBytes > 0xFFFEu) { why = "anchored leftmost-first automaton too large for the run kernel's LDS table"; return false; }
-    std::vector<uint16_t> tab(static_cast<size_t>(nstates) * (nsym + 1), 0);
-    for (size_t i = 0; i < ns; i++) {
-      if (!cls[i]) continue;
-      uint16_t* row = &tab[static_cast<size_t>(cls[i]) * (nsym + 1)];
-      for (size_t s = 0; s <= nsym; s++) {
-        const int32_t x = s < nsym ? t.next[i][s] : -1;
-        const uint32_t tgt = x < 0 ? 0u : cls[static_cast<size_t>(x)];
-        row[s] = static_cast<uint16_t>(tgt * rowBytes | (t.flag[i][s] ? 1u : 0u));
-      }
-    }
-    // the shortest match: breadth-first over the minimised machine
-    {
-      std::vector<int> dist(nstates, -1);
-      std::vector<uint32_t> q;
-      for (int k = 0; k < 4; k++) { const uint32_t s0 = cls[static_cast<size_t>(t.start[k])]; if (s0 && dist[s0] < 0) { dist[s0] = 0; q.push_back(s0); } }
-      int best = -1;
-      for (size_t qi = 0; qi < q.size() && best < 0; qi++) {
-        const uint32_t s0 = q[qi];
-        for (size_t s = 0; s <= nsym; s++) {
-          const uint16_t e = tab[static_cast<size_t>(s0) * (nsym + 1) + s];
-          if (e & 1u) { best = dist[s0]; break; }
-          const uint32_t x = (e & 0xFFFEu) / rowBytes;
-          if (x && dist[x] < 0) { dist[x] = dist[s0] + 1; q.push_back(x); }
-        }
-      }
-      if (best < 1) { why = "no match reachable / nullable"; return false; }
-      h.min_len = static_cast<uint32_t>(best);
-    }
-    h.magic = cxgdev::kRunsMagic;
-    h.nstates = nstates;
-    h.nsym = static_cast<uint32_t>(nsym + 1);
-    for (int k = 0; k < 4; k++) h.start[k] = cls[static_cast<size_t>(t.start[k])] * rowBytes;
-    h.cls_off = sizeof h;
-    h.tab_off = h.cls_off + 256u;
-    h.total_bytes = h.tab_off + nstates * rowBytes;
-    h.total_bytes = (h.total_bytes + 15u) & ~15u;
-    image.assign(h.total_bytes, 0);
-    std::memcpy(image.data(), &h, sizeof h);
-    for (int b = 0; b < 256; b++) {
-      const uint32_t kind = (look && sy.hasLine && b == '\n') ? 2u : (look && sy.hasWordB && isWord(b)) ? 1u : 0u;
-      image[h.cls_off + static_cast<size_t>(b)] = static_cast<uint8_t>(sy.symOf[b] | (kind << 5) | (inAlpha[b] ? 0x80u : 0u));
-    }
-    std::memcpy(image.data() + h.tab_off, tab.data(), tab.size() * sizeof(uint16_t));
-    return true;
-  } catch (const Refuse& e) {
-    why = e.why;
-  } catch (const BuildError& e) {
-    why = e.msg;
-  }
-  image.clear();
-  return false;
 }
 
 }  // namespace cxg

@@ -17,9 +17,4 @@ void refuseLookDfaQuirks(const cxg_nfa& nfa, const cxg_nfa* reverse, bool existe
 // leftmost-first anchored search, history-free, and (runSkip = CXG_FLAG_DIGIT_RUN_SKIP_SAFE) the digit-run skip is sound.
 void refuseLookDigitQuirks(const cxg_nfa& nfa, bool runSkip);
 
-// Image of the alphabet-run kernel (device/runs.hpp, scan_runs_wave.hip) for a NON-NULLABLE program whose FindAll is plain
-// leftmost-first: false + why when the pattern's alphabet is not a union of <= 4 ASCII ranges, its anchored leftmost-first
-// automaton does not fit the kernel's LDS table, or it holds a text anchor.
-bool buildRunsImage(const cxg_nfa& nfa, std::vector<uint8_t>& image, std::string& why);
-
 }  // namespace cxg

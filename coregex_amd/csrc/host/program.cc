@@ -787,23 +787,7 @@ bool isDelimited(const Dfa& d, int& open, int& close, bool& plus) {
   return true;
 }
 
-namespace { void buildProgramFromNfaCore(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags); }
-
 void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
-  buildProgramFromNfaCore(p, nfa, strategy, flags);
-  // The alphabet-run image (lookdfa.cc buildRunsImage) beside the transducer's, for the programs capi.hip would hand to the
-  // transducer kernel: plain leftmost-first FindAll, not nullable, no UseBoth restart span.
-  p->runsBlob.clear();
-  if (!p->supported || p->nullable || p->blob.size() < sizeof(cxgdev::BlobHeader) || p->fsmBlob.empty()) return;
-  const cxgdev::BlobHeader* h = reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data());
-  if (h->kind != cxgdev::kKindDigit && h->kind != cxgdev::kKindBidir && h->kind != cxgdev::kKindFsmOnly) return;
-  if (h->flags & cxgdev::kFlagBothRestart) return;
-  if (reinterpret_cast<const cxgdev::FsmHeader*>(p->fsmBlob.data())->max_len != 0u) return;
-  if (!buildRunsImage(nfa, p->runsBlob, p->runsWhyNot)) p->runsBlob.clear();
-}
-
-namespace {
-void buildProgramFromNfaCore(cxg_program* p, const cxg_nfa& nfa, int strategy, uint32_t flags) {
   p->strategy = strategy;
   p->flags = flags;
   p->ngroups = static_cast<int>(nfa.capture_count);
@@ -1197,7 +1181,6 @@ void buildProgramFromNfaCore(cxg_program* p, const cxg_nfa& nfa, int strategy, u
     p->whyNot = e.msg;
   }
 }
-}  // namespace
 
 namespace {
 

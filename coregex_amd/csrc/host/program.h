@@ -55,12 +55,6 @@ struct cxg_program {
   // served by a bit-parallel / literal / char-class kernel alone or the transducer exceeds its budget (fsmWhyNot).
   std::vector<uint8_t> fsmBlob, subFsmBlob;   // FindAllIndex / Count; spans of FindAllSubmatchIndex
   std::string fsmWhyNot;
-  // Alphabet-run kernel (device/runs.hpp, scan_runs_wave.hip; round 4): in front of the transducer for programs whose alphabet is a
-  // few ASCII ranges (`(?:25[0-5]|…)\.…`).  Empty: not such a program (runsWhyNot).  runsOff: the kernel gave up on this program's
-  // input once (runs too long / too many per tile): later calls go straight to the transducer.
-  std::vector<uint8_t> runsBlob;
-  std::string runsWhyNot;
-  mutable std::atomic<uint8_t> runsOff{0};
   // FindAllSubmatchIndex: spans from a bidirectional DFA image + one-pass capture table (any strategy:
   // the reference sends FindAllSubmatch of DFA/Both/NFA/DigitPrefilter engines to the PikeVM, whose
   // result is plain leftmost-first, meta/findall.go:89-98)
@@ -86,7 +80,6 @@ struct cxg_program {
   void* devCap[16] = {nullptr};
   void* devFsm[16] = {nullptr};
   void* devSubFsm[16] = {nullptr};
-  void* devRuns[16] = {nullptr};
 };
 
 namespace cxg {

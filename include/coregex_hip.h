@@ -123,8 +123,7 @@ enum cxg_kernel {
   CXG_K_FIELDS_WAVE = 13,  /* scan_fields_wave.hip: fields programs such as `\d+\.\d+\.\d+\.\d+` (round 3) */
   CXG_K_TRIO_WAVE = 14,    /* scan_fields_wave.hip k_scan_trio_wave: run a run b run programs such as `(\w+)@(\w+)\.(\w+)` (round 3) */
   CXG_K_FIELDS_PERS = 15,  /* scan_fields_wave.hip k_scan_fields_pers: the fields mathematics on a persistent grid, ordering deferred by a round (round 4) */
-  CXG_K_DELIM_WAVE = 16,   /* scan_delim_wave.hip: `O [^E]+ E` programs such as `\[[^\]]+\]` (round 4) */
-  CXG_K_RUNS_WAVE = 17     /* scan_runs_wave.hip: patterns over a few ASCII ranges, walked inside the runs of those bytes (round 4) */
+  CXG_K_DELIM_WAVE = 16    /* scan_delim_wave.hip: `O [^E]+ E` programs such as `\[[^\]]+\]` (round 4) */
 };
 const char* cxg_kernel_name(int kernel);
 
@@ -167,10 +166,6 @@ int cxg_program_blob(const cxg_program* p, const void** data, size_t* len);
  * FindAllIndex program (submatch == 0) or of the span program of FindAllSubmatchIndex (submatch != 0).
  * CXG_E_UNSUPPORTED when the program has none (served by other kernels alone, or outside the table budget). */
 int cxg_program_fsm_image(const cxg_program* p, int submatch, const void** data, size_t* len);
-/* Image of the alphabet-run kernel (coregex_amd/csrc/device/runs.hpp; the kernel in front of the transducer for patterns over a
-   few ASCII ranges, e.g. the digit-prefilter programs of meta/find_indices.go:1050-1088): CXG_E_UNSUPPORTED + reason when the
-   program has none.  Test infrastructure (the sequential twin walks it); the pointer lives as long as the program. */
-int cxg_program_runs_image(const cxg_program* p, const void** data, size_t* len);
 /* Images used by the FindAllSubmatch path: bidirectional-DFA span program + one-pass capture table. */
 int cxg_program_submatch_blobs(const cxg_program* p, const void** span_blob, size_t* span_len,
                                const void** cap_blob, size_t* cap_len);

@@ -257,20 +257,3 @@ def find_all_delim(open_byte: int, close_byte: int, plus: bool, hay, tile: int =
         if n <= cap:
             return out[:n].reshape(-1, 2).copy()
         cap = int(n)
-
-
-def find_all_runs(image: bytes, hay, tile: int = 3840, max_runs: int = 256, max_rows_run: int = 4):
-    """scan_runs_wave.hip (alphabet runs, device/runs.hpp), emulated; the int reason (< 0) when the kernel would raise its fallback flag."""
-    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
-    L = lib()
-    L.emu_find_all_runs.restype = C.c_int64
-    L.emu_find_all_runs.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int]
-    cap = 1 << 12
-    while True:
-        out = np.empty(cap, dtype=np.int64)
-        n = L.emu_find_all_runs(image, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, tile, max_runs, max_rows_run)
-        if n < 0:
-            return int(n)
-        if n <= cap:
-            return out[:n].reshape(-1, 2).copy()
-        cap = int(n)

@@ -12,7 +12,6 @@
 #include "../../coregex_amd/csrc/device/scan_dfa.h"
 #include "../../coregex_amd/csrc/device/walk.hpp"
 #include "../../coregex_amd/csrc/device/bt.hpp"
-#include "../../coregex_amd/csrc/device/runs.hpp"
 
 using namespace cxgdev;
 
@@ -616,44 +615,4 @@ extern "C" int64_t emu_find_all_delim(int open_byte, int close_byte, int plus, c
   const int64_t nv = static_cast<int64_t>(res.size());
   if (out && nv <= cap_vals) std::memcpy(out, res.data(), nv * sizeof(int64_t));
   return nv;
-}
-
-// ---- scan_runs_wave.hip (alphabet runs, device/runs.hpp): per tile of `tile_bytes` the runs that START in it, at least min_len
-// long, each walked by runs_attempt position by position.  Mirrors the kernel's give-ups: -(16 + 1) a qualifying run longer than
-// kRunsMaxRun, -(16 + 2) more than `max_runs` qualifying runs in a tile, -(16 + 4) more than `max_rows_run` rows in one run.
-extern "C" int64_t emu_find_all_runs(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int tile_bytes, int max_runs, int max_rows_run) {
-  const cxgdev::RunsHeader* h = reinterpret_cast<const cxgdev::RunsHeader*>(img);
-  if (h->magic != cxgdev::kRunsMagic) return -2;
-  const uint8_t* cls = img + h->cls_off;
-  const uint16_t* tab = reinterpret_cast<const uint16_t*>(img + h->tab_off);
-  auto byte = [&](int64_t i) { return hay[i]; };
-  const int64_t n = static_cast<int64_t>(len);
-  int64_t nvals = 0;
-  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
-  for (uint64_t t = 0; t < ntiles; t++) {
-    const int64_t lo = static_cast<int64_t>(t) * tile_bytes, hi = std::min<int64_t>(n, lo + tile_bytes);
-    int nq = 0;
-    for (int64_t s = lo; s < hi; s++) {
-      if (!(cls[hay[s]] & 0x80u) || (s > 0 && (cls[hay[s - 1]] & 0x80u))) continue;      // run starts owned by this tile
-      int64_t e = s;
-      while (e < n && e - s < static_cast<int64_t>(h->min_len) && (cls[hay[e]] & 0x80u)) e++;
-      if (e - s < static_cast<int64_t>(h->min_len)) continue;                               // (the kernel's erosion)
-      if (++nq > max_runs) return -(16 + 2);
-      while (e < n && e - s <= static_cast<int64_t>(cxgdev::kRunsMaxRun) && (cls[hay[e]] & 0x80u)) e++;
-      if (e - s > static_cast<int64_t>(cxgdev::kRunsMaxRun)) return -(16 + 1);
-      int rows = 0;
-      int64_t p = s;
-      while (p < e) {
-        const uint32_t behind = p == 0 ? 3u : (cls[hay[p - 1]] >> 5) & 3u;
-        const int64_t end = cxgdev::runs_attempt(h, cls, tab, byte, p, n, behind);
-        if (end > p) {
-          if (++rows > max_rows_run) return -(16 + 4);
-          if (nvals + 2 <= cap_vals) { out[nvals] = p; out[nvals + 1] = end; }
-          nvals += 2;
-          p = end;
-        } else p++;
-      }
-    }
-  }
-  return nvals;
 }
