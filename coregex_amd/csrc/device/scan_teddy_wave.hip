@@ -119,13 +119,22 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
   }
   s_T[tid] = static_cast<uint32_t>(t_ab[tid]) | (((a.blob + h->info_off)[tid] & kInfoSync) ? 0x1000000u : 0u);
   __syncthreads();
-  if (static_cast<uint32_t>(tid) < nlits) atomicOr(&s_T[t_bytes[t_off[tid] + 2]], 0x10000u << t_bucket[tid]);   // third-byte masks
+  const bool fold = (ax->looks & kTeddyFold) != 0u;                  // case-insensitive set: lower-case literals, a letter matches both cases
+  if (static_cast<uint32_t>(tid) < nlits) {                          // third-byte masks
+    const uint32_t b3 = t_bytes[t_off[tid] + 2];
+    atomicOr(&s_T[b3], 0x10000u << t_bucket[tid]);
+    if (fold && b3 >= 'a' && b3 <= 'z') atomicOr(&s_T[b3 ^ 0x20u], 0x10000u << t_bucket[tid]);
+  }
   if (static_cast<uint32_t>(tid) < nlits && tid < 32) {             // verification compares dwords (below)
     const uint8_t* lb = t_bytes + t_off[tid];
     const uint32_t len = t_lens[tid];
     for (uint32_t k = 0; k < 3; k++) {
       uint32_t L = 0, M = 0;
-      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) { L |= static_cast<uint32_t>(lb[4 * k + b]) << (8 * b); M |= 0xFFu << (8 * b); }
+      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) {
+        const uint32_t c = lb[4 * k + b];
+        L |= c << (8 * b);
+        M |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);     // a folded letter: bit 5 does not count
+      }
       s_lit[tid][k] = L; s_lit[tid][3 + k] = M;
     }
   }
@@ -297,7 +306,8 @@ __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(Sc
                 }
                 const uint8_t* lit = t_bytes + t_off[id];
                 int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
-                while (q < len && wb[c + q] == lit[q]) q++;
+                if (fold) { while (q < len && (wb[c + q] == lit[q] || (lit[q] >= 'a' && lit[q] <= 'z' && (wb[c + q] | 0x20u) == lit[q]))) q++; }
+                else while (q < len && wb[c + q] == lit[q]) q++;
                 if (q == len) mlen = len;
               }
             }

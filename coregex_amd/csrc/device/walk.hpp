@@ -263,11 +263,15 @@ struct TeddyView {
   uint32_t nlits;
 };
 
+constexpr uint32_t kTeddyFold = 1u << 16;   // TeddyAux::looks
+
 struct TeddyAux {           // layout of the blob's aux section (all offsets relative to aux start)
   uint32_t nlits, nbuckets, minlen, maxlen;
   uint32_t ab_off, order_off, lens_off, bucket_off, off_off, bytes_off, bytes_len;
   // Literals between two assertions (`\berror\b`, `(?m)^(GET|POST)`, round 4): looks = pre | post << 8, each 0 (none) or nfa.Look + 1
   // (3 StartLine, 4 EndLine, 5 WordBoundary, 6 NoWordBoundary); an occurrence counts when both hold around it (teddy_look_holds)
+  // bit 16 (kTeddyFold): case-insensitive set — the literals are stored in lower case and a letter matches either case
+  // (`(?i)(error|fail|panic)`); only scan_teddy_wave.hip knows it, like the assertions
   uint32_t looks;
   // kFlagPrefixLiteral images (a UseDFA program behind its required literal prefix): the anchored forward DFA,
   // [dfa_states][256] u8, that turns a prefix occurrence into the match end (0 states: plain literal set)

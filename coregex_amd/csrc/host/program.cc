@@ -12,8 +12,8 @@
 
 namespace cxg {
 
-void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count);
-bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why);
+void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count, bool fold = false);
+bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why, bool fold = false);
 
 namespace {
 
@@ -570,7 +570,7 @@ bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits
   if (cur >= N) return false;
   uint32_t terminal = CXG_NFA_INVALID;
   std::vector<uint8_t> path;
-  size_t visited = 0;
+  size_t visited = 0, nFolded = 0, nPlainLetters = 0;
   bool ok = true;
   std::function<void(uint32_t)> dfs = [&](uint32_t q) {
     if (!ok) return;
@@ -578,13 +578,58 @@ bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits
     if (q >= N || ++visited > 8192 || path.size() > 255) { ok = false; return; }
     const cxg_nfa_state& x = nfa.states[q];
     switch (x.kind) {
-      case CXG_NFA_SPLIT: dfs(x.left); dfs(x.right); return;
+      case CXG_NFA_SPLIT: {
+        // `(?i)e`: a split over the two cases of one letter that join again is ONE folded character, not two alternatives
+        // (`(?i)s`: [Ss] and the two bytes of U+017F beside them — the pair folds, the rest stays an alternative).
+        std::vector<uint32_t> branches, todo{q};
+        while (!todo.empty() && branches.size() <= 128) {             // the split tree under q, in priority order
+          const uint32_t b = skip(todo.back());
+          todo.pop_back();
+          if (b >= N) { ok = false; return; }
+          if (nfa.states[b].kind == CXG_NFA_SPLIT) { todo.push_back(nfa.states[b].right); todo.push_back(nfa.states[b].left); }
+          else branches.push_back(b);
+        }
+        if (branches.size() > 128) { ok = false; return; }
+        std::vector<uint8_t> role(branches.size(), 0);               // 1: upper-case half of a pair (walked with its lower-case half), 2: the lower-case half
+        for (size_t i = 0; i < branches.size(); i++)
+          for (size_t k = 0; k < branches.size() && !role[i]; k++) {
+            const cxg_nfa_state& a = nfa.states[branches[i]];
+            const cxg_nfa_state& b = nfa.states[branches[k]];
+            if (i != k && !role[k] && a.kind == CXG_NFA_BYTE_RANGE && b.kind == CXG_NFA_BYTE_RANGE && a.lo == a.hi && b.lo == b.hi && a.lo >= 'A' && a.lo <= 'Z' &&
+                b.lo == (a.lo | 0x20u) && skip(a.next) == skip(b.next)) { role[i] = 1; role[k] = 2; }
+          }
+        for (size_t i = 0; i < branches.size(); i++) {
+          if (role[i] == 1) continue;
+          if (role[i] == 2) { nFolded++; path.push_back(nfa.states[branches[i]].lo); dfs(nfa.states[branches[i]].next); path.pop_back(); continue; }
+          dfs(branches[i]);
+        }
+        return;
+      }
       case CXG_NFA_BYTE_RANGE:
         if (x.lo != x.hi) { ok = false; return; }
+        if ((x.lo >= 'a' && x.lo <= 'z') || (x.lo >= 'A' && x.lo <= 'Z')) nPlainLetters++;
         path.push_back(x.lo); dfs(x.next); path.pop_back(); return;
       case CXG_NFA_SPARSE:
-        if (x.trans_len != 1 || nfa.trans[x.trans_off].lo != nfa.trans[x.trans_off].hi) { ok = false; return; }
-        path.push_back(nfa.trans[x.trans_off].lo); dfs(nfa.trans[x.trans_off].next); path.pop_back(); return;
+        {                                                             // a small set of bytes (`ju[ln]` under (?i): [LNln]): one alternative per byte, case pairs folded
+          std::vector<std::pair<uint8_t, uint32_t>> alts;
+          for (uint32_t k = 0; k < x.trans_len; k++) {
+            const cxg_nfa_trans& t = nfa.trans[x.trans_off + k];
+            if (t.hi - t.lo > 3 || alts.size() > 16) { ok = false; return; }
+            for (uint32_t b = t.lo; b <= t.hi; b++) alts.emplace_back(static_cast<uint8_t>(b), t.next);
+          }
+          std::vector<uint8_t> role(alts.size(), 0);
+          for (size_t i = 0; i < alts.size(); i++)
+            for (size_t k = 0; k < alts.size() && !role[i]; k++)
+              if (i != k && !role[k] && alts[i].first >= 'A' && alts[i].first <= 'Z' && alts[k].first == (alts[i].first | 0x20u) && skip(alts[i].second) == skip(alts[k].second)) { role[i] = 1; role[k] = 2; }
+          for (size_t i = 0; i < alts.size(); i++) {
+            if (role[i] == 1) continue;
+            const uint8_t c = alts[i].first;
+            if (role[i] == 2) nFolded++;
+            else if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) nPlainLetters++;
+            path.push_back(c); dfs(alts[i].second); path.pop_back();
+          }
+          return;
+        }
       case CXG_NFA_LOOK: case CXG_NFA_MATCH:
         if (terminal == CXG_NFA_INVALID) terminal = q;
         if (terminal != q || path.empty() || lits.size() >= 64) { ok = false; return; }
@@ -598,8 +643,12 @@ bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits
   uint32_t t = terminal;
   if (nfa.states[t].kind == CXG_NFA_LOOK) { if (nfa.states[t].lo < 2) return false; post = nfa.states[t].lo + 1u; t = skip(nfa.states[t].next); }
   if (t >= N || nfa.states[t].kind != CXG_NFA_MATCH) return false;
-  if (pre == 0 && post == 0) return false;
-  looks = pre | (post << 8);
+  // case-insensitive literals (`(?i)(error|fail|panic)`: 600 case variants for the reference, its PikeVM — UseNFA): the literal
+  // kernels compare letters ignoring bit 5 (walk.hpp kTeddyFold).  All letters folded or none — a mixed set stays where it was.
+  const bool fold = nFolded != 0;
+  if (fold && nPlainLetters != 0) return false;
+  if (pre == 0 && post == 0 && !fold) return false;
+  looks = pre | (post << 8) | (fold ? cxgdev::kTeddyFold : 0u);
   return true;
 }
 
@@ -1098,7 +1147,27 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       cxg_nfa rvw = rn.view();
       Dfa rv;
       if (!look) rv = determinize(rvw, rvw.start_anchored, false, kMaxDfaStates);
-      if (!buildFsmImage(*prog, rv, 0u, p->fsmBlob, p->fsmWhyNot, look ? &rvw : nullptr)) { p->fsmBlob.clear(); p->nullable = false; throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
+      // (the determinisation above throws for the few programs past its state budget — with them the literal shape below is not tried)
+      const bool fsmBuilt = buildFsmImage(*prog, rv, 0u, p->fsmBlob, p->fsmWhyNot, look ? &rvw : nullptr);
+      if (!fsmBuilt) p->fsmBlob.clear();
+      // literals between assertions / case-insensitive literals: the literal kernel in front of the transducer (which stays: its
+      // fallback — where the pattern has one: `(?i)\b(error|fail|exception|panic|fatal)\b` has more than 64 symbols x kinds and
+      // runs on the literal kernel alone, CXG_E_INPUT for a haystack that kernel gives up on)
+      const bool noWrapped = getenv("CXG_NO_WRAPPED_LITERALS") != nullptr;   // (read per build: tests/test_gpu_fsm.py keeps these programs on the transducer)
+      std::vector<std::vector<uint8_t>> wl;
+      uint32_t wlooks = 0;
+      if (!p->nullable && !noWrapped && wrappedLiterals(nfa, wl, wlooks)) {
+        cxg_program tmp;
+        buildLiteralImage(&tmp, wl, 1, (wlooks & cxgdev::kTeddyFold) != 0u);
+        if (tmp.supported) {
+          const cxgdev::BlobHeader* th = reinterpret_cast<const cxgdev::BlobHeader*>(tmp.blob.data());
+          reinterpret_cast<cxgdev::TeddyAux*>(tmp.blob.data() + th->aux_off)->looks = wlooks;
+          p->blob.swap(tmp.blob);
+          p->supported = true;
+          return;
+        }
+      }
+      if (!fsmBuilt) { p->nullable = false; throw BuildError{CXG_E_UNSUPPORTED, p->fsmWhyNot}; }
       h.kind = cxgdev::kKindFsmOnly;
       h.info_off = static_cast<uint32_t>(blob.size());
       blob.insert(blob.end(), info, info + 256);
@@ -1106,19 +1175,6 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       std::memcpy(blob.data(), &h, sizeof h);
       p->blob.swap(blob);
       p->supported = true;
-      // literals between assertions: the literal kernel in front of the transducer (which stays: its fallback)
-      const bool noWrapped = getenv("CXG_NO_WRAPPED_LITERALS") != nullptr;   // (read per build: tests/test_gpu_fsm.py keeps these programs on the transducer)
-      std::vector<std::vector<uint8_t>> wl;
-      uint32_t wlooks = 0;
-      if (look && !p->nullable && !noWrapped && wrappedLiterals(nfa, wl, wlooks)) {
-        cxg_program tmp;
-        buildLiteralImage(&tmp, wl, 1);
-        if (tmp.supported) {
-          const cxgdev::BlobHeader* th = reinterpret_cast<const cxgdev::BlobHeader*>(tmp.blob.data());
-          reinterpret_cast<cxgdev::TeddyAux*>(tmp.blob.data() + th->aux_off)->looks = wlooks;
-          p->blob.swap(tmp.blob);
-        }
-      }
       return;
     } else {
       throw BuildError{CXG_E_UNSUPPORTED, std::string("strategy ") + cxg_strategy_name(strategy) + " has no device kernel"};
@@ -1761,7 +1817,7 @@ void buildProgramFromLiterals(cxg_program* p, const std::vector<std::vector<uint
 // min_count 1: a single literal of a UseDFA program (buildProgramFromNfa) searched with the same kernels.
 // Literal tables of the Teddy kernels (walk.hpp TeddyAux + arrays), appended to `aux`; false + why when the set is
 // outside the device subset.
-bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why) {
+bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_count, std::vector<uint8_t>& aux, std::string& why, bool fold) {
   if (lits.size() < min_count || lits.size() > 64) { why = "Teddy takes 2..64 literals"; return false; }
   size_t minlen = SIZE_MAX, maxlen = 0;
   for (auto& l : lits) { minlen = std::min(minlen, l.size()); maxlen = std::max(maxlen, l.size()); }
@@ -1795,6 +1851,10 @@ bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_co
   for (size_t id = 0; id < lits.size(); id++) {
     ab[lits[id][0]] |= static_cast<uint16_t>(1u << bucketOf[id]);
     ab[lits[id][1]] |= static_cast<uint16_t>(0x100u << bucketOf[id]);
+    if (fold) {                                      // folded set (lower-case letters stand for both cases): the other case is a candidate too
+      if (lits[id][0] >= 'a' && lits[id][0] <= 'z') ab[lits[id][0] ^ 0x20u] |= static_cast<uint16_t>(1u << bucketOf[id]);
+      if (lits[id][1] >= 'a' && lits[id][1] <= 'z') ab[lits[id][1] ^ 0x20u] |= static_cast<uint16_t>(0x100u << bucketOf[id]);
+    }
   }
   cxgdev::TeddyAux ax;
   std::memset(&ax, 0, sizeof ax);
@@ -1824,10 +1884,10 @@ bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_co
   return true;
 }
 
-void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count) {
+void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count, bool fold) {
   p->supported = false;
   std::vector<uint8_t> aux;
-  if (!makeLiteralAux(lits, min_count, aux, p->whyNot)) return;
+  if (!makeLiteralAux(lits, min_count, aux, p->whyNot, fold)) return;
   cxgdev::BlobHeader h;
   std::memset(&h, 0, sizeof h);
   h.magic = cxgdev::kBlobMagic;
@@ -1836,7 +1896,7 @@ void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& 
   std::vector<uint8_t> blob(sizeof h, 0);
   h.info_off = static_cast<uint32_t>(blob.size());
   bool inAlpha[256] = {false};
-  for (auto& l : lits) for (uint8_t b : l) inAlpha[b] = true;
+  for (auto& l : lits) for (uint8_t b : l) { inAlpha[b] = true; if (fold && b >= 'a' && b <= 'z') inAlpha[b ^ 0x20u] = true; }
   for (int b = 0; b < 256; b++) blob.push_back(inAlpha[b] ? 0 : cxgdev::kInfoSync);
   h.aux_off = static_cast<uint32_t>(blob.size());
   h.aux_len = static_cast<uint32_t>(aux.size());

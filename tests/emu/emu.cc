@@ -421,7 +421,12 @@ extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* h
                aux + ax->bucket_off, reinterpret_cast<const uint16_t*>(aux + ax->off_off), aux + ax->bytes_off, ax->nlits};
   uint32_t T[256];
   for (int b = 0; b < 256; b++) T[b] = tv.ab[b] | ((info[b] & kInfoSync) ? 0x1000000u : 0u);
-  for (uint32_t id = 0; id < tv.nlits; id++) T[tv.bytes[tv.off[id] + 2]] |= 0x10000u << tv.bucket[id];
+  const bool fold = (ax->looks & kTeddyFold) != 0u;              // case-insensitive set: lower-case literals, a letter matches both cases
+  for (uint32_t id = 0; id < tv.nlits; id++) {
+    const uint32_t b3 = tv.bytes[tv.off[id] + 2];
+    T[b3] |= 0x10000u << tv.bucket[id];
+    if (fold && b3 >= 'a' && b3 <= 'z') T[b3 ^ 0x20u] |= 0x10000u << tv.bucket[id];
+  }
   const int64_t N = tile_bytes + halo_bytes;
   std::vector<int64_t> res;
   const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
@@ -464,10 +469,13 @@ extern "C" int64_t emu_find_all_teddy_wave(const uint8_t* blob, const uint8_t* h
           if (tv.bucket[id] != bk) continue;
           const int64_t ln = tv.lens[id];
           if (c + ln > rend) continue;
-          if (std::memcmp(g + c, tv.bytes + tv.off[id], static_cast<size_t>(ln)) == 0) mlen = ln;
+          const uint8_t* lit = tv.bytes + tv.off[id];
+          int64_t q = 0;
+          while (q < ln && (g[c + q] == lit[q] || (fold && lit[q] >= 'a' && lit[q] <= 'z' && (g[c + q] | 0x20u) == lit[q]))) q++;
+          if (q == ln) mlen = ln;
         }
       }
-      if (mlen && !verify_dfa && ax->looks) {    // literals between assertions: both must hold around the occurrence
+      if (mlen && !verify_dfa && (ax->looks & 0xFFFFu)) {    // literals between assertions: both must hold around the occurrence
         const int pb = (tile_lo + c) > 0 ? g[c - 1] : -1;
         const int nb = c + mlen < rend ? (c + mlen < N ? g[c + mlen] : -2) : -1;
         if (nb == -2) return -(16 + 32);
