@@ -9,7 +9,7 @@
 // first path that reaches Match is the winner, and it ends at e because e is that winner's end.  The haystack is cut at
 // e, as the reference's SearchWithCapturesInSpan does (pikevm.go:1210).  A (state, position) pair that failed once fails
 // again: a visited bitmap bounds the work by states x (e - s + 1).
-// Assertions (LOOK states, lo = nfa.Look 2..5: (?m)^ (?m)$ \b \B; pikevm.go:1646-1674) read the haystack bytes on both sides of
+// Assertions (LOOK states, lo = nfa.Look 0 and 2..5: \A (?m)^ (?m)$ \b \B; pikevm.go:1646-1674) read the haystack bytes on both sides of
 // the position — also in front of s and behind e — inside [hay_lo, hay_hi); outside of it counts as a line break, not a
 // word byte (what the transducer kernel assumes around a shard, fsm.hpp "Look-around").
 // Shared by capi.hip (device) and tests/emu (host twin); plain C++.
@@ -161,7 +161,8 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
         else if (x.lo == 3) ok = right == '\n';                             // EndLine
         else if (x.lo == 4) ok = bt_word_byte(left) != bt_word_byte(right);  // WordBoundary
         else if (x.lo == 5) ok = bt_word_byte(left) == bt_word_byte(right);  // NoWordBoundary
-        else ok = false;                                                    // text anchors: not in the device subset
+        else if (x.lo == 0) ok = !has_left;                                  // StartText (round 4): the first position of the haystack
+        else ok = false;                                                    // EndText: not in the device subset
         if (!ok) break;
         q = x.next;
       } else break;                                                    // FAIL

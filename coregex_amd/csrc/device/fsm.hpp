@@ -88,7 +88,10 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
                                                    // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch.  nk > 1: knd = u8[256] 2 * kind of a byte, then
                                                    // u16[nk] start rows by the kind of the haystack's first byte, then u16[nk * nk] reverse start rows by
                                                    // nk * kind(hay[e-1]) + kind(hay[e]) for a match that ends at e
-  uint32_t outside_byte, pad3[3];                  // what the positions in front of and behind the haystack read as ('\n' with line anchors, else 0)
+  uint32_t outside_byte;                           // what the positions in front of and behind the haystack read as ('\n' with line anchors, else 0)
+  uint32_t rev_text_col;                           // != 0: the pattern holds a text-start anchor (\A, ^): byte offset of the reverse rows' extra column,
+                                                   // columns by the kind of the text's first byte, 1 = "accepting if this position is the start of the text"
+  uint32_t pad3[2];
 };
 
 // Look-around (word boundaries `\b` `\B`, multi-line anchors `(?m)^` `(?m)$`; nfa.Look, nfa/nfa.go:92-117).  An assertion
@@ -110,6 +113,7 @@ struct FsmView {
   const uint8_t* rev;
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
   uint32_t alias_lo, u_lo, top_off, rev_start_off, rev_accept_off;
+  uint32_t rev_text_col;    // FsmHeader::rev_text_col
   uint32_t create_lo, rematch_lo;
   const uint8_t* mem;       // members of the set rows
   uint32_t row_shift;
@@ -448,7 +452,7 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
 // positions are relative to the tile origin and may be negative.
 constexpr int32_t kFsmNoStart = -0x7FFFFFFF - 1;
 template <class Mem>
-CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over, int32_t text_pos = kFsmNoStart) {
   uint32_t s = m.rstart(v, e);
   int32_t st = kFsmNoStart;
   int32_t at = e - 1;
@@ -482,6 +486,10 @@ CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, in
     if (s == 0u) break;
     if (s >= v.rev_accept_off) st = at;
   }
+  // text_pos: where the text starts, relative to `m` (kFsmNoStart: not within reach).  A walk that stepped over the text's first
+  // byte alive stands there: a text-start anchor of the pattern (\A, ^) holds now and nowhere else — the state says whether that
+  // makes the position a match start (host/fsm.cc).
+  if (v.rev_text_col != 0u && text_pos != kFsmNoStart && at == text_pos - 1 && s != 0u && !over && fsm_u16(v.rev, s + v.rev_text_col + v.knd[m.byte(text_pos)]) != 0u) st = text_pos;
   return st;
 }
 

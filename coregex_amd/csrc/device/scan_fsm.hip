@@ -89,7 +89,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.rev = body + (h->rev_off - hs);
   v.ncls2 = 2u * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   v.knd = body + (h->knd_off - hs);
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           // reverse DFA that is still alive there report `over`
           const int32_t bound = q ? static_cast<int32_t>(s_re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
-          const int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over);
+          const int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           // over: the reverse DFA was still alive at the window's first byte and the haystack goes on in front of it
           // (a match longer than the 64 bytes staged there): length 0 = unresolved, finished in the epilogue
           const uint32_t len = (over || s == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - s);
@@ -740,13 +740,14 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           const int64_t lo = prev > 0 ? prev : 0;
           uint32_t sr = v.rev_start_off;
           if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + (v.knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : outside] >> 1)));
-          int64_t st = -1;
-          for (int64_t at = e - 1; at >= lo; at--) {
+          int64_t st = -1, at = e - 1;
+          for (; at >= lo; at--) {
             if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
             sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
             if (sr == 0u) break;
             if (sr >= v.rev_accept_off) st = at;
           }
+          if (LOOK && v.rev_text_col != 0u && at < 0 && sr != 0u && fsm_u16(v.rev, sr + v.rev_text_col + v.knd[a.hay[0]]) != 0u) st = 0;   // text-start anchor (fsm.hpp fsm_match_start)
           if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s = st;
         }
       }

@@ -946,12 +946,11 @@ struct NfaB {
       case Node::Empty: { uint32_t e = eps(); return {e, e}; }
       case Node::Any: return dot(true);            // compileAnyChar compile.go:977-992 (default configuration)
       case Node::AnyNotNL: return dot(false);      // compileAnyCharNotNL compile.go:995-1010
-      case Node::BeginText: case Node::EndText:
-        unsupported("text anchors (\\A \\z, ^ $ without (?m))");
+      case Node::BeginText: case Node::EndText:      // (round 4: \A / ^ inside an unanchored pattern is served, program.cc; \z / $ is refused there)
       case Node::BeginLine: case Node::EndLine:
       case Node::WordB: case Node::NoWordB: {       // compile.go:286-289 addLook; cxg_nfa_state.lo = nfa.Look (nfa/nfa.go:92-117)
         auto s = blank(CXG_NFA_LOOK);
-        s.lo = x.kind == Node::BeginLine ? 2 : x.kind == Node::EndLine ? 3 : x.kind == Node::WordB ? 4 : 5;
+        s.lo = x.kind == Node::BeginText ? 0 : x.kind == Node::EndText ? 1 : x.kind == Node::BeginLine ? 2 : x.kind == Node::EndLine ? 3 : x.kind == Node::WordB ? 4 : 5;
         const uint32_t id = push(s);
         return {id, id};
       }
@@ -1411,7 +1410,7 @@ Plan selectStrategyOf(const Ast& ast, const HostNfa& nfa) {
   // literal engines (hasNonLineAnchors compile.go:686-703), (?m)^ is not: Teddy keeps its complete literals behind a
   // line-start check (prefilter.WrapLineAnchor, compile.go:670-677).  (The multi-line reverse-suffix strategy: below.)
   const bool lineAnchor = sh.has(root, {Node::BeginLine, Node::EndLine});
-  const bool nonLineAnchors = wordB || sh.has(root, {Node::EndLine});
+  const bool nonLineAnchors = wordB || sh.has(root, {Node::EndLine, Node::BeginText, Node::EndText});   // hasNonLineAnchors compile.go:686-703
   p.lineStart = sh.has(root, {Node::BeginLine});
   {
     // Does every match begin at a line start?  (Used for UseTeddy below: the reference wraps the WHOLE literal prefilter

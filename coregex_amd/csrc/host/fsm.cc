@@ -20,7 +20,7 @@ namespace cxg {
 namespace {
 
 constexpr uint32_t kSep = 0xFFFFFFFEu;     // separates the levels of a stack in its key vector
-constexpr uint8_t kLookStartLine = 2, kLookEndLine = 3, kLookWordBoundary = 4, kLookNoWordBoundary = 5;   // nfa.Look (nfa/nfa.go:92-117), carried in cxg_nfa_state.lo
+constexpr uint8_t kLookStartText = 0, kLookEndText = 1, kLookStartLine = 2, kLookEndLine = 3, kLookWordBoundary = 4, kLookNoWordBoundary = 5;   // nfa.Look (nfa/nfa.go:92-117), carried in cxg_nfa_state.lo
 inline int wordKind(int b) { return (b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z') || b == '_' || (b >= 'a' && b <= 'z'); }
 
 struct Stepper {
@@ -33,13 +33,16 @@ struct Stepper {
   // byte, and a line edge); checkLook, nfa/pikevm.go:1646-1674
   int left = 0, right = 0;
   bool word[3] = {false, false, false}, newline[3] = {false, false, false};
+  bool textStart = false;                                          // the position is the start of the text (\A, ^ without (?m)): only the
+                                                                   // search at the haystack's first byte and the reverse walk that reaches it
   explicit Stepper(const cxg_nfa& nfa) : n(nfa), mark(nfa.n_states, 0) {}
   bool lookHolds(uint8_t look) const {
     if (look == kLookWordBoundary) return word[left] != word[right];
     if (look == kLookNoWordBoundary) return word[left] == word[right];
     if (look == kLookStartLine) return newline[left];            // pos == 0 || hay[pos-1] == '\n'
     if (look == kLookEndLine) return newline[right];             // pos == len || hay[pos] == '\n'
-    return false;                                                // text anchors: refused before any closure is taken
+    if (look == kLookStartText) return textStart;
+    return false;                                                // \z / $: refused before any closure is taken
   }
   void closure(std::vector<uint32_t>& out, uint32_t seed) {      // epsilonClosureInto, builder.go:245-293
     stack.clear();
@@ -105,15 +108,20 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
 namespace {
 bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa, const uint32_t rowBudget) {
   image.clear();
-  bool hasWord = false, hasLine = false;
+  bool hasWord = false, hasLine = false, hasText = false;
   for (uint32_t i = 0; i < nfa.n_states; i++)
     if (nfa.states[i].kind == CXG_NFA_LOOK) {
       const uint8_t lk = nfa.states[i].lo;
       if (lk == kLookWordBoundary || lk == kLookNoWordBoundary) hasWord = true;
       else if (lk == kLookStartLine || lk == kLookEndLine) hasLine = true;
-      else { why = "text anchor in NFA (\\A, \\z, ^ and $ without (?m) are not served)"; return false; }
+      else if (lk == kLookStartText) hasText = true;
+      else { why = "end-of-text anchor in NFA (\\z, $ without (?m): not served; \\A and ^ are)"; return false; }
     }
-  const bool hasLook = hasWord || hasLine;
+  // Text start (\A, ^ without (?m); nfa.LookStartText, dfa/lazy/start.go:64-172 StartText): holds at position 0 and nowhere else.
+  // Forward it only changes the state the scan STARTS in (the start rows below are closed with it); positions > 0 are searched
+  // from states closed without it.  Backward it can only make position 0 a match start: every reverse state carries a flag
+  // "accepting if this is the start of the text", read by the walk that arrives at position 0 alive (fsm.hpp fsm_match_start).
+  const bool hasLook = hasWord || hasLine || hasText;
   if (hasLook && !revNfa) { why = "internal: look-around program without its reversed NFA"; return false; }
   // kinds of the byte behind a step (fsm.hpp "Look-around"): what the pattern's assertions tell apart
   const uint32_t nk = (hasWord && hasLine) ? 3u : (hasLook ? 2u : 1u);
@@ -179,7 +187,16 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     return kind | (j << 2) | (conts ? 32u : 0u) | (died << 8);
   };
   uint32_t startOf[3] = {0, 0, 0};                // the search at the haystack's first byte, by the kind of that byte; row 0 = kind 0
-  for (uint32_t k = 0; k < nk; k++) startOf[k] = intern({freshLR[outsideKind][k]});
+  for (uint32_t k = 0; k < nk; k++) {
+    std::vector<uint32_t> first;
+    st.gen++;
+    st.left = outsideKind; st.right = static_cast<int>(k);
+    st.textStart = hasText;
+    st.closure(first, nfa.start_unanchored);
+    st.textStart = false;
+    if (st.matchIndex(first) >= 0) { why = "nullable pattern (empty match at the start of the text)"; return false; }
+    startOf[k] = intern({first});
+  }
   for (uint32_t cur = 0; cur < keys.size() && !tooBig; cur++) {
     // split the key into its levels
     std::vector<std::pair<size_t, size_t>> lv;    // [begin, end) in keys[cur]
@@ -295,6 +312,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   std::vector<std::vector<uint32_t>> rtab;          // [state][ncls] (renumbered)
   uint32_t rStates = rev.nstates, rFirstAccept = rev.firstAccept, rStart = rev.start;
   uint32_t rStart9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<uint8_t> rTextAcc;                   // hasText: per reverse state (renumbered)
   if (hasLook) {
     Stepper rs(*revNfa);
     setKinds(rs);
@@ -340,8 +358,26 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     for (uint32_t i = 0; i < rStates; i++) for (uint32_t c = 0; c < ncls; c++) rtab[i][c] = renum[rnext[order[i]][c]];
     for (uint32_t q = 0; q < nk * nk; q++) { rStart9[q] = renum[s9[q]]; if (rStart9[q] >= rFirstAccept) { why = "nullable pattern (empty matches)"; return false; } }
     rStart = rStart9[0];
+    if (hasText) {
+      // "accepting at the start of the text": the state's set closed once more with the anchor holding, in front of the haystack's
+      // first byte (left = outside), once per kind of that byte (the walk has just stepped over it and looks its kind up).
+      rTextAcc.assign(static_cast<size_t>(rStates) * nk, 0);
+      for (uint32_t i = 0; i < rStates; i++) {
+        const std::vector<uint32_t>& set = rsets[order[i]];
+        for (int r = 0; r < static_cast<int>(nk); r++) {
+          std::vector<uint32_t> closed;
+          rs.gen++;
+          rs.left = outsideKind; rs.right = r;
+          rs.textStart = true;
+          for (uint32_t q : set) rs.closure(closed, q);
+          rs.textStart = false;
+          rTextAcc[static_cast<size_t>(i) * nk + static_cast<size_t>(r)] = rs.matchIndex(closed) >= 0 ? 1 : 0;
+        }
+      }
+    }
   }
-  if (rStates == 0 || static_cast<size_t>(rStates) * ncls * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
+  const uint32_t rcols = ncls + (hasText ? nk : 0u);   // hasText: nk more columns, the text-start flags of the state
+  if (rStates == 0 || static_cast<size_t>(rStates) * rcols * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
   auto offT = [&](uint32_t s) { return s * rowBytes; };
   auto offA = [&](uint32_t a) { return (nT + a) * rowBytes; };
   auto offU = [&](uint32_t u) { return (nT + nA + u) * rowBytes; };
@@ -397,11 +433,13 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   put(mem.data(), mem.size() * 2, h.mem_off);
   // reverse DFA, class-compressed, entries = byte offset of the target row; the classes come from the same NFA ranges,
   // so a class never straddles a reverse transition
-  const uint32_t revRow = ncls * 2;
-  std::vector<uint16_t> rv(static_cast<size_t>(rStates) * ncls, 0);
+  const uint32_t revRow = rcols * 2;
+  std::vector<uint16_t> rv(static_cast<size_t>(rStates) * rcols, 0);
   if (hasLook) {
-    for (uint32_t s = 0; s < rStates; s++)
-      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rtab[s][c] * revRow);
+    for (uint32_t s = 0; s < rStates; s++) {
+      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * rcols + c] = static_cast<uint16_t>(rtab[s][c] * revRow);
+      if (hasText) for (uint32_t r = 0; r < nk; r++) rv[static_cast<size_t>(s) * rcols + ncls + r] = rTextAcc[static_cast<size_t>(s) * nk + r];
+    }
   } else {
     for (uint32_t s = 0; s < rev.nstates; s++)
       for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rev.table[static_cast<size_t>(s) * 256 + reps[c]] * revRow);
@@ -411,6 +449,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   }
   put(rv.data(), rv.size() * 2, h.rev_off);
   h.rev_states = rStates; h.rev_start_off = rStart * revRow; h.rev_accept_off = rFirstAccept * revRow; h.rev_row_bytes = revRow;
+  h.rev_text_col = hasText ? ncls * 2u : 0u;
   if (hasLook) {
     auto put16 = [&](uint32_t v16) { kndBlock.push_back(static_cast<uint8_t>(v16 & 0xFF)); kndBlock.push_back(static_cast<uint8_t>(v16 >> 8)); };
     for (uint32_t k = 0; k < nk; k++) put16(offT(startOf[k]));

@@ -1233,6 +1233,25 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       if (!p->supported) { p->blob.swap(keep); p->supported = true; p->whyNot.clear(); }
       p->ngroups = static_cast<int>(nfa.capture_count);
     }
+    // `(?i)(select|insert|update|delete)`: a UseDFA / UseBoth program that is a case-insensitive alternation of literals — the folded
+    // literal set (wrappedLiterals, walk.hpp kTeddyFold) instead of literal prefixes + anchored DFA walks; the transducer stays its
+    // fallback.  (UseBoth: no literal is longer than the restart span, so the long-match condition cannot arise.)
+    if ((strategy == CXG_USE_DFA || strategy == CXG_USE_BOTH) && !hasLook && !p->nullable && getenv("CXG_NO_WRAPPED_LITERALS") == nullptr &&
+        reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data())->kind == cxgdev::kKindBidir) {
+      std::vector<std::vector<uint8_t>> wl;
+      uint32_t wlooks = 0;
+      if (wrappedLiterals(nfa, wl, wlooks) && wlooks == cxgdev::kTeddyFold) {
+        size_t longest = 0;
+        for (auto& l : wl) longest = std::max(longest, l.size());
+        cxg_program tmp;
+        if (longest <= cxgdev::kBothRestartSpan) buildLiteralImage(&tmp, wl, 1, true);
+        if (tmp.supported) {
+          const cxgdev::BlobHeader* th = reinterpret_cast<const cxgdev::BlobHeader*>(tmp.blob.data());
+          reinterpret_cast<cxgdev::TeddyAux*>(tmp.blob.data() + th->aux_off)->looks = wlooks;
+          p->blob.swap(tmp.blob);
+        }
+      }
+    }
   } catch (const BuildError& e) {
     p->whyNot = e.msg;
   }

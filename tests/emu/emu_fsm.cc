@@ -39,7 +39,7 @@ FsmView view_of(const uint8_t* img) {
   v.rev = img + h->rev_off;
   v.ncls2 = 2 * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   v.knd = img + h->knd_off;
@@ -119,12 +119,12 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
         const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;      // bytes exist in front of the window
         const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
         const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
-        int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over);
+        int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
         if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
           // the kernel's epilogue: the walk again, bounded by the previous row's end, bytes from HBM / L2
           st[3]++;
           over = 0;
-          s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), -static_cast<int32_t>(tile_lo), over);
+          s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), -static_cast<int32_t>(tile_lo), over, -static_cast<int32_t>(tile_lo));
         }
         if (over) return -16 - 8;
         if (s == kFsmNoStart) return -2;

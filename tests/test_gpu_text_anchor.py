@@ -1,0 +1,76 @@
+"""Text-start anchors on the device: `k_scan_fsm` started in the text-start state, its reverse walks accepting position 0
+by the per-state flag — in the window, and in the epilogue for a first match that is longer than the window's reach."""
+import random
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+from routing import routed
+from test_text_anchor_cpu import TEXT
+
+pytestmark = pytest.mark.gpu
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("pat", TEXT)
+def test_rows_and_captures(pat, oracle):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    rng = random.Random(len(pat) * 17)
+    toks = [b"foo", b"bar", b"12", b",", b" ", b"error", b"abc", b"x7", b"ab", b"GET", b"POST", b"k=1", b"\n", b":", b"z", b"_", b"pad pad pad pad "]
+    hays = [b"bar", b"foo", b"bar foo bar", b"12,12 12", b" error", b"zabc", b"x7", b"xab", b"GET /a POST", b"k=1 k=2", b"\nbar", b"a" * 300 + b",b"]
+    for n in (3839, 3841, 61441, 400000, 2_000_000):
+        for lead in (b"", b"bar", b"12", b"abc", b"x9", b"GET", b"k=2", b"ab", b"error"):
+            hays.append(lead + b"".join(rng.choice(toks) for _ in range(n // 5)))
+    for hay in hays:
+        a = _u8(hay)
+        exp = o.find_all_index(a)
+        try:
+            got = rx.find_all_index(a)
+        except cx.UnsupportedInput:
+            continue                                                    # (a dense random haystack past the transducer's budgets)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), hay[:40], got[:4].tolist(), exp[:4].tolist())
+        assert rx.count(a) == len(exp) and np.array_equal(rx.find_all_index(a, 2), exp[:2])
+        if rx.submatch_supported and rx.num_groups > 1 and len(hay) < 500000:
+            es = o.find_all_submatch_index(a)
+            gs = rx.find_all_submatch_index(a)
+            assert gs.shape == es.shape and np.array_equal(gs, es), (pat, len(hay), hay[:40], "submatch")
+
+
+def test_long_first_match(oracle):
+    """The match that starts at the text start and runs on: found while it ends within the transducer's reach behind its tile (190 bytes);
+    past that the call is refused for the haystack (CXG_E_INPUT: a look-around program has no table-walking kernel behind the transducer)."""
+    for pat in (r"(?:^|,)[a-c]+", r"(?:^|x)[a-c]+"):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        for n in (100, 3000, 3810, 3900, 3990, 9000, 70000):
+            for tail in (b"", b",ab ,c", b" x,a"):
+                a = _u8(b"abc" * (n // 3) + tail)
+                exp = o.find_all_index(a)
+                assert exp[0].tolist() == [0, 3 * (n // 3)]
+                try:
+                    assert np.array_equal(rx.find_all_index(a), exp), (pat, n, tail)
+                except cx.UnsupportedInput:
+                    assert n > 3840 + 150, (pat, n, tail)
+                b = _u8(b"z" + bytes(a))                               # the same behind another byte: the anchor does not hold
+                try:
+                    assert np.array_equal(rx.find_all_index(b), o.find_all_index(b)), (pat, n, tail, "shifted")
+                except cx.UnsupportedInput:
+                    assert n > 3840 + 150, (pat, n, tail)
+
+
+def test_each_call_is_one_text(oracle):
+    """`base` moves the rows, not the text: the anchor holds at the first byte of every call's haystack."""
+    import torch
+    pat = r"(?:^|,)\d+"
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    hay = _u8(b"12 34,56 78\n")
+    exp = o.find_all_index(hay)
+    d = torch.from_numpy(hay.copy()).cuda()
+    out = torch.empty((8, 2), dtype=torch.int64, device="cuda")
+    t = cx.Timing()
+    n = rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), 8, base=1000, timing=t)
+    assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp + 1000)
+    routed(t.kernels == [10], t.kernels)

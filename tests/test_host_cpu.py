@@ -972,7 +972,8 @@ def test_case_insensitive_programs_through_the_twins(oracle):
         for hay in (generate_test_input()[:60000], words, b"", b"ERROR"):
             exp = o.find_all_index(hay).tolist()
             a = np.frombuffer(hay, dtype=np.uint8)
-            if kind != 5:
+            folded = kind == 4 and struct.unpack_from("<I", blob, struct.unpack_from("<I", blob, 56)[0] + 44)[0] != 0   # TeddyAux::looks (round 4: folded sets)
+            if kind != 5 and not folded:                              # (the table kernel knows neither assertions nor folded sets: capi.hip never sends them there)
                 assert emu.find_all(blob, hay).tolist() == exp, (pat, "lanes", len(hay))
             if rx.fsm_image() is not None:
                 got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32)

@@ -1,0 +1,59 @@
+"""Text-start anchors inside unanchored patterns (`(^|,)\\d+`, `foo|\\Abar`: SURVEY a9, round 4).  The reference's lazy DFA has a
+start state per kind of the byte in front of the search, Text among them (dfa/lazy/start.go:64-172); the transducer starts the scan
+in a state closed with the anchor holding and its reverse walk accepts position 0 by a per-state flag (host/fsm.cc, fsm.hpp
+fsm_match_start).  CPU tier: front-end strategy, build-time proofs and the transducer's sequential twin against the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import coregex_amd as cx
+import emu
+
+TEXT = [r"foo|^bar", r"\Afoo|bar", r"(?:^|,)\d+", r"(^|\s)error", r"(?:^|[^a-z])abc", r"^\d+|x\d+", r"(^|x)[a-c]+", r"(^|\s)(GET|POST)", r"(^|\s)(\w+)=(\d+)",
+        r"\bfoo|^bar", r"(?:^|,)[a-c]+", r"(?m)(?:\A|^x)\d+", r"(?:^|:)\w+\b", r"(?:^|x)*a"]
+REFUSED = [r"foo$|x", r"x\z|foo", r"(?:^|,)\d+$", r"^foo", r"\Afoo", r"foo|^"]
+
+
+def _twin(rx, a):
+    img = rx.fsm_image()
+    got = emu.find_all_fsm(img, a, 3840, 32)
+    if isinstance(got, int) and got in (-18, -32):
+        got = emu.find_all_fsm(img, a, 3840, 32, dense=1)
+    return got
+
+
+@pytest.mark.parametrize("pat", TEXT)
+def test_twin_equals_oracle(pat, oracle):
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.strategy == o.strategy and rx.supported and rx.fsm_image() is not None, (pat, rx.strategy, o.strategy, rx.why_unsupported)
+    rng = random.Random(len(pat) * 13)
+    hays = [b"", b"bar", b"foo", b"barbar", b"bar foo bar", b"12,12 12", b"error error", b" error", b"abc abc", b"zabc", b"7x7", b"x7", b"abab", b"xab",
+            b"GET /a POST", b"k=1 k=2", b"a=b=3", b"\nbar", b"12\n12", b"x1\nx2", b"w:w w", b"a" * 300 + b",b", b"c" * 5000 + b",a"]
+    toks = [b"foo", b"bar", b"12", b",", b" ", b"error", b"abc", b"x7", b"ab", b"GET", b"POST", b"k=1", b"\n", b":", b"z", b"_"]
+    for n in (50, 500, 3839, 3841, 9000):
+        for lead in (b"", b"bar", b"12", b"abc", b"x9", b" ", b"GET", b"k=2", b"ab"):
+            hays.append(lead + b"".join(rng.choice(toks) for _ in range(n // 3)))
+    for hay in hays:
+        a = np.frombuffer(hay, dtype=np.uint8)
+        exp = o.find_all_index(a)
+        got = _twin(rx, a)
+        if isinstance(got, int):
+            continue                                                    # a tile past the twin's row buffers (the kernel's denser modes)
+        assert np.array_equal(got, exp), (pat, hay[:60], got[:4].tolist(), exp[:4].tolist())
+        if rx.submatch_supported and rx.num_groups > 1 and len(hay) < 6000:
+            es = o.find_all_submatch_index(a)
+            oc = rx.offset_captures
+            if oc is not None:
+                for k, (src, d) in enumerate(oc):
+                    assert np.array_equal(es[:, k], es[:, 1 if src else 0] + d), (pat, k)
+            else:
+                gs = emu.captures_bt(rx.submatch_blobs()[1], a, es[:, :2], es.shape[1])
+                assert np.array_equal(gs, es), (pat, hay[:60], gs[:3].tolist(), es[:3].tolist())
+
+
+@pytest.mark.parametrize("pat", REFUSED)
+def test_end_of_text_and_anchored_patterns_stay_refused(pat, oracle):
+    rx = cx.compile(pat)
+    assert not rx.supported, pat
+    assert rx.strategy == oracle.Regex(pat).strategy, pat
