@@ -22,6 +22,10 @@ WIDE = bool(os.environ.get("FUZZ_WIDE"))      # `.` and classes past U+007F in e
 WIDE_ATOMS = [".", ".", ".*", ".+", ".?", r"[^x]", r'[^"]', r"\S", r"\S+", r"\D", r"\W", r"[^a-c]+", r"[^\n]*", "(.)", r"(\S+)", r'"[^"]*"', "é", "[aé]", r"[^:]*:", ".+?", r"\D+?", "x.y", "(?s:.)"]
 FOLD = bool(os.environ.get("FUZZ_FOLD"))      # a case-insensitive literal in every pattern (literal sets of case variants; never run on a device in round 3)
 FOLD_ATOMS = ["(?i:error)", "(?i:warn)", "(?i:k)", "(?i:s1)", "(?i:ok)", "(?i:get)", "(?i:ab|xy)", "(?i:(abc))", "(?i:exception)", "(?i:a)b", "(?i:xyz)+", "(?i:[a-c])", "(?i:[x-z]+)", "(?i:a|b)c"]
+TEXT = bool(os.environ.get("FUZZ_TEXT"))      # a text-start anchor (\A, ^ without (?m)) in every pattern (round 4); the haystacks get leads that match at position 0
+TEXT_ATOMS = ["^", "^", r"\A", "(?:^|,)", r"(^|\s)", "(?:^|x)", "(?:a|^b)", "(?:^a|b)", r"(?:^|:)"]
+if TEXT:
+    atoms = atoms[:36] + TEXT_ATOMS * 4 + [",", " ", r"\b", r"\w+", "abc", r"\d+"]
 if WIDE:
     atoms = atoms + WIDE_ATOMS * 3
 if FOLD:
@@ -40,6 +44,8 @@ if FOLD:
     toks += [b" ", b":", b"1", b"\n", "\u212a".encode(), "\u017f".encode(), b"-"]
     hays += [b"".join(toks[int(i)] for i in rng.integers(0, len(toks), size=n)) for n in (40, 4000, 60000)]
     hays = [np.frombuffer(bytes(h), dtype=np.uint8) if not isinstance(h, np.ndarray) else h for h in hays]
+if TEXT:
+    hays = [h for h in hays] + [np.concatenate([np.frombuffer(lead, dtype=np.uint8), h]) for lead in (b"abc", b"12", b"xyz,", b"a", b"b:") for h in (hays[2], hays[5], hays[7])]
 if os.environ.get("FUZZ_FEW"):
     # few-symbol haystacks of several groups (120 KiB each): the sets of possible entry states stay unresolved for long
     # stretches, so the transducer kernel's member maps, its serial chain and the tile / group hand-off do the work
@@ -61,6 +67,8 @@ while len(seen) < npat:
             continue
         pat = "(?m)" + pat
     if FOLD and "(?i" not in pat:
+        continue
+    if TEXT and not any(t in pat for t in ("^", "\\A")):
         continue
     if WIDE and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")):
         continue
