@@ -1604,7 +1604,7 @@ Plan selectStrategyOf(const Ast& ast, const HostNfa& nfa) {
   {  // selectPrefilter (prefilter/prefilter.go:261-297) over the prefix literals: one literal, or 2+ literals of >= 3 bytes each
     size_t minLen = ~size_t(0);
     for (auto& l : p.prefixes) minLen = std::min(minLen, l.bytes.size());
-    if (!p.prefixes.empty() && minLen >= 1 && (p.prefixes.size() == 1 || minLen >= 3)) p.flags |= CXG_FLAG_HAS_PREFILTER;
+    if (!p.prefixes.empty() && (p.prefixes.size() == 1 || minLen >= 3)) p.flags |= CXG_FLAG_HAS_PREFILTER;   // one literal of any length (an empty needle is found at once: the PikeVM runs from `at`)
   }
   return p;
 }

@@ -732,7 +732,7 @@ std::unique_ptr<Engine> compileEngine(const std::string& pattern) {
   if (!e->prefixes.empty()) {
     size_t minLen = ~size_t(0);
     for (auto& l : e->prefixes.lits) minLen = std::min(minLen, l.bytes.size());
-    hasPrefilter = minLen >= 1 && (e->prefixes.lits.size() == 1 || minLen >= 3);
+    hasPrefilter = e->prefixes.lits.size() == 1 || minLen >= 3;   // (one literal of ANY length: memchr / memmem — an empty needle is found at once, prefilter.go:270-283)
   }
   auto prefilterFind = [lits = e->prefixes.lits](Bytes h, int64_t n, int64_t pos) -> int64_t {
     for (int64_t i = pos; i < n; i++)

@@ -74,3 +74,17 @@ def test_each_call_is_one_text(oracle):
     n = rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), 8, base=1000, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp + 1000)
     routed(t.kernels == [10], t.kernels)
+
+
+def test_reference_pairs_on_the_device(oracle):
+    """tests/golden "text_anchor_compat" (edge_cases_test.go:262-290,320; spans by Python re) through the device."""
+    import json, os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    served = 0
+    for c in vec["text_anchor_compat"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        if not rx.supported:
+            continue
+        served += 1
+        assert rx.find_all_index(_u8(c["input"].encode())).tolist() == c["want"], c
+    assert served >= 5

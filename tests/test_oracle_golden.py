@@ -101,6 +101,15 @@ def test_lookaround_compat(oracle):
         assert got == c["want"], c
 
 
+def test_text_anchor_compat(oracle):
+    """^ / $ without (?m) inside alternations: the reference's own differential pairs (edge_cases_test.go:262-290), spans by Python re
+    (gen_text_anchor_expected.py).  The empty-match rows follow Go's FindAll rule (no empty match at the end of the previous match)."""
+    for c in VEC["text_anchor_compat"]["cases"] + VEC["text_anchor_compat_oracle_only"]["cases"]:
+        got = oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist()
+        want = [w for k, w in enumerate(c["want"]) if not (w[0] == w[1] and k and c["want"][k - 1][1] == w[0])]   # meta/findall.go:251-257
+        assert got == want, (c, got)
+
+
 def test_literal_extraction(oracle):
     """literal.Extractor (prefixes, suffixes, inner literals) against the tables of literal/extractor_test.go."""
     for c in VEC["literal_extraction"]["cases"]:

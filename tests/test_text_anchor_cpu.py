@@ -57,3 +57,22 @@ def test_end_of_text_and_anchored_patterns_stay_refused(pat, oracle):
     rx = cx.compile(pat)
     assert not rx.supported, pat
     assert rx.strategy == oracle.Regex(pat).strategy, pat
+
+
+def test_reference_pairs_on_the_twin(oracle):
+    """tests/golden "text_anchor_compat": the reference's own differential pairs with a text-start anchor inside an alternation
+    (edge_cases_test.go:262-290,320), expected spans by Python re; front-end, proofs and transducer twin."""
+    import json, os
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    served = 0
+    for c in vec["text_anchor_compat"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        assert rx.strategy == oracle.Regex(c["pattern"]).strategy, c
+        if not rx.supported:
+            continue
+        served += 1
+        got = _twin(rx, np.frombuffer(c["input"].encode(), dtype=np.uint8))
+        assert not isinstance(got, int) and got.tolist() == c["want"], (c, got)
+    assert served >= 5
+    for c in vec["text_anchor_compat_oracle_only"]["cases"]:
+        assert not cx.compile(c["pattern"]).supported, c
