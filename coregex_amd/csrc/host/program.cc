@@ -582,7 +582,9 @@ bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits
         // `(?i)e`: a split over the two cases of one letter that join again is ONE folded character, not two alternatives
         // (`(?i)s`: [Ss] and the two bytes of U+017F beside them — the pair folds, the rest stays an alternative).
         std::vector<uint32_t> branches, todo{q};
+        size_t steps = 0;
         while (!todo.empty() && branches.size() <= 128) {             // the split tree under q, in priority order
+          if (++steps > 1024) { ok = false; return; }                // (a cycle of splits — `(?:a*)*` — is no literal tree: found by the sanitizer run)
           const uint32_t b = skip(todo.back());
           todo.pop_back();
           if (b >= N) { ok = false; return; }

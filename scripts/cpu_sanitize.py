@@ -19,7 +19,7 @@ def main(n=3000, seed=1):
         elif isinstance(x, list):
             for v in x: walk(v)
     walk(vec)
-    atoms = F.ATOMS + F.LOOK_ATOMS + L.ATOMS * 2 + F.WIDE_ATOMS * 2 + F.FOLD_ATOMS * 2 + ["[\\x{100}-\\x{7FF}]", "[\\x{800}-\\x{FFFF}]", "[^\\x00-\\x7F]", "(?i:exception)", "(?i:kkkkkk)", "^", "$", "\\z", "\\A"] + ["(", ")", "[", "]", "{2,", "}", "|", "*", "+", "?", "\\", "(?i)", "(?m)", "(?s)", ".", "[^a]", r"\x41", r"\pL", "{1000}", "(?:", "(?P<n>a)", "[a-", "\\Q.\\E", "a{,3}"]
+    atoms = F.ATOMS + F.LOOK_ATOMS + L.ATOMS * 2 + F.WIDE_ATOMS * 2 + F.FOLD_ATOMS * 2 + ["[\\x{100}-\\x{7FF}]", "[\\x{800}-\\x{FFFF}]", "[^\\x00-\\x7F]", "(?i:exception)", "(?i:kkkkkk)", "^", "$", "\\z", "\\A", "(?i)(error|fail|panic)", "(?i:(?:jan|jun|jul))", "(?:^|,)", "(^|\\s)", "(?:a*)*"] + ["(", ")", "[", "]", "{2,", "}", "|", "*", "+", "?", "\\", "(?i)", "(?m)", "(?s)", ".", "[^a]", r"\x41", r"\pL", "{1000}", "(?:", "(?P<n>a)", "[a-", "\\Q.\\E", "a{,3}"]
     while len(pats) < n:
         pats.add("".join(rng.choice(atoms) for _ in range(rng.randint(1, 6))))
     data = "\n".join(p for p in pats if "\n" not in p).encode()
