@@ -1,8 +1,8 @@
-# Last device call of round 4: smoke(), the whole GPU tier, config-2 evidence and the default bench line on the tree that is left behind.
+# Last device call of round 4: device fuzz (general, look-around), smoke(), the whole GPU tier and the default bench line on the tree that is left behind.
+# (CFGS=2 scripts/gpu_r4_evidence.sh + the 64 GiB line ran in the previous call of this script's first version: profiles/r04_final_cfg2_*.)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONPATH=$GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
+timeout 100 python scripts/gpu_fuzz.py 93 300 > gpurun_out/r04_gpu_fuzz_general_final.txt 2>&1; tail -1 gpurun_out/r04_gpu_fuzz_general_final.txt | cut -c1-300
+FUZZ_LOOK=1 timeout 100 python scripts/gpu_fuzz.py 94 200 > gpurun_out/r04_gpu_fuzz_look_final.txt 2>&1; tail -1 gpurun_out/r04_gpu_fuzz_look_final.txt | cut -c1-300
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 800 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/r04_pytest_gpu.log 2>&1; echo pytest=$?; tail -14 gpurun_out/r04_pytest_gpu.log | cut -c1-300
-timeout 200 python bench.py --steps 20 --warmup 3 > gpurun_out/r04_bench_final.json 2> gpurun_out/r04_bench_final.err; echo bench=$?; cut -c1-600 gpurun_out/r04_bench_final.json
-{ timeout 150 python scripts/time_patterns.py '(^|\s)error' '(?:^|,)\d+' '(^|\s)(GET|POST)' 'foo|^bar' '(?i)(select|insert|update|delete)' '(?i)(error|fail|exception|panic|fatal)' 2>&1 | grep -v amdgpu.ids | tail -6 | sed 's/  */ /g'
-} > gpurun_out/r04_time_final_new_programs.txt 2>&1; cat gpurun_out/r04_time_final_new_programs.txt | cut -c1-250
-CFGS=2 timeout 420 bash $R/scripts/gpu_r4_evidence.sh 2>&1 | tail -6
+timeout 600 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/r04_pytest_gpu.log 2>&1; echo pytest=$?; tail -9 gpurun_out/r04_pytest_gpu.log | cut -c1-300
+timeout 150 python bench.py --steps 20 --warmup 3 > gpurun_out/r04_bench_final.json 2> gpurun_out/r04_bench_final.err; echo bench=$?; cut -c1-420 gpurun_out/r04_bench_final.json
