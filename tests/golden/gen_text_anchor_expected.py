@@ -3,7 +3,8 @@
 expected spans computed by Python `re` on bytes — the reference's tests assert equality with Go's regexp; `^` without (?m) is the start of
 the text in both, and `$` without (?m) is the end of the text in Go while Python's also matches in front of a final newline: none of these
 inputs holds one.  Writes the groups "text_anchor_compat" (text-start anchors, non-nullable: served by the device since round 4) and
-"text_anchor_compat_oracle_only" (end-of-text anchors and nullable rows: the device refuses them) into reference_vectors.json.
+"text_anchor_compat_oracle_only" (end-of-text anchors and nullable rows: the device refuses them) into reference_vectors.json, and
+"case_folding_compat" (stdlib_compat_test.go:1361-1367, the rows that test asserts).
 
     python tests/golden/gen_text_anchor_expected.py
 """
@@ -20,6 +21,11 @@ OTHER = [  # edge_cases_test.go:273-290 (end-of-text anchors; `ab?|$` is nullabl
 ]
 
 
+FOLD = [  # stdlib_compat_test.go:1361-1367 TestStdlibCompat_CaseFolding (the three rows it asserts; `(?i)hello` and `(?i)abc` are skipped there)
+    (r"(?i)[a-z]+", "ABC def GHI"), (r"(?i)a|b|c", "AbC"), (r"(?i)\w+", "HELLO World"),
+]
+
+
 def rows(pairs):
     return [{"pattern": p, "input": s, "want": [[m.start(), m.end()] for m in re.finditer(p.encode(), s.encode())]} for p, s in pairs]
 
@@ -30,8 +36,9 @@ def main():
     src = "edge_cases_test.go:262-290,320, nfa/coverage_final_test.go:71 (compareWithStdlib pairs); expected spans by Python re on bytes (tests/golden/gen_text_anchor_expected.py)"
     v["text_anchor_compat"] = {"source": src, "cases": rows(START)}
     v["text_anchor_compat_oracle_only"] = {"source": src, "cases": rows(OTHER)}
+    v["case_folding_compat"] = {"source": "stdlib_compat_test.go:1361-1367 (FindAllString equal to Go regexp); expected spans by Python re on bytes", "cases": rows(FOLD)}
     json.dump(v, open(path, "w"), indent=1)
-    print(len(START), "+", len(OTHER), "rows")
+    print(len(START), "+", len(OTHER), "+", len(FOLD), "rows")
 
 
 if __name__ == "__main__":

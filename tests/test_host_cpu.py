@@ -1027,3 +1027,20 @@ def test_bounded_backtracker_programs_through_the_twins(oracle):
         if rx.supported:
             got = emu.find_all_charclass_wave(rx.blob(), corpus) if struct.unpack_from("<I", rx.blob(), 4)[0] == 3 else emu.find_all(rx.blob(), corpus)
             assert len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name
+
+
+def test_case_folding_golden_rows(oracle):
+    """tests/golden "case_folding_compat" (stdlib_compat_test.go:1361-1367): strategy of the front-end == the oracle's; the served programs
+    give the golden spans on the kernels' sequential twins."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    for c in vec["case_folding_compat"]["cases"]:
+        rx, o = cx.compile(c["pattern"]), oracle.Regex(c["pattern"])
+        assert rx.strategy == o.strategy, c
+        if not rx.supported:
+            continue
+        hay = c["input"].encode()
+        got = emu.find_all(rx.blob(), hay) if rx.strategy != "UseCharClassSearcher" else emu.find_all_charclass_wave(rx.blob(), hay)
+        if rx.nullable and not isinstance(got, int):
+            got = emu.merge_empty_matches(got, len(hay))
+        assert not isinstance(got, int) and got.tolist() == c["want"], (c, got)

@@ -110,6 +110,13 @@ def test_text_anchor_compat(oracle):
         assert got == want, (c, got)
 
 
+def test_case_folding_compat(oracle):
+    """(?i) rows of stdlib_compat_test.go:1361-1367 (the three the reference asserts), spans by Python re; the product's host path and
+    twins see the same rows in tests/test_host_cpu.py::test_case_folding_golden_rows."""
+    for c in VEC["case_folding_compat"]["cases"]:
+        assert oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist() == c["want"], c
+
+
 def test_literal_extraction(oracle):
     """literal.Extractor (prefixes, suffixes, inner literals) against the tables of literal/extractor_test.go."""
     for c in VEC["literal_extraction"]["cases"]:
