@@ -4,7 +4,7 @@ expected spans computed by Python `re` on bytes — the reference's tests assert
 the text in both, and `$` without (?m) is the end of the text in Go while Python's also matches in front of a final newline: none of these
 inputs holds one.  Writes the groups "text_anchor_compat" (text-start anchors, non-nullable: served by the device since round 4) and
 "text_anchor_compat_oracle_only" (end-of-text anchors and nullable rows: the device refuses them) into reference_vectors.json, and
-"case_folding_compat" (stdlib_compat_test.go:1361-1367, the rows that test asserts).
+"real_world_compat" (edge_cases_test.go:370-400).
 
     python tests/golden/gen_text_anchor_expected.py
 """
@@ -21,8 +21,10 @@ OTHER = [  # edge_cases_test.go:273-290 (end-of-text anchors; `ab?|$` is nullabl
 ]
 
 
-FOLD = [  # stdlib_compat_test.go:1361-1367 TestStdlibCompat_CaseFolding (the three rows it asserts; `(?i)hello` and `(?i)abc` are skipped there)
-    (r"(?i)[a-z]+", "ABC def GHI"), (r"(?i)a|b|c", "AbC"), (r"(?i)\w+", "HELLO World"),
+REAL = [  # edge_cases_test.go:370-400 TestRealWorldEdgeCases (log-level is in gen_lookaround_expected.py)
+    (r"\d{4}-\d{2}-\d{2}", "2025-12-07 10:30:00"), (r"[a-zA-Z0-9._%+-]+@[a-zA-Z0-9.-]+\.[a-zA-Z]{2,}", "test@example.com"), (r"https?://", "https://example.com"),
+    (r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", "192.168.1.1"), (r"\.(txt|log|json)$", "file.json"), (r"^\s+|\s+$", "  hello world  "), (r"\s+", "hello   world"),
+    (r'"[^"]*"', 'say "hello" to "world"'), (r"v?\d+\.\d+\.\d+", "v1.2.3"),
 ]
 
 
@@ -36,9 +38,10 @@ def main():
     src = "edge_cases_test.go:262-290,320, nfa/coverage_final_test.go:71 (compareWithStdlib pairs); expected spans by Python re on bytes (tests/golden/gen_text_anchor_expected.py)"
     v["text_anchor_compat"] = {"source": src, "cases": rows(START)}
     v["text_anchor_compat_oracle_only"] = {"source": src, "cases": rows(OTHER)}
-    v["case_folding_compat"] = {"source": "stdlib_compat_test.go:1361-1367 (FindAllString equal to Go regexp); expected spans by Python re on bytes", "cases": rows(FOLD)}
+    v.pop("case_folding_compat", None)               # (the rows of stdlib_compat_test.go:1361-1367 live in "case_folding_find_all_string" since round 3)
+    v["real_world_compat"] = {"source": "edge_cases_test.go:370-400 TestRealWorldEdgeCases (compareWithStdlib pairs); expected spans by Python re on bytes", "cases": rows(REAL)}
     json.dump(v, open(path, "w"), indent=1)
-    print(len(START), "+", len(OTHER), "+", len(FOLD), "rows")
+    print(len(START), "+", len(OTHER), "+", len(REAL), "rows")
 
 
 if __name__ == "__main__":

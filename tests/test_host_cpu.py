@@ -1029,18 +1029,27 @@ def test_bounded_backtracker_programs_through_the_twins(oracle):
             assert len(got) == gold[name]["count"] and "%016x" % span_hash(got) == gold[name]["hash"], name
 
 
-def test_case_folding_golden_rows(oracle):
-    """tests/golden "case_folding_compat" (stdlib_compat_test.go:1361-1367): strategy of the front-end == the oracle's; the served programs
-    give the golden spans on the kernels' sequential twins."""
+def test_golden_find_all_rows_through_the_twins(oracle):
+    """Every FindAll-shaped group of tests/golden/reference_vectors.json that came from the reference's differential tests — anchors inside
+    alternations, look-around, case folding, the real-world patterns of edge_cases_test.go:370-400: the front-end names the oracle's
+    strategy, and what it serves gives the golden spans on the sequential twin of the kernel its first launch would run (tests/twins.py)."""
     import json
+    from twins import rows_on_twin
     vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
-    for c in vec["case_folding_compat"]["cases"]:
-        rx, o = cx.compile(c["pattern"]), oracle.Regex(c["pattern"])
-        assert rx.strategy == o.strategy, c
-        if not rx.supported:
-            continue
-        hay = c["input"].encode()
-        got = emu.find_all(rx.blob(), hay) if rx.strategy != "UseCharClassSearcher" else emu.find_all_charclass_wave(rx.blob(), hay)
-        if rx.nullable and not isinstance(got, int):
-            got = emu.merge_empty_matches(got, len(hay))
-        assert not isinstance(got, int) and got.tolist() == c["want"], (c, got)
+    served = 0
+    for group in ("real_world_compat", "text_anchor_compat", "text_anchor_compat_oracle_only", "lookaround_compat", "lookaround_compat_more", "case_folding_find_all_string"):
+        for c in vec[group]["cases"]:
+            rx, o = cx.compile(c["pattern"]), oracle.Regex(c["pattern"])
+            assert rx.strategy == o.strategy, (group, c)
+            if not rx.supported:
+                continue
+            served += 1
+            hay = c["input"].encode()
+            got = rows_on_twin(rx, hay)
+            assert not isinstance(got, int), (group, c, got)
+            want = c["want"] if not c["want"] or isinstance(c["want"][0], list) else None
+            if want is None:                                          # (FindAllString rows: the matched strings)
+                assert [hay[s:e].decode() for s, e in got.tolist()] == c["want"], (group, c)
+            else:
+                assert got.tolist() == want, (group, c, got.tolist())
+    assert served >= 35

@@ -110,10 +110,9 @@ def test_text_anchor_compat(oracle):
         assert got == want, (c, got)
 
 
-def test_case_folding_compat(oracle):
-    """(?i) rows of stdlib_compat_test.go:1361-1367 (the three the reference asserts), spans by Python re; the product's host path and
-    twins see the same rows in tests/test_host_cpu.py::test_case_folding_golden_rows."""
-    for c in VEC["case_folding_compat"]["cases"]:
+def test_real_world_compat(oracle):
+    """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
+    for c in VEC["real_world_compat"]["cases"]:
         assert oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist() == c["want"], c
 
 
