@@ -1053,3 +1053,35 @@ def test_golden_find_all_rows_through_the_twins(oracle):
             else:
                 assert got.tolist() == want, (group, c, got.tolist())
     assert served >= 35
+
+
+def test_stdlib_find_tests_through_the_front_end_and_the_twins(oracle):
+    """tests/golden "stdlib_find_tests" (the reference's copy of Go's find_test table): the front-end names the oracle's strategy for every
+    row; the rows it serves give the table's spans on the twin of their first kernel, and the table's capture rows on the capture twins."""
+    import json
+    from twins import rows_on_twin
+    blk = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["stdlib_find_tests"]
+    served = caps = 0
+    for c in blk["cases"]:
+        hay = bytes.fromhex(c["input_hex"])
+        try:
+            rx = cx.compile(c["pattern"])
+        except cx.CoregexError:
+            continue                                                  # (a Unicode class the front-end does not parse: refused, never mis-served)
+        assert rx.strategy == oracle.Regex(c["pattern"]).strategy, c
+        if rx.supported:
+            served += 1
+            got = rows_on_twin(rx, hay)
+            assert not isinstance(got, int) and got.tolist() == [w[:2] for w in c["want"]], (c, got)
+        if rx.num_groups > 1 and rx.submatch_supported and c["pattern"] not in blk["submatch_not_asserted"]:
+            want = np.array(c["want"], dtype=np.int64).reshape(-1, 2 * rx.num_groups)
+            oc = rx.offset_captures
+            if oc is not None:
+                for k, (src, d) in enumerate(oc):
+                    assert np.array_equal(want[:, k], want[:, 1 if src else 0] + d), (c, k)
+            else:
+                sb, cb = rx.submatch_blobs()[:2]
+                got = emu.find_all_submatch(sb, cb, hay, want.shape[1]) if len(want) else want
+                assert np.array_equal(got, want), (c, got.tolist())
+            caps += 1
+    assert served >= 25 and caps >= 3, (served, caps)

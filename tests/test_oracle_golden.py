@@ -110,6 +110,19 @@ def test_text_anchor_compat(oracle):
         assert got == want, (c, got)
 
 
+def test_stdlib_find_tests(oracle):
+    """The reference's copy of Go's find_test table (stdlib_compat_test.go:79-219): FindAllIndex on all 73 rows, FindAllSubmatchIndex on the
+    rows whose pattern is not in the reference's own skip list (patternsWithSubmatchDiffs, :530-544) — the numbers are the table's."""
+    blk = VEC["stdlib_find_tests"]
+    assert len(blk["cases"]) >= 70
+    for c in blk["cases"]:
+        hay = bytes.fromhex(c["input_hex"])
+        rx = oracle.Regex(c["pattern"])
+        assert rx.find_all_index(hay).tolist() == [w[:2] for w in c["want"]], c
+        if c["pattern"] not in blk["submatch_not_asserted"]:
+            assert oracle.Regex(c["pattern"]).find_all_submatch_index(hay).tolist() == c["want"], c
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:

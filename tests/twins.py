@@ -30,6 +30,8 @@ def rows_on_twin(rx, hay):
         got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32)
         if isinstance(got, int) and got in (-18, -32):
             got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32, dense=1)
+        if isinstance(got, int):                                     # denser still (`.`: a match per byte): the table-walking kernel, the ladder's last rung
+            got = emu.find_all(blob, a)
     else:
         got = emu.find_all(blob, a)
     if got is None:
