@@ -123,6 +123,18 @@ def test_stdlib_find_tests(oracle):
             assert oracle.Regex(c["pattern"]).find_all_submatch_index(hay).tolist() == c["want"], c
 
 
+def test_edge_case_pairs(oracle):
+    """The reference's differential edge-case tables (empty alternations, FindAll iteration over nullable and non-greedy patterns, {0} groups,
+    doubled word boundaries, anchors in FindAll): FindAllIndex on every row; the capture rows of TestCaptureGroupZeroQuantifier."""
+    cases = VEC["edge_case_pairs"]["cases"]
+    assert len(cases) >= 70
+    for c in cases:
+        hay = c["input"].encode()
+        assert oracle.Regex(c["pattern"]).find_all_index(hay).tolist() == [w[:2] for w in c["want"]], c
+        if c["table"] == "TestCaptureGroupZeroQuantifier":
+            assert oracle.Regex(c["pattern"]).find_all_submatch_index(hay).tolist() == c["want"], c
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
