@@ -1038,7 +1038,7 @@ def test_golden_find_all_rows_through_the_twins(oracle):
     vec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
     served = 0
     for group in ("real_world_compat", "text_anchor_compat", "text_anchor_compat_oracle_only", "lookaround_compat", "lookaround_compat_more", "case_folding_find_all_string",
-                  "edge_case_pairs"):
+                  "edge_case_pairs", "findall_string_kat"):
         for c in vec[group]["cases"]:
             rx, o = cx.compile(c["pattern"]), oracle.Regex(c["pattern"])
             assert rx.strategy == o.strategy, (group, c)

@@ -135,6 +135,13 @@ def test_edge_case_pairs(oracle):
             assert oracle.Regex(c["pattern"]).find_all_submatch_index(hay).tolist() == c["want"], c
 
 
+def test_findall_string_kat(oracle):
+    """FindAllString rows the reference's tests spell out (regex_test.go:180-185, word_boundary_test.go:273-276)."""
+    for c in VEC["findall_string_kat"]["cases"]:
+        hay = c["input"].encode()
+        assert [hay[s:e].decode() for s, e in oracle.Regex(c["pattern"]).find_all_index(hay).tolist()] == c["want"], c
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
