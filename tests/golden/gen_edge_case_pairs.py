@@ -11,7 +11,7 @@ import json, os, re, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from gen_stdlib_find_tests import go_string
+from gen_stdlib_find_tests import go_string, strip_comments
 
 TABLES = [("/root/reference/edge_cases_test.go", "func TestEmptyMatchPatterns"), ("/root/reference/edge_cases_test.go", "func TestFindAllIterationSemantics"),
           ("/root/reference/edge_cases_test.go", "func TestCaptureGroupZeroQuantifier"), ("/root/reference/edge_cases_test.go", "func TestWordBoundaryCornerCases"),
@@ -56,7 +56,7 @@ def main():
         text = open(path, encoding="utf-8").read()
         body = text[text.index(func):]
         body = body[body.index("}{") + 2:body.index("\n\t}\n")]
-        body = re.sub(r"//[^\n]*", "", body)
+        body = strip_comments(body)
         for m in re.finditer(r"\{\s*" + lit + r"\s*,\s*" + lit + r"\s*\}", body):
             pat, inp = go_string(m.group(1)), go_string(m.group(2))
             if b"\\B" in pat and inp == b"":

@@ -32,11 +32,32 @@ def go_string(tok):
     return bytes(out)
 
 
+def strip_comments(body):
+    """Go line comments removed — outside string literals only (`https?://` is a pattern, not a comment)."""
+    out, i = [], 0
+    while i < len(body):
+        c = body[i]
+        if c == "`":
+            j = body.index("`", i + 1)
+            out.append(body[i:j + 1]); i = j + 1
+        elif c == '"':
+            j = i + 1
+            while body[j] != '"':
+                j += 2 if body[j] == "\\" else 1
+            out.append(body[i:j + 1]); i = j + 1
+        elif body.startswith("//", i):
+            j = body.find("\n", i)
+            i = len(body) if j < 0 else j
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
 def main():
     text = open(SRC, encoding="utf-8").read()
     body = text[text.index("var findTests = []FindTest{"):]
     body = body[body.index("{") + 1:body.index("\n}\n")]
-    body = re.sub(r"//[^\n]*", "", body)                              # comments (the KNOWN DIFFERENCE rows are commented out in the table)
+    body = strip_comments(body)                                       # (the KNOWN DIFFERENCE rows are commented out in the table)
     lit = r'(`[^`]*`|"(?:[^"\\]|\\.)*")'
     rows = []
     for m in re.finditer(r"\{\s*" + lit + r"\s*,\s*" + lit + r"\s*,\s*(nil|build\(([^)]*)\))\s*,?\s*\}", body, re.S):

@@ -1086,3 +1086,23 @@ def test_stdlib_find_tests_through_the_front_end_and_the_twins(oracle):
                 assert np.array_equal(got, want), (c, got.tolist())
             caps += 1
     assert served >= 25 and caps >= 3, (served, caps)
+
+
+def test_fuzz_seed_matrix_through_the_front_end_and_the_twins(oracle):
+    """tests/golden "fuzz_seed_matrix" (the seed corpus of the reference's FuzzFindAllStdlib, 56 patterns x 27 inputs): the front-end names the
+    oracle's strategy for every pattern, and every pattern it serves gives the matrix's rows on the twin of its first kernel for all 27 inputs."""
+    import json
+    from twins import rows_on_twin
+    blk = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["fuzz_seed_matrix"]
+    served = rows = 0
+    for pi, pat in enumerate(blk["patterns"]):
+        rx = cx.compile(pat)
+        assert rx.strategy == oracle.Regex(pat).strategy, pat
+        if not rx.supported:
+            continue
+        served += 1
+        for ii, inp in enumerate(blk["inputs"]):
+            got = rows_on_twin(rx, inp.encode())
+            assert not isinstance(got, int) and got.tolist() == blk["want"][pi][ii], (pat, inp, got if isinstance(got, int) else got.tolist())
+            rows += 1
+    assert served >= 35 and rows >= 900, (served, rows)

@@ -142,6 +142,18 @@ def test_findall_string_kat(oracle):
         assert [hay[s:e].decode() for s, e in oracle.Regex(c["pattern"]).find_all_index(hay).tolist()] == c["want"], c
 
 
+def test_fuzz_seed_matrix(oracle):
+    """The seed corpus of the reference's differential fuzz test (fuzz_stdlib_test.go:31-138, FuzzFindAllStdlib): 56 ASCII patterns x 27 ASCII
+    inputs, FindAllIndex on all 1 512 pairs (nullable, non-greedy, anchored and class patterns among them); ONE engine per pattern over all
+    inputs, as a compiled Regexp is used."""
+    blk = VEC["fuzz_seed_matrix"]
+    assert len(blk["patterns"]) * len(blk["inputs"]) >= 1500
+    for pi, pat in enumerate(blk["patterns"]):
+        rx = oracle.Regex(pat)
+        for ii, inp in enumerate(blk["inputs"]):
+            assert rx.find_all_index(inp.encode()).tolist() == blk["want"][pi][ii], (pat, inp)
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
