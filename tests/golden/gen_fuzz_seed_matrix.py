@@ -49,7 +49,23 @@ def main():
         "source": "fuzz_stdlib_test.go:31-138 seedPatterns x seedInputs (seeds of FuzzFindAllStdlib, :306-363: FindAllStringIndex == Go regexp); ASCII rows; expected spans by Go's "
                   "FindAll loop over Python re (tests/golden/gen_fuzz_seed_matrix.py)",
         "patterns": [p.decode() for p in pats], "inputs": [s.decode() for s in inps], "want": want}
-    json.dump(v, open(path, "w"), indent=None, separators=(",", ":")) if False else json.dump(v, open(path, "w"), indent=1)
+    # FuzzFindSubmatchStdlib (:369-440): its capture patterns x the same inputs, FindSubmatchIndex == Go regexp outside hasRepeatedCaptureGroupDifference (:198-209)
+    body = text[text.index("capturePatterns := []string{"):]
+    body = strip_comments(body[body.index("{") + 1:body.index("\n\t}\n")])
+    cpats = [go_string(t) for t in re.findall(r'(`[^`]*`|"(?:[^"\\]|\\.)*")', body)]
+    rep = text[text.index("repeatedCapturePatterns := map[string]bool{"):]
+    rep = [go_string(t) for t in re.findall(r"(`[^`]*`)\s*:\s*true", rep[:rep.index("\n\t}\n")])]
+    cpats = [p for p in cpats if p not in rep and p.isascii()]
+    first = [[(go_find_all(py_pattern(p), s) or [[]])[0] for s in inps] for p in cpats]
+    # FindSubmatchIndex is the single-match API; the FindAll family is this repository's path, and the reference itself lists `(.*)` under
+    # "known difference: empty match behavior" for FindAllSubmatchIndex (stdlib_compat_test.go:530-544): rows whose match is empty are left out (null)
+    first = [[None if (r and r[0] == r[1]) else r for r in row] for row in first]
+    v["fuzz_seed_submatch_first"] = {
+        "source": "fuzz_stdlib_test.go:369-440 FuzzFindSubmatchStdlib: capturePatterns (outside hasRepeatedCaptureGroupDifference) x seedInputs, FindSubmatchIndex == Go regexp; "
+                  "expected row ([]: no match; null: an empty match, not transcribed) by Python re (tests/golden/gen_fuzz_seed_matrix.py)",
+        "patterns": [p.decode() for p in cpats], "inputs": [s.decode() for s in inps], "want": first}
+    json.dump(v, open(path, "w"), indent=1)
+    print(len(cpats), "capture patterns x", len(inps), "inputs")
     print(len(pats), "patterns x", len(inps), "inputs =", len(pats) * len(inps), "rows")
 
 

@@ -1106,3 +1106,33 @@ def test_fuzz_seed_matrix_through_the_front_end_and_the_twins(oracle):
             assert not isinstance(got, int) and got.tolist() == blk["want"][pi][ii], (pat, inp, got if isinstance(got, int) else got.tolist())
             rows += 1
     assert served >= 35 and rows >= 900, (served, rows)
+
+
+def test_fuzz_seed_capture_rows_through_the_capture_twins(oracle):
+    """tests/golden "fuzz_seed_submatch_first" (capture seeds of the reference's FuzzFindSubmatchStdlib): for the patterns whose captures the
+    device serves, the first row of the capture twin (one-pass table / backtracking pass / offsets) is the golden row."""
+    import json
+    blk = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["fuzz_seed_submatch_first"]
+    served = rows = 0
+    for pi, pat in enumerate(blk["patterns"]):
+        rx, o = cx.compile(pat), oracle.Regex(pat)
+        assert rx.strategy == o.strategy, pat
+        if not rx.submatch_supported or rx.nullable:
+            continue
+        served += 1
+        w = 2 * rx.num_groups
+        oc = rx.offset_captures
+        sb, cb = rx.submatch_blobs()[:2]
+        for ii, inp in enumerate(blk["inputs"]):
+            want = blk["want"][pi][ii]
+            if want is None:
+                continue
+            hay = inp.encode()
+            if oc is not None:
+                if want:
+                    assert all(want[k] == want[1 if src else 0] + d for k, (src, d) in enumerate(oc)), (pat, inp)
+            else:
+                got = emu.find_all_submatch(sb, cb, hay, w)
+                assert (got[0].tolist() if len(got) else []) == want, (pat, inp, got[:1].tolist())
+            rows += 1
+    assert served >= 8 and rows >= 200, (served, rows)

@@ -154,6 +154,23 @@ def test_fuzz_seed_matrix(oracle):
             assert rx.find_all_index(inp.encode()).tolist() == blk["want"][pi][ii], (pat, inp)
 
 
+def test_fuzz_seed_submatch_first(oracle):
+    """The capture seeds of the reference's FuzzFindSubmatchStdlib (fuzz_stdlib_test.go:369-440): the first row of FindAllSubmatchIndex for 13
+    patterns x 27 inputs (rows with an empty match are not transcribed: the reference lists them as known differences of the FindAll family)."""
+    blk = VEC["fuzz_seed_submatch_first"]
+    n = 0
+    for pi, pat in enumerate(blk["patterns"]):
+        rx = oracle.Regex(pat)
+        for ii, inp in enumerate(blk["inputs"]):
+            want = blk["want"][pi][ii]
+            if want is None:
+                continue
+            rows = rx.find_all_submatch_index(inp.encode()).tolist()
+            assert (rows[0] if rows else []) == want, (pat, inp)
+            n += 1
+    assert n >= 330
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
