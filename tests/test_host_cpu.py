@@ -1136,3 +1136,20 @@ def test_fuzz_seed_capture_rows_through_the_capture_twins(oracle):
                 assert (got[0].tolist() if len(got) else []) == want, (pat, inp, got[:1].tolist())
             rows += 1
     assert served >= 8 and rows >= 200, (served, rows)
+
+
+def test_find_indices_all_strategies_rows_served(oracle):
+    """tests/golden "find_indices_all_strategies": the front-end names the oracle's strategy for each row, and the rows it serves give the
+    table's first match on the twins."""
+    import json
+    from twins import rows_on_twin
+    served = 0
+    for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))["find_indices_all_strategies"]["cases"]:
+        rx = cx.compile(c["pattern"])
+        assert rx.strategy == oracle.Regex(c["pattern"]).strategy, c
+        if not rx.supported:
+            continue
+        served += 1
+        got = rows_on_twin(rx, c["input"].encode())
+        assert not isinstance(got, int) and (got[0].tolist() if len(got) else None) == c["want"], (c, got)
+    assert served >= 12

@@ -171,6 +171,16 @@ def test_fuzz_seed_submatch_first(oracle):
     assert n >= 330
 
 
+def test_find_indices_all_strategies(oracle):
+    """meta/find_indices_extended_test.go:11-101: one first-match case per engine strategy (reverse suffix / suffix set / inner / anchored, char
+    class, bounded backtracker, composite, digit prefilter, Teddy, anchored literal, start-anchored, empty pattern, NFA), answers from the table."""
+    cases = VEC["find_indices_all_strategies"]["cases"]
+    assert len(cases) >= 30
+    for c in cases:
+        rows = oracle.Regex(c["pattern"]).find_all_index(c["input"].encode()).tolist()
+        assert (rows[0] if rows else None) == c["want"], c
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
