@@ -181,6 +181,16 @@ def test_find_indices_all_strategies(oracle):
         assert (rows[0] if rows else None) == c["want"], c
 
 
+def test_count_edge_cases_and_submatch_counts(oracle):
+    """meta/findall_coverage_test.go:134-170 (Count with a limit; limit 0 counts nothing, a negative one everything) and :56-90 (number of
+    FindAllSubmatch rows): the numbers written in the tables."""
+    for c in VEC["count_edge_cases"]["cases"]:
+        assert oracle.Regex(c["pattern"]).count(c["input"].encode(), c["limit"]) == c["want"], c
+        assert len(oracle.Regex(c["pattern"]).find_all_index(c["input"].encode(), c["limit"])) == c["want"], c
+    for c in VEC["find_all_submatch_count"]["cases"]:
+        assert len(oracle.Regex(c["pattern"]).find_all_submatch_index(c["input"].encode())) == c["want"], c
+
+
 def test_real_world_compat(oracle):
     """edge_cases_test.go:370-400 TestRealWorldEdgeCases (dates, URLs, addresses, quoted strings, whitespace, versions), spans by Python re."""
     for c in VEC["real_world_compat"]["cases"]:
