@@ -6,7 +6,10 @@ FindAll path (see the headers of oracle/*.hpp for the file:line map).  Only
 import this module; the product package ``coregex_amd`` never does.
 
 Parity status: pinned against the reference's own known-answer vectors transcribed
-under ``tests/golden/`` (tests/test_oracle_golden.py) and against the differential
+under ``tests/golden/`` (tests/test_oracle_golden.py) — since round 4 also the reference's
+copy of Go's find_test table (73 rows with their FindAllSubmatchIndex answers), the seed
+matrix of its differential fuzz test (56 patterns x 27 inputs), its edge-case tables
+(101 pairs) and its per-strategy first-match table — and against the differential
 corpus recipe of meta/stdlib_compat_test.go:146-199.  The reference (Go) cannot be
 built in this image (no Go toolchain), so there is no ``oracle/_ref``.
 """
