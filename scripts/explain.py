@@ -59,7 +59,9 @@ def explain(pat):
         out["transducer_image"] = len(img) if img is not None else 0
     if rx.num_groups > 1:
         out["captures"] = rx.submatch_supported
-        if rx.submatch_supported:
+        if rx.submatch_supported and rx.offset_captures is not None:     # round 4: slots at fixed distances from the span's ends
+            out["capture_path"] = first_kernel(rx) + " / offsets of the span (k_caps_offsets)"
+        elif rx.submatch_supported:
             cb = rx.submatch_blobs()[1]
             caps = "in the span kernel" if rx.chain_captures() is not None else "backtracking pass per row" if cb[:4] == b"TBXC" else "one-pass table"
             out["capture_path"] = first_kernel(rx, True) + " / " + caps
