@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--pattern", default=None, help="override the configuration's pattern (ad-hoc timing; no cpu_baseline)")
     ap.add_argument("--synth-config", type=int, default=None)
+    ap.add_argument("--no-north-star", action="store_true",
+                    help="default run (config 2, 1 GiB, one GPU) only: skip the `north_star` object — the same FindAllIndex over 64 GiB resident on this "
+                         "one GPU (BASELINE.json north_star's size), 10 timed steps, every row checked against the oracle")
+    ap.add_argument("--north-star-gib", type=float, default=64.0)
     ap.add_argument("--u32-rows", action="store_true",
                     help="rows through cxg_find_all_device_u32 (two uint32 relative to the shard, 8 bytes per match) instead of the int64 ABI; "
                          "the algorithmic bytes of the roofline follow the layout.  Char-class and fields programs only (configs 4 and 2)")
@@ -183,7 +187,7 @@ class DeviceWorkload:
             "read_only_GBps": round(nbytes / (k_ms * 1e-3) / 1e9, 2),
         }
         rank, world = self.rank, self.world
-        under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        under_profiler = _under_profiler()
         if rank == 0 and world == 1 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
             # HBM traffic of the dominant kernel, measured NOW: two child runs of this very workload under rocprofv3, one PMC
             # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.
@@ -282,10 +286,52 @@ def main(argv=None, make_workload=DeviceWorkload, script=None):
                        per_rank_rows=per_rank_rows, corpus_checksum="%016x" % corpus_checksum),
     }
     wl.finish(result, k_ms)
+    if (make_workload is DeviceWorkload and world == 1 and args.config == 2 and args.pattern is None and args.total_gib == 0 and args.gib_per_gpu == 1.0
+            and not args.u32_rows and not args.no_north_star and not os.environ.get("CXG_DEBUG") and not _under_profiler()):
+        del wl
+        result["north_star"] = _north_star(args)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _under_profiler():
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def _north_star(args):
+    """The size BASELINE.json's north_star is stated on, on ONE GPU, inside the default run: FindAllIndex of the IP
+    regex over --north-star-gib (64) GiB of synthlog-v1 config 2 resident in HBM, int64 rows written, 10 timed steps bracketed like the
+    main line, its own roofline object (HIP-event kernel time of the same launches), and count + order-sensitive checksum of ALL rows
+    against the oracle on all host cores (after the timed region).  A device with less free HBM than the corpus + rows reports why."""
+    import numpy as np
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    need = int(args.north_star_gib * (1 << 30) * 1.25) + (4 << 30)
+    if free < need:
+        return {"skipped": f"{free >> 30} GiB of HBM free, {need >> 30} GiB needed for {args.north_star_gib:g} GiB of corpus + rows"}
+    ns = argparse.Namespace(**vars(args))
+    ns.total_gib, ns.steps, ns.warmup, ns.settle, ns.check_all_rows, ns.no_pmc, ns.no_cpu_baseline = args.north_star_gib, 10, 2, 3, True, True, True
+    wl = DeviceWorkload(ns, 0, 0, 1)
+    wl.setup()
+    for _ in range(ns.settle + ns.warmup):
+        wl.step(False)
+    wl.sync()
+    t0 = time.perf_counter()
+    kernel_ms = [wl.step(True) for _ in range(ns.steps)]
+    wl.sync()
+    elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean(kernel_ms))
+    _, part = wl.rows_and_checksum(0)
+    out = {
+        "metric": wl.metric(), "value": round(wl.nbytes / (elapsed / ns.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": ns.steps, "warmup": ns.warmup,
+        "ms_per_step": round(elapsed * 1e3 / ns.steps, 4), "dtype": "u8", "data": wl.data,
+        "config": dict(wl.describe(), matches_total=wl.nmatch, corpus_checksum="%016x" % part),
+    }
+    wl.finish(out, k_ms)                                              # roofline (no PMC passes at this size) + all_rows_check
+    out["all_rows_check"] = out.pop("cpu_baseline")["all_rows_check"]
+    return out
 
 
 def _check_all_rows(pattern, synth, seed, first_page, npages, out, nmatch, width, base):
@@ -443,7 +489,7 @@ def _pmc_traffic_live(args, kernel):
     if not os.path.exists(exe):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "3", "--warmup", "1", "--settle", "2",
-             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc"]
+             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc", "--no-north-star"]
     if args.pattern is not None:
         child += ["--pattern", args.pattern]
     if args.synth_config is not None:

@@ -63,23 +63,34 @@ namespace {
 constexpr int kFPre = 64;                                  // window bytes in front of the tile
 constexpr int kFWin = kWaveTile + kWaveHalo;               // 4096
 constexpr int kFRows = 64 * kTilesPerWave;                                // rows buffered per wave and group
-constexpr unsigned long long kFOwn = 0x1FFFFFFFFFFFFFFEull;   // lanes 1..60 own their words
+constexpr unsigned long long kFOwn = 0x1FFFFFFFFFFFFFFEull;   // lanes 1..60 own their words (64 window bytes in front of the tile)
+// The persistent kernel's window: 128 bytes in front of the tile, lanes 2..61 own, 128 bytes behind — every window starts and
+// ends on a 128-byte line (tiles are 30 lines), and inside a unit the words 0..3 of a tile ARE the words 60..63 of the tile
+// in front of it: they are carried over in LDS instead of being fetched again (round 5; round 4 read 33 lines per 30-line tile).
+constexpr int kFPrePers = 128;
+constexpr unsigned long long kFOwnPers = 0x3FFFFFFFFFFFFFFCull;
 
-// 0x80 in every byte of x that IS in the class.
+// 0x80 in every byte of x that IS in the class.  t = x & 0x7F7F7F7F is shared by the classes of a dword; (t ^ c) + k is one
+// v_xad_u32, the final ~(u | x) & 0x80808080 one v_bitop3_b32: two instructions per class and dword behind the shared AND.
+__device__ __forceinline__ uint32_t xad(uint32_t t, uint32_t c, uint32_t k) {   // (t ^ c) + k; c uniform (the one scalar operand), k in a register
+  uint32_t r;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(c), "v"(k));
+  return r;
+}
 template <int KIND>
-__device__ __forceinline__ uint32_t incls4(uint32_t x, uint32_t lo4, uint32_t hi4) {   // lo4 / hi4: bounds splat over the bytes (hi4 = 0x7F - hi)
-  if (KIND == kClsDigit) return ~((((x ^ 0x30303030u) & 0x7F7F7F7Fu) + 0x76767676u) | x) & 0x80808080u;
-  if (KIND == kClsByte) return ~((((x ^ lo4) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+__device__ __forceinline__ uint32_t incls4(uint32_t x, uint32_t t, uint32_t lo4, uint32_t hi4) {   // lo4 / hi4: bounds splat over the bytes (hi4 = 0x7F - hi)
+  if (KIND == kClsDigit) return ~(xad(t, 0x30303030u, 0x76767676u) | x) & 0x80808080u;
+  if (KIND == kClsByte) return ~(xad(t, lo4, 0x7F7F7F7Fu) | x) & 0x80808080u;
   const uint32_t ge = (x | 0x80808080u) - lo4;
-  const uint32_t gt = (x & 0x7F7F7F7Fu) + hi4;
+  const uint32_t gt = t + hi4;
   return ge & ~gt & ~x & 0x80808080u;
 }
 // 16 class bits of a 16-byte vector: the four flags of a dword are gathered by one v_dot4_u32_u8 (weights 1,2,4,8 resp.
 // 16,32,64,128: 128 x the byte of flags accumulates over a dword pair).  Bits above 15 are garbage (ds_write_b16 drops them).
 template <int KIND>
-__device__ __forceinline__ uint32_t piece16(const u32x4& x, uint32_t lo4, uint32_t hi4) {
-  const uint32_t lo = __builtin_amdgcn_udot4(incls4<KIND>(x.y, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.x, lo4, hi4), 0x08040201u, 0u, false), false);
-  const uint32_t hi = __builtin_amdgcn_udot4(incls4<KIND>(x.w, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.z, lo4, hi4), 0x08040201u, 0u, false), false);
+__device__ __forceinline__ uint32_t piece16(const u32x4& x, const u32x4& t, uint32_t lo4, uint32_t hi4) {
+  const uint32_t lo = __builtin_amdgcn_udot4(incls4<KIND>(x.y, t.y, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.x, t.x, lo4, hi4), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(incls4<KIND>(x.w, t.w, lo4, hi4), 0x80402010u, __builtin_amdgcn_udot4(incls4<KIND>(x.z, t.z, lo4, hi4), 0x08040201u, 0u, false), false);
   return (lo >> 7) | (hi << 1);
 }
 // (a1:a0) + (b1:b0) -> (s1:s0), carry-out of the 64-bit addition of every lane as a wave mask (the v_addc's own carry
@@ -133,7 +144,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum_fused(uint32_t v) {
 struct FieldsTile { uint32_t e0, e1, b0, b1; bool ovf; };   // ends / group starts of the lane's word; ovf (uniform): a marker left the window
 
 // Phases B-D for one window: (d1:d0) / (p1:p0) = field / separator bitmap word of this lane.
-template <int K>
+template <int K, unsigned long long OWN = kFOwn>
 __device__ __forceinline__ FieldsTile fields_core(uint32_t d0, uint32_t d1, uint32_t p0, uint32_t p1) {
   // words of 64 field bytes pass a carry on (with no marker of their own; a word that generates needs no propagate)
   const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
@@ -145,7 +156,7 @@ __device__ __forceinline__ FieldsTile fields_core(uint32_t d0, uint32_t d1, uint
   const uint32_t L0 = p0 & Dl0 & Dr0, L1 = p1 & Dl1 & Dr1;
   const uint32_t prev_l1 = dpp_from_lower(L1);
   const uint32_t Ll0 = __builtin_amdgcn_alignbit(L0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(L1, L0, 31);   // L << 1
-  uint32_t b0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), b1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // B: group starts (first: the owned super-run starts)
+  uint32_t b0 = sel_lanes(d0 & ~Dl0 & ~Ll0, OWN), b1 = sel_lanes(d1 & ~Dl1 & ~Ll1, OWN);   // B: group starts (first: the owned super-run starts)
   if (CXG_FABL >= 2) { b0 = 0; b1 = 0; }
   // ---- C: hop over K fields
   unsigned long long ovf = 0;                                     // bit 63: a marker left the window (scalar)
@@ -220,42 +231,51 @@ __device__ __forceinline__ void fields_rows(const FieldsTile& t, int lane, uint3
 // bytes that exist (rounded up to a dword): lanes past the end of the input read zeros, no tail path.  nvalid = window bytes
 // that are data (or lie in front of the haystack); the window of the haystack's first tile starts 64 bytes in front of the
 // haystack: those lanes are sent out of range by the caller.
+template <int PRE = kFPre>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fields_window(const uint8_t* hay, uint64_t len, uint64_t lo, bool live, int32_t& nvalid) {
   int nrec = 0;
   uint64_t wlo = 0;
   nvalid = 0;
   if (live && lo < len) {
-    wlo = lo >= static_cast<uint64_t>(kFPre) ? lo - kFPre : 0;
+    wlo = lo >= static_cast<uint64_t>(PRE) ? lo - PRE : 0;
     const uint64_t rem = len - wlo;
-    const uint64_t full = static_cast<uint64_t>(kFWin) - (lo - wlo == 0 ? kFPre : 0);
+    const uint64_t full = static_cast<uint64_t>(kFWin) - (lo - wlo == 0 ? PRE : 0);
     nrec = rem >= full ? static_cast<int>(full) : static_cast<int>((rem + 3) & ~3ull);
-    const uint64_t nv = len - lo + kFPre;
+    const uint64_t nv = len - lo + PRE;
     nvalid = nv >= static_cast<uint64_t>(kFWin) ? kFWin : static_cast<int32_t>(nv);
   }
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(hay) + wlo, 0, nrec, 0x00020000);
 }
 // Phase A for one window held in x[]: class pieces into the wave's LDS scratch; every vector's register is refilled from
 // `rnext` right behind its last use.  Returns the lane's words (d1:d0), (p1:p0), masked to the valid bytes of a short window.
-template <int KD, int KP>
+// CARRY (the persistent kernel): carry_cur — the words 0..3 of this window were left in sd / sp [0..3] by the tile in front (the
+// pieces of the first 16 lanes' first vector, which was not loaded, go to the dump words 64..67); carry_next — the next window
+// follows this one in the same unit: its first 256 bytes are not loaded, and this tile's words 60..63 are left behind for it.
+template <int KD, int KP, bool CARRY = false>
 __device__ __forceinline__ void fields_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t rnext, int lane, uint64_t* sd, uint64_t* sp, int32_t nvalid,
                                              uint32_t dlo4, uint32_t dhi4, uint32_t plo4, uint32_t phi4, uint32_t& sink,
-                                             uint32_t& d0, uint32_t& d1, uint32_t& p0, uint32_t& p1) {
+                                             uint32_t& d0, uint32_t& d1, uint32_t& p0, uint32_t& p1, bool carry_cur = false, bool carry_next = false) {
   {
     uint16_t* pd = reinterpret_cast<uint16_t*>(sd);
     uint16_t* pp = reinterpret_cast<uint16_t*>(sp);
     const uint32_t voff = static_cast<uint32_t>(lane) << 4;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      int at = lane + 64 * k;
+      if (CARRY && k == 0) at = (carry_cur && lane < 16) ? lane + 256 : lane;
       if (CXG_FABL >= 4) {
         sink ^= x[k].x ^ x[k].y ^ x[k].z ^ x[k].w;
       } else if (CXG_FABL == 3) {
-        pd[lane + 64 * k] = static_cast<uint16_t>(x[k].x ^ x[k].z ^ x[k].y ^ x[k].w);
-        pp[lane + 64 * k] = 0;
+        pd[at] = static_cast<uint16_t>(x[k].x ^ x[k].z ^ x[k].y ^ x[k].w);
+        pp[at] = 0;
       } else {
-        pd[lane + 64 * k] = static_cast<uint16_t>(piece16<KD>(x[k], dlo4, dhi4));
-        pp[lane + 64 * k] = static_cast<uint16_t>(piece16<KP>(x[k], plo4, phi4));
+        const u32x4 t = x[k] & 0x7F7F7F7Fu;
+        pd[at] = static_cast<uint16_t>(piece16<KD>(x[k], t, dlo4, dhi4));
+        pp[at] = static_cast<uint16_t>(piece16<KP>(x[k], t, plo4, phi4));
       }
-      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, CXG_HAY_LOAD_AUX);
+      uint32_t off = voff + 1024u * k;
+      if (CARRY && k == 0 && carry_next && lane < 16) off = 0x7FFFFFF0u;   // out of range: zeros, nothing fetched
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, off, 0, CXG_HAY_LOAD_AUX);
       __builtin_amdgcn_sched_barrier(0);                            // keep the refill right behind its vector's last use
     }
   }
@@ -273,13 +293,18 @@ __device__ __forceinline__ void fields_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc
     d0 &= static_cast<uint32_t>(vf); d1 &= static_cast<uint32_t>(vf >> 32);
     p0 &= static_cast<uint32_t>(vf); p1 &= static_cast<uint32_t>(vf >> 32);
   }
+  if (CARRY && carry_next && lane >= 60) {                          // words 60..63 are the next window's words 0..3
+    sd[lane - 60] = (static_cast<uint64_t>(d1) << 32) | d0;
+    sp[lane - 60] = (static_cast<uint64_t>(p1) << 32) | p0;
+  }
 }
 // The first loads of a wave (window of the tile at `lo`); `first`: the haystack's first tile, window bytes 0..63 do not exist.
+template <int PRE = kFPre>
 __device__ __forceinline__ void fields_first_loads(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t r0, int lane, bool first) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     uint32_t off = static_cast<uint32_t>(lane + 64 * k) << 4;
-    if (first) off = off >= static_cast<uint32_t>(kFPre) ? off - kFPre : 0x7FFFFFF0u;
+    if (first) off = off >= static_cast<uint32_t>(PRE) ? off - PRE : 0x7FFFFFF0u;
     x[k] = __builtin_amdgcn_raw_buffer_load_b128(r0, off, 0, CXG_HAY_LOAD_AUX);
     __builtin_amdgcn_sched_barrier(0);                              // issue order = use order: the tile loop waits for x[0] with vmcnt(3), not for all four
   }
@@ -470,16 +495,23 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
 #ifndef CXG_PF_TILES
 #define CXG_PF_TILES 7
 #endif
+// 1: line-aligned windows, the 256 bytes two neighbouring tiles of a unit share carried in LDS (round 5); 0: round 4's windows
+#ifndef CXG_PF_CARRY
+#define CXG_PF_CARRY 1
+#endif
 constexpr int kPfTiles = CXG_PF_TILES;
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
 constexpr uint32_t kPfSpinLimit = 1u << 20;
 
 template <int K, int KD, int KP>
 __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64];
-  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64];
-  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - 64
+  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64 + 4];   // (+ 4 dump words: fields_words CARRY)
+  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64 + 4];
+  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - kPre
 
+  constexpr bool kCarry = CXG_PF_CARRY != 0;
+  constexpr int kPre = kCarry ? kFPrePers : kFPre;
+  constexpr unsigned long long kOwn = kCarry ? kFOwnPers : kFOwn;
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
@@ -583,7 +615,7 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
   u32x4 x[4];
   uint32_t sink = 0;
   int32_t nvalid_cur = 0;
-  fields_first_loads(x, fields_window(a.hay, a.len, unit_tile(0) * static_cast<uint64_t>(kWaveTile), true, nvalid_cur), lane, wv == 0);
+  fields_first_loads<kPre>(x, fields_window<kPre>(a.hay, a.len, unit_tile(0) * static_cast<uint64_t>(kWaveTile), true, nvalid_cur), lane, wv == 0);
   uint64_t running = 0;                                               // rows in front of the round being ordered (uniform)
   uint64_t my_total = 0;                                              // count-only: rows of this wave's units
   uint32_t fallback = 0;
@@ -622,15 +654,15 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
         const bool last = j + 1 == tpw;
         const bool more = !last || r + 1 < R_me;
         const uint64_t lo_next = (last ? unit_tile(r + 1) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
-        const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, lo_next, more, nvalid_next);
+        const __amdgpu_buffer_rsrc_t rnext = fields_window<kPre>(a.hay, a.len, lo_next, more, nvalid_next);
         uint32_t d0, d1, p0, p1;
-        fields_words<KD, KP>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1);
+        fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
         nvalid_cur = nvalid_next;
         const bool duty = duty_stage != 0u;                           // a leader's look of this tile
         u32x4 dv = {0u, 0u, 0u, 0u};
         if (duty) duty_load(dv);
         if (last && order && r > 0) status_load(r - 1, vr, vs);       // consumed behind this tile's mathematics
-        const FieldsTile t = fields_core<K>(d0, d1, p0, p1);
+        const FieldsTile t = fields_core<K, kOwn>(d0, d1, p0, p1);
         if (t.ovf) fallback |= 1u;
         const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
         const uint32_t incl = wave_inclusive_sum_fused(c);
@@ -679,7 +711,7 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       const uint64_t base = running + pre;
       running += tot;
       if (a.out != nullptr && CXG_PFABL < 3) {
-        const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kFPre;
+        const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kPre;
         const uint32_t n = nrows_prev < static_cast<uint32_t>(kFRows) ? nrows_prev : static_cast<uint32_t>(kFRows);
         for (uint32_t i = lane0; i < n; i += 64) {
           if (base + i < a.cap) {

@@ -29,6 +29,8 @@ def lib():
             f.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.emu_find_all_fields.restype = C.c_int64
         L.emu_find_all_fields.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
+        L.emu_find_all_fields2.restype = C.c_int64
+        L.emu_find_all_fields2.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.emu_fields_shape.restype = C.c_int
         L.emu_fields_shape.argtypes = [C.c_char_p]
         L.emu_find_all_trio.restype = C.c_int64
@@ -184,14 +186,15 @@ def fields_shape(blob: bytes) -> int:
     return int(lib().emu_fields_shape(blob))
 
 
-def find_all_fields(blob: bytes, hay, own_words: int = 60):
-    """Sequential twin of scan_fields_wave.hip.  Returns None where a tile would raise the fallback flag."""
+def find_all_fields(blob: bytes, hay, own_words: int = 60, pre_words: int = 1):
+    """Sequential twin of scan_fields_wave.hip.  Returns None where a tile would raise the fallback flag.  pre_words = 1: the grouped
+    kernel's window (64 bytes in front of the tile); 2: the persistent kernel's (128 in front, 128 behind at own_words = 60)."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
     cap = 1 << 12
     while True:
         out = np.empty(cap, dtype=np.int64)
-        n = lib().emu_find_all_fields(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words))
+        n = lib().emu_find_all_fields2(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words), int(pre_words))
         if n <= -16:
             return None
         assert n >= 0, f"emulator error {n}"

@@ -36,17 +36,19 @@ extern "C" int emu_fields_shape(const uint8_t* blob) {
   return fields_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));
 }
 
-extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
+// pre_words: window words in front of the tile — 1 for k_scan_fields_wave (64 bytes, lanes 1..60 own, 192 bytes behind), 2 for
+// k_scan_fields_pers since round 5 (128 bytes, lanes 2..61 own, 128 bytes behind: line-aligned windows).
+extern "C" int64_t emu_find_all_fields2(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words, int pre_words) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
   if (h->magic != kBlobMagic) return -1;
   if (!(h->flags & kFlagChainOrdered)) return -4;
   const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
   const int K = fields_shape_host(ch);
   if (!K) return -5;
-  if (own_words < 1 || own_words > 62) return -2;
+  if (own_words < 1 || pre_words < 1 || pre_words > 2 || own_words + pre_words > 63) return -2;
   const int NW = 64;
-  const int64_t tile_bytes = 64LL * own_words, pre = 64, N = 64LL * NW;
-  const unsigned long long own_mask = ((own_words == 63 ? ~0ull : ((1ull << own_words) - 1ull)) << 1);   // lanes 1..own_words
+  const int64_t tile_bytes = 64LL * own_words, pre = 64LL * pre_words, N = 64LL * NW;
+  const unsigned long long own_mask = ((1ull << own_words) - 1ull) << pre_words;   // lanes pre_words .. pre_words + own_words - 1
   std::vector<int64_t> res;
   const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
   for (uint64_t t = 0; t < ntiles; t++) {
@@ -149,6 +151,10 @@ extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, 
   const int64_t n = static_cast<int64_t>(res.size());
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
+}
+
+extern "C" int64_t emu_find_all_fields(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words) {
+  return emu_find_all_fields2(blob, hay, len, out, cap_vals, own_words, 1);
 }
 
 // ---- twin of k_scan_trio_wave<K> (scan_fields_wave.hip): run(F) (byte(c_i) run(F)){K-1}, K = 2..4 ------------------------------

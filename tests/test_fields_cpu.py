@@ -46,13 +46,13 @@ def test_random_text(pat, oracle):
         w = ([3, 3, 1] + [1] * len(alpha) if kind < 0.3 else [1] * len(alpha) if kind < 0.6 else [5] + [1] * len(alpha))[: len(alpha)]
         hay = "".join(rng.choices(alpha, weights=w, k=n)).encode()
         exp = o.find_all_index(_u8(hay))
-        for ow in (60, 5, 2, 1):
-            got = emu.find_all_fields(rx.blob(), hay, ow)
+        for ow, pw in ((60, 1), (5, 1), (2, 1), (1, 1), (60, 2), (6, 2), (1, 2)):
+            got = emu.find_all_fields(rx.blob(), hay, ow, pw)
             if got is None:
                 continue
             served += 1
-            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, ow, hay[:120])
-    assert served > 500
+            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, ow, pw, hay[:120])
+    assert served > 900
 
 
 def test_super_runs_with_many_fields(oracle):
@@ -62,9 +62,9 @@ def test_super_runs_with_many_fields(oracle):
     for hay in (b"1.2.3.4.5.6.7.8", b"x 1.2.3.4.5 y", b"1.2.3.4.5.6.7 1.2.3", b"9." * 40 + b"9 tail 1.1.1.1", b"ab" * 29 + b"11.22.33.44.55.66.77.88.99.00.11.22 z",
                 b"12.34.56.78." * 30 + b" end", (b"7." * 90) + b"7 " + b"1.2.3.4\n" * 50):
         exp = o.find_all_index(_u8(hay))
-        for ow in (60, 3, 1):
-            got = emu.find_all_fields(rx.blob(), hay, ow)
-            assert got is not None and np.array_equal(got, exp), (hay[:40], ow)
+        for ow, pw in ((60, 1), (3, 1), (1, 1), (60, 2), (3, 2)):
+            got = emu.find_all_fields(rx.blob(), hay, ow, pw)
+            assert got is not None and np.array_equal(got, exp), (hay[:40], ow, pw)
 
 
 def test_long_fields_and_word_filling_runs(oracle):
@@ -78,14 +78,14 @@ def test_long_fields_and_word_filling_runs(oracle):
             for n2 in (1, 64, 130):
                 hay = b"x" * pre + b"5" * n1 + b"." + b"6" * n2 + b" 1.5 y"
                 exp = o.find_all_index(_u8(hay))
-                for ow in (60, 4):
-                    got = emu.find_all_fields(rx.blob(), hay, ow)
+                for ow, pw in ((60, 1), (4, 1), (60, 2), (4, 2)):
+                    got = emu.find_all_fields(rx.blob(), hay, ow, pw)
                     if got is None:
                         assert n1 + n2 + 1 > 64          # only a match longer than a word may be handed over
                         continue
                     served += 1
-                    assert np.array_equal(got, exp), (pre, n1, n2, ow)
-    assert served > 60
+                    assert np.array_equal(got, exp), (pre, n1, n2, ow, pw)
+    assert served > 120
 
 
 def test_window_overrun_hands_over(oracle):
@@ -98,6 +98,12 @@ def test_window_overrun_hands_over(oracle):
     hay2 = b"y" * 100 + b"1." * 300 + b"1"
     got = emu.find_all_fields(rx.blob(), hay2, 60)
     assert np.array_equal(got, oracle.Regex(pat).find_all_index(_u8(hay2)))
+    # the persistent kernel's window ends 128 bytes behind its tile: a super-run from the tile's last bytes to 150 bytes behind it is
+    # handed over there and served by the grouped kernel's window (192 behind)
+    hay3 = b"y" * 3830 + b"1." * 80 + b"1 z"
+    assert emu.find_all_fields(rx.blob(), hay3, 60, 2) is None
+    got3 = emu.find_all_fields(rx.blob(), hay3, 60, 1)
+    assert np.array_equal(got3, oracle.Regex(pat).find_all_index(_u8(hay3)))
 
 
 def test_edges(oracle):
@@ -109,9 +115,9 @@ def test_edges(oracle):
              b"\xb1.\xb2.\xb3.\xb4 1.2.3.4", bytes(range(256)) * 3]
     for hay in cases:
         exp = o.find_all_index(_u8(hay))
-        for ow in (60, 1):
-            got = emu.find_all_fields(rx.blob(), hay, ow)
-            assert got is not None and got.shape == exp.shape and np.array_equal(got, exp), (hay[:30], ow)
+        for ow, pw in ((60, 1), (1, 1), (60, 2), (1, 2)):
+            got = emu.find_all_fields(rx.blob(), hay, ow, pw)
+            assert got is not None and got.shape == exp.shape and np.array_equal(got, exp), (hay[:30], ow, pw)
 
 
 def test_synthlog_pages(oracle):
@@ -119,6 +125,6 @@ def test_synthlog_pages(oracle):
     rx, o = cx.compile(pat), oracle.Regex(pat)
     host = cx.synth_pages(2, 0xC0FFEE02, 0, 64)
     exp = o.find_all_index(host)
-    for ow in (60, 7):
-        got = emu.find_all_fields(rx.blob(), host, ow)
+    for ow, pw in ((60, 1), (7, 1), (60, 2), (7, 2)):
+        got = emu.find_all_fields(rx.blob(), host, ow, pw)
         assert got is not None and np.array_equal(got, exp)
