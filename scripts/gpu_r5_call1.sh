@@ -26,3 +26,6 @@ done > $R/gpurun_out/r05_c1_fetch_size.txt 2>&1; cat $R/gpurun_out/r05_c1_fetch_
 cd $R
 timeout 600 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/r05_c1_pytest_gpu.log 2>&1; echo pytest=$?; tail -12 gpurun_out/r05_c1_pytest_gpu.log | cut -c1-300
 timeout 400 python bench.py > gpurun_out/r05_c1_bench_default.json 2> gpurun_out/r05_c1_bench_default.err; echo bench=$?; cut -c1-600 gpurun_out/r05_c1_bench_default.json; grep -o '"north_star".*' gpurun_out/r05_c1_bench_default.json | cut -c1-1500; tail -3 gpurun_out/r05_c1_bench_default.err
+# this box's baseline for the other kernels (before this round's work on them)
+{ timeout 200 python scripts/time_configs.py 1 3 4 5 2>&1 | grep -v amdgpu.ids
+  timeout 200 python scripts/time_patterns.py '(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)' '\b\d+\.\d+\b' '\b\d+\b' '(?m)^\d+' 2>&1 | grep -v amdgpu.ids | sed 's/  */ /g'; } > gpurun_out/r05_c1_other_kernels_baseline.txt 2>&1; cat gpurun_out/r05_c1_other_kernels_baseline.txt | cut -c1-260
