@@ -60,6 +60,13 @@ def set_device(i: int):
     _check(_lib.lib().cxg_set_device(i))
 
 
+def path_state(device: int = 0) -> dict:
+    """cxg_path_state: calls left on the slower launch mode and watchdog hits per mode (static groups, persistent grid, delimiter kernel)."""
+    st = _lib.PathState()
+    _check(_lib.lib().cxg_path_state(device, C.byref(st)))
+    return {n: int(getattr(st, n)) for n, _ in _lib.PathState._fields_ if n != "reserved"}
+
+
 def _host_view(hay):
     if isinstance(hay, np.ndarray):
         a = np.ascontiguousarray(hay, dtype=np.uint8)

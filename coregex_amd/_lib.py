@@ -26,7 +26,7 @@ SYMBOLS = [
     "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
-    "cxg_find_all_submatch_device",
+    "cxg_find_all_submatch_device", "cxg_abi_version", "cxg_timing_size", "cxg_path_state", "cxg_debug_demote",
 ]
 
 
@@ -39,6 +39,12 @@ class Timing(C.Structure):
     def kernels(self):
         """cxg_kernel id of every span launch of the call, in order (a fallback adds a rung)."""
         return [int(self.ladder[i]) for i in range(min(int(self.n_ladder), 12))]
+
+
+class PathState(C.Structure):
+    """cxg_path_state_t: launch-mode demotions of a device (watchdog hygiene, include/coregex_hip.h)."""
+    _fields_ = [("static_penalty", C.c_uint32), ("static_hits", C.c_uint32), ("persistent_penalty", C.c_uint32), ("persistent_hits", C.c_uint32),
+                ("delim_penalty", C.c_uint32), ("delim_hits", C.c_uint32), ("persistent_in_flight", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class NfaTrans(C.Structure):
@@ -138,5 +144,10 @@ def lib():
     L.cxg_find_all_device.argtypes = [vp, vp, u64, i64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
     L.cxg_find_all_device_u32.argtypes = [vp, vp, u64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
     L.cxg_find_all_submatch_device.argtypes = [vp, vp, u64, i64, i64, vp, u64, C.POINTER(u64), vp, C.POINTER(Timing)]
+    L.cxg_timing_size.restype = C.c_size_t
+    L.cxg_path_state.argtypes = [C.c_int, C.POINTER(PathState)]
+    L.cxg_debug_demote.argtypes = [C.c_int, C.c_int]
+    if L.cxg_abi_version() != 3 or L.cxg_timing_size() != C.sizeof(Timing):
+        raise RuntimeError(f"{LIB_PATH}: ABI {L.cxg_abi_version()} / cxg_timing of {L.cxg_timing_size()} bytes, this binding expects 3 / {C.sizeof(Timing)}")
     _lib = L
     return L

@@ -58,6 +58,44 @@ int failHip(hipError_t e, const char* what) {
 
 std::atomic<bool> g_exiting{false};   // set by an atexit hook: the HIP runtime may already be gone, leave its memory to the OS
 
+// Fast-path state per device, process-wide.  Three launch modes rest on how the device dispatches workgroups — static group
+// assignment (workgroups arrive in index order), the persistent fields kernel (its whole grid is co-resident) and the delimiter
+// kernel (index order) — and each has a spin watchdog that turns a broken assumption into an error bit instead of a hang.  Another
+// tenant of the GPU can break them for a while, so a watchdog hit is a DEMOTION WITH A TERM, not a verdict (round 4 latched
+// "never again" for the whole process): the call that was hit reruns one mode down, the next `penalty` calls that would have
+// used the mode stay one mode down, then the mode is tried again; a second hit doubles the term (8, 16, ... 1024 calls), a clean
+// call on the mode resets it.  cxg_path_state() shows the counters to the host.
+struct PathMode {
+  std::atomic<uint32_t> penalty{0};     // calls left one mode down
+  std::atomic<uint32_t> backoff{8};     // term of the next demotion
+  std::atomic<uint32_t> hits{0};        // watchdog hits since the process started
+  bool allowed() const { return penalty.load(std::memory_order_relaxed) == 0; }
+  void consume() {                      // a call that wanted the mode and was kept off it
+    uint32_t v = penalty.load(std::memory_order_relaxed);
+    while (v != 0 && !penalty.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {}
+  }
+  void demote() {
+    hits.fetch_add(1, std::memory_order_relaxed);
+    const uint32_t b = backoff.load(std::memory_order_relaxed);
+    penalty.store(b, std::memory_order_relaxed);
+    backoff.store(b >= 512 ? 1024 : b * 2, std::memory_order_relaxed);
+  }
+  void clean() { backoff.store(8, std::memory_order_relaxed); }
+};
+struct PathState {
+  PathMode staticGroups, persistent, delim;
+  // One persistent launch at a time per device from THIS process: two of them would each hold half the CUs and wait for waves
+  // that cannot become resident (every goroutine of a cgo host may be scanning).  The second caller takes the grouped kernel.
+  std::atomic<int> persInFlight{0};
+};
+PathState g_path[16];
+struct PersSlot {                       // RAII: the persistent-launch slot of a device
+  std::atomic<int>* f = nullptr;
+  bool tryAcquire(std::atomic<int>& flag) { int z = 0; if (flag.compare_exchange_strong(z, 1)) { f = &flag; return true; } return false; }
+  void release() { if (f) { f->store(0); f = nullptr; } }
+  ~PersSlot() { release(); }
+};
+
 int deviceCount() {
   static int n = -1;
   static std::mutex mu;
@@ -516,18 +554,20 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   }
   // `O [^E]+ E` programs: the delimiter kernel first (spans, no FindAll n: its kind look-back has no early stop), the transducer behind it
   static const bool delimOk = getenv("CXG_NO_DELIM_KERNEL") == nullptr;
-  static std::atomic<bool> delimWatchdog{false};
-  if (delimOk && !delimWatchdog.load() && !submatch && gen == 10 && p->delim[3] != 0u && limit <= 0 && d_fsm && getenv("CXG_TICKETS") == nullptr) {
-    gen = 11;
-    fsmTried = false;
+  static const bool ticketsForced = getenv("CXG_TICKETS") != nullptr;
+  PathState& ps = g_path[t_device];
+  bool staticDenied = ticketsForced, persDenied = false;            // this call: a watchdog hit (or the environment) took the mode away
+  if (delimOk && !submatch && gen == 10 && p->delim[3] != 0u && limit <= 0 && d_fsm && !ticketsForced) {
+    if (ps.delim.allowed() && ps.staticGroups.allowed()) { gen = 11; fsmTried = false; }
+    else ps.delim.consume();
   }
   if (h->kind == cxgdev::kKindFsmOnly) {                            // UseNFA programs (word boundaries): the transducer kernel is the only one
     if (!d_fsm) return fail(CXG_E_UNSUPPORTED, "program runs on the transducer kernel only (CXG_NO_FSM is set)");
     gen = 10;
     fsmTried = true;
   }
-  // Wave kernels: static group assignment unless a look-back watchdog ever fired in this process (block_common.hpp).
-  static std::atomic<bool> staticGroupsOk{getenv("CXG_TICKETS") == nullptr};
+  // Wave kernels: static group assignment unless a look-back watchdog demoted it for a while (PathState above, block_common.hpp).
+  if (gen >= 6 && !ticketsForced && !ps.staticGroups.allowed()) { staticDenied = true; ps.staticGroups.consume(); }
   static const bool fuseCapsOk = getenv("CXG_NO_FUSED_CAPTURES") == nullptr;
   bool fusedCaps = false;                                          // captures written by the chain kernel itself
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
@@ -545,7 +585,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   persKernel = false;
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
-  a.static_groups = (gen >= 6 && staticGroupsOk.load()) ? 1u : 0u;
+  PersSlot persSlot;                                               // released when this iteration ends (every path out of it)
+  a.static_groups = (gen >= 6 && !staticDenied) ? 1u : 0u;
   if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
@@ -643,7 +684,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
     a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
-    if (fieldsKernel && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0) {
+    bool persWanted = fieldsKernel && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
+    if (persWanted && !ps.persistent.allowed()) { ps.persistent.consume(); persDenied = true; persWanted = false; }
+    if (persWanted && !persSlot.tryAcquire(ps.persInFlight)) persWanted = false;   // another thread's persistent launch is in flight on this device
+    if (persWanted) {
       const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
       const uint64_t need = nwt / 4u + 2u * 8192u + 64u;                                       // (full rounds + 1) x W unit words, W <= 8192 waves
       const uint64_t rneed = nwt / (4u * 1024u) + 2u;                                          // rounds: >= 1024 waves on a long haystack
@@ -783,16 +827,29 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
     }
   }
-  if ((err & 2u) && gen == 11) {                                    // the delimiter kernel needs dispatch in index order: never again, the transducer
-    delimWatchdog.store(true);
-    relaunches++; gen = 10; fsmTried = true; continue;
+  persSlot.release();
+  if (err & 2u) {
+    static const bool wdVerbose = getenv("CXG_VERBOSE") != nullptr;
+    const uint32_t origin = (err >> 24) & 15u;
+    if (wdVerbose) fprintf(stderr, "[cxg] spin watchdog fired (wait %u, kernel %u, static groups %u): this call reruns one mode down\n", origin, kernelId, a.static_groups);
+    if (gen == 11) {                                                // the delimiter kernel needs dispatch in index order: the transducer for a while
+      ps.delim.demote();
+      relaunches++; gen = 10; fsmTried = true; continue;
+    }
+    if (persKernel) {                                               // the persistent grid was not co-resident: the grouped kernel, still with static groups
+      ps.persistent.demote();
+      persDenied = true; relaunches++; continue;
+    }
+    if (a.static_groups) {                                          // dispatch was not in index order: tickets
+      ps.staticGroups.demote();
+      staticDenied = true; relaunches++; continue;
+    }
+  } else {
+    if (gen == 11) ps.delim.clean();
+    if (persKernel) ps.persistent.clean();
+    else if (a.static_groups) ps.staticGroups.clean();
   }
-  if ((err & 2u) && a.static_groups) {                              // watchdog under static groups: never again, rerun with tickets
-    staticGroupsOk.store(false);
-    fprintf(stderr, "[cxg] look-back watchdog fired with static group assignment: switching to tickets\n");
-    relaunches++;
-    continue;
-  }
+  err &= 0x00FFFFFFu;
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
     if (gen == 10 && ((err >> 8) & 0x32u) != 0u && ((err >> 8) & ~0x72u) == 0u && fsmMode < 2) {   // transducer kernel: row / event buffers overflowed
@@ -1252,7 +1309,7 @@ constexpr uint64_t kZeroCopyVals = 128ull << 10;    // int64 values of rows writ
 int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* rows, uint64_t cap,
              uint64_t* n_out, int width) {
   if (!p) return fail(CXG_E_INVALID, "null program");
-  if (width > 2 ? !p->subSupported : !p->supported)
+  if (width > 2 ? !(p->subSupported || (p->offCapsOn && p->supported)) : !p->supported)   // (the predicate of cxg_program_submatch_supported)
     return fail(CXG_E_UNSUPPORTED, width > 2 ? p->subWhyNot : (p->whyNot.empty() ? "unsupported program" : p->whyNot));
   if (n_out) *n_out = 0;
   if (limit == 0 || (len == 0 && !(p->nullable && width == 2))) return CXG_OK;   // (a nullable pattern matches the empty haystack once)
@@ -1329,7 +1386,25 @@ struct cxg_buffer {
 extern "C" {
 
 const char* cxg_last_error(void) { return t_err.c_str(); }
-const char* cxg_version(void) { return "coregex_hip 0.1 (gfx950)"; }
+const char* cxg_version(void) { return "coregex_hip 0.2 (gfx950)"; }
+int cxg_abi_version(void) { return CXG_ABI_VERSION; }
+size_t cxg_timing_size(void) { return sizeof(cxg_timing); }
+int cxg_debug_demote(int device, int mode) {
+  if (device < 0 || device >= 16 || mode < 0 || mode > 2) return fail(CXG_E_INVALID, "bad argument");
+  PathState& ps = g_path[device];
+  (mode == 0 ? ps.staticGroups : mode == 1 ? ps.persistent : ps.delim).demote();
+  return CXG_OK;
+}
+int cxg_path_state(int device, cxg_path_state_t* out) {
+  if (!out || device < 0 || device >= 16) return fail(CXG_E_INVALID, "bad argument");
+  const PathState& ps = g_path[device];
+  out->static_penalty = ps.staticGroups.penalty.load(); out->static_hits = ps.staticGroups.hits.load();
+  out->persistent_penalty = ps.persistent.penalty.load(); out->persistent_hits = ps.persistent.hits.load();
+  out->delim_penalty = ps.delim.penalty.load(); out->delim_hits = ps.delim.hits.load();
+  out->persistent_in_flight = static_cast<uint32_t>(ps.persInFlight.load());
+  out->reserved = 0;
+  return CXG_OK;
+}
 int cxg_device_count(void) { return deviceCount(); }
 int cxg_set_device(int device) {
   if (device < 0 || device >= 16) return fail(CXG_E_INVALID, "bad device index");

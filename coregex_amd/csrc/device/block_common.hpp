@@ -19,6 +19,11 @@ __device__ __forceinline__ void raise_err(uint32_t* err, uint32_t bits) {
   __hip_atomic_fetch_or(err, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// A spin watchdog ran out: error bit 1, and WHICH wait it was in bits 24..27 (capi.hip reads it to decide what to demote:
+// 1 grouped look-back, 2 delimiter look-back, 3 / 4 transducer hand-off / group entry, 5 / 6 persistent kernel duty / record).
+constexpr uint32_t kWdLookback = 1, kWdDelim = 2, kWdFsmExit = 3, kWdFsmEntry = 4, kWdPersDuty = 5, kWdPersRecord = 6;
+__device__ __forceinline__ void raise_watchdog(uint32_t* err, uint32_t origin) { raise_err(err, 2u | (origin << 24)); }
+
 // One output pair (16 bytes, 16-byte aligned) with a NONTEMPORAL store.  Rows are written once and not read again by the
 // kernel that writes them; stored through the default write-back path of the XCD's L2 the 160 MB of rows of the headline
 // workload cost 0.037 ms of a 0.26 ms launch, nontemporal 0.007 (round 4, profiles/r04_pers_64g.txt: 1 GiB 0.2626 -> 0.2323 ms,
@@ -126,7 +131,7 @@ __device__ __forceinline__ void tile_lookback(uint64_t* status, uint64_t* total_
         if (idx >= 0) w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
         if (!__all(ready)) {
-          if (++spins > kSpinLimit) { if (lane == 0) raise_err(err, 2u); break; }
+          if (++spins > kSpinLimit) { if (lane == 0) raise_watchdog(err, kWdLookback); break; }
           __builtin_amdgcn_s_sleep(2);
           continue;
         }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_delim_wave(ScanArgs a) {
         if (idx >= 0) w = __hip_atomic_load(a.status2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool ready = (w >> 32) == (etag >> 32) && (w & 4u) != 0u;
         if (!__all(ready)) {
-          if (++spins > kSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+          if (++spins > kSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdDelim); break; }
           __builtin_amdgcn_s_sleep(2);
           continue;
         }

@@ -491,23 +491,27 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
 #endif
 // Tiles per unit.  ODD on purpose: the waves start in lockstep, so at any moment they read at (v * unit + progress) — with a
 // unit of 8 tiles = 120 x 256 bytes the offsets v * 120 mod 128 take 16 values, i.e. an eighth of the channels of any
-// power-of-two interleave; 7 tiles = 105 x 256 bytes is coprime to it and spreads the waves over all of them.
+// power-of-two interleave; 7 tiles = 105 x 256 bytes is coprime to it and spreads the waves over all of them.  Round 5: 9 tiles
+// (135 x 256 bytes): with the halo carried inside a unit a longer unit re-reads less (1 GiB: 0.2264 -> 0.2218 ms mean of 20,
+// 11 tiles 0.2200 but 768 parked rows per wave cost a workgroup per CU; profiles/r05_c1_headline_ab.txt).
 #ifndef CXG_PF_TILES
-#define CXG_PF_TILES 7
+#define CXG_PF_TILES 9
 #endif
 // 1: line-aligned windows, the 256 bytes two neighbouring tiles of a unit share carried in LDS (round 5); 0: round 4's windows
 #ifndef CXG_PF_CARRY
 #define CXG_PF_CARRY 1
 #endif
 constexpr int kPfTiles = CXG_PF_TILES;
+static_assert((kPfTiles - 1) * kWaveTile + kWaveTile + kWaveHalo < 65536, "a parked row holds two 16-bit offsets from the unit's first window byte");
+constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per unit and wave (twice: rounds r and r - 1); 64 per tile + 64 as in the grouped kernel
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
-constexpr uint32_t kPfSpinLimit = 1u << 20;
+constexpr uint32_t kPfSpinLimit = 1u << 18;                  // polls of ~1.5 us: a wave that waits ~0.4 s gives up (capi.hip demotes the mode for a while)
 
 template <int K, int KD, int KP>
 __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64 + 4];   // (+ 4 dump words: fields_words CARRY)
   __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64 + 4];
-  __shared__ uint32_t s_row[2][kWavesPerBlock][kFRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - kPre
+  __shared__ uint32_t s_row[2][kWavesPerBlock][kPfRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - kPre
 
   constexpr bool kCarry = CXG_PF_CARRY != 0;
   constexpr int kPre = kCarry ? kFPrePers : kFPre;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       const uint32_t before = duty_stage;
       duty_check(dv);
       if (duty_stage == before) {
-        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
       }
     }
@@ -668,17 +672,17 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
         const uint32_t incl = wave_inclusive_sum_fused(c);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
         if (tot != 0 && want_rows)
-          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kFRows - 1)); },
+          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kPfRows - 1)); },
                       j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
         nrows_w += tot;
         if (duty) duty_check(dv);
       }
       st_scan += __builtin_readcyclecounter() - st_a;
-      if (nrows_w > static_cast<uint32_t>(kFRows)) fallback |= 16u;
+      if (nrows_w > static_cast<uint32_t>(kPfRows)) fallback |= 16u;
       wave_lds_sync();
       bool bad = false, long_hit = false;
       if (want_rows) {
-        for (uint32_t q = lane0; q < nrows_w && q < static_cast<uint32_t>(kFRows); q += 64) {
+        for (uint32_t q = lane0; q < nrows_w && q < static_cast<uint32_t>(kPfRows); q += 64) {
           const uint32_t v = s_row[par][wave][q];
           const uint32_t sb = v & 0xFFFFu, eb = v >> 16;
           bad = bad || sb >= eb;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       const uint32_t rp = r - 1u, parp = rp & 1u;
       uint32_t pre = 0, tot = 0, spins = 0;
       while (!status_reduce(vr, vs, pre, tot)) {                      // something of the round was not there yet
-        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_err(a.err, 2u); break; }
+        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
         status_load(rp, vr, vs);
       }
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
       running += tot;
       if (a.out != nullptr && CXG_PFABL < 3) {
         const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kPre;
-        const uint32_t n = nrows_prev < static_cast<uint32_t>(kFRows) ? nrows_prev : static_cast<uint32_t>(kFRows);
+        const uint32_t n = nrows_prev < static_cast<uint32_t>(kPfRows) ? nrows_prev : static_cast<uint32_t>(kPfRows);
         for (uint32_t i = lane0; i < n; i += 64) {
           if (base + i < a.cap) {
             const uint32_t v = s_row[parp][wave][i];

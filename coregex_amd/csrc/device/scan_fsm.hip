@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t wait_tile_exit(uint32_t* s_exit, uint64_t* s
     }
     w = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(w)));
     if (w & kExitValid) break;
-    if (spins > (kSpinLimit << 6)) { if (lane == 0) raise_err(err, 2u); break; }   // (a hand-off chain over every tile of the input is legitimate)
+    if (spins > (kSpinLimit << 6)) { if (lane == 0) raise_watchdog(err, kWdFsmExit); break; }   // (a hand-off chain over every tile of the input is legitimate)
     // Input without synchronising structure makes this a serial chain over every tile (17 476 hops for 64 MiB): the poll
     // interval IS the hop latency.  s_sleep 4 (256 cycles) gave 323 ns per tile = 5.65 ms; the LDS hop inside a workgroup
     // is polled back to back, the HBM hop between workgroups with the shortest sleep.
@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t fsm_group_entry(const FsmView& v, const Scan
     const unsigned long long notready = ~__ballot(isval || ismap);
     const int nready = notready ? __builtin_ctzll(notready) : 64;
     if (nready == 0) {
-      if (++spins > kSpinLimit) { if (lane == 0) raise_err(a.err, 2u); return 0u; }
+      if (++spins > kSpinLimit) { if (lane == 0) raise_watchdog(a.err, kWdFsmEntry); return 0u; }
       __builtin_amdgcn_s_sleep(2);
       continue;
     }

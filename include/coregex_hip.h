@@ -129,6 +129,30 @@ const char* cxg_kernel_name(int kernel);
 
 const char* cxg_last_error(void);          /* thread-local text of the last failure */
 const char* cxg_version(void);
+/* ABI of this header: bumped whenever a struct a caller allocates (cxg_timing, cxg_path_state_t, cxg_nfa*) changes size or
+ * layout.  A binding compiled against another header must refuse to run: `cxg_abi_version() != CXG_ABI_VERSION` or
+ * `cxg_timing_size() != sizeof(cxg_timing)`.  History: 1 = rounds 1-3; 2 = round 4 (cxg_timing grew by n_ladder + ladder[12]:
+ * 16 bytes, every *_device entry point writes the whole struct); 3 = round 5 (cxg_path_state_t, cxg_pending). */
+#define CXG_ABI_VERSION 3
+int cxg_abi_version(void);
+size_t cxg_timing_size(void);
+
+/* Launch-mode state of a device (process-wide).  The fastest launch modes assume that the device dispatches workgroups in index
+ * order (static groups, delimiter kernel) or holds a whole grid resident (persistent fields kernel); a spin watchdog catches the
+ * cases where another tenant of the GPU breaks that.  A hit demotes the mode for `*_penalty` further calls (8, doubling to 1024
+ * on repeated hits, reset by a clean call), then it is tried again; the call that was hit reruns one mode down and still
+ * returns the reference's rows.  `*_hits` count watchdog hits since the process started. */
+typedef struct cxg_path_state_t {
+  uint32_t static_penalty, static_hits;
+  uint32_t persistent_penalty, persistent_hits;
+  uint32_t delim_penalty, delim_hits;
+  uint32_t persistent_in_flight;   /* 1 while a persistent launch of this process runs on the device (a second caller takes the grouped kernel) */
+  uint32_t reserved;
+} cxg_path_state_t;
+int cxg_path_state(int device, cxg_path_state_t* out);
+/* Diagnostics / tests: act as if the spin watchdog of a mode had fired on `device` (mode 0 static groups, 1 persistent grid,
+ * 2 delimiter kernel): the mode is demoted for its current term, exactly as a real hit would. */
+int cxg_debug_demote(int device, int mode);
 int cxg_device_count(void);                /* gfx950 devices visible; 0 => every search returns CXG_E_NO_GPU */
 int cxg_set_device(int device);            /* per-thread device for subsequent calls (default 0) */
 /* Frees the calling thread's stream, events, pinned buffers and HBM staging (they are per OS thread and are also freed
