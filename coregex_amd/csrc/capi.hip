@@ -32,6 +32,7 @@ hipError_t launch_scan_chain_wave(const ScanArgs& a, uint32_t ncls, bool sets, b
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
 hipError_t launch_scan_delim_wave(const ScanArgs& a, hipStream_t stream);   // scan_delim_wave.hip
 int fields_shape(const ChainAux& c);
+int literal_shape(const ChainAux& c);
 int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
@@ -573,6 +574,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool fieldsKernel = false;                                       // gen 6 served by scan_fields_wave.hip
   bool trioKernel = false;                                         // gen 6 served by k_scan_trio_wave
   bool persKernel = false;                                         // ... by k_scan_fields_pers (the launcher says)
+  bool litKernel = false;                                          // ... by its literal mode (round 5)
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // wave kernels: match-dense input seen before
   int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 (very dense)
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
@@ -583,6 +585,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   fusedCaps = false;
   fieldsKernel = false;
   persKernel = false;
+  litKernel = false;
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   PersSlot persSlot;                                               // released when this iteration ends (every path out of it)
@@ -679,12 +682,16 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     const bool fieldsCould = !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                              cxgdev::fields_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
     fieldsKernel = fieldsOk && !submatch && !denseChain && fieldsCould;
+    // border-free literals over <= 4 distinct bytes (`error`, BASELINE configs[0]): the persistent kernel's literal mode, or the chain kernel
+    static const bool literalOk = getenv("CXG_NO_LITERAL_KERNEL") == nullptr;
+    litKernel = literalOk && !fieldsKernel && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
+                cxgdev::literal_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
     // ... on a persistent grid with the ordering of the rows deferred by a round (k_scan_fields_pers) unless FindAll has an n
     // (the early stop lives in the grouped kernel's look-back), the phase profile is on, or a watchdog ever fired
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
     a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
-    bool persWanted = fieldsKernel && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
+    bool persWanted = (fieldsKernel || litKernel) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
     if (persWanted && !ps.persistent.allowed()) { ps.persistent.consume(); persDenied = true; persWanted = false; }
     if (persWanted && !persSlot.tryAcquire(ps.persInFlight)) persWanted = false;   // another thread's persistent launch is in flight on this device
     if (persWanted) {
@@ -715,13 +722,14 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       a.pf_status = s.pfStatus; a.pf_cap = s.pfCap; a.pf_epoch = ++s.pfEpoch;
       a.pf_rec = s.pfRec; a.pf_rec_rounds = s.pfRecRounds; a.pf_stats = s.pfStats;
     }
+    if (a.pf_status == nullptr) litKernel = false;                  // no persistent launch for this call: the chain kernel
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
-    a.count_sum = (fieldsKernel && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
+    a.count_sum = ((fieldsKernel || litKernel) && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
     // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
     // start, the end or the end of the first / second run plus a constant (ChainCaps)
     static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
     const int trioShape = cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
-    if (!fieldsKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
+    if (!fieldsKernel && !litKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
       bool ok = !submatch || a.out == nullptr || fusedCaps;
       // spans with one separator for every link are the fields kernel's where it can serve the chain (with CXG_NO_FIELDS_KERNEL
       // the chain kernel's: the A/B of tests/test_gpu_fields.py); a set class (`\w+@\w+@\w+`) stays here, on the EQ instantiation
@@ -734,9 +742,15 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
       trioKernel = ok;
     }
-    if (a.u32_rows && a.out != nullptr && !(fieldsKernel && a.pf_status != nullptr))
+    if (a.u32_rows && a.out != nullptr && !((fieldsKernel || litKernel) && a.pf_status != nullptr))
       return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
-    if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream);
+    le = hipSuccess;
+    if (litKernel) {                                                // (a launch the persistent geometry cannot hold: the chain kernel below)
+      le = cxgdev::launch_scan_fields_wave(a, stream, &persKernel);
+      if (!persKernel) { litKernel = false; a.count_sum = 0; (void)hipGetLastError(); }
+    }
+    if (litKernel) {}
+    else if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream);
     else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream, &persKernel);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
@@ -752,7 +766,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -1425,6 +1439,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_TRIO_WAVE: return "k_scan_trio_wave";
     case CXG_K_FIELDS_PERS: return "k_scan_fields_pers";
     case CXG_K_DELIM_WAVE: return "k_scan_delim_wave";
+    case CXG_K_LITERAL_PERS: return "k_scan_fields_pers<LIT>";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";

@@ -310,6 +310,81 @@ __device__ __forceinline__ void fields_first_loads(u32x4 (&x)[4], __amdgpu_buffe
   }
 }
 
+
+// ---- literal programs on the persistent kernel (round 5) -----------------------------------------------------------------
+// A chain of m single-byte steps over NC <= 4 distinct bytes with no border (no proper prefix of the literal is a suffix of it:
+// occurrences cannot overlap, so FindAll = all occurrences): `error`, `GET`, `HTTP/1.1`.  One bitmap per distinct byte (phase A as
+// for the fields programs), then  O = AND_j (B_c(j) >> j)  — an occurrence starts where byte j of the literal stands j places on,
+// for every j —, ends = O << m.  No candidate is verified against memory and nothing is walked: simd.Memmem's rare-byte pair scan
+// (simd/memmem.go:53-152) with every byte of the needle in the filter.
+constexpr int kLitClsStride = kWavesPerBlock * (64 + 4);     // words between the bitmaps of two classes (k_scan_fields_pers s_c)
+struct LitRegs { uint32_t m, nc; uint32_t b4[4]; uint64_t cls2_lo, cls2_hi; };   // m steps; byte of class c splat; 2 bits per step: its class
+
+template <int NC, bool CARRY>
+__device__ __forceinline__ void lit_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t rnext, int lane, uint64_t* sc0, int32_t nvalid, const LitRegs& lr,   // sc0: this wave's words of class 0; class c at + c * kLitClsStride
+                                          uint32_t (&w0)[NC], uint32_t (&w1)[NC], bool carry_cur, bool carry_next) {
+  {
+    const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int at = lane + 64 * k;
+      if (CARRY && k == 0) at = (carry_cur && lane < 16) ? lane + 256 : lane;
+      const u32x4 t = x[k] & 0x7F7F7F7Fu;
+#pragma unroll
+      for (int c = 0; c < NC; c++) reinterpret_cast<uint16_t*>(sc0 + c * kLitClsStride)[at] = static_cast<uint16_t>(piece16<kClsByte>(x[k], t, lr.b4[c], 0u));
+      uint32_t off = voff + 1024u * k;
+      if (CARRY && k == 0 && carry_next && lane < 16) off = 0x7FFFFFF0u;
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, off, 0, CXG_HAY_LOAD_AUX);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  wave_lds_sync();
+  int lw = lane;
+  asm volatile("" : "+v"(lw));
+  uint64_t vf = ~0ull;
+  if (nvalid != kFWin) {
+    const int32_t nf = nvalid - 64 * lane;
+    vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+  }
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const uint64_t W = sc0[c * kLitClsStride + lw] & vf;
+    w0[c] = static_cast<uint32_t>(W); w1[c] = static_cast<uint32_t>(W >> 32);
+    if (CARRY && carry_next && lane >= 60) sc0[c * kLitClsStride + lane - 60] = W;
+  }
+}
+
+// (h1:h0 of this lane, n1:n0 of the next lane) >> k, 0 <= k < 64, low 64 bits
+__device__ __forceinline__ void shr128(uint32_t h0, uint32_t h1, uint32_t n0, uint32_t n1, uint32_t k, uint32_t& r0, uint32_t& r1) {
+  if (k < 32u) { r0 = __builtin_amdgcn_alignbit(h1, h0, k); r1 = __builtin_amdgcn_alignbit(n0, h1, k); }
+  else { r0 = __builtin_amdgcn_alignbit(n0, h1, k - 32u); r1 = __builtin_amdgcn_alignbit(n1, n0, k - 32u); }
+}
+template <int NC, unsigned long long OWN>
+__device__ __forceinline__ FieldsTile lit_core(const uint32_t (&w0)[NC], const uint32_t (&w1)[NC], const LitRegs& lr) {
+  uint32_t n0[NC], n1[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) {                                     // the next lane's words (behind the window: nothing)
+    n0[c] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(w0[c]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+    n1[c] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(w1[c]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
+  }
+  uint32_t o0 = ~0u, o1 = ~0u;
+  for (uint32_t j = 0; j < lr.m; j++) {                               // uniform trip count and shifts
+    const uint32_t c = static_cast<uint32_t>((j < 32u ? lr.cls2_lo >> (2u * j) : lr.cls2_hi >> (2u * (j - 32u))) & 3ull);
+    uint32_t r0 = 0, r1 = 0;
+#pragma unroll
+    for (int q = 0; q < NC; q++) if (c == static_cast<uint32_t>(q)) shr128(w0[q], w1[q], n0[q], n1[q], j, r0, r1);
+    o0 &= r0; o1 &= r1;
+  }
+  o0 = sel_lanes(o0, OWN); o1 = sel_lanes(o1, OWN);                   // occurrences that START in the tile
+  // ends (exclusive) = starts << m, m < 64: the bits that leave this lane's word arrive in the next one's
+  const uint32_t p0 = dpp_from_lower_z(o0), p1 = dpp_from_lower_z(o1);
+  uint32_t e0, e1;
+  const uint32_t m = lr.m;
+  if (m < 32u) { e0 = m ? __builtin_amdgcn_alignbit(o0, p1, 32u - m) : o0; e1 = m ? __builtin_amdgcn_alignbit(o1, o0, 32u - m) : o1; }
+  else if (m == 32u) { e0 = p1; e1 = o0; }
+  else { e0 = __builtin_amdgcn_alignbit(p1, p0, 64u - m); e1 = __builtin_amdgcn_alignbit(o0, p1, 64u - m); }
+  return FieldsTile{e0, e1, o0, o1, false};
+}
 }  // namespace
 
 // K: number of fields (2..4).  KD / KP: kind of the field / separator class (walk.hpp ChainClassKind; kClsRange also
@@ -507,10 +582,13 @@ constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per 
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
 constexpr uint32_t kPfSpinLimit = 1u << 18;                  // polls of ~1.5 us: a wave that waits ~0.4 s gives up (capi.hip demotes the mode for a while)
 
-template <int K, int KD, int KP>
-__global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint64_t s_d[kWavesPerBlock][64 + 4];   // (+ 4 dump words: fields_words CARRY)
-  __shared__ __attribute__((aligned(16))) uint64_t s_p[kWavesPerBlock][64 + 4];
+// LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused).
+template <int K, int KD, int KP, int LIT = 0>
+__global__ __launch_bounds__(kThreads, (LIT ? (LIT >= 3 ? 4 : 5) : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (literal mode: 96 / 128 VGPRs, no scratch)
+  constexpr int kNBitmaps = LIT ? LIT : 2;
+  __shared__ __attribute__((aligned(16))) uint64_t s_c[kNBitmaps][kWavesPerBlock][64 + 4];   // class bitmaps of the wave's window (+ 4 dump words: CARRY)
+  uint64_t (*const s_d)[64 + 4] = s_c[0];
+  uint64_t (*const s_p)[64 + 4] = s_c[1];
   __shared__ uint32_t s_row[2][kWavesPerBlock][kPfRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - kPre
 
   constexpr bool kCarry = CXG_PF_CARRY != 0;
@@ -529,6 +607,12 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
   const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
   const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
   const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
+  LitRegs lr;
+  if (LIT) {
+    lr.m = gch->nops; lr.nc = gch->ncls; lr.cls2_lo = gch->cls2_lo; lr.cls2_hi = gch->cls2_hi;
+#pragma unroll
+    for (int c = 0; c < 4; c++) lr.b4[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[c] * 0x01010101u)));
+  }
   const uint32_t ep = a.pf_epoch;
   const uint32_t tag = ep << 16;
   const bool want_rows = a.out != nullptr || a.max_len != 0;
@@ -659,14 +743,17 @@ __global__ __launch_bounds__(kThreads, CXG_PF_OCC) void k_scan_fields_pers(ScanA
         const bool more = !last || r + 1 < R_me;
         const uint64_t lo_next = (last ? unit_tile(r + 1) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
         const __amdgpu_buffer_rsrc_t rnext = fields_window<kPre>(a.hay, a.len, lo_next, more, nvalid_next);
-        uint32_t d0, d1, p0, p1;
-        fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
+        uint32_t d0 = 0, d1 = 0, p0 = 0, p1 = 0;
+        uint32_t lw0[kNBitmaps], lw1[kNBitmaps];
+        if (LIT) {
+          lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, lw0, lw1, j != 0u, !last);
+        } else fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
         nvalid_cur = nvalid_next;
         const bool duty = duty_stage != 0u;                           // a leader's look of this tile
         u32x4 dv = {0u, 0u, 0u, 0u};
         if (duty) duty_load(dv);
         if (last && order && r > 0) status_load(r - 1, vr, vs);       // consumed behind this tile's mathematics
-        const FieldsTile t = fields_core<K, kOwn>(d0, d1, p0, p1);
+        const FieldsTile t = LIT ? lit_core<kNBitmaps, kOwn>(lw0, lw1, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
         if (t.ovf) fallback |= 1u;
         const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
         const uint32_t incl = wave_inclusive_sum_fused(c);
@@ -752,15 +839,35 @@ int fields_shape(const ChainAux& c) {
   return static_cast<int>((c.nops + 1) / 2);
 }
 
+// Is the chain a literal the persistent kernel's literal mode evaluates?  2..63 single-byte steps over 2..4 distinct ASCII bytes, and
+// no border: no proper prefix of the literal is also its suffix (`abab`, `aa`: occurrences overlap and FindAll keeps every
+// other one — a sequential rule; those stay on the chain kernel).  Returns the number of distinct bytes, else 0.
+int literal_shape(const ChainAux& c) {
+  if (c.nops < 2 || c.nops > 63 || c.ncls < 2 || c.ncls > 4 || c.restart_check) return 0;
+  uint8_t lit[64];
+  for (uint32_t k = 0; k < c.nops; k++) {
+    const uint32_t q = c.op_cls[k];
+    if (c.op_kind[k] != kChainByte || q >= c.ncls || c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q] || c.cls_lo[q] > 0x7Fu) return 0;
+    lit[k] = c.cls_lo[q];
+  }
+  for (uint32_t q = 0; q < c.ncls; q++) for (uint32_t r = q + 1; r < c.ncls; r++) if (c.cls_lo[q] == c.cls_lo[r]) return 0;
+  for (uint32_t b = 1; b < c.nops; b++) {                            // a border of length b
+    bool same = true;
+    for (uint32_t i = 0; i < b && same; i++) same = lit[i] == lit[c.nops - b + i];
+    if (same) return 0;
+  }
+  return static_cast<int>(c.ncls);
+}
+
 __global__ void k_sum_counts(const uint64_t* counts, uint64_t n, uint64_t* total);
 
 namespace {
-template <int K, int KD, int KP>
+template <int K, int KD, int KP, int LIT = 0>
 int pers_occupancy() {                                               // resident workgroups per CU of the persistent instantiation
   static int occ = -1;
   if (occ < 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_fields_pers<K, KD, KP>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_fields_pers<K, KD, KP, LIT>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
     int want = CXG_PF_OCC;
     if (const char* e = getenv("CXG_PF_OCC")) want = atoi(e);
     occ = n < want ? n : want;
@@ -768,9 +875,9 @@ int pers_occupancy() {                                               // resident
   }
   return occ;
 }
-template <int K, int KD, int KP>
+template <int K, int KD, int KP, int LIT = 0>
 bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
-  const int occ = pers_occupancy<K, KD, KP>();
+  const int occ = pers_occupancy<K, KD, KP, LIT>();
   if (occ <= 0) return false;
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
@@ -785,7 +892,7 @@ bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
   const uint64_t units_last = tpw_last ? (rem + tpw_last - 1) / tpw_last : 0;
   if ((full + 1) * W > a.pf_cap || full + 1 > a.pf_rec_rounds || full > 0xFFFFull) return false;   // (the round number is part of a block sum's tag: 16 bits = 64 Ki rounds of 180 MiB)
   a.pf_full = static_cast<uint32_t>(full); a.pf_tpw_last = static_cast<uint32_t>(tpw_last); a.pf_units_last = static_cast<uint32_t>(units_last);
-  hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP, LIT>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
   if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, W, a.total);
   return true;
 }
@@ -822,6 +929,14 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const uint64_t* counts, uin
 hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* persistent) {
   if (persistent) *persistent = false;
   const ChainAux& c = *reinterpret_cast<const ChainAux*>(a.chain);
+  if (const int nc = literal_shape(c)) {                              // literal mode: the persistent kernel or nothing (the caller keeps the chain kernel)
+    if (a.pf_status == nullptr) return hipErrorInvalidValue;
+    const bool done = nc == 2 ? launch_pers_inst<2, kClsByte, kClsByte, 2>(a, stream) : nc == 3 ? launch_pers_inst<2, kClsByte, kClsByte, 3>(a, stream)
+                                                                                                : launch_pers_inst<2, kClsByte, kClsByte, 4>(a, stream);
+    if (!done) return hipErrorInvalidValue;
+    if (persistent) *persistent = true;
+    return hipGetLastError();
+  }
   const int k = fields_shape(c);
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   if (a.pf_status != nullptr) {                                      // persistent grid, deferred ordering (k_scan_fields_pers)

@@ -31,6 +31,10 @@ def lib():
         L.emu_find_all_fields.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int]
         L.emu_find_all_fields2.restype = C.c_int64
         L.emu_find_all_fields2.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.emu_find_all_literal.restype = C.c_int64
+        L.emu_find_all_literal.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.emu_literal_shape.restype = C.c_int
+        L.emu_literal_shape.argtypes = [C.c_char_p]
         L.emu_fields_shape.restype = C.c_int
         L.emu_fields_shape.argtypes = [C.c_char_p]
         L.emu_find_all_trio.restype = C.c_int64
@@ -197,6 +201,25 @@ def find_all_fields(blob: bytes, hay, own_words: int = 60, pre_words: int = 1):
         n = lib().emu_find_all_fields2(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words), int(pre_words))
         if n <= -16:
             return None
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
+            return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
+
+
+def literal_shape(blob: bytes) -> int:
+    """Number of distinct bytes (2..4) when the persistent kernel's literal mode serves the program (a border-free literal), else 0."""
+    return int(lib().emu_literal_shape(blob))
+
+
+def find_all_literal(blob: bytes, hay, own_words: int = 60, pre_words: int = 2):
+    """Sequential twin of k_scan_fields_pers's literal mode (lit_core)."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_literal(blob, padded.ctypes.data, a.size, out.ctypes.data, cap, int(own_words), int(pre_words))
         assert n >= 0, f"emulator error {n}"
         if n <= cap:
             return out[:n].reshape(-1, 2).copy()

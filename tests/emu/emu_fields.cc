@@ -330,3 +330,105 @@ extern "C" int64_t emu_find_all_trio(const uint8_t* blob, const uint8_t* hay, ui
   if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
   return n;
 }
+
+// ---- twin of k_scan_fields_pers's literal mode (scan_fields_wave.hip lit_core) ------------------------------------------------
+// One bitmap per distinct byte of the literal, occurrences O = AND_j (B_c(j) >> j) by the kernel's 128-bit funnel shifts (this
+// lane's word and the next one's), starts restricted to the owned lanes, ends = O << m with the bits that leave a word arriving in
+// the next lane's.  Rows: per end bit the highest start below it in (previous word : this word), as fields_rows does.
+namespace {
+int literal_shape_host(const ChainAux& c) {      // scan_fields_wave.hip literal_shape
+  if (c.nops < 2 || c.nops > 63 || c.ncls < 2 || c.ncls > 4 || c.restart_check) return 0;
+  uint8_t lit[64];
+  for (uint32_t k = 0; k < c.nops; k++) {
+    const uint32_t q = c.op_cls[k];
+    if (c.op_kind[k] != kChainByte || q >= c.ncls || c.cls_kind[q] == kClsSet || c.cls_kind[q] == kClsDigit || c.cls_lo[q] != c.cls_hi[q] || c.cls_lo[q] > 0x7Fu) return 0;
+    lit[k] = c.cls_lo[q];
+  }
+  for (uint32_t q = 0; q < c.ncls; q++) for (uint32_t r = q + 1; r < c.ncls; r++) if (c.cls_lo[q] == c.cls_lo[r]) return 0;
+  for (uint32_t b = 1; b < c.nops; b++) {
+    bool same = true;
+    for (uint32_t i = 0; i < b && same; i++) same = lit[i] == lit[c.nops - b + i];
+    if (same) return 0;
+  }
+  return static_cast<int>(c.ncls);
+}
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t k) { return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (k & 31u)); }
+}  // namespace
+
+extern "C" int emu_literal_shape(const uint8_t* blob) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic || !(h->flags & kFlagChainOrdered) || (h->flags & (kFlagChainBounded | kFlagChainSets))) return 0;
+  return literal_shape_host(*reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256));
+}
+
+extern "C" int64_t emu_find_all_literal(const uint8_t* blob, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals, int own_words, int pre_words) {
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(blob);
+  if (h->magic != kBlobMagic) return -1;
+  if (!(h->flags & kFlagChainOrdered)) return -4;
+  const ChainAux& ch = *reinterpret_cast<const ChainAux*>(blob + h->aux_off + 256);
+  const int NC = literal_shape_host(ch);
+  if (!NC) return -5;
+  if (own_words < 1 || pre_words < 1 || pre_words > 2 || own_words + pre_words > 63) return -2;
+  const uint32_t m = ch.nops;
+  const int64_t tile_bytes = 64LL * own_words, pre = 64LL * pre_words, N = 4096;
+  const unsigned long long own_mask = ((1ull << own_words) - 1ull) << pre_words;
+  std::vector<int64_t> res;
+  const uint64_t ntiles = (len + tile_bytes - 1) / tile_bytes;
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const int64_t wlo = static_cast<int64_t>(t) * tile_bytes - pre;
+    uint32_t w0[4][64], w1[4][64];
+    std::memset(w0, 0, sizeof w0); std::memset(w1, 0, sizeof w1);
+    for (int64_t b = 0; b < N; b++) {
+      const int64_t p = wlo + b;
+      if (p < 0 || p >= static_cast<int64_t>(len)) continue;
+      for (int c = 0; c < NC; c++) if (hay[p] == ch.cls_lo[c]) { if (b & 32) w1[c][b >> 6] |= 1u << (b & 31); else w0[c][b >> 6] |= 1u << (b & 31); }
+    }
+    uint32_t o0[64], o1[64];
+    for (int l = 0; l < 64; l++) {
+      uint32_t a0 = ~0u, a1 = ~0u;
+      for (uint32_t j = 0; j < m; j++) {
+        const uint32_t c = static_cast<uint32_t>((j < 32u ? ch.cls2_lo >> (2u * j) : ch.cls2_hi >> (2u * (j - 32u))) & 3ull);
+        const uint32_t h0 = w0[c][l], h1 = w1[c][l], n0 = l < 63 ? w0[c][l + 1] : 0u, n1 = l < 63 ? w1[c][l + 1] : 0u;
+        uint32_t r0, r1;
+        if (j < 32u) { r0 = alignbit(h1, h0, j); r1 = alignbit(n0, h1, j); }
+        else { r0 = alignbit(n0, h1, j - 32u); r1 = alignbit(n1, n0, j - 32u); }
+        a0 &= r0; a1 &= r1;
+      }
+      const bool own = (own_mask >> l) & 1ull;
+      o0[l] = own ? a0 : 0u; o1[l] = own ? a1 : 0u;
+    }
+    for (int l = 0; l < 64; l++) {
+      const uint32_t p0 = l ? o0[l - 1] : 0u, p1 = l ? o1[l - 1] : 0u;
+      uint32_t e0, e1;
+      if (m < 32u) { e0 = alignbit(o0[l], p1, 32u - m); e1 = alignbit(o1[l], o0[l], 32u - m); }
+      else if (m == 32u) { e0 = p1; e1 = o0[l]; }
+      else { e0 = alignbit(p1, p0, 64u - m); e1 = alignbit(o0[l], p1, 64u - m); }
+      const uint32_t b0 = o0[l], b1 = o1[l], pb0 = p0, pb1 = p1;
+      const uint32_t lane64 = static_cast<uint32_t>(l) << 6;
+      auto emit = [&](uint32_t s, uint32_t e) { res.push_back(wlo + s); res.push_back(wlo + e); };
+      {
+        const uint32_t tp = umin(ffbh_raw(pb1) | 32u, ffbh_raw(pb0) | 64u);
+        uint32_t xx = e0;
+        while (xx) {
+          const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+          xx &= xx - 1u;
+          const uint32_t d = umin(ffbh_raw(b0 & ((1u << b) - 1u)), tp);
+          emit((lane64 + 31u - d) & 0xFFFFu, lane64 + b);
+        }
+      }
+      {
+        const uint32_t tp = umin(umin(ffbh_raw(b0) | 32u, ffbh_raw(pb1) | 64u), ffbh_raw(pb0) | 96u);
+        uint32_t xx = e1;
+        while (xx) {
+          const uint32_t b = static_cast<uint32_t>(__builtin_ctz(xx));
+          xx &= xx - 1u;
+          const uint32_t d = umin(ffbh_raw(b1 & ((1u << b) - 1u)), tp);
+          emit((lane64 + 63u - d) & 0xFFFFu, lane64 + 32u + b);
+        }
+      }
+    }
+  }
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n <= cap_vals) std::memcpy(out, res.data(), n * sizeof(int64_t));
+  return n;
+}
