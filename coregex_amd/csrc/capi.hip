@@ -18,6 +18,7 @@
 #include "device/synth.hpp"
 #include "device/block_common.hpp"
 #include "device/walk.hpp"
+#include "device/wave_common.hpp"
 #include "device/fsm.hpp"
 #include "device/bt.hpp"
 #include "host/frontend.h"
@@ -489,6 +490,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.pf_status = nullptr;                                           // (set per launch by the fields programs' branch below)
+  std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
   a.u32_rows = t_u32Rows ? 1u : 0u;
   if (a.u32_rows && (len >> 32) != 0) return fail(CXG_E_INVALID, "compact rows: the haystack must be shorter than 4 GiB (shard it)");
   a.hay = static_cast<const uint8_t*>(d_hay);
@@ -660,6 +662,12 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     // `Q[^Q]*Q` programs count EVENTS (occurrences of Q, two per row) in the look-back: FindAll's n is 2 n events
     const bool pairsProg = reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off)->pairs != 0u;
     cxgdev::ScanArgs b = a;
+    {
+      const cxgdev::CharClassAux* cax = reinterpret_cast<const cxgdev::CharClassAux*>(p->blob.data() + h->aux_off);
+      static const bool plansOk = getenv("CXG_NO_PLANS") == nullptr;   // A/B: the generic range tests
+      b.plan = cxgdev::plan_class(cax->nr, cax->lo, cax->hi);
+      b.plan_shape = plansOk ? static_cast<uint32_t>(cxgdev::plan_shape(b.plan)) : 0u;
+    }
     if (pairsProg) b.limit = a.limit * 2u;
     le = cxgdev::launch_scan_charclass_wave(b, stream);
   }
@@ -744,6 +752,17 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     }
     if (a.u32_rows && a.out != nullptr && !((fieldsKernel || litKernel) && a.pf_status != nullptr))
       return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
+    if (trioKernel) {                                               // the field class as a class plan (wave_common.hpp)
+      const cxgdev::ChainAux* tc = reinterpret_cast<const cxgdev::ChainAux*>(a.chain);
+      uint8_t lo1[4] = {0, 0, 0, 0}, hi1[4] = {0, 0, 0, 0};
+      uint32_t n1 = 1;
+      if (tc->cls_kind[0] == cxgdev::kClsSet) { n1 = tc->cls_nr[0]; for (uint32_t q = 0; q < 4; q++) { lo1[q] = tc->cls_rlo[0][q]; hi1[q] = tc->cls_rhi[0][q]; } }
+      else if (tc->cls_kind[0] == cxgdev::kClsDigit) { lo1[0] = 0x30; hi1[0] = 0x39; }
+      else { lo1[0] = tc->cls_lo[0]; hi1[0] = tc->cls_hi[0]; }
+      static const bool plansOk = getenv("CXG_NO_PLANS") == nullptr;
+      a.plan = cxgdev::plan_class(n1, lo1, hi1);
+      a.plan_shape = plansOk ? static_cast<uint32_t>(cxgdev::plan_shape(a.plan)) : 0u;
+    }
     le = hipSuccess;
     if (litKernel) {                                                // (a launch the persistent geometry cannot hold: the chain kernel below)
       le = cxgdev::launch_scan_fields_wave(a, stream, &persKernel);

@@ -30,6 +30,13 @@
 #include "walk.hpp"
 #include "wave_common.hpp"
 
+#ifndef CXG_CC_PLANS
+#define CXG_CC_PLANS 1
+#endif
+#ifndef CXG_CC_LOAD_AUX
+#define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
+#endif
+
 namespace cxgdev {
 
 namespace {
@@ -63,6 +70,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const bool pairs = ax->pairs != 0u;
 #pragma unroll
   for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
+  // round 5: the ranges as a class plan (wave_common.hpp: `\w` in 9 instructions per dword instead of 15); shape 0 keeps notset4
+  static_assert(CXG_CC_PLANS == 0 || CXG_CC_PLANS == 1, "");
+  const ClassPlan& plan = a.plan;                                     // kernel arguments: scalar loads
+  const int shape = CXG_CC_PLANS ? static_cast<int>(a.plan_shape) : 0;
   __syncthreads();
   const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     const int pre = (nrec && lo) ? 16 : 0;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, 0);
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, CXG_CC_LOAD_AUX);
     xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, pre ? 12 : nrec + pre, 0);
   };
   issue_loads(0);
@@ -101,13 +112,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
       const int32_t stage = rend < kWin ? rend : kWin;
       uint16_t* pieces = reinterpret_cast<uint16_t*>(s_m[wave]);
+      with_shape(shape, [&]<int SHAPE>() {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t lo = __builtin_amdgcn_udot4(notset4(x[k].y, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].x, rg), 0x08040201u, 0u, false), false);
-        const uint32_t hi = __builtin_amdgcn_udot4(notset4(x[k].w, rg), 0x80402010u, __builtin_amdgcn_udot4(notset4(x[k].z, rg), 0x08040201u, 0u, false), false);
-        pieces[lane + 64 * k] = static_cast<uint16_t>(((lo >> 7) | (hi << 1)) ^ flip);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int k = 0; k < 4; k++) {
+          pieces[lane + 64 * k] = static_cast<uint16_t>(notshape16<SHAPE>(x[k], plan, rg) ^ flip);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
       const uint32_t xprev_cur = xprev;
       issue_loads(j + 1);
       wave_lds_sync();

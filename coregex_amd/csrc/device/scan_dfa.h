@@ -47,6 +47,10 @@ inline WalkLimit walk_limit(uint64_t remaining, int32_t window) {
 constexpr int kPfBlocks = 128;
 constexpr uint64_t kPfRecStride = 3ull * kPfBlocks;
 
+// A union of <= 4 ASCII ranges prepared for the SWAR class tests (wave_common.hpp "class plans"): nx X terms (xc, xk), nr R terms
+// (ra, rb; the first one over the case-folded bytes when fold).  ok == 0: a bound >= 0x80 — the kernel keeps notset4 / its table.
+struct ClassPlan { uint32_t nx, nr, fold, ok; uint32_t xc[4], xk[4], ra[4], rb[4]; };
+
 struct ScanArgs {
   const uint8_t* hay;   // device, 16-byte aligned
   uint64_t len;
@@ -83,6 +87,8 @@ struct ScanArgs {
   uint64_t* pf_rec;     // [pf_rec_rounds][384] per round: 128 records {rows of the round in front of the block, rows of the round} + 128 block sums, each word tagged pf_epoch << 48
   uint64_t pf_rec_rounds;
   uint64_t* pf_stats;   // [8192] per wave: units that waited << 32 | polls (CXG_VERBOSE)
+  ClassPlan plan;       // scan_charclass_wave.hip: the class; k_scan_trio_wave: the field class (filled on the host per launch)
+  uint32_t plan_shape;  // wave_common.hpp plan_shape(plan); 0: the generic range tests
   uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };
 

@@ -985,6 +985,9 @@ namespace {
 #ifndef CXG_TRIO_WAVES
 #define CXG_TRIO_WAVES 8
 #endif
+#ifndef CXG_TRIO_SWAR
+#define CXG_TRIO_SWAR 1
+#endif
 constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per wave and group
 
 struct TrioTile { uint32_t e0, e1; bool ovf; };
@@ -1145,6 +1148,25 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_sca
     for (int i = 0; i < K - 1; i++) f |= chain_class_has(*gch, gch->op_cls[2 * i + 1], b) ? (2u << i) : 0u;
     s_cls[tid] = static_cast<uint8_t>(f);
   }
+  SetRanges frg;                                                     // class 0 as ranges (trio_shape: ASCII), the separators as splat bytes
+  uint32_t sep4[K - 1];
+  bool swar_ok = CXG_TRIO_SWAR != 0;                                  // (uniform) every bound below 0x80: the SWAR tests see bytes >= 0x80 as outside
+  {
+    const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
+    const uint32_t kind0 = gch->cls_kind[0];
+    frg.n = kind0 == kClsSet ? gch->cls_nr[0] : 1u;
+    for (uint32_t q = 0; q < frg.n && q < 4u; q++) swar_ok = swar_ok && (kind0 == kClsSet ? gch->cls_rhi[0][q] : kind0 == kClsDigit ? 0x39u : gch->cls_hi[0]) < 0x80u;
+    for (int i = 0; i < K - 1; i++) swar_ok = swar_ok && gch->cls_lo[gch->op_cls[2 * i + 1]] < 0x80u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t lo = kind0 == kClsSet ? gch->cls_rlo[0][q] : kind0 == kClsDigit ? 0x30u : gch->cls_lo[0];
+      const uint32_t hi = kind0 == kClsSet ? gch->cls_rhi[0][q] : kind0 == kClsDigit ? 0x39u : gch->cls_hi[0];
+      frg.lo4[q] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo * 0x01010101u)));
+      frg.hi4[q] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - hi) * 0x01010101u)));
+    }
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) sep4[i] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[gch->op_cls[2 * i + 1]] * 0x01010101u)));
+  }
   __syncthreads();
   constexpr int tpw = kTilesPerWave;
   uint32_t nrows_w = 0, fallback = 0;
@@ -1159,7 +1181,22 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_sca
     asm volatile("" : "+v"(lane));
     int32_t nvalid_next = 0;
     const __amdgpu_buffer_rsrc_t rnext = fields_window(a.hay, a.len, tile_lo_of(j + 1), j + 1 < tpw, nvalid_next);
-    // ---- A: one table lookup per byte; 16 flags per class and vector through the LDS scratch
+    // ---- A: class flags, 16 per class and vector through the LDS scratch.  CXG_TRIO_SWAR (round 5): F as a union of <= 4 ASCII ranges
+    // by SWAR compares and the separators as byte compares, as the fields kernel does — no LDS lookups (the byte table cost 16
+    // ds_read_u8 per vector and lane: the LDS pipe of a CU, shared by its four SIMDs, was as busy as the VALUs).  0: the table.
+    if (swar_ok) {
+      uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
+      const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32x4 t = x[k] & 0x7F7F7F7Fu;
+        with_shape(static_cast<int>(a.plan_shape), [&]<int SHAPE>() { pd[lane + 64 * k] = static_cast<uint16_t>(notshape16<SHAPE>(x[k], a.plan, frg) ^ 0xFFFFu); });
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) reinterpret_cast<uint16_t*>(s_c[i][wave])[lane + 64 * k] = static_cast<uint16_t>(piece16<kClsByte>(x[k], t, sep4[i], 0u));
+        x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, voff + 1024u * k, 0, CXG_HAY_LOAD_AUX);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
     {
       uint16_t* pd = reinterpret_cast<uint16_t*>(s_d[wave]);
       const uint32_t voff = static_cast<uint32_t>(lane) << 4;

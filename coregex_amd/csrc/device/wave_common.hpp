@@ -20,6 +20,116 @@ __device__ __forceinline__ uint32_t notset4(uint32_t x, const SetRanges& r) {
   return ~(in & ~x) & 0x80808080u;
 }
 
+// ---- class plans (round 5) ---------------------------------------------------------------------------------------------------
+// The same union of ASCII ranges evaluated with fewer instructions per dword: with t = x & 0x7F7F7F7F (shared),
+//   * an X term — a single byte, or a range [lo, lo + span] whose lo has its low ceil(log2(span + 1)) bits clear (the digits:
+//     0x30..0x39): (t ^ lo) + (0x7F - span) carries into bit 7 exactly for the bytes OUTSIDE it — one v_xad_u32;
+//   * an R term — any other range: (s + 0x80 - lo) & ~(s + 0x7F - hi) has bit 7 set exactly inside it — two adds;
+//   * FOLD — the R terms [lo, hi] and [lo + 0x20, hi + 0x20] with 0x40 <= lo, hi <= 0x5F (`A-Z` and `a-z`) are ONE R term over
+//     s = x & 0x5F5F5F5F (bit 5 cleared).
+// `\w` = [0-9A-Z_a-z] is two X terms (digits, `_`) and one folded R term: 9 instructions per dword instead of 15.
+// (struct ClassPlan: scan_dfa.h, beside ScanArgs)
+__host__ __device__ inline ClassPlan plan_class(uint32_t n, const uint8_t* lo, const uint8_t* hi) {   // run on the HOST per launch (ScanArgs::plan: kernel arguments, scalar loads)
+  ClassPlan p;
+  p.nx = p.nr = p.fold = 0; p.ok = 1;
+  uint32_t rl[4], rh[4], nrr = 0;
+  for (uint32_t i = 0; i < 4; i++) { p.xc[i] = p.xk[i] = p.ra[i] = p.rb[i] = 0; rl[i] = rh[i] = 0; }
+  for (uint32_t i = 0; i < n && i < 4u; i++) {
+    const uint32_t a = lo[i], b = hi[i];
+    if (b > 0x7Fu || a > b) { p.ok = 0; continue; }
+    const uint32_t span = b - a;
+    uint32_t bits = 0;
+    while ((1u << bits) <= span) bits++;
+    if ((a & ((1u << bits) - 1u)) == 0u) { p.xc[p.nx] = a * 0x01010101u; p.xk[p.nx] = (0x7Fu - span) * 0x01010101u; p.nx++; }
+    else { rl[nrr] = a; rh[nrr] = b; nrr++; }
+  }
+  // fold one pair of R ranges that differ by 0x20 (upper / lower case)
+  for (uint32_t i = 0; i < nrr && !p.fold; i++)
+    for (uint32_t j = 0; j < nrr && !p.fold; j++)
+      if (i != j && rl[i] >= 0x40u && rh[i] <= 0x5Fu && rl[j] == rl[i] + 0x20u && rh[j] == rh[i] + 0x20u) {
+        p.fold = 1;
+        const uint32_t a = rl[i], b = rh[i];
+        uint32_t kl[4], kh[4], kn = 0;
+        for (uint32_t q = 0; q < nrr; q++) if (q != i && q != j) { kl[kn] = rl[q]; kh[kn] = rh[q]; kn++; }
+        rl[0] = a; rh[0] = b;
+        for (uint32_t q = 0; q < kn; q++) { rl[q + 1] = kl[q]; rh[q + 1] = kh[q]; }
+        nrr = kn + 1;
+      }
+  for (uint32_t i = 0; i < nrr; i++) { p.ra[i] = (0x80u - rl[i]) * 0x01010101u; p.rb[i] = (0x7Fu - rh[i]) * 0x01010101u; }
+  p.nr = nrr;
+  return p;
+}
+__device__ __forceinline__ uint32_t xad_u32(uint32_t t, uint32_t c, uint32_t k) {   // (t ^ c) + k; c uniform (the one scalar operand), k in a register
+  uint32_t r;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "s"(c), "v"(k));
+  return r;
+}
+// 0x80 in every byte of x that is NOT a member (notset4's convention), for a plan of exactly NX X terms and NR R terms.
+template <int NX, int NR, bool FOLD>
+__device__ __forceinline__ uint32_t notplan4(uint32_t x, const ClassPlan& p) {
+  const uint32_t t = x & 0x7F7F7F7Fu;
+  uint32_t in = 0;
+#pragma unroll
+  for (int i = 0; i < NX; i++) in |= ~xad_u32(t, p.xc[i], p.xk[i]);
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    const uint32_t s = (FOLD && i == 0) ? (x & 0x5F5F5F5Fu) : t;
+    in |= (s + p.ra[i]) & ~(s + p.rb[i]);
+  }
+  return ~(in & ~x) & 0x80808080u;
+}
+
+// The shapes the kernels instantiate (a uniform switch around the classification of a whole window); 0: notset4.
+__host__ __device__ inline int plan_shape(const ClassPlan& p) {
+  if (!p.ok) return 0;
+  const uint32_t key = p.nx * 100u + p.nr * 10u + p.fold;
+  switch (key) {
+    case 211: return 1;   // \w
+    case 111: return 2;   // [A-Za-z0-9]
+    case 11: return 3;    // [A-Za-z]
+    case 100: return 4;   // \d, one byte
+    case 10: return 5;    // [a-z]
+    case 200: return 6;   // two X terms
+    case 110: return 7;   // [a-z0-9]
+    case 300: return 8;   // [.,;]
+    default: return 0;
+  }
+}
+template <int SHAPE>
+__device__ __forceinline__ uint32_t notshape4(uint32_t x, const ClassPlan& p, const SetRanges& r) {
+  if (SHAPE == 1) return notplan4<2, 1, true>(x, p);
+  if (SHAPE == 2) return notplan4<1, 1, true>(x, p);
+  if (SHAPE == 3) return notplan4<0, 1, true>(x, p);
+  if (SHAPE == 4) return notplan4<1, 0, false>(x, p);
+  if (SHAPE == 5) return notplan4<0, 1, false>(x, p);
+  if (SHAPE == 6) return notplan4<2, 0, false>(x, p);
+  if (SHAPE == 7) return notplan4<1, 1, false>(x, p);
+  if (SHAPE == 8) return notplan4<3, 0, false>(x, p);
+  return notset4(x, r);
+}
+// 16 NOT-member bits of a 16-byte vector (bits above 15 are garbage: ds_write_b16 drops them)
+template <int SHAPE>
+__device__ __forceinline__ uint32_t notshape16(const u32x4& x, const ClassPlan& p, const SetRanges& r) {
+  const uint32_t lo = __builtin_amdgcn_udot4(notshape4<SHAPE>(x.y, p, r), 0x80402010u, __builtin_amdgcn_udot4(notshape4<SHAPE>(x.x, p, r), 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(notshape4<SHAPE>(x.w, p, r), 0x80402010u, __builtin_amdgcn_udot4(notshape4<SHAPE>(x.z, p, r), 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1);
+}
+// `f.template operator()<SHAPE>()` for the plan's shape (uniform switch)
+template <class F>
+__device__ __forceinline__ void with_shape(int shape, F&& f) {
+  switch (shape) {
+    case 1: f.template operator()<1>(); break;
+    case 2: f.template operator()<2>(); break;
+    case 3: f.template operator()<3>(); break;
+    case 4: f.template operator()<4>(); break;
+    case 5: f.template operator()<5>(); break;
+    case 6: f.template operator()<6>(); break;
+    case 7: f.template operator()<7>(); break;
+    case 8: f.template operator()<8>(); break;
+    default: f.template operator()<0>(); break;
+  }
+}
+
 // Neighbour-lane moves as DPP wavefront shifts (one VALU op per dword, no LDS crossbar round trip).
 __device__ __forceinline__ uint32_t dpp_from_lower(uint32_t v) {  // lane i <- lane i-1 (lane 0 keeps its own)
   return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));

@@ -17,7 +17,7 @@ for o in $(cd $SRC/build && find . -name '*.o' | sed 's|^\./||'); do
   for f in "$@"; do
     if [ "$f" = "$s" ]; then
       mkdir -p $(dirname $SRC/build_var/$NAME/$o)
-      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $EXTRA -x hip -c $SRC/$s -o $SRC/build_var/$NAME/$o
+      /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wno-unused-function $EXTRA -x hip -c $SRC/$s -o $SRC/build_var/$NAME/$o
       use=$SRC/build_var/$NAME/$o
     fi
   done
