@@ -44,7 +44,7 @@ class Timing(C.Structure):
 class PathState(C.Structure):
     """cxg_path_state_t: launch-mode demotions of a device (watchdog hygiene, include/coregex_hip.h)."""
     _fields_ = [("static_penalty", C.c_uint32), ("static_hits", C.c_uint32), ("persistent_penalty", C.c_uint32), ("persistent_hits", C.c_uint32),
-                ("delim_penalty", C.c_uint32), ("delim_hits", C.c_uint32), ("persistent_in_flight", C.c_uint32), ("reserved", C.c_uint32)]
+                ("delim_penalty", C.c_uint32), ("delim_hits", C.c_uint32), ("order_waiters", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class NfaTrans(C.Structure):

@@ -86,17 +86,16 @@ struct PathMode {
 };
 struct PathState {
   PathMode staticGroups, persistent, delim;
-  // One persistent launch at a time per device from THIS process: two of them would each hold half the CUs and wait for waves
-  // that cannot become resident (every goroutine of a cgo host may be scanning).  The second caller takes the grouped kernel.
-  std::atomic<int> persInFlight{0};
+  // ONE order-dependent launch at a time per device from THIS process (every goroutine of a cgo host may be scanning): two
+  // persistent grids would each hold half the CUs and wait for waves that cannot become resident, and a persistent grid beside a
+  // static-group kernel deadlocks just the same — the resident workgroups of either wait (for co-residency resp. for the look-back
+  // word of a group that is not resident yet) in the slots the other one needs; measured in round 5: two threads scanning 1 GiB each
+  // ran into the 0.4 s watchdog.  Such launches take this mutex from launch to completion; the scans are HBM-bound, so callers
+  // lose nothing by taking turns.  Ticket-mode and table-walking launches wait for nothing that is not running and stay outside.
+  std::mutex orderMutex;
+  std::atomic<uint32_t> orderWaiters{0};
 };
 PathState g_path[16];
-struct PersSlot {                       // RAII: the persistent-launch slot of a device
-  std::atomic<int>* f = nullptr;
-  bool tryAcquire(std::atomic<int>& flag) { int z = 0; if (flag.compare_exchange_strong(z, 1)) { f = &flag; return true; } return false; }
-  void release() { if (f) { f->store(0); f = nullptr; } }
-  ~PersSlot() { release(); }
-};
 
 int deviceCount() {
   static int n = -1;
@@ -590,8 +589,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   litKernel = false;
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
-  PersSlot persSlot;                                               // released when this iteration ends (every path out of it)
   a.static_groups = (gen >= 6 && !staticDenied) ? 1u : 0u;
+  std::unique_lock<std::mutex> orderLock(ps.orderMutex, std::defer_lock);   // released when this iteration ends (every path out of it)
+  if (a.static_groups) { ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); orderLock.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed); }
   if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
@@ -701,7 +701,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
     bool persWanted = (fieldsKernel || litKernel) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
     if (persWanted && !ps.persistent.allowed()) { ps.persistent.consume(); persDenied = true; persWanted = false; }
-    if (persWanted && !persSlot.tryAcquire(ps.persInFlight)) persWanted = false;   // another thread's persistent launch is in flight on this device
     if (persWanted) {
       const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
       const uint64_t need = nwt / 4u + 2u * 8192u + 64u;                                       // (full rounds + 1) x W unit words, W <= 8192 waves
@@ -860,7 +859,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
     }
   }
-  persSlot.release();
+  if (orderLock.owns_lock()) orderLock.unlock();
   if (err & 2u) {
     static const bool wdVerbose = getenv("CXG_VERBOSE") != nullptr;
     const uint32_t origin = (err >> 24) & 15u;
@@ -1434,7 +1433,7 @@ int cxg_path_state(int device, cxg_path_state_t* out) {
   out->static_penalty = ps.staticGroups.penalty.load(); out->static_hits = ps.staticGroups.hits.load();
   out->persistent_penalty = ps.persistent.penalty.load(); out->persistent_hits = ps.persistent.hits.load();
   out->delim_penalty = ps.delim.penalty.load(); out->delim_hits = ps.delim.hits.load();
-  out->persistent_in_flight = static_cast<uint32_t>(ps.persInFlight.load());
+  out->order_waiters = ps.orderWaiters.load();
   out->reserved = 0;
   return CXG_OK;
 }

@@ -322,7 +322,7 @@ struct LitRegs { uint32_t m, nc; uint32_t b4[4]; uint64_t cls2_lo, cls2_hi; };  
 
 template <int NC, bool CARRY>
 __device__ __forceinline__ void lit_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t rnext, int lane, uint64_t* sc0, int32_t nvalid, const LitRegs& lr,   // sc0: this wave's words of class 0; class c at + c * kLitClsStride
-                                          uint32_t (&w0)[NC], uint32_t (&w1)[NC], bool carry_cur, bool carry_next) {
+                                          bool carry_cur, bool carry_next) {
   {
     const uint32_t voff = static_cast<uint32_t>(lane) << 4;
 #pragma unroll
@@ -341,38 +341,40 @@ __device__ __forceinline__ void lit_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t 
   wave_lds_sync();
   int lw = lane;
   asm volatile("" : "+v"(lw));
-  uint64_t vf = ~0ull;
-  if (nvalid != kFWin) {
+  if (nvalid != kFWin) {                                            // short last window (rare): what lies behind the input is no byte of the literal
     const int32_t nf = nvalid - 64 * lane;
-    vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
-  }
+    const uint64_t vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
 #pragma unroll
-  for (int c = 0; c < NC; c++) {
-    const uint64_t W = sc0[c * kLitClsStride + lw] & vf;
-    w0[c] = static_cast<uint32_t>(W); w1[c] = static_cast<uint32_t>(W >> 32);
-    if (CARRY && carry_next && lane >= 60) sc0[c * kLitClsStride + lane - 60] = W;
+    for (int c = 0; c < NC; c++) sc0[c * kLitClsStride + lw] &= vf;
+    wave_lds_sync();
   }
+  (void)lw;
+}
+// words 60..63 are the next window's words 0..3 — BEHIND lit_core, which reads the bitmaps from LDS
+template <int NC>
+__device__ __forceinline__ void lit_carry(uint64_t* sc0, int lane) {
+  if (lane >= 60) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) sc0[c * kLitClsStride + lane - 60] = sc0[c * kLitClsStride + lane];
+  }
+  wave_lds_sync();
 }
 
-// (h1:h0 of this lane, n1:n0 of the next lane) >> k, 0 <= k < 64, low 64 bits
-__device__ __forceinline__ void shr128(uint32_t h0, uint32_t h1, uint32_t n0, uint32_t n1, uint32_t k, uint32_t& r0, uint32_t& r1) {
-  if (k < 32u) { r0 = __builtin_amdgcn_alignbit(h1, h0, k); r1 = __builtin_amdgcn_alignbit(n0, h1, k); }
-  else { r0 = __builtin_amdgcn_alignbit(n0, h1, k - 32u); r1 = __builtin_amdgcn_alignbit(n1, n0, k - 32u); }
-}
-template <int NC, unsigned long long OWN>
-__device__ __forceinline__ FieldsTile lit_core(const uint32_t (&w0)[NC], const uint32_t (&w1)[NC], const LitRegs& lr) {
-  uint32_t n0[NC], n1[NC];
-#pragma unroll
-  for (int c = 0; c < NC; c++) {                                     // the next lane's words (behind the window: nothing)
-    n0[c] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(w0[c]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-    n1[c] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(w1[c]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));
-  }
+// The bitmaps stay in LDS: step j reads the words of its class at this lane and the next one (one ds_read2_b64, a scalar base per
+// class) and funnels them right by j.  No register arrays, no branch inside the step.
+template <unsigned long long OWN>
+__device__ __forceinline__ FieldsTile lit_core(const uint64_t* sc0, int lane, const LitRegs& lr) {
   uint32_t o0 = ~0u, o1 = ~0u;
-  for (uint32_t j = 0; j < lr.m; j++) {                               // uniform trip count and shifts
-    const uint32_t c = static_cast<uint32_t>((j < 32u ? lr.cls2_lo >> (2u * j) : lr.cls2_hi >> (2u * (j - 32u))) & 3ull);
-    uint32_t r0 = 0, r1 = 0;
-#pragma unroll
-    for (int q = 0; q < NC; q++) if (c == static_cast<uint32_t>(q)) shr128(w0[q], w1[q], n0[q], n1[q], j, r0, r1);
+  const uint64_t* base = sc0 + lane;
+  auto cls_of = [&](uint32_t j) -> uint32_t { return static_cast<uint32_t>((j < 32u ? lr.cls2_lo >> (2u * j) : lr.cls2_hi >> (2u * (j - 32u))) & 3ull); };
+  const uint64_t* w = base + cls_of(0) * kLitClsStride;
+  uint64_t cur = w[0], nxt = w[1];                                    // (lane 63 reads a dump word: it owns nothing)
+  for (uint32_t j = 0; j < lr.m; j++) {                               // uniform trip count, shifts and classes; the next step's words are on their way
+    const uint32_t h0 = static_cast<uint32_t>(cur), h1 = static_cast<uint32_t>(cur >> 32), n0 = static_cast<uint32_t>(nxt), n1 = static_cast<uint32_t>(nxt >> 32);
+    if (j + 1u < lr.m) { w = base + cls_of(j + 1u) * kLitClsStride; cur = w[0]; nxt = w[1]; }
+    uint32_t r0, r1;
+    if (j < 32u) { r0 = __builtin_amdgcn_alignbit(h1, h0, j); r1 = __builtin_amdgcn_alignbit(n0, h1, j); }
+    else { r0 = __builtin_amdgcn_alignbit(n0, h1, j - 32u); r1 = __builtin_amdgcn_alignbit(n1, n0, j - 32u); }
     o0 &= r0; o1 &= r1;
   }
   o0 = sel_lanes(o0, OWN); o1 = sel_lanes(o1, OWN);                   // occurrences that START in the tile
@@ -380,7 +382,7 @@ __device__ __forceinline__ FieldsTile lit_core(const uint32_t (&w0)[NC], const u
   const uint32_t p0 = dpp_from_lower_z(o0), p1 = dpp_from_lower_z(o1);
   uint32_t e0, e1;
   const uint32_t m = lr.m;
-  if (m < 32u) { e0 = m ? __builtin_amdgcn_alignbit(o0, p1, 32u - m) : o0; e1 = m ? __builtin_amdgcn_alignbit(o1, o0, 32u - m) : o1; }
+  if (m < 32u) { e0 = __builtin_amdgcn_alignbit(o0, p1, 32u - m); e1 = __builtin_amdgcn_alignbit(o1, o0, 32u - m); }
   else if (m == 32u) { e0 = p1; e1 = o0; }
   else { e0 = __builtin_amdgcn_alignbit(p1, p0, 64u - m); e1 = __builtin_amdgcn_alignbit(o0, p1, 64u - m); }
   return FieldsTile{e0, e1, o0, o1, false};
@@ -584,7 +586,7 @@ constexpr uint32_t kPfSpinLimit = 1u << 18;                  // polls of ~1.5 us
 
 // LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused).
 template <int K, int KD, int KP, int LIT = 0>
-__global__ __launch_bounds__(kThreads, (LIT ? (LIT >= 3 ? 4 : 5) : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (literal mode: 96 / 128 VGPRs, no scratch)
+__global__ __launch_bounds__(kThreads, (LIT >= 4 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (four bitmaps: 29 KB of LDS per workgroup)
   constexpr int kNBitmaps = LIT ? LIT : 2;
   __shared__ __attribute__((aligned(16))) uint64_t s_c[kNBitmaps][kWavesPerBlock][64 + 4];   // class bitmaps of the wave's window (+ 4 dump words: CARRY)
   uint64_t (*const s_d)[64 + 4] = s_c[0];
@@ -744,16 +746,15 @@ __global__ __launch_bounds__(kThreads, (LIT ? (LIT >= 3 ? 4 : 5) : CXG_PF_OCC)) 
         const uint64_t lo_next = (last ? unit_tile(r + 1) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
         const __amdgpu_buffer_rsrc_t rnext = fields_window<kPre>(a.hay, a.len, lo_next, more, nvalid_next);
         uint32_t d0 = 0, d1 = 0, p0 = 0, p1 = 0;
-        uint32_t lw0[kNBitmaps], lw1[kNBitmaps];
-        if (LIT) {
-          lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, lw0, lw1, j != 0u, !last);
-        } else fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
+        if (LIT) lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, j != 0u, !last);
+        else fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
         nvalid_cur = nvalid_next;
         const bool duty = duty_stage != 0u;                           // a leader's look of this tile
         u32x4 dv = {0u, 0u, 0u, 0u};
         if (duty) duty_load(dv);
         if (last && order && r > 0) status_load(r - 1, vr, vs);       // consumed behind this tile's mathematics
-        const FieldsTile t = LIT ? lit_core<kNBitmaps, kOwn>(lw0, lw1, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
+        const FieldsTile t = LIT ? lit_core<kOwn>(&s_c[0][wave][0], lane, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
+        if (LIT && kCarry && !last) lit_carry<kNBitmaps>(&s_c[0][wave][0], lane);
         if (t.ovf) fallback |= 1u;
         const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
         const uint32_t incl = wave_inclusive_sum_fused(c);
@@ -986,7 +987,7 @@ namespace {
 #define CXG_TRIO_WAVES 8
 #endif
 #ifndef CXG_TRIO_SWAR
-#define CXG_TRIO_SWAR 1
+#define CXG_TRIO_SWAR 0                                      // measured (profiles/r05_c2_configs.txt, config 5): SWAR + class plan 0.429 ms, the byte table 0.397
 #endif
 constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per wave and group
 

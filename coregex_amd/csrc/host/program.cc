@@ -537,7 +537,9 @@ bool validateNfa(const cxg_nfa& nfa, std::string& why) {
         break;
       case CXG_NFA_CAPTURE:
         if (!target(s.next)) return bad(i, "next out of range");
-        if (s.cap_index >= nfa.capture_count) return bad(i, "capture index >= capture_count");
+        // capture_count == 1: the caller wants spans only (the FindAllIndex / Count program of an NFA WITH groups — what the cgo shim
+        // passes, integration/go/meta/findall_hip.go nfaProgram): every capture state is then an epsilon to the span program
+        if (nfa.capture_count > 1 && s.cap_index >= nfa.capture_count) return bad(i, "capture index >= capture_count");
         break;
       default: return bad(i, "unknown state kind");
     }

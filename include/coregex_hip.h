@@ -147,7 +147,7 @@ typedef struct cxg_path_state_t {
   uint32_t static_penalty, static_hits;
   uint32_t persistent_penalty, persistent_hits;
   uint32_t delim_penalty, delim_hits;
-  uint32_t persistent_in_flight;   /* 1 while a persistent launch of this process runs on the device (a second caller takes the grouped kernel) */
+  uint32_t order_waiters;          /* threads waiting for the device's order-dependent launch slot (such launches take turns: two of them side by side can deadlock) */
   uint32_t reserved;
 } cxg_path_state_t;
 int cxg_path_state(int device, cxg_path_state_t* out);

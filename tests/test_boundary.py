@@ -245,6 +245,7 @@ def test_constructor_programs_other_shapes(oracle):
     ("literals", ",".join(LITS16), 3, "|".join(LITS16)), ("charclass", "0-9,A-Z,_-_,a-z", 4, r"[\w]+"),
     ("submatch", r"(\w+)@(\w+)\.(\w+)", 5, r"(\w+)@(\w+)\.(\w+)"),
     ("nfa", r"\berror\b", 1, r"\berror\b"), ("nfa", r"(?m)^\d+", 2, r"(?m)^\d+"),
+    ("nfa", r"(\w+)@(\w+)\.(\w+)", 5, r"(\w+)@(\w+)\.(\w+)"),   # spans of a pattern WITH groups: the shim's FindAllIndex program has capture_count 1
 ])
 def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
     """examples/shim_harness.c — the Go shim statement for statement in C (flattenNFA into malloc'ed arrays, constructor,
@@ -268,3 +269,19 @@ def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
     assert rows == exp.tolist()
     if cfg == 4:                                             # [\w]+: ~1 row per 5.5 bytes >> len/100+1: the retry loop ran
         assert "1 capacity retries" in outp.stdout
+
+
+def test_span_program_of_an_nfa_with_groups(oracle):
+    """integration/go/meta/findall_hip.go nfaProgram(captures=false): the NFA of a pattern with groups handed over with capture_count 1 —
+    every capture state is an epsilon to the FindAllIndex / Count program (round 5: the constructor used to refuse this as malformed)."""
+    from twins import rows_on_twin
+    hay = cx.synth_pages(5, 0xC0FFEE05, 3, 8).tobytes() + b" 1.2 a@b.c 10.20 aabc"
+    for pat in (r"(\w+)@(\w+)\.(\w+)", r"(a|b)+c", r"(\d+)\.(\d+)"):
+        rx = cx.compile(pat)
+        n, keep = cx.flatten_nfa(rx.nfa())
+        n.capture_count = 1
+        p = cx.program_from_nfa(n, rx.strategy, rx.flags)
+        assert p.supported and p.num_groups == 1 and p.strategy == rx.strategy
+        got = rows_on_twin(p, hay)
+        assert not isinstance(got, int) and got.tolist() == oracle.Regex(pat).find_all_index(hay).tolist(), pat
+        del keep

@@ -43,9 +43,15 @@ def test_programs_without_the_compact_epilogue_say_so():
     hay = cx.synth_pages(1, 0xC0FFEE01, 0, 64)
     d = torch.from_numpy(hay).cuda()
     out = torch.empty((1 << 16, 2), dtype=torch.int32, device="cuda")
-    for pat in (r"error", r"(\w+)@(\w+)\.(\w+)", r"a*"):
+    for pat in (r"rr", r"(\w+)@(\w+)\.(\w+)", r"a*"):            # `rr`: a literal with a border stays on the chain kernel (int64 rows only)
         rx = cx.compile(pat)
         with pytest.raises(cx.CoregexError):
             rx.find_all_device_u32(d.data_ptr(), hay.size, out.data_ptr(), out.shape[0])
-        if pat == r"error":                                          # counting needs no rows (nullable and UseBoth programs are refused outright)
+        if pat == r"rr":                                             # counting needs no rows (nullable and UseBoth programs are refused outright)
             assert rx.find_all_device_u32(d.data_ptr(), hay.size) == rx.find_all_device(d.data_ptr(), hay.size)
+    # `error` runs in the persistent kernel's literal mode since round 5, which has the compact epilogue
+    rx = cx.compile(r"error")
+    n = rx.find_all_device_u32(d.data_ptr(), hay.size, out.data_ptr(), out.shape[0])
+    o64 = torch.empty((n + 8, 2), dtype=torch.int64, device="cuda")
+    assert rx.find_all_device(d.data_ptr(), hay.size, o64.data_ptr(), n + 8) == n
+    assert torch.equal(out[:n].to(torch.int64) & 0xFFFFFFFF, o64[:n])

@@ -1,7 +1,6 @@
 """Watchdog hygiene (capi.hip PathState): a spin-watchdog hit demotes a launch mode for a TERM of calls and
 the mode is tried again afterwards; two threads that each scan a large haystack on the same device do not starve each other's
-persistent grids (one persistent launch at a time per device, the other caller takes the grouped kernel) and both get the
-reference's rows."""
+launches (order-dependent launches take turns per device) and both get the reference's rows."""
 import threading
 
 import numpy as np
