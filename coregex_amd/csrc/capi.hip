@@ -1563,6 +1563,10 @@ int cxg_program_from_nfa(const cxg_nfa* nfa, int strategy, uint32_t flags, cxg_p
   cxg_program* p = nullptr;
   try {
     std::string why;
+    if (nfa->states)
+      for (uint32_t i = 0; i < nfa->n_states; i++)
+        if (nfa->states[i].kind == CXG_NFA_RUNE_ANY || nfa->states[i].kind == CXG_NFA_RUNE_ANY_NOT_NL)
+          return fail(CXG_E_UNSUPPORTED, "state " + std::to_string(i) + ": nfa.StateRuneAny / StateRuneAnyNotNL (the PikeVM's rune NFA) has no device form; pass Engine.nfa");
     if (!cxg::validateNfa(*nfa, why)) return fail(CXG_E_INVALID, why);
     p = new cxg_program();
     cxg::buildProgramFromNfa(p, *nfa, strategy, flags);

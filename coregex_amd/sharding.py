@@ -26,6 +26,24 @@ def plan_shards(nbytes: int, world: int, page: int = PAGE):
     return out
 
 
+def shardable(rx) -> bool:
+    """May this program be scanned shard by shard and its rows concatenated?  Not when a match depends on the haystack as a WHOLE:
+    nullable programs (`a*`: FindAll emits an empty match at the end of every shard and at position 0 of the next, and skips an empty
+    match only at the end of a match of the SAME call, meta/findall.go:251-257) and quote-pair programs (`"[^"]*"`: which quote opens
+    is the parity of the quotes from the haystack's first byte).  Such programs are scanned as one haystack (64 GiB fit one MI355X)."""
+    import struct
+    if rx.nullable:
+        return False
+    blob = rx.blob()
+    kind, flags = struct.unpack_from("<II", blob, 4)
+    if kind == 3 and flags & 64:                                        # kKindCharClass with ranges: CharClassAux.pairs
+        aux_off = struct.unpack_from("<I", blob, 14 * 4)[0]
+        nr, lo, hi, neg, pairs = struct.unpack_from("<I4s4sII", blob, aux_off)
+        if pairs:
+            return False
+    return True
+
+
 def cut_is_safe(sync_table: np.ndarray, byte_before_cut: int) -> bool:
     """A shard may start at `cut` iff hay[cut-1] is a sync byte of the program (info table bit 0)."""
     return bool(sync_table[byte_before_cut] & 1)

@@ -63,7 +63,10 @@ enum cxg_strategy {
 /* nfa.StateKind (nfa/nfa.go:23-60), same numbering. */
 enum cxg_nfa_kind {
   CXG_NFA_MATCH = 0, CXG_NFA_BYTE_RANGE = 1, CXG_NFA_SPARSE = 2, CXG_NFA_SPLIT = 3,
-  CXG_NFA_EPSILON = 4, CXG_NFA_CAPTURE = 5, CXG_NFA_FAIL = 6, CXG_NFA_LOOK = 7
+  CXG_NFA_EPSILON = 4, CXG_NFA_CAPTURE = 5, CXG_NFA_FAIL = 6, CXG_NFA_LOOK = 7,
+  /* nfa.StateRuneAny / StateRuneAnyNotNL (nfa/nfa.go:53-59): states of the PikeVM's rune NFA only, never of Engine.nfa.  Known to the
+     library so that a binding which meets one gets CXG_E_UNSUPPORTED (the caller keeps its CPU loop), not CXG_E_INVALID. */
+  CXG_NFA_RUNE_ANY = 8, CXG_NFA_RUNE_ANY_NOT_NL = 9
 };
 
 #define CXG_NFA_INVALID 0xFFFFFFFFu

@@ -18,3 +18,21 @@ def oracle():
     from oracle import oracle as O
     O.build()
     return O
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Kernel-routing expectations recorded by tests/routing.py are judged when the session ENDS, whatever subset of the tier ran
+    (`-k`, a single file or `-x` never reached the last-collected test that used to assert them)."""
+    try:
+        import routing
+    except ImportError:
+        return
+    if routing.MISSES and exitstatus == 0:
+        tr = session.config.pluginmanager.get_plugin("terminalreporter")
+        lines = ["ROUTING REGRESSION: a program ran on another kernel (or more launches) than the routing table names:"] + [repr(m) for m in routing.MISSES[:40]]
+        if tr is not None:
+            for ln in lines:
+                tr.write_line(ln, red=True)
+        else:
+            print("\n".join(lines))
+        session.exitstatus = 1

@@ -285,3 +285,14 @@ def test_span_program_of_an_nfa_with_groups(oracle):
         got = rows_on_twin(p, hay)
         assert not isinstance(got, int) and got.tolist() == oracle.Regex(pat).find_all_index(hay).tolist(), pat
         del keep
+
+
+def test_rune_states_are_unsupported_not_malformed():
+    """nfa.StateRuneAny (8) / StateRuneAnyNotNL (9), nfa/nfa.go:53-59: CXG_E_UNSUPPORTED — the shim degrades — while an unknown kind stays CXG_E_INVALID."""
+    rx = cx.compile(r"a.c")
+    for kind, exc in ((8, cx.UnsupportedPattern), (9, cx.UnsupportedPattern), (10, cx.CoregexError)):
+        n, keep = cx.flatten_nfa(rx.nfa())
+        keep[0][1].kind = kind
+        with pytest.raises(exc) as ei:
+            cx.program_from_nfa(n, rx.strategy, rx.flags)
+        assert (ei.value.code == -2) == (kind < 10), (kind, ei.value.code)

@@ -84,3 +84,22 @@ def test_newline_is_a_sync_byte_for_all_benchmark_patterns():
     for pat in (r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error",
                 "error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow"):
         assert sharding.cut_is_safe(sharding.sync_table_of(cx.compile(pat)), ord("\n")), pat
+
+
+def test_programs_that_must_not_be_sharded_say_so():
+    """nullable programs (an empty match at the end of every shard and at position 0 of the next) and quote-pair programs
+    (pairing by parity from the haystack's first byte) are whole-haystack programs; everything the benchmarks shard is shardable."""
+    import coregex_amd as cx
+    from coregex_amd import sharding
+    for pat in (r"\d+\.\d+\.\d+\.\d+", r"[\w]+", r"error", r"(\w+)@(\w+)\.(\w+)", r"\[[^\]]+\]"):
+        assert sharding.shardable(cx.compile(pat)), pat
+    for pat in (r"a*", r"x?y*", r'"[^"]*"'):
+        rx = cx.compile(pat)
+        assert rx.supported and not sharding.shardable(rx), pat
+    # the spurious row the rule prevents: `a*` over `xb|ay` cut behind the b
+    import emu
+    from twins import rows_on_twin
+    rx = cx.compile(r"a*")
+    whole = rows_on_twin(rx, b"xbay").tolist()
+    parts = rows_on_twin(rx, b"xb").tolist() + (rows_on_twin(rx, b"ay") + 2).tolist()
+    assert [2, 2] in parts and [2, 2] not in whole and [2, 3] in whole
