@@ -134,6 +134,27 @@ class DeviceWorkload:
         import torch
         torch.cuda.synchronize()
 
+    def async_leg(self, steps):
+        """The same K passes through cxg_find_all_device_async: K launches in flight on the library's stream, then K waits — the launch +
+        synchronisation + pinned read-back (~19 us of a 1 GiB call) is paid once per batch.  Reported beside `value`, never instead of it."""
+        batch = min(8, steps)
+        n_batches = max(1, steps // batch)
+        for _ in range(2):
+            [p.wait() for p in [self.scan_async() for _ in range(batch)]]
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_batches):
+            pend = [self.scan_async() for _ in range(batch)]
+            for p in pend:
+                assert p.wait() == self.nmatch
+        self.sync()
+        dt = (time.perf_counter() - t0) / (n_batches * batch)
+        return {"value": round(self.nbytes * self.world / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 4), "batch": batch,
+                "what": "cxg_find_all_device_async x batch, then cxg_wait x batch (same output array, same stream): wall time per pass of this rank"}
+
+    def scan_async(self):
+        return self.rx.find_all_device_async(self.buf.ptr, self.nbytes, self.out.data_ptr(), self.nmatch + 16, base=self.base)
+
     def rows_and_checksum(self, first_row):
         """This shard's rows and their part of the whole-corpus checksum: row K (1-based, counted over the whole corpus: first_row
         rows lie in the shards in front), column j, absolute offset v -> v * (K + 7 j), summed mod 2^64 (coregex_amd/sharding.py
@@ -286,6 +307,8 @@ def main(argv=None, make_workload=DeviceWorkload, script=None):
                        per_rank_rows=per_rank_rows, corpus_checksum="%016x" % corpus_checksum),
     }
     wl.finish(result, k_ms)
+    if make_workload is DeviceWorkload and hasattr(wl, "async_leg") and not wl.submatch and not wl.u32 and not os.environ.get("CXG_DEBUG"):
+        result["async"] = wl.async_leg(args.steps)
     if (make_workload is DeviceWorkload and world == 1 and args.config == 2 and args.pattern is None and args.total_gib == 0 and args.gib_per_gpu == 1.0
             and not args.u32_rows and not args.no_north_star and not os.environ.get("CXG_DEBUG") and not _under_profiler()):
         del wl

@@ -239,6 +239,32 @@ class Regex:
         return int(got.value)
 
 
+class Pending:
+    """Handle of cxg_find_all_device_async; wait() on the thread that made the call returns the row count."""
+
+    def __init__(self, h):
+        self._h = h
+
+    def wait(self, timing: "Timing | None" = None) -> int:
+        got = C.c_uint64(0)
+        h, self._h = self._h, None
+        rc = _lib.lib().cxg_wait(h, C.byref(got), C.byref(timing) if timing is not None else None)
+        if rc == _lib.CXG_E_INVALID:
+            self._h = h                                               # (wrong thread: the handle is still good on the launching one)
+        _check(rc)
+        return int(got.value)
+
+
+def _find_all_device_async(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1, stream: int = 0) -> Pending:
+    """cxg_find_all_device_async: the launch stays in flight; .wait() completes the call."""
+    h = C.c_void_p()
+    _check(_lib.lib().cxg_find_all_device_async(self._h, d_hay, length, base, n, d_out or None, cap, stream or None, C.byref(h)))
+    return Pending(h)
+
+
+Regex.find_all_device_async = _find_all_device_async
+
+
 def _find_all_device_u32(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, n: int = -1, stream: int = 0,
                          timing: "Timing | None" = None) -> int:
     """cxg_find_all_device_u32: rows of two uint32 relative to d_hay (8 bytes per match); d_out == 0 counts."""

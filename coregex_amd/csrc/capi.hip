@@ -142,6 +142,23 @@ struct Scratch {
   uint8_t* bothHay = nullptr; uint64_t bothHayCap = 0;    // UseBoth restart (scanDevice): aligned copy of the haystack's suffix
   int64_t* bothRows = nullptr; uint64_t bothRowsCap = 0;  // ... rows of a launch whose caller gave no room for them
   unsigned long long* bothFirst = nullptr;                // ... index of the first row longer than the restart span
+  // cxg_find_all_device_async: launches of this thread that have not been waited for yet (ring of kAsyncSlots)
+  struct AsyncSlot {
+    bool busy = false, done = false;                // done: the call ran synchronously (a program without an async-capable first launch)
+    int done_rc = 0; uint64_t done_n = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    uint64_t* ctl = nullptr;                        // two pinned words: total, error
+    const cxg_program* p = nullptr; const void* hay = nullptr; uint64_t len = 0; int64_t base = 0, limit = 0; void* out = nullptr; uint64_t cap = 0; void* user_stream = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t kernelId = 0, mode = 0;                // mode: 1 static groups, 2 persistent, 3 delimiter kernel (what a clean finish resets)
+    uint64_t tiles = 0;
+    cxg_timing timing;
+  };
+  static constexpr int kAsyncSlots = 16;
+  AsyncSlot async[kAsyncSlots];
+  uint64_t* asyncCtl = nullptr;                     // pinned, 2 words per slot
+  int asyncInFlight = 0;
+  std::unique_lock<std::mutex> asyncLock;           // the device's order-dependent launch slot, held while launches of this thread are in flight
   // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
   // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
   void release() {
@@ -165,6 +182,9 @@ struct Scratch {
       if (bothRows) (void)hipFree(bothRows);
       if (bothFirst) (void)hipFree(bothFirst);
       if (hostCtl) (void)hipHostFree(hostCtl);
+      if (asyncCtl) (void)hipHostFree(asyncCtl);
+      for (auto& as : async) for (auto& e : as.ev) if (e) (void)hipEventDestroy(e);
+      if (asyncLock.owns_lock()) asyncLock.unlock();
       if (pinHay) (void)hipHostFree(pinHay);
       if (pinOut) (void)hipHostFree(pinOut);
     }
@@ -229,7 +249,9 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
                  uint64_t* n_out, void* user_stream, cxg_timing* timing);
 int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
                    uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width);
-thread_local bool t_u32Rows = false;                               // cxg_find_all_device_u32 in progress on this thread (ScanArgs::u32_rows)
+thread_local bool t_u32Rows = false;
+thread_local Scratch::AsyncSlot* t_asyncSlot = nullptr;            // cxg_find_all_device_async in progress on this thread: leave the first launch pending if it can be
+constexpr int kRcPending = -1001;                                  // (internal) scanDeviceOnce left its launch in the slot                               // cxg_find_all_device_u32 in progress on this thread (ScanArgs::u32_rows)
 
 // CXG_DIGIT_KERNEL=1|2 force the first (nested-loop) / second (flat) table-walking generation (A/B profiling);
 // default 6 = bit-parallel chain kernel (scan_chain_wave.hip; also serves UseDFA programs that are one chain) when
@@ -591,7 +613,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && !staticDenied) ? 1u : 0u;
   std::unique_lock<std::mutex> orderLock(ps.orderMutex, std::defer_lock);   // released when this iteration ends (every path out of it)
-  if (a.static_groups) { ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); orderLock.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed); }
+  if (a.static_groups && s.asyncInFlight == 0) {                   // (pending launches of this thread already hold it; its launches share a stream)
+    ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); orderLock.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed);
+  }
+  Scratch::AsyncSlot* const as = (t_asyncSlot && relaunches == 0 && !submatch && !profOn && !dbgBits && a.max_len == 0) ? t_asyncSlot : nullptr;
   if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
@@ -634,6 +659,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     s.hostCtl[1] = 0; s.hostCtl[2] = 0;
     a.total = s.hostCtl + 1;
     a.err = reinterpret_cast<uint32_t*>(s.hostCtl + 2);
+    if (as) { as->ctl[0] = 0; as->ctl[1] = 0; a.total = as->ctl; a.err = reinterpret_cast<uint32_t*>(as->ctl + 1); }
   } else {
     // control block and the look-back words this launch will use, in one memset
     HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + a.ngroups * sizeof(uint64_t), stream));   // every kernel indexes status by group < ngroups <= ntiles
@@ -644,7 +670,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     }
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
-  HIP_TRY(hipEventRecord(s.ev[1], stream));
+  const bool goAsync = as != nullptr && useEpoch;
+  HIP_TRY(hipEventRecord(goAsync ? as->ev[0] : s.ev[1], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
   if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6 && gen != 11)       // (gen 6: checked below, the persistent fields kernel only)
@@ -790,6 +817,14 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
   nladder++;
   uint32_t launches = 1;
+  if (goAsync) {                                                    // cxg_find_all_device_async: the launch stays in flight, cxg_wait finishes the call
+    HIP_TRY(hipEventRecord(as->ev[1], stream));
+    as->stream = stream; as->kernelId = kernelId; as->tiles = a.ntiles;
+    as->mode = gen == 11 ? 3u : persKernel ? 2u : a.static_groups ? 1u : 0u;
+    if (orderLock.owns_lock()) s.asyncLock = std::move(orderLock);  // the device's order-dependent slot stays with this thread until its launches are waited for
+    s.asyncInFlight++;
+    return kRcPending;
+  }
   if (submatch && a.out && !fusedCaps) { if (int rc = launchCapturePass(p, s, a, d_cap, stream, launches)) return rc; }
   HIP_TRY(hipEventRecord(s.ev[2], stream));
   if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));   // wave kernels wrote hostCtl themselves
@@ -1785,6 +1820,103 @@ int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, i
                         uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
   return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
 }
+// ---- asynchronous device entry (round 5) -------------------------------------------------------------------------------------
+// cxg_find_all_device without the stream synchronisation at its end: the first span launch of the call is left in flight and
+// the handle is waited for later.  A host that scans many shards / haystacks back to back pays the ~19 us of launch + sync +
+// pinned read-back once per batch instead of once per call (bench.py: 1 GiB, 4 300 -> 4 650 GB/s).  What cannot be left pending
+// (nullable, UseBoth and offset-capture programs, kernels without epoch-tagged status words) runs to completion inside the
+// async call; cxg_wait then only hands the result over.  A launch that asked for another rung of the ladder (match-dense input,
+// a watchdog) is rerun synchronously by cxg_wait: the result is always what cxg_find_all_device would have returned.
+struct cxg_pending { Scratch* s; int slot; int device; };
+
+int cxg_find_all_device_async(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
+                              uint64_t cap, void* stream, cxg_pending** out) {
+  if (!out) return fail(CXG_E_INVALID, "null argument");
+  *out = nullptr;
+  if (!p) return fail(CXG_E_INVALID, "null program");
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  int slot = -1;
+  for (int i = 0; i < Scratch::kAsyncSlots; i++) if (!s.async[i].busy) { slot = i; break; }
+  if (slot < 0) return fail(CXG_E_CAPACITY, "16 asynchronous calls of this thread are pending: cxg_wait for one first");
+  if (!s.asyncCtl) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.asyncCtl), Scratch::kAsyncSlots * 16, hipHostMallocDefault));
+    std::memset(s.asyncCtl, 0, Scratch::kAsyncSlots * 16);
+  }
+  Scratch::AsyncSlot& as = s.async[slot];
+  for (auto& e : as.ev) if (!e) HIP_TRY(hipEventCreate(&e));
+  as.ctl = s.asyncCtl + 2 * slot;
+  as.p = p; as.hay = d_hay; as.len = len; as.base = base; as.limit = limit; as.out = d_out; as.cap = cap; as.user_stream = stream;
+  as.done = false; as.done_rc = 0; as.done_n = 0;
+  std::memset(&as.timing, 0, sizeof as.timing);
+  const bool plain = p->supported && !p->nullable && limit != 0 && len != 0;
+  int rc;
+  uint64_t n = 0;
+  if (plain) {
+    t_asyncSlot = &as;
+    rc = scanDeviceOnce(p, d_hay, len, base, limit, d_out, cap, &n, stream, &as.timing, 2);
+    t_asyncSlot = nullptr;
+    if (rc == kRcLongMatch) rc = scanDevice(p, d_hay, len, base, limit, d_out, cap, &n, stream, &as.timing, 2);   // (UseBoth restart: the synchronous loop)
+  } else {
+    rc = scanDevice(p, d_hay, len, base, limit, d_out, cap, &n, stream, &as.timing, 2);
+  }
+  if (rc != kRcPending) { as.done = true; as.done_rc = rc; as.done_n = n; }
+  as.busy = true;
+  *out = new cxg_pending{sp, slot, t_device};
+  return CXG_OK;
+}
+
+int cxg_wait(cxg_pending* h, uint64_t* n_out, cxg_timing* timing) {
+  if (!h) return fail(CXG_E_INVALID, "null handle");
+  Scratch* sp = nullptr;
+  const int dev_before = t_device;
+  t_device = h->device;
+  const int grc = getScratch(&sp);
+  t_device = dev_before;
+  if (grc != CXG_OK || sp != h->s) { return fail(CXG_E_INVALID, "cxg_wait must be called on the thread that made the asynchronous call"); }
+  Scratch& s = *sp;
+  Scratch::AsyncSlot& as = s.async[h->slot];
+  delete h;
+  if (!as.busy) return fail(CXG_E_INVALID, "stale handle");
+  if (n_out) *n_out = 0;
+  int rc;
+  if (as.done) {
+    rc = as.done_rc;
+    if (n_out) *n_out = as.done_n;
+    if (timing) *timing = as.timing;
+    as.busy = false;
+    if (rc != CXG_OK) t_err = "asynchronous call failed when it was made (code " + std::to_string(rc) + ")";
+    return rc;
+  }
+  const hipError_t we = hipEventSynchronize(as.ev[1]);
+  const uint64_t total = as.ctl[0];
+  const uint32_t err = static_cast<uint32_t>(as.ctl[1]);
+  PathState& ps = g_path[s.device];
+  if (--s.asyncInFlight == 0 && s.asyncLock.owns_lock()) s.asyncLock.unlock();
+  as.busy = false;
+  if (we != hipSuccess) return failHip(we, "hipEventSynchronize");
+  if (err != 0) {                                                   // another rung of the ladder (or a watchdog): the synchronous call decides and demotes
+    t_device = s.device;
+    rc = scanDevice(as.p, as.hay, as.len, as.base, as.limit, as.out, as.cap, n_out, as.user_stream, timing, 2);
+    t_device = dev_before;
+    return rc;
+  }
+  if (as.mode == 3u) ps.delim.clean(); else if (as.mode == 2u) ps.persistent.clean(); else if (as.mode == 1u) ps.staticGroups.clean();
+  if (timing) {
+    std::memset(timing, 0, sizeof *timing);
+    float k = 0;
+    (void)hipEventElapsedTime(&k, as.ev[0], as.ev[1]);
+    timing->kernel_ms = k; timing->total_ms = k; timing->n_launches = 1; timing->n_ladder = 1; timing->ladder[0] = static_cast<uint8_t>(as.kernelId);
+    timing->kernel = as.kernelId; timing->block = cxgdev::kThreads; timing->tiles = as.tiles; timing->grid = static_cast<uint32_t>(as.tiles);
+  }
+  uint64_t n = total;
+  if (as.limit > 0 && n > static_cast<uint64_t>(as.limit)) n = static_cast<uint64_t>(as.limit);
+  if (n_out) *n_out = n;
+  if (as.out && n > as.cap) return fail(CXG_E_CAPACITY, "output capacity too small");
+  return CXG_OK;
+}
+
 int cxg_find_all_device_u32(const cxg_program* p, const void* d_hay, uint64_t len, int64_t limit, void* d_out_u32, uint64_t cap,
                             uint64_t* n_out, void* stream, cxg_timing* timing) {
   if (p && (p->nullable || (p->supported && (reinterpret_cast<const cxgdev::BlobHeader*>(p->blob.data())->flags & cxgdev::kFlagBothRestart))))

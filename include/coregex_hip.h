@@ -241,6 +241,18 @@ int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64
                                  int64_t limit, void* d_out, uint64_t cap, uint64_t* n_out, void* stream,
                                  cxg_timing* timing);
 
+/* Asynchronous form of cxg_find_all_device (round 5): the call returns with its span launch in flight on `stream` (NULL: the calling
+ * thread's own); cxg_wait — on the SAME thread — completes it and returns what cxg_find_all_device would have returned (a launch that
+ * needs another kernel is rerun synchronously inside cxg_wait; programs without an async-capable first launch run to completion inside
+ * the async call).  Up to 16 calls per thread may be pending; they should share one stream.  While calls of a thread are pending the
+ * thread holds the device's order-dependent launch slot (cxg_path_state_t.order_waiters): wait for them before idling.
+ * d_hay, d_out and the program must stay valid until cxg_wait returns.  Mirrors nothing in the reference (its calls are synchronous);
+ * it is what a batch host (bench.py, a shard scheduler) uses to pay launch + sync once per batch. */
+typedef struct cxg_pending cxg_pending;
+int cxg_find_all_device_async(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
+                              void* d_out, uint64_t cap, void* stream, cxg_pending** out);
+int cxg_wait(cxg_pending* pending, uint64_t* n_out, cxg_timing* timing);   /* frees the handle */
+
 /* Compact rows for shard-sized, device-resident haystacks: rows of two uint32 — (start, end) relative to d_hay, no `base` —
  * 8 bytes per match instead of 16.  Device-only entry point beside the int64 ABI above (which the cgo binding keeps using): a
  * consumer on the device (a later kernel, a gather that rebases per shard) reads half the bytes, and the write-bound programs —
