@@ -67,6 +67,11 @@ def path_state(device: int = 0) -> dict:
     return {n: int(getattr(st, n)) for n, _ in _lib.PathState._fields_ if n != "reserved"}
 
 
+def path_reset(device: int = 0):
+    """cxg_path_reset: forget every launch-mode demotion of the device."""
+    _check(_lib.lib().cxg_path_reset(device))
+
+
 def _host_view(hay):
     if isinstance(hay, np.ndarray):
         a = np.ascontiguousarray(hay, dtype=np.uint8)

@@ -26,7 +26,7 @@ SYMBOLS = [
     "cxg_program_nfa", "cxg_program_fsm_image", "cxg_program_submatch_blobs", "cxg_program_chain_captures", "cxg_program_chain_bounds", "cxg_program_submatch_supported", "cxg_find_all", "cxg_count", "cxg_find_all_submatch", "cxg_buffer_alloc",
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
-    "cxg_find_all_submatch_device", "cxg_abi_version", "cxg_timing_size", "cxg_path_state", "cxg_debug_demote", "cxg_find_all_device_async", "cxg_wait",
+    "cxg_find_all_submatch_device", "cxg_abi_version", "cxg_timing_size", "cxg_path_state", "cxg_debug_demote", "cxg_path_reset", "cxg_find_all_device_async", "cxg_wait",
 ]
 
 
@@ -147,6 +147,7 @@ def lib():
     L.cxg_timing_size.restype = C.c_size_t
     L.cxg_path_state.argtypes = [C.c_int, C.POINTER(PathState)]
     L.cxg_debug_demote.argtypes = [C.c_int, C.c_int]
+    L.cxg_path_reset.argtypes = [C.c_int]
     L.cxg_find_all_device_async.argtypes = [vp, vp, u64, i64, i64, vp, u64, vp, C.POINTER(vp)]
     L.cxg_wait.argtypes = [vp, C.POINTER(u64), C.POINTER(Timing)]
     if L.cxg_abi_version() != 3 or L.cxg_timing_size() != C.sizeof(Timing):

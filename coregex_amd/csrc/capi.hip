@@ -646,7 +646,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     }
     a.fsm_maps = s.fsmMaps;
   }
-  HIP_TRY(hipEventRecord(s.ev[0], stream));
+  if (!(as != nullptr && useEpoch)) HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
       HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
@@ -671,7 +671,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     s.needZero = true;                                              // legacy words and error bits are left behind
   }
   const bool goAsync = as != nullptr && useEpoch;
-  HIP_TRY(hipEventRecord(goAsync ? as->ev[0] : s.ev[1], stream));
+  static const bool asyncTiming = getenv("CXG_ASYNC_TIMING") != nullptr;   // a start event per pending launch (cxg_wait's kernel_ms); off: one event per launch
+  if (!goAsync) HIP_TRY(hipEventRecord(s.ev[1], stream));
+  else if (asyncTiming) HIP_TRY(hipEventRecord(as->ev[0], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
   if (a.u32_rows && a.out != nullptr && gen != 8 && gen != 6 && gen != 11)       // (gen 6: checked below, the persistent fields kernel only)
@@ -776,8 +778,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
       trioKernel = ok;
     }
-    if (a.u32_rows && a.out != nullptr && !((fieldsKernel || litKernel) && a.pf_status != nullptr))
-      return fail(relaunches ? CXG_E_INPUT : CXG_E_UNSUPPORTED, "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
+    if (a.u32_rows && a.out != nullptr && !((fieldsKernel || litKernel) && a.pf_status != nullptr)) {
+      // the persistent kernel has the compact epilogue; when THIS call cannot have it (a rerun, the mode demoted for a while, FindAll's n) the
+      // caller uses cxg_find_all_device for the call (CXG_E_INPUT), the program itself stays served
+      const bool couldPers = (fieldsCould && fieldsOk && !submatch) || cxgdev::literal_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+      return fail((relaunches || couldPers) ? CXG_E_INPUT : CXG_E_UNSUPPORTED, couldPers ? "compact rows (cxg_find_all_device_u32): the persistent kernel is not available for this call (demoted after a watchdog hit, FindAll with an n, or match-dense input): use cxg_find_all_device"
+                                                                                            : "compact rows (cxg_find_all_device_u32): this program's span kernel writes int64 rows only");
+    }
     if (trioKernel) {                                               // the field class as a class plan (wave_common.hpp)
       const cxgdev::ChainAux* tc = reinterpret_cast<const cxgdev::ChainAux*>(a.chain);
       uint8_t lo1[4] = {0, 0, 0, 0}, hi1[4] = {0, 0, 0, 0};
@@ -1456,6 +1463,12 @@ const char* cxg_last_error(void) { return t_err.c_str(); }
 const char* cxg_version(void) { return "coregex_hip 0.2 (gfx950)"; }
 int cxg_abi_version(void) { return CXG_ABI_VERSION; }
 size_t cxg_timing_size(void) { return sizeof(cxg_timing); }
+int cxg_path_reset(int device) {
+  if (device < 0 || device >= 16) return fail(CXG_E_INVALID, "bad device index");
+  PathState& ps = g_path[device];
+  for (PathMode* m : {&ps.staticGroups, &ps.persistent, &ps.delim}) { m->penalty.store(0); m->backoff.store(8); }
+  return CXG_OK;
+}
 int cxg_debug_demote(int device, int mode) {
   if (device < 0 || device >= 16 || mode < 0 || mode > 2) return fail(CXG_E_INVALID, "bad argument");
   PathState& ps = g_path[device];
@@ -1906,7 +1919,8 @@ int cxg_wait(cxg_pending* h, uint64_t* n_out, cxg_timing* timing) {
   if (timing) {
     std::memset(timing, 0, sizeof *timing);
     float k = 0;
-    (void)hipEventElapsedTime(&k, as.ev[0], as.ev[1]);
+    static const bool asyncTiming = getenv("CXG_ASYNC_TIMING") != nullptr;
+    if (asyncTiming) (void)hipEventElapsedTime(&k, as.ev[0], as.ev[1]);   // else 0: pending launches carry no start event
     timing->kernel_ms = k; timing->total_ms = k; timing->n_launches = 1; timing->n_ladder = 1; timing->ladder[0] = static_cast<uint8_t>(as.kernelId);
     timing->kernel = as.kernelId; timing->block = cxgdev::kThreads; timing->tiles = as.tiles; timing->grid = static_cast<uint32_t>(as.tiles);
   }

@@ -33,6 +33,12 @@
 #ifndef CXG_CC_PLANS
 #define CXG_CC_PLANS 1
 #endif
+// Staging index of rank r (pass 2).  In one ds_write_b16 lane l writes rank r_l + i with r_l ~ 11 l on log text: indices r / 2 mod 32
+// put ~11 lanes on every LDS bank.  r * 13 mod 1024 (a bijection) spreads them — the coalesced read-out of consecutive ranks stays
+// two lanes per bank.
+#ifndef CXG_CC_SWIZZLE
+#define CXG_CC_SWIZZLE 1
+#endif
 #ifndef CXG_CC_LOAD_AUX
 #define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
 #endif
@@ -42,6 +48,7 @@ namespace cxgdev {
 namespace {
 constexpr int kWin = kWaveTile + kWaveHalo;       // 4096
 constexpr int kCcStage = 1024;                    // rows staged per wave-tile (typical log text: ~700)
+__device__ __forceinline__ uint32_t cc_slot(uint32_t r) { return CXG_CC_SWIZZLE ? ((r * 13u) & static_cast<uint32_t>(kCcStage - 1)) : r; }
 }
 
 __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a) {
@@ -201,8 +208,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
         // (par == 1: the tile's first event, k = 1, is end 0 and closes a row opened in front of the tile)
         const uint32_t slot = (k & 1u) ? (k >> 1) : (k >> 1) - par;
         if (slot < static_cast<uint32_t>(kCcStage)) {
-          if (k & 1u) s_re[wave][slot] = static_cast<uint16_t>(64 * lane0 + bit + 1);   // closes: exclusive end behind the Q
-          else s_rs[wave][slot] = static_cast<uint16_t>(64 * lane0 + bit);
+          if (k & 1u) s_re[wave][cc_slot(slot)] = static_cast<uint16_t>(64 * lane0 + bit + 1);   // closes: exclusive end behind the Q
+          else s_rs[wave][cc_slot(slot)] = static_cast<uint16_t>(64 * lane0 + bit);
         }
         k++;
       }
@@ -212,21 +219,21 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       open = par;
       row0 = (row0 + 1u) >> 1;                                       // rows opened in front of the tile
     } else {
-    uint32_t r = (incl & 0xFFFFu) - ns;
-    uint64_t sb = S;
-    while (sb) {
-      const int bit = __builtin_ctzll(sb);
-      sb &= sb - 1;
-      if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
-      r++;
-    }
-    r = (incl >> 16) - ne;
-    uint64_t eb = E;
-    while (eb) {
-      const int bit = __builtin_ctzll(eb);
-      eb &= eb - 1;
-      if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][r] = static_cast<uint16_t>(64 * lane0 + bit);
-      r++;
+    uint32_t r = (incl & 0xFFFFu) - ns, q = (incl >> 16) - ne;
+    uint64_t sb = S, eb = E;
+    while (sb | eb) {                                               // one loop for both bitmaps: a lane has as many ends as starts, give or take one
+      if (sb) {
+        const int bit = __builtin_ctzll(sb);
+        sb &= sb - 1;
+        if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
+        r++;
+      }
+      if (eb) {
+        const int bit = __builtin_ctzll(eb);
+        eb &= eb - 1;
+        if (q < static_cast<uint32_t>(kCcStage)) s_re[wave][cc_slot(q)] = static_cast<uint16_t>(64 * lane0 + bit);
+        q++;
+      }
     }
     }
     wave_lds_sync();
@@ -236,16 +243,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     for (uint32_t i = lane0; i < nst; i += 64) {
       if (row0 + i < a.cap) {
         if (i + open < nen) {                                       // both halves of the row are this tile's
-          longlong2 v; v.x = tb + s_rs[wave][i]; v.y = tb + s_re[wave][i + open];
+          longlong2 v; v.x = tb + s_rs[wave][cc_slot(i)]; v.y = tb + s_re[wave][cc_slot(i + open)];
           if (u32) store_pair32_nt(out32 + (row0 + i) * 2, static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
           else store_pair_nt(a.out + (row0 + i) * 2, v.x, v.y);
-        } else if (u32) out32[(row0 + i) * 2] = static_cast<uint32_t>(tb + s_rs[wave][i]);
-        else a.out[(row0 + i) * 2] = tb + s_rs[wave][i];           // the run ends in a later tile
+        } else if (u32) out32[(row0 + i) * 2] = static_cast<uint32_t>(tb + s_rs[wave][cc_slot(i)]);
+        else a.out[(row0 + i) * 2] = tb + s_rs[wave][cc_slot(i)];  // the run ends in a later tile
       }
     }
     if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) {       // a run begun in an earlier tile ends here
-      if (u32) out32[(row0 - 1) * 2 + 1] = static_cast<uint32_t>(tb + s_re[wave][0]);
-      else a.out[(row0 - 1) * 2 + 1] = tb + s_re[wave][0];
+      if (u32) out32[(row0 - 1) * 2 + 1] = static_cast<uint32_t>(tb + s_re[wave][cc_slot(0)]);
+      else a.out[(row0 - 1) * 2 + 1] = tb + s_re[wave][cc_slot(0)];
     }
     wave_lds_sync();                                                // staging is reused by the next tile
   }

@@ -34,6 +34,7 @@
 // super-run that reaches past its window (> 192 bytes behind its tile), a match longer than its start search (64..127
 // bytes), row-buffer overflow (reason 0x10: match-dense input).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
@@ -586,7 +587,7 @@ constexpr uint32_t kPfSpinLimit = 1u << 18;                  // polls of ~1.5 us
 
 // LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused).
 template <int K, int KD, int KP, int LIT = 0>
-__global__ __launch_bounds__(kThreads, (LIT >= 4 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (four bitmaps: 29 KB of LDS per workgroup)
+__global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (three / four bitmaps: 27 / 29 KB of LDS per workgroup — six do not fit a CU)
   constexpr int kNBitmaps = LIT ? LIT : 2;
   __shared__ __attribute__((aligned(16))) uint64_t s_c[kNBitmaps][kWavesPerBlock][64 + 4];   // class bitmaps of the wave's window (+ 4 dump words: CARRY)
   uint64_t (*const s_d)[64 + 4] = s_c[0];
@@ -879,7 +880,8 @@ int pers_occupancy() {                                               // resident
 template <int K, int KD, int KP, int LIT = 0>
 bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
   const int occ = pers_occupancy<K, KD, KP, LIT>();
-  if (occ <= 0) return false;
+  static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
+  if (occ <= 0) { if (verbose) fprintf(stderr, "[cxg] persistent kernel (LIT %d): the occupancy query says %d workgroups per CU — not launched\n", LIT, occ); return false; }
   static int cus = 0;
   if (cus == 0) { int dev = 0; cus = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
   const uint64_t nwt = (a.len + kWaveTile - 1) / kWaveTile;
@@ -891,7 +893,11 @@ bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
   const uint64_t full = nwt / per_round, rem = nwt - full * per_round;
   const uint64_t tpw_last = (rem + W - 1) / W;
   const uint64_t units_last = tpw_last ? (rem + tpw_last - 1) / tpw_last : 0;
-  if ((full + 1) * W > a.pf_cap || full + 1 > a.pf_rec_rounds || full > 0xFFFFull) return false;   // (the round number is part of a block sum's tag: 16 bits = 64 Ki rounds of 180 MiB)
+  if ((full + 1) * W > a.pf_cap || full + 1 > a.pf_rec_rounds || full > 0xFFFFull) {
+    if (verbose) fprintf(stderr, "[cxg] persistent kernel: %llu rounds of %llu waves do not fit the status arrays (%llu words, %llu rounds) — not launched\n",
+                         (unsigned long long)(full + 1), (unsigned long long)W, (unsigned long long)a.pf_cap, (unsigned long long)a.pf_rec_rounds);
+    return false;
+  }   // (the round number is part of a block sum's tag: 16 bits = 64 Ki rounds of 180 MiB)
   a.pf_full = static_cast<uint32_t>(full); a.pf_tpw_last = static_cast<uint32_t>(tpw_last); a.pf_units_last = static_cast<uint32_t>(units_last);
   hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP, LIT>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
   if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, W, a.total);

@@ -154,6 +154,8 @@ typedef struct cxg_path_state_t {
   uint32_t reserved;
 } cxg_path_state_t;
 int cxg_path_state(int device, cxg_path_state_t* out);
+/* Forget every demotion of `device` (penalties 0, terms back to 8): for a host that knows the co-tenant that caused them is gone. */
+int cxg_path_reset(int device);
 /* Diagnostics / tests: act as if the spin watchdog of a mode had fired on `device` (mode 0 static groups, 1 persistent grid,
  * 2 delimiter kernel): the mode is demoted for its current term, exactly as a real hit would. */
 int cxg_debug_demote(int device, int mode);
@@ -251,7 +253,8 @@ int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64
 typedef struct cxg_pending cxg_pending;
 int cxg_find_all_device_async(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit,
                               void* d_out, uint64_t cap, void* stream, cxg_pending** out);
-int cxg_wait(cxg_pending* pending, uint64_t* n_out, cxg_timing* timing);   /* frees the handle */
+int cxg_wait(cxg_pending* pending, uint64_t* n_out, cxg_timing* timing);   /* frees the handle; timing->kernel_ms is 0 unless CXG_ASYNC_TIMING
+                                                                               is set in the environment (a start event per pending launch) */
 
 /* Compact rows for shard-sized, device-resident haystacks: rows of two uint32 — (start, end) relative to d_hay, no `base` —
  * 8 bytes per match instead of 16.  Device-only entry point beside the int64 ABI above (which the cgo binding keeps using): a

@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_path_state(request):
+    """GPU tier: launch-mode demotions are process-wide (a watchdog hit of an earlier test — one that ran scans beside foreign kernels or many
+    threads — keeps a mode off for a term of calls).  Tests assert kernels and the compact-row entry needs the persistent kernel, so every
+    GPU test starts from a clean slate (cxg_path_reset); the demotion logic itself is tested in tests/test_gpu_watchdog.py."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import coregex_amd as cx
+        cx.path_reset(0)
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with g++."""
