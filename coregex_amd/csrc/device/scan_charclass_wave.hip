@@ -39,6 +39,9 @@
 #ifndef CXG_CC_SWIZZLE
 #define CXG_CC_SWIZZLE 1
 #endif
+#ifndef CXG_CC_MERGED
+#define CXG_CC_MERGED 1                                      // one extraction loop over starts and ends (0: two loops, round 4)
+#endif
 #ifndef CXG_CC_LOAD_AUX
 #define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
 #endif
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       open = par;
       row0 = (row0 + 1u) >> 1;                                       // rows opened in front of the tile
     } else {
+#if CXG_CC_MERGED
     uint32_t r = (incl & 0xFFFFu) - ns, q = (incl >> 16) - ne;
     uint64_t sb = S, eb = E;
     while (sb | eb) {                                               // one loop for both bitmaps: a lane has as many ends as starts, give or take one
@@ -235,6 +239,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
         q++;
       }
     }
+#else
+    uint32_t r = (incl & 0xFFFFu) - ns;
+    uint64_t sb = S;
+    while (sb) {
+      const int bit = __builtin_ctzll(sb);
+      sb &= sb - 1;
+      if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
+      r++;
+    }
+    r = (incl >> 16) - ne;
+    uint64_t eb = E;
+    while (eb) {
+      const int bit = __builtin_ctzll(eb);
+      eb &= eb - 1;
+      if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
+      r++;
+    }
+#endif
     }
     wave_lds_sync();
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;

@@ -583,7 +583,10 @@ constexpr int kPfTiles = CXG_PF_TILES;
 static_assert((kPfTiles - 1) * kWaveTile + kWaveTile + kWaveHalo < 65536, "a parked row holds two 16-bit offsets from the unit's first window byte");
 constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per unit and wave (twice: rounds r and r - 1); 64 per tile + 64 as in the grouped kernel
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
-constexpr uint32_t kPfSpinLimit = 1u << 18;                  // polls of ~1.5 us: a wave that waits ~0.4 s gives up (capi.hip demotes the mode for a while)
+// A wave that has waited this long for a word of another wave gives up (capi.hip reruns the call one mode down and demotes the mode for a
+// term): s_memtime ticks of 10 ns.  Legitimate waits are microseconds; round 5 measured what a missing co-resident wave costs with the
+// old count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt).
+constexpr uint64_t kPfWaitTicks = 5000000ull;                // 50 ms
 
 // LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused).
 template <int K, int KD, int KP, int LIT = 0>
@@ -691,13 +694,15 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
   };
   auto duty_finish = [&]() {                                          // no tiles left to hide behind (end of a round with the duty still open, end of the launch)
     uint32_t spins = 0;
+    uint64_t t_wait = 0;
     while (duty_stage != 0u) {
       u32x4 dv = {0u, 0u, 0u, 0u};
       duty_load(dv);
       const uint32_t before = duty_stage;
       duty_check(dv);
       if (duty_stage == before) {
-        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
+        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
       }
     }
@@ -795,8 +800,10 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
       // ---- order and write the rows of round r - 1
       const uint32_t rp = r - 1u, parp = rp & 1u;
       uint32_t pre = 0, tot = 0, spins = 0;
+      uint64_t t_wait = 0;
       while (!status_reduce(vr, vs, pre, tot)) {                      // something of the round was not there yet
-        if (++spins > kPfSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
+        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
+        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
         status_load(rp, vr, vs);
       }
@@ -864,16 +871,30 @@ int literal_shape(const ChainAux& c) {
 __global__ void k_sum_counts(const uint64_t* counts, uint64_t n, uint64_t* total);
 
 namespace {
+// Resident workgroups per CU of a persistent instantiation.  The grid must be co-resident, so this errs on the low side: the
+// runtime's occupancy query, and our own count from the kernel's attributes — LDS in 1 280-byte granules of the CU's 160 KiB,
+// VGPRs in granules of 8 of the SIMD's 512.  (Round 5: the query answered 6 for the three-bitmap literal instantiation, 27 008
+// bytes of LDS; five fit — the sixth workgroup of every CU never started and the launch ran into its watchdog.)
 template <int K, int KD, int KP, int LIT = 0>
-int pers_occupancy() {                                               // resident workgroups per CU of the persistent instantiation
+int pers_occupancy() {
   static int occ = -1;
   if (occ < 0) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scan_fields_pers<K, KD, KP, LIT>, kThreads, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_scan_fields_pers<K, KD, KP, LIT>)) == hipSuccess) {
+      const int lds = static_cast<int>((fa.sharedSizeBytes + 1279) / 1280 * 1280);
+      const int by_lds = lds > 0 ? (160 * 1024) / lds : 8;
+      const int regs = (fa.numRegs + 7) / 8 * 8;
+      const int by_regs = regs > 0 ? 512 / regs : 8;                // waves per SIMD = workgroups per CU (four waves, four SIMDs)
+      if (by_lds < n) n = by_lds;
+      if (by_regs < n) n = by_regs;
+    } else (void)hipGetLastError();
     int want = CXG_PF_OCC;
     if (const char* e = getenv("CXG_PF_OCC")) want = atoi(e);
     occ = n < want ? n : want;
     if (occ < 0) occ = 0;
+    if (getenv("CXG_VERBOSE")) fprintf(stderr, "[cxg] persistent kernel (LIT %d): %d workgroups per CU\n", LIT, occ);
   }
   return occ;
 }

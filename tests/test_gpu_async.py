@@ -34,7 +34,7 @@ def test_pending_launches_return_the_synchronous_rows(oracle):
     for p, o, c, s in zip(pend, outs, counts, sync):
         t = cx.Timing()
         assert p.wait(t) == c
-        assert int(t.kernel) == 15 and t.kernel_ms > 0
+        assert int(t.kernel) == 15 and t.kernel_ms >= 0                # (kernel_ms: only with CXG_ASYNC_TIMING, a start event per pending launch)
         assert torch.equal(o[:c], s)
     # count-only and a too small output array
     assert rx.find_all_device_async(bufs[0].ptr, n).wait() == counts[0]
