@@ -40,7 +40,7 @@
 #define CXG_CC_SWIZZLE 1
 #endif
 #ifndef CXG_CC_MERGED
-#define CXG_CC_MERGED 1                                      // one extraction loop over starts and ends (0: two loops, round 4)
+#define CXG_CC_MERGED 0                                      // one extraction loop over starts and ends (0: two loops, round 4)
 #endif
 #ifndef CXG_CC_LOAD_AUX
 #define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
