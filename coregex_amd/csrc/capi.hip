@@ -35,7 +35,7 @@ hipError_t launch_scan_delim_wave(const ScanArgs& a, hipStream_t stream);   // s
 int fields_shape(const ChainAux& c);
 int literal_shape(const ChainAux& c);
 int trio_shape(const ChainAux& c);
-hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream);   // scan_fields_wave.hip
+hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
@@ -723,12 +723,29 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     static const bool literalOk = getenv("CXG_NO_LITERAL_KERNEL") == nullptr;
     litKernel = literalOk && !fieldsKernel && !submatch && !denseChain && !(h->flags & (cxgdev::kFlagChainBounded | cxgdev::kFlagChainSets)) &&
                 cxgdev::literal_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain)) != 0;
+    // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
+    // start, the end or the end of the first / second run plus a constant (ChainCaps)
+    static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
+    const int trioShape = cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
+    if (!fieldsKernel && !litKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
+      bool ok = !submatch || a.out == nullptr || fusedCaps;
+      // spans with one separator for every link are the fields kernel's where it can serve the chain (with CXG_NO_FIELDS_KERNEL
+      // the chain kernel's: the A/B of tests/test_gpu_fields.py); a set class (`\w+@\w+@\w+`) stays here, on the EQ instantiation
+      if ((trioShape & 8) && !submatch && fieldsCould) ok = false;
+      if (fusedCaps) {
+        const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
+        for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] & 1u) == 0u && cc->run_op[i] <= 6u;
+        for (uint32_t k = 0; k < cc->nslots; k++) ok = ok && (cc->src[k] <= cxgdev::kCapSrcEnd || (cc->src[k] >= cxgdev::kCapSrcRun0 && cc->src[k] < cxgdev::kCapSrcRun0 + cc->nruns));
+        ok = ok && (a.row_width & 1u) == 0u && a.row_width <= 128u && cc->nslots == a.row_width;   // <= 64 lanes write a row
+      }
+      trioKernel = ok;
+    }
     // ... on a persistent grid with the ordering of the rows deferred by a round (k_scan_fields_pers) unless FindAll has an n
     // (the early stop lives in the grouped kernel's look-back), the phase profile is on, or a watchdog ever fired
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
     a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
-    bool persWanted = (fieldsKernel || litKernel) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
+    bool persWanted = (fieldsKernel || litKernel || trioKernel) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
     if (persWanted && !ps.persistent.allowed()) { ps.persistent.consume(); persDenied = true; persWanted = false; }
     if (persWanted) {
       const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
@@ -760,24 +777,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     }
     if (a.pf_status == nullptr) litKernel = false;                  // no persistent launch for this call: the chain kernel
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;
-    a.count_sum = ((fieldsKernel || litKernel) && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
-    // run a run b run programs (`(\\w+)@(\\w+)\\.(\\w+)`, BASELINE configs[4]): spans, or the capture slots when every slot is the
-    // start, the end or the end of the first / second run plus a constant (ChainCaps)
-    static const bool trioOk = getenv("CXG_NO_TRIO_KERNEL") == nullptr;
-    const int trioShape = cxgdev::trio_shape(*reinterpret_cast<const cxgdev::ChainAux*>(a.chain));
-    if (!fieldsKernel && !litKernel && trioOk && !denseChain && !(h->flags & cxgdev::kFlagChainBounded) && trioShape != 0) {
-      bool ok = !submatch || a.out == nullptr || fusedCaps;
-      // spans with one separator for every link are the fields kernel's where it can serve the chain (with CXG_NO_FIELDS_KERNEL
-      // the chain kernel's: the A/B of tests/test_gpu_fields.py); a set class (`\w+@\w+@\w+`) stays here, on the EQ instantiation
-      if ((trioShape & 8) && !submatch && fieldsCould) ok = false;
-      if (fusedCaps) {
-        const cxgdev::ChainCaps* cc = reinterpret_cast<const cxgdev::ChainCaps*>(a.caps);
-        for (uint32_t i = 0; i < cc->nruns && i < static_cast<uint32_t>(cxgdev::kCapMaxRuns); i++) ok = ok && (cc->run_op[i] & 1u) == 0u && cc->run_op[i] <= 6u;
-        for (uint32_t k = 0; k < cc->nslots; k++) ok = ok && (cc->src[k] <= cxgdev::kCapSrcEnd || (cc->src[k] >= cxgdev::kCapSrcRun0 && cc->src[k] < cxgdev::kCapSrcRun0 + cc->nruns));
-        ok = ok && (a.row_width & 1u) == 0u && a.row_width <= 128u && cc->nslots == a.row_width;   // <= 64 lanes write a row
-      }
-      trioKernel = ok;
-    }
+    a.count_sum = ((fieldsKernel || litKernel || (trioKernel && a.pf_status != nullptr)) && countSumOk && a.out == nullptr && a.max_len == 0 && a.limit == 0 && a.prof == nullptr && !a.dbg) ? 1u : 0u;
     if (a.u32_rows && a.out != nullptr && !((fieldsKernel || litKernel) && a.pf_status != nullptr)) {
       // the persistent kernel has the compact epilogue; when THIS call cannot have it (a rerun, the mode demoted for a while, FindAll's n) the
       // caller uses cxg_find_all_device for the call (CXG_E_INPUT), the program itself stays served
@@ -802,7 +802,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       if (!persKernel) { litKernel = false; a.count_sum = 0; (void)hipGetLastError(); }
     }
     if (litKernel) {}
-    else if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream);
+    else if (trioKernel) le = cxgdev::launch_scan_trio_wave(a, stream, &persKernel);   // (the grouped kernel ignores count_sum: its look-back leaves the total)
     else if (fieldsKernel) le = cxgdev::launch_scan_fields_wave(a, stream, &persKernel);
     else le = cxgdev::launch_scan_chain_wave(a, reinterpret_cast<const cxgdev::ChainAux*>(hb + h->aux_off + 256)->ncls,
                                         (h->flags & cxgdev::kFlagChainSets) != 0, fusedCaps, stream);
@@ -818,7 +818,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? CXG_K_TRIO_WAVE : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -1506,6 +1506,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_FIELDS_PERS: return "k_scan_fields_pers";
     case CXG_K_DELIM_WAVE: return "k_scan_delim_wave";
     case CXG_K_LITERAL_PERS: return "k_scan_fields_pers<LIT>";
+    case CXG_K_TRIO_PERS: return "k_scan_fields_pers<TRIO>";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";

@@ -524,6 +524,208 @@ __global__ __launch_bounds__(kThreads, CXG_FIELDS_WAVES) void k_scan_fields_wave
   }
 }
 
+// ---- tile mathematics of the run-a-run-b-run programs (k_scan_trio_wave below, and the persistent kernel in its TRIO mode) ----
+namespace {
+#ifndef CXG_TRIO_ROWS
+#define CXG_TRIO_ROWS (64 * kTilesPerWave)
+#endif
+#ifndef CXG_TRIO_WAVES
+#define CXG_TRIO_WAVES 8
+#endif
+#ifndef CXG_TRIO_SWAR
+#define CXG_TRIO_SWAR 0                                      // measured (profiles/r05_c2_configs.txt, config 5): SWAR + class plan 0.429 ms, the byte table 0.397
+#endif
+constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per wave and group
+
+struct TrioTile { uint32_t e0, e1; bool ovf; };
+
+// K fields, K - 1 links: lk[i] = bitmap of the bytes of the i-th separator class (word of this lane).  For K >= 3 the separator
+// classes are pairwise different (trio_shape): a candidate can then only share the LAST run of an earlier match.
+// EQ: one separator for every link (K >= 3).  Two candidates can then share up to K - 1 runs, but the selection needs no
+// resolution at all: the matches of a super-run are its fields K at a time from its start, as in the fields kernel.
+template <int K, bool EQ, unsigned long long OWN = kFOwn>
+__device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const uint32_t (&c0)[K - 1], const uint32_t (&c1)[K - 1]) {
+  const uint32_t prev_d1 = dpp_from_lower(d1);
+  const uint32_t next_d0 = dpp_from_upper_ones(d0);
+  const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
+  const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
+  uint32_t lk0[K - 1], lk1[K - 1];
+  uint32_t l0 = 0, l1 = 0;
+#pragma unroll
+  for (int i = 0; i < K - 1; i++) { lk0[i] = c0[i] & Dl0 & Dr0; lk1[i] = c1[i] & Dl1 & Dr1; l0 |= lk0[i]; l1 |= lk1[i]; }
+  const uint32_t la0 = lk0[0], la1 = lk1[0];                       // the first link of a match
+  const uint32_t x0 = d0 | l0, x1 = d1 | l1;                       // super-runs
+  const uint32_t prev_l1 = dpp_from_lower(l1);
+  const uint32_t Ll0 = __builtin_amdgcn_alignbit(l0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(l1, l0, 31);   // L << 1
+  const uint32_t ws0 = sel_lanes(d0 & ~Dl0 & ~Ll0, OWN), ws1 = sel_lanes(d1 & ~Dl1 & ~Ll1, OWN);   // owned super-run starts
+  const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
+  const unsigned long long PPx = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(x1) << 32) | x0, ~0ull, 32 /*eq*/);
+  unsigned long long ovf = 0;
+  auto carry_in = [&](unsigned long long GG, unsigned long long PP) -> unsigned long long {
+    const unsigned long long Pe = PP & ~GG;
+    const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;
+    ovf |= GG | (Pe & recv);
+    return recv;
+  };
+  (void)PPx;
+  // hop over one run from link bits q (subset of L): the carry of q + q runs through the F bytes behind the link
+  auto hop = [&](uint32_t q0, uint32_t q1, uint32_t& r0, uint32_t& r1) {
+    unsigned long long G2;
+    add64_co(d0 | q0, d1 | q1, q0, q1, r0, r1, G2);
+    add64_cin(r0, r1, carry_in(G2, PPd));
+  };
+  auto hops = [&](uint32_t q0, uint32_t q1, uint32_t& e0, uint32_t& e1) {   // ends of the candidates whose first link is in q
+    uint32_t r0, r1;
+    hop(q0, q1, r0, r1);
+#pragma unroll
+    for (int i = 1; i < K - 1; i++) {                                       // ... every further run must end on the link of its place
+      const uint32_t m0 = r0 & lk0[i], m1 = r1 & lk1[i];
+      hop(m0, m1, r0, r1);
+    }
+    e0 = r0 & ~d0; e1 = r1 & ~d1;
+  };
+  uint32_t e0, e1;
+  if (EQ) {
+    uint32_t r0, r1, q0, q1, sel0 = 0, sel1 = 0;
+    hop(ws0, ws1, r0, r1);                                                  // over the first run of every owned super-run:
+    q0 = r0 & l0; q1 = r1 & l1;                                             // its link, if it has one
+    for (int guard = 0; guard < 64; guard++) {
+      hops(q0, q1, e0, e1);
+      sel0 |= e0; sel1 |= e1;
+      const uint32_t n0 = e0 & l0, n1 = e1 & l1;                            // an end on a link: more fields behind it
+      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(n1) << 32) | n0, 0ull, 33 /*ne*/) == 0ull) break;
+      hop(n0, n1, r0, r1);                                                  // over the next match's first run
+      q0 = r0 & l0; q1 = r1 & l1;
+      if (guard == 63) ovf |= 1ull << 63;
+    }
+    return TrioTile{sel0, sel1, (ovf >> 63) != 0ull};
+  }
+  // owned span: the bits of X that the addition of the owned starts clears
+  uint32_t s0, s1;
+  unsigned long long GG;
+  add64_co(x0, x1, ws0, ws1, s0, s1, GG);
+  add64_cin(s0, s1, carry_in(GG, PPx));
+  const uint32_t own0 = x0 & ~s0, own1 = x1 & ~s1;
+  hops(la0 & own0, la1 & own1, e0, e1);
+  // ends that sit on a first link: the candidate that begins with that link (if it is one) shares a run with this match
+  uint32_t xa0 = e0 & la0, xa1 = e1 & la1;
+  if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(xa1) << 32) | xa0, 0ull, 33 /*ne*/) != 0ull) {
+    uint32_t r0 = e0, r1 = e1, sel0 = 0, sel1 = 0;                          // undecided / selected (by their ends)
+    for (int guard = 0; guard < 64; guard++) {
+      uint32_t k0, k1;
+      hops(r0 & la0, r1 & la1, k0, k1);                                     // ends of candidates blocked by undecided ones
+      const uint32_t h0 = r0 & ~k0, h1 = r1 & ~k1;                          // heads: undecided, not blocked by an undecided one
+      sel0 |= h0; sel1 |= h1;
+      hops(h0 & la0, h1 & la1, k0, k1);                                     // what the heads block
+      r0 &= ~(h0 | k0); r1 &= ~(h1 | k1);
+      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(r1) << 32) | r0, 0ull, 33 /*ne*/) == 0ull) break;
+      if (guard == 63) ovf |= 1ull << 63;
+    }
+    e0 = sel0; e1 = sel1;
+  }
+  return TrioTile{e0, e1, (ovf >> 63) != 0ull};
+}
+
+// highest set bit of the 128-bit value (h : l), or -1; and the value with that bit cleared
+__device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
+  if (h) { const int32_t k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
+  if (l) { const int32_t k = 63 - __builtin_clzll(l); l &= ~(1ull << k); return k; }
+  return -1;
+}
+
+// rows of the lane's end bits: start | end << 16 (window bit indices) at rows[r], and the links as distances from the start,
+// (la - start) | (lb - start) << 8, at links[r] (all three lie within two words: < 128) — 6 bytes per row keep the kernel at 8
+// workgroups per CU with 512 rows per wave; r counts up from r0
+template <int K, typename LinkT>
+__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, LinkT* links, uint32_t r, uint32_t cap, uint32_t shift = 0u) {   // shift: added to both halves of a row
+  const uint64_t z = ~((static_cast<uint64_t>(d1) << 32) | d0);             // bytes outside F, this lane's word
+  const uint64_t pz = (static_cast<uint64_t>(dpp_from_lower_z(static_cast<uint32_t>(z >> 32))) << 32) | dpp_from_lower_z(static_cast<uint32_t>(z));   // previous lane's (lane 0: none)
+  const int32_t base = (lane << 6) - 64;                                    // window index of bit 0 of (pz : z)
+  uint64_t ee = (static_cast<uint64_t>(t.e1) << 32) | t.e0;
+  while (ee) {
+    const int32_t b = __builtin_ctzll(ee);
+    ee &= ee - 1ull;
+    uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;             // bytes outside F below the end, nearest first:
+    int32_t pl[K - 1];                                                      // the links, last first
+#pragma unroll
+    for (int i = K - 2; i >= 0; i--) pl[i] = take_top(l, h);
+    const int32_t ps = take_top(l, h);                                      // the byte in front of the match
+    uint32_t w0 = 0, w1 = 0;                                                // start not found within two words: row void (start >= end), caught below
+    if (ps >= 0) {
+      w0 = (static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16)) + shift;
+#pragma unroll
+      for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(pl[i] - ps - 1) << (8 * i);
+    }
+    const uint32_t rr = r < cap ? r : cap - 1u;
+    rows[rr] = w0; links[rr] = static_cast<LinkT>(w1);
+    r++;
+  }
+}
+}  // namespace
+
+
+namespace {
+// Phase A of the TRIO mode of the persistent kernel: the flags of K classes (field class F, K - 1 separator bytes) from ONE byte table in
+// LDS, 16 bits per class and vector through the wave's bitmaps — k_scan_trio_wave's phase A with the halo carry of fields_words.
+// sc0: this wave's words of class 0 (F); class c at + c * kLitClsStride.
+template <int K, bool CARRY>
+__device__ __forceinline__ void trio_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t rnext, int lane, uint64_t* sc0, const uint8_t* s_cls, int32_t nvalid,
+                                           bool carry_cur, bool carry_next, uint32_t& d0, uint32_t& d1, uint32_t (&c0)[K - 1], uint32_t (&c1)[K - 1]) {
+  {
+    const uint32_t voff = static_cast<uint32_t>(lane) << 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int at = lane + 64 * k;
+      if (CARRY && k == 0) at = (carry_cur && lane < 16) ? lane + 256 : lane;
+      const uint32_t w[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+      uint32_t fd = 0, fc[K - 1];
+#pragma unroll
+      for (int i = 0; i < K - 1; i++) fc[i] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t f = static_cast<uint32_t>(s_cls[w[q] & 0xFFu]) | (static_cast<uint32_t>(s_cls[(w[q] >> 8) & 0xFFu]) << 8) |
+                           (static_cast<uint32_t>(s_cls[(w[q] >> 16) & 0xFFu]) << 16) | (static_cast<uint32_t>(s_cls[w[q] >> 24]) << 24);
+        const uint32_t wt = (q & 1) ? 0x80402010u : 0x08040201u;
+        if (q < 2) {
+          fd = __builtin_amdgcn_udot4(f & 0x01010101u, wt, fd, false);
+#pragma unroll
+          for (int i = 0; i < K - 1; i++) fc[i] = __builtin_amdgcn_udot4((f >> (i + 1)) & 0x01010101u, wt, fc[i], false);
+        } else {
+          fd += __builtin_amdgcn_udot4(f & 0x01010101u, wt, 0u, false) << 8;
+#pragma unroll
+          for (int i = 0; i < K - 1; i++) fc[i] += __builtin_amdgcn_udot4((f >> (i + 1)) & 0x01010101u, wt, 0u, false) << 8;
+        }
+      }
+      reinterpret_cast<uint16_t*>(sc0)[at] = static_cast<uint16_t>(fd);
+#pragma unroll
+      for (int i = 0; i < K - 1; i++) reinterpret_cast<uint16_t*>(sc0 + (i + 1) * kLitClsStride)[at] = static_cast<uint16_t>(fc[i]);
+      uint32_t off = voff + 1024u * k;
+      if (CARRY && k == 0 && carry_next && lane < 16) off = 0x7FFFFFF0u;
+      x[k] = __builtin_amdgcn_raw_buffer_load_b128(rnext, off, 0, CXG_HAY_LOAD_AUX);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  wave_lds_sync();
+  int lw = lane;
+  asm volatile("" : "+v"(lw));
+  uint64_t vf = ~0ull;
+  if (nvalid != kFWin) {
+    const int32_t nf = nvalid - 64 * lane;
+    vf = nf <= 0 ? 0ull : (nf >= 64 ? ~0ull : ((1ull << nf) - 1ull));
+  }
+  uint64_t W[K];
+#pragma unroll
+  for (int c = 0; c < K; c++) W[c] = sc0[c * kLitClsStride + lw] & vf;
+  d0 = static_cast<uint32_t>(W[0]); d1 = static_cast<uint32_t>(W[0] >> 32);
+#pragma unroll
+  for (int i = 0; i < K - 1; i++) { c0[i] = static_cast<uint32_t>(W[i + 1]); c1[i] = static_cast<uint32_t>(W[i + 1] >> 32); }
+  if (CARRY && carry_next && lane >= 60) {                          // words 60..63 are the next window's words 0..3
+#pragma unroll
+    for (int c = 0; c < K; c++) sc0[c * kLitClsStride + lane - 60] = W[c];
+  }
+}
+}  // namespace
+
 // =====================================================================================================================
 // k_scan_fields_pers — the same tile mathematics on a PERSISTENT grid of autonomous waves, the ordering of the rows DEFERRED
 // by one round (round 4).  Why: the grouped kernel above spends more of a workgroup's life waiting in the look-back than
@@ -588,10 +790,19 @@ constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64
 // old count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt).
 constexpr uint64_t kPfWaitTicks = 5000000ull;                // 50 ms
 
-// LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused).
+// LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused);
+// 16 + K' + 8 EQ = TRIO mode (round 5): run(F) (byte(c_i) run(F)){K'-1} programs with their capture slots, k_scan_trio_wave's tile
+// mathematics (trio_core<K', EQ>) and row epilogue on this kernel's grid and protocol (BASELINE configs[4], `(\w+)@(\w+)\.(\w+)`).
 template <int K, int KD, int KP, int LIT = 0>
-__global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (three / four bitmaps: 27 / 29 KB of LDS per workgroup — six do not fit a CU)
-  constexpr int kNBitmaps = LIT ? LIT : 2;
+__global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // (three / four bitmaps: 27 / 29 KB of LDS per workgroup — six do not fit a CU)
+  constexpr bool kTrio = LIT >= 16;
+  constexpr int TK = kTrio ? ((LIT - 16) & 7) : 2;                    // fields of a TRIO program
+  constexpr bool TEQ = kTrio && ((LIT - 16) >> 3) != 0;
+  constexpr bool kLit = LIT >= 2 && LIT <= 4;
+  typedef typename std::conditional<TK == 4, uint32_t, uint16_t>::type LinkT;
+  constexpr int kNBitmaps = kTrio ? TK : (kLit ? LIT : 2);
+  __shared__ LinkT s_lnk[kTrio ? 2 : 1][kWavesPerBlock][kTrio ? kPfRows : 1];   // TRIO: the links of a parked row as distances from its start
+  __shared__ uint8_t s_cls[kTrio ? 256 : 4];                          // TRIO: byte -> class flags (bit 0 F, bit i + 1 the separator of link i)
   __shared__ __attribute__((aligned(16))) uint64_t s_c[kNBitmaps][kWavesPerBlock][64 + 4];   // class bitmaps of the wave's window (+ 4 dump words: CARRY)
   uint64_t (*const s_d)[64 + 4] = s_c[0];
   uint64_t (*const s_p)[64 + 4] = s_c[1];
@@ -606,6 +817,14 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
   const uint32_t W = gridDim.x * static_cast<uint32_t>(kWavesPerBlock);
   const uint32_t wv = blockIdx.x * static_cast<uint32_t>(kWavesPerBlock) + static_cast<uint32_t>(wave);
   const uint32_t full = a.pf_full, tpw_last = a.pf_tpw_last, units_last = a.pf_units_last;
+  if (kTrio) {                                                        // (in front of the first early return: every wave of the workgroup reaches the barrier)
+    const ChainAux* tch = reinterpret_cast<const ChainAux*>(a.chain);
+    const uint32_t b = static_cast<uint32_t>(tid);
+    uint32_t f = chain_class_has(*tch, 0, b) ? 1u : 0u;
+    for (int i = 0; i < TK - 1; i++) f |= chain_class_has(*tch, tch->op_cls[2 * i + 1], b) ? (2u << i) : 0u;
+    s_cls[tid] = static_cast<uint8_t>(f);
+    __syncthreads();
+  }
   const uint32_t R_me = full + (wv < units_last ? 1u : 0u);           // rounds in which this wave has a unit
   if (R_me == 0) { if (a.count_sum != 0u && lane0 == 0) a.status[wv] = 0; return; }   // (short input, tapered round with fewer units than waves)
   const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
@@ -614,7 +833,7 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
   const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
   const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
   LitRegs lr;
-  if (LIT) {
+  if (kLit) {
     lr.m = gch->nops; lr.nc = gch->ncls; lr.cls2_lo = gch->cls2_lo; lr.cls2_hi = gch->cls2_hi;
 #pragma unroll
     for (int c = 0; c < 4; c++) lr.b4[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[c] * 0x01010101u)));
@@ -623,6 +842,23 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
   const uint32_t tag = ep << 16;
   const bool want_rows = a.out != nullptr || a.max_len != 0;
   const bool order = a.count_sum == 0u;                               // count-only calls need no place in the output
+  // TRIO: which two slots of a row this lane writes and what they are made of (k_scan_trio_wave's epilogue): sel 0 start, 1 end,
+  // 2 + i the end of run i (link i), 7 unset
+  uint32_t t_lsh = 0, t_pr = 0, t_sel0 = 0, t_sel1 = 1; int32_t t_off0 = 0, t_off1 = 0; bool t_lane_on = true;
+  if (kTrio) {
+    const ChainCaps* cp = reinterpret_cast<const ChainCaps*>(a.caps);
+    const uint32_t npairs = a.row_width >> 1;
+    t_lsh = npairs <= 1u ? 0u : 32u - static_cast<uint32_t>(__builtin_clz(npairs - 1u));
+    t_pr = static_cast<uint32_t>(lane0) & ((1u << t_lsh) - 1u);
+    t_lane_on = t_pr < npairs;
+    auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {
+      const uint32_t src = cp->src[k];
+      sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 7u;
+      if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = (op >> 1) < static_cast<uint32_t>(TK - 1) ? 2u + (op >> 1) : 1u; }
+      off = cp->off[k];
+    };
+    if (cp->on == 1u && t_lane_on) { slot_of(2u * t_pr, t_sel0, t_off0); slot_of(2u * t_pr + 1u, t_sel1, t_off1); }
+  }
   const uint32_t myblk = wv >> 6, myidx = wv & 63u;
   const uint32_t hw_wave = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (3 << 11)) & 15u;   // wave slot on its SIMD
 
@@ -752,22 +988,29 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
         const uint64_t lo_next = (last ? unit_tile(r + 1) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
         const __amdgpu_buffer_rsrc_t rnext = fields_window<kPre>(a.hay, a.len, lo_next, more, nvalid_next);
         uint32_t d0 = 0, d1 = 0, p0 = 0, p1 = 0;
-        if (LIT) lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, j != 0u, !last);
+        uint32_t tc0[TK - 1], tc1[TK - 1];
+        if (kTrio) trio_words<TK, kCarry>(x, rnext, lane, &s_c[0][wave][0], s_cls, nvalid_cur, j != 0u, !last, d0, d1, tc0, tc1);
+        else if (kLit) lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, j != 0u, !last);
         else fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
         nvalid_cur = nvalid_next;
         const bool duty = duty_stage != 0u;                           // a leader's look of this tile
         u32x4 dv = {0u, 0u, 0u, 0u};
         if (duty) duty_load(dv);
         if (last && order && r > 0) status_load(r - 1, vr, vs);       // consumed behind this tile's mathematics
-        const FieldsTile t = LIT ? lit_core<kOwn>(&s_c[0][wave][0], lane, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
-        if (LIT && kCarry && !last) lit_carry<kNBitmaps>(&s_c[0][wave][0], lane);
+        FieldsTile t;
+        if (kTrio) { const TrioTile tt = trio_core<TK, TEQ, kOwn>(d0, d1, tc0, tc1); t = FieldsTile{tt.e0, tt.e1, 0u, 0u, tt.ovf}; }
+        else t = kLit ? lit_core<kOwn>(&s_c[0][wave][0], lane, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
+        if (kLit && kCarry && !last) lit_carry<kNBitmaps>(&s_c[0][wave][0], lane);
         if (t.ovf) fallback |= 1u;
         const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
         const uint32_t incl = wave_inclusive_sum_fused(c);
         const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-        if (tot != 0 && want_rows)
-          fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kPfRows - 1)); },
-                      j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
+        if (tot != 0 && want_rows) {
+          if (kTrio) trio_rows<TK, LinkT>(TrioTile{t.e0, t.e1, t.ovf}, d0, d1, lane, s_row[par][wave], s_lnk[kTrio ? par : 0][wave], nrows_w + incl - c, static_cast<uint32_t>(kPfRows),
+                                          j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
+          else fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kPfRows - 1)); },
+                           j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
+        }
         nrows_w += tot;
         if (duty) duty_check(dv);
       }
@@ -813,6 +1056,17 @@ __global__ __launch_bounds__(kThreads, (LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_
       if (a.out != nullptr && CXG_PFABL < 3) {
         const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(unit_tile(rp) * static_cast<uint64_t>(kWaveTile)) - kPre;
         const uint32_t n = nrows_prev < static_cast<uint32_t>(kPfRows) ? nrows_prev : static_cast<uint32_t>(kPfRows);
+        if (kTrio) {                                                  // capture rows (or spans): k_scan_trio_wave's epilogue, a power of two of lanes per row
+          for (uint32_t i = lane0; i < (n << t_lsh); i += 64) {
+            const uint32_t rr = i >> t_lsh;
+            if (t_lane_on && base + rr < a.cap) {
+              const uint32_t w0 = s_row[parp][wave][rr], w1 = s_lnk[kTrio ? parp : 0][wave][rr];
+              const int64_t ps = origin + (w0 & 0xFFFFu), pe = origin + (w0 >> 16);
+              auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
+              store_pair_nt(a.out + (base + rr) * a.row_width + 2u * t_pr, t_sel0 == 7u ? -1 : pos_of(t_sel0) + t_off0, t_sel1 == 7u ? -1 : pos_of(t_sel1) + t_off1);
+            }
+          }
+        } else
         for (uint32_t i = lane0; i < n; i += 64) {
           if (base + i < a.cap) {
             const uint32_t v = s_row[parp][wave][i];
@@ -1006,144 +1260,6 @@ hipError_t launch_scan_fields_wave(const ScanArgs& a, hipStream_t stream, bool* 
 //      A row is four positions (start, LA link, LB link, end); the epilogue turns them into the program's capture slots
 //      (walk.hpp ChainCaps: start / end / end of the first / second run, plus a constant) or into [start, end).
 // Fallback flag: as for the fields kernel (the host reruns on scan_chain_wave.hip).
-namespace {
-#ifndef CXG_TRIO_ROWS
-#define CXG_TRIO_ROWS (64 * kTilesPerWave)
-#endif
-#ifndef CXG_TRIO_WAVES
-#define CXG_TRIO_WAVES 8
-#endif
-#ifndef CXG_TRIO_SWAR
-#define CXG_TRIO_SWAR 0                                      // measured (profiles/r05_c2_configs.txt, config 5): SWAR + class plan 0.429 ms, the byte table 0.397
-#endif
-constexpr int kTRows = CXG_TRIO_ROWS;                     // rows buffered per wave and group
-
-struct TrioTile { uint32_t e0, e1; bool ovf; };
-
-// K fields, K - 1 links: lk[i] = bitmap of the bytes of the i-th separator class (word of this lane).  For K >= 3 the separator
-// classes are pairwise different (trio_shape): a candidate can then only share the LAST run of an earlier match.
-// EQ: one separator for every link (K >= 3).  Two candidates can then share up to K - 1 runs, but the selection needs no
-// resolution at all: the matches of a super-run are its fields K at a time from its start, as in the fields kernel.
-template <int K, bool EQ>
-__device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const uint32_t (&c0)[K - 1], const uint32_t (&c1)[K - 1]) {
-  const uint32_t prev_d1 = dpp_from_lower(d1);
-  const uint32_t next_d0 = dpp_from_upper_ones(d0);
-  const uint32_t Dl0 = __builtin_amdgcn_alignbit(d0, prev_d1, 31), Dl1 = __builtin_amdgcn_alignbit(d1, d0, 31);   // D << 1
-  const uint32_t Dr0 = __builtin_amdgcn_alignbit(d1, d0, 1), Dr1 = __builtin_amdgcn_alignbit(next_d0, d1, 1);     // D >> 1
-  uint32_t lk0[K - 1], lk1[K - 1];
-  uint32_t l0 = 0, l1 = 0;
-#pragma unroll
-  for (int i = 0; i < K - 1; i++) { lk0[i] = c0[i] & Dl0 & Dr0; lk1[i] = c1[i] & Dl1 & Dr1; l0 |= lk0[i]; l1 |= lk1[i]; }
-  const uint32_t la0 = lk0[0], la1 = lk1[0];                       // the first link of a match
-  const uint32_t x0 = d0 | l0, x1 = d1 | l1;                       // super-runs
-  const uint32_t prev_l1 = dpp_from_lower(l1);
-  const uint32_t Ll0 = __builtin_amdgcn_alignbit(l0, prev_l1, 31), Ll1 = __builtin_amdgcn_alignbit(l1, l0, 31);   // L << 1
-  const uint32_t ws0 = sel_lanes(d0 & ~Dl0 & ~Ll0, kFOwn), ws1 = sel_lanes(d1 & ~Dl1 & ~Ll1, kFOwn);   // owned super-run starts
-  const unsigned long long PPd = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(d1) << 32) | d0, ~0ull, 32 /*eq*/);
-  const unsigned long long PPx = __builtin_amdgcn_uicmpl((static_cast<uint64_t>(x1) << 32) | x0, ~0ull, 32 /*eq*/);
-  unsigned long long ovf = 0;
-  auto carry_in = [&](unsigned long long GG, unsigned long long PP) -> unsigned long long {
-    const unsigned long long Pe = PP & ~GG;
-    const unsigned long long recv = (Pe + (GG << 1)) ^ Pe;
-    ovf |= GG | (Pe & recv);
-    return recv;
-  };
-  (void)PPx;
-  // hop over one run from link bits q (subset of L): the carry of q + q runs through the F bytes behind the link
-  auto hop = [&](uint32_t q0, uint32_t q1, uint32_t& r0, uint32_t& r1) {
-    unsigned long long G2;
-    add64_co(d0 | q0, d1 | q1, q0, q1, r0, r1, G2);
-    add64_cin(r0, r1, carry_in(G2, PPd));
-  };
-  auto hops = [&](uint32_t q0, uint32_t q1, uint32_t& e0, uint32_t& e1) {   // ends of the candidates whose first link is in q
-    uint32_t r0, r1;
-    hop(q0, q1, r0, r1);
-#pragma unroll
-    for (int i = 1; i < K - 1; i++) {                                       // ... every further run must end on the link of its place
-      const uint32_t m0 = r0 & lk0[i], m1 = r1 & lk1[i];
-      hop(m0, m1, r0, r1);
-    }
-    e0 = r0 & ~d0; e1 = r1 & ~d1;
-  };
-  uint32_t e0, e1;
-  if (EQ) {
-    uint32_t r0, r1, q0, q1, sel0 = 0, sel1 = 0;
-    hop(ws0, ws1, r0, r1);                                                  // over the first run of every owned super-run:
-    q0 = r0 & l0; q1 = r1 & l1;                                             // its link, if it has one
-    for (int guard = 0; guard < 64; guard++) {
-      hops(q0, q1, e0, e1);
-      sel0 |= e0; sel1 |= e1;
-      const uint32_t n0 = e0 & l0, n1 = e1 & l1;                            // an end on a link: more fields behind it
-      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(n1) << 32) | n0, 0ull, 33 /*ne*/) == 0ull) break;
-      hop(n0, n1, r0, r1);                                                  // over the next match's first run
-      q0 = r0 & l0; q1 = r1 & l1;
-      if (guard == 63) ovf |= 1ull << 63;
-    }
-    return TrioTile{sel0, sel1, (ovf >> 63) != 0ull};
-  }
-  // owned span: the bits of X that the addition of the owned starts clears
-  uint32_t s0, s1;
-  unsigned long long GG;
-  add64_co(x0, x1, ws0, ws1, s0, s1, GG);
-  add64_cin(s0, s1, carry_in(GG, PPx));
-  const uint32_t own0 = x0 & ~s0, own1 = x1 & ~s1;
-  hops(la0 & own0, la1 & own1, e0, e1);
-  // ends that sit on a first link: the candidate that begins with that link (if it is one) shares a run with this match
-  uint32_t xa0 = e0 & la0, xa1 = e1 & la1;
-  if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(xa1) << 32) | xa0, 0ull, 33 /*ne*/) != 0ull) {
-    uint32_t r0 = e0, r1 = e1, sel0 = 0, sel1 = 0;                          // undecided / selected (by their ends)
-    for (int guard = 0; guard < 64; guard++) {
-      uint32_t k0, k1;
-      hops(r0 & la0, r1 & la1, k0, k1);                                     // ends of candidates blocked by undecided ones
-      const uint32_t h0 = r0 & ~k0, h1 = r1 & ~k1;                          // heads: undecided, not blocked by an undecided one
-      sel0 |= h0; sel1 |= h1;
-      hops(h0 & la0, h1 & la1, k0, k1);                                     // what the heads block
-      r0 &= ~(h0 | k0); r1 &= ~(h1 | k1);
-      if (__builtin_amdgcn_uicmpl((static_cast<uint64_t>(r1) << 32) | r0, 0ull, 33 /*ne*/) == 0ull) break;
-      if (guard == 63) ovf |= 1ull << 63;
-    }
-    e0 = sel0; e1 = sel1;
-  }
-  return TrioTile{e0, e1, (ovf >> 63) != 0ull};
-}
-
-// highest set bit of the 128-bit value (h : l), or -1; and the value with that bit cleared
-__device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
-  if (h) { const int32_t k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
-  if (l) { const int32_t k = 63 - __builtin_clzll(l); l &= ~(1ull << k); return k; }
-  return -1;
-}
-
-// rows of the lane's end bits: start | end << 16 (window bit indices) at rows[r], and the links as distances from the start,
-// (la - start) | (lb - start) << 8, at links[r] (all three lie within two words: < 128) — 6 bytes per row keep the kernel at 8
-// workgroups per CU with 512 rows per wave; r counts up from r0
-template <int K, typename LinkT>
-__device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32_t d1, int lane, uint32_t* rows, LinkT* links, uint32_t r, uint32_t cap) {
-  const uint64_t z = ~((static_cast<uint64_t>(d1) << 32) | d0);             // bytes outside F, this lane's word
-  const uint64_t pz = (static_cast<uint64_t>(dpp_from_lower_z(static_cast<uint32_t>(z >> 32))) << 32) | dpp_from_lower_z(static_cast<uint32_t>(z));   // previous lane's (lane 0: none)
-  const int32_t base = (lane << 6) - 64;                                    // window index of bit 0 of (pz : z)
-  uint64_t ee = (static_cast<uint64_t>(t.e1) << 32) | t.e0;
-  while (ee) {
-    const int32_t b = __builtin_ctzll(ee);
-    ee &= ee - 1ull;
-    uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;             // bytes outside F below the end, nearest first:
-    int32_t pl[K - 1];                                                      // the links, last first
-#pragma unroll
-    for (int i = K - 2; i >= 0; i--) pl[i] = take_top(l, h);
-    const int32_t ps = take_top(l, h);                                      // the byte in front of the match
-    uint32_t w0 = 0, w1 = 0;                                                // start not found within two words: row void (start >= end), caught below
-    if (ps >= 0) {
-      w0 = static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16);
-#pragma unroll
-      for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(pl[i] - ps - 1) << (8 * i);
-    }
-    const uint32_t rr = r < cap ? r : cap - 1u;
-    rows[rr] = w0; links[rr] = static_cast<LinkT>(w1);
-    r++;
-  }
-}
-}  // namespace
-
 template <int K, bool EQ>
 __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_scan_trio_wave(ScanArgs a) {
   typedef typename std::conditional<K == 4, uint32_t, uint16_t>::type LinkT;   // K - 1 byte distances per row
@@ -1377,8 +1493,21 @@ int trio_shape(const ChainAux& c) {
   return K;
 }
 
-hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream) {
+hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* persistent) {
+  if (persistent) *persistent = false;
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
+  if (a.pf_status != nullptr) {                                      // the persistent kernel's TRIO mode (round 5)
+    bool done = false;
+    switch (trio_shape(*reinterpret_cast<const ChainAux*>(a.chain))) {
+      case 2: done = launch_pers_inst<2, kClsByte, kClsByte, 16 + 2>(a, stream); break;
+      case 3: done = launch_pers_inst<2, kClsByte, kClsByte, 16 + 3>(a, stream); break;
+      case 4: done = launch_pers_inst<2, kClsByte, kClsByte, 16 + 4>(a, stream); break;
+      case 3 | 8: done = launch_pers_inst<2, kClsByte, kClsByte, 16 + 3 + 8>(a, stream); break;
+      case 4 | 8: done = launch_pers_inst<2, kClsByte, kClsByte, 16 + 4 + 8>(a, stream); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (done) { if (persistent) *persistent = true; return hipGetLastError(); }
+  }
   switch (trio_shape(*reinterpret_cast<const ChainAux*>(a.chain))) {
     case 2: hipLaunchKernelGGL((k_scan_trio_wave<2, false>), grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL((k_scan_trio_wave<3, false>), grid, block, 0, stream, a); break;
