@@ -216,6 +216,8 @@ class DeviceWorkload:
             if live is not None:
                 result["roofline"]["traffic"] = live["traffic_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = live["source"]
+                result["roofline"]["traffic_counters"] = {"FETCH_SIZE_KB_mean": live["FETCH_SIZE_KB_mean"], "WRITE_SIZE_KB_mean": live["WRITE_SIZE_KB_mean"],
+                                                           "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM); WRITE_SIZE as reported"}
             elif result["roofline"]["traffic"] is not None:
                 result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not self.u32 and not os.environ.get("CXG_DEBUG"):
@@ -575,7 +577,7 @@ def _pmc_traffic_live(args, kernel):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     fetch_kb, write_kb = means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]
-    return {"traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+    return {"traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024), "FETCH_SIZE_KB_mean": round(fetch_kb, 1), "WRITE_SIZE_KB_mean": round(write_kb, 1),
             "source": f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one counter per child pass of this command "
                       f"({means['FETCH_SIZE'][2]} launches of {means['FETCH_SIZE'][0]}), 2 x FETCH_SIZE + WRITE_SIZE"}
 

@@ -745,7 +745,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
     a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
-    bool persWanted = (fieldsKernel || litKernel || trioKernel) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
+    // (TRIO mode: built and measured in round 5 — config 5 0.438 ms against 0.395 on the grouped kernel, `(\d+)\.(\d+)\.(\d+)\.(\d+)` 0.57
+    // against 0.44: that mathematics is VALU- and LDS-bound and the persistent instantiation holds half the waves — so off unless asked for)
+    static const bool trioPers = getenv("CXG_TRIO_PERS") != nullptr;
+    bool persWanted = (fieldsKernel || litKernel || (trioKernel && trioPers)) && persOk && a.static_groups && a.limit == 0 && a.prof == nullptr && a.dbg == 0 && !persDenied;
     if (persWanted && !ps.persistent.allowed()) { ps.persistent.consume(); persDenied = true; persWanted = false; }
     if (persWanted) {
       const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
