@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -200,6 +201,23 @@ thread_local ScratchSet t_scratch_set;
 #define t_scratch t_scratch_set.s
 // Staging buffers above this size are returned after the call instead of being kept for the thread's lifetime.
 constexpr uint64_t kKeepStagingBytes = 256ull << 20;
+
+// Wait for the call's stream.  hipStreamSynchronize parks the thread and is woken by an interrupt (~10 us after the kernel ended);
+// a 1 GiB scan takes 0.22 ms, so the first 2 ms are spent polling hipStreamQuery instead (round 5: the synchronous entry's wall time
+// per call minus the kernel time fell from ~20 us; CXG_NO_SPIN_SYNC=1 restores the plain wait).
+hipError_t syncStream(hipStream_t stream) {
+  static const bool spin = getenv("CXG_NO_SPIN_SYNC") == nullptr;
+  if (spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0;; i++) {
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) return q;
+      if ((i & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  return hipStreamSynchronize(stream);
+}
 
 int getScratch(Scratch** out) {
   if (deviceCount() <= 0) return fail(CXG_E_NO_GPU, "no gfx950 device visible (this library has no CPU search path)");
@@ -646,7 +664,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     }
     a.fsm_maps = s.fsmMaps;
   }
-  if (!(as != nullptr && useEpoch)) HIP_TRY(hipEventRecord(s.ev[0], stream));
+  // events only for a caller that asked for timing (the cgo shim does not); the "total" event only in front of a memset
+  const bool wantEv = timing != nullptr && !(as != nullptr && useEpoch);
+  const bool ev0 = wantEv && (!useEpoch || s.needZero || s.epoch >= 1023u);
+  if (ev0) HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (useEpoch) {
     if (s.needZero || s.epoch >= 1023u) {
       HIP_TRY(hipMemsetAsync(s.ctl, 0, 64 + 2 * s.statusCap * sizeof(uint64_t), stream));
@@ -672,7 +693,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   }
   const bool goAsync = as != nullptr && useEpoch;
   static const bool asyncTiming = getenv("CXG_ASYNC_TIMING") != nullptr;   // a start event per pending launch (cxg_wait's kernel_ms); off: one event per launch
-  if (!goAsync) HIP_TRY(hipEventRecord(s.ev[1], stream));
+  if (!goAsync) { if (wantEv) HIP_TRY(hipEventRecord(s.ev[1], stream)); }
   else if (asyncTiming) HIP_TRY(hipEventRecord(as->ev[0], stream));
   hipError_t le;
   a.blob = gen == 10 ? d_fsm : d_blob;
@@ -836,15 +857,15 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     return kRcPending;
   }
   if (submatch && a.out && !fusedCaps) { if (int rc = launchCapturePass(p, s, a, d_cap, stream, launches)) return rc; }
-  HIP_TRY(hipEventRecord(s.ev[2], stream));
+  if (wantEv) HIP_TRY(hipEventRecord(s.ev[2], stream));
   if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));   // wave kernels wrote hostCtl themselves
-  HIP_TRY(hipStreamSynchronize(stream));
+  HIP_TRY(syncStream(stream));
   const uint64_t total = s.hostCtl[1];
   uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
   if (timing) {
     float k = 0, t = 0;
     (void)hipEventElapsedTime(&k, s.ev[1], s.ev[2]);
-    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
+    if (ev0) (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]); else t = k;
     timing->kernel_ms = k; timing->total_ms = t; timing->n_launches = launches + relaunches;
     timing->n_ladder = nladder;
     std::memcpy(timing->ladder, ladder, sizeof ladder);
