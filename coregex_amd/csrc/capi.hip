@@ -267,6 +267,8 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
                  uint64_t* n_out, void* user_stream, cxg_timing* timing);
 int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
                    uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width);
+int scanNullableSubmatch(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                         uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width);
 thread_local bool t_u32Rows = false;
 thread_local Scratch::AsyncSlot* t_asyncSlot = nullptr;            // cxg_find_all_device_async in progress on this thread: leave the first launch pending if it can be
 constexpr int kRcPending = -1001;                                  // (internal) scanDeviceOnce left its launch in the slot                               // cxg_find_all_device_u32 in progress on this thread (ScanArgs::u32_rows)
@@ -1023,6 +1025,7 @@ constexpr int kMaxBothRestarts = 64;
 int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                uint64_t cap, uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
   if (p && p->nullable && row_width == 2 && p->supported) return scanNullable(p, d_hay, len, base, limit, d_out, cap, n_out, user_stream, timing);
+  if (p && p->nullable && row_width > 2 && p->subNullable && p->supported) return scanNullableSubmatch(p, d_hay, len, base, limit, d_out, cap, n_out, user_stream, timing, row_width);
   // capture slots at fixed distances from the span's ends: FindAll + one expansion kernel (no capture pass per row), unless the
   // chain kernels write the slots themselves
   static const bool offCapsOk = getenv("CXG_NO_OFFSET_CAPS") == nullptr;
@@ -1323,6 +1326,103 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
   return CXG_OK;
 }
 
+// ---- FindAllSubmatch of a nullable pattern (round 5; meta/findall.go:390-447) ------------------------------------------------------------
+// Rows of FindAllIndex (scanNullable: the non-empty variant's rows + the empty matches, Go's skip rule) widened to 2 x groups, then the
+// backtracking capture pass over the pattern's own NFA for EVERY row: anchored at the row's start, accepting at its end — for an
+// empty row the top-priority empty path, which decides the groups that take part (`(a*)(b)?` at an empty match: group 1 = (p, p),
+// group 2 unset).
+__global__ void k_null_sub_expand(const int64_t* spans, uint64_t n, uint32_t width, int64_t* out) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // one thread per pair of slots
+  const uint32_t pairs = width >> 1;
+  const uint64_t i = t / pairs;
+  const uint32_t k = static_cast<uint32_t>(t % pairs) * 2u;
+  if (i >= n) return;
+  if (k == 0) cxgdev::store_pair_nt(out + i * width, spans[2 * i], spans[2 * i + 1]);
+  else cxgdev::store_pair_nt(out + i * width + k, -1, -1);
+}
+// The reference's own quirk, kept: a search that STARTS at the end of the haystack answers an empty match with every group unset
+// (nfa/pikevm.go:2201-2212: buildCapturesFromSlots(nil, at, at)), and for a nullable pattern the empty match at len is always found by a
+// search that starts there.  Only the last row can be that match.
+__global__ void k_null_sub_eoi(int64_t* out, uint64_t n, uint32_t width, int64_t end_abs) {
+  int64_t* row = out + (n - 1) * width;
+  if (row[0] == end_abs && row[1] == end_abs) for (uint32_t k = 2 + threadIdx.x; k < width; k += blockDim.x) row[k] = -1;
+}
+int scanNullableSubmatch(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
+                         uint64_t* n_out, void* user_stream, cxg_timing* timing, int row_width) {
+  if (n_out) *n_out = 0;
+  if (!d_out) return scanNullable(p, d_hay, len, base, limit, nullptr, 0, n_out, user_stream, timing);   // a row per match
+  if (reinterpret_cast<uintptr_t>(d_out) & 15u) return fail(CXG_E_INVALID, "device output must be 16-byte aligned");
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  Scratch& s = *sp;
+  hipStream_t stream = user_stream ? static_cast<hipStream_t>(user_stream) : s.stream;
+  cxg_timing t0;
+  std::memset(&t0, 0, sizeof t0);
+  float kernel_ms = 0, total_ms = 0;
+  uint32_t launches = 0;
+  uint64_t n = 0;
+  if (int rc = scanNullable(p, d_hay, len, base, limit, nullptr, 0, &n, user_stream, &t0)) return rc;   // the count sizes the span array
+  kernel_ms += t0.kernel_ms; total_ms += t0.total_ms; launches += t0.n_launches;
+  if (n_out) *n_out = n;
+  if (n > cap) return fail(CXG_E_CAPACITY, "output capacity too small");
+  if (n == 0) { if (timing) { *timing = t0; } return CXG_OK; }
+  if (2 * n + 2 > s.offSpansCap) {
+    if (s.offSpans) HIP_TRY(hipFree(s.offSpans));
+    s.offSpans = nullptr; s.offSpansCap = 0;
+    const uint64_t c = 2 * n + n / 2 + 1024;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.offSpans), c * sizeof(int64_t)));
+    s.offSpansCap = c;
+  }
+  uint64_t n2 = 0;
+  if (int rc = scanNullable(p, d_hay, len, base, limit, s.offSpans, n, &n2, user_stream, &t0)) return rc;
+  if (n2 != n) return fail(CXG_E_INTERNAL, "nullable captures: the rerun for rows disagrees with the count");
+  kernel_ms += t0.kernel_ms; total_ms += t0.total_ms; launches += t0.n_launches;
+  const uint8_t* d_cap = nullptr;
+  if (int rc = deviceCopy(p->capBlob, &const_cast<cxg_program*>(p)->devCap[t_device], &d_cap)) return rc;
+  if (!s.bothFirst) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothFirst), 16));
+  uint32_t* d_err = reinterpret_cast<uint32_t*>(s.bothFirst);
+  HIP_TRY(hipMemsetAsync(d_err, 0, 8, stream));
+  HIP_TRY(hipEventRecord(s.ev[0], stream));
+  int64_t* out = static_cast<int64_t*>(d_out);
+  const uint32_t width = static_cast<uint32_t>(row_width);
+  {
+    const uint64_t threads = n * (width / 2);
+    hipLaunchKernelGGL(k_null_sub_expand, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream, s.offSpans, n, width, out);
+  }
+  {
+    const unsigned blk = 64, grd = static_cast<unsigned>(std::min<uint64_t>((n + blk - 1) / blk, 64));
+    const size_t need = static_cast<size_t>(grd) * blk * (cxgdev::kBtVisitedWords * 4ull + cxgdev::kBtStackEntries * 8ull);
+    if (s.btCap < need) {
+      if (s.bt) HIP_TRY(hipFree(s.bt));
+      s.bt = nullptr; s.btCap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bt), need));
+      s.btCap = need;
+    }
+    const uint32_t img = reinterpret_cast<const cxgdev::BtHeader*>(p->capBlob.data())->total_bytes;
+    const uint32_t img_lds = img <= 16384u ? ((img + 3u) & ~3u) : 0u;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned g1 = static_cast<unsigned>(std::min<uint64_t>((n + 255) / 256, static_cast<uint64_t>(cus) * 2u));
+    const uint8_t* hay = static_cast<const uint8_t*>(d_hay);
+    hipLaunchKernelGGL(k_captures_bt_lds<false>, dim3(g1), dim3(256), img_lds, stream, hay, base, len, out, n, width, d_cap, img_lds, d_err);
+    hipLaunchKernelGGL(k_captures_bt<false>, dim3(grd), dim3(blk), 0, stream, hay, base, len, out, n, width, d_cap, s.bt, d_err);
+    hipLaunchKernelGGL(k_null_sub_eoi, dim3(1), dim3(64), 0, stream, out, n, width, base + static_cast<int64_t>(len));
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(s.ev[2], stream));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  float t = 0;
+  (void)hipEventElapsedTime(&t, s.ev[0], s.ev[2]);
+  kernel_ms += t; total_ms += t; launches += 3;
+  if (timing) { *timing = t0; timing->kernel_ms = kernel_ms; timing->total_ms = total_ms; timing->n_launches = launches; }
+  if (s.offSpansCap * sizeof(int64_t) > kKeepStagingBytes) { (void)hipFree(s.offSpans); s.offSpans = nullptr; s.offSpansCap = 0; }
+  if (err & cxgdev::kErrSerialLimit) return fail(CXG_E_INPUT, "nullable captures: a match too long for the backtracking pass's budget (65 536 / NFA states bytes)");
+  if (err) return fail(CXG_E_INTERNAL, "nullable captures: the backtracking pass found no path for a row (flag " + std::to_string(err) + ")");
+  return CXG_OK;
+}
+
 // ---- offset captures ---------------------------------------------------------------------------------------------------------
 struct OffCapsArg { uint8_t src[32]; int32_t delta[32]; };
 __global__ void k_caps_offsets(const int64_t* spans, uint64_t n, uint32_t width, OffCapsArg oc, int64_t* out) {
@@ -1410,7 +1510,7 @@ int scanHostBuffer(const cxg_program* p, const uint8_t* hay, uint64_t len, int64
   if (width > 2 ? !(p->subSupported || (p->offCapsOn && p->supported)) : !p->supported)   // (the predicate of cxg_program_submatch_supported)
     return fail(CXG_E_UNSUPPORTED, width > 2 ? p->subWhyNot : (p->whyNot.empty() ? "unsupported program" : p->whyNot));
   if (n_out) *n_out = 0;
-  if (limit == 0 || (len == 0 && !(p->nullable && width == 2))) return CXG_OK;   // (a nullable pattern matches the empty haystack once)
+  if (limit == 0 || (len == 0 && !p->nullable)) return CXG_OK;   // (a nullable pattern matches the empty haystack once, captures included)
   Scratch* sp;
   if (int rc = getScratch(&sp)) return rc;
   Scratch& s = *sp;

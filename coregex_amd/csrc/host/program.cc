@@ -1385,8 +1385,47 @@ void deriveChainCaps(const cxgdev::ChainAux& chain, const std::vector<uint8_t>& 
 
 }  // namespace
 
+// General capture pass: the NFA itself as a device image, walked depth-first in priority order per match row (device/bt.hpp).
+static void buildBtCaptureImage(cxg_program* p, const cxg_nfa& nfa, bool hasLook) {
+      if (nfa.n_states > 4096 || nfa.n_trans > (1u << 20)) throw BuildError{CXG_E_UNSUPPORTED, "NFA too large for the backtracking capture image"};
+      cxgdev::BtHeader bh;
+      std::memset(&bh, 0, sizeof bh);
+      bh.magic = cxgdev::kBtMagic; bh.n_states = nfa.n_states; bh.n_trans = nfa.n_trans; bh.start = nfa.start_anchored;
+      bh.nslots = nfa.capture_count * 2;
+      std::vector<uint8_t> bb(sizeof bh, 0);
+      bh.states_off = static_cast<uint32_t>(bb.size());
+      for (uint32_t i = 0; i < nfa.n_states; i++) {
+        const cxg_nfa_state& x = nfa.states[i];
+        cxgdev::BtState t;
+        std::memset(&t, 0, sizeof t);
+        t.kind = x.kind; t.lo = x.lo; t.hi = x.hi;
+        t.next = x.kind == CXG_NFA_SPLIT ? x.left : x.next;
+        t.alt = x.kind == CXG_NFA_SPLIT ? x.right : cxgdev::kBtInvalid;
+        if (x.kind == CXG_NFA_CAPTURE) { const uint32_t sl = x.cap_index * 2 + (x.cap_start ? 0u : 1u); t.cap_slot = static_cast<uint8_t>(sl < 255 ? sl : 255); }
+        if (x.kind == CXG_NFA_SPARSE) {
+          if (x.trans_len > 0xFFFu) throw BuildError{CXG_E_UNSUPPORTED, "sparse state with more than 4095 transitions"};
+          t.trans_off_len = (x.trans_off << 12) | x.trans_len;
+        }
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
+        bb.insert(bb.end(), q, q + sizeof t);
+      }
+      bh.trans_off = static_cast<uint32_t>(bb.size());
+      for (uint32_t i = 0; i < nfa.n_trans; i++) {
+        cxgdev::BtTrans t{nfa.trans[i].lo, nfa.trans[i].hi, 0, nfa.trans[i].next};
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
+        bb.insert(bb.end(), q, q + sizeof t);
+      }
+      while (bb.size() % 16) bb.push_back(0);
+      bh.total_bytes = static_cast<uint32_t>(bb.size());
+      std::memcpy(bb.data(), &bh, sizeof bh);
+      p->capBlob.swap(bb);
+      p->capHasLook = hasLook;
+      std::memset(p->chainCaps, 0, sizeof p->chainCaps);
+}
+
 void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
   p->subSupported = false;
+  p->subNullable = false;
   try {
     if (nfa.capture_count > 16) throw BuildError{CXG_E_UNSUPPORTED, "more than 15 capture groups"};
     if (nfa.start_unanchored == nfa.start_anchored) throw BuildError{CXG_E_UNSUPPORTED, "start-anchored pattern"};
@@ -1425,7 +1464,20 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
     } else {
     // ---- spans: unanchored forward + reverse DFA (the bidirectional image of buildProgramFromNfa)
     Dfa fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
-    if (fwd.start >= fwd.firstAccept) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+    if (fwd.start >= fwd.firstAccept) {
+      // Nullable pattern (round 5; meta/findall.go:390-447, the same empty-match rule as FindAllIndex :247-257): the spans are what the
+      // FindAllIndex program of the pattern gives (non-empty variant + merged empty matches, capi.hip scanNullable); every row — the empty
+      // ones too: the top-priority empty path decides which groups take part — gets its slots from the backtracking pass over THIS NFA
+      // anchored at the row's start and ending at its end.  A search of a nullable pattern always answers at its own start position, so
+      // the reported match is the top-priority path from there, which is what the pass finds first.
+      if (!(p->nullable && p->supported)) throw BuildError{CXG_E_UNSUPPORTED, "nullable pattern (empty matches)"};
+      buildBtCaptureImage(p, nfa, false);
+      p->subBlob.clear(); p->subFsmBlob.clear();
+      std::memset(p->chainCaps, 0, sizeof p->chainCaps);
+      p->subNullable = true;
+      p->subSupported = true;
+      return;
+    }
     HostNfa rn = reverseOf(nfa);
     cxg_nfa rv = rn.view();
     Dfa rev = determinize(rv, rv.start_anchored, false, kMaxDfaStates);
@@ -1542,41 +1594,7 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
     p->capBlob.swap(cb);
     if (spanChain.nops) deriveChainCaps(spanChain, p->capBlob, nfa.capture_count * 2, p->chainCaps);
     } catch (const BuildError& onePassErr) {
-      // General capture pass: the NFA itself, walked depth-first in priority order per match row.
-      if (nfa.n_states > 4096 || nfa.n_trans > (1u << 20)) throw;
-      cxgdev::BtHeader bh;
-      std::memset(&bh, 0, sizeof bh);
-      bh.magic = cxgdev::kBtMagic; bh.n_states = nfa.n_states; bh.n_trans = nfa.n_trans; bh.start = nfa.start_anchored;
-      bh.nslots = nfa.capture_count * 2;
-      std::vector<uint8_t> bb(sizeof bh, 0);
-      bh.states_off = static_cast<uint32_t>(bb.size());
-      for (uint32_t i = 0; i < nfa.n_states; i++) {
-        const cxg_nfa_state& x = nfa.states[i];
-        cxgdev::BtState t;
-        std::memset(&t, 0, sizeof t);
-        t.kind = x.kind; t.lo = x.lo; t.hi = x.hi;
-        t.next = x.kind == CXG_NFA_SPLIT ? x.left : x.next;
-        t.alt = x.kind == CXG_NFA_SPLIT ? x.right : cxgdev::kBtInvalid;
-        if (x.kind == CXG_NFA_CAPTURE) { const uint32_t sl = x.cap_index * 2 + (x.cap_start ? 0u : 1u); t.cap_slot = static_cast<uint8_t>(sl < 255 ? sl : 255); }
-        if (x.kind == CXG_NFA_SPARSE) {
-          if (x.trans_len > 0xFFFu) throw BuildError{CXG_E_UNSUPPORTED, "sparse state with more than 4095 transitions"};
-          t.trans_off_len = (x.trans_off << 12) | x.trans_len;
-        }
-        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
-        bb.insert(bb.end(), q, q + sizeof t);
-      }
-      bh.trans_off = static_cast<uint32_t>(bb.size());
-      for (uint32_t i = 0; i < nfa.n_trans; i++) {
-        cxgdev::BtTrans t{nfa.trans[i].lo, nfa.trans[i].hi, 0, nfa.trans[i].next};
-        const uint8_t* q = reinterpret_cast<const uint8_t*>(&t);
-        bb.insert(bb.end(), q, q + sizeof t);
-      }
-      while (bb.size() % 16) bb.push_back(0);
-      bh.total_bytes = static_cast<uint32_t>(bb.size());
-      std::memcpy(bb.data(), &bh, sizeof bh);
-      p->capBlob.swap(bb);
-      p->capHasLook = hasLook;
-      std::memset(p->chainCaps, 0, sizeof p->chainCaps);
+      buildBtCaptureImage(p, nfa, hasLook);
       (void)onePassErr;
     }
     p->subSupported = true;

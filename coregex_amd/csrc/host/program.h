@@ -59,6 +59,7 @@ struct cxg_program {
   // the reference sends FindAllSubmatch of DFA/Both/NFA/DigitPrefilter engines to the PikeVM, whose
   // result is plain leftmost-first, meta/findall.go:89-98)
   bool subSupported = false;
+  bool subNullable = false;      // FindAllSubmatch of a nullable pattern: spans by the FindAllIndex program, slots by the backtracking pass (no span image)
   std::string subWhyNot;
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays

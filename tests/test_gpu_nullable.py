@@ -69,6 +69,19 @@ def test_device_resident_haystack_with_base(oracle):
         rx.find_all_device(d.data_ptr(), hay.size, small.data_ptr(), 100)
 
 
-def test_submatch_of_a_nullable_pattern_is_refused():
-    rx = cx.compile(r"(a*)")
-    assert rx.supported and not rx.submatch_supported
+@pytest.mark.parametrize("pat", [r"(a*)", r"(a*)(b)?", r"(\d*)x?", r"(a)*", r"(a|b)*c?", r"(a*)(b*)", r"(x?)(y*)z?", r"((a)|b)*", r"(a?)(b?)(c?)", r"([a-z]*)(\d*)"])
+def test_submatch_of_nullable_patterns(pat, oracle):
+    """FindAllSubmatchIndex of nullable patterns (round 5; meta/findall.go:390-447): rows of FindAllIndex + the backtracking capture pass for
+    every row, empty ones included; the reference's quirk at the end of the haystack (every group unset, nfa/pikevm.go:2201-2212) kept."""
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.supported and rx.nullable and rx.submatch_supported
+    for hay in (b"", b"a", b"ab", b"xaab aaa b", b"aabbcc xyz 123x", b"bbbaac", b"yyz xz", b"ab12 cd345 x" * 300, cx.synth_pages(2, 0xC0FFEE02, 0, 2).tobytes()):
+        exp = o.find_all_submatch_index(hay)
+        got = rx.find_all_submatch_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:40], got[:6].tolist(), exp[:6].tolist())
+        assert rx.find_all_submatch_index(hay, 3).tolist() == exp[:3].tolist(), (pat, hay[:40])
+
+
+def test_submatch_of_a_nullable_pattern_with_assertions_is_refused():
+    rx = cx.compile(r"(\b\w*)")
+    assert not rx.submatch_supported

@@ -56,3 +56,23 @@ def test_golden_empty_match_rule(oracle):
 @pytest.mark.parametrize("pat", [r"\b", r"a*\b", r"(?m)^", r"(?m)$|a"])
 def test_nullable_with_assertions_is_refused(pat):
     assert not cx.compile(pat).supported
+
+
+@pytest.mark.parametrize("pat", [r"(a*)", r"(a*)(b)?", r"(\d*)x?", r"(a)*", r"(a|b)*c?", r"(a*)(b*)", r"(x?)(y*)z?", r"((a)|b)*", r"(a?)(b?)(c?)", r"([a-z]*)(\d*)"])
+def test_submatch_of_nullable_patterns_through_the_twins(pat, oracle):
+    """FindAllSubmatch of a nullable pattern (round 5, capi.hip scanNullableSubmatch): the rows of FindAllIndex through the twin of the
+    pattern's first kernel + merged empty matches, then the backtracking capture twin (device/bt.hpp compiled for the host) for EVERY row
+    — the empty ones too — and the reference's end-of-haystack quirk (every group unset, nfa/pikevm.go:2201-2212) on the last row."""
+    from twins import rows_on_twin
+    rx, o = cx.compile(pat), oracle.Regex(pat)
+    assert rx.supported and rx.nullable and rx.submatch_supported
+    cb = rx.submatch_blobs()[1]
+    w = 2 * rx.num_groups
+    for hay in (b"", b"a", b"ab", b"xaab aaa b", b"aabbcc xyz 123x", b"bbbaac", b"yyz xz", b"ab12 cd345 x" * 40):
+        spans = rows_on_twin(rx, hay)
+        assert not isinstance(spans, int)
+        got = emu.captures_bt(cb, hay, spans, w)
+        if len(got) and got[-1][0] == got[-1][1] == len(hay):
+            got[-1][2:] = -1
+        exp = o.find_all_submatch_index(hay)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (pat, hay[:40], got[:6].tolist(), exp[:6].tolist())
