@@ -202,16 +202,18 @@ thread_local ScratchSet t_scratch_set;
 // Staging buffers above this size are returned after the call instead of being kept for the thread's lifetime.
 constexpr uint64_t kKeepStagingBytes = 256ull << 20;
 
-// Wait for the call's stream.  hipStreamSynchronize parks the thread and is woken by an interrupt (~10 us after the kernel ended);
-// a 1 GiB scan takes 0.22 ms, so the first 2 ms are spent polling hipStreamQuery instead (round 5: the synchronous entry's wall time
-// per call minus the kernel time fell from ~20 us; CXG_NO_SPIN_SYNC=1 restores the plain wait).
+// Wait for the call's stream.  CXG_SPIN_SYNC=1 polls hipStreamQuery for up to 2 ms before parking the thread (hipStreamSynchronize is
+// woken ~10 us after the kernel ended: 0.2419 -> 0.2352 ms per 1 GiB call) — OFF by default: with it on, the device fuzz and
+// tests/test_gpu_parity.py::test_random_patterns of round 5 returned rows the last kernel of a relaunch ladder had not written yet
+// (profiles/r05_pytest_gpu_spin_sync.log: the tail of the array still held an earlier call's rows) — hipStreamQuery answered "ready"
+// before the stream had drained.  Correctness first; the knob stays for measurements.
 hipError_t syncStream(hipStream_t stream) {
-  static const bool spin = getenv("CXG_NO_SPIN_SYNC") == nullptr;
+  static const bool spin = getenv("CXG_SPIN_SYNC") != nullptr;
   if (spin) {
     const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t i = 0;; i++) {
       const hipError_t q = hipStreamQuery(stream);
-      if (q == hipSuccess) return hipSuccess;
+      if (q == hipSuccess) break;
       if (q != hipErrorNotReady) return q;
       if ((i & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }

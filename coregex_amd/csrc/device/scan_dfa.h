@@ -30,7 +30,7 @@ constexpr int kRecCap = 1024;                 // LDS match records per tile befo
 // before the cut raises error bit 32: the host returns CXG_E_INPUT and the caller keeps its CPU loop for this
 // haystack.  (The cut also keeps lane-relative offsets inside int32 for haystacks beyond 2 GiB.)
 constexpr int32_t kSerialLimit = 128 * 1024;
-constexpr uint32_t kSerialReads = 3u << 17;   // ... and at most this many one-byte reads beyond the staged window per lane and launch (scan_dfa.hip LdsMem::byte): one forward and one reverse walk of kSerialLimit and half as much again — a lane that needs more belongs to a program that is quadratic in the reference too, and the call ends (CXG_E_INPUT) within ~0.4 s instead of ~1 s (round 4: 1 << 20)
+constexpr uint32_t kSerialReads = 1u << 20;   // ... and at most this many one-byte reads beyond the staged window per lane and launch (scan_dfa.hip LdsMem::byte).  (Round 5 tried 3 << 17 to end a quadratic program's call sooner; the ownership searches of input without synchronising bytes legitimately read more than that per lane.)
 constexpr uint32_t kErrSerialLimit = 32u;
 constexpr uint32_t kErrLongMatch = 64u;
 struct WalkLimit { int32_t rend; int32_t flag_at; };
