@@ -264,6 +264,14 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
   return deviceCopy(p->blob, &const_cast<cxg_program*>(p)->dev[device], out);
 }
 
+// The device's launch slot for the small kernels outside scanDeviceOnce (merges of nullable programs, capture expansions, corpus fills):
+// held from launch to completion, not taken by a thread whose pending asynchronous calls already hold it.
+std::unique_lock<std::mutex> lockOrder(Scratch& s) {
+  std::unique_lock<std::mutex> lk(g_path[s.device < 0 ? 0 : s.device].orderMutex, std::defer_lock);
+  if (s.asyncInFlight == 0) lk.lock();
+  return lk;
+}
+
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
                  uint64_t* n_out, void* user_stream, cxg_timing* timing);
@@ -635,7 +643,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && !staticDenied) ? 1u : 0u;
   std::unique_lock<std::mutex> orderLock(ps.orderMutex, std::defer_lock);   // released when this iteration ends (every path out of it)
-  if (a.static_groups && s.asyncInFlight == 0) {                   // (pending launches of this thread already hold it; its launches share a stream)
+  if (s.asyncInFlight == 0) {                                      // (pending launches of this thread already hold it; its launches share a stream)
+    // every launch of the library takes the slot, not only the order-dependent ones: ANY kernel beside a persistent grid can keep
+    // part of it from becoming resident (profiles/r05_c4_foreign_kernel.txt) — inside one process nothing of ours does
     ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); orderLock.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed);
   }
   Scratch::AsyncSlot* const as = (t_asyncSlot && relaunches == 0 && !submatch && !profOn && !dbgBits && a.max_len == 0) ? t_asyncSlot : nullptr;
@@ -1279,6 +1289,7 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
   }
   const uint64_t nb = (n + kNullBlock - 1) / kNullBlock;
   uint64_t covered = 0;
+  std::unique_lock<std::mutex> orderLock = lockOrder(s);
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (n > 0) {
     if (n + nb + 8 > s.nullCovCap) {
@@ -1383,6 +1394,7 @@ int scanNullableSubmatch(const cxg_program* p, const void* d_hay, uint64_t len, 
   if (int rc = deviceCopy(p->capBlob, &const_cast<cxg_program*>(p)->devCap[t_device], &d_cap)) return rc;
   if (!s.bothFirst) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothFirst), 16));
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.bothFirst);
+  std::unique_lock<std::mutex> orderLock = lockOrder(s);
   HIP_TRY(hipMemsetAsync(d_err, 0, 8, stream));
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   int64_t* out = static_cast<int64_t*>(d_out);
@@ -1476,6 +1488,7 @@ int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     std::memcpy(oc.src, p->offSrc, sizeof oc.src);
     std::memcpy(oc.delta, p->offDelta, sizeof oc.delta);
     const uint64_t threads = n * static_cast<uint64_t>(row_width / 2);
+    std::unique_lock<std::mutex> orderLock = lockOrder(s);
     HIP_TRY(hipEventRecord(s.ev[0], stream));
     hipLaunchKernelGGL(k_caps_offsets, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream, s.offSpans, n, static_cast<uint32_t>(row_width), oc, static_cast<int64_t*>(d_out));
     HIP_TRY(hipGetLastError());
@@ -1946,6 +1959,8 @@ int cxg_buffer_fill_synth(cxg_buffer* b, uint32_t config, uint64_t seed, uint64_
   if (npages == 0) return CXG_OK;
   const unsigned block = 64;
   const unsigned grid = static_cast<unsigned>((npages + block - 1) / block);
+  std::unique_lock<std::mutex> orderLock(g_path[b->device].orderMutex, std::defer_lock);   // (a fill beside another thread's persistent scan would be a foreign kernel to it)
+  if (t_scratch[b->device].asyncInFlight == 0) orderLock.lock();
   hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, b->d, npages, config, seed, first_page);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
