@@ -67,13 +67,13 @@ def test_two_threads_scan_a_gib_each_on_one_device(oracle):
             cnt = rx.find_all_device(buf.ptr, n)
             out = torch.empty((cnt + 8, 2), dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
-            gate.wait()                                             # only the library's own launches run side by side below (torch's kernels are foreign to it)
+            gate.wait(timeout=300)                                  # only the library's own launches run side by side below (torch's kernels are foreign to it)
             kernels = set()
             for _ in range(12):
                 t = cx.Timing()
                 assert rx.find_all_device(buf.ptr, n, out.data_ptr(), cnt + 8, timing=t) == cnt
                 kernels.add(int(t.kernel))
-            gate.wait()
+            gate.wait(timeout=600)
             k = torch.arange(1, cnt + 1, dtype=torch.int64, device="cuda")
             sums = [int((out[:cnt, j] * (k + 7 * j)).sum().item()) & ((1 << 64) - 1) for j in range(2)]
             res[tid] = (cnt, sums, kernels)
