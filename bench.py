@@ -65,6 +65,7 @@ def parse_args(argv=None):
                     help="default run (config 2, 1 GiB, one GPU) only: skip the `north_star` object — the same FindAllIndex over 64 GiB resident on this "
                          "one GPU (BASELINE.json north_star's size), 10 timed steps, every row checked against the oracle")
     ap.add_argument("--north-star-gib", type=float, default=64.0)
+    ap.add_argument("--no-async", action="store_true", help="skip the `async` leg (batches of cxg_find_all_device_async behind the timed region)")
     ap.add_argument("--u32-rows", action="store_true",
                     help="rows through cxg_find_all_device_u32 (two uint32 relative to the shard, 8 bytes per match) instead of the int64 ABI; "
                          "the algorithmic bytes of the roofline follow the layout.  Char-class and fields programs only (configs 4 and 2)")
@@ -150,7 +151,9 @@ class DeviceWorkload:
         self.sync()
         dt = (time.perf_counter() - t0) / (n_batches * batch)
         return {"value": round(self.nbytes * self.world / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 4), "batch": batch,
-                "what": "cxg_find_all_device_async x batch, then cxg_wait x batch (same output array, same stream): wall time per pass of this rank"}
+                "what": "cxg_find_all_device_async x batch, then cxg_wait x batch (same output array, same stream): wall time per pass of this rank.  Measured in round 5: "
+                        "launches that follow each other without a host round trip run 10-15 % longer each (profiles/r05_cfg2_kernel_stats.txt, last quarter), so batching "
+                        "does not beat the synchronous entry for the persistent kernels — the entry exists for hosts that overlap their own work with the scan"}
 
     def scan_async(self):
         return self.rx.find_all_device_async(self.buf.ptr, self.nbytes, self.out.data_ptr(), self.nmatch + 16, base=self.base)
@@ -309,7 +312,7 @@ def main(argv=None, make_workload=DeviceWorkload, script=None):
                        per_rank_rows=per_rank_rows, corpus_checksum="%016x" % corpus_checksum),
     }
     wl.finish(result, k_ms)
-    if make_workload is DeviceWorkload and hasattr(wl, "async_leg") and not wl.submatch and not wl.u32 and not os.environ.get("CXG_DEBUG"):
+    if make_workload is DeviceWorkload and hasattr(wl, "async_leg") and not args.no_async and not wl.submatch and not wl.u32 and not os.environ.get("CXG_DEBUG"):
         result["async"] = wl.async_leg(args.steps)
     if (make_workload is DeviceWorkload and world == 1 and args.config == 2 and args.pattern is None and args.total_gib == 0 and args.gib_per_gpu == 1.0
             and not args.u32_rows and not args.no_north_star and not os.environ.get("CXG_DEBUG") and not _under_profiler()):
@@ -544,7 +547,7 @@ def _pmc_traffic_live(args, kernel):
     if not os.path.exists(exe):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "3", "--warmup", "1", "--settle", "2",
-             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc", "--no-north-star"]
+             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc", "--no-north-star", "--no-async"]
     if args.pattern is not None:
         child += ["--pattern", args.pattern]
     if args.synth_config is not None:
