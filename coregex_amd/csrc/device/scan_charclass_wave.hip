@@ -45,6 +45,14 @@
 #ifndef CXG_CC_LOAD_AUX
 #define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
 #endif
+// Windows in flight per wave in pass 1 (1, 2 or 4 = all of the wave's tiles issued before the first is classified).  Pass 1 alone
+// (a count-only launch) ran at 2.5 TB/s with one window of prefetch: 16 waves per CU x 4 KiB are too few bytes in flight.
+#ifndef CXG_CC_DEPTH
+#define CXG_CC_DEPTH 1
+#endif
+#ifndef CXG_CC_HALVES
+#define CXG_CC_HALVES 0                                      // extraction: both 32-bit halves of a word per loop iteration
+#endif
 
 namespace cxgdev {
 
@@ -91,9 +99,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   uint32_t fallback = 0;
 
-  u32x4 x[4];
-  uint32_t xprev = 0;
-  auto issue_loads = [&](int jj) {
+  static_assert(CXG_CC_DEPTH == 1 || CXG_CC_DEPTH == 2 || CXG_CC_DEPTH == 4, "");
+  u32x4 xs[CXG_CC_DEPTH][4];
+  uint32_t xprevs[CXG_CC_DEPTH];
+  auto issue_loads = [&](int jj, u32x4 (&x)[4], uint32_t& xprev) {
     const uint64_t wtn = group * (kWavesPerBlock * kCcTilesPerWave) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
@@ -107,10 +116,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (lane + 64 * k) << 4, pre, CXG_CC_LOAD_AUX);
     xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 0, pre ? 12 : nrec + pre, 0);
   };
-  issue_loads(0);
+#pragma unroll
+  for (int d = 0; d < CXG_CC_DEPTH; d++) issue_loads(d, xs[d], xprevs[d]);
 
   // ---- pass 1: bitmaps and counts
+#if CXG_CC_DEPTH > 1
+#pragma unroll
+#endif
   for (int j = 0; j < kCcTilesPerWave; j++) {
+    u32x4 (&x)[4] = xs[j % CXG_CC_DEPTH];
+    uint32_t& xprev = xprevs[j % CXG_CC_DEPTH];
     lane = lane0;
     asm volatile("" : "+v"(lane));
     const uint64_t wt = group * (kWavesPerBlock * kCcTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
         }
       });
       const uint32_t xprev_cur = xprev;
-      issue_loads(j + 1);
+      if (CXG_CC_DEPTH == 1 || j + CXG_CC_DEPTH < kCcTilesPerWave) issue_loads(j + CXG_CC_DEPTH, x, xprev);
       wave_lds_sync();
       uint64_t M = s_m[wave][lane];
       if (stage != kWin) {                                          // short last window: nothing past the data is a member
@@ -237,6 +252,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
         eb &= eb - 1;
         if (q < static_cast<uint32_t>(kCcStage)) s_re[wave][cc_slot(q)] = static_cast<uint16_t>(64 * lane0 + bit);
         q++;
+      }
+    }
+#elif CXG_CC_HALVES
+    // both halves of the word per iteration: the loop runs max(popcount of a half) times instead of popcount of the word.  No bound
+    // check on the rank: cc_slot masks it, and a tile with more than kCcStage starts or ends has raised the fallback flag.
+    static_assert(CXG_CC_SWIZZLE, "cc_slot must mask");
+    {
+      uint32_t b0 = static_cast<uint32_t>(S), b1 = static_cast<uint32_t>(S >> 32);
+      uint32_t r0 = (incl & 0xFFFFu) - ns, r1 = r0 + static_cast<uint32_t>(__popc(b0));
+      while (b0 | b1) {
+        if (b0) { const int bit = __builtin_ctz(b0); b0 &= b0 - 1; s_rs[wave][cc_slot(r0)] = static_cast<uint16_t>(64 * lane0 + bit); r0++; }
+        if (b1) { const int bit = __builtin_ctz(b1); b1 &= b1 - 1; s_rs[wave][cc_slot(r1)] = static_cast<uint16_t>(64 * lane0 + 32 + bit); r1++; }
+      }
+      b0 = static_cast<uint32_t>(E); b1 = static_cast<uint32_t>(E >> 32);
+      r0 = (incl >> 16) - ne; r1 = r0 + static_cast<uint32_t>(__popc(b0));
+      while (b0 | b1) {
+        if (b0) { const int bit = __builtin_ctz(b0); b0 &= b0 - 1; s_re[wave][cc_slot(r0)] = static_cast<uint16_t>(64 * lane0 + bit); r0++; }
+        if (b1) { const int bit = __builtin_ctz(b1); b1 &= b1 - 1; s_re[wave][cc_slot(r1)] = static_cast<uint16_t>(64 * lane0 + 32 + bit); r1++; }
       }
     }
 #else
