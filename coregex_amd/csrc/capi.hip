@@ -129,6 +129,7 @@ struct Scratch {
   uint32_t epoch = 0;            // last launch epoch used on `status` (block_common.hpp kEpochShift), 1..1023
   bool needZero = true;          // the next epoch launch must start from a zeroed control block + status array
   uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
+  static constexpr size_t kProfRecords = 1u << 18;
   uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
@@ -575,8 +576,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.stop = reinterpret_cast<uint32_t*>(s.ctl + 24);                   // device word of the control block (zeroed with it; epoch-tagged otherwise)
   a.max_len = (h->flags & cxgdev::kFlagBothRestart) ? cxgdev::kBothRestartSpan : 0u;
   if (profOn) {
-    if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128));
-    HIP_TRY(hipMemsetAsync(s.prof, 0, 128, stream));
+    // 16 summed counters, then one record of 8 timestamps per workgroup for the kernels that keep them (k_scan_charclass_wave)
+    if (!s.prof) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.prof), 128 + Scratch::kProfRecords * 64));
+    HIP_TRY(hipMemsetAsync(s.prof, 0, 128 + Scratch::kProfRecords * 64, stream));
     a.prof = s.prof;
   }
   int gen = digitKernelGeneration();
@@ -904,6 +906,29 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%llu", names[i], (unsigned long long)(pc[8 + i] / pc[15]));
       fprintf(stderr, "\n");
     }
+    if (kernelId == CXG_K_CHARCLASS_WAVE) {                          // one record of timestamps (shader clock) per workgroup, wave 0
+      const size_t ng = a.ngroups < Scratch::kProfRecords ? static_cast<size_t>(a.ngroups) : Scratch::kProfRecords;
+      std::vector<uint64_t> rec(ng * 8);
+      HIP_TRY(hipMemcpy(rec.data(), s.prof + 16, ng * 64, hipMemcpyDeviceToHost));
+      uint64_t t0 = ~0ull, t1 = 0;
+      double ph[5] = {0, 0, 0, 0, 0};
+      size_t n = 0;
+      for (size_t g = 0; g < ng; g++) {
+        const uint64_t* r = &rec[g * 8];
+        if (!r[0]) continue;
+        n++;
+        if (r[0] < t0) t0 = r[0];
+        if (r[5] > t1) t1 = r[5];
+        for (int i = 0; i < 5; i++) ph[i] += static_cast<double>(r[i + 1] - r[i]);
+      }
+      if (n) {
+        fprintf(stderr, "[CXG_PROF] charclass: %zu workgroups, wave 0, shader-clock cycles per workgroup: claim+issue %.0f, pass 1 %.0f, barrier %.0f, prefix+look-back %.0f, pass 2 %.0f; "
+                        "first start to last end %llu cycles; starts of workgroups 0 / 1023 / 1024 / 2048 / 8192 after the first: %llu %llu %llu %llu %llu\n",
+                n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, (unsigned long long)(t1 - t0),
+                (unsigned long long)(rec[0] - t0), (unsigned long long)(ng > 1023 ? rec[1023 * 8] - t0 : 0), (unsigned long long)(ng > 1024 ? rec[1024 * 8] - t0 : 0),
+                (unsigned long long)(ng > 2048 ? rec[2048 * 8] - t0 : 0), (unsigned long long)(ng > 8192 ? rec[8192 * 8] - t0 : 0));
+      }
+    }
     if (gen == 6 && pc[7])
       fprintf(stderr, "[CXG_PROF] gen6 pairing mismatch: tile_lo=%llu n=%llu n_ends=%llu cout=%llu zA=%lld zB=%lld stage=%llu (count %llu)\n",
               (unsigned long long)pc[0], (unsigned long long)pc[1], (unsigned long long)pc[2], (unsigned long long)pc[3],
@@ -932,10 +957,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       fprintf(stderr, "[cxg] persistent fields kernel: %llu units waited for their round's record, %llu polls (most by one wave: %llu)\n", (unsigned long long)w, (unsigned long long)pl, (unsigned long long)mx);
       if (nw) {
         std::sort(lives.begin(), lives.end()); std::sort(scans.begin(), scans.end());
-        auto q = [&](const std::vector<uint64_t>& v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))] / 100.0; };
-        fprintf(stderr, "[cxg]   %llu waves; life us min/p10/median/p90/max %.1f %.1f %.1f %.1f %.1f; in tile loops %.1f %.1f %.1f %.1f %.1f\n", (unsigned long long)nw,
+        auto q = [&](const std::vector<uint64_t>& v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))] / 1000.0; };
+        fprintf(stderr, "[cxg]   %llu waves; life in 1000 s_memtime ticks (~2.2 GHz in a busy kernel) min/p10/median/p90/max %.1f %.1f %.1f %.1f %.1f; in tile loops %.1f %.1f %.1f %.1f %.1f\n", (unsigned long long)nw,
                 q(lives, 0), q(lives, 0.1), q(lives, 0.5), q(lives, 0.9), q(lives, 1), q(scans, 0), q(scans, 0.1), q(scans, 0.5), q(scans, 0.9), q(scans, 1));
-        for (int x = 0; x < 8; x++) if (nX[x]) fprintf(stderr, "[cxg]   XCD %d: %llu waves, life mean %.1f max %.1f us, tile loops mean %.1f us\n", x, (unsigned long long)nX[x], lifeX[x] / nX[x] / 100.0, lifeMaxX[x] / 100.0, scanX[x] / nX[x] / 100.0);
+        for (int x = 0; x < 8; x++) if (nX[x]) fprintf(stderr, "[cxg]   XCD %d: %llu waves, life mean %.1f max %.1f k ticks, tile loops mean %.1f k ticks\n", x, (unsigned long long)nX[x], lifeX[x] / nX[x] / 1000.0, lifeMaxX[x] / 1000.0, scanX[x] / nX[x] / 1000.0);
       }
     }
   }

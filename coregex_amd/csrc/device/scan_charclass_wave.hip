@@ -3,23 +3,26 @@
 // bytes, in order, a trailing run closed at the end of input.
 //
 // Output dominates this path (one 16-byte span per ~5.5 bytes of log text: 3 bytes written per byte read), so a
-// group's rows are never buffered as a whole: bitmaps wait in LDS for the group's base, rows are staged one
+// group's rows are never buffered as a whole: membership words wait in LDS for the group's base, rows are staged one
 // wave-tile at a time.
 //   pass 1  per wave-tile (60 x 64 B = 3840 B + 256 B halo = 64 bitmap words, one per lane): window by four
-//           buffer_load_dwordx4 per lane, membership by SWAR range tests (the class is a union of <= 4 ASCII
-//           ranges) + v_dot4 gather, 16-bit pieces through LDS -> word M per lane;
+//           buffer_load_dwordx4 per lane (two windows in flight per wave), membership by SWAR range tests (class plans,
+//           wave_common.hpp) + v_dot4 gather, 16-bit pieces through LDS -> word M per lane, which stays there;
 //             starts S = M & ~(M << 1 | carry),  ends E = ~M & (M << 1 | carry)   (exclusive ends)
 //           starts and ends are owned SEPARATELY: the tile owns the starts at its bytes [0, 3840) and the exclusive
 //           ends at (0, 3840] — a run may be as long as the haystack, nobody has to see both of its ends.  Runs
 //           alternate start, end, start, end, so the k-th start and the k-th end of the haystack are row k: with
 //           B = number of starts in front of the tile (look-back), the tile's i-th start is row B + i and its j-th
-//           end is row B - open + j, open = 1 when a run crosses the tile's first byte.  S and E words stay in LDS,
-//           the start counts are summed per tile;
-//   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, one look-back -> global base of every tile;
-//   pass 2  per wave-tile every lane drops the starts and ends it holds into the wave's LDS staging at their
-//           ranks, then the wave writes the rows that have both halves here as fully coalesced 16-byte stores
-//           (1 KiB per instruction); the end of a run begun in an earlier tile and the start of a run that ends in a
-//           later one go out as lone 8-byte stores.
+//           end is row B - open + j, open = 1 when a run crosses the tile's first byte.  The start counts are summed per tile;
+//   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, the group's total published, the first tile of every wave staged
+//           (that needs no base: the time would otherwise pass in the look-back's wait), look-back -> base of every tile;
+//   pass 2  per wave-tile S and E again from M (a DPP shift and six bit operations), every lane drops the starts and ends it
+//           holds into the wave's LDS staging at their ranks — both 32-bit halves of its word per loop iteration — then the
+//           wave writes the rows that have both halves here as fully coalesced 16-byte stores (1 KiB per instruction); the end
+//           of a run begun in an earlier tile and the start of a run that ends in a later one go out as lone 8-byte stores.
+// LDS: 24.7 KB per workgroup (M 8 KB, staging 16 KB) — six workgroups per CU.  Round 5 measurements behind this form
+// (profiles/r05_c8..c11_*): parking S and E (34.7 KB, four workgroups), one window in flight, one bit per iteration of
+// 64-bit loops: 1.08 ms per GiB of config 4; this form 0.99.
 // Fallback flag (err bit 8: the host reruns the scan with scan_charclass.hip): more than 1024 starts or ends in one
 // wave-tile.
 #include <hip/hip_runtime.h>
@@ -33,25 +36,26 @@
 #ifndef CXG_CC_PLANS
 #define CXG_CC_PLANS 1
 #endif
-// Staging index of rank r (pass 2).  In one ds_write_b16 lane l writes rank r_l + i with r_l ~ 11 l on log text: indices r / 2 mod 32
-// put ~11 lanes on every LDS bank.  r * 13 mod 1024 (a bijection) spreads them — the coalesced read-out of consecutive ranks stays
-// two lanes per bank.
-#ifndef CXG_CC_SWIZZLE
-#define CXG_CC_SWIZZLE 1
-#endif
-#ifndef CXG_CC_MERGED
-#define CXG_CC_MERGED 0                                      // one extraction loop over starts and ends (0: two loops, round 4)
-#endif
 #ifndef CXG_CC_LOAD_AUX
-#define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B)
+#define CXG_CC_LOAD_AUX 0                                    // cache policy of the haystack loads (2 = nt; A/B: no difference)
 #endif
-// Windows in flight per wave in pass 1 (1, 2 or 4 = all of the wave's tiles issued before the first is classified).  Pass 1 alone
-// (a count-only launch) ran at 2.5 TB/s with one window of prefetch: 16 waves per CU x 4 KiB are too few bytes in flight.
+// Windows in flight per wave in pass 1 (1, 2 or 4 = all of the wave's tiles issued before the first is classified; 4 needs 84
+// VGPRs: five waves per SIMD).
 #ifndef CXG_CC_DEPTH
-#define CXG_CC_DEPTH 1
+#define CXG_CC_DEPTH 2
 #endif
-#ifndef CXG_CC_HALVES
-#define CXG_CC_HALVES 0                                      // extraction: both 32-bit halves of a word per loop iteration
+#ifndef CXG_CC_OCC
+#define CXG_CC_OCC 6
+#endif
+// Stage the wave's first tile between publishing the group's total and the look-back (1) or behind it like the others (0).
+#ifndef CXG_CC_EARLY
+#define CXG_CC_EARLY 0                                       // (measured: 1.016 against 1.003 ms — no gain)
+#endif
+// Start-up stagger in shader-clock cycles per resident slot (0 = off): the workgroups that fill the device at the start of a launch all
+// read, then all wait for the look-back, then all extract and write — phase by phase in step, so that the time of a launch is the SUM of
+// a memory-bound and an issue-bound phase.  Workgroup b of the first 256 x OCC waits (b / 256) x this before it begins.
+#ifndef CXG_CC_STAGGER
+#define CXG_CC_STAGGER 0
 #endif
 
 namespace cxgdev {
@@ -59,15 +63,20 @@ namespace cxgdev {
 namespace {
 constexpr int kWin = kWaveTile + kWaveHalo;       // 4096
 constexpr int kCcStage = 1024;                    // rows staged per wave-tile (typical log text: ~700)
-__device__ __forceinline__ uint32_t cc_slot(uint32_t r) { return CXG_CC_SWIZZLE ? ((r * 13u) & static_cast<uint32_t>(kCcStage - 1)) : r; }
+// Staging slot of rank r (pass 2).  In one ds_write_b16 lane l writes rank r_l + i with r_l ~ 11 l on log text: slots r / 2 mod 32
+// would put ~11 lanes on every LDS bank.  r * 13 mod 1024 (a bijection) spreads them — the coalesced read-out of consecutive ranks
+// stays two lanes per bank.  Byte offset = (r * 26) & 2046, OR-ed onto the wave's 2 KB-aligned staging array.
+__device__ __forceinline__ uint32_t cc_slot(uint32_t r) { return (r * 13u) & static_cast<uint32_t>(kCcStage - 1); }
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ uint32_t lds_off(const void* p) { return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)p)); }
+__device__ __forceinline__ void lds_st16(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u16*>(addr) = static_cast<uint16_t>(v); }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t addr) { return *reinterpret_cast<lds_u16*>(addr); }
 }
 
-__global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) uint64_t s_m[kWavesPerBlock][64];                    // membership pieces -> words
-  __shared__ __attribute__((aligned(16))) uint64_t s_S[kWavesPerBlock][kCcTilesPerWave][64];   // owned starts
-  __shared__ __attribute__((aligned(16))) uint64_t s_E[kWavesPerBlock][kCcTilesPerWave][64];   // their ends
-  __shared__ uint16_t s_rs[kWavesPerBlock][kCcStage];              // pass 2 staging: start / end inside the window
-  __shared__ uint16_t s_re[kWavesPerBlock][kCcStage];
+__global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_M[kWavesPerBlock][kCcTilesPerWave][64];   // membership words (the 16-bit pieces land here)
+  __shared__ __attribute__((aligned(2048))) uint16_t s_rs[kWavesPerBlock][kCcStage];   // pass 2 staging: start / end inside the window
+  __shared__ __attribute__((aligned(2048))) uint16_t s_re[kWavesPerBlock][kCcStage];   // (a wave's 2 KB: aligned, so that offsets are OR-ed on)
   __shared__ uint32_t s_cnt[kWavesPerBlock][kCcTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kCcTilesPerWave + 1];
   __shared__ uint64_t s_group;
@@ -76,6 +85,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
+#if CXG_CC_STAGGER
+  if (a.ngroups > 4u * 256u * CXG_CC_OCC && blockIdx.x < 256u * CXG_CC_OCC && blockIdx.x >= 256u) {
+    const uint64_t wait = static_cast<uint64_t>(blockIdx.x / 256u) * CXG_CC_STAGGER, t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
+  const uint64_t pt0 = a.prof ? __builtin_readcyclecounter() : 0ull;   // CXG_PROF=1: wave 0's timestamps per phase, one record per workgroup
   if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   const bool pairs = ax->pairs != 0u;
 #pragma unroll
   for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
-  // round 5: the ranges as a class plan (wave_common.hpp: `\w` in 9 instructions per dword instead of 15); shape 0 keeps notset4
+  // the ranges as a class plan (wave_common.hpp: `\w` in 9 instructions per dword instead of 15); shape 0 keeps notset4
   static_assert(CXG_CC_PLANS == 0 || CXG_CC_PLANS == 1, "");
   const ClassPlan& plan = a.plan;                                     // kernel arguments: scalar loads
   const int shape = CXG_CC_PLANS ? static_cast<int>(a.plan_shape) : 0;
@@ -118,8 +134,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   };
 #pragma unroll
   for (int d = 0; d < CXG_CC_DEPTH; d++) issue_loads(d, xs[d], xprevs[d]);
+  const uint64_t pt1 = a.prof ? __builtin_readcyclecounter() : 0ull;
 
-  // ---- pass 1: bitmaps and counts
+  // ---- pass 1: membership words and counts
 #if CXG_CC_DEPTH > 1
 #pragma unroll
 #endif
@@ -130,13 +147,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     asm volatile("" : "+v"(lane));
     const uint64_t wt = group * (kWavesPerBlock * kCcTilesPerWave) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
     const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
-    uint64_t S = 0, E = 0;
     uint32_t n = 0;
     if (tile_lo < a.len) {
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
       const int32_t stage = rend < kWin ? rend : kWin;
-      uint16_t* pieces = reinterpret_cast<uint16_t*>(s_m[wave]);
+      uint16_t* pieces = reinterpret_cast<uint16_t*>(s_M[wave][j]);
       with_shape(shape, [&]<int SHAPE>() {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -147,10 +163,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       const uint32_t xprev_cur = xprev;
       if (CXG_CC_DEPTH == 1 || j + CXG_CC_DEPTH < kCcTilesPerWave) issue_loads(j + CXG_CC_DEPTH, x, xprev);
       wave_lds_sync();
-      uint64_t M = s_m[wave][lane];
+      uint64_t M = s_M[wave][j][lane];
       if (stage != kWin) {                                          // short last window: nothing past the data is a member
         const int32_t nv = stage - 64 * lane;
         M &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+        s_M[wave][j][lane] = M;                                     // pass 2 reads the masked word
       }
       // the byte in front of the tile
       uint32_t prev_member = 0;
@@ -163,8 +180,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       uint64_t carry = from_lower64(M) >> 63;                      // DPP outside lane-dependent branches
       if (lane == 0) carry = prev_member;
       const uint64_t P = (M << 1) | carry;                          // "the previous byte is a member"
-      S = M & ~P;
-      E = ~M & P;                                                   // exclusive end: first non-member after a run
+      uint64_t S = M & ~P;
+      uint64_t E = ~M & P;                                          // exclusive end: first non-member after a run
       if (pairs) { S = M; E = 0; prev_member = 0; }                 // every occurrence is an event of the tile that holds it
       S &= word_range(lane, 0, kWaveTile - 1);                      // starts at [0, 3840), exclusive ends at (0, 3840]
       E &= word_range(lane, 1, kWaveTile);
@@ -176,18 +193,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       // a run crosses the tile's first byte: the byte in front and the first byte are both members
       const uint32_t open = prev_member & static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(M) & 1u)));
       if (n > static_cast<uint32_t>(kCcStage) || n_ends > static_cast<uint32_t>(kCcStage)) fallback |= 8;
-      s_S[wave][j][lane] = S;
-      s_E[wave][j][lane] = E;
-      if (lane == 0) s_cnt[wave][j] = n | (n_ends << 12) | (open << 31);   // n, n_ends <= 3840 < 4096
+      if (lane == 0) s_cnt[wave][j] = n | (n_ends << 12) | (prev_member << 30) | (open << 31);   // n, n_ends <= 3840 < 4096
     } else {
-      s_S[wave][j][lane] = 0; s_E[wave][j][lane] = 0;
       if (lane == 0) s_cnt[wave][j] = 0;
     }
   }
   if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+  const uint64_t pt2 = a.prof ? __builtin_readcyclecounter() : 0ull;
   __syncthreads();
+  const uint64_t pt3 = a.prof ? __builtin_readcyclecounter() : 0ull;
 
-  // ---- group: exclusive prefix over the wave-tiles q = j*4 + wave, look-back
+  // ---- group: exclusive prefix over the wave-tiles q = j*4 + wave
   if (tid < 64) {
     const int q = tid;
     const uint32_t v = (q < kWavesPerBlock * kCcTilesPerWave) ? (s_cnt[q % kWavesPerBlock][q / kWavesPerBlock] & 0xFFFu) : 0u;
@@ -197,9 +213,61 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
   }
   __syncthreads();
   const uint32_t total = s_qbase[kWavesPerBlock * kCcTilesPerWave];
+
+  // S and E of tile j again from its parked M, the tile's counts word cn
+  const uint32_t p0 = 64u * static_cast<uint32_t>(lane0), p1 = p0 + 32u;
+  const uint32_t rsb = lds_off(s_rs[wave]), reb = lds_off(s_re[wave]);
+  auto owned = [&](int j, uint32_t cn, uint64_t& S, uint64_t& E) {
+    const uint64_t M = s_M[wave][j][lane0];
+    uint64_t carry = from_lower64(M) >> 63;
+    if (lane0 == 0) carry = (cn >> 30) & 1u;                        // the byte in front of the tile (pass 1)
+    const uint64_t P = (M << 1) | carry;
+    S = M & ~P;
+    E = ~M & P;
+    if (pairs) { S = M; E = 0; }
+    S &= word_range(lane0, 0, kWaveTile - 1);
+    E &= word_range(lane0, 1, kWaveTile);
+  };
+  // every lane drops the bits of its word at their ranks into the staging array at `base`: both 32-bit halves per iteration (the
+  // loop runs max(popcount of a half) times, on 32-bit values).  No bound check on the rank: the slot is masked, and a tile with
+  // more than kCcStage starts or ends has raised the fallback flag.
+  auto drop = [&](uint64_t W, uint32_t rank, uint32_t base) {
+    uint32_t b0 = static_cast<uint32_t>(W), b1 = static_cast<uint32_t>(W >> 32);
+    uint32_t a0 = rank * 26u, a1 = a0 + static_cast<uint32_t>(__popc(b0)) * 26u;
+    while (b0 | b1) {
+      if (b0) { lds_st16((a0 & 2046u) | base, p0 | static_cast<uint32_t>(__builtin_ctz(b0))); b0 &= b0 - 1; a0 += 26u; }
+      if (b1) { lds_st16((a1 & 2046u) | base, p1 | static_cast<uint32_t>(__builtin_ctz(b1))); b1 &= b1 - 1; a1 += 26u; }
+    }
+  };
+  auto stage_runs = [&](int j, uint32_t cn) {                        // (not for pairs: their roles depend on the base)
+    uint64_t S, E;
+    owned(j, cn, S, E);
+    const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
+    const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
+    drop(S, (incl & 0xFFFFu) - ns, rsb);
+    drop(E, (incl >> 16) - ne, reb);
+  };
+
+  // the group's total goes out first (tile_lookback stores the same word again), then the wave's first tile is staged — it
+  // needs no base, and the groups in front are given that much more time before this one polls them
+  const bool early = CXG_CC_EARLY && a.out != nullptr && !pairs;
+  if (early) {
+    if (tid == 0)
+      __hip_atomic_store(a.status + group, (group == 0 ? kFlagInclusive : kFlagAggregate) | (static_cast<uint64_t>(a.epoch) << kEpochShift) | static_cast<uint64_t>(total),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t cn = s_cnt[wave][0];
+    if ((cn & 0xFFFFFFu) != 0u) stage_runs(0, cn);
+  }
   tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &s_base, a.epoch, a.limit, a.stop);
   if (pairs && group == a.ngroups - 1 && tid == 0) *a.total = (s_base + total) >> 1;   // rows = events / 2 (an unpaired last Q opens nothing)
-  if (a.out == nullptr) return;
+  const uint64_t pt4 = a.prof ? __builtin_readcyclecounter() : 0ull;
+  auto prof_out = [&]() {
+    if (a.prof && tid == 0 && group < (1u << 18)) {
+      uint64_t* r = a.prof + 16 + group * 8;
+      r[0] = pt0; r[1] = pt1; r[2] = pt2; r[3] = pt3; r[4] = pt4; r[5] = __builtin_readcyclecounter();
+    }
+  };
+  if (a.out == nullptr) { prof_out(); return; }
 
   // ---- pass 2: starts and ends straight to their rows
   const uint64_t base = s_base;
@@ -210,14 +278,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     const uint32_t cn = s_cnt[wave][j];
     uint32_t n = cn & 0xFFFu, n_ends = (cn >> 12) & 0xFFFu, open = cn >> 31;
     if (n == 0 && n_ends == 0) continue;
-    const uint64_t S = s_S[wave][j][lane0], E = s_E[wave][j][lane0];
-    const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
-    const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
     uint64_t row0 = base + s_qbase[j * kWavesPerBlock + wave];
     if (pairs) {
+      uint64_t S, E;
+      owned(j, cn, S, E);
+      const uint32_t ns = static_cast<uint32_t>(__popcll(S));
+      const uint32_t incl = wave_inclusive_sum(ns);
       // events in front of the tile: row0 of them; event k of the haystack is the start of row k / 2 (k even) or its end (k odd)
       const uint32_t par = static_cast<uint32_t>(row0) & 1u;
-      uint32_t k = par + (incl & 0xFFFFu) - ns;                    // parity-true index of this lane's first event, counted from an even event
+      uint32_t k = par + incl - ns;                                  // parity-true index of this lane's first event, counted from an even event
       uint64_t sb = S;
       while (sb) {
         const int bit = __builtin_ctzll(sb);
@@ -236,73 +305,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
       n = par ? n >> 1 : (n + 1u) >> 1;
       open = par;
       row0 = (row0 + 1u) >> 1;                                       // rows opened in front of the tile
-    } else {
-#if CXG_CC_MERGED
-    uint32_t r = (incl & 0xFFFFu) - ns, q = (incl >> 16) - ne;
-    uint64_t sb = S, eb = E;
-    while (sb | eb) {                                               // one loop for both bitmaps: a lane has as many ends as starts, give or take one
-      if (sb) {
-        const int bit = __builtin_ctzll(sb);
-        sb &= sb - 1;
-        if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
-        r++;
-      }
-      if (eb) {
-        const int bit = __builtin_ctzll(eb);
-        eb &= eb - 1;
-        if (q < static_cast<uint32_t>(kCcStage)) s_re[wave][cc_slot(q)] = static_cast<uint16_t>(64 * lane0 + bit);
-        q++;
-      }
-    }
-#elif CXG_CC_HALVES
-    // both halves of the word per iteration: the loop runs max(popcount of a half) times instead of popcount of the word.  No bound
-    // check on the rank: cc_slot masks it, and a tile with more than kCcStage starts or ends has raised the fallback flag.
-    static_assert(CXG_CC_SWIZZLE, "cc_slot must mask");
-    {
-      uint32_t b0 = static_cast<uint32_t>(S), b1 = static_cast<uint32_t>(S >> 32);
-      uint32_t r0 = (incl & 0xFFFFu) - ns, r1 = r0 + static_cast<uint32_t>(__popc(b0));
-      while (b0 | b1) {
-        if (b0) { const int bit = __builtin_ctz(b0); b0 &= b0 - 1; s_rs[wave][cc_slot(r0)] = static_cast<uint16_t>(64 * lane0 + bit); r0++; }
-        if (b1) { const int bit = __builtin_ctz(b1); b1 &= b1 - 1; s_rs[wave][cc_slot(r1)] = static_cast<uint16_t>(64 * lane0 + 32 + bit); r1++; }
-      }
-      b0 = static_cast<uint32_t>(E); b1 = static_cast<uint32_t>(E >> 32);
-      r0 = (incl >> 16) - ne; r1 = r0 + static_cast<uint32_t>(__popc(b0));
-      while (b0 | b1) {
-        if (b0) { const int bit = __builtin_ctz(b0); b0 &= b0 - 1; s_re[wave][cc_slot(r0)] = static_cast<uint16_t>(64 * lane0 + bit); r0++; }
-        if (b1) { const int bit = __builtin_ctz(b1); b1 &= b1 - 1; s_re[wave][cc_slot(r1)] = static_cast<uint16_t>(64 * lane0 + 32 + bit); r1++; }
-      }
-    }
-#else
-    uint32_t r = (incl & 0xFFFFu) - ns;
-    uint64_t sb = S;
-    while (sb) {
-      const int bit = __builtin_ctzll(sb);
-      sb &= sb - 1;
-      if (r < static_cast<uint32_t>(kCcStage)) s_rs[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
-      r++;
-    }
-    r = (incl >> 16) - ne;
-    uint64_t eb = E;
-    while (eb) {
-      const int bit = __builtin_ctzll(eb);
-      eb &= eb - 1;
-      if (r < static_cast<uint32_t>(kCcStage)) s_re[wave][cc_slot(r)] = static_cast<uint16_t>(64 * lane0 + bit);
-      r++;
-    }
-#endif
+    } else if (!(early && j == 0)) {
+      stage_runs(j, cn);
     }
     wave_lds_sync();
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
     const uint32_t nst = n < static_cast<uint32_t>(kCcStage) ? n : static_cast<uint32_t>(kCcStage);
     const uint32_t nen = n_ends < static_cast<uint32_t>(kCcStage) ? n_ends : static_cast<uint32_t>(kCcStage);
-    for (uint32_t i = lane0; i < nst; i += 64) {
-      if (row0 + i < a.cap) {
-        if (i + open < nen) {                                       // both halves of the row are this tile's
-          longlong2 v; v.x = tb + s_rs[wave][cc_slot(i)]; v.y = tb + s_re[wave][cc_slot(i + open)];
-          if (u32) store_pair32_nt(out32 + (row0 + i) * 2, static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y));
-          else store_pair_nt(a.out + (row0 + i) * 2, v.x, v.y);
-        } else if (u32) out32[(row0 + i) * 2] = static_cast<uint32_t>(tb + s_rs[wave][cc_slot(i)]);
-        else a.out[(row0 + i) * 2] = tb + s_rs[wave][cc_slot(i)];  // the run ends in a later tile
+    // rows of this tile that fit the output array (uniform): no per-lane capacity test in the loops
+    const uint32_t fit = row0 >= a.cap ? 0u : (a.cap - row0 < nst ? static_cast<uint32_t>(a.cap - row0) : nst);
+    const uint32_t both = nen > open ? nen - open : 0u;              // rows [0, both) have their end in this tile
+    uint32_t ao = static_cast<uint32_t>(lane0) * 26u;
+    if (!u32) {
+      int64_t* po = a.out + (row0 + lane0) * 2;
+      for (uint32_t i = lane0; i < fit; i += 64, po += 128, ao += 64u * 26u) {
+        const int64_t st = tb + static_cast<int64_t>(lds_ld16((ao & 2046u) | rsb));
+        if (i < both) store_pair_nt(po, st, tb + static_cast<int64_t>(lds_ld16(((ao + open * 26u) & 2046u) | reb)));
+        else *po = st;                                               // the run ends in a later tile
+      }
+    } else {
+      uint32_t* po = out32 + (row0 + lane0) * 2;
+      for (uint32_t i = lane0; i < fit; i += 64, po += 128, ao += 64u * 26u) {
+        const uint32_t st = static_cast<uint32_t>(tb) + lds_ld16((ao & 2046u) | rsb);
+        if (i < both) store_pair32_nt(po, st, static_cast<uint32_t>(tb) + lds_ld16(((ao + open * 26u) & 2046u) | reb));
+        else *po = st;
       }
     }
     if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) {       // a run begun in an earlier tile ends here
@@ -311,6 +337,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_charclass_wave(ScanArgs a)
     }
     wave_lds_sync();                                                // staging is reused by the next tile
   }
+  prof_out();
 }
 
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream) {

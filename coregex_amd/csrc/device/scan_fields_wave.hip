@@ -786,9 +786,13 @@ static_assert((kPfTiles - 1) * kWaveTile + kWaveTile + kWaveHalo < 65536, "a par
 constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per unit and wave (twice: rounds r and r - 1); 64 per tile + 64 as in the grouped kernel
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
 // A wave that has waited this long for a word of another wave gives up (capi.hip reruns the call one mode down and demotes the mode for a
-// term): s_memtime ticks of 10 ns.  Legitimate waits are microseconds; round 5 measured what a missing co-resident wave costs with the
-// old count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt).
-constexpr uint64_t kPfWaitTicks = 5000000ull;                // 50 ms
+// term): s_memtime ticks.  Legitimate waits are microseconds; round 5 measured what a missing co-resident wave costs with the old
+// count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt), and with this limit 51 ms (r05_c5_foreign_kernel.txt).
+// What s_memtime counts is not settled: in busy kernels it ran at the shader clock (607 k ticks in a 0.26 ms launch, round 4; 131 k
+// ticks per 55 us workgroup of the char-class kernel, round 5: ~2.2 GHz, which makes this limit 2.3 ms), while the stall it ends
+// measured 50 ms to the millisecond, i.e. 100 MHz — either the counter follows a clock that drops while every wave sleeps, or
+// several waits expire one after another.  The limit is therefore "between 2 and 50 ms".
+constexpr uint64_t kPfWaitTicks = 5000000ull;
 
 // LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused);
 // 16 + K' + 8 EQ = TRIO mode (round 5): run(F) (byte(c_i) run(F)){K'-1} programs with their capture slots, k_scan_trio_wave's tile
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
   if (!order) { if (lane0 == 0) a.status[wv] = my_total; return; }    // k_sum_counts adds the W words up
   if (lane0 == 0) {
     a.pf_stats[wv] = (static_cast<uint64_t>(st_waits) << 32) | st_polls;
-    a.pf_stats[8192 + wv] = __builtin_readcyclecounter() - st_t0;     // s_memtime ticks of this wave's life (100 MHz)
+    a.pf_stats[8192 + wv] = __builtin_readcyclecounter() - st_t0;     // s_memtime ticks of this wave's life (~2.2 GHz in a busy kernel)
     a.pf_stats[16384 + wv] = st_scan;                                 // ... of which inside the tile loops
     a.pf_stats[24576 + wv] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11)) | (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11))) << 32);
   }
