@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
   __shared__ __attribute__((aligned(16))) uint64_t s_M[kWavesPerBlock][kCcTilesPerWave][64];   // membership words (the 16-bit pieces land here)
   __shared__ __attribute__((aligned(2048))) uint16_t s_rs[kWavesPerBlock][kCcStage];   // pass 2 staging: start / end inside the window
   __shared__ __attribute__((aligned(2048))) uint16_t s_re[kWavesPerBlock][kCcStage];   // (a wave's 2 KB: aligned, so that offsets are OR-ed on)
+  __shared__ uint16_t s_dump[kWavesPerBlock][64];                 // where an exhausted stream of pass 2 writes (one slot per lane)
   __shared__ uint32_t s_cnt[kWavesPerBlock][kCcTilesPerWave];
   __shared__ uint32_t s_qbase[kWavesPerBlock * kCcTilesPerWave + 1];
   __shared__ uint64_t s_group;
@@ -102,8 +103,10 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
   // k / 2 when k is even and closes it (exclusive end: the byte behind it) when k is odd.  Pass 1 keeps the occurrence bitmap and
   // counts events; which of them are starts is known behind the look-back, from the parity of the events in front of the tile.
   const bool pairs = ax->pairs != 0u;
+  const uint32_t cls_nr = ax->nr, cls_neg = ax->neg ? 1u : 0u;      // read once: the loops below store to LDS and memory, the compiler would reload them per tile
+  uint32_t cls_lo[4], cls_hi[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) { rg.lo4[q] = ax->lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - ax->hi[q]) * 0x01010101u; }
+  for (int q = 0; q < 4; q++) { cls_lo[q] = ax->lo[q]; cls_hi[q] = ax->hi[q]; rg.lo4[q] = cls_lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - cls_hi[q]) * 0x01010101u; }
   // the ranges as a class plan (wave_common.hpp: `\w` in 9 instructions per dword instead of 15); shape 0 keeps notset4
   static_assert(CXG_CC_PLANS == 0 || CXG_CC_PLANS == 1, "");
   const ClassPlan& plan = a.plan;                                     // kernel arguments: scalar loads
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
       if (tile_lo > 0) {
         const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
 #pragma unroll
-        for (int q = 0; q < 4; q++) if (static_cast<uint32_t>(q) < ax->nr && pb >= ax->lo[q] && pb <= ax->hi[q]) prev_member = 1;
-        prev_member ^= ax->neg ? 1u : 0u;
+        for (int q = 0; q < 4; q++) prev_member |= (static_cast<uint32_t>(q) < cls_nr && pb >= cls_lo[q] && pb <= cls_hi[q]) ? 1u : 0u;
+        prev_member ^= cls_neg;
       }
       uint64_t carry = from_lower64(M) >> 63;                      // DPP outside lane-dependent branches
       if (lane == 0) carry = prev_member;
@@ -228,15 +231,29 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
     S &= word_range(lane0, 0, kWaveTile - 1);
     E &= word_range(lane0, 1, kWaveTile);
   };
-  // every lane drops the bits of its word at their ranks into the staging array at `base`: both 32-bit halves per iteration (the
-  // loop runs max(popcount of a half) times, on 32-bit values).  No bound check on the rank: the slot is masked, and a tile with
-  // more than kCcStage starts or ends has raised the fallback flag.
-  auto drop = [&](uint64_t W, uint32_t rank, uint32_t base) {
-    uint32_t b0 = static_cast<uint32_t>(W), b1 = static_cast<uint32_t>(W >> 32);
-    uint32_t a0 = rank * 26u, a1 = a0 + static_cast<uint32_t>(__popc(b0)) * 26u;
-    while (b0 | b1) {
-      if (b0) { lds_st16((a0 & 2046u) | base, p0 | static_cast<uint32_t>(__builtin_ctz(b0))); b0 &= b0 - 1; a0 += 26u; }
-      if (b1) { lds_st16((a1 & 2046u) | base, p1 | static_cast<uint32_t>(__builtin_ctz(b1))); b1 &= b1 - 1; a1 += 26u; }
+  // Every lane drops the bits of its S and E words at their ranks into the staging arrays: four streams per lane (the 32-bit halves
+  // of both words), one bit of each per iteration, NO exec-masked branch inside — an exhausted stream writes to the lane's dump slot
+  // — and one uniform branch per iteration (any stream of any lane left?).  The wave kernels are bound by instruction issue (a SIMD
+  // issues about one instruction of whatever kind per 4 cycles: measured), so the scalar mask juggling and the
+  // three branches per iteration of the masked form cost as much as its arithmetic.  No bound check on the rank: the slot is masked,
+  // and a tile with more than kCcStage starts or ends has raised the fallback flag.
+  const uint32_t dumpa = lds_off(&s_dump[wave][lane0]);
+  auto step = [&](uint32_t& b, uint32_t& ofs, uint32_t base, uint32_t pos) {
+    uint32_t bit;
+    asm("v_ffbl_b32 %0, %1" : "=v"(bit) : "v"(b));                  // -1 for an empty stream: the value goes to the dump slot
+    lds_st16(b != 0u ? ((ofs & 2046u) | base) : dumpa, pos | bit);
+    b &= b - 1u;
+    ofs += 26u;
+  };
+  auto drop = [&](uint64_t S, uint32_t srank, uint64_t E, uint32_t erank) {
+    uint32_t s0 = static_cast<uint32_t>(S), s1 = static_cast<uint32_t>(S >> 32), e0 = static_cast<uint32_t>(E), e1 = static_cast<uint32_t>(E >> 32);
+    uint32_t as0 = srank * 26u, as1 = as0 + static_cast<uint32_t>(__popc(s0)) * 26u;
+    uint32_t ae0 = erank * 26u, ae1 = ae0 + static_cast<uint32_t>(__popc(e0)) * 26u;
+    while (__builtin_amdgcn_ballot_w64((s0 | s1 | e0 | e1) != 0u) != 0ull) {
+      step(s0, as0, rsb, p0);
+      step(s1, as1, rsb, p1);
+      step(e0, ae0, reb, p0);
+      step(e1, ae1, reb, p1);
     }
   };
   auto stage_runs = [&](int j, uint32_t cn) {                        // (not for pairs: their roles depend on the base)
@@ -244,8 +261,7 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
     owned(j, cn, S, E);
     const uint32_t ns = static_cast<uint32_t>(__popcll(S)), ne = static_cast<uint32_t>(__popcll(E));
     const uint32_t incl = wave_inclusive_sum(ns | (ne << 16));
-    drop(S, (incl & 0xFFFFu) - ns, rsb);
-    drop(E, (incl >> 16) - ne, reb);
+    drop(S, (incl & 0xFFFFu) - ns, E, (incl >> 16) - ne);
   };
 
   // the group's total goes out first (tile_lookback stores the same word again), then the wave's first tile is staged — it
@@ -312,24 +328,22 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
     const uint32_t nst = n < static_cast<uint32_t>(kCcStage) ? n : static_cast<uint32_t>(kCcStage);
     const uint32_t nen = n_ends < static_cast<uint32_t>(kCcStage) ? n_ends : static_cast<uint32_t>(kCcStage);
-    // rows of this tile that fit the output array (uniform): no per-lane capacity test in the loops
+    // rows of this tile that fit the output array (uniform): no per-lane capacity test in the loops.  Rows [0, both) have their end
+    // in this tile; at most one more start follows (its run ends in a later tile: starts and ends alternate).
     const uint32_t fit = row0 >= a.cap ? 0u : (a.cap - row0 < nst ? static_cast<uint32_t>(a.cap - row0) : nst);
-    const uint32_t both = nen > open ? nen - open : 0u;              // rows [0, both) have their end in this tile
-    uint32_t ao = static_cast<uint32_t>(lane0) * 26u;
+    const uint32_t both = nen > open ? nen - open : 0u;
+    const uint32_t npair = both < fit ? both : fit;
+    uint32_t ao = static_cast<uint32_t>(lane0) * 26u, ae = ao + open * 26u;
     if (!u32) {
       int64_t* po = a.out + (row0 + lane0) * 2;
-      for (uint32_t i = lane0; i < fit; i += 64, po += 128, ao += 64u * 26u) {
-        const int64_t st = tb + static_cast<int64_t>(lds_ld16((ao & 2046u) | rsb));
-        if (i < both) store_pair_nt(po, st, tb + static_cast<int64_t>(lds_ld16(((ao + open * 26u) & 2046u) | reb)));
-        else *po = st;                                               // the run ends in a later tile
-      }
+      for (uint32_t i = lane0; i < npair; i += 64, po += 128, ao += 64u * 26u, ae += 64u * 26u)
+        store_pair_nt(po, tb + static_cast<int64_t>(lds_ld16((ao & 2046u) | rsb)), tb + static_cast<int64_t>(lds_ld16((ae & 2046u) | reb)));
+      if (both < fit && lane0 == 0) a.out[(row0 + both) * 2] = tb + s_rs[wave][cc_slot(both)];
     } else {
       uint32_t* po = out32 + (row0 + lane0) * 2;
-      for (uint32_t i = lane0; i < fit; i += 64, po += 128, ao += 64u * 26u) {
-        const uint32_t st = static_cast<uint32_t>(tb) + lds_ld16((ao & 2046u) | rsb);
-        if (i < both) store_pair32_nt(po, st, static_cast<uint32_t>(tb) + lds_ld16(((ao + open * 26u) & 2046u) | reb));
-        else *po = st;
-      }
+      for (uint32_t i = lane0; i < npair; i += 64, po += 128, ao += 64u * 26u, ae += 64u * 26u)
+        store_pair32_nt(po, static_cast<uint32_t>(tb) + lds_ld16((ao & 2046u) | rsb), static_cast<uint32_t>(tb) + lds_ld16((ae & 2046u) | reb));
+      if (both < fit && lane0 == 0) out32[(row0 + both) * 2] = static_cast<uint32_t>(tb) + s_rs[wave][cc_slot(both)];
     }
     if (open && nen != 0 && lane0 == 0 && row0 - 1 < a.cap) {       // a run begun in an earlier tile ends here
       if (u32) out32[(row0 - 1) * 2 + 1] = static_cast<uint32_t>(tb + s_re[wave][cc_slot(0)]);

@@ -21,7 +21,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerWave = CXG_TPW;
 constexpr int kDenseTilesPerWave = 2;          // chain kernel on match-dense input: 256 rows of buffer per wave-tile instead of 64
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
-constexpr int kCcTilesPerWave = 4;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup
+#ifndef CXG_CC_TILES
+#define CXG_CC_TILES 4
+#endif
+constexpr int kCcTilesPerWave = CXG_CC_TILES;             // scan_charclass_wave.hip: 4 waves x 4 wave-tiles = 60 KiB per workgroup
 constexpr uint64_t kCcGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kCcTilesPerWave;
 constexpr int kRecCap = 1024;                 // LDS match records per tile before the direct-write path
 // Serial-walk budget.  A lane that owns a stretch without synchronising bytes walks it alone at ~1.6 us per byte
