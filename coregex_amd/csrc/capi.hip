@@ -543,6 +543,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   cxgdev::ScanArgs a;
   a.pf_status = nullptr;                                           // (set per launch by the fields programs' branch below)
   std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
+  a.cc_nr = a.cc_neg = a.cc_pairs = 0; std::memset(a.cc_lo, 0, 4); std::memset(a.cc_hi, 0, 4);
   a.u32_rows = t_u32Rows ? 1u : 0u;
   if (a.u32_rows && (len >> 32) != 0) return fail(CXG_E_INVALID, "compact rows: the haystack must be shorter than 4 GiB (shard it)");
   a.hay = static_cast<const uint8_t*>(d_hay);
@@ -733,6 +734,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       static const bool plansOk = getenv("CXG_NO_PLANS") == nullptr;   // A/B: the generic range tests
       b.plan = cxgdev::plan_class(cax->nr, cax->lo, cax->hi);
       b.plan_shape = plansOk ? static_cast<uint32_t>(cxgdev::plan_shape(b.plan)) : 0u;
+      b.cc_nr = cax->nr; b.cc_neg = cax->neg; b.cc_pairs = cax->pairs;
+      for (int q = 0; q < 4; q++) { b.cc_lo[q] = cax->lo[q]; b.cc_hi[q] = cax->hi[q]; }
     }
     if (pairsProg) b.limit = a.limit * 2u;
     le = cxgdev::launch_scan_charclass_wave(b, stream);

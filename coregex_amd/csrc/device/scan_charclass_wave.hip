@@ -93,27 +93,31 @@ __global__ __launch_bounds__(kThreads, CXG_CC_OCC) void k_scan_charclass_wave(Sc
   }
 #endif
   const uint64_t pt0 = a.prof ? __builtin_readcyclecounter() : 0ull;   // CXG_PROF=1: wave 0's timestamps per phase, one record per workgroup
-  if (tid == 0) s_group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
-  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
-  const CharClassAux* ax = reinterpret_cast<const CharClassAux*>(a.blob + h->aux_off);   // uniform address: scalar loads
+  // the class (walk.hpp CharClassAux) travels as kernel arguments: read from the program image it cost two dependent scalar loads
+  // before the first window could be requested, and three scalar loads per tile — which were the bound of pass 1 (0.36 -> 0.26 ms
+  // for a count-only launch over 1 GiB, profiles/r05_c15_cfg4.txt)
   SetRanges rg;
-  rg.n = ax->nr;
-  const uint32_t flip = ax->neg ? 0u : 0xFFFFu;                     // notset4 flags the bytes OUTSIDE the ranges: the members of a complemented class
+  rg.n = a.cc_nr;
+  const uint32_t cls_nr = a.cc_nr, cls_neg = a.cc_neg ? 1u : 0u;
+  const uint32_t flip = cls_neg ? 0u : 0xFFFFu;                     // notset4 flags the bytes OUTSIDE the ranges: the members of a complemented class
   // `Q[^Q]*Q` programs (walk.hpp CharClassAux::pairs): the EVENTS are the occurrences of Q; the k-th of the haystack opens row
   // k / 2 when k is even and closes it (exclusive end: the byte behind it) when k is odd.  Pass 1 keeps the occurrence bitmap and
   // counts events; which of them are starts is known behind the look-back, from the parity of the events in front of the tile.
-  const bool pairs = ax->pairs != 0u;
-  const uint32_t cls_nr = ax->nr, cls_neg = ax->neg ? 1u : 0u;      // read once: the loops below store to LDS and memory, the compiler would reload them per tile
+  const bool pairs = a.cc_pairs != 0u;
   uint32_t cls_lo[4], cls_hi[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) { cls_lo[q] = ax->lo[q]; cls_hi[q] = ax->hi[q]; rg.lo4[q] = cls_lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - cls_hi[q]) * 0x01010101u; }
+  for (int q = 0; q < 4; q++) { cls_lo[q] = a.cc_lo[q]; cls_hi[q] = a.cc_hi[q]; rg.lo4[q] = cls_lo[q] * 0x01010101u; rg.hi4[q] = (0x7Fu - cls_hi[q]) * 0x01010101u; }
   // the ranges as a class plan (wave_common.hpp: `\w` in 9 instructions per dword instead of 15); shape 0 keeps notset4
   static_assert(CXG_CC_PLANS == 0 || CXG_CC_PLANS == 1, "");
   const ClassPlan& plan = a.plan;                                     // kernel arguments: scalar loads
   const int shape = CXG_CC_PLANS ? static_cast<int>(a.plan_shape) : 0;
-  __syncthreads();
-  const uint64_t group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
-                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  uint64_t group = blockIdx.x;                                       // static groups: no claim, no barrier in front of the first loads
+  if (!a.static_groups) {
+    if (tid == 0) s_group = claim_group(false, a.ticket, a.ngroups);
+    __syncthreads();
+    group = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group >> 32))) << 32) |
+            static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(s_group)));
+  }
   if (group >= a.ngroups) return;
   if (limit_reached_skip(a, group, &s_base)) return;                 // FindAll with n > 0 (block_common.hpp)
   uint32_t fallback = 0;

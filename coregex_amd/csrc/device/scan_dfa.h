@@ -92,6 +92,8 @@ struct ScanArgs {
   uint64_t* pf_stats;   // [8192] per wave: units that waited << 32 | polls (CXG_VERBOSE)
   ClassPlan plan;       // scan_charclass_wave.hip: the class; k_scan_trio_wave: the field class (filled on the host per launch)
   uint32_t plan_shape;  // wave_common.hpp plan_shape(plan); 0: the generic range tests
+  uint32_t cc_nr, cc_neg, cc_pairs;   // scan_charclass_wave.hip: walk.hpp CharClassAux copied by the host (kernel arguments: no dependent
+  uint8_t cc_lo[4], cc_hi[4];         // loads from the program image before the first window can be requested)
   uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };
 
