@@ -626,6 +626,9 @@ __device__ __forceinline__ TrioTile trio_core(uint32_t d0, uint32_t d1, const ui
   return TrioTile{e0, e1, (ovf >> 63) != 0ull};
 }
 
+#ifndef CXG_TRIO_ROWS_FAST
+#define CXG_TRIO_ROWS_FAST 1                                  // trio_rows: the K highest bits of one 64-bit word when the row lies within 64 bytes (0: always the two-word search; A/B)
+#endif
 // highest set bit of the 128-bit value (h : l), or -1; and the value with that bit cleared
 __device__ __forceinline__ int32_t take_top(uint64_t& l, uint64_t& h) {
   if (h) { const int32_t k = 63 - __builtin_clzll(h); h &= ~(1ull << k); return 64 + k; }
@@ -645,16 +648,30 @@ __device__ __forceinline__ void trio_rows(const TrioTile& t, uint32_t d0, uint32
   while (ee) {
     const int32_t b = __builtin_ctzll(ee);
     ee &= ee - 1ull;
-    uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;             // bytes outside F below the end, nearest first:
-    int32_t pl[K - 1];                                                      // the links, last first
-#pragma unroll
-    for (int i = K - 2; i >= 0; i--) pl[i] = take_top(l, h);
-    const int32_t ps = take_top(l, h);                                      // the byte in front of the match
     uint32_t w0 = 0, w1 = 0;                                                // start not found within two words: row void (start >= end), caught below
-    if (ps >= 0) {
+    // the 64 bytes below the end as ONE word (bit i = index b + i of (z : pz)): when the K bytes outside F that make up the row — the
+    // links, last first, then the byte in front of the match — lie in it (every match shorter than 64 bytes), they are its K highest
+    // bits: K x (count leading zeros, clear) without a branch (round 5: 0.402 -> 0.389 ms on config 5, profiles/r05_c19_cfg5.txt).
+    uint64_t W = (pz >> b) | (b ? (z << (64 - b)) : 0ull);
+    if (CXG_TRIO_ROWS_FAST && __popcll(W) >= K) {
+      int32_t idx[K];                                                       // indices in (z : pz), nearest first
+#pragma unroll
+      for (int i = 0; i < K; i++) { const int32_t c = __builtin_clzll(W); idx[i] = b + 63 - c; W &= ~(0x8000000000000000ull >> c); }
+      const int32_t ps = idx[K - 1];
       w0 = (static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16)) + shift;
 #pragma unroll
-      for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(pl[i] - ps - 1) << (8 * i);
+      for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(idx[K - 2 - i] - ps - 1) << (8 * i);
+    } else {
+      uint64_t l = pz, h = b ? (z & ((1ull << b) - 1ull)) : 0ull;           // bytes outside F below the end, nearest first:
+      int32_t pl[K - 1];                                                    // the links, last first
+#pragma unroll
+      for (int i = K - 2; i >= 0; i--) pl[i] = take_top(l, h);
+      const int32_t ps = take_top(l, h);                                    // the byte in front of the match
+      if (ps >= 0) {
+        w0 = (static_cast<uint32_t>(base + ps + 1) | (static_cast<uint32_t>(base + 64 + b) << 16)) + shift;
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) w1 |= static_cast<uint32_t>(pl[i] - ps - 1) << (8 * i);
+      }
     }
     const uint32_t rr = r < cap ? r : cap - 1u;
     rows[rr] = w0; links[rr] = static_cast<LinkT>(w1);
@@ -1451,23 +1468,32 @@ __global__ __launch_bounds__(kThreads, (K == 4 ? 6 : CXG_TRIO_WAVES)) void k_sca
   uint32_t sel0 = 0, sel1 = 1; int32_t off0 = 0, off1 = 0;
   if (caps && lane_on) { slot_of(2u * pr, sel0, off0); slot_of(2u * pr + 1u, sel1, off1); }
   const int64_t origin = a.base + static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw) - kFPre;
+  // What a lane's two slots are made of, as shifts and masks decided once (the kernels are bound by instruction issue, DESIGN.md
+  // section 5: a chain of selects on 64-bit values per slot and row cost as much as the tile mathematics of the rows):
+  //   slot = tb + off + ((w0 >> shA) & 0xFFFF) + ((w1 >> shB) & mB)      start: shA 0, mB 0; end: shA 16, mB 0; link i: shA 0, shB 8 i, mB 0xFF
+  const uint32_t shA0 = sel0 == 1u ? 16u : 0u, shA1 = sel1 == 1u ? 16u : 0u;
+  const bool lk0 = sel0 >= 2u && sel0 != 7u, lk1 = sel1 >= 2u && sel1 != 7u;
+  const uint32_t shB0 = lk0 ? 8u * (sel0 - 2u) : 0u, shB1 = lk1 ? 8u * (sel1 - 2u) : 0u, mB0 = lk0 ? 0xFFu : 0u, mB1 = lk1 ? 0xFFu : 0u;
+  const bool un0 = sel0 == 7u, un1 = sel1 == 7u;
+  const uint32_t per = 64u >> lsh;                                   // rows per iteration of a wave
   uint32_t start = 0;
   for (int j = 0; j < tpw; j++) {
     const uint32_t n = s_cnt[wave][j];
     const uint64_t dst = base + s_qbase[j * kWavesPerBlock + wave];
     const int64_t tb = origin + static_cast<int64_t>(j * kWavesPerBlock + wave) * kWaveTile;
-    for (uint32_t i = lane0; i < (n << lsh); i += 64) {               // consecutive lanes write consecutive 16 bytes
-      const uint32_t rr = i >> lsh;
-      const uint32_t r = start + rr;
-      if (lane_on && r < static_cast<uint32_t>(kTRows) && dst + rr < a.cap) {
-        const uint32_t w0 = s_row[wave][r], w1 = s_lnk[wave][r];
-        const int64_t ps = tb + (w0 & 0xFFFFu), pe = tb + (w0 >> 16);
-        auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
-        longlong2 o;
-        o.x = sel0 == 7u ? -1 : pos_of(sel0) + off0; o.y = sel1 == 7u ? -1 : pos_of(sel1) + off1;
-        store_pair_nt(a.out + (dst + rr) * a.row_width + 2u * pr, o.x, o.y);
+    // rows of this tile that are parked and fit the output array (uniform)
+    uint32_t fit = start >= static_cast<uint32_t>(kTRows) ? 0u : (n < static_cast<uint32_t>(kTRows) - start ? n : static_cast<uint32_t>(kTRows) - start);
+    fit = dst >= a.cap ? 0u : (a.cap - dst < fit ? static_cast<uint32_t>(a.cap - dst) : fit);
+    const int64_t tb0 = tb + off0, tb1 = tb + off1;
+    uint32_t rr = static_cast<uint32_t>(lane0) >> lsh;
+    int64_t* po = a.out + (dst + rr) * a.row_width + 2u * pr;
+    if (lane_on)
+      for (; rr < fit; rr += per, po += static_cast<uint64_t>(per) * a.row_width) {   // consecutive lanes write consecutive 16 bytes
+        const uint32_t w0 = s_row[wave][start + rr], w1 = s_lnk[wave][start + rr];
+        const int64_t v0 = tb0 + static_cast<int64_t>(((w0 >> shA0) & 0xFFFFu) + ((w1 >> shB0) & mB0));
+        const int64_t v1 = tb1 + static_cast<int64_t>(((w0 >> shA1) & 0xFFFFu) + ((w1 >> shB1) & mB1));
+        store_pair_nt(po, un0 ? -1 : v0, un1 ? -1 : v1);
       }
-    }
     start += n;
   }
 }
