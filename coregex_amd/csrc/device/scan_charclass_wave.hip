@@ -14,15 +14,15 @@
 //           alternate start, end, start, end, so the k-th start and the k-th end of the haystack are row k: with
 //           B = number of starts in front of the tile (look-back), the tile's i-th start is row B + i and its j-th
 //           end is row B - open + j, open = 1 when a run crosses the tile's first byte.  The start counts are summed per tile;
-//   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, the group's total published, the first tile of every wave staged
-//           (that needs no base: the time would otherwise pass in the look-back's wait), look-back -> base of every tile;
+//   group   (4 waves x 4 wave-tiles = 60 KiB) one barrier, look-back -> base of every tile (CXG_CC_EARLY=1 stages the first tile of
+//           every wave in front of the look-back: measured, no gain);
 //   pass 2  per wave-tile S and E again from M (a DPP shift and six bit operations), every lane drops the starts and ends it
-//           holds into the wave's LDS staging at their ranks — both 32-bit halves of its word per loop iteration — then the
+//           holds into the wave's LDS staging at their ranks — four streams per lane, no exec-masked branch (see `drop`) — then the
 //           wave writes the rows that have both halves here as fully coalesced 16-byte stores (1 KiB per instruction); the end
 //           of a run begun in an earlier tile and the start of a run that ends in a later one go out as lone 8-byte stores.
-// LDS: 24.7 KB per workgroup (M 8 KB, staging 16 KB) — six workgroups per CU.  Round 5 measurements behind this form
-// (profiles/r05_c8..c11_*): parking S and E (34.7 KB, four workgroups), one window in flight, one bit per iteration of
-// 64-bit loops: 1.08 ms per GiB of config 4; this form 0.99.
+// LDS: 25.2 KB per workgroup (M 8 KB, staging 16 KB, dump slots) — six workgroups per CU.  Round 5 measurements behind this form
+// (profiles/README.md, calls 8-18): parking S and E (34.7 KB, four workgroups), one window in flight, the class read from the
+// program image per tile, one bit per iteration of exec-masked 64-bit loops: 1.08 ms per GiB of config 4; this form 0.86-0.93.
 // Fallback flag (err bit 8: the host reruns the scan with scan_charclass.hip): more than 1024 starts or ends in one
 // wave-tile.
 #include <hip/hip_runtime.h>
