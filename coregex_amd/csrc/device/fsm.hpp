@@ -396,6 +396,59 @@ CXG_FSM_HD void fsm_finish_shallow(const FsmView& v, const Mem& m, const FsmTrac
   }
 }
 
+// ---- Round 6: rows of a SHALLOW machine from the event bits alone (no walk past the chunk, no per-lane row buffers).
+// The steps of a tile are one stream of events, two bits per byte (bit 2p the step over byte p created a match, bit
+// 2p + 1 it rematched one).  With at most one pending match a rematch always extends the match of the event in front of
+// it, and a create always finds that match committed.  So:   an event is a ROW END  <=>  the event behind it is not a
+// rematch   (no event behind it: the match stands as it is — end of input, or its threads die).  A row belongs to the
+// chunk its end lies in, whoever created it; the events behind a tile come from lanes that walk the window's tail for
+// nothing but their bits.  "The event behind me is a rematch" is a predecessor search: in the bit-reversed stream it is
+// one subtraction  D = T' - ((R' << 1) | cin)  whose borrow runs from a rematch through the gap in front of it and stops at
+// the first event it meets; ends = T' & D.  cin: the first event behind this word is a rematch (fsm_lanes_succ_r, the same
+// trick one level up, lanes as bits).
+// T: a lane's 128 event bits (two sub-chunks, ascending); Er: its row ends, bit-reversed — Er[0] bit 0 is T[3] bit 31.
+CXG_FSM_HD uint32_t fsm_brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x);
+#else
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+#endif
+}
+CXG_FSM_HD void fsm_lane_ends(const uint32_t (&T)[4], uint32_t cin, uint32_t (&Er)[4]) {
+  uint32_t tr[4], a[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int i = 0; i < 4; i++) {
+    tr[i] = fsm_brev32(T[3 - i]);
+    a[i] = (tr[i] & 0x55555555u) << 1;                 // rematch bits (odd before the reversal, even after), moved onto the next slot
+  }
+  a[0] |= cin & 1u;
+  const uint64_t tl = (static_cast<uint64_t>(tr[1]) << 32) | tr[0], th = (static_cast<uint64_t>(tr[3]) << 32) | tr[2];
+  const uint64_t al = (static_cast<uint64_t>(a[1]) << 32) | a[0], ah = (static_cast<uint64_t>(a[3]) << 32) | a[2];
+  const uint64_t dl = tl - al, dh = th - ah - (tl < al ? 1ull : 0ull);
+  Er[0] = tr[0] & static_cast<uint32_t>(dl); Er[1] = tr[1] & static_cast<uint32_t>(dl >> 32);
+  Er[2] = tr[2] & static_cast<uint32_t>(dh); Er[3] = tr[3] & static_cast<uint32_t>(dh >> 32);
+}
+// the first (lowest) event of the 128 bits is a rematch
+CXG_FSM_HD bool fsm_first_is_r(const uint32_t (&T)[4]) {
+  const uint32_t w = T[0] ? T[0] : (T[1] ? T[1] : (T[2] ? T[2] : T[3]));
+  return ((w & (0u - w)) & 0xAAAAAAAAu) != 0u;
+}
+// ne: lanes with events, fr: lanes whose first event is a rematch (a subset of ne).  Returns the lanes whose LAST event
+// is followed by a rematch somewhere in the lanes above.
+CXG_FSM_HD uint64_t fsm_brev64(uint64_t v) { return (static_cast<uint64_t>(fsm_brev32(static_cast<uint32_t>(v))) << 32) | fsm_brev32(static_cast<uint32_t>(v >> 32)); }
+CXG_FSM_HD uint64_t fsm_lanes_succ_r(uint64_t ne, uint64_t fr) {
+  const uint64_t rne = fsm_brev64(ne), rfr = fsm_brev64(fr);
+  return fsm_brev64(((rfr << 1) + ~rne) & rne);
+}
+// low 2 * n bits (n bytes of a 32-byte sub-chunk are input)
+CXG_FSM_HD uint64_t fsm_valid_bits(int32_t n) { return n >= 32 ? ~0ull : (n <= 0 ? 0ull : ((1ull << (2 * n)) - 1ull)); }
+
 // fast: trace of the chunk's fast part, or nullptr when the chunk was not walked yet (edge chunks: end of input inside).
 template <class Mem, class Rows, class Events>
 CXG_FSM_HD void fsm_finish(const FsmView& v, const Mem& m, uint32_t entry, const FsmTrace* fast, int32_t c0, int32_t c1, int32_t rend,

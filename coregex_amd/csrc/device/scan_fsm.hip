@@ -50,7 +50,7 @@ namespace cxgdev {
 namespace {
 
 constexpr int kFsmStride = 68;                       // LDS bytes per 64-byte chunk
-constexpr int kFsmWinBytes = 64 * kFsmStride;        // 4352 per wave
+constexpr int kFsmWinBytes = 64 * kFsmStride + 16;   // 4352 per wave + the dword BEHIND the window (look-around: the kind of the byte behind a step)
 constexpr int kFsmLeft = 64;                         // bytes staged in front of the tile
 constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the window (192 bytes past the tile)
 
@@ -114,9 +114,9 @@ template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
-  uint16_t lrow[kWavesPerBlock][64 * 2 * FsmMode<MODE>::kRows];      // per-lane row ends of the current tile (two sub-chunks)
+  uint16_t lrow[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kRows];   // per-lane row ends of the current tile (two sub-chunks); shallow machines: rows come from the event bits
   uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
-  uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // rows of the group: end inside its wave-tile
+  uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];      // rows of the group: end inside its wave-tile (+ a dump slot for the branch-free row loop)
   uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];          // ... and length (0: unresolved)
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
   union {                                                      // (the 10 KiB-image instantiations sit 320 bytes below 4 workgroups per CU)
@@ -356,20 +356,23 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
   uint32_t nrows_w = 0, fallback = 0, long_hit = 0;
 
   u32x4 x[4];
+  uint32_t xbehind = 0;                                // look-around: the dword behind the window (the last step of the window's tail reads its first byte)
   auto issue_loads = [&](int jj) {
     const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
     const int pre = lo ? 0 : kFsmLeft;                 // the first tile has nothing in front of it
     const uint64_t from = lo ? lo - kFsmLeft : 0;
+    constexpr int kStaged = 4096 + (LOOK ? 4 : 0);
     if (jj < tpw && lo < a.len) {
       const uint64_t rem = a.len - from;
-      nrec = rem >= static_cast<uint64_t>(4096 - pre) ? 4096 - pre : static_cast<int>((rem + 3) & ~3ull);
+      nrec = rem >= static_cast<uint64_t>(kStaged - pre) ? kStaged - pre : static_cast<int>((rem + 3) & ~3ull);
     }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? from : 0), 0, nrec, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 4; k++)                        // window offsets below `pre` wrap around: out of range, read as zero
       x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((lane + 64 * k) << 4) - pre, 0, 0);
+    if (LOOK) xbehind = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 4096 - pre, 0, 0);   // (every lane the same dword: one request)
   };
   issue_loads(0);
 #if CXG_FSM_PROF
@@ -405,12 +408,13 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         uint32_t* d = reinterpret_cast<uint32_t*>(win + wo + (wo >> 6) * 4u);
         d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
       }
+      if (LOOK && lane == 0) *reinterpret_cast<uint32_t*>(win + 64 * kFsmStride) = xbehind;   // window position 4096
       issue_loads(j + 1);
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
       if (LOOK && lane == 0) {                          // the byte in front of the haystack and the one behind its end (DS ops of a wave keep their order)
         if (tile_lo == 0) win[kFsmLeft - 1] = static_cast<uint8_t>(outside);
-        if (rend < kFsmWinEnd) { const uint32_t w = static_cast<uint32_t>(rend + kFsmLeft); win[w + (w >> 6) * 4u] = static_cast<uint8_t>(outside); }
+        if (rend <= kFsmWinEnd) { const uint32_t w = static_cast<uint32_t>(rend + kFsmLeft); win[w + (w >> 6) * 4u] = static_cast<uint8_t>(outside); }
       }
       wave_lds_sync();
       FSM_MARK(0);                                      // window staged
@@ -426,8 +430,12 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       // ---- E + R: entry states, replay.  A lane's 64 bytes are two sub-chunks of 32 walked in lockstep (two
       // independent chains of dependent LDS reads per lane).
       const int32_t c0 = (lane - 1) * kFsmChunk;
-      const bool active = lane >= 1 && lane <= kWaveTile / kFsmChunk && c0 < rend;
+      const bool owned = lane >= 1 && lane <= kWaveTile / kFsmChunk && c0 < rend;
+      // shallow machines: the three lanes behind the tile walk the window's tail for nothing but its event bits (fsm.hpp "Round 6")
+      const bool active = SHALLOW ? (lane >= 1 && c0 < rend) : owned;
       const int32_t cc[2] = {c0, c0 + kFsmSub};
+      uint64_t KK[2] = {0ull, 0ull};                   // shallow: the event bits of the two sub-chunks (two per byte)
+      uint32_t xend[2] = {0u, 0u};                     // ... and the row behind each of them
       const bool second = active && cc[1] < rend;
       const bool whole = c0 + kFsmChunk <= rend && c0 + kFsmChunk <= budget;   // both sub-chunks are staged data
       const int q_tile = j * kWavesPerBlock + wave;    // index of the tile inside the group
@@ -454,22 +462,22 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       const bool unres0 = active && entry[0] >= v.u_lo, unres1 = second && entry[1] >= v.u_lo;
       const unsigned long long um0 = __ballot(unres0), um1 = __ballot(unres1);
       if (map_only && (um0 | um1) == 0ull) {            // only the exit: the last sub-chunk of the tile from its known entry
-        const unsigned long long am = __ballot(active);
+        const unsigned long long am = __ballot(owned);
         const int ll = 63 - __builtin_clzll(am | 1ull);
         const int sbl = second ? 1 : 0;
         const int32_t to = cc[sbl] + kFsmSub < rend ? cc[sbl] + kFsmSub : rend;
-        const uint32_t xe = (active && lane == ll) ? fsm_canon(v, fsm_walk(v, m, sbl ? entry[1] : entry[0], cc[sbl], to, true)) : 0u;
+        const uint32_t xe = (owned && lane == ll) ? fsm_canon(v, fsm_walk(v, m, sbl ? entry[1] : entry[0], cc[sbl], to, true)) : 0u;
         const uint32_t ex = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xe), ll));
         if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
         deferred = true;
       } else if ((um0 | um1) == 0ull) {
         if (active) {
-          if (whole && SHALLOW) {
+          if (SHALLOW) {                               // (bytes behind the end of the input read as zeros: their bits are masked below)
             FsmTraceS t[2] = {{entry[0], 0u, 0u}, {entry[1], 0u, 0u}};
             if (!(CXG_FSM_ABL & 2)) fsm_fast_shallow<2>(v, m, cc, t);
             FSM_MARK(2);                                // lockstep walk
-            fsm_finish_shallow(v, m, t[0], cc[0], rend, budget, L[0], rows[0]);
-            fsm_finish_shallow(v, m, t[1], cc[1], rend, budget, L[1], rows[1]);
+            KK[0] = (static_cast<uint64_t>(t[0].k1) << 32) | t[0].k0; KK[1] = (static_cast<uint64_t>(t[1].k1) << 32) | t[1].k0;
+            xend[0] = t[0].x & ~3u; xend[1] = t[1].x & ~3u;
           } else if (whole) {
             FsmTrace t[2] = {{entry[0], 0u, 0u, kLaneEvents}, {entry[1], 0u, 0u, kLaneEvents}};
             fsm_fast<2>(v, m, cc, t, evs);
@@ -491,13 +499,12 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         // operations per unresolved sub-chunk.
         auto replay_one = [&](int sb, uint32_t from_state) {   // one sub-chunk from a known entry state
           const int32_t c1s = cc[sb] + kFsmSub;
-          if (SHALLOW && c1s <= rend && c1s <= budget) {          // (shallow instantiations have no event buffers)
+          if (SHALLOW) {
             const int32_t c1a[1] = {cc[sb]};
             FsmTraceS ts[1] = {{from_state, 0u, 0u}};
             fsm_fast_shallow<1>(v, m, c1a, ts);
-            fsm_finish_shallow(v, m, ts[0], cc[sb], rend, budget, L[sb], rows[sb]);
-          } else if (SHALLOW) {
-            fsm_finish(v, m, from_state, static_cast<const FsmTrace*>(nullptr), cc[sb], c1s, rend, budget, L[sb], rows[sb], evs[sb]);
+            KK[sb] = (static_cast<uint64_t>(ts[0].k1) << 32) | ts[0].k0;
+            xend[sb] = ts[0].x & ~3u;
           } else {
             fsm_replay(v, m, from_state, cc[sb], c1s, rend, budget, L[sb], rows[sb], evs[sb]);
           }
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
             xc[sb] = fsm_canon(v, fsm_walk(v, m, entry[sb], cc[sb], c1s < rend ? c1s : rend, true));
           } else if (has && !unres) {
             replay_one(sb, entry[sb]);
-            xc[sb] = fsm_canon(v, L[sb].xc1);
+            xc[sb] = fsm_canon(v, SHALLOW ? xend[sb] : L[sb].xc1);
           } else if (has) {
             if (fsm_member(v, entry[sb], 0) == 0xFFFFu) fallback |= 1u;      // more than 8 possible states: not listed
             const int32_t to = c1s < rend ? c1s : rend;
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         // <= 8 candidates and a chain of true entries, one step per unresolved sub-chunk, up to 126 per tile and ~35
         // instructions each) were 13 k of the 31 k instructions of a tile on input without synchronising structure.
         FSM_MARK(2);                                    // (unresolved tiles: replays of the known sub-chunks + member maps)
-        const unsigned long long am_all = __ballot(active);
+        const unsigned long long am_all = __ballot(owned);             // (the tile ends behind its last OWNED lane; the tail lanes take part in the scan for their entries only)
         const int last_lane = 63 - __builtin_clzll(am_all | 1ull);
         uint32_t pred_exit = 0u;
         const bool first_open = (um0 >> 1) & 1ull;
@@ -644,22 +651,60 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           if (!deferred && (sb ? unres1 : unres0)) replay_one(sb, true_entry[sb]);
       }
       if (!deferred) {
-      if (active) fallback |= (L[0].flags | L[1].flags) << 1;
+      if (!SHALLOW && active) fallback |= (L[0].flags | L[1].flags) << 1;
       {  // this tile's exit state, for a following tile whose first set does not collapse
-        const unsigned long long am = __ballot(active);
+        const unsigned long long am = __ballot(owned);
         const int ll = 63 - __builtin_clzll(am | 1ull);
-        const uint32_t xl = second ? L[1].xc1 : L[0].xc1;
+        const uint32_t xl = SHALLOW ? (second ? xend[1] : xend[0]) : (second ? L[1].xc1 : L[0].xc1);
         const uint32_t ex = fsm_canon(v, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xl), ll)));
         if (lane == 0) publish_tile_exit(S.exit, a.status2, group, q_tile, kWavesPerBlock * tpw, a.epoch, ex);
       }
       FSM_MARK(3);                                      // rows of the lanes (+ divergence of the whole E/R block)
       // ---- S: rows in lane order, then their starts
+      if (SHALLOW) {
+        // Row ends from the event bits (fsm.hpp "Round 6"): an event is a row's end unless the event behind it is a rematch.
+        const uint64_t k0 = active ? (KK[0] & fsm_valid_bits(rend - cc[0])) : 0ull, k1 = active ? (KK[1] & fsm_valid_bits(rend - cc[1])) : 0ull;
+        const uint32_t T[4] = {static_cast<uint32_t>(k0), static_cast<uint32_t>(k0 >> 32), static_cast<uint32_t>(k1), static_cast<uint32_t>(k1 >> 32)};
+        const bool ne = (T[0] | T[1] | T[2] | T[3]) != 0u;
+        const unsigned long long NE = __ballot(ne), FR = __ballot(ne && fsm_first_is_r(T));
+        const unsigned long long LN = fsm_lanes_succ_r(NE, FR);           // (scalar unit)
+        // The window's last event with the input going on behind the window: whether a rematch follows is not known here.  A row
+        // of this tile only when that event lies in an owned lane AND a match is still pending at the window's end — a match
+        // that reaches 190 bytes past its tile: the host's next rung.
+        if (rend > kFsmWinEnd && NE != 0ull && 63 - __builtin_clzll(NE) <= kWaveTile / kFsmChunk) {
+          const uint32_t pend = fsm_u16(v.tab, xend[1] + v.ncls2 + 2u);
+          if (__builtin_amdgcn_readlane(static_cast<int>(pend), 63) != 0) fallback |= 8u;
+        }
+        uint32_t Er[4];
+        fsm_lane_ends(T, static_cast<uint32_t>(LN >> lane) & 1u, Er);
+        if (!owned || (CXG_FSM_ABL & 4)) Er[0] = Er[1] = Er[2] = Er[3] = 0u;
+        const uint32_t nl = static_cast<uint32_t>(__builtin_popcount(Er[0]) + __builtin_popcount(Er[1]) + __builtin_popcount(Er[2]) + __builtin_popcount(Er[3]));
+        const uint32_t incl = wave_inclusive_sum(nl);
+        tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        uint32_t idx = nrows_w + incl - nl;
+        // the ends in ascending order: T's dword i is Er[3 - i] reversed, so its lowest position is the highest bit there.  No masked
+        // branch in the loop (a lane without a bit writes the dump slot), one uniform branch per round.
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          uint32_t xw = Er[3 - i];
+          const int32_t e0 = c0 + 16 * i + 1;
+          while (__builtin_amdgcn_ballot_w64(xw != 0u) != 0ull) {
+            const bool has = xw != 0u;
+            const uint32_t q = static_cast<uint32_t>(__builtin_clz(xw | 1u));
+            xw &= ~(0x80000000u >> q);
+            const uint32_t slot = (has && idx < static_cast<uint32_t>(kRowsPerWave)) ? idx : static_cast<uint32_t>(kRowsPerWave);
+            s_re[wave][slot] = static_cast<uint16_t>(e0 + static_cast<int32_t>(q >> 1));
+            idx += has ? 1u : 0u;
+          }
+        }
+      } else {
       const uint32_t nl0 = (active && !(CXG_FSM_ABL & 4)) ? L[0].nrows : 0u, nl = nl0 + ((active && !(CXG_FSM_ABL & 4)) ? L[1].nrows : 0u);
       const uint32_t incl = wave_inclusive_sum(nl);
       tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
       const uint32_t first = nrows_w + incl - nl;
       for (uint32_t r = 0; r < nl; r++)
         if (first + r < static_cast<uint32_t>(kRowsPerWave)) s_re[wave][first + r] = r < nl0 ? rows[0].slot[r] : rows[1].slot[r - nl0];
+      }
       wave_lds_sync();
       FSM_MARK(4);                                      // rows gathered
       if (a.out != nullptr || a.max_len != 0) {

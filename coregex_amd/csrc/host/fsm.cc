@@ -253,6 +253,49 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   // survives the step: `(?:ab)*[ab]` on "abb" creates [1,2) under the pending [0,1) — no threads of its own, so the stack
   // stays one deep — and the parent then grows to [0,3) and must drop it.  Such machines take the event-list path.
   if (createUnderPending && depth < 2) depth = 2;
+  // ---- Round 6: minimise.  Stacks of ordered thread lists tell apart much that no input can: the README IPv4 pattern
+  // (README.md:64) explores 95 stacks that behave as 20 states, `https?://[^ ]+` 28 as 10.  What the kernels observe of a state
+  // is its number of pending levels and, per input symbol, the event descriptor and the next state — Moore's refinement over
+  // exactly that.  Fewer states means a smaller image (more workgroups per CU), fewer and smaller sets of possible entry states
+  // (they collapse sooner), and it is what lets the byte-indexed tables of the kernel's direct mode fit into LDS.
+  static const bool noMinimise = getenv("CXG_FSM_NO_MINIMISE") != nullptr;   // A/B
+  if (!noMinimise) {
+    const uint32_t n0 = static_cast<uint32_t>(keys.size());
+    std::vector<uint32_t> part(n0);
+    for (uint32_t s = 0; s < n0; s++) part[s] = levels[s];
+    size_t nblocks = 0;
+    for (;;) {
+      std::map<std::vector<uint32_t>, uint32_t> sig;
+      std::vector<uint32_t> next(n0);
+      for (uint32_t s = 0; s < n0; s++) {
+        std::vector<uint32_t> k;
+        k.reserve(ncls + 1);
+        k.push_back(part[s]);
+        for (uint32_t c = 0; c < ncls; c++) k.push_back((trans[s][c] & 0xFFFF0000u) | part[trans[s][c] & 0xFFFFu]);
+        next[s] = sig.emplace(std::move(k), static_cast<uint32_t>(sig.size())).first->second;   // blocks numbered by first occurrence: state 0 stays 0
+      }
+      part.swap(next);
+      if (sig.size() == nblocks) break;
+      nblocks = sig.size();
+    }
+    if (nblocks < n0) {
+      std::vector<std::vector<uint32_t>> ntrans(nblocks);
+      std::vector<uint8_t> nlevels(nblocks, 0);
+      std::vector<std::vector<uint32_t>> nkeys(nblocks);
+      std::vector<bool> have(nblocks, false);
+      for (uint32_t s = 0; s < n0; s++) {
+        const uint32_t b = part[s];
+        if (have[b]) continue;
+        have[b] = true;
+        nlevels[b] = levels[s];
+        nkeys[b] = keys[s];
+        ntrans[b].resize(ncls);
+        for (uint32_t c = 0; c < ncls; c++) ntrans[b][c] = (trans[s][c] & 0xFFFF0000u) | part[trans[s][c] & 0xFFFFu];
+      }
+      for (uint32_t k = 0; k < nk; k++) startOf[k] = part[startOf[k]];
+      trans.swap(ntrans); levels.swap(nlevels); keys.swap(nkeys);
+    }
+  }
   const uint32_t nT = static_cast<uint32_t>(keys.size());
 
   // ---- uncertainty rows: sets of states, from "any state" (top) until they collapse to one state

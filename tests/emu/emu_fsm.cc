@@ -142,10 +142,118 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
 }
 
 
+// Round 6: the SHALLOW instantiation's row derivation (scan_fsm.hip "S", fsm.hpp "Round 6").  Lanes of 64 bytes = two sub-chunks of
+// kFsmSub; `tile / 64` owned lanes, then `budget_bytes / 64` tail lanes that only contribute their event bits; rows = the events of
+// the owned lanes that no rematch follows, through the very functions the kernel calls (fsm_fast_shallow, fsm_first_is_r,
+// fsm_lanes_succ_r, fsm_lane_ends).  Entry states by the kernel's policy (16 bytes of warm-up, then 64, then the true state).
+template <bool LOOK>
+static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                               int tile, int budget_bytes, uint64_t* stats) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  const FsmView v = view_of(img);
+  std::vector<int64_t> res;
+  const int own = tile / 64, tail = budget_bytes / 64;
+  const uint64_t ntiles = (len + static_cast<uint64_t>(tile) - 1) / static_cast<uint64_t>(tile);
+  int64_t prev_end = 0;
+  uint32_t tile_entry = 0;                                // canonical state at the tile's first byte
+  uint64_t st[4] = {0, 0, 0, 0};
+  for (uint64_t t = 0; t < ntiles; t++) {
+    const uint64_t tile_lo = t * static_cast<uint64_t>(tile);
+    const uint64_t remaining = len - tile_lo;
+    const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+    const int32_t win_end = tile + budget_bytes;
+    const int32_t lowest = tile_lo > static_cast<uint64_t>(budget_bytes) ? -budget_bytes : -static_cast<int32_t>(tile_lo);
+    HostMem<LOOK> m;
+    m.hay = hay; m.origin_abs = static_cast<int64_t>(tile_lo); m.len = static_cast<int64_t>(len); m.outside = LOOK ? h->outside_byte : 0u;
+    uint32_t T[64][4];
+    uint64_t ne = 0, fr = 0;
+    uint32_t cur = tile_entry, x_end = 0;
+    int nact = 0;
+    for (int l = 0; l < own + tail; l++) {
+      const int32_t c0 = l * 64;
+      for (int q = 0; q < 4; q++) T[l][q] = 0;
+      if (c0 >= rend) break;
+      nact = l + 1;
+      for (int sb = 0; sb < 2; sb++) {
+        const int32_t c = c0 + sb * kFsmSub;
+        uint32_t entry = m.origin(v);
+        if (c < rend) st[0]++;
+        if (tile_lo + static_cast<uint64_t>(c) > 0) {
+          const int64_t avail = static_cast<int64_t>(tile_lo) + c;
+          const int32_t w1 = static_cast<int32_t>(avail < 16 ? avail : 16), w2 = static_cast<int32_t>(avail < 64 ? avail : 64);
+          entry = fsm_walk(v, m, v.top_off, c - w1, c, (w1 % 4) == 0);
+          if (entry >= v.u_lo && w2 > w1) { entry = fsm_walk(v, m, v.top_off, c - w2, c, (w2 % 4) == 0); st[1]++; }
+          if (entry >= v.u_lo) {
+            st[2]++;
+            if (c < rend && fsm_member(v, entry, 0) == 0xFFFFu) return -16 - 1;
+            entry = cur;
+          } else if (c < rend && fsm_canon(v, entry) != cur) return -3;          // a collapsed set holds the true state
+        }
+        const int32_t cc[1] = {c};
+        FsmTraceS ts[1] = {{entry, 0u, 0u}};
+        fsm_fast_shallow<1>(v, m, cc, ts);
+        const uint64_t k = ((static_cast<uint64_t>(ts[0].k1) << 32) | ts[0].k0) & fsm_valid_bits(rend - c);
+        T[l][2 * sb] = static_cast<uint32_t>(k); T[l][2 * sb + 1] = static_cast<uint32_t>(k >> 32);
+        if (c < rend) {                                                           // the true state behind the sub-chunk (behind the input's end inside it)
+          const int32_t to = c + kFsmSub < rend ? c + kFsmSub : rend;
+          cur = fsm_canon(v, fsm_walk(v, m, entry, c, to, false));
+        }
+        x_end = ts[0].x & ~3u;
+      }
+      if (l == own - 1) tile_entry = cur;
+      if (T[l][0] | T[l][1] | T[l][2] | T[l][3]) { ne |= 1ull << l; if (fsm_first_is_r(T[l])) fr |= 1ull << l; }
+    }
+    if (nact <= own - 1) tile_entry = cur;
+    const uint64_t ln = fsm_lanes_succ_r(ne, fr);
+    if (rend > win_end && ne != 0) {
+      int top = 63;
+      while (!((ne >> top) & 1ull)) top--;
+      if (top < own && fsm_u16(v.tab, x_end + v.ncls2 + 2u) != 0u) return -16 - 8;   // a match pending past the window's end
+    }
+    bool first_in_tile = true;
+    for (int l = 0; l < own && l < nact; l++) {
+      uint32_t Er[4];
+      fsm_lane_ends(T[l], static_cast<uint32_t>(ln >> l) & 1u, Er);
+      for (int i = 0; i < 4; i++) {
+        uint32_t xw = Er[3 - i];
+        while (xw) {
+          uint32_t q = 0;
+          while (!((xw << q) & 0x80000000u)) q++;
+          xw &= ~(0x80000000u >> q);
+          const int32_t e = l * 64 + 16 * i + 1 + static_cast<int32_t>(q >> 1);
+          uint32_t over = 0;
+          const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;
+          const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
+          const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
+          int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+          if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
+            st[3]++;
+            over = 0;
+            s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), -static_cast<int32_t>(tile_lo), over, -static_cast<int32_t>(tile_lo));
+          }
+          if (over) return -16 - 8;
+          if (s == kFsmNoStart) return -2;
+          first_in_tile = false;
+          res.push_back(static_cast<int64_t>(tile_lo) + s);
+          res.push_back(static_cast<int64_t>(tile_lo) + e);
+          prev_end = static_cast<int64_t>(tile_lo) + e;
+        }
+      }
+    }
+  }
+  if (stats) std::memcpy(stats, st, sizeof st);
+  const int64_t n = static_cast<int64_t>(res.size());
+  if (out && n > 0 && n <= cap_vals) std::memcpy(out, res.data(), static_cast<size_t>(n) * sizeof(int64_t));
+  return n;
+}
+
 extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                                     int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
+  // the kernel's SHALLOW instantiation in its own geometry (64-byte lanes, a tail of whole lanes)
+  if (h->depth <= 1 && chunk == kFsmSub && tile % 64 == 0 && budget_bytes % 64 == 0 && budget_bytes > 0 && (tile + budget_bytes) / 64 <= 63)
+    return h->nk > 1 ? emu_fsm_shallow<true>(img, hay, len, out, cap_vals, tile, budget_bytes, stats) : emu_fsm_shallow<false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
   return h->nk > 1 ? emu_fsm<true>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
                    : emu_fsm<false>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
 }
