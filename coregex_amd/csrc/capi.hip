@@ -40,7 +40,7 @@ hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* pe
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream, uint32_t direct_bytes = 0);
 }  // namespace cxgdev
 
 namespace {
@@ -633,6 +633,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool litKernel = false;                                          // ... by its literal mode (round 5)
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // wave kernels: match-dense input seen before
   int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 (very dense)
+  static const bool fsmDirectOk = getenv("CXG_FSM_NO_DIRECT") == nullptr;                     // A/B: the class-indexed kernel for every machine
+  bool fsmDirect = fsmDirectOk && p->fsmNoDirect[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0;   // byte-indexed rows (fsm.hpp "Direct mode") while they serve the input
+  bool fsmDirectRan = false;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
   // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:
@@ -719,7 +722,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
-    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream);
+    fsmDirectRan = fsmDirect && !deepOnly && fh->direct_off != 0u && fh->depth <= 1 && fh->nk == 1 && a.prof == nullptr && a.dbg == 0;
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream, fsmDirectRan ? fh->direct_bytes : 0u);
   }
   else if (gen == 11) {
     std::memcpy(a.chain, p->delim, sizeof p->delim);
@@ -861,7 +865,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : (gen == 10 && fsmDirectRan) ? CXG_K_FSM_DIRECT : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -992,6 +996,13 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   err &= 0x00FFFFFFu;
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
+    if (gen == 10 && fsmDirectRan && ((err >> 8) & ~0x72u) != 0u) {   // direct mode: an entry state that did not collapse, a match pending past the window — the class-indexed kernel has the machinery
+      if (verbose) fprintf(stderr, "[cxg] transducer kernel, direct mode: reason bits 0x%x, rerunning on the class-indexed kernel\n", err >> 8);
+      fsmDirect = false;
+      if ((err >> 8) & 1u) p->fsmNoDirect[submatch ? 1 : 0].store(1, std::memory_order_relaxed);   // (input without synchronising structure: remembered for the program)
+      relaunches++;
+      continue;
+    }
     if (gen == 10 && ((err >> 8) & 0x32u) != 0u && ((err >> 8) & ~0x72u) == 0u && fsmMode < 2) {   // transducer kernel: row / event buffers overflowed
       // (0x40 — a row without a start — beside an overflow bit is a consequence of the dropped rows, not a finding)
       // 0x20 alone: the wave's row list -> mode 1 (2 tiles per wave); a sub-chunk's own buffers (0x02 rows, 0x10 events), or
@@ -1678,6 +1689,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
     case CXG_K_FSM: return "k_scan_fsm";
+    case CXG_K_FSM_DIRECT: return "k_scan_fsmd";
     case CXG_K_TEDDY_TABLE: return "k_scan_teddy";
     case CXG_K_CHARCLASS_TABLE: return "k_scan_charclass";
     default: return "none";

@@ -91,8 +91,15 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t outside_byte;                           // what the positions in front of and behind the haystack read as ('\n' with line anchors, else 0)
   uint32_t rev_text_col;                           // != 0: the pattern holds a text-start anchor (\A, ^): byte offset of the reverse rows' extra column,
                                                    // columns by the kind of the text's first byte, 1 = "accepting if this position is the start of the text"
-  uint32_t pad3[2];
+  // Round 6 — byte-indexed tables of the kernel's DIRECT mode (shallow machines without look-around whose rows fit): see "Direct mode"
+  uint32_t direct_off, direct_bytes;               // section offset from the header (0: none) and its size: d_slots rows of 256 bytes, then u8[256] per slot: 0x80 a set, else pending levels
+  uint32_t d_slots;                                // rows ("slots"); an entry is the slot of the next row
+  uint32_t d_racc_lo, d_rstart;                    // reverse automaton in the same slot space: accepting slots >= d_racc_lo, start slot; slot value 0 = dead
+  uint32_t d_top;                                  // slot of the set "any state"
+  uint32_t d_pad[4];
 };
+constexpr uint32_t kFsmdMaxBytes = 12288u;         // largest direct section the kernel has an instantiation for: beyond it the rows cost a resident workgroup per CU and their
+                                                   // reads collide in the LDS banks (README IPv4 pattern, 20 KiB: 0.71 ms against 0.62 class-indexed — profiles/r06_c2_*)
 
 // Look-around (word boundaries `\b` `\B`, multi-line anchors `(?m)^` `(?m)$`; nfa.Look, nfa/nfa.go:92-117).  An assertion
 // at position p reads the bytes on both sides of p.  The machine stays a plain left-to-right transducer with IMMEDIATE
@@ -286,6 +293,7 @@ CXG_FSM_HD void fsm_step_rec(const FsmView& v, uint32_t cls2, uint32_t bit, FsmT
 // hide behind those of the others).  Class lookups do not depend on the state: those of the NEXT dword are issued
 // before this dword's chain, so a chain step is one LDS read + one add.
 constexpr int kFsmSub = 32;
+constexpr int32_t kFsmNoStart = -0x7FFFFFFF - 1;   // fsm_match_start: the reverse automaton never accepted
 template <int N, class Mem, class Events>
 CXG_FSM_HD void fsm_fast(const FsmView& v, const Mem& m, const int32_t (&c0)[N], FsmTrace (&t)[N], Events* evs) {
   uint32_t kk[N][4], nn[N][4];
@@ -396,6 +404,119 @@ CXG_FSM_HD void fsm_finish_shallow(const FsmView& v, const Mem& m, const FsmTrac
   }
 }
 
+// ---- Direct mode (round 6).  The class-indexed walk costs five instructions per byte: extract the byte, look its class up, v_and_or,
+// table read, flag shift.  With rows indexed by the BYTE (256 one-byte entries, an entry = the slot of the next row) a step is
+//   v_perm_b32  addr = slot << 8 | byte k of the data dword      ds_read_u8  slot = table[addr]      v_alignbit  flags
+// — no class lookup, one LDS read instead of two.  The two event flags live in the low bits of the slot number:
+//   slot 4k      state k                         slot 4k + 1   state k entered by a step that CREATED a match   (a copy of row 4k)
+//   slot 4k + 2  ... that REMATCHED one          any free slot a set of possible states (warm-up rows; d_top = "any state"), the wide row
+// so the warm-up walk and the walk of the chunk are one walk over one table; a 256-byte property table behind the rows says which
+// slots are sets (a chunk entered through one is unresolved) and how many levels a state has pending.  Rows of the reverse
+// automaton sit in free slots too (accepting ones above the others).  Only for machines that fit: <= 64 states, <= 256 slots,
+// kFsmdMaxBytes.  Built by host/fsm.cc behind the minimisation.
+CXG_FSM_HD uint32_t fsmd_addr(uint32_t slot, uint32_t dword, int k) {       // slot << 8 | byte k of dword
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(slot, dword, 0x0C0C0400u | static_cast<uint32_t>(k));
+#else
+  return ((slot & 0xFFu) << 8) | ((dword >> (8 * k)) & 0xFFu);
+#endif
+}
+// Mem concept as below (dword()); Tab: uint32_t at(uint32_t addr) — the kernel's LDS image at address 0, the twin's byte array.
+// N walks of nbytes (a multiple of 4) staged bytes each in lockstep, x in / out: the warm-up in front of a chunk.
+template <int N, class Mem, class Tab>
+CXG_FSM_HD void fsmd_walk_n(const Mem& m, const Tab& tab, const int32_t (&from)[N], int32_t nbytes, uint32_t (&x)[N]) {
+  for (int32_t i = 0; i < nbytes; i += 4) {
+    uint32_t d[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < N; a++) d[a] = m.dword(from[a] + i);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) x[a] = tab.at(fsmd_addr(x[a], d[a], k));
+    }
+  }
+}
+// N chunks of kFsmSub bytes in lockstep from the slots t[a].x; the two flag bits of every step are shifted into k0 / k1 as in
+// fsm_fast_shallow (a slot's low bits ARE its flags).
+template <int N, class Mem, class Tab>
+CXG_FSM_HD void fsmd_chunk(const Mem& m, const Tab& tab, const int32_t (&c0)[N], FsmTraceS (&t)[N]) {
+  uint32_t d[N], dn[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int a = 0; a < N; a++) { d[a] = m.dword(c0[a]); dn[a] = 0u; t[a].k0 = t[a].k1 = 0u; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int q = 0; q < kFsmSub / 4; q++) {
+    if (q + 1 < kFsmSub / 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) dn[a] = m.dword(c0[a] + 4 * (q + 1));
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int a = 0; a < N; a++) {
+        t[a].x = tab.at(fsmd_addr(t[a].x, d[a], k));
+        if (q < 4) t[a].k0 = fsm_shift_in2(t[a].k0, t[a].x); else t[a].k1 = fsm_shift_in2(t[a].k1, t[a].x);
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int a = 0; a < N; a++) d[a] = dn[a];
+  }
+}
+// fsm_match_start over the byte-indexed reverse rows: smallest p >= bound with hay[p, e) in the language, kFsmNoStart when the
+// automaton never accepts; over: still alive at budget_lo with the haystack going on in front of it.
+template <class Mem, class Tab>
+CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, uint32_t rstart, uint32_t racc_lo, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  uint32_t s = rstart;
+  int32_t st = kFsmNoStart, at = e - 1;
+  const int32_t low = bound > budget_lo ? bound : budget_lo;
+  uint32_t b[4], bn[4];                                  // four bytes fetched together (clamped to the window), the next four before this group's chain
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 4; k++) { const int32_t p = at - k; b[k] = m.byte(p > budget_lo ? p : budget_lo); }
+  while (at >= low) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) { const int32_t p = at - 4 - k; bn[k] = m.byte(p > budget_lo ? p : budget_lo); }
+    bool dead = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) {
+      if (dead || at - k < low) break;
+      s = tab.at(fsmd_addr(s, b[k], 0));
+      if (s == 0u) { dead = true; break; }
+      if (s >= racc_lo) st = at - k;
+    }
+    if (dead) return st;
+    at = at - 4 >= low - 1 ? at - 4 : low - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) b[k] = bn[k];
+  }
+  if (at >= bound) over = 1u;
+  return st;
+}
+
 // ---- Round 6: rows of a SHALLOW machine from the event bits alone (no walk past the chunk, no per-lane row buffers).
 // The steps of a tile are one stream of events, two bits per byte (bit 2p the step over byte p created a match, bit
 // 2p + 1 it rematched one).  With at most one pending match a rematch always extends the match of the event in front of
@@ -503,42 +624,45 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
 // DFA without break-at-match (meta/compile.go:193-194), walked from e - 1 downwards (lazy.go:1769-1920).  lowest:
 // first position that exists.  Returns kFsmNoStart when the reverse DFA never accepts (cannot happen for a real match);
 // positions are relative to the tile origin and may be negative.
-constexpr int32_t kFsmNoStart = -0x7FFFFFFF - 1;
 template <class Mem>
 CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over, int32_t text_pos = kFsmNoStart) {
   uint32_t s = m.rstart(v, e);
   int32_t st = kFsmNoStart;
   int32_t at = e - 1;
-  // Four steps at a time while four bytes are available: the byte reads and the class lookups of a group do not depend
-  // on the automaton's state and are issued together, so the dependent chain per step is ONE table read instead of
-  // three (byte -> class -> row).  This walk runs once per row with a single chain per lane: it is latency, not issue, that
-  // it costs (0.27 of 0.78 ms/GiB on the README IP pattern before).
+  // Four steps at a time: the byte reads and the class lookups of a group do not depend on the automaton's state and are
+  // issued together — and those of the NEXT group before this group's chain (round 6) — so the dependent chain per step is
+  // ONE table read instead of three (byte -> class -> row).  Positions below the walk's lower end are read clamped (they lie
+  // in the window, their classes are not used): short walks between dense rows (`\b\d+\b`: the previous row ends a few
+  // bytes below) take the same path instead of a byte-by-byte loop of three dependent reads per step.
   const int32_t low = bound > budget_lo ? bound : budget_lo;
-  while (at - 3 >= low) {
-    uint32_t c[4];
+  uint32_t c[4], cn[4];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 4; k++) c[k] = m.rcls(v, at - k);
+  for (int k = 0; k < 4; k++) { const int32_t p = at - k; c[k] = m.rcls(v, p > budget_lo ? p : budget_lo); }
+  while (at >= low) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) { const int32_t p = at - 4 - k; cn[k] = m.rcls(v, p > budget_lo ? p : budget_lo); }
     bool dead = false;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < 4; k++) {
-      if (dead) break;
+      if (dead || at - k < low) break;
       s = fsm_u16(v.rev, s + c[k]);
       if (s == 0u) { dead = true; break; }
       if (s >= v.rev_accept_off) st = at - k;
     }
     if (dead) return st;
-    at -= 4;
+    at = at - 4 >= low - 1 ? at - 4 : low - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; k++) c[k] = cn[k];
   }
-  for (; at >= bound; at--) {
-    if (at < budget_lo) { over = 1u; break; }
-    s = fsm_u16(v.rev, s + m.rcls(v, at));
-    if (s == 0u) break;
-    if (s >= v.rev_accept_off) st = at;
-  }
+  if (at >= bound) over = 1u;                           // stopped at the window's first byte with the haystack going on in front of it
   // text_pos: where the text starts, relative to `m` (kFsmNoStart: not within reach).  A walk that stepped over the text's first
   // byte alive stands there: a text-start anchor of the pattern (\A, ^) holds now and nowhere else — the state says whether that
   // makes the position a match start (host/fsm.cc).

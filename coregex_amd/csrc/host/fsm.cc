@@ -503,6 +503,87 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   h.total_bytes = static_cast<uint32_t>(img.size());
   h.lds_bytes = h.total_bytes - static_cast<uint32_t>(sizeof h);
   if (h.lds_bytes > 28672) { why = "FindAll transducer image exceeds the LDS budget"; return false; }
+  // ---- Round 6: the byte-indexed tables of the kernel's direct mode (fsm.hpp "Direct mode"), behind the image it replaces in LDS
+  static const bool noDirect = getenv("CXG_FSM_NO_DIRECT") != nullptr;   // A/B
+  if (!noDirect && depth <= 1 && !hasLook && nT <= 64 && rev.nstates >= 2) {
+    // the reverse automaton, minimised (Moore over dead / accepting / other; the README IPv4 pattern: 37 -> 25 states)
+    const uint32_t rn = rev.nstates;
+    std::vector<uint32_t> rpart(rn);
+    for (uint32_t s = 0; s < rn; s++) rpart[s] = s == 0 ? 0u : (s >= rev.firstAccept ? 2u : 1u);
+    for (size_t nb = 0;;) {
+      std::map<std::vector<uint32_t>, uint32_t> sig;
+      std::vector<uint32_t> next(rn);
+      for (uint32_t s = 0; s < rn; s++) {
+        std::vector<uint32_t> k(1 + nbc);
+        k[0] = rpart[s];
+        for (uint32_t c = 0; c < nbc; c++) k[1 + c] = rpart[rev.table[static_cast<size_t>(s) * 256 + reps[c]]];
+        next[s] = sig.emplace(std::move(k), static_cast<uint32_t>(sig.size())).first->second;   // state 0 (dead) keeps block 0
+      }
+      rpart.swap(next);
+      if (sig.size() == nb) break;
+      nb = sig.size();
+    }
+    uint32_t rblocks = 0;
+    for (uint32_t s = 0; s < rn; s++) rblocks = std::max(rblocks, rpart[s] + 1);
+    std::vector<uint32_t> rrep(rblocks, 0xFFFFFFFFu);
+    for (uint32_t s = 0; s < rn; s++) if (rrep[rpart[s]] == 0xFFFFFFFFu) rrep[rpart[s]] = s;
+    // slots: state k at 4k, its create / rematch copies at 4k + 1 / 4k + 2 where some step enters them; everything else is free for the
+    // reverse rows (accepting ones above the others) and the sets of possible entry states
+    std::vector<int> used(256, 0);
+    auto slotOfTrans = [&](uint32_t t) -> uint32_t {
+      const uint32_t kind = (t >> 16) & 3u, to = t & 0xFFFFu;
+      return 4u * to + (kind == cxgdev::kFsmEvCreate ? 1u : (kind == cxgdev::kFsmEvRematch ? 2u : 0u));
+    };
+    for (uint32_t s = 0; s < nT; s++) { used[4 * s] = 1; for (uint32_t c = 0; c < ncls; c++) used[slotOfTrans(trans[s][c])] = 1; }
+    const std::vector<int> fwdUsed = used;
+    std::vector<uint32_t> rslot(rblocks, 0u), uslot(nU + 1, 0u);
+    uint32_t nslots = 4u * nT, cursor = 1;
+    bool fits = true;
+    auto takeFree = [&](uint32_t from) -> uint32_t { uint32_t q = from; while (q < 256 && used[q]) q++; return q; };
+    for (int pass = 0; pass < 2 && fits; pass++)                   // block 0 = dead has no row: slot value 0
+      for (uint32_t b = 1; b < rblocks && fits; b++) {
+        const bool acc = rrep[b] >= rev.firstAccept;
+        if (acc != (pass == 1)) continue;
+        const uint32_t q = takeFree(cursor);
+        if (q >= 256) { fits = false; break; }
+        used[q] = 1; rslot[b] = q; cursor = q + 1;               // ascending: every accepting slot lies above every other reverse slot
+        nslots = std::max(nslots, q + 1);
+      }
+    for (uint32_t u = 0; u <= nU && fits; u++) {                  // (u == nU: the wide row)
+      const uint32_t q = takeFree(1);
+      if (q >= 256) { fits = false; break; }
+      used[q] = 1; uslot[u] = q;
+      nslots = std::max(nslots, q + 1);
+    }
+    uint32_t raccLo = 256;
+    for (uint32_t b = 1; b < rblocks; b++) if (rrep[b] >= rev.firstAccept) raccLo = std::min(raccLo, rslot[b]);
+    const uint32_t dbytes = nslots * 256u + 256u;
+    if (fits && raccLo < 256 && rpart[rev.start] != 0 && dbytes <= cxgdev::kFsmdMaxBytes) {
+      std::vector<uint8_t> d(dbytes, 0);
+      uint8_t* prop = d.data() + static_cast<size_t>(nslots) * 256;   // per slot: 0x80 a set (or the wide row), else the pending levels of the state
+      for (uint32_t s = 0; s < nT; s++)
+        for (uint32_t f = 0; f < 3; f++) {
+          if (!fwdUsed[4 * s + f]) continue;                       // (a create / rematch copy nobody enters is a free slot)
+          for (int b = 0; b < 256; b++) d[static_cast<size_t>(4 * s + f) * 256 + b] = static_cast<uint8_t>(slotOfTrans(trans[s][cls[b]]));
+          prop[4 * s + f] = levels[s];
+        }
+      for (uint32_t u = 0; u < nU; u++) {
+        for (int b = 0; b < 256; b++) {
+          const uint16_t t = utrans[u][cls[b]];
+          d[static_cast<size_t>(uslot[u]) * 256 + b] = static_cast<uint8_t>(t == kWideMark ? uslot[nU] : (t >= kSetBase ? uslot[t - kSetBase] : 4u * t));
+        }
+        prop[uslot[u]] = 0x80;
+      }
+      for (int b = 0; b < 256; b++) d[static_cast<size_t>(uslot[nU]) * 256 + b] = static_cast<uint8_t>(uslot[nU]);
+      prop[uslot[nU]] = 0x80;
+      for (uint32_t b = 1; b < rblocks; b++)
+        for (int x = 0; x < 256; x++) d[static_cast<size_t>(rslot[b]) * 256 + x] = static_cast<uint8_t>(rslot[rpart[rev.table[static_cast<size_t>(rrep[b]) * 256 + x]]]);
+      put(d.data(), d.size(), h.direct_off);
+      h.direct_bytes = dbytes; h.d_slots = nslots; h.d_racc_lo = raccLo; h.d_rstart = rslot[rpart[rev.start]]; h.d_top = uslot[0];
+      while (img.size() % 16) img.push_back(0);
+      h.total_bytes = static_cast<uint32_t>(img.size());           // (lds_bytes stays the class-indexed image's: the two are staged alternatively)
+    }
+  }
   std::memcpy(img.data(), &h, sizeof h);
   image.swap(img);
   return true;

@@ -37,6 +37,7 @@ def main(n=300, seed=1, look=False, wide=False):
     n_strat = 0
     seen, n_img, n_checked, reasons = set(), 0, 0, {}
     n_caps = 0
+    n_direct = 0
     t0 = time.time()
     while len(seen) < n:
         pat = "".join(atoms[int(rng.integers(0, len(atoms)))] for _ in range(int(rng.integers(*LEN_RANGE))))
@@ -88,6 +89,22 @@ def main(n=300, seed=1, look=False, wide=False):
                             np.save("/tmp/fsm_fail_hay.npy", hay)
                             print("EMU ERROR (dense)", ex, repr(pat), which, tile, chunk)
                             return 1
+                    if chunk == 32:                                      # round 6: the same rows through the byte-indexed tables (k_scan_fsmd's twin)
+                        try:
+                            gd = emu.find_all_fsm_direct(image, hay, tile)
+                        except AssertionError as ex:
+                            np.save("/tmp/fsm_fail_hay.npy", hay)
+                            print("EMU ERROR (direct)", ex, repr(pat), rx.strategy, which, tile, bytes(hay[:120]))
+                            return 1
+                        if gd is not None:
+                            n_direct += 1
+                            if isinstance(gd, int): reasons[("direct", gd)] = reasons.get(("direct", gd), 0) + 1
+                            else:
+                                gd2 = emu.merge_empty_matches(gd, len(hay)) if (which == "idx" and rx.nullable) else gd
+                                if gd2.shape != exp.shape or not np.array_equal(gd2, exp):
+                                    np.save("/tmp/fsm_fail_hay.npy", hay)
+                                    print("MISMATCH (direct)", repr(pat), rx.strategy, which, tile, bytes(hay[:120]), gd2[:6].tolist(), exp[:6].tolist())
+                                    return 1
                     if isinstance(got, int):
                         reasons[got] = reasons.get(got, 0) + 1
                         continue
@@ -114,7 +131,7 @@ def main(n=300, seed=1, look=False, wide=False):
                             return 1
     if look: print(f"{n_strat} strategies compared with the oracle")
     if look: print(f"{n_caps} capture-row comparisons (backtracking pass with assertions) clean")
-    print(f"{len(seen)} patterns, {n_img} with a transducer image, {n_checked} comparisons clean, fallback reasons {reasons}, {time.time()-t0:.1f}s")
+    print(f"{len(seen)} patterns, {n_img} with a transducer image, {n_checked} comparisons clean ({n_direct} more through the direct tables), fallback reasons {reasons}, {time.time()-t0:.1f}s")
     return 0
 
 if __name__ == "__main__":

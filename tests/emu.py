@@ -43,6 +43,8 @@ def lib():
         L.emu_trio_shape.argtypes = [C.c_char_p]
         L.emu_fsm_maps_check.restype = C.c_int64
         L.emu_fsm_maps_check.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+        L.emu_find_all_fsm_direct.restype = C.c_int64
+        L.emu_find_all_fsm_direct.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.emu_find_all_fsm.restype = C.c_int64
         L.emu_find_all_fsm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.emu_find_all_submatch.restype = C.c_int64
@@ -164,6 +166,28 @@ def find_all_teddy_wave(blob: bytes, hay, tile: int = 3840, halo: int = 256):
 def find_all_charclass_wave(blob: bytes, hay, tile: int = 3840, halo: int = 256):
     """scan_charclass_wave.hip, emulated; the int reason (< 0) when a tile would raise the fallback flag."""
     return _wave_twin("emu_find_all_charclass_wave", blob, hay, tile, halo)
+
+
+def find_all_fsm_direct(image: bytes, hay, tile: int = 3840, budget: int = 192, stats=None):
+    """scan_fsm.hip k_scan_fsmd (round 6: the transducer through byte-indexed rows), emulated; None when the image has no direct
+    section, the int reason (< 0) when a tile would raise the fallback flag."""
+    a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
+    padded = np.concatenate([np.zeros(8, dtype=np.uint8), a, np.zeros(8, dtype=np.uint8)])
+    cap = 1 << 12
+    st = np.zeros(4, dtype=np.uint64)
+    while True:
+        out = np.empty(cap, dtype=np.int64)
+        n = lib().emu_find_all_fsm_direct(image, padded.ctypes.data + 8, a.size, out.ctypes.data, cap, tile, budget, st.ctypes.data)
+        if n == -1:
+            return None
+        if n <= -16:
+            return int(n)
+        assert n >= 0, f"emulator error {n}"
+        if n <= cap:
+            if stats is not None:
+                stats[:] = st
+            return out[:n].reshape(-1, 2).copy()
+        cap = int(n)
 
 
 def find_all_fsm(image: bytes, hay, tile: int = 3840, chunk: int = 32, budget: int = 192, stats=None, dense: int = 0):

@@ -146,11 +146,18 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
 // kFsmSub; `tile / 64` owned lanes, then `budget_bytes / 64` tail lanes that only contribute their event bits; rows = the events of
 // the owned lanes that no rematch follows, through the very functions the kernel calls (fsm_fast_shallow, fsm_first_is_r,
 // fsm_lanes_succ_r, fsm_lane_ends).  Entry states by the kernel's policy (16 bytes of warm-up, then 64, then the true state).
-template <bool LOOK>
+struct HostTab {                                          // the direct section: rows of 256 bytes, then the property table
+  const uint8_t* d;
+  uint32_t at(uint32_t addr) const { return d[addr]; }
+};
+template <bool LOOK, bool DIRECT>
 static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                                int tile, int budget_bytes, uint64_t* stats) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   const FsmView v = view_of(img);
+  HostTab tab;
+  tab.d = img + h->direct_off;
+  const uint32_t prop = h->d_slots << 8;
   std::vector<int64_t> res;
   const int own = tile / 64, tail = budget_bytes / 64;
   const uint64_t ntiles = (len + static_cast<uint64_t>(tile) - 1) / static_cast<uint64_t>(tile);
@@ -176,8 +183,37 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
       nact = l + 1;
       for (int sb = 0; sb < 2; sb++) {
         const int32_t c = c0 + sb * kFsmSub;
-        uint32_t entry = m.origin(v);
         if (c < rend) st[0]++;
+        const int32_t cc[1] = {c};
+        FsmTraceS ts[1] = {{0u, 0u, 0u}};
+        uint32_t entry = 0;
+        if (DIRECT) {
+          // k_scan_fsmd: 16 bytes from "any state", 64 when the set has not collapsed, then the host's rerun (reason 1)
+          const bool origin = tile_lo + static_cast<uint64_t>(c) == 0, from_start = tile_lo + static_cast<uint64_t>(c) == static_cast<uint64_t>(kFsmSub);
+          uint32_t e[1] = {h->d_top};
+          const int32_t f16[1] = {c - 16};
+          fsmd_walk_n<1>(m, tab, f16, 16, e);
+          if (origin) e[0] = 0u;
+          if (tab.at(prop + e[0]) & 0x80u) {
+            st[1]++;
+            const int32_t f64[1] = {from_start ? 0 : c - 64};
+            e[0] = from_start ? 0u : h->d_top;
+            fsmd_walk_n<1>(m, tab, f64, c - f64[0], e);
+            if (tab.at(prop + e[0]) & 0x80u) { st[2]++; if (c < rend) return -16 - 1; }
+          }
+          entry = e[0];
+          ts[0].x = entry;
+          fsmd_chunk<1>(m, tab, cc, ts);
+          if (c < rend) {
+            const int32_t to = c + kFsmSub < rend ? c + kFsmSub : rend;
+            uint32_t xx = entry & ~3u;
+            for (int32_t i = c; i < to; i++) xx = tab.at(fsmd_addr(xx, m.byte(i), 0));
+            if ((entry & ~3u) != cur * 4u) return -3;                             // the entry the warm-up found is the true state
+            cur = xx >> 2;
+          }
+          x_end = ts[0].x;
+        } else {
+        entry = m.origin(v);
         if (tile_lo + static_cast<uint64_t>(c) > 0) {
           const int64_t avail = static_cast<int64_t>(tile_lo) + c;
           const int32_t w1 = static_cast<int32_t>(avail < 16 ? avail : 16), w2 = static_cast<int32_t>(avail < 64 ? avail : 64);
@@ -189,16 +225,16 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
             entry = cur;
           } else if (c < rend && fsm_canon(v, entry) != cur) return -3;          // a collapsed set holds the true state
         }
-        const int32_t cc[1] = {c};
-        FsmTraceS ts[1] = {{entry, 0u, 0u}};
+        ts[0].x = entry;
         fsm_fast_shallow<1>(v, m, cc, ts);
-        const uint64_t k = ((static_cast<uint64_t>(ts[0].k1) << 32) | ts[0].k0) & fsm_valid_bits(rend - c);
-        T[l][2 * sb] = static_cast<uint32_t>(k); T[l][2 * sb + 1] = static_cast<uint32_t>(k >> 32);
         if (c < rend) {                                                           // the true state behind the sub-chunk (behind the input's end inside it)
           const int32_t to = c + kFsmSub < rend ? c + kFsmSub : rend;
           cur = fsm_canon(v, fsm_walk(v, m, entry, c, to, false));
         }
         x_end = ts[0].x & ~3u;
+        }
+        const uint64_t k = ((static_cast<uint64_t>(ts[0].k1) << 32) | ts[0].k0) & fsm_valid_bits(rend - c);
+        T[l][2 * sb] = static_cast<uint32_t>(k); T[l][2 * sb + 1] = static_cast<uint32_t>(k >> 32);
       }
       if (l == own - 1) tile_entry = cur;
       if (T[l][0] | T[l][1] | T[l][2] | T[l][3]) { ne |= 1ull << l; if (fsm_first_is_r(T[l])) fr |= 1ull << l; }
@@ -208,7 +244,7 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
     if (rend > win_end && ne != 0) {
       int top = 63;
       while (!((ne >> top) & 1ull)) top--;
-      if (top < own && fsm_u16(v.tab, x_end + v.ncls2 + 2u) != 0u) return -16 - 8;   // a match pending past the window's end
+      if (top < own && (DIRECT ? (tab.at(prop + x_end) & 0x7Fu) : fsm_u16(v.tab, x_end + v.ncls2 + 2u)) != 0u) return -16 - 8;   // a match pending past the window's end
     }
     bool first_in_tile = true;
     for (int l = 0; l < own && l < nact; l++) {
@@ -225,11 +261,14 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
           const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;
           const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
           const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
-          int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+          int32_t s = DIRECT ? fsmd_match_start(m, tab, h->d_rstart, h->d_racc_lo, e, bound, lowest, over)
+                             : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
             st[3]++;
             over = 0;
-            s = fsm_match_start(v, m, e, static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo)), -static_cast<int32_t>(tile_lo), over, -static_cast<int32_t>(tile_lo));
+            const int32_t pb = static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
+            s = DIRECT ? fsmd_match_start(m, tab, h->d_rstart, h->d_racc_lo, e, pb, -static_cast<int32_t>(tile_lo), over)
+                       : fsm_match_start(v, m, e, pb, -static_cast<int32_t>(tile_lo), over, -static_cast<int32_t>(tile_lo));
           }
           if (over) return -16 - 8;
           if (s == kFsmNoStart) return -2;
@@ -247,13 +286,21 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
   return n;
 }
 
+// k_scan_fsmd (direct mode) in the kernel's geometry; -1: the image has no direct section
+extern "C" int64_t emu_find_all_fsm_direct(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
+                                           int tile, int budget_bytes, uint64_t* stats) {
+  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
+  if (h->magic != kFsmMagic || h->direct_off == 0u || h->depth > 1 || h->nk != 1 || tile % 64 != 0 || budget_bytes % 64 != 0 || budget_bytes <= 0 || (tile + budget_bytes) / 64 > 63) return -1;
+  return emu_fsm_shallow<false, true>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
+}
+
 extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                                     int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
   // the kernel's SHALLOW instantiation in its own geometry (64-byte lanes, a tail of whole lanes)
   if (h->depth <= 1 && chunk == kFsmSub && tile % 64 == 0 && budget_bytes % 64 == 0 && budget_bytes > 0 && (tile + budget_bytes) / 64 <= 63)
-    return h->nk > 1 ? emu_fsm_shallow<true>(img, hay, len, out, cap_vals, tile, budget_bytes, stats) : emu_fsm_shallow<false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
+    return h->nk > 1 ? emu_fsm_shallow<true, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats) : emu_fsm_shallow<false, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
   return h->nk > 1 ? emu_fsm<true>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
                    : emu_fsm<false>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
 }

@@ -43,6 +43,12 @@ def _check(oracle, pat, hays, look):
                 continue
             assert got.shape == exp.shape and np.array_equal(got, exp), (pat, tile, chunk, len(hay))
             n_ok += 1
+            if chunk == 32:                                          # round 6: the same rows through the byte-indexed tables (k_scan_fsmd's twin)
+                gd = emu.find_all_fsm_direct(img, hay, tile)
+                if gd is not None and not isinstance(gd, int):
+                    assert gd.shape == exp.shape and np.array_equal(gd, exp), (pat, tile, "direct", len(hay))
+                elif gd is not None:
+                    assert gd in (-17, -24), (pat, tile, "direct", gd)
     assert n_ok >= len(hays), (pat, n_ok)                               # most geometries must actually answer
 
 
@@ -261,3 +267,18 @@ def test_map_compositions_give_the_true_entry_states(pat):
             assert r >= 0, (pat, bytes(unit), n, tile, tpg, r)
             checked += r
     assert checked > 10000 or unlisted > 0, (checked, unlisted)
+
+
+def test_direct_tables_exist_for_the_benchmark_patterns():
+    """Round 6: shallow machines without look-around carry the byte-indexed section (fsm.hpp "Direct mode") when it fits; the README
+    IPv4 pattern's 95 explored stacks minimise to 20 states (host/fsm.cc), which is what makes its section fit."""
+    import struct
+    for pat, want in ((GENERAL[-1], True), (r"\d+\.\d+x?", True), (r"a+b|b+a", True), (r"\b\d+\b", False)):
+        img = cx.compile(pat).fsm_image()
+        n_t, depth, nk = struct.unpack_from("<I", img, 4)[0], struct.unpack_from("<I", img, 28)[0], struct.unpack_from("<I", img, 92)[0]
+        direct_off, direct_bytes, d_slots = struct.unpack_from("<III", img, 120)
+        assert (direct_off != 0) == want, (pat, direct_off)
+        if want:
+            assert depth <= 1 and nk == 1 and n_t <= 64 and direct_bytes == d_slots * 256 + 256 and direct_bytes <= 12288, (pat, n_t, direct_bytes)
+    readme = r"(?:(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)\.){3}(?:25[0-5]|2[0-4][0-9]|[01]?[0-9][0-9]?)"
+    assert struct.unpack_from("<I", cx.compile(readme).fsm_image(), 4)[0] == 20

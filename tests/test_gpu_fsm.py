@@ -9,7 +9,7 @@ from refcorpus import COMPAT_PATTERNS, generate_test_input
 
 pytestmark = pytest.mark.gpu
 
-K_FSM = 10
+K_FSM = (10, 19)   # CXG_K_FSM, CXG_K_FSM_DIRECT (round 6: the same machine through byte-indexed rows)
 
 
 @pytest.fixture(autouse=True)
@@ -62,7 +62,7 @@ def test_general_dfas_run_on_the_transducer_kernel(oracle, pat):
     # than a chunk's row / event buffers on this corpus (every number or every 'a' of a log line is too dense: those
     # hand over to the table-walking kernel — same rows, checked above)
     if pat in FSM_EXPECTED:
-        assert routed(t.kernel == K_FSM and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
+        assert routed(t.kernel in K_FSM and t.n_launches == 1, t.kernel, t.n_launches, t.fallback_reason), (pat, t.kernel, t.n_launches, t.fallback_reason)
 
 
 def test_transducer_kernel_edges(oracle):
@@ -81,7 +81,7 @@ def test_transducer_kernel_edges(oracle):
         exp = o.find_all_index(hay)
         assert np.array_equal(rx.find_all_index(hay), exp), off
         rows, t = _device_rows(rx, hay)
-        assert np.array_equal(rows, exp) and routed(t.kernel == K_FSM, t.kernel), off
+        assert np.array_equal(rows, exp) and routed(t.kernel in K_FSM, t.kernel), off
     for n in (1, 63, 64, 65, 3839, 3840, 3841, 4095, 4096, 4097, group - 1, group, group + 1):
         rep = (b"a12b a. ab x" * (n // 12 + 2))[:n]
         assert np.array_equal(rx.find_all_index(rep), o.find_all_index(rep)), n
@@ -99,7 +99,7 @@ def test_transducer_kernel_edges(oracle):
         exp = o2.find_all_index(hay)
         assert len(exp) == 2 and exp[1][0] == exp[0][1]
         rows, t = _device_rows(rx2, hay)
-        assert np.array_equal(rows, exp) and routed(t.kernel == K_FSM, t.kernel), (off, rows.tolist(), exp.tolist())
+        assert np.array_equal(rows, exp) and routed(t.kernel in K_FSM, t.kernel), (off, rows.tolist(), exp.tolist())
     # matches longer than the 64 bytes staged in front of a tile / the 192 bytes behind it: the start is finished in the
     # epilogue from HBM, a walk past the window's end hands the scan over — the oracle's rows either way
     long1 = np.frombuffer(b"a" + b"7" * 150 + b"b", dtype=np.uint8)
@@ -149,7 +149,7 @@ def test_input_without_synchronising_structure(oracle, pat, unit):
     rows, t = _device_rows(rx, hay)
     exp = o.find_all_index(hay)
     assert rows.shape == exp.shape and np.array_equal(rows, exp), (t.kernel, t.n_launches, t.fallback_reason)
-    assert routed(t.kernel == K_FSM, t.kernel)
+    assert routed(t.kernel in K_FSM, t.kernel)
 
 
 # ---- word boundaries (\b \B): UseNFA in the reference (PikeVM, nfa/pikevm.go:1646-1674), the transducer kernel here with
@@ -174,7 +174,7 @@ def test_word_boundary_programs(oracle, pat):
         assert rx.count(hay) == len(exp)
     rows, t = _device_rows(rx, hays[1])
     assert np.array_equal(rows, o.find_all_index(hays[1]))
-    assert routed(t.kernel == K_FSM, t.kernel), (pat, t.kernel)
+    assert routed(t.kernel in K_FSM, t.kernel), (pat, t.kernel)
 
 
 # ---- assertions inside the reference's lazy-DFA strategies: served when host/lookdfa.cc proves that the reference's look-aware
@@ -198,7 +198,7 @@ def test_look_programs_of_lazy_dfa_strategies(oracle, pat, strategy):
         assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay))
         assert rx.count(hay) == len(exp)
     rows, t = _device_rows(rx, hays[2])
-    assert np.array_equal(rows, o.find_all_index(hays[2])) and routed(t.kernel == K_FSM, t.kernel), (pat, t.kernel)
+    assert np.array_equal(rows, o.find_all_index(hays[2])) and routed(t.kernel in K_FSM, t.kernel), (pat, t.kernel)
     assert not cx.compile(r"\b(DEBUG|INFO|WARN|ERROR)\b").supported          # byte class mixes word and non-word bytes: history-dependent reference
 
 
@@ -218,7 +218,7 @@ def test_word_boundary_edges(oracle):
                 hay[off:off + len(a)] = a
                 exp = o.find_all_index(hay)
                 rows, t = _device_rows(rx, hay)
-                assert np.array_equal(rows, exp) and routed(t.kernel == K_FSM, t.kernel), (pat, off, lit, rows.tolist(), exp.tolist())
+                assert np.array_equal(rows, exp) and routed(t.kernel in K_FSM, t.kernel), (pat, off, lit, rows.tolist(), exp.tolist())
         for n in (1, 5, 6, 31, 32, 33, 63, 64, 65, 3839, 3840, 3841, 4031, 4032, 4033, 4095, 4096, 4097, group - 1, group, group + 1):
             for tail in (b"error", b"xerror", b" error", b"errorx"):
                 hay = np.full(n, ord(" "), dtype=np.uint8)
@@ -254,7 +254,7 @@ def test_word_boundary_long_words_and_budgets(oracle):
     # tile to tile (its start then comes from HBM in the epilogue) — served, where rounds 2-5 ran out of their walk budget
     assert np.array_equal(rx2.find_all_index(hay), o2.find_all_index(hay))
     # what still is a budget: a match that stays PENDING without events past the window's end (`!` may still come: threads alive, nothing to report)
-    rx3, o3 = cx.compile(r"\berror(?:[a-z]*!)?"), oracle.Regex(r"\berror(?:[a-z]*!)?")
+    rx3, o3 = cx.compile(r"\berror(?:z*!)?"), oracle.Regex(r"\berror(?:z*!)?")
     assert np.array_equal(rx3.find_all_index(hay[:165]), o3.find_all_index(hay[:165]))
     with pytest.raises(cx.CoregexError) as ei:
         rx3.find_all_index(hay)
@@ -296,7 +296,7 @@ def test_multiline_anchor_programs(oracle, pat):
         assert got.shape == exp.shape and np.array_equal(got, exp), (pat, len(hay), hay[:40])
         assert rx.count(hay) == len(exp)
     rows, t = _device_rows(rx, hays[1])
-    assert np.array_equal(rows, o.find_all_index(hays[1])) and routed(t.kernel == K_FSM, t.kernel)
+    assert np.array_equal(rows, o.find_all_index(hays[1])) and routed(t.kernel in K_FSM, t.kernel)
 
 
 def test_multiline_anchor_edges(oracle):
@@ -314,7 +314,7 @@ def test_multiline_anchor_edges(oracle):
                 hay[off:off + len(a)] = a
                 exp = o.find_all_index(hay)
                 rows, t = _device_rows(rx, hay)
-                assert np.array_equal(rows, exp) and routed(t.kernel == K_FSM, t.kernel), (pat, off, lit, rows.tolist(), exp.tolist())
+                assert np.array_equal(rows, exp) and routed(t.kernel in K_FSM, t.kernel), (pat, off, lit, rows.tolist(), exp.tolist())
         for n in (1, 4, 5, 6, 31, 32, 33, 63, 64, 65, 3839, 3840, 3841, 4031, 4032, 4033, 4095, 4096, 4097, group - 1, group, group + 1):
             for tail in (b"line", b"\nline", b"error", b" error", b"\nerror"):
                 hay = np.full(n, ord(" "), dtype=np.uint8)
