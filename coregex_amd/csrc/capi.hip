@@ -136,6 +136,7 @@ struct Scratch {
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
   uint8_t* bt = nullptr; size_t btCap = 0;         // k_captures_bt: per-thread visited bitmap + stack
   uint32_t* pfStatus = nullptr; uint64_t pfCap = 0; uint32_t pfEpoch = 0;   // k_scan_fields_pers: one word per unit, own 16-bit launch epoch
+  uint32_t* pfTickets = nullptr;   // ... [32][64] ticket counters a cache line apart, one block per launch epoch (scan_fields_wave.hip, round 6)
   uint64_t* pfRec = nullptr; uint64_t pfRecRounds = 0;   // ... 128 records of 16 bytes per round, tagged with the same epoch
   uint64_t* pfStats = nullptr;                           // ... per wave: units that waited, polls (CXG_VERBOSE)
   int64_t* offSpans = nullptr; uint64_t offSpansCap = 0;  // offset captures (scanOffsetCaps): the spans in front of the expansion kernel
@@ -172,6 +173,7 @@ struct Scratch {
       if (fsmMaps) (void)hipFree(fsmMaps);
       if (pfStatus) (void)hipFree(pfStatus);
       if (pfRec) (void)hipFree(pfRec);
+      if (pfTickets) (void)hipFree(pfTickets);
       if (pfStats) (void)hipFree(pfStats);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
@@ -541,7 +543,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool fsmTried = false;
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
-  a.pf_status = nullptr;                                           // (set per launch by the fields programs' branch below)
+  a.pf_status = nullptr; a.pf_ticket = nullptr; a.pf_ncounters = 0;   // (set per launch by the fields programs' branch below)
   std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
   a.cc_nr = a.cc_neg = a.cc_pairs = 0; std::memset(a.cc_lo, 0, 4); std::memset(a.cc_hi, 0, 4);
   a.u32_rows = t_u32Rows ? 1u : 0u;
@@ -788,7 +790,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     // (the early stop lives in the grouped kernel's look-back), the phase profile is on, or a watchdog ever fired
     static const bool persOk = getenv("CXG_NO_PERSIST") == nullptr;
     a.pf_status = nullptr; a.pf_cap = 0; a.pf_epoch = 0; a.pf_full = a.pf_tpw_last = a.pf_units_last = 0;
-    a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr;
+    a.pf_rec = nullptr; a.pf_rec_rounds = 0; a.pf_stats = nullptr; a.pf_ticket = nullptr; a.pf_ncounters = 0;
     // (TRIO mode: built and measured in round 5 — config 5 0.438 ms against 0.395 on the grouped kernel, `(\d+)\.(\d+)\.(\d+)\.(\d+)` 0.57
     // against 0.44: that mathematics is VALU- and LDS-bound and the persistent instantiation holds half the waves — so off unless asked for)
     static const bool trioPers = getenv("CXG_TRIO_PERS") != nullptr;
@@ -797,7 +799,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     if (persWanted) {
       const uint64_t nwt = (len + cxgdev::kWaveTile - 1) / cxgdev::kWaveTile;
       const uint64_t need = nwt / 4u + 2u * 8192u + 64u;                                       // (full rounds + 1) x W unit words, W <= 8192 waves
-      const uint64_t rneed = nwt / (4u * 1024u) + 2u;                                          // rounds: >= 1024 waves on a long haystack
+      const uint64_t rneed = nwt / (4u * 1024u) + 8u;                                          // rounds: >= 1024 waves on a long haystack (+ the tail's small units)
       bool fresh = false;
       if (need > s.pfCap) {
         if (s.pfStatus) HIP_TRY(hipFree(s.pfStatus));
@@ -813,14 +815,16 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfRec), c * cxgdev::kPfRecStride * 8u));
         s.pfRecRounds = c; fresh = true;
       }
-      if (fresh || s.pfEpoch >= 0xFFFFu) {                                                     // both arrays carry the same epoch
+      if (!s.pfTickets) { HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfTickets), 32 * 64 * cxgdev::kPfCtrStride * sizeof(uint32_t))); fresh = true; }
+      if (fresh || s.pfEpoch >= 0xFFFFu) {                                                     // all three arrays carry the same epoch
+        HIP_TRY(hipMemsetAsync(s.pfTickets, 0, 32 * 64 * cxgdev::kPfCtrStride * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(s.pfStatus, 0, s.pfCap * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(s.pfRec, 0, s.pfRecRounds * cxgdev::kPfRecStride * 8u, stream));
         s.pfEpoch = 0;
       }
       if (!s.pfStats) { HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pfStats), 4 * 8192 * sizeof(uint64_t))); HIP_TRY(hipMemsetAsync(s.pfStats, 0, 4 * 8192 * sizeof(uint64_t), stream)); }
       a.pf_status = s.pfStatus; a.pf_cap = s.pfCap; a.pf_epoch = ++s.pfEpoch;
-      a.pf_rec = s.pfRec; a.pf_rec_rounds = s.pfRecRounds; a.pf_stats = s.pfStats;
+      a.pf_rec = s.pfRec; a.pf_rec_rounds = s.pfRecRounds; a.pf_stats = s.pfStats; a.pf_ticket = s.pfTickets;
     }
     if (a.pf_status == nullptr) litKernel = false;                  // no persistent launch for this call: the chain kernel
     static const bool countSumOk = getenv("CXG_NO_COUNT_SUM") == nullptr;

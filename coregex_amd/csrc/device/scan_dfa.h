@@ -48,7 +48,8 @@ inline WalkLimit walk_limit(uint64_t remaining, int32_t window) {
 
 // k_scan_fields_pers (scan_fields_wave.hip): pf_rec holds 384 words of 8 bytes per round — 128 records of two words, 128 block sums
 constexpr int kPfBlocks = 128;
-constexpr uint64_t kPfRecStride = 3ull * kPfBlocks;
+constexpr uint32_t kPfCtrStride = 32;           // uint32 between two ticket counters (128 bytes: one cache line each); ring of 32 launch epochs x 64 counters
+constexpr uint64_t kPfRecStride = 3ull * kPfBlocks + 8ull;   // (+ the round's inclusive row count, round 6)
 
 // A union of <= 4 ASCII ranges prepared for the SWAR class tests (wave_common.hpp "class plans"): nx X terms (xc, xk), nr R terms
 // (ra, rb; the first one over the case-folded bytes when fold).  ok == 0: a bound >= 0x80 — the kernel keeps notset4 / its table.
@@ -86,10 +87,12 @@ struct ScanArgs {
   uint32_t* pf_status;  // [pf_cap] one word per unit (a wave's 8 wave-tiles of a round): pf_epoch << 16 | rows of the unit
   uint64_t pf_cap;
   uint32_t pf_epoch;    // 1..65535, own counter (the words are 4 bytes: block_common.hpp's 10-bit epoch words do not fit)
-  uint32_t pf_full, pf_tpw_last, pf_units_last;   // filled in by the launcher: full rounds, tiles per unit / units of the tapered last round
+  uint32_t pf_full, pf_tpw_last, pf_units_last;   // filled in by the launcher — round 6 (tickets): units of kPfTiles tiles, of three tiles, of one tile (round 5: full rounds, tiles per unit / units of the tapered last round)
   uint64_t* pf_rec;     // [pf_rec_rounds][384] per round: 128 records {rows of the round in front of the block, rows of the round} + 128 block sums, each word tagged pf_epoch << 48
   uint64_t pf_rec_rounds;
   uint64_t* pf_stats;   // [8192] per wave: units that waited << 32 | polls (CXG_VERBOSE)
+  uint32_t* pf_ticket;  // [32][64] ticket counters, kPfCtrStride words apart; block pf_epoch & 31 is this launch's (round 6: units are claimed, not assigned)
+  uint32_t pf_ncounters;   // counters in use: a power of two <= min(64, workgroups)
   ClassPlan plan;       // scan_charclass_wave.hip: the class; k_scan_trio_wave: the field class (filled on the host per launch)
   uint32_t plan_shape;  // wave_common.hpp plan_shape(plan); 0: the generic range tests
   uint32_t cc_nr, cc_neg, cc_pairs;   // scan_charclass_wave.hip: walk.hpp CharClassAux copied by the host (kernel arguments: no dependent

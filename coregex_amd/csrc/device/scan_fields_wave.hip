@@ -811,6 +811,30 @@ constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64
 // several waits expire one after another.  The limit is therefore "between 2 and 50 ms".
 constexpr uint64_t kPfWaitTicks = 5000000ull;
 
+#ifndef CXG_PF_EAGER
+#define CXG_PF_EAGER 0
+#endif
+#ifndef CXG_PF_TAIL3
+#define CXG_PF_TAIL3 1
+#endif
+#ifndef CXG_PF_TAIL1
+#define CXG_PF_TAIL1 2
+#endif
+// Round 6 built the kernel with CLAIMED units (tickets; below, -DCXG_PF_TICKETS=1) — a wave that holds unit u then only ever waits for smaller
+// units, which removes the need for a co-resident grid — and measured it against the static assignment (unit = round * W + wave):
+//   * a returning atomic on ONE address is served ~20 times per microsecond; a 6 TB/s scan in 34 KiB units asks ~190 times: 8 counters
+//     cost a pure streaming kernel 25 %, 64 counters a cache line apart 2 % (scripts/microbench/ticket_atomics.hip; scalar s_atomic_add
+//     works on gfx950 and behaves the same);
+//   * with the counters fast, the ORDERING is what costs: rows can only be written once every smaller unit has been counted, and with one
+//     unit of slack (two parked row lists fill the LDS that six workgroups per CU leave) every unit ends up waiting for the slowest of the
+//     ~6 000 units in flight — 16 GiB: 5.9 ms with a counter per workgroup, 4.8 with the counters asked in rotation, 3.9 with every unit
+//     doing its own decoupled look-back over block aggregates, against 3.3 static; 1 GiB 0.27-0.35 ms against 0.22 (profiles/r06_c4..c7_*).
+// The static grid stays the product (its spin watchdog and the demotion ladder of capi.hip cover a grid that is not co-resident); the
+// ticketed form stays buildable for whoever finds the second unit of slack.
+#ifndef CXG_PF_TICKETS
+#define CXG_PF_TICKETS 0
+#endif
+#if !CXG_PF_TICKETS
 // LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused);
 // 16 + K' + 8 EQ = TRIO mode (round 5): run(F) (byte(c_i) run(F)){K'-1} programs with their capture slots, k_scan_trio_wave's tile
 // mathematics (trio_core<K', EQ>) and row epilogue on this kernel's grid and protocol (BASELINE configs[4], `(\w+)@(\w+)\.(\w+)`).
@@ -1110,6 +1134,445 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
   if (wv == 0 && lane0 == 0) *a.total = running;                      // wave 0 has a unit in every round
 }
 
+#else
+// LIT: 0 = a fields program (K, KD, KP as above); 2..4 = a literal over that many distinct bytes (lit_core; K, KD, KP unused);
+// 16 + K' + 8 EQ = TRIO mode (round 5): run(F) (byte(c_i) run(F)){K'-1} programs with their capture slots, k_scan_trio_wave's tile
+// mathematics (trio_core<K', EQ>) and row epilogue on this kernel's grid and protocol (BASELINE configs[4], `(\w+)@(\w+)\.(\w+)`).
+template <int K, int KD, int KP, int LIT = 0>
+__global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OCC)) void k_scan_fields_pers(ScanArgs a) {   // ticketed (round 6)   // (three / four bitmaps: 27 / 29 KB of LDS per workgroup — six do not fit a CU)
+  constexpr bool kTrio = LIT >= 16;
+  constexpr int TK = kTrio ? ((LIT - 16) & 7) : 2;                    // fields of a TRIO program
+  constexpr bool TEQ = kTrio && ((LIT - 16) >> 3) != 0;
+  constexpr bool kLit = LIT >= 2 && LIT <= 4;
+  typedef typename std::conditional<TK == 4, uint32_t, uint16_t>::type LinkT;
+  constexpr int kNBitmaps = kTrio ? TK : (kLit ? LIT : 2);
+  __shared__ LinkT s_lnk[kTrio ? 2 : 1][kWavesPerBlock][kTrio ? kPfRows : 1];   // TRIO: the links of a parked row as distances from its start
+  __shared__ uint8_t s_cls[kTrio ? 256 : 4];                          // TRIO: byte -> class flags (bit 0 F, bit i + 1 the separator of link i)
+  __shared__ __attribute__((aligned(16))) uint64_t s_c[kNBitmaps][kWavesPerBlock][64 + 4];   // class bitmaps of the wave's window (+ 4 dump words: CARRY)
+  uint64_t (*const s_d)[64 + 4] = s_c[0];
+  uint64_t (*const s_p)[64 + 4] = s_c[1];
+  __shared__ uint32_t s_row[2][kWavesPerBlock][kPfRows];                         // rows of round r and r - 1: start | end << 16, offsets from the unit's first byte - kPre
+
+  constexpr bool kCarry = CXG_PF_CARRY != 0;
+  constexpr int kPre = kCarry ? kFPrePers : kFPre;
+  constexpr unsigned long long kOwn = kCarry ? kFOwnPers : kFOwn;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  const uint32_t W = gridDim.x * static_cast<uint32_t>(kWavesPerBlock);
+  const uint32_t wv = blockIdx.x * static_cast<uint32_t>(kWavesPerBlock) + static_cast<uint32_t>(wave);   // (the wave's slot in the statistics and the count-only sums — NOT what it scans)
+  // Units, in haystack order (launch_pers_inst): U9 of kPfTiles tiles (the last of them may be shorter), then U3 of three, then U1 of
+  // one — the tail in small units so that the waves end within a tile of each other.  Unit u belongs to round u / W, block
+  // (u % W) / 64 of that round: the words and records of the ordering protocol are indexed by the unit, whoever scans it.
+  const uint32_t U9 = a.pf_full, U3 = a.pf_tpw_last, U1 = a.pf_units_last, U = U9 + U3 + U1;
+  const uint64_t nwt_all = (a.len + static_cast<uint64_t>(kWaveTile) - 1) / static_cast<uint64_t>(kWaveTile);
+  const uint64_t T9 = nwt_all - 3ull * U3 - U1;
+  auto unit_first = [&](uint32_t u) -> uint64_t {
+    return u < U9 ? static_cast<uint64_t>(u) * kPfTiles : (u < U9 + U3 ? T9 + 3ull * (u - U9) : T9 + 3ull * U3 + (u - U9 - U3));
+  };
+  auto unit_tiles = [&](uint32_t u) -> uint32_t {
+    return u < U9 ? (u + 1u == U9 ? static_cast<uint32_t>(T9 - static_cast<uint64_t>(U9 - 1u) * kPfTiles) : static_cast<uint32_t>(kPfTiles)) : (u < U9 + U3 ? 3u : 1u);
+  };
+  // ---- tickets.  A wave takes the next unit from a counter — so whoever holds unit u knows that every unit below u of that counter is
+  // held by a wave that RUNS or has finished, and every wait of the protocol below is for a smaller unit: forward progress without
+  // the whole grid being resident, beside any other kernel.  One counter serialises at ~20 returning atomics per microsecond (a
+  // 64-GiB scan asks for 190: scripts/microbench/ticket_atomics.hip — 8 counters cost 25 % of a streaming kernel, 64 cost 2 %), so
+  // there are NC <= 64 of them, a cache line apart, counter c = workgroup & (NC - 1) handing out the units c, c + NC, ...: the
+  // workgroups dispatched first cover all counters.  The counters of launch epoch e are block e & 31 of a ring; this launch clears
+  // the block 16 epochs ahead (nothing in flight uses it).
+  const uint32_t ncnt = a.pf_ncounters;                               // a power of two <= the number of workgroups
+  // (Round 6, second form: a wave asks the counters IN ROTATION — with a fixed counter per workgroup the counters advance at the speeds
+  // of their workgroups, the order of the units drifts apart from the order in time, and every wave waits for the slowest counter
+  // at every unit: 16 GiB 5.9 ms against 3.3, profiles/r06_c5_tail_ab.txt.)
+  uint32_t cme = (blockIdx.x * static_cast<uint32_t>(kWavesPerBlock) + static_cast<uint32_t>(wave)) & (ncnt - 1u);
+  uint32_t* const ctr0 = a.pf_ticket + (a.pf_epoch & 31u) * (64u * kPfCtrStride);
+  auto per_ctr = [&](uint32_t c) -> uint32_t { return (U + ncnt - 1u - c) / ncnt; };
+  uint32_t casked = cme;                                              // the counter of the ticket in flight
+  auto claim_issue = [&]() -> uint32_t {                              // lane 0's ticket of the next counter of the wave's rotation (valid in lane 0)
+    cme = (cme + 1u) & (ncnt - 1u);
+    casked = cme;
+    uint32_t t = 0;
+    if (lane0 == 0) t = __hip_atomic_fetch_add(ctr0 + cme * kPfCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  auto claim_resolve = [&](uint32_t t_raw) -> uint32_t {              // the unit of that ticket; that counter exhausted: two neighbours are asked, then the wave is done; U: nothing left
+    const uint32_t t = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t_raw)));
+    if (t < per_ctr(casked)) return t * ncnt + casked;
+    for (uint32_t kx = 1; kx < 3u && kx < ncnt; kx++) {
+      const uint32_t c = (casked + kx) & (ncnt - 1u);
+      uint32_t t2 = 0;
+      if (lane0 == 0) t2 = __hip_atomic_fetch_add(ctr0 + c * kPfCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t2 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t2)));
+      if (t2 < per_ctr(c)) return t2 * ncnt + c;
+    }
+    return U;
+  };
+  const uint32_t tk_first = claim_issue();
+  if (blockIdx.x == 0 && tid < 64) a.pf_ticket[(((a.pf_epoch + 16u) & 31u) * 64u + static_cast<uint32_t>(tid)) * kPfCtrStride] = 0u;
+  if (kTrio) {                                                        // (in front of the first early return: every wave of the workgroup reaches the barrier)
+    const ChainAux* tch = reinterpret_cast<const ChainAux*>(a.chain);
+    const uint32_t b = static_cast<uint32_t>(tid);
+    uint32_t f = chain_class_has(*tch, 0, b) ? 1u : 0u;
+    for (int i = 0; i < TK - 1; i++) f |= chain_class_has(*tch, tch->op_cls[2 * i + 1], b) ? (2u << i) : 0u;
+    s_cls[tid] = static_cast<uint8_t>(f);
+  }
+  __syncthreads();
+  uint32_t u_cur = claim_resolve(tk_first);
+  if (u_cur >= U) { if (a.count_sum != 0u && lane0 == 0) a.status[wv] = 0; return; }   // (more waves than units)
+  const ChainAux* gch = reinterpret_cast<const ChainAux*>(a.chain);
+  const uint32_t dlo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[0] * 0x01010101u)));
+  const uint32_t dhi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[0]) * 0x01010101u)));
+  const uint32_t plo4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[1] * 0x01010101u)));
+  const uint32_t phi4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((0x7Fu - gch->cls_hi[1]) * 0x01010101u)));
+  LitRegs lr;
+  if (kLit) {
+    lr.m = gch->nops; lr.nc = gch->ncls; lr.cls2_lo = gch->cls2_lo; lr.cls2_hi = gch->cls2_hi;
+#pragma unroll
+    for (int c = 0; c < 4; c++) lr.b4[c] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gch->cls_lo[c] * 0x01010101u)));
+  }
+  const uint32_t ep = a.pf_epoch;
+  const uint32_t tag = ep << 16;
+  const bool want_rows = a.out != nullptr || a.max_len != 0;
+  const bool order = a.count_sum == 0u;                               // count-only calls need no place in the output
+  // TRIO: which two slots of a row this lane writes and what they are made of (k_scan_trio_wave's epilogue): sel 0 start, 1 end,
+  // 2 + i the end of run i (link i), 7 unset
+  uint32_t t_lsh = 0, t_pr = 0, t_sel0 = 0, t_sel1 = 1; int32_t t_off0 = 0, t_off1 = 0; bool t_lane_on = true;
+  if (kTrio) {
+    const ChainCaps* cp = reinterpret_cast<const ChainCaps*>(a.caps);
+    const uint32_t npairs = a.row_width >> 1;
+    t_lsh = npairs <= 1u ? 0u : 32u - static_cast<uint32_t>(__builtin_clz(npairs - 1u));
+    t_pr = static_cast<uint32_t>(lane0) & ((1u << t_lsh) - 1u);
+    t_lane_on = t_pr < npairs;
+    auto slot_of = [&](uint32_t k, uint32_t& sel, int32_t& off) {
+      const uint32_t src = cp->src[k];
+      sel = src == kCapSrcStart ? 0u : src == kCapSrcEnd ? 1u : 7u;
+      if (src >= kCapSrcRun0 && src < kCapSrcRun0 + kCapMaxRuns) { const uint32_t op = cp->run_op[src - kCapSrcRun0]; sel = (op >> 1) < static_cast<uint32_t>(TK - 1) ? 2u + (op >> 1) : 1u; }
+      off = cp->off[k];
+    };
+    if (cp->on == 1u && t_lane_on) { slot_of(2u * t_pr, t_sel0, t_off0); slot_of(2u * t_pr + 1u, t_sel1, t_off1); }
+  }
+  const uint32_t hw_wave = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (3 << 11)) & 15u;   // wave slot on its SIMD
+
+  // ---- ordering.  Units are grouped in BLOCKS of 64 consecutive units (block g = units 64 g .. 64 g + 63, whoever scanned them).  The
+  // wave that holds a block's LAST unit owes the block: first its sum (the 64 unit words), published as an aggregate, then — a decoupled
+  // look-back over the block words in front, 64 per look — the rows up to the block's end, published as an inclusive word.  A unit's
+  // rows start at  inclusive(block in front) + the units of its own block below it.  Every word anybody waits for belongs to a SMALLER
+  // unit, and a leader looks at its duty once per tile of the unit it scans meanwhile: nobody spins while it has tiles.
+  // pf_rec[g] = epoch << 48 | inclusive << 47 | rows (47 bits)
+  const uint64_t ep48 = static_cast<uint64_t>(a.pf_epoch) << 48;
+  constexpr uint64_t kBwIncl = 1ull << 47, kBwRows = kBwIncl - 1ull;
+  uint64_t* const bw = a.pf_rec;
+  const uint32_t nblk = (U + 63u) >> 6;
+  const __amdgpu_buffer_rsrc_t units_rs = __builtin_amdgcn_make_buffer_rsrc(a.pf_status, 0, static_cast<int>(U * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t blocks_rs = __builtin_amdgcn_make_buffer_rsrc(bw, 0, static_cast<int>(nblk * 8u), 0x00020000);
+  struct WordPair { uint32_t lo, hi; };
+  // what the rows of unit (block g, index idx) wait for: the inclusive word of block g - 1 (same address in every lane) and the words of
+  // the units of block g below it (both past the L1: sc0 sc1)
+  auto status_load = [&](uint32_t g, WordPair& vr, uint32_t& vs) {
+    if (CXG_PFABL >= 1) return;
+    vs = __builtin_amdgcn_raw_buffer_load_b32(units_rs, (g * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
+    if (g != 0u) {                                                    // ONE 8-byte load: the word changes from aggregate to inclusive, two dword loads could see half of each
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(blocks_rs, (g - 1u) * 8u, 0, 17);
+      vr.lo = w.x; vr.hi = w.y;
+    }
+  };
+  // all there?  then base = rows in front of the unit
+  auto status_reduce = [&](const WordPair& vr, uint32_t vs, uint32_t g, uint32_t idx, uint64_t& base) -> bool {
+    if (CXG_PFABL >= 1) { base = static_cast<uint64_t>(wv) * 64u; return true; }
+    const bool mine = static_cast<uint32_t>(lane0) < idx;             // the units of the block in front of this one
+    const bool ok = (g == 0u || (vr.hi >> 15) == ((ep << 1) | 1u)) && (!mine || (vs >> 16) == ep);
+    if (__ballot(!ok) != 0ull) return false;
+    const uint32_t p = mine ? (vs & 0xFFFFu) : 0u;
+    const uint64_t inc = g == 0u ? 0ull : (((static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vr.hi)))) << 32) |
+                                             static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vr.lo)))) & kBwRows);
+    base = inc + static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(p)), 63));
+    return true;
+  };
+  // ---- duties of a block's leader.  duty_stage 0 = nothing owed, 1 = the block's sum, 2 = the look-back.
+  uint32_t duty_g = 0, duty_stage = 0, duty_look = 0;
+  uint64_t duty_acc = 0;                                              // own sum + the aggregates looked back over so far
+  auto blk_leader = [&](uint32_t u) -> bool { return (u & 63u) == 63u || u + 1u == U; };   // the LAST unit of a block: it waits for smaller units only
+  struct DutyWords { uint32_t lo, hi; };
+  auto duty_load = [&](DutyWords& dw) {
+    if (duty_stage == 1u) dw.lo = __builtin_amdgcn_raw_buffer_load_b32(units_rs, (duty_g * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
+    else if (static_cast<uint32_t>(lane0) <= duty_look) {             // lane l: block duty_look - l (one 8-byte load each: see status_load)
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(blocks_rs, (duty_look - static_cast<uint32_t>(lane0)) * 8u, 0, 17);
+      dw.lo = w.x; dw.hi = w.y;
+    }
+  };
+  auto duty_publish = [&](uint64_t rows_incl) {                       // the look-back is through: rows up to the end of block duty_g
+    if (lane0 == 0) {
+      __hip_atomic_store(bw + duty_g, ep48 | kBwIncl | rows_incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (duty_g + 1u == nblk) *a.total = rows_incl;                  // the whole haystack's rows
+    }
+    duty_stage = 0u;
+  };
+  auto duty_check = [&](const DutyWords& dw) {                        // looks at what duty_load brought; publishes and moves on when complete
+    if (duty_stage == 1u) {
+      const uint32_t first = duty_g * 64u;
+      const uint32_t expect = U - first < 64u ? U - first : 64u;
+      const bool in = static_cast<uint32_t>(lane0) < expect;
+      if (__ballot(in && (dw.lo >> 16) != ep) != 0ull) return;
+      const uint32_t sum = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(in ? (dw.lo & 0xFFFFu) : 0u)), 63));
+      duty_acc = sum;
+      if (duty_g == 0u) { duty_publish(sum); return; }
+      if (lane0 == 0) __hip_atomic_store(bw + duty_g, ep48 | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // aggregate: later leaders need not wait for this look-back
+      duty_stage = 2u; duty_look = duty_g - 1u;
+      return;
+    }
+    // lanes 0 .. min(63, duty_look): the blocks duty_look, duty_look - 1, ...; the nearest inclusive word ends the look-back
+    const bool have = static_cast<uint32_t>(lane0) <= duty_look;
+    const bool ready = !have || (dw.hi >> 16) == ep;
+    const unsigned long long nr = __ballot(!ready);
+    const uint32_t nready = nr ? static_cast<uint32_t>(__builtin_ctzll(nr)) : 64u;
+    const unsigned long long im = __ballot(have && ready && ((dw.hi >> 15) & 1u) != 0u) & (nready >= 64u ? ~0ull : ((1ull << nready) - 1ull));
+    const uint32_t ntake = im ? static_cast<uint32_t>(__builtin_ctzll(im)) + 1u : (nready == 64u || nready > duty_look ? (duty_look + 1u < 64u ? duty_look + 1u : 64u) : 0u);
+    if (ntake == 0u) return;                                          // a block in front has not published anything yet: next tile
+    const uint64_t v = (have && static_cast<uint32_t>(lane0) < ntake) ? (((static_cast<uint64_t>(dw.hi) << 32) | dw.lo) & kBwRows) : 0ull;
+    uint32_t vlo = static_cast<uint32_t>(v), vhi = static_cast<uint32_t>(v >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {                               // (64-bit wave sum: block words hold up to 47 bits)
+      const uint32_t olo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(vlo), d, 64)), ohi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(vhi), d, 64));
+      const uint64_t sum2 = ((static_cast<uint64_t>(vhi) << 32) | vlo) + ((static_cast<uint64_t>(ohi) << 32) | olo);
+      vlo = static_cast<uint32_t>(sum2); vhi = static_cast<uint32_t>(sum2 >> 32);
+    }
+    duty_acc += (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vhi)))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vlo)));
+    if (im != 0ull || ntake > duty_look) { duty_publish(duty_acc); return; }   // reached an inclusive word, or the haystack's first block
+    duty_look -= ntake;                                               // 64 aggregates and no inclusive word among them: further back on the next look
+  };
+  auto duty_finish = [&]() {                                          // no tiles left to hide behind (end of a round with the duty still open, end of the launch)
+    uint32_t spins = 0;
+    uint64_t t_wait = 0;
+    while (duty_stage != 0u) {
+      DutyWords dv = {0u, 0u};
+      duty_load(dv);
+      const uint32_t before = duty_stage, before_look = duty_look;
+      duty_check(dv);
+      if (duty_stage == before && duty_look == before_look) {
+        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
+        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+        __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
+      }
+    }
+  };
+
+  u32x4 x[4];
+  uint32_t sink = 0;
+  int32_t nvalid_cur = 0;
+  fields_first_loads<kPre>(x, fields_window<kPre>(a.hay, a.len, unit_first(u_cur) * static_cast<uint64_t>(kWaveTile), true, nvalid_cur), lane, u_cur == 0u);
+  uint64_t my_total = 0;                                              // count-only: rows of this wave's units
+  uint32_t fallback = 0;
+  uint32_t st_waits = 0, st_polls = 0;
+  const uint64_t st_t0 = __builtin_readcyclecounter();
+  uint64_t st_scan = 0;
+  // the unit whose rows are parked (written one unit later: their base is ready by then, nobody waits)
+  bool have_prev = false;
+  uint32_t prev_blk = 0, prev_idx = 0, prev_rows = 0, prev_par = 0;
+  uint64_t prev_first = 0;
+  uint32_t par = 0;
+  auto wave_sum64 = [&](uint64_t v) -> uint64_t {                      // (block words hold up to 47 bits)
+    uint32_t vlo = static_cast<uint32_t>(v), vhi = static_cast<uint32_t>(v >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t olo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(vlo), d, 64)), ohi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(vhi), d, 64));
+      const uint64_t s2 = ((static_cast<uint64_t>(vhi) << 32) | vlo) + ((static_cast<uint64_t>(ohi) << 32) | olo);
+      vlo = static_cast<uint32_t>(s2); vhi = static_cast<uint32_t>(s2 >> 32);
+    }
+    return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vhi)))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(vlo)));
+  };
+  auto write_prev = [&](WordPair vr, uint32_t vs) {                     // order and write the rows of the parked unit
+    uint64_t base = 0;
+    uint32_t spins = 0;
+    if (!status_reduce(vr, vs, prev_blk, prev_idx, base)) {
+      // The inclusive word of the block in front was not there when this unit's last tile asked for it.  Do not wait for that block's
+      // leader: look back over the block words in front oneself, 64 per look — aggregates add up, the nearest inclusive word ends the
+      // walk (decoupled look-back; the leaders' inclusive words only keep these walks short).  What this still waits for are units
+      // that have not been scanned yet: the words of the own block below this unit, and the aggregate of a block whose units are
+      // still being scanned.
+      uint64_t t_wait = 0;
+      uint64_t acc = 0;
+      uint32_t own = 0, look = prev_blk;                               // blocks 0 .. look - 1 are not accounted for yet
+      bool have_own = false;
+      for (;;) {
+        if (!have_own) {
+          const bool mine = static_cast<uint32_t>(lane0) < prev_idx;
+          if (__ballot(mine && (vs >> 16) != ep) == 0ull) {
+            own = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum_fused(mine ? (vs & 0xFFFFu) : 0u)), 63));
+            have_own = true;
+          }
+        }
+        if (look != 0u) {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const bool have = static_cast<uint32_t>(lane0) < look;      // lane l: block look - 1 - l
+          u32x2 w = {0u, 0u};
+          if (have) w = __builtin_amdgcn_raw_buffer_load_b64(blocks_rs, (look - 1u - static_cast<uint32_t>(lane0)) * 8u, 0, 17);
+          const bool ready = !have || (w.y >> 16) == ep;
+          const unsigned long long nr = __ballot(!ready);
+          const uint32_t nready = nr ? static_cast<uint32_t>(__builtin_ctzll(nr)) : 64u;
+          const unsigned long long im = __ballot(have && ready && ((w.y >> 15) & 1u) != 0u) & (nready >= 64u ? ~0ull : ((1ull << nready) - 1ull));
+          const uint32_t ntake = im ? static_cast<uint32_t>(__builtin_ctzll(im)) + 1u : (nready < look ? nready : look);
+          if (ntake != 0u) {
+            acc += wave_sum64((have && static_cast<uint32_t>(lane0) < ntake) ? (((static_cast<uint64_t>(w.y) << 32) | w.x) & kBwRows) : 0ull);
+            look = im ? 0u : look - ntake;
+          }
+        }
+        if (have_own && look == 0u) break;
+        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
+        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
+        if (duty_stage != 0u) { DutyWords dv = {0u, 0u}; duty_load(dv); duty_check(dv); }   // (a leader that waits keeps looking at its own duty)
+        __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
+        if (!have_own) vs = __builtin_amdgcn_raw_buffer_load_b32(units_rs, (prev_blk * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
+      }
+      base = acc + own;
+    }
+    st_waits += spins != 0u ? 1u : 0u; st_polls += spins;             // CXG_VERBOSE statistics, left per wave at the end
+    if (a.out != nullptr && CXG_PFABL < 3) {
+      const int64_t origin = (a.u32_rows ? 0 : a.base) + static_cast<int64_t>(prev_first * static_cast<uint64_t>(kWaveTile)) - kPre;
+      const uint32_t n = prev_rows < static_cast<uint32_t>(kPfRows) ? prev_rows : static_cast<uint32_t>(kPfRows);
+      if (kTrio) {                                                    // capture rows (or spans): k_scan_trio_wave's epilogue, a power of two of lanes per row
+        for (uint32_t i = lane0; i < (n << t_lsh); i += 64) {
+          const uint32_t rr = i >> t_lsh;
+          if (t_lane_on && base + rr < a.cap) {
+            const uint32_t w0 = s_row[prev_par][wave][rr], w1 = s_lnk[kTrio ? prev_par : 0][wave][rr];
+            const int64_t ps = origin + (w0 & 0xFFFFu), pe = origin + (w0 >> 16);
+            auto pos_of = [&](uint32_t sel) -> int64_t { return sel == 0u ? ps : sel == 1u ? pe : ps + ((w1 >> (8u * (sel - 2u))) & 0xFFu); };
+            store_pair_nt(a.out + (base + rr) * a.row_width + 2u * t_pr, t_sel0 == 7u ? -1 : pos_of(t_sel0) + t_off0, t_sel1 == 7u ? -1 : pos_of(t_sel1) + t_off1);
+          }
+        }
+      } else
+      for (uint32_t i = lane0; i < n; i += 64) {
+        if (base + i < a.cap) {
+          const uint32_t v = s_row[prev_par][wave][i];
+          if (a.u32_rows) store_pair32_nt(reinterpret_cast<uint32_t*>(a.out) + (base + i) * 2u, static_cast<uint32_t>(origin + (v & 0xFFFFu)), static_cast<uint32_t>(origin + (v >> 16)));
+          else store_pair_nt(a.out + (base + i) * a.row_width, origin + (v & 0xFFFFu), origin + (v >> 16));
+        }
+      }
+    }
+  };
+
+  for (;;) {
+    const uint32_t blk = u_cur >> 6, idx = u_cur & 63u;
+    WordPair vr = {0u, 0u};
+    uint32_t vs = 0;
+    uint32_t nrows_w = 0;
+    const uint32_t tpw = unit_tiles(u_cur);
+    const uint64_t t0 = unit_first(u_cur);
+    const uint32_t tk_raw = claim_issue();                            // the ticket behind this unit: asked for now, looked at in front of the unit's last tile
+    uint32_t u_next = U;
+    {
+      const uint64_t st_a = __builtin_readcyclecounter();
+      for (uint32_t j = 0; j < tpw; j++) {
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        if (CXG_PF_PRIO) {
+          // VALU issue on a SIMD goes to the highest priority, then to the OLDEST wave: with equal priorities the first-dispatched
+          // of the six waves of a SIMD runs nearly unimpeded and the youngest gets what is left (profiles/r04_pers_wave_times.txt).
+          // Rotate the priorities: (time slice + wave slot) mod 4, the same clock for all waves of a SIMD.
+          const uint32_t slice = static_cast<uint32_t>(__builtin_readcyclecounter() >> CXG_PF_PRIO_SHIFT);
+          switch ((slice + hw_wave) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+          }
+        }
+        int32_t nvalid_next = 0;
+        const bool last = j + 1 == tpw;
+        if (last) u_next = claim_resolve(tk_raw);
+        const bool more = !last || u_next < U;
+        const uint64_t lo_next = (last ? unit_first(u_next < U ? u_next : 0u) : t0 + j + 1) * static_cast<uint64_t>(kWaveTile);
+        const __amdgpu_buffer_rsrc_t rnext = fields_window<kPre>(a.hay, a.len, lo_next, more, nvalid_next);
+        uint32_t d0 = 0, d1 = 0, p0 = 0, p1 = 0;
+        uint32_t tc0[TK - 1], tc1[TK - 1];
+        if (kTrio) trio_words<TK, kCarry>(x, rnext, lane, &s_c[0][wave][0], s_cls, nvalid_cur, j != 0u, !last, d0, d1, tc0, tc1);
+        else if (kLit) lit_words<kNBitmaps, kCarry>(x, rnext, lane, &s_c[0][wave][0], nvalid_cur, lr, j != 0u, !last);
+        else fields_words<KD, KP, kCarry>(x, rnext, lane, s_d[wave], s_p[wave], nvalid_cur, dlo4, dhi4, plo4, phi4, sink, d0, d1, p0, p1, j != 0u, !last);
+        nvalid_cur = nvalid_next;
+        const bool duty = duty_stage != 0u;                           // a leader's look of this tile
+        DutyWords dv = {0u, 0u};
+        if (duty) duty_load(dv);
+        if (last && order && have_prev) status_load(prev_blk, vr, vs);   // consumed behind this tile's mathematics
+        FieldsTile t;
+        if (kTrio) { const TrioTile tt = trio_core<TK, TEQ, kOwn>(d0, d1, tc0, tc1); t = FieldsTile{tt.e0, tt.e1, 0u, 0u, tt.ovf}; }
+        else t = kLit ? lit_core<kOwn>(&s_c[0][wave][0], lane, lr) : fields_core<K, kOwn>(d0, d1, p0, p1);
+        if (kLit && kCarry && !last) lit_carry<kNBitmaps>(&s_c[0][wave][0], lane);
+        if (t.ovf) fallback |= 1u;
+        const uint32_t c = static_cast<uint32_t>(__popc(t.e0)) + static_cast<uint32_t>(__popc(t.e1));
+        const uint32_t incl = wave_inclusive_sum_fused(c);
+        const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        if (tot != 0 && want_rows) {
+          if (kTrio) trio_rows<TK, LinkT>(TrioTile{t.e0, t.e1, t.ovf}, d0, d1, lane, s_row[par][wave], s_lnk[kTrio ? par : 0][wave], nrows_w + incl - c, static_cast<uint32_t>(kPfRows),
+                                          j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
+          else fields_rows(t, lane, s_row[par][wave], nrows_w + incl - c, [](uint32_t rr) { return min(rr, static_cast<uint32_t>(kPfRows - 1)); },
+                           j * static_cast<uint32_t>(kWaveTile) * 0x10001u);
+        }
+        nrows_w += tot;
+        if (duty) duty_check(dv);
+      }
+      st_scan += __builtin_readcyclecounter() - st_a;
+      if (nrows_w > static_cast<uint32_t>(kPfRows)) fallback |= 16u;
+      wave_lds_sync();
+      bool bad = false, long_hit = false;
+      if (want_rows) {
+        for (uint32_t q = lane0; q < nrows_w && q < static_cast<uint32_t>(kPfRows); q += 64) {
+          const uint32_t v = s_row[par][wave][q];
+          const uint32_t sb = v & 0xFFFFu, eb = v >> 16;
+          bad = bad || sb >= eb;
+          long_hit = long_hit || (a.max_len != 0 && eb - sb > a.max_len);
+        }
+      }
+      if (__ballot(bad) != 0ull) fallback |= 2u;
+      if (__ballot(long_hit) != 0ull && lane0 == 0) raise_err(a.err, kErrLongMatch);
+      my_total += nrows_w;
+      if (order && CXG_PFABL < 2) {                                   // publish the unit's row count; the last unit of a block takes on its duty
+        if (lane0 == 0) __hip_atomic_store(a.pf_status + u_cur, tag | nrows_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CXG_PFABL < 1 && blk_leader(u_cur)) {
+          duty_finish();                                              // (still owing for an earlier block: everybody behind it waits for that)
+          duty_g = blk; duty_stage = 1u;
+          if (CXG_PF_EAGER) duty_finish();                            // (A/B: the leader settles its block before it scans on)
+          else {                                                      // the block's AGGREGATE at once — every look-back over this block needs it; the inclusive word behind the coming tiles
+            uint32_t sp2 = 0;
+            uint64_t tw2 = 0;
+            while (duty_stage == 1u) {
+              DutyWords dv = {0u, 0u};
+              duty_load(dv);
+              duty_check(dv);
+              if (duty_stage != 1u) break;
+              if (sp2++ == 0u) tw2 = __builtin_readcyclecounter();
+              else if ((sp2 & 15u) == 0u && __builtin_readcyclecounter() - tw2 > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+              __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
+            }
+          }
+        }
+      }
+    }
+    if (order && u_next >= U) duty_finish();                          // no further unit to hide behind: a record may be waiting for this wave
+    if (order && have_prev) write_prev(vr, vs);
+    have_prev = true;
+    prev_blk = blk; prev_idx = idx; prev_rows = nrows_w; prev_par = par; prev_first = t0;
+    par ^= 1u;
+    if (u_next >= U) break;
+    u_cur = u_next;
+  }
+  if (order) {                                                        // the rows of the wave's last unit
+    WordPair vr = {0u, 0u};
+    uint32_t vs = 0;
+    status_load(prev_blk, vr, vs);
+    write_prev(vr, vs);
+  }
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+  if (!order) { if (lane0 == 0) a.status[wv] = my_total; return; }    // k_sum_counts adds the W words up
+  if (lane0 == 0) {
+    a.pf_stats[wv] = (static_cast<uint64_t>(st_waits) << 32) | st_polls;
+    a.pf_stats[8192 + wv] = __builtin_readcyclecounter() - st_t0;     // s_memtime ticks of this wave's life (~2.2 GHz in a busy kernel)
+    a.pf_stats[16384 + wv] = st_scan;                                 // ... of which inside the tile loops
+    a.pf_stats[24576 + wv] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11)) | (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11))) << 32);
+  }
+}
+
+#endif
 // Does the chain have the shape this kernel evaluates?  run(0) (byte(1) run(0)){K-1}, two classes of one range each,
 // disjoint, K = 2..4, no restart check.  Returns K, else 0.
 int fields_shape(const ChainAux& c) {
@@ -1185,6 +1648,23 @@ bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
   if (G * kWavesPerBlock > static_cast<uint64_t>(kPfMaxWaves)) G = kPfMaxWaves / kWavesPerBlock;
   if (G > (nwt + 3) / 4) G = (nwt + 3) / 4;                           // short input: one tile per wave
   const uint64_t W = G * kWavesPerBlock;
+#if CXG_PF_TICKETS
+  // units in haystack order: the bulk in units of kPfTiles tiles, then W units of three tiles, then 2 W single tiles — the waves
+  // end within a tile of each other whatever their speeds were (round 5's static rounds ended with their slowest wave: ~7 % of a
+  // 1 GiB launch).  -DCXG_PF_TAIL3 / CXG_PF_TAIL1: those two counts in units of W, for A/B.
+  const uint64_t t1 = std::min<uint64_t>(nwt, static_cast<uint64_t>(CXG_PF_TAIL1) * W);
+  const uint64_t t3 = std::min<uint64_t>(nwt - t1, 3ull * CXG_PF_TAIL3 * W) / 3ull * 3ull;
+  const uint64_t t9 = nwt - t1 - t3;
+  const uint64_t u9 = (t9 + kPfTiles - 1) / kPfTiles, u3 = t3 / 3ull, u1 = t1, units = u9 + u3 + u1;
+  const uint64_t rounds = (units + W - 1) / W;
+  if (units + 64 > a.pf_cap || rounds + 1 > a.pf_rec_rounds || units > 0x7FFFFFFFull || a.pf_ticket == nullptr) {
+    if (verbose) fprintf(stderr, "[cxg] persistent kernel: %llu units in %llu rounds of %llu waves do not fit the status arrays (%llu words, %llu rounds) — not launched\n",
+                         (unsigned long long)units, (unsigned long long)rounds, (unsigned long long)W, (unsigned long long)a.pf_cap, (unsigned long long)a.pf_rec_rounds);
+    return false;
+  }
+  a.pf_full = static_cast<uint32_t>(u9); a.pf_tpw_last = static_cast<uint32_t>(u3); a.pf_units_last = static_cast<uint32_t>(u1);
+  { uint32_t nc = 1; while (nc * 2u <= G && nc < 64u) nc *= 2u; a.pf_ncounters = nc; }   // (every counter has workgroups asking it, the first-dispatched ones among them)
+#else
   const uint64_t per_round = static_cast<uint64_t>(kPfTiles) * W;
   const uint64_t full = nwt / per_round, rem = nwt - full * per_round;
   const uint64_t tpw_last = (rem + W - 1) / W;
@@ -1195,6 +1675,7 @@ bool launch_pers_inst(ScanArgs a, hipStream_t stream) {
     return false;
   }   // (the round number is part of a block sum's tag: 16 bits = 64 Ki rounds of 180 MiB)
   a.pf_full = static_cast<uint32_t>(full); a.pf_tpw_last = static_cast<uint32_t>(tpw_last); a.pf_units_last = static_cast<uint32_t>(units_last);
+#endif
   hipLaunchKernelGGL((k_scan_fields_pers<K, KD, KP, LIT>), dim3(static_cast<unsigned>(G)), dim3(kThreads), 0, stream, a);
   if (a.count_sum) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, stream, a.status, W, a.total);
   return true;
