@@ -189,11 +189,15 @@ class DeviceWorkload:
         }
 
 
+    def alg_bytes(self):
+        """Algorithmic bytes of one launch of this rank: N + W * M (DESIGN.md "Roofline")."""
+        return self.nbytes + (4 if self.u32 else 8) * self.width * self.nmatch
+
     def finish(self, result, k_ms):
         """roofline and cpu_baseline of the JSON line (rank 0, after the timed region)."""
         args, cx, nbytes, width, nmatch = self.args, self.cx, self.nbytes, self.width, self.nmatch
         row_bytes = (4 if self.u32 else 8) * width
-        alg_bytes = nbytes + row_bytes * nmatch                          # per launch, this rank (DESIGN.md "Roofline")
+        alg_bytes = self.alg_bytes()                                     # per launch, this rank (DESIGN.md "Roofline")
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         kname = "+".join(cx._lib.lib().cxg_kernel_name(k).decode() for k in sorted(self.kernels))
         result["roofline"] = {
@@ -212,10 +216,12 @@ class DeviceWorkload:
         }
         rank, world = self.rank, self.world
         under_profiler = _under_profiler()
-        if rank == 0 and world == 1 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
+        if rank == 0 and not args.no_pmc and not under_profiler and not os.environ.get("CXG_DEBUG"):
             # HBM traffic of the dominant kernel, measured NOW: two child runs of this very workload under rocprofv3, one PMC
-            # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.
-            live = _pmc_traffic_live(args, kname)
+            # counter each (after the timed region; the parent only waits).  The committed profile is the fallback.  With N > 1
+            # ranks (round 6) the children run rank 0's shard alone on rank 0's device (HIP_VISIBLE_DEVICES pinned) while the other
+            # ranks wait at the closing barrier: every rank scans a shard of the same size with the same kernel.
+            live = _pmc_traffic_live(args, kname, gib_per_gpu=nbytes / float(1 << 30), device_env=pmc_child_device_env(self.local_rank))
             if live is not None:
                 result["roofline"]["traffic"] = live["traffic_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = live["source"]
@@ -224,7 +230,7 @@ class DeviceWorkload:
             elif result["roofline"]["traffic"] is not None:
                 result["roofline"]["traffic_source"] = "committed profile of the same workload and kernel (profiles/*_pmc_traffic.json); the live rocprofv3 passes failed"
         if rank == 0 and world == 1 and not args.no_cpu_baseline and args.pattern is None and not self.u32 and not os.environ.get("CXG_DEBUG"):
-            result["cpu_baseline"] = _cpu_baseline(args.config, self.cfg, self.pattern, self.buf, self.out, nmatch, nbytes, width, self.base)
+            result["cpu_baseline"] = _cpu_baseline(args.config, self.cfg, self.pattern, self.buf, self.out, nmatch, nbytes, width, self.base, self.synth, self.seed)
         if args.check_all_rows and not os.environ.get("CXG_DEBUG"):
             result.setdefault("cpu_baseline", {})["all_rows_check"] = _check_all_rows(self.pattern, self.synth, self.seed, rank * self.npages, self.npages, self.out, nmatch, width, self.base)
 
@@ -284,6 +290,13 @@ def main(argv=None, make_workload=DeviceWorkload, script=None):
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         per_rank_rows = [int(x) for x in tr.tolist()]
     total_matches = sum(per_rank_rows)
+    # per-rank achieved bandwidth on algorithmic bytes (north_star: "achieved HBM GB/s against peak at 1, 2, 4 and 8 GPUs")
+    per_rank_alg = [int(wl.alg_bytes())] if hasattr(wl, "alg_bytes") else None
+    if per_rank_alg is not None and dist is not None:
+        ta = torch.zeros(world, dtype=torch.int64, device=wl.tensor_device)
+        ta[rank] = per_rank_alg[0]
+        dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+        per_rank_alg = [int(x) for x in ta.tolist()]
     _, part = wl.rows_and_checksum(sum(per_rank_rows[:rank]))
     corpus_checksum = part
     if dist is not None:
@@ -311,6 +324,9 @@ def main(argv=None, make_workload=DeviceWorkload, script=None):
         "config": dict(wl.describe(), matches_total=total_matches, rccl_world_size=world, per_rank_kernel_ms=per_rank_ms,
                        per_rank_rows=per_rank_rows, corpus_checksum="%016x" % corpus_checksum),
     }
+    if per_rank_alg is not None:
+        result["config"]["per_rank_achieved_GBps"] = [round(b / (ms * 1e-3) / 1e9, 2) for b, ms in zip(per_rank_alg, per_rank_ms)]
+        result["config"]["per_rank_roofline_frac"] = [round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for b, ms in zip(per_rank_alg, per_rank_ms)]
     wl.finish(result, k_ms)
     if make_workload is DeviceWorkload and hasattr(wl, "async_leg") and not args.no_async and not wl.submatch and not wl.u32 and not os.environ.get("CXG_DEBUG"):
         result["async"] = wl.async_leg(args.steps)
@@ -406,10 +422,9 @@ def _relaunch_one_rank_per_gpu(n, script, need_gpus=True):
     os.execvpe(cmd[0], cmd, env)
 
 
-def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
+def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base, synth, seed):
     """One thread and all cores, on a bounded sample of the very bytes the GPU scanned; parity of the rows on the sample."""
     import numpy as np
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     L = O.lib()
     i64, vp = C.c_int64, C.c_void_p
@@ -455,37 +470,30 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
     same = len(cpu_rows) >= k_in and bool(np.array_equal(cpu_rows[:k_in], gpu_rows[:k_in]))
     if not same:
         raise SystemExit("PARITY FAILURE: GPU rows differ from the CPU port on the benchmark corpus")
-    # ---- all cores: page-aligned blocks are independent (every page ends in '\n'), one engine per thread
+    # ---- all cores, in C++ (oracle/cpu_baseline.cpp orc_baseline_all_cores; round 6): a std::thread pool over page-aligned 1 MiB blocks
+    # of one pre-generated host buffer of the same synthlog pages (blocks are independent: every page ends in '\n'), engine and
+    # scratch once per thread, the buffer sized for about 1.5 s per pass (<= 8 GiB and a quarter of the host's free memory)
     threads = max(1, len(os.sched_getaffinity(0)))
-    rate1 = sample / cpu_s                                            # bound the all-cores leg to ~10 s of wall time
-    all_sample = int(min(nbytes, 1 << 30, max(sample, rate1 * threads * 10.0))) // 4096 * 4096
-    big = host if all_sample == sample else buf.download(0, all_sample)
-    nblk = threads * 4
-    pages = all_sample // 4096
-    cuts = [(pages * i // nblk) * 4096 for i in range(nblk + 1)]
-    engines = [O.Regex(pattern) for _ in range(threads)]
-    counts = [0] * nblk
-
-    def work(tid):
-        e = engines[tid]
-        scratch = np.empty(max(4096, (cuts[1] - cuts[0]) // 4), dtype=np.int64)   # the ports count past the capacity
-        for b in range(tid, nblk, threads):
-            lo, hi = cuts[b], cuts[b + 1]
-            if hi > lo:
-                counts[b] = port(e._h, big.ctypes.data + lo, hi - lo, scratch.ctypes.data, scratch.size)
-
-    all_runs = []
-    with ThreadPoolExecutor(max_workers=threads) as ex:             # one pool: the first pass also starts its threads
-        for _ in range(5):
-            a0 = time.perf_counter()
-            list(ex.map(work, range(threads)))
-            all_runs.append(time.perf_counter() - a0)
-            if sum(all_runs) > 12.0:
-                break
+    rate1 = sample / cpu_s
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        avail = 8 << 30
+    all_sample = int(min(8 << 30, avail // 4, max(256 << 20, rate1 * threads * 1.5))) // (1 << 20) * (1 << 20)
+    L.orc_baseline_all_cores.restype = C.c_int
+    L.orc_baseline_all_cores.argtypes = [C.c_char_p, i64, C.c_int, vp, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, vp]
+    npasses = 5
+    res = np.zeros(4 + npasses, dtype=np.uint64)
+    check_pages = min(all_sample, nbytes) // 4096 // 256 * 256        # whole 1 MiB blocks inside what the GPU scanned
+    rc = L.orc_baseline_all_cores(lit, len(lit), config, pair.ctypes.data, synth, seed, base // 4096, all_sample // 4096, check_pages,
+                                  threads, npasses, width, res.ctypes.data)
+    if rc != 0:
+        raise SystemExit(f"cpu baseline: the all-cores leg failed ({rc})")
+    all_runs = [float(v) / 1e9 for v in res[4:4 + npasses].tolist()]
     all_s = sorted(all_runs)[len(all_runs) // 2]
-    k_all = int(np.searchsorted(gpu_rows[:, 1], all_sample, side="right"))
-    if sum(counts) // width != k_all:
-        raise SystemExit(f"PARITY FAILURE: all-cores CPU port counted {sum(counts) // width} rows, the GPU {k_all}")
+    k_all = int(np.searchsorted(gpu_rows[:, 1], check_pages * 4096, side="right"))
+    if int(res[1]) != k_all:
+        raise SystemExit(f"PARITY FAILURE: all-cores CPU port counted {int(res[1])} rows in the first {check_pages * 4096 >> 20} MiB, the GPU {k_all}")
     anchor = _sparse_digit_anchor(L, eng) if config == 2 else None
     return {
         "value": round(sample / cpu_s / 1e9, 4),
@@ -503,7 +511,9 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base):
                       5: "PikeVM restatement (the oracle), not tuned.",
                   }[config],
         "all_cores": {"value": round(all_sample / all_s / 1e9, 3), "unit": "GB/s", "cores": threads,
-                      "sample": f"first {all_sample >> 20} MiB in {nblk} page-aligned blocks, one engine per thread, median of {len(all_runs)} passes {all_s:.3f} s wall; row count equals the GPU's",
+                      "scaling_efficiency": round((all_sample / all_s) / (rate1 * threads), 3),
+                      "sample": f"{all_sample >> 20} MiB of the same corpus generated on the host ({float(res[2]) / 1e9:.2f} s on all threads), C++ std::thread pool over page-aligned 1 MiB blocks "
+                                f"(dynamic hand-out), one engine and one scratch per thread, median of {len(all_runs)} passes {all_s:.3f} s wall; rows of the first {check_pages * 4096 >> 20} MiB equal the GPU's count",
                       "runs_s": [round(r, 3) for r in all_runs]},
         "host_cpu": _cpu_model(),
         "host_threads_available": os.cpu_count(),
@@ -538,7 +548,16 @@ def _sparse_digit_anchor(L, eng):
                     f"runs at memchr speed here — the 0.7 GB/s of the main figure is the digit-dense corpus (a DFA verification every few bytes), not the port"}
 
 
-def _pmc_traffic_live(args, kernel):
+def pmc_child_device_env(local_rank, environ=None):
+    """HIP_VISIBLE_DEVICES for a one-GPU child that must run on the device this rank uses: the local_rank-th entry of the parent's own
+    list when it has one (a launcher may already have narrowed it), else the index itself.  ROCR_VISIBLE_DEVICES is left alone: HIP
+    indices count inside it."""
+    environ = os.environ if environ is None else environ
+    vis = [v for v in environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+    return {"HIP_VISIBLE_DEVICES": vis[local_rank] if local_rank < len(vis) else str(local_rank)}
+
+
+def _pmc_traffic_live(args, kernel, gib_per_gpu=None, device_env=None):
     """2 x FETCH_SIZE + WRITE_SIZE per launch of `kernel`, from two child invocations of this script under
     `rocprofv3 --kernel-trace --pmc <one counter>` (separate passes, kernel trace only beside the counters —
     MI355X_MICROARCH.md "HBM"; FETCH_SIZE doubled: gfx950 reports half of wide coalesced reads).  None on any failure."""
@@ -547,7 +566,7 @@ def _pmc_traffic_live(args, kernel):
     if not os.path.exists(exe):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--config", str(args.config), "--steps", "3", "--warmup", "1", "--settle", "2",
-             "--gib-per-gpu", str(args.gib_per_gpu), "--no-cpu-baseline", "--no-pmc", "--no-north-star", "--no-async"]
+             "--gib-per-gpu", repr(float(gib_per_gpu if gib_per_gpu is not None else args.gib_per_gpu)), "--no-cpu-baseline", "--no-pmc", "--no-north-star", "--no-async"]
     if args.pattern is not None:
         child += ["--pattern", args.pattern]
     if args.synth_config is not None:
@@ -561,7 +580,9 @@ def _pmc_traffic_live(args, kernel):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR="/tmp")
-            env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)
+            env.update(device_env or {})
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "pmc", "--output-format", "csv", "--"] + child,
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:

@@ -245,19 +245,46 @@ class Regex:
 
 
 class Pending:
-    """Handle of cxg_find_all_device_async; wait() on the thread that made the call returns the row count."""
+    """Handle of cxg_find_all_device_async; wait() on the thread that made the call returns the row count.  Also a context manager
+    (`with rx.find_all_device_async(...) as p:` waits on exit) — and a handle that is dropped is waited for when it is collected, so
+    that its scratch slot comes back.  (Since round 6 a pending call holds no lock: other threads' scans queue behind it on the device.)"""
 
     def __init__(self, h):
         self._h = h
+        self.rows = None
 
     def wait(self, timing: "Timing | None" = None) -> int:
+        if self._h is None:
+            if self.rows is None:
+                raise CoregexError(_lib.CXG_E_INVALID, "this asynchronous call was already waited for and failed")
+            return self.rows
         got = C.c_uint64(0)
         h, self._h = self._h, None
         rc = _lib.lib().cxg_wait(h, C.byref(got), C.byref(timing) if timing is not None else None)
-        if rc == _lib.CXG_E_INVALID:
-            self._h = h                                               # (wrong thread: the handle is still good on the launching one)
+        if rc == _lib.CXG_E_THREAD:
+            self._h = h                                               # wrong thread: the C side has not touched the handle (every other code consumes it)
         _check(rc)
-        return int(got.value)
+        self.rows = int(got.value)
+        return self.rows
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self._h is not None:
+            try:
+                self.wait()
+            except CoregexError:
+                if exc[0] is None:
+                    raise
+        return False
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None:
+            try:
+                self.wait()
+            except Exception:                                         # noqa: BLE001 (collection on another thread, interpreter shutdown)
+                pass
 
 
 def _find_all_device_async(self, d_hay: int, length: int, d_out: int = 0, cap: int = 0, base: int = 0, n: int = -1, stream: int = 0) -> Pending:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("CXG_LIB_PATH") or os.path.join(_HERE, "libcoregex_hip
 _lib = None
 
 CXG_OK, CXG_E_INVALID, CXG_E_UNSUPPORTED, CXG_E_CAPACITY = 0, -1, -2, -3
-CXG_E_DEVICE, CXG_E_NO_GPU, CXG_E_SYNTAX, CXG_E_INTERNAL, CXG_E_INPUT = -4, -5, -6, -7, -8
+CXG_E_DEVICE, CXG_E_NO_GPU, CXG_E_SYNTAX, CXG_E_INTERNAL, CXG_E_INPUT, CXG_E_THREAD = -4, -5, -6, -7, -8, -9
 
 # every symbol declared in include/coregex_hip.h (tests check the exports against the header)
 SYMBOLS = [

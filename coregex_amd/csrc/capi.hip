@@ -87,14 +87,36 @@ struct PathMode {
 };
 struct PathState {
   PathMode staticGroups, persistent, delim;
-  // ONE order-dependent launch at a time per device from THIS process (every goroutine of a cgo host may be scanning): two
-  // persistent grids would each hold half the CUs and wait for waves that cannot become resident, and a persistent grid beside a
-  // static-group kernel deadlocks just the same — the resident workgroups of either wait (for co-residency resp. for the look-back
-  // word of a group that is not resident yet) in the slots the other one needs; measured in round 5: two threads scanning 1 GiB each
-  // ran into the 0.4 s watchdog.  Such launches take this mutex from launch to completion; the scans are HBM-bound, so callers
-  // lose nothing by taking turns.  Ticket-mode and table-walking launches wait for nothing that is not running and stay outside.
+  // ONE launch section at a time per device from THIS process (every goroutine of a cgo host may be scanning): two persistent grids
+  // would each hold half the CUs and wait for waves that cannot become resident, and a persistent grid beside a static-group kernel
+  // waits just the same (measured in round 5: two threads scanning 1 GiB each ran into the 0.4 s watchdog); the scans are HBM-bound,
+  // so callers lose nothing by taking turns.  Round 5 held a mutex from launch to completion — and, for asynchronous calls, until
+  // cxg_wait: a handle that was never waited for blocked every other thread.  Now the turns are taken ON THE
+  // DEVICE: a launch section (OrderGate below) makes its stream wait for the completion event of the section in front of it,
+  // enqueues its kernels, and records its own completion event; the mutex only guards that event while the section is being
+  // enqueued (microseconds), nothing is held across a synchronisation or an API boundary.
   std::mutex orderMutex;
+  hipEvent_t orderEvent = nullptr;      // completion of the last launch section any thread enqueued on this device
+  bool orderValid = false;
   std::atomic<uint32_t> orderWaiters{0};
+};
+struct OrderGate {
+  PathState& ps;
+  hipStream_t stream;
+  std::unique_lock<std::mutex> lk;
+  OrderGate(PathState& p, hipStream_t st) : ps(p), stream(st), lk(p.orderMutex, std::defer_lock) {
+    ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); lk.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed);
+    if (!ps.orderEvent && hipEventCreateWithFlags(&ps.orderEvent, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ps.orderEvent = nullptr; }
+    if (ps.orderEvent && ps.orderValid && hipStreamWaitEvent(stream, ps.orderEvent, 0) != hipSuccess) (void)hipGetLastError();
+  }
+  void close() {                        // everything of the section is enqueued: the next section (any thread) runs behind it
+    if (!lk.owns_lock()) return;
+    if (ps.orderEvent) { if (hipEventRecord(ps.orderEvent, stream) == hipSuccess) ps.orderValid = true; else (void)hipGetLastError(); }
+    lk.unlock();
+  }
+  ~OrderGate() { close(); }
+  OrderGate(const OrderGate&) = delete;
+  OrderGate& operator=(const OrderGate&) = delete;
 };
 PathState g_path[16];
 
@@ -161,7 +183,6 @@ struct Scratch {
   AsyncSlot async[kAsyncSlots];
   uint64_t* asyncCtl = nullptr;                     // pinned, 2 words per slot
   int asyncInFlight = 0;
-  std::unique_lock<std::mutex> asyncLock;           // the device's order-dependent launch slot, held while launches of this thread are in flight
   // Everything above belongs to ONE OS thread.  A cgo host moves goroutines across many threads, so the scratch is
   // released when its thread exits (thread_local destructor) or on request (cxg_thread_release).
   void release() {
@@ -188,7 +209,6 @@ struct Scratch {
       if (hostCtl) (void)hipHostFree(hostCtl);
       if (asyncCtl) (void)hipHostFree(asyncCtl);
       for (auto& as : async) for (auto& e : as.ev) if (e) (void)hipEventDestroy(e);
-      if (asyncLock.owns_lock()) asyncLock.unlock();
       if (pinHay) (void)hipHostFree(pinHay);
       if (pinOut) (void)hipHostFree(pinOut);
     }
@@ -267,13 +287,8 @@ int deviceBlob(const cxg_program* p, int device, const uint8_t** out) {
   return deviceCopy(p->blob, &const_cast<cxg_program*>(p)->dev[device], out);
 }
 
-// The device's launch slot for the small kernels outside scanDeviceOnce (merges of nullable programs, capture expansions, corpus fills):
-// held from launch to completion, not taken by a thread whose pending asynchronous calls already hold it.
-std::unique_lock<std::mutex> lockOrder(Scratch& s) {
-  std::unique_lock<std::mutex> lk(g_path[s.device < 0 ? 0 : s.device].orderMutex, std::defer_lock);
-  if (s.asyncInFlight == 0) lk.lock();
-  return lk;
-}
+// (The small kernels outside scanDeviceOnce — merges of nullable programs, capture expansions, corpus fills — are launch sections too:
+// OrderGate gate(g_path[device], stream) around their launches.)
 
 uint64_t tilesFor(uint32_t kind, uint64_t len);
 int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out, uint64_t cap,
@@ -650,12 +665,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   trioKernel = false;
   std::memset(a.caps, 0, sizeof a.caps);
   a.static_groups = (gen >= 6 && !staticDenied) ? 1u : 0u;
-  std::unique_lock<std::mutex> orderLock(ps.orderMutex, std::defer_lock);   // released when this iteration ends (every path out of it)
-  if (s.asyncInFlight == 0) {                                      // (pending launches of this thread already hold it; its launches share a stream)
-    // every launch of the library takes the slot, not only the order-dependent ones: ANY kernel beside a persistent grid can keep
-    // part of it from becoming resident (profiles/r05_c4_foreign_kernel.txt) — inside one process nothing of ours does
-    ps.orderWaiters.fetch_add(1, std::memory_order_relaxed); orderLock.lock(); ps.orderWaiters.fetch_sub(1, std::memory_order_relaxed);
-  }
+  OrderGate orderGate(ps, stream);                                 // this iteration's launch section: behind whatever any thread enqueued on the device before (closed once everything is enqueued)
   Scratch::AsyncSlot* const as = (t_asyncSlot && relaunches == 0 && !submatch && !profOn && !dbgBits && a.max_len == 0) ? t_asyncSlot : nullptr;
   if (gen == 11 && !a.static_groups) { gen = 10; fsmTried = true; }   // the delimiter kernel has no ticket mode
   a.ngroups = a.ntiles;
@@ -879,13 +889,14 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     HIP_TRY(hipEventRecord(as->ev[1], stream));
     as->stream = stream; as->kernelId = kernelId; as->tiles = a.ntiles;
     as->mode = gen == 11 ? 3u : persKernel ? 2u : a.static_groups ? 1u : 0u;
-    if (orderLock.owns_lock()) s.asyncLock = std::move(orderLock);  // the device's order-dependent slot stays with this thread until its launches are waited for
+    orderGate.close();
     s.asyncInFlight++;
     return kRcPending;
   }
   if (submatch && a.out && !fusedCaps) { if (int rc = launchCapturePass(p, s, a, d_cap, stream, launches)) return rc; }
   if (wantEv) HIP_TRY(hipEventRecord(s.ev[2], stream));
   if (!a.epoch) HIP_TRY(hipMemcpyAsync(s.hostCtl, s.ctl, 32, hipMemcpyDeviceToHost, stream));   // wave kernels wrote hostCtl themselves
+  orderGate.close();
   HIP_TRY(syncStream(stream));
   const uint64_t total = s.hostCtl[1];
   uint32_t err = static_cast<uint32_t>(s.hostCtl[2]);
@@ -975,7 +986,6 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
     }
   }
-  if (orderLock.owns_lock()) orderLock.unlock();
   if (err & 2u) {
     static const bool wdVerbose = getenv("CXG_VERBOSE") != nullptr;
     const uint32_t origin = (err >> 24) & 15u;
@@ -1139,6 +1149,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
       if (rc != kRcLongMatch || !agrees) return rc == kRcLongMatch || rc == CXG_OK ? fail(CXG_E_INTERNAL, "UseBoth restart: the rerun for rows disagrees with the count") : rc;
       rows = s.bothRows;
     }
+    OrderGate restartGate(g_path[s.device < 0 ? 0 : s.device], stream);   // (this helper kernel ran outside the device's launch order)
     HIP_TRY(hipMemsetAsync(s.bothFirst, 0xFF, 8, stream));
     const uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((nscan + 255) / 256, 4096));
     // The first row of a RESTARTED search is what the reference's PikeVM returned from end - 100: it stands whatever its length
@@ -1147,6 +1158,7 @@ int scanDevice(const cxg_program* p, const void* d_hay, uint64_t len, int64_t ba
     hipLaunchKernelGGL(k_first_long, dim3(blocks), dim3(256), 0, stream, rows + skip * width, nscan - skip, static_cast<uint32_t>(row_width), static_cast<int64_t>(cxgdev::kBothRestartSpan), s.bothFirst);
     unsigned long long k = 0;
     HIP_TRY(hipMemcpyAsync(&k, s.bothFirst, 8, hipMemcpyDeviceToHost, stream));
+    restartGate.close();
     HIP_TRY(hipStreamSynchronize(stream));
     k = k >= nscan - skip ? nscan : k + skip;
     bool over_estimate = false;
@@ -1332,7 +1344,7 @@ int scanNullable(const cxg_program* p, const void* d_hay, uint64_t len, int64_t 
   }
   const uint64_t nb = (n + kNullBlock - 1) / kNullBlock;
   uint64_t covered = 0;
-  std::unique_lock<std::mutex> orderLock = lockOrder(s);
+  OrderGate orderGate(g_path[s.device < 0 ? 0 : s.device], stream);
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   if (n > 0) {
     if (n + nb + 8 > s.nullCovCap) {
@@ -1437,7 +1449,7 @@ int scanNullableSubmatch(const cxg_program* p, const void* d_hay, uint64_t len, 
   if (int rc = deviceCopy(p->capBlob, &const_cast<cxg_program*>(p)->devCap[t_device], &d_cap)) return rc;
   if (!s.bothFirst) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.bothFirst), 16));
   uint32_t* d_err = reinterpret_cast<uint32_t*>(s.bothFirst);
-  std::unique_lock<std::mutex> orderLock = lockOrder(s);
+  OrderGate orderGate(g_path[s.device < 0 ? 0 : s.device], stream);
   HIP_TRY(hipMemsetAsync(d_err, 0, 8, stream));
   HIP_TRY(hipEventRecord(s.ev[0], stream));
   int64_t* out = static_cast<int64_t*>(d_out);
@@ -1531,7 +1543,7 @@ int scanOffsetCaps(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     std::memcpy(oc.src, p->offSrc, sizeof oc.src);
     std::memcpy(oc.delta, p->offDelta, sizeof oc.delta);
     const uint64_t threads = n * static_cast<uint64_t>(row_width / 2);
-    std::unique_lock<std::mutex> orderLock = lockOrder(s);
+    OrderGate orderGate(g_path[s.device < 0 ? 0 : s.device], stream);
     HIP_TRY(hipEventRecord(s.ev[0], stream));
     hipLaunchKernelGGL(k_caps_offsets, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream, s.offSpans, n, static_cast<uint32_t>(row_width), oc, static_cast<int64_t*>(d_out));
     HIP_TRY(hipGetLastError());
@@ -2003,10 +2015,11 @@ int cxg_buffer_fill_synth(cxg_buffer* b, uint32_t config, uint64_t seed, uint64_
   if (npages == 0) return CXG_OK;
   const unsigned block = 64;
   const unsigned grid = static_cast<unsigned>((npages + block - 1) / block);
-  std::unique_lock<std::mutex> orderLock(g_path[b->device].orderMutex, std::defer_lock);   // (a fill beside another thread's persistent scan would be a foreign kernel to it)
-  if (t_scratch[b->device].asyncInFlight == 0) orderLock.lock();
-  hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, b->d, npages, config, seed, first_page);
-  HIP_TRY(hipGetLastError());
+  {
+    OrderGate orderGate(g_path[b->device], nullptr);               // (a fill beside another thread's persistent scan would be a foreign kernel to it)
+    hipLaunchKernelGGL(k_fill_synth, dim3(grid), dim3(block), 0, nullptr, b->d, npages, config, seed, first_page);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipDeviceSynchronize());
   return CXG_OK;
 }
@@ -2073,7 +2086,7 @@ int cxg_wait(cxg_pending* h, uint64_t* n_out, cxg_timing* timing) {
   t_device = h->device;
   const int grc = getScratch(&sp);
   t_device = dev_before;
-  if (grc != CXG_OK || sp != h->s) { return fail(CXG_E_INVALID, "cxg_wait must be called on the thread that made the asynchronous call"); }
+  if (grc != CXG_OK || sp != h->s) { return fail(CXG_E_THREAD, "cxg_wait must be called on the thread that made the asynchronous call (the handle stays valid there)"); }
   Scratch& s = *sp;
   Scratch::AsyncSlot& as = s.async[h->slot];
   delete h;
@@ -2092,7 +2105,7 @@ int cxg_wait(cxg_pending* h, uint64_t* n_out, cxg_timing* timing) {
   const uint64_t total = as.ctl[0];
   const uint32_t err = static_cast<uint32_t>(as.ctl[1]);
   PathState& ps = g_path[s.device];
-  if (--s.asyncInFlight == 0 && s.asyncLock.owns_lock()) s.asyncLock.unlock();
+  --s.asyncInFlight;
   as.busy = false;
   if (we != hipSuccess) return failHip(we, "hipEventSynchronize");
   if (err != 0) {                                                   // another rung of the ladder (or a watchdog): the synchronous call decides and demotes

@@ -49,6 +49,7 @@ extern "C" {
                                    (b) a program WITHOUT a transducer image (cxg_program_fsm_image: > 224 stack states, or
                                    a table beyond the LDS budget) met > 128 KiB without a synchronising byte.  Programs
                                    with the image have no such limit (64 MiB of "1.1.1.1..." is answered, tests). */
+#define CXG_E_THREAD (-9)       /* cxg_wait on another thread than the one that made the asynchronous call: the handle is untouched, wait there */
 
 /* meta.Strategy values (meta/strategy.go:19-230), same numbering. */
 enum cxg_strategy {
@@ -248,8 +249,10 @@ int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64
 /* Asynchronous form of cxg_find_all_device (round 5): the call returns with its span launch in flight on `stream` (NULL: the calling
  * thread's own); cxg_wait — on the SAME thread — completes it and returns what cxg_find_all_device would have returned (a launch that
  * needs another kernel is rerun synchronously inside cxg_wait; programs without an async-capable first launch run to completion inside
- * the async call).  Up to 16 calls per thread may be pending; they should share one stream.  While calls of a thread are pending the
- * thread holds the device's order-dependent launch slot (cxg_path_state_t.order_waiters): wait for them before idling.
+ * the async call).  Up to 16 calls per thread may be pending, on any streams: since round 6 the launch sections of ALL threads are
+ * chained on the device (each section's stream waits for the completion event of the section in front of it), so a pending call
+ * holds no lock — other threads' scans simply queue behind it — and pending calls on different streams cannot overtake each other's
+ * scratch words.  cxg_wait on another thread returns CXG_E_THREAD and leaves the handle valid; every other return frees it.
  * d_hay, d_out and the program must stay valid until cxg_wait returns.  Mirrors nothing in the reference (its calls are synchronous);
  * it is what a batch host (bench.py, a shard scheduler) uses to pay launch + sync once per batch. */
 typedef struct cxg_pending cxg_pending;

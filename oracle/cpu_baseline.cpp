@@ -44,11 +44,11 @@ inline int64_t digitScanAVX2(const uint8_t* h, int64_t n, int64_t at) {
 extern "C" int64_t orc_baseline_digit_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals) {
   Engine* e = static_cast<Engine*>(ev);
   if (e->strategy != UseDigitPrefilter || !e->dfa.nfa) return -1;
-  {  // warm the lazy DFA so the flat table below is (almost always) complete
-    std::vector<int64_t> tmp;
-    e->findAll(h, len < (1 << 20) ? len : (1 << 20), -1, tmp);
-  }
   LazyDFA& d = e->dfa;
+  if (d.states.size() < 8) {  // warm the lazy DFA ONCE per engine so the flat table below is (almost always) complete — round 6: this ran on every
+    std::vector<int64_t> tmp;  // call, i.e. the all-cores leg (1 MiB blocks) timed the oracle's warm-up, not the port (256 threads: 2.1 GB/s)
+    e->findAll(h, len < (1 << 16) ? len : (1 << 16), -1, tmp);
+  }
   const int stride = e->nfa.alphabetLen;
   auto snapshot = [&](std::vector<int32_t>& flat, std::vector<uint8_t>& isMatch) {
     flat.assign(d.states.size() * stride, LazyDFA::kUnknown);
@@ -249,4 +249,123 @@ extern "C" int64_t orc_baseline_literal_find_all(const uint8_t* lit, int64_t lit
     pos = found + litLen;
   }
   return n;
+}
+
+// ---- all host cores (round 6; VERDICT round 5, weak #1: the Python thread pool over ctypes calls measured its own harness).
+// A std::thread pool over page-aligned blocks of ONE pre-generated host buffer of synthlog pages (every page ends in '\n': blocks
+// are independent), one engine and one row scratch per thread allocated once, the threads kept across the passes
+// (they meet at a barrier in front of every pass), blocks handed out dynamically (an atomic counter: 1 MiB each).  The caller
+// sizes the buffer so that a pass takes about a second.  Nothing here is the product: coregex_amd/ never links this file.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "../coregex_amd/csrc/device/synth.hpp"   // the corpus generator (host twin of the device fill kernel), not an algorithm of the path
+
+extern "C" int64_t orc_baseline_literal_find_all(const uint8_t* lit, int64_t litLen, const int32_t* pair, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals);
+extern "C" int64_t orc_baseline_digit_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals);
+extern "C" int64_t orc_baseline_teddy_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals);
+extern "C" int64_t orc_baseline_charclass_find_all(void* ev, const uint8_t* h, int64_t len, int64_t* out, int64_t capVals);
+
+// config: the BASELINE configuration (1..5: which port runs); synth_config / seed / first_page / npages: the corpus; check_pages: rows
+// of the blocks inside the first check_pages pages are also summed separately (the part the GPU scanned: its row count is compared).
+// out: [0] rows of all pages, [1] rows of the first check_pages pages, [2] ns to generate the buffer, [3] threads used,
+// [4 .. 4 + npasses) wall ns of each pass.  Returns 0; -1 bad argument / compile error; -2 the buffer could not be allocated.
+extern "C" int orc_baseline_all_cores(const char* pattern, int64_t plen, int config, const int32_t* pair, uint32_t synth_config, uint64_t seed,
+                                      uint64_t first_page, uint64_t npages, uint64_t check_pages, int nthreads, int npasses, int width, uint64_t* out) {
+  if (nthreads < 1 || npasses < 1 || npasses > 32 || config < 1 || config > 5 || npages == 0) return -1;
+  constexpr uint64_t kBlockPages = 256;                       // 1 MiB per unit of work
+  const uint64_t nblocks = (npages + kBlockPages - 1) / kBlockPages;
+  std::unique_ptr<uint8_t[]> buf(new (std::nothrow) uint8_t[npages * cxgsynth::kPage + 64]);
+  if (!buf) return -2;
+  std::atomic<uint64_t> next{0};
+  std::atomic<int> bad{0};
+  std::vector<uint64_t> blockRows(nblocks, 0);
+  // generation, all threads (also pages the buffer in)
+  const auto g0 = std::chrono::steady_clock::now();
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back([&]() {
+      for (;;) {
+        const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+        if (b >= nblocks) break;
+        const uint64_t p0 = b * kBlockPages, p1 = std::min(npages, p0 + kBlockPages);
+        for (uint64_t p = p0; p < p1; p++) cxgsynth::page(synth_config, seed, first_page + p, buf.get() + p * cxgsynth::kPage);
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+  std::memset(buf.get() + npages * cxgsynth::kPage, 0, 64);
+  const auto g1 = std::chrono::steady_clock::now();
+  // the passes: persistent threads, a barrier in front of each pass
+  std::mutex mu;
+  std::condition_variable cv;
+  int pass_open = -1, arrived = 0;
+  bool quit = false;
+  const std::string pat(pattern, static_cast<size_t>(plen));
+  auto worker = [&](int) {
+    std::unique_ptr<Engine> e;
+    try { e = compileEngine(pat); } catch (...) { bad = 1; }
+    std::vector<int64_t> scratch(static_cast<size_t>(kBlockPages * cxgsynth::kPage / 2 + 64) * static_cast<size_t>(width > 2 ? width / 2 : 1));
+    std::vector<int64_t> rows;                                 // (the PikeVM port appends)
+    int seen = -1;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        arrived++;
+        cv.notify_all();
+        cv.wait(lk, [&] { return quit || pass_open > seen; });
+        if (quit) return;
+        seen = pass_open;
+      }
+      if (bad) continue;
+      for (;;) {
+        const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+        if (b >= nblocks) break;
+        const uint64_t p0 = b * kBlockPages, p1 = std::min(npages, p0 + kBlockPages);
+        const uint8_t* h = buf.get() + p0 * cxgsynth::kPage;
+        const int64_t len = static_cast<int64_t>((p1 - p0) * cxgsynth::kPage);
+        int64_t nv = -1;
+        switch (config) {
+          case 1: nv = orc_baseline_literal_find_all(reinterpret_cast<const uint8_t*>(pat.data()), static_cast<int64_t>(pat.size()), pair, h, len, scratch.data(), static_cast<int64_t>(scratch.size())); break;
+          case 2: nv = orc_baseline_digit_find_all(e.get(), h, len, scratch.data(), static_cast<int64_t>(scratch.size())); break;
+          case 3: nv = orc_baseline_teddy_find_all(e.get(), h, len, scratch.data(), static_cast<int64_t>(scratch.size())); break;
+          case 4: nv = orc_baseline_charclass_find_all(e.get(), h, len, scratch.data(), static_cast<int64_t>(scratch.size())); break;
+          default: rows.clear(); e->findAllSubmatch(h, len, -1, rows); nv = static_cast<int64_t>(rows.size()); break;
+        }
+        if (nv < 0) { bad = 1; break; }
+        blockRows[b] = static_cast<uint64_t>(nv) / static_cast<uint64_t>(width);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+  for (int p = 0; p < npasses; p++) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return arrived == nthreads * (p + 1); });   // everybody is back (engines compiled, previous pass done)
+      next = 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      pass_open = p;
+      cv.notify_all();
+      cv.wait(lk, [&] { return arrived == nthreads * (p + 2); });
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    out[4 + p] = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count());
+  }
+  { std::unique_lock<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+  for (auto& x : th) x.join();
+  if (bad) return -1;
+  uint64_t all = 0, chk = 0;
+  for (uint64_t b = 0; b < nblocks; b++) { all += blockRows[b]; if ((b + 1) * kBlockPages <= check_pages) chk += blockRows[b]; }
+  out[0] = all; out[1] = chk;
+  out[2] = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(g1 - g0).count());
+  out[3] = static_cast<uint64_t>(nthreads);
+  return 0;
 }

@@ -45,6 +45,9 @@ class StubWorkload:
         rows = np.stack([100 * k, 100 * k + 7], axis=1)
         return self.nmatch, sharding.row_checksum(rows, first_row)
 
+    def alg_bytes(self):
+        return self.nbytes + 16 * self.nmatch
+
     def metric(self):
         return "launcher test: no scan"
 

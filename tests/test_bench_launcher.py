@@ -28,6 +28,11 @@ def test_plain_invocation_starts_two_ranks():
     assert d["data"] == "stub" and d["scaling"] == "weak" and d["higher_is_better"] is True
     # whole-job value: both ranks' bytes over the max-over-ranks time
     assert abs(d["value"] - 2 * (1 << 30) / (d["ms_per_step"] * 1e-3) / 1e9) / d["value"] < 0.01
+    # per-rank achieved bandwidth on algorithmic bytes (round 6: an N-GPU line names every rank's GB/s and roofline fraction)
+    ach = d["config"]["per_rank_achieved_GBps"]
+    assert len(ach) == 2 and len(d["config"]["per_rank_roofline_frac"]) == 2
+    for a, ms, rows in zip(ach, d["config"]["per_rank_kernel_ms"], d["config"]["per_rank_rows"]):
+        assert abs(a - ((1 << 30) + 16 * rows) / (ms * 1e-3) / 1e9) / a < 0.01
     # per-rank rows and the corpus checksum: the same table split over one rank gives the same line
     assert d["config"]["per_rank_rows"] == [500, 500] and d["config"]["matches_total"] == 1000
     r1 = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--settle", "0"])
@@ -53,3 +58,13 @@ def test_more_ranks_than_gpus_is_refused():
         return
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], script="bench.py")
     assert r.returncode != 0 and "one rank per GPU" in r.stderr
+
+
+def test_pmc_children_are_pinned_to_rank_zeros_device():
+    """Round 6: with N > 1 ranks the two rocprofv3 --pmc child passes run rank 0's shard alone on rank 0's device."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.pmc_child_device_env(0, {}) == {"HIP_VISIBLE_DEVICES": "0"}
+    assert bench.pmc_child_device_env(3, {}) == {"HIP_VISIBLE_DEVICES": "3"}
+    assert bench.pmc_child_device_env(1, {"HIP_VISIBLE_DEVICES": "4,6,7"}) == {"HIP_VISIBLE_DEVICES": "6"}
+    assert bench.pmc_child_device_env(0, {"HIP_VISIBLE_DEVICES": "5"}) == {"HIP_VISIBLE_DEVICES": "5"}

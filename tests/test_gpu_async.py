@@ -74,5 +74,37 @@ def test_programs_without_an_async_launch_and_the_wrong_thread(oracle):
     res = []
     th = threading.Thread(target=lambda: res.append(pytest.raises(cx.CoregexError, p.wait)))
     th.start(); th.join()
-    assert res and res[0].value.code == -1                           # CXG_E_INVALID: the handle belongs to the launching thread
+    assert res and res[0].value.code == -9                           # CXG_E_THREAD: the handle belongs to the launching thread (and is left untouched)
     assert p.wait() == len(oracle.Regex(IP).find_all_index(hay[:-64]))   # ... where it still completes
+
+
+def test_a_pending_call_blocks_nobody_and_a_dropped_handle_is_collected(oracle):
+    """round 5 kept the device's launch mutex until cxg_wait — a handle that was never waited for hung every other
+    thread.  Round 6 orders launch sections on the device (an event chain): with a call pending on this thread another thread scans
+    and gets its rows; a handle that is dropped is waited for by its finaliser; `with` waits on exit."""
+    import gc
+    import torch
+    n = 1 << 22
+    buf = cx.DeviceBuffer(n)
+    buf.fill_synth(2, 0xC0FFEE02, 0)
+    host = cx.synth_pages(2, 0xC0FFEE02, 0, n // 4096)
+    rx = cx.compile(IP)
+    exp = oracle.Regex(IP).find_all_index(host)
+    out = torch.empty((len(exp) + 8, 2), dtype=torch.int64, device="cuda")
+    p = rx.find_all_device_async(buf.ptr, n, out.data_ptr(), len(exp) + 8)        # pending, not waited for
+    res = []
+
+    def other():
+        o2 = torch.empty((len(exp) + 8, 2), dtype=torch.int64, device="cuda")
+        res.append((rx.find_all_device(buf.ptr, n, o2.data_ptr(), len(exp) + 8), o2[:len(exp)].cpu().numpy()))
+
+    th = threading.Thread(target=other)
+    th.start(); th.join(timeout=60)
+    assert not th.is_alive() and res and res[0][0] == len(exp) and np.array_equal(res[0][1], exp)
+    del p                                                                          # dropped: the finaliser waits, the slot comes back
+    gc.collect()
+    for _ in range(40):                                                            # more calls than the thread has slots: none of them leaked
+        with rx.find_all_device_async(buf.ptr, n, out.data_ptr(), len(exp) + 8) as q:
+            pass
+        assert q.rows == len(exp)
+    assert np.array_equal(out[:len(exp)].cpu().numpy(), exp)
