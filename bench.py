@@ -473,7 +473,19 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base, s
     # ---- all cores, in C++ (oracle/cpu_baseline.cpp orc_baseline_all_cores; round 6): a std::thread pool over page-aligned 1 MiB blocks
     # of one pre-generated host buffer of the same synthlog pages (blocks are independent: every page ends in '\n'), engine and
     # scratch once per thread, the buffer sized for about 1.5 s per pass (<= 8 GiB and a quarter of the host's free memory)
-    threads = max(1, len(os.sched_getaffinity(0)))
+    affinity = max(1, len(os.sched_getaffinity(0)))
+    quota = _cgroup_cpu_quota()                                      # the container may be allowed fewer cores than it can see (round 6: 256 visible threads scaled 8x — a CPU quota, not the harness)
+    # ... or the host may be shared: measure what 1 and all visible threads get out of a spin loop
+    L.orc_spin_ns.restype = C.c_uint64
+    L.orc_spin_ns.argtypes = [C.c_int, C.c_uint64]
+    spin1 = min(L.orc_spin_ns(1, 200_000_000) for _ in range(2))
+    spinN = min(L.orc_spin_ns(affinity, 200_000_000) for _ in range(2))
+    effective = round(affinity * spin1 / max(spinN, 1), 1)
+    threads = affinity
+    if quota:
+        threads = max(1, min(affinity, int(quota + 0.999)))
+    elif effective < 0.5 * affinity:
+        threads = max(1, int(effective + 0.5))
     rate1 = sample / cpu_s
     try:
         avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
@@ -517,6 +529,9 @@ def _cpu_baseline(config, cfg, pattern, buf, out, nmatch, nbytes, width, base, s
                       "runs_s": [round(r, 3) for r in all_runs]},
         "host_cpu": _cpu_model(),
         "host_threads_available": os.cpu_count(),
+        "host_threads_in_affinity_mask": affinity,
+        "cgroup_cpu_quota_cores": quota,
+        "effective_cores_by_spin_test": effective,
     }
 
 
@@ -621,6 +636,21 @@ def _pmc_traffic(config, nbytes, kernel):
                 and kernel.split("<")[0] in d.get("kernel", ""):
             return d.get("traffic_bytes_per_launch")
     return None
+
+
+def _cgroup_cpu_quota():
+    """Cores' worth of CPU time the container may use per period (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us); None: unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
 
 
 def _cpu_model():

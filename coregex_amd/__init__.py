@@ -204,6 +204,32 @@ class Regex:
             return np.zeros((0, w), dtype=np.int64)
         return self._rows(_lib.lib().cxg_find_all_submatch, hay, n, w)
 
+    def find_index(self, hay):
+        """Regexp.FindIndex(b) (regex.go; meta/find.go:29 Engine.Find): (start, end) of the first match, or None."""
+        a = _host_view(hay)
+        span = (C.c_int64 * 2)(-1, -1)
+        found = C.c_int(0)
+        _check(_lib.lib().cxg_find(self._h, a.ctypes.data, a.size, span, C.byref(found)))
+        return (int(span[0]), int(span[1])) if found.value else None
+
+    def is_match(self, hay) -> bool:
+        """Regexp.Match(b) (meta/ismatch.go:27 Engine.IsMatch)."""
+        a = _host_view(hay)
+        m = C.c_int(0)
+        _check(_lib.lib().cxg_is_match(self._h, a.ctypes.data, a.size, C.byref(m)))
+        return bool(m.value)
+
+    def find_device(self, d_hay: int, length: int, base: int = 0, stream: int = 0):
+        span = (C.c_int64 * 2)(-1, -1)
+        found = C.c_int(0)
+        _check(_lib.lib().cxg_find_device(self._h, d_hay, length, base, span, C.byref(found), stream or None))
+        return (int(span[0]), int(span[1])) if found.value else None
+
+    def is_match_device(self, d_hay: int, length: int, stream: int = 0) -> bool:
+        m = C.c_int(0)
+        _check(_lib.lib().cxg_is_match_device(self._h, d_hay, length, C.byref(m), stream or None))
+        return bool(m.value)
+
     def count(self, hay, n: int = -1) -> int:
         a = _host_view(hay)
         out = C.c_uint64(0)
@@ -308,6 +334,13 @@ def _find_all_device_u32(self, d_hay: int, length: int, d_out: int = 0, cap: int
 
 
 Regex.find_all_device_u32 = _find_all_device_u32
+
+
+def device_mem_info(device: int = 0):
+    """(free, total) bytes of HBM on `device` (cxg_device_mem_info)."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(_lib.lib().cxg_device_mem_info(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def compile(pattern) -> Regex:  # noqa: A001  (mirrors coregex.Compile)

@@ -27,6 +27,7 @@ SYMBOLS = [
     "cxg_buffer_free", "cxg_buffer_upload", "cxg_buffer_download", "cxg_buffer_len",
     "cxg_buffer_device_ptr", "cxg_buffer_fill_synth", "cxg_synth_page_host", "cxg_find_all_device", "cxg_find_all_device_u32",
     "cxg_find_all_submatch_device", "cxg_abi_version", "cxg_timing_size", "cxg_path_state", "cxg_debug_demote", "cxg_path_reset", "cxg_find_all_device_async", "cxg_wait",
+    "cxg_device_mem_info", "cxg_find", "cxg_is_match", "cxg_find_device", "cxg_is_match_device",
 ]
 
 
@@ -150,6 +151,11 @@ def lib():
     L.cxg_path_reset.argtypes = [C.c_int]
     L.cxg_find_all_device_async.argtypes = [vp, vp, u64, i64, i64, vp, u64, vp, C.POINTER(vp)]
     L.cxg_wait.argtypes = [vp, C.POINTER(u64), C.POINTER(Timing)]
+    L.cxg_device_mem_info.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
+    L.cxg_find.argtypes = [vp, vp, u64, C.POINTER(i64), C.POINTER(C.c_int)]
+    L.cxg_is_match.argtypes = [vp, vp, u64, C.POINTER(C.c_int)]
+    L.cxg_find_device.argtypes = [vp, vp, u64, i64, C.POINTER(i64), C.POINTER(C.c_int), vp]
+    L.cxg_is_match_device.argtypes = [vp, vp, u64, C.POINTER(C.c_int), vp]
     if L.cxg_abi_version() != 3 or L.cxg_timing_size() != C.sizeof(Timing):
         raise RuntimeError(f"{LIB_PATH}: ABI {L.cxg_abi_version()} / cxg_timing of {L.cxg_timing_size()} bytes, this binding expects 3 / {C.sizeof(Timing)}")
     _lib = L

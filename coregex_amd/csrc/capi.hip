@@ -153,6 +153,7 @@ struct Scratch {
   uint64_t* prof = nullptr;      // CXG_PROF phase counters (device)
   static constexpr size_t kProfRecords = 1u << 18;
   uint8_t* hay = nullptr; uint64_t hayCap = 0;     // staging for host haystacks
+  int64_t* findRow = nullptr;                       // cxg_find_device: the one row (16 bytes used)
   int64_t* out = nullptr; uint64_t outCap = 0;     // staging for host result arrays (rows*width)
   uint8_t* pinHay = nullptr;     // small host haystacks: pinned, read by the kernels over PCIe (no copy calls)
   int64_t* pinOut = nullptr;     // ... and their rows, written straight into pinned host memory
@@ -195,6 +196,7 @@ struct Scratch {
       if (pfStatus) (void)hipFree(pfStatus);
       if (pfRec) (void)hipFree(pfRec);
       if (pfTickets) (void)hipFree(pfTickets);
+      if (findRow) (void)hipFree(findRow);
       if (pfStats) (void)hipFree(pfStats);
       if (prof) (void)hipFree(prof);
       if (hay) (void)hipFree(hay);
@@ -1686,6 +1688,20 @@ int cxg_set_device(int device) {
   return CXG_OK;
 }
 
+int cxg_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (device < 0 || device >= deviceCount()) return fail(CXG_E_NO_GPU, "no such device");
+  int before = 0;
+  (void)hipGetDevice(&before);
+  HIP_TRY(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  const hipError_t e = hipMemGetInfo(&f, &t);
+  (void)hipSetDevice(before);
+  if (e != hipSuccess) return failHip(e, "hipMemGetInfo");
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return CXG_OK;
+}
+
 void cxg_thread_release(void) {
   for (auto& x : t_scratch) x.release();
 }
@@ -1969,6 +1985,27 @@ int cxg_find_all(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t
 int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, uint64_t* n_out) {
   return scanHostBuffer(p, hay, len, limit, nullptr, 0, n_out, 2);
 }
+// Engine.Find (meta/find.go:29) and Engine.IsMatch (meta/ismatch.go:27) of a whole haystack: FindAll with n == 1 — the first match in
+// haystack order.  The early stop is FindAll's: the group whose look-back has counted the first row raises the stop word, groups that
+// start afterwards publish and leave (block_common.hpp limit_reached_skip), so a haystack with an early match costs the groups that
+// were resident, not its length.  An empty match counts (nullable programs go through their merge with the same limit).
+int cxg_find(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t span[2], int* found) {
+  if (!span || !found) return fail(CXG_E_INVALID, "null argument");
+  uint64_t n = 0;
+  int64_t row[2] = {-1, -1};
+  *found = 0;
+  if (const int rc = scanHostBuffer(p, hay, len, 1, row, 1, &n, 2)) return rc;
+  if (n != 0) { *found = 1; span[0] = row[0]; span[1] = row[1]; }
+  return CXG_OK;
+}
+int cxg_is_match(const cxg_program* p, const uint8_t* hay, uint64_t len, int* matched) {
+  if (!matched) return fail(CXG_E_INVALID, "null argument");
+  uint64_t n = 0;
+  *matched = 0;
+  if (const int rc = scanHostBuffer(p, hay, len, 1, nullptr, 0, &n, 2)) return rc;
+  *matched = n != 0 ? 1 : 0;
+  return CXG_OK;
+}
 int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, int64_t* slots,
                           uint64_t cap, uint64_t* n_out) {
   if (p && p->ngroups == 1) return scanHostBuffer(p, hay, len, limit, slots, cap, n_out, 2);
@@ -2031,6 +2068,30 @@ int cxg_synth_page_host(uint32_t config, uint64_t seed, uint64_t page, uint8_t o
 int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t limit, void* d_out,
                         uint64_t cap, uint64_t* n_out, void* stream, cxg_timing* timing) {
   return scanDevice(p, d_hay, len, base, limit, d_out, cap, n_out, stream, timing, 2);
+}
+// The same two questions of a device-resident haystack (a shard): the row comes back through 16 bytes of the thread's scratch.
+int cxg_find_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t span[2], int* found, void* stream) {
+  if (!span || !found) return fail(CXG_E_INVALID, "null argument");
+  *found = 0;
+  Scratch* sp;
+  if (int rc = getScratch(&sp)) return rc;
+  if (!sp->findRow) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sp->findRow), 64));
+  uint64_t n = 0;
+  if (const int rc = scanDevice(p, d_hay, len, base, 1, sp->findRow, 1, &n, stream, nullptr, 2)) return rc;
+  if (n != 0) {
+    int64_t row[2];
+    HIP_TRY(hipMemcpy(row, sp->findRow, 16, hipMemcpyDeviceToHost));
+    *found = 1; span[0] = row[0]; span[1] = row[1];
+  }
+  return CXG_OK;
+}
+int cxg_is_match_device(const cxg_program* p, const void* d_hay, uint64_t len, int* matched, void* stream) {
+  if (!matched) return fail(CXG_E_INVALID, "null argument");
+  uint64_t n = 0;
+  *matched = 0;
+  if (const int rc = scanDevice(p, d_hay, len, 0, 1, nullptr, 0, &n, stream, nullptr, 2)) return rc;
+  *matched = n != 0 ? 1 : 0;
+  return CXG_OK;
 }
 // ---- asynchronous device entry (round 5) -------------------------------------------------------------------------------------
 // cxg_find_all_device without the stream synchronisation at its end: the first span launch of the call is left in flight and

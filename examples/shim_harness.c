@@ -174,8 +174,50 @@ static int find_all_submatch_hip(const hip_program* h, const uint8_t* hay, uint6
   }
 }
 
+/* Thread hygiene (round 6; findall_hip.go's worker pool): the library's scratch is per OS thread.  `threads N SPEC FILE`: N short-lived
+ * threads, one after another in groups of 8, each runs find_all_hip once over FILE and exits; the device's free memory is printed before,
+ * after the threads are gone, and after the main thread's own cxg_thread_release — thread_local destructors must have handed everything
+ * back (what the Go runtime's thread churn would otherwise leave behind). */
+#include <pthread.h>
+typedef struct { const hip_program* h; const uint8_t* hay; uint64_t len; uint64_t got; int ok; } thread_job;
+static void* thread_main(void* arg) {
+  thread_job* j = (thread_job*)arg;
+  int64_t* rows = NULL;
+  int retries = 0;
+  j->ok = find_all_hip(j->h, j->hay, j->len, -1, &rows, &j->got, &retries);
+  free(rows);
+  return NULL;                                                 /* no cxg_thread_release: the thread's exit must do it */
+}
+static int threads_mode(int nthreads, char* spec, const char* file) {
+  hip_init();
+  uint64_t len = 0;
+  uint8_t* hay = read_file(file, &len);
+  hip_program h = build_hip_program("nfa", spec);
+  if (!h.p) { fprintf(stderr, "device path refuses the program: %s\n", cxg_last_error()); return 4; }
+  uint64_t want = 0, f0 = 0, f1 = 0, f2 = 0, tot = 0;
+  { int64_t* rows = NULL; int retries = 0; if (!find_all_hip(&h, hay, len, -1, &rows, &want, &retries)) return 1; free(rows); }   /* main thread: context, program image, its own scratch */
+  cxg_device_mem_info(0, &f0, &tot);
+  for (int base = 0; base < nthreads; base += 8) {
+    pthread_t th[8];
+    thread_job job[8];
+    const int n = nthreads - base < 8 ? nthreads - base : 8;
+    for (int i = 0; i < n; i++) { job[i].h = &h; job[i].hay = hay; job[i].len = len; job[i].got = 0; job[i].ok = 0; pthread_create(&th[i], NULL, thread_main, &job[i]); }
+    for (int i = 0; i < n; i++) { pthread_join(th[i], NULL); if (!job[i].ok || job[i].got != want) { fprintf(stderr, "thread %d: %d rows, want %llu\n", base + i, (int)job[i].got, (unsigned long long)want); return 1; } }
+  }
+  cxg_device_mem_info(0, &f1, &tot);
+  cxg_thread_release();
+  cxg_device_mem_info(0, &f2, &tot);
+  printf("# %d threads x %llu rows; device free bytes before %llu, after the threads %llu, after cxg_thread_release %llu\n", nthreads, (unsigned long long)want,
+         (unsigned long long)f0, (unsigned long long)f1, (unsigned long long)f2);
+  printf("leaked_by_threads %lld\n", (long long)f0 - (long long)f1);
+  cxg_program_destroy(h.p);
+  free(hay);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc != 4) { fprintf(stderr, "usage: %s nfa|submatch|literals|charclass SPEC FILE\n", argv[0]); return 2; }
+  if (argc == 5 && !strcmp(argv[1], "threads")) return threads_mode(atoi(argv[2]), argv[3], argv[4]);
+  if (argc != 4) { fprintf(stderr, "usage: %s nfa|submatch|literals|charclass SPEC FILE | threads N SPEC FILE\n", argv[0]); return 2; }
   const char* mode = argv[1];
   if (strcmp(mode, "nfa") && strcmp(mode, "submatch") && strcmp(mode, "literals") && strcmp(mode, "charclass")) { fprintf(stderr, "unknown mode %s\n", mode); return 2; }
   hip_init();

@@ -163,6 +163,8 @@ int cxg_path_reset(int device);
  * 2 delimiter kernel): the mode is demoted for its current term, exactly as a real hit would. */
 int cxg_debug_demote(int device, int mode);
 int cxg_device_count(void);                /* gfx950 devices visible; 0 => every search returns CXG_E_NO_GPU */
+int cxg_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);   /* hipMemGetInfo of that device: a host sizes its shards with it, the
+                                                                                    thread-hygiene test watches it (round 6) */
 int cxg_set_device(int device);            /* per-thread device for subsequent calls (default 0) */
 /* Frees the calling thread's stream, events, pinned buffers and HBM staging (they are per OS thread and are also freed
  * when the thread exits).  A host whose callers hop across threads (cgo) may call it when a thread goes idle. */
@@ -222,6 +224,12 @@ int cxg_program_nfa(const cxg_program* p, cxg_nfa* out);
 int cxg_find_all(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit,
                  int64_t* spans /* [cap][2] */, uint64_t cap, uint64_t* n_out);
 int cxg_count(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit, uint64_t* n_out);
+/* (*Engine).Find (meta/find.go:29) and (*Engine).IsMatch (meta/ismatch.go:27) of a whole haystack (round 6): the first match in haystack
+ * order — FindAll with n == 1, whose early stop lets workgroups that start after the first row has been counted leave at once.  *found /
+ * *matched are 0 or 1; span = (start, end) of the match when found.  Same error conventions as cxg_find_all: anything but CXG_OK means
+ * "run the CPU search". */
+int cxg_find(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t span[2], int* found);
+int cxg_is_match(const cxg_program* p, const uint8_t* hay, uint64_t len, int* matched);
 int cxg_find_all_submatch(const cxg_program* p, const uint8_t* hay, uint64_t len, int64_t limit,
                           int64_t* slots /* [cap][2*groups], -1 unset */, uint64_t cap, uint64_t* n_out);
 
@@ -245,6 +253,9 @@ int cxg_find_all_device(const cxg_program* p, const void* d_hay, uint64_t len, i
 int cxg_find_all_submatch_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base,
                                  int64_t limit, void* d_out, uint64_t cap, uint64_t* n_out, void* stream,
                                  cxg_timing* timing);
+
+int cxg_find_device(const cxg_program* p, const void* d_hay, uint64_t len, int64_t base, int64_t span[2], int* found, void* stream);
+int cxg_is_match_device(const cxg_program* p, const void* d_hay, uint64_t len, int* matched, void* stream);
 
 /* Asynchronous form of cxg_find_all_device (round 5): the call returns with its span launch in flight on `stream` (NULL: the calling
  * thread's own); cxg_wait — on the SAME thread — completes it and returns what cxg_find_all_device would have returned (a launch that

@@ -21,7 +21,9 @@ import "C"
 
 import (
 	"runtime"
+	"sync"
 	"sync/atomic"
+	"time"
 	"unsafe"
 
 	"github.com/coregx/coregex/nfa"
@@ -46,6 +48,64 @@ func init() {
 	if C.cxg_abi_version() != C.CXG_ABI_VERSION {
 		panic("coregex_hip: library ABI differs from the header this file was compiled against")
 	}
+}
+
+// The library keeps its per-call scratch — a HIP stream, pinned control words, up to 256 MiB of HBM staging for host haystacks and
+// rows — per OS THREAD (thread_local: the SearchState analogue), and a search must start and finish on one thread.  Goroutines
+// migrate between the runtime's threads, and the runtime grows its thread count under blocking cgo calls: called from arbitrary
+// goroutines the library would leave a scratch block behind on every M the runtime ever used.  So every search entry runs on one
+// of a FIXED set of worker goroutines, each locked to its OS thread for life; a worker that has been idle for hipIdleRelease hands its
+// scratch back (cxg_thread_release) and takes it again on its next call.  hipWorkers bounds the device memory the binding can
+// pin: hipWorkers x 256 MiB, whatever GOMAXPROCS and however many goroutines call FindAll.  (Calls of different workers take
+// turns on the device inside the library — the scans are HBM-bound — so more workers than a few buy overlap of the PCIe copies only.)
+const (
+	hipWorkers     = 4
+	hipIdleRelease = 30 * time.Second
+)
+
+var (
+	hipPoolOnce sync.Once
+	hipJobs     chan func()
+)
+
+func hipWorker() {
+	runtime.LockOSThread() // never unlocked: the thread dies with the goroutine, and its thread_local scratch with it
+	idle := time.NewTimer(hipIdleRelease)
+	released := true
+	for {
+		select {
+		case job := <-hipJobs:
+			job()
+			released = false
+			if !idle.Stop() {
+				select {
+				case <-idle.C:
+				default:
+				}
+			}
+			idle.Reset(hipIdleRelease)
+		case <-idle.C:
+			if !released {
+				C.cxg_thread_release()
+				released = true
+			}
+			idle.Reset(hipIdleRelease)
+		}
+	}
+}
+
+// hipDo runs f on a worker thread and waits for it.  The haystack and result slices f hands to C stay reachable through the
+// caller's frame for the duration (cgo pins what a call passes; nothing is retained past return).
+func hipDo(f func()) {
+	hipPoolOnce.Do(func() {
+		hipJobs = make(chan func())
+		for i := 0; i < hipWorkers; i++ {
+			go hipWorker()
+		}
+	})
+	done := make(chan struct{})
+	hipJobs <- func() { f(); close(done) }
+	<-done
 }
 
 // buildHipProgram runs once per Engine, at the end of CompileRegexp (hooks.patch, meta/compile.go).
@@ -257,8 +317,13 @@ func (e *Engine) nfaProgram(strategy C.int, captures bool) *C.cxg_program {
 	return prog
 }
 
-// bumpStats: once per batch, what the CPU loop would have counted per search is not known here — the batch counts as one
-// search of the engine family that would have run (meta/engine.go:159-183; SURVEY section 5).
+// bumpStats: once per batch, what the CPU loop would have counted per search is not known here — the batch counts as ONE search
+// of the engine family that would have run (meta/engine.go:159-183; SURVEY section 5): DFASearches += 1 for the DFA strategies,
+// NFASearches += 1 for UseNFA / UseBoundedBacktracker and for every FindAllSubmatch batch (the CPU path of those is the PikeVM,
+// meta/findall.go:89-98), and for the prefilter strategies PrefilterHits += rows — the CPU loop counts a hit per candidate that
+// verified, which for Teddy and the digit prefilter is once per match.  PrefilterMisses, the cache-fill counters and the
+// per-search fallback counters stay untouched: nothing on the device corresponds to them.  A host that reads Stats to decide
+// about engines sees the batches as cheap DFA searches, which is what they are from its side.
 func (e *Engine) bumpHipStats(rows int) {
 	switch e.strategy {
 	case UseNFA, UseBoundedBacktracker:
@@ -286,8 +351,11 @@ func (e *Engine) findAllHip(haystack []byte, n int, results [][2]int) ([][2]int,
 	for {
 		var got C.uint64_t
 		results = results[:cap(results)]
-		rc := C.cxg_find_all(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit,
-			(*C.int64_t)(unsafe.Pointer(&results[0])), C.uint64_t(len(results)), &got) // [2]int is int64[2] on the 64-bit targets the library exists for
+		var rc C.int
+		hipDo(func() {
+			rc = C.cxg_find_all(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit,
+				(*C.int64_t)(unsafe.Pointer(&results[0])), C.uint64_t(len(results)), &got) // [2]int is int64[2] on the 64-bit targets the library exists for
+		})
 		switch rc {
 		case C.CXG_OK:
 			e.bumpHipStats(int(got))
@@ -300,6 +368,44 @@ func (e *Engine) findAllHip(haystack []byte, n int, results [][2]int) ([][2]int,
 	}
 }
 
+// findHip is the device path of Find (meta/find.go:29): the first match of a whole haystack — FindAll with n == 1 on the device,
+// whose early stop lets the workgroups behind the first counted row leave at once.  Worth it for haystacks whose first match is far
+// in (or absent); a match in the first few KiB is found faster by the CPU search, which is why the threshold is the batch path's.
+func (e *Engine) findHip(haystack []byte) (*Match, bool) {
+	if e.hip == nil || e.hip.p == nil || len(haystack) < hipThreshold {
+		return nil, false
+	}
+	var span [2]C.int64_t
+	var found, rc C.int
+	hipDo(func() {
+		rc = C.cxg_find(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), &span[0], &found)
+	})
+	if rc != C.CXG_OK {
+		return nil, false
+	}
+	e.bumpHipStats(int(found))
+	if found == 0 {
+		return nil, true
+	}
+	return NewMatch(int(span[0]), int(span[1]), haystack), true
+}
+
+// isMatchHip is the device path of IsMatch (meta/ismatch.go:27).
+func (e *Engine) isMatchHip(haystack []byte) (matched bool, ok bool) {
+	if e.hip == nil || e.hip.p == nil || len(haystack) < hipThreshold {
+		return false, false
+	}
+	var m, rc C.int
+	hipDo(func() {
+		rc = C.cxg_is_match(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), &m)
+	})
+	if rc != C.CXG_OK {
+		return false, false
+	}
+	e.bumpHipStats(int(m))
+	return m != 0, true
+}
+
 // countHip is the batch path of Count (meta/findall.go:297).
 func (e *Engine) countHip(haystack []byte, n int) (int, bool) {
 	if e.hip == nil || e.hip.p == nil || len(haystack) < hipThreshold {
@@ -310,7 +416,11 @@ func (e *Engine) countHip(haystack []byte, n int) (int, bool) {
 		limit = C.int64_t(n)
 	}
 	var got C.uint64_t
-	if C.cxg_count(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit, &got) != C.CXG_OK {
+	var rc C.int
+	hipDo(func() {
+		rc = C.cxg_count(e.hip.p, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit, &got)
+	})
+	if rc != C.CXG_OK {
 		return 0, false
 	}
 	e.bumpHipStats(int(got))
@@ -331,8 +441,11 @@ func (e *Engine) findAllSubmatchHip(haystack []byte, n int) ([]*MatchWithCapture
 	rows := make([]int64, (len(haystack)/100+1)*width)
 	for {
 		var got C.uint64_t
-		rc := C.cxg_find_all_submatch(e.hip.sub, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit,
-			(*C.int64_t)(unsafe.Pointer(&rows[0])), C.uint64_t(len(rows)/width), &got)
+		var rc C.int
+		hipDo(func() {
+			rc = C.cxg_find_all_submatch(e.hip.sub, (*C.uint8_t)(unsafe.Pointer(&haystack[0])), C.uint64_t(len(haystack)), limit,
+				(*C.int64_t)(unsafe.Pointer(&rows[0])), C.uint64_t(len(rows)/width), &got)
+		})
 		switch rc {
 		case C.CXG_OK:
 			out := make([]*MatchWithCaptures, int(got))

@@ -17,3 +17,7 @@ func (e *Engine) countHip(haystack []byte, n int) (int, bool) { return 0, false 
 func (e *Engine) findAllSubmatchHip(haystack []byte, n int) ([]*MatchWithCaptures, bool) {
 	return nil, false
 }
+
+func (e *Engine) findHip(haystack []byte) (*Match, bool) { return nil, false }
+
+func (e *Engine) isMatchHip(haystack []byte) (bool, bool) { return false, false }

@@ -369,3 +369,21 @@ extern "C" int orc_baseline_all_cores(const char* pattern, int64_t plen, int con
   out[3] = static_cast<uint64_t>(nthreads);
   return 0;
 }
+
+// How many cores does this process REALLY get?  nthreads threads each spin through `iters` dependent multiply-adds; returns the wall
+// nanoseconds.  bench.py compares 1 thread with all visible threads: a container with a CPU quota (or an oversubscribed host) shows
+// far fewer effective cores than its affinity mask (round 6: 256 visible, ~8 effective on the GPU box) — the all-cores leg then
+// runs on what is really there and says so.
+extern "C" uint64_t orc_spin_ns(int nthreads, uint64_t iters) {
+  std::atomic<uint64_t> sink{0};
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back([&, t]() {
+    uint64_t x = 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(t);
+    for (uint64_t i = 0; i < iters; i++) x = x * 6364136223846793005ull + 1442695040888963407ull;
+    sink.fetch_add(x, std::memory_order_relaxed);
+  });
+  for (auto& x : th) x.join();
+  const auto t1 = std::chrono::steady_clock::now();
+  return static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count()) + (sink.load() == 1 ? 1 : 0);
+}

@@ -255,7 +255,7 @@ def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "coregex_amd", "csrc"), "rocm"])
     exe = tmp_path / "shim_harness"
-    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shim_harness.c"),
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shim_harness.c"),
                            "-L", os.path.join(ROOT, "coregex_amd"), "-lcoregex_hip_rocm", "-o", str(exe)])
     hay = cx.synth_pages(cfg, 0xC0FFEE00 + cfg, 21, 256).tobytes()          # 1 MiB: the shim's hipThreshold
     f = tmp_path / "hay.log"
@@ -269,6 +269,27 @@ def test_c_shim_harness(oracle, tmp_path, mode, spec, cfg, pat):
     assert rows == exp.tolist()
     if cfg == 4:                                             # [\w]+: ~1 row per 5.5 bytes >> len/100+1: the retry loop ran
         assert "1 capacity retries" in outp.stdout
+
+
+@pytest.mark.gpu
+def test_short_lived_threads_leave_device_memory_flat(tmp_path):
+    """Round 6: the library's scratch — stream, pinned words, HBM staging — is per OS thread; a cgo host whose
+    goroutines wander over the runtime's threads would leave a block behind on each.  integration/go/meta/findall_hip.go runs every search
+    on a fixed pool of OS-locked workers; what this test pins is the other half: 64 threads that search once and EXIT (no
+    cxg_thread_release) hand everything back through their thread_local destructors — examples/shim_harness.c `threads`."""
+    lib = os.path.join(ROOT, "coregex_amd", "libcoregex_hip_rocm.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "coregex_amd", "csrc"), "rocm"])
+    exe = tmp_path / "shim_harness"
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "shim_harness.c"),
+                           "-L", os.path.join(ROOT, "coregex_amd"), "-lcoregex_hip_rocm", "-o", str(exe)])
+    f = tmp_path / "hay.log"
+    f.write_bytes(cx.synth_pages(2, 0xC0FFEE02, 5, 1024).tobytes())         # 4 MiB: host staging of 4 MiB + rows per thread
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "coregex_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    outp = subprocess.run([str(exe), "threads", "64", r"\d+\.\d+\.\d+\.\d+", str(f)], env=env, capture_output=True, text=True, timeout=300)
+    assert outp.returncode == 0, outp.stderr
+    leaked = [int(ln.split()[1]) for ln in outp.stdout.splitlines() if ln.startswith("leaked_by_threads")]
+    assert leaked and leaked[0] < (32 << 20), outp.stdout                    # 64 threads x (4 MiB + rows) would be > 300 MiB if nothing came back
 
 
 def test_span_program_of_an_nfa_with_groups(oracle):
