@@ -40,7 +40,7 @@ hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* pe
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream, uint32_t direct_bytes = 0);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes = 0);
 }  // namespace cxgdev
 
 namespace {
@@ -737,7 +737,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
     fsmDirectRan = fsmDirect && !deepOnly && fh->direct_off != 0u && fh->depth <= 1 && fh->nk == 1 && a.prof == nullptr && a.dbg == 0;
-    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->nk > 1, stream, fsmDirectRan ? fh->direct_bytes : 0u);
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->end_col != 0u ? 2 : (fh->nk > 1 ? 1 : 0), stream, fsmDirectRan ? fh->direct_bytes : 0u);
   }
   else if (gen == 11) {
     std::memcpy(a.chain, p->delim, sizeof p->delim);

@@ -162,7 +162,7 @@ CXG_BT_HD uint32_t bt_captures(const BtHeader* h, const uint8_t* hay, int64_t* r
         else if (x.lo == 4) ok = bt_word_byte(left) != bt_word_byte(right);  // WordBoundary
         else if (x.lo == 5) ok = bt_word_byte(left) == bt_word_byte(right);  // NoWordBoundary
         else if (x.lo == 0) ok = !has_left;                                  // StartText (round 4): the first position of the haystack
-        else ok = false;                                                    // EndText: not in the device subset
+        else ok = !has_right;                                                // EndText (round 6): behind the haystack's last byte
         if (!ok) break;
         q = x.next;
       } else break;                                                    // FAIL

@@ -96,7 +96,9 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t d_slots;                                // rows ("slots"); an entry is the slot of the next row
   uint32_t d_racc_lo, d_rstart;                    // reverse automaton in the same slot space: accepting slots >= d_racc_lo, start slot; slot value 0 = dead
   uint32_t d_top;                                  // slot of the set "any state"
-  uint32_t d_pad[4];
+  uint32_t end_col;                                // != 0: the pattern holds an end-of-text anchor (\z, $ without (?m)): 2 * the kind "end of the text" — a kind NO byte
+                                                   // has; the step over the haystack's last byte takes column class + end_col (fsm.hpp "End of text")
+  uint32_t d_pad[3];
 };
 constexpr uint32_t kFsmdMaxBytes = 12288u;         // largest direct section the kernel has an instantiation for: beyond it the rows cost a resident workgroup per CU and their
                                                    // reads collide in the LDS banks (README IPv4 pattern, 20 KiB: 0.71 ms against 0.62 class-indexed — profiles/r06_c2_*)
@@ -111,6 +113,13 @@ constexpr uint32_t kFsmdMaxBytes = 12288u;         // largest direct section the
 // reported by the step over byte i as always.  The reverse DFA mirrors it: the step over byte i (walking down) sees
 // the kind of hay[i-1].  Only the class lookup changes — it is part of the Mem concept below, so programs without
 // assertions (nk == 1) compile to the same instructions as before.
+//
+// End of text (`\z`, `$` without (?m); nfa.LookEndText, nfa/pikevm.go:1651: pos == len) inside an unanchored pattern (`a$|z`).  The
+// position behind the haystack is no byte: it gets a kind of its own (the LAST of the nk kinds, FsmHeader::end_col = 2 * kind), which
+// is a line edge and not a word byte like the other outside position, and the only kind at which the anchor holds.  Exactly one
+// forward step sees it — the step over the haystack's last byte — and one reverse start row (a match that ends at len); a thread
+// that passed the anchor can consume nothing, so everything else runs as if the anchor never held.  LOOK == 2 instantiations
+// compare a step's position with the last byte's (Mem::last()) and swap the kind in: two VALU per byte, for these programs only.
 CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
 struct FsmView {
   const uint8_t* cls2;      // 2 * nk * class of a byte: byte offset of the class's first column
@@ -121,19 +130,25 @@ struct FsmView {
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
   uint32_t alias_lo, u_lo, top_off, rev_start_off, rev_accept_off;
   uint32_t rev_text_col;    // FsmHeader::rev_text_col
+  uint32_t end_col;         // FsmHeader::end_col
   uint32_t create_lo, rematch_lo;
   const uint8_t* mem;       // members of the set rows
   uint32_t row_shift;
 };
 // Class lookups of a Mem type, from its byte() / dword(): CRTP base shared by the kernel's LDS window and the twin's
-// host memory.  LOOK = the image has nk == 2.
-template <class Derived, bool LOOK>
+// host memory.  LOOK: 0 = no assertions (nk == 1), 1 = the image has nk > 1, 2 = ... and an end-of-text kind (the Mem type then
+// has int32_t last(): position of the haystack's last byte, relative like every position; out of reach: any value no step takes).
+template <class Derived, int LOOK>
 struct FsmClassify {
   CXG_FSM_HD const Derived& self() const { return *static_cast<const Derived*>(this); }
   // column offset of the forward step over byte i
   CXG_FSM_HD uint32_t cls(const FsmView& v, int32_t i) const {
     uint32_t c = v.cls2[self().byte(i)];
-    if (LOOK) c += v.knd[self().byte(i + 1)];
+    if (LOOK) {
+      uint32_t kn = v.knd[self().byte(i + 1)];
+      if (LOOK == 2) kn = i == self().last() ? v.end_col : kn;
+      c += kn;
+    }
     return c;
   }
   // ... of the four steps over the aligned dword at r
@@ -141,8 +156,12 @@ struct FsmClassify {
     const uint32_t d = self().dword(r);
     k[0] = v.cls2[d & 0xFFu]; k[1] = v.cls2[(d >> 8) & 0xFFu]; k[2] = v.cls2[(d >> 16) & 0xFFu]; k[3] = v.cls2[d >> 24];
     if (LOOK) {
-      k[0] += v.knd[(d >> 8) & 0xFFu]; k[1] += v.knd[(d >> 16) & 0xFFu]; k[2] += v.knd[d >> 24];
-      k[3] += v.knd[self().byte(r + 4)];
+      uint32_t kn[4] = {v.knd[(d >> 8) & 0xFFu], v.knd[(d >> 16) & 0xFFu], v.knd[d >> 24], v.knd[self().byte(r + 4)]};
+      if (LOOK == 2) {
+        const int32_t dl = self().last() - r;
+        kn[0] = dl == 0 ? v.end_col : kn[0]; kn[1] = dl == 1 ? v.end_col : kn[1]; kn[2] = dl == 2 ? v.end_col : kn[2]; kn[3] = dl == 3 ? v.end_col : kn[3];
+      }
+      k[0] += kn[0]; k[1] += kn[1]; k[2] += kn[2]; k[3] += kn[3];
     }
   }
   // column offset of the reverse step over byte i (walking down)
@@ -154,7 +173,9 @@ struct FsmClassify {
   // reverse start row for a match that ends at e
   CXG_FSM_HD uint32_t rstart(const FsmView& v, int32_t e) const {
     if (!LOOK) return v.rev_start_off;
-    const uint32_t idx = (v.knd[self().byte(e - 1)] >> 1) * v.nk + (v.knd[self().byte(e)] >> 1);
+    uint32_t right = v.knd[self().byte(e)];
+    if (LOOK == 2) right = e == self().last() + 1 ? v.end_col : right;
+    const uint32_t idx = (v.knd[self().byte(e - 1)] >> 1) * v.nk + (right >> 1);
     return fsm_u16(v.knd, 256u + 2u * v.nk + 2u * idx);
   }
   // start row of the search at the haystack's first byte (tile-relative position 0 of the first tile)
@@ -162,7 +183,7 @@ struct FsmClassify {
     if (!LOOK) return 0u;
     return fsm_u16(v.knd, 256u + v.knd[self().byte(0)]);
   }
-  static constexpr bool kLook = LOOK;
+  static constexpr bool kLook = LOOK != 0;
 };
 // the state's own row (an alias row is a copy of it)
 CXG_FSM_HD uint32_t fsm_canon(const FsmView& v, uint32_t x) { return fsm_u16(v.tab, x + v.ncls2 + 4u); }

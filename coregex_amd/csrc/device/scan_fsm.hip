@@ -59,9 +59,11 @@ constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the
 // that is in flight: the prefetch would be worth nothing.  Walks that leave the window are finished elsewhere: a match
 // start in front of the window in the epilogue (rows marked unresolved), a walk past the window's end by the fallback.
 typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
-template <bool LOOK>
+template <int LOOK>
 struct FsmMem : FsmClassify<FsmMem<LOOK>, LOOK> {
   lds_bytes_t win;         // this wave's LDS window: tile-relative bytes [-kFsmLeft, 4096 - kFsmLeft)
+  int32_t last_;           // LOOK == 2: tile-relative position of the haystack's last byte (fsm.hpp "End of text")
+  __device__ __forceinline__ int32_t last() const { return last_; }
   __device__ __forceinline__ uint32_t byte(int32_t r) const {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
     return win[w + (w >> 6) * 4u];
@@ -89,7 +91,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.rev = body + (h->rev_off - hs);
   v.ncls2 = 2u * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   v.knd = body + (h->knd_off - hs);
@@ -370,8 +372,9 @@ __device__ __forceinline__ uint32_t fsm_rows_from_events(const uint64_t (&KK)[2]
 
 // SHALLOW: the machine never holds more than one pending match (FsmHeader::depth <= 1): rows from two event bitmaps
 // per sub-chunk instead of a recorded event list (fsm.hpp).  MODE: buffer geometry by match density (FsmMode).
-// LOOK: the image has word-boundary assertions (nk == 2): a step's class also reads the next byte (fsm.hpp "Look-around").
-template <bool SHALLOW, int IMG, int MODE, bool LOOK>
+// LOOK: 1 = the image has assertions (nk > 1): a step's class also reads the next byte (fsm.hpp "Look-around"); 2 = ... and an
+// end-of-text anchor: the step over the haystack's last byte takes the column of the kind no byte has (fsm.hpp "End of text").
+template <bool SHALLOW, int IMG, int MODE, int LOOK>
 __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE> S;
   constexpr int kLaneRows = FsmMode<MODE>::kRows, kLaneEvents = FsmMode<MODE>::kEvents, kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
       const int32_t rev_lowest = (LOOK && tile_lo) ? lowest + 1 : lowest;
       FsmMem<LOOK> m;
       m.win = (lds_bytes_t)win;
+      m.last_ = rend - 1;
       // ---- E + R: entry states, replay.  A lane's 64 bytes are two sub-chunks of 32 walked in lockstep (two
       // independent chains of dependent LDS reads per lane).
       const int32_t c0 = (lane - 1) * kFsmChunk;
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
         if (prev > s || s == e) {                                           // rare: walk again from HBM / L2, bounded
           const int64_t lo = prev > 0 ? prev : 0;
           uint32_t sr = v.rev_start_off;
-          if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + (v.knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : outside] >> 1)));
+          if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + ((static_cast<uint64_t>(e) < a.len ? v.knd[a.hay[e]] : (LOOK == 2 ? v.end_col : v.knd[outside])) >> 1)));
           int64_t st = -1, at = e - 1;
           for (; at >= lo; at--) {
             if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
@@ -835,7 +839,8 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   const uint8_t* rev = a.blob + h->rev_off;
   const bool look = h->nk > 1;
   const uint32_t outside = h->outside_byte;
-  uint32_t sr = look ? fsm_u16(knd, 256u + 2u * h->nk + 2u * ((knd[a.hay[e - 1]] >> 1) * h->nk + (knd[static_cast<uint64_t>(e) < a.len ? a.hay[e] : outside] >> 1))) : h->rev_start_off;
+  const uint32_t right = static_cast<uint64_t>(e) < a.len ? knd[a.hay[e]] : (h->end_col ? h->end_col : knd[outside]);   // (fsm.hpp "End of text")
+  uint32_t sr = look ? fsm_u16(knd, 256u + 2u * h->nk + 2u * ((knd[a.hay[e - 1]] >> 1) * h->nk + (right >> 1))) : h->rev_start_off;
   int64_t st = -1;
   for (int64_t at = e - 1; at >= prev; at--) {
     sr = fsm_u16(rev, sr + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
@@ -1054,7 +1059,7 @@ __global__ __launch_bounds__(kThreads, (MODE == 2 ? 2 : 4)) void k_scan_fsmd(Sca
 }
 
 namespace {
-template <int IMG, bool LOOK>
+template <int IMG, int LOOK>
 void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 block, hipStream_t stream) {
   if (shallow) {
     if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 0, LOOK>), grid, block, 0, stream, a);
@@ -1078,7 +1083,8 @@ void launch_fsmd_img(const ScanArgs& a, int mode, dim3 grid, dim3 block, hipStre
 }  // namespace
 
 // direct_bytes != 0: the direct mode's kernel (the caller has checked that the image carries the section and the machine is shallow)
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, bool look, hipStream_t stream, uint32_t direct_bytes) {
+// look: 0 / 1 / 2 as the kernel's LOOK (2: FsmHeader::end_col != 0 — rare programs, one image size only)
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
   if (lds_bytes > 28672) return hipErrorInvalidValue;
@@ -1087,14 +1093,15 @@ hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, 
     if (direct_bytes <= 6144) launch_fsmd_img<6144>(a, mode, grid, block, stream);
     else launch_fsmd_img<12288>(a, mode, grid, block, stream);
   }
+  else if (look == 2) launch_fsm_img<28672, 2>(a, shallow, mode, grid, block, stream);             // end-of-text programs
   else if (look) {                                                                                   // word-boundary programs
-    if (lds_bytes <= 3072) launch_fsm_img<3072, true>(a, shallow, mode, grid, block, stream);
-    else if (lds_bytes <= 10240) launch_fsm_img<10240, true>(a, shallow, mode, grid, block, stream);
-    else launch_fsm_img<28672, true>(a, shallow, mode, grid, block, stream);
+    if (lds_bytes <= 3072) launch_fsm_img<3072, 1>(a, shallow, mode, grid, block, stream);
+    else if (lds_bytes <= 10240) launch_fsm_img<10240, 1>(a, shallow, mode, grid, block, stream);
+    else launch_fsm_img<28672, 1>(a, shallow, mode, grid, block, stream);
   }
-  else if (lds_bytes <= 3072) launch_fsm_img<3072, false>(a, shallow, mode, grid, block, stream);   // instantiations by image size
-  else if (lds_bytes <= 10240) launch_fsm_img<10240, false>(a, shallow, mode, grid, block, stream);
-  else launch_fsm_img<28672, false>(a, shallow, mode, grid, block, stream);
+  else if (lds_bytes <= 3072) launch_fsm_img<3072, 0>(a, shallow, mode, grid, block, stream);   // instantiations by image size
+  else if (lds_bytes <= 10240) launch_fsm_img<10240, 0>(a, shallow, mode, grid, block, stream);
+  else launch_fsm_img<28672, 0>(a, shallow, mode, grid, block, stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || a.out == nullptr || a.ngroups < 2) return e;
   const unsigned fb = 256, fg = static_cast<unsigned>((a.ngroups + fb - 1) / fb);

@@ -1537,7 +1537,19 @@ Plan selectStrategyOf(const Ast& ast, const HostNfa& nfa) {
   }
   // selectReverseStrategy returns at once for word boundaries (:988) and for an end anchor that does not end the pattern
   // in the sense of nfa.isEndAnchored — which (?m)$ never does (nfa.HasImpossibleEndAnchor, nfa/compile.go:1858-1888)
-  if (!fastPrefix && !wordB && !sh.has(root, {Node::EndLine})) {
+  std::function<bool(int)> endsWithTextAnchor = [&](int n) -> bool {   // nfa.isEndAnchored, nfa/compile.go:1798-1824 (as in textAnchorStrategy below)
+    const auto& x = ast.at(n);
+    switch (x.kind) {
+      case Node::EndText: return true;
+      case Node::Concat: return !x.kids.empty() && endsWithTextAnchor(x.kids.back());
+      case Node::Capture: return !x.kids.empty() && endsWithTextAnchor(x.kids[0]);
+      case Node::Alt: if (x.kids.empty()) return false; for (int c : x.kids) if (!endsWithTextAnchor(c)) return false; return true;
+      default: return false;
+    }
+  };
+  // (round 6: `$[a-z0-9]+:-`, `(\s|$)abc[0-4]+ ` — a \z / $ that does not end the pattern is an impossible end anchor too)
+  const bool impossibleEnd = sh.has(root, {Node::EndLine}) || (sh.has(root, {Node::EndText}) && !endsWithTextAnchor(root));
+  if (!fastPrefix && !wordB && !impossibleEnd) {
     int reverse = 0;
     bool decided = false;
     Lits suf = lx.suffixes(root, 0);

@@ -32,7 +32,8 @@ struct Stepper {
   // behind it (word[k] / newline[k] say what kind k is; the positions outside the haystack have a kind too: not a word
   // byte, and a line edge); checkLook, nfa/pikevm.go:1646-1674
   int left = 0, right = 0;
-  bool word[3] = {false, false, false}, newline[3] = {false, false, false};
+  bool word[4] = {false, false, false, false}, newline[4] = {false, false, false, false};
+  bool endText[4] = {false, false, false, false};                  // the kind "behind the haystack's last byte" (round 6): no byte has it
   bool textStart = false;                                          // the position is the start of the text (\A, ^ without (?m)): only the
                                                                    // search at the haystack's first byte and the reverse walk that reaches it
   explicit Stepper(const cxg_nfa& nfa) : n(nfa), mark(nfa.n_states, 0) {}
@@ -42,7 +43,8 @@ struct Stepper {
     if (look == kLookStartLine) return newline[left];            // pos == 0 || hay[pos-1] == '\n'
     if (look == kLookEndLine) return newline[right];             // pos == len || hay[pos] == '\n'
     if (look == kLookStartText) return textStart;
-    return false;                                                // \z / $: refused before any closure is taken
+    if (look == kLookEndText) return endText[right];             // pos == len
+    return false;
   }
   void closure(std::vector<uint32_t>& out, uint32_t seed) {      // epsilonClosureInto, builder.go:245-293
     stack.clear();
@@ -108,23 +110,29 @@ bool buildFsmImage(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::ve
 namespace {
 bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, std::vector<uint8_t>& image, std::string& why, const cxg_nfa* revNfa, const uint32_t rowBudget) {
   image.clear();
-  bool hasWord = false, hasLine = false, hasText = false;
+  bool hasWord = false, hasLine = false, hasText = false, hasEnd = false;
   for (uint32_t i = 0; i < nfa.n_states; i++)
     if (nfa.states[i].kind == CXG_NFA_LOOK) {
       const uint8_t lk = nfa.states[i].lo;
       if (lk == kLookWordBoundary || lk == kLookNoWordBoundary) hasWord = true;
       else if (lk == kLookStartLine || lk == kLookEndLine) hasLine = true;
       else if (lk == kLookStartText) hasText = true;
-      else { why = "end-of-text anchor in NFA (\\z, $ without (?m): not served; \\A and ^ are)"; return false; }
+      else if (lk == kLookEndText) hasEnd = true;
+      else { why = "unknown assertion in NFA"; return false; }
     }
   // Text start (\A, ^ without (?m); nfa.LookStartText, dfa/lazy/start.go:64-172 StartText): holds at position 0 and nowhere else.
   // Forward it only changes the state the scan STARTS in (the start rows below are closed with it); positions > 0 are searched
   // from states closed without it.  Backward it can only make position 0 a match start: every reverse state carries a flag
   // "accepting if this is the start of the text", read by the walk that arrives at position 0 alive (fsm.hpp fsm_match_start).
-  const bool hasLook = hasWord || hasLine || hasText;
+  // Text end (\z, $ without (?m); nfa.LookEndText, nfa/pikevm.go:1651; round 6): holds at position len and nowhere else.  The position
+  // behind the haystack gets a kind of its own, the last one (kEnd): not a word byte, a line edge, and the only right-hand kind at
+  // which the anchor holds.  The step over the haystack's last byte takes its column (fsm.hpp "End of text"); nothing else ever does.
+  const bool hasLook = hasWord || hasLine || hasText || hasEnd;
   if (hasLook && !revNfa) { why = "internal: look-around program without its reversed NFA"; return false; }
   // kinds of the byte behind a step (fsm.hpp "Look-around"): what the pattern's assertions tell apart
-  const uint32_t nk = (hasWord && hasLine) ? 3u : (hasLook ? 2u : 1u);
+  const uint32_t nkBytes = (hasWord && hasLine) ? 3u : ((hasWord || hasLine || hasText) ? 2u : 1u);   // kinds a byte can have
+  const uint32_t nk = nkBytes + (hasEnd ? 1u : 0u);
+  const int kEnd = hasEnd ? static_cast<int>(nkBytes) : -1;
   const int kWord = hasWord ? 1 : -1, kNl = hasLine ? (hasWord ? 2 : 1) : -1;
   auto kindOfByte = [&](int b) { return (hasWord && wordKind(b)) ? kWord : ((hasLine && b == '\n') ? kNl : 0); };
   const int outsideKind = hasLine ? kNl : 0;     // in front of / behind the haystack: a line edge, not a word byte
@@ -147,13 +155,13 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   const uint32_t ncls = nbc * nk;                               // input symbols = table columns: nk * class + kind of the next byte
   if (ncls > 64) { why = "more than 64 input symbols (byte classes x kinds)"; return false; }
   auto kindOf = [&](uint32_t bc) { return kindOfByte(reps[bc]); };
-  auto setKinds = [&](Stepper& x) { if (kWord >= 0) x.word[kWord] = true; if (kNl >= 0) x.newline[kNl] = true; };
+  auto setKinds = [&](Stepper& x) { if (kWord >= 0) x.word[kWord] = true; if (kNl >= 0) x.newline[kNl] = true; if (kEnd >= 0) { x.newline[kEnd] = true; x.endText[kEnd] = true; } };
 
   Stepper st(nfa);
   setKinds(st);
   // the search that starts at a position, by the kinds of the bytes on its two sides
-  std::vector<uint32_t> freshLR[3][3];
-  for (int l = 0; l < static_cast<int>(nk); l++)
+  std::vector<uint32_t> freshLR[4][4];
+  for (int l = 0; l < static_cast<int>(nkBytes); l++)              // (the kind in front of a position is a byte's, or the outside kind: never kEnd)
     for (int r = 0; r < static_cast<int>(nk); r++) {
       st.gen++;
       st.left = l; st.right = r;
@@ -186,7 +194,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   auto eventOf = [&](uint32_t kind, uint32_t j, bool conts, uint32_t died) -> uint32_t {   // descriptor, 0 = nothing happened
     return kind | (j << 2) | (conts ? 32u : 0u) | (died << 8);
   };
-  uint32_t startOf[3] = {0, 0, 0};                // the search at the haystack's first byte, by the kind of that byte; row 0 = kind 0
+  uint32_t startOf[4] = {0, 0, 0, 0};                // the search at the haystack's first byte, by the kind of that byte; row 0 = kind 0
   for (uint32_t k = 0; k < nk; k++) {
     std::vector<uint32_t> first;
     st.gen++;
@@ -194,8 +202,8 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     st.textStart = hasText;
     st.closure(first, nfa.start_unanchored);
     st.textStart = false;
-    if (st.matchIndex(first) >= 0) { why = "nullable pattern (empty match at the start of the text)"; return false; }
-    startOf[k] = intern({first});
+    if (st.matchIndex(first) >= 0) { why = static_cast<int>(k) == kEnd ? "nullable pattern (matches the empty text)" : "nullable pattern (empty match at the start of the text)"; return false; }
+    if (static_cast<int>(k) != kEnd) startOf[k] = intern({first});   // (an empty haystack is never scanned: no start row for kEnd)
   }
   for (uint32_t cur = 0; cur < keys.size() && !tooBig; cur++) {
     // split the key into its levels
@@ -354,7 +362,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   // lists: the reverse search runs without break-at-match (meta/compile.go:193-194).  Row 0 dead, accepting rows last.
   std::vector<std::vector<uint32_t>> rtab;          // [state][ncls] (renumbered)
   uint32_t rStates = rev.nstates, rFirstAccept = rev.firstAccept, rStart = rev.start;
-  uint32_t rStart9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t rStart9[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<uint8_t> rTextAcc;                   // hasText: per reverse state (renumbered)
   if (hasLook) {
     Stepper rs(*revNfa);
@@ -374,8 +382,8 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
       return id;
     };
     rintern({});                                   // 0: dead
-    uint32_t s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int l = 0; l < static_cast<int>(nk); l++)
+    uint32_t s9[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < static_cast<int>(nkBytes); l++)
       for (int r = 0; r < static_cast<int>(nk); r++) {
         std::vector<uint32_t> set;
         rs.gen++;
@@ -386,6 +394,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     for (uint32_t cur = 1; cur < rsets.size(); cur++) {
       if (rsets.size() > 4096) { why = "reverse automaton too large"; return false; }
       for (uint32_t c = 0; c < ncls; c++) {
+        if (static_cast<int>(c % nk) == kEnd) continue;            // (no reverse step has the end of the text in front of its byte: column unused, dead)
         rs.left = static_cast<int>(c % nk); rs.right = kindOf(c / nk);
         const std::vector<uint32_t> lst = rsets[cur];
         rnext[cur][c] = rintern(rs.step(lst.data(), lst.size(), reps[c / nk]));
@@ -434,7 +443,7 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   cxgdev::FsmHeader h;
   std::memset(&h, 0, sizeof h);
   h.magic = cxgdev::kFsmMagic; h.n_t = nT; h.n_a = nA; h.n_u = nU; h.ncls = ncls; h.stride = stride; h.row_bytes = rowBytes; h.depth = depth;
-  h.nk = nk; h.outside_byte = outsideByte;
+  h.nk = nk; h.outside_byte = outsideByte; h.end_col = hasEnd ? 2u * static_cast<uint32_t>(kEnd) : 0u;
   h.alias_lo = offA(0); h.u_lo = offU(0); h.top_off = offU(0); h.wide_off = wideOff; h.max_len = max_len;
   h.create_lo = offA(nDied); h.rematch_lo = offA(nDied + nCreate); h.row_shift = rowShift;
   std::vector<uint8_t> img(sizeof h, 0);

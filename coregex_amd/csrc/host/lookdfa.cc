@@ -522,7 +522,7 @@ Symbols symbolsOf(const cxg_nfa& nfa) {
     const cxg_nfa_state& s = nfa.states[i];
     if (s.kind != CXG_NFA_LOOK) continue;
     // (\A / ^: the machines below know the Text start kind — start.go:64-172, look.go:88-107; the transducer serves it, fsm.cc)
-    if (s.lo == kLkEndText) throw BuildError{CXG_E_UNSUPPORTED, "end-of-text anchor (\\z, $ without (?m)) in a lazy-DFA program: the transducer has no end-of-text symbol"};
+    // (\z / $: both machines below know the end of the input — kSymEnd, CheckEOIMatch — and the transducer has its kind since round 6)
     if (s.lo == kLkWordB || s.lo == kLkNoWordB) sy.hasWordB = true;
     if (s.lo == kLkStartLine || s.lo == kLkEndLine) sy.hasLine = true;
     if (s.lo == kLkEndLine) sy.hasEndLine = true;

@@ -30,10 +30,17 @@ def shardable(rx) -> bool:
     """May this program be scanned shard by shard and its rows concatenated?  Not when a match depends on the haystack as a WHOLE:
     nullable programs (`a*`: FindAll emits an empty match at the end of every shard and at position 0 of the next, and skips an empty
     match only at the end of a match of the SAME call, meta/findall.go:251-257) and quote-pair programs (`"[^"]*"`: which quote opens
-    is the parity of the quotes from the haystack's first byte).  Such programs are scanned as one haystack (64 GiB fit one MI355X)."""
+    is the parity of the quotes from the haystack's first byte), and programs with a text anchor (`(^|,)\\d+`, `a$|z`: a shard's first or last
+    position is not the text's).  Such programs are scanned as one haystack (64 GiB fit one MI355X)."""
     import struct
     if rx.nullable:
         return False
+    img = rx.fsm_image()
+    if img is not None and len(img) >= 37 * 4:
+        # FsmHeader::rev_text_col / end_col (device/fsm.hpp): the pattern holds \A / ^ resp. \z / $ — only the haystack's own first
+        # and last position are the text's
+        if struct.unpack_from("<I", img, 29 * 4)[0] or struct.unpack_from("<I", img, 36 * 4)[0]:
+            return False
     blob = rx.blob()
     kind, flags = struct.unpack_from("<II", blob, 4)
     if kind == 3 and flags & 64:                                        # kKindCharClass with ranges: CharClassAux.pairs

@@ -1,7 +1,7 @@
 """CPU fuzz of host/lookdfa.cc: look-around programs of the reference's lazy-DFA strategies (UseDFA / UseBoth / UseDigitPrefilter) that the build-time
 proof accepts must give, on the transducer's sequential twin, exactly what the oracle's restated look-aware lazy DFA gives — with
 ONE oracle engine per pattern reused over all haystacks (the proof also claims independence of cache history).
-python scripts/cpu_fuzz_lookdfa.py [n_patterns] [seed]"""
+python scripts/cpu_fuzz_lookdfa.py [n_patterns] [seed] [text]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +16,8 @@ ATOMS = [r"\b", r"\b", r"\B", r"\w", r"\w+", r"\w+", r"\w*", r"\w?", r"[\w.]+", 
 
 DIGIT_LEADS = [r"\d+", r"\d+", r"\d", r"\d{2}", r"[0-9]+", r"\d+\.", r"\d+\.\d+", r"[0-5]+", r"\d{2,}", r"\d+-"]
 
+TEXT_ANCHORS = False
+
 def main(n=400, seed=1):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"abfor xyERZ_0912 .=:@-;\n\t  ", dtype=np.uint8)
@@ -29,14 +31,15 @@ def main(n=400, seed=1):
         if rng.random() < 0.25: pat = DIGIT_LEADS[int(rng.integers(0, len(DIGIT_LEADS)))] + pat      # digit-lead: UseDigitPrefilter
         if pat in seen or not any(t in pat for t in (r"\b", r"\B", "^", "$")): continue
         seen.add(pat)
-        pat = "(?m)" + pat
+        if not TEXT_ANCHORS or rng.random() < 0.5: pat = "(?m)" + pat      # (third argument "text": half of the patterns keep ^ / $ as text anchors, round 6)
         try: o = O.Regex(pat)
         except O.OracleError: continue
         if o.strategy not in ("UseDFA", "UseBoth", "UseDigitPrefilter"): continue
         try: rx = cx.compile(pat)
         except cx.CoregexError: continue
         if rx.strategy != o.strategy:
-            print("STRATEGY", repr(pat), rx.strategy, o.strategy); return 1
+            if rx.supported or not TEXT_ANCHORS: print("STRATEGY", repr(pat), rx.strategy, o.strategy); return 1
+            continue                                              # (a refused pattern with `$` in its middle — it never matches — whose strategy name differs, as in cpu_fuzz_text.py)
         n_dfa += 1
         n_digit += o.strategy == "UseDigitPrefilter"
         if not rx.supported:
@@ -77,4 +80,5 @@ def main(n=400, seed=1):
     return 0
 
 if __name__ == "__main__":
+    TEXT_ANCHORS = len(sys.argv) > 3 and sys.argv[3] == "text"
     sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 400, int(sys.argv[2]) if len(sys.argv) > 2 else 1))

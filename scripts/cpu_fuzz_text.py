@@ -1,6 +1,6 @@
 """CPU fuzz of text anchors inside unanchored patterns (`(^|,)\\d+`, `foo|\\Abar`; round 4): the front-end's strategy against the
 oracle's, and — for the programs the build accepts — the transducer's sequential twin against the oracle on haystacks whose first bytes
-matter.  python scripts/cpu_fuzz_text.py [n_patterns] [seed]"""
+matter.  python scripts/cpu_fuzz_text.py [n_patterns] [seed] [end]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +11,8 @@ from oracle import oracle as O
 
 ATOMS = ["^", "^", r"\A", "(?:^|,)", r"(^|\s)", "(?:^|x)", r"\b", r"\d+", r"\d", "[a-c]+", "[a-c]", "foo", "bar", "ab", "x", ",", " ", r"\s", r"\w+", "(?:foo|bar)", "(?:a|^b)", "(?:^a|b)", ":", r"\.",
          "(a|b)", r"\S+", r"\w", "a+", "x?", "(?:ab)+", "$", r"\z"]
+
+NEED = ("^", r"\A")     # third argument "end": patterns with an end-of-text anchor instead (round 6)
 
 def main(n=300, seed=1):
     rng = np.random.default_rng(seed)
@@ -23,7 +25,7 @@ def main(n=300, seed=1):
         k = int(rng.integers(2, 6))
         pat = "".join(ATOMS[int(rng.integers(0, len(ATOMS)))] for _ in range(k))
         if rng.random() < 0.4: pat = pat + "|" + "".join(ATOMS[int(rng.integers(0, len(ATOMS)))] for _ in range(int(rng.integers(1, 4))))
-        if pat in seen or not any(t in pat for t in ("^", r"\A")): continue
+        if pat in seen or not any(t in pat for t in NEED): continue
         seen.add(pat)
         try: o = O.Regex(pat)
         except O.OracleError: continue
@@ -75,9 +77,10 @@ def main(n=300, seed=1):
                 n_cmp += 1
                 if got.shape != exp.shape or not np.array_equal(got, exp):
                     print("MISMATCH", repr(pat), rx.strategy, tile, chunk, hay[:80], got[:6].tolist(), exp[:6].tolist()); return 1
-    print(f"{n_pat} patterns with a text-start anchor {strat}; {n_served} served, {n_cmp} twin comparisons clean, {n_sub} capture comparisons clean, {n_strat_refused} refused patterns with another strategy name, {time.time()-t0:.1f}s")
+    print(f"{n_pat} patterns with a text anchor {NEED} {strat}; {n_served} served, {n_cmp} twin comparisons clean, {n_sub} capture comparisons clean, {n_strat_refused} refused patterns with another strategy name, {time.time()-t0:.1f}s")
     for k, v in sorted(why.items(), key=lambda kv: -kv[1]): print(f"  refused {v:5d}: {k}")
     return 0
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "end": NEED = ("$", r"\z")
     sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1))

@@ -26,6 +26,10 @@ TEXT = bool(os.environ.get("FUZZ_TEXT"))      # a text-start anchor (\A, ^ witho
 TEXT_ATOMS = ["^", "^", r"\A", "(?:^|,)", r"(^|\s)", "(?:^|x)", "(?:a|^b)", "(?:^a|b)", r"(?:^|:)"]
 if TEXT:
     atoms = atoms[:36] + TEXT_ATOMS * 4 + [",", " ", r"\b", r"\w+", "abc", r"\d+"]
+END = bool(os.environ.get("FUZZ_END"))        # an end-of-text anchor (\z, $ without (?m)) in every pattern (round 6); the haystacks get tails that match at the last position
+END_ATOMS = ["$", "$", r"\z", "(?:$|,)", r"(\s|$)", "(?:x|$)", "(?:a$|b)", "(?:a|b$)", r"(?:\z|:)"]
+if END:
+    atoms = atoms[:36] + END_ATOMS * 4 + [",", " ", r"\b", r"\w+", "abc", r"\d+", "|", "|"]
 if WIDE:
     atoms = atoms + WIDE_ATOMS * 3
 if FOLD:
@@ -46,6 +50,9 @@ if FOLD:
     hays = [np.frombuffer(bytes(h), dtype=np.uint8) if not isinstance(h, np.ndarray) else h for h in hays]
 if TEXT:
     hays = [h for h in hays] + [np.concatenate([np.frombuffer(lead, dtype=np.uint8), h]) for lead in (b"abc", b"12", b"xyz,", b"a", b"b:") for h in (hays[2], hays[5], hays[7])]
+if END:
+    hays = [h for h in hays] + [np.concatenate([h[:cut], np.frombuffer(tail, dtype=np.uint8)]) for tail in (b"abc", b"12", b",xyz", b"a", b":b", b"x")
+                                for h, cut in ((hays[2], T - 1), (hays[3], T - 2), (hays[4], 32 * T - 3), (hays[5], 32 * T - 1), (hays[7], 199999))]
 if os.environ.get("FUZZ_FEW"):
     # few-symbol haystacks of several groups (120 KiB each): the sets of possible entry states stay unresolved for long
     # stretches, so the transducer kernel's member maps, its serial chain and the tile / group hand-off do the work
@@ -69,6 +76,8 @@ while len(seen) < npat:
     if FOLD and "(?i" not in pat:
         continue
     if TEXT and not any(t in pat for t in ("^", "\\A")):
+        continue
+    if END and (not any(t in pat for t in ("$", "\\z")) or pat.startswith("|") or pat.endswith("|") or "||" in pat):
         continue
     if WIDE and not any(a in pat for a in (".", "[^", "\\S", "\\D", "\\W", "é")):
         continue

@@ -13,8 +13,9 @@
 using namespace cxgdev;
 
 namespace {
-template <bool LOOK>
+template <int LOOK>
 struct HostMem : FsmClassify<HostMem<LOOK>, LOOK> {
+  int32_t last() const { const int64_t d = len - 1 - origin_abs; return d > 0x7FFF0000 ? 0x7FFF0000 : static_cast<int32_t>(d); }   // LOOK == 2: the haystack's last byte (fsm.hpp "End of text")
   const uint8_t* hay;   // whole haystack
   int64_t origin_abs;   // absolute position of the tile origin
   int64_t len;
@@ -39,7 +40,7 @@ FsmView view_of(const uint8_t* img) {
   v.rev = img + h->rev_off;
   v.ncls2 = 2 * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   v.knd = img + h->knd_off;
@@ -52,7 +53,7 @@ FsmView view_of(const uint8_t* img) {
 // fallback flag (reason 1: a lane's entry state did not collapse, 2: more than kFsmLaneRows rows in a chunk,
 // 4: level stack overflow, 8: walk budget), -1 on a bad image.  stats (optional, 4 values): chunks, chunks whose entry
 // needed the full warm-up, chunks whose entry set did not collapse, rows fixed against the previous row.
-template <bool LOOK>
+template <int LOOK>
 static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                        int tile, int chunk, int budget_bytes, uint64_t* stats, int dense) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
@@ -150,7 +151,7 @@ struct HostTab {                                          // the direct section:
   const uint8_t* d;
   uint32_t at(uint32_t addr) const { return d[addr]; }
 };
-template <bool LOOK, bool DIRECT>
+template <int LOOK, bool DIRECT>
 static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
                                int tile, int budget_bytes, uint64_t* stats) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
@@ -291,7 +292,7 @@ extern "C" int64_t emu_find_all_fsm_direct(const uint8_t* img, const uint8_t* ha
                                            int tile, int budget_bytes, uint64_t* stats) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   if (h->magic != kFsmMagic || h->direct_off == 0u || h->depth > 1 || h->nk != 1 || tile % 64 != 0 || budget_bytes % 64 != 0 || budget_bytes <= 0 || (tile + budget_bytes) / 64 > 63) return -1;
-  return emu_fsm_shallow<false, true>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
+  return emu_fsm_shallow<0, true>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
 }
 
 extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int64_t* out, int64_t cap_vals,
@@ -300,9 +301,11 @@ extern "C" int64_t emu_find_all_fsm(const uint8_t* img, const uint8_t* hay, uint
   if (h->magic != kFsmMagic || chunk % 4 != 0 || tile % chunk != 0) return -1;
   // the kernel's SHALLOW instantiation in its own geometry (64-byte lanes, a tail of whole lanes)
   if (h->depth <= 1 && chunk == kFsmSub && tile % 64 == 0 && budget_bytes % 64 == 0 && budget_bytes > 0 && (tile + budget_bytes) / 64 <= 63)
-    return h->nk > 1 ? emu_fsm_shallow<true, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats) : emu_fsm_shallow<false, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
-  return h->nk > 1 ? emu_fsm<true>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
-                   : emu_fsm<false>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
+    return h->end_col ? emu_fsm_shallow<2, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats)
+         : h->nk > 1  ? emu_fsm_shallow<1, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats) : emu_fsm_shallow<0, false>(img, hay, len, out, cap_vals, tile, budget_bytes, stats);
+  return h->end_col ? emu_fsm<2>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
+       : h->nk > 1  ? emu_fsm<1>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense)
+                    : emu_fsm<0>(img, hay, len, out, cap_vals, tile, chunk, budget_bytes, stats, dense);
 }
 
 // ---- round 3: the kernel's way of finding entry states without waiting (scan_fsm.hip "Maps instead of waits") -------------------
@@ -335,7 +338,7 @@ EMap emap_then(const EMap& first, const EMap& second) {     // second o first (f
 }
 }  // namespace
 
-template <bool LOOK>
+template <int LOOK>
 static int64_t emu_fsm_maps(const uint8_t* img, const uint8_t* hay, uint64_t len, int tile, int tiles_per_group) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   const FsmView v = view_of(img);
@@ -451,5 +454,5 @@ static int64_t emu_fsm_maps(const uint8_t* img, const uint8_t* hay, uint64_t len
 extern "C" int64_t emu_fsm_maps_check(const uint8_t* img, const uint8_t* hay, uint64_t len, int tile, int tiles_per_group) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(img);
   if (h->magic != kFsmMagic || tile % (2 * kFsmSub) != 0 || tile > 64 * 2 * kFsmSub || tiles_per_group < 1) return -1;
-  return h->nk > 1 ? emu_fsm_maps<true>(img, hay, len, tile, tiles_per_group) : emu_fsm_maps<false>(img, hay, len, tile, tiles_per_group);
+  return h->end_col ? emu_fsm_maps<2>(img, hay, len, tile, tiles_per_group) : h->nk > 1 ? emu_fsm_maps<1>(img, hay, len, tile, tiles_per_group) : emu_fsm_maps<0>(img, hay, len, tile, tiles_per_group);
 }

@@ -12,7 +12,11 @@ import emu
 
 TEXT = [r"foo|^bar", r"\Afoo|bar", r"(?:^|,)\d+", r"(^|\s)error", r"(?:^|[^a-z])abc", r"^\d+|x\d+", r"(^|x)[a-c]+", r"(^|\s)(GET|POST)", r"(^|\s)(\w+)=(\d+)",
         r"\bfoo|^bar", r"(?:^|,)[a-c]+", r"(?m)(?:\A|^x)\d+", r"(?:^|:)\w+\b", r"(?:^|x)*a"]
-REFUSED = [r"foo$|x", r"x\z|foo", r"(?:^|,)\d+$", r"^foo", r"\Afoo", r"foo|^"]
+# end-of-text anchors inside unanchored patterns (round 6): the kind "behind the haystack's last byte" of host/fsm.cc
+TEXT_END = [r"foo$|x", r"x\z|foo", r"(?:^|,)\d+$", r"a$|z", r"(a$)b$", r"^a$|^b$", r"foo$|bar", r"\d+$|x", r"(?m)foo$|bar\z", r"\bfoo\z|ba+", r"(?:^|,)[a-c]+$|,", r"(\w+)=(\d+)\z|k=",
+            r"error$|warn(ing)?"]
+TEXT = TEXT + TEXT_END
+REFUSED = [r"^foo", r"\Afoo", r"foo|^", r"a+$|a", r"\z(?:^|,)|[a-c]\w+", r"ab?|$"]
 
 
 def _twin(rx, a):
@@ -34,6 +38,12 @@ def test_twin_equals_oracle(pat, oracle):
     for n in (50, 500, 3839, 3841, 9000):
         for lead in (b"", b"bar", b"12", b"abc", b"x9", b" ", b"GET", b"k=2", b"ab"):
             hays.append(lead + b"".join(rng.choice(toks) for _ in range(n // 3)))
+    if pat in TEXT_END:                                                 # the haystack's LAST bytes matter: every tail at every distance from a tile / chunk edge
+        hays += [b"a", b"za", b"ayyyyy", b"ab", b"b", b"xfoo", b"foo x foo", b",12", b"k=1 k=12", b"foo\n", b"error", b"warn error"]
+        for n in (31, 32, 33, 63, 64, 65, 3776, 3839, 3840, 3841, 3904, 4031, 4032, 4033, 7679, 7680, 7681):
+            for tail in (b"a", b"foo", b",12", b"ab", b"k=12", b"x", b"\n", b"bar", b",abc", b"error", b"za"):
+                body = b"".join(rng.choice(toks) for _ in range(n))[:n]
+                hays.append(body[: n - len(tail)] + tail)
     for hay in hays:
         a = np.frombuffer(hay, dtype=np.uint8)
         exp = o.find_all_index(a)
@@ -53,7 +63,9 @@ def test_twin_equals_oracle(pat, oracle):
 
 
 @pytest.mark.parametrize("pat", REFUSED)
-def test_end_of_text_and_anchored_patterns_stay_refused(pat, oracle):
+def test_anchored_quirky_and_nullable_patterns_stay_refused(pat, oracle):
+    """Start-anchored patterns (other strategies), `a+$|a` (the reference's reverse DFA ignores the anchor and reports another start:
+    lookdfa.cc proves it), a pattern that matches only the empty text, a nullable pattern with an assertion."""
     rx = cx.compile(pat)
     assert not rx.supported, pat
     assert rx.strategy == oracle.Regex(pat).strategy, pat
@@ -74,5 +86,16 @@ def test_reference_pairs_on_the_twin(oracle):
         got = _twin(rx, np.frombuffer(c["input"].encode(), dtype=np.uint8))
         assert not isinstance(got, int) and got.tolist() == c["want"], (c, got)
     assert served >= 5
+    # the pairs with an end-of-text anchor (oracle-only until round 6): `a$|z`, `(a$)b$`, `^a$|^b$` are UseDFA programs and served; the
+    # others are the reference's reverse / anchored strategies (out of scope) or nullable
+    served_end = 0
     for c in vec["text_anchor_compat_oracle_only"]["cases"]:
-        assert not cx.compile(c["pattern"]).supported, c
+        rx = cx.compile(c["pattern"])
+        assert rx.strategy == oracle.Regex(c["pattern"]).strategy, c
+        if not rx.supported:
+            assert rx.strategy in ("UseReverseAnchored", "UseBoundedBacktracker") or "nullable" in rx.why_unsupported, (c, rx.why_unsupported)
+            continue
+        served_end += 1
+        got = _twin(rx, np.frombuffer(c["input"].encode(), dtype=np.uint8))
+        assert not isinstance(got, int) and got.tolist() == c["want"], (c, got)
+    assert served_end == 5, served_end
