@@ -82,7 +82,8 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   uint32_t ncls, stride, row_bytes, depth;
   uint32_t alias_lo, u_lo, top_off, wide_off;      // byte offsets of the first alias row, the first set row, "any state", wide
   uint32_t cls_off, tab_off, mem_off, rev_off;     // cls: u8[256] = 2 * class; tab: u16[rows][stride]; mem: u16[n_u + 1][8] rows of a set's members, 0xFFFF pad / not listed
-  uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][ncls] target row byte offsets, row 0 dead; accepting rows >= rev_accept_off
+  uint32_t rev_states, rev_start_off, rev_accept_off, rev_row_bytes;   // rev: u16[rev_states][rev_row_bytes / 2] (a power of two); an entry = the target row's offset FROM THE END OF THE HEADER
+                                                   // (its LDS address in the kernel; rev_start_off / rev_accept_off count the same way) | 1 when the target accepts; row 0 = dead, leads to itself
   uint32_t total_bytes, lds_bytes, max_len, nk;    // nk: kinds of the byte BEHIND a step that the step depends on (1: none; 2 or 3, see "Look-around")
   uint32_t create_lo, rematch_lo, row_shift, knd_off; // row_bytes == 1 << row_shift; alias rows are ordered by event kind: [alias_lo, create_lo) levels died only,
                                                    // [create_lo, rematch_lo) create, [rematch_lo, u_lo) rematch.  nk > 1: knd = u8[256] 2 * kind of a byte, then
@@ -129,6 +130,7 @@ struct FsmView {
   const uint8_t* rev;
   uint32_t ncls2;           // 2 * ncls: byte offset of the event column inside a row
   uint32_t alias_lo, u_lo, top_off, rev_start_off, rev_accept_off;
+  uint32_t rev_dead;        // the dead reverse state's entry (= rev_off - header size)
   uint32_t rev_text_col;    // FsmHeader::rev_text_col
   uint32_t end_col;         // FsmHeader::end_col
   uint32_t create_lo, rematch_lo;
@@ -644,12 +646,11 @@ CXG_FSM_HD void fsm_replay(const FsmView& v, const Mem& m, uint32_t entry, int32
 // Start of the match that ends at e: the smallest p >= bound with hay[p, e) in the language — the anchored reverse
 // DFA without break-at-match (meta/compile.go:193-194), walked from e - 1 downwards (lazy.go:1769-1920).  lowest:
 // first position that exists.  Returns kFsmNoStart when the reverse DFA never accepts (cannot happen for a real match);
-// positions are relative to the tile origin and may be negative.
+// positions are relative to the tile origin and may be negative.  A reverse entry is the target row's byte offset | 1 when
+// the target accepts (round 6); rows are a power of two long.
+// fsm_match_start_from: the walk goes on from state s (an entry) with byte `at` the next to step over and st the smallest start so far.
 template <class Mem>
-CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over, int32_t text_pos = kFsmNoStart) {
-  uint32_t s = m.rstart(v, e);
-  int32_t st = kFsmNoStart;
-  int32_t at = e - 1;
+CXG_FSM_HD int32_t fsm_match_start_from(const FsmView& v, const Mem& m, uint32_t s, int32_t st, int32_t at, int32_t bound, int32_t budget_lo, uint32_t& over, int32_t text_pos = kFsmNoStart) {
   // Four steps at a time: the byte reads and the class lookups of a group do not depend on the automaton's state and are
   // issued together — and those of the NEXT group before this group's chain (round 6) — so the dependent chain per step is
   // ONE table read instead of three (byte -> class -> row).  Positions below the walk's lower end are read clamped (they lie
@@ -672,9 +673,9 @@ CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, in
 #endif
     for (int k = 0; k < 4; k++) {
       if (dead || at - k < low) break;
-      s = fsm_u16(v.rev, s + c[k]);
-      if (s == 0u) { dead = true; break; }
-      if (s >= v.rev_accept_off) st = at - k;
+      s = fsm_u16(v.tab, (s & ~1u) | c[k]);
+      if (s == v.rev_dead) { dead = true; break; }
+      if (s & 1u) st = at - k;
     }
     if (dead) return st;
     at = at - 4 >= low - 1 ? at - 4 : low - 1;
@@ -687,7 +688,58 @@ CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, in
   // text_pos: where the text starts, relative to `m` (kFsmNoStart: not within reach).  A walk that stepped over the text's first
   // byte alive stands there: a text-start anchor of the pattern (\A, ^) holds now and nowhere else — the state says whether that
   // makes the position a match start (host/fsm.cc).
-  if (v.rev_text_col != 0u && text_pos != kFsmNoStart && at == text_pos - 1 && s != 0u && !over && fsm_u16(v.rev, s + v.rev_text_col + v.knd[m.byte(text_pos)]) != 0u) st = text_pos;
+  if (v.rev_text_col != 0u && text_pos != kFsmNoStart && at == text_pos - 1 && s != v.rev_dead && !over && fsm_u16(v.tab, (s & ~1u) + v.rev_text_col + v.knd[m.byte(text_pos)]) != 0u) st = text_pos;
+  return st;
+}
+template <class Mem>
+CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over, int32_t text_pos = kFsmNoStart) {
+  return fsm_match_start_from(v, m, m.rstart(v, e), kFsmNoStart, e - 1, bound, budget_lo, over, text_pos);
+}
+
+// Round 6: the first 16 steps of that walk without a branch.  Most matches of log patterns are shorter (an IPv4 address, a number, a
+// word), and the loop above pays for its exits: every step tests "dead" and "below the bound" with the exec mask of the lanes that are
+// still walking.  Here the 16 bytes below e come as four dwords (Mem::below: five aligned reads and v_alignbyte on the device), their
+// classes are looked up at once, and a step is  s = rev[(s & ~1) | column]  + one v_alignbit that shifts the entry's accept bit into a
+// word: the dead state (row 0) absorbs, steps below the bound are masked out of the word afterwards, the smallest start is its highest
+// bit.  Only a walk that is still alive after 16 steps with room below goes on in the loop above.  Needs e - 17 inside the window
+// (rows end behind the tile origin and the window begins 64 bytes in front of it) and a pattern without a text-start anchor
+// (the caller's business).  Mem::below(e, W): the 17 bytes e - 17 .. e - 1 in ascending order, byte i = (W[i >> 2] >> 8 (i & 3)) & 255.
+CXG_FSM_HD uint32_t fsm_shift_in1(uint32_t mask, uint32_t t) {   // (mask >> 1) | (t << 31)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(t, mask, 1u);
+#else
+  return (mask >> 1) | (t << 31);
+#endif
+}
+template <class Mem>
+CXG_FSM_HD int32_t fsm_match_start16(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  uint32_t W[5];
+  m.below(e, W);
+  uint32_t c[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 16; k++) {                          // step k is over byte e - 1 - k = byte 16 - k of W; with look-around it sees the kind of the byte in front
+    const int i = 16 - k;
+    c[k] = v.cls2[(W[i >> 2] >> (8 * (i & 3))) & 0xFFu];
+    if (Mem::kLook) c[k] += v.knd[(W[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu];
+  }
+  uint32_t s = m.rstart(v, e), acc = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 16; k++) {
+    s = fsm_u16(v.tab, (s & ~1u) | c[k]);               // (an entry is the row's offset in the image = its LDS address: no base to add)
+    acc = fsm_shift_in1(acc, s);
+  }
+  const int32_t low = bound > budget_lo ? bound : budget_lo;
+  const uint32_t room = static_cast<uint32_t>(e - low);   // steps the walk may take (>= 1)
+  if (room <= 16u && low != bound) return fsm_match_start(v, m, e, bound, budget_lo, over);   // (the window's first byte within 16 bytes of a row's end: not in the kernel's geometry)
+  uint32_t f = acc >> 16;                                 // bit k: hay[e - 1 - k, e) is in the language
+  if (room < 16u) f &= (1u << room) - 1u;
+  int32_t st = f ? e - 1 - (31 - static_cast<int32_t>(__builtin_clz(f))) : kFsmNoStart;
+  // room <= 16 ends at the bound (low == bound then: the window begins 64 bytes in front of the tile and rows end behind its origin)
+  if (room > 16u && (s & ~1u) != v.rev_dead) st = fsm_match_start_from(v, m, s, st, e - 17, bound, budget_lo, over);
   return st;
 }
 

@@ -39,6 +39,10 @@
 #ifndef CXG_FSM_ABL
 #define CXG_FSM_ABL 0
 #endif
+// -DCXG_FSM_FAST_STARTS=0 (A/B): match starts by the loop alone, without the 16 branch-free steps in front of it (fsm.hpp fsm_match_start16)
+#ifndef CXG_FSM_FAST_STARTS
+#define CXG_FSM_FAST_STARTS 1
+#endif
 #if CXG_FSM_PROF
 #define FSM_MARK(i) do { const uint64_t t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -72,6 +76,18 @@ struct FsmMem : FsmClassify<FsmMem<LOOK>, LOOK> {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
     return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
   }
+  // the 17 bytes below e (fsm.hpp fsm_match_start16): five aligned dwords, shifted into place
+  __device__ __forceinline__ void below(int32_t e, uint32_t (&W)[5]) const {
+    const uint32_t w0 = static_cast<uint32_t>(e - 17 + kFsmLeft), wb = w0 & ~3u, sh = w0 & 3u;
+    uint32_t d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const uint32_t w = wb + 4u * j;
+      d[j] = *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) W[j] = __builtin_amdgcn_alignbyte(d[j < 4 ? j + 1 : 4], d[j], sh);
+  }
 };
 struct LdsRows {
   uint16_t* slot;          // this lane's kFsmLaneRows ends
@@ -91,7 +107,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.rev = body + (h->rev_off - hs);
   v.ncls2 = 2u * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col; v.rev_dead = h->rev_off - hs;
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   v.knd = body + (h->knd_off - hs);
@@ -729,7 +745,9 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           // reverse DFA that is still alive there report `over`
           const int32_t bound = q ? static_cast<int32_t>(s_re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
-          const int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+          // (a text-start anchor is the loop's business: the walk that arrives at position 0 alive asks the state)
+          const int32_t s = (CXG_FSM_FAST_STARTS && (v.rev_text_col == 0u || tile_lo != 0)) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)
+                                                                                              : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           // over: the reverse DFA was still alive at the window's first byte and the haystack goes on in front of it
           // (a match longer than the 64 bytes staged there): length 0 = unresolved, finished in the epilogue
           const uint32_t len = (over || s == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - s);
@@ -803,11 +821,11 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
           int64_t st = -1, at = e - 1;
           for (; at >= lo; at--) {
             if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-            sr = fsm_u16(v.rev, sr + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
-            if (sr == 0u) break;
-            if (sr >= v.rev_accept_off) st = at;
+            sr = fsm_u16(v.tab, (sr & ~1u) + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
+            if (sr == v.rev_dead) break;
+            if (sr & 1u) st = at;
           }
-          if (LOOK && v.rev_text_col != 0u && at < 0 && sr != 0u && fsm_u16(v.rev, sr + v.rev_text_col + v.knd[a.hay[0]]) != 0u) st = 0;   // text-start anchor (fsm.hpp fsm_match_start)
+          if (LOOK && v.rev_text_col != 0u && at < 0 && sr != v.rev_dead && fsm_u16(v.tab, (sr & ~1u) + v.rev_text_col + v.knd[a.hay[0]]) != 0u) st = 0;   // text-start anchor (fsm.hpp fsm_match_start)
           if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s = st;
         }
       }
@@ -836,16 +854,17 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
   const uint8_t* cls2 = a.blob + h->cls_off;
   const uint8_t* knd = a.blob + h->knd_off;
-  const uint8_t* rev = a.blob + h->rev_off;
+  const uint8_t* rev = a.blob + sizeof(FsmHeader);                 // (reverse entries count from the end of the header)
+  const uint32_t rdead = h->rev_off - static_cast<uint32_t>(sizeof(FsmHeader));
   const bool look = h->nk > 1;
   const uint32_t outside = h->outside_byte;
   const uint32_t right = static_cast<uint64_t>(e) < a.len ? knd[a.hay[e]] : (h->end_col ? h->end_col : knd[outside]);   // (fsm.hpp "End of text")
   uint32_t sr = look ? fsm_u16(knd, 256u + 2u * h->nk + 2u * ((knd[a.hay[e - 1]] >> 1) * h->nk + (right >> 1))) : h->rev_start_off;
   int64_t st = -1;
   for (int64_t at = e - 1; at >= prev; at--) {
-    sr = fsm_u16(rev, sr + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
-    if (sr == 0u) break;
-    if (sr >= h->rev_accept_off) st = at;
+    sr = fsm_u16(rev, (sr & ~1u) + cls2[a.hay[at]] + (look ? knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
+    if (sr == rdead) break;
+    if (sr & 1u) st = at;
   }
   if (st < 0) { raise_err(a.err, 8u | (64u << 8)); return; }
   row[0] = a.base + st;

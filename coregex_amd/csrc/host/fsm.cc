@@ -429,7 +429,11 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     }
   }
   const uint32_t rcols = ncls + (hasText ? nk : 0u);   // hasText: nk more columns, the text-start flags of the state
-  if (rStates == 0 || static_cast<size_t>(rStates) * rcols * 2 > 65535) { why = "reverse DFA missing or too large"; return false; }
+  // Round 6: reverse rows are a power of two long and an entry's bit 0 says "the target accepts" (rows stay ordered, accepting ones last):
+  // a reverse step is  s = rev[(s & ~1) | column]  and the kernel shifts the accept bits of 16 steps into one word (fsm.hpp fsm_match_start16)
+  uint32_t revRowP2 = 4;
+  while (revRowP2 < rcols * 2) revRowP2 *= 2;
+  if (rStates == 0 || static_cast<size_t>(rStates) * revRowP2 > 65535) { why = "reverse DFA missing or too large"; return false; }
   auto offT = [&](uint32_t s) { return s * rowBytes; };
   auto offA = [&](uint32_t a) { return (nT + a) * rowBytes; };
   auto offU = [&](uint32_t u) { return (nT + nA + u) * rowBytes; };
@@ -485,27 +489,34 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
   put(mem.data(), mem.size() * 2, h.mem_off);
   // reverse DFA, class-compressed, entries = byte offset of the target row; the classes come from the same NFA ranges,
   // so a class never straddles a reverse transition
-  const uint32_t revRow = rcols * 2;
-  std::vector<uint16_t> rv(static_cast<size_t>(rStates) * rcols, 0);
+  // ... and the offset is counted from the image's first byte behind the header, i.e. it is the row's LDS address in the kernel: a step
+  // needs no base added.  The table is aligned to its row size for the `|`; row 0 is the dead state and leads to itself.
+  const uint32_t revRow = revRowP2, rstride = revRowP2 / 2;
+  while ((img.size() - sizeof h) % revRow) img.push_back(0);
+  const uint32_t revBase = static_cast<uint32_t>(img.size() - sizeof h);
+  if (revBase + static_cast<size_t>(rStates) * revRow > 65535) { why = "reverse DFA missing or too large"; return false; }
+  std::vector<uint16_t> rv(static_cast<size_t>(rStates) * rstride, 0);
+  auto rentry = [&](uint32_t to) { return static_cast<uint16_t>((revBase + to * revRow) | (to >= rFirstAccept ? 1u : 0u)); };
   if (hasLook) {
     for (uint32_t s = 0; s < rStates; s++) {
-      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * rcols + c] = static_cast<uint16_t>(rtab[s][c] * revRow);
-      if (hasText) for (uint32_t r = 0; r < nk; r++) rv[static_cast<size_t>(s) * rcols + ncls + r] = rTextAcc[static_cast<size_t>(s) * nk + r];
+      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * rstride + c] = rentry(rtab[s][c]);
+      if (hasText) for (uint32_t r = 0; r < nk; r++) rv[static_cast<size_t>(s) * rstride + ncls + r] = rTextAcc[static_cast<size_t>(s) * nk + r];
     }
   } else {
     for (uint32_t s = 0; s < rev.nstates; s++)
-      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * ncls + c] = static_cast<uint16_t>(rev.table[static_cast<size_t>(s) * 256 + reps[c]] * revRow);
+      for (uint32_t c = 0; c < ncls; c++) rv[static_cast<size_t>(s) * rstride + c] = rentry(rev.table[static_cast<size_t>(s) * 256 + reps[c]]);
     for (uint32_t s = 0; s < rev.nstates; s++)
       for (int b = 0; b < 256; b++)
-        if (rev.table[static_cast<size_t>(s) * 256 + b] * revRow != rv[static_cast<size_t>(s) * ncls + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
+        if (rentry(rev.table[static_cast<size_t>(s) * 256 + b]) != rv[static_cast<size_t>(s) * rstride + cls[b]]) { why = "internal: reverse DFA splits a byte class"; return false; }
   }
   put(rv.data(), rv.size() * 2, h.rev_off);
-  h.rev_states = rStates; h.rev_start_off = rStart * revRow; h.rev_accept_off = rFirstAccept * revRow; h.rev_row_bytes = revRow;
+  if (h.rev_off - sizeof h != revBase) { why = "internal: image layout (reverse table)"; return false; }
+  h.rev_states = rStates; h.rev_start_off = revBase + rStart * revRow; h.rev_accept_off = revBase + rFirstAccept * revRow; h.rev_row_bytes = revRow;
   h.rev_text_col = hasText ? ncls * 2u : 0u;
   if (hasLook) {
     auto put16 = [&](uint32_t v16) { kndBlock.push_back(static_cast<uint8_t>(v16 & 0xFF)); kndBlock.push_back(static_cast<uint8_t>(v16 >> 8)); };
     for (uint32_t k = 0; k < nk; k++) put16(offT(startOf[k]));
-    for (uint32_t q = 0; q < nk * nk; q++) put16(rStart9[q] * revRow);
+    for (uint32_t q = 0; q < nk * nk; q++) put16(revBase + rStart9[q] * revRow);
     put(kndBlock.data(), kndBlock.size(), h.knd_off);
   } else h.knd_off = h.cls_off;
   while (img.size() % 16) img.push_back(0);

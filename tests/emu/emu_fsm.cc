@@ -22,6 +22,7 @@ struct HostMem : FsmClassify<HostMem<LOOK>, LOOK> {
   uint32_t outside;     // FsmHeader::outside_byte: what the kernel writes into its window around the haystack
   uint32_t byte(int32_t r) const { const int64_t p = origin_abs + r; return (p >= 0 && p < len) ? hay[p] : outside; }
   uint32_t dword(int32_t r) const { return byte(r) | (byte(r + 1) << 8) | (byte(r + 2) << 16) | (byte(r + 3) << 24); }
+  void below(int32_t e, uint32_t (&W)[5]) const { for (int j = 0; j < 5; j++) W[j] = dword(e - 17 + 4 * j); }   // fsm.hpp fsm_match_start16
 };
 struct LaneRows {
   int32_t end[kFsmLaneRowsMax];
@@ -40,7 +41,7 @@ FsmView view_of(const uint8_t* img) {
   v.rev = img + h->rev_off;
   v.ncls2 = 2 * h->ncls;
   v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col;
+  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col; v.rev_dead = h->rev_off - static_cast<uint32_t>(sizeof(FsmHeader));
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   v.knd = img + h->knd_off;
@@ -120,7 +121,8 @@ static int64_t emu_fsm(const uint8_t* img, const uint8_t* hay, uint64_t len, int
         const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;      // bytes exist in front of the window
         const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
         const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
-        int32_t s = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+        int32_t s = (v.rev_text_col == 0u || tile_lo != 0) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)      // as the kernel chooses
+                                                           : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
         if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
           // the kernel's epilogue: the walk again, bounded by the previous row's end, bytes from HBM / L2
           st[3]++;
@@ -263,6 +265,7 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
           const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
           const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
           int32_t s = DIRECT ? fsmd_match_start(m, tab, h->d_rstart, h->d_racc_lo, e, bound, lowest, over)
+                             : (v.rev_text_col == 0u || tile_lo != 0) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)
                              : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
             st[3]++;
