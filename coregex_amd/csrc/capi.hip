@@ -40,7 +40,7 @@ hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* pe
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes = 0);
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes = 0, bool lean = false);
 }  // namespace cxgdev
 
 namespace {
@@ -652,9 +652,12 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool litKernel = false;                                          // ... by its literal mode (round 5)
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // wave kernels: match-dense input seen before
   int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 (very dense)
-  static const bool fsmDirectOk = getenv("CXG_FSM_NO_DIRECT") == nullptr;                     // A/B: the class-indexed kernel for every machine
-  bool fsmDirect = fsmDirectOk && p->fsmNoDirect[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0;   // byte-indexed rows (fsm.hpp "Direct mode") while they serve the input
-  bool fsmDirectRan = false;
+  static const bool fsmDirectOk = getenv("CXG_FSM_NO_DIRECT") == nullptr;                     // A/B: the class-indexed tables for every machine
+  static const bool fsmLeanOk = getenv("CXG_FSM_NO_LEAN") == nullptr;                         // A/B: k_scan_fsm for every machine
+  // the lean kernel (scan_fsm.hip k_scan_fsml: shallow machines, entry states that collapse; byte-indexed rows where the image has them)
+  // while it serves the program's input
+  bool fsmDirect = fsmLeanOk && p->fsmNoDirect[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0;
+  bool fsmDirectRan = false, fsmDirectTables = false;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
   // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:
@@ -736,8 +739,9 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   if (gen == 10) {
     static const bool deepOnly = getenv("CXG_FSM_DEEP") != nullptr;   // A/B: the general event-list instantiation for every machine
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
-    fsmDirectRan = fsmDirect && !deepOnly && fh->direct_off != 0u && fh->depth <= 1 && fh->nk == 1 && a.prof == nullptr && a.dbg == 0;
-    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->end_col != 0u ? 2 : (fh->nk > 1 ? 1 : 0), stream, fsmDirectRan ? fh->direct_bytes : 0u);
+    fsmDirectRan = fsmDirect && !deepOnly && fh->depth <= 1 && a.prof == nullptr && a.dbg == 0;
+    fsmDirectTables = fsmDirectRan && fsmDirectOk && fh->direct_off != 0u && fh->nk == 1;
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->end_col != 0u ? 2 : (fh->nk > 1 ? 1 : 0), stream, fsmDirectTables ? fh->direct_bytes : 0u, fsmDirectRan);
   }
   else if (gen == 11) {
     std::memcpy(a.chain, p->delim, sizeof p->delim);
@@ -881,7 +885,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : (gen == 10 && fsmDirectRan) ? CXG_K_FSM_DIRECT : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : (gen == 10 && fsmDirectRan) ? (fsmDirectTables ? CXG_K_FSM_DIRECT : CXG_K_FSM_LEAN) : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -1012,8 +1016,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   err &= 0x00FFFFFFu;
   if ((err & 8u) && gen >= 3) {
     static const bool verbose = getenv("CXG_VERBOSE") != nullptr;
-    if (gen == 10 && fsmDirectRan && ((err >> 8) & ~0x72u) != 0u) {   // direct mode: an entry state that did not collapse, a match pending past the window — the class-indexed kernel has the machinery
-      if (verbose) fprintf(stderr, "[cxg] transducer kernel, direct mode: reason bits 0x%x, rerunning on the class-indexed kernel\n", err >> 8);
+    if (gen == 10 && fsmDirectRan && ((err >> 8) & ~0x72u) != 0u) {   // the lean kernel: an entry state that did not collapse, a match pending past the window — k_scan_fsm has the machinery
+      if (verbose) fprintf(stderr, "[cxg] transducer kernel, lean form: reason bits 0x%x, rerunning on k_scan_fsm\n", err >> 8);
       fsmDirect = false;
       if ((err >> 8) & 1u) p->fsmNoDirect[submatch ? 1 : 0].store(1, std::memory_order_relaxed);   // (input without synchronising structure: remembered for the program)
       relaunches++;
@@ -1721,7 +1725,8 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
     case CXG_K_FSM: return "k_scan_fsm";
-    case CXG_K_FSM_DIRECT: return "k_scan_fsmd";
+    case CXG_K_FSM_DIRECT: return "k_scan_fsml<direct>";
+    case CXG_K_FSM_LEAN: return "k_scan_fsml";
     case CXG_K_TEDDY_TABLE: return "k_scan_teddy";
     case CXG_K_CHARCLASS_TABLE: return "k_scan_charclass";
     default: return "none";

@@ -95,11 +95,12 @@ struct FsmHeader {              // device image; offsets in bytes from the heade
   // Round 6 — byte-indexed tables of the kernel's DIRECT mode (shallow machines without look-around whose rows fit): see "Direct mode"
   uint32_t direct_off, direct_bytes;               // section offset from the header (0: none) and its size: d_slots rows of 256 bytes, then u8[256] per slot: 0x80 a set, else pending levels
   uint32_t d_slots;                                // rows ("slots"); an entry is the slot of the next row
-  uint32_t d_racc_lo, d_rstart;                    // reverse automaton in the same slot space: accepting slots >= d_racc_lo, start slot; slot value 0 = dead
+  uint32_t d_racc_lo, d_rstart;                    // reverse automaton in the same slot space: accepting slots >= d_racc_lo, start slot; dead: d_rdead
   uint32_t d_top;                                  // slot of the set "any state"
   uint32_t end_col;                                // != 0: the pattern holds an end-of-text anchor (\z, $ without (?m)): 2 * the kind "end of the text" — a kind NO byte
                                                    // has; the step over the haystack's last byte takes column class + end_col (fsm.hpp "End of text")
-  uint32_t d_pad[3];
+  uint32_t d_rdead;                                // slot of the dead reverse state (its row leads to itself)
+  uint32_t d_pad[2];
 };
 constexpr uint32_t kFsmdMaxBytes = 12288u;         // largest direct section the kernel has an instantiation for: beyond it the rows cost a resident workgroup per CU and their
                                                    // reads collide in the LDS banks (README IPv4 pattern, 20 KiB: 0.71 ms against 0.62 class-indexed — profiles/r06_c2_*)
@@ -121,7 +122,13 @@ constexpr uint32_t kFsmdMaxBytes = 12288u;         // largest direct section the
 // forward step sees it — the step over the haystack's last byte — and one reverse start row (a match that ends at len); a thread
 // that passed the anchor can consume nothing, so everything else runs as if the anchor never held.  LOOK == 2 instantiations
 // compare a step's position with the last byte's (Mem::last()) and swap the kind in: two VALU per byte, for these programs only.
-CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) { return *reinterpret_cast<const uint16_t*>(p + byte_off); }
+CXG_FSM_HD uint32_t fsm_u16(const uint8_t* p, uint32_t byte_off) {
+  uint32_t r = *reinterpret_cast<const uint16_t*>(p + byte_off);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(r));   // opaque: knowing that the upper half is zero the compiler narrows the next step's  (entry & ~3) | class  to 16-bit operations
+#endif                 // and widens the result again — two or three instructions where v_and_or_b32 is one (round 6, ISA of the walks)
+  return r;
+}
 struct FsmView {
   const uint8_t* cls2;      // 2 * nk * class of a byte: byte offset of the class's first column
   const uint8_t* knd;       // 2 * kind of a byte (nk > 1); behind it the start-row tables (FsmHeader::knd_off)
@@ -192,7 +199,7 @@ CXG_FSM_HD uint32_t fsm_canon(const FsmView& v, uint32_t x) { return fsm_u16(v.t
 // member j (0..7) of the set row u, as a row offset; 0xFFFF: none / the set is not listed
 CXG_FSM_HD uint32_t fsm_member(const FsmView& v, uint32_t u, uint32_t j) { return fsm_u16(v.mem, (((u - v.u_lo) >> v.row_shift) * 8u + j) * 2u); }
 // one step: entry t (row offset | flags) and 2 * class -> next entry
-CXG_FSM_HD uint32_t fsm_next(const FsmView& v, uint32_t t, uint32_t cls2) { return fsm_u16(v.tab, (t & ~3u) | cls2); }
+CXG_FSM_HD uint32_t fsm_next(const FsmView& v, uint32_t t, uint32_t cls2) { return fsm_u16(v.tab, (t & 0xFFFCu) | cls2); }   // (an entry is 16 bits wide: with ~3 the compiler zero-extends it by a second instruction in some walks)
 CXG_FSM_HD uint32_t fsm_shift_in2(uint32_t mask, uint32_t t) {   // (mask >> 2) | (t << 30): v_alignbit_b32
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_alignbit(t, mask, 2u);
@@ -503,11 +510,11 @@ CXG_FSM_HD void fsmd_chunk(const Mem& m, const Tab& tab, const int32_t (&c0)[N],
   }
 }
 // fsm_match_start over the byte-indexed reverse rows: smallest p >= bound with hay[p, e) in the language, kFsmNoStart when the
-// automaton never accepts; over: still alive at budget_lo with the haystack going on in front of it.
+// automaton never accepts; over: still alive at budget_lo with the haystack going on in front of it.  R: the reverse automaton's
+// start, first accepting and dead slots (FsmHeader::d_rstart, d_racc_lo, d_rdead).
+struct FsmdRev { uint32_t start, acc_lo, dead; };
 template <class Mem, class Tab>
-CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, uint32_t rstart, uint32_t racc_lo, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
-  uint32_t s = rstart;
-  int32_t st = kFsmNoStart, at = e - 1;
+CXG_FSM_HD int32_t fsmd_match_start_from(const Mem& m, const Tab& tab, const FsmdRev& R, uint32_t s, int32_t st, int32_t at, int32_t bound, int32_t budget_lo, uint32_t& over) {
   const int32_t low = bound > budget_lo ? bound : budget_lo;
   uint32_t b[4], bn[4];                                  // four bytes fetched together (clamped to the window), the next four before this group's chain
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -526,8 +533,8 @@ CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, uint32_t rstar
     for (int k = 0; k < 4; k++) {
       if (dead || at - k < low) break;
       s = tab.at(fsmd_addr(s, b[k], 0));
-      if (s == 0u) { dead = true; break; }
-      if (s >= racc_lo) st = at - k;
+      if (s == R.dead) { dead = true; break; }
+      if (s >= R.acc_lo) st = at - k;
     }
     if (dead) return st;
     at = at - 4 >= low - 1 ? at - 4 : low - 1;
@@ -537,6 +544,34 @@ CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, uint32_t rstar
     for (int k = 0; k < 4; k++) b[k] = bn[k];
   }
   if (at >= bound) over = 1u;
+  return st;
+}
+template <class Mem, class Tab>
+CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, const FsmdRev& R, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  return fsmd_match_start_from(m, tab, R, R.start, kFsmNoStart, e - 1, bound, budget_lo, over);
+}
+// ... and its first 16 steps without a branch (fsm_match_start16 below, where the reasons are): v_perm_b32 + ds_read_u8 per step, the
+// accept test as a compare whose carry is added into the flag word.
+template <class Mem, class Tab>
+CXG_FSM_HD int32_t fsmd_match_start16(const Mem& m, const Tab& tab, const FsmdRev& R, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  uint32_t W[5];
+  m.below(e, W);
+  uint32_t s = R.start, acc = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < 16; k++) {                          // step k is over byte e - 1 - k = byte 16 - k of W
+    const int i = 16 - k;
+    s = tab.at(fsmd_addr(s, W[i >> 2], i & 3));
+    acc = acc + acc + (s >= R.acc_lo ? 1u : 0u);          // bit 15 - k
+  }
+  const int32_t low = bound > budget_lo ? bound : budget_lo;
+  const uint32_t room = static_cast<uint32_t>(e - low);
+  if (room <= 16u && low != bound) return fsmd_match_start(m, tab, R, e, bound, budget_lo, over);
+  uint32_t f = acc;
+  if (room < 16u) f &= ~((1u << (16u - room)) - 1u);
+  int32_t st = f ? e - 16 + static_cast<int32_t>(__builtin_ctz(f)) : kFsmNoStart;   // lowest bit = largest k: k = 15 - ctz, start e - 1 - k
+  if (room > 16u && s != R.dead) st = fsmd_match_start_from(m, tab, R, s, st, e - 17, bound, budget_lo, over);
   return st;
 }
 

@@ -21,99 +21,11 @@
 // (block_common.hpp) and written as coalesced 16-byte stores.  The first row of a GROUP cannot see its predecessor's
 // end inside the kernel: k_fsm_fix_heads checks those rows afterwards (one thread per group).
 // Roofline: HBM-bound by design (each byte read once, 16 B per match written); in practice LDS-latency / VALU bound.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-
-#include "block_common.hpp"
-#include "fsm.hpp"
-#include "scan_dfa.h"
-#include "wave_common.hpp"
-
-// -DCXG_FSM_PROF=1 (experiments only): s_memtime at the phase boundaries, cycles summed into ScanArgs::prof[8..15]
-#ifndef CXG_FSM_PROF
-#define CXG_FSM_PROF 0
-#endif
-// -DCXG_FSM_ABL=n (experiments only, results WRONG): bit 0 = no entry-state walks, bit 1 = no lockstep walk of the
-// chunk, bit 2 = no row gathering / starts.  Attributes instruction counts to the phases.
-#ifndef CXG_FSM_ABL
-#define CXG_FSM_ABL 0
-#endif
-// -DCXG_FSM_FAST_STARTS=0 (A/B): match starts by the loop alone, without the 16 branch-free steps in front of it (fsm.hpp fsm_match_start16)
-#ifndef CXG_FSM_FAST_STARTS
-#define CXG_FSM_FAST_STARTS 1
-#endif
-#if CXG_FSM_PROF
-#define FSM_MARK(i) do { const uint64_t t_ = __builtin_readcyclecounter(); pacc[i] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define FSM_MARK(i) do { } while (0)
-#endif
+#include "scan_fsm_common.hpp"
 
 namespace cxgdev {
 
 namespace {
-
-constexpr int kFsmStride = 68;                       // LDS bytes per 64-byte chunk
-constexpr int kFsmWinBytes = 64 * kFsmStride + 16;   // 4352 per wave + the dword BEHIND the window (look-around: the kind of the byte behind a step)
-constexpr int kFsmLeft = 64;                         // bytes staged in front of the tile
-constexpr int32_t kFsmWinEnd = 4096 - kFsmLeft;      // tile-relative end of the window (192 bytes past the tile)
-
-// The tile loop reads haystack bytes from the LDS window ONLY.  A load from HBM anywhere in the loop body — even on a
-// path that is never taken — makes the compiler wait for vmcnt(0) at the join, i.e. for the window of the NEXT tile
-// that is in flight: the prefetch would be worth nothing.  Walks that leave the window are finished elsewhere: a match
-// start in front of the window in the epilogue (rows marked unresolved), a walk past the window's end by the fallback.
-typedef __attribute__((address_space(3))) const uint8_t* lds_bytes_t;
-template <int LOOK>
-struct FsmMem : FsmClassify<FsmMem<LOOK>, LOOK> {
-  lds_bytes_t win;         // this wave's LDS window: tile-relative bytes [-kFsmLeft, 4096 - kFsmLeft)
-  int32_t last_;           // LOOK == 2: tile-relative position of the haystack's last byte (fsm.hpp "End of text")
-  __device__ __forceinline__ int32_t last() const { return last_; }
-  __device__ __forceinline__ uint32_t byte(int32_t r) const {
-    const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    return win[w + (w >> 6) * 4u];
-  }
-  __device__ __forceinline__ uint32_t dword(int32_t r) const {
-    const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
-  }
-  // the 17 bytes below e (fsm.hpp fsm_match_start16): five aligned dwords, shifted into place
-  __device__ __forceinline__ void below(int32_t e, uint32_t (&W)[5]) const {
-    const uint32_t w0 = static_cast<uint32_t>(e - 17 + kFsmLeft), wb = w0 & ~3u, sh = w0 & 3u;
-    uint32_t d[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      const uint32_t w = wb + 4u * j;
-      d[j] = *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) W[j] = __builtin_amdgcn_alignbyte(d[j < 4 ? j + 1 : 4], d[j], sh);
-  }
-};
-struct LdsRows {
-  uint16_t* slot;          // this lane's kFsmLaneRows ends
-  __device__ __forceinline__ void set_end(uint32_t r, int32_t e) { slot[r] = static_cast<uint16_t>(e); }
-};
-struct LdsEvents {
-  uint16_t* slot;          // kFsmLaneEvents alias rows of one sub-chunk
-  __device__ __forceinline__ void push(uint32_t k, uint32_t row) { slot[k] = static_cast<uint16_t>(row); }
-  __device__ __forceinline__ uint32_t row_at(uint32_t k) const { return slot[k]; }
-};
-
-__device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader* h) {   // body = image without its header, in LDS
-  FsmView v;
-  const uint32_t hs = static_cast<uint32_t>(sizeof(FsmHeader));
-  v.tab = body;             // fixed layout (host/fsm.cc): the transition table first — at LDS address 0, see FsmLds
-  v.cls2 = body + (h->cls_off - hs);
-  v.rev = body + (h->rev_off - hs);
-  v.ncls2 = 2u * h->ncls;
-  v.alias_lo = h->alias_lo; v.u_lo = h->u_lo; v.top_off = h->top_off;
-  v.rev_start_off = h->rev_start_off; v.rev_accept_off = h->rev_accept_off; v.rev_text_col = h->rev_text_col; v.end_col = h->end_col; v.rev_dead = h->rev_off - hs;
-  v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
-  v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
-  v.knd = body + (h->knd_off - hs);
-  v.nk = h->nk;
-  return v;
-}
 
 // All LDS of the kernel is ONE struct, the image first: the transition table then sits at LDS address 0 and a walk
 // step's address  (entry & ~3) | 2 * class  goes straight into the ds_read — no base add on the dependent chain
@@ -122,12 +34,6 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
 // MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per
 // tile, match-dense input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match
 // per 2 bytes).  The host escalates after an overflow and remembers the mode for the program (capi.hip).
-template <int MODE> struct FsmMode {
-  static constexpr int kTpw = MODE == 0 ? kTilesPerWave : (MODE == 1 ? kDenseTilesPerWave : 1);
-  static constexpr int kRows = MODE == 2 ? kFsmLaneRowsMax : kFsmLaneRows;
-  static constexpr int kEvents = MODE == 2 ? kFsmLaneEventsMax : kFsmLaneEvents;
-  static constexpr int kRowsPerWave = MODE == 2 ? 2048 : 512;
-};
 template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];
@@ -338,50 +244,6 @@ __device__ __forceinline__ void fsm_resolve_exits(const FsmView& v, uint32_t* s_
       if (lane == 0) s_exit[q] = c | kExitValid;
     }
   }
-}
-
-// Rows of a tile from the event bits of its lanes (fsm.hpp "Round 6"): an event is a row's end unless the event behind it is a rematch.
-// KK: the lane's two sub-chunks (two bits per byte), active: the lane walked, owned: its rows are this tile's (lanes 1..60; the
-// three lanes behind them only contribute their bits).  The ends land in s_re[nrows_w ...] in ascending order; returns their
-// number.  pend_at_end(): pending levels of the row behind the lane's second sub-chunk (asked of lane 63 only, rarely).
-template <int kRowsPerWave, class Pend>
-__device__ __forceinline__ uint32_t fsm_rows_from_events(const uint64_t (&KK)[2], bool active, bool owned, int32_t rend, int32_t c0, int lane,
-                                                         uint16_t* s_re_wave, uint32_t nrows_w, uint32_t& fallback, Pend pend_at_end) {
-  const uint64_t k0 = active ? (KK[0] & fsm_valid_bits(rend - c0)) : 0ull, k1 = active ? (KK[1] & fsm_valid_bits(rend - c0 - kFsmSub)) : 0ull;
-  const uint32_t T[4] = {static_cast<uint32_t>(k0), static_cast<uint32_t>(k0 >> 32), static_cast<uint32_t>(k1), static_cast<uint32_t>(k1 >> 32)};
-  const bool ne = (T[0] | T[1] | T[2] | T[3]) != 0u;
-  const unsigned long long NE = __ballot(ne), FR = __ballot(ne && fsm_first_is_r(T));
-  const unsigned long long LN = fsm_lanes_succ_r(NE, FR);           // (scalar unit)
-  // The window's last event with the input going on behind the window: whether a rematch follows is not known here.  A row
-  // of this tile only when that event lies in an owned lane AND a match is still pending at the window's end — a match
-  // that reaches 190 bytes past its tile: the host's next rung.
-  if (rend > kFsmWinEnd && NE != 0ull && 63 - __builtin_clzll(NE) <= kWaveTile / kFsmChunk) {
-    const uint32_t pend = pend_at_end();
-    if (__builtin_amdgcn_readlane(static_cast<int>(pend), 63) != 0) fallback |= 8u;
-  }
-  uint32_t Er[4];
-  fsm_lane_ends(T, static_cast<uint32_t>(LN >> lane) & 1u, Er);
-  if (!owned || (CXG_FSM_ABL & 4)) Er[0] = Er[1] = Er[2] = Er[3] = 0u;
-  const uint32_t nl = static_cast<uint32_t>(__builtin_popcount(Er[0]) + __builtin_popcount(Er[1]) + __builtin_popcount(Er[2]) + __builtin_popcount(Er[3]));
-  const uint32_t incl = wave_inclusive_sum(nl);
-  const uint32_t tot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-  uint32_t idx = nrows_w + incl - nl;
-  // the ends in ascending order: T's dword i is Er[3 - i] reversed, so its lowest position is the highest bit there.  No masked
-  // branch in the loop (a lane without a bit writes the dump slot), one uniform branch per round.
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint32_t xw = Er[3 - i];
-    const int32_t e0 = c0 + 16 * i + 1;
-    while (__builtin_amdgcn_ballot_w64(xw != 0u) != 0ull) {
-      const bool has = xw != 0u;
-      const uint32_t q = static_cast<uint32_t>(__builtin_clz(xw | 1u));
-      xw &= ~(0x80000000u >> q);
-      const uint32_t slot = (has && idx < static_cast<uint32_t>(kRowsPerWave)) ? idx : static_cast<uint32_t>(kRowsPerWave);
-      s_re_wave[slot] = static_cast<uint16_t>(e0 + static_cast<int32_t>(q >> 1));
-      idx += has ? 1u : 0u;
-    }
-  }
-  return tot;
 }
 
 }  // namespace
@@ -870,213 +732,6 @@ __global__ void k_fsm_fix_heads(ScanArgs a) {
   row[0] = a.base + st;
 }
 
-// ---- Direct mode (round 6, fsm.hpp "Direct mode"): shallow machines without look-around whose byte-indexed rows fit.  Same
-// geometry, window, row derivation, group ordering and look-back as k_scan_fsm<SHALLOW>; the walks read ONE table entry per byte
-// (v_perm_b32 + ds_read_u8 + v_alignbit instead of five instructions), the warm-up and the chunk are one walk, match starts come
-// from byte-indexed reverse rows.  What this kernel does not carry is the machinery for entry states that do not collapse
-// (maps, deferred tiles, hand-offs between groups): such input raises fallback reason 1 and the host reruns the call — and
-// the program's next calls — on k_scan_fsm.
-namespace {
-template <int IMG, int MODE>
-struct FsmdLds {
-  uint8_t img[IMG];                                            // the direct section: rows of 256 bytes at LDS address 0, then the property table
-  uint8_t win[kWavesPerBlock][kFsmWinBytes];
-  uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];
-  uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];
-  uint32_t cnt[kWavesPerBlock][kTilesPerWave];
-  uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
-  int64_t tail[kWavesPerBlock * kTilesPerWave];
-  uint64_t group;
-  uint64_t base;
-};
-struct FsmdTab {                                               // the image sits at LDS address 0: a step's address goes straight into the ds_read
-  lds_bytes_t img;
-  __device__ __forceinline__ uint32_t at(uint32_t addr) const { return img[addr]; }
-};
-struct FsmdMem {
-  lds_bytes_t win;
-  __device__ __forceinline__ uint32_t byte(int32_t r) const {
-    const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    return win[w + (w >> 6) * 4u];
-  }
-  __device__ __forceinline__ uint32_t dword(int32_t r) const {
-    const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
-    return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
-  }
-};
-}  // namespace
-
-template <int IMG, int MODE>
-__global__ __launch_bounds__(kThreads, (MODE == 2 ? 2 : 4)) void k_scan_fsmd(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) FsmdLds<IMG, MODE> S;
-  constexpr int kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
-  constexpr int tpw = FsmMode<MODE>::kTpw;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid == 0) S.group = claim_group(a.static_groups != 0, a.ticket, a.ngroups);
-  const FsmHeader* h = reinterpret_cast<const FsmHeader*>(a.blob);
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(a.blob + h->direct_off);
-    const uint32_t nvec = h->direct_bytes >> 4;
-    for (uint32_t i = tid; i < nvec; i += kThreads) reinterpret_cast<uint4*>(S.img)[i] = src[i];
-  }
-  __syncthreads();
-  const uint64_t group = S.group;
-  if (group >= a.ngroups) return;
-  FsmdTab tab;
-  tab.img = (lds_bytes_t)S.img;
-  const uint32_t top = h->d_top, prop = h->d_slots << 8, rstart = h->d_rstart, racc_lo = h->d_racc_lo;
-  uint32_t nrows_w = 0, fallback = 0, long_hit = 0;
-
-  u32x4 x[4];
-  auto issue_loads = [&](int jj) {
-    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
-    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
-    int nrec = 0;
-    const int pre = lo ? 0 : kFsmLeft;
-    const uint64_t from = lo ? lo - kFsmLeft : 0;
-    if (jj < tpw && lo < a.len) {
-      const uint64_t rem = a.len - from;
-      nrec = rem >= static_cast<uint64_t>(4096 - pre) ? 4096 - pre : static_cast<int>((rem + 3) & ~3ull);
-    }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? from : 0), 0, nrec, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((lane + 64 * k) << 4) - pre, 0, 0);
-  };
-  issue_loads(0);
-  for (int j = 0; j < tpw; j++) {
-    const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
-    const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
-    uint32_t tot = 0;
-    if (tile_lo < a.len) {
-      uint8_t* win = S.win[wave];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t wo = static_cast<uint32_t>(lane + 64 * k) << 4;
-        uint32_t* d = reinterpret_cast<uint32_t*>(win + wo + (wo >> 6) * 4u);
-        d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
-      }
-      issue_loads(j + 1);
-      const uint64_t remaining = a.len - tile_lo;
-      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
-      wave_lds_sync();
-      const int32_t lowest = tile_lo ? -kFsmLeft : 0;
-      FsmdMem m;
-      m.win = (lds_bytes_t)win;
-      const int32_t c0 = (lane - 1) * kFsmChunk;
-      const bool owned = lane >= 1 && lane <= kWaveTile / kFsmChunk && c0 < rend;
-      const bool active = lane >= 1 && c0 < rend;               // the three lanes behind the tile: event bits of the window's tail
-      const int32_t cc[2] = {c0, c0 + kFsmSub};
-      uint64_t KK[2] = {0ull, 0ull};
-      uint32_t xend1 = 0u;
-      if (active) {
-        // warm-up: 16 bytes from "any state" in front of each sub-chunk (bytes in front of the haystack read as zeros and are
-        // overruled below); a set that has not collapsed by then gets 64 bytes, and what is left after that is the host's
-        const bool at_origin = tile_lo + static_cast<uint64_t>(c0) == 0;
-        uint32_t e[2] = {top, top};
-        const int32_t wfrom[2] = {cc[0] - 16, cc[1] - 16};
-        fsmd_walk_n<2>(m, tab, wfrom, 16, e);
-        if (at_origin) e[0] = 0u;                               // the haystack's first byte: the search starts in state 0
-        const uint32_t u0 = tab.at(prop + e[0]) & 0x80u, u1 = tab.at(prop + e[1]) & 0x80u;
-        if (u0 | u1) {                                          // rare on text
-#pragma unroll 1
-          for (int sb = 0; sb < 2; sb++) {
-            if (!(sb ? u1 : u0)) continue;
-            const bool from_start = at_origin && sb;            // (the second sub-chunk of the haystack's first chunk: from the true start state)
-            const int32_t f1[1] = {from_start ? 0 : cc[sb] - 64};
-            uint32_t xx[1] = {from_start ? 0u : top};
-            fsmd_walk_n<1>(m, tab, f1, cc[sb] - f1[0], xx);
-            e[sb] = xx[0];
-            if (tab.at(prop + xx[0]) & 0x80u) fallback |= 1u;
-          }
-        }
-        // the chunk: two chains in lockstep, the flag bits of every step shifted into the masks
-        FsmTraceS t[2] = {{e[0], 0u, 0u}, {e[1], 0u, 0u}};
-        fsmd_chunk<2>(m, tab, cc, t);
-        KK[0] = (static_cast<uint64_t>(t[0].k1) << 32) | t[0].k0; KK[1] = (static_cast<uint64_t>(t[1].k1) << 32) | t[1].k0;
-        xend1 = t[1].x;
-      }
-      tot = fsm_rows_from_events<kRowsPerWave>(KK, active, owned, rend, c0, lane, S.re[wave], nrows_w, fallback,
-                                               [&]() { return tab.at(prop + xend1) & 0x7Fu; });
-      wave_lds_sync();
-      if (a.out != nullptr || a.max_len != 0) {
-        for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kRowsPerWave); q += 64) {
-          const int32_t e = S.re[wave][nrows_w + q];
-          const int32_t bound = q ? static_cast<int32_t>(S.re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
-          uint32_t over = 0;
-          const int32_t st = fsmd_match_start(m, tab, rstart, racc_lo, e, bound, lowest, over);
-          const uint32_t len = (over || st == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - st);
-          if (st == kFsmNoStart && !over) fallback |= 64u;
-          S.rl[wave][nrows_w + q] = static_cast<uint16_t>(len);
-        }
-      }
-    }
-    if (lane == 0) S.cnt[wave][j] = tot;
-    nrows_w += tot;
-  }
-  if (nrows_w > static_cast<uint32_t>(kRowsPerWave)) fallback |= 32u;
-  {
-    uint32_t f = fallback;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) f |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(f), d, 64));
-    if (f != 0 && lane == 0) raise_err(a.err, 8u | (f << 8));
-  }
-  __syncthreads();
-  // ---- order the group's rows (as k_scan_fsm): wave-tile q = j * 4 + wave
-  if (tid < 64) {
-    const int q = tid;
-    const uint32_t c = (q < kWavesPerBlock * tpw) ? S.cnt[q % kWavesPerBlock][q / kWavesPerBlock] : 0u;
-    const uint32_t incl = wave_inclusive_sum(c);
-    if (q < kWavesPerBlock * tpw) S.qbase[q] = incl - c;
-    if (q == kWavesPerBlock * tpw - 1) S.qbase[kWavesPerBlock * tpw] = incl;
-  }
-  const int64_t gorigin = static_cast<int64_t>(group * static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * tpw);
-  if (tid >= 64 && tid < 64 + kWavesPerBlock * tpw) {
-    const int q = tid - 64, w = q % kWavesPerBlock, jj = q / kWavesPerBlock;
-    uint32_t st = 0;
-    for (int k = 0; k < jj; k++) st += S.cnt[w][k];
-    const uint32_t n = S.cnt[w][jj];
-    S.tail[q] = (n && st + n <= static_cast<uint32_t>(kRowsPerWave)) ? gorigin + static_cast<int64_t>(q) * kWaveTile + S.re[w][st + n - 1] : -1;
-  }
-  __syncthreads();
-  const uint32_t total = S.qbase[kWavesPerBlock * tpw];
-  tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &S.base, a.epoch);
-  const uint64_t base = S.base;
-  uint32_t start = 0;
-  for (int j = 0; j < tpw; j++) {
-    const uint32_t n = S.cnt[wave][j];
-    const int q = j * kWavesPerBlock + wave;
-    const uint64_t dst = base + S.qbase[q];
-    const int64_t tb = gorigin + static_cast<int64_t>(q) * kWaveTile;
-    for (uint32_t i = lane; i < n; i += 64) {
-      const uint32_t r = start + i;
-      if (r >= static_cast<uint32_t>(kRowsPerWave)) continue;
-      int64_t e = tb + S.re[wave][r], s0 = e - S.rl[wave][r];
-      if ((i == 0 || s0 == e) && (a.out != nullptr || a.max_len != 0)) {
-        int64_t prev = -1;
-        if (i > 0) prev = tb + S.re[wave][r - 1];
-        else for (int p = q - 1; p >= 0 && prev < 0; p--) prev = S.tail[p];
-        if (prev > s0 || s0 == e) {                                           // rare: walk again from HBM / L2, bounded
-          const int64_t lo = prev > 0 ? prev : 0;
-          uint32_t sr = rstart;
-          int64_t st = -1, at = e - 1;
-          for (; at >= lo; at--) {
-            if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-            sr = tab.at(fsmd_addr(sr, a.hay[at], 0));
-            if (sr == 0u) break;
-            if (sr >= racc_lo) st = at;
-          }
-          if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s0 = st;
-        }
-      }
-      if (a.max_len != 0 && static_cast<uint64_t>(e - s0) > a.max_len) long_hit = 1;
-      if (a.out != nullptr && dst + i < a.cap) store_pair_nt(a.out + (dst + i) * a.row_width, a.base + s0, a.base + e);
-    }
-    start += n;
-  }
-  if (long_hit) raise_err(a.err, kErrLongMatch);
-}
-
 namespace {
 template <int IMG, int LOOK>
 void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 block, hipStream_t stream) {
@@ -1092,26 +747,15 @@ void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 b
 }
 }  // namespace
 
-namespace {
-template <int IMG>
-void launch_fsmd_img(const ScanArgs& a, int mode, dim3 grid, dim3 block, hipStream_t stream) {
-  if (mode == 0) hipLaunchKernelGGL((k_scan_fsmd<IMG, 0>), grid, block, 0, stream, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_scan_fsmd<IMG, 1>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((k_scan_fsmd<IMG, 2>), grid, block, 0, stream, a);
-}
-}  // namespace
+hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes);   // scan_fsml.hip
 
-// direct_bytes != 0: the direct mode's kernel (the caller has checked that the image carries the section and the machine is shallow)
-// look: 0 / 1 / 2 as the kernel's LOOK (2: FsmHeader::end_col != 0 — rare programs, one image size only)
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes) {
+// lean != 0: the lean kernel (the machine is shallow); direct_bytes != 0 with it: its direct mode (the caller has checked that the image
+// carries the section).  look: 0 / 1 / 2 as the kernels' LOOK (2: FsmHeader::end_col != 0 — rare programs, one image size only)
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, bool lean) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
   const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
   if (lds_bytes > 28672) return hipErrorInvalidValue;
-  if (direct_bytes != 0u) {
-    if (direct_bytes > kFsmdMaxBytes || !shallow || look) return hipErrorInvalidValue;
-    if (direct_bytes <= 6144) launch_fsmd_img<6144>(a, mode, grid, block, stream);
-    else launch_fsmd_img<12288>(a, mode, grid, block, stream);
-  }
+  if (lean) { const hipError_t el = launch_scan_fsml(a, lds_bytes, shallow, look, stream, direct_bytes); if (el != hipSuccess) return el; }
   else if (look == 2) launch_fsm_img<28672, 2>(a, shallow, mode, grid, block, stream);             // end-of-text programs
   else if (look) {                                                                                   // word-boundary programs
     if (lds_bytes <= 3072) launch_fsm_img<3072, 1>(a, shallow, mode, grid, block, stream);

@@ -560,8 +560,8 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
     uint32_t nslots = 4u * nT, cursor = 1;
     bool fits = true;
     auto takeFree = [&](uint32_t from) -> uint32_t { uint32_t q = from; while (q < 256 && used[q]) q++; return q; };
-    for (int pass = 0; pass < 2 && fits; pass++)                   // block 0 = dead has no row: slot value 0
-      for (uint32_t b = 1; b < rblocks && fits; b++) {
+    for (int pass = 0; pass < 2 && fits; pass++)                   // (block 0 = dead has a row of its own that leads to itself: the branch-free walk needs it to absorb)
+      for (uint32_t b = 0; b < rblocks && fits; b++) {
         const bool acc = rrep[b] >= rev.firstAccept;
         if (acc != (pass == 1)) continue;
         const uint32_t q = takeFree(cursor);
@@ -596,10 +596,10 @@ bool buildFsmImageCapped(const cxg_nfa& nfa, const Dfa& rev, uint32_t max_len, s
       }
       for (int b = 0; b < 256; b++) d[static_cast<size_t>(uslot[nU]) * 256 + b] = static_cast<uint8_t>(uslot[nU]);
       prop[uslot[nU]] = 0x80;
-      for (uint32_t b = 1; b < rblocks; b++)
+      for (uint32_t b = 0; b < rblocks; b++)
         for (int x = 0; x < 256; x++) d[static_cast<size_t>(rslot[b]) * 256 + x] = static_cast<uint8_t>(rslot[rpart[rev.table[static_cast<size_t>(rrep[b]) * 256 + x]]]);
       put(d.data(), d.size(), h.direct_off);
-      h.direct_bytes = dbytes; h.d_slots = nslots; h.d_racc_lo = raccLo; h.d_rstart = rslot[rpart[rev.start]]; h.d_top = uslot[0];
+      h.direct_bytes = dbytes; h.d_slots = nslots; h.d_racc_lo = raccLo; h.d_rstart = rslot[rpart[rev.start]]; h.d_top = uslot[0]; h.d_rdead = rslot[0];
       while (img.size() % 16) img.push_back(0);
       h.total_bytes = static_cast<uint32_t>(img.size());           // (lds_bytes stays the class-indexed image's: the two are staged alternatively)
     }

@@ -67,7 +67,7 @@ struct cxg_program {
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: a wave kernel overflowed its row buffers on this program's
                                                               // input once: later calls start with two tiles per wave (capi.hip)
   mutable std::atomic<uint8_t> fsmMode[2] = {{0}, {0}};      // ... the transducer kernel's density mode seen necessary: 0, 1 (2 tiles per wave), 2 (1 tile)
-  mutable std::atomic<uint8_t> fsmNoDirect[2] = {{0}, {0}};  // ... its direct mode (byte-indexed rows) met an entry state that did not collapse: the class-indexed kernel from now on
+  mutable std::atomic<uint8_t> fsmNoDirect[2] = {{0}, {0}};  // ... its lean kernel (k_scan_fsml) met an entry state that did not collapse: k_scan_fsm from now on
   // Offset captures (round 4): every capture boundary lies a fixed number of bytes behind the match's start or in front of its end
   // (`user=(\S+)`, `"([^"]*)"`, `\[([^\]]+)\]`).  FindAllSubmatch is then FindAll + one expansion kernel (capi.hip scanOffsetCaps)
   // instead of a backtracking pass per row.  offCaps[0] != 0: on; slot k >= 2: offSrc[k] 0 = start, 1 = end; offDelta[k] added.

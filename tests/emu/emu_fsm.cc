@@ -264,14 +264,15 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
           const bool window_cut = static_cast<int64_t>(tile_lo) + lowest > 0;
           const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
           const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
-          int32_t s = DIRECT ? fsmd_match_start(m, tab, h->d_rstart, h->d_racc_lo, e, bound, lowest, over)
+          const FsmdRev R = {h->d_rstart, h->d_racc_lo, h->d_rdead};
+          int32_t s = DIRECT ? fsmd_match_start16(m, tab, R, e, bound, lowest, over)
                              : (v.rev_text_col == 0u || tile_lo != 0) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)
                              : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
             st[3]++;
             over = 0;
             const int32_t pb = static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
-            s = DIRECT ? fsmd_match_start(m, tab, h->d_rstart, h->d_racc_lo, e, pb, -static_cast<int32_t>(tile_lo), over)
+            s = DIRECT ? fsmd_match_start(m, tab, R, e, pb, -static_cast<int32_t>(tile_lo), over)
                        : fsm_match_start(v, m, e, pb, -static_cast<int32_t>(tile_lo), over, -static_cast<int32_t>(tile_lo));
           }
           if (over) return -16 - 8;

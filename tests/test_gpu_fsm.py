@@ -9,7 +9,7 @@ from refcorpus import COMPAT_PATTERNS, generate_test_input
 
 pytestmark = pytest.mark.gpu
 
-K_FSM = (10, 19)   # CXG_K_FSM, CXG_K_FSM_DIRECT (round 6: the same machine through byte-indexed rows)
+K_FSM = (10, 19, 20)   # CXG_K_FSM, CXG_K_FSM_DIRECT (round 6: the same machine through byte-indexed rows), CXG_K_FSM_LEAN (the lean kernel)
 
 
 @pytest.fixture(autouse=True)

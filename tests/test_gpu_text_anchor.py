@@ -72,7 +72,7 @@ def test_end_of_text_at_every_edge(pat, oracle):
     out = torch.empty((len(exp) + 8, 2), dtype=torch.int64, device="cuda")
     n = rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), len(exp) + 8, base=5000, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp + 5000)
-    routed(10 in t.kernels, t.kernels)
+    routed(10 in t.kernels or 20 in t.kernels, t.kernels)
 
 
 def test_long_first_match(oracle):
@@ -108,7 +108,7 @@ def test_each_call_is_one_text(oracle):
     t = cx.Timing()
     n = rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), 8, base=1000, timing=t)
     assert n == len(exp) and np.array_equal(out[:n].cpu().numpy(), exp + 1000)
-    routed(t.kernels == [10], t.kernels)
+    routed(t.kernels in ([10], [20]), t.kernels)
 
 
 def test_reference_pairs_on_the_device(oracle):
