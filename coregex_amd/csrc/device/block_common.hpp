@@ -19,7 +19,7 @@ __device__ __forceinline__ void raise_err(uint32_t* err, uint32_t bits) {
   __hip_atomic_fetch_or(err, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// A spin watchdog ran out: error bit 1, and WHICH wait it was in bits 24..27 (capi.hip reads it to decide what to demote:
+// A spin watchdog ran out: error bit 1, and WHICH wait it was in bits 24..27 (capi_ladder.hip reads it to decide what to demote:
 // 1 grouped look-back, 2 delimiter look-back, 3 / 4 transducer hand-off / group entry, 5 / 6 persistent kernel duty / record).
 constexpr uint32_t kWdLookback = 1, kWdDelim = 2, kWdFsmExit = 3, kWdFsmEntry = 4, kWdPersDuty = 5, kWdPersRecord = 6;
 __device__ __forceinline__ void raise_watchdog(uint32_t* err, uint32_t origin) { raise_err(err, 2u | (origin << 24)); }
@@ -78,7 +78,7 @@ __device__ __forceinline__ uint64_t claim_tile(uint32_t* tickets, uint64_t ntile
 // smaller group is resident or finished"; workgroups are handed to each XCD in index order, so the smallest
 // unfinished group always finds a free slot on its XCD (slots there are only ever held by smaller, i.e. finished
 // or running, groups) and never waits.  Should a device dispatch differently, the look-back's spin watchdog raises
-// error bit 1 and the host reruns the scan with tickets (capi.hip).
+// error bit 1 and the host reruns the scan with tickets (capi_ladder.hip).
 __device__ __forceinline__ uint64_t claim_group(bool static_groups, uint32_t* tickets, uint64_t ngroups) {
   return static_groups ? static_cast<uint64_t>(blockIdx.x) : claim_tile(tickets, ngroups);
 }

@@ -12,7 +12,7 @@
 // Assertions (LOOK states, lo = nfa.Look 0 and 2..5: \A (?m)^ (?m)$ \b \B; pikevm.go:1646-1674) read the haystack bytes on both sides of
 // the position — also in front of s and behind e — inside [hay_lo, hay_hi); outside of it counts as a line break, not a
 // word byte (what the transducer kernel assumes around a shard, fsm.hpp "Look-around").
-// Shared by capi.hip (device) and tests/emu (host twin); plain C++.
+// Shared by capi_captures.hip (device) and tests/emu (host twin); plain C++.
 #pragma once
 #include <stdint.h>
 
@@ -41,7 +41,7 @@ constexpr uint32_t kBtInvalid = 0xFFFFFFFFu;
 constexpr uint32_t kBtStackEntries = 1024;     // per thread: 8 KiB
 constexpr uint32_t kBtVisitedWords = 2048;     // per thread: 8 KiB = 65 536 (state, position) pairs
 
-// Small tier of the device kernel (capi.hip k_captures_bt_lds): scratch of one thread in LDS.  Rows that do not fit are
+// Small tier of the device kernel (capi_captures.hip k_captures_bt_lds): scratch of one thread in LDS.  Rows that do not fit are
 // left to the large tier (k_captures_bt, scratch in HBM): log matches are short, so the small tier takes almost all rows
 // with sixteen times the threads in flight.
 constexpr uint32_t kBtSmallStack = 24, kBtSmallVisited = 16;   // 192 + 64 = 256 bytes per thread

@@ -552,28 +552,30 @@ CXG_FSM_HD int32_t fsmd_match_start(const Mem& m, const Tab& tab, const FsmdRev&
 }
 // ... and its first 16 steps without a branch (fsm_match_start16 below, where the reasons are): v_perm_b32 + ds_read_u8 per step, the
 // accept test as a compare whose carry is added into the flag word.
-template <class Mem, class Tab>
-CXG_FSM_HD int32_t fsmd_match_start16(const Mem& m, const Tab& tab, const FsmdRev& R, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
-  uint32_t W[5];
-  m.below(e, W);
+template <int N, class Mem, class Tab>
+CXG_FSM_HD int32_t fsmd_match_startN(const Mem& m, const Tab& tab, const FsmdRev& R, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  uint32_t W[N / 4 + 1];
+  m.template below<N>(e, W);
   uint32_t s = R.start, acc = 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int k = 0; k < 16; k++) {                          // step k is over byte e - 1 - k = byte 16 - k of W
-    const int i = 16 - k;
+  for (int k = 0; k < N; k++) {                           // step k is over byte e - 1 - k = byte N - k of W
+    const int i = N - k;
     s = tab.at(fsmd_addr(s, W[i >> 2], i & 3));
-    acc = acc + acc + (s >= R.acc_lo ? 1u : 0u);          // bit 15 - k
+    acc = acc + acc + (s >= R.acc_lo ? 1u : 0u);          // bit N - 1 - k
   }
   const int32_t low = bound > budget_lo ? bound : budget_lo;
   const uint32_t room = static_cast<uint32_t>(e - low);
-  if (room <= 16u && low != bound) return fsmd_match_start(m, tab, R, e, bound, budget_lo, over);
+  if (room <= static_cast<uint32_t>(N) && low != bound) return fsmd_match_start(m, tab, R, e, bound, budget_lo, over);
   uint32_t f = acc;
-  if (room < 16u) f &= ~((1u << (16u - room)) - 1u);
-  int32_t st = f ? e - 16 + static_cast<int32_t>(__builtin_ctz(f)) : kFsmNoStart;   // lowest bit = largest k: k = 15 - ctz, start e - 1 - k
-  if (room > 16u && s != R.dead) st = fsmd_match_start_from(m, tab, R, s, st, e - 17, bound, budget_lo, over);
+  if (room < static_cast<uint32_t>(N)) f &= ~((1u << (static_cast<uint32_t>(N) - room)) - 1u);
+  int32_t st = f ? e - N + static_cast<int32_t>(__builtin_ctz(f)) : kFsmNoStart;   // lowest bit = largest k: k = N - 1 - ctz, start e - 1 - k
+  if (room > static_cast<uint32_t>(N) && s != R.dead) st = fsmd_match_start_from(m, tab, R, s, st, e - (N + 1), bound, budget_lo, over);
   return st;
 }
+template <class Mem, class Tab>
+CXG_FSM_HD int32_t fsmd_match_start16(const Mem& m, const Tab& tab, const FsmdRev& R, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) { return fsmd_match_startN<16>(m, tab, R, e, bound, budget_lo, over); }
 
 // ---- Round 6: rows of a SHALLOW machine from the event bits alone (no walk past the chunk, no per-lane row buffers).
 // The steps of a tile are one stream of events, two bits per byte (bit 2p the step over byte p created a match, bit
@@ -738,7 +740,7 @@ CXG_FSM_HD int32_t fsm_match_start(const FsmView& v, const Mem& m, int32_t e, in
 // word: the dead state (row 0) absorbs, steps below the bound are masked out of the word afterwards, the smallest start is its highest
 // bit.  Only a walk that is still alive after 16 steps with room below goes on in the loop above.  Needs e - 17 inside the window
 // (rows end behind the tile origin and the window begins 64 bytes in front of it) and a pattern without a text-start anchor
-// (the caller's business).  Mem::below(e, W): the 17 bytes e - 17 .. e - 1 in ascending order, byte i = (W[i >> 2] >> 8 (i & 3)) & 255.
+// (the caller's business).  Mem::below<N>(e, W): the N + 1 bytes e - N - 1 .. e - 1 in ascending order, byte i = (W[i >> 2] >> 8 (i & 3)) & 255.
 CXG_FSM_HD uint32_t fsm_shift_in1(uint32_t mask, uint32_t t) {   // (mask >> 1) | (t << 31)
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_alignbit(t, mask, 1u);
@@ -746,16 +748,17 @@ CXG_FSM_HD uint32_t fsm_shift_in1(uint32_t mask, uint32_t t) {   // (mask >> 1) 
   return (mask >> 1) | (t << 31);
 #endif
 }
-template <class Mem>
-CXG_FSM_HD int32_t fsm_match_start16(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
-  uint32_t W[5];
-  m.below(e, W);
-  uint32_t c[16];
+// N: 16, or 8 where matches are short (the kernels take 8 for tiles with 128 rows and more: `\\b\\d+\\b`, 9 rounds of rows per tile).
+template <int N, class Mem>
+CXG_FSM_HD int32_t fsm_match_startN(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) {
+  uint32_t W[N / 4 + 1];
+  m.template below<N>(e, W);
+  uint32_t c[N];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int k = 0; k < 16; k++) {                          // step k is over byte e - 1 - k = byte 16 - k of W; with look-around it sees the kind of the byte in front
-    const int i = 16 - k;
+  for (int k = 0; k < N; k++) {                           // step k is over byte e - 1 - k = byte N - k of W; with look-around it sees the kind of the byte in front
+    const int i = N - k;
     c[k] = v.cls2[(W[i >> 2] >> (8 * (i & 3))) & 0xFFu];
     if (Mem::kLook) c[k] += v.knd[(W[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu];
   }
@@ -763,19 +766,21 @@ CXG_FSM_HD int32_t fsm_match_start16(const FsmView& v, const Mem& m, int32_t e, 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < N; k++) {
     s = fsm_u16(v.tab, (s & ~1u) | c[k]);               // (an entry is the row's offset in the image = its LDS address: no base to add)
     acc = fsm_shift_in1(acc, s);
   }
   const int32_t low = bound > budget_lo ? bound : budget_lo;
   const uint32_t room = static_cast<uint32_t>(e - low);   // steps the walk may take (>= 1)
-  if (room <= 16u && low != bound) return fsm_match_start(v, m, e, bound, budget_lo, over);   // (the window's first byte within 16 bytes of a row's end: not in the kernel's geometry)
-  uint32_t f = acc >> 16;                                 // bit k: hay[e - 1 - k, e) is in the language
-  if (room < 16u) f &= (1u << room) - 1u;
+  if (room <= static_cast<uint32_t>(N) && low != bound) return fsm_match_start(v, m, e, bound, budget_lo, over);   // (the window's first byte within N bytes of a row's end: not in the kernel's geometry)
+  uint32_t f = acc >> (32 - N);                           // bit k: hay[e - 1 - k, e) is in the language
+  if (room < static_cast<uint32_t>(N)) f &= (1u << room) - 1u;
   int32_t st = f ? e - 1 - (31 - static_cast<int32_t>(__builtin_clz(f))) : kFsmNoStart;
-  // room <= 16 ends at the bound (low == bound then: the window begins 64 bytes in front of the tile and rows end behind its origin)
-  if (room > 16u && (s & ~1u) != v.rev_dead) st = fsm_match_start_from(v, m, s, st, e - 17, bound, budget_lo, over);
+  // room <= N ends at the bound (low == bound then: the window begins 64 bytes in front of the tile and rows end behind its origin)
+  if (room > static_cast<uint32_t>(N) && (s & ~1u) != v.rev_dead) st = fsm_match_start_from(v, m, s, st, e - (N + 1), bound, budget_lo, over);
   return st;
 }
+template <class Mem>
+CXG_FSM_HD int32_t fsm_match_start16(const FsmView& v, const Mem& m, int32_t e, int32_t bound, int32_t budget_lo, uint32_t& over) { return fsm_match_startN<16>(v, m, e, bound, budget_lo, over); }
 
 }  // namespace cxgdev

@@ -168,7 +168,7 @@ struct Words4 {
 // CAP: the rows carry capture slots (ScanArgs::caps, walk.hpp ChainCaps): the ends of up to four runs are compacted
 // next to the starts and ends (dynamic LDS, 4 KiB per run), and every slot is one of those positions plus a constant.
 // DENSE: two tiles per wave instead of eight (four times the row-buffer room per tile) for match-dense input; the host
-// switches after a row-buffer overflow (capi.hip).  A template parameter: a run-time tile count cost the default 1.2 %.
+// switches after a row-buffer overflow (capi_ladder.hip).  A template parameter: a run-time tile count cost the default 1.2 %.
 // ALTK > 0: the chain is run(class 0) (byte(separator) run(class 0)){ALTK-1} — fields of one class with single-byte
 // separators (`\d+\.\d+\.\d+\.\d+`, `\d+:\d+:\d+`, `\w+@\w+\.\w+`): the step loops unroll with constant step kinds, the
 // runs use class 0 without a select (with two classes the separator is class 1, with more it is read from the

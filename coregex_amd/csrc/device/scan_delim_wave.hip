@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan_delim_wave(ScanArgs a) {
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = lane0;
-  const uint64_t group = blockIdx.x;                                // static groups only (capi.hip)
+  const uint64_t group = blockIdx.x;                                // static groups only (capi_ladder.hip)
   if (group >= a.ngroups) return;
   const DelimAux* ax = reinterpret_cast<const DelimAux*>(a.chain);
   const uint32_t o4 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ax->open_byte * 0x01010101u)));

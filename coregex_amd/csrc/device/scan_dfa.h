@@ -1,4 +1,4 @@
-// Launch interface of the DFA scan kernels (scan_dfa.hip); shared with capi.hip and tests/emu.
+// Launch interface of the DFA scan kernels (scan_dfa.hip); shared with capi_internal.hpp and tests/emu.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>

@@ -769,7 +769,7 @@ __device__ __forceinline__ void trio_words(u32x4 (&x)[4], __amdgpu_buffer_rsrc_t
 // tiles).
 // Co-residency: every wave of the grid must be resident (a waiting wave waits for words of waves that run at the same
 // time).  The grid comes from the occupancy query; should a device admit fewer, the spin watchdog raises error bit 1 and
-// the host reruns with the grouped kernel (capi.hip staticGroupsOk).
+// the host reruns with the grouped kernel (capi_ladder.hip staticGroupsOk).
 #ifndef CXG_PF_OCC
 #define CXG_PF_OCC 6
 #endif
@@ -802,7 +802,7 @@ constexpr int kPfTiles = CXG_PF_TILES;
 static_assert((kPfTiles - 1) * kWaveTile + kWaveTile + kWaveHalo < 65536, "a parked row holds two 16-bit offsets from the unit's first window byte");
 constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per unit and wave (twice: rounds r and r - 1); 64 per tile + 64 as in the grouped kernel
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
-// A wave that has waited this long for a word of another wave gives up (capi.hip reruns the call one mode down and demotes the mode for a
+// A wave that has waited this long for a word of another wave gives up (capi_ladder.hip reruns the call one mode down and demotes the mode for a
 // term): s_memtime ticks.  Legitimate waits are microseconds; round 5 measured what a missing co-resident wave costs with the old
 // count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt), and with this limit 51 ms (r05_c5_foreign_kernel.txt).
 // What s_memtime counts is not settled: in busy kernels it ran at the shader clock (607 k ticks in a 0.26 ms launch, round 4; 131 k
@@ -829,7 +829,7 @@ constexpr uint64_t kPfWaitTicks = 5000000ull;
 //     unit of slack (two parked row lists fill the LDS that six workgroups per CU leave) every unit ends up waiting for the slowest of the
 //     ~6 000 units in flight — 16 GiB: 5.9 ms with a counter per workgroup, 4.8 with the counters asked in rotation, 3.9 with every unit
 //     doing its own decoupled look-back over block aggregates, against 3.3 static; 1 GiB 0.27-0.35 ms against 0.22 (profiles/r06_c4..c7_*).
-// The static grid stays the product (its spin watchdog and the demotion ladder of capi.hip cover a grid that is not co-resident); the
+// The static grid stays the product (its spin watchdog and the demotion ladder of capi_ladder.hip cover a grid that is not co-resident); the
 // ticketed form stays buildable for whoever finds the second unit of slack.
 #ifndef CXG_PF_TICKETS
 #define CXG_PF_TICKETS 0

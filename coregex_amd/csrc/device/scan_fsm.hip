@@ -33,7 +33,7 @@ namespace {
 // wrap, so it does not use the instruction's immediate offset).  IMG = bytes reserved for the image.
 // MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per
 // tile, match-dense input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match
-// per 2 bytes).  The host escalates after an overflow and remembers the mode for the program (capi.hip).
+// per 2 bytes).  The host escalates after an overflow and remembers the mode for the program (capi_ladder.hip).
 template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];

@@ -57,17 +57,19 @@ struct FsmMem : FsmClassify<FsmMem<LOOK>, LOOK> {
     const uint32_t w = static_cast<uint32_t>(r + kFsmLeft);
     return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
   }
-  // the 17 bytes below e (fsm.hpp fsm_match_start16): five aligned dwords, shifted into place
-  __device__ __forceinline__ void below(int32_t e, uint32_t (&W)[5]) const {
-    const uint32_t w0 = static_cast<uint32_t>(e - 17 + kFsmLeft), wb = w0 & ~3u, sh = w0 & 3u;
-    uint32_t d[5];
+  // the N + 1 bytes below e (fsm.hpp fsm_match_start16; N = 16 or 8): N / 4 + 1 aligned dwords, shifted into place
+  template <int N>
+  __device__ __forceinline__ void below(int32_t e, uint32_t (&W)[N / 4 + 1]) const {
+    constexpr int D = N / 4 + 1;
+    const uint32_t w0 = static_cast<uint32_t>(e - (N + 1) + kFsmLeft), wb = w0 & ~3u, sh = w0 & 3u;
+    uint32_t d[D];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
+    for (int j = 0; j < D; j++) {
       const uint32_t w = wb + 4u * j;
       d[j] = *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(win + w + (w >> 6) * 4u);
     }
 #pragma unroll
-    for (int j = 0; j < 5; j++) W[j] = __builtin_amdgcn_alignbyte(d[j < 4 ? j + 1 : 4], d[j], sh);
+    for (int j = 0; j < D; j++) W[j] = __builtin_amdgcn_alignbyte(d[j < D - 1 ? j + 1 : D - 1], d[j], sh);
   }
 };
 struct LdsRows {
@@ -98,7 +100,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
 
 // MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per tile, match-dense
 // input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match per 2 bytes).  The host escalates
-// after an overflow and remembers the mode for the program (capi.hip).
+// after an overflow and remembers the mode for the program (capi_ladder.hip).
 template <int MODE> struct FsmMode {
   static constexpr int kTpw = MODE == 0 ? kTilesPerWave : (MODE == 1 ? kDenseTilesPerWave : 1);
   static constexpr int kRows = MODE == 2 ? kFsmLaneRowsMax : kFsmLaneRows;
@@ -113,7 +115,8 @@ template <int MODE> struct FsmMode {
 template <int kRowsPerWave, class Pend>
 __device__ __forceinline__ uint32_t fsm_rows_from_events(const uint64_t (&KK)[2], bool active, bool owned, int32_t rend, int32_t c0, int lane,
                                                          uint16_t* s_re_wave, uint32_t nrows_w, uint32_t& fallback, Pend pend_at_end) {
-  const uint64_t k0 = active ? (KK[0] & fsm_valid_bits(rend - c0)) : 0ull, k1 = active ? (KK[1] & fsm_valid_bits(rend - c0 - kFsmSub)) : 0ull;
+  uint64_t k0 = active ? KK[0] : 0ull, k1 = active ? KK[1] : 0ull;
+  if (rend < kFsmWinEnd) { k0 &= fsm_valid_bits(rend - c0); k1 &= fsm_valid_bits(rend - c0 - kFsmSub); }   // (uniform: the input ends inside this window)
   const uint32_t T[4] = {static_cast<uint32_t>(k0), static_cast<uint32_t>(k0 >> 32), static_cast<uint32_t>(k1), static_cast<uint32_t>(k1 >> 32)};
   const bool ne = (T[0] | T[1] | T[2] | T[3]) != 0u;
   const unsigned long long NE = __ballot(ne), FR = __ballot(ne && fsm_first_is_r(T));

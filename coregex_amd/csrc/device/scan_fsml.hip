@@ -8,7 +8,7 @@ namespace cxgdev {
 // row derivation, group ordering and look-back as k_scan_fsm<SHALLOW>; what it does not carry is the machinery for entry states that
 // do NOT collapse (member maps, deferred tiles, hand-offs between tiles and groups — two thirds of k_scan_fsm's code and, through
 // the registers and the control flow they cost, a quarter of its instructions on ordinary input): such input raises fallback
-// reason 1 and the host reruns the call — and the program's next calls — on k_scan_fsm (capi.hip).
+// reason 1 and the host reruns the call — and the program's next calls — on k_scan_fsm (capi_ladder.hip).
 // KIND -1: direct mode (fsm.hpp "Direct mode": byte-indexed rows, v_perm_b32 + ds_read_u8 + v_alignbit per byte, machines without
 // look-around whose rows fit); KIND 0 / 1 / 2: the class-indexed tables, LOOK = KIND.
 namespace {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
         FsmTraceS t[2];
         if constexpr (DIRECT) {
           uint32_t e[2] = {top, top};
-          fsmd_walk_n<2>(m, tab, wfrom, 16, e);
+          if (!(CXG_FSM_ABL & 1)) fsmd_walk_n<2>(m, tab, wfrom, 16, e);
           if (at_origin) e[0] = 0u;                               // the haystack's first byte: the search starts in state 0
           const uint32_t u0 = tab.at(prop + e[0]) & 0x80u, u1 = tab.at(prop + e[1]) & 0x80u;
           if (u0 | u1) {                                          // rare on text
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
           }
           // the chunk: two chains in lockstep, the flag bits of every step shifted into the masks
           t[0] = {e[0], 0u, 0u}; t[1] = {e[1], 0u, 0u};
-          fsmd_chunk<2>(m, tab, cc, t);
+          if (!(CXG_FSM_ABL & 2)) fsmd_chunk<2>(m, tab, cc, t);
           xend1 = t[1].x;
         } else {
-          uint32_t e[2];
-          fsm_walk_n<2>(v, m, v.top_off, wfrom, 16, e);
+          uint32_t e[2] = {0u, 0u};
+          if (!(CXG_FSM_ABL & 1)) fsm_walk_n<2>(v, m, v.top_off, wfrom, 16, e);
           if (at_origin) e[0] = m.origin(v);
           if ((e[0] >= v.u_lo) | (e[1] >= v.u_lo)) {              // rare on text
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
             }
           }
           t[0] = {e[0], 0u, 0u}; t[1] = {e[1], 0u, 0u};
-          fsm_fast_shallow<2>(v, m, cc, t);
+          if (!(CXG_FSM_ABL & 2)) fsm_fast_shallow<2>(v, m, cc, t);
           xend1 = t[1].x & ~3u;
         }
         KK[0] = (static_cast<uint64_t>(t[0].k1) << 32) | t[0].k0; KK[1] = (static_cast<uint64_t>(t[1].k1) << 32) | t[1].k0;
@@ -158,14 +158,24 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
                                                [&]() -> uint32_t { if constexpr (DIRECT) return tab.at(prop + xend1) & 0x7Fu; else return fsm_u16(v.tab, xend1 + v.ncls2 + 2u); });
       wave_lds_sync();
       if (a.out != nullptr || a.max_len != 0) {
+        // a tile with 128 rows and more (`\\b\\d+\\b`: 535, nine rounds of this loop) has short matches: 8 branch-free steps in front of the loop
+        // instead of 16 (the answer is the same, fsm.hpp fsm_match_startN)
+        const bool short_rows = tot >= 128u;
         for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kRowsPerWave); q += 64) {
           const int32_t e = S.re[wave][nrows_w + q];
           const int32_t bound = q ? static_cast<int32_t>(S.re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
           int32_t st;
-          if constexpr (DIRECT) st = CXG_FSM_FAST_STARTS ? fsmd_match_start16(m, tab, R, e, bound, lowest, over) : fsmd_match_start(m, tab, R, e, bound, lowest, over);
-          else st = (CXG_FSM_FAST_STARTS && (v.rev_text_col == 0u || tile_lo != 0)) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)
-                                                                                     : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+          if constexpr (DIRECT) {
+            if (!CXG_FSM_FAST_STARTS) st = fsmd_match_start(m, tab, R, e, bound, lowest, over);
+            else if (short_rows) st = fsmd_match_startN<8>(m, tab, R, e, bound, lowest, over);
+            else st = fsmd_match_startN<16>(m, tab, R, e, bound, lowest, over);
+          } else {
+            // (a text-start anchor is the loop's business: the walk that arrives at position 0 alive asks the state)
+            if (!CXG_FSM_FAST_STARTS || (v.rev_text_col != 0u && tile_lo == 0)) st = fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
+            else if (short_rows) st = fsm_match_startN<8>(v, m, e, bound, rev_lowest, over);
+            else st = fsm_match_startN<16>(v, m, e, bound, rev_lowest, over);
+          }
           const uint32_t len = (over || st == kFsmNoStart) ? 0u : static_cast<uint32_t>(e - st);
           if (st == kFsmNoStart && !over) fallback |= 64u;
           S.rl[wave][nrows_w + q] = static_cast<uint16_t>(len);

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t gather16_01(uint32_t t0, uint32_t t1, uint32
 // of the literal is extended to the match end by walking the anchored forward DFA (table in dynamic LDS) over the
 // window's bytes; a walk still alive at the window edge hands the scan to the DFA-pair kernel.
 // DENSE: two tiles per wave instead of eight — four times the row-buffer room per tile — after a row-buffer overflow
-// on match-dense input (capi.hip), as in scan_chain_wave.hip.
+// on match-dense input (capi_ladder.hip), as in scan_chain_wave.hip.
 template <bool VERIFY, bool DENSE>
 __global__ __launch_bounds__(kThreads, VERIFY ? 4 : 5) void k_scan_teddy_wave(ScanArgs a) {
   constexpr int tpw = DENSE ? kDenseTilesPerWave : kTilesPerWave;

@@ -664,7 +664,7 @@ bool wrappedLiterals(const cxg_nfa& nfa, std::vector<std::vector<uint8_t>>& lits
 //     in the closure of its start (order of dfa/lazy/builder.go:245-293 = order of pikevm.go's thread list) —, and
 //   * an empty match at every position 0..len that no non-empty match [s, e) covers with its closed interval [s, e].
 // The variant is the same NFA entered through a chain of splits over those threads (their continuations are untouched); the
-// device serves it like any UseNFA program, capi.hip scanNullable adds the empty matches.  Returns false when the start's
+// device serves it like any UseNFA program, capi_nullable.hip scanNullable adds the empty matches.  Returns false when the start's
 // closure holds no Match (not nullable); sawLook: an assertion stands in front of it (refused: nullable at SOME positions only).
 bool nonEmptyVariant(const cxg_nfa& nfa, HostNfa& out, bool& sawLook, size_t& nthreads) {
   sawLook = false;
@@ -1120,7 +1120,7 @@ void buildProgramFromNfa(cxg_program* p, const cxg_nfa& nfa, int strategy, uint3
       bool look = false;
       for (uint32_t i = 0; i < nfa.n_states; i++) look = look || nfa.states[i].kind == CXG_NFA_LOOK;
       // Nullable pattern (the reference sends every one of them here: canMatchEmpty, meta/strategy.go:1503): the program is the
-      // non-empty variant's transducer, the empty matches are added behind the scan (capi.hip scanNullable).
+      // non-empty variant's transducer, the empty matches are added behind the scan (capi_nullable.hip scanNullable).
       HostNfa variant;
       const cxg_nfa* prog = &nfa;
       cxg_nfa variantView;
@@ -1466,7 +1466,7 @@ void buildSubmatchProgram(cxg_program* p, const cxg_nfa& nfa, int strategy) {
     Dfa fwd = determinize(nfa, nfa.start_unanchored, true, kMaxDfaStates);
     if (fwd.start >= fwd.firstAccept) {
       // Nullable pattern (round 5; meta/findall.go:390-447, the same empty-match rule as FindAllIndex :247-257): the spans are what the
-      // FindAllIndex program of the pattern gives (non-empty variant + merged empty matches, capi.hip scanNullable); every row — the empty
+      // FindAllIndex program of the pattern gives (non-empty variant + merged empty matches, capi_nullable.hip scanNullable); every row — the empty
       // ones too: the top-priority empty path decides which groups take part — gets its slots from the backtracking pass over THIS NFA
       // anchored at the row's start and ending at its end.  A search of a nullable pattern always answers at its own start position, so
       // the reported match is the top-priority path from there, which is what the pass finds first.

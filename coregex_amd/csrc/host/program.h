@@ -45,7 +45,7 @@ struct cxg_program {
   bool supported = false;
   std::string whyNot;
   // Nullable pattern (`a*`, `x?y*`; always UseNFA, meta/strategy.go:1503): the device program is the pattern's NON-EMPTY variant;
-  // capi.hip scanNullable merges its rows with the empty matches of meta/findall.go:251-275.  nullableOnlyEmpty: no path of
+  // capi_nullable.hip scanNullable merges its rows with the empty matches of meta/findall.go:251-275.  nullableOnlyEmpty: no path of
   // higher priority than the empty one consumes a byte (`a*?`, `(|a)`): every match is empty, no device program at all.
   bool nullable = false, nullableOnlyEmpty = false;
   cxg::HostNfa nfa;              // kept for cxg_program_nfa (cxg_compile only)
@@ -63,20 +63,20 @@ struct cxg_program {
   std::string subWhyNot;
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
-  bool capHasLook = false;       // the backtracking image holds assertion states: capi.hip launches the LOOK instantiation of its kernels
+  bool capHasLook = false;       // the backtracking image holds assertion states: capi_captures.hip launches the LOOK instantiation of its kernels
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: a wave kernel overflowed its row buffers on this program's
-                                                              // input once: later calls start with two tiles per wave (capi.hip)
+                                                              // input once: later calls start with two tiles per wave (capi_ladder.hip)
   mutable std::atomic<uint8_t> fsmMode[2] = {{0}, {0}};      // ... the transducer kernel's density mode seen necessary: 0, 1 (2 tiles per wave), 2 (1 tile)
   mutable std::atomic<uint8_t> fsmNoDirect[2] = {{0}, {0}};  // ... its lean kernel (k_scan_fsml) met an entry state that did not collapse: k_scan_fsm from now on
   // Offset captures (round 4): every capture boundary lies a fixed number of bytes behind the match's start or in front of its end
-  // (`user=(\S+)`, `"([^"]*)"`, `\[([^\]]+)\]`).  FindAllSubmatch is then FindAll + one expansion kernel (capi.hip scanOffsetCaps)
+  // (`user=(\S+)`, `"([^"]*)"`, `\[([^\]]+)\]`).  FindAllSubmatch is then FindAll + one expansion kernel (capi_nullable.hip scanOffsetCaps)
   // instead of a backtracking pass per row.  offCaps[0] != 0: on; slot k >= 2: offSrc[k] 0 = start, 1 = end; offDelta[k] added.
   uint8_t offCapsOn = 0, offSrc[32] = {0};
   int32_t offDelta[32] = {0};
   uint32_t delim[4] = {0, 0, 0, 0};   // cxgdev::DelimAux: `O [^E]+ E` / `O [^E]* E` programs ([3] != 0), the delimiter kernel in front of the transducer
   uint8_t chainBounds[40] = {0}; // cxgdev::ChainCaps with on == 2: field bounds of a bounded-repetition program (kFlagChainBounded)
   uint8_t chainCaps[40] = {0};   // cxgdev::ChainCaps: captures straight from the chain kernel ([0] == 0: not available)
-  // device copies, one per device, created on first use (capi.hip)
+  // device copies, one per device, created on first use (capi_state.hip)
   void* dev[16] = {nullptr};
   void* devSub[16] = {nullptr};
   void* devCap[16] = {nullptr};

@@ -61,7 +61,7 @@ def main(n=300, seed=1):
                     for k2, (src, d) in enumerate(oc):
                         if not np.array_equal(es[:, k2], es[:, 1 if src else 0] + d): print("OFFSET-CAPS", repr(pat), k2, hay[:60]); return 1
                 else:
-                    try: gs = emu.captures_bt(cb, hay, es[:, :2], es.shape[1])      # the backtracking pass over the spans (capi.hip launchCapturePass)
+                    try: gs = emu.captures_bt(cb, hay, es[:, :2], es.shape[1])      # the backtracking pass over the spans (capi_captures.hip launchCapturePass)
                     except AssertionError as e:
                         if "error -4" not in str(e): print("SUBMATCH-TWIN", repr(pat), hay[:60], e); return 1
                         gs = None

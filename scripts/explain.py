@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What would the library do with a pattern?  Strategy (the reference's, as the front-end derives it), whether the device subset serves
-it and — if so — the first kernel a call launches, following capi.hip scanDeviceOnce (fallbacks then follow the ladder of DESIGN §1:
+it and — if so — the first kernel a call launches, following capi_ladder.hip scanDeviceOnce (fallbacks then follow the ladder of DESIGN §1:
 wave kernel -> transducer -> table-walking kernel).  No GPU needed.
 
   python scripts/explain.py 'PATTERN' ['PATTERN' ...]

@@ -83,7 +83,7 @@ def find_all_submatch(span_blob: bytes, cap_blob: bytes, hay, width: int, chunk:
 
 
 def captures_bt(cap_blob: bytes, hay, spans: np.ndarray, width: int) -> np.ndarray:
-    """Rows of FindAllSubmatchIndex from given spans: the backtracking capture pass (both tiers), as capi.hip runs it."""
+    """Rows of FindAllSubmatchIndex from given spans: the backtracking capture pass (both tiers), as capi_captures.hip runs it."""
     a = np.frombuffer(bytes(hay), dtype=np.uint8) if not isinstance(hay, np.ndarray) else np.ascontiguousarray(hay)
     padded = np.concatenate([a, np.zeros(8, dtype=np.uint8)])
     sp = np.ascontiguousarray(spans, dtype=np.int64).reshape(-1, 2)
@@ -283,7 +283,7 @@ def fsm_maps_check(image: bytes, hay, tile: int = 3840, tiles_per_group: int = 3
 
 def merge_empty_matches(rows: np.ndarray, n: int) -> np.ndarray:
     """FindAll of a NULLABLE pattern from the rows of its non-empty variant over a haystack of n bytes (meta/findall.go:216-283;
-    what capi.hip scanNullable computes on the device): an empty match at every position 0..n outside the closed intervals [s, e]."""
+    what capi_nullable.hip scanNullable computes on the device): an empty match at every position 0..n outside the closed intervals [s, e]."""
     covered = np.zeros(n + 2, dtype=bool)
     for s, e in np.asarray(rows).reshape(-1, 2).tolist():
         covered[s:e + 1] = True

@@ -22,7 +22,7 @@ struct HostMem : FsmClassify<HostMem<LOOK>, LOOK> {
   uint32_t outside;     // FsmHeader::outside_byte: what the kernel writes into its window around the haystack
   uint32_t byte(int32_t r) const { const int64_t p = origin_abs + r; return (p >= 0 && p < len) ? hay[p] : outside; }
   uint32_t dword(int32_t r) const { return byte(r) | (byte(r + 1) << 8) | (byte(r + 2) << 16) | (byte(r + 3) << 24); }
-  void below(int32_t e, uint32_t (&W)[5]) const { for (int j = 0; j < 5; j++) W[j] = dword(e - 17 + 4 * j); }   // fsm.hpp fsm_match_start16
+  template <int N> void below(int32_t e, uint32_t (&W)[N / 4 + 1]) const { for (int j = 0; j < N / 4 + 1; j++) W[j] = dword(e - (N + 1) + 4 * j); }   // fsm.hpp fsm_match_startN
 };
 struct LaneRows {
   int32_t end[kFsmLaneRowsMax];
@@ -265,8 +265,9 @@ static int64_t emu_fsm_shallow(const uint8_t* img, const uint8_t* hay, uint64_t 
           const int32_t rev_lowest = (LOOK && window_cut) ? lowest + 1 : lowest;
           const int32_t bound = first_in_tile ? (window_cut ? lowest - 1 : lowest) : static_cast<int32_t>(prev_end - static_cast<int64_t>(tile_lo));
           const FsmdRev R = {h->d_rstart, h->d_racc_lo, h->d_rdead};
-          int32_t s = DIRECT ? fsmd_match_start16(m, tab, R, e, bound, lowest, over)
-                             : (v.rev_text_col == 0u || tile_lo != 0) ? fsm_match_start16(v, m, e, bound, rev_lowest, over)
+          const bool n8 = ((tile_lo / static_cast<uint64_t>(tile)) & 1u) != 0;   // (the kernel takes 8 steps for tiles with many rows: the answer is the same, every other tile here)
+          int32_t s = DIRECT ? (n8 ? fsmd_match_startN<8>(m, tab, R, e, bound, lowest, over) : fsmd_match_startN<16>(m, tab, R, e, bound, lowest, over))
+                             : (v.rev_text_col == 0u || tile_lo != 0) ? (n8 ? fsm_match_startN<8>(v, m, e, bound, rev_lowest, over) : fsm_match_startN<16>(v, m, e, bound, rev_lowest, over))
                              : fsm_match_start(v, m, e, bound, rev_lowest, over, tile_lo == 0 ? 0 : kFsmNoStart);
           if (over || (first_in_tile && s != kFsmNoStart && static_cast<int64_t>(tile_lo) + s < prev_end)) {
             st[3]++;

@@ -1,4 +1,4 @@
-"""Nullable patterns on the device (meta/findall.go:216-283): the transducer of the non-empty variant + capi.hip
+"""Nullable patterns on the device (meta/findall.go:216-283): the transducer of the non-empty variant + capi_nullable.hip
 scanNullable's two kernels, against the oracle's FindAll loop.  The CPU half (variant through the twin, merge restated in numpy)
 is tests/test_nullable_cpu.py."""
 import random

@@ -1,5 +1,5 @@
 """Offset captures on the device (round 4): FindAllSubmatch = FindAll (whatever kernel serves the spans: class runs, quote pairs,
-delimiters, literal + DFA, transducer) + the expansion kernel of capi.hip scanOffsetCaps, against the oracle's capture rows."""
+delimiters, literal + DFA, transducer) + the expansion kernel of capi_nullable.hip scanOffsetCaps, against the oracle's capture rows."""
 import random
 
 import numpy as np

@@ -423,7 +423,7 @@ def test_find_all_n_stops_the_wave_kernels_early(need_gpu, oracle, cfg, pat, sub
 def test_use_both_programs(need_gpu, oracle):
     """UseBoth (find_indices.go:408-441): the DFA's end only picks where the PikeVM starts (end-100 for far ends), so
     FindAllIndex is plain leftmost-first unless a match is longer than 100 bytes; then the reference's PikeVM starts inside
-    the match.  The device path restarts its search at the same place (capi.hip scanDevice): rows == oracle."""
+    the match.  The device path restarts its search at the same place (capi_ladder.hip scanDevice): rows == oracle."""
     pat = r"(\w+)@(\w+)\.(\w+)"
     rx, o = cx.compile(pat), oracle.Regex(pat)
     assert rx.strategy == o.strategy == "UseBoth" and rx.supported

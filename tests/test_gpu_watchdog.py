@@ -1,4 +1,4 @@
-"""Watchdog hygiene (capi.hip PathState): a spin-watchdog hit demotes a launch mode for a TERM of calls and
+"""Watchdog hygiene (capi_internal.hpp PathState): a spin-watchdog hit demotes a launch mode for a TERM of calls and
 the mode is tried again afterwards; two threads that each scan a large haystack on the same device do not starve each other's
 launches (order-dependent launches take turns per device) and both get the reference's rows."""
 import threading

@@ -878,7 +878,7 @@ def test_product_literal_sets_pinned_on_reference_rows():
 
 
 def test_use_both_restart_rule_equals_the_reference_iteration(oracle):
-    """capi.hip scanDevice (round 3) answers a UseBoth program WITHOUT a usable prefilter by iterating plain leftmost-first rows
+    """capi_ladder.hip scanDevice (round 3) answers a UseBoth program WITHOUT a usable prefilter by iterating plain leftmost-first rows
     and, at the first match longer than 100 bytes, restarting the search at that match's end - 100 (find_indices.go:432-441: the
     DFA's end only picks where the PikeVM starts).  The same loop in Python over the oracle's plain leftmost-first spans (its
     PikeVM: FindAllSubmatch of a UseBoth program does not restart) must reproduce the oracle's UseBoth FindAllIndex.  (This test found that the first row of a
@@ -973,7 +973,7 @@ def test_case_insensitive_programs_through_the_twins(oracle):
             exp = o.find_all_index(hay).tolist()
             a = np.frombuffer(hay, dtype=np.uint8)
             folded = kind == 4 and struct.unpack_from("<I", blob, struct.unpack_from("<I", blob, 56)[0] + 44)[0] != 0   # TeddyAux::looks (round 4: folded sets)
-            if kind != 5 and not folded:                              # (the table kernel knows neither assertions nor folded sets: capi.hip never sends them there)
+            if kind != 5 and not folded:                              # (the table kernel knows neither assertions nor folded sets: capi_ladder.hip never sends them there)
                 assert emu.find_all(blob, hay).tolist() == exp, (pat, "lanes", len(hay))
             if rx.fsm_image() is not None:
                 got = emu.find_all_fsm(rx.fsm_image(), a, 3840, 32)

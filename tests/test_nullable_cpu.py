@@ -1,5 +1,5 @@
 """Nullable patterns (`a*`, `x?y*`, `\\d*`: SURVEY row a3, meta/findall.go:216-283), CPU tier.  The device program of such a pattern
-is its NON-EMPTY variant (program.cc nonEmptyVariant); capi.hip scanNullable adds an empty match at every position outside the
+is its NON-EMPTY variant (program.cc nonEmptyVariant); capi_nullable.hip scanNullable adds an empty match at every position outside the
 closed intervals of the variant's rows.  Here: the variant's transducer through its sequential twin, the merge restated in numpy
 (`merge_empty_matches`, the specification the two device kernels are tested against in tests/test_gpu_nullable.py), against the
 oracle's FindAll loop."""
@@ -60,7 +60,7 @@ def test_nullable_with_assertions_is_refused(pat):
 
 @pytest.mark.parametrize("pat", [r"(a*)", r"(a*)(b)?", r"(\d*)x?", r"(a)*", r"(a|b)*c?", r"(a*)(b*)", r"(x?)(y*)z?", r"((a)|b)*", r"(a?)(b?)(c?)", r"([a-z]*)(\d*)"])
 def test_submatch_of_nullable_patterns_through_the_twins(pat, oracle):
-    """FindAllSubmatch of a nullable pattern (round 5, capi.hip scanNullableSubmatch): the rows of FindAllIndex through the twin of the
+    """FindAllSubmatch of a nullable pattern (round 5, capi_nullable.hip scanNullableSubmatch): the rows of FindAllIndex through the twin of the
     pattern's first kernel + merged empty matches, then the backtracking capture twin (device/bt.hpp compiled for the host) for EVERY row
     — the empty ones too — and the reference's end-of-haystack quirk (every group unset, nfa/pikevm.go:2201-2212) on the last row."""
     from twins import rows_on_twin

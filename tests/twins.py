@@ -1,4 +1,4 @@
-"""The sequential twin of the kernel a program's FIRST launch would run (capi.hip scanDeviceOnce's routing, as scripts/cpu_fuzz.py and
+"""The sequential twin of the kernel a program's FIRST launch would run (capi_ladder.hip scanDeviceOnce's routing, as scripts/cpu_fuzz.py and
 scripts/explain.py follow it): rows of FindAllIndex on the CPU through the device images, without a GPU.  Test infrastructure."""
 import struct
 
