@@ -802,14 +802,26 @@ constexpr int kPfTiles = CXG_PF_TILES;
 static_assert((kPfTiles - 1) * kWaveTile + kWaveTile + kWaveHalo < 65536, "a parked row holds two 16-bit offsets from the unit's first window byte");
 constexpr int kPfRows = 64 * (kPfTiles + 1);                 // rows parked per unit and wave (twice: rounds r and r - 1); 64 per tile + 64 as in the grouped kernel
 constexpr int kPfMaxWaves = 8192;                            // 128 blocks of 64 units per round
-// A wave that has waited this long for a word of another wave gives up (capi_ladder.hip reruns the call one mode down and demotes the mode for a
-// term): s_memtime ticks.  Legitimate waits are microseconds; round 5 measured what a missing co-resident wave costs with the old
-// count of 2^18 polls: 1.66 s per call (profiles/r05_c4_foreign_kernel.txt), and with this limit 51 ms (r05_c5_foreign_kernel.txt).
-// What s_memtime counts is not settled: in busy kernels it ran at the shader clock (607 k ticks in a 0.26 ms launch, round 4; 131 k
-// ticks per 55 us workgroup of the char-class kernel, round 5: ~2.2 GHz, which makes this limit 2.3 ms), while the stall it ends
-// measured 50 ms to the millisecond, i.e. 100 MHz — either the counter follows a clock that drops while every wave sleeps, or
-// several waits expire one after another.  The limit is therefore "between 2 and 50 ms".
-constexpr uint64_t kPfWaitTicks = 5000000ull;
+// A wave that has waited this long for a word of another wave gives up (capi_ladder.hip reruns the call one mode down and demotes the
+// mode for a term).  Legitimate waits are microseconds; what a missing co-resident wave costs is this limit per call.
+// The clock (round 6, scripts/microbench/clocks.hip, profiles/r06_c16_clocks.txt): s_memtime (__builtin_readcyclecounter, clock64) counts
+// the shader clock — 2 389 ticks per microsecond at the 2.4 GHz these boxes hold, asleep or busy, one wave or a full grid — so the
+// 5 M ticks of round 5 were 2.1 ms, not the "2 to 50 ms" its comment guessed (the 51 ms stalls it saw were a sequence of expiries and
+// reruns); s_memrealtime (wall_clock64) counts a constant 100 MHz (99.96 - 99.99 ticks per microsecond measured,
+// hipDeviceAttributeWallClockRate = 100 000 kHz).  The limit is stated in that clock: 5 ms.
+constexpr uint64_t kPfWaitTicks = 500000ull;                  // s_memrealtime ticks: 5 000 us
+#ifdef CXG_PF_WD_MEMTIME                                        // (A/B: the shader clock of round 5, 2.1 ms at 2.4 GHz for the same number)
+__device__ __forceinline__ uint64_t pf_wait_clock() { return __builtin_readcyclecounter() / 24u; }
+#else
+__device__ __forceinline__ uint64_t pf_wait_clock() { return __builtin_amdgcn_s_memrealtime(); }
+#endif
+// One expiry ends every wait of the launch: the wave that gives up leaves the launch's epoch in a word all waiters look at beside their
+// clock.  Without it the waits expired one after another along the chains of rounds and duties — a foreign kernel beside the grid cost
+// 51 ms (round 5, 2.1 ms limit) and 87 ms (5 ms limit, profiles/r06_c17_foreign_kernel.txt) per hit, ~20 limits in a row.
+constexpr uint32_t kPfAbortWord = 32u * 64u * kPfCtrStride - 1u;       // the last word of pf_ticket (its counters sit at multiples of their stride; unused by the static grid)
+__device__ __forceinline__ bool pf_aborted(const ScanArgs& a) { return __hip_atomic_load(a.pf_ticket + kPfAbortWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.pf_epoch; }
+__device__ __forceinline__ void pf_abort(const ScanArgs& a) { __hip_atomic_store(a.pf_ticket + kPfAbortWord, a.pf_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool pf_wait_over(const ScanArgs& a, uint64_t t0) { return pf_aborted(a) || pf_wait_clock() - t0 > kPfWaitTicks; }
 
 #ifndef CXG_PF_EAGER
 #define CXG_PF_EAGER 0
@@ -982,8 +994,8 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
       const uint32_t before = duty_stage;
       duty_check(dv);
       if (duty_stage == before) {
-        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
-        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+        if (spins++ == 0u) t_wait = pf_wait_clock();
+        else if ((spins & 15u) == 0u && pf_wait_over(a, t_wait)) { if (lane0 == 0 && !pf_aborted(a)) raise_watchdog(a.err, kWdPersDuty); pf_abort(a); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
       }
     }
@@ -1090,8 +1102,8 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
       uint32_t pre = 0, tot = 0, spins = 0;
       uint64_t t_wait = 0;
       while (!status_reduce(vr, vs, pre, tot)) {                      // something of the round was not there yet
-        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
-        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
+        if (spins++ == 0u) t_wait = pf_wait_clock();
+        else if ((spins & 15u) == 0u && pf_wait_over(a, t_wait)) { if (lane0 == 0 && !pf_aborted(a)) raise_watchdog(a.err, kWdPersRecord); pf_abort(a); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
         status_load(rp, vr, vs);
       }
@@ -1351,8 +1363,8 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
       const uint32_t before = duty_stage, before_look = duty_look;
       duty_check(dv);
       if (duty_stage == before && duty_look == before_look) {
-        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
-        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+        if (spins++ == 0u) t_wait = pf_wait_clock();
+        else if ((spins & 15u) == 0u && pf_wait_over(a, t_wait)) { if (lane0 == 0 && !pf_aborted(a)) raise_watchdog(a.err, kWdPersDuty); pf_abort(a); break; }
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
       }
     }
@@ -1419,8 +1431,8 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
           }
         }
         if (have_own && look == 0u) break;
-        if (spins++ == 0u) t_wait = __builtin_readcyclecounter();
-        else if ((spins & 15u) == 0u && __builtin_readcyclecounter() - t_wait > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersRecord); break; }
+        if (spins++ == 0u) t_wait = pf_wait_clock();
+        else if ((spins & 15u) == 0u && pf_wait_over(a, t_wait)) { if (lane0 == 0 && !pf_aborted(a)) raise_watchdog(a.err, kWdPersRecord); pf_abort(a); break; }
         if (duty_stage != 0u) { DutyWords dv = {0u, 0u}; duty_load(dv); duty_check(dv); }   // (a leader that waits keeps looking at its own duty)
         __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
         if (!have_own) vs = __builtin_amdgcn_raw_buffer_load_b32(units_rs, (prev_blk * 64u + static_cast<uint32_t>(lane0)) * 4u, 0, 17);
@@ -1540,8 +1552,8 @@ __global__ __launch_bounds__(kThreads, (LIT >= 16 ? 4 : LIT >= 3 ? 5 : CXG_PF_OC
               duty_load(dv);
               duty_check(dv);
               if (duty_stage != 1u) break;
-              if (sp2++ == 0u) tw2 = __builtin_readcyclecounter();
-              else if ((sp2 & 15u) == 0u && __builtin_readcyclecounter() - tw2 > kPfWaitTicks) { if (lane0 == 0) raise_watchdog(a.err, kWdPersDuty); break; }
+              if (sp2++ == 0u) tw2 = pf_wait_clock();
+              else if ((sp2 & 15u) == 0u && pf_wait_over(a, tw2)) { if (lane0 == 0 && !pf_aborted(a)) raise_watchdog(a.err, kWdPersDuty); pf_abort(a); break; }
               __builtin_amdgcn_s_sleep(CXG_PF_SLEEP);
             }
           }

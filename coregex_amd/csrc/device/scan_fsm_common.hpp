@@ -111,10 +111,12 @@ template <int MODE> struct FsmMode {
 // Rows of a tile from the event bits of its lanes (fsm.hpp "Round 6"): an event is a row's end unless the event behind it is a rematch.
 // KK: the lane's two sub-chunks (two bits per byte), active: the lane walked, owned: its rows are this tile's (lanes 1..60; the
 // three lanes behind them only contribute their bits).  The ends land in s_re[nrows_w ...] in ascending order; returns their
-// number.  pend_at_end(): pending levels of the row behind the lane's second sub-chunk (asked of lane 63 only, rarely).
+// number.  pend_at_end(): pending levels of the row behind the lane's second sub-chunk (asked of lane 63 only, rarely).  tag: or-ed
+// into every end (the lean kernel keeps the tile's number j in bits 12..14 — an end is at most 4032 — so that its epilogue can walk
+// the wave's rows as ONE list).
 template <int kRowsPerWave, class Pend>
 __device__ __forceinline__ uint32_t fsm_rows_from_events(const uint64_t (&KK)[2], bool active, bool owned, int32_t rend, int32_t c0, int lane,
-                                                         uint16_t* s_re_wave, uint32_t nrows_w, uint32_t& fallback, Pend pend_at_end) {
+                                                         uint16_t* s_re_wave, uint32_t nrows_w, uint32_t& fallback, Pend pend_at_end, uint32_t tag = 0u) {
   uint64_t k0 = active ? KK[0] : 0ull, k1 = active ? KK[1] : 0ull;
   if (rend < kFsmWinEnd) { k0 &= fsm_valid_bits(rend - c0); k1 &= fsm_valid_bits(rend - c0 - kFsmSub); }   // (uniform: the input ends inside this window)
   const uint32_t T[4] = {static_cast<uint32_t>(k0), static_cast<uint32_t>(k0 >> 32), static_cast<uint32_t>(k1), static_cast<uint32_t>(k1 >> 32)};
@@ -140,7 +142,7 @@ __device__ __forceinline__ uint32_t fsm_rows_from_events(const uint64_t (&KK)[2]
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     uint32_t xw = Er[3 - i];
-    const int32_t e0 = c0 + 16 * i + 1;
+    const int32_t e0 = (c0 + 16 * i + 1) | static_cast<int32_t>(tag);     // (c0 is a multiple of 64 and the sum stays below 4096: the tag's bits are free)
     while (__builtin_amdgcn_ballot_w64(xw != 0u) != 0ull) {
       const bool has = xw != 0u;
       const uint32_t q = static_cast<uint32_t>(__builtin_clz(xw | 1u));

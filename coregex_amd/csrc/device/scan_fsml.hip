@@ -19,6 +19,7 @@ struct FsmdLds {
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];
   uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
+  int32_t wdst[kWavesPerBlock][kTilesPerWave];                 // epilogue: output index of a tile's first row minus its index in the wave's list
   uint32_t qbase[kWavesPerBlock * kTilesPerWave + 4];
   int64_t tail[kWavesPerBlock * kTilesPerWave];
   uint64_t group;
@@ -59,14 +60,15 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
 
   u32x4 x[4];
   uint32_t xbehind = 0;
-  auto issue_loads = [&](int jj) {
-    const uint64_t wtn = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(jj) * kWavesPerBlock + wave;
-    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+  // (a tile's offset is carried from tile to tile: the 64-bit products of the tile's number were a dozen scalar instructions per tile)
+  constexpr uint64_t kTileStep = static_cast<uint64_t>(kWavesPerBlock) * kWaveTile;
+  uint64_t tlo = (group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile);
+  auto issue_loads = [&](uint64_t lo, bool in_group) {
     int nrec = 0;
     const int pre = lo ? 0 : kFsmLeft;
     const uint64_t from = lo ? lo - kFsmLeft : 0;
     constexpr int kStaged = 4096 + (LOOK ? 4 : 0);
-    if (jj < tpw && lo < a.len) {
+    if (in_group && lo < a.len) {
       const uint64_t rem = a.len - from;
       nrec = rem >= static_cast<uint64_t>(kStaged - pre) ? kStaged - pre : static_cast<int>((rem + 3) & ~3ull);
     }
@@ -75,10 +77,9 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
     for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((lane + 64 * k) << 4) - pre, 0, 0);
     if (LOOK) xbehind = __builtin_amdgcn_raw_buffer_load_b32(rsrc, 4096 - pre, 0, 0);
   };
-  issue_loads(0);
-  for (int j = 0; j < tpw; j++) {
-    const uint64_t wt = group * (kWavesPerBlock * tpw) + static_cast<uint64_t>(j) * kWavesPerBlock + wave;
-    const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
+  issue_loads(tlo, true);
+  for (int j = 0; j < tpw; j++, tlo += kTileStep) {
+    const uint64_t tile_lo = tlo;
     uint32_t tot = 0;
     if (tile_lo < a.len) {
       uint8_t* win = S.win[wave];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
         d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
       }
       if (LOOK && lane == 0) *reinterpret_cast<uint32_t*>(win + 64 * kFsmStride) = xbehind;   // window position 4096
-      issue_loads(j + 1);
+      issue_loads(tlo + kTileStep, j + 1 < tpw);
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
       if (LOOK && lane == 0) {                          // the byte in front of the haystack and the one behind its end (DS ops of a wave keep their order)
@@ -155,15 +156,16 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
         KK[0] = (static_cast<uint64_t>(t[0].k1) << 32) | t[0].k0; KK[1] = (static_cast<uint64_t>(t[1].k1) << 32) | t[1].k0;
       }
       tot = fsm_rows_from_events<kRowsPerWave>(KK, active, owned, rend, c0, lane, S.re[wave], nrows_w, fallback,
-                                               [&]() -> uint32_t { if constexpr (DIRECT) return tab.at(prop + xend1) & 0x7Fu; else return fsm_u16(v.tab, xend1 + v.ncls2 + 2u); });
+                                               [&]() -> uint32_t { if constexpr (DIRECT) return tab.at(prop + xend1) & 0x7Fu; else return fsm_u16(v.tab, xend1 + v.ncls2 + 2u); },
+                                               static_cast<uint32_t>(j) << 12);
       wave_lds_sync();
       if (a.out != nullptr || a.max_len != 0) {
         // a tile with 128 rows and more (`\\b\\d+\\b`: 535, nine rounds of this loop) has short matches: 8 branch-free steps in front of the loop
         // instead of 16 (the answer is the same, fsm.hpp fsm_match_startN)
         const bool short_rows = tot >= 128u;
         for (uint32_t q = lane; q < tot && nrows_w + q < static_cast<uint32_t>(kRowsPerWave); q += 64) {
-          const int32_t e = S.re[wave][nrows_w + q];
-          const int32_t bound = q ? static_cast<int32_t>(S.re[wave][nrows_w + q - 1]) : (tile_lo ? lowest - 1 : 0);
+          const int32_t e = S.re[wave][nrows_w + q] & 4095;       // (bits 12..14: the tile's number, for the epilogue)
+          const int32_t bound = q ? static_cast<int32_t>(S.re[wave][nrows_w + q - 1] & 4095) : (tile_lo ? lowest - 1 : 0);
           uint32_t over = 0;
           int32_t st;
           if constexpr (DIRECT) {
@@ -207,58 +209,64 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
     uint32_t st = 0;
     for (int k = 0; k < jj; k++) st += S.cnt[w][k];
     const uint32_t n = S.cnt[w][jj];
-    S.tail[q] = (n && st + n <= static_cast<uint32_t>(kRowsPerWave)) ? gorigin + static_cast<int64_t>(q) * kWaveTile + S.re[w][st + n - 1] : -1;
+    S.tail[q] = (n && st + n <= static_cast<uint32_t>(kRowsPerWave)) ? gorigin + static_cast<int64_t>(q) * kWaveTile + (S.re[w][st + n - 1] & 4095) : -1;
+  }
+  __syncthreads();
+  if (tid >= 128 && tid < 128 + kWavesPerBlock * tpw) {       // (behind the barrier: qbase is there)
+    const int q = tid - 128, w = q % kWavesPerBlock, jj = q / kWavesPerBlock;
+    uint32_t st = 0;
+    for (int k = 0; k < jj; k++) st += S.cnt[w][k];
+    S.wdst[w][jj] = static_cast<int32_t>(S.qbase[q]) - static_cast<int32_t>(st);
   }
   __syncthreads();
   const uint32_t total = S.qbase[kWavesPerBlock * tpw];
   tile_lookback(a.status, a.total, a.err, group, a.ngroups, total, &S.base, a.epoch);
   const uint64_t base = S.base;
-  uint32_t start = 0;
-  for (int j = 0; j < tpw; j++) {
-    const uint32_t n = S.cnt[wave][j];
-    const int q = j * kWavesPerBlock + wave;
-    const uint64_t dst = base + S.qbase[q];
+  // the wave's rows as one list (an end carries its tile's number): five rounds of 64 rows for the 288 of an ordinary group instead of one
+  // round per tile with 36 of 64 lanes at work
+  const uint32_t nr = nrows_w < static_cast<uint32_t>(kRowsPerWave) ? nrows_w : static_cast<uint32_t>(kRowsPerWave);
+  for (uint32_t r = lane; r < nr; r += 64) {
+    const uint32_t vr = S.re[wave][r], jr = vr >> 12;
+    const int q = static_cast<int>(jr) * kWavesPerBlock + wave;
     const int64_t tb = gorigin + static_cast<int64_t>(q) * kWaveTile;
-    for (uint32_t i = lane; i < n; i += 64) {
-      const uint32_t r = start + i;
-      if (r >= static_cast<uint32_t>(kRowsPerWave)) continue;
-      int64_t e = tb + S.re[wave][r], s0 = e - S.rl[wave][r];
-      if ((i == 0 || s0 == e) && (a.out != nullptr || a.max_len != 0)) {
-        // the tile's first row was walked without a bound (its predecessor is another wave's row); an unresolved row (s0 == e) left
-        // the window.  Previous end: inside the tile, else the nearest earlier tile of the group with rows; the group's first row is
-        // checked by k_fsm_fix_heads.
-        int64_t prev = -1;
-        if (i > 0) prev = tb + S.re[wave][r - 1];
-        else for (int p = q - 1; p >= 0 && prev < 0; p--) prev = S.tail[p];
-        if (prev > s0 || s0 == e) {                                           // rare: walk again from HBM / L2, bounded
-          const int64_t lo = prev > 0 ? prev : 0;
-          int64_t st = -1, at = e - 1;
-          if constexpr (DIRECT) {
-            uint32_t sr = R.start;
-            for (; at >= lo; at--) {
-              if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-              sr = tab.at(fsmd_addr(sr, a.hay[at], 0));
-              if (sr == R.dead) break;
-              if (sr >= R.acc_lo) st = at;
-            }
-          } else {
-            uint32_t sr = v.rev_start_off;
-            if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + ((static_cast<uint64_t>(e) < a.len ? v.knd[a.hay[e]] : (LOOK == 2 ? v.end_col : v.knd[outside])) >> 1)));
-            for (; at >= lo; at--) {
-              if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
-              sr = fsm_u16(v.tab, (sr & ~1u) + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
-              if (sr == v.rev_dead) break;
-              if (sr & 1u) st = at;
-            }
-            if (LOOK && v.rev_text_col != 0u && at < 0 && sr != v.rev_dead && fsm_u16(v.tab, (sr & ~1u) + v.rev_text_col + v.knd[a.hay[0]]) != 0u) st = 0;   // text-start anchor (fsm.hpp fsm_match_start)
+    int64_t e = tb + static_cast<int64_t>(vr & 4095u), s0 = e - S.rl[wave][r];
+    const uint32_t vp = r ? S.re[wave][r - 1] : 0xFFFFu;
+    const bool first = (vp >> 12) != jr;                                      // the tile's first row
+    if ((first || s0 == e) && (a.out != nullptr || a.max_len != 0)) {
+      // the tile's first row was walked without a bound (its predecessor is another wave's row); an unresolved row (s0 == e) left
+      // the window.  Previous end: inside the tile, else the nearest earlier tile of the group with rows; the group's first row is
+      // checked by k_fsm_fix_heads.
+      int64_t prev = -1;
+      if (!first) prev = tb + static_cast<int64_t>(vp & 4095u);
+      else for (int p = q - 1; p >= 0 && prev < 0; p--) prev = S.tail[p];
+      if (prev > s0 || s0 == e) {                                           // rare: walk again from HBM / L2, bounded
+        const int64_t lo = prev > 0 ? prev : 0;
+        int64_t st = -1, at = e - 1;
+        if constexpr (DIRECT) {
+          uint32_t sr = R.start;
+          for (; at >= lo; at--) {
+            if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
+            sr = tab.at(fsmd_addr(sr, a.hay[at], 0));
+            if (sr == R.dead) break;
+            if (sr >= R.acc_lo) st = at;
           }
-          if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s0 = st;
+        } else {
+          uint32_t sr = v.rev_start_off;
+          if (LOOK) sr = fsm_u16(v.knd, 256u + 2u * v.nk + 2u * ((v.knd[a.hay[e - 1]] >> 1) * v.nk + ((static_cast<uint64_t>(e) < a.len ? v.knd[a.hay[e]] : (LOOK == 2 ? v.end_col : v.knd[outside])) >> 1)));
+          for (; at >= lo; at--) {
+            if (e - at > kSerialLimit) { raise_err(a.err, kErrSerialLimit); break; }
+            sr = fsm_u16(v.tab, (sr & ~1u) + v.cls2[a.hay[at]] + (LOOK ? v.knd[at > 0 ? a.hay[at - 1] : outside] : 0u));
+            if (sr == v.rev_dead) break;
+            if (sr & 1u) st = at;
+          }
+          if (LOOK && v.rev_text_col != 0u && at < 0 && sr != v.rev_dead && fsm_u16(v.tab, (sr & ~1u) + v.rev_text_col + v.knd[a.hay[0]]) != 0u) st = 0;   // text-start anchor (fsm.hpp fsm_match_start)
         }
+        if (st < 0) raise_err(a.err, 8u | (64u << 8)); else s0 = st;
       }
-      if (a.max_len != 0 && static_cast<uint64_t>(e - s0) > a.max_len) long_hit = 1;
-      if (a.out != nullptr && dst + i < a.cap) store_pair_nt(a.out + (dst + i) * a.row_width, a.base + s0, a.base + e);
     }
-    start += n;
+    if (a.max_len != 0 && static_cast<uint64_t>(e - s0) > a.max_len) long_hit = 1;
+    const uint64_t di = base + static_cast<uint64_t>(static_cast<int64_t>(S.wdst[wave][jr]) + static_cast<int64_t>(r));
+    if (a.out != nullptr && di < a.cap) store_pair_nt(a.out + di * a.row_width, a.base + s0, a.base + e);
   }
   if (long_hit) raise_err(a.err, kErrLongMatch);
 }
