@@ -28,24 +28,11 @@ int deviceCount() {
   return n;
 }
 
-// Wait for the call's stream.  CXG_SPIN_SYNC=1 polls hipStreamQuery for up to 2 ms before parking the thread (hipStreamSynchronize is
-// woken ~10 us after the kernel ended: 0.2419 -> 0.2352 ms per 1 GiB call) — OFF by default: with it on, the device fuzz and
-// tests/test_gpu_parity.py::test_random_patterns of round 5 returned rows the last kernel of a relaunch ladder had not written yet
-// (profiles/r05_pytest_gpu_spin_sync.log: the tail of the array still held an earlier call's rows) — hipStreamQuery answered "ready"
-// before the stream had drained.  Correctness first; the knob stays for measurements.
-hipError_t syncStream(hipStream_t stream) {
-  static const bool spin = getenv("CXG_SPIN_SYNC") != nullptr;
-  if (spin) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t i = 0;; i++) {
-      const hipError_t q = hipStreamQuery(stream);
-      if (q == hipSuccess) break;
-      if (q != hipErrorNotReady) return q;
-      if ((i & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-    }
-  }
-  return hipStreamSynchronize(stream);
-}
+// Wait for the call's stream.  (Round 5 had a CXG_SPIN_SYNC knob that polled hipStreamQuery in front of this: 4 us saved per call, and rows
+// of a relaunch ladder's last kernel read before they were written — profiles/r05_pytest_gpu_spin_sync.log.  The cause was never
+// found — hipStreamSynchronize followed the poll unconditionally, so an early "ready" cannot explain it — and the knob
+// is gone.)
+hipError_t syncStream(hipStream_t stream) { return hipStreamSynchronize(stream); }
 
 int getScratch(Scratch** out) {
   if (deviceCount() <= 0) return fail(CXG_E_NO_GPU, "no gfx950 device visible (this library has no CPU search path)");

@@ -32,7 +32,11 @@ struct FsmdTab {                                               // the image sits
 }  // namespace
 
 template <int IMG, int MODE, int KIND>
-__global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)) ? 2 : 4)) void k_scan_fsml(ScanArgs a) {
+#ifndef CXG_FSML_OCC
+#define CXG_FSML_OCC 5          // workgroups per CU the register allocation aims at: 96 VGPRs (round 6, profiles/r06_c19_fsml_occ_*: README IP pattern 0.488 -> 0.466 ms
+                                // against 4 / 127 VGPRs on one box; 12 bytes of scratch in the plain instantiation)
+#endif
+__global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)) ? 2 : CXG_FSML_OCC)) void k_scan_fsml(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) FsmdLds<IMG, MODE> S;
   constexpr int kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   constexpr int tpw = FsmMode<MODE>::kTpw;
