@@ -38,6 +38,7 @@ template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
+  uint16_t lk16[256];                                          // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
   uint16_t lrow[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kRows];   // per-lane row ends of the current tile (two sub-chunks); shallow machines: rows come from the event bits
   uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];      // rows of the group: end inside its wave-tile (+ a dump slot for the branch-free row loop)
@@ -275,7 +276,12 @@ __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) voi
   __syncthreads();
   const uint64_t group = s_group;
   if (group >= a.ngroups) return;
-  const FsmView v = view_of(s_img, h);
+  FsmView v = view_of(s_img, h);
+  if (LOOK) {                                                     // (kThreads == 256: one entry each; every thread of the group is still here)
+    S.lk16[tid] = static_cast<uint16_t>(v.cls2[tid] | (static_cast<uint32_t>(v.knd[tid]) << 8));
+    __syncthreads();
+  }
+  v.lk16 = S.lk16;
   const uint32_t outside = LOOK ? h->outside_byte : 0u;           // what the positions around the haystack read as
   constexpr int tpw = FsmMode<MODE>::kTpw;
   uint32_t nrows_w = 0, fallback = 0, long_hit = 0;

@@ -94,6 +94,7 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = body + (h->mem_off - hs); v.row_shift = h->row_shift;
   v.knd = body + (h->knd_off - hs);
+  v.lk16 = nullptr;          // (set by the kernel once it has filled its table)
   v.nk = h->nk;
   return v;
 }

@@ -16,6 +16,7 @@ template <int IMG, int MODE>
 struct FsmdLds {
   uint8_t img[IMG];                                            // direct: rows of 256 bytes at LDS address 0, then the property table; class-indexed: the image behind its header
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
+  uint16_t lk16[256];                                          // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];
   uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
@@ -56,7 +57,12 @@ __global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)
   if (group >= a.ngroups) return;
   FsmdTab tab;
   tab.img = (lds_bytes_t)S.img;
-  const FsmView v = view_of(S.img, h);                                            // (class-indexed kinds; direct: unused)
+  FsmView v = view_of(S.img, h);                                                  // (class-indexed kinds; direct: unused)
+  if (LOOK) {                                                                     // (kThreads == 256: one entry each)
+    S.lk16[tid] = static_cast<uint16_t>(v.cls2[tid] | (static_cast<uint32_t>(v.knd[tid]) << 8));
+    __syncthreads();
+  }
+  v.lk16 = S.lk16;
   const uint32_t top = h->d_top, prop = h->d_slots << 8;                                                  // (direct)
   const FsmdRev R = {h->d_rstart, h->d_racc_lo, h->d_rdead};
   const uint32_t outside = LOOK ? h->outside_byte : 0u;

@@ -45,6 +45,11 @@ FsmView view_of(const uint8_t* img) {
   v.create_lo = h->create_lo; v.rematch_lo = h->rematch_lo;
   v.mem = img + h->mem_off; v.row_shift = h->row_shift;
   v.knd = img + h->knd_off;
+  {                                       // FsmView::lk16 (the kernels fill theirs in LDS): one table per thread is enough here
+    static thread_local uint16_t lk[256];
+    for (int b = 0; b < 256; b++) lk[b] = static_cast<uint16_t>(v.cls2[b] | (static_cast<uint32_t>(h->nk > 1 ? v.knd[b] : 0) << 8));
+    v.lk16 = lk;
+  }
   v.nk = h->nk;
   return v;
 }

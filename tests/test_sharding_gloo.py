@@ -96,6 +96,12 @@ def test_programs_that_must_not_be_sharded_say_so():
     for pat in (r"a*", r"x?y*", r'"[^"]*"'):
         rx = cx.compile(pat)
         assert rx.supported and not sharding.shardable(rx), pat
+    # round 6: a text anchor holds at the TEXT's first / last position only — a shard's own ends are not the text's
+    for pat in (r"(?:^|,)\d+", r"foo|\Abar", r"a$|z", r"x\z|foo", r"^\s+|\s+$"):
+        rx = cx.compile(pat)
+        assert rx.supported and not sharding.shardable(rx), pat
+    for pat in (r"\berror\b", r"(?m)^\d+", r"(?m)[a-z]+$"):                      # line anchors and word boundaries shard at '\n' like everything else
+        assert sharding.shardable(cx.compile(pat)), pat
     # the spurious row the rule prevents: `a*` over `xb|ay` cut behind the b
     import emu
     from twins import rows_on_twin
