@@ -132,7 +132,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   bool persKernel = false;                                         // ... by k_scan_fields_pers (the launcher says)
   bool litKernel = false;                                          // ... by its literal mode (round 5)
   bool denseChain = p->denseChain[submatch ? 1 : 0].load(std::memory_order_relaxed) != 0;   // wave kernels: match-dense input seen before
-  int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 (very dense)
+  int fsmMode = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);                // transducer kernel: 0, 1 (dense), 2 and 3 (very dense: 1 024 / 2 048 rows per tile)
   static const bool fsmDirectOk = getenv("CXG_FSM_NO_DIRECT") == nullptr;                     // A/B: the class-indexed tables for every machine
   static const bool fsmLeanOk = getenv("CXG_FSM_NO_LEAN") == nullptr;                         // A/B: k_scan_fsm for every machine
   // the lean kernel (scan_fsm.hip k_scan_fsml: shallow machines, entry states that collapse; byte-indexed rows where the image has them)
@@ -159,7 +159,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
-    a.tiles_per_wave = (gen == 10 && fsmMode == 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, mode 2: one tile, 2048 rows
+    a.tiles_per_wave = (gen == 10 && fsmMode >= 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, modes 2 and 3: one tile, 1 024 / 2 048 rows
     const uint64_t gb = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kWavesPerBlock * a.tiles_per_wave;
     a.ngroups = (len + gb - 1) / gb;
   }
@@ -222,7 +222,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     const cxgdev::FsmHeader* fh = reinterpret_cast<const cxgdev::FsmHeader*>(fsmImg.data());
     fsmDirectRan = fsmDirect && !deepOnly && fh->depth <= 1 && a.prof == nullptr && a.dbg == 0;
     fsmDirectTables = fsmDirectRan && fsmDirectOk && fh->direct_off != 0u && fh->nk == 1;
-    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->end_col != 0u ? 2 : (fh->nk > 1 ? 1 : 0), stream, fsmDirectTables ? fh->direct_bytes : 0u, fsmDirectRan);
+    le = cxgdev::launch_scan_fsm(a, fh->lds_bytes, fh->depth <= 1 && !deepOnly, fh->end_col != 0u ? 2 : (fh->nk > 1 ? 1 : 0), stream, fsmDirectTables ? fh->direct_bytes : 0u, fsmDirectRan, fsmMode);
   }
   else if (gen == 11) {
     std::memcpy(a.chain, p->delim, sizeof p->delim);
@@ -504,11 +504,11 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       relaunches++;
       continue;
     }
-    if (gen == 10 && ((err >> 8) & 0x32u) != 0u && ((err >> 8) & ~0x72u) == 0u && fsmMode < 2) {   // transducer kernel: row / event buffers overflowed
+    if (gen == 10 && ((err >> 8) & 0x32u) != 0u && ((err >> 8) & ~0x72u) == 0u && fsmMode < 3) {   // transducer kernel: row / event buffers overflowed
       // (0x40 — a row without a start — beside an overflow bit is a consequence of the dropped rows, not a finding)
       // 0x20 alone: the wave's row list -> mode 1 (2 tiles per wave); a sub-chunk's own buffers (0x02 rows, 0x10 events), or
-      // mode 1 was not enough -> mode 2 (1 tile, 2048 rows, 16 rows / 32 events per 32 bytes)
-      fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : 2;
+      // mode 1 was not enough -> mode 2 (1 tile, 1 024 rows, 16 rows / 32 events per 32 bytes) -> mode 3 (2 048 rows; two workgroups per CU)
+      fsmMode = ((err >> 8) == 0x20u && fsmMode == 0) ? 1 : (fsmMode < 2 ? 2 : 3);
       if (verbose) fprintf(stderr, "[cxg] transducer kernel: match-dense input (reason bits 0x%x), rerunning in mode %d\n", err >> 8, fsmMode);
       {                                                             // remembered per program; only grows
         uint8_t old = p->fsmMode[submatch ? 1 : 0].load(std::memory_order_relaxed);

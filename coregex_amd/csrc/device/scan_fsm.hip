@@ -31,9 +31,7 @@ namespace {
 // step's address  (entry & ~3) | 2 * class  goes straight into the ds_read — no base add on the dependent chain
 // (with the table anywhere else the compiler adds the base in a VALU op: it cannot prove that base + offset does not
 // wrap, so it does not use the instruction's immediate offset).  IMG = bytes reserved for the image.
-// MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per
-// tile, match-dense input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match
-// per 2 bytes).  The host escalates after an overflow and remembers the mode for the program (capi_ladder.hip).
+// MODE: buffer geometry by match density, 0..3 (scan_fsm_common.hpp FsmMode).
 template <bool SHALLOW, int IMG, int MODE>
 struct FsmLds {
   uint8_t img[IMG];
@@ -254,7 +252,7 @@ __device__ __forceinline__ void fsm_resolve_exits(const FsmView& v, uint32_t* s_
 // LOOK: 1 = the image has assertions (nk > 1): a step's class also reads the next byte (fsm.hpp "Look-around"); 2 = ... and an
 // end-of-text anchor: the step over the haystack's last byte takes the column of the kind no byte has (fsm.hpp "End of text").
 template <bool SHALLOW, int IMG, int MODE, int LOOK>
-__global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 2) ? 2 : 4)) void k_scan_fsm(ScanArgs a) {
+__global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 3 || (MODE == 2 && !SHALLOW)) ? 2 : (MODE == 2 ? 3 : 4))) void k_scan_fsm(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE> S;
   constexpr int kLaneRows = FsmMode<MODE>::kRows, kLaneEvents = FsmMode<MODE>::kEvents, kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   uint8_t* const s_img = S.img;
@@ -744,24 +742,26 @@ void launch_fsm_img(const ScanArgs& a, bool shallow, int mode, dim3 grid, dim3 b
   if (shallow) {
     if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 0, LOOK>), grid, block, 0, stream, a);
     else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 1, LOOK>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_fsm<true, IMG, 2, LOOK>), grid, block, 0, stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_scan_fsm<true, IMG, 2, LOOK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<true, IMG, 3, LOOK>), grid, block, 0, stream, a);
   } else {
     if (mode == 0) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 0, LOOK>), grid, block, 0, stream, a);
     else if (mode == 1) hipLaunchKernelGGL((k_scan_fsm<false, IMG, 1, LOOK>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_scan_fsm<false, IMG, 2, LOOK>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_scan_fsm<false, IMG, 3, LOOK>), grid, block, 0, stream, a);   // (machines with event lists: their per-lane buffers dominate the LDS, modes 2 and 3 are one)
   }
 }
 }  // namespace
 
-hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes);   // scan_fsml.hip
+hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, int mode);   // scan_fsml.hip
 
 // lean != 0: the lean kernel (the machine is shallow); direct_bytes != 0 with it: its direct mode (the caller has checked that the image
 // carries the section).  look: 0 / 1 / 2 as the kernels' LOOK (2: FsmHeader::end_col != 0 — rare programs, one image size only)
-hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, bool lean) {
+// mode: 0..3 (scan_fsm_common.hpp FsmMode; a.tiles_per_wave = 8, 2, 1, 1 goes with it)
+hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, bool lean, int mode) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
+  if (mode < 0 || mode > 3 || a.tiles_per_wave != static_cast<uint32_t>(mode == 0 ? kTilesPerWave : (mode == 1 ? kDenseTilesPerWave : 1))) return hipErrorInvalidValue;
   if (lds_bytes > 28672) return hipErrorInvalidValue;
-  if (lean) { const hipError_t el = launch_scan_fsml(a, lds_bytes, shallow, look, stream, direct_bytes); if (el != hipSuccess) return el; }
+  if (lean) { const hipError_t el = launch_scan_fsml(a, lds_bytes, shallow, look, stream, direct_bytes, mode); if (el != hipSuccess) return el; }
   else if (look == 2) launch_fsm_img<28672, 2>(a, shallow, mode, grid, block, stream);             // end-of-text programs
   else if (look) {                                                                                   // word-boundary programs
     if (lds_bytes <= 3072) launch_fsm_img<3072, 1>(a, shallow, mode, grid, block, stream);

@@ -30,6 +30,10 @@
 #define FSM_MARK(i) do { } while (0)
 #endif
 
+#ifndef CXG_FSML_OCC2
+#define CXG_FSML_OCC2 4         // workgroups per CU the lean kernel's register allocation aims at in mode 2 (38 KB of LDS per workgroup)
+#endif
+
 namespace cxgdev {
 
 namespace {
@@ -100,13 +104,15 @@ __device__ __forceinline__ FsmView view_of(const uint8_t* body, const FsmHeader*
 }
 
 // MODE: 0 = 8 wave-tiles per wave and group, 512 rows buffered per wave; 1 = 2 wave-tiles (four times the row room per tile, match-dense
-// input); 2 = 1 wave-tile, 2048 rows per tile, 16 rows / 32 events per 32-byte sub-chunk (one match per 2 bytes).  The host escalates
-// after an overflow and remembers the mode for the program (capi_ladder.hip).
+// input); 2 = 1 wave-tile, 1 024 rows per tile; 3 = 1 wave-tile, 2 048 rows (one match per 2 bytes); 2 and 3: 16 rows / 32 events per
+// 32-byte sub-chunk.  The host escalates after an overflow and remembers the mode for the program (capi_ladder.hip).  Round 6 put
+// mode 2 in front of the old one (now 3): with 2 048 rows the row buffers alone are 33 KB and two workgroups fit a CU — `\\b\\d+\\b`
+// (535 rows per tile) ran 2.74 ms per GiB there and runs 1.77 with 1 024 rows and four workgroups (profiles/r06_c22_mode2_*).
 template <int MODE> struct FsmMode {
   static constexpr int kTpw = MODE == 0 ? kTilesPerWave : (MODE == 1 ? kDenseTilesPerWave : 1);
-  static constexpr int kRows = MODE == 2 ? kFsmLaneRowsMax : kFsmLaneRows;
-  static constexpr int kEvents = MODE == 2 ? kFsmLaneEventsMax : kFsmLaneEvents;
-  static constexpr int kRowsPerWave = MODE == 2 ? 2048 : 512;
+  static constexpr int kRows = MODE >= 2 ? kFsmLaneRowsMax : kFsmLaneRows;
+  static constexpr int kEvents = MODE >= 2 ? kFsmLaneEventsMax : kFsmLaneEvents;
+  static constexpr int kRowsPerWave = MODE == 3 ? 2048 : (MODE == 2 ? 1024 : 512);
 };
 
 // Rows of a tile from the event bits of its lanes (fsm.hpp "Round 6"): an event is a row's end unless the event behind it is a rematch.

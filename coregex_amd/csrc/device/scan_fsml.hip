@@ -37,7 +37,7 @@ template <int IMG, int MODE, int KIND>
 #define CXG_FSML_OCC 5          // workgroups per CU the register allocation aims at: 96 VGPRs (round 6, profiles/r06_c19_fsml_occ_*: README IP pattern 0.488 -> 0.466 ms
                                 // against 4 / 127 VGPRs on one box; 12 bytes of scratch in the plain instantiation)
 #endif
-__global__ __launch_bounds__(kThreads, ((MODE == 2 || (KIND >= 0 && IMG > 10240)) ? 2 : CXG_FSML_OCC)) void k_scan_fsml(ScanArgs a) {
+__global__ __launch_bounds__(kThreads, (((KIND >= 0 && IMG > 10240) || MODE == 3) ? 2 : MODE == 2 ? CXG_FSML_OCC2 : CXG_FSML_OCC)) void k_scan_fsml(ScanArgs a) {
   __shared__ __attribute__((aligned(16))) FsmdLds<IMG, MODE> S;
   constexpr int kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   constexpr int tpw = FsmMode<MODE>::kTpw;
@@ -286,15 +286,15 @@ template <int IMG, int KIND>
 void launch_fsml_img(const ScanArgs& a, int mode, dim3 grid, dim3 block, hipStream_t stream) {
   if (mode == 0) hipLaunchKernelGGL((k_scan_fsml<IMG, 0, KIND>), grid, block, 0, stream, a);
   else if (mode == 1) hipLaunchKernelGGL((k_scan_fsml<IMG, 1, KIND>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((k_scan_fsml<IMG, 2, KIND>), grid, block, 0, stream, a);
+  else if (mode == 2) hipLaunchKernelGGL((k_scan_fsml<IMG, 2, KIND>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((k_scan_fsml<IMG, 3, KIND>), grid, block, 0, stream, a);
 }
 }  // namespace
 
 // direct_bytes != 0: the direct mode (the caller has checked that the image carries the section); look: 0 / 1 / 2 as the kernel's KIND.
 // The first rows of the groups are checked by k_fsm_fix_heads behind it (launch_scan_fsm, scan_fsm.hip).
-hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes) {
+hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, int mode) {
   const dim3 grid(static_cast<unsigned>(a.ngroups)), block(kThreads);
-  const int mode = a.tiles_per_wave == static_cast<uint32_t>(kTilesPerWave) ? 0 : (a.tiles_per_wave == static_cast<uint32_t>(kDenseTilesPerWave) ? 1 : 2);
   if (lds_bytes > 28672 || !shallow) return hipErrorInvalidValue;
   if (direct_bytes != 0u) {
     if (direct_bytes > kFsmdMaxBytes || look) return hipErrorInvalidValue;
