@@ -32,11 +32,11 @@ namespace {
 // (with the table anywhere else the compiler adds the base in a VALU op: it cannot prove that base + offset does not
 // wrap, so it does not use the instruction's immediate offset).  IMG = bytes reserved for the image.
 // MODE: buffer geometry by match density, 0..3 (scan_fsm_common.hpp FsmMode).
-template <bool SHALLOW, int IMG, int MODE>
+template <bool SHALLOW, int IMG, int MODE, bool LOOKTAB>
 struct FsmLds {
   uint8_t img[IMG];
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
-  uint16_t lk16[256];                                          // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
+  uint16_t lk16[LOOKTAB ? 256 : 2];                            // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
   uint16_t lrow[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kRows];   // per-lane row ends of the current tile (two sub-chunks); shallow machines: rows come from the event bits
   uint16_t lev[kWavesPerBlock][SHALLOW ? 4 : 64 * 2 * FsmMode<MODE>::kEvents];   // per-lane recorded events (alias rows); machines with depth > 1 only
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];      // rows of the group: end inside its wave-tile (+ a dump slot for the branch-free row loop)
@@ -253,7 +253,7 @@ __device__ __forceinline__ void fsm_resolve_exits(const FsmView& v, uint32_t* s_
 // end-of-text anchor: the step over the haystack's last byte takes the column of the kind no byte has (fsm.hpp "End of text").
 template <bool SHALLOW, int IMG, int MODE, int LOOK>
 __global__ __launch_bounds__(kThreads, ((IMG > 10240 || MODE == 3 || (MODE == 2 && !SHALLOW)) ? 2 : (MODE == 2 ? 3 : 4))) void k_scan_fsm(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE> S;
+  __shared__ __attribute__((aligned(16))) FsmLds<SHALLOW, IMG, MODE, (LOOK != 0)> S;
   constexpr int kLaneRows = FsmMode<MODE>::kRows, kLaneEvents = FsmMode<MODE>::kEvents, kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   uint8_t* const s_img = S.img;
   auto& s_win = S.win; auto& s_lrow = S.lrow; auto& s_lev = S.lev; auto& s_re = S.re; auto& s_rl = S.rl;

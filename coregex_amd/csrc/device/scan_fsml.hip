@@ -12,11 +12,11 @@ namespace cxgdev {
 // KIND -1: direct mode (fsm.hpp "Direct mode": byte-indexed rows, v_perm_b32 + ds_read_u8 + v_alignbit per byte, machines without
 // look-around whose rows fit); KIND 0 / 1 / 2: the class-indexed tables, LOOK = KIND.
 namespace {
-template <int IMG, int MODE>
+template <int IMG, int MODE, bool LOOKTAB>
 struct FsmdLds {
   uint8_t img[IMG];                                            // direct: rows of 256 bytes at LDS address 0, then the property table; class-indexed: the image behind its header
   uint8_t win[kWavesPerBlock][kFsmWinBytes];
-  uint16_t lk16[256];                                          // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
+  uint16_t lk16[LOOKTAB ? 256 : 2];                            // look-around: class | kind << 8 of a byte (fsm.hpp FsmView::lk16)
   uint16_t re[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave + 8];
   uint16_t rl[kWavesPerBlock][FsmMode<MODE>::kRowsPerWave];
   uint32_t cnt[kWavesPerBlock][kTilesPerWave];
@@ -37,8 +37,9 @@ template <int IMG, int MODE, int KIND>
 #define CXG_FSML_OCC 5          // workgroups per CU the register allocation aims at: 96 VGPRs (round 6, profiles/r06_c19_fsml_occ_*: README IP pattern 0.488 -> 0.466 ms
                                 // against 4 / 127 VGPRs on one box; 12 bytes of scratch in the plain instantiation)
 #endif
-__global__ __launch_bounds__(kThreads, (((KIND >= 0 && IMG > 10240) || MODE == 3) ? 2 : MODE == 2 ? CXG_FSML_OCC2 : CXG_FSML_OCC)) void k_scan_fsml(ScanArgs a) {
-  __shared__ __attribute__((aligned(16))) FsmdLds<IMG, MODE> S;
+// (the LDS decides how many workgroups fit a CU — window 17 KB, rows 8 / 16 / 33 KB, the image: the register allocation aims at that number)
+__global__ __launch_bounds__(kThreads, (((KIND >= 0 && IMG > 10240) || MODE == 3) ? 2 : MODE == 2 ? CXG_FSML_OCC2 : IMG > 6144 ? 4 : CXG_FSML_OCC)) void k_scan_fsml(ScanArgs a) {
+  __shared__ __attribute__((aligned(16))) FsmdLds<IMG, MODE, (KIND > 0)> S;
   constexpr int kRowsPerWave = FsmMode<MODE>::kRowsPerWave;
   constexpr int tpw = FsmMode<MODE>::kTpw;
   constexpr bool DIRECT = KIND < 0;
@@ -301,7 +302,11 @@ hipError_t launch_scan_fsml(const ScanArgs& a, uint32_t lds_bytes, bool shallow,
     if (direct_bytes <= 6144) launch_fsml_img<6144, -1>(a, mode, grid, block, stream);
     else launch_fsml_img<12288, -1>(a, mode, grid, block, stream);
   }
-  else if (look == 2) launch_fsml_img<28672, 2>(a, mode, grid, block, stream);
+  else if (look == 2) {                                                                              // end-of-text programs
+    if (lds_bytes <= 3072) launch_fsml_img<3072, 2>(a, mode, grid, block, stream);
+    else if (lds_bytes <= 10240) launch_fsml_img<10240, 2>(a, mode, grid, block, stream);
+    else launch_fsml_img<28672, 2>(a, mode, grid, block, stream);
+  }
   else if (look) {
     if (lds_bytes <= 3072) launch_fsml_img<3072, 1>(a, mode, grid, block, stream);
     else if (lds_bytes <= 10240) launch_fsml_img<10240, 1>(a, mode, grid, block, stream);
