@@ -24,8 +24,14 @@ def first_kernel(rx, sub=False):
         return "k_scan_teddy_wave" if aux_len <= 2048 else "k_scan_teddy"
     if kind == 3:
         return "k_scan_charclass_wave" if flags & 64 else "k_scan_charclass"
+    def fsm_name():                                             # round 6: shallow machines start on the lean kernel (FsmHeader: depth, nk, direct_off)
+        img = rx.fsm_image(sub)
+        depth, nk, direct = struct.unpack_from("<I", img, 7 * 4)[0], struct.unpack_from("<I", img, 23 * 4)[0], struct.unpack_from("<I", img, 30 * 4)[0]
+        if depth > 1:
+            return "k_scan_fsm"
+        return "k_scan_fsml<direct>" if direct and nk == 1 else "k_scan_fsml (k_scan_fsm for input whose entry states do not collapse)"
     if kind == 5:
-        return "k_scan_fsm (look-around / large NFA: no other kernel)"
+        return fsm_name() + " (look-around / large NFA: no other kernel)"
     if flags & 16:                                              # complete ordered chain
         if sub:
             caps = rx.chain_captures() is not None
@@ -42,7 +48,7 @@ def first_kernel(rx, sub=False):
     if kind == 2 and flags & 256:
         return "k_scan_teddy_wave<VERIFY> (literal prefixes + anchored DFA walk)"
     if fsm:
-        return "k_scan_fsm"
+        return fsm_name()
     return "k_scan_digit_flat" if kind == 1 else "k_scan_dfa<bidir>"
 
 
