@@ -79,6 +79,7 @@ const char* cxg_kernel_name(int k) {
     case CXG_K_LITERAL_PERS: return "k_scan_fields_pers<LIT>";
     case CXG_K_TRIO_PERS: return "k_scan_fields_pers<TRIO>";
     case CXG_K_TEDDY_WAVE: return "k_scan_teddy_wave";
+    case CXG_K_TEDDY_PAIR: return "k_scan_teddy_pair";
     case CXG_K_CHARCLASS_WAVE: return "k_scan_charclass_wave";
     case CXG_K_PREFIX_WAVE: return "k_scan_teddy_wave<VERIFY>";
     case CXG_K_FSM: return "k_scan_fsm";

@@ -40,6 +40,7 @@ int trio_shape(const ChainAux& c);
 hipError_t launch_scan_trio_wave(const ScanArgs& a, hipStream_t stream, bool* persistent);   // scan_fields_wave.hip
 hipError_t launch_scan_teddy(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_teddy_wave(const ScanArgs& a, uint32_t verify_dfa_states, hipStream_t stream);
+hipError_t launch_scan_teddy_pair(const ScanArgs& a, uint32_t workgroups, hipStream_t stream);
 hipError_t launch_scan_charclass_wave(const ScanArgs& a, hipStream_t stream);
 hipError_t launch_scan_fsm(const ScanArgs& a, uint32_t lds_bytes, bool shallow, int look, hipStream_t stream, uint32_t direct_bytes, bool lean, int mode);
 }  // namespace cxgdev
@@ -149,6 +150,7 @@ struct Scratch {
   uint32_t* pfTickets = nullptr;   // ... [32][64] ticket counters a cache line apart, one block per launch epoch (scan_fields_wave.hip, round 6)
   uint64_t* pfRec = nullptr; uint64_t pfRecRounds = 0;   // ... 128 records of 16 bytes per round, tagged with the same epoch
   uint64_t* pfStats = nullptr;                           // ... per wave: units that waited, polls (CXG_VERBOSE)
+  uint32_t* pairCtr = nullptr; uint32_t pairSeq = 0;     // scan_teddy_pair.hip: two sets of 8 group counters a cache line apart; launch n claims from set n & 1 and zeroes the other
   int64_t* offSpans = nullptr; uint64_t offSpansCap = 0;  // offset captures (scanOffsetCaps): the spans in front of the expansion kernel
   int64_t* nullRows = nullptr; uint64_t nullRowsCap = 0;  // nullable programs (scanNullable): rows of the non-empty variant,
   uint64_t* nullCov = nullptr; uint64_t nullCovCap = 0;   // ... inclusive sums of the positions they cover, + one sum per block of 4096 rows
@@ -183,6 +185,7 @@ struct Scratch {
       if (pfStatus) (void)hipFree(pfStatus);
       if (pfRec) (void)hipFree(pfRec);
       if (pfTickets) (void)hipFree(pfTickets);
+      if (pairCtr) (void)hipFree(pairCtr);
       if (findRow) (void)hipFree(findRow);
       if (pfStats) (void)hipFree(pfStats);
       if (prof) (void)hipFree(prof);

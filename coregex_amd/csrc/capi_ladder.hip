@@ -42,6 +42,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.pf_status = nullptr; a.pf_ticket = nullptr; a.pf_ncounters = 0;   // (set per launch by the fields programs' branch below)
+  a.pair_ctr = nullptr; a.pair_seq = 0; a.pair_nctr = 0;
   std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
   a.cc_nr = a.cc_neg = a.cc_pairs = 0; std::memset(a.cc_lo, 0, 4); std::memset(a.cc_hi, 0, 4);
   a.u32_rows = t_u32Rows ? 1u : 0u;
@@ -139,6 +140,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   // while it serves the program's input
   bool fsmDirect = fsmLeanOk && p->fsmNoDirect[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0;
   bool fsmDirectRan = false, fsmDirectTables = false;
+  // literal sets: the pair kernel (scan_teddy_pair.hip, round 6) for the spans of a plain call — FindAll's n lives in the grouped kernels'
+  // look-back, and match-dense input (a row buffer overflowed before) or a fallback flag of the pair kernel itself stay on the wave kernel
+  static const bool pairOk = getenv("CXG_NO_TEDDY_PAIR") == nullptr;
+  if (gen == 7 && pairOk && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
   // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:
@@ -157,6 +162,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
+  if (gen == 12) a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = (gen == 10 && fsmMode >= 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, modes 2 and 3: one tile, 1 024 / 2 048 rows
@@ -244,6 +250,18 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     le = cxgdev::launch_scan_charclass_wave(b, stream);
   }
   else if (gen == 7) le = cxgdev::launch_scan_teddy_wave(a, 0, stream);
+  else if (gen == 12) {                                             // one workgroup per CU, groups claimed (scan_teddy_pair.hip)
+    static int cus = 0;
+    if (cus == 0) { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus = n > 0 ? n : 256; }
+    if (!s.pairCtr) {
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.pairCtr), 2 * 8 * cxgdev::kPairCtrStride * sizeof(uint32_t)));
+      HIP_TRY(hipMemsetAsync(s.pairCtr, 0, 2 * 8 * cxgdev::kPairCtrStride * sizeof(uint32_t), stream));
+      s.pairSeq = 0;
+    }
+    a.pair_ctr = s.pairCtr; a.pair_seq = ++s.pairSeq;
+    a.pair_nctr = a.static_groups ? 8u : 1u;                        // (tickets forced, or the mode demoted after a look-back watchdog hit: one counter, strict ticket order)
+    le = cxgdev::launch_scan_teddy_pair(a, static_cast<uint32_t>(a.ngroups < static_cast<uint64_t>(cus) ? a.ngroups : static_cast<uint64_t>(cus)), stream);
+  }
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)
     const uint8_t* hb = submatch ? p->subBlob.data() : p->blob.data();
     le = cxgdev::launch_scan_teddy_wave(a, reinterpret_cast<const cxgdev::TeddyAux*>(hb + h->aux_off)->dfa_states, stream);
@@ -366,7 +384,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     default: return fail(CXG_E_INTERNAL, "unknown program kind");
   }
   if (le != hipSuccess) return failHip(le, "kernel launch");
-  const uint32_t kernelId = static_cast<uint32_t>(gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : (gen == 10 && fsmDirectRan) ? (fsmDirectTables ? CXG_K_FSM_DIRECT : CXG_K_FSM_LEAN) : gen >= 6 ? gen
+  const uint32_t kernelId = static_cast<uint32_t>(gen == 12 ? CXG_K_TEDDY_PAIR : gen == 11 ? CXG_K_DELIM_WAVE : trioKernel ? (persKernel ? CXG_K_TRIO_PERS : CXG_K_TRIO_WAVE) : litKernel ? CXG_K_LITERAL_PERS : persKernel ? CXG_K_FIELDS_PERS : fieldsKernel ? CXG_K_FIELDS_WAVE : (gen == 10 && fsmDirectRan) ? (fsmDirectTables ? CXG_K_FSM_DIRECT : CXG_K_FSM_LEAN) : gen >= 6 ? gen
                                                   : h->kind == cxgdev::kKindDigit ? (gen == 1 ? CXG_K_DFA_TABLE : CXG_K_DIGIT_FLAT)
                                                   : h->kind == cxgdev::kKindBidir ? CXG_K_DFA_TABLE : h->kind == cxgdev::kKindTeddy ? CXG_K_TEDDY_TABLE : CXG_K_CHARCLASS_TABLE);
   if (nladder < sizeof ladder) ladder[nladder] = static_cast<uint8_t>(kernelId);
@@ -516,6 +534,12 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       }
       relaunches++;
       continue;
+    }
+    if (gen == 12) {                                                // the pair kernel's budgets: the wave kernel (three-byte fingerprint, its own dense mode) for this program from now on
+      if (verbose) fprintf(stderr, "[cxg] pair kernel raised the fallback flag (reason bits 0x%x): rerunning on scan_teddy_wave.hip\n", err >> 8);
+      p->noPair[submatch ? 1 : 0].store(1, std::memory_order_relaxed);
+      lastReason = err >> 8;
+      relaunches++; gen = 7; continue;
     }
     if ((gen == 6 || gen == 7 || gen == 9) && (err >> 8) == 0x10u && !denseChain && !(h->flags & cxgdev::kFlagChainBounded)) {   // only the row buffers overflowed: same kernel, two tiles per wave
       if (verbose) fprintf(stderr, "[cxg] wave kernel: row buffers overflowed (match-dense input), rerunning with %d tiles per wave\n", cxgdev::kDenseTilesPerWave);

@@ -21,6 +21,11 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerWave = CXG_TPW;
 constexpr int kDenseTilesPerWave = 2;          // chain kernel on match-dense input: 256 rows of buffer per wave-tile instead of 64
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
+// scan_teddy_pair.hip: one workgroup of 16 waves per CU (its pair table takes 64 KiB of LDS), groups of 16 x 4 wave-tiles = 240 KiB
+constexpr int kPairWaves = 16;
+constexpr int kPairTilesPerWave = 4;
+constexpr uint32_t kPairCtrStride = 32;       // uint32 between two group counters (128 bytes)
+constexpr uint64_t kPairGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairTilesPerWave;
 #ifndef CXG_CC_TILES
 #define CXG_CC_TILES 4
 #endif
@@ -97,6 +102,8 @@ struct ScanArgs {
   uint32_t plan_shape;  // wave_common.hpp plan_shape(plan); 0: the generic range tests
   uint32_t cc_nr, cc_neg, cc_pairs;   // scan_charclass_wave.hip: walk.hpp CharClassAux copied by the host (kernel arguments: no dependent
   uint8_t cc_lo[4], cc_hi[4];         // loads from the program image before the first window can be requested)
+  uint32_t* pair_ctr;   // scan_teddy_pair.hip: [2][8] group counters, kPairCtrStride words apart; set pair_seq & 1 is this launch's, the kernel zeroes the other
+  uint32_t pair_seq, pair_nctr;   // pair_nctr: 8 (workgroup b claims from counter b & 7 first), or 1: strict ticket order (after a watchdog hit)
   uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };
 

@@ -1,0 +1,500 @@
+// scan_teddy_pair.hip — FindAll for UseTeddy (exact literal alternation, <= 64 prefix-free literals of >= 3 bytes), third
+// generation (round 6): the fingerprint is looked up per byte PAIR, on a persistent grid of one 16-wave workgroup per CU.
+//
+// Reference semantics kept (meta/find_indices.go:925-951 -> prefilter.Teddy.FindMatch, prefilter/teddy.go:391-444,
+// verifyBucket :532-550; FindAll advance meta/findall.go:267-275): the next match is at the first fingerprint candidate at or
+// after `pos` at which a literal of a hit bucket compares equal; the search resumes at its end.  Any superset of the true
+// match starts is a valid candidate set — candidates are verified exactly, in the bucket / id order of scan_teddy_wave.hip.
+//
+// Why pairs.  scan_teddy_wave.hip pays four instructions per haystack byte for its filter (address, LDS lookup, two SDWA
+// ANDs) and 1.4 more to gather the flags into bits: 350 of a wave-tile's 750 instructions, and the kernel is bound by
+// instruction issue.  Here one LDS lookup serves TWO bytes: a table of 65 536 one-byte entries, indexed
+// by the 16 bits of an aligned byte pair (b0 | b1 << 8), says everything a literal start at either byte of the pair or at
+// the four bytes in front of it needs to know about the pair:
+//   bit 0 AB  (b0, b1) are bytes 0, 1 of a literal          bit 1 A2  b1 is byte 0 of a literal
+//   bit 2 CD  (b0, b1) are bytes 2, 3 of a literal          bit 3 BC  (b0, b1) are bytes 1, 2 of a literal
+//   bit 4 E1  b0 is byte 4 of a literal                     bit 5 DE  (b0, b1) are bytes 3, 4 of a literal
+//   bit 6 S1  b0 is outside the literals' alphabet          bit 7 S2  b1 is outside it
+// (a literal shorter than the byte asked for: every value qualifies).  With W_k the entry of pair k, a literal can start
+//   at the pair's first byte  iff  AB(W_k) & CD(W_k+1) & E1(W_k+2),   at its second byte  iff  A2(W_k) & BC(W_k+1) & DE(W_k+2):
+// both at once as W_k & (W_k+1 >> 2) & (W_k+2 >> 4) & 3 — on four pairs per instruction, because the entries of four pairs
+// sit in the bytes of one register.  A five-byte fingerprint of exact pairs: on BASELINE config 3 (16 literals) 20.6
+// candidates per 3 840-byte tile against 15.8 matches (the three-byte, eight-bucket fingerprint of scan_teddy_wave.hip: 21.8).
+// Per 64 bytes of a lane: 32 lookups + 32 index extractions + 24 packs, then 5 instructions per 8 bytes to combine and
+// 2 v_dot4 per 8 bytes to make the candidate and synchronising bits dense — ~190 instead of ~420.
+//
+// The table is 64 KiB of LDS, so a CU holds ONE workgroup: 16 waves, and the grid is persistent — groups of 64 wave-tiles
+// (240 KiB of haystack) are CLAIMED through one atomic counter, two tickets ahead.  A workgroup that holds group g only ever
+// waits for groups < g, which are held by running workgroups: forward progress does not depend on co-residency or on the
+// order of dispatch.  The table is built once per workgroup.  The rows of a group are ordered
+// with the decoupled look-back of block_common.hpp, deferred by one group: a group's count is published when its tiles are
+// done, its base is resolved (wave 0, the status loads issued a group earlier) and its rows are written while the next
+// group's windows are in flight — nobody waits for the look-back.
+//
+// Window, ownership (synchronising bytes), candidate ranking, verification and FindAll order are those of
+// scan_teddy_wave.hip; the verifier reads the candidate's bytes from global memory (L2 hits: the window was just loaded)
+// instead of an LDS copy of the window.
+// Fallback flag (err bit 8; capi_ladder.hip reruns the call on scan_teddy_wave.hip): no synchronising byte in a halo,
+// > 192 owned candidates in a wave-tile, row buffer overflow, an assertion that needs a byte behind the window.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "block_common.hpp"
+#include "scan_dfa.h"
+#include "walk.hpp"
+#include "wave_common.hpp"
+
+namespace cxgdev {
+
+namespace {
+
+constexpr int kPWaves = kPairWaves;               // 16
+constexpr int kPThreads = kPWaves * 64;           // 1024
+constexpr int kPTpw = kPairTilesPerWave;          // 4: 64 wave-tiles per group (the prefix over a group's tiles is one wave wide)
+constexpr int kPRows = 192;                       // rows buffered per wave per group
+constexpr int kPCands = 192;                      // owned candidates listed per wave-tile
+constexpr int kPAuxMax = 2048;
+constexpr int32_t kPFar = 1 << 20;
+constexpr int kPWin = kWaveTile + kWaveHalo;      // 4096
+static_assert(kPWaves * kPTpw == 64, "the group prefix is one wave wide");
+
+struct PairWaveLds {
+  uint32_t w[512];                                // pair entries of the window: piece p (16 bytes) -> dwords 2p, 2p + 1
+  uint16_t cpos[kPCands];
+  uint16_t rs[2][kPRows], re[2][kPRows];          // rows of this group and of the group before it
+  uint16_t ce[64];
+  uint8_t em[64];
+};
+struct PairLds {
+  uint8_t tab[65536];                             // at LDS address 0: the pair is the address
+  uint32_t T[256];                                // scan_teddy_wave.hip's table: A | B << 8 | C << 16 | sync << 24 (verification, ownership)
+  __attribute__((aligned(16))) uint8_t aux[kPAuxMax];
+  uint32_t lit[32][6];
+  __attribute__((aligned(16))) uint8_t F[256];
+  __attribute__((aligned(16))) uint8_t G[256];
+  uint8_t boff[16];
+  uint64_t base[2];
+  uint32_t gq[4];                                 // ring of claimed groups (three in use)
+  uint32_t tot[2];
+  uint32_t cnt[2][kPWaves][kPTpw];
+  uint32_t qbase[2][kPWaves * kPTpw + 1];
+  PairWaveLds wv[kPWaves];
+};
+static_assert(sizeof(PairLds) <= 160 * 1024, "LDS");
+
+// LDS address of the entry of the pair (b0, b1): (b0 | b1 << 8) ^ (b1 << 2).  The plain index puts a pair on bank (b0 >> 2) & 31
+// whatever b1 is — text whose pairs begin with a digit or a lower-case letter would use 3 + 7 of the 32 banks; the XOR spreads
+// them by b1 as well.  A bijection of the 16 bits (b1 keeps its bits 6, 7; b0 is XORed with a function of b1).
+__host__ __device__ constexpr uint32_t pair_addr(uint32_t b0, uint32_t b1) { return ((b0 | (b1 << 8)) ^ (b1 << 2)) & 0xFFFFu; }
+// ... of the low / high pair of a dword: two SDWA operations each (shift of byte 1 / 3, XOR with word 0 / 1)
+#define CXG_PAIR_ADDR(dst, x, BYTE, WORD) \
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #BYTE "\n\t" \
+      "v_xor_b32_sdwa %0, %0, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #WORD : "=&v"(dst) : "v"(two), "v"(x))
+
+// status word of the look-back (block_common.hpp): wave 0
+__device__ __forceinline__ uint64_t pair_status_load(const uint64_t* status, int64_t idx, uint64_t etag) {
+  return idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (kFlagInclusive | etag);
+}
+// exclusive base of `group` (> 0) from the words in front of it; w = the words of groups group-1-lane, loaded earlier
+__device__ __forceinline__ uint64_t pair_resolve(const uint64_t* status, uint32_t* err, uint64_t group, uint64_t w, uint64_t etag, int lane) {
+  uint64_t base = 0;
+  int64_t look = static_cast<int64_t>(group) - 1;
+  uint32_t spins = 0;
+  for (;;) {
+    const bool ready = (w & kFlagMask) != 0 && (w & kEpochMask) == etag;
+    if (!__all(ready)) {
+      if (++spins > kSpinLimit) { if (lane == 0) raise_watchdog(err, kWdLookback); break; }
+      __builtin_amdgcn_s_sleep(2);
+      w = pair_status_load(status, look - lane, etag);
+      continue;
+    }
+    const unsigned long long incl_mask = __ballot((w & kFlagMask) == kFlagInclusive);
+    const int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
+    uint64_t v = (lane <= first_incl) ? (w & kValueMask) : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    base += v;
+    if (first_incl < 64) break;
+    look -= 64;
+    w = pair_status_load(status, look - lane, etag);
+  }
+  return base;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
+  __shared__ PairLds S;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = lane0;
+  PairWaveLds& L = S.wv[wave];
+  const uint64_t etag = static_cast<uint64_t>(a.epoch) << kEpochShift;
+
+  // ---- once per workgroup: claim two groups, the literal tables, the pair table
+  // Groups are claimed from pair_nctr counters: counter x hands out groups x, x + nctr, ..; workgroup b asks counter b & (nctr - 1) and,
+  // once that is exhausted, the others in turn.  (One counter serves ~20 returning atomics per microsecond: a GiB has 4 370 groups.)
+  const uint32_t nctr = a.pair_nctr, cls = blockIdx.x & (nctr - 1u);
+  const uint32_t ngroups32 = static_cast<uint32_t>(a.ngroups);
+  uint32_t* const ctr = a.pair_ctr + (a.pair_seq & 1u) * (8u * kPairCtrStride);
+  if (blockIdx.x == 0 && tid < 8) a.pair_ctr[((a.pair_seq + 1u) & 1u) * (8u * kPairCtrStride) + static_cast<uint32_t>(tid) * kPairCtrStride] = 0u;   // the next launch's set
+  auto draw = [&]() -> uint32_t { return __hip_atomic_fetch_add(ctr + cls * kPairCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto claimed = [&](uint32_t t) -> uint32_t {                      // ticket of the own counter -> group; 0xFFFFFFFF: no group left anywhere
+    uint32_t g = t * nctr + cls;
+    for (uint32_t k = 1; g >= ngroups32 && k < nctr; k++) {
+      const uint32_t x = (cls + k) & (nctr - 1u);
+      g = __hip_atomic_fetch_add(ctr + x * kPairCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * nctr + x;
+    }
+    return g < ngroups32 ? g : 0xFFFFFFFFu;
+  };
+  uint32_t t0 = 0, t1 = 0;
+  if (tid == 0) { t0 = draw(); t1 = draw(); }                     // (consumed behind the table build)
+  const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
+  for (uint32_t i = tid; i < h->aux_len / 4 && i < kPAuxMax / 4; i += kPThreads)
+    reinterpret_cast<uint32_t*>(S.aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
+  __syncthreads();
+  const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(S.aux);
+  const uint16_t* t_ab = reinterpret_cast<const uint16_t*>(S.aux + ax->ab_off);
+  const uint8_t* t_order = S.aux + ax->order_off;
+  const uint8_t* t_lens = S.aux + ax->lens_off;
+  const uint8_t* t_bucket = S.aux + ax->bucket_off;
+  const uint16_t* t_off = reinterpret_cast<const uint16_t*>(S.aux + ax->off_off);
+  const uint8_t* t_bytes = S.aux + ax->bytes_off;
+  const uint32_t nlits = ax->nlits;
+  const uint32_t look_pre = ax->looks & 0xFFu, look_post = (ax->looks >> 8) & 0xFFu;
+  const bool fold = (ax->looks & kTeddyFold) != 0u;
+  auto same = [&](uint32_t b, uint32_t c) { return b == c || (fold && c >= 'a' && c <= 'z' && (b | 0x20u) == c); };   // byte b stands for literal byte c
+  if (tid < 256) {
+    const uint32_t b = static_cast<uint32_t>(tid);
+    const uint32_t sync = ((a.blob + h->info_off)[tid] & kInfoSync) ? 1u : 0u;
+    S.T[tid] = static_cast<uint32_t>(t_ab[tid]) | (sync ? 0x1000000u : 0u);
+    uint32_t f = sync << 6, g = sync << 7;
+    for (uint32_t id = 0; id < nlits; id++) {
+      const uint8_t* lb = t_bytes + t_off[id];
+      const uint32_t len = t_lens[id];
+      if (same(b, lb[0])) g |= 2u;                                  // A2
+      if (len == 3u) { if (same(b, lb[2])) f |= 4u; f |= 0x30u; }   // CD with any second byte; E1 and DE: nothing to ask
+      else if (len == 4u) { if (same(b, lb[3])) f |= 0x20u; f |= 0x10u; }   // DE with any second byte; E1: nothing to ask
+      else if (same(b, lb[4])) f |= 0x10u;                          // E1
+    }
+    S.F[tid] = static_cast<uint8_t>(f);
+    S.G[tid] = static_cast<uint8_t>(g);
+  }
+  __syncthreads();
+  {                                                                 // entry(b0, b1) = F[b0] | G[b1] at pair_addr(b0, b1); thread t: b1 = t >> 2, b0 = (t & 3) * 64 ..
+    const uint32_t b1 = static_cast<uint32_t>(tid) >> 2;
+    const uint32_t g4 = static_cast<uint32_t>(S.G[b1]) * 0x01010101u;
+    const uint32_t* f1 = reinterpret_cast<const uint32_t*>(S.F) + (tid & 3) * 16;
+    uint32_t* row = reinterpret_cast<uint32_t*>(S.tab) + ((b1 ^ (b1 >> 6)) << 6);   // the swizzle moves whole dwords inside a row of 256 entries
+#pragma unroll
+    for (uint32_t q = 0; q < 16; q++) row[(((tid & 3) * 16u) + q) ^ (b1 & 63u)] = f1[q] | g4;
+  }
+  if (static_cast<uint32_t>(tid) < nlits) {                          // third-byte masks of T (scan_teddy_wave.hip)
+    const uint32_t b3 = t_bytes[t_off[tid] + 2];
+    atomicOr(&S.T[b3], 0x10000u << t_bucket[tid]);
+    if (fold && b3 >= 'a' && b3 <= 'z') atomicOr(&S.T[b3 ^ 0x20u], 0x10000u << t_bucket[tid]);
+  }
+  if (static_cast<uint32_t>(tid) < nlits && tid < 32) {             // verification compares dwords
+    const uint8_t* lb = t_bytes + t_off[tid];
+    const uint32_t len = t_lens[tid];
+    for (uint32_t k = 0; k < 3; k++) {
+      uint32_t Lw = 0, M = 0;
+      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) {
+        const uint32_t c = lb[4 * k + b];
+        Lw |= c << (8 * b);
+        M |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);
+      }
+      S.lit[tid][k] = Lw; S.lit[tid][3 + k] = M;
+    }
+  }
+  if (tid < 16) {
+    uint32_t first = nlits;
+    for (uint32_t k = nlits; k-- > 0;) if (t_bucket[t_order[k]] >= static_cast<uint32_t>(tid)) first = k;
+    S.boff[tid] = static_cast<uint8_t>(first);
+  }
+  __syncthreads();
+  if (static_cast<uint32_t>(tid) < nlits) {                          // the exact pairs: AB (bit 0), BC (3), CD (2), DE (5)
+    const uint8_t* lb = t_bytes + t_off[tid];
+    const uint32_t len = t_lens[tid];
+    uint32_t* tab32 = reinterpret_cast<uint32_t*>(S.tab);
+    for (uint32_t k = 0; k < 4u && k + 1u < len; k++) {
+      const uint32_t bit = k == 0u ? 1u : k == 1u ? 8u : k == 2u ? 4u : 0x20u;
+      const uint32_t c0 = lb[k], c1 = lb[k + 1];
+      const uint32_t n0 = (fold && c0 >= 'a' && c0 <= 'z') ? 2u : 1u, n1 = (fold && c1 >= 'a' && c1 <= 'z') ? 2u : 1u;
+      for (uint32_t i0 = 0; i0 < n0; i0++)
+        for (uint32_t i1 = 0; i1 < n1; i1++) {
+          const uint32_t idx = pair_addr(c0 ^ (i0 ? 0x20u : 0u), c1 ^ (i1 ? 0x20u : 0u));
+          atomicOr(&tab32[idx >> 2], bit << (8u * (idx & 3u)));
+        }
+    }
+  }
+  if (tid == 0) { const uint32_t g0 = claimed(t0); S.gq[0] = g0; S.gq[1] = g0 == 0xFFFFFFFFu ? g0 : claimed(t1); }
+  __syncthreads();
+
+  const uint64_t ngroups = a.ngroups;
+  uint32_t fallback = 0, edge_hit = 0;
+
+  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead — across groups too
+  u32x4 x[4];
+  uint32_t xprev = 0;
+  __amdgpu_buffer_rsrc_t rsrc_n;
+  int pre_n = 0;
+  auto issue_loads = [&](uint64_t g, int jj) {
+    const uint64_t wtn = g * (kPWaves * kPTpw) + static_cast<uint64_t>(jj) * kPWaves + wave;
+    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
+    int nrec = 0;
+    if (g < ngroups && lo < a.len) {
+      const uint64_t rem = a.len - lo;
+      nrec = rem >= static_cast<uint64_t>(kPWin) ? kPWin : static_cast<int>((rem + 3) & ~3ull);
+    }
+    const int pre = (nrec && lo) ? 16 : 0;
+    rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
+    pre_n = pre;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (lane + 64 * k) << 4, pre, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, 0, pre ? 12 : nrec + pre, 0);
+  };
+  issue_loads(S.gq[0], 0);
+
+  uint64_t prev = ~0ull;                                            // the group whose rows wait to be written
+  for (uint32_t it = 0;; it++) {
+    const uint32_t b = it & 1u;
+    const uint64_t group = S.gq[it % 3u];
+    const uint64_t next_group = S.gq[(it + 1u) % 3u];
+    const bool live = group < ngroups;
+    uint32_t n2 = 0;
+    uint64_t lw = 0;
+    if (wave == kPWaves - 1 && live && lane0 == 0) n2 = draw();      // the group after next: the ticket is read in front of the barrier
+    if (wave == 0) {
+      if (prev != ~0ull && prev > 0) lw = pair_status_load(a.status, static_cast<int64_t>(prev) - 1 - lane0, etag);   // look-back of the group before: words requested now, read behind the tiles
+    }
+    uint32_t nrows_w = 0;                                           // wave-uniform
+    if (live) for (int j = 0; j < kPTpw; j++) {
+      lane = lane0;
+      asm volatile("" : "+v"(lane));                                // (scan_chain_wave.hip: no hoisted-and-spilled lane constants)
+      const uint64_t wt = group * (kPWaves * kPTpw) + static_cast<uint64_t>(j) * kPWaves + wave;
+      const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
+      uint32_t emitted_here = 0;
+      if (tile_lo < a.len) {
+        const uint64_t remaining = a.len - tile_lo;
+        const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+        const int32_t stage = rend < kPWin ? rend : kPWin;
+
+        const uint32_t two = 2u;
+        // ---- A: one lookup per byte pair, the entries of a piece's eight pairs in two registers, transposed through LDS
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32x4 v = x[k];
+          uint32_t i0, i1, i2, i3, i4, i5, i6, i7;
+          CXG_PAIR_ADDR(i0, v.x, 1, 0); CXG_PAIR_ADDR(i1, v.x, 3, 1); CXG_PAIR_ADDR(i2, v.y, 1, 0); CXG_PAIR_ADDR(i3, v.y, 3, 1);
+          CXG_PAIR_ADDR(i4, v.z, 1, 0); CXG_PAIR_ADDR(i5, v.z, 3, 1); CXG_PAIR_ADDR(i6, v.w, 1, 0); CXG_PAIR_ADDR(i7, v.w, 3, 1);
+          const uint32_t e0 = S.tab[i0], e1 = S.tab[i1], e2 = S.tab[i2], e3 = S.tab[i3], e4 = S.tab[i4], e5 = S.tab[i5], e6 = S.tab[i6], e7 = S.tab[i7];
+          uint2 o;
+          o.x = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+          o.y = e4 | (e5 << 8) | (e6 << 16) | (e7 << 24);
+          *reinterpret_cast<uint2*>(&L.w[2 * (lane + 64 * k)]) = o;
+        }
+        const uint32_t xprev_cur = xprev;
+        const __amdgpu_buffer_rsrc_t rsrc = rsrc_n;
+        const int pre = pre_n;
+        if (j + 1 < kPTpw) issue_loads(group, j + 1); else issue_loads(next_group, 0);   // x[] is free from here on
+        wave_lds_sync();
+        uint32_t W[9];
+        {
+          const u32x4 wa = *reinterpret_cast<const u32x4*>(&L.w[8 * lane]);
+          const u32x4 wb = *reinterpret_cast<const u32x4*>(&L.w[8 * lane + 4]);
+          W[0] = wa.x; W[1] = wa.y; W[2] = wa.z; W[3] = wa.w; W[4] = wb.x; W[5] = wb.y; W[6] = wb.z; W[7] = wb.w;
+          W[8] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(W[0]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));   // lane 63: nothing behind the window
+        }
+        uint32_t cd[8], zd[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const uint32_t a1 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 10);   // entry of the next pair >> 2
+          const uint32_t a2 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 20);   // entry of the pair behind it >> 4
+          cd[q] = __builtin_amdgcn_udot4(W[q] & a1 & a2 & 0x03030303u, 0x40100401u, 0u, false);   // eight bits: the dword's eight byte positions
+          zd[q] = __builtin_amdgcn_udot4(W[q] & 0xC0C0C0C0u, 0x40100401u, 0u, false);             // the same for S1 / S2, << 6
+        }
+        const uint64_t C = (static_cast<uint64_t>(cd[4] | (cd[5] << 8) | (cd[6] << 16) | (cd[7] << 24)) << 32) | (cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24));
+        uint64_t Z = (static_cast<uint64_t>(((zd[4] | (zd[5] << 8)) >> 6) | (((zd[6] | (zd[7] << 8)) >> 6) << 16)) << 32) |
+                     (((zd[0] | (zd[1] << 8)) >> 6) | (((zd[2] | (zd[3] << 8)) >> 6) << 16));
+        if (stage != kPWin) {                                        // short last window: bytes past the data read as 0
+          const int32_t nv = stage - 64 * lane;
+          Z &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+        }
+
+        // ---- O: ownership bounds (scan_teddy_wave.hip)
+        int32_t zA = -1, zB = kPFar;
+        if (tile_lo > 0) {
+          const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
+          if (!(S.T[pb] & 0x1000000u)) {                              // the segment at the tile's first byte began earlier
+            const unsigned long long bz = __ballot(Z != 0ull);
+            if (bz) {
+              const int Lz = __builtin_ctzll(bz);
+              zA = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, Lz)));
+              if (Lz >= 16) fallback |= 1;                            // (the same budget as scan_teddy_wave.hip: a synchronising byte in the first KiB)
+            }
+            else zA = kPFar;
+          }
+        }
+        {
+          const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kPWin - 1);
+          const unsigned long long bzb = __ballot(Zb != 0ull);
+          if (bzb) { const int Lz = __builtin_ctzll(bzb); zB = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, Lz))); }
+          else if (stage != rend) { zB = -2; fallback |= 1; }
+        }
+        const uint64_t Co = C & word_range(lane, zA + 1, zB);
+
+        // ---- V: list the owned candidates, verify 64 at a time
+        const uint32_t nc_lane = static_cast<uint32_t>(__popcll(Co));
+        const uint32_t incl = wave_inclusive_sum(nc_lane);
+        uint32_t ncand = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+        if (ncand > static_cast<uint32_t>(kPCands)) { fallback |= 8; ncand = kPCands; }
+        if (ncand) {
+          uint32_t idx = incl - nc_lane;
+          uint64_t cb = Co;
+          while (cb) {
+            const int bit = __builtin_ctzll(cb);
+            cb &= cb - 1;
+            if (idx < static_cast<uint32_t>(kPCands)) L.cpos[idx] = static_cast<uint16_t>(64 * lane + bit);
+            idx++;
+          }
+          wave_lds_sync();
+          auto wbyte = [&](int32_t i) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b8(rsrc, i + pre, 0, 0); };   // window byte i (0 past the data)
+          int32_t cur_end = -1;                                       // wave-uniform: end of the last emitted match
+          for (uint32_t r0 = 0; r0 < ncand; r0 += 64) {
+            int32_t c = 0, mlen = 0;
+            if (r0 + static_cast<uint32_t>(lane) < ncand) {
+              c = L.cpos[r0 + lane];
+              // the 12 bytes at the candidate as three dwords: one 16-byte load at the dword in front of it + v_alignbit
+              const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c & ~3) + pre, 0, 0);
+              const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
+              const uint32_t w0 = __builtin_amdgcn_alignbit(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbit(d.z, d.y, sh), w2 = __builtin_amdgcn_alignbit(d.w, d.z, sh);
+              uint32_t mask = (S.T[w0 & 0xFFu] & 0xFFu) & ((S.T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((S.T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
+              while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
+                const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
+                mask &= mask - 1;
+                for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
+                  const uint32_t id = t_order[k];
+                  const int32_t len = t_lens[id];
+                  if (c + len > rend) continue;
+                  if (id < 32u) {
+                    const uint32_t diff = ((w0 ^ S.lit[id][0]) & S.lit[id][3]) | ((w1 ^ S.lit[id][1]) & S.lit[id][4]) | ((w2 ^ S.lit[id][2]) & S.lit[id][5]);
+                    if (diff != 0u) continue;
+                    if (len <= 12) { mlen = len; continue; }
+                  }
+                  const uint8_t* lit = t_bytes + t_off[id];
+                  int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
+                  while (q < len && same(wbyte(c + q), lit[q])) q++;
+                  if (q == len) mlen = len;
+                }
+              }
+              if (mlen && (look_pre | look_post) != 0u) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
+                const int pbv = c > 0 ? static_cast<int>(wbyte(c - 1)) : (tile_lo > 0 ? static_cast<int>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1);
+                const int nb = c + mlen < rend ? (c + mlen < kPWin ? static_cast<int>(wbyte(c + mlen)) : -2) : -1;
+                if (nb == -2) { edge_hit = 1; mlen = 0; }               // the byte behind the occurrence lies behind the window: hand the scan over
+                else if (!teddy_look_holds(look_pre, pbv, static_cast<int>(w0 & 0xFFu)) || !teddy_look_holds(look_post, static_cast<int>(wbyte(c + mlen - 1)), nb)) mlen = 0;
+              }
+            }
+            // ---- D: FindAll order inside the round (candidates ascend with the lane)
+            const int32_t e = mlen ? c + mlen : 0;
+            int32_t pmax = e;                                         // inclusive prefix max of the ends
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const int32_t o = __shfl_up(pmax, d, 64);
+              if (lane >= d && o > pmax) pmax = o;
+            }
+            int32_t before = static_cast<int32_t>(dpp_from_lower(static_cast<uint32_t>(pmax)));
+            if (lane == 0) before = 0;
+            if (cur_end > before) before = cur_end;
+            uint32_t emit = mlen ? 1u : 0u;
+            if (__ballot(mlen && c < before) != 0ull) {               // some verified candidate lies inside an earlier match
+              L.ce[lane] = static_cast<uint16_t>(e);
+              wave_lds_sync();
+              if (lane == 0) {
+                int32_t ce = cur_end;
+                for (uint32_t k = 0; k < 64; k++) {                   // all 64: lanes past ncand hold e = 0 and must read em = 0
+                  const int32_t ek = L.ce[k];
+                  uint8_t em = 0;
+                  if (ek && static_cast<int32_t>(L.cpos[r0 + k]) >= ce) { em = 1; ce = ek; }
+                  L.em[k] = em;
+                }
+              }
+              wave_lds_sync();
+              emit = L.em[lane];
+            }
+            const unsigned long long em_mask = __ballot(emit != 0);
+            if (em_mask) {
+              const int last = 63 - __builtin_clzll(em_mask);
+              cur_end = __builtin_amdgcn_readlane(e, last);
+              const uint32_t n_em = static_cast<uint32_t>(__popcll(em_mask));
+              if (emit) {
+                const uint32_t r = nrows_w + emitted_here + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
+                if (r < static_cast<uint32_t>(kPRows)) { L.rs[b][r] = static_cast<uint16_t>(c); L.re[b][r] = static_cast<uint16_t>(e); }
+              }
+              emitted_here += n_em;
+            }
+          }
+        }
+      }
+      if (lane == 0) S.cnt[b][wave][j] = emitted_here;
+      nrows_w += emitted_here;
+    }
+    if (nrows_w > static_cast<uint32_t>(kPRows)) fallback |= 16;
+
+    // ---- the group before: its base (wave 0), then — behind the barrier — its rows; this group: its count
+    if (wave == 0) {
+      if (prev != ~0ull) {
+        const uint64_t base = prev > 0 ? pair_resolve(a.status, a.err, prev, lw, etag, lane0) : 0ull;
+        if (lane0 == 0) {
+          const uint64_t incl = base + S.tot[b ^ 1u];
+          if (prev > 0) __hip_atomic_store(a.status + prev, kFlagInclusive | etag | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          S.base[b ^ 1u] = base;
+          if (prev == ngroups - 1) *a.total = incl;
+        }
+      }
+    }
+    if (wave == kPWaves - 1 && live && lane0 == 0) S.gq[(it + 2u) % 3u] = claimed(n2);
+    __syncthreads();
+    if (live && wave == 0) {                                        // exclusive prefix over the group's wave-tiles q = j * 16 + wave; publish the count
+      const int q = lane0;
+      const uint32_t v = S.cnt[b][q % kPWaves][q / kPWaves];
+      const uint32_t incl = wave_inclusive_sum(v);
+      S.qbase[b][q] = incl - v;
+      if (q == 63) {
+        S.qbase[b][64] = incl;
+        S.tot[b] = incl;
+        __hip_atomic_store(a.status + group, (group == 0 ? kFlagInclusive : kFlagAggregate) | etag | static_cast<uint64_t>(incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (prev != ~0ull && a.out != nullptr) {                        // rows of the group before (buffers b ^ 1)
+      const uint32_t pbuf = b ^ 1u;
+      const uint64_t base = S.base[pbuf];
+      const int64_t origin = a.base + static_cast<int64_t>(prev * static_cast<uint64_t>(kWaveTile) * kPWaves * kPTpw);
+      uint32_t start = 0;
+      for (int j = 0; j < kPTpw; j++) {
+        const uint32_t n = S.cnt[pbuf][wave][j];
+        const uint64_t dst = base + S.qbase[pbuf][j * kPWaves + wave];
+        for (uint32_t i = lane0; i < n; i += 64) {
+          const uint32_t r = start + i;
+          if (r < static_cast<uint32_t>(kPRows) && dst + i < a.cap) {
+            const int64_t tb = origin + static_cast<int64_t>(j * kPWaves + wave) * kWaveTile;
+            store_pair_nt(a.out + (dst + i) * a.row_width, tb + L.rs[pbuf][r], tb + L.re[pbuf][r]);
+          }
+        }
+        start += n;
+      }
+    }
+    if (!live) break;
+    prev = group;
+  }
+  if (__ballot(edge_hit != 0) != 0ull) fallback |= 32;
+  if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
+}
+
+hipError_t launch_scan_teddy_pair(const ScanArgs& a, uint32_t workgroups, hipStream_t stream) {
+  const dim3 grid(workgroups), block(kPThreads);
+  hipLaunchKernelGGL(k_scan_teddy_pair, grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace cxgdev

@@ -64,6 +64,7 @@ struct cxg_program {
   std::vector<uint8_t> subBlob;  // kKindBidir image
   std::vector<uint8_t> capBlob;  // cxgdev::CapHeader + arrays
   bool capHasLook = false;       // the backtracking image holds assertion states: capi_captures.hip launches the LOOK instantiation of its kernels
+  mutable std::atomic<uint8_t> noPair[2] = {{0}, {0}};       // scan_teddy_pair.hip raised its fallback flag on this program's input once: scan_teddy_wave.hip from then on
   mutable std::atomic<uint8_t> denseChain[2] = {{0}, {0}};   // [spans, submatch]: a wave kernel overflowed its row buffers on this program's
                                                               // input once: later calls start with two tiles per wave (capi_ladder.hip)
   mutable std::atomic<uint8_t> fsmMode[2] = {{0}, {0}};      // ... the transducer kernel's density mode seen necessary: 0, 1 (2 tiles per wave), 2 (1 tile)

@@ -131,7 +131,8 @@ enum cxg_kernel {
   CXG_K_LITERAL_PERS = 17, /* k_scan_fields_pers in its literal mode: border-free literals over <= 4 distinct bytes such as `error` (round 5) */
   CXG_K_TRIO_PERS = 18,    /* k_scan_fields_pers in its TRIO mode: k_scan_trio_wave's programs (spans or capture rows) on the persistent grid (round 5) */
   CXG_K_FSM_DIRECT = 19,   /* scan_fsm.hip k_scan_fsml<direct>: the transducer with byte-indexed rows — one table read per byte, no class lookup (round 6) */
-  CXG_K_FSM_LEAN = 20      /* scan_fsm.hip k_scan_fsml: shallow machines on input whose entry states collapse, without k_scan_fsm's machinery for those that do not (round 6) */
+  CXG_K_FSM_LEAN = 20,     /* scan_fsm.hip k_scan_fsml: shallow machines on input whose entry states collapse, without k_scan_fsm's machinery for those that do not (round 6) */
+  CXG_K_TEDDY_PAIR = 21    /* scan_teddy_pair.hip: literal sets with one fingerprint lookup per byte PAIR, persistent grid with claimed groups (round 6) */
 };
 const char* cxg_kernel_name(int kernel);
 
