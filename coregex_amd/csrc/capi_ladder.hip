@@ -162,7 +162,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
-  if (gen == 12) a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
+  if (gen == 12) {                                                 // look-back words per UNIT (a wave's four wave-tiles of a group): 16 per group
+    a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
+    if (a.ngroups * cxgdev::kPairWaves > s.statusCap) return fail(CXG_E_INTERNAL, "status words: more units than the allocation covers");
+  }
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = (gen == 10 && fsmMode >= 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, modes 2 and 3: one tile, 1 024 / 2 048 rows
@@ -259,7 +262,8 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       s.pairSeq = 0;
     }
     a.pair_ctr = s.pairCtr; a.pair_seq = ++s.pairSeq;
-    a.pair_nctr = a.static_groups ? 8u : 1u;                        // (tickets forced, or the mode demoted after a look-back watchdog hit: one counter, strict ticket order)
+    static const uint32_t pairNctr = getenv("CXG_PAIR_NCTR") ? static_cast<uint32_t>(atoi(getenv("CXG_PAIR_NCTR"))) : 8u;   // (A/B: 1, 2, 4 or 8 counters)
+    a.pair_nctr = a.static_groups ? ((pairNctr == 1u || pairNctr == 2u || pairNctr == 4u) ? pairNctr : 8u) : 1u;                        // (tickets forced, or the mode demoted after a look-back watchdog hit: one counter, strict ticket order)
     le = cxgdev::launch_scan_teddy_pair(a, static_cast<uint32_t>(a.ngroups < static_cast<uint64_t>(cus) ? a.ngroups : static_cast<uint64_t>(cus)), stream);
   }
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)

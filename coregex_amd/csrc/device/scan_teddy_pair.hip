@@ -54,14 +54,19 @@ constexpr int kPTpw = kPairTilesPerWave;          // 4: 64 wave-tiles per group 
 constexpr int kPRows = 192;                       // rows buffered per wave per group
 constexpr int kPCands = 192;                      // owned candidates listed per wave-tile
 constexpr int kPAuxMax = 2048;
+constexpr uint32_t kPRing = 8;
+constexpr uint32_t kPDefer = 2;                   // a unit's base is resolved and its rows are written this many units later
+#ifndef CXG_PAIR_ABL
+#define CXG_PAIR_ABL 0                    // timing experiments (scripts/build_variant.sh; WRONG rows): 1 no verification, 2 no candidate list either, 4 no table lookups, 8 no look-back / row write
+#endif
 constexpr int32_t kPFar = 1 << 20;
 constexpr int kPWin = kWaveTile + kWaveHalo;      // 4096
 static_assert(kPWaves * kPTpw == 64, "the group prefix is one wave wide");
 
 struct PairWaveLds {
   uint32_t w[512];                                // pair entries of the window: piece p (16 bytes) -> dwords 2p, 2p + 1
-  uint16_t cpos[kPCands];
-  uint16_t rs[2][kPRows], re[2][kPRows];          // rows of this group and of the group before it
+  uint16_t cpos[2][kPCands];                      // owned candidates of the tile being verified and of the tile being filtered
+  uint16_t rs[kPDefer + 1][kPRows], re[kPDefer + 1][kPRows];   // rows of this unit and of the units whose bases are not resolved yet
   uint16_t ce[64];
   uint8_t em[64];
 };
@@ -73,11 +78,9 @@ struct PairLds {
   __attribute__((aligned(16))) uint8_t F[256];
   __attribute__((aligned(16))) uint8_t G[256];
   uint8_t boff[16];
-  uint64_t base[2];
-  uint32_t gq[4];                                 // ring of claimed groups (three in use)
-  uint32_t tot[2];
-  uint32_t cnt[2][kPWaves][kPTpw];
-  uint32_t qbase[2][kPWaves * kPTpw + 1];
+  uint64_t ring[kPRing];                          // claimed groups: slot n % kPRing holds (n + 1) << 32 | group once claim n of this workgroup is known
+  uint32_t want;                                  // claims asked for so far (the first wave to reach an iteration asks for the claim two iterations ahead)
+  uint32_t prog[kPWaves];                         // iteration every wave is in (a slot is not overwritten while a wave may still read it)
   PairWaveLds wv[kPWaves];
 };
 static_assert(sizeof(PairLds) <= 160 * 1024, "LDS");
@@ -110,10 +113,10 @@ __device__ __forceinline__ uint64_t pair_resolve(const uint64_t* status, uint32_
     }
     const unsigned long long incl_mask = __ballot((w & kFlagMask) == kFlagInclusive);
     const int first_incl = incl_mask ? __builtin_ctzll(incl_mask) : 64;
-    uint64_t v = (lane <= first_incl) ? (w & kValueMask) : 0ull;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    base += v;
+    // counts (aggregate words: a unit's rows, far below 2^32) of the units behind the first inclusive word: one DPP sum; the inclusive word itself: two v_readlane
+    const uint32_t agg = lane < first_incl ? static_cast<uint32_t>(w) : 0u;
+    base += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_inclusive_sum(agg)), 63));
+    if (first_incl < 64) base += readlane64(w & kValueMask, first_incl);
     if (first_incl < 64) break;
     look -= 64;
     w = pair_status_load(status, look - lane, etag);
@@ -228,19 +231,40 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         }
     }
   }
-  if (tid == 0) { const uint32_t g0 = claimed(t0); S.gq[0] = g0; S.gq[1] = g0 == 0xFFFFFFFFu ? g0 : claimed(t1); }
+  if (tid == 0) {
+    const uint32_t g0 = claimed(t0), g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1);
+    S.ring[0] = (1ull << 32) | g0; S.ring[1] = (2ull << 32) | g1;
+    for (uint32_t q = 2; q < kPRing; q++) S.ring[q] = 0ull;
+    S.want = 2u;
+  }
+  if (tid < kPWaves) S.prog[tid] = 0u;
   __syncthreads();
+  // From here on the waves of the workgroup do not meet again: every wave scans its own units (kPTpw consecutive wave-tiles of each
+  // group the workgroup claims), publishes their counts, resolves their bases and writes their rows by itself.
+  auto ring_get = [&](uint32_t n) -> uint32_t {                     // claim n of this workgroup (waits until the wave that asked for it has it)
+    uint64_t v;
+    uint32_t spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(&S.ring[n % kPRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (static_cast<uint32_t>(v >> 32) == n + 1u) break;
+      if (++spins > kSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdLookback); return 0xFFFFFFFFu; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return static_cast<uint32_t>(v);
+  };
 
   const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
 
-  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead — across groups too
-  u32x4 x[4];
-  uint32_t xprev = 0;
-  __amdgpu_buffer_rsrc_t rsrc_n;
-  int pre_n = 0;
-  auto issue_loads = [&](uint64_t g, int jj) {
-    const uint64_t wtn = g * (kPWaves * kPTpw) + static_cast<uint64_t>(jj) * kPWaves + wave;
+  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), TWO tiles ahead — across units too: with one window
+  // (4 KiB) in flight per wave a CU has 64 KiB on its way, and the device 16 MiB: what 4.4 TB/s need at the latency seen here (the
+  // filter alone ran at 0.24 ms per GiB that way).  Tile j of a unit lives in buffer j & 1.
+  u32x4 x[2][4];
+  uint32_t xprev[2] = {0u, 0u};
+  __amdgpu_buffer_rsrc_t rsrc_n[2];
+  int pre_n[2] = {0, 0};
+  auto issue_loads = [&](uint64_t g, int jj, int p) {
+    const uint64_t wtn = g * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + jj;      // a wave's unit: kPTpw consecutive wave-tiles
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
     if (g < ngroups && lo < a.len) {
@@ -248,244 +272,284 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       nrec = rem >= static_cast<uint64_t>(kPWin) ? kPWin : static_cast<int>((rem + 3) & ~3ull);
     }
     const int pre = (nrec && lo) ? 16 : 0;
-    rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
-    pre_n = pre;
+    rsrc_n[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
+    pre_n[p] = pre;
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (lane + 64 * k) << 4, pre, 0);
-    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, 0, pre ? 12 : nrec + pre, 0);
+    for (int k = 0; k < 4; k++) x[p][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n[p], (lane + 64 * k) << 4, pre, 0);
+    xprev[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n[p], 0, pre ? 12 : nrec + pre, 0);
   };
-  issue_loads(S.gq[0], 0);
+  issue_loads(static_cast<uint32_t>(S.ring[0]), 0, 0);
+  issue_loads(static_cast<uint32_t>(S.ring[0]), 1, 1);
 
-  uint64_t prev = ~0ull;                                            // the group whose rows wait to be written
-  for (uint32_t it = 0;; it++) {
-    const uint32_t b = it & 1u;
-    const uint64_t group = S.gq[it % 3u];
-    const uint64_t next_group = S.gq[(it + 1u) % 3u];
-    const bool live = group < ngroups;
-    uint32_t n2 = 0;
-    uint64_t lw = 0;
-    if (wave == kPWaves - 1 && live && lane0 == 0) n2 = draw();      // the group after next: the ticket is read in front of the barrier
-    if (wave == 0) {
-      if (prev != ~0ull && prev > 0) lw = pair_status_load(a.status, static_cast<int64_t>(prev) - 1 - lane0, etag);   // look-back of the group before: words requested now, read behind the tiles
+  // Units scanned and not yet resolved, oldest first: the unit, its rows, the iteration it was scanned in (its row buffer).  The look-back
+  // makes every unit wait for all units in front of it — anywhere on the device — to be COUNTED; the waves drift apart by more than a
+  // unit's time, so a base is asked for kPDefer units late (one unit late: 0.067 ms of a 0.41 ms launch went into that wait).
+  uint64_t pu[kPDefer]; uint32_t pn[kPDefer], pit[kPDefer];
+#pragma unroll
+  for (uint32_t k = 0; k < kPDefer; k++) { pu[k] = ~0ull; pn[k] = 0; pit[k] = 0; }
+  auto finish_unit = [&](uint64_t u, uint32_t nrows, uint32_t buf, uint64_t lw) {   // base, inclusive sum, rows
+    if (CXG_PAIR_ABL & 8) return;
+    const uint64_t base = (u > 0 && !(CXG_PAIR_ABL & 32)) ? pair_resolve(a.status, a.err, u, lw, etag, lane0) : 0ull;
+    if (lane0 == 0) {
+      if (u > 0) __hip_atomic_store(a.status + u, kFlagInclusive | etag | (base + nrows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (u == a.ngroups * kPWaves - 1) *a.total = base + nrows;
     }
+    if (a.out != nullptr && !(CXG_PAIR_ABL & 16)) {
+      const int64_t origin = a.base + static_cast<int64_t>(u * static_cast<uint64_t>(kWaveTile) * kPTpw);
+      const uint32_t n = nrows < static_cast<uint32_t>(kPRows) ? nrows : static_cast<uint32_t>(kPRows);
+      for (uint32_t i = lane0; i < n; i += 64)
+        if (base + i < a.cap) store_pair_nt(a.out + (base + i) * a.row_width, origin + L.rs[buf][i], origin + L.re[buf][i]);
+    }
+  };
+  uint32_t pend_n = 0xFFFFFFFFu, pend_t = 0;                        // a claim this wave asked for: its number and the ticket drawn for it
+  // The claim this wave asked for: published two tiles later — the ticket has had that long to come back, and the other waves want the
+  // claim at the top of their next iteration.
+  auto publish_pending = [&]() {
+    if (pend_n == 0xFFFFFFFFu) return;
+    uint32_t g = 0;
+    if (lane0 == 0) g = claimed(pend_t);
+    g = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g)));
+    for (uint32_t spins = 0;; spins++) {                            // slot pend_n % kPRing was claim pend_n - kPRing: no wave may still be reading it
+      const uint32_t pr = __hip_atomic_load(&S.prog[lane0 & (kPWaves - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (__ballot(pr + kPRing <= pend_n + 1u) == 0ull) break;      // a wave in iteration p reads claims p and p + 1
+      if (spins > kSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdLookback); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane0 == 0) __hip_atomic_store(&S.ring[pend_n % kPRing], (static_cast<uint64_t>(pend_n + 1u) << 32) | g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pend_n = 0xFFFFFFFFu;
+  };
+  for (uint32_t it = 0;; it++) {
+    const uint32_t b = it % (kPDefer + 1u);
+    publish_pending();                                              // (a claim asked for in an iteration that ended early)
+    if (lane0 == 0) __hip_atomic_store(&S.prog[wave], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t group = ring_get(it);
+    const uint64_t next_group = ring_get(it + 1u);
+    const bool live = group < ngroups;
+    const uint64_t unit = group * kPWaves + static_cast<uint64_t>(wave);
+    if (live) {                                                     // the first wave to get here asks for claim it + 2
+      uint32_t old = 0;
+      if (lane0 == 0) old = atomicMax(&S.want, it + 3u);
+      old = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(old)));
+      if (old < it + 3u) { pend_n = it + 2u; if (lane0 == 0) pend_t = draw(); }
+    }
+    uint64_t lw = 0;
+    if (pu[0] != ~0ull && pu[0] > 0) lw = pair_status_load(a.status, static_cast<int64_t>(pu[0]) - 1 - lane0, etag);   // look-back of the oldest unit: words requested now, read behind the tiles
     uint32_t nrows_w = 0;                                           // wave-uniform
-    if (live) for (int j = 0; j < kPTpw; j++) {
+    // A wave-tile in two stages.  filter(j): pair lookups, candidate and synchronising bits, ownership, the owned candidates listed
+    // in LDS.  verify(j): the candidates against the literals, FindAll order, rows.  The 16 bytes at each of the first 64 candidates
+    // are REQUESTED (global memory: an L2 round trip) in front of filter(j + 1) and compared behind it.
+    struct TileCtx { __amdgpu_buffer_rsrc_t rsrc; int pre; int32_t prevb; int32_t rend; uint32_t ncand; };
+    auto filter = [&](int j, uint32_t cb_, TileCtx& cx) {
       lane = lane0;
       asm volatile("" : "+v"(lane));                                // (scan_chain_wave.hip: no hoisted-and-spilled lane constants)
-      const uint64_t wt = group * (kPWaves * kPTpw) + static_cast<uint64_t>(j) * kPWaves + wave;
+      const uint64_t wt = group * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + j;
       const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
-      uint32_t emitted_here = 0;
-      if (tile_lo < a.len) {
-        const uint64_t remaining = a.len - tile_lo;
-        const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
-        const int32_t stage = rend < kPWin ? rend : kPWin;
-
-        const uint32_t two = 2u;
-        // ---- A: one lookup per byte pair, the entries of a piece's eight pairs in two registers, transposed through LDS
+      const int p = j & 1;                                         // compile-time: the tile loop is unrolled
+      // the loads of the tile two ahead (the unit behind this one may lie anywhere in the haystack — a stolen claim —, also when this tile lies behind its end)
+      auto issue_next = [&]() { if (j + 2 < kPTpw) issue_loads(group, j + 2, p); else issue_loads(next_group, j + 2 - kPTpw, p); };
+      cx.ncand = 0; cx.rend = 0; cx.pre = 0; cx.prevb = -1; cx.rsrc = rsrc_n[p];
+      if (tile_lo >= a.len) { issue_next(); return; }
+      const uint64_t remaining = a.len - tile_lo;
+      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      const int32_t stage = rend < kPWin ? rend : kPWin;
+      const uint32_t two = 2u;
+      // ---- A: one lookup per byte pair, the entries of a piece's eight pairs in two registers, transposed through LDS
+      uint32_t ia[32];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32x4 v = x[k];
-          uint32_t i0, i1, i2, i3, i4, i5, i6, i7;
-          CXG_PAIR_ADDR(i0, v.x, 1, 0); CXG_PAIR_ADDR(i1, v.x, 3, 1); CXG_PAIR_ADDR(i2, v.y, 1, 0); CXG_PAIR_ADDR(i3, v.y, 3, 1);
-          CXG_PAIR_ADDR(i4, v.z, 1, 0); CXG_PAIR_ADDR(i5, v.z, 3, 1); CXG_PAIR_ADDR(i6, v.w, 1, 0); CXG_PAIR_ADDR(i7, v.w, 3, 1);
-          const uint32_t e0 = S.tab[i0], e1 = S.tab[i1], e2 = S.tab[i2], e3 = S.tab[i3], e4 = S.tab[i4], e5 = S.tab[i5], e6 = S.tab[i6], e7 = S.tab[i7];
-          uint2 o;
-          o.x = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
-          o.y = e4 | (e5 << 8) | (e6 << 16) | (e7 << 24);
-          *reinterpret_cast<uint2*>(&L.w[2 * (lane + 64 * k)]) = o;
+      for (int k = 0; k < 4; k++) {
+        const u32x4 v = x[p][k];
+        CXG_PAIR_ADDR(ia[8 * k + 0], v.x, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 1], v.x, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 2], v.y, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 3], v.y, 3, 1);
+        CXG_PAIR_ADDR(ia[8 * k + 4], v.z, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 5], v.z, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 6], v.w, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 7], v.w, 3, 1);
+      }
+      const uint32_t xprev_cur = xprev[p];
+      cx.rsrc = rsrc_n[p]; cx.pre = pre_n[p]; cx.rend = rend;
+      cx.prevb = tile_lo > 0 ? static_cast<int32_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1;
+      issue_next();                                                // x[p][] is free from here on
+      uint32_t ea[32];
+#pragma unroll
+      for (int q = 0; q < 32; q++) ea[q] = (CXG_PAIR_ABL & 4) ? (ia[q] & 0x3Fu) : S.tab[ia[q]];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint2 o;
+        o.x = ea[8 * k] | (ea[8 * k + 1] << 8) | (ea[8 * k + 2] << 16) | (ea[8 * k + 3] << 24);
+        o.y = ea[8 * k + 4] | (ea[8 * k + 5] << 8) | (ea[8 * k + 6] << 16) | (ea[8 * k + 7] << 24);
+        *reinterpret_cast<uint2*>(&L.w[2 * (lane + 64 * k)]) = o;
+      }
+      wave_lds_sync();
+      uint32_t W[9];
+      {
+        const u32x4 wa = *reinterpret_cast<const u32x4*>(&L.w[8 * lane]);
+        const u32x4 wb = *reinterpret_cast<const u32x4*>(&L.w[8 * lane + 4]);
+        W[0] = wa.x; W[1] = wa.y; W[2] = wa.z; W[3] = wa.w; W[4] = wb.x; W[5] = wb.y; W[6] = wb.z; W[7] = wb.w;
+        W[8] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(W[0]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));   // lane 63: nothing behind the window
+      }
+      uint32_t cd[8], zd[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t a1 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 10);   // entry of the next pair >> 2
+        const uint32_t a2 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 20);   // entry of the pair behind it >> 4
+        cd[q] = __builtin_amdgcn_udot4(W[q] & a1 & a2 & 0x03030303u, 0x40100401u, 0u, false);   // eight bits: the dword's eight byte positions
+        zd[q] = __builtin_amdgcn_udot4(W[q] & 0xC0C0C0C0u, 0x40100401u, 0u, false);             // the same for S1 / S2, << 6
+      }
+      const uint64_t C = (static_cast<uint64_t>(cd[4] | (cd[5] << 8) | (cd[6] << 16) | (cd[7] << 24)) << 32) | (cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24));
+      uint64_t Z = (static_cast<uint64_t>(((zd[4] | (zd[5] << 8)) >> 6) | (((zd[6] | (zd[7] << 8)) >> 6) << 16)) << 32) |
+                   (((zd[0] | (zd[1] << 8)) >> 6) | (((zd[2] | (zd[3] << 8)) >> 6) << 16));
+      if (stage != kPWin) {                                        // short last window: bytes past the data read as 0
+        const int32_t nv = stage - 64 * lane;
+        Z &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+      }
+      // ---- O: ownership bounds (scan_teddy_wave.hip)
+      int32_t zA = -1, zB = kPFar;
+      if (tile_lo > 0) {
+        if (!(S.T[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
+          const unsigned long long bz = __ballot(Z != 0ull);
+          if (bz) {
+            const int Lz = __builtin_ctzll(bz);
+            zA = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, Lz)));
+            if (Lz >= 16) fallback |= 1;                            // (the same budget as scan_teddy_wave.hip: a synchronising byte in the first KiB)
+          }
+          else zA = kPFar;
         }
-        const uint32_t xprev_cur = xprev;
-        const __amdgpu_buffer_rsrc_t rsrc = rsrc_n;
-        const int pre = pre_n;
-        if (j + 1 < kPTpw) issue_loads(group, j + 1); else issue_loads(next_group, 0);   // x[] is free from here on
+      }
+      {
+        const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kPWin - 1);
+        const unsigned long long bzb = __ballot(Zb != 0ull);
+        if (bzb) { const int Lz = __builtin_ctzll(bzb); zB = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, Lz))); }
+        else if (stage != rend) { zB = -2; fallback |= 1; }
+      }
+      const uint64_t Co = C & word_range(lane, zA + 1, zB);
+      // ---- list the owned candidates
+      const uint32_t nc_lane = static_cast<uint32_t>(__popcll(Co));
+      const uint32_t incl = wave_inclusive_sum(nc_lane);
+      uint32_t ncand = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+      if (ncand > static_cast<uint32_t>(kPCands)) { fallback |= 8; ncand = kPCands; }
+      if (CXG_PAIR_ABL & 2) ncand = 0;
+      cx.ncand = (CXG_PAIR_ABL & 1) ? 0u : ncand;
+      if (ncand) {
+        uint32_t idx = incl - nc_lane;
+        uint64_t cb = Co;
+        while (cb) {
+          const int bit = __builtin_ctzll(cb);
+          cb &= cb - 1;
+          if (idx < static_cast<uint32_t>(kPCands)) L.cpos[cb_][idx] = static_cast<uint16_t>(64 * lane + bit);
+          idx++;
+        }
         wave_lds_sync();
-        uint32_t W[9];
-        {
-          const u32x4 wa = *reinterpret_cast<const u32x4*>(&L.w[8 * lane]);
-          const u32x4 wb = *reinterpret_cast<const u32x4*>(&L.w[8 * lane + 4]);
-          W[0] = wa.x; W[1] = wa.y; W[2] = wa.z; W[3] = wa.w; W[4] = wb.x; W[5] = wb.y; W[6] = wb.z; W[7] = wb.w;
-          W[8] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(W[0]), 0x130 /*wave_shl:1*/, 0xF, 0xF, true));   // lane 63: nothing behind the window
-        }
-        uint32_t cd[8], zd[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const uint32_t a1 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 10);   // entry of the next pair >> 2
-          const uint32_t a2 = __builtin_amdgcn_alignbit(W[q + 1], W[q], 20);   // entry of the pair behind it >> 4
-          cd[q] = __builtin_amdgcn_udot4(W[q] & a1 & a2 & 0x03030303u, 0x40100401u, 0u, false);   // eight bits: the dword's eight byte positions
-          zd[q] = __builtin_amdgcn_udot4(W[q] & 0xC0C0C0C0u, 0x40100401u, 0u, false);             // the same for S1 / S2, << 6
-        }
-        const uint64_t C = (static_cast<uint64_t>(cd[4] | (cd[5] << 8) | (cd[6] << 16) | (cd[7] << 24)) << 32) | (cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24));
-        uint64_t Z = (static_cast<uint64_t>(((zd[4] | (zd[5] << 8)) >> 6) | (((zd[6] | (zd[7] << 8)) >> 6) << 16)) << 32) |
-                     (((zd[0] | (zd[1] << 8)) >> 6) | (((zd[2] | (zd[3] << 8)) >> 6) << 16));
-        if (stage != kPWin) {                                        // short last window: bytes past the data read as 0
-          const int32_t nv = stage - 64 * lane;
-          Z &= nv <= 0 ? 0ull : (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
-        }
-
-        // ---- O: ownership bounds (scan_teddy_wave.hip)
-        int32_t zA = -1, zB = kPFar;
-        if (tile_lo > 0) {
-          const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24;
-          if (!(S.T[pb] & 0x1000000u)) {                              // the segment at the tile's first byte began earlier
-            const unsigned long long bz = __ballot(Z != 0ull);
-            if (bz) {
-              const int Lz = __builtin_ctzll(bz);
-              zA = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Z, Lz)));
-              if (Lz >= 16) fallback |= 1;                            // (the same budget as scan_teddy_wave.hip: a synchronising byte in the first KiB)
-            }
-            else zA = kPFar;
-          }
-        }
-        {
-          const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kPWin - 1);
-          const unsigned long long bzb = __ballot(Zb != 0ull);
-          if (bzb) { const int Lz = __builtin_ctzll(bzb); zB = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, Lz))); }
-          else if (stage != rend) { zB = -2; fallback |= 1; }
-        }
-        const uint64_t Co = C & word_range(lane, zA + 1, zB);
-
-        // ---- V: list the owned candidates, verify 64 at a time
-        const uint32_t nc_lane = static_cast<uint32_t>(__popcll(Co));
-        const uint32_t incl = wave_inclusive_sum(nc_lane);
-        uint32_t ncand = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-        if (ncand > static_cast<uint32_t>(kPCands)) { fallback |= 8; ncand = kPCands; }
-        if (ncand) {
-          uint32_t idx = incl - nc_lane;
-          uint64_t cb = Co;
-          while (cb) {
-            const int bit = __builtin_ctzll(cb);
-            cb &= cb - 1;
-            if (idx < static_cast<uint32_t>(kPCands)) L.cpos[idx] = static_cast<uint16_t>(64 * lane + bit);
-            idx++;
-          }
-          wave_lds_sync();
-          auto wbyte = [&](int32_t i) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b8(rsrc, i + pre, 0, 0); };   // window byte i (0 past the data)
-          int32_t cur_end = -1;                                       // wave-uniform: end of the last emitted match
-          for (uint32_t r0 = 0; r0 < ncand; r0 += 64) {
-            int32_t c = 0, mlen = 0;
-            if (r0 + static_cast<uint32_t>(lane) < ncand) {
-              c = L.cpos[r0 + lane];
-              // the 12 bytes at the candidate as three dwords: one 16-byte load at the dword in front of it + v_alignbit
-              const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (c & ~3) + pre, 0, 0);
-              const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
-              const uint32_t w0 = __builtin_amdgcn_alignbit(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbit(d.z, d.y, sh), w2 = __builtin_amdgcn_alignbit(d.w, d.z, sh);
-              uint32_t mask = (S.T[w0 & 0xFFu] & 0xFFu) & ((S.T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((S.T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
-              while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
-                const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
-                mask &= mask - 1;
-                for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
-                  const uint32_t id = t_order[k];
-                  const int32_t len = t_lens[id];
-                  if (c + len > rend) continue;
-                  if (id < 32u) {
-                    const uint32_t diff = ((w0 ^ S.lit[id][0]) & S.lit[id][3]) | ((w1 ^ S.lit[id][1]) & S.lit[id][4]) | ((w2 ^ S.lit[id][2]) & S.lit[id][5]);
-                    if (diff != 0u) continue;
-                    if (len <= 12) { mlen = len; continue; }
-                  }
-                  const uint8_t* lit = t_bytes + t_off[id];
-                  int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
-                  while (q < len && same(wbyte(c + q), lit[q])) q++;
-                  if (q == len) mlen = len;
+      }
+    };
+    // the 16 bytes at the dword in front of candidate r of the list (requested; compared in verify)
+    auto request = [&](uint32_t cb_, const TileCtx& cx, uint32_t r, int32_t& c, u32x4& d) {
+      c = 0; d = u32x4{0u, 0u, 0u, 0u};
+      if (r < cx.ncand) {
+        c = L.cpos[cb_][r];
+        d = __builtin_amdgcn_raw_buffer_load_b128(cx.rsrc, (c & ~3) + cx.pre, 0, 0);
+      }
+    };
+    auto verify = [&](int j, uint32_t cb_, const TileCtx& cx, int32_t c0, u32x4 d0) {
+      uint32_t emitted_here = 0;
+      const uint32_t ncand = cx.ncand;
+      const int32_t rend = cx.rend;
+      if (ncand) {
+        auto wbyte = [&](int32_t i) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b8(cx.rsrc, i + cx.pre, 0, 0); };   // window byte i (0 past the data)
+        int32_t cur_end = -1;                                       // wave-uniform: end of the last emitted match
+        for (uint32_t r0 = 0; r0 < ncand; r0 += 64) {
+          int32_t c = c0, mlen = 0;
+          u32x4 d = d0;
+          if (r0) request(cb_, cx, r0 + static_cast<uint32_t>(lane), c, d);
+          if (r0 + static_cast<uint32_t>(lane) < ncand) {
+            // the 12 bytes at the candidate as three dwords (v_alignbit over the 16 loaded)
+            const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbit(d.z, d.y, sh), w2 = __builtin_amdgcn_alignbit(d.w, d.z, sh);
+            uint32_t mask = (S.T[w0 & 0xFFu] & 0xFFu) & ((S.T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((S.T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
+            while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
+              const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
+              mask &= mask - 1;
+              for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
+                const uint32_t id = t_order[k];
+                const int32_t len = t_lens[id];
+                if (c + len > rend) continue;
+                if (id < 32u) {
+                  const uint32_t diff = ((w0 ^ S.lit[id][0]) & S.lit[id][3]) | ((w1 ^ S.lit[id][1]) & S.lit[id][4]) | ((w2 ^ S.lit[id][2]) & S.lit[id][5]);
+                  if (diff != 0u) continue;
+                  if (len <= 12) { mlen = len; continue; }
                 }
-              }
-              if (mlen && (look_pre | look_post) != 0u) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
-                const int pbv = c > 0 ? static_cast<int>(wbyte(c - 1)) : (tile_lo > 0 ? static_cast<int>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1);
-                const int nb = c + mlen < rend ? (c + mlen < kPWin ? static_cast<int>(wbyte(c + mlen)) : -2) : -1;
-                if (nb == -2) { edge_hit = 1; mlen = 0; }               // the byte behind the occurrence lies behind the window: hand the scan over
-                else if (!teddy_look_holds(look_pre, pbv, static_cast<int>(w0 & 0xFFu)) || !teddy_look_holds(look_post, static_cast<int>(wbyte(c + mlen - 1)), nb)) mlen = 0;
+                const uint8_t* lit = t_bytes + t_off[id];
+                int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
+                while (q < len && same(wbyte(c + q), lit[q])) q++;
+                if (q == len) mlen = len;
               }
             }
-            // ---- D: FindAll order inside the round (candidates ascend with the lane)
-            const int32_t e = mlen ? c + mlen : 0;
-            int32_t pmax = e;                                         // inclusive prefix max of the ends
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-              const int32_t o = __shfl_up(pmax, d, 64);
-              if (lane >= d && o > pmax) pmax = o;
+            if (mlen && (look_pre | look_post) != 0u) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
+              const int pbv = c > 0 ? static_cast<int>(wbyte(c - 1)) : cx.prevb;
+              const int nb = c + mlen < rend ? (c + mlen < kPWin ? static_cast<int>(wbyte(c + mlen)) : -2) : -1;
+              if (nb == -2) { edge_hit = 1; mlen = 0; }               // the byte behind the occurrence lies behind the window: hand the scan over
+              else if (!teddy_look_holds(look_pre, pbv, static_cast<int>(w0 & 0xFFu)) || !teddy_look_holds(look_post, static_cast<int>(wbyte(c + mlen - 1)), nb)) mlen = 0;
             }
-            int32_t before = static_cast<int32_t>(dpp_from_lower(static_cast<uint32_t>(pmax)));
-            if (lane == 0) before = 0;
-            if (cur_end > before) before = cur_end;
-            uint32_t emit = mlen ? 1u : 0u;
-            if (__ballot(mlen && c < before) != 0ull) {               // some verified candidate lies inside an earlier match
-              L.ce[lane] = static_cast<uint16_t>(e);
-              wave_lds_sync();
-              if (lane == 0) {
-                int32_t ce = cur_end;
-                for (uint32_t k = 0; k < 64; k++) {                   // all 64: lanes past ncand hold e = 0 and must read em = 0
-                  const int32_t ek = L.ce[k];
-                  uint8_t em = 0;
-                  if (ek && static_cast<int32_t>(L.cpos[r0 + k]) >= ce) { em = 1; ce = ek; }
-                  L.em[k] = em;
-                }
+          }
+          // ---- D: FindAll order inside the round (candidates ascend with the lane)
+          const int32_t e = mlen ? c + mlen : 0;
+          const int32_t pmax = static_cast<int32_t>(wave_inclusive_max(static_cast<uint32_t>(e)));   // inclusive prefix max of the ends
+          int32_t before = static_cast<int32_t>(dpp_from_lower(static_cast<uint32_t>(pmax)));
+          if (lane == 0) before = 0;
+          if (cur_end > before) before = cur_end;
+          uint32_t emit = mlen ? 1u : 0u;
+          if (__ballot(mlen && c < before) != 0ull) {               // some verified candidate lies inside an earlier match
+            L.ce[lane] = static_cast<uint16_t>(e);
+            wave_lds_sync();
+            if (lane == 0) {
+              int32_t ce = cur_end;
+              for (uint32_t k = 0; k < 64; k++) {                   // all 64: lanes past ncand hold e = 0 and must read em = 0
+                const int32_t ek = L.ce[k];
+                uint8_t em = 0;
+                if (ek && static_cast<int32_t>(L.cpos[cb_][(r0 + k) < static_cast<uint32_t>(kPCands) ? r0 + k : 0u]) >= ce) { em = 1; ce = ek; }
+                L.em[k] = em;
               }
-              wave_lds_sync();
-              emit = L.em[lane];
             }
-            const unsigned long long em_mask = __ballot(emit != 0);
-            if (em_mask) {
-              const int last = 63 - __builtin_clzll(em_mask);
-              cur_end = __builtin_amdgcn_readlane(e, last);
-              const uint32_t n_em = static_cast<uint32_t>(__popcll(em_mask));
-              if (emit) {
-                const uint32_t r = nrows_w + emitted_here + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
-                if (r < static_cast<uint32_t>(kPRows)) { L.rs[b][r] = static_cast<uint16_t>(c); L.re[b][r] = static_cast<uint16_t>(e); }
-              }
-              emitted_here += n_em;
+            wave_lds_sync();
+            emit = L.em[lane];
+          }
+          const unsigned long long em_mask = __ballot(emit != 0);
+          if (em_mask) {
+            const int last = 63 - __builtin_clzll(em_mask);
+            cur_end = __builtin_amdgcn_readlane(e, last);
+            const uint32_t n_em = static_cast<uint32_t>(__popcll(em_mask));
+            if (emit) {
+              const uint32_t r = nrows_w + emitted_here + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
+              if (r < static_cast<uint32_t>(kPRows)) { L.rs[b][r] = static_cast<uint16_t>(j * kWaveTile + c); L.re[b][r] = static_cast<uint16_t>(j * kWaveTile + e); }
             }
+            emitted_here += n_em;
           }
         }
       }
-      if (lane == 0) S.cnt[b][wave][j] = emitted_here;
       nrows_w += emitted_here;
+    };
+    if (live) {
+      TileCtx cx[2];
+      filter(0, 0u, cx[0]);
+#pragma unroll
+      for (int j = 0; j < kPTpw; j++) {
+        int32_t c0; u32x4 d0;
+        request(j & 1, cx[j & 1], static_cast<uint32_t>(lane), c0, d0);
+        if (j + 1 < kPTpw) filter(j + 1, (j + 1) & 1, cx[(j + 1) & 1]);
+        verify(j, j & 1, cx[j & 1], c0, d0);
+        if (j == 1) publish_pending();
+      }
     }
     if (nrows_w > static_cast<uint32_t>(kPRows)) fallback |= 16;
 
-    // ---- the group before: its base (wave 0), then — behind the barrier — its rows; this group: its count
-    if (wave == 0) {
-      if (prev != ~0ull) {
-        const uint64_t base = prev > 0 ? pair_resolve(a.status, a.err, prev, lw, etag, lane0) : 0ull;
-        if (lane0 == 0) {
-          const uint64_t incl = base + S.tot[b ^ 1u];
-          if (prev > 0) __hip_atomic_store(a.status + prev, kFlagInclusive | etag | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          S.base[b ^ 1u] = base;
-          if (prev == ngroups - 1) *a.total = incl;
-        }
-      }
+    // ---- this unit: its count; the unit before: its base, its inclusive sum, its rows
+    if (live && lane0 == 0)
+      __hip_atomic_store(a.status + unit, (unit == 0 ? kFlagInclusive : kFlagAggregate) | etag | static_cast<uint64_t>(nrows_w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pu[0] != ~0ull) finish_unit(pu[0], pn[0], pit[0] % (kPDefer + 1u), lw);
+#pragma unroll
+    for (uint32_t k = 0; k + 1 < kPDefer; k++) { pu[k] = pu[k + 1]; pn[k] = pn[k + 1]; pit[k] = pit[k + 1]; }
+    pu[kPDefer - 1] = live ? unit : ~0ull; pn[kPDefer - 1] = nrows_w; pit[kPDefer - 1] = it;
+    if (!live) {                                                    // no group left: the units still waiting, oldest first
+#pragma unroll
+      for (uint32_t k = 0; k < kPDefer; k++)
+        if (pu[k] != ~0ull) finish_unit(pu[k], pn[k], pit[k] % (kPDefer + 1u), pu[k] > 0 ? pair_status_load(a.status, static_cast<int64_t>(pu[k]) - 1 - lane0, etag) : 0ull);
+      break;
     }
-    if (wave == kPWaves - 1 && live && lane0 == 0) S.gq[(it + 2u) % 3u] = claimed(n2);
-    __syncthreads();
-    if (live && wave == 0) {                                        // exclusive prefix over the group's wave-tiles q = j * 16 + wave; publish the count
-      const int q = lane0;
-      const uint32_t v = S.cnt[b][q % kPWaves][q / kPWaves];
-      const uint32_t incl = wave_inclusive_sum(v);
-      S.qbase[b][q] = incl - v;
-      if (q == 63) {
-        S.qbase[b][64] = incl;
-        S.tot[b] = incl;
-        __hip_atomic_store(a.status + group, (group == 0 ? kFlagInclusive : kFlagAggregate) | etag | static_cast<uint64_t>(incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (prev != ~0ull && a.out != nullptr) {                        // rows of the group before (buffers b ^ 1)
-      const uint32_t pbuf = b ^ 1u;
-      const uint64_t base = S.base[pbuf];
-      const int64_t origin = a.base + static_cast<int64_t>(prev * static_cast<uint64_t>(kWaveTile) * kPWaves * kPTpw);
-      uint32_t start = 0;
-      for (int j = 0; j < kPTpw; j++) {
-        const uint32_t n = S.cnt[pbuf][wave][j];
-        const uint64_t dst = base + S.qbase[pbuf][j * kPWaves + wave];
-        for (uint32_t i = lane0; i < n; i += 64) {
-          const uint32_t r = start + i;
-          if (r < static_cast<uint32_t>(kPRows) && dst + i < a.cap) {
-            const int64_t tb = origin + static_cast<int64_t>(j * kPWaves + wave) * kWaveTile;
-            store_pair_nt(a.out + (dst + i) * a.row_width, tb + L.rs[pbuf][r], tb + L.re[pbuf][r]);
-          }
-        }
-        start += n;
-      }
-    }
-    if (!live) break;
-    prev = group;
   }
   if (__ballot(edge_hit != 0) != 0ull) fallback |= 32;
   if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));

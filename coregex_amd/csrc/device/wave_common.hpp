@@ -185,6 +185,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
   v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143 /*row_bcast:31*/, 0xC, 0xF, false));
   return v;
 }
+// Inclusive prefix maximum of unsigned values over the 64 lanes, the same DPP ladder (lanes outside a shift contribute 0).
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111 /*row_shr:1*/, 0xF, 0xF, true)));
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112 /*row_shr:2*/, 0xF, 0xF, true)));
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114 /*row_shr:4*/, 0xF, 0xF, true)));
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118 /*row_shr:8*/, 0xF, 0xF, true)));
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142 /*row_bcast:15*/, 0xA, 0xF, false)));
+  v = mx(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143 /*row_bcast:31*/, 0xC, 0xF, false)));
+  return v;
+}
 // bits [lo, hi] (inclusive, window bit indices) that fall into lane's word [64*lane, 64*lane+63]
 __device__ __forceinline__ uint64_t word_range(int lane, int32_t lo, int32_t hi) {
   // bits >= a and <= b of the word, a/b relative to the word and clamped so that the shifts stay in range

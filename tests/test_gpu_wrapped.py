@@ -30,7 +30,10 @@ def test_rows(pat, oracle):
                 assert cnt == len(exp), (pat, n, sparse)
                 served += t.kernels[0] == 7
             got = rx.find_all_index(hay)
-            assert got.shape == exp.shape and np.array_equal(got, exp), (pat, n, sparse, bytes(hay[:60]), got[:4].tolist(), exp[:4].tolist())
+            if got.shape != exp.shape or not np.array_equal(got, exp):                # (what differs, for the log)
+                miss = sorted(set(map(tuple, exp.tolist())) - set(map(tuple, got.tolist())))[:4]
+                extra = sorted(set(map(tuple, got.tolist())) - set(map(tuple, exp.tolist())))[:4]
+                raise AssertionError((pat, n, sparse, len(got), len(exp), "missing", miss, "extra", extra, [bytes(hay[max(0, m[0] - 6):m[1] + 6]) for m in miss]))
             assert np.array_equal(rx.find_all_index(hay, 2), exp[:2])
     assert routed(served >= 8, served)
 
