@@ -162,10 +162,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
-  if (gen == 12) {                                                 // look-back words per UNIT (a wave's four wave-tiles of a group): 16 per group
-    a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
-    if (a.ngroups * cxgdev::kPairWaves > s.statusCap) return fail(CXG_E_INTERNAL, "status words: more units than the allocation covers");
-  }
+  if (gen == 12) a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = (gen == 10 && fsmMode >= 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, modes 2 and 3: one tile, 1 024 / 2 048 rows

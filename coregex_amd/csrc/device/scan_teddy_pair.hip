@@ -54,8 +54,6 @@ constexpr int kPTpw = kPairTilesPerWave;          // 4: 64 wave-tiles per group 
 constexpr int kPRows = 192;                       // rows buffered per wave per group
 constexpr int kPCands = 192;                      // owned candidates listed per wave-tile
 constexpr int kPAuxMax = 2048;
-constexpr uint32_t kPRing = 8;
-constexpr uint32_t kPDefer = 2;                   // a unit's base is resolved and its rows are written this many units later
 #ifndef CXG_PAIR_ABL
 #define CXG_PAIR_ABL 0                    // timing experiments (scripts/build_variant.sh; WRONG rows): 1 no verification, 2 no candidate list either, 4 no table lookups, 8 no look-back / row write
 #endif
@@ -66,7 +64,7 @@ static_assert(kPWaves * kPTpw == 64, "the group prefix is one wave wide");
 struct PairWaveLds {
   uint32_t w[512];                                // pair entries of the window: piece p (16 bytes) -> dwords 2p, 2p + 1
   uint16_t cpos[2][kPCands];                      // owned candidates of the tile being verified and of the tile being filtered
-  uint16_t rs[kPDefer + 1][kPRows], re[kPDefer + 1][kPRows];   // rows of this unit and of the units whose bases are not resolved yet
+  uint16_t rs[2][kPRows], re[2][kPRows];          // rows of this unit (relative to its first byte) and of the unit of the group before
   uint16_t ce[64];
   uint8_t em[64];
 };
@@ -78,9 +76,10 @@ struct PairLds {
   __attribute__((aligned(16))) uint8_t F[256];
   __attribute__((aligned(16))) uint8_t G[256];
   uint8_t boff[16];
-  uint64_t ring[kPRing];                          // claimed groups: slot n % kPRing holds (n + 1) << 32 | group once claim n of this workgroup is known
-  uint32_t want;                                  // claims asked for so far (the first wave to reach an iteration asks for the claim two iterations ahead)
-  uint32_t prog[kPWaves];                         // iteration every wave is in (a slot is not overwritten while a wave may still read it)
+  uint64_t base[2];                               // output base of the group before (two groups alternate)
+  uint32_t gq[4];                                 // ring of claimed groups (three in use)
+  uint32_t tot[2];
+  uint32_t wcnt[2][kPWaves], woff[2][kPWaves];    // rows of every wave's unit, and their exclusive sums inside the group
   PairWaveLds wv[kPWaves];
 };
 static_assert(sizeof(PairLds) <= 160 * 1024, "LDS");
@@ -233,37 +232,20 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   }
   if (tid == 0) {
     const uint32_t g0 = claimed(t0), g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1);
-    S.ring[0] = (1ull << 32) | g0; S.ring[1] = (2ull << 32) | g1;
-    for (uint32_t q = 2; q < kPRing; q++) S.ring[q] = 0ull;
-    S.want = 2u;
+    S.gq[0] = g0; S.gq[1] = g1;
   }
-  if (tid < kPWaves) S.prog[tid] = 0u;
   __syncthreads();
-  // From here on the waves of the workgroup do not meet again: every wave scans its own units (kPTpw consecutive wave-tiles of each
-  // group the workgroup claims), publishes their counts, resolves their bases and writes their rows by itself.
-  auto ring_get = [&](uint32_t n) -> uint32_t {                     // claim n of this workgroup (waits until the wave that asked for it has it)
-    uint64_t v;
-    uint32_t spins = 0;
-    for (;;) {
-      v = __hip_atomic_load(&S.ring[n % kPRing], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (static_cast<uint32_t>(v >> 32) == n + 1u) break;
-      if (++spins > kSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdLookback); return 0xFFFFFFFFu; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    return static_cast<uint32_t>(v);
-  };
 
   const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
 
-  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), TWO tiles ahead — across units too: with one window
-  // (4 KiB) in flight per wave a CU has 64 KiB on its way, and the device 16 MiB: what 4.4 TB/s need at the latency seen here (the
-  // filter alone ran at 0.24 ms per GiB that way).  Tile j of a unit lives in buffer j & 1.
-  u32x4 x[2][4];
-  uint32_t xprev[2] = {0u, 0u};
-  __amdgpu_buffer_rsrc_t rsrc_n[2];
-  int pre_n[2] = {0, 0};
-  auto issue_loads = [&](uint64_t g, int jj, int p) {
+  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead — across groups too.  (Two windows in
+  // flight were measured: no gain — the kernel is bound by the number of instructions it issues, not by the latency of its loads.)
+  u32x4 x[4];
+  uint32_t xprev = 0;
+  __amdgpu_buffer_rsrc_t rsrc_n;
+  int pre_n = 0;
+  auto issue_loads = [&](uint64_t g, int jj) {
     const uint64_t wtn = g * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + jj;      // a wave's unit: kPTpw consecutive wave-tiles
     const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
     int nrec = 0;
@@ -272,68 +254,24 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       nrec = rem >= static_cast<uint64_t>(kPWin) ? kPWin : static_cast<int>((rem + 3) & ~3ull);
     }
     const int pre = (nrec && lo) ? 16 : 0;
-    rsrc_n[p] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
-    pre_n[p] = pre;
+    rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
+    pre_n = pre;
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[p][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n[p], (lane + 64 * k) << 4, pre, 0);
-    xprev[p] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n[p], 0, pre ? 12 : nrec + pre, 0);
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (lane + 64 * k) << 4, pre, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, 0, pre ? 12 : nrec + pre, 0);
   };
-  issue_loads(static_cast<uint32_t>(S.ring[0]), 0, 0);
-  issue_loads(static_cast<uint32_t>(S.ring[0]), 1, 1);
+  issue_loads(S.gq[0], 0);
 
-  // Units scanned and not yet resolved, oldest first: the unit, its rows, the iteration it was scanned in (its row buffer).  The look-back
-  // makes every unit wait for all units in front of it — anywhere on the device — to be COUNTED; the waves drift apart by more than a
-  // unit's time, so a base is asked for kPDefer units late (one unit late: 0.067 ms of a 0.41 ms launch went into that wait).
-  uint64_t pu[kPDefer]; uint32_t pn[kPDefer], pit[kPDefer];
-#pragma unroll
-  for (uint32_t k = 0; k < kPDefer; k++) { pu[k] = ~0ull; pn[k] = 0; pit[k] = 0; }
-  auto finish_unit = [&](uint64_t u, uint32_t nrows, uint32_t buf, uint64_t lw) {   // base, inclusive sum, rows
-    if (CXG_PAIR_ABL & 8) return;
-    const uint64_t base = (u > 0 && !(CXG_PAIR_ABL & 32)) ? pair_resolve(a.status, a.err, u, lw, etag, lane0) : 0ull;
-    if (lane0 == 0) {
-      if (u > 0) __hip_atomic_store(a.status + u, kFlagInclusive | etag | (base + nrows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (u == a.ngroups * kPWaves - 1) *a.total = base + nrows;
-    }
-    if (a.out != nullptr && !(CXG_PAIR_ABL & 16)) {
-      const int64_t origin = a.base + static_cast<int64_t>(u * static_cast<uint64_t>(kWaveTile) * kPTpw);
-      const uint32_t n = nrows < static_cast<uint32_t>(kPRows) ? nrows : static_cast<uint32_t>(kPRows);
-      for (uint32_t i = lane0; i < n; i += 64)
-        if (base + i < a.cap) store_pair_nt(a.out + (base + i) * a.row_width, origin + L.rs[buf][i], origin + L.re[buf][i]);
-    }
-  };
-  uint32_t pend_n = 0xFFFFFFFFu, pend_t = 0;                        // a claim this wave asked for: its number and the ticket drawn for it
-  // The claim this wave asked for: published two tiles later — the ticket has had that long to come back, and the other waves want the
-  // claim at the top of their next iteration.
-  auto publish_pending = [&]() {
-    if (pend_n == 0xFFFFFFFFu) return;
-    uint32_t g = 0;
-    if (lane0 == 0) g = claimed(pend_t);
-    g = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(g)));
-    for (uint32_t spins = 0;; spins++) {                            // slot pend_n % kPRing was claim pend_n - kPRing: no wave may still be reading it
-      const uint32_t pr = __hip_atomic_load(&S.prog[lane0 & (kPWaves - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (__ballot(pr + kPRing <= pend_n + 1u) == 0ull) break;      // a wave in iteration p reads claims p and p + 1
-      if (spins > kSpinLimit) { if (lane0 == 0) raise_watchdog(a.err, kWdLookback); break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (lane0 == 0) __hip_atomic_store(&S.ring[pend_n % kPRing], (static_cast<uint64_t>(pend_n + 1u) << 32) | g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    pend_n = 0xFFFFFFFFu;
-  };
+  uint64_t prev = ~0ull;                                            // the group whose rows wait to be written
   for (uint32_t it = 0;; it++) {
-    const uint32_t b = it % (kPDefer + 1u);
-    publish_pending();                                              // (a claim asked for in an iteration that ended early)
-    if (lane0 == 0) __hip_atomic_store(&S.prog[wave], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint64_t group = ring_get(it);
-    const uint64_t next_group = ring_get(it + 1u);
+    const uint32_t b = it & 1u;
+    const uint64_t group = S.gq[it % 3u];
+    const uint64_t next_group = S.gq[(it + 1u) % 3u];
     const bool live = group < ngroups;
-    const uint64_t unit = group * kPWaves + static_cast<uint64_t>(wave);
-    if (live) {                                                     // the first wave to get here asks for claim it + 2
-      uint32_t old = 0;
-      if (lane0 == 0) old = atomicMax(&S.want, it + 3u);
-      old = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(old)));
-      if (old < it + 3u) { pend_n = it + 2u; if (lane0 == 0) pend_t = draw(); }
-    }
+    uint32_t n2 = 0;
     uint64_t lw = 0;
-    if (pu[0] != ~0ull && pu[0] > 0) lw = pair_status_load(a.status, static_cast<int64_t>(pu[0]) - 1 - lane0, etag);   // look-back of the oldest unit: words requested now, read behind the tiles
+    if (wave == kPWaves - 1 && live && lane0 == 0) n2 = draw();      // the group after next: the ticket is read in front of the barrier
+    if (wave == 0 && prev != ~0ull && prev > 0) lw = pair_status_load(a.status, static_cast<int64_t>(prev) - 1 - lane0, etag);   // look-back of the group before: words requested now, read behind the tiles
     uint32_t nrows_w = 0;                                           // wave-uniform
     // A wave-tile in two stages.  filter(j): pair lookups, candidate and synchronising bits, ownership, the owned candidates listed
     // in LDS.  verify(j): the candidates against the literals, FindAll order, rows.  The 16 bytes at each of the first 64 candidates
@@ -344,10 +282,9 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       asm volatile("" : "+v"(lane));                                // (scan_chain_wave.hip: no hoisted-and-spilled lane constants)
       const uint64_t wt = group * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + j;
       const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
-      const int p = j & 1;                                         // compile-time: the tile loop is unrolled
-      // the loads of the tile two ahead (the unit behind this one may lie anywhere in the haystack — a stolen claim —, also when this tile lies behind its end)
-      auto issue_next = [&]() { if (j + 2 < kPTpw) issue_loads(group, j + 2, p); else issue_loads(next_group, j + 2 - kPTpw, p); };
-      cx.ncand = 0; cx.rend = 0; cx.pre = 0; cx.prevb = -1; cx.rsrc = rsrc_n[p];
+      // the loads of the next tile (the unit behind this one may lie anywhere in the haystack — a stolen claim —, also when this tile lies behind its end)
+      auto issue_next = [&]() { if (j + 1 < kPTpw) issue_loads(group, j + 1); else issue_loads(next_group, 0); };
+      cx.ncand = 0; cx.rend = 0; cx.pre = 0; cx.prevb = -1; cx.rsrc = rsrc_n;
       if (tile_lo >= a.len) { issue_next(); return; }
       const uint64_t remaining = a.len - tile_lo;
       const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
@@ -357,14 +294,14 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       uint32_t ia[32];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const u32x4 v = x[p][k];
+        const u32x4 v = x[k];
         CXG_PAIR_ADDR(ia[8 * k + 0], v.x, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 1], v.x, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 2], v.y, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 3], v.y, 3, 1);
         CXG_PAIR_ADDR(ia[8 * k + 4], v.z, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 5], v.z, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 6], v.w, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 7], v.w, 3, 1);
       }
-      const uint32_t xprev_cur = xprev[p];
-      cx.rsrc = rsrc_n[p]; cx.pre = pre_n[p]; cx.rend = rend;
+      const uint32_t xprev_cur = xprev;
+      cx.rsrc = rsrc_n; cx.pre = pre_n; cx.rend = rend;
       cx.prevb = tile_lo > 0 ? static_cast<int32_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1;
-      issue_next();                                                // x[p][] is free from here on
+      issue_next();                                                // x[] is free from here on
       uint32_t ea[32];
 #pragma unroll
       for (int q = 0; q < 32; q++) ea[q] = (CXG_PAIR_ABL & 4) ? (ia[q] & 0x3Fu) : S.tab[ia[q]];
@@ -532,24 +469,43 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         request(j & 1, cx[j & 1], static_cast<uint32_t>(lane), c0, d0);
         if (j + 1 < kPTpw) filter(j + 1, (j + 1) & 1, cx[(j + 1) & 1]);
         verify(j, j & 1, cx[j & 1], c0, d0);
-        if (j == 1) publish_pending();
       }
     }
     if (nrows_w > static_cast<uint32_t>(kPRows)) fallback |= 16;
 
-    // ---- this unit: its count; the unit before: its base, its inclusive sum, its rows
-    if (live && lane0 == 0)
-      __hip_atomic_store(a.status + unit, (unit == 0 ? kFlagInclusive : kFlagAggregate) | etag | static_cast<uint64_t>(nrows_w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (pu[0] != ~0ull) finish_unit(pu[0], pn[0], pit[0] % (kPDefer + 1u), lw);
-#pragma unroll
-    for (uint32_t k = 0; k + 1 < kPDefer; k++) { pu[k] = pu[k + 1]; pn[k] = pn[k + 1]; pit[k] = pit[k + 1]; }
-    pu[kPDefer - 1] = live ? unit : ~0ull; pn[kPDefer - 1] = nrows_w; pit[kPDefer - 1] = it;
-    if (!live) {                                                    // no group left: the units still waiting, oldest first
-#pragma unroll
-      for (uint32_t k = 0; k < kPDefer; k++)
-        if (pu[k] != ~0ull) finish_unit(pu[k], pn[k], pit[k] % (kPDefer + 1u), pu[k] > 0 ? pair_status_load(a.status, static_cast<int64_t>(pu[k]) - 1 - lane0, etag) : 0ull);
-      break;
+    // ---- the group before: its base (wave 0), then — behind the barrier — its rows; this group: its count
+    if (live && lane0 == 0) S.wcnt[b][wave] = nrows_w;
+    if (wave == 0 && prev != ~0ull && !(CXG_PAIR_ABL & 8)) {
+      const uint64_t base = prev > 0 ? pair_resolve(a.status, a.err, prev, lw, etag, lane0) : 0ull;
+      if (lane0 == 0) {
+        const uint64_t incl = base + S.tot[b ^ 1u];
+        if (prev > 0) __hip_atomic_store(a.status + prev, kFlagInclusive | etag | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.base[b ^ 1u] = base;
+        if (prev == ngroups - 1) *a.total = incl;
+      }
     }
+    if (wave == kPWaves - 1 && live && lane0 == 0) S.gq[(it + 2u) % 3u] = claimed(n2);
+    __syncthreads();
+    if (live && wave == 0) {                                        // exclusive sums over the group's 16 units; the group's count is published
+      const uint32_t v = lane0 < kPWaves ? S.wcnt[b][lane0] : 0u;
+      const uint32_t incl = wave_inclusive_sum(v);
+      if (lane0 < kPWaves) S.woff[b][lane0] = incl - v;
+      if (lane0 == 63) {
+        S.tot[b] = incl;
+        __hip_atomic_store(a.status + group, (group == 0 ? kFlagInclusive : kFlagAggregate) | etag | static_cast<uint64_t>(incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (prev != ~0ull && a.out != nullptr && !(CXG_PAIR_ABL & 8)) {   // rows of the group before (buffers b ^ 1): every wave its own unit's
+      const uint32_t pbuf = b ^ 1u;
+      const uint64_t base = S.base[pbuf] + S.woff[pbuf][wave];
+      const int64_t origin = a.base + static_cast<int64_t>((prev * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile) * kPTpw);
+      const uint32_t nr = S.wcnt[pbuf][wave];
+      const uint32_t n = nr < static_cast<uint32_t>(kPRows) ? nr : static_cast<uint32_t>(kPRows);
+      for (uint32_t i = lane0; i < n; i += 64)
+        if (base + i < a.cap) store_pair_nt(a.out + (base + i) * a.row_width, origin + L.rs[pbuf][i], origin + L.re[pbuf][i]);
+    }
+    if (!live) break;
+    prev = group;
   }
   if (__ballot(edge_hit != 0) != 0ull) fallback |= 32;
   if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));
