@@ -239,28 +239,34 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
 
-  // window loads: four buffer_load_dwordx4 per lane (zeros past the end of input), one tile ahead — across groups too.  (Two windows in
-  // flight were measured: no gain — the kernel is bound by the number of instructions it issues, not by the latency of its loads.)
+  // Window loads: four buffer_load_dwordx4 per lane, one tile ahead — across groups too.  (Two windows in flight were measured: no gain —
+  // the kernel is bound by the number of instructions it issues, not by the latency of its loads.)  ONE buffer descriptor per unit
+  // (a wave's kPTpw consecutive tiles + the last one's halo, 16 bytes in front for the byte before the unit; zeros past the end of input):
+  // a tile costs one add, not a descriptor (the 64-bit tile arithmetic was ~70 scalar instructions of a tile's 730).
+  struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped)
+  auto make_unit = [&](uint64_t g) -> UnitGeo {
+    UnitGeo u;
+    const uint64_t ulo = (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw);
+    const bool any = g < ngroups && ulo < a.len;
+    const uint64_t rem64 = any ? a.len - ulo : 0ull;
+    u.rem = rem64 > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(rem64);
+    const int32_t span = u.rem < kWaveTile * kPTpw + kWaveHalo ? u.rem : kWaveTile * kPTpw + kWaveHalo;
+    u.pre = (any && ulo) ? 16 : 0;
+    u.nrec = ((span + 3) & ~3) + u.pre;
+    u.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (any ? ulo - u.pre : 0), 0, u.nrec, 0x00020000);
+    return u;
+  };
   u32x4 x[4];
   uint32_t xprev = 0;
-  __amdgpu_buffer_rsrc_t rsrc_n;
-  int pre_n = 0;
-  auto issue_loads = [&](uint64_t g, int jj) {
-    const uint64_t wtn = g * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + jj;      // a wave's unit: kPTpw consecutive wave-tiles
-    const uint64_t lo = wtn * static_cast<uint64_t>(kWaveTile);
-    int nrec = 0;
-    if (g < ngroups && lo < a.len) {
-      const uint64_t rem = a.len - lo;
-      nrec = rem >= static_cast<uint64_t>(kPWin) ? kPWin : static_cast<int>((rem + 3) & ~3ull);
-    }
-    const int pre = (nrec && lo) ? 16 : 0;
-    rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (nrec ? lo - pre : 0), 0, nrec + pre, 0x00020000);
-    pre_n = pre;
+  auto issue_loads = [&](const UnitGeo& u, int jj) {
+    const int32_t soff = u.pre + jj * kWaveTile;
+    const int32_t vo = (lane << 4) + soff;
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_n, (lane + 64 * k) << 4, pre, 0);
-    xprev = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, 0, pre ? 12 : nrec + pre, 0);
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(u.rsrc, vo + (k << 10), 0, 0);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, soff ? soff - 4 : u.nrec, 0, 0);   // (the haystack's first tile: no byte in front, an offset outside the descriptor reads 0)
   };
-  issue_loads(S.gq[0], 0);
+  UnitGeo cur = make_unit(S.gq[0]), nxt = cur;
+  issue_loads(cur, 0);
 
   uint64_t prev = ~0ull;                                            // the group whose rows wait to be written
   for (uint32_t it = 0;; it++) {
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     const uint64_t group = S.gq[it % 3u];
     const uint64_t next_group = S.gq[(it + 1u) % 3u];
     const bool live = group < ngroups;
+    if (it) cur = nxt;                                              // (built when this unit's first window was asked for)
     uint32_t n2 = 0;
     uint64_t lw = 0;
     if (wave == kPWaves - 1 && live && lane0 == 0) n2 = draw();      // the group after next: the ticket is read in front of the barrier
@@ -276,18 +283,16 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     // A wave-tile in two stages.  filter(j): pair lookups, candidate and synchronising bits, ownership, the owned candidates listed
     // in LDS.  verify(j): the candidates against the literals, FindAll order, rows.  The 16 bytes at each of the first 64 candidates
     // are REQUESTED (global memory: an L2 round trip) in front of filter(j + 1) and compared behind it.
-    struct TileCtx { __amdgpu_buffer_rsrc_t rsrc; int pre; int32_t prevb; int32_t rend; uint32_t ncand; };
+    struct TileCtx { int32_t soff; int32_t prevb; int32_t rend; uint32_t ncand; };   // soff: the tile's first byte in the unit's descriptor
     auto filter = [&](int j, uint32_t cb_, TileCtx& cx) {
       lane = lane0;
       asm volatile("" : "+v"(lane));                                // (scan_chain_wave.hip: no hoisted-and-spilled lane constants)
-      const uint64_t wt = group * (kPWaves * kPTpw) + static_cast<uint64_t>(wave) * kPTpw + j;
-      const uint64_t tile_lo = wt * static_cast<uint64_t>(kWaveTile);
       // the loads of the next tile (the unit behind this one may lie anywhere in the haystack — a stolen claim —, also when this tile lies behind its end)
-      auto issue_next = [&]() { if (j + 1 < kPTpw) issue_loads(group, j + 1); else issue_loads(next_group, 0); };
-      cx.ncand = 0; cx.rend = 0; cx.pre = 0; cx.prevb = -1; cx.rsrc = rsrc_n;
-      if (tile_lo >= a.len) { issue_next(); return; }
-      const uint64_t remaining = a.len - tile_lo;
-      const int32_t rend = remaining > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(remaining);
+      auto issue_next = [&]() { if (j + 1 < kPTpw) issue_loads(cur, j + 1); else { nxt = make_unit(next_group); issue_loads(nxt, 0); } };
+      const int32_t rend = cur.rem - j * kWaveTile;
+      const bool first_tile = j == 0 && cur.pre == 0;               // the haystack's first tile (or a unit behind its end)
+      cx.ncand = 0; cx.rend = rend; cx.soff = cur.pre + j * kWaveTile; cx.prevb = -1;
+      if (rend <= 0) { issue_next(); return; }
       const int32_t stage = rend < kPWin ? rend : kPWin;
       const uint32_t two = 2u;
       // ---- A: one lookup per byte pair, the entries of a piece's eight pairs in two registers, transposed through LDS
@@ -298,9 +303,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         CXG_PAIR_ADDR(ia[8 * k + 0], v.x, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 1], v.x, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 2], v.y, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 3], v.y, 3, 1);
         CXG_PAIR_ADDR(ia[8 * k + 4], v.z, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 5], v.z, 3, 1); CXG_PAIR_ADDR(ia[8 * k + 6], v.w, 1, 0); CXG_PAIR_ADDR(ia[8 * k + 7], v.w, 3, 1);
       }
-      const uint32_t xprev_cur = xprev;
-      cx.rsrc = rsrc_n; cx.pre = pre_n; cx.rend = rend;
-      cx.prevb = tile_lo > 0 ? static_cast<int32_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev_cur))) >> 24) : -1;
+      cx.prevb = first_tile ? -1 : static_cast<int32_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev))) >> 24);
       issue_next();                                                // x[] is free from here on
       uint32_t ea[32];
 #pragma unroll
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       }
       // ---- O: ownership bounds (scan_teddy_wave.hip)
       int32_t zA = -1, zB = kPFar;
-      if (tile_lo > 0) {
+      if (!first_tile) {
         if (!(S.T[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
           const unsigned long long bz = __ballot(Z != 0ull);
           if (bz) {
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       c = 0; d = u32x4{0u, 0u, 0u, 0u};
       if (r < cx.ncand) {
         c = L.cpos[cb_][r];
-        d = __builtin_amdgcn_raw_buffer_load_b128(cx.rsrc, (c & ~3) + cx.pre, 0, 0);
+        d = __builtin_amdgcn_raw_buffer_load_b128(cur.rsrc, (c & ~3) + cx.soff, 0, 0);
       }
     };
     auto verify = [&](int j, uint32_t cb_, const TileCtx& cx, int32_t c0, u32x4 d0) {
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       const uint32_t ncand = cx.ncand;
       const int32_t rend = cx.rend;
       if (ncand) {
-        auto wbyte = [&](int32_t i) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b8(cx.rsrc, i + cx.pre, 0, 0); };   // window byte i (0 past the data)
+        auto wbyte = [&](int32_t i) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b8(cur.rsrc, i + cx.soff, 0, 0); };   // window byte i (0 past the data)
         int32_t cur_end = -1;                                       // wave-uniform: end of the last emitted match
         for (uint32_t r0 = 0; r0 < ncand; r0 += 64) {
           int32_t c = c0, mlen = 0;
