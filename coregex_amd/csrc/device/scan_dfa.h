@@ -21,9 +21,9 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerWave = CXG_TPW;
 constexpr int kDenseTilesPerWave = 2;          // chain kernel on match-dense input: 256 rows of buffer per wave-tile instead of 64
 constexpr uint64_t kWaveGroupBytes = static_cast<uint64_t>(kWaveTile) * kWavesPerBlock * kTilesPerWave;   // 120 KiB per workgroup
-// scan_teddy_pair.hip: one workgroup of 16 waves per CU (its pair table takes 64 KiB of LDS), groups of 16 x 4 wave-tiles = 240 KiB
+// scan_teddy_pair.hip: one workgroup of 16 waves per CU (its pair table takes 64 KiB of LDS), groups of 16 x 8 wave-tiles = 480 KiB
 constexpr int kPairWaves = 16;
-constexpr int kPairTilesPerWave = 4;
+constexpr int kPairTilesPerWave = 8;
 constexpr uint32_t kPairCtrStride = 32;       // uint32 between two group counters (128 bytes)
 constexpr uint64_t kPairGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairTilesPerWave;
 #ifndef CXG_CC_TILES

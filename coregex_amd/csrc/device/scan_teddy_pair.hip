@@ -50,8 +50,8 @@ namespace {
 
 constexpr int kPWaves = kPairWaves;               // 16
 constexpr int kPThreads = kPWaves * 64;           // 1024
-constexpr int kPTpw = kPairTilesPerWave;          // 4: 64 wave-tiles per group (the prefix over a group's tiles is one wave wide)
-constexpr int kPRows = 192;                       // rows buffered per wave per group
+constexpr int kPTpw = kPairTilesPerWave;          // 8 consecutive wave-tiles per wave and group: a unit
+constexpr int kPRows = 320;                       // rows buffered per wave per group (8 tiles; scan_teddy_wave.hip's figure)
 constexpr int kPCands = 192;                      // owned candidates listed per wave-tile
 constexpr int kPAuxMax = 2048;
 #ifndef CXG_PAIR_ABL
@@ -59,7 +59,7 @@ constexpr int kPAuxMax = 2048;
 #endif
 constexpr int32_t kPFar = 1 << 20;
 constexpr int kPWin = kWaveTile + kWaveHalo;      // 4096
-static_assert(kPWaves * kPTpw == 64, "the group prefix is one wave wide");
+static_assert(kPTpw % 2 == 0 && kWaveTile * kPTpw + kWaveHalo + 256 < 65536, "rows are kept as 16-bit offsets into the unit");
 
 struct PairWaveLds {
   uint32_t w[512];                                // pair entries of the window: piece p (16 bytes) -> dwords 2p, 2p + 1
@@ -72,7 +72,7 @@ struct PairLds {
   uint8_t tab[65536];                             // at LDS address 0: the pair is the address
   uint32_t T[256];                                // scan_teddy_wave.hip's table: A | B << 8 | C << 16 | sync << 24 (verification, ownership)
   __attribute__((aligned(16))) uint8_t aux[kPAuxMax];
-  uint32_t lit[32][6];
+  __attribute__((aligned(16))) uint32_t litx[64][8];   // verification slot k (bucket-major, ids ascending: order[]): the literal's first 12 bytes as three dwords, m0 | m1, m2 (their masks), length, id
   __attribute__((aligned(16))) uint8_t F[256];
   __attribute__((aligned(16))) uint8_t G[256];
   uint8_t boff[16];
@@ -196,18 +196,21 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     atomicOr(&S.T[b3], 0x10000u << t_bucket[tid]);
     if (fold && b3 >= 'a' && b3 <= 'z') atomicOr(&S.T[b3 ^ 0x20u], 0x10000u << t_bucket[tid]);
   }
-  if (static_cast<uint32_t>(tid) < nlits && tid < 32) {             // verification compares dwords
-    const uint8_t* lb = t_bytes + t_off[tid];
-    const uint32_t len = t_lens[tid];
+  if (static_cast<uint32_t>(tid) < nlits) {                          // verification compares dwords: slot tid of the verification order
+    const uint32_t id = t_order[tid];
+    const uint8_t* lb = t_bytes + t_off[id];
+    const uint32_t len = t_lens[id];
+    uint32_t Lw[3], M[3];
     for (uint32_t k = 0; k < 3; k++) {
-      uint32_t Lw = 0, M = 0;
+      Lw[k] = 0; M[k] = 0;
       for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) {
         const uint32_t c = lb[4 * k + b];
-        Lw |= c << (8 * b);
-        M |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);
+        Lw[k] |= c << (8 * b);
+        M[k] |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);
       }
-      S.lit[tid][k] = Lw; S.lit[tid][3 + k] = M;
     }
+    S.litx[tid][0] = Lw[0]; S.litx[tid][1] = Lw[1]; S.litx[tid][2] = Lw[2]; S.litx[tid][3] = M[0];
+    S.litx[tid][4] = M[1]; S.litx[tid][5] = M[2]; S.litx[tid][6] = len; S.litx[tid][7] = id;
   }
   if (tid < 16) {
     uint32_t first = nlits;
@@ -238,6 +241,18 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
 
   const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
+  // bucket b's verification slots are [boff[b], boff[b + 1]): the nine bytes in two uniform words (a lane's bucket picks its pair by a shift)
+  uint64_t boff_lo = 0, boff_hi = 0;
+  uint32_t maxbucket = 0;
+  for (uint32_t bq = 0; bq < 8; bq++) {
+    const uint32_t k0 = S.boff[bq], k1 = S.boff[bq + 1];
+    boff_lo |= static_cast<uint64_t>(k0) << (8 * bq); boff_hi |= static_cast<uint64_t>(k1) << (8 * bq);
+    maxbucket = k1 - k0 > maxbucket ? k1 - k0 : maxbucket;
+  }
+  boff_lo = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_lo >> 32))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_lo)));
+  boff_hi = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_hi >> 32))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_hi)));
+  maxbucket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(maxbucket)));
+  const bool short_lits = ax->maxlen <= 12u;                         // every literal is compared whole by the three masked dwords
 
   // Window loads: four buffer_load_dwordx4 per lane, one tile ahead — across groups too.  (Two windows in flight were measured: no gain —
   // the kernel is bound by the number of instructions it issues, not by the latency of its loads.)  ONE buffer descriptor per unit
@@ -396,30 +411,62 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
           int32_t c = c0, mlen = 0;
           u32x4 d = d0;
           if (r0) request(cb_, cx, r0 + static_cast<uint32_t>(lane), c, d);
-          if (r0 + static_cast<uint32_t>(lane) < ncand) {
+          {
             // the 12 bytes at the candidate as three dwords (v_alignbit over the 16 loaded)
+            const bool have = r0 + static_cast<uint32_t>(lane) < ncand;
             const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
             const uint32_t w0 = __builtin_amdgcn_alignbit(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbit(d.z, d.y, sh), w2 = __builtin_amdgcn_alignbit(d.w, d.z, sh);
             uint32_t mask = (S.T[w0 & 0xFFu] & 0xFFu) & ((S.T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((S.T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
-            while (mask && !mlen) {                                 // buckets low to high, ids ascending (verifyBucket)
-              const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
-              mask &= mask - 1;
-              for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
-                const uint32_t id = t_order[k];
-                const int32_t len = t_lens[id];
-                if (c + len > rend) continue;
-                if (id < 32u) {
-                  const uint32_t diff = ((w0 ^ S.lit[id][0]) & S.lit[id][3]) | ((w1 ^ S.lit[id][1]) & S.lit[id][4]) | ((w2 ^ S.lit[id][2]) & S.lit[id][5]);
-                  if (diff != 0u) continue;
-                  if (len <= 12) { mlen = len; continue; }
-                }
-                const uint8_t* lit = t_bytes + t_off[id];
-                int32_t q = id < 32u ? 12 : 0;                     // Fat Teddy ids >= 32 and the tail of long literals: bytes
+            if (!have) mask = 0u;
+            // the first hit bucket, without a divergent branch: maxbucket (uniform) steps over its slots, a lane past its bucket's end compares slot 0 in vain.
+            // (Buckets low to high, ids ascending — verifyBucket; the set is prefix-free: at most one literal matches at a position.)
+            bool tail = false;                                       // a literal longer than 12 bytes agreed on its first 12
+            uint32_t tail_k = 0;
+            {
+              const uint32_t bk8 = mask ? 8u * static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;
+              const uint32_t kbeg = static_cast<uint32_t>(boff_lo >> bk8) & 0xFFu, kend = mask ? static_cast<uint32_t>(boff_hi >> bk8) & 0xFFu : 0u;
+              for (uint32_t i = 0; i < maxbucket; i++) {
+                const uint32_t k = kbeg + i;
+                const bool valid = k < kend;
+                const uint32_t* lx = S.litx[valid ? k : 0u];
+                const u32x4 la = *reinterpret_cast<const u32x4*>(lx), lb4 = *reinterpret_cast<const u32x4*>(lx + 4);
+                const uint32_t diff = ((w0 ^ la.x) & la.w) | ((w1 ^ la.y) & lb4.x) | ((w2 ^ la.z) & lb4.y);
+                const int32_t len = static_cast<int32_t>(lb4.z);
+                const bool hit = valid && diff == 0u && c + len <= rend && mlen == 0;
+                if (short_lits) mlen = hit ? len : mlen;
+                else if (hit) { if (len <= 12) mlen = len; else if (!tail) { tail = true; tail_k = k; } }
+              }
+              mask &= mask - 1u;
+            }
+            if (!short_lits && __ballot(tail) != 0ull) {           // the bytes behind the twelfth
+              if (tail && !mlen) {
+                const uint32_t* lx = S.litx[tail_k];
+                const int32_t len = static_cast<int32_t>(lx[6]);
+                const uint8_t* lit = t_bytes + t_off[lx[7]];
+                int32_t q = 12;
                 while (q < len && same(wbyte(c + q), lit[q])) q++;
                 if (q == len) mlen = len;
               }
             }
-            if (mlen && (look_pre | look_post) != 0u) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
+            if (__ballot(mask != 0u && mlen == 0) != 0ull) {        // fingerprints of more than one bucket met at this position, and the first bucket's literals did not match
+              while (mask && !mlen) {
+                const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
+                mask &= mask - 1;
+                for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
+                  const uint32_t* lx = S.litx[k];
+                  const int32_t len = static_cast<int32_t>(lx[6]);
+                  if (c + len > rend) continue;
+                  const uint32_t diff = ((w0 ^ lx[0]) & lx[3]) | ((w1 ^ lx[1]) & lx[4]) | ((w2 ^ lx[2]) & lx[5]);
+                  if (diff != 0u) continue;
+                  if (len <= 12) { mlen = len; continue; }
+                  const uint8_t* lit = t_bytes + t_off[lx[7]];
+                  int32_t q = 12;
+                  while (q < len && same(wbyte(c + q), lit[q])) q++;
+                  if (q == len) mlen = len;
+                }
+              }
+            }
+            if ((look_pre | look_post) != 0u && mlen) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
               const int pbv = c > 0 ? static_cast<int>(wbyte(c - 1)) : cx.prevb;
               const int nb = c + mlen < rend ? (c + mlen < kPWin ? static_cast<int>(wbyte(c + mlen)) : -2) : -1;
               if (nb == -2) { edge_hit = 1; mlen = 0; }               // the byte behind the occurrence lies behind the window: hand the scan over
@@ -464,14 +511,16 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       nrows_w += emitted_here;
     };
     if (live) {
-      TileCtx cx[2];
-      filter(0, 0u, cx[0]);
-#pragma unroll
-      for (int j = 0; j < kPTpw; j++) {
+      TileCtx cxa, cxb;                                             // even / odd tiles (the loop body is two tiles: no indexed registers)
+      filter(0, 0u, cxa);
+      for (int j = 0; j < kPTpw; j += 2) {
         int32_t c0; u32x4 d0;
-        request(j & 1, cx[j & 1], static_cast<uint32_t>(lane), c0, d0);
-        if (j + 1 < kPTpw) filter(j + 1, (j + 1) & 1, cx[(j + 1) & 1]);
-        verify(j, j & 1, cx[j & 1], c0, d0);
+        request(0u, cxa, static_cast<uint32_t>(lane), c0, d0);
+        filter(j + 1, 1u, cxb);
+        verify(j, 0u, cxa, c0, d0);
+        request(1u, cxb, static_cast<uint32_t>(lane), c0, d0);
+        if (j + 2 < kPTpw) filter(j + 2, 0u, cxa);
+        verify(j + 1, 1u, cxb, c0, d0);
       }
     }
     if (nrows_w > static_cast<uint32_t>(kPRows)) fallback |= 16;
