@@ -63,8 +63,8 @@ static_assert(kPTpw % 2 == 0 && kWaveTile * kPTpw + kWaveHalo + 256 < 65536, "ro
 
 struct PairWaveLds {
   uint32_t w[512];                                // pair entries of the window: piece p (16 bytes) -> dwords 2p, 2p + 1
-  uint16_t cpos[2][kPCands];                      // owned candidates of the tile being verified and of the tile being filtered
-  uint16_t rs[2][kPRows], re[2][kPRows];          // rows of this unit (relative to its first byte) and of the unit of the group before
+  uint16_t cpos[2][kPCands + 2];                      // owned candidates of the tile being verified and of the tile being filtered
+  uint16_t rs[2][kPRows + 2], re[2][kPRows + 2];          // rows of this unit (relative to its first byte) and of the unit of the group before
   uint16_t ce[64];
   uint8_t em[64];
 };
@@ -320,6 +320,8 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       }
       cx.prevb = first_tile ? -1 : static_cast<int32_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(xprev))) >> 24);
       issue_next();                                                // x[] is free from here on
+      // (ds_read_u8_d16 / _d16_hi would put two entries into the halves of one register without VALU packing — measured: with SRAM ECC
+      // on, a D16 load clears the other half of its register on this device, the kernel found nothing.)
       uint32_t ea[32];
 #pragma unroll
       for (int q = 0; q < 32; q++) ea[q] = (CXG_PAIR_ABL & 4) ? (ia[q] & 0x3Fu) : S.tab[ia[q]];
@@ -383,22 +385,20 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       if (ncand) {
         uint32_t idx = incl - nc_lane;
         uint64_t cb = Co;
-        while (cb) {
-          const int bit = __builtin_ctzll(cb);
+        while (__ballot(cb != 0ull) != 0ull) {                      // a uniform loop: a lane without a candidate left writes the dump slot
+          const bool has = cb != 0ull && idx < static_cast<uint32_t>(kPCands);
+          const int bit = __builtin_ctzll(cb | (1ull << 63));
+          L.cpos[cb_][has ? idx : static_cast<uint32_t>(kPCands)] = static_cast<uint16_t>(64 * lane + bit);
+          idx += cb != 0ull ? 1u : 0u;
           cb &= cb - 1;
-          if (idx < static_cast<uint32_t>(kPCands)) L.cpos[cb_][idx] = static_cast<uint16_t>(64 * lane + bit);
-          idx++;
         }
         wave_lds_sync();
       }
     };
     // the 16 bytes at the dword in front of candidate r of the list (requested; compared in verify)
     auto request = [&](uint32_t cb_, const TileCtx& cx, uint32_t r, int32_t& c, u32x4& d) {
-      c = 0; d = u32x4{0u, 0u, 0u, 0u};
-      if (r < cx.ncand) {
-        c = L.cpos[cb_][r];
-        d = __builtin_amdgcn_raw_buffer_load_b128(cur.rsrc, (c & ~3) + cx.soff, 0, 0);
-      }
+      c = L.cpos[cb_][r < static_cast<uint32_t>(kPCands) ? r : static_cast<uint32_t>(kPCands)];   // (a lane behind the list reads a stale entry: its load stays inside the descriptor, verify() ignores it)
+      d = __builtin_amdgcn_raw_buffer_load_b128(cur.rsrc, (c & ~3) + cx.soff, 0, 0);
     };
     auto verify = [&](int j, uint32_t cb_, const TileCtx& cx, int32_t c0, u32x4 d0) {
       uint32_t emitted_here = 0;
@@ -500,9 +500,10 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
             const int last = 63 - __builtin_clzll(em_mask);
             cur_end = __builtin_amdgcn_readlane(e, last);
             const uint32_t n_em = static_cast<uint32_t>(__popcll(em_mask));
-            if (emit) {
+            {
               const uint32_t r = nrows_w + emitted_here + static_cast<uint32_t>(__popcll(em_mask & ((1ull << lane) - 1ull)));
-              if (r < static_cast<uint32_t>(kPRows)) { L.rs[b][r] = static_cast<uint16_t>(j * kWaveTile + c); L.re[b][r] = static_cast<uint16_t>(j * kWaveTile + e); }
+              const uint32_t slot = (emit && r < static_cast<uint32_t>(kPRows)) ? r : static_cast<uint32_t>(kPRows);   // (dump slot)
+              L.rs[b][slot] = static_cast<uint16_t>(j * kWaveTile + c); L.re[b][slot] = static_cast<uint16_t>(j * kWaveTile + e);
             }
             emitted_here += n_em;
           }
