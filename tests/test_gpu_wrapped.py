@@ -1,4 +1,4 @@
-"""Literals between assertions on the device (round 4): `k_scan_teddy_wave` with the assertions in its verification, against the
+"""Literals between assertions on the device (round 4): `k_scan_teddy_wave` / `k_scan_teddy_pair` (round 6) with the assertions in their verification, against the
 oracle; the transducer as its fallback (dense haystacks)."""
 import random
 
@@ -28,7 +28,7 @@ def test_rows(pat, oracle):
                 d = torch.from_numpy(hay.copy()).cuda()
                 cnt = rx.find_all_device(d.data_ptr(), hay.size, timing=t)
                 assert cnt == len(exp), (pat, n, sparse)
-                served += t.kernels[0] == 7
+                served += t.kernels[0] in (7, 21)                   # the literal kernels: scan_teddy_wave.hip, scan_teddy_pair.hip (round 6)
             got = rx.find_all_index(hay)
             if got.shape != exp.shape or not np.array_equal(got, exp):                # (what differs, for the log)
                 miss = sorted(set(map(tuple, exp.tolist())) - set(map(tuple, got.tolist())))[:4]
@@ -48,7 +48,7 @@ def test_error_on_the_config_1_corpus(oracle):
         out = torch.empty((len(exp) + 4, 2), dtype=torch.int64, device="cuda")
         t = cx.Timing()
         assert rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), len(exp) + 4, timing=t) == len(exp)
-        assert np.array_equal(out[:len(exp)].cpu().numpy(), exp) and routed(t.kernels == [7], t.kernels)
+        assert np.array_equal(out[:len(exp)].cpu().numpy(), exp) and routed(t.kernels in ([7], [21]), t.kernels)
 
 
 @pytest.mark.parametrize("pat", FOLDED)
@@ -75,7 +75,7 @@ def test_case_insensitive_alternations(pat, oracle):
                 assert dense and rx.fsm_image() is None                # the literal kernel gave up and the pattern has no transducer
                 continue
             assert cnt == len(exp), (pat, n, dense)
-            served += t.kernels[0] == 7
+            served += t.kernels[0] in (7, 21)                   # the literal kernels: scan_teddy_wave.hip, scan_teddy_pair.hip (round 6)
             got = rx.find_all_index(hay)
             assert got.shape == exp.shape and np.array_equal(got, exp), (pat, n, dense, bytes(hay[:60]), got[:4].tolist(), exp[:4].tolist())
             assert np.array_equal(rx.find_all_index(hay, 3), exp[:3])
@@ -96,4 +96,4 @@ def test_case_insensitive_keywords_on_the_log_corpus(oracle):
     out = torch.empty((len(exp) + 4, 2), dtype=torch.int64, device="cuda")
     t = cx.Timing()
     assert rx.find_all_device(d.data_ptr(), hay.size, out.data_ptr(), len(exp) + 4, timing=t) == len(exp) and len(exp) > 1000
-    assert np.array_equal(out[:len(exp)].cpu().numpy(), exp) and routed(t.kernels == [7], t.kernels)
+    assert np.array_equal(out[:len(exp)].cpu().numpy(), exp) and routed(t.kernels in ([7], [21]), t.kernels)
