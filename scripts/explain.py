@@ -21,7 +21,7 @@ def first_kernel(rx, sub=False):
     aux_len = struct.unpack_from("<I", blob, 60)[0]
     fsm = rx.fsm_image(sub) is not None
     if kind == 4:
-        return "k_scan_teddy_wave" if aux_len <= 2048 else "k_scan_teddy"
+        return "k_scan_teddy_pair (k_scan_teddy_wave behind it: FindAll with an n, match-dense input)" if aux_len <= 2048 else "k_scan_teddy"
     if kind == 3:
         return "k_scan_charclass_wave" if flags & 64 else "k_scan_charclass"
     def fsm_name():                                             # round 6: shallow machines start on the lean kernel (FsmHeader: depth, nk, direct_off)
