@@ -54,6 +54,12 @@ constexpr int kPTpw = kPairTilesPerWave;          // 8 consecutive wave-tiles pe
 constexpr int kPRows = 320;                       // rows buffered per wave per group (8 tiles; scan_teddy_wave.hip's figure)
 constexpr int kPCands = 192;                      // owned candidates listed per wave-tile
 constexpr int kPAuxMax = 2048;
+#ifndef CXG_PAIR_WAUX
+#define CXG_PAIR_WAUX 0                   // cache policy bits of the window loads / of the verifier's requests (A/B builds: 1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef CXG_PAIR_VAUX
+#define CXG_PAIR_VAUX 2                   // (nt: the requests miss the L2 either way — measured —, a nontemporal miss fetches half as much: FETCH_SIZE 1.50 -> 1.26 x the haystack, same time)
+#endif
 #ifndef CXG_PAIR_ABL
 #define CXG_PAIR_ABL 0                    // timing experiments (scripts/build_variant.sh; WRONG rows): 1 no verification, 2 no candidate list either, 4 no table lookups, 8 no look-back / row write
 #endif
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     const int32_t soff = u.pre + jj * kWaveTile;
     const int32_t vo = (lane << 4) + soff;
 #pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(u.rsrc, vo + (k << 10), 0, 0);
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(u.rsrc, vo + (k << 10), 0, CXG_PAIR_WAUX);
     xprev = __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, soff ? soff - 4 : u.nrec, 0, 0);   // (the haystack's first tile: no byte in front, an offset outside the descriptor reads 0)
   };
   UnitGeo cur = make_unit(S.gq[0]), nxt = cur;
@@ -369,7 +375,8 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         }
       }
       {
-        const uint64_t Zb = Z & word_range(lane, kWaveTile - 1, kPWin - 1);
+        // (bits 3839 .. 4095 of the window: the top bit of lane 59's word, all of the lanes behind it)
+        const uint64_t Zb = lane > 59 ? Z : (lane == 59 ? Z & (1ull << 63) : 0ull);
         const unsigned long long bzb = __ballot(Zb != 0ull);
         if (bzb) { const int Lz = __builtin_ctzll(bzb); zB = 64 * Lz + static_cast<int32_t>(__builtin_ctzll(readlane64(Zb, Lz))); }
         else if (stage != rend) { zB = -2; fallback |= 1; }
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     // the 16 bytes at the dword in front of candidate r of the list (requested; compared in verify)
     auto request = [&](uint32_t cb_, const TileCtx& cx, uint32_t r, int32_t& c, u32x4& d) {
       c = L.cpos[cb_][r < static_cast<uint32_t>(kPCands) ? r : static_cast<uint32_t>(kPCands)];   // (a lane behind the list reads a stale entry: its load stays inside the descriptor, verify() ignores it)
-      d = __builtin_amdgcn_raw_buffer_load_b128(cur.rsrc, (c & ~3) + cx.soff, 0, 0);
+      if (CXG_PAIR_ABL & 64) d = u32x4{0u, 0u, 0u, 0u}; else d = __builtin_amdgcn_raw_buffer_load_b128(cur.rsrc, (c & ~3) + cx.soff, 0, CXG_PAIR_VAUX);
     };
     auto verify = [&](int j, uint32_t cb_, const TileCtx& cx, int32_t c0, u32x4 d0) {
       uint32_t emitted_here = 0;
