@@ -42,7 +42,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.pf_status = nullptr; a.pf_ticket = nullptr; a.pf_ncounters = 0;   // (set per launch by the fields programs' branch below)
-  a.pair_ctr = nullptr; a.pair_seq = 0; a.pair_nctr = 0;
+  a.pair_ctr = nullptr; a.pair_seq = 0; a.pair_nctr = 0; a.pair_nbig = 0;
   std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
   a.cc_nr = a.cc_neg = a.cc_pairs = 0; std::memset(a.cc_lo, 0, 4); std::memset(a.cc_hi, 0, 4);
   a.u32_rows = t_u32Rows ? 1u : 0u;
@@ -143,7 +143,11 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   // literal sets: the pair kernel (scan_teddy_pair.hip, round 6) for the spans of a plain call — FindAll's n lives in the grouped kernels'
   // look-back, and match-dense input (a row buffer overflowed before) or a fallback flag of the pair kernel itself stay on the wave kernel
   static const bool pairOk = getenv("CXG_NO_TEDDY_PAIR") == nullptr;
-  if (gen == 7 && pairOk && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
+  // ... and for LONG haystacks: the pair kernel builds a 64 KiB table per workgroup (20 us before its first byte against the wave kernel's 10)
+  // and one workgroup per CU works through 480 KiB groups — 0.25 us per MiB against 0.37, ahead from ~300 MiB (r06_c64_pair_tail.txt:
+  // 256 MiB 122 against 119 us, 512 MiB 182 against 213, 1 GiB 314 against 402).  CXG_PAIR_MIN_BYTES moves the border (the GPU test tier sets 0).
+  static const uint64_t pairMinBytes = getenv("CXG_PAIR_MIN_BYTES") ? strtoull(getenv("CXG_PAIR_MIN_BYTES"), nullptr, 10) : (320ull << 20);
+  if (gen == 7 && pairOk && len >= pairMinBytes && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
   // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:
@@ -162,7 +166,16 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
-  if (gen == 12) a.ngroups = (len + cxgdev::kPairGroupBytes - 1) / cxgdev::kPairGroupBytes;
+  if (gen == 12) {                                                 // big groups, and small ones for the last stretch (one big group per CU, or the whole of a short haystack)
+    static int pcus = 0;
+    if (pcus == 0) { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); pcus = n > 0 ? n : 256; }
+    static const uint64_t tailEighths = getenv("CXG_PAIR_TAIL8") ? static_cast<uint64_t>(atoi(getenv("CXG_PAIR_TAIL8"))) : 1u;   // (the small-group stretch in eighths of one big group per CU; measured 0 .. 16: profiles/r06_c64_pair_tail.txt)
+    const uint64_t tail = static_cast<uint64_t>(pcus) * cxgdev::kPairGroupBytes * tailEighths / 8u;
+    const uint64_t nbig = len > tail ? (len - tail) / cxgdev::kPairGroupBytes : 0;
+    const uint64_t rest = len - nbig * cxgdev::kPairGroupBytes;
+    a.pair_nbig = static_cast<uint32_t>(nbig);
+    a.ngroups = nbig + (rest + cxgdev::kPairSmallGroupBytes - 1) / cxgdev::kPairSmallGroupBytes;
+  }
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
     a.tiles_per_wave = (gen == 10 && fsmMode >= 2) ? 1u : static_cast<uint32_t>(cxgdev::kDenseTilesPerWave);   // transducer kernel, modes 2 and 3: one tile, 1 024 / 2 048 rows

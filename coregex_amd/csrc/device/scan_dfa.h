@@ -26,6 +26,8 @@ constexpr int kPairWaves = 16;
 constexpr int kPairTilesPerWave = 8;
 constexpr uint32_t kPairCtrStride = 32;       // uint32 between two group counters (128 bytes)
 constexpr uint64_t kPairGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairTilesPerWave;
+constexpr int kPairSmallTilesPerWave = 2;     // ... and SMALL groups of 16 x 2 wave-tiles = 120 KiB behind them: the last stretch of a haystack (one big group per CU), so that the
+constexpr uint64_t kPairSmallGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairSmallTilesPerWave;   // launch does not end with half of the CUs idle for a big group's time
 #ifndef CXG_CC_TILES
 #define CXG_CC_TILES 4
 #endif
@@ -103,6 +105,7 @@ struct ScanArgs {
   uint32_t cc_nr, cc_neg, cc_pairs;   // scan_charclass_wave.hip: walk.hpp CharClassAux copied by the host (kernel arguments: no dependent
   uint8_t cc_lo[4], cc_hi[4];         // loads from the program image before the first window can be requested)
   uint32_t* pair_ctr;   // scan_teddy_pair.hip: [2][8] group counters, kPairCtrStride words apart; set pair_seq & 1 is this launch's, the kernel zeroes the other
+  uint32_t pair_nbig;   // groups [0, pair_nbig) are big (kPairGroupBytes), the rest small (kPairSmallGroupBytes), laid out behind them
   uint32_t pair_seq, pair_nctr;   // pair_nctr: 8 (workgroup b claims from counter b & 7 first), or 1: strict ticket order (after a watchdog hit)
   uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };

@@ -264,14 +264,20 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   // the kernel is bound by the number of instructions it issues, not by the latency of its loads.)  ONE buffer descriptor per unit
   // (a wave's kPTpw consecutive tiles + the last one's halo, 16 bytes in front for the byte before the unit; zeros past the end of input):
   // a tile costs one add, not a descriptor (the 64-bit tile arithmetic was ~70 scalar instructions of a tile's 730).
-  struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped)
+  struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; int32_t tiles; uint64_t lo; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped); tiles: 8 in a big group, 2 in a small one
   auto make_unit = [&](uint64_t g) -> UnitGeo {
     UnitGeo u;
-    const uint64_t ulo = (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw);
+    // groups [0, nbig) are big (8 tiles per wave); small ones (2 tiles per wave) cover the haystack's last stretch behind them
+    const uint64_t nbig = a.pair_nbig;
+    const bool big = g < nbig;
+    u.tiles = big ? kPTpw : kPairSmallTilesPerWave;
+    const uint64_t ulo = big ? (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw)
+                             : nbig * kPairGroupBytes + ((g - nbig) * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPairSmallTilesPerWave);
+    u.lo = ulo;
     const bool any = g < ngroups && ulo < a.len;
     const uint64_t rem64 = any ? a.len - ulo : 0ull;
     u.rem = rem64 > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(rem64);
-    const int32_t span = u.rem < kWaveTile * kPTpw + kWaveHalo ? u.rem : kWaveTile * kPTpw + kWaveHalo;
+    const int32_t span = u.rem < kWaveTile * u.tiles + kWaveHalo ? u.rem : kWaveTile * u.tiles + kWaveHalo;
     u.pre = (any && ulo) ? 16 : 0;
     u.nrec = ((span + 3) & ~3) + u.pre;
     u.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (any ? ulo - u.pre : 0), 0, u.nrec, 0x00020000);
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   UnitGeo cur = make_unit(S.gq[0]), nxt = cur;
   issue_loads(cur, 0);
 
-  uint64_t prev = ~0ull;                                            // the group whose rows wait to be written
+  uint64_t prev = ~0ull, prev_lo = 0;                               // the group whose rows wait to be written, and where this wave's unit of it begins
   for (uint32_t it = 0;; it++) {
     const uint32_t b = it & 1u;
     const uint64_t group = S.gq[it % 3u];
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       lane = lane0;
       asm volatile("" : "+v"(lane));                                // (scan_chain_wave.hip: no hoisted-and-spilled lane constants)
       // the loads of the next tile (the unit behind this one may lie anywhere in the haystack — a stolen claim —, also when this tile lies behind its end)
-      auto issue_next = [&]() { if (j + 1 < kPTpw) issue_loads(cur, j + 1); else { nxt = make_unit(next_group); issue_loads(nxt, 0); } };
+      auto issue_next = [&]() { if (j + 1 < cur.tiles) issue_loads(cur, j + 1); else { nxt = make_unit(next_group); issue_loads(nxt, 0); } };
       const int32_t rend = cur.rem - j * kWaveTile;
       const bool first_tile = j == 0 && cur.pre == 0;               // the haystack's first tile (or a unit behind its end)
       cx.ncand = 0; cx.rend = rend; cx.soff = cur.pre + j * kWaveTile; cx.prevb = -1;
@@ -521,13 +527,13 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     if (live) {
       TileCtx cxa, cxb;                                             // even / odd tiles (the loop body is two tiles: no indexed registers)
       filter(0, 0u, cxa);
-      for (int j = 0; j < kPTpw; j += 2) {
+      for (int j = 0; j < cur.tiles; j += 2) {
         int32_t c0; u32x4 d0;
         request(0u, cxa, static_cast<uint32_t>(lane), c0, d0);
         filter(j + 1, 1u, cxb);
         verify(j, 0u, cxa, c0, d0);
         request(1u, cxb, static_cast<uint32_t>(lane), c0, d0);
-        if (j + 2 < kPTpw) filter(j + 2, 0u, cxa);
+        if (j + 2 < cur.tiles) filter(j + 2, 0u, cxa);
         verify(j + 1, 1u, cxb, c0, d0);
       }
     }
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     if (prev != ~0ull && a.out != nullptr && !(CXG_PAIR_ABL & 8)) {   // rows of the group before (buffers b ^ 1): every wave its own unit's
       const uint32_t pbuf = b ^ 1u;
       const uint64_t base = S.base[pbuf] + S.woff[pbuf][wave];
-      const int64_t origin = a.base + static_cast<int64_t>((prev * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile) * kPTpw);
+      const int64_t origin = a.base + static_cast<int64_t>(prev_lo);
       const uint32_t nr = S.wcnt[pbuf][wave];
       const uint32_t n = nr < static_cast<uint32_t>(kPRows) ? nr : static_cast<uint32_t>(kPRows);
       for (uint32_t i = lane0; i < n; i += 64)
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     }
     if (!live) break;
     prev = group;
+    prev_lo = cur.lo;
   }
   if (__ballot(edge_hit != 0) != 0ull) fallback |= 32;
   if (fallback != 0 && lane0 == 0) raise_err(a.err, 8u | (fallback << 8));

@@ -1,6 +1,7 @@
 """Stress (GPU box): the pair kernel against the wave kernel (the same call with FindAll's n set: capi_ladder.hip keeps such calls on
 scan_teddy_wave.hip) on haystacks of many lengths, thousands of launches; prints every disagreement."""
-import random, sys, time
+import os, random, sys, time
+os.environ.setdefault("CXG_PAIR_MIN_BYTES", "0")      # (by default the pair kernel serves haystacks from 320 MiB on)
 import numpy as np, torch
 sys.path.insert(0, "tests")
 import coregex_amd as cx

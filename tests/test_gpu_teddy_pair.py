@@ -1,6 +1,6 @@
 """The pair kernel for literal sets (round 6, `scan_teddy_pair.hip`): one fingerprint lookup per byte PAIR, persistent 16-wave workgroups
 with claimed groups.  Rows against the oracle at every edge of its geometry (wave-tile 3 840 B, window 4 096 B, unit = 8 tiles = 30 720 B,
-group = 16 units = 491 520 B), for literals of 3 / 4 / 5+ bytes at even and odd offsets, folded sets, assertions, Fat sets and literals
+group = 16 units = 491 520 B; small groups of 2-tile units behind them), for literals of 3 / 4 / 5+ bytes at even and odd offsets, folded sets, assertions, Fat sets and literals
 longer than the 12 bytes the verifier compares at once; and against the wave kernel (`scan_teddy_wave.hip`, which FindAll's n keeps a
 call on) over hundreds of haystack lengths — the claims of a launch are handed out in an order that depends on timing."""
 import random
@@ -14,6 +14,7 @@ from routing import routed
 pytestmark = pytest.mark.gpu
 
 TILE, WIN, UNIT, GROUP = 3840, 4096, 3840 * 8, 3840 * 8 * 16
+USMALL, GSMALL = 3840 * 2, 3840 * 2 * 16       # the last stretch of a haystack (one big group per CU: all of a short one) is cut into small groups
 K_PAIR, K_WAVE = 21, 7
 
 
@@ -49,7 +50,7 @@ def test_edges_of_tile_window_unit_and_group(oracle):
     n = GROUP + UNIT + 9000
     base = np.full(n, ord(" "), dtype=np.uint8)
     spots = []
-    for edge in (64, TILE, WIN, 2 * TILE, UNIT, UNIT + TILE, 8 * UNIT, GROUP, GROUP + UNIT):
+    for edge in (64, TILE, WIN, 2 * TILE, USMALL, USMALL + TILE, 3 * USMALL, GSMALL, GSMALL + USMALL, UNIT, UNIT + TILE, 8 * UNIT, GROUP, GROUP + UNIT):
         spots += list(range(edge - 9, edge + 3))
     for lit in (b"spider", b"error", b"crawler"):
         ip = np.frombuffer(lit, dtype=np.uint8)
@@ -149,3 +150,22 @@ def test_config_3_on_the_synthetic_corpus_against_the_wave_kernel():
     assert rx.find_all_device(buf.ptr, n, out_b.data_ptr(), cnt + 8, n=1 << 40) == cnt
     assert torch.equal(out_a[:cnt], out_b[:cnt]) and cnt > 1_000_000
     assert routed(list(t.kernels) == [K_PAIR], list(t.kernels), t.fallback_reason)
+
+
+def test_default_routing_by_length():
+    """Without CXG_PAIR_MIN_BYTES (this tier sets 0): literal sets run on the wave kernel below 320 MiB, on the pair kernel from there on."""
+    import os, subprocess, sys
+    code = ("import coregex_amd as cx\n"
+            "n = 384 << 20\n"
+            "buf = cx.DeviceBuffer(n); buf.fill_synth(3, 0xC0FFEE03, 0)\n"
+            "rx = cx.compile('error|warning|fatal|critical')\n"
+            "t = cx.Timing(); a = rx.find_all_device(buf.ptr, 64 << 20, timing=t); ka = list(t.kernels)\n"
+            "b = rx.find_all_device(buf.ptr, n, timing=t); kb = list(t.kernels)\n"
+            "print('ROUTE', ka, kb, a, b)\n")
+    env = dict(os.environ)
+    env.pop("CXG_PAIR_MIN_BYTES", None)
+    env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("ROUTE")]
+    assert line, out.stderr[-2000:]
+    assert "[7] [21]" in line[0], line[0]
