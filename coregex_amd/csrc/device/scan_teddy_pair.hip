@@ -76,12 +76,12 @@ struct PairWaveLds {
 };
 struct PairLds {
   uint8_t tab[65536];                             // at LDS address 0: the pair is the address
-  uint32_t T[256];                                // scan_teddy_wave.hip's table: A | B << 8 | C << 16 | sync << 24 (verification, ownership)
+  uint32_t FB[256];                               // by byte value: the verification slots [beg, end) of the literals that BEGIN with it (beg | end << 8), and sync << 24
+  uint32_t maxrun;                                // most literals sharing a first byte
   __attribute__((aligned(16))) uint8_t aux[kPAuxMax];
-  __attribute__((aligned(16))) uint32_t litx[64][8];   // verification slot k (bucket-major, ids ascending: order[]): the literal's first 12 bytes as three dwords, m0 | m1, m2 (their masks), length, id
+  __attribute__((aligned(16))) uint32_t litx[64][8];   // verification slot k (literals ordered by first byte, then id): the literal's first 12 bytes as three dwords, m0 | m1, m2 (their masks), length, id
   __attribute__((aligned(16))) uint8_t F[256];
   __attribute__((aligned(16))) uint8_t G[256];
-  uint8_t boff[16];
   uint64_t base[2];                               // output base of the group before (two groups alternate)
   uint32_t gq[4];                                 // ring of claimed groups (three in use)
   uint32_t tot[2];
@@ -157,15 +157,13 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   };
   uint32_t t0 = 0, t1 = 0;
   if (tid == 0) { t0 = draw(); t1 = draw(); }                     // (consumed behind the table build)
+  if (tid == 0) S.maxrun = 0u;
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kPAuxMax / 4; i += kPThreads)
     reinterpret_cast<uint32_t*>(S.aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
   __syncthreads();
   const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(S.aux);
-  const uint16_t* t_ab = reinterpret_cast<const uint16_t*>(S.aux + ax->ab_off);
-  const uint8_t* t_order = S.aux + ax->order_off;
   const uint8_t* t_lens = S.aux + ax->lens_off;
-  const uint8_t* t_bucket = S.aux + ax->bucket_off;
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(S.aux + ax->off_off);
   const uint8_t* t_bytes = S.aux + ax->bytes_off;
   const uint32_t nlits = ax->nlits;
@@ -175,7 +173,13 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   if (tid < 256) {
     const uint32_t b = static_cast<uint32_t>(tid);
     const uint32_t sync = ((a.blob + h->info_off)[tid] & kInfoSync) ? 1u : 0u;
-    S.T[tid] = static_cast<uint32_t>(t_ab[tid]) | (sync ? 0x1000000u : 0u);
+    {                                                               // slots of the literals that begin with this byte (a folded set keeps lower-case literals: an upper-case letter asks as its lower-case twin)
+      const uint32_t nb = (fold && b >= 'A' && b <= 'Z') ? (b | 0x20u) : b;
+      uint32_t beg = 0, cnt = 0;
+      for (uint32_t id = 0; id < nlits; id++) { const uint32_t c0 = t_bytes[t_off[id]]; beg += c0 < nb ? 1u : 0u; cnt += c0 == nb ? 1u : 0u; }
+      S.FB[tid] = beg | ((beg + cnt) << 8) | (sync ? 0x1000000u : 0u);
+      if (cnt) atomicMax(&S.maxrun, cnt);
+    }
     uint32_t f = sync << 6, g = sync << 7;
     for (uint32_t id = 0; id < nlits; id++) {
       const uint8_t* lb = t_bytes + t_off[id];
@@ -197,15 +201,12 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
 #pragma unroll
     for (uint32_t q = 0; q < 16; q++) row[(((tid & 3) * 16u) + q) ^ (b1 & 63u)] = f1[q] | g4;
   }
-  if (static_cast<uint32_t>(tid) < nlits) {                          // third-byte masks of T (scan_teddy_wave.hip)
-    const uint32_t b3 = t_bytes[t_off[tid] + 2];
-    atomicOr(&S.T[b3], 0x10000u << t_bucket[tid]);
-    if (fold && b3 >= 'a' && b3 <= 'z') atomicOr(&S.T[b3 ^ 0x20u], 0x10000u << t_bucket[tid]);
-  }
-  if (static_cast<uint32_t>(tid) < nlits) {                          // verification compares dwords: slot tid of the verification order
-    const uint32_t id = t_order[tid];
+  if (static_cast<uint32_t>(tid) < nlits) {                          // verification compares dwords: literal tid goes to the slot of its rank by (first byte, id)
+    const uint32_t id = static_cast<uint32_t>(tid);
     const uint8_t* lb = t_bytes + t_off[id];
     const uint32_t len = t_lens[id];
+    uint32_t slot = 0;
+    for (uint32_t o = 0; o < nlits; o++) { const uint32_t co = t_bytes[t_off[o]]; slot += (co < lb[0] || (co == lb[0] && o < id)) ? 1u : 0u; }
     uint32_t Lw[3], M[3];
     for (uint32_t k = 0; k < 3; k++) {
       Lw[k] = 0; M[k] = 0;
@@ -215,13 +216,8 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         M[k] |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);
       }
     }
-    S.litx[tid][0] = Lw[0]; S.litx[tid][1] = Lw[1]; S.litx[tid][2] = Lw[2]; S.litx[tid][3] = M[0];
-    S.litx[tid][4] = M[1]; S.litx[tid][5] = M[2]; S.litx[tid][6] = len; S.litx[tid][7] = id;
-  }
-  if (tid < 16) {
-    uint32_t first = nlits;
-    for (uint32_t k = nlits; k-- > 0;) if (t_bucket[t_order[k]] >= static_cast<uint32_t>(tid)) first = k;
-    S.boff[tid] = static_cast<uint8_t>(first);
+    S.litx[slot][0] = Lw[0]; S.litx[slot][1] = Lw[1]; S.litx[slot][2] = Lw[2]; S.litx[slot][3] = M[0];
+    S.litx[slot][4] = M[1]; S.litx[slot][5] = M[2]; S.litx[slot][6] = len; S.litx[slot][7] = id;
   }
   __syncthreads();
   if (static_cast<uint32_t>(tid) < nlits) {                          // the exact pairs: AB (bit 0), BC (3), CD (2), DE (5)
@@ -247,17 +243,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
 
   const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
-  // bucket b's verification slots are [boff[b], boff[b + 1]): the nine bytes in two uniform words (a lane's bucket picks its pair by a shift)
-  uint64_t boff_lo = 0, boff_hi = 0;
-  uint32_t maxbucket = 0;
-  for (uint32_t bq = 0; bq < 8; bq++) {
-    const uint32_t k0 = S.boff[bq], k1 = S.boff[bq + 1];
-    boff_lo |= static_cast<uint64_t>(k0) << (8 * bq); boff_hi |= static_cast<uint64_t>(k1) << (8 * bq);
-    maxbucket = k1 - k0 > maxbucket ? k1 - k0 : maxbucket;
-  }
-  boff_lo = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_lo >> 32))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_lo)));
-  boff_hi = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_hi >> 32))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(boff_hi)));
-  maxbucket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(maxbucket)));
+  const uint32_t maxrun = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.maxrun)));
   const bool short_lits = ax->maxlen <= 12u;                         // every literal is compared whole by the three masked dwords
 
   // Window loads: four buffer_load_dwordx4 per lane, one tile ahead — across groups too.  (Two windows in flight were measured: no gain —
@@ -340,8 +326,9 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         uint2 o;
-        o.x = ea[8 * k] | (ea[8 * k + 1] << 8) | (ea[8 * k + 2] << 16) | (ea[8 * k + 3] << 24);
-        o.y = ea[8 * k + 4] | (ea[8 * k + 5] << 8) | (ea[8 * k + 6] << 16) | (ea[8 * k + 7] << 24);
+        // three instructions per dword: v_perm_b32 takes the low bytes of two registers, v_lshl_or joins the halves
+        o.x = __builtin_amdgcn_perm(ea[8 * k + 1], ea[8 * k], 0x0C0C0400u) | (__builtin_amdgcn_perm(ea[8 * k + 3], ea[8 * k + 2], 0x0C0C0400u) << 16);
+        o.y = __builtin_amdgcn_perm(ea[8 * k + 5], ea[8 * k + 4], 0x0C0C0400u) | (__builtin_amdgcn_perm(ea[8 * k + 7], ea[8 * k + 6], 0x0C0C0400u) << 16);
         *reinterpret_cast<uint2*>(&L.w[2 * (lane + 64 * k)]) = o;
       }
       wave_lds_sync();
@@ -370,7 +357,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       // ---- O: ownership bounds (scan_teddy_wave.hip)
       int32_t zA = -1, zB = kPFar;
       if (!first_tile) {
-        if (!(S.T[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
+        if (!(S.FB[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
           const unsigned long long bz = __ballot(Z != 0ull);
           if (bz) {
             const int Lz = __builtin_ctzll(bz);
@@ -429,55 +416,35 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
             const bool have = r0 + static_cast<uint32_t>(lane) < ncand;
             const uint32_t sh = (static_cast<uint32_t>(c) & 3u) * 8u;
             const uint32_t w0 = __builtin_amdgcn_alignbit(d.y, d.x, sh), w1 = __builtin_amdgcn_alignbit(d.z, d.y, sh), w2 = __builtin_amdgcn_alignbit(d.w, d.z, sh);
-            uint32_t mask = (S.T[w0 & 0xFFu] & 0xFFu) & ((S.T[(w0 >> 8) & 0xFFu] >> 8) & 0xFFu) & ((S.T[(w0 >> 16) & 0xFFu] >> 16) & 0xFFu);
-            if (!have) mask = 0u;
-            // the first hit bucket, without a divergent branch: maxbucket (uniform) steps over its slots, a lane past its bucket's end compares slot 0 in vain.
-            // (Buckets low to high, ids ascending — verifyBucket; the set is prefix-free: at most one literal matches at a position.)
+            // The slots of the literals that begin with the candidate's first byte, without a divergent branch: maxrun (uniform) steps, a lane
+            // past its range compares slot 0 in vain.  (The reference verifies bucket by bucket, ids ascending — verifyBucket; the set is
+            // prefix-free: at most one literal matches at a position, the order cannot be observed.)
+            const uint32_t fb = S.FB[w0 & 0xFFu];
+            const uint32_t kbeg = fb & 0xFFu, kend = have ? (fb >> 8) & 0xFFu : 0u;
             bool tail = false;                                       // a literal longer than 12 bytes agreed on its first 12
-            uint32_t tail_k = 0;
-            {
-              const uint32_t bk8 = mask ? 8u * static_cast<uint32_t>(__builtin_ctz(mask)) : 0u;
-              const uint32_t kbeg = static_cast<uint32_t>(boff_lo >> bk8) & 0xFFu, kend = mask ? static_cast<uint32_t>(boff_hi >> bk8) & 0xFFu : 0u;
-              for (uint32_t i = 0; i < maxbucket; i++) {
-                const uint32_t k = kbeg + i;
-                const bool valid = k < kend;
-                const uint32_t* lx = S.litx[valid ? k : 0u];
-                const u32x4 la = *reinterpret_cast<const u32x4*>(lx), lb4 = *reinterpret_cast<const u32x4*>(lx + 4);
-                const uint32_t diff = ((w0 ^ la.x) & la.w) | ((w1 ^ la.y) & lb4.x) | ((w2 ^ la.z) & lb4.y);
-                const int32_t len = static_cast<int32_t>(lb4.z);
-                const bool hit = valid && diff == 0u && c + len <= rend && mlen == 0;
-                if (short_lits) mlen = hit ? len : mlen;
-                else if (hit) { if (len <= 12) mlen = len; else if (!tail) { tail = true; tail_k = k; } }
-              }
-              mask &= mask - 1u;
+            for (uint32_t i = 0; i < maxrun; i++) {
+              const uint32_t k = kbeg + i;
+              const bool valid = k < kend;
+              const uint32_t* lx = S.litx[valid ? k : 0u];
+              const u32x4 la = *reinterpret_cast<const u32x4*>(lx), lb4 = *reinterpret_cast<const u32x4*>(lx + 4);
+              const uint32_t diff = ((w0 ^ la.x) & la.w) | ((w1 ^ la.y) & lb4.x) | ((w2 ^ la.z) & lb4.y);
+              const int32_t len = static_cast<int32_t>(lb4.z);
+              const bool hit = valid && diff == 0u && c + len <= rend;
+              if (short_lits) mlen = hit ? len : mlen;
+              else { mlen = (hit && len <= 12) ? len : mlen; tail = tail || (hit && len > 12); }
             }
-            if (!short_lits && __ballot(tail) != 0ull) {           // the bytes behind the twelfth
-              if (tail && !mlen) {
-                const uint32_t* lx = S.litx[tail_k];
-                const int32_t len = static_cast<int32_t>(lx[6]);
-                const uint8_t* lit = t_bytes + t_off[lx[7]];
-                int32_t q = 12;
-                while (q < len && same(wbyte(c + q), lit[q])) q++;
-                if (q == len) mlen = len;
-              }
-            }
-            if (__ballot(mask != 0u && mlen == 0) != 0ull) {        // fingerprints of more than one bucket met at this position, and the first bucket's literals did not match
-              while (mask && !mlen) {
-                const uint32_t bk = static_cast<uint32_t>(__builtin_ctz(mask));
-                mask &= mask - 1;
-                for (uint32_t k = S.boff[bk]; k < S.boff[bk + 1] && !mlen; k++) {
+            if (!short_lits && __ballot(tail && mlen == 0) != 0ull) {   // the bytes behind the twelfth, of every literal of the range that agreed so far
+              if (tail && !mlen)
+                for (uint32_t k = kbeg; k < kend && !mlen; k++) {
                   const uint32_t* lx = S.litx[k];
                   const int32_t len = static_cast<int32_t>(lx[6]);
-                  if (c + len > rend) continue;
-                  const uint32_t diff = ((w0 ^ lx[0]) & lx[3]) | ((w1 ^ lx[1]) & lx[4]) | ((w2 ^ lx[2]) & lx[5]);
-                  if (diff != 0u) continue;
-                  if (len <= 12) { mlen = len; continue; }
+                  if (len <= 12 || c + len > rend) continue;
+                  if ((((w0 ^ lx[0]) & lx[3]) | ((w1 ^ lx[1]) & lx[4]) | ((w2 ^ lx[2]) & lx[5])) != 0u) continue;
                   const uint8_t* lit = t_bytes + t_off[lx[7]];
                   int32_t q = 12;
                   while (q < len && same(wbyte(c + q), lit[q])) q++;
                   if (q == len) mlen = len;
                 }
-              }
             }
             if ((look_pre | look_post) != 0u && mlen) {             // the assertions around the occurrence (checkLook, nfa/pikevm.go:1646-1674)
               const int pbv = c > 0 ? static_cast<int>(wbyte(c - 1)) : cx.prevb;
