@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   // once that is exhausted, the others in turn.  (One counter serves ~20 returning atomics per microsecond: a GiB has 4 370 groups.)
   const uint32_t nctr = a.pair_nctr, cls = blockIdx.x & (nctr - 1u);
   const uint32_t ngroups32 = static_cast<uint32_t>(a.ngroups);
+  const uint64_t ngroups = a.ngroups;
   uint32_t* const ctr = a.pair_ctr + (a.pair_seq & 1u) * (8u * kPairCtrStride);
   if (blockIdx.x == 0 && tid < 8) a.pair_ctr[((a.pair_seq + 1u) & 1u) * (8u * kPairCtrStride) + static_cast<uint32_t>(tid) * kPairCtrStride] = 0u;   // the next launch's set
   auto draw = [&]() -> uint32_t { return __hip_atomic_fetch_add(ctr + cls * kPairCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -161,7 +162,47 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kPAuxMax / 4; i += kPThreads)
     reinterpret_cast<uint32_t*>(S.aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
+  if (tid == 0) {                                                   // (the tickets have had the image's load to come back)
+    const uint32_t g0 = claimed(t0), g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1);
+    S.gq[0] = g0; S.gq[1] = g1;
+  }
   __syncthreads();
+  // (The first window is asked for HERE, in front of the table build: its latency hides behind it.)
+  // Window loads: four buffer_load_dwordx4 per lane, one tile ahead — across groups too.  (Two windows in flight were measured: no gain —
+  // the kernel is bound by the number of instructions it issues, not by the latency of its loads.)  ONE buffer descriptor per unit
+  // (a wave's kPTpw consecutive tiles + the last one's halo, 16 bytes in front for the byte before the unit; zeros past the end of input):
+  // a tile costs one add, not a descriptor (the 64-bit tile arithmetic was ~70 scalar instructions of a tile's 730).
+  struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; int32_t tiles; uint64_t lo; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped); tiles: 8 in a big group, 2 in a small one
+  auto make_unit = [&](uint64_t g) -> UnitGeo {
+    UnitGeo u;
+    // groups [0, nbig) are big (8 tiles per wave); small ones (2 tiles per wave) cover the haystack's last stretch behind them
+    const uint64_t nbig = a.pair_nbig;
+    const bool big = g < nbig;
+    u.tiles = big ? kPTpw : kPairSmallTilesPerWave;
+    const uint64_t ulo = big ? (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw)
+                             : nbig * kPairGroupBytes + ((g - nbig) * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPairSmallTilesPerWave);
+    u.lo = ulo;
+    const bool any = g < ngroups && ulo < a.len;
+    const uint64_t rem64 = any ? a.len - ulo : 0ull;
+    u.rem = rem64 > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(rem64);
+    const int32_t span = u.rem < kWaveTile * u.tiles + kWaveHalo ? u.rem : kWaveTile * u.tiles + kWaveHalo;
+    u.pre = (any && ulo) ? 16 : 0;
+    u.nrec = ((span + 3) & ~3) + u.pre;
+    u.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (any ? ulo - u.pre : 0), 0, u.nrec, 0x00020000);
+    return u;
+  };
+  u32x4 x[4];
+  uint32_t xprev = 0;
+  auto issue_loads = [&](const UnitGeo& u, int jj) {
+    const int32_t soff = u.pre + jj * kWaveTile;
+    const int32_t vo = (lane << 4) + soff;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(u.rsrc, vo + (k << 10), 0, CXG_PAIR_WAUX);
+    xprev = __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, soff ? soff - 4 : u.nrec, 0, 0);   // (the haystack's first tile: no byte in front, an offset outside the descriptor reads 0)
+  };
+  UnitGeo cur = make_unit(S.gq[0]), nxt = cur;
+  issue_loads(cur, 0);
+
   const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(S.aux);
   const uint8_t* t_lens = S.aux + ax->lens_off;
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(S.aux + ax->off_off);
@@ -235,51 +276,11 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
         }
     }
   }
-  if (tid == 0) {
-    const uint32_t g0 = claimed(t0), g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1);
-    S.gq[0] = g0; S.gq[1] = g1;
-  }
   __syncthreads();
 
-  const uint64_t ngroups = a.ngroups;
   uint32_t fallback = 0, edge_hit = 0;
   const uint32_t maxrun = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.maxrun)));
   const bool short_lits = ax->maxlen <= 12u;                         // every literal is compared whole by the three masked dwords
-
-  // Window loads: four buffer_load_dwordx4 per lane, one tile ahead — across groups too.  (Two windows in flight were measured: no gain —
-  // the kernel is bound by the number of instructions it issues, not by the latency of its loads.)  ONE buffer descriptor per unit
-  // (a wave's kPTpw consecutive tiles + the last one's halo, 16 bytes in front for the byte before the unit; zeros past the end of input):
-  // a tile costs one add, not a descriptor (the 64-bit tile arithmetic was ~70 scalar instructions of a tile's 730).
-  struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; int32_t tiles; uint64_t lo; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped); tiles: 8 in a big group, 2 in a small one
-  auto make_unit = [&](uint64_t g) -> UnitGeo {
-    UnitGeo u;
-    // groups [0, nbig) are big (8 tiles per wave); small ones (2 tiles per wave) cover the haystack's last stretch behind them
-    const uint64_t nbig = a.pair_nbig;
-    const bool big = g < nbig;
-    u.tiles = big ? kPTpw : kPairSmallTilesPerWave;
-    const uint64_t ulo = big ? (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw)
-                             : nbig * kPairGroupBytes + ((g - nbig) * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPairSmallTilesPerWave);
-    u.lo = ulo;
-    const bool any = g < ngroups && ulo < a.len;
-    const uint64_t rem64 = any ? a.len - ulo : 0ull;
-    u.rem = rem64 > 0x7FFF0000ull ? 0x7FFF0000 : static_cast<int32_t>(rem64);
-    const int32_t span = u.rem < kWaveTile * u.tiles + kWaveHalo ? u.rem : kWaveTile * u.tiles + kWaveHalo;
-    u.pre = (any && ulo) ? 16 : 0;
-    u.nrec = ((span + 3) & ~3) + u.pre;
-    u.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(a.hay) + (any ? ulo - u.pre : 0), 0, u.nrec, 0x00020000);
-    return u;
-  };
-  u32x4 x[4];
-  uint32_t xprev = 0;
-  auto issue_loads = [&](const UnitGeo& u, int jj) {
-    const int32_t soff = u.pre + jj * kWaveTile;
-    const int32_t vo = (lane << 4) + soff;
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_raw_buffer_load_b128(u.rsrc, vo + (k << 10), 0, CXG_PAIR_WAUX);
-    xprev = __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, soff ? soff - 4 : u.nrec, 0, 0);   // (the haystack's first tile: no byte in front, an offset outside the descriptor reads 0)
-  };
-  UnitGeo cur = make_unit(S.gq[0]), nxt = cur;
-  issue_loads(cur, 0);
 
   uint64_t prev = ~0ull, prev_lo = 0;                               // the group whose rows wait to be written, and where this wave's unit of it begins
   for (uint32_t it = 0;; it++) {
