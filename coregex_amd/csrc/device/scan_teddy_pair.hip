@@ -4,7 +4,8 @@
 // Reference semantics kept (meta/find_indices.go:925-951 -> prefilter.Teddy.FindMatch, prefilter/teddy.go:391-444,
 // verifyBucket :532-550; FindAll advance meta/findall.go:267-275): the next match is at the first fingerprint candidate at or
 // after `pos` at which a literal of a hit bucket compares equal; the search resumes at its end.  Any superset of the true
-// match starts is a valid candidate set — candidates are verified exactly, in the bucket / id order of scan_teddy_wave.hip.
+// match starts is a valid candidate set — candidates are verified exactly; the set is prefix-free, so at most one literal
+// matches at a position and the order in which literals are tried (here: by first byte, then id) cannot be observed.
 //
 // Why pairs.  scan_teddy_wave.hip pays four instructions per haystack byte for its filter (address, LDS lookup, two SDWA
 // ANDs) and 1.4 more to gather the flags into bits: 350 of a wave-tile's 750 instructions, and the kernel is bound by
@@ -20,20 +21,24 @@
 // both at once as W_k & (W_k+1 >> 2) & (W_k+2 >> 4) & 3 — on four pairs per instruction, because the entries of four pairs
 // sit in the bytes of one register.  A five-byte fingerprint of exact pairs: on BASELINE config 3 (16 literals) 20.6
 // candidates per 3 840-byte tile against 15.8 matches (the three-byte, eight-bucket fingerprint of scan_teddy_wave.hip: 21.8).
-// Per 64 bytes of a lane: 32 lookups + 32 index extractions + 24 packs, then 5 instructions per 8 bytes to combine and
-// 2 v_dot4 per 8 bytes to make the candidate and synchronising bits dense — ~190 instead of ~420.
+// Per 64 bytes of a lane: 32 lookups + 64 address instructions (the bank swizzle, pair_addr below) + 24 packs, then 5
+// instructions per 8 bytes to combine and 2 v_dot4 per 8 bytes to make the candidate and synchronising bits dense.
 //
-// The table is 64 KiB of LDS, so a CU holds ONE workgroup: 16 waves, and the grid is persistent — groups of 64 wave-tiles
-// (240 KiB of haystack) are CLAIMED through one atomic counter, two tickets ahead.  A workgroup that holds group g only ever
-// waits for groups < g, which are held by running workgroups: forward progress does not depend on co-residency or on the
-// order of dispatch.  The table is built once per workgroup.  The rows of a group are ordered
-// with the decoupled look-back of block_common.hpp, deferred by one group: a group's count is published when its tiles are
-// done, its base is resolved (wave 0, the status loads issued a group earlier) and its rows are written while the next
-// group's windows are in flight — nobody waits for the look-back.
+// The table is 64 KiB of LDS, so a CU holds ONE workgroup: 16 waves, and the grid is persistent.  GROUPS — 16 units of 8
+// consecutive wave-tiles (480 KiB), and small ones of 2-tile units for the haystack's last stretch — are CLAIMED through
+// atomic counters, two claims ahead (the ticket is drawn by one lane a group early; this file is compiled with
+// -amdgpu-atomic-optimizer-strategy=None: the optimizer's wave reduction waited for the ticket, and for every window load
+// in flight, on the spot).  A workgroup that holds group g only ever waits for groups < g, which are held by running
+// workgroups: forward progress does not depend on co-residency or on the order of dispatch.  The
+// table is built once per workgroup.  A wave scans one unit per group behind ONE buffer descriptor, in a two-tile loop body:
+// filter(j + 1) runs between the REQUEST of the 16 bytes at each candidate of tile j (global memory; there is no room for an
+// LDS copy of the window) and their comparison.  The rows of a group are ordered with the decoupled look-back of
+// block_common.hpp, deferred by one group: a group's count is published behind the iteration's one barrier, its base is
+// resolved by wave 0 a group later (the status words requested a group earlier), every wave writes its own unit's rows then.
 //
-// Window, ownership (synchronising bytes), candidate ranking, verification and FindAll order are those of
-// scan_teddy_wave.hip; the verifier reads the candidate's bytes from global memory (L2 hits: the window was just loaded)
-// instead of an LDS copy of the window.
+// Window, ownership (synchronising bytes), candidate ranking and FindAll order are those of scan_teddy_wave.hip.  The kernel
+// is bound by the number of instructions it issues (four waves per SIMD: instruction types hardly overlap) — hence the
+// dump slots instead of exec-masked branches, the uniform verification loop, the 32-bit tile arithmetic.
 // Fallback flag (err bit 8; capi_ladder.hip reruns the call on scan_teddy_wave.hip): no synchronising byte in a halo,
 // > 192 owned candidates in a wave-tile, row buffer overflow, an assertion that needs a byte behind the window.
 #include <hip/hip_runtime.h>
