@@ -147,7 +147,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   // and one workgroup per CU works through 480 KiB groups — 0.25 us per MiB against 0.37, ahead from ~300 MiB (r06_c64_pair_tail.txt:
   // 256 MiB 122 against 119 us, 512 MiB 182 against 213, 1 GiB 314 against 402).  CXG_PAIR_MIN_BYTES moves the border (the GPU test tier sets 0).
   static const uint64_t pairMinBytes = getenv("CXG_PAIR_MIN_BYTES") ? strtoull(getenv("CXG_PAIR_MIN_BYTES"), nullptr, 10) : (320ull << 20);
-  if (gen == 7 && pairOk && len >= pairMinBytes && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
+  if (gen == 7 && pairOk && reinterpret_cast<const cxgdev::TeddyAux*>(p->blob.data() + h->aux_off)->pair_off != 0u && len >= pairMinBytes && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
   // One iteration = one span launch (+ its capture pass).  What comes next is decided at the bottom from the kernel's error word:

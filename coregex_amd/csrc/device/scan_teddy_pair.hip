@@ -80,13 +80,8 @@ struct PairWaveLds {
   uint8_t em[64];
 };
 struct PairLds {
-  uint8_t tab[65536];                             // at LDS address 0: the pair is the address
-  uint32_t FB[256];                               // by byte value: the verification slots [beg, end) of the literals that BEGIN with it (beg | end << 8), and sync << 24
-  uint32_t maxrun;                                // most literals sharing a first byte
+  PairImage img;                                  // at LDS address 0 (the pair is the address): pair table, slot ranges by first byte, slot records — copied from the program image
   __attribute__((aligned(16))) uint8_t aux[kPAuxMax];
-  __attribute__((aligned(16))) uint32_t litx[64][8];   // verification slot k (literals ordered by first byte, then id): the literal's first 12 bytes as three dwords, m0 | m1, m2 (their masks), length, id
-  __attribute__((aligned(16))) uint8_t F[256];
-  __attribute__((aligned(16))) uint8_t G[256];
   uint64_t base[2];                               // output base of the group before (two groups alternate)
   uint32_t gq[4];                                 // ring of claimed groups (three in use)
   uint32_t tot[2];
@@ -95,10 +90,7 @@ struct PairLds {
 };
 static_assert(sizeof(PairLds) <= 160 * 1024, "LDS");
 
-// LDS address of the entry of the pair (b0, b1): (b0 | b1 << 8) ^ (b1 << 2).  The plain index puts a pair on bank (b0 >> 2) & 31
-// whatever b1 is — text whose pairs begin with a digit or a lower-case letter would use 3 + 7 of the 32 banks; the XOR spreads
-// them by b1 as well.  A bijection of the 16 bits (b1 keeps its bits 6, 7; b0 is XORed with a function of b1).
-__host__ __device__ constexpr uint32_t pair_addr(uint32_t b0, uint32_t b1) { return ((b0 | (b1 << 8)) ^ (b1 << 2)) & 0xFFFFu; }
+// (pair_addr — the table's address swizzle — : walk.hpp)
 // ... of the low / high pair of a dword: two SDWA operations each (shift of byte 1 / 3, XOR with word 0 / 1)
 #define CXG_PAIR_ADDR(dst, x, BYTE, WORD) \
   asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #BYTE "\n\t" \
@@ -163,7 +155,6 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   };
   uint32_t t0 = 0, t1 = 0;
   if (tid == 0) { t0 = draw(); t1 = draw(); }                     // (consumed behind the table build)
-  if (tid == 0) S.maxrun = 0u;
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kPAuxMax / 4; i += kPThreads)
     reinterpret_cast<uint32_t*>(S.aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
@@ -209,82 +200,20 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   issue_loads(cur, 0);
 
   const TeddyAux* ax = reinterpret_cast<const TeddyAux*>(S.aux);
-  const uint8_t* t_lens = S.aux + ax->lens_off;
   const uint16_t* t_off = reinterpret_cast<const uint16_t*>(S.aux + ax->off_off);
   const uint8_t* t_bytes = S.aux + ax->bytes_off;
-  const uint32_t nlits = ax->nlits;
   const uint32_t look_pre = ax->looks & 0xFFu, look_post = (ax->looks >> 8) & 0xFFu;
   const bool fold = (ax->looks & kTeddyFold) != 0u;
   auto same = [&](uint32_t b, uint32_t c) { return b == c || (fold && c >= 'a' && c <= 'z' && (b | 0x20u) == c); };   // byte b stands for literal byte c
-  if (tid < 256) {
-    const uint32_t b = static_cast<uint32_t>(tid);
-    const uint32_t sync = ((a.blob + h->info_off)[tid] & kInfoSync) ? 1u : 0u;
-    {                                                               // slots of the literals that begin with this byte (a folded set keeps lower-case literals: an upper-case letter asks as its lower-case twin)
-      const uint32_t nb = (fold && b >= 'A' && b <= 'Z') ? (b | 0x20u) : b;
-      uint32_t beg = 0, cnt = 0;
-      for (uint32_t id = 0; id < nlits; id++) { const uint32_t c0 = t_bytes[t_off[id]]; beg += c0 < nb ? 1u : 0u; cnt += c0 == nb ? 1u : 0u; }
-      S.FB[tid] = beg | ((beg + cnt) << 8) | (sync ? 0x1000000u : 0u);
-      if (cnt) atomicMax(&S.maxrun, cnt);
-    }
-    uint32_t f = sync << 6, g = sync << 7;
-    for (uint32_t id = 0; id < nlits; id++) {
-      const uint8_t* lb = t_bytes + t_off[id];
-      const uint32_t len = t_lens[id];
-      if (same(b, lb[0])) g |= 2u;                                  // A2
-      if (len == 3u) { if (same(b, lb[2])) f |= 4u; f |= 0x30u; }   // CD with any second byte; E1 and DE: nothing to ask
-      else if (len == 4u) { if (same(b, lb[3])) f |= 0x20u; f |= 0x10u; }   // DE with any second byte; E1: nothing to ask
-      else if (same(b, lb[4])) f |= 0x10u;                          // E1
-    }
-    S.F[tid] = static_cast<uint8_t>(f);
-    S.G[tid] = static_cast<uint8_t>(g);
-  }
-  __syncthreads();
-  {                                                                 // entry(b0, b1) = F[b0] | G[b1] at pair_addr(b0, b1); thread t: b1 = t >> 2, b0 = (t & 3) * 64 ..
-    const uint32_t b1 = static_cast<uint32_t>(tid) >> 2;
-    const uint32_t g4 = static_cast<uint32_t>(S.G[b1]) * 0x01010101u;
-    const uint32_t* f1 = reinterpret_cast<const uint32_t*>(S.F) + (tid & 3) * 16;
-    uint32_t* row = reinterpret_cast<uint32_t*>(S.tab) + ((b1 ^ (b1 >> 6)) << 6);   // the swizzle moves whole dwords inside a row of 256 entries
-#pragma unroll
-    for (uint32_t q = 0; q < 16; q++) row[(((tid & 3) * 16u) + q) ^ (b1 & 63u)] = f1[q] | g4;
-  }
-  if (static_cast<uint32_t>(tid) < nlits) {                          // verification compares dwords: literal tid goes to the slot of its rank by (first byte, id)
-    const uint32_t id = static_cast<uint32_t>(tid);
-    const uint8_t* lb = t_bytes + t_off[id];
-    const uint32_t len = t_lens[id];
-    uint32_t slot = 0;
-    for (uint32_t o = 0; o < nlits; o++) { const uint32_t co = t_bytes[t_off[o]]; slot += (co < lb[0] || (co == lb[0] && o < id)) ? 1u : 0u; }
-    uint32_t Lw[3], M[3];
-    for (uint32_t k = 0; k < 3; k++) {
-      Lw[k] = 0; M[k] = 0;
-      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < len) {
-        const uint32_t c = lb[4 * k + b];
-        Lw[k] |= c << (8 * b);
-        M[k] |= ((fold && c >= 'a' && c <= 'z') ? 0xDFu : 0xFFu) << (8 * b);
-      }
-    }
-    S.litx[slot][0] = Lw[0]; S.litx[slot][1] = Lw[1]; S.litx[slot][2] = Lw[2]; S.litx[slot][3] = M[0];
-    S.litx[slot][4] = M[1]; S.litx[slot][5] = M[2]; S.litx[slot][6] = len; S.litx[slot][7] = id;
-  }
-  __syncthreads();
-  if (static_cast<uint32_t>(tid) < nlits) {                          // the exact pairs: AB (bit 0), BC (3), CD (2), DE (5)
-    const uint8_t* lb = t_bytes + t_off[tid];
-    const uint32_t len = t_lens[tid];
-    uint32_t* tab32 = reinterpret_cast<uint32_t*>(S.tab);
-    for (uint32_t k = 0; k < 4u && k + 1u < len; k++) {
-      const uint32_t bit = k == 0u ? 1u : k == 1u ? 8u : k == 2u ? 4u : 0x20u;
-      const uint32_t c0 = lb[k], c1 = lb[k + 1];
-      const uint32_t n0 = (fold && c0 >= 'a' && c0 <= 'z') ? 2u : 1u, n1 = (fold && c1 >= 'a' && c1 <= 'z') ? 2u : 1u;
-      for (uint32_t i0 = 0; i0 < n0; i0++)
-        for (uint32_t i1 = 0; i1 < n1; i1++) {
-          const uint32_t idx = pair_addr(c0 ^ (i0 ? 0x20u : 0u), c1 ^ (i1 ? 0x20u : 0u));
-          atomicOr(&tab32[idx >> 2], bit << (8u * (idx & 3u)));
-        }
-    }
+  {                                                                 // the tables, built on the host once per program (program.cc buildPairImage): 67 KiB per workgroup from L2
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.blob + ax->pair_off);
+    u32x4* dst = reinterpret_cast<u32x4*>(&S.img);
+    for (uint32_t i = tid; i < sizeof(PairImage) / 16; i += kPThreads) dst[i] = src[i];
   }
   __syncthreads();
 
   uint32_t fallback = 0, edge_hit = 0;
-  const uint32_t maxrun = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.maxrun)));
+  const uint32_t maxrun = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.img.maxrun)));
   const bool short_lits = ax->maxlen <= 12u;                         // every literal is compared whole by the three masked dwords
 
   uint64_t prev = ~0ull, prev_lo = 0;                               // the group whose rows wait to be written, and where this wave's unit of it begins
@@ -328,7 +257,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       // on, a D16 load clears the other half of its register on this device, the kernel found nothing.)
       uint32_t ea[32];
 #pragma unroll
-      for (int q = 0; q < 32; q++) ea[q] = (CXG_PAIR_ABL & 4) ? (ia[q] & 0x3Fu) : S.tab[ia[q]];
+      for (int q = 0; q < 32; q++) ea[q] = (CXG_PAIR_ABL & 4) ? (ia[q] & 0x3Fu) : S.img.tab[ia[q]];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         uint2 o;
@@ -363,7 +292,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
       // ---- O: ownership bounds (scan_teddy_wave.hip)
       int32_t zA = -1, zB = kPFar;
       if (!first_tile) {
-        if (!(S.FB[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
+        if (!(S.img.FB[cx.prevb] & 0x1000000u)) {                          // the segment at the tile's first byte began earlier
           const unsigned long long bz = __ballot(Z != 0ull);
           if (bz) {
             const int Lz = __builtin_ctzll(bz);
@@ -425,13 +354,13 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
             // The slots of the literals that begin with the candidate's first byte, without a divergent branch: maxrun (uniform) steps, a lane
             // past its range compares slot 0 in vain.  (The reference verifies bucket by bucket, ids ascending — verifyBucket; the set is
             // prefix-free: at most one literal matches at a position, the order cannot be observed.)
-            const uint32_t fb = S.FB[w0 & 0xFFu];
+            const uint32_t fb = S.img.FB[w0 & 0xFFu];
             const uint32_t kbeg = fb & 0xFFu, kend = have ? (fb >> 8) & 0xFFu : 0u;
             bool tail = false;                                       // a literal longer than 12 bytes agreed on its first 12
             for (uint32_t i = 0; i < maxrun; i++) {
               const uint32_t k = kbeg + i;
               const bool valid = k < kend;
-              const uint32_t* lx = S.litx[valid ? k : 0u];
+              const uint32_t* lx = S.img.litx[valid ? k : 0u];
               const u32x4 la = *reinterpret_cast<const u32x4*>(lx), lb4 = *reinterpret_cast<const u32x4*>(lx + 4);
               const uint32_t diff = ((w0 ^ la.x) & la.w) | ((w1 ^ la.y) & lb4.x) | ((w2 ^ la.z) & lb4.y);
               const int32_t len = static_cast<int32_t>(lb4.z);
@@ -442,7 +371,7 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
             if (!short_lits && __ballot(tail && mlen == 0) != 0ull) {   // the bytes behind the twelfth, of every literal of the range that agreed so far
               if (tail && !mlen)
                 for (uint32_t k = kbeg; k < kend && !mlen; k++) {
-                  const uint32_t* lx = S.litx[k];
+                  const uint32_t* lx = S.img.litx[k];
                   const int32_t len = static_cast<int32_t>(lx[6]);
                   if (len <= 12 || c + len > rend) continue;
                   if ((((w0 ^ lx[0]) & lx[3]) | ((w1 ^ lx[1]) & lx[4]) | ((w2 ^ lx[2]) & lx[5])) != 0u) continue;

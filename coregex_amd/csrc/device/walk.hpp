@@ -276,6 +276,22 @@ struct TeddyAux {           // layout of the blob's aux section (all offsets rel
   // kFlagPrefixLiteral images (a UseDFA program behind its required literal prefix): the anchored forward DFA,
   // [dfa_states][256] u8, that turns a prefix occurrence into the match end (0 states: plain literal set)
   uint32_t dfa_off, dfa_states, dfa_start, dfa_first_accept;
+  // kKindTeddy images (round 6): offset of the PairImage below from the start of the BLOB (16-byte aligned; 0: none) — the tables of
+  // scan_teddy_pair.hip, built once on the host (program.cc buildPairImage) and copied into LDS by every workgroup
+  uint32_t pair_off;
+};
+
+// LDS address of the entry of the byte pair (b0, b1) in scan_teddy_pair.hip's table: (b0 | b1 << 8) ^ (b1 << 2).  The plain index puts a
+// pair on bank (b0 >> 2) & 31 whatever b1 is — text whose pairs begin with a digit or a lower-case letter would use 3 + 7 of the 32 banks;
+// the XOR spreads them by b1 as well.  A bijection of the 16 bits (b1 keeps its bits 6, 7; b0 is XORed with a function of b1).
+CXG_HD constexpr uint32_t pair_addr(uint32_t b0, uint32_t b1) { return ((b0 | (b1 << 8)) ^ (b1 << 2)) & 0xFFFFu; }
+// The kernel's tables as they sit in LDS (scan_teddy_pair.hip explains the entry bits):
+struct PairImage {
+  uint8_t tab[65536];        // entry of every byte pair, at pair_addr(b0, b1)
+  uint32_t FB[256];          // by byte value: the verification slots [beg, end) of the literals that BEGIN with it (beg | end << 8); sync << 24
+  uint32_t litx[64][8];      // verification slot k (literals ordered by first byte, then id): the first 12 bytes as three dwords, m0 | m1, m2 (their masks), length, id
+  uint32_t maxrun;           // most literals sharing a first byte
+  uint32_t pad[3];
 };
 
 // checkLook (nfa/pikevm.go:1646-1674) for one assertion at a position with the byte in front of it and the byte behind it; outside the

@@ -1925,6 +1925,60 @@ bool makeLiteralAux(const std::vector<std::vector<uint8_t>>& lits, size_t min_co
   return true;
 }
 
+// The tables of scan_teddy_pair.hip (walk.hpp PairImage): the entry of every byte pair — AB / BC / CD / DE: the pair is bytes 0,1 / 1,2 / 2,3 /
+// 3,4 of a literal; A2: its second byte begins one; E1: its first byte is a fifth byte; S1 / S2: the byte lies outside the alphabet; a
+// literal shorter than the byte asked for lets every value pass —, the verification slots by first byte, the slot records.  A folded set
+// keeps lower-case literals: a letter stands for both cases.  tests/test_teddy_pair_cpu.py restates the table in numpy and compares.
+static std::vector<uint8_t> buildPairImage(const std::vector<std::vector<uint8_t>>& lits, bool fold, const bool* inAlpha) {
+  std::vector<uint8_t> img(sizeof(cxgdev::PairImage), 0);
+  cxgdev::PairImage* I = reinterpret_cast<cxgdev::PairImage*>(img.data());
+  auto lower = [&](uint32_t c) { return fold && c >= 'a' && c <= 'z'; };
+  auto same = [&](uint32_t b, uint32_t c) { return b == c || (lower(c) && (b | 0x20u) == c); };
+  uint8_t F[256], G[256];
+  for (uint32_t b = 0; b < 256; b++) {
+    uint32_t f = inAlpha[b] ? 0u : 0x40u, g = inAlpha[b] ? 0u : 0x80u;
+    for (auto& l : lits) {
+      if (same(b, l[0])) g |= 2u;                                     // A2
+      if (l.size() == 3) { if (same(b, l[2])) f |= 4u; f |= 0x30u; }  // CD with any second byte; E1 and DE: nothing to ask
+      else if (l.size() == 4) { if (same(b, l[3])) f |= 0x20u; f |= 0x10u; }   // DE with any second byte; E1: nothing to ask
+      else if (same(b, l[4])) f |= 0x10u;                             // E1
+    }
+    F[b] = static_cast<uint8_t>(f); G[b] = static_cast<uint8_t>(g);
+  }
+  for (uint32_t b1 = 0; b1 < 256; b1++)
+    for (uint32_t b0 = 0; b0 < 256; b0++) I->tab[cxgdev::pair_addr(b0, b1)] = F[b0] | G[b1];
+  for (auto& l : lits)
+    for (size_t k = 0; k < 4 && k + 1 < l.size(); k++) {               // the exact pairs: AB (bit 0), BC (3), CD (2), DE (5)
+      const uint8_t bit = k == 0 ? 1 : k == 1 ? 8 : k == 2 ? 4 : 0x20;
+      for (uint32_t i0 = 0; i0 < (lower(l[k]) ? 2u : 1u); i0++)
+        for (uint32_t i1 = 0; i1 < (lower(l[k + 1]) ? 2u : 1u); i1++)
+          I->tab[cxgdev::pair_addr(l[k] ^ (i0 ? 0x20u : 0u), l[k + 1] ^ (i1 ? 0x20u : 0u))] |= bit;
+    }
+  uint32_t maxrun = 0;
+  for (uint32_t b = 0; b < 256; b++) {                                 // (an upper-case letter asks as its lower-case twin)
+    const uint32_t nb = (fold && b >= 'A' && b <= 'Z') ? (b | 0x20u) : b;
+    uint32_t beg = 0, cnt = 0;
+    for (auto& l : lits) { beg += l[0] < nb ? 1u : 0u; cnt += l[0] == nb ? 1u : 0u; }
+    I->FB[b] = beg | ((beg + cnt) << 8) | (inAlpha[b] ? 0u : 0x1000000u);
+    maxrun = std::max(maxrun, cnt);
+  }
+  I->maxrun = maxrun;
+  for (size_t id = 0; id < lits.size() && id < 64; id++) {
+    const auto& l = lits[id];
+    uint32_t slot = 0;
+    for (size_t o = 0; o < lits.size(); o++) slot += (lits[o][0] < l[0] || (lits[o][0] == l[0] && o < id)) ? 1u : 0u;
+    uint32_t* x = I->litx[slot];
+    for (uint32_t k = 0; k < 3; k++)
+      for (uint32_t b = 0; b < 4; b++) if (4 * k + b < l.size()) {
+        const uint32_t c = l[4 * k + b];
+        x[k] |= c << (8 * b);
+        x[3 + k] |= (lower(c) ? 0xDFu : 0xFFu) << (8 * b);
+      }
+    x[6] = static_cast<uint32_t>(l.size()); x[7] = static_cast<uint32_t>(id);
+  }
+  return img;
+}
+
 void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& lits, size_t min_count, bool fold) {
   p->supported = false;
   std::vector<uint8_t> aux;
@@ -1942,6 +1996,12 @@ void buildLiteralImage(cxg_program* p, const std::vector<std::vector<uint8_t>>& 
   h.aux_off = static_cast<uint32_t>(blob.size());
   h.aux_len = static_cast<uint32_t>(aux.size());
   blob.insert(blob.end(), aux.begin(), aux.end());
+  while (blob.size() % 16) blob.push_back(0);
+  {                                                                  // scan_teddy_pair.hip's tables: the LAST section of the image
+    const std::vector<uint8_t> img = buildPairImage(lits, fold, inAlpha);
+    reinterpret_cast<cxgdev::TeddyAux*>(blob.data() + h.aux_off)->pair_off = static_cast<uint32_t>(blob.size());
+    blob.insert(blob.end(), img.begin(), img.end());
+  }
   h.total_bytes = static_cast<uint32_t>(blob.size());
   std::memcpy(blob.data(), &h, sizeof h);
   p->blob.swap(blob);

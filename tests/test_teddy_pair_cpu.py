@@ -134,3 +134,33 @@ def test_config_3_fingerprint_is_selective():
     cand, _ = device_bits(build_table(lits, False), hay)
     m = len(re.findall(b"|".join(lits), hay.tobytes()))
     assert m <= int(cand.sum()) <= int(1.6 * m)
+
+
+def test_host_built_image_equals_the_restatement():
+    """The program image of a literal set ends with the pair kernel's tables (walk.hpp PairImage, built by program.cc buildPairImage):
+    the pair table equals build_table() above byte for byte; the slot ranges by first byte and the slot records are consistent."""
+    import struct
+    import coregex_amd as cx
+    cases = [("error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow", False),
+             ("abc|wxyz|hello", False), ("abc|xyz", False), ("(?i)(error|fail|panic)", True), ("connection_reset_by_peer|connection_reset_by_pear|connection_refused", False)]
+    size = 65536 + 1024 + 64 * 32 + 16
+    for pat, fold in cases:
+        rx = cx.compile(pat)
+        assert rx.supported and rx.strategy in ("UseTeddy", "UseNFA", "UseDFA"), (pat, rx.strategy)
+        blob = rx.blob()
+        img = blob[-size:]
+        lits = [l.encode() for l in (pat[5:-1] if fold else pat).split("|")]
+        tab = np.frombuffer(img[:65536], np.uint8)
+        want = build_table(lits, fold)
+        assert np.array_equal(tab, want), (pat, int((tab != want).sum()))
+        FB = np.frombuffer(img[65536:65536 + 1024], np.uint32)
+        litx = np.frombuffer(img[65536 + 1024:65536 + 1024 + 2048], np.uint32).reshape(64, 8)
+        maxrun = struct.unpack_from("<I", img, 65536 + 1024 + 2048)[0]
+        firsts = sorted(l[0] for l in lits)
+        assert maxrun == max(firsts.count(c) for c in set(firsts))
+        for b in range(256):
+            nb = (b | 0x20) if fold and ord("A") <= b <= ord("Z") else b
+            beg, end = int(FB[b]) & 0xFF, (int(FB[b]) >> 8) & 0xFF
+            assert end - beg == firsts.count(nb) and all(int(litx[k][0]) & 0xFF == nb for k in range(beg, end)), (pat, b)
+        ids = sorted(int(litx[k][7]) for k in range(len(lits)))
+        assert ids == list(range(len(lits))) and all(int(litx[k][6]) == len(lits[int(litx[k][7])]) for k in range(len(lits)))
