@@ -143,7 +143,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   // literal sets: the pair kernel (scan_teddy_pair.hip, round 6) for the spans of a plain call — FindAll's n lives in the grouped kernels'
   // look-back, and match-dense input (a row buffer overflowed before) or a fallback flag of the pair kernel itself stay on the wave kernel
   static const bool pairOk = getenv("CXG_NO_TEDDY_PAIR") == nullptr;
-  // ... and for LONG haystacks: the pair kernel builds a 64 KiB table per workgroup (20 us before its first byte against the wave kernel's 10)
+  // ... and for LONG haystacks: the pair kernel copies 67 KiB of tables per workgroup (15 us before its first byte against the wave kernel's 10)
   // and one workgroup per CU works through 480 KiB groups — 0.25 us per MiB against 0.37, ahead from ~300 MiB (r06_c64_pair_tail.txt:
   // 256 MiB 122 against 119 us, 512 MiB 182 against 213, 1 GiB 314 against 402).  CXG_PAIR_MIN_BYTES moves the border (the GPU test tier sets 0).
   static const uint64_t pairMinBytes = getenv("CXG_PAIR_MIN_BYTES") ? strtoull(getenv("CXG_PAIR_MIN_BYTES"), nullptr, 10) : (320ull << 20);

@@ -30,7 +30,7 @@
 // -amdgpu-atomic-optimizer-strategy=None: the optimizer's wave reduction waited for the ticket, and for every window load
 // in flight, on the spot).  A workgroup that holds group g only ever waits for groups < g, which are held by running
 // workgroups: forward progress does not depend on co-residency or on the order of dispatch.  The
-// table is built once per workgroup.  A wave scans one unit per group behind ONE buffer descriptor, in a two-tile loop body:
+// tables come with the program image (built on the host: program.cc buildPairImage).  A wave scans one unit per group behind ONE buffer descriptor, in a two-tile loop body:
 // filter(j + 1) runs between the REQUEST of the 16 bytes at each candidate of tile j (global memory; there is no room for an
 // LDS copy of the window) and their comparison.  The rows of a group are ordered with the decoupled look-back of
 // block_common.hpp, deferred by one group: a group's count is published behind the iteration's one barrier, its base is
