@@ -26,7 +26,10 @@ constexpr int kPairWaves = 16;
 constexpr int kPairTilesPerWave = 8;
 constexpr uint32_t kPairCtrStride = 32;       // uint32 between two group counters (128 bytes)
 constexpr uint64_t kPairGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairTilesPerWave;
-constexpr int kPairSmallTilesPerWave = 2;     // ... and SMALL groups of 16 x 2 wave-tiles = 120 KiB behind them: the last stretch of a haystack (one big group per CU), so that the
+#ifndef CXG_PAIR_SMALL_TPW
+#define CXG_PAIR_SMALL_TPW 2               // (A/B builds: 4)
+#endif
+constexpr int kPairSmallTilesPerWave = CXG_PAIR_SMALL_TPW;     // ... and SMALL groups of 16 x 2 wave-tiles = 120 KiB behind them: the last stretch of a haystack (one big group per CU), so that the
 constexpr uint64_t kPairSmallGroupBytes = static_cast<uint64_t>(kWaveTile) * kPairWaves * kPairSmallTilesPerWave;   // launch does not end with half of the CUs idle for a big group's time
 #ifndef CXG_CC_TILES
 #define CXG_CC_TILES 4
