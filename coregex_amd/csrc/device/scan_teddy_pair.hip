@@ -66,7 +66,7 @@ constexpr int kPAuxMax = 2048;
 #define CXG_PAIR_VAUX 2                   // (nt: the requests miss the L2 either way — measured —, a nontemporal miss fetches half as much: FETCH_SIZE 1.50 -> 1.26 x the haystack, same time)
 #endif
 #ifndef CXG_PAIR_ABL
-#define CXG_PAIR_ABL 0                    // timing experiments (scripts/build_variant.sh; WRONG rows): 1 no verification, 2 no candidate list either, 4 no table lookups, 8 no look-back / row write
+#define CXG_PAIR_ABL 0                    // timing experiments (scripts/build_variant.sh; WRONG rows): 1 no verification, 2 no candidate list either, 4 no table lookups, 8 no look-back / row write, 64 no requests of candidate bytes
 #endif
 constexpr int32_t kPFar = 1 << 20;
 constexpr int kPWin = kWaveTile + kWaveHalo;      // 4096
