@@ -8,9 +8,12 @@ import torch
 import coregex_amd as cx
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "torchfill"
+# argv[2] == "literals" (round 6): BASELINE config 3's literal set on config 3's corpus — the pair kernel (scan_teddy_pair.hip), whose
+# groups are claimed: it needs neither co-residency nor dispatch in index order
+lits = len(sys.argv) > 2 and sys.argv[2] == "literals"
 n = 1 << 30
-buf = cx.DeviceBuffer(n); buf.fill_synth(2, 0xC0FFEE02, 0)
-rx = cx.compile(r"\d+\.\d+\.\d+\.\d+")
+buf = cx.DeviceBuffer(n); buf.fill_synth(3 if lits else 2, 0xC0FFEE03 if lits else 0xC0FFEE02, 0)
+rx = cx.compile("error|warning|fatal|critical|panic|timeout|refused|denied|googlebot|bingbot|yandexbot|crawler|spider|failure|exception|overflow" if lits else r"\d+\.\d+\.\d+\.\d+")
 cnt = rx.find_all_device(buf.ptr, n)
 out = torch.empty((cnt + 8, 2), dtype=torch.int64, device="cuda")
 for _ in range(20):
