@@ -42,7 +42,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   uint32_t lastReason = 0;
   cxgdev::ScanArgs a;
   a.pf_status = nullptr; a.pf_ticket = nullptr; a.pf_ncounters = 0;   // (set per launch by the fields programs' branch below)
-  a.pair_ctr = nullptr; a.pair_seq = 0; a.pair_nctr = 0; a.pair_nbig = 0;
+  a.pair_ctr = nullptr; a.pair_seq = 0; a.pair_nctr = 0; a.pair_nbig = 0; a.pair_n6 = 0; a.pair_n4 = 0;
   std::memset(&a.plan, 0, sizeof a.plan); a.plan_shape = 0;
   a.cc_nr = a.cc_neg = a.cc_pairs = 0; std::memset(a.cc_lo, 0, 4); std::memset(a.cc_hi, 0, 4);
   a.u32_rows = t_u32Rows ? 1u : 0u;
@@ -166,15 +166,19 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   a.ngroups = a.ntiles;
   if (gen == 8 || gen == 11) a.ngroups = (len + cxgdev::kCcGroupBytes - 1) / cxgdev::kCcGroupBytes;
   if (gen == 6 || gen == 7 || gen == 9 || gen == 10) a.ngroups = (len + cxgdev::kWaveGroupBytes - 1) / cxgdev::kWaveGroupBytes;
-  if (gen == 12) {                                                 // big groups, and small ones for the last stretch (one big group per CU, or the whole of a short haystack)
+  if (gen == 12) {                                                 // groups of 8 tiles per wave; the last stretch in smaller ones
     static int pcus = 0;
     if (pcus == 0) { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); pcus = n > 0 ? n : 256; }
-    static const uint64_t tailEighths = getenv("CXG_PAIR_TAIL8") ? static_cast<uint64_t>(atoi(getenv("CXG_PAIR_TAIL8"))) : 1u;   // (the small-group stretch in eighths of one big group per CU; measured 0 .. 16: profiles/r06_c64_pair_tail.txt)
-    const uint64_t tail = static_cast<uint64_t>(pcus) * cxgdev::kPairGroupBytes * tailEighths / 8u;
-    const uint64_t nbig = len > tail ? (len - tail) / cxgdev::kPairGroupBytes : 0;
-    const uint64_t rest = len - nbig * cxgdev::kPairGroupBytes;
-    a.pair_nbig = static_cast<uint32_t>(nbig);
-    a.ngroups = nbig + (rest + cxgdev::kPairSmallGroupBytes - 1) / cxgdev::kPairSmallGroupBytes;
+    static const int taper = getenv("CXG_PAIR_TAPER") ? atoi(getenv("CXG_PAIR_TAPER")) : 0;   // (1: one group of 6, 4 and 2 tiles per wave and CU behind the big ones — measured: +5 us at 1 GiB, r06_c80_pair_taper.txt; 0: an eighth of a big group per CU in groups of 2)
+    const uint64_t rowBytes = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kPairWaves;   // one tile per wave
+    const uint64_t R = (len + rowBytes - 1) / rowBytes;
+    const uint64_t P = static_cast<uint64_t>(pcus);
+    uint64_t n8 = 0, n6 = 0, n4 = 0;
+    if (taper && R >= 20 * P) { n6 = P; n4 = P; n8 = (R - 12 * P) / 8; }          // (behind them: P groups of 2 and what the division left)
+    else if (!taper && R > P) n8 = (R - P) / 8;
+    const uint64_t left = R - 8 * n8 - 6 * n6 - 4 * n4;
+    a.pair_nbig = static_cast<uint32_t>(n8); a.pair_n6 = static_cast<uint32_t>(n6); a.pair_n4 = static_cast<uint32_t>(n4);
+    a.ngroups = n8 + n6 + n4 + (left + 1) / 2;
   }
   a.tiles_per_wave = cxgdev::kTilesPerWave;
   if (((gen == 6 || gen == 7 || gen == 9) && denseChain) || (gen == 10 && fsmMode != 0)) {   // four times the row-buffer room per wave-tile
@@ -272,8 +276,12 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
       s.pairSeq = 0;
     }
     a.pair_ctr = s.pairCtr; a.pair_seq = ++s.pairSeq;
-    static const uint32_t pairNctr = getenv("CXG_PAIR_NCTR") ? static_cast<uint32_t>(atoi(getenv("CXG_PAIR_NCTR"))) : 8u;   // (A/B: 1, 2, 4 or 8 counters)
-    a.pair_nctr = a.static_groups ? ((pairNctr == 1u || pairNctr == 2u || pairNctr == 4u) ? pairNctr : 8u) : 1u;                        // (tickets forced, or the mode demoted after a look-back watchdog hit: one counter, strict ticket order)
+    // ONE counter: strict ticket order.  With several counters (workgroup b asks counter b & 7 first and STEALS from the others once its own is
+    // exhausted) a workgroup can draw a group in front of one it has scanned and not yet resolved — its own look-back then waits for a group it
+    // holds itself (seen as [21, 21]: a watchdog rerun, on short haystacks where the first claims outnumber the groups).  In ticket order every
+    // workgroup's groups ascend and the smallest uncounted group is always being scanned.  Measured: no difference in time (r06_c44_pair_nctr.txt).
+    static const uint32_t pairNctr = getenv("CXG_PAIR_NCTR") ? static_cast<uint32_t>(atoi(getenv("CXG_PAIR_NCTR"))) : 1u;   // (A/B only: 2, 4 or 8 counters)
+    a.pair_nctr = (a.static_groups && (pairNctr == 2u || pairNctr == 4u || pairNctr == 8u)) ? pairNctr : 1u;
     le = cxgdev::launch_scan_teddy_pair(a, static_cast<uint32_t>(a.ngroups < static_cast<uint64_t>(cus) ? a.ngroups : static_cast<uint64_t>(cus)), stream);
   }
   else if (gen == 9) {                                              // required literal prefix + anchored DFA (kFlagPrefixLiteral)

@@ -108,7 +108,8 @@ struct ScanArgs {
   uint32_t cc_nr, cc_neg, cc_pairs;   // scan_charclass_wave.hip: walk.hpp CharClassAux copied by the host (kernel arguments: no dependent
   uint8_t cc_lo[4], cc_hi[4];         // loads from the program image before the first window can be requested)
   uint32_t* pair_ctr;   // scan_teddy_pair.hip: [2][8] group counters, kPairCtrStride words apart; set pair_seq & 1 is this launch's, the kernel zeroes the other
-  uint32_t pair_nbig;   // groups [0, pair_nbig) are big (kPairGroupBytes), the rest small (kPairSmallGroupBytes), laid out behind them
+  uint32_t pair_nbig;   // groups [0, pair_nbig) are big (kPairGroupBytes: 8 tiles per wave), the next pair_n6 have 6 tiles per wave, the next pair_n4 have 4,
+  uint32_t pair_n6, pair_n4;   // the rest 2 (kPairSmallGroupBytes), laid out one behind the other: the groups of a launch taper off, so that its CUs end together
   uint32_t pair_seq, pair_nctr;   // pair_nctr: 8 (workgroup b claims from counter b & 7 first), or 1: strict ticket order (after a watchdog hit)
   uint32_t u32_rows;    // cxg_find_all_device_u32: `out` holds rows of two uint32 relative to `hay` (kernels with the compact epilogue only)
 };

@@ -145,7 +145,12 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   uint32_t* const ctr = a.pair_ctr + (a.pair_seq & 1u) * (8u * kPairCtrStride);
   if (blockIdx.x == 0 && tid < 8) a.pair_ctr[((a.pair_seq + 1u) & 1u) * (8u * kPairCtrStride) + static_cast<uint32_t>(tid) * kPairCtrStride] = 0u;   // the next launch's set
   auto draw = [&]() -> uint32_t { return __hip_atomic_fetch_add(ctr + cls * kPairCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // One counter (the product): workgroup b begins with groups b and b + G (G workgroups) without asking anybody — 2 G simultaneous atomics on
+  // one address would take the last of them 25 us —, ticket t is group 2 G + t: every workgroup's groups ascend, the order of the groups is
+  // the order in which they were handed out, and the smallest uncounted group is always being scanned by a workgroup that waits for nobody.
+  const uint32_t G2 = nctr == 1u ? 2u * gridDim.x : 0u;
   auto claimed = [&](uint32_t t) -> uint32_t {                      // ticket of the own counter -> group; 0xFFFFFFFF: no group left anywhere
+    if (nctr == 1u) return t + G2 < ngroups32 && t + G2 >= G2 ? t + G2 : 0xFFFFFFFFu;
     uint32_t g = t * nctr + cls;
     for (uint32_t k = 1; g >= ngroups32 && k < nctr; k++) {
       const uint32_t x = (cls + k) & (nctr - 1u);
@@ -154,12 +159,14 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
     return g < ngroups32 ? g : 0xFFFFFFFFu;
   };
   uint32_t t0 = 0, t1 = 0;
-  if (tid == 0) { t0 = draw(); t1 = draw(); }                     // (consumed behind the table build)
+  if (tid == 0 && nctr != 1u) { t0 = draw(); t1 = draw(); }       // (consumed behind the image's load)
   const BlobHeader* h = reinterpret_cast<const BlobHeader*>(a.blob);
   for (uint32_t i = tid; i < h->aux_len / 4 && i < kPAuxMax / 4; i += kPThreads)
     reinterpret_cast<uint32_t*>(S.aux)[i] = reinterpret_cast<const uint32_t*>(a.blob + h->aux_off)[i];
   if (tid == 0) {                                                   // (the tickets have had the image's load to come back)
-    const uint32_t g0 = claimed(t0), g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1);
+    uint32_t g0, g1;
+    if (nctr == 1u) { g0 = blockIdx.x < ngroups32 ? blockIdx.x : 0xFFFFFFFFu; g1 = blockIdx.x + gridDim.x < ngroups32 ? blockIdx.x + gridDim.x : 0xFFFFFFFFu; }
+    else { g0 = claimed(t0); g1 = g0 == 0xFFFFFFFFu ? g0 : claimed(t1); }
     S.gq[0] = g0; S.gq[1] = g1;
   }
   __syncthreads();
@@ -171,12 +178,13 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   struct UnitGeo { __amdgpu_buffer_rsrc_t rsrc; int32_t pre; int32_t rem; int32_t nrec; int32_t tiles; uint64_t lo; };   // rem: bytes from the unit's first byte to the end of input (0: none; clamped); tiles: 8 in a big group, 2 in a small one
   auto make_unit = [&](uint64_t g) -> UnitGeo {
     UnitGeo u;
-    // groups [0, nbig) are big (8 tiles per wave); small ones (2 tiles per wave) cover the haystack's last stretch behind them
-    const uint64_t nbig = a.pair_nbig;
-    const bool big = g < nbig;
-    u.tiles = big ? kPTpw : kPairSmallTilesPerWave;
-    const uint64_t ulo = big ? (g * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPTpw)
-                             : nbig * kPairGroupBytes + ((g - nbig) * kPWaves + static_cast<uint64_t>(wave)) * static_cast<uint64_t>(kWaveTile * kPairSmallTilesPerWave);
+    // groups [0, n8) have 8 tiles per wave, the next n6 have 6, the next n4 have 4, the rest 2: one behind the other in the haystack
+    const uint64_t n8 = a.pair_nbig, n6 = a.pair_n6, n4 = a.pair_n4;
+    const uint64_t g6 = g > n8 ? g - n8 : 0ull, g4 = g6 > n6 ? g6 - n6 : 0ull, g2 = g4 > n4 ? g4 - n4 : 0ull;
+    u.tiles = g < n8 ? 8 : (g6 < n6 ? 6 : (g4 < n4 ? 4 : 2));
+    // tile rows (16 tiles: one per wave) in front of the group
+    const uint64_t rows = 8ull * (g < n8 ? g : n8) + 6ull * (g6 < n6 ? g6 : n6) + 4ull * (g4 < n4 ? g4 : n4) + 2ull * g2;
+    const uint64_t ulo = (rows * kPWaves + static_cast<uint64_t>(wave) * static_cast<uint64_t>(u.tiles)) * static_cast<uint64_t>(kWaveTile);
     u.lo = ulo;
     const bool any = g < ngroups && ulo < a.len;
     const uint64_t rem64 = any ? a.len - ulo : 0ull;

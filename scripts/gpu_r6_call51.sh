@@ -1,6 +1,6 @@
 # Round 6, call 51: the pair kernel back on group-level look-back (one barrier per group) with a wave's tiles consecutive; A/B, stress, tests, instruction counts.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R
-T=${TAG:-c72}
+T=${TAG:-c82}
 O=gpurun_out/r06_${T}_pair.txt; rm -f $O
 timeout 200 python scripts/teddy_pair_ab.py cfg3 four fold 2>&1 | grep -v amdgpu.ids | tee -a $O
 timeout 300 python scripts/gpu_stress_pair.py 20000 2>&1 | grep -v amdgpu.ids | tee -a $O

@@ -1,4 +1,4 @@
-"""Literal-set kernels on 64 MiB .. 1 GiB of synthlog-v1 config 3 (GPU box): kernel time by haystack length (CXG_PAIR_TAIL8: the pair kernel's
+"""Literal-set kernels on 64 MiB .. 1 GiB of synthlog-v1 config 3 (GPU box): kernel time by haystack length (CXG_PAIR_TAPER: the pair kernel's
 small-group stretch; CXG_NO_TEDDY_PAIR=1: the wave kernel)."""
 import sys, os
 os.environ.setdefault("CXG_PAIR_MIN_BYTES", "0")
@@ -15,4 +15,4 @@ for n in (64 << 20, 128 << 20, 256 << 20, 512 << 20, 1 << 30):
         rx.find_all_device(buf.ptr, n, out.data_ptr(), 4500000, timing=t)
         if i: best = min(best, t.kernel_ms)
     res.append(f"{n >> 20} MiB {best * 1e3:.1f}")
-print(os.environ.get("CXG_PAIR_TAIL8", "default"), "| us:", " | ".join(res), flush=True)
+print(os.environ.get("CXG_PAIR_TAPER", "default"), "| us:", " | ".join(res), flush=True)
