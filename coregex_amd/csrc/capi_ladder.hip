@@ -143,10 +143,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
   // literal sets: the pair kernel (scan_teddy_pair.hip, round 6) for the spans of a plain call — FindAll's n lives in the grouped kernels'
   // look-back, and match-dense input (a row buffer overflowed before) or a fallback flag of the pair kernel itself stay on the wave kernel
   static const bool pairOk = getenv("CXG_NO_TEDDY_PAIR") == nullptr;
-  // ... and for LONG haystacks: the pair kernel copies 67 KiB of tables per workgroup (15 us before its first byte against the wave kernel's 10)
-  // and one workgroup per CU works through 480 KiB groups — 0.25 us per MiB against 0.37, ahead from ~300 MiB (r06_c64_pair_tail.txt:
-  // 256 MiB 122 against 119 us, 512 MiB 182 against 213, 1 GiB 314 against 402).  CXG_PAIR_MIN_BYTES moves the border (the GPU test tier sets 0).
-  static const uint64_t pairMinBytes = getenv("CXG_PAIR_MIN_BYTES") ? strtoull(getenv("CXG_PAIR_MIN_BYTES"), nullptr, 10) : (320ull << 20);
+  // (Until the first two groups of a workgroup were assigned without an atomic, a launch began with 512 atomics queueing on the counters and
+  // the wave kernel was ahead below 320 MiB; now the pair kernel is level or ahead from 1 KiB on — r06_c83_pair_sizes_final.txt: 64 KiB 13.6
+  // against 23.0 us, 1 MiB 17.4 / 33.7, 64 MiB 43.5 / 48.0, 1 GiB 294 / 405.  CXG_PAIR_MIN_BYTES moves the border for A/B runs.)
+  static const uint64_t pairMinBytes = getenv("CXG_PAIR_MIN_BYTES") ? strtoull(getenv("CXG_PAIR_MIN_BYTES"), nullptr, 10) : 0ull;
   if (gen == 7 && pairOk && reinterpret_cast<const cxgdev::TeddyAux*>(p->blob.data() + h->aux_off)->pair_off != 0u && len >= pairMinBytes && limit <= 0 && !denseChain && !profOn && dbgBits == 0 && p->noPair[submatch ? 1 : 0].load(std::memory_order_relaxed) == 0) gen = 12;
   uint8_t ladder[sizeof(cxg_timing{}.ladder)] = {0};               // kernel id of every span launch of this call, in order
   uint32_t nladder = 0;
@@ -175,7 +175,7 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     const uint64_t P = static_cast<uint64_t>(pcus);
     uint64_t n8 = 0, n6 = 0, n4 = 0;
     if (taper && R >= 20 * P) { n6 = P; n4 = P; n8 = (R - 12 * P) / 8; }          // (behind them: P groups of 2 and what the division left)
-    else if (!taper && R > P) n8 = (R - P) / 8;
+    else if (!taper && R >= 9 * P) n8 = (R - P) / 8;                 // (a short haystack — less than nine tile rows per CU — is cut into groups of 2 only: more CUs get to work)
     const uint64_t left = R - 8 * n8 - 6 * n6 - 4 * n4;
     a.pair_nbig = static_cast<uint32_t>(n8); a.pair_n6 = static_cast<uint32_t>(n6); a.pair_n4 = static_cast<uint32_t>(n4);
     a.ngroups = n8 + n6 + n4 + (left + 1) / 2;

@@ -4,9 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The pair kernel for literal sets (scan_teddy_pair.hip) serves haystacks from 320 MiB on by default (capi_ladder.hip: below that the wave
-# kernel is faster).  The test tier takes the border away, so that every literal-set test — edges, short haystacks, fuzz seeds — runs on the
-# pair kernel; the default routing is asserted in a subprocess (tests/test_gpu_teddy_pair.py::test_default_routing_by_length).
+# The pair kernel for literal sets (scan_teddy_pair.hip) serves haystacks of every length by default; CXG_PAIR_MIN_BYTES is a border for A/B
+# runs.  The test tier pins it to 0 whatever the caller's environment says less explicitly; the default routing is asserted in a subprocess
+# (tests/test_gpu_teddy_pair.py::test_default_routing).
 os.environ.setdefault("CXG_PAIR_MIN_BYTES", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -154,20 +154,22 @@ def test_config_3_on_the_synthetic_corpus_against_the_wave_kernel():
     assert routed(list(t.kernels) == [K_PAIR], list(t.kernels), t.fallback_reason)
 
 
-def test_default_routing_by_length():
-    """Without CXG_PAIR_MIN_BYTES (this tier sets 0): literal sets run on the wave kernel below 320 MiB, on the pair kernel from there on."""
+def test_default_routing():
+    """Without CXG_PAIR_MIN_BYTES (a border for A/B runs; this tier sets 0 explicitly): literal sets run on the pair kernel at every length,
+    FindAll with an n on the wave kernel."""
     import os, subprocess, sys
     code = ("import coregex_amd as cx\n"
-            "n = 384 << 20\n"
+            "n = 64 << 20\n"
             "buf = cx.DeviceBuffer(n); buf.fill_synth(3, 0xC0FFEE03, 0)\n"
             "rx = cx.compile('error|warning|fatal|critical')\n"
-            "t = cx.Timing(); a = rx.find_all_device(buf.ptr, 64 << 20, timing=t); ka = list(t.kernels)\n"
+            "t = cx.Timing(); a = rx.find_all_device(buf.ptr, 4096, timing=t); ka = list(t.kernels)\n"
             "b = rx.find_all_device(buf.ptr, n, timing=t); kb = list(t.kernels)\n"
-            "print('ROUTE', ka, kb, a, b)\n")
+            "c = rx.find_all_device(buf.ptr, n, n=5, timing=t); kc = list(t.kernels)\n"
+            "print('ROUTE', ka, kb, kc, a, b, c)\n")
     env = dict(os.environ)
     env.pop("CXG_PAIR_MIN_BYTES", None)
     env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l.startswith("ROUTE")]
     assert line, out.stderr[-2000:]
-    assert "[7] [21]" in line[0], line[0]
+    assert "[21] [21] [7]" in line[0], line[0]
