@@ -26,7 +26,7 @@
 //
 // The table is 64 KiB of LDS, so a CU holds ONE workgroup: 16 waves, and the grid is persistent.  GROUPS — 16 units of 8
 // consecutive wave-tiles (480 KiB), and small ones of 2-tile units for the haystack's last stretch — are CLAIMED through
-// atomic counters, two claims ahead (the ticket is drawn by one lane a group early; this file is compiled with
+// one atomic counter, two claims ahead, the first two groups of a workgroup without an atomic (the ticket is drawn by one lane a group early; this file is compiled with
 // -amdgpu-atomic-optimizer-strategy=None: the optimizer's wave reduction waited for the ticket, and for every window load
 // in flight, on the spot).  A workgroup that holds group g only ever waits for groups < g, which are held by running
 // workgroups: forward progress does not depend on co-residency or on the order of dispatch.  The
@@ -137,8 +137,9 @@ __global__ __launch_bounds__(kPThreads, 4) void k_scan_teddy_pair(ScanArgs a) {
   const uint64_t etag = static_cast<uint64_t>(a.epoch) << kEpochShift;
 
   // ---- once per workgroup: claim two groups, the literal tables, the pair table
-  // Groups are claimed from pair_nctr counters: counter x hands out groups x, x + nctr, ..; workgroup b asks counter b & (nctr - 1) and,
-  // once that is exhausted, the others in turn.  (One counter serves ~20 returning atomics per microsecond: a GiB has 4 370 groups.)
+  // Groups are claimed from pair_nctr counters — ONE in the product (below); with several (A/B builds of the ladder) counter x hands out groups
+  // x, x + nctr, .. and workgroup b asks counter b & (nctr - 1) and, once that is exhausted, the others in turn: that form can deadlock a
+  // workgroup on its own look-back.  (One counter serves ~20 returning atomics per microsecond: a GiB has 2 200 groups.)
   const uint32_t nctr = a.pair_nctr, cls = blockIdx.x & (nctr - 1u);
   const uint32_t ngroups32 = static_cast<uint32_t>(a.ngroups);
   const uint64_t ngroups = a.ngroups;
