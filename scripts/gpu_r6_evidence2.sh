@@ -28,7 +28,7 @@ timeout 300 python scripts/gpu_fuzz.py 901 300 > gpurun_out/r06_e2_gpu_fuzz_gene
 FUZZ_FEW=1 timeout 200 python scripts/gpu_fuzz.py 908 80 > gpurun_out/r06_e2_gpu_fuzz_few.txt 2>&1; tail -1 gpurun_out/r06_e2_gpu_fuzz_few.txt | cut -c1-300
 unset CXG_PAIR_MIN_BYTES
 timeout 300 python scripts/gpu_stress_pair.py 20000 > gpurun_out/r06_e2_stress_pair.txt 2>&1; tail -1 gpurun_out/r06_e2_stress_pair.txt
-CXG_PAIR_TAIL8=1 timeout 120 python scripts/pair_sizes_big.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_e2_pair_sizes.txt
-CXG_NO_TEDDY_PAIR=1 CXG_PAIR_TAIL8=wave timeout 120 python scripts/pair_sizes_big.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06_e2_pair_sizes.txt
+timeout 120 python scripts/pair_sizes_big.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_e2_pair_sizes.txt
+CXG_NO_TEDDY_PAIR=1 CXG_PAIR_TAPER=wave timeout 120 python scripts/pair_sizes_big.py 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06_e2_pair_sizes.txt
 timeout 1800 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/r06_e2_pytest_gpu.log 2>&1; echo pytest=$?; tail -9 gpurun_out/r06_e2_pytest_gpu.log | cut -c1-300
 cd /tmp; timeout 500 python $R/bench.py > $R/gpurun_out/r06_e2_bench_default.json 2> $R/gpurun_out/r06_e2_bench_default.err; echo "default bench rc=$?"; tail -c 600 $R/gpurun_out/r06_e2_bench_default.json
