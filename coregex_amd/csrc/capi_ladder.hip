@@ -173,9 +173,10 @@ int scanDeviceOnce(const cxg_program* p, const void* d_hay, uint64_t len, int64_
     const uint64_t rowBytes = static_cast<uint64_t>(cxgdev::kWaveTile) * cxgdev::kPairWaves;   // one tile per wave
     const uint64_t R = (len + rowBytes - 1) / rowBytes;
     const uint64_t P = static_cast<uint64_t>(pcus);
+    static const uint64_t tailRows = getenv("CXG_PAIR_TAIL_ROWS") ? static_cast<uint64_t>(atoi(getenv("CXG_PAIR_TAIL_ROWS"))) : 1u;   // (A/B: tile rows per CU left to the groups of 2)
     uint64_t n8 = 0, n6 = 0, n4 = 0;
     if (taper && R >= 20 * P) { n6 = P; n4 = P; n8 = (R - 12 * P) / 8; }          // (behind them: P groups of 2 and what the division left)
-    else if (!taper && R >= 9 * P) n8 = (R - P) / 8;                 // (a short haystack — less than nine tile rows per CU — is cut into groups of 2 only: more CUs get to work)
+    else if (!taper && R >= 9 * P) n8 = (R - tailRows * P) / 8;                 // (a short haystack — less than nine tile rows per CU — is cut into groups of 2 only: more CUs get to work)
     const uint64_t left = R - 8 * n8 - 6 * n6 - 4 * n4;
     a.pair_nbig = static_cast<uint32_t>(n8); a.pair_n6 = static_cast<uint32_t>(n6); a.pair_n4 = static_cast<uint32_t>(n4);
     a.ngroups = n8 + n6 + n4 + (left + 1) / 2;
